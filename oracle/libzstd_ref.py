@@ -1,0 +1,156 @@
+"""TEST INFRASTRUCTURE -- the *real* libzstd, loaded from the image (never shipped),
+driven with exactly the call sequence and buffer sizes of the reference:
+  RawEncoder::compress_with_prefix hot loop  lib/src/encode.rs:340-346
+  RawEncoder::end_frame epilogue loop        lib/src/encode.rs:442-464
+  Decoder::decompress_with_prefix hot loop   lib/src/decode.rs:242-256
+libzstd 1.5.7 is the version the reference pins (Cargo.lock:1192-1193); the only
+1.5.7 build in the image is pillow's bundled one (slow build: oracle only, never timed).
+The distro 1.4.8 is the timing baseline (bench.py cpu_baseline) and a second decoder
+that must accept GPU-encoded frames.
+"""
+import ctypes as C
+import glob
+
+CSTREAM_OUT = 131591   # ZSTD_CStreamOutSize  (encode.rs:599)
+DSTREAM_IN = 131075    # ZSTD_DStreamInSize   (decode.rs:181)
+DSTREAM_OUT = 131072   # ZSTD_DStreamOutSize  (decode.rs:184)
+
+
+class InBuf(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+
+class OutBuf(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+
+_CANDIDATES = {
+    "1.5.7": sorted(glob.glob("/usr/local/lib/python3*/dist-packages/pillow.libs/libzstd-*.so.1.5.7")),
+    "system": ["/usr/lib/x86_64-linux-gnu/libzstd.so.1", "/opt/conda/lib/libzstd.so.1"],
+}
+_cache = {}
+
+
+def load(which="system"):
+    """which: '1.5.7' (pinned oracle build) or 'system' (fast distro build). Returns None if absent."""
+    if which in _cache:
+        return _cache[which]
+    l = None
+    for p in _CANDIDATES[which]:
+        try:
+            l = C.CDLL(p)
+            break
+        except OSError:
+            continue
+    if l is not None:
+        l.ZSTD_versionString.restype = C.c_char_p
+        l.ZSTD_createCCtx.restype = C.c_void_p
+        l.ZSTD_createDCtx.restype = C.c_void_p
+        l.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+        l.ZSTD_freeDCtx.argtypes = [C.c_void_p]
+        l.ZSTD_CCtx_setParameter.restype = C.c_size_t
+        l.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.ZSTD_CCtx_reset.restype = C.c_size_t
+        l.ZSTD_CCtx_reset.argtypes = [C.c_void_p, C.c_int]
+        l.ZSTD_DCtx_reset.restype = C.c_size_t
+        l.ZSTD_DCtx_reset.argtypes = [C.c_void_p, C.c_int]
+        l.ZSTD_compressStream2.restype = C.c_size_t
+        l.ZSTD_compressStream2.argtypes = [C.c_void_p, C.POINTER(OutBuf), C.POINTER(InBuf), C.c_int]
+        l.ZSTD_decompressStream.restype = C.c_size_t
+        l.ZSTD_decompressStream.argtypes = [C.c_void_p, C.POINTER(OutBuf), C.POINTER(InBuf)]
+        l.ZSTD_isError.restype = C.c_uint
+        l.ZSTD_isError.argtypes = [C.c_size_t]
+        l.ZSTD_getErrorName.restype = C.c_char_p
+        l.ZSTD_getErrorName.argtypes = [C.c_size_t]
+    _cache[which] = l
+    return l
+
+
+def version(which="system"):
+    l = load(which)
+    return l.ZSTD_versionString().decode() if l else None
+
+
+class ZstdError(Exception):
+    pass
+
+
+def _chk(l, r):
+    if l.ZSTD_isError(r):
+        raise ZstdError(l.ZSTD_getErrorName(r).decode())
+    return r
+
+
+def encode_seekable_frames(data: bytes, frame_size: int, level: int = 1, checksum: bool = False,
+                           which: str = "system"):
+    """Reference Encoder loop (Uncompressed(frame_size) policy). Returns (payload bytes, [(c,d)...]).
+
+    An empty input yields one empty frame (Encoder::finish always calls end_frame, encode.rs:755-757)."""
+    l = load(which)
+    cctx = l.ZSTD_createCCtx()
+    _chk(l, l.ZSTD_CCtx_setParameter(cctx, 100, level))
+    _chk(l, l.ZSTD_CCtx_setParameter(cctx, 201, int(checksum)))
+    data = bytes(data)
+    src = C.create_string_buffer(data, len(data)) if data else C.create_string_buffer(1)
+    base = C.addressof(src)
+    ob = C.create_string_buffer(CSTREAM_OUT)
+    out = bytearray()
+    frames = []
+    pos = 0
+    n = len(data)
+    first = True
+    while pos < n or first:
+        first = False
+        d = min(frame_size, n - pos)
+        c = 0
+        inb = InBuf(base + pos, d, 0)
+        while inb.pos < d:                              # encode.rs:340-346
+            outb = OutBuf(C.addressof(ob), CSTREAM_OUT, 0)
+            _chk(l, l.ZSTD_compressStream2(cctx, C.byref(outb), C.byref(inb), 0))
+            out += ob.raw[:outb.pos]
+            c += outb.pos
+        while True:                                     # encode.rs:442-464
+            empty = InBuf(None, 0, 0)
+            outb = OutBuf(C.addressof(ob), CSTREAM_OUT, 0)
+            r = _chk(l, l.ZSTD_compressStream2(cctx, C.byref(outb), C.byref(empty), 2))
+            out += ob.raw[:outb.pos]
+            c += outb.pos
+            if r == 0:
+                break
+        _chk(l, l.ZSTD_CCtx_reset(cctx, 1))             # encode.rs:504-506
+        frames.append((c, d))
+        pos += d
+    l.ZSTD_freeCCtx(cctx)
+    return bytes(out), frames
+
+
+def decode_stream(comp: bytes, expect: int = -1, which: str = "system") -> bytes:
+    """Reference Decoder hot loop over a whole payload (concatenated frames; skippable frames skipped)."""
+    l = load(which)
+    dctx = l.ZSTD_createDCtx()
+    comp = bytes(comp)
+    src = C.create_string_buffer(comp, len(comp)) if comp else C.create_string_buffer(1)
+    base = C.addressof(src)
+    ob = C.create_string_buffer(DSTREAM_OUT)
+    out = bytearray()
+    pos = 0
+    try:
+        while pos < len(comp):
+            take = min(DSTREAM_IN, len(comp) - pos)
+            inb = InBuf(base + pos, take, 0)
+            while inb.pos < take:                       # decode.rs:242-256
+                outb = OutBuf(C.addressof(ob), DSTREAM_OUT, 0)
+                _chk(l, l.ZSTD_decompressStream(dctx, C.byref(outb), C.byref(inb)))
+                out += ob.raw[:outb.pos]
+            pos += take
+        while True:                                     # drain what is still buffered inside the DCtx
+            inb = InBuf(base, 0, 0)
+            outb = OutBuf(C.addressof(ob), DSTREAM_OUT, 0)
+            _chk(l, l.ZSTD_decompressStream(dctx, C.byref(outb), C.byref(inb)))
+            if outb.pos == 0:
+                break
+            out += ob.raw[:outb.pos]
+    finally:
+        l.ZSTD_freeDCtx(dctx)
+    assert expect < 0 or len(out) == expect, (len(out), expect)
+    return bytes(out)

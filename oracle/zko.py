@@ -1,0 +1,107 @@
+"""TEST INFRASTRUCTURE -- ctypes binding of the CPU oracle (oracle/libzko.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+The product package (zeekstd_amd) must never import it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_SRCS = ("zstd_oracle.c", "zstd_oracle_enc.c", "gen.c")
+
+
+class FrameStats(C.Structure):
+    _fields_ = [
+        ("n_blocks", C.c_uint32), ("n_raw", C.c_uint32), ("n_rle", C.c_uint32), ("n_comp", C.c_uint32),
+        ("lit_raw", C.c_uint32), ("lit_rle", C.c_uint32), ("lit_huf4", C.c_uint32), ("lit_huf1", C.c_uint32),
+        ("lit_treeless", C.c_uint32),
+        ("mode_count", (C.c_uint32 * 4) * 3),
+        ("n_seq", C.c_uint64),
+        ("window_size", C.c_uint32), ("has_checksum", C.c_uint32), ("single_segment", C.c_uint32),
+        ("fcs", C.c_uint64), ("fcs_present", C.c_uint32), ("max_offset", C.c_uint32),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libzko.so")
+    srcs = [os.path.join(_HERE, f) for f in _SRCS]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libzko.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        l = C.CDLL(build())
+        l.zko_xxh64.restype = C.c_uint64
+        l.zko_xxh64.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+        l.zko_frame_decode.restype = C.c_int64
+        l.zko_frame_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                       C.POINTER(C.c_size_t), C.c_int, C.POINTER(FrameStats)]
+        l.zko_gen_text.restype = None
+        l.zko_gen_text.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+        l.zko_gen_chunks.restype = None
+        l.zko_gen_chunks.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+        l.zko_gen_vocab.restype = C.c_void_p
+        l.zko_gen_vocab.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        if hasattr(l, "zko_frame_encode"):
+            l.zko_frame_encode.restype = C.c_int64
+            l.zko_frame_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+        _LIB = l
+    return _LIB
+
+
+def xxh64(data: bytes, seed: int = 0) -> int:
+    data = bytes(data)
+    return lib().zko_xxh64(data, len(data), seed)
+
+
+def gen_text(n: int, seed: int) -> bytes:
+    buf = C.create_string_buffer(max(n, 1))
+    lib().zko_gen_text(buf, n, seed)
+    return buf.raw[:n]
+
+
+def gen_chunks(total: int, k0: int = 0) -> bytes:
+    buf = C.create_string_buffer(max(total, 1))
+    lib().zko_gen_chunks(buf, total, k0)
+    return buf.raw[:total]
+
+
+def gen_vocab(i: int) -> bytes:
+    n = C.c_int()
+    p = lib().zko_gen_vocab(i, C.byref(n))
+    return C.string_at(p, n.value)
+
+
+class OracleError(Exception):
+    def __init__(self, code):
+        super().__init__(f"oracle zstd error code {code}")
+        self.code = code
+
+
+def frame_decode(src: bytes, dst_cap: int, verify: bool = True, want_stats: bool = False):
+    """Decode ONE frame at the start of src. Returns (decoded bytes, consumed[, stats])."""
+    src = bytes(src)
+    out = C.create_string_buffer(max(dst_cap, 1))
+    used = C.c_size_t()
+    st = FrameStats()
+    r = lib().zko_frame_decode(src, len(src), out, dst_cap, C.byref(used), int(verify), C.byref(st))
+    if r < 0:
+        raise OracleError(-r)
+    if want_stats:
+        return out.raw[:r], used.value, st
+    return out.raw[:r], used.value
+
+
+def frame_encode(src: bytes, level: int = 1, checksum: bool = False) -> bytes:
+    src = bytes(src)
+    cap = len(src) + (len(src) >> 7) + 1024
+    out = C.create_string_buffer(cap)
+    r = lib().zko_frame_encode(src, len(src), out, cap, level, int(checksum))
+    if r < 0:
+        raise OracleError(-r)
+    return out.raw[:r]
