@@ -1,0 +1,349 @@
+// zk_decode.hip -- gfx950 kernels of the batched seekable-zstd frame decoder.
+//
+// Replaces, for N frames at a time, what the reference does one 128 KiB step at a time
+// through ZSTD_decompressStream (lib/src/decode.rs:242-256; libzstd 1.5.7 underneath).
+//
+// Pipeline (all launches on one stream, data resident in HBM):
+//   zk_k_walk (count)  one lane per frame: frame header + block chain -> ZkFrameInfo
+//   zk_k_scan          exclusive prefix sums over frames -> ZkFrameBase, totals
+//   zk_k_walk (fill)   one lane per frame -> ZkBlock[] (block list, table inheritance)
+//   zk_k_huf           one lane per Huffman stream (4 per block), tables in LDS -> literal scratch
+//   zk_k_fse           one lane per block: FSE tables in LDS, 3-state walk -> ZkSeq[] (+ out_size, symbolic reps)
+//   zk_k_exec          one workgroup per frame: byte-parallel sequence execution, coalesced 16 B stores
+//   zk_k_xxh64         4 lanes per frame (the 4 XXH64 accumulators), verifies Content_Checksum
+//
+// No MFMA anywhere: this is byte-serial entropy decoding; the roofline is HBM (c_i + d_i bytes per frame).
+#include <hip/hip_runtime.h>
+#include "zk_device.h"
+#include "zk_kernels.h"
+
+// ------------------------------------------------------------------------------------------------ walk
+__global__ __launch_bounds__(64) void zk_k_walk(const uint8_t *comp, const uint64_t *c_off, const uint64_t *d_off,
+                                                uint32_t first, uint32_t count, const ZkFrameBase *bases,
+                                                ZkBlock *blocks, ZkFrameInfo *infos)
+{
+    uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= count) return;
+    uint64_t cb = c_off[first + f], ce = c_off[first + f + 1];
+    uint64_t dsz = d_off[first + f + 1] - d_off[first + f];
+    ZkFrameInfo fi;
+    if (!bases) {                                   // pass 1: count
+        zk_walk_frame(comp, cb, ce, dsz, f, nullptr, nullptr, fi);
+        if (dsz > ZK_MAX_FRAME && fi.status == ZK_OK) fi.status = ZK_E_FRAMEPARAM_UNSUPPORTED;
+        if (fi.status != ZK_OK) { fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; }   // contributes no work
+        infos[f] = fi;
+    } else if (infos[f].status == ZK_OK) {          // pass 2: fill the block list
+        zk_walk_frame(comp, cb, ce, dsz, f, &bases[f], blocks, fi);
+    }
+}
+
+// exclusive scan of (n_blocks, n_seq, lit_bytes) over frames; one workgroup
+__global__ __launch_bounds__(1024) void zk_k_scan(const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals)
+{
+    __shared__ uint64_t wsum[16][3];
+    __shared__ uint64_t carry[3];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 3) carry[tid] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < count; base += 1024) {
+        uint32_t f = base + tid;
+        uint64_t v[3] = {0, 0, 0};
+        if (f < count) { v[0] = infos[f].n_blocks; v[1] = infos[f].n_seq; v[2] = infos[f].lit_bytes; }
+        uint64_t inc[3];
+        for (int k = 0; k < 3; k++) {
+            uint64_t x = v[k];
+            for (int d = 1; d < 64; d <<= 1) { uint64_t y = __shfl_up(x, d, 64); if ((int)lane >= d) x += y; }
+            inc[k] = x;
+            if (lane == 63) wsum[wave][k] = x;
+        }
+        __syncthreads();
+        uint64_t pre[3];
+        for (int k = 0; k < 3; k++) {
+            uint64_t s = carry[k];
+            for (uint32_t w = 0; w < wave; w++) s += wsum[w][k];
+            pre[k] = s;
+        }
+        if (f < count) {
+            bases[f].block_base = pre[0] + inc[0] - v[0];
+            bases[f].seq_base = pre[1] + inc[1] - v[1];
+            bases[f].lit_base = pre[2] + inc[2] - v[2];
+        }
+        __syncthreads();
+        if (tid == 1023) for (int k = 0; k < 3; k++) carry[k] = pre[k] + inc[k];
+        __syncthreads();
+    }
+    if (tid < 3) totals[tid] = carry[tid];
+}
+
+// ------------------------------------------------------------------------------------------------ Huffman literals
+// 64 lanes = 16 blocks x 4 streams.  Per block one 2^11-entry table (u16) in LDS.
+constexpr int ZK_HUF_BLOCKS = 16;
+__global__ __launch_bounds__(64) void zk_k_huf(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint8_t *lit_scratch)
+{
+    __shared__ uint16_t tab[ZK_HUF_BLOCKS][2048];
+    __shared__ ZkHufScratch sc[ZK_HUF_BLOCKS];
+    __shared__ uint32_t s_maxbits[ZK_HUF_BLOCKS], s_desc[ZK_HUF_BLOCKS];
+    const uint32_t lane = threadIdx.x, slot = lane >> 2, stream = lane & 3;
+    const uint32_t bi = blockIdx.x * ZK_HUF_BLOCKS + slot;
+    bool active = false;
+    ZkBlock b;
+    if (bi < nblocks) {
+        b = blocks[bi];
+        active = b.type == 2 && b.lit_type >= 2 && b.status == ZK_OK;
+    }
+    if (active && stream == 0) {
+        const ZkBlock &def = blocks[b.huf_def];
+        uint32_t mb = 0;
+        uint32_t r = zk_huf_build(comp + def.src + def.lit_off, def.lit_comp, tab[slot], &sc[slot], &mb);
+        s_desc[slot] = r; s_maxbits[slot] = mb;
+    }
+    __syncthreads();
+    if (!active) return;
+    bool ok = s_desc[slot] != 0;
+    if (ok) {
+        const uint8_t *pay = comp + b.src + b.lit_off;
+        uint32_t size = b.lit_comp;
+        if (b.lit_type == 2) { pay += s_desc[slot]; size -= s_desc[slot]; }      // own tree description precedes the streams
+        uint8_t *dst = lit_scratch + b.lit_base;
+        const uint32_t mb = s_maxbits[slot], regen = b.lit_regen;
+        if (b.lit_streams == 1) {
+            if (stream == 0) ok = zk_huf_decode_stream(tab[slot], mb, pay, size, dst, regen);
+        } else if (size < 6) {
+            ok = false;
+        } else {
+            uint32_t s1 = zk_rd16(pay), s2 = zk_rd16(pay + 2), s3 = zk_rd16(pay + 4);
+            uint32_t q = (regen + 3) / 4;
+            if (6 + s1 + s2 + s3 > size || 3 * q > regen) ok = false;
+            else {
+                uint32_t s4 = size - 6 - s1 - s2 - s3;
+                uint32_t start = 6 + (stream > 0 ? s1 : 0) + (stream > 1 ? s2 : 0) + (stream > 2 ? s3 : 0);
+                uint32_t len = stream == 0 ? s1 : stream == 1 ? s2 : stream == 2 ? s3 : s4;
+                uint32_t n = stream == 3 ? regen - 3 * q : q;
+                ok = zk_huf_decode_stream(tab[slot], mb, pay + start, len, dst + stream * q, n);
+            }
+        }
+    }
+    if (!ok) blocks[bi].status = ZK_E_CORRUPTION;
+}
+
+// ------------------------------------------------------------------------------------------------ FSE sequences
+// One lane per block; each lane owns 5.25 KiB of LDS (LL/ML 2^9 + OF 2^8 cells + build scratch).
+constexpr int ZK_FSE_BLOCKS = 28;
+__global__ __launch_bounds__(64) void zk_k_fse(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
+{
+    __shared__ ZkSeqTables T[ZK_FSE_BLOCKS];
+    __shared__ uint32_t llv[36], mlv[53];
+    const uint32_t lane = threadIdx.x;
+    {
+        const uint32_t ll_init[36] = ZK_LL_TABLE;
+        const uint32_t ml_init[53] = ZK_ML_TABLE;
+        if (lane < 36) llv[lane] = ll_init[lane];
+        if (lane < 53) mlv[lane] = ml_init[lane];
+    }
+    __syncthreads();
+    if (lane >= ZK_FSE_BLOCKS) return;
+    const uint32_t bi = blockIdx.x * ZK_FSE_BLOCKS + lane;
+    if (bi >= nblocks) return;
+    ZkBlock b = blocks[bi];
+    if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK) return;
+    zk_decode_sequences(comp, blocks, b, &T[lane], seqs + b.seq_base, llv, mlv);
+    ZkBlock *o = &blocks[bi];
+    o->out_size = b.out_size;
+    o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
+    o->status = b.status;
+}
+
+// ------------------------------------------------------------------------------------------------ sequence execution
+// One workgroup per frame.  Sequences are staged in LDS in chunks; the output range of a chunk is
+// produced in tiles of 256 lanes x 16 B: every lane resolves the source of its own 16 output bytes
+// (literal buffer, or history already written, chasing through in-tile matches) and issues one
+// coalesced 16 B store.  Tiles are ordered by a workgroup barrier.
+constexpr int ZK_EXEC_THREADS = 256;
+constexpr int ZK_EXEC_B = 16;
+constexpr int ZK_EXEC_CHUNK = 1024;
+
+__global__ __launch_bounds__(ZK_EXEC_THREADS) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
+                                                             const ZkBlock *blocks, const ZkFrameBase *bases,
+                                                             ZkFrameInfo *infos, const ZkSeq *seqs,
+                                                             const uint8_t *lit_scratch, uint8_t *dst)
+{
+    __shared__ uint32_t oe[ZK_EXEC_CHUNK + 1], mlv[ZK_EXEC_CHUNK + 1], ofv[ZK_EXEC_CHUNK + 1], le[ZK_EXEC_CHUNK + 1];
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const ZkFrameInfo fi = infos[f];
+    if (fi.status != ZK_OK) return;
+    const uint64_t d_size = d_off[first + f + 1] - d_off[first + f];
+    uint8_t *out = dst + (d_off[first + f] - d_off[first]);
+    const ZkBlock *fb = blocks + bases[f].block_base;
+    uint64_t pos = 0;
+    uint32_t rep[3] = {1, 4, 8};
+    uint32_t err = ZK_OK;
+
+    for (uint32_t bk = 0; bk < fi.n_blocks && err == ZK_OK; bk++) {
+        const ZkBlock &b = fb[bk];
+        if (b.status != ZK_OK) { err = b.status; break; }
+        if (pos + b.out_size > d_size) { err = ZK_E_CORRUPTION; break; }
+        uint8_t *bout = out + pos;
+        if (b.type == 0) {
+            const uint8_t *s = comp + b.src;
+            for (uint32_t i = tid; i < b.bsize; i += ZK_EXEC_THREADS) bout[i] = s[i];
+        } else if (b.type == 1) {
+            const uint8_t v = comp[b.src];
+            for (uint32_t i = tid; i < b.bsize; i += ZK_EXEC_THREADS) bout[i] = v;
+        } else {
+            const ZkSeq *sq = seqs + b.seq_base;
+            const uint8_t *lit = b.lit_type >= 2 ? lit_scratch + b.lit_base : comp + b.src + b.lit_off;
+            const uint32_t lit_stride = b.lit_type == 1 ? 0u : 1u;
+            const uint32_t nseq = b.nseq;
+            uint32_t s0 = 0, cpos = 0;
+            for (;;) {
+                const uint32_t ns = nseq - s0 < (uint32_t)ZK_EXEC_CHUNK ? nseq - s0 : (uint32_t)ZK_EXEC_CHUNK;
+                const bool lastchunk = s0 + ns == nseq;
+                int bad = 0;
+                for (uint32_t i = tid; i < ns; i += ZK_EXEC_THREADS) {
+                    ZkSeq s = sq[s0 + i];
+                    uint32_t off = zk_rep_resolve(s.off, rep);
+                    oe[i] = s.out_end; mlv[i] = s.ml; ofv[i] = off; le[i] = s.lit_end;
+                    uint32_t mstart = s.out_end - s.ml;
+                    if (off == 0 || pos + mstart < off || off > fi.window) bad = 1;
+                }
+                if (lastchunk && tid == 0) { oe[ns] = b.out_size; mlv[ns] = 0; ofv[ns] = 0; le[ns] = b.lit_regen; }
+                if (__syncthreads_or(bad)) { err = ZK_E_CORRUPTION; break; }
+                const uint32_t nent = ns + (lastchunk ? 1u : 0u);
+                const uint32_t cend = lastchunk ? b.out_size : oe[ns - 1];
+                for (uint32_t ts = cpos; ts < cend; ts += ZK_EXEC_THREADS * ZK_EXEC_B) {
+                    const uint32_t q0 = ts + tid * ZK_EXEC_B;
+                    if (q0 < cend) {
+                        const uint32_t nb = cend - q0 < (uint32_t)ZK_EXEC_B ? cend - q0 : (uint32_t)ZK_EXEC_B;
+                        uint32_t j = zk_seq_find(oe, 0, nent, q0);
+                        uint8_t ob[ZK_EXEC_B];
+#pragma unroll
+                        for (int k = 0; k < ZK_EXEC_B; k++) {
+                            ob[k] = 0;
+                            if ((uint32_t)k < nb) {
+                                const uint32_t q = q0 + k;
+                                while (oe[j] <= q) j++;
+                                uint64_t src = zk_resolve_byte(oe, mlv, ofv, le, j, q, (int32_t)ts);
+                                if (src & ZK_SRC_HIST) ob[k] = bout[(int64_t)(int32_t)((uint32_t)src - 0x40000000u)];
+                                else ob[k] = lit[(uint32_t)src * lit_stride];
+                            }
+                        }
+                        uint8_t *w = bout + q0;
+                        if (nb == ZK_EXEC_B && (((uintptr_t)w) & 15) == 0) {
+                            uint4 v;
+                            v.x = ob[0] | (ob[1] << 8) | (ob[2] << 16) | ((uint32_t)ob[3] << 24);
+                            v.y = ob[4] | (ob[5] << 8) | (ob[6] << 16) | ((uint32_t)ob[7] << 24);
+                            v.z = ob[8] | (ob[9] << 8) | (ob[10] << 16) | ((uint32_t)ob[11] << 24);
+                            v.w = ob[12] | (ob[13] << 8) | (ob[14] << 16) | ((uint32_t)ob[15] << 24);
+                            *reinterpret_cast<uint4 *>(w) = v;
+                        } else {
+                            for (uint32_t k = 0; k < nb; k++) w[k] = ob[k];
+                        }
+                    }
+                    __syncthreads();          // tile bytes visible to the next tile's history reads
+                }
+                __syncthreads();              // LDS chunk arrays are reused
+                cpos = cend; s0 += ns;
+                if (lastchunk) break;
+            }
+            if (err == ZK_OK) {
+                uint32_t r0 = zk_rep_resolve(b.rep_out[0], rep), r1 = zk_rep_resolve(b.rep_out[1], rep), r2 = zk_rep_resolve(b.rep_out[2], rep);
+                rep[0] = r0; rep[1] = r1; rep[2] = r2;
+            }
+        }
+        pos += b.out_size;
+        __syncthreads();                      // block bytes visible before the next block reads history
+    }
+    if (err == ZK_OK && pos != d_size) err = ZK_E_CORRUPTION;
+    if (tid == 0 && err != ZK_OK) infos[f].status = err;
+}
+
+// ------------------------------------------------------------------------------------------------ XXH64
+// 4 lanes per frame = the four XXH64 accumulators (each consumes 8 of every 32 bytes, in order);
+// 16 frames per wave.  mode: hashes != nullptr -> store the 64-bit hash; infos != nullptr -> verify checksum.
+__device__ __forceinline__ uint64_t zk_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+constexpr uint64_t XP1 = 0x9E3779B185EBCA87ull, XP2 = 0xC2B2AE3D27D4EB4Full, XP3 = 0x165667B19E3779F9ull,
+                   XP4 = 0x85EBCA77C2B2AE63ull, XP5 = 0x27D4EB2F165667C5ull;
+__device__ __forceinline__ uint64_t zk_xround(uint64_t acc, uint64_t x) { return zk_rotl64(acc + x * XP2, 31) * XP1; }
+__device__ __forceinline__ uint64_t zk_ld64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+__global__ __launch_bounds__(64) void zk_k_xxh64(const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
+                                                 ZkFrameInfo *infos, uint64_t *hashes)
+{
+    const uint32_t lane = threadIdx.x, k = lane & 3;
+    const uint32_t f = blockIdx.x * 16 + (lane >> 2);
+    bool active = f < count;
+    if (active && infos) active = infos[f].status == ZK_OK && infos[f].checksum_flag;
+    const uint8_t *p = data;
+    uint64_t len = 0;
+    if (active) { p = data + (d_off[first + f] - d_off[first]); len = d_off[first + f + 1] - d_off[first + f]; }
+    const uint64_t nstripes = len >> 5;
+    uint64_t acc = k == 0 ? XP1 + XP2 : k == 1 ? XP2 : k == 2 ? 0 : 0 - XP1;
+    const uint8_t *q = p + 8 * k;
+#pragma unroll 8
+    for (uint64_t i = 0; i < nstripes; i++) acc = zk_xround(acc, zk_ld64(q + (i << 5)));
+    const int g = (int)(lane & ~3u);
+    uint64_t v1 = __shfl(acc, g, 64), v2 = __shfl(acc, g + 1, 64), v3 = __shfl(acc, g + 2, 64), v4 = __shfl(acc, g + 3, 64);
+    if (!active || k != 0) return;
+    uint64_t h;
+    if (len >= 32) {
+        h = zk_rotl64(v1, 1) + zk_rotl64(v2, 7) + zk_rotl64(v3, 12) + zk_rotl64(v4, 18);
+        h = (h ^ zk_xround(0, v1)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v2)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v3)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v4)) * XP1 + XP4;
+    } else h = XP5;
+    h += len;
+    const uint8_t *t = p + (nstripes << 5), *end = p + len;
+    while (t + 8 <= end) { h ^= zk_xround(0, zk_ld64(t)); h = zk_rotl64(h, 27) * XP1 + XP4; t += 8; }
+    if (t + 4 <= end) { h ^= (uint64_t)zk_rd32(t) * XP1; h = zk_rotl64(h, 23) * XP2 + XP3; t += 4; }
+    while (t < end) { h ^= (uint64_t)(*t) * XP5; h = zk_rotl64(h, 11) * XP1; t++; }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    if (hashes) hashes[f] = h;
+    if (infos && (uint32_t)h != infos[f].checksum) infos[f].status = ZK_E_CHECKSUM_WRONG;
+}
+
+// per-frame status words + first failing frame ((frame << 32) | code, min over frames)
+__global__ __launch_bounds__(256) void zk_k_status(const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, unsigned long long *first_err)
+{
+    uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= count) return;
+    uint32_t st = infos[f].status;
+    if (status_out) status_out[f] = (int32_t)st;
+    if (st != ZK_OK) atomicMin(first_err, ((unsigned long long)f << 32) | st);
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+void zk_launch_status(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, uint64_t *first_err)
+{
+    hipLaunchKernelGGL(zk_k_status, dim3((count + 255) / 256), dim3(256), 0, st, infos, count, status_out, (unsigned long long *)first_err);
+}
+void zk_launch_walk(hipStream_t st, const uint8_t *comp, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
+                    uint32_t count, const ZkFrameBase *bases, ZkBlock *blocks, ZkFrameInfo *infos)
+{
+    hipLaunchKernelGGL(zk_k_walk, dim3((count + 63) / 64), dim3(64), 0, st, comp, c_off, d_off, first, count, bases, blocks, infos);
+}
+void zk_launch_scan(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals)
+{
+    hipLaunchKernelGGL(zk_k_scan, dim3(1), dim3(1024), 0, st, infos, count, bases, totals);
+}
+void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint8_t *lit)
+{
+    if (!nblocks) return;
+    hipLaunchKernelGGL(zk_k_huf, dim3((nblocks + ZK_HUF_BLOCKS - 1) / ZK_HUF_BLOCKS), dim3(64), 0, st, comp, blocks, nblocks, lit);
+}
+void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
+{
+    if (!nblocks) return;
+    hipLaunchKernelGGL(zk_k_fse, dim3((nblocks + ZK_FSE_BLOCKS - 1) / ZK_FSE_BLOCKS), dim3(64), 0, st, comp, blocks, nblocks, seqs);
+}
+void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
+                    const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeq *seqs,
+                    const uint8_t *lit, uint8_t *dst)
+{
+    hipLaunchKernelGGL(zk_k_exec, dim3(count), dim3(ZK_EXEC_THREADS), 0, st, comp, d_off, first, blocks, bases, infos, seqs, lit, dst);
+}
+void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
+                     ZkFrameInfo *infos, uint64_t *hashes)
+{
+    hipLaunchKernelGGL(zk_k_xxh64, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
+}

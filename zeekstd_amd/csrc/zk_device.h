@@ -1,0 +1,686 @@
+// zk_device.h -- per-lane building blocks of the gfx950 frame decoder.
+//
+// Everything here is straight-line integer code that one lane executes on its own
+// stream/block: bit readers, FSE / Huffman table construction, header parsing and
+// the byte-source resolver of the sequence executor.  The kernels in zk_decode.hip
+// own the orchestration (LDS placement, wave/workgroup cooperation, launches).
+// The functions are ZK_HD (host+device) so that tests/sim/ can run the very same
+// lane code on the CPU against the oracle before a GPU is involved.
+//
+// What this replaces in the reference: the arithmetic behind
+// ZSTD_decompressStream at lib/src/decode.rs:242-256 (libzstd 1.5.7, not in the
+// reference tree).  Format facts: RFC 8878 / SURVEY.md Appendix A.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define ZK_HD __host__ __device__ __forceinline__
+#else
+#define ZK_HD static inline
+#endif
+
+// ZSTD_ErrorCode values used on this path (per-frame status words; 0 = ok)
+enum : uint32_t {
+    ZK_OK = 0,
+    ZK_E_GENERIC = 1,
+    ZK_E_PREFIX_UNKNOWN = 10,
+    ZK_E_FRAMEPARAM_UNSUPPORTED = 14,
+    ZK_E_WINDOW_TOO_LARGE = 16,
+    ZK_E_CORRUPTION = 20,
+    ZK_E_CHECKSUM_WRONG = 22,
+    ZK_E_DICT_WRONG = 32,
+    ZK_E_DST_TOO_SMALL = 70,
+    ZK_E_SRC_SIZE_WRONG = 72,
+};
+
+constexpr uint32_t ZK_BLOCK_MAX = 131072;          // Block_Maximum_Size upper bound
+constexpr uint32_t ZK_MAX_FRAME = 0x40000000u;     // SEEKABLE_MAX_FRAME_SIZE (reference lib.rs:58)
+
+// ---------------------------------------------------------------- data records in HBM
+struct ZkFrameInfo {            // written by the frame walker, one per frame
+    uint32_t n_blocks;
+    uint32_t n_seq;             // total sequences in the frame
+    uint32_t lit_bytes;         // total Huffman-coded literal bytes (need literal scratch)
+    uint32_t status;            // ZSTD_ErrorCode, 0 ok
+    uint32_t checksum_flag;
+    uint32_t checksum;          // stored Content_Checksum (valid if flag)
+    uint32_t window;            // clamped to 2^31
+    uint32_t pad;
+};
+
+struct ZkFrameBase {            // exclusive prefix sums over frames
+    uint64_t block_base;
+    uint64_t seq_base;
+    uint64_t lit_base;
+};
+
+struct ZkBlock {                // one per block, contiguous per frame
+    uint64_t src;               // absolute offset (in the compressed buffer) of the block content
+    uint64_t lit_base;          // literal scratch offset (Huffman literals)
+    uint64_t seq_base;          // sequence scratch index
+    uint32_t bsize;             // Block_Size
+    uint32_t frame;             // frame index inside the batch
+    uint8_t type;               // 0 raw, 1 rle, 2 compressed
+    uint8_t lit_type;           // 0 raw, 1 rle, 2 huffman, 3 treeless
+    uint8_t lit_streams;        // 1 or 4
+    uint8_t seq_modes;          // Symbol_Compression_Modes byte
+    uint32_t lit_regen;         // Regenerated_Size of the literals
+    uint32_t lit_off;           // offset in the block content of the literal payload
+    uint32_t lit_comp;          // payload bytes (huffman: tree description + streams)
+    uint32_t seq_off;           // offset in the block content of the modes byte (nseq > 0)
+    uint32_t nseq;
+    uint32_t huf_def;           // global block index whose literal section carries the tree in force
+    uint32_t tab_def[3];        // global block index whose sequence header defines LL / OF / ML table in force
+    uint32_t out_size;          // regenerated size of the block
+    uint32_t rep_out[3];        // repeat-offset history after the block (symbolic, see zk_rep_*)
+    uint32_t status;
+    uint32_t pad;
+};
+static_assert(sizeof(ZkBlock) == 96, "ZkBlock layout");
+
+struct ZkSeq {                  // one per sequence, 16 B
+    uint32_t out_end;           // block-relative output position after this sequence's match
+    uint32_t ml;                // match length
+    uint32_t off;               // offset, possibly symbolic (zk_rep_*)
+    uint32_t lit_end;           // block-relative literal count after this sequence's literals
+};
+
+// ---------------------------------------------------------------- small helpers
+ZK_HD uint32_t zk_highbit(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+ZK_HD uint32_t zk_rd16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+ZK_HD uint32_t zk_rd24(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+ZK_HD uint32_t zk_rd32(const uint8_t *p) { return zk_rd24(p) | ((uint32_t)p[3] << 24); }
+
+// 64-bit little-endian word at stream offset `off`; bytes outside [0,len) read as zero.
+ZK_HD uint64_t zk_ldword(const uint8_t *base, int32_t off, uint32_t len)
+{
+    if (off >= 0 && (uint32_t)off + 8u <= len) {
+        uint64_t v;
+        memcpy(&v, base + off, 8);
+        return v;
+    }
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++) {
+        int32_t o = off + i;
+        if (o >= 0 && (uint32_t)o < len) v |= (uint64_t)base[o] << (8 * i);
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------- backward bit reader (A.7)
+// cur: next unread bit is the MSB; cnt valid bits.  res: reserve word, left aligned.
+// nxt: word prefetched one step ahead so the HBM/L2 latency overlaps the decode chain.
+struct ZkBwd {
+    const uint8_t *base;
+    uint64_t cur, res, nxt;
+    uint32_t len;
+    int32_t cnt, rescnt, next_off;
+    int32_t bits_left;          // real (non zero-fill) bits still unread; < 0 == over-read
+};
+
+ZK_HD bool zk_bwd_init(ZkBwd &b, const uint8_t *base, uint32_t len)
+{
+    if (len == 0) return false;
+    uint32_t last = base[len - 1];
+    if (last == 0) return false;
+    uint32_t hb = zk_highbit(last);
+    b.base = base; b.len = len;
+    b.bits_left = (int32_t)((len - 1) * 8 + hb);
+    uint64_t w = zk_ldword(base, (int32_t)len - 8, len);
+    b.cur = w << (8 - hb);
+    b.cnt = 56 + (int32_t)hb;
+    b.res = zk_ldword(base, (int32_t)len - 16, len);
+    b.rescnt = 64;
+    b.nxt = zk_ldword(base, (int32_t)len - 24, len);
+    b.next_off = (int32_t)len - 32;
+    return true;
+}
+
+// top up cur to 64 bits (zero-fill once the stream is exhausted)
+ZK_HD void zk_bwd_refill(ZkBwd &b)
+{
+    if (b.cnt >= 64) return;
+    int32_t room = 64 - b.cnt;                       // 1..64
+    b.cur |= b.cnt ? (b.res >> b.cnt) : b.res;
+    if (b.rescnt > room) {                           // reserve still has bits left
+        b.res <<= room; b.rescnt -= room; b.cnt = 64;
+        return;
+    }
+    b.cnt += b.rescnt;                               // reserve fully consumed
+    b.res = b.nxt; b.rescnt = 64;
+    b.nxt = zk_ldword(b.base, b.next_off, b.len);
+    b.next_off -= 8;
+    room = 64 - b.cnt;
+    if (room > 0) {                                  // cnt >= 1 here, so room <= 63
+        b.cur |= b.res >> b.cnt;
+        b.res <<= room; b.rescnt -= room; b.cnt = 64;
+    }
+}
+
+// n <= 32 and n <= cnt (caller refills)
+ZK_HD uint32_t zk_bwd_read(ZkBwd &b, uint32_t n)
+{
+    uint32_t v = n ? (uint32_t)(b.cur >> (64 - n)) : 0u;
+    b.cur = n >= 64 ? 0 : b.cur << n;
+    b.cnt -= (int32_t)n; b.bits_left -= (int32_t)n;
+    return v;
+}
+ZK_HD uint32_t zk_bwd_peek(const ZkBwd &b, uint32_t n) { return (uint32_t)(b.cur >> (64 - n)); }   // 1 <= n <= 32
+ZK_HD void zk_bwd_skip(ZkBwd &b, uint32_t n) { b.cur <<= n; b.cnt -= (int32_t)n; b.bits_left -= (int32_t)n; }
+
+// ---------------------------------------------------------------- FSE
+// packed decode cell: sym[7:0] | nb[11:8] | xbits[16:12] | base[31:17]
+ZK_HD uint32_t zk_cell(uint32_t sym, uint32_t nb, uint32_t xbits, uint32_t base) { return sym | (nb << 8) | (xbits << 12) | (base << 17); }
+ZK_HD uint32_t zk_cell_sym(uint32_t c) { return c & 0xff; }
+ZK_HD uint32_t zk_cell_nb(uint32_t c) { return (c >> 8) & 0xf; }
+ZK_HD uint32_t zk_cell_xbits(uint32_t c) { return (c >> 12) & 0x1f; }
+ZK_HD uint32_t zk_cell_base(uint32_t c) { return c >> 17; }
+
+// value tables: base | bits << 24
+#define ZK_LLV(b, n) ((uint32_t)(b) | ((uint32_t)(n) << 24))
+#define ZK_LL_TABLE { \
+    ZK_LLV(0,0),ZK_LLV(1,0),ZK_LLV(2,0),ZK_LLV(3,0),ZK_LLV(4,0),ZK_LLV(5,0),ZK_LLV(6,0),ZK_LLV(7,0), \
+    ZK_LLV(8,0),ZK_LLV(9,0),ZK_LLV(10,0),ZK_LLV(11,0),ZK_LLV(12,0),ZK_LLV(13,0),ZK_LLV(14,0),ZK_LLV(15,0), \
+    ZK_LLV(16,1),ZK_LLV(18,1),ZK_LLV(20,1),ZK_LLV(22,1),ZK_LLV(24,2),ZK_LLV(28,2),ZK_LLV(32,3),ZK_LLV(40,3), \
+    ZK_LLV(48,4),ZK_LLV(64,6),ZK_LLV(128,7),ZK_LLV(256,8),ZK_LLV(512,9),ZK_LLV(1024,10),ZK_LLV(2048,11),ZK_LLV(4096,12), \
+    ZK_LLV(8192,13),ZK_LLV(16384,14),ZK_LLV(32768,15),ZK_LLV(65536,16) }
+#define ZK_ML_TABLE { \
+    ZK_LLV(3,0),ZK_LLV(4,0),ZK_LLV(5,0),ZK_LLV(6,0),ZK_LLV(7,0),ZK_LLV(8,0),ZK_LLV(9,0),ZK_LLV(10,0), \
+    ZK_LLV(11,0),ZK_LLV(12,0),ZK_LLV(13,0),ZK_LLV(14,0),ZK_LLV(15,0),ZK_LLV(16,0),ZK_LLV(17,0),ZK_LLV(18,0), \
+    ZK_LLV(19,0),ZK_LLV(20,0),ZK_LLV(21,0),ZK_LLV(22,0),ZK_LLV(23,0),ZK_LLV(24,0),ZK_LLV(25,0),ZK_LLV(26,0), \
+    ZK_LLV(27,0),ZK_LLV(28,0),ZK_LLV(29,0),ZK_LLV(30,0),ZK_LLV(31,0),ZK_LLV(32,0),ZK_LLV(33,0),ZK_LLV(34,0), \
+    ZK_LLV(35,1),ZK_LLV(37,1),ZK_LLV(39,1),ZK_LLV(41,1),ZK_LLV(43,2),ZK_LLV(47,2),ZK_LLV(51,3),ZK_LLV(59,3), \
+    ZK_LLV(67,4),ZK_LLV(83,4),ZK_LLV(99,5),ZK_LLV(131,7),ZK_LLV(259,8),ZK_LLV(515,9),ZK_LLV(1027,10),ZK_LLV(2051,11), \
+    ZK_LLV(4099,12),ZK_LLV(8195,13),ZK_LLV(16387,14),ZK_LLV(32771,15),ZK_LLV(65539,16) }
+
+// predefined normalised distributions (A.6)
+#define ZK_LL_DEFNORM {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1}
+#define ZK_OF_DEFNORM {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1}
+#define ZK_ML_DEFNORM {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1}
+
+enum { ZK_TAB_LL = 0, ZK_TAB_OF = 1, ZK_TAB_ML = 2 };
+ZK_HD uint32_t zk_tab_maxsym(int t) { return t == ZK_TAB_LL ? 35u : t == ZK_TAB_OF ? 31u : 52u; }
+ZK_HD uint32_t zk_tab_maxal(int t) { return t == ZK_TAB_OF ? 8u : 9u; }
+
+// A.5 normalised-count header.  Forward LSB-first bits.  norm[] gets max_sym+1 entries at most.
+// Returns bytes consumed (>0) or 0 on corruption.
+ZK_HD uint32_t zk_fse_read_ncount(const uint8_t *src, uint32_t len, uint32_t max_sym, uint32_t max_al,
+                                  int16_t *norm, uint32_t *nsym_out, uint32_t *al_out)
+{
+    if (len == 0) return 0;
+    uint32_t bitpos = 0;
+    uint64_t w = zk_ldword(src, 0, len);
+    uint32_t wbase = 0;                                   // byte offset of w
+#define ZK_FPEEK(n) ((uint32_t)(w >> (bitpos - wbase * 8)) & ((1u << (n)) - 1u))
+#define ZK_FADV(n) do { bitpos += (n); if (bitpos - wbase * 8 > 32) { wbase = bitpos >> 3; w = zk_ldword(src, (int32_t)wbase, len); } } while (0)
+    uint32_t al = ZK_FPEEK(4) + 5; ZK_FADV(4);
+    if (al > max_al) return 0;
+    int32_t remaining = (1 << al) + 1, threshold = 1 << al;
+    uint32_t nb = al + 1, sym = 0;
+    while (remaining > 1 && sym <= max_sym) {
+        int32_t max = 2 * threshold - 1 - remaining;
+        uint32_t v = ZK_FPEEK(nb);
+        int32_t cnt;
+        if ((int32_t)(v & (uint32_t)(threshold - 1)) < max) { cnt = (int32_t)(v & (uint32_t)(threshold - 1)); ZK_FADV(nb - 1); }
+        else { cnt = (int32_t)(v & (uint32_t)(2 * threshold - 1)); if (cnt >= threshold) cnt -= max; ZK_FADV(nb); }
+        cnt -= 1;
+        remaining -= cnt < 0 ? -cnt : cnt;
+        norm[sym++] = (int16_t)cnt;
+        if (cnt == 0) {
+            for (;;) {
+                uint32_t rep = ZK_FPEEK(2); ZK_FADV(2);
+                for (uint32_t i = 0; i < rep; i++) { if (sym > max_sym) return 0; norm[sym++] = 0; }
+                if (rep != 3) break;
+            }
+        }
+        while (remaining < threshold) { nb--; threshold >>= 1; }
+        if (bitpos > len * 8 + 16) return 0;
+    }
+#undef ZK_FPEEK
+#undef ZK_FADV
+    if (remaining != 1 || sym > max_sym + 1) return 0;
+    uint32_t used = (bitpos + 7) >> 3;
+    if (used > len) return 0;
+    *nsym_out = sym; *al_out = al;
+    return used;
+}
+
+// A.6 decode-table build.  cells[1<<al]; next[] scratch of nsym u16.  kind selects the xbits column.
+ZK_HD bool zk_fse_build(uint32_t *cells, const int16_t *norm, uint32_t nsym, uint32_t al, uint16_t *next,
+                        const uint32_t *value_table /* LL/ML value table or nullptr (OF / weights) */)
+{
+    uint32_t size = 1u << al, mask = size - 1;
+    int32_t high = (int32_t)size - 1;
+    for (uint32_t s = 0; s < nsym; s++) {
+        if (norm[s] == -1) { if (high < 0) return false; cells[high--] = s; next[s] = 1; }
+        else next[s] = (uint16_t)norm[s];
+    }
+    uint32_t step = (size >> 1) + (size >> 3) + 3, pos = 0;
+    for (uint32_t s = 0; s < nsym; s++) {
+        for (int32_t i = 0; i < norm[s]; i++) {
+            cells[pos] = s;
+            do { pos = (pos + step) & mask; } while ((int32_t)pos > high);
+        }
+    }
+    if (pos != 0) return false;
+    for (uint32_t i = 0; i < size; i++) {
+        uint32_t s = cells[i];
+        uint32_t x = next[s]++;
+        uint32_t nb = al - zk_highbit(x);
+        uint32_t xb = value_table ? (value_table[s] >> 24) : s;
+        cells[i] = zk_cell(s, nb, xb & 31u, (x << nb) - size);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- Huffman (A.4)
+// table cell: sym | nbits << 8 (u16).  Scratch: weights[256] u8, rank[16] u32, fse cells[64] u32, norm[16], next[16].
+struct ZkHufScratch {
+    uint8_t weights[256];
+    uint32_t rank[16];
+    uint32_t fse[64];
+    int16_t norm[16];
+    uint16_t next[16];
+};
+
+// Parses the tree description at src (len = bytes available) and fills table[1 << maxbits].
+// Returns description size in bytes (0 on corruption); *maxbits_out receives the table log.
+ZK_HD uint32_t zk_huf_build(const uint8_t *src, uint32_t len, uint16_t *table, ZkHufScratch *sc, uint32_t *maxbits_out)
+{
+    if (len < 1) return 0;
+    uint32_t h = src[0], n = 0, used;
+    uint8_t *w = sc->weights;
+    if (h >= 128) {
+        n = h - 127;
+        used = 1 + (n + 1) / 2;
+        if (used > len) return 0;
+        for (uint32_t i = 0; i < n; i++) { uint32_t b = src[1 + i / 2]; w[i] = (uint8_t)((i & 1) ? (b & 15) : (b >> 4)); }
+    } else {
+        used = 1 + h;
+        if (used > len || h < 2) return 0;
+        uint32_t nsym, al;
+        uint32_t r = zk_fse_read_ncount(src + 1, h, 11, 6, sc->norm, &nsym, &al);
+        if (r == 0 || r >= h) return 0;
+        if (!zk_fse_build(sc->fse, sc->norm, nsym, al, sc->next, nullptr)) return 0;
+        ZkBwd b;
+        if (!zk_bwd_init(b, src + 1 + r, h - r)) return 0;
+        uint32_t s1 = zk_bwd_read(b, al), s2 = zk_bwd_read(b, al);
+        for (;;) {                                        // two interleaved states, stop on over-read
+            if (n >= 254) return 0;
+            zk_bwd_refill(b);
+            uint32_t c1 = sc->fse[s1];
+            w[n++] = (uint8_t)zk_cell_sym(c1);
+            if (b.bits_left < (int32_t)zk_cell_nb(c1)) { w[n++] = (uint8_t)zk_cell_sym(sc->fse[s2]); break; }
+            s1 = zk_cell_base(c1) + zk_bwd_read(b, zk_cell_nb(c1));
+            if (n >= 254) return 0;
+            uint32_t c2 = sc->fse[s2];
+            w[n++] = (uint8_t)zk_cell_sym(c2);
+            if (b.bits_left < (int32_t)zk_cell_nb(c2)) { w[n++] = (uint8_t)zk_cell_sym(sc->fse[s1]); break; }
+            s2 = zk_cell_base(c2) + zk_bwd_read(b, zk_cell_nb(c2));
+        }
+    }
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < 13; i++) sc->rank[i] = 0;
+    for (uint32_t i = 0; i < n; i++) { uint32_t x = w[i]; if (x > 11) return 0; if (x) sum += 1u << (x - 1); sc->rank[x]++; }
+    if (sum == 0) return 0;
+    uint32_t maxbits = zk_highbit(sum) + 1;
+    if (maxbits > 11) return 0;
+    uint32_t rest = (1u << maxbits) - sum;
+    if (rest & (rest - 1)) return 0;
+    uint32_t lastw = zk_highbit(rest) + 1;
+    w[n++] = (uint8_t)lastw; sc->rank[lastw]++;
+    // rank[wt] -> first table index of weight wt (weight 1 first)
+    uint32_t pos = 0;
+    for (uint32_t wt = 1; wt <= maxbits; wt++) { uint32_t c = sc->rank[wt]; sc->rank[wt] = pos; pos += c << (wt - 1); }
+    if (pos != (1u << maxbits)) return 0;
+    for (uint32_t s = 0; s < n; s++) {
+        uint32_t wt = w[s];
+        if (!wt) continue;
+        uint32_t cnt = 1u << (wt - 1), at = sc->rank[wt];
+        uint16_t cell = (uint16_t)(s | ((maxbits + 1 - wt) << 8));
+        for (uint32_t k = 0; k < cnt; k++) table[at + k] = cell;
+        sc->rank[wt] = at + cnt;
+    }
+    *maxbits_out = maxbits;
+    return used;
+}
+
+// Decode n symbols of one Huffman stream into dst.  Returns false on corruption.
+ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const uint8_t *src, uint32_t len,
+                                uint8_t *dst, uint32_t n)
+{
+    ZkBwd b;
+    if (!zk_bwd_init(b, src, len)) return false;
+    uint32_t i = 0;
+    while (i < n) {
+        zk_bwd_refill(b);
+        // 64 bits are enough for 5 symbols of <= 11 bits
+        uint32_t lim = n - i < 5 ? n - i : 5;
+        for (uint32_t k = 0; k < lim; k++) {
+            uint32_t c = table[zk_bwd_peek(b, maxbits)];
+            dst[i + k] = (uint8_t)c;
+            zk_bwd_skip(b, c >> 8);
+        }
+        i += lim;
+    }
+    return b.bits_left == 0;
+}
+
+// ---------------------------------------------------------------- header parsing
+struct ZkLitHdr { uint32_t type, streams, regen, comp, hdr; };
+
+// literals section header (A.3); avail = bytes of block content
+ZK_HD bool zk_parse_lit_hdr(const uint8_t *p, uint32_t avail, ZkLitHdr &h)
+{
+    if (avail < 1) return false;
+    uint32_t b0 = p[0];
+    h.type = b0 & 3;
+    uint32_t sf = (b0 >> 2) & 3;
+    h.streams = 4;
+    if (h.type < 2) {
+        if (sf == 0 || sf == 2) { h.hdr = 1; h.regen = b0 >> 3; }
+        else if (sf == 1) { h.hdr = 2; if (avail < 2) return false; h.regen = (b0 >> 4) + ((uint32_t)p[1] << 4); }
+        else { h.hdr = 3; if (avail < 3) return false; h.regen = (b0 >> 4) + ((uint32_t)p[1] << 4) + ((uint32_t)p[2] << 12); }
+        h.comp = h.type == 0 ? h.regen : 1;
+    } else {
+        if (sf < 2) { h.hdr = 3; if (avail < 3) return false; uint32_t v = zk_rd24(p); h.regen = (v >> 4) & 0x3ff; h.comp = (v >> 14) & 0x3ff; if (sf == 0) h.streams = 1; }
+        else if (sf == 2) { h.hdr = 4; if (avail < 4) return false; uint32_t v = zk_rd32(p); h.regen = (v >> 4) & 0x3fff; h.comp = v >> 18; }
+        else { h.hdr = 5; if (avail < 5) return false; uint64_t v = (uint64_t)zk_rd32(p) | ((uint64_t)p[4] << 32); h.regen = (uint32_t)(v >> 4) & 0x3ffff; h.comp = (uint32_t)(v >> 22) & 0x3ffff; }
+    }
+    if (h.regen > ZK_BLOCK_MAX) return false;
+    if ((uint64_t)h.hdr + h.comp > avail) return false;
+    return true;
+}
+
+// Number_of_Sequences (A.8); returns header length (1..3) or 0
+ZK_HD uint32_t zk_parse_nseq(const uint8_t *p, uint32_t avail, uint32_t &nseq)
+{
+    if (avail < 1) return 0;
+    uint32_t b0 = p[0];
+    if (b0 < 128) { nseq = b0; return 1; }
+    if (b0 < 255) { if (avail < 2) return 0; nseq = ((b0 - 128) << 8) + p[1]; return 2; }
+    if (avail < 3) return 0;
+    nseq = (uint32_t)p[1] + ((uint32_t)p[2] << 8) + 0x7F00;
+    return 3;
+}
+
+// ---------------------------------------------------------------- frame walker
+// One lane walks one frame.  blocks == nullptr: count only.
+// comp/c_begin/c_end: the frame occupies comp[c_begin, c_end).  d_size: expected decompressed size.
+ZK_HD void zk_walk_frame(const uint8_t *comp, uint64_t c_begin, uint64_t c_end, uint64_t d_size,
+                         uint32_t frame_idx, const ZkFrameBase *base, ZkBlock *blocks, ZkFrameInfo &fi)
+{
+    fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; fi.status = ZK_OK;
+    fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.pad = 0;
+    uint64_t csz = c_end - c_begin;
+    const uint8_t *f = comp + c_begin;
+    if (csz < 6) { fi.status = ZK_E_SRC_SIZE_WRONG; return; }
+    if (zk_rd32(f) != 0xFD2FB528u) { fi.status = ZK_E_PREFIX_UNKNOWN; return; }
+    uint32_t fhd = f[4];
+    uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, cks = (fhd >> 2) & 1, did = fhd & 3;
+    if (fhd & 0x08) { fi.status = ZK_E_FRAMEPARAM_UNSUPPORTED; return; }
+    uint64_t p = 5, window = 0;
+    if (!single) {
+        uint32_t wd = f[p++];
+        uint32_t e = wd >> 3, m = wd & 7;
+        if (10 + e > 31) { fi.status = ZK_E_WINDOW_TOO_LARGE; return; }
+        window = 1ull << (10 + e); window += (window >> 3) * m;
+    }
+    uint32_t dl = did == 3 ? 4 : did;
+    uint32_t fl = fcs_flag == 0 ? single : (1u << fcs_flag);
+    if (p + dl + fl > csz) { fi.status = ZK_E_SRC_SIZE_WRONG; return; }
+    uint32_t dict = 0;
+    for (uint32_t i = 0; i < dl; i++) dict |= (uint32_t)f[p + i] << (8 * i);
+    if (dict) { fi.status = ZK_E_DICT_WRONG; return; }
+    p += dl;
+    uint64_t fcs = 0;
+    for (uint32_t i = 0; i < fl; i++) fcs |= (uint64_t)f[p + i] << (8 * i);
+    if (fl == 2) fcs += 256;
+    p += fl;
+    if (single) window = fcs;
+    if (fl && fcs != d_size) { fi.status = ZK_E_CORRUPTION; return; }
+    fi.checksum_flag = cks;
+    fi.window = window > 0x80000000ull ? 0x80000000u : (uint32_t)window;
+    uint32_t block_max = window < ZK_BLOCK_MAX ? (uint32_t)window : ZK_BLOCK_MAX;
+
+    uint64_t blk = base ? base->block_base : 0, seqb = base ? base->seq_base : 0, litb = base ? base->lit_base : 0;
+    uint32_t huf_def = 0xFFFFFFFFu, tab_def[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint64_t out_known = 0;                                 // regenerated bytes of raw/rle blocks (sanity bound)
+    for (;;) {
+        if (p + 3 > csz) { fi.status = ZK_E_SRC_SIZE_WRONG; return; }
+        uint32_t bh = zk_rd24(f + p); p += 3;
+        uint32_t last = bh & 1, type = (bh >> 1) & 3, bsize = bh >> 3;
+        if (type == 3 || bsize > block_max) { fi.status = ZK_E_CORRUPTION; return; }
+        uint32_t content = type == 1 ? 1u : bsize;
+        if (p + content > csz) { fi.status = ZK_E_SRC_SIZE_WRONG; return; }
+        ZkBlock b;
+        b.src = c_begin + p; b.lit_base = litb; b.seq_base = seqb; b.bsize = bsize; b.frame = frame_idx;
+        b.type = (uint8_t)type; b.lit_type = 0; b.lit_streams = 0; b.seq_modes = 0;
+        b.lit_regen = 0; b.lit_off = 0; b.lit_comp = 0; b.seq_off = 0; b.nseq = 0;
+        b.out_size = type == 2 ? 0 : bsize;
+        b.status = ZK_OK; b.pad = 0;
+        if (type == 2) {
+            const uint8_t *c = f + p;
+            ZkLitHdr lh;
+            if (bsize < 2 || !zk_parse_lit_hdr(c, bsize, lh)) { fi.status = ZK_E_CORRUPTION; return; }
+            b.lit_type = (uint8_t)lh.type; b.lit_streams = (uint8_t)lh.streams;
+            b.lit_regen = lh.regen; b.lit_off = lh.hdr; b.lit_comp = lh.comp;
+            if (lh.type == 2) huf_def = (uint32_t)blk;
+            if (lh.type >= 2) {
+                if (huf_def == 0xFFFFFFFFu) { fi.status = ZK_E_CORRUPTION; return; }
+                litb += lh.regen; fi.lit_bytes += lh.regen;
+            }
+            uint32_t so = lh.hdr + lh.comp, nseq = 0;
+            uint32_t nh = zk_parse_nseq(c + so, bsize - so, nseq);
+            if (nh == 0) { fi.status = ZK_E_CORRUPTION; return; }
+            so += nh;
+            b.nseq = nseq;
+            if (nseq == 0) {
+                if (so != bsize) { fi.status = ZK_E_CORRUPTION; return; }
+                b.out_size = lh.regen;
+            } else {
+                if (so + 1 > bsize) { fi.status = ZK_E_CORRUPTION; return; }
+                uint32_t modes = c[so];
+                if (modes & 3) { fi.status = ZK_E_CORRUPTION; return; }
+                b.seq_modes = (uint8_t)modes; b.seq_off = so;
+                for (int t = 0; t < 3; t++) {
+                    uint32_t m = (modes >> (6 - 2 * t)) & 3;
+                    if (m != 3) tab_def[t] = (uint32_t)blk;
+                    else if (tab_def[t] == 0xFFFFFFFFu) { fi.status = ZK_E_CORRUPTION; return; }
+                }
+                seqb += nseq; fi.n_seq += nseq;
+            }
+        } else {
+            out_known += bsize;
+            if (out_known > d_size) { fi.status = ZK_E_CORRUPTION; return; }
+        }
+        b.huf_def = huf_def;
+        b.tab_def[0] = tab_def[0]; b.tab_def[1] = tab_def[1]; b.tab_def[2] = tab_def[2];
+        b.rep_out[0] = 0x80000000u; b.rep_out[1] = 0x90000000u; b.rep_out[2] = 0xA0000000u;   // identity (symbolic)
+        if (blocks) blocks[blk] = b;
+        blk++; fi.n_blocks++;
+        p += content;
+        if (last) break;
+    }
+    if (cks) {
+        if (p + 4 > csz) { fi.status = ZK_E_SRC_SIZE_WRONG; return; }
+        fi.checksum = zk_rd32(f + p); p += 4;
+    }
+    if (p != csz) { fi.status = ZK_E_SRC_SIZE_WRONG; return; }   // seek-table c_size must match the frame exactly
+    if (fi.lit_bytes > d_size) { fi.status = ZK_E_CORRUPTION; return; }
+}
+
+// ---------------------------------------------------------------- repeat offsets, symbolic across blocks
+// A block's sequences are entropy-decoded before the previous block's final repeat
+// history is known.  An offset value v is concrete if v < 2^31, else it names
+// "history slot s at block entry, minus d": s = (v >> 28) & 3, d = v & 0x0FFFFFFF.
+ZK_HD uint32_t zk_rep_sym(uint32_t slot) { return 0x80000000u | (slot << 28); }
+ZK_HD bool zk_rep_is_sym(uint32_t v) { return (v & 0x80000000u) != 0; }
+ZK_HD uint32_t zk_rep_resolve(uint32_t v, const uint32_t init[3])
+{
+    if (!(v & 0x80000000u)) return v;
+    uint32_t s = (v >> 28) & 3, d = v & 0x0FFFFFFFu;
+    uint32_t x = init[s];
+    return d >= x ? 0u : x - d;             // 0 == invalid, caught by the caller
+}
+
+// ---------------------------------------------------------------- sequence section decode (one lane per block)
+struct ZkSeqTables {                 // LDS-resident, per lane
+    uint32_t ll[512];
+    uint32_t ml[512];
+    uint32_t of[256];
+    int16_t norm[64];
+    uint16_t next[64];
+};
+
+// Locate + build table t of block `def` (the block whose header defines the table in force).
+// comp: compressed buffer.  Returns bytes the description occupies in `def` (for own-block parsing), or -1.
+ZK_HD int32_t zk_seq_table_setup(const uint8_t *comp, const ZkBlock &def, int t, ZkSeqTables *T, uint32_t *al_out,
+                                 const uint32_t *ll_values, const uint32_t *ml_values)
+{
+    const int16_t ll_def[36] = ZK_LL_DEFNORM;
+    const int16_t of_def[29] = ZK_OF_DEFNORM;
+    const int16_t ml_def[53] = ZK_ML_DEFNORM;
+    const uint8_t *c = comp + def.src;
+    uint32_t modes = def.seq_modes;
+    uint32_t p = def.seq_off + 1;
+    uint32_t nsym, al;
+    // skip the descriptions that precede table t
+    for (int u = 0; u < t; u++) {
+        uint32_t m = (modes >> (6 - 2 * u)) & 3;
+        if (m == 1) p += 1;
+        else if (m == 2) {
+            if (p >= def.bsize) return -1;
+            uint32_t r = zk_fse_read_ncount(c + p, def.bsize - p, zk_tab_maxsym(u), zk_tab_maxal(u), T->norm, &nsym, &al);
+            if (!r) return -1;
+            p += r;
+        }
+    }
+    uint32_t m = (modes >> (6 - 2 * t)) & 3;
+    uint32_t *cells = t == ZK_TAB_LL ? T->ll : t == ZK_TAB_OF ? T->of : T->ml;
+    const uint32_t *vt = t == ZK_TAB_LL ? ll_values : t == ZK_TAB_ML ? ml_values : nullptr;
+    if (m == 0) {
+        const int16_t *d = t == ZK_TAB_LL ? ll_def : t == ZK_TAB_OF ? of_def : ml_def;
+        nsym = t == ZK_TAB_LL ? 36 : t == ZK_TAB_OF ? 29 : 53;
+        al = t == ZK_TAB_OF ? 5 : 6;
+        for (uint32_t i = 0; i < nsym; i++) T->norm[i] = d[i];
+        if (!zk_fse_build(cells, T->norm, nsym, al, T->next, vt)) return -1;
+        *al_out = al;
+        return 0;
+    }
+    if (m == 1) {
+        if (p >= def.bsize) return -1;
+        uint32_t s = c[p];
+        if (s > zk_tab_maxsym(t)) return -1;
+        cells[0] = zk_cell(s, 0, (vt ? (vt[s] >> 24) : s) & 31u, 0);
+        *al_out = 0;
+        return 1;
+    }
+    if (m == 2) {
+        if (p >= def.bsize) return -1;
+        uint32_t r = zk_fse_read_ncount(c + p, def.bsize - p, zk_tab_maxsym(t), zk_tab_maxal(t), T->norm, &nsym, &al);
+        if (!r) return -1;
+        if (!zk_fse_build(cells, T->norm, nsym, al, T->next, vt)) return -1;
+        *al_out = al;
+        return (int32_t)r;
+    }
+    return -1;   // a defining block never has Repeat_Mode for this table
+}
+
+// Decode all sequences of block b into seqs[]; fills b.out_size / b.rep_out / b.status.
+ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlock &b, ZkSeqTables *T, ZkSeq *seqs,
+                               const uint32_t *ll_values, const uint32_t *ml_values)
+{
+    uint32_t al[3];
+    uint32_t own = 0;                                   // bytes of table descriptions in this block
+    for (int t = 0; t < 3; t++) {
+        uint32_t m = (b.seq_modes >> (6 - 2 * t)) & 3;
+        const ZkBlock &def = m == 3 ? blocks[b.tab_def[t]] : b;
+        int32_t r = zk_seq_table_setup(comp, def, t, T, &al[t], ll_values, ml_values);
+        if (r < 0) { b.status = ZK_E_CORRUPTION; return; }
+        if (m != 3) own += (uint32_t)r;
+    }
+    uint32_t bs_off = b.seq_off + 1 + own;
+    if (bs_off >= b.bsize) { b.status = ZK_E_CORRUPTION; return; }
+    ZkBwd r;
+    if (!zk_bwd_init(r, comp + b.src + bs_off, b.bsize - bs_off)) { b.status = ZK_E_CORRUPTION; return; }
+    zk_bwd_refill(r);
+    uint32_t sl = zk_bwd_read(r, al[0]), so = zk_bwd_read(r, al[1]), sm = zk_bwd_read(r, al[2]);
+    uint32_t rep0 = zk_rep_sym(0), rep1 = zk_rep_sym(1), rep2 = zk_rep_sym(2);
+    uint32_t out = 0, lit = 0;
+    const uint32_t nseq = b.nseq;
+    bool bad = false;
+    for (uint32_t i = 0; i < nseq; i++) {
+        uint32_t cl = T->ll[sl], co = T->of[so], cm = T->ml[sm];
+        zk_bwd_refill(r);
+        uint32_t ofc = zk_cell_sym(co);
+        if (ofc > 30) { bad = true; break; }
+        uint32_t ofv = (1u << ofc) + zk_bwd_read(r, ofc);
+        uint32_t mlv = ml_values[zk_cell_sym(cm)], llv = ll_values[zk_cell_sym(cl)];
+        uint32_t ml = (mlv & 0xFFFFFFu) + zk_bwd_read(r, zk_cell_xbits(cm));
+        uint32_t ll = (llv & 0xFFFFFFu) + zk_bwd_read(r, zk_cell_xbits(cl));
+        uint32_t off;
+        if (ofv > 3) { off = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
+        else {
+            uint32_t idx = ofv - 1 + (ll == 0);
+            if (idx == 0) off = rep0;
+            else {
+                if (idx == 3) {
+                    // rep0 - 1: concrete -> must stay >= 1; symbolic -> one more subtracted
+                    if (zk_rep_is_sym(rep0)) off = rep0 + 1; else { off = rep0 - 1; if (off == 0) { bad = true; break; } }
+                } else off = idx == 1 ? rep1 : rep2;
+                if (idx > 1) rep2 = rep1;
+                rep1 = rep0; rep0 = off;
+            }
+        }
+        if (i + 1 < nseq) {
+            if (r.cnt < 26) zk_bwd_refill(r);
+            sl = zk_cell_base(cl) + zk_bwd_read(r, zk_cell_nb(cl));
+            sm = zk_cell_base(cm) + zk_bwd_read(r, zk_cell_nb(cm));
+            so = zk_cell_base(co) + zk_bwd_read(r, zk_cell_nb(co));
+        }
+        lit += ll; out += ll + ml;
+        if (r.bits_left < 0 || lit > b.lit_regen || out > ZK_BLOCK_MAX) { bad = true; break; }
+        ZkSeq s; s.out_end = out; s.ml = ml; s.off = off; s.lit_end = lit;
+        seqs[i] = s;
+    }
+    if (bad || r.bits_left != 0) { b.status = ZK_E_CORRUPTION; return; }
+    out += b.lit_regen - lit;
+    if (out > ZK_BLOCK_MAX) { b.status = ZK_E_CORRUPTION; return; }
+    b.out_size = out;
+    b.rep_out[0] = rep0; b.rep_out[1] = rep1; b.rep_out[2] = rep2;
+}
+
+// ---------------------------------------------------------------- sequence execution: byte-source resolver
+// Chunk of sequences staged in LDS: oe[i] (block-relative end), ml[i], of[i] (resolved), le[i].
+// Index n (one past the chunk) may be the trailing-literals pseudo sequence (ml = 0).
+// first index j with oe[j] > q, searching [lo, hi)
+ZK_HD uint32_t zk_seq_find(const uint32_t *oe, uint32_t lo, uint32_t hi, uint32_t q)
+{
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (oe[mid] > q) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// Where does output byte q (block-relative, inside the chunk) come from?
+// Returns: >= 0  -> literal index (block-relative) ;  < 0 -> -(1 + P) hmm see below
+// Encoded as int64: literal L -> L ; history byte at block-relative position P (P < tile_start, may be negative) -> ZK_SRC_HIST | (P + 2^31)
+constexpr uint64_t ZK_SRC_HIST = 1ull << 40;
+ZK_HD uint64_t zk_resolve_byte(const uint32_t *oe, const uint32_t *mlv, const uint32_t *ofv, const uint32_t *le,
+                               uint32_t j, uint32_t q, int32_t tile_start)
+{
+    int32_t qq = (int32_t)q;
+    for (;;) {
+        int32_t mstart = (int32_t)(oe[j] - mlv[j]);
+        if (qq < mstart) return (uint64_t)(le[j] - (uint32_t)(mstart - qq));
+        int32_t off = (int32_t)ofv[j];
+        int32_t p = qq - off;
+        if (p >= mstart) p = mstart - off + (qq - mstart) % off;        // overlapping match: periodic source
+        if (p < tile_start) return ZK_SRC_HIST | (uint64_t)(uint32_t)(p + (int32_t)0x40000000);
+        qq = p;
+        j = zk_seq_find(oe, 0, j + 1, (uint32_t)qq);                     // in-tile dependency: chase the source
+    }
+}

@@ -1,0 +1,216 @@
+// zk_engine.hip -- the batch engine behind the C ABI of include/zeekstd_amd.h (Level A).
+// Owns the device scratch (frame infos, block list, sequence records, literal scratch) and
+// sequences the kernel pipeline of zk_decode.hip / zk_encode.hip on one HIP stream.
+// No CPU fallback: every entry point needs a live gfx950 device.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/zeekstd_amd.h"
+#include "zk_engine.h"
+#include "zk_kernels.h"
+
+#define ZK_HIP(call)                                                                                 \
+    do {                                                                                             \
+        hipError_t _e = (call);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            e->last_err = std::string(#call) + ": " + hipGetErrorString(_e);                         \
+            return ZK_ERR_HIP;                                                                       \
+        }                                                                                            \
+    } while (0)
+
+int zk_devbuf_reserve(zk_engine *e, zk_devbuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return 0;
+    if (b.p) ZK_HIP(hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    ZK_HIP(hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+extern "C" int zk_abi_version(void) { return ZK_ABI_VERSION; }
+
+extern "C" const char *zk_error_name(int code)
+{
+    switch (code) {
+    case 0: return "No error detected";
+    case -1: return "Error (generic)";
+    case -10: return "Unknown frame descriptor";
+    case -12: return "Version not supported";
+    case -14: return "Unsupported frame parameter";
+    case -16: return "Frame requires too much memory for decoding";
+    case -20: return "Data corruption detected";
+    case -22: return "Restored data doesn't match checksum";
+    case -30: return "Dictionary is corrupted";
+    case -32: return "Dictionary mismatch";
+    case -40: return "Unsupported parameter";
+    case -42: return "Parameter is out of bound";
+    case -64: return "Allocation error : not enough memory";
+    case -70: return "Destination buffer is too small";
+    case -72: return "Src size is incorrect";
+    case -74: return "Operation on NULL destination buffer";
+    case ZK_ERR_OFFSET_OUT_OF_RANGE: return "offset out of range";
+    case ZK_ERR_FRAME_INDEX_TOO_LARGE: return "frame index too large";
+    case ZK_ERR_NUMBER_CONVERSION: return "number conversion failed";
+    case ZK_ERR_IO: return "io error";
+    case ZK_ERR_HIP: return "HIP runtime error";
+    case ZK_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case ZK_ERR_ARGUMENT: return "invalid argument";
+    default: return "Unspecified error code";
+    }
+}
+
+extern "C" int zk_engine_create(int device, zk_engine **out)
+{
+    if (!out) return ZK_ERR_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return ZK_ERR_NO_DEVICE;
+    zk_engine *e = new zk_engine();
+    e->device = device;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { delete e; return ZK_ERR_NO_DEVICE; }
+    snprintf(e->devname, sizeof e->devname, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete e; return ZK_ERR_NO_DEVICE; }   // kernels are built for gfx950 only
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return ZK_ERR_NO_DEVICE; }
+    if (hipHostMalloc((void **)&e->h_words, 16 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { hipStreamDestroy(e->stream); delete e; return ZK_ERR_HIP; }
+    *out = e;
+    return 0;
+}
+
+extern "C" void zk_engine_destroy(zk_engine *e)
+{
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    zk_devbuf *bufs[] = {&e->infos, &e->bases, &e->words, &e->blocks, &e->seqs, &e->lit, &e->st_comp, &e->st_off, &e->st_dst, &e->st_misc,
+                         &e->enc_a, &e->enc_b, &e->enc_c, &e->enc_d};
+    for (zk_devbuf *b : bufs) if (b->p) hipFree(b->p);
+    if (e->h_words) hipHostFree(e->h_words);
+    hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" const char *zk_engine_last_hip_error(const zk_engine *e) { return e ? e->last_err.c_str() : ""; }
+extern "C" const char *zk_engine_device_name(const zk_engine *e) { return e ? e->devname : ""; }
+
+// ---------------------------------------------------------------------------------------------- decode
+extern "C" int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off,
+                                    const void *d_d_off, uint32_t first, uint32_t count, void *d_dst, uint64_t dst_cap,
+                                    int verify, void *d_frame_status, void *stream)
+{
+    (void)comp_size; (void)dst_cap;
+    if (!e || (count && (!d_comp || !d_c_off || !d_d_off || !d_dst))) return ZK_ERR_ARGUMENT;
+    if (count == 0) return 0;
+    ZK_HIP(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    const uint8_t *comp = (const uint8_t *)d_comp;
+    const uint64_t *c_off = (const uint64_t *)d_c_off, *d_off = (const uint64_t *)d_d_off;
+    int rc;
+    if ((rc = zk_devbuf_reserve(e, e->infos, (size_t)count * sizeof(ZkFrameInfo)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->bases, (size_t)count * sizeof(ZkFrameBase)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->words, 16 * sizeof(uint64_t)))) return rc;
+    ZkFrameInfo *infos = (ZkFrameInfo *)e->infos.p;
+    ZkFrameBase *bases = (ZkFrameBase *)e->bases.p;
+    uint64_t *words = (uint64_t *)e->words.p;          // [0..2] totals, [3] first error
+
+    zk_launch_walk(st, comp, c_off, d_off, first, count, nullptr, nullptr, infos);
+    zk_launch_scan(st, infos, count, bases, words);
+    ZK_HIP(hipMemcpyAsync(e->h_words, words, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    const uint64_t nblocks = e->h_words[0], nseq = e->h_words[1], nlit = e->h_words[2];
+    if (nblocks > 0xFFFFFFF0ull) return -(int)ZK_E_GENERIC;
+    if ((rc = zk_devbuf_reserve(e, e->blocks, (size_t)(nblocks + 1) * sizeof(ZkBlock)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->seqs, (size_t)(nseq + 1) * sizeof(ZkSeq)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->lit, (size_t)nlit + 64))) return rc;
+    ZkBlock *blocks = (ZkBlock *)e->blocks.p;
+    ZkSeq *seqs = (ZkSeq *)e->seqs.p;
+    uint8_t *lit = (uint8_t *)e->lit.p;
+
+    e->h_words[3] = ~0ull;
+    ZK_HIP(hipMemcpyAsync(words + 3, e->h_words + 3, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    zk_launch_walk(st, comp, c_off, d_off, first, count, bases, blocks, infos);
+    zk_launch_huf(st, comp, blocks, (uint32_t)nblocks, lit);
+    zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, seqs);
+    zk_launch_exec(st, comp, d_off, first, count, blocks, bases, infos, seqs, lit, (uint8_t *)d_dst);
+    if (verify) zk_launch_xxh64(st, (const uint8_t *)d_dst, d_off, first, count, infos, nullptr);
+    zk_launch_status(st, infos, count, (int32_t *)d_frame_status, words + 3);
+    ZK_HIP(hipMemcpyAsync(e->h_words + 3, words + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+    if (e->h_words[3] != ~0ull) return -(int)(uint32_t)(e->h_words[3] & 0xFFFFFFFFu);
+    return 0;
+}
+
+extern "C" int zk_decode_frames(zk_engine *e, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off,
+                                const uint64_t *d_off, uint32_t first, uint32_t count, uint8_t *dst, uint64_t dst_cap,
+                                int verify, int32_t *frame_status)
+{
+    if (!e || (count && (!comp || !c_off || !d_off))) return ZK_ERR_ARGUMENT;
+    if (count == 0) return 0;
+    ZK_HIP(hipSetDevice(e->device));
+    const uint64_t c_lo = c_off[first], c_hi = c_off[first + count];
+    const uint64_t d_lo = d_off[first], d_hi = d_off[first + count];
+    if (c_hi < c_lo || c_hi > comp_size || d_hi < d_lo) return ZK_ERR_ARGUMENT;
+    if (d_hi - d_lo > dst_cap) return -(int)ZK_E_DST_TOO_SMALL;
+    if (d_hi > d_lo && !dst) return ZK_ERR_ARGUMENT;
+    // stage only the byte range of the requested frames; offsets are rebased to it
+    std::vector<uint64_t> offs(2 * ((size_t)count + 1));
+    for (uint32_t i = 0; i <= count; i++) { offs[i] = c_off[first + i] - c_lo; offs[count + 1 + i] = d_off[first + i] - d_lo; }
+    int rc;
+    if ((rc = zk_devbuf_reserve(e, e->st_comp, (size_t)(c_hi - c_lo) + 64))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->st_off, offs.size() * 8))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->st_dst, (size_t)(d_hi - d_lo) + 64))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->st_misc, (size_t)count * 4))) return rc;
+    hipStream_t st = e->stream;
+    ZK_HIP(hipMemcpyAsync(e->st_comp.p, comp + c_lo, c_hi - c_lo, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(e->st_off.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipStreamSynchronize(st));            // offs is a stack-lifetime vector
+    const uint64_t *dc = (const uint64_t *)e->st_off.p, *dd = dc + count + 1;
+    rc = zk_decode_frames_dev(e, e->st_comp.p, c_hi - c_lo, dc, dd, 0, count, e->st_dst.p, d_hi - d_lo, verify, e->st_misc.p, st);
+    if (rc == ZK_ERR_HIP || rc == ZK_ERR_ARGUMENT) return rc;
+    if (d_hi > d_lo) ZK_HIP(hipMemcpyAsync(dst, e->st_dst.p, d_hi - d_lo, hipMemcpyDeviceToHost, st));
+    if (frame_status) ZK_HIP(hipMemcpyAsync(frame_status, e->st_misc.p, (size_t)count * 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------- XXH64
+extern "C" int zk_xxh64_frames_dev(zk_engine *e, const void *d_data, const void *d_off, uint32_t count, void *d_out, void *stream)
+{
+    if (!e || (count && (!d_off || !d_out))) return ZK_ERR_ARGUMENT;
+    if (count == 0) return 0;
+    ZK_HIP(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    zk_launch_xxh64(st, (const uint8_t *)d_data, (const uint64_t *)d_off, 0, count, nullptr, (uint64_t *)d_out);
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int zk_xxh64_frames(zk_engine *e, const uint8_t *data, const uint64_t *off, uint32_t count, uint64_t *out)
+{
+    if (!e || (count && (!off || !out))) return ZK_ERR_ARGUMENT;
+    if (count == 0) return 0;
+    ZK_HIP(hipSetDevice(e->device));
+    const uint64_t lo = off[0], hi = off[count];
+    if (hi < lo || (hi > lo && !data)) return ZK_ERR_ARGUMENT;
+    std::vector<uint64_t> offs((size_t)count + 1);
+    for (uint32_t i = 0; i <= count; i++) offs[i] = off[i] - lo;
+    int rc;
+    if ((rc = zk_devbuf_reserve(e, e->st_dst, (size_t)(hi - lo) + 64))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->st_off, offs.size() * 8))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->st_misc, (size_t)count * 8))) return rc;
+    hipStream_t st = e->stream;
+    if (hi > lo) ZK_HIP(hipMemcpyAsync(e->st_dst.p, data + lo, hi - lo, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(e->st_off.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    rc = zk_xxh64_frames_dev(e, e->st_dst.p, e->st_off.p, count, e->st_misc.p, st);
+    if (rc) return rc;
+    ZK_HIP(hipMemcpy(out, e->st_misc.p, (size_t)count * 8, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -1,0 +1,92 @@
+"""Level-A batch engine binding (include/zeekstd_amd.h): N frames in, N frames out on one MI355X."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+
+
+class ZkError(Exception):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = _lib.error_name(code)
+        super().__init__(f"{msg} (code {code}){': ' + detail if detail else ''}")
+
+
+def _u64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+
+
+class Engine:
+    """Owns one GPU's scratch + stream. One thread at a time (like a libzstd context)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        rc = lib.zk_engine_create(device, C.byref(h))
+        if rc != 0:
+            raise ZkError(rc)
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib.zk_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_name(self) -> str:
+        return lib.zk_engine_device_name(self._h).decode()
+
+    def _raise(self, rc):
+        raise ZkError(rc, lib.zk_engine_last_hip_error(self._h).decode() if rc == -2001 else "")
+
+    # ---- host-pointer entry points
+    def decode_frames(self, comp, c_off, d_off, first=0, count=None, verify=True, raise_on_error=True):
+        """Returns (bytes of frames [first, first+count), per-frame status array)."""
+        comp = np.frombuffer(comp, dtype=np.uint8) if not isinstance(comp, np.ndarray) else comp
+        c_off, d_off = _u64(c_off), _u64(d_off)
+        if count is None:
+            count = len(c_off) - 1 - first
+        out_len = int(d_off[first + count] - d_off[first])
+        out = np.empty(max(out_len, 1), dtype=np.uint8)
+        status = np.zeros(max(count, 1), dtype=np.int32)
+        rc = lib.zk_decode_frames(self._h, comp.ctypes.data, comp.size, c_off.ctypes.data, d_off.ctypes.data,
+                                  first, count, out.ctypes.data, out_len, int(verify), status.ctypes.data)
+        if rc != 0 and (raise_on_error or rc <= -1000):
+            self._raise(rc)
+        return out[:out_len].tobytes(), status[:count]
+
+    def xxh64_frames(self, data, off):
+        data = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        off = _u64(off)
+        n = len(off) - 1
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        rc = lib.zk_xxh64_frames(self._h, data.ctypes.data if data.size else None, off.ctypes.data, n, out.ctypes.data)
+        if rc != 0:
+            self._raise(rc)
+        return out[:n]
+
+    # ---- device-pointer entry points (torch tensors or raw ints)
+    @staticmethod
+    def _ptr(t):
+        return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
+
+    def decode_frames_dev(self, d_comp, comp_size, d_c_off, d_d_off, first, count, d_dst, dst_cap, verify=True,
+                          d_status=None, stream=None):
+        rc = lib.zk_decode_frames_dev(self._h, self._ptr(d_comp), comp_size, self._ptr(d_c_off), self._ptr(d_d_off),
+                                      first, count, self._ptr(d_dst), dst_cap, int(verify),
+                                      self._ptr(d_status) if d_status is not None else None, stream)
+        if rc <= -1000:
+            self._raise(rc)
+        return rc
+
+    def xxh64_frames_dev(self, d_data, d_off, count, d_out, stream=None):
+        rc = lib.zk_xxh64_frames_dev(self._h, self._ptr(d_data), self._ptr(d_off), count, self._ptr(d_out), stream)
+        if rc != 0:
+            self._raise(rc)
