@@ -127,26 +127,31 @@ __global__ __launch_bounds__(64) void zk_k_huf(const uint8_t *comp, ZkBlock *blo
 }
 
 // ------------------------------------------------------------------------------------------------ FSE sequences
-// One lane per block; each lane owns 5.25 KiB of LDS (LL/ML 2^9 + OF 2^8 cells + build scratch).
+// One lane per block; each lane owns 5.25 KiB of LDS (LL/ML 2^9 + OF 2^8 cells + build scratch), so a
+// CU holds 28 blocks.  The 3-state walk is a dependent chain (cells -> bit counts -> next states), so
+// the 28 lanes are spread over 4 waves (one per SIMD) instead of sitting in one.
 constexpr int ZK_FSE_BLOCKS = 28;
-__global__ __launch_bounds__(64) void zk_k_fse(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
+constexpr int ZK_FSE_WAVES = 4;
+constexpr int ZK_FSE_PER_WAVE = ZK_FSE_BLOCKS / ZK_FSE_WAVES;
+__global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
 {
     __shared__ ZkSeqTables T[ZK_FSE_BLOCKS];
     __shared__ uint32_t llv[36], mlv[53];
-    const uint32_t lane = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
         const uint32_t ll_init[36] = ZK_LL_TABLE;
         const uint32_t ml_init[53] = ZK_ML_TABLE;
-        if (lane < 36) llv[lane] = ll_init[lane];
-        if (lane < 53) mlv[lane] = ml_init[lane];
+        if (tid < 36) llv[tid] = ll_init[tid];
+        if (tid < 53) mlv[tid] = ml_init[tid];
     }
     __syncthreads();
-    if (lane >= ZK_FSE_BLOCKS) return;
-    const uint32_t bi = blockIdx.x * ZK_FSE_BLOCKS + lane;
+    if (lane >= ZK_FSE_PER_WAVE) return;
+    const uint32_t slot = wave * ZK_FSE_PER_WAVE + lane;
+    const uint32_t bi = blockIdx.x * ZK_FSE_BLOCKS + slot;
     if (bi >= nblocks) return;
     ZkBlock b = blocks[bi];
     if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK) return;
-    zk_decode_sequences(comp, blocks, b, &T[lane], seqs + b.seq_base, llv, mlv);
+    zk_decode_sequences(comp, blocks, b, &T[slot], seqs + b.seq_base, llv, mlv);
     ZkBlock *o = &blocks[bi];
     o->out_size = b.out_size;
     o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
@@ -154,21 +159,54 @@ __global__ __launch_bounds__(64) void zk_k_fse(const uint8_t *comp, ZkBlock *blo
 }
 
 // ------------------------------------------------------------------------------------------------ sequence execution
-// One workgroup per frame.  Sequences are staged in LDS in chunks; the output range of a chunk is
-// produced in tiles of 256 lanes x 16 B: every lane resolves the source of its own 16 output bytes
-// (literal buffer, or history already written, chasing through in-tile matches) and issues one
-// coalesced 16 B store.  Tiles are ordered by a workgroup barrier.
-constexpr int ZK_EXEC_THREADS = 256;
+// One workgroup (T lanes) per frame.  The output of a compressed block is produced in tiles of
+// T x 16 B.  Per tile:
+//   1. the sequences overlapping the tile are staged in LDS (16 B records, offsets resolved);
+//   2. every sequence drops a mark on the first 16 B bucket it covers; a prefix-max over the
+//      buckets gives each lane the sequence its 16 bytes start in (no searches);
+//   3. every lane resolves the source address of its 16 output bytes -- literal buffer, history
+//      before the tile (already in HBM/L2), or, for a source inside the tile, the source's own
+//      source (chase through the bucket table) -- then issues the 16 byte loads back to back;
+//   4. one coalesced 16 B store per lane; a workgroup barrier orders the tiles.
 constexpr int ZK_EXEC_B = 16;
-constexpr int ZK_EXEC_CHUNK = 1024;
 
-__global__ __launch_bounds__(ZK_EXEC_THREADS) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
-                                                             const ZkBlock *blocks, const ZkFrameBase *bases,
-                                                             ZkFrameInfo *infos, const ZkSeq *seqs,
-                                                             const uint8_t *lit_scratch, uint8_t *dst)
+struct ZkChase {
+    const uint4 *S;
+    const uint16_t *jstart;
+    uint32_t ts;
+};
+
+// source address of block-relative position p (p >= ts), which lies inside the current tile
+__device__ __forceinline__ const uint8_t *zk_chase(const ZkChase &c, int32_t p, const uint8_t *lit, uint32_t lit_stride,
+                                                   const uint8_t *bout)
 {
-    __shared__ uint32_t oe[ZK_EXEC_CHUNK + 1], mlv[ZK_EXEC_CHUNK + 1], ofv[ZK_EXEC_CHUNK + 1], le[ZK_EXEC_CHUNK + 1];
-    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    for (;;) {
+        uint32_t j = c.jstart[((uint32_t)p - c.ts) >> 4];
+        uint4 s = c.S[j];
+        while ((uint32_t)p >= s.x) s = c.S[++j];
+        int32_t ms = (int32_t)(s.x - s.y);
+        if (p < ms) return lit + (size_t)(s.w - (uint32_t)(ms - p)) * lit_stride;
+        int32_t off = (int32_t)s.z;
+        int32_t p2 = p - off;
+        if (p2 >= ms) p2 = ms - off + (p - ms) % off;
+        if (p2 < (int32_t)c.ts) return bout + p2;
+        p = p2;
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
+                                               const ZkBlock *blocks, const ZkFrameBase *bases,
+                                               ZkFrameInfo *infos, const ZkSeq *seqs,
+                                               const uint8_t *lit_scratch, uint8_t *dst)
+{
+    constexpr int CAP = 2 * T;
+    constexpr int NW = T / 64;
+    __shared__ uint4 S[CAP + 1];
+    __shared__ uint16_t mark[T], jstart[T];
+    __shared__ uint32_t wmax[NW];
+    __shared__ uint32_t s_jn;
+    const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ZkFrameInfo fi = infos[f];
     if (fi.status != ZK_OK) return;
     const uint64_t d_size = d_off[first + f + 1] - d_off[first + f];
@@ -185,65 +223,105 @@ __global__ __launch_bounds__(ZK_EXEC_THREADS) void zk_k_exec(const uint8_t *comp
         uint8_t *bout = out + pos;
         if (b.type == 0) {
             const uint8_t *s = comp + b.src;
-            for (uint32_t i = tid; i < b.bsize; i += ZK_EXEC_THREADS) bout[i] = s[i];
+            for (uint32_t i = tid; i < b.bsize; i += T) bout[i] = s[i];
         } else if (b.type == 1) {
             const uint8_t v = comp[b.src];
-            for (uint32_t i = tid; i < b.bsize; i += ZK_EXEC_THREADS) bout[i] = v;
+            for (uint32_t i = tid; i < b.bsize; i += T) bout[i] = v;
         } else {
             const ZkSeq *sq = seqs + b.seq_base;
             const uint8_t *lit = b.lit_type >= 2 ? lit_scratch + b.lit_base : comp + b.src + b.lit_off;
             const uint32_t lit_stride = b.lit_type == 1 ? 0u : 1u;
-            const uint32_t nseq = b.nseq;
-            uint32_t s0 = 0, cpos = 0;
-            for (;;) {
-                const uint32_t ns = nseq - s0 < (uint32_t)ZK_EXEC_CHUNK ? nseq - s0 : (uint32_t)ZK_EXEC_CHUNK;
-                const bool lastchunk = s0 + ns == nseq;
+            const uint32_t nseq = b.nseq, out_size = b.out_size;
+            uint32_t ja = 0, ts = 0;
+            while (ts < out_size) {
+                // 1. stage sequences [ja, ja + nl); index nseq is the trailing-literals pseudo sequence
+                const uint32_t nl = nseq + 1 - ja < (uint32_t)CAP ? nseq + 1 - ja : (uint32_t)CAP;
                 int bad = 0;
-                for (uint32_t i = tid; i < ns; i += ZK_EXEC_THREADS) {
-                    ZkSeq s = sq[s0 + i];
-                    uint32_t off = zk_rep_resolve(s.off, rep);
-                    oe[i] = s.out_end; mlv[i] = s.ml; ofv[i] = off; le[i] = s.lit_end;
-                    uint32_t mstart = s.out_end - s.ml;
-                    if (off == 0 || pos + mstart < off || off > fi.window) bad = 1;
+                for (uint32_t i = tid; i < nl; i += T) {
+                    const uint32_t idx = ja + i;
+                    uint4 r;
+                    if (idx < nseq) {
+                        const uint4 s = reinterpret_cast<const uint4 *>(sq)[idx];      // out_end, ml, off, lit_end
+                        const uint32_t off = zk_rep_resolve(s.z, rep);
+                        const uint32_t mstart = s.x - s.y;
+                        if (off == 0 || pos + mstart < off || off > fi.window) bad = 1;
+                        r = make_uint4(s.x, s.y, off, s.w);
+                    } else r = make_uint4(out_size, 0, 0, b.lit_regen);
+                    S[i] = r;
                 }
-                if (lastchunk && tid == 0) { oe[ns] = b.out_size; mlv[ns] = 0; ofv[ns] = 0; le[ns] = b.lit_regen; }
+                mark[tid] = 0;
+                if (tid == 0) s_jn = 0;
                 if (__syncthreads_or(bad)) { err = ZK_E_CORRUPTION; break; }
-                const uint32_t nent = ns + (lastchunk ? 1u : 0u);
-                const uint32_t cend = lastchunk ? b.out_size : oe[ns - 1];
-                for (uint32_t ts = cpos; ts < cend; ts += ZK_EXEC_THREADS * ZK_EXEC_B) {
-                    const uint32_t q0 = ts + tid * ZK_EXEC_B;
-                    if (q0 < cend) {
-                        const uint32_t nb = cend - q0 < (uint32_t)ZK_EXEC_B ? cend - q0 : (uint32_t)ZK_EXEC_B;
-                        uint32_t j = zk_seq_find(oe, 0, nent, q0);
-                        uint8_t ob[ZK_EXEC_B];
+                const uint32_t cap_end = S[nl - 1].x;
+                const uint32_t te = ts + T * ZK_EXEC_B < cap_end ? ts + T * ZK_EXEC_B : cap_end;
+                // 2. bucket marks + number of sequences that end inside the tile
+                uint32_t done = 0;
+                for (uint32_t i = tid; i < nl; i += T) {
+                    const uint32_t e = S[i].x;
+                    uint32_t lo = i ? S[i - 1].x : ts;
+                    if (lo < ts) lo = ts;
+                    const uint32_t hi = e < te ? e : te;
+                    if (lo < hi) {
+                        const uint32_t b0 = (lo - ts + 15) >> 4;
+                        if (ts + (b0 << 4) < hi) mark[b0] = (uint16_t)i;
+                    }
+                    if (e <= te) done = i + 1;
+                }
+                if (done) atomicMax(&s_jn, done);
+                __syncthreads();
+                // 3. prefix max over the buckets
+                uint32_t m = mark[tid];
 #pragma unroll
-                        for (int k = 0; k < ZK_EXEC_B; k++) {
-                            ob[k] = 0;
-                            if ((uint32_t)k < nb) {
-                                const uint32_t q = q0 + k;
-                                while (oe[j] <= q) j++;
-                                uint64_t src = zk_resolve_byte(oe, mlv, ofv, le, j, q, (int32_t)ts);
-                                if (src & ZK_SRC_HIST) ob[k] = bout[(int64_t)(int32_t)((uint32_t)src - 0x40000000u)];
-                                else ob[k] = lit[(uint32_t)src * lit_stride];
+                for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(m, d, 64); if ((int)lane >= d && y > m) m = y; }
+                if (lane == 63) wmax[wave] = m;
+                __syncthreads();
+                for (uint32_t w = 0; w < wave; w++) { uint32_t y = wmax[w]; if (y > m) m = y; }
+                jstart[tid] = (uint16_t)m;
+                const uint32_t jn = s_jn;
+                __syncthreads();
+                // 4. resolve + gather + store
+                const uint32_t q0 = ts + tid * ZK_EXEC_B;
+                if (q0 < te) {
+                    const uint32_t nb = te - q0 < (uint32_t)ZK_EXEC_B ? te - q0 : (uint32_t)ZK_EXEC_B;
+                    ZkChase ch{S, jstart, ts};
+                    uint32_t j = m;
+                    uint4 s = S[j];
+                    int32_t ms = (int32_t)(s.x - s.y);
+                    const uint8_t *addr[ZK_EXEC_B];
+#pragma unroll
+                    for (int k = 0; k < ZK_EXEC_B; k++) {
+                        const uint32_t q = q0 + k;
+                        const uint8_t *a = bout;                   // harmless default for k >= nb
+                        if ((uint32_t)k < nb) {
+                            if (q >= s.x) { s = S[++j]; ms = (int32_t)(s.x - s.y); }
+                            if ((int32_t)q < ms) a = lit + (size_t)(s.w - (uint32_t)(ms - (int32_t)q)) * lit_stride;
+                            else {
+                                const int32_t off = (int32_t)s.z;
+                                int32_t p = (int32_t)q - off;
+                                if (p >= ms) p = ms - off + ((int32_t)q - ms) % off;
+                                a = p < (int32_t)ts ? bout + p : zk_chase(ch, p, lit, lit_stride, bout);
                             }
                         }
-                        uint8_t *w = bout + q0;
-                        if (nb == ZK_EXEC_B && (((uintptr_t)w) & 15) == 0) {
-                            uint4 v;
-                            v.x = ob[0] | (ob[1] << 8) | (ob[2] << 16) | ((uint32_t)ob[3] << 24);
-                            v.y = ob[4] | (ob[5] << 8) | (ob[6] << 16) | ((uint32_t)ob[7] << 24);
-                            v.z = ob[8] | (ob[9] << 8) | (ob[10] << 16) | ((uint32_t)ob[11] << 24);
-                            v.w = ob[12] | (ob[13] << 8) | (ob[14] << 16) | ((uint32_t)ob[15] << 24);
-                            *reinterpret_cast<uint4 *>(w) = v;
-                        } else {
-                            for (uint32_t k = 0; k < nb; k++) w[k] = ob[k];
-                        }
+                        addr[k] = a;
                     }
-                    __syncthreads();          // tile bytes visible to the next tile's history reads
+                    uint32_t ob[ZK_EXEC_B];
+#pragma unroll
+                    for (int k = 0; k < ZK_EXEC_B; k++) ob[k] = *addr[k];
+                    uint8_t *w = bout + q0;
+                    if (nb == ZK_EXEC_B && (((uintptr_t)w) & 15) == 0) {
+                        uint4 v;
+                        v.x = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+                        v.y = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+                        v.z = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+                        v.w = ob[12] | (ob[13] << 8) | (ob[14] << 16) | (ob[15] << 24);
+                        *reinterpret_cast<uint4 *>(w) = v;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < ZK_EXEC_B; k++) if ((uint32_t)k < nb) w[k] = (uint8_t)ob[k];
+                    }
                 }
-                __syncthreads();              // LDS chunk arrays are reused
-                cpos = cend; s0 += ns;
-                if (lastchunk) break;
+                __syncthreads();              // tile bytes visible to the next tile; LDS reuse
+                ja += jn; ts = te;
             }
             if (err == ZK_OK) {
                 uint32_t r0 = zk_rep_resolve(b.rep_out[0], rep), r1 = zk_rep_resolve(b.rep_out[1], rep), r2 = zk_rep_resolve(b.rep_out[2], rep);
@@ -258,32 +336,48 @@ __global__ __launch_bounds__(ZK_EXEC_THREADS) void zk_k_exec(const uint8_t *comp
 }
 
 // ------------------------------------------------------------------------------------------------ XXH64
-// 4 lanes per frame = the four XXH64 accumulators (each consumes 8 of every 32 bytes, in order);
-// 16 frames per wave.  mode: hashes != nullptr -> store the 64-bit hash; infos != nullptr -> verify checksum.
+// hashes != nullptr -> store the 64-bit hash; infos != nullptr -> verify Content_Checksum.
 __device__ __forceinline__ uint64_t zk_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 constexpr uint64_t XP1 = 0x9E3779B185EBCA87ull, XP2 = 0xC2B2AE3D27D4EB4Full, XP3 = 0x165667B19E3779F9ull,
                    XP4 = 0x85EBCA77C2B2AE63ull, XP5 = 0x27D4EB2F165667C5ull;
 __device__ __forceinline__ uint64_t zk_xround(uint64_t acc, uint64_t x) { return zk_rotl64(acc + x * XP2, 31) * XP1; }
-__device__ __forceinline__ uint64_t zk_ld64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
 
+// One wave per frame.  All 64 lanes stream the frame in 1 KiB chunks (coalesced 16 B loads, one chunk
+// in flight ahead) and pre-multiply every word by P2; the products go through LDS to lanes 0-3, which
+// run the four serial accumulator chains acc = rotl(acc + x*P2, 31) * P1.
 __global__ __launch_bounds__(64) void zk_k_xxh64(const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
                                                  ZkFrameInfo *infos, uint64_t *hashes)
 {
-    const uint32_t lane = threadIdx.x, k = lane & 3;
-    const uint32_t f = blockIdx.x * 16 + (lane >> 2);
-    bool active = f < count;
-    if (active && infos) active = infos[f].status == ZK_OK && infos[f].checksum_flag;
-    const uint8_t *p = data;
-    uint64_t len = 0;
-    if (active) { p = data + (d_off[first + f] - d_off[first]); len = d_off[first + f + 1] - d_off[first + f]; }
-    const uint64_t nstripes = len >> 5;
-    uint64_t acc = k == 0 ? XP1 + XP2 : k == 1 ? XP2 : k == 2 ? 0 : 0 - XP1;
-    const uint8_t *q = p + 8 * k;
+    __shared__ uint64_t prod[128];
+    const uint32_t lane = threadIdx.x, f = blockIdx.x;
+    if (infos && !(infos[f].status == ZK_OK && infos[f].checksum_flag)) return;
+    const uint8_t *p = data + (d_off[first + f] - d_off[first]);
+    const uint64_t len = d_off[first + f + 1] - d_off[first + f];
+    const uint64_t nchunks = len >> 10;
+    uint64_t acc = lane == 0 ? XP1 + XP2 : lane == 1 ? XP2 : lane == 2 ? 0 : 0 - XP1;
+    const bool aligned = (((uintptr_t)p) & 15) == 0;
+    uint64_t a = 0, b = 0;
+    auto ldpair = [&](uint64_t c) {
+        const uint8_t *q = p + (c << 10) + lane * 16;
+        if (aligned) { uint4 v = *reinterpret_cast<const uint4 *>(q); a = v.x | ((uint64_t)v.y << 32); b = v.z | ((uint64_t)v.w << 32); }
+        else { a = zk_ld64(q); b = zk_ld64(q + 8); }
+    };
+    if (nchunks) ldpair(0);
+    for (uint64_t c = 0; c < nchunks; c++) {
+        prod[2 * lane] = a * XP2; prod[2 * lane + 1] = b * XP2;
+        if (c + 1 < nchunks) ldpair(c + 1);
+        __syncthreads();
+        if (lane < 4) {
 #pragma unroll 8
-    for (uint64_t i = 0; i < nstripes; i++) acc = zk_xround(acc, zk_ld64(q + (i << 5)));
-    const int g = (int)(lane & ~3u);
-    uint64_t v1 = __shfl(acc, g, 64), v2 = __shfl(acc, g + 1, 64), v3 = __shfl(acc, g + 2, 64), v4 = __shfl(acc, g + 3, 64);
-    if (!active || k != 0) return;
+            for (int r = 0; r < 32; r++) acc = zk_rotl64(acc + prod[4 * r + lane], 31) * XP1;
+        }
+        __syncthreads();
+    }
+    // remaining whole stripes (< 32 of them), straight from memory
+    const uint64_t nstripes = len >> 5;
+    if (lane < 4) for (uint64_t i = nchunks << 5; i < nstripes; i++) acc = zk_xround(acc, zk_ld64(p + (i << 5) + 8 * lane));
+    uint64_t v1 = __shfl(acc, 0, 64), v2 = __shfl(acc, 1, 64), v3 = __shfl(acc, 2, 64), v4 = __shfl(acc, 3, 64);
+    if (lane != 0) return;
     uint64_t h;
     if (len >= 32) {
         h = zk_rotl64(v1, 1) + zk_rotl64(v2, 7) + zk_rotl64(v3, 12) + zk_rotl64(v4, 18);
@@ -334,16 +428,18 @@ void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
 void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
 {
     if (!nblocks) return;
-    hipLaunchKernelGGL(zk_k_fse, dim3((nblocks + ZK_FSE_BLOCKS - 1) / ZK_FSE_BLOCKS), dim3(64), 0, st, comp, blocks, nblocks, seqs);
+    hipLaunchKernelGGL(zk_k_fse, dim3((nblocks + ZK_FSE_BLOCKS - 1) / ZK_FSE_BLOCKS), dim3(64 * ZK_FSE_WAVES), 0, st, comp, blocks, nblocks, seqs);
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
                     const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeq *seqs,
                     const uint8_t *lit, uint8_t *dst)
 {
-    hipLaunchKernelGGL(zk_k_exec, dim3(count), dim3(ZK_EXEC_THREADS), 0, st, comp, d_off, first, blocks, bases, infos, seqs, lit, dst);
+    // few frames: big tiles (more bytes in flight per frame); many frames: 4-wave workgroups, 8 per CU
+    if (count >= 1024) hipLaunchKernelGGL(zk_k_exec<256>, dim3(count), dim3(256), 0, st, comp, d_off, first, blocks, bases, infos, seqs, lit, dst);
+    else hipLaunchKernelGGL(zk_k_exec<1024>, dim3(count), dim3(1024), 0, st, comp, d_off, first, blocks, bases, infos, seqs, lit, dst);
 }
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
                      ZkFrameInfo *infos, uint64_t *hashes)
 {
-    hipLaunchKernelGGL(zk_k_xxh64, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
+    hipLaunchKernelGGL(zk_k_xxh64, dim3(count), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
 }

@@ -347,16 +347,33 @@ ZK_HD uint32_t zk_huf_build(const uint8_t *src, uint32_t len, uint16_t *table, Z
 }
 
 // Decode n symbols of one Huffman stream into dst.  Returns false on corruption.
+// Eight symbols are packed into one 64-bit store (two refills of <= 4 x 11 bits).
 ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const uint8_t *src, uint32_t len,
                                 uint8_t *dst, uint32_t n)
 {
     ZkBwd b;
     if (!zk_bwd_init(b, src, len)) return false;
     uint32_t i = 0;
+    while (i + 8 <= n) {
+        uint64_t pack = 0;
+        zk_bwd_refill(b);
+        for (uint32_t k = 0; k < 4; k++) {
+            uint32_t c = table[zk_bwd_peek(b, maxbits)];
+            pack |= (uint64_t)(c & 0xff) << (8 * k);
+            zk_bwd_skip(b, c >> 8);
+        }
+        zk_bwd_refill(b);
+        for (uint32_t k = 4; k < 8; k++) {
+            uint32_t c = table[zk_bwd_peek(b, maxbits)];
+            pack |= (uint64_t)(c & 0xff) << (8 * k);
+            zk_bwd_skip(b, c >> 8);
+        }
+        memcpy(dst + i, &pack, 8);
+        i += 8;
+    }
     while (i < n) {
         zk_bwd_refill(b);
-        // 64 bits are enough for 5 symbols of <= 11 bits
-        uint32_t lim = n - i < 5 ? n - i : 5;
+        uint32_t lim = n - i < 4 ? n - i : 4;
         for (uint32_t k = 0; k < lim; k++) {
             uint32_t c = table[zk_bwd_peek(b, maxbits)];
             dst[i + k] = (uint8_t)c;
@@ -530,8 +547,10 @@ struct ZkSeqTables {                 // LDS-resident, per lane
     uint32_t ll[512];
     uint32_t ml[512];
     uint32_t of[256];
-    int16_t norm[64];
-    uint16_t next[64];
+    union {                          // table-build scratch, later the output ring (16 x ZkSeq = 256 B)
+        struct { int16_t norm[64]; uint16_t next[64]; };
+        ZkSeq ring[16];
+    };
 };
 
 // Locate + build table t of block `def` (the block whose header defines the table in force).
@@ -588,6 +607,24 @@ ZK_HD int32_t zk_seq_table_setup(const uint8_t *comp, const ZkBlock &def, int t,
     return -1;   // a defining block never has Repeat_Mode for this table
 }
 
+// Reverse bit window for the sequence bitstream: W holds stream bits [wpos, wpos+64); pos = unread bits.
+// The window for bit position pos starts at byte max(0, (pos-57)>>3), so it always offers >= 57 bits
+// below pos (or everything that is left).  The 8-byte load may touch up to 7 bytes past a stream that
+// is shorter than 8 bytes: compressed buffers carry ZK_COMP_PADDING readable bytes at the end.
+constexpr uint32_t ZK_COMP_PADDING = 8;
+struct ZkRev { const uint8_t *base; uint64_t W; int32_t pos, wpos; };
+ZK_HD uint64_t zk_ld64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+ZK_HD int32_t zk_rev_byte(int32_t pos) { int32_t b = (pos - 57) >> 3; return b < 0 ? 0 : b; }
+ZK_HD void zk_rev_load(ZkRev &r) { int32_t bo = zk_rev_byte(r.pos); r.W = zk_ld64(r.base + bo); r.wpos = bo * 8; }
+ZK_HD uint32_t zk_rev_bits(const ZkRev &r, int32_t at, uint32_t n) { return (uint32_t)(r.W >> ((at - r.wpos) & 63)) & ((1u << n) - 1u); }   // n <= 31
+ZK_HD uint32_t zk_rev_read_slow(ZkRev &r, uint32_t n)          // any n <= 31, reloads the window first
+{
+    zk_rev_load(r);
+    r.pos -= (int32_t)n;
+    if (r.pos < 0) return 0;                                    // over-read; caller checks pos
+    return zk_rev_bits(r, r.pos, n);
+}
+
 // Decode all sequences of block b into seqs[]; fills b.out_size / b.rep_out / b.status.
 ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlock &b, ZkSeqTables *T, ZkSeq *seqs,
                                const uint32_t *ll_values, const uint32_t *ml_values)
@@ -603,49 +640,76 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
     }
     uint32_t bs_off = b.seq_off + 1 + own;
     if (bs_off >= b.bsize) { b.status = ZK_E_CORRUPTION; return; }
-    ZkBwd r;
-    if (!zk_bwd_init(r, comp + b.src + bs_off, b.bsize - bs_off)) { b.status = ZK_E_CORRUPTION; return; }
-    zk_bwd_refill(r);
-    uint32_t sl = zk_bwd_read(r, al[0]), so = zk_bwd_read(r, al[1]), sm = zk_bwd_read(r, al[2]);
+    const uint32_t blen = b.bsize - bs_off;
+    ZkRev r;
+    r.base = comp + b.src + bs_off;
+    {
+        uint32_t last = r.base[blen - 1];
+        if (last == 0) { b.status = ZK_E_CORRUPTION; return; }
+        r.pos = (int32_t)((blen - 1) * 8 + zk_highbit(last));
+    }
+    uint32_t sl = zk_rev_read_slow(r, al[0]), so = zk_rev_read_slow(r, al[1]), sm = zk_rev_read_slow(r, al[2]);
+    zk_rev_load(r);
     uint32_t rep0 = zk_rep_sym(0), rep1 = zk_rep_sym(1), rep2 = zk_rep_sym(2);
     uint32_t out = 0, lit = 0;
     const uint32_t nseq = b.nseq;
-    bool bad = false;
+    uint32_t bad = r.pos < 0;
+    // The loop body is branch-free apart from the (rare) wide-sequence path and the ring flush: errors
+    // only accumulate into `bad`; a corrupt stream keeps walking harmlessly (states stay inside their
+    // tables, window addresses are clamped) and is rejected after the loop.
     for (uint32_t i = 0; i < nseq; i++) {
-        uint32_t cl = T->ll[sl], co = T->of[so], cm = T->ml[sm];
-        zk_bwd_refill(r);
-        uint32_t ofc = zk_cell_sym(co);
-        if (ofc > 30) { bad = true; break; }
-        uint32_t ofv = (1u << ofc) + zk_bwd_read(r, ofc);
-        uint32_t mlv = ml_values[zk_cell_sym(cm)], llv = ll_values[zk_cell_sym(cl)];
-        uint32_t ml = (mlv & 0xFFFFFFu) + zk_bwd_read(r, zk_cell_xbits(cm));
-        uint32_t ll = (llv & 0xFFFFFFu) + zk_bwd_read(r, zk_cell_xbits(cl));
-        uint32_t off;
-        if (ofv > 3) { off = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
-        else {
-            uint32_t idx = ofv - 1 + (ll == 0);
-            if (idx == 0) off = rep0;
-            else {
-                if (idx == 3) {
-                    // rep0 - 1: concrete -> must stay >= 1; symbolic -> one more subtracted
-                    if (zk_rep_is_sym(rep0)) off = rep0 + 1; else { off = rep0 - 1; if (off == 0) { bad = true; break; } }
-                } else off = idx == 1 ? rep1 : rep2;
-                if (idx > 1) rep2 = rep1;
-                rep1 = rep0; rep0 = off;
-            }
+        const uint32_t cl = T->ll[sl], co = T->of[so], cm = T->ml[sm];
+        const uint32_t nOf = zk_cell_sym(co), nMl = zk_cell_xbits(cm), nLl = zk_cell_xbits(cl);
+        const bool more = i + 1 < nseq;
+        const uint32_t nbl = more ? zk_cell_nb(cl) : 0, nbm = more ? zk_cell_nb(cm) : 0, nbo = more ? zk_cell_nb(co) : 0;
+        bad |= nOf > 30;
+        const int32_t npos = r.pos - (int32_t)(nOf + nMl + nLl + nbl + nbm + nbo);
+        // window of the NEXT sequence: its address only needs the bit counts, so the load is in
+        // flight while this sequence's fields are extracted
+        const int32_t nbyte = zk_rev_byte(npos);
+        const uint64_t Wn = zk_ld64(r.base + nbyte);
+        uint32_t ofx, mlx, llx;
+        if (npos >= r.wpos) {                           // every field lies inside the current window
+            uint64_t X = r.W << ((64 - (r.pos - r.wpos)) & 63);          // left-align the unread bits
+            ofx = nOf ? (uint32_t)(X >> 32) >> (32 - nOf) : 0; X <<= nOf;
+            mlx = nMl ? (uint32_t)(X >> 32) >> (32 - nMl) : 0; X <<= nMl;
+            llx = nLl ? (uint32_t)(X >> 32) >> (32 - nLl) : 0; X <<= nLl;
+            sl = zk_cell_base(cl) + (nbl ? (uint32_t)(X >> 32) >> (32 - nbl) : 0); X <<= nbl;
+            sm = zk_cell_base(cm) + (nbm ? (uint32_t)(X >> 32) >> (32 - nbm) : 0); X <<= nbm;
+            so = zk_cell_base(co) + (nbo ? (uint32_t)(X >> 32) >> (32 - nbo) : 0);
+        } else {                                        // > 57 bits in one sequence (or over-read): field by field
+            ofx = zk_rev_read_slow(r, nOf & 31); mlx = zk_rev_read_slow(r, nMl); llx = zk_rev_read_slow(r, nLl);
+            sl = zk_cell_base(cl) + zk_rev_read_slow(r, nbl);
+            sm = zk_cell_base(cm) + zk_rev_read_slow(r, nbm);
+            so = zk_cell_base(co) + zk_rev_read_slow(r, nbo);
         }
-        if (i + 1 < nseq) {
-            if (r.cnt < 26) zk_bwd_refill(r);
-            sl = zk_cell_base(cl) + zk_bwd_read(r, zk_cell_nb(cl));
-            sm = zk_cell_base(cm) + zk_bwd_read(r, zk_cell_nb(cm));
-            so = zk_cell_base(co) + zk_bwd_read(r, zk_cell_nb(co));
-        }
+        bad |= npos < 0;
+        r.pos = npos; r.W = Wn; r.wpos = nbyte * 8;
+        const uint32_t ofv = (1u << (nOf & 31)) + ofx;
+        const uint32_t ml = (ml_values[zk_cell_sym(cm)] & 0xFFFFFFu) + mlx;
+        const uint32_t ll = (ll_values[zk_cell_sym(cl)] & 0xFFFFFFu) + llx;
+        // offset + repeat history, select form (A.8)
+        const bool is_rep = ofv <= 3;
+        const uint32_t idx = ofv - 1 + (ll == 0);                    // 0..3 when is_rep
+        const uint32_t r0m1 = zk_rep_is_sym(rep0) ? rep0 + 1 : rep0 - 1;   // "rep0 - 1" (symbolic: one more subtracted)
+        const uint32_t cand = idx == 0 ? rep0 : idx == 1 ? rep1 : idx == 2 ? rep2 : r0m1;
+        const uint32_t off = is_rep ? cand : ofv - 3;
+        bad |= off == 0;                                             // concrete rep0 - 1 == 0
+        const bool sh1 = !is_rep || idx >= 1, sh2 = !is_rep || idx >= 2;
+        rep2 = sh2 ? rep1 : rep2;
+        rep1 = sh1 ? rep0 : rep1;
+        rep0 = off;
         lit += ll; out += ll + ml;
-        if (r.bits_left < 0 || lit > b.lit_regen || out > ZK_BLOCK_MAX) { bad = true; break; }
+        bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX);
+        // Records are parked in LDS and written out 16 at a time (few, wide store bursts).
         ZkSeq s; s.out_end = out; s.ml = ml; s.off = off; s.lit_end = lit;
-        seqs[i] = s;
+        T->ring[i & 15] = s;
+        if ((i & 15) == 15) {
+            for (uint32_t k = 0; k < 16; k++) seqs[i - 15 + k] = T->ring[k];
+        }
     }
-    if (bad || r.bits_left != 0) { b.status = ZK_E_CORRUPTION; return; }
+    if (bad || r.pos != 0) { b.status = ZK_E_CORRUPTION; return; }
+    for (uint32_t k = nseq & ~15u; k < nseq; k++) seqs[k] = T->ring[k & 15];
     out += b.lit_regen - lit;
     if (out > ZK_BLOCK_MAX) { b.status = ZK_E_CORRUPTION; return; }
     b.out_size = out;
