@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path of BASELINE.json on MI355X: seekable-zstd frame decode (GiB/s of decompressed data).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2]
+
+A step = one pass of the decode hot path over one batch of synthetic frames that are already resident in
+HBM (compressed payload + seek-table offsets in, decompressed bytes out, Content_Checksums verified).
+Workloads (BASELINE.json configs, generator of SURVEY.md 8d):
+  c3 (default)  configs[2]: 4 GiB per GPU = 2048 frames x 2 MiB, level 1, XXH64 checksums on  -- the
+                configuration the north-star target is quoted on; weak scaling: every rank owns its own
+                2048 frames (configs[4] = 8 x this, frames sharded across ranks, no data-path collective)
+  c2            configs[1]: 256 MiB = 128 frames x 2 MiB, level 1, decode-only
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL for the barrier /
+max-over-ranks only).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FRAME = 2 << 20
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def _make_part(job):
+    """Worker (forked, CPU only): generate chunks [k0, k0+n) and compress them with the reference loop."""
+    k0, n, level, cks = job
+    from oracle import zko, libzstd_ref as Z
+    data = zko.gen_chunks(n * FRAME, k0)
+    which = "system" if Z.load("system") is not None else None
+    if which is None:
+        raise RuntimeError("no libzstd on this box to prepare the archive")
+    comp, frames = Z.encode_seekable_frames(data, FRAME, level, cks, which)
+    hashes = [zko.xxh64(data[i * FRAME:(i + 1) * FRAME]) for i in range(n)]
+    return comp, frames, hashes
+
+
+def build_archive(k0, nframes, level, cks, workers):
+    per = max(1, min(16, nframes // max(1, workers)))
+    jobs = [(k0 + i, min(per, nframes - i), level, cks) for i in range(0, nframes, per)]
+    with mp.get_context("fork").Pool(workers) as pool:
+        parts = pool.map(_make_part, jobs)
+    comp = b"".join(p[0] for p in parts)
+    frames = [f for p in parts for f in p[1]]
+    hashes = [h for p in parts for h in p[2]]
+    return comp, frames, hashes
+
+
+def cpu_baseline(comp, frames, sample_frames, target_seconds=10.0):
+    """Reference CPU path (C restatement of zeekstd::Decoder's loop over the box's libzstd), 1 thread."""
+    from oracle import zko, libzstd_ref as Z
+    lib = zko.lib()
+    path = next((p for p in Z._CANDIDATES["system"] if os.path.exists(p)), None)
+    if path is None or lib.zkb_open(path.encode()) != 0:
+        return None
+    lib.zkb_version.restype = C.c_char_p
+    lib.zkb_time_decode.restype = C.c_double
+    lib.zkb_time_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+    n = min(sample_frames, len(frames))
+    csz = sum(f[0] for f in frames[:n])
+    dsz = sum(f[1] for f in frames[:n])
+    sink = C.c_uint64(0)
+    t1 = lib.zkb_time_decode(comp[:csz], csz, dsz, 1, C.byref(sink))
+    if t1 <= 0:
+        return None
+    reps = max(1, min(20, int(target_seconds / t1) - 1))
+    best = min(t1, lib.zkb_time_decode(comp[:csz], csz, dsz, reps, C.byref(sink)))
+    return {"value": dsz / best / 2**30, "unit": "GiB/s", "cores": 1, "kind": "port",
+            "sample": f"zeekstd::Decoder loop (decode.rs:201-270, bench protocol decompress.rs:18-39) in C over dlopen'd "
+                      f"libzstd {lib.zkb_version().decode()}, first {n} frames ({dsz >> 20} MiB) of the same archive, "
+                      f"best of {reps + 1} passes, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2"])
+    ap.add_argument("--frames", type=int, default=0, help="override frames per GPU (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    nframes = args.frames or (2048 if args.workload == "c3" else 128)
+    cks = args.workload == "c3"
+    level = 1
+
+    # ---- untimed setup on the host cores (before any HIP initialisation: workers are forked)
+    cores = os.cpu_count() or 8
+    workers = max(1, min(64, cores // max(1, world) - 1))
+    t0 = time.time()
+    comp, frames, hashes = build_archive(rank * nframes, nframes, level, cks, workers)
+    t_setup = time.time() - t0
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base = cpu_baseline(comp, frames, 512 if args.workload == "c3" else 128)
+
+    import torch
+    import torch.distributed as dist
+    import zeekstd_amd as zk
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    eng = zk.Engine(local_rank)
+
+    c = np.zeros(nframes + 1, np.uint64)
+    d = np.zeros(nframes + 1, np.uint64)
+    c[1:] = np.cumsum([f[0] for f in frames])
+    d[1:] = np.cumsum([f[1] for f in frames])
+    csize, dsize = int(c[-1]), int(d[-1])
+    d_comp = torch.from_numpy(np.frombuffer(comp + b"\0" * 64, np.uint8).copy()).to(dev)
+    d_c = torch.from_numpy(c.view(np.int64)).to(dev)
+    d_d = torch.from_numpy(d.view(np.int64)).to(dev)
+    d_out = torch.empty(dsize + 64, dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(nframes, dtype=torch.int32, device=dev)
+    d_hash = torch.zeros(nframes, dtype=torch.int64, device=dev)
+
+    def step():
+        rc = eng.decode_frames_dev(d_comp, csize, d_c, d_d, 0, nframes, d_out, dsize, True, d_st)
+        if rc != 0:
+            raise RuntimeError(f"decode failed: {zk.error_name(rc)}")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    # parity gate before anything is timed: every frame's XXH64 equals the generator's
+    eng.xxh64_frames_dev(d_out, d_d, nframes, d_hash)
+    got = d_hash.cpu().numpy().view(np.uint64)
+    if not np.array_equal(got, np.array(hashes, dtype=np.uint64)) or int(d_st.abs().sum().item()) != 0:
+        raise RuntimeError("GPU decode is not bit-exact against the generator bytes")
+
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_bytes = dsize * world * args.steps
+    value = total_bytes / elapsed / 2**30
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, live
+    eng.set_profiling(True)
+    acc = {}
+    nprof = 3
+    for _ in range(nprof):
+        step()
+        for k, ms in eng.kernel_times().items():
+            acc[k] = acc.get(k, 0.0) + ms / nprof
+    eng.set_profiling(False)
+    dom = max(acc, key=acc.get)
+    algo_bytes = csize + dsize                    # decode = c_i + d_i per frame, summed over the launch
+    achieved = algo_bytes / (acc[dom] * 1e-3) / 1e9
+
+    if rank == 0:
+        line = {
+            "metric": "decode_decompressed_GiB_per_s", "value": round(value, 3), "unit": "GiB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": ("configs[2]: 4 GiB/GPU, 2048 x 2 MiB frames, level 1, XXH64 checksums verified"
+                                    if args.workload == "c3" else "configs[1]: 256 MiB, 128 x 2 MiB frames, level 1, decode-only"),
+                       "frames_per_gpu": nframes, "frame_size": FRAME, "compressed_bytes_per_gpu": csize,
+                       "archive": "CPU libzstd (reference Encoder loop), inputs from the SURVEY 8d generator",
+                       "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",
+                       "bit_exact": True},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": {k: round(v, 3) for k, v in acc.items()}},
+            "cpu_baseline": base,
+            "setup_s": round(t_setup, 1),
+        }
+        if base:
+            line["speedup_vs_cpu_1thread"] = round(value / base["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

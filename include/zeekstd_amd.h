@@ -67,6 +67,14 @@ const char *zk_engine_last_hip_error(const zk_engine *e);
 /* name of the device the engine runs on, e.g. "gfx950..." */
 const char *zk_engine_device_name(const zk_engine *e);
 
+/* Per-kernel timing for roofline reports: when on, every kernel launch of the next decode/encode call is
+ * bracketed by HIP events on the launch stream; zk_engine_kernel_times returns the last call's
+ * durations in ms, indexed like zk_engine_kernel_name (0 <= k < zk_engine_kernel_count()). */
+int zk_engine_set_profiling(zk_engine *e, int on);
+int zk_engine_kernel_count(void);
+const char *zk_engine_kernel_name(int k);
+int zk_engine_kernel_times(const zk_engine *e, float *ms_out, int n);
+
 /*
  * Decode frames [first, first+count) of a seekable payload.
  *   comp      compressed payload; frame i occupies comp[c_off[i], c_off[i+1])
@@ -84,6 +92,7 @@ int zk_decode_frames(zk_engine *e, const uint8_t *comp, uint64_t comp_size, cons
                      int verify, int32_t *frame_status);
 /* Same with every buffer resident in HBM (c_off/d_off/frame_status are device pointers too).
  * stream: hipStream_t (NULL = the engine's own stream).  Synchronises the stream before returning. */
+#define ZK_COMP_PADDING 8 /* device-resident compressed buffers must be readable this many bytes past comp_size */
 int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off,
                          const void *d_d_off, uint32_t first, uint32_t count, void *d_dst, uint64_t dst_cap,
                          int verify, void *d_frame_status, void *stream);

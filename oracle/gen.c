@@ -72,3 +72,12 @@ void zko_gen_chunks(uint8_t *dst, size_t total, uint64_t k0)
         zko_gen_text(dst + off, n, 0x5EED0002ULL + k0 + k);
     }
 }
+
+/* incompressible bytes: xorshift64* stream (same PRNG as the text generator) */
+void zko_gen_random(uint8_t *dst, size_t n, uint64_t seed)
+{
+    uint64_t s = seed_state(seed);
+    size_t i = 0;
+    while (i + 8 <= n) { uint64_t v = next(&s); memcpy(dst + i, &v, 8); i += 8; }
+    if (i < n) { uint64_t v = next(&s); memcpy(dst + i, &v, n - i); }
+}

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-_SRCS = ("zstd_oracle.c", "zstd_oracle_enc.c", "gen.c")
+_SRCS = ("zstd_oracle.c", "zstd_oracle_enc.c", "gen.c", "cpu_baseline.c")
 
 
 class FrameStats(C.Structure):
@@ -45,6 +45,8 @@ def lib():
         l.zko_gen_text.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
         l.zko_gen_chunks.restype = None
         l.zko_gen_chunks.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+        l.zko_gen_random.restype = None
+        l.zko_gen_random.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
         l.zko_gen_vocab.restype = C.c_void_p
         l.zko_gen_vocab.argtypes = [C.c_int, C.POINTER(C.c_int)]
         if hasattr(l, "zko_frame_encode"):
@@ -69,6 +71,51 @@ def gen_chunks(total: int, k0: int = 0) -> bytes:
     buf = C.create_string_buffer(max(total, 1))
     lib().zko_gen_chunks(buf, total, k0)
     return buf.raw[:total]
+
+
+def gen_random(n: int, seed: int) -> bytes:
+    buf = C.create_string_buffer(max(n, 1))
+    lib().zko_gen_random(buf, n, seed)
+    return buf.raw[:n]
+
+
+def make_input(recipe) -> bytes:
+    """Deterministic test inputs named by a small recipe (list of parts), shared by the golden
+    fixtures (tests/golden/archives.json) and the GPU tests:
+      ["text", n, seed] | ["zeros", n] | ["random", n, seed] | ["rep", hexpattern, count] | ["chunks", n, k0]
+      ["records", count, seed, hexconst]            count x (4 random bytes + const)
+      ["slices", src_len, src_seed, count, seed, minlen, maxlen, hexsep]
+                                                    text source, then count x (random slice of it + separator)"""
+    import struct
+    out = bytearray()
+    for part in recipe:
+        kind = part[0]
+        if kind == "text":
+            out += gen_text(part[1], part[2])
+        elif kind == "chunks":
+            out += gen_chunks(part[1], part[2])
+        elif kind == "zeros":
+            out += bytes(part[1])
+        elif kind == "random":
+            out += gen_random(part[1], part[2])
+        elif kind == "rep":
+            out += bytes.fromhex(part[1]) * part[2]
+        elif kind == "records":
+            rnd, const = gen_random(4 * part[1], part[2]), bytes.fromhex(part[3])
+            for i in range(part[1]):
+                out += rnd[4 * i:4 * i + 4] + const
+        elif kind == "slices":
+            _, n_src, s_src, count, seed, lo, hi, sep = part
+            src, sepb = gen_text(n_src, s_src), bytes.fromhex(sep)
+            r = struct.unpack(f"<{2 * count}I", gen_random(8 * count, seed))
+            out += src
+            for i in range(count):
+                o = r[2 * i] % (n_src - hi)
+                l = lo + r[2 * i + 1] % (hi - lo)
+                out += src[o:o + l] + sepb
+        else:
+            raise ValueError(kind)
+    return bytes(out)
 
 
 def gen_vocab(i: int) -> bytes:

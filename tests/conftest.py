@@ -1,0 +1,121 @@
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_present():
+    return os.path.exists("/dev/kfd")
+
+
+def pytest_collection_modifyitems(config, items):
+    if _gpu_present():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+# ---------------------------------------------------------------- golden fixtures
+class Golden:
+    def __init__(self, meta, blob):
+        self.meta = meta
+        self.name = meta["name"]
+        self.comp = blob[meta["offset"]:meta["offset"] + meta["length"]]
+        self.frames = [tuple(f) for f in meta["frames"]]
+
+    def input(self):
+        from oracle import zko
+        data = zko.make_input(self.meta["recipe"])
+        assert len(data) == self.meta["input_len"]
+        assert f"{zko.xxh64(data):016x}" == self.meta["input_xxh64"], "input generator drifted"
+        return data
+
+    def offsets(self):
+        c = np.zeros(len(self.frames) + 1, np.uint64)
+        d = np.zeros(len(self.frames) + 1, np.uint64)
+        c[1:] = np.cumsum([f[0] for f in self.frames])
+        d[1:] = np.cumsum([f[1] for f in self.frames])
+        return c, d
+
+
+def load_goldens():
+    gdir = os.path.join(ROOT, "tests", "golden")
+    with open(os.path.join(gdir, "archives.json")) as f:
+        idx = json.load(f)
+    with open(os.path.join(gdir, "archives.bin"), "rb") as f:
+        blob = f.read()
+    return [Golden(m, blob) for m in idx["cases"]]
+
+
+GOLDENS = load_goldens()
+
+
+@pytest.fixture(params=GOLDENS, ids=[g.name for g in GOLDENS])
+def golden(request):
+    return request.param
+
+
+def offsets_from_frames(frames):
+    c = np.zeros(len(frames) + 1, np.uint64)
+    d = np.zeros(len(frames) + 1, np.uint64)
+    c[1:] = np.cumsum([f[0] for f in frames])
+    d[1:] = np.cumsum([f[1] for f in frames])
+    return c, d
+
+
+# ---------------------------------------------------------------- CPU simulation of the device lane code
+_SIM = None
+
+
+def sim_lib():
+    """tests/sim/zk_sim.cpp compiled with g++: the kernels' per-lane code run on the CPU."""
+    global _SIM
+    if _SIM is None:
+        src = os.path.join(ROOT, "tests", "sim", "zk_sim.cpp")
+        so = os.path.join(ROOT, "tests", "sim", "libzk_sim.so")
+        hdr = os.path.join(ROOT, "zeekstd_amd", "csrc", "zk_device.h")
+        if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
+        l = C.CDLL(so)
+        l.zk_sim_decode.restype = C.c_int
+        l.zk_sim_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_int]
+        _SIM = l
+    return _SIM
+
+
+def sim_decode(comp, frames, first=0, count=None, B=16, CH=1024):
+    c, d = offsets_from_frames(frames)
+    n = len(frames)
+    if count is None:
+        count = n - first
+    out_len = int(d[first + count] - d[first])
+    out = np.zeros(out_len + 1, np.uint8)
+    st = np.zeros(max(count, 1), np.int32)
+    buf = np.frombuffer(bytes(comp) + b"\0" * 8, np.uint8)
+    rc = sim_lib().zk_sim_decode(buf.ctypes.data, c.ctypes.data, d.ctypes.data, first, count, out.ctypes.data,
+                                 st.ctypes.data, B, CH)
+    return rc, out[:out_len].tobytes(), st[:count]
+
+
+# ---------------------------------------------------------------- GPU engine
+@pytest.fixture(scope="session")
+def engine():
+    import zeekstd_amd as zk
+    e = zk.Engine(0)
+    yield e
+    e.close()

@@ -1,0 +1,130 @@
+"""Parity of the HIP decode path (through the C ABI of include/zeekstd_amd.h) against the golden
+libzstd-1.5.7 archives, the CPU oracle and -- at larger sizes -- archives made by the system libzstd
+with the reference's Encoder loop.  Mirrors the scenarios of the reference's own decode tests
+(lib/src/decode.rs:664-771: full decode, frame ranges; lib/src/lib.rs:82-134 round trips)."""
+import numpy as np
+import pytest
+
+from conftest import GOLDENS, offsets_from_frames
+from oracle import zko
+from oracle import libzstd_ref as Z
+
+pytestmark = pytest.mark.gpu
+
+
+def test_engine_reports_gfx950(engine):
+    assert "gfx950" in engine.device_name
+
+
+def test_goldens_bit_exact(engine, golden):
+    data = golden.input()
+    c, d = golden.offsets()
+    out, st = engine.decode_frames(golden.comp + b"\0" * 8, c, d, verify=True)
+    assert not st.any()
+    assert out == data
+
+
+def test_goldens_match_oracle_per_frame(engine):
+    g = next(x for x in GOLDENS if x.name == "text_100B_frames")
+    c, d = g.offsets()
+    out, _ = engine.decode_frames(g.comp + b"\0" * 8, c, d)
+    pos = 0
+    for i, (cs, ds) in enumerate(g.frames):
+        ref, _ = zko.frame_decode(g.comp[pos:pos + cs], ds, True)
+        assert out[int(d[i]):int(d[i + 1])] == ref
+        pos += cs
+
+
+@pytest.mark.parametrize("first,count", [(0, 1), (3, 1), (7, 20), (59, 1), (0, 60), (30, 0)])
+def test_frame_ranges(engine, first, count):
+    # decode.rs:685-730: lower_frame / upper_frame ranges
+    g = next(x for x in GOLDENS if x.name == "text_100B_frames")
+    data = g.input()
+    c, d = g.offsets()
+    out, st = engine.decode_frames(g.comp + b"\0" * 8, c, d, first=first, count=count)
+    assert out == data[int(d[first]):int(d[first + count])]
+
+
+def test_xxh64_kernel(engine):
+    datas = [b"", b"a", b"Hello, World!", bytes(range(256)), zko.gen_text(100000, 7), zko.gen_random(31, 1),
+             zko.gen_random(32, 2), zko.gen_random(33, 3), zko.gen_random(1023, 4), zko.gen_random(1024, 5),
+             zko.gen_random(1025, 6), zko.gen_text(2 << 20, 0x5EED0002)]
+    blob = b"".join(datas)
+    off = np.zeros(len(datas) + 1, np.uint64)
+    off[1:] = np.cumsum([len(x) for x in datas])
+    h = engine.xxh64_frames(blob, off)
+    assert [int(x) for x in h] == [zko.xxh64(x) for x in datas]
+    assert int(h[-1]) == 0xAD0311EAAD1ED582          # SURVEY 8(d) KAT
+
+
+def test_checksum_mismatch_is_reported(engine):
+    g = next(x for x in GOLDENS if x.name == "text_l1_64k")
+    c, d = g.offsets()
+    comp = bytearray(g.comp)
+    comp[int(c[2]) - 1] ^= 0x40                       # last byte of frame 1 = its Content_Checksum
+    out, st = engine.decode_frames(bytes(comp) + b"\0" * 8, c, d, verify=True, raise_on_error=False)
+    assert list(st) == [0, 22, 0, 0]                  # ZSTD_error_checksum_wrong, other frames untouched
+    data = g.input()
+    assert out[:int(d[1])] == data[:int(d[1])] and out[int(d[2]):] == data[int(d[2]):]
+    out2, st2 = engine.decode_frames(bytes(comp) + b"\0" * 8, c, d, verify=False)
+    assert out2 == data and not st2.any()
+
+
+def test_corruption_never_escapes(engine):
+    import zeekstd_amd as zk
+    g = next(x for x in GOLDENS if x.name == "text_l1_64k")
+    c, d = g.offsets()
+    data = g.input()
+    rng = np.random.default_rng(11)
+    rejected = 0
+    for _ in range(60):
+        comp = bytearray(g.comp)
+        i = int(rng.integers(0, len(comp)))
+        comp[i] ^= 1 << int(rng.integers(0, 8))
+        out, st = engine.decode_frames(bytes(comp) + b"\0" * 8, c, d, verify=True, raise_on_error=False)
+        # with checksums on, a flipped bit must never yield a silently wrong frame
+        for f in range(len(g.frames)):
+            if st[f] == 0:
+                assert out[int(d[f]):int(d[f + 1])] == data[int(d[f]):int(d[f + 1])]
+            else:
+                rejected += 1
+    assert rejected >= 55
+    with pytest.raises(zk.ZkError) as e:
+        engine.decode_frames(b"\0" * 64, [0, 30], [0, 100])
+    assert e.value.code == -10                         # prefix_unknown
+
+
+def test_error_codes(engine):
+    g = next(x for x in GOLDENS if x.name == "hello")
+    _, st = engine.decode_frames(g.comp + b"\0" * 8, [0, 21], [0, 13], raise_on_error=False)
+    assert st[0] == 72                                 # srcSize_wrong: seek table c_size shorter than the frame
+    _, st = engine.decode_frames(g.comp + b"\0" * 8, [0, 22], [0, 14], raise_on_error=False)
+    assert st[0] == 20                                 # corruption: d_size disagrees with the frame content
+
+
+@pytest.mark.skipif(Z.load("system") is None, reason="no system libzstd on this box")
+@pytest.mark.parametrize("level,fs,cks", [(1, 2 << 20, True), (1, 65536, False), (3, 2 << 20, True), (19, 1 << 20, True),
+                                          (-5, 2 << 20, False), (1, 1000, True), (3, 100, False)])
+def test_live_libzstd_archives(engine, level, fs, cks):
+    """Archives produced on this box by the reference's Encoder loop over the system libzstd."""
+    n = (9 << 20) + 12345 if fs >= 65536 and level < 19 else (1 << 20) + 77 if fs >= 65536 else 60000
+    data = zko.make_input([["chunks", n * 3 // 4, 5], ["zeros", n // 16], ["random", n // 16, 9],
+                           ["text", n - n * 3 // 4 - 2 * (n // 16), 10]])
+    comp, frames = Z.encode_seekable_frames(data, fs, level, cks, "system")
+    c, d = offsets_from_frames(frames)
+    out, st = engine.decode_frames(comp + b"\0" * 8, c, d, verify=True)
+    assert not st.any() and out == data
+
+
+@pytest.mark.skipif(Z.load("system") is None, reason="no system libzstd on this box")
+def test_baseline_config_2_decode_only(engine):
+    """BASELINE.json configs[1] at reduced size (32 MiB of the 256 MiB): 2 MiB frames, level 1, decode-only,
+    bit-exact vs the generator bytes; per-frame XXH64 KATs of SURVEY 8(d) as a size-independent check."""
+    n = 32 << 20
+    data = zko.gen_chunks(n)
+    comp, frames = Z.encode_seekable_frames(data, 2 << 20, 1, False, "system")
+    c, d = offsets_from_frames(frames)
+    out, st = engine.decode_frames(comp + b"\0" * 8, c, d)
+    assert out == data
+    h = engine.xxh64_frames(out, d)
+    assert int(h[0]) == 0xAD0311EAAD1ED582 and int(h[1]) == 0x8CC2C9BC11FFCCA2

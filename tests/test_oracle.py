@@ -1,0 +1,109 @@
+"""The CPU oracle (oracle/) pinned against golden vectors: SURVEY Appendix B bytes captured from
+libzstd 1.5.7 with the reference call sequence, XXH64 / generator KATs, and the committed
+libzstd-1.5.7 archives (tests/golden, made by tools/make_goldens.py)."""
+import pytest
+
+from oracle import zko
+from oracle import libzstd_ref as Z
+
+H = bytes.fromhex
+
+
+def test_xxh64_kats():
+    # SURVEY Appendix B (python-xxhash 3.8.1 == libzstd frame checksums)
+    assert zko.xxh64(b"") == 0xEF46DB3751D8E999
+    assert zko.xxh64(b"a") == 0xD24EC4F1A98C6E5B
+    assert zko.xxh64(b"Hello, World!") == 0xC49AACF8080FE47F
+    assert zko.xxh64(bytes(range(256))) == 0x1FACBE8406CD904B
+
+
+def test_xxh64_against_python_xxhash():
+    xxhash = pytest.importorskip("xxhash")
+    for n in [0, 1, 3, 4, 7, 8, 31, 32, 33, 63, 64, 65, 1000, 4097]:
+        d = zko.gen_random(n, 1000 + n)
+        assert zko.xxh64(d) == xxhash.xxh64(d, seed=0).intdigest()
+        assert zko.xxh64(d, 12345) == xxhash.xxh64(d, seed=12345).intdigest()
+
+
+def test_generator_kats():
+    # SURVEY 8(d)
+    assert [zko.gen_vocab(i) for i in range(5)] == [b"isa", b"lv", b"lcvk", b"uenoot", b"uemu"]
+    assert zko.gen_vocab(4095) == b"avbyfshr"
+    c0 = zko.gen_text(2 << 20, 0x5EED0002)
+    assert c0.startswith(b"jpucbf ss wuh. fkzkq jqkqubjob i")
+    assert zko.xxh64(c0) == 0xAD0311EAAD1ED582
+    assert zko.xxh64(zko.gen_text(2 << 20, 0x5EED0002 + 1)) == 0x8CC2C9BC11FFCCA2
+    assert zko.gen_chunks(3 << 20)[:2 << 20] == c0
+
+
+APPENDIX_B = [
+    # (frame bytes, decoded, has checksum)
+    (H("28b52ffd2000010000"), b"", False),
+    (H("28b52ffd240001000099e9d851"), b"", True),
+    (H("28b52ffd004869000048656c6c6f2c20576f726c6421"), b"Hello, World!", False),
+    (H("28b52ffd044869000048656c6c6f2c20576f726c64217fe40f08"), b"Hello, World!", True),
+    (H("28b52ffd005869000048656c6c6f2c20576f726c6421"), b"Hello, World!", False),
+]
+
+
+@pytest.mark.parametrize("frame,plain,cks", APPENDIX_B)
+def test_appendix_b_frames(frame, plain, cks):
+    out, used, st = zko.frame_decode(frame, 64, True, True)
+    assert out == plain and used == len(frame) and bool(st.has_checksum) == cks
+
+
+def test_checksum_mismatch_detected():
+    bad = bytearray(H("28b52ffd044869000048656c6c6f2c20576f726c64217fe40f08"))
+    bad[-1] ^= 1
+    with pytest.raises(zko.OracleError) as e:
+        zko.frame_decode(bytes(bad), 64, True)
+    assert e.value.code == 22
+    assert zko.frame_decode(bytes(bad), 64, False)[0] == b"Hello, World!"
+
+
+def test_goldens_decode(golden):
+    data = golden.input()
+    pos = dpos = 0
+    for c, d in golden.frames:
+        out, used = zko.frame_decode(golden.comp[pos:pos + c], d, True)
+        assert used == c
+        assert out == data[dpos:dpos + d]
+        pos += c
+        dpos += d
+    assert pos == len(golden.comp) and dpos == len(data)
+
+
+def test_goldens_cover_the_format():
+    """The fixture set must exercise every block / literal / table mode the decoder implements."""
+    from conftest import GOLDENS
+    tot = dict(raw=0, rle=0, comp=0, lit_raw=0, lit_rle=0, huf4=0, huf1=0, treeless=0)
+    modes = [[0] * 4 for _ in range(3)]
+    for g in GOLDENS:
+        pos = 0
+        for c, d in g.frames:
+            _, _, st = zko.frame_decode(g.comp[pos:pos + c], d, True, True)
+            pos += c
+            tot["raw"] += st.n_raw; tot["rle"] += st.n_rle; tot["comp"] += st.n_comp
+            tot["lit_raw"] += st.lit_raw; tot["lit_rle"] += st.lit_rle
+            tot["huf4"] += st.lit_huf4; tot["huf1"] += st.lit_huf1; tot["treeless"] += st.lit_treeless
+            for t in range(3):
+                for m in range(4):
+                    modes[t][m] += st.mode_count[t][m]
+    assert all(v > 0 for v in tot.values()), tot
+    for t in range(3):
+        assert modes[t][0] and modes[t][2] and modes[t][3], modes   # predefined, fse, repeat for LL, OF, ML
+    assert modes[1][1], modes                                       # RLE mode (OF; libzstd never picked it for LL/ML here)
+
+
+@pytest.mark.skipif(Z.load("system") is None, reason="no system libzstd")
+@pytest.mark.parametrize("level", [-5, 1, 3, 6, 12, 19])
+def test_oracle_vs_live_libzstd(level):
+    data = zko.make_input([["text", 90000, 40 + level], ["zeros", 5000], ["random", 3000, 5], ["text", 40000, 41]])
+    for fs in (1 << 20, 20000, 333):
+        d = data if fs >= 20000 else data[:9000]
+        comp, frames = Z.encode_seekable_frames(d, fs, level, True, "system")
+        pos = dpos = 0
+        for c, dd in frames:
+            out, used = zko.frame_decode(comp[pos:pos + c], dd, True)
+            assert used == c and out == d[dpos:dpos + dd]
+            pos += c; dpos += dd

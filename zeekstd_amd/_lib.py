@@ -35,6 +35,10 @@ _sig = {
     "zk_engine_destroy": (None, [_P]),
     "zk_engine_last_hip_error": (C.c_char_p, [_P]),
     "zk_engine_device_name": (C.c_char_p, [_P]),
+    "zk_engine_set_profiling": (C.c_int, [_P, C.c_int]),
+    "zk_engine_kernel_count": (C.c_int, []),
+    "zk_engine_kernel_name": (C.c_char_p, [C.c_int]),
+    "zk_engine_kernel_times": (C.c_int, [_P, _P, C.c_int]),
     "zk_decode_frames": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_int, _P]),
     "zk_decode_frames_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_int, _P, _P]),
     "zk_xxh64_frames": (C.c_int, [_P, _P, _P, C.c_uint32, _P]),

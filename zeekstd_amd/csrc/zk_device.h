@@ -610,8 +610,8 @@ ZK_HD int32_t zk_seq_table_setup(const uint8_t *comp, const ZkBlock &def, int t,
 // Reverse bit window for the sequence bitstream: W holds stream bits [wpos, wpos+64); pos = unread bits.
 // The window for bit position pos starts at byte max(0, (pos-57)>>3), so it always offers >= 57 bits
 // below pos (or everything that is left).  The 8-byte load may touch up to 7 bytes past a stream that
-// is shorter than 8 bytes: compressed buffers carry ZK_COMP_PADDING readable bytes at the end.
-constexpr uint32_t ZK_COMP_PADDING = 8;
+// is shorter than 8 bytes: compressed buffers carry ZK_DEV_COMP_PADDING readable bytes at the end.
+constexpr uint32_t ZK_DEV_COMP_PADDING = 8;     // == ZK_COMP_PADDING of include/zeekstd_amd.h
 struct ZkRev { const uint8_t *base; uint64_t W; int32_t pos, wpos; };
 ZK_HD uint64_t zk_ld64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
 ZK_HD int32_t zk_rev_byte(int32_t pos) { int32_t b = (pos - 57) >> 3; return b < 0 ? 0 : b; }

@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <string>
 
+enum { ZK_K_WALK_COUNT = 0, ZK_K_SCAN, ZK_K_WALK_FILL, ZK_K_HUF, ZK_K_FSE, ZK_K_EXEC, ZK_K_XXH64, ZK_K_STATUS,
+       ZK_K_ENC_MATCH, ZK_K_ENC_ENTROPY, ZK_K_ENC_COMPACT, ZK_K_ENC_XXH64, ZK_NKERNELS };
+
 struct zk_devbuf { void *p = nullptr; size_t cap = 0; };
 
 struct zk_engine {
@@ -16,8 +19,24 @@ struct zk_engine {
     zk_devbuf infos, bases, words, blocks, seqs, lit;
     // staging for the host-pointer entry points
     zk_devbuf st_comp, st_off, st_dst, st_misc;
+    // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+    bool profiling = false;
+    hipEvent_t ev_start[ZK_NKERNELS] = {}, ev_stop[ZK_NKERNELS] = {};
+    bool ev_used[ZK_NKERNELS] = {};
+    float kernel_ms[ZK_NKERNELS] = {};
     // encode scratch
     zk_devbuf enc_a, enc_b, enc_c, enc_d;
 };
 
 int zk_devbuf_reserve(zk_engine *e, zk_devbuf &b, size_t bytes);
+
+// RAII-free helper: brackets one launch with events when profiling is on
+struct zk_kernel_timer {
+    zk_engine *e; int k; hipStream_t st;
+    zk_kernel_timer(zk_engine *e_, int k_, hipStream_t st_) : e(e_), k(k_), st(st_) {
+        if (e->profiling) { (void)hipEventRecord(e->ev_start[k], st); e->ev_used[k] = true; }
+    }
+    ~zk_kernel_timer() { if (e->profiling) (void)hipEventRecord(e->ev_stop[k], st); }
+};
+void zk_profile_begin(zk_engine *e);
+void zk_profile_collect(zk_engine *e);

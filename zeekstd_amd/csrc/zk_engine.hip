@@ -32,6 +32,41 @@ int zk_devbuf_reserve(zk_engine *e, zk_devbuf &b, size_t bytes)
     return 0;
 }
 
+void zk_profile_begin(zk_engine *e)
+{
+    if (!e->profiling) return;
+    for (int k = 0; k < ZK_NKERNELS; k++) { e->ev_used[k] = false; e->kernel_ms[k] = 0.f; }
+}
+void zk_profile_collect(zk_engine *e)       // call after the stream has been synchronised
+{
+    if (!e->profiling) return;
+    for (int k = 0; k < ZK_NKERNELS; k++)
+        if (e->ev_used[k]) { float ms = 0.f; if (hipEventElapsedTime(&ms, e->ev_start[k], e->ev_stop[k]) == hipSuccess) e->kernel_ms[k] = ms; }
+}
+
+extern "C" int zk_engine_set_profiling(zk_engine *e, int on)
+{
+    if (!e) return ZK_ERR_ARGUMENT;
+    ZK_HIP(hipSetDevice(e->device));
+    if (on && !e->ev_start[0])
+        for (int k = 0; k < ZK_NKERNELS; k++) { ZK_HIP(hipEventCreate(&e->ev_start[k])); ZK_HIP(hipEventCreate(&e->ev_stop[k])); }
+    e->profiling = on != 0;
+    return 0;
+}
+extern "C" int zk_engine_kernel_count(void) { return ZK_NKERNELS; }
+extern "C" const char *zk_engine_kernel_name(int k)
+{
+    static const char *names[ZK_NKERNELS] = {"zk_k_walk(count)", "zk_k_scan", "zk_k_walk(fill)", "zk_k_huf", "zk_k_fse", "zk_k_exec",
+                                             "zk_k_xxh64", "zk_k_status", "zk_k_enc_match", "zk_k_enc_entropy", "zk_k_enc_compact", "zk_k_enc_xxh64"};
+    return k >= 0 && k < ZK_NKERNELS ? names[k] : "";
+}
+extern "C" int zk_engine_kernel_times(const zk_engine *e, float *ms_out, int n)
+{
+    if (!e || !ms_out) return ZK_ERR_ARGUMENT;
+    for (int k = 0; k < n && k < ZK_NKERNELS; k++) ms_out[k] = e->kernel_ms[k];
+    return 0;
+}
+
 extern "C" int zk_abi_version(void) { return ZK_ABI_VERSION; }
 
 extern "C" const char *zk_error_name(int code)
@@ -77,7 +112,7 @@ extern "C" int zk_engine_create(int device, zk_engine **out)
     snprintf(e->devname, sizeof e->devname, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete e; return ZK_ERR_NO_DEVICE; }   // kernels are built for gfx950 only
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return ZK_ERR_NO_DEVICE; }
-    if (hipHostMalloc((void **)&e->h_words, 16 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { hipStreamDestroy(e->stream); delete e; return ZK_ERR_HIP; }
+    if (hipHostMalloc((void **)&e->h_words, 16 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return ZK_ERR_HIP; }
     *out = e;
     return 0;
 }
@@ -85,13 +120,14 @@ extern "C" int zk_engine_create(int device, zk_engine **out)
 extern "C" void zk_engine_destroy(zk_engine *e)
 {
     if (!e) return;
-    hipSetDevice(e->device);
-    hipStreamSynchronize(e->stream);
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
     zk_devbuf *bufs[] = {&e->infos, &e->bases, &e->words, &e->blocks, &e->seqs, &e->lit, &e->st_comp, &e->st_off, &e->st_dst, &e->st_misc,
                          &e->enc_a, &e->enc_b, &e->enc_c, &e->enc_d};
-    for (zk_devbuf *b : bufs) if (b->p) hipFree(b->p);
-    if (e->h_words) hipHostFree(e->h_words);
-    hipStreamDestroy(e->stream);
+    for (zk_devbuf *b : bufs) if (b->p) (void)hipFree(b->p);
+    if (e->h_words) (void)hipHostFree(e->h_words);
+    for (int k = 0; k < ZK_NKERNELS; k++) { if (e->ev_start[k]) (void)hipEventDestroy(e->ev_start[k]); if (e->ev_stop[k]) (void)hipEventDestroy(e->ev_stop[k]); }
+    (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
@@ -118,8 +154,9 @@ extern "C" int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t c
     ZkFrameBase *bases = (ZkFrameBase *)e->bases.p;
     uint64_t *words = (uint64_t *)e->words.p;          // [0..2] totals, [3] first error
 
-    zk_launch_walk(st, comp, c_off, d_off, first, count, nullptr, nullptr, infos);
-    zk_launch_scan(st, infos, count, bases, words);
+    zk_profile_begin(e);
+    { zk_kernel_timer t(e, ZK_K_WALK_COUNT, st); zk_launch_walk(st, comp, c_off, d_off, first, count, nullptr, nullptr, infos); }
+    { zk_kernel_timer t(e, ZK_K_SCAN, st); zk_launch_scan(st, infos, count, bases, words); }
     ZK_HIP(hipMemcpyAsync(e->h_words, words, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     const uint64_t nblocks = e->h_words[0], nseq = e->h_words[1], nlit = e->h_words[2];
@@ -133,15 +170,16 @@ extern "C" int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t c
 
     e->h_words[3] = ~0ull;
     ZK_HIP(hipMemcpyAsync(words + 3, e->h_words + 3, sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    zk_launch_walk(st, comp, c_off, d_off, first, count, bases, blocks, infos);
-    zk_launch_huf(st, comp, blocks, (uint32_t)nblocks, lit);
-    zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, seqs);
-    zk_launch_exec(st, comp, d_off, first, count, blocks, bases, infos, seqs, lit, (uint8_t *)d_dst);
-    if (verify) zk_launch_xxh64(st, (const uint8_t *)d_dst, d_off, first, count, infos, nullptr);
-    zk_launch_status(st, infos, count, (int32_t *)d_frame_status, words + 3);
+    { zk_kernel_timer t(e, ZK_K_WALK_FILL, st); zk_launch_walk(st, comp, c_off, d_off, first, count, bases, blocks, infos); }
+    { zk_kernel_timer t(e, ZK_K_HUF, st); zk_launch_huf(st, comp, blocks, (uint32_t)nblocks, lit); }
+    { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, seqs); }
+    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, blocks, bases, infos, seqs, lit, (uint8_t *)d_dst); }
+    if (verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)d_dst, d_off, first, count, infos, nullptr); }
+    { zk_kernel_timer t(e, ZK_K_STATUS, st); zk_launch_status(st, infos, count, (int32_t *)d_frame_status, words + 3); }
     ZK_HIP(hipMemcpyAsync(e->h_words + 3, words + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     ZK_HIP(hipGetLastError());
+    zk_profile_collect(e);
     if (e->h_words[3] != ~0ull) return -(int)(uint32_t)(e->h_words[3] & 0xFFFFFFFFu);
     return 0;
 }

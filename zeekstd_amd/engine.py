@@ -43,6 +43,18 @@ class Engine:
     def device_name(self) -> str:
         return lib.zk_engine_device_name(self._h).decode()
 
+    def set_profiling(self, on: bool):
+        rc = lib.zk_engine_set_profiling(self._h, int(on))
+        if rc != 0:
+            self._raise(rc)
+
+    def kernel_times(self):
+        """{kernel name: ms} of the last decode/encode call (profiling must be on)."""
+        n = lib.zk_engine_kernel_count()
+        ms = (C.c_float * n)()
+        lib.zk_engine_kernel_times(self._h, ms, n)
+        return {lib.zk_engine_kernel_name(k).decode(): float(ms[k]) for k in range(n) if ms[k] > 0}
+
     def _raise(self, rc):
         raise ZkError(rc, lib.zk_engine_last_hip_error(self._h).decode() if rc == -2001 else "")
 
