@@ -102,6 +102,86 @@ int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, c
 int zk_xxh64_frames(zk_engine *e, const uint8_t *data, const uint64_t *off, uint32_t count, uint64_t *out);
 int zk_xxh64_frames_dev(zk_engine *e, const void *d_data, const void *d_off, uint32_t count, void *d_out, void *stream);
 
+/* ================================================================ Level B: the zeekstd API as C handles
+ * One-to-one with the crate's public items; C++ callers can use the classes in
+ * zeekstd_amd/csrc/host/zeekstd.hpp directly.  Functions that can fail return 0 / a negative code and
+ * deliver values through out-pointers; zk_last_error_message() holds the Display text of the last error
+ * on this thread (lib/src/error.rs:60-71). */
+const char *zk_last_error_message(void);
+
+#define ZK_FORMAT_HEAD 0 /* seek_table::Format (lib/src/seek_table.rs:228-241) */
+#define ZK_FORMAT_FOOT 1
+
+/* ---- SeekTable (lib/src/seek_table.rs:243-935) */
+typedef struct zk_seek_table zk_seek_table;
+typedef struct zk_serializer zk_serializer;
+zk_seek_table *zk_seek_table_new(void);                                                        /* SeekTable::new :287 */
+zk_seek_table *zk_seek_table_clone(const zk_seek_table *t);
+void zk_seek_table_free(zk_seek_table *t);
+/* from_seekable_format over a BytesWrapper (seek_table.rs:379-436, seekable.rs:55-97) */
+int zk_seek_table_from_bytes(const uint8_t *src, size_t len, int format, zk_seek_table **out);
+/* from_reader (Head format, :461-493); max_read > 0 makes the reader return at most that many bytes per read */
+int zk_seek_table_from_reader_bytes(const uint8_t *p, size_t len, size_t max_read, zk_seek_table **out);
+int zk_seek_table_log_frame(zk_seek_table *t, uint32_t c_size, uint32_t d_size);               /* :513-525 */
+uint32_t zk_seek_table_num_frames(const zk_seek_table *t);                                     /* :540 */
+uint32_t zk_seek_table_frame_index_comp(const zk_seek_table *t, uint64_t offset);              /* :560 */
+uint32_t zk_seek_table_frame_index_decomp(const zk_seek_table *t, uint64_t offset);            /* :579 */
+int zk_seek_table_frame_start_comp(const zk_seek_table *t, uint32_t index, uint64_t *out);     /* :604 */
+int zk_seek_table_frame_start_decomp(const zk_seek_table *t, uint32_t index, uint64_t *out);   /* :633 */
+int zk_seek_table_frame_end_comp(const zk_seek_table *t, uint32_t index, uint64_t *out);       /* :662 */
+int zk_seek_table_frame_end_decomp(const zk_seek_table *t, uint32_t index, uint64_t *out);     /* :691 */
+int zk_seek_table_frame_size_comp(const zk_seek_table *t, uint32_t index, uint64_t *out);      /* :720 */
+int zk_seek_table_frame_size_decomp(const zk_seek_table *t, uint32_t index, uint64_t *out);    /* :750 */
+uint64_t zk_seek_table_max_frame_size_comp(const zk_seek_table *t);                            /* :774 */
+uint64_t zk_seek_table_max_frame_size_decomp(const zk_seek_table *t);                          /* :799 */
+uint64_t zk_seek_table_size_comp(const zk_seek_table *t);                                      /* :827 */
+uint64_t zk_seek_table_size_decomp(const zk_seek_table *t);                                    /* :853 */
+int zk_seek_table_equal(const zk_seek_table *a, const zk_seek_table *b);                       /* PartialEq :266 */
+/* the n+1 prefix sums (what zk_decode_frames takes); returns n+1 */
+size_t zk_seek_table_entries(const zk_seek_table *t, uint64_t *c_off, uint64_t *d_off, size_t cap);
+/* ---- Serializer (seek_table.rs:937-1059): resumable at byte granularity, 0 == done */
+zk_serializer *zk_seek_table_serializer(const zk_seek_table *t, int format);                   /* into_format_serializer :907 */
+size_t zk_serializer_write_into(zk_serializer *s, uint8_t *buf, size_t len);                   /* :967-1005 */
+void zk_serializer_reset(zk_serializer *s);                                                    /* :1034 */
+size_t zk_serializer_encoded_len(const zk_serializer *s);                                      /* :1042 */
+void zk_serializer_free(zk_serializer *s);
+
+/* ---- DecodeOptions / Decoder (lib/src/decode.rs) */
+typedef struct zk_decoder zk_decoder;
+#define ZK_DEC_HAS_OFFSET 1u
+#define ZK_DEC_HAS_OFFSET_LIMIT 2u
+#define ZK_DEC_HAS_LOWER_FRAME 4u
+#define ZK_DEC_HAS_UPPER_FRAME 8u
+#define ZK_DEC_NO_VERIFY 16u
+typedef struct zk_decode_opts {          /* DecodeOptions builder fields, decode.rs:13-114 */
+    uint32_t flags;
+    uint32_t lower_frame, upper_frame;   /* :73, :81 (upper is inclusive) */
+    uint64_t offset, offset_limit;       /* :90, :99 */
+    const zk_seek_table *seek_table;     /* :65; NULL = parse it from the source's tail */
+    uint64_t batch_bytes;                /* engine-specific: decode-ahead per GPU submission (0 = default 64 MiB) */
+} zk_decode_opts;
+#define ZK_SEEK_START 0
+#define ZK_SEEK_END 1
+#define ZK_SEEK_CURRENT 2
+/* e == NULL: the decoder creates (and owns) an engine on device 0, like DecodeOptions::new creating a DCtx (:30).
+ * The byte source is borrowed and must outlive the decoder (BytesWrapper<'a>). */
+int zk_decoder_open_bytes(zk_engine *e, const uint8_t *src, size_t len, const zk_decode_opts *o, zk_decoder **out);
+int zk_decoder_open_file(zk_engine *e, const char *path, const zk_decode_opts *o, zk_decoder **out);   /* Read+Seek source, seekable.rs:112-138 */
+void zk_decoder_free(zk_decoder *d);
+int64_t zk_decoder_decompress(zk_decoder *d, uint8_t *buf, size_t len);                        /* :314; bytes written or <0 */
+int zk_decoder_decompress_with_prefix(zk_decoder *d, uint8_t *buf, size_t len, const uint8_t *prefix, size_t plen, size_t *out); /* :201 */
+void zk_decoder_reset(zk_decoder *d);                                                          /* :346 */
+int zk_decoder_set_lower_frame(zk_decoder *d, uint32_t index, uint64_t *out);                  /* :367 */
+int zk_decoder_set_upper_frame(zk_decoder *d, uint32_t index, uint64_t *out);                  /* :383 */
+int zk_decoder_set_offset(zk_decoder *d, uint64_t offset);                                     /* :402 */
+int zk_decoder_set_offset_limit(zk_decoder *d, uint64_t limit);                                /* :432 */
+uint64_t zk_decoder_read_compressed(const zk_decoder *d);                                      /* :448 */
+uint64_t zk_decoder_offset(const zk_decoder *d);                                               /* :458 */
+uint64_t zk_decoder_offset_limit(const zk_decoder *d);                                         /* :463 */
+zk_seek_table *zk_decoder_seek_table(const zk_decoder *d);                                     /* :453 (a copy; free it) */
+int zk_decoder_seek(zk_decoder *d, int whence, int64_t n, uint64_t *out);                      /* io::Seek :545-579 */
+uint64_t zk_decoder_gpu_submissions(const zk_decoder *d);                                      /* engine-specific counter */
+
 #ifdef __cplusplus
 }
 #endif

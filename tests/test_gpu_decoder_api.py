@@ -1,0 +1,233 @@
+"""zeekstd::Decoder semantics on the GPU engine -- the reference's decode tests restated
+(lib/src/decode.rs:632-939) plus the fuzz target's property (fuzz/fuzz_targets/roundtrip_seek.rs:7-43)."""
+import numpy as np
+import pytest
+
+import zeekstd_amd as zk
+from zeekstd_amd import DecodeOptions, Decoder, SeekFrom, SeekTable
+from oracle import zko
+from oracle import libzstd_ref as Z
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(Z.load("system") is None, reason="needs a libzstd to build archives")]
+
+INPUT = zko.gen_text(12345, 4242)       # stand-in for include_str!("./lib.rs") (lib.rs:80), similar size
+
+
+def new_seekable(frame_size=None, checksum=False, level=3):
+    """decode.rs:587-629: data frames + Foot seek table."""
+    comp, frames = Z.encode_seekable_frames(INPUT, frame_size or 0x200000, level, checksum, "system")
+    st = SeekTable.new()
+    for c, d in frames:
+        st.log_frame(c, d)
+    return comp + st.to_bytes()
+
+
+@pytest.fixture(scope="module")
+def eng(engine):
+    return engine
+
+
+def dec(seekable, eng):
+    return DecodeOptions(seekable).engine(eng).into_decoder()
+
+
+def test_options(eng):                  # decode.rs:632-661
+    seekable = new_seekable()
+    st = SeekTable.from_seekable(seekable)
+    oks = [DecodeOptions(seekable), DecodeOptions(seekable).lower_frame(st.num_frames() - 1),
+           DecodeOptions(seekable).upper_frame(st.num_frames() - 1), DecodeOptions(seekable).offset(st.size_decomp()),
+           DecodeOptions(seekable).offset_limit(st.size_decomp()), DecodeOptions(b"\x00\x80").seek_table(st.clone())]
+    errs = [DecodeOptions(b"\x00\x80"), DecodeOptions(seekable).lower_frame(st.num_frames()),
+            DecodeOptions(seekable).upper_frame(st.num_frames()), DecodeOptions(seekable).offset(st.size_decomp() + 1),
+            DecodeOptions(seekable).offset_limit(st.size_decomp() + 1)]
+    for o in oks:
+        o.engine(eng).into_decoder()
+    for o in errs:
+        with pytest.raises(zk.Error):
+            o.engine(eng).into_decoder()
+
+
+def test_decompress_and_reset(eng):     # decode.rs:664-682
+    d = dec(new_seekable(), eng)
+    out = bytearray(len(INPUT))
+    assert d.decompress(out) == len(out) and bytes(out) == INPUT
+    assert d.decompress(out) == 0
+    d.reset()
+    assert d.decompress(out) == len(out) and bytes(out) == INPUT
+
+
+def test_decompress_until_upper_frame(eng):     # decode.rs:685-698
+    fs = len(INPUT) // 7
+    d = dec(new_seekable(fs), eng)
+    d.set_lower_frame(0); d.set_upper_frame(5)
+    out = bytearray(fs * 6)
+    assert d.decompress(out) == fs * 6 and bytes(out) == INPUT[:fs * 6]
+
+
+def test_decompress_last_frames(eng):   # decode.rs:701-715
+    fs = len(INPUT) // 9
+    d = dec(new_seekable(fs), eng)
+    d.set_lower_frame(5); d.set_upper_frame(9)
+    n = len(INPUT) - fs * 5
+    out = bytearray(n)
+    assert d.decompress(out) == n and bytes(out) == INPUT[len(INPUT) - n:]
+
+
+def test_upper_frame_lower_than_lower_frame(eng):   # decode.rs:718-730
+    d = dec(new_seekable(len(INPUT) // 13), eng)
+    d.set_lower_frame(9); d.set_upper_frame(8)
+    assert d.decompress(bytearray(len(INPUT))) == 0
+
+
+def test_reset_decompression(eng):      # decode.rs:733-744
+    d = dec(new_seekable(), eng)
+    d.decompress(bytearray(128))
+    d.reset()
+    out = bytearray(len(INPUT))
+    assert d.decompress(out) == len(INPUT) and bytes(out) == INPUT
+
+
+def test_decompress_everything_after_partly_decompression(eng):   # decode.rs:747-771
+    fs = len(INPUT) // 32
+    d = dec(new_seekable(fs), eng)
+    d.set_lower_frame(23); d.set_upper_frame(29)
+    out = bytearray(len(INPUT))
+    n = d.decompress(out)
+    assert n == fs * 30 - fs * 23 and bytes(out[:n]) == INPUT[fs * 23:fs * 30]
+    d.set_lower_frame(0); d.set_upper_frame(d.seek_table().num_frames() - 1)
+    assert d.decompress(out) == len(INPUT) and bytes(out) == INPUT
+
+
+def test_set_frame_boundaries(eng):     # decode.rs:774-795
+    d = dec(new_seekable(), eng)
+    n = d.seek_table().num_frames()
+    d.set_lower_frame(n - 1); d.set_upper_frame(n - 1)
+    for f in (d.set_lower_frame, d.set_upper_frame):
+        with pytest.raises(zk.Error) as e:
+            f(n)
+        assert e.value.is_frame_index_too_large()
+
+
+def test_set_offset_boundaries(eng):    # decode.rs:798-819
+    d = dec(new_seekable(), eng)
+    off = d.seek_table().size_decomp()
+    d.set_offset(off); d.set_offset_limit(off)
+    for f in (d.set_offset, d.set_offset_limit):
+        with pytest.raises(zk.Error) as e:
+            f(off + 1)
+        assert e.value.is_offset_out_of_range() and str(e.value) == "offset out of range"
+
+
+def test_decompress_within_offset_boundaries(eng):   # decode.rs:822-851
+    d = dec(new_seekable(len(INPUT) // 34), eng)
+    off = len(INPUT) // 3
+    lim = 2 * off
+    d.set_offset(off); d.set_offset_limit(lim)
+    out = bytearray(len(INPUT))
+    n = d.decompress(out)
+    assert n == lim - off and bytes(out[:n]) == INPUT[off:lim]
+    d.set_offset(3)                     # limit stays unchanged
+    n = d.decompress(out)
+    assert n == lim - 3 and bytes(out[:n]) == INPUT[3:lim]
+    d.reset()                           # reset unsets offset and limit
+    assert d.offset() == 0 and d.offset_limit() == d.seek_table().size_decomp() and d.read_compressed() == 0
+    assert d.decompress(out) == len(INPUT) and bytes(out) == INPUT
+
+
+def test_seek_decoder(eng):             # decode.rs:856-908
+    fs = len(INPUT) // 52
+    d = dec(new_seekable(fs), eng)
+    seek_pos, end = fs * 13, fs * 51
+    d.set_offset_limit(end)
+    d.seek(SeekFrom.Start, seek_pos)
+    assert d.offset() == seek_pos
+    out = bytearray(len(INPUT))
+    n = d.decompress(out)
+    assert d.read_compressed() != 0
+    assert n == end - seek_pos and bytes(out[:n]) == INPUT[seek_pos:end]
+    assert d.offset() == end            # reading moves offset accordingly
+    sp = -(2 * fs)
+    start = len(INPUT) + sp
+    d.seek(SeekFrom.End, sp)
+    assert d.offset() == start and d.read_compressed() == 0
+    n = d.decompress(out)
+    assert n == end - start and bytes(out[:n]) == INPUT[start:end]
+    d.seek(SeekFrom.Start, 69); d.seek(SeekFrom.Current, 10)
+    assert d.offset() == 79
+    n = d.decompress(out)
+    assert n == end - 79 and bytes(out[:n]) == INPUT[79:end]
+    d.seek(SeekFrom.Start, 69); d.seek(SeekFrom.Current, -10)
+    assert d.offset() == 59
+    n = d.decompress(out)
+    assert n == end - 59 and bytes(out[:n]) == INPUT[59:end]
+    with pytest.raises(zk.Error):       # SeekFrom::End(n > 0) is an error (decode.rs:555-558)
+        d.seek(SeekFrom.End, 1)
+
+
+def test_set_offset_within_frame_continues_decompression(eng):   # decode.rs:912-939
+    d = dec(new_seekable(100), eng)
+    assert d.read_compressed() == 0
+    d.set_offset(10)
+    assert len(d.read(10)) == 10
+    assert d.read_compressed() != 0
+    subs = d.gpu_submissions()
+    d.set_offset(30)                    # same frame, forward: no reset
+    assert d.offset() == 30 and d.read_compressed() != 0
+    assert d.read(20) == INPUT[30:50] and d.gpu_submissions() == subs     # served from the decoded frame
+    out = bytearray(len(INPUT))
+    n = d.decompress(out)
+    assert n == len(INPUT) - 50 and bytes(out[:n]) == INPUT[50:]
+    d.set_offset(101)                   # another frame: reset
+    assert d.offset() == 101 and d.read_compressed() == 0
+    n = d.decompress(out)
+    assert n == len(INPUT) - 101 and bytes(out[:n]) == INPUT[101:]
+
+
+def test_tiny_reads_and_streaming(eng):  # lib.rs:82-134: every call is partial (buffer of len/500 bytes)
+    d = dec(new_seekable(1000, checksum=True), eng)
+    step = max(1, len(INPUT) // 500)
+    out = bytearray()
+    while True:
+        chunk = d.read(step)
+        if not chunk:
+            break
+        out += chunk
+    assert bytes(out) == INPUT
+
+
+def test_prefix_is_rejected_not_ignored(eng):
+    d = dec(new_seekable(), eng)
+    with pytest.raises(zk.Error) as e:
+        d.decompress_with_prefix(bytearray(10), b"some prefix")
+    assert e.value.code == -40          # parameter_unsupported: patch mode is out of scope
+
+
+def test_checksum_of_cut_frame_is_not_verified(eng):    # doc decode.rs:425-427
+    seekable = bytearray(new_seekable(1000, checksum=True))
+    st = SeekTable.from_seekable(bytes(seekable))
+    seekable[st.frame_end_comp(2) - 1] ^= 0xFF           # break frame 2's Content_Checksum
+    d = dec(bytes(seekable), eng)
+    d.set_offset(1990); d.set_offset_limit(2500)         # limit cuts frame 2 short
+    assert d.read(4096) == INPUT[1990:2500]
+    d.set_offset_limit(3000)                             # frame 2 fully inside the range: must fail
+    d.set_offset(1990)
+    with pytest.raises(zk.Error) as e:
+        d.read(4096)
+    assert e.value.code == -22
+
+
+def test_roundtrip_seek_property(eng):  # fuzz/fuzz_targets/roundtrip_seek.rs
+    seekable = new_seekable(100)
+    rng = np.random.default_rng(3)
+    d = dec(seekable, eng)
+    for _ in range(25):
+        o = int(rng.integers(0, len(INPUT) + 1))
+        d.set_offset(o)
+        assert d.read_to_end() == INPUT[o:]
+
+
+def test_file_source(eng, tmp_path):     # the Read + Seek blanket impl (seekable.rs:112-138)
+    p = tmp_path / "a.zst"
+    p.write_bytes(new_seekable(777, checksum=True))
+    d = DecodeOptions(str(p)).engine(eng).offset(1500).offset_limit(9000).into_decoder()
+    assert d.read_to_end() == INPUT[1500:9000]

@@ -5,3 +5,9 @@ there is no CPU fallback (import fails loudly without libzeekstd_amd.so).
 """
 from ._lib import LIB_PATH, error_name, lib  # noqa: F401
 from .engine import Engine, ZkError  # noqa: F401
+from .api import DecodeOptions, Decoder, Error, Format, SeekFrom, SeekTable, Serializer  # noqa: F401,E402
+
+SEEKABLE_MAGIC_NUMBER = 0x8F92EAB1      # lib.rs:52-58
+SEEKABLE_MAX_FRAMES = 0x08000000
+SEEK_TABLE_INTEGRITY_SIZE = 9
+SEEKABLE_MAX_FRAME_SIZE = 0x40000000

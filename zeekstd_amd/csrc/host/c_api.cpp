@@ -1,0 +1,157 @@
+// c_api.cpp -- Level B of include/zeekstd_amd.h: C handles over the zeekstd:: host classes.
+#include <string.h>
+#include <algorithm>
+#include <new>
+#include "../../../include/zeekstd_amd.h"
+#include "zeekstd.hpp"
+
+using namespace zeekstd;
+
+struct zk_seek_table { SeekTable t; };
+struct zk_serializer { Serializer s; };
+struct zk_decoder { Decoder d; explicit zk_decoder(Decoder &&x) : d(std::move(x)) {} };
+
+static thread_local std::string g_last_error;
+
+template <typename F>
+static int guard(F &&f)
+{
+    try { f(); return 0; }
+    catch (const Error &e) { g_last_error = e.what(); return e.abi_code(); }
+    catch (const std::bad_alloc &) { g_last_error = "allocation failed"; return -64; }
+    catch (const std::exception &e) { g_last_error = e.what(); return -1; }
+}
+
+extern "C" {
+
+const char *zk_last_error_message(void) { return g_last_error.c_str(); }
+
+// ---------------------------------------------------------------- SeekTable
+zk_seek_table *zk_seek_table_new(void) { return new (std::nothrow) zk_seek_table(); }
+void zk_seek_table_free(zk_seek_table *t) { delete t; }
+zk_seek_table *zk_seek_table_clone(const zk_seek_table *t) { return t ? new (std::nothrow) zk_seek_table(*t) : nullptr; }
+
+int zk_seek_table_from_bytes(const uint8_t *src, size_t len, int format, zk_seek_table **out)
+{
+    if (!out) return ZK_ERR_ARGUMENT;
+    *out = nullptr;
+    return guard([&] {
+        BytesWrapper w(src, len);
+        SeekTable t = SeekTable::from_seekable_format(w, format == ZK_FORMAT_HEAD ? Format::Head : Format::Foot);
+        *out = new zk_seek_table{std::move(t)};
+    });
+}
+
+int zk_seek_table_from_reader_bytes(const uint8_t *p, size_t len, size_t max_read, zk_seek_table **out)
+{
+    if (!out) return ZK_ERR_ARGUMENT;
+    *out = nullptr;
+    struct R : SeekTable::Reader {
+        const uint8_t *p; size_t len, pos = 0, cap;
+        size_t read(uint8_t *buf, size_t n) override
+        {
+            n = std::min({n, len - pos, cap ? cap : n});
+            memcpy(buf, p + pos, n); pos += n; return n;
+        }
+    } r;
+    r.p = p; r.len = len; r.cap = max_read;
+    return guard([&] { *out = new zk_seek_table{SeekTable::from_reader(r)}; });
+}
+
+int zk_seek_table_log_frame(zk_seek_table *t, uint32_t c_size, uint32_t d_size) { return guard([&] { t->t.log_frame(c_size, d_size); }); }
+uint32_t zk_seek_table_num_frames(const zk_seek_table *t) { return t->t.num_frames(); }
+uint32_t zk_seek_table_frame_index_comp(const zk_seek_table *t, uint64_t off) { return t->t.frame_index_comp(off); }
+uint32_t zk_seek_table_frame_index_decomp(const zk_seek_table *t, uint64_t off) { return t->t.frame_index_decomp(off); }
+int zk_seek_table_frame_start_comp(const zk_seek_table *t, uint32_t i, uint64_t *out) { return guard([&] { *out = t->t.frame_start_comp(i); }); }
+int zk_seek_table_frame_start_decomp(const zk_seek_table *t, uint32_t i, uint64_t *out) { return guard([&] { *out = t->t.frame_start_decomp(i); }); }
+int zk_seek_table_frame_end_comp(const zk_seek_table *t, uint32_t i, uint64_t *out) { return guard([&] { *out = t->t.frame_end_comp(i); }); }
+int zk_seek_table_frame_end_decomp(const zk_seek_table *t, uint32_t i, uint64_t *out) { return guard([&] { *out = t->t.frame_end_decomp(i); }); }
+int zk_seek_table_frame_size_comp(const zk_seek_table *t, uint32_t i, uint64_t *out) { return guard([&] { *out = t->t.frame_size_comp(i); }); }
+int zk_seek_table_frame_size_decomp(const zk_seek_table *t, uint32_t i, uint64_t *out) { return guard([&] { *out = t->t.frame_size_decomp(i); }); }
+uint64_t zk_seek_table_max_frame_size_comp(const zk_seek_table *t) { return t->t.max_frame_size_comp(); }
+uint64_t zk_seek_table_max_frame_size_decomp(const zk_seek_table *t) { return t->t.max_frame_size_decomp(); }
+uint64_t zk_seek_table_size_comp(const zk_seek_table *t) { return t->t.size_comp(); }
+uint64_t zk_seek_table_size_decomp(const zk_seek_table *t) { return t->t.size_decomp(); }
+int zk_seek_table_equal(const zk_seek_table *a, const zk_seek_table *b) { return a->t == b->t; }
+size_t zk_seek_table_entries(const zk_seek_table *t, uint64_t *c_off, uint64_t *d_off, size_t cap)
+{
+    const auto &e = t->t.entries();
+    for (size_t i = 0; i < e.size() && i < cap; i++) { if (c_off) c_off[i] = e[i].c_offset; if (d_off) d_off[i] = e[i].d_offset; }
+    return e.size();
+}
+
+zk_serializer *zk_seek_table_serializer(const zk_seek_table *t, int format)
+{
+    return new (std::nothrow) zk_serializer{t->t.into_format_serializer(format == ZK_FORMAT_HEAD ? Format::Head : Format::Foot)};
+}
+size_t zk_serializer_write_into(zk_serializer *s, uint8_t *buf, size_t len) { return s->s.write_into(buf, len); }
+void zk_serializer_reset(zk_serializer *s) { s->s.reset(); }
+size_t zk_serializer_encoded_len(const zk_serializer *s) { return s->s.encoded_len(); }
+void zk_serializer_free(zk_serializer *s) { delete s; }
+
+// ---------------------------------------------------------------- Decoder
+static DecodeOptions make_opts(std::shared_ptr<Seekable> src, zk_engine *e, const zk_decode_opts *o)
+{
+    DecodeOptions opts(std::move(src));
+    if (e) opts.engine(e);
+    if (o) {
+        if (o->seek_table) opts.seek_table(o->seek_table->t);
+        if (o->flags & ZK_DEC_HAS_LOWER_FRAME) opts.lower_frame(o->lower_frame);
+        if (o->flags & ZK_DEC_HAS_UPPER_FRAME) opts.upper_frame(o->upper_frame);
+        if (o->flags & ZK_DEC_HAS_OFFSET) opts.offset(o->offset);
+        if (o->flags & ZK_DEC_HAS_OFFSET_LIMIT) opts.offset_limit(o->offset_limit);
+        if (o->flags & ZK_DEC_NO_VERIFY) opts.verify_checksums(false);
+        if (o->batch_bytes) opts.batch_bytes(o->batch_bytes);
+    }
+    return opts;
+}
+
+int zk_decoder_open_bytes(zk_engine *e, const uint8_t *src, size_t len, const zk_decode_opts *o, zk_decoder **out)
+{
+    if (!out) return ZK_ERR_ARGUMENT;
+    *out = nullptr;
+    return guard([&] { *out = new zk_decoder(Decoder(make_opts(std::make_shared<BytesWrapper>(src, len), e, o))); });
+}
+
+int zk_decoder_open_file(zk_engine *e, const char *path, const zk_decode_opts *o, zk_decoder **out)
+{
+    if (!out || !path) return ZK_ERR_ARGUMENT;
+    *out = nullptr;
+    return guard([&] {
+        FILE *f = fopen(path, "rb");
+        if (!f) throw Error::io(std::string("cannot open ") + path);
+        *out = new zk_decoder(Decoder(make_opts(std::make_shared<FileSeekable>(f, true), e, o)));
+    });
+}
+
+void zk_decoder_free(zk_decoder *d) { delete d; }
+int64_t zk_decoder_decompress(zk_decoder *d, uint8_t *buf, size_t len)
+{
+    int64_t n = 0;
+    int rc = guard([&] { n = (int64_t)d->d.decompress(buf, len); });
+    return rc ? rc : n;
+}
+int zk_decoder_decompress_with_prefix(zk_decoder *d, uint8_t *buf, size_t len, const uint8_t *prefix, size_t plen, size_t *out)
+{
+    return guard([&] { *out = d->d.decompress_with_prefix(buf, len, prefix, plen); });
+}
+void zk_decoder_reset(zk_decoder *d) { d->d.reset(); }
+int zk_decoder_set_lower_frame(zk_decoder *d, uint32_t i, uint64_t *out) { return guard([&] { uint64_t v = d->d.set_lower_frame(i); if (out) *out = v; }); }
+int zk_decoder_set_upper_frame(zk_decoder *d, uint32_t i, uint64_t *out) { return guard([&] { uint64_t v = d->d.set_upper_frame(i); if (out) *out = v; }); }
+int zk_decoder_set_offset(zk_decoder *d, uint64_t off) { return guard([&] { d->d.set_offset(off); }); }
+int zk_decoder_set_offset_limit(zk_decoder *d, uint64_t lim) { return guard([&] { d->d.set_offset_limit(lim); }); }
+uint64_t zk_decoder_read_compressed(const zk_decoder *d) { return d->d.read_compressed(); }
+uint64_t zk_decoder_offset(const zk_decoder *d) { return d->d.offset(); }
+uint64_t zk_decoder_offset_limit(const zk_decoder *d) { return d->d.offset_limit(); }
+uint64_t zk_decoder_gpu_submissions(const zk_decoder *d) { return d->d.gpu_submissions(); }
+zk_seek_table *zk_decoder_seek_table(const zk_decoder *d) { return new (std::nothrow) zk_seek_table{d->d.seek_table()}; }
+int zk_decoder_seek(zk_decoder *d, int whence, int64_t n, uint64_t *out)
+{
+    return guard([&] {
+        Decoder::SeekFrom w = whence == ZK_SEEK_START ? Decoder::SeekFrom::Start : whence == ZK_SEEK_END ? Decoder::SeekFrom::End : Decoder::SeekFrom::Current;
+        uint64_t v = d->d.seek(w, n);
+        if (out) *out = v;
+    });
+}
+
+}  // extern "C"
