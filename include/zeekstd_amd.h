@@ -97,6 +97,25 @@ int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, c
                          const void *d_d_off, uint32_t first, uint32_t count, void *d_dst, uint64_t dst_cap,
                          int verify, void *d_frame_status, void *stream);
 
+/*
+ * Encode src[0, n) as ceil(n / frame_size) independent zstd frames (FrameSizePolicy::Uncompressed(frame_size),
+ * lib/src/encode.rs:21-39, 528-544; n == 0 yields one empty frame like Encoder::finish, encode.rs:755-757),
+ * concatenated in dst, and report the seek-table entries: c_sizes[i] / d_sizes[i] are what
+ * SeekTable::log_frame receives (seek_table.rs:513-525).  checksum != 0 appends the XXH64 Content_Checksum
+ * (ZSTD_c_checksumFlag, encode.rs:283-284).  level is ZSTD_c_compressionLevel (encode.rs:281-282): accepted
+ * for drop-in compatibility; the engine has one strategy (greedy hash matching, Huffman literals, predefined
+ * FSE tables) that every level maps to.  Replaces the ZSTD_compressStream2 loops of encode.rs:340-346, 442-464.
+ * dst_cap >= zk_compress_bound(n, frame_size) always suffices; otherwise -70 (dstSize_tooSmall) may come back.
+ */
+uint64_t zk_compress_bound(uint64_t n, uint32_t frame_size);
+int zk_encode_frames(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_size, int level, int checksum,
+                     uint8_t *dst, uint64_t dst_cap, uint32_t *c_sizes, uint32_t *d_sizes, uint32_t frames_cap,
+                     uint32_t *n_frames, uint64_t *written);
+/* Device-resident variant: d_src / d_dst / d_c_sizes / d_d_sizes (uint32 arrays, may be NULL) live in HBM. */
+int zk_encode_frames_dev(zk_engine *e, const void *d_src, uint64_t n, uint32_t frame_size, int level, int checksum,
+                         void *d_dst, uint64_t dst_cap, void *d_c_sizes, void *d_d_sizes, uint32_t *n_frames,
+                         uint64_t *written, void *stream);
+
 /* XXH64(seed 0) of count byte ranges data[off[i], off[i+1]) -> out[i].  (The checksum libzstd
  * computes when ZSTD_c_checksumFlag is set: encode.rs:163-167, 283-284.) */
 int zk_xxh64_frames(zk_engine *e, const uint8_t *data, const uint64_t *off, uint32_t count, uint64_t *out);

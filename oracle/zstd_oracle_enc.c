@@ -1,0 +1,376 @@
+/*
+ * zstd_oracle_enc.c -- TEST INFRASTRUCTURE: CPU twin of the GPU frame encoder (zeekstd_amd/csrc/zk_encode.hip).
+ *
+ * What the reference does here is libzstd's ZSTD_compressStream2 (lib/src/encode.rs:340-346, 442-464);
+ * compressed payload bytes are unpinned by the reference (libzstd 1.4.8 and 1.5.7 already
+ * differ), only validity + round trip.  This file restates, sequentially, the algorithm the HIP kernels
+ * run in parallel so that block/sequence/bitstream decisions can be compared kernel-vs-CPU byte for byte:
+ *   match finder : positions in tiles of ZKE_TILE; phase 1: every position of a tile looks its 5-byte hash up
+ *                  in a 2^14-entry table (window 64 KiB) as it was before the tile, and probes the offset of
+ *                  the last match taken before the tile; lengths capped at 64; then the tile is inserted
+ *   parse        : phase 2: greedy, left to right over the per-position results; capped matches are extended
+ *   literals     : Huffman (<= 11 bits, direct 4-bit weights) in 4 streams, or raw / RLE
+ *   sequences    : FSE with the PREDEFINED LL/OF/ML tables (Symbol_Compression_Modes = 0)
+ *   frame        : magic, FHD (checksum bit), Window_Descriptor, <=128 KiB blocks, optional XXH64
+ * Frames are checked by the oracle decoder AND by the real libzstd 1.5.7 / 1.4.8 in tests.
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef uint8_t u8; typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t u64; typedef int64_t i64;
+u64 zko_xxh64(const u8 *p, size_t len, u64 seed);
+
+#define ZKE_BLOCK 131072u
+#define ZKE_HASH_LOG 14
+#define ZKE_MINMATCH 6
+#define ZKE_WINDOW 65535u          /* 16-bit positions in the hash table */
+
+static int g_tile = 1024;
+void zko_enc_set_tile(int t) { g_tile = t; }
+
+static inline u32 hb32(u32 v) { return 31 - (u32)__builtin_clz(v); }
+static inline u64 ld64(const u8 *p) { u64 v; memcpy(&v, p, 8); return v; }
+static inline u32 hash5(const u8 *p) { return (u32)(((ld64(p) << 24) * 889523592379ULL) >> (64 - ZKE_HASH_LOG)); }
+
+/* ------------------------------------------------------------------ code tables (RFC 8878 3.1.1.3.2.1.1) */
+static const u8 LL_BITS[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
+static const u32 LL_BASE[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
+static const u8 ML_BITS[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16};
+static const u32 ML_BASE[53] = {3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,37,39,41,43,47,51,59,67,83,99,131,259,515,1027,2051,4099,8195,16387,32771,65539};
+static const short LL_DEF[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1};
+static const short OF_DEF[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
+static const short ML_DEF[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
+
+static u32 ll_code(u32 ll) { if (ll < 16) return ll; if (ll < 64) { static const u8 t[64] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24}; return t[ll]; } return hb32(ll) + 19; }
+static u32 ml_code(u32 mlb /* ml - 3 */) { if (mlb < 128) { static const u8 t[128] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,32,33,33,34,34,35,35,36,36,36,36,37,37,37,37,38,38,38,38,38,38,38,38,39,39,39,39,39,39,39,39,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42}; return t[mlb]; } return hb32(mlb) + 36; }
+
+/* ------------------------------------------------------------------ FSE compression tables for the predefined distributions */
+typedef struct { int al; u16 state[512]; int dfs[64]; u32 dnb[64]; } fse_ctable;
+static fse_ctable CT_LL, CT_OF, CT_ML;
+static int g_ct_ready;
+
+static void build_ctable(fse_ctable *ct, const short *norm, int nsym, int al)
+{
+    int size = 1 << al, mask = size - 1, step = (size >> 1) + (size >> 3) + 3, high = size - 1;
+    u8 sym[512]; int cumul[66];
+    ct->al = al;
+    cumul[0] = 0;
+    for (int u = 1; u <= nsym; u++) {
+        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; sym[high--] = (u8)(u - 1); }
+        else cumul[u] = cumul[u - 1] + norm[u - 1];
+    }
+    int pos = 0;
+    for (int s = 0; s < nsym; s++) for (int i = 0; i < norm[s]; i++) { sym[pos] = (u8)s; do pos = (pos + step) & mask; while (pos > high); }
+    for (int u = 0; u < size; u++) { int s = sym[u]; ct->state[cumul[s]++] = (u16)(size + u); }
+    int total = 0;
+    for (int s = 0; s < nsym; s++) {
+        if (norm[s] == 0) { ct->dnb[s] = ((u32)(al + 1) << 16) - (1u << al); ct->dfs[s] = 0; }
+        else if (norm[s] == -1 || norm[s] == 1) { ct->dnb[s] = ((u32)al << 16) - (1u << al); ct->dfs[s] = total - 1; total++; }
+        else { u32 mbo = (u32)al - hb32((u32)norm[s] - 1); u32 msp = (u32)norm[s] << mbo; ct->dnb[s] = (mbo << 16) - msp; ct->dfs[s] = total - norm[s]; total += norm[s]; }
+    }
+}
+static void ct_init(void)
+{
+    if (g_ct_ready) return;
+    build_ctable(&CT_LL, LL_DEF, 36, 6); build_ctable(&CT_OF, OF_DEF, 29, 5); build_ctable(&CT_ML, ML_DEF, 53, 6);
+    g_ct_ready = 1;
+}
+/* exported so the GPU engine's host-built tables can be compared with these */
+void zko_enc_ctable(int which, u16 *state, int *dfs, u32 *dnb)
+{
+    ct_init();
+    fse_ctable *c = which == 0 ? &CT_LL : which == 1 ? &CT_OF : &CT_ML;
+    memcpy(state, c->state, sizeof(u16) << c->al); memcpy(dfs, c->dfs, sizeof c->dfs); memcpy(dnb, c->dnb, sizeof c->dnb);
+}
+
+/* ------------------------------------------------------------------ forward bit writer (LSB first) */
+typedef struct { u8 *p; size_t cap, pos; u64 acc; int n; int ovf; } bitw;
+static void bw_init(bitw *b, u8 *p, size_t cap) { b->p = p; b->cap = cap; b->pos = 0; b->acc = 0; b->n = 0; b->ovf = 0; }
+static void bw_add(bitw *b, u32 v, int n)
+{
+    if (!n) return;
+    b->acc |= (u64)(v & ((n == 32) ? 0xFFFFFFFFu : ((1u << n) - 1))) << b->n; b->n += n;
+    while (b->n >= 8) { if (b->pos < b->cap) b->p[b->pos] = (u8)b->acc; else b->ovf = 1; b->pos++; b->acc >>= 8; b->n -= 8; }
+}
+static size_t bw_close(bitw *b) { bw_add(b, 1, 1); if (b->n) { if (b->pos < b->cap) b->p[b->pos] = (u8)b->acc; else b->ovf = 1; b->pos++; } return b->ovf ? 0 : b->pos; }
+
+/* ------------------------------------------------------------------ sequences */
+typedef struct { u32 ll, ml, offbase; } seq_t;      /* offbase = Offset_Value (>3: offset+3, 1..3: repeat codes) */
+
+static size_t encode_sequences(const seq_t *sq, u32 n, u8 *dst, size_t cap)
+{
+    ct_init();
+    bitw b; bw_init(&b, dst, cap);
+    u32 llc = ll_code(sq[n - 1].ll), mlc = ml_code(sq[n - 1].ml - 3), ofc = hb32(sq[n - 1].offbase);
+#define CINIT(ct, s, st) do { u32 nb = ((ct).dnb[s] + (1u << 15)) >> 16; u32 v = (nb << 16) - (ct).dnb[s]; st = (ct).state[(v >> nb) + (u32)(ct).dfs[s]]; } while (0)
+#define CENC(ct, s, st) do { u32 nb = (st + (ct).dnb[s]) >> 16; bw_add(&b, st, (int)nb); st = (ct).state[(st >> nb) + (u32)(ct).dfs[s]]; } while (0)
+    u32 sm, so, sl;
+    CINIT(CT_ML, mlc, sm); CINIT(CT_OF, ofc, so); CINIT(CT_LL, llc, sl);
+    bw_add(&b, sq[n - 1].ll - LL_BASE[llc], LL_BITS[llc]);
+    bw_add(&b, sq[n - 1].ml - ML_BASE[mlc], ML_BITS[mlc]);
+    bw_add(&b, sq[n - 1].offbase - (1u << ofc), (int)ofc);
+    for (u32 i = n - 1; i-- > 0;) {
+        llc = ll_code(sq[i].ll); mlc = ml_code(sq[i].ml - 3); ofc = hb32(sq[i].offbase);
+        CENC(CT_OF, ofc, so); CENC(CT_ML, mlc, sm); CENC(CT_LL, llc, sl);
+        bw_add(&b, sq[i].ll - LL_BASE[llc], LL_BITS[llc]);
+        bw_add(&b, sq[i].ml - ML_BASE[mlc], ML_BITS[mlc]);
+        bw_add(&b, sq[i].offbase - (1u << ofc), (int)ofc);
+    }
+    bw_add(&b, sm, CT_ML.al); bw_add(&b, so, CT_OF.al); bw_add(&b, sl, CT_LL.al);
+    return bw_close(&b);
+}
+
+/* ------------------------------------------------------------------ Huffman */
+/* code lengths (<= 11) from counts: package by repeated count halving until the tree fits */
+static int huf_lengths(const u32 *cnt_in, int nsym, u8 *len)
+{
+    u32 cnt[256]; int idx[256], m = 0;
+    memcpy(cnt, cnt_in, sizeof(u32) * (size_t)nsym);
+    for (;;) {
+        m = 0;
+        for (int s = 0; s < nsym; s++) if (cnt[s]) idx[m++] = s;
+        if (m < 2) return -1;
+        /* two-queue Huffman over symbols sorted by (count, symbol) */
+        for (int i = 1; i < m; i++) { int k = idx[i], j = i - 1; while (j >= 0 && (cnt[idx[j]] > cnt[k] || (cnt[idx[j]] == cnt[k] && idx[j] > k))) { idx[j + 1] = idx[j]; j--; } idx[j + 1] = k; }
+        u32 w[512]; int parent[512]; int nn = m;
+        for (int i = 0; i < m; i++) w[i] = cnt[idx[i]];
+        int a = 0, bq = m;                       /* leaves queue [a, m), internal queue [bq, nn) */
+        while ((m - a) + (nn - bq) > 1) {
+            int p[2];
+            for (int k = 0; k < 2; k++) {
+                if (a < m && (bq >= nn || w[a] <= w[bq])) p[k] = a++; else p[k] = bq++;
+            }
+            w[nn] = w[p[0]] + w[p[1]]; parent[p[0]] = parent[p[1]] = nn; nn++;
+        }
+        int maxd = 0; u8 depth[512];
+        depth[nn - 1] = 0;
+        for (int i = nn - 2; i >= 0; i--) { depth[i] = (u8)(depth[parent[i]] + 1); }
+        for (int i = 0; i < m; i++) if (depth[i] > maxd) maxd = depth[i];
+        if (maxd <= 11) {
+            memset(len, 0, (size_t)nsym);
+            for (int i = 0; i < m; i++) len[idx[i]] = depth[i];
+            return maxd;
+        }
+        for (int s = 0; s < nsym; s++) if (cnt[s]) cnt[s] = (cnt[s] + 1) >> 1;      /* flatten and retry */
+    }
+}
+
+/* canonical codes as the decoder builds them: weight = maxbits+1-len; table filled weight 1 first,
+ * symbols ascending; code value = (table index) >> (maxbits - len), read MSB first */
+static void huf_codes(const u8 *len, int nsym, int maxbits, u16 *code)
+{
+    u32 pos = 0;
+    for (int wt = 1; wt <= maxbits; wt++)
+        for (int s = 0; s < nsym; s++) if (len[s] && maxbits + 1 - len[s] == wt) { code[s] = (u16)(pos >> (wt - 1)); pos += 1u << (wt - 1); }
+}
+
+static size_t huf_encode_stream(const u8 *lit, size_t n, const u8 *len, const u16 *code, u8 *dst, size_t cap)
+{
+    bitw b; bw_init(&b, dst, cap);
+    for (size_t i = n; i-- > 0;) bw_add(&b, code[lit[i]], len[lit[i]]);      /* last symbol first: decoder reads backward */
+    return bw_close(&b);
+}
+
+/* literals section. Returns bytes written (0 on failure/overflow). */
+static size_t encode_literals(const u8 *lit, size_t n, u8 *dst, size_t cap)
+{
+    /* RLE / tiny / raw fallbacks */
+    int same = n > 0;
+    for (size_t i = 1; i < n && same; i++) same = lit[i] == lit[0];
+    size_t raw_hdr = n < 32 ? 1 : n < 4096 ? 2 : 3;
+    if (same && n > 0) {
+        if (cap < raw_hdr + 1) return 0;
+        if (raw_hdr == 1) dst[0] = (u8)(1 | (n << 3)); else if (raw_hdr == 2) { dst[0] = (u8)(1 | (1 << 2) | (n << 4)); dst[1] = (u8)(n >> 4); }
+        else { dst[0] = (u8)(1 | (3 << 2) | (n << 4)); dst[1] = (u8)(n >> 4); dst[2] = (u8)(n >> 12); }
+        dst[raw_hdr] = lit[0];
+        return raw_hdr + 1;
+    }
+    u32 cnt[256] = {0}; int maxsym = 0;
+    for (size_t i = 0; i < n; i++) cnt[lit[i]]++;
+    for (int s = 0; s < 256; s++) if (cnt[s]) maxsym = s;
+    size_t out = 0;
+    if (n >= 64 && maxsym < 128) {                                   /* direct 4-bit weights cover symbols 0..127 */
+        u8 len[256]; u16 code[256];
+        int nsym = maxsym + 1;
+        int maxbits = huf_lengths(cnt, nsym, len);
+        if (maxbits > 0) {
+            huf_codes(len, nsym, maxbits, code);
+            u8 tmp[ZKE_BLOCK + 1024];
+            size_t hdr = n < 1024 ? 3 : n < 16384 ? 4 : 5;           /* 4 streams always (>= 64 literals) */
+            size_t p = hdr;
+            /* tree: weights of symbols 0..nsym-2 (the last one is implied) */
+            int nw = nsym - 1;
+            tmp[p++] = (u8)(127 + nw);
+            for (int i = 0; i < nw; i += 2) {
+                u8 w0 = len[i] ? (u8)(maxbits + 1 - len[i]) : 0, w1 = (i + 1 < nw && len[i + 1]) ? (u8)(maxbits + 1 - len[i + 1]) : 0;
+                tmp[p++] = (u8)((w0 << 4) | w1);
+            }
+            size_t q = (n + 3) / 4, jt = p; p += 6;
+            size_t sizes[4]; int ok = 1;
+            for (int k = 0; k < 4 && ok; k++) {
+                size_t cnt_k = k < 3 ? q : n - 3 * q;
+                sizes[k] = huf_encode_stream(lit + k * q, cnt_k, len, code, tmp + p, sizeof tmp - p);
+                if (!sizes[k] || (k < 3 && sizes[k] > 65535)) ok = 0;
+                p += sizes[k];
+            }
+            size_t comp = p - hdr;
+            if (ok && comp < n - (n >> 6) && comp < (hdr == 3 ? 1024u : hdr == 4 ? 16384u : 262144u)) {
+                for (int k = 0; k < 3; k++) { tmp[jt + 2 * k] = (u8)sizes[k]; tmp[jt + 2 * k + 1] = (u8)(sizes[k] >> 8); }
+                u64 h;
+                if (hdr == 3) h = 2 | (1 << 2) | ((u64)n << 4) | ((u64)comp << 14);
+                else if (hdr == 4) h = 2 | (2 << 2) | ((u64)n << 4) | ((u64)comp << 18);
+                else h = 2 | (3 << 2) | ((u64)n << 4) | ((u64)comp << 22);
+                for (size_t i = 0; i < hdr; i++) tmp[i] = (u8)(h >> (8 * i));
+                if (p > cap) return 0;
+                memcpy(dst, tmp, p);
+                out = p;
+            }
+        }
+    }
+    if (!out) {                                                      /* raw literals */
+        if (cap < raw_hdr + n) return 0;
+        if (raw_hdr == 1) dst[0] = (u8)(n << 3); else if (raw_hdr == 2) { dst[0] = (u8)((1 << 2) | (n << 4)); dst[1] = (u8)(n >> 4); }
+        else { dst[0] = (u8)((3 << 2) | (n << 4)); dst[1] = (u8)(n >> 4); dst[2] = (u8)(n >> 12); }
+        memcpy(dst + raw_hdr, lit, n);
+        out = raw_hdr + n;
+    }
+    return out;
+}
+
+/* ------------------------------------------------------------------ match finder + parse for one block */
+#define ZKE_PARCAP 64u              /* match length measured per position in the parallel phase; longer ones are extended by the parse */
+typedef struct { u32 table[1 << ZKE_HASH_LOG]; u32 probe; } enc_state;   /* table: frame-relative position + 1 (0 = empty) */
+
+static u32 match_len(const u8 *a, const u8 *b, const u8 *end)        /* b > a */
+{
+    const u8 *s = b;
+    while (b + 8 <= end) { u64 x = ld64(a) ^ ld64(b); if (x) return (u32)(b - s) + (u32)(__builtin_ctzll(x) >> 3); a += 8; b += 8; }
+    while (b < end && *a == *b) { a++; b++; }
+    return (u32)(b - s);
+}
+
+/* offset -> Offset_Value.  rep[] is the history the DECODER will have; an entry of 0 means "not known to
+ * the encoder": every block starts with an unknown history because the previous block may still be
+ * emitted raw/RLE (which would leave the decoder's history untouched) -- the decision is taken after
+ * all blocks of the frame have been parsed. */
+static u32 off_to_code(u32 off, u32 ll, u32 *rep)
+{
+    u32 code = off + 3;
+    if (ll) { if (off == rep[0]) code = 1; else if (off == rep[1] && rep[0]) code = 2; else if (off == rep[2] && rep[0] && rep[1]) code = 3; }
+    else { if (off == rep[1] && rep[0]) code = 1; else if (off == rep[2] && rep[0] && rep[1]) code = 2; else if (rep[0] > 1 && off == rep[0] - 1 && rep[1]) code = 3; }
+    if (code > 3) { rep[2] = rep[1]; rep[1] = rep[0]; rep[0] = off; }
+    else {
+        u32 idx = code - 1 + (ll == 0);
+        if (idx) { u32 v = idx == 3 ? rep[0] - 1 : rep[idx]; if (idx > 1) rep[2] = rep[1]; rep[1] = rep[0]; rep[0] = v; }
+    }
+    return code;
+}
+
+/* frame-relative positions; base = frame start. Emits sequences for block [bs, be). */
+static u32 find_sequences(enc_state *st, const u8 *base, u32 bs, u32 be, u32 fend, seq_t *sq, u8 *lits, u32 *nlit_out)
+{
+    u32 nseq = 0, nlit = 0, anchor = bs, next = bs;                  /* next: first position the parse may still use */
+    static u32 blen[8192], boff[8192];
+    u32 rep[3] = {0, 0, 0};
+    const u8 *lim = base + be;                                       /* matches stop at the block end */
+    for (u32 ts = bs; ts < be; ts += (u32)g_tile) {
+        u32 te = ts + (u32)g_tile < be ? ts + (u32)g_tile : be;
+        const u32 R = st->probe;                                     /* offset of the last match taken before this tile */
+        /* phase 1 (parallel on the GPU): per position, the hash candidate from the table as it was BEFORE
+         * the tile, and the probe at offset R; lengths capped at ZKE_PARCAP */
+        for (u32 p = ts; p < te; p++) {
+            u32 l1 = 0, o1 = 0, l2 = 0;
+            if (p + 8 <= fend) {
+                u32 e = st->table[hash5(base + p)];
+                if (e && p - (e - 1) <= ZKE_WINDOW) { o1 = p - (e - 1); l1 = match_len(base + p - o1, base + p, base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim); }
+            }
+            if (R && R <= p) l2 = match_len(base + p - R, base + p, base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim);
+            if (l1 < ZKE_MINMATCH) l1 = 0;
+            if (l2 < 4) l2 = 0;
+            if (l2 && l2 >= l1) { blen[p - ts] = l2; boff[p - ts] = R; }
+            else { blen[p - ts] = l1; boff[p - ts] = o1; }
+        }
+        /* phase 1b: insert the tile (largest position wins a slot) */
+        for (u32 p = ts; p < te; p++) if (p + 8 <= fend) st->table[hash5(base + p)] = p + 1;
+        /* phase 2: greedy parse of the tile */
+        u32 p = next > ts ? next : ts;
+        while (p < te) {
+            u32 len = blen[p - ts];
+            if (len) {
+                u32 off = boff[p - ts];
+                if (len == ZKE_PARCAP) len += match_len(base + p + len - off, base + p + len, lim);
+                u32 ll = p - anchor;
+                memcpy(lits + nlit, base + anchor, ll); nlit += ll;
+                sq[nseq].ll = ll; sq[nseq].ml = len; sq[nseq].offbase = off_to_code(off, ll, rep); nseq++;
+                st->probe = off;
+                p += len; anchor = p;
+            } else p++;
+        }
+        next = p;
+    }
+    memcpy(lits + nlit, base + anchor, be - anchor); nlit += be - anchor;
+    *nlit_out = nlit;
+    return nseq;
+}
+
+/* ------------------------------------------------------------------ frame */
+static size_t nseq_header(u8 *d, u32 n) { if (n < 128) { d[0] = (u8)n; return 1; } if (n < 0x7F00) { d[0] = (u8)((n >> 8) + 128); d[1] = (u8)n; return 2; } d[0] = 255; d[1] = (u8)(n - 0x7F00); d[2] = (u8)((n - 0x7F00) >> 8); return 3; }
+
+/* Encode src[0..n) as ONE zstd frame. level is accepted for API symmetry (single strategy). Returns size or <0. */
+i64 zko_frame_encode(const u8 *src, size_t n, u8 *dst, size_t cap, int level, int checksum)
+{
+    (void)level;
+    if (n > 0x40000000u) return -72;
+    size_t p = 0;
+    if (cap < 32) return -70;
+    if (n == 0) {                                                    /* exactly what the reference emits for an empty frame */
+        static const u8 e[9] = {0x28, 0xB5, 0x2F, 0xFD, 0x20, 0x00, 0x01, 0x00, 0x00};
+        memcpy(dst, e, 9); p = 9; dst[4] = checksum ? 0x24 : 0x20;
+        if (checksum) { u32 h = (u32)zko_xxh64(src, 0, 0); memcpy(dst + p, &h, 4); p += 4; }
+        return (i64)p;
+    }
+    dst[0] = 0x28; dst[1] = 0xB5; dst[2] = 0x2F; dst[3] = 0xFD; dst[4] = checksum ? 0x04 : 0x00;
+    /* Window_Descriptor: smallest power of two >= min(n, 64 KiB reach) but at least 1 KiB; blocks need window >= block size */
+    u32 wlog = 10; while ((1u << wlog) < n && wlog < 17) wlog++;     /* <= 128 KiB: offsets never exceed 65535 */
+    dst[5] = (u8)((wlog - 10) << 3);
+    p = 6;
+    enc_state *st = calloc(1, sizeof *st);
+    seq_t *sq = malloc(sizeof(seq_t) * (ZKE_BLOCK / 3 + 8));
+    u8 *lits = malloc(ZKE_BLOCK + 64), *body = malloc(ZKE_BLOCK * 2);
+    st->probe = 1;                                                   /* first probe: offset 1 (runs) */
+    i64 rc = 0;
+    u32 bmax = (1u << wlog) < ZKE_BLOCK ? (1u << wlog) : ZKE_BLOCK;
+    for (u32 bs = 0; bs < n; bs += bmax) {
+        u32 be = bs + bmax < n ? bs + bmax : (u32)n;
+        u32 bsz = be - bs, last = be == n;
+        u32 nlit = 0;
+        u32 nseq = find_sequences(st, src, bs, be, (u32)n, sq, lits, &nlit);
+        size_t b = encode_literals(lits, nlit, body, ZKE_BLOCK * 2);
+        size_t total = 0;
+        if (b) {
+            b += nseq_header(body + b, nseq);
+            if (nseq) {
+                body[b++] = 0;                                       /* predefined LL / OF / ML */
+                size_t s = encode_sequences(sq, nseq, body + b, ZKE_BLOCK * 2 - b);
+                if (s) total = b + s;
+            } else total = b;
+        }
+        int rle = 1;
+        for (u32 i = 1; i < bsz && rle; i++) rle = src[bs + i] == src[bs];
+        if (p + 3 + bsz + 8 > cap) { rc = -70; break; }
+        if (rle && bsz > 1) {                                        /* RLE block */
+            u32 h = last | (1 << 1) | (bsz << 3); dst[p] = (u8)h; dst[p + 1] = (u8)(h >> 8); dst[p + 2] = (u8)(h >> 16); dst[p + 3] = src[bs]; p += 4;
+        } else if (total && total < bsz) {
+            u32 h = last | (2 << 1) | ((u32)total << 3); dst[p] = (u8)h; dst[p + 1] = (u8)(h >> 8); dst[p + 2] = (u8)(h >> 16); p += 3;
+            memcpy(dst + p, body, total); p += total;
+        } else {                                                     /* raw block */
+            u32 h = last | (bsz << 3); dst[p] = (u8)h; dst[p + 1] = (u8)(h >> 8); dst[p + 2] = (u8)(h >> 16); p += 3;
+            memcpy(dst + p, src + bs, bsz); p += bsz;
+        }
+    }
+    if (rc == 0 && checksum) { if (p + 4 > cap) rc = -70; else { u32 h = (u32)zko_xxh64(src, n, 0); memcpy(dst + p, &h, 4); p += 4; } }
+    free(st); free(sq); free(lits); free(body);
+    return rc ? rc : (i64)p;
+}

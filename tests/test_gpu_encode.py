@@ -1,0 +1,90 @@
+"""HIP encode path (C ABI zk_encode_frames): frames must be valid zstd -- accepted by the CPU oracle decoder,
+by the real libzstd (1.4.8 on the box) and by the GPU decoder -- round-trip bit-exact, carry the right seek
+entries / checksums, and be byte-identical to the CPU twin of the algorithm (oracle/zstd_oracle_enc.c).
+Reference behaviour restated: lib/src/encode.rs:834-870 (checksum flag bit in every frame header),
+lib/src/lib.rs:82-134, 315-357 (round trips at many frame sizes), Appendix B empty-frame bytes."""
+import numpy as np
+import pytest
+
+from conftest import offsets_from_frames
+from oracle import zko
+from oracle import libzstd_ref as Z
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "empty": [], "one": [["rep", "41", 1]], "hello": [["rep", b"Hello, World!".hex(), 1]],
+    "text": [["chunks", (5 << 20) + 1234, 3]], "zeros": [["zeros", 300000]], "random": [["random", 200000, 3]],
+    "mixed": [["random", 30000, 22], ["text", 120000, 23], ["zeros", 40000], ["rep", "616263", 20000], ["text", 50000, 23],
+              ["rep", "6162", 3000], ["rep", "78", 70000]],
+    "records": [["records", 6000, 99, b"0123456789abcdefghij".hex()]],
+    "slices": [["slices", 100000, 77, 9000, 5, 8, 40, "ff"]],
+    "binary": [["random", 1000, 5], ["rep", "00ff80c1", 30000], ["random", 50000, 6]],
+    "short63": [["text", 63, 1]], "t1000": [["text", 1000, 3]], "t131073": [["text", 131073, 5]],
+}
+
+
+def check_payload(engine, data, comp, frames, frame_size, checksum):
+    assert sum(d for _, d in frames) == len(data) and sum(c for c, _ in frames) == len(comp)
+    pos = dpos = 0
+    for c, d in frames:
+        assert d == min(frame_size, len(data) - dpos) or (len(data) == 0 and d == 0)
+        f = comp[pos:pos + c]
+        assert f[:4] == b"\x28\xb5\x2f\xfd"
+        assert bool(f[4] & 0x04) == checksum                         # encode.rs:834-870
+        out, used = zko.frame_decode(f, d, True)                      # CPU oracle decoder accepts it
+        assert used == c and out == data[dpos:dpos + d]
+        pos += c; dpos += d
+    if Z.load("system") is not None:                                  # the real libzstd accepts it
+        assert Z.decode_stream(comp, len(data), "system") == data
+    c_off, d_off = offsets_from_frames(frames)
+    out, st = engine.decode_frames(comp + b"\0" * 8, c_off, d_off, verify=True)   # and so does the GPU decoder
+    assert not st.any() and out == data
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("checksum", [False, True])
+def test_encode_roundtrip_and_twin(engine, name, checksum):
+    data = zko.make_input(CASES[name])
+    fs = 2 << 20
+    comp, frames = engine.encode_frames(data, fs, 1, checksum)
+    check_payload(engine, data, comp, frames, fs, checksum)
+    # byte-identical to the CPU twin, frame by frame
+    pos = dpos = 0
+    for c, d in frames:
+        assert comp[pos:pos + c] == zko.frame_encode(data[dpos:dpos + d], 1, checksum), (name, dpos)
+        pos += c; dpos += d
+
+
+def test_empty_frame_golden_bytes(engine):
+    # what the reference emits for end_frame() without input
+    assert engine.encode_frames(b"", 2 << 20, 1, False) == (bytes.fromhex("28b52ffd2000010000"), [(9, 0)])
+    assert engine.encode_frames(b"", 2 << 20, 1, True) == (bytes.fromhex("28b52ffd240001000099e9d851"), [(13, 0)])
+
+
+@pytest.mark.parametrize("fs", [10, 100, 123, 1000, 3000, 65536, 70000, 131072, 200000])
+def test_frame_sizes(engine, fs):            # lib.rs:315-357 (proptest 1..1023) / cli tests 10,123,3K,2M
+    data = zko.make_input([["text", 40000 if fs < 3000 else 700001, 100 + fs % 7], ["zeros", 5000], ["random", 3000, 2]])
+    comp, frames = engine.encode_frames(data, fs, 3, True)
+    check_payload(engine, data, comp, frames, fs, True)
+
+
+def test_compression_ratio_sanity(engine):
+    data = zko.gen_chunks(8 << 20)
+    comp, frames = engine.encode_frames(data, 2 << 20, 1, True)
+    assert len(frames) == 4 and len(data) / len(comp) > 2.0          # text: libzstd level 1 gets ~2.5
+    z, _ = engine.encode_frames(bytes(4 << 20), 2 << 20, 1, False)
+    assert len(z) < 200
+    r = zko.gen_random(1 << 20, 9)
+    c, _ = engine.encode_frames(r, 2 << 20, 1, False)
+    assert len(c) <= len(r) + 64                                      # incompressible: raw blocks
+
+
+def test_roundtrip_property(engine):         # fuzz/fuzz_targets/roundtrip_basic.rs at 100-byte frames
+    rng = np.random.default_rng(1)
+    for i in range(30):
+        n = int(rng.integers(0, 5000))
+        kind = i % 3
+        data = zko.gen_text(n, i) if kind == 0 else zko.gen_random(n, i) if kind == 1 else (zko.gen_text(max(1, n // 7), i) * 7)[:n]
+        comp, frames = engine.encode_frames(data, 100, 1, bool(i & 1))
+        check_payload(engine, data, comp, frames, 100, bool(i & 1))

@@ -1,0 +1,434 @@
+// zk_encode.hip -- gfx950 kernels of the batched seekable-zstd frame encoder.
+//
+// Replaces, for N frames at a time, what the reference does through ZSTD_compressStream2
+// (lib/src/encode.rs:340-346 hot loop, 442-464 epilogue; libzstd 1.5.7 underneath) plus the seek-table
+// bookkeeping of SeekTable::log_frame (lib/src/seek_table.rs:513-525): (c_size, d_size) per frame are
+// produced on the device.  Compressed bytes are not pinned by the reference (only validity / round trip);
+// the CPU twin of this algorithm is oracle/zstd_oracle_enc.c and the GPU output is byte-identical to it.
+//
+// Pipeline (one stream, everything resident in HBM):
+//   zk_k_xxh64        (checksum_flag) XXH64 of every frame's input
+//   zk_k_enc_match    one workgroup per frame: tiles of 1024 positions -- phase 1 all lanes: 5-byte hash
+//                     lookup in a 2^14-entry LDS table + probe of the last offset, lengths capped at 64;
+//                     phase 1b insert (atomicMax); phase 2 wave 0: greedy parse with ballot skipping,
+//                     wave-wide literal copies -> packed sequences + literal buffer per <=128 KiB block
+//   zk_k_enc_entropy  one workgroup per block: literal histogram, Huffman lengths (<= 11 bits), 4 literal
+//                     streams (4 lanes) and the FSE sequence bitstream with the predefined tables (1 lane)
+//                     side by side, block payload assembled in scratch, raw / RLE fallbacks decided
+//   zk_k_enc_sizes    per frame: compressed size = header + blocks (+ checksum)   -> seek-table entries
+//   zk_k_scan64       exclusive scan of the frame sizes -> where each frame lands in the output stream
+//   zk_k_enc_assemble one workgroup per frame: frame header, block headers, payload copies into the
+//                     final contiguous stream
+// HBM-bound integer/byte work; no MFMA.
+#include <hip/hip_runtime.h>
+#include "zk_device.h"
+#include "zk_enc_device.h"
+#include "zk_kernels.h"
+
+// ------------------------------------------------------------------------------------------------ match + parse
+constexpr int ZKE_THREADS = 256;
+
+__device__ __forceinline__ uint32_t zke_match_len(const uint8_t *a, const uint8_t *b, const uint8_t *end)   // b > a
+{
+    const uint8_t *s = b;
+    while (b + 8 <= end) {
+        uint64_t x = zk_ld64(a) ^ zk_ld64(b);
+        if (x) return (uint32_t)(b - s) + (uint32_t)(__builtin_ctzll(x) >> 3);
+        a += 8; b += 8;
+    }
+    while (b < end && *a == *b) { a++; b++; }
+    return (uint32_t)(b - s);
+}
+
+__global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
+                                                              uint64_t *seqs, uint8_t *lits)
+{
+    __shared__ uint32_t table[1 << ZKE_HASH_LOG];          // frame-relative position + 1, 0 = empty
+    __shared__ uint32_t best[ZKE_TILE];                    // len (7 bits) | offset << 8
+    __shared__ uint32_t s_probe;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ZkEncFrame fr = frames[blockIdx.x];
+    const uint8_t *base = src + fr.src_off;
+    const uint32_t fend = fr.d_size;
+    for (uint32_t i = tid; i < (1u << ZKE_HASH_LOG); i += ZKE_THREADS) table[i] = 0;
+    if (tid == 0) s_probe = 1;
+    __syncthreads();
+    // parse state, uniform over wave 0
+    uint32_t probe = 1;
+    for (uint32_t bi = 0; bi < fr.n_blocks; bi++) {
+        const uint32_t bs = bi * fr.block_max;
+        const uint32_t be = bs + fr.block_max < fend ? bs + fr.block_max : fend;
+        ZkEncBlock *blk = &blocks[fr.block_base + bi];
+        uint64_t *sq = seqs + blk->seq_base;
+        uint8_t *lt = lits + blk->lit_base;
+        const uint8_t *lim = base + be;
+        uint32_t nseq = 0, nlit = 0, anchor = bs, next = bs;
+        uint32_t rep0 = 0, rep1 = 0, rep2 = 0;
+        for (uint32_t ts = bs; ts < be; ts += ZKE_TILE) {
+            const uint32_t te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
+            const uint32_t R = s_probe;
+            // phase 1: candidates of every position, from the table as it was before this tile
+            uint32_t hsh[ZKE_TILE / ZKE_THREADS];
+#pragma unroll
+            for (int k = 0; k < ZKE_TILE / ZKE_THREADS; k++) {
+                const uint32_t p = ts + tid + k * ZKE_THREADS;
+                uint32_t l1 = 0, o1 = 0, l2 = 0;
+                hsh[k] = 0xFFFFFFFFu;
+                if (p < te) {
+                    const uint8_t *cap = base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim;
+                    if (p + 8 <= fend) {
+                        hsh[k] = zke_hash5(base + p);
+                        const uint32_t e = table[hsh[k]];
+                        if (e && p - (e - 1) <= ZKE_WINDOW) { o1 = p - (e - 1); l1 = zke_match_len(base + p - o1, base + p, cap); }
+                    }
+                    if (R && R <= p) l2 = zke_match_len(base + p - R, base + p, cap);
+                    if (l1 < ZKE_MINMATCH) l1 = 0;
+                    if (l2 < 4) l2 = 0;
+                    best[p - ts] = (l2 && l2 >= l1) ? (l2 | (R << 8)) : (l1 | (o1 << 8));
+                }
+            }
+            __syncthreads();
+            // phase 1b: insert the tile, the largest position wins a slot
+#pragma unroll
+            for (int k = 0; k < ZKE_TILE / ZKE_THREADS; k++) {
+                const uint32_t p = ts + tid + k * ZKE_THREADS;
+                if (hsh[k] != 0xFFFFFFFFu) atomicMax(&table[hsh[k]], p + 1);
+            }
+            // phase 2: greedy parse by wave 0
+            if (wave == 0) {
+                uint32_t p = next > ts ? next : ts;
+                while (p < te) {
+                    const uint32_t pos = p + lane;
+                    const uint32_t v = pos < te ? best[pos - ts] : 0;
+                    const uint64_t mask = __ballot((v & 0xFF) != 0);
+                    if (mask == 0) { p = p + 64 < te ? p + 64 : te; continue; }
+                    const int first = __builtin_ctzll(mask);
+                    p += (uint32_t)first;
+                    const uint32_t e = __shfl(v, first, 64);
+                    uint32_t len = e & 0xFF;
+                    const uint32_t off = e >> 8;
+                    if (len == ZKE_PARCAP) {                 // capped in phase 1: extend, 64 bytes per step
+                        for (;;) {
+                            const uint8_t *q = base + p + len + lane;
+                            const bool diff = q >= lim || *q != *(q - off);
+                            const uint64_t m = __ballot(diff);
+                            if (m) { len += (uint32_t)__builtin_ctzll(m); break; }
+                            len += 64;
+                        }
+                    }
+                    const uint32_t ll = p - anchor;
+                    for (uint32_t i = lane; i < ll; i += 64) lt[nlit + i] = base[anchor + i];
+                    nlit += ll;
+                    const uint32_t code = zke_off_to_code(off, ll, rep0, rep1, rep2);
+                    if (lane == 0) sq[nseq] = (uint64_t)ll | ((uint64_t)len << 20) | ((uint64_t)code << 40);
+                    nseq++;
+                    probe = off;
+                    p += len; anchor = p;
+                }
+                next = p;
+                if (lane == 0) s_probe = probe;
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            const uint32_t tail = be - anchor;
+            for (uint32_t i = lane; i < tail; i += 64) lt[nlit + i] = base[anchor + i];
+            nlit += tail;
+            if (lane == 0) { blk->nseq = nseq; blk->nlit = nlit; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ entropy stage
+// LSB-first bit writer into global scratch (one lane).
+struct ZkeBits {
+    uint8_t *p; uint32_t cap, pos; uint64_t acc; uint32_t n; bool ovf;
+    __device__ __forceinline__ void init(uint8_t *p_, uint32_t cap_) { p = p_; cap = cap_; pos = 0; acc = 0; n = 0; ovf = false; }
+    __device__ __forceinline__ void add(uint32_t v, uint32_t nb)
+    {
+        acc |= (uint64_t)(v & ((1u << nb) - 1u)) << n; n += nb;          // nb <= 24
+        if (n >= 32) {
+            if (pos + 4 <= cap) { uint32_t w = (uint32_t)acc; memcpy(p + pos, &w, 4); } else ovf = true;
+            pos += 4; acc >>= 32; n -= 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t close()
+    {
+        add(1, 1);
+        while (n > 0) { if (pos < cap) p[pos] = (uint8_t)acc; else ovf = true; pos++; acc >>= 8; n = n > 8 ? n - 8 : 0; }
+        return ovf ? 0u : pos;
+    }
+};
+
+constexpr int ZKE_ENT_THREADS = 128;
+
+__global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
+                                                                   const uint64_t *seqs, const uint8_t *lits, uint8_t *scratch,
+                                                                   const ZkEncTables *tabs)
+{
+    __shared__ uint32_t cnt[256];
+    __shared__ ZkEncTables T;                              // predefined FSE compression tables
+    __shared__ ZkHufWork hw;
+    __shared__ uint32_t s_sizes[5];                        // 4 literal streams + sequence bitstream
+    __shared__ uint32_t s_lit_mode, s_maxbits, s_hdr, s_tree, s_all_same, s_mode;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ZkEncBlock *blk = &blocks[blockIdx.x];
+    const ZkEncFrame fr = frames[blk->frame];
+    const uint8_t *raw = src + fr.src_off + blk->bs;
+    const uint32_t bsz = blk->bsz, nlit = blk->nlit, nseq = blk->nseq;
+    const uint8_t *lt = lits + blk->lit_base;
+    const uint64_t *sq = seqs + blk->seq_base;
+    uint8_t *scr = scratch + blk->scratch_base;            // [payload: bsz][stream temps][sequence temp]
+    uint8_t *payload = scr;
+    const uint32_t q = (nlit + 3) / 4;
+    const uint32_t scap = q + (q >> 1) + 16;               // per literal stream: 11 bits per symbol at most
+    uint8_t *stemp = scr + bsz;
+    uint8_t *qtemp = stemp + 4 * scap;
+    const uint32_t qcap = bsz;
+
+    for (uint32_t i = tid; i < 256; i += ZKE_ENT_THREADS) cnt[i] = 0;
+    for (uint32_t i = tid; i < sizeof(ZkEncTables) / 4; i += ZKE_ENT_THREADS) ((uint32_t *)&T)[i] = ((const uint32_t *)tabs)[i];
+    if (tid == 0) s_all_same = 1;
+    __syncthreads();
+    // raw block all one byte?  literal histogram
+    {
+        const uint8_t b0 = raw[0];
+        bool diff = false;
+        for (uint32_t i = tid; i < bsz; i += ZKE_ENT_THREADS) diff |= raw[i] != b0;
+        if (diff) s_all_same = 0;
+        for (uint32_t i = tid; i < nlit; i += ZKE_ENT_THREADS) atomicAdd(&cnt[lt[i]], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // literal mode: 1 = RLE, 2 = Huffman (4 streams), 0 = raw      (oracle encode_literals)
+        uint32_t mode = 0, maxsym = 0, distinct = 0;
+        for (uint32_t s = 0; s < 256; s++) if (cnt[s]) { maxsym = s; distinct++; }
+        if (nlit > 0 && distinct == 1) mode = 1;
+        else if (nlit >= 64 && maxsym < 128) {
+            int mb = zke_huf_lengths(cnt, (int)maxsym + 1, &hw);
+            if (mb > 0) { zke_huf_codes(&hw, (int)maxsym + 1, mb); mode = 2; s_maxbits = (uint32_t)mb; s_tree = maxsym; }
+        }
+        s_lit_mode = mode;
+        s_hdr = nlit < 1024 ? 3 : nlit < 16384 ? 4 : 5;
+    }
+    __syncthreads();
+    const uint32_t lit_mode = s_lit_mode;
+    // literal streams (wave 0, lanes 0-3) and sequence bitstream (wave 1, lane 0) side by side
+    if (wave == 0 && lane < 4 && lit_mode == 2) {
+        const uint32_t k = lane;
+        const uint32_t n_k = k < 3 ? q : nlit - 3 * q;
+        const uint8_t *sp = lt + k * q;
+        ZkeBits b; b.init(stemp + k * scap, scap);
+        for (uint32_t i = n_k; i-- > 0;) { const uint32_t s = sp[i]; b.add(hw.code[s], hw.len[s]); }   // last symbol first
+        s_sizes[k] = b.close();
+    }
+    if (wave == 1 && lane == 0) {
+        uint32_t sz = 0;
+        if (nseq) {
+            ZkeBits b; b.init(qtemp, qcap);
+            uint64_t s = sq[nseq - 1];
+            uint32_t ll = (uint32_t)s & 0xFFFFF, ml = (uint32_t)(s >> 20) & 0xFFFFF, ob = (uint32_t)(s >> 40);
+            uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
+            uint32_t sm = zke_cinit(T.ml_state, T.ml_dnb[mlc], T.ml_dfs[mlc]);
+            uint32_t so = zke_cinit(T.of_state, T.of_dnb[ofc], T.of_dfs[ofc]);
+            uint32_t sl = zke_cinit(T.ll_state, T.ll_dnb[llc], T.ll_dfs[llc]);
+            b.add(ll - (T.ll_val[llc] & 0xFFFFFF), T.ll_val[llc] >> 24);
+            b.add(ml - (T.ml_val[mlc] & 0xFFFFFF), T.ml_val[mlc] >> 24);
+            b.add(ob - (1u << ofc), ofc);
+            for (uint32_t i = nseq - 1; i-- > 0;) {
+                s = sq[i];
+                ll = (uint32_t)s & 0xFFFFF; ml = (uint32_t)(s >> 20) & 0xFFFFF; ob = (uint32_t)(s >> 40);
+                llc = zke_ll_code(ll); mlc = zke_ml_code(ml - 3); ofc = zk_highbit(ob);
+                { uint32_t nb = (so + T.of_dnb[ofc]) >> 16; b.add(so, nb); so = T.of_state[(so >> nb) + T.of_dfs[ofc]]; }
+                { uint32_t nb = (sm + T.ml_dnb[mlc]) >> 16; b.add(sm, nb); sm = T.ml_state[(sm >> nb) + T.ml_dfs[mlc]]; }
+                { uint32_t nb = (sl + T.ll_dnb[llc]) >> 16; b.add(sl, nb); sl = T.ll_state[(sl >> nb) + T.ll_dfs[llc]]; }
+                b.add(ll - (T.ll_val[llc] & 0xFFFFFF), T.ll_val[llc] >> 24);
+                b.add(ml - (T.ml_val[mlc] & 0xFFFFFF), T.ml_val[mlc] >> 24);
+                b.add(ob - (1u << ofc), ofc);
+            }
+            b.add(sm, 6); b.add(so, 5); b.add(sl, 6);
+            sz = b.close();
+        }
+        s_sizes[4] = sz;
+    }
+    __syncthreads();
+    // layout of the block payload
+    if (tid == 0) {
+        uint32_t mode = 2, total = 0;
+        const uint32_t raw_hdr = nlit < 32 ? 1 : nlit < 4096 ? 2 : 3;
+        uint32_t lm = lit_mode, lit_sz = 0;
+        if (lm == 2) {
+            const uint32_t tree = 1 + (s_tree + 1) / 2;            // weights of symbols 0..maxsym-1, two per byte
+            uint32_t comp = tree + 6 + s_sizes[0] + s_sizes[1] + s_sizes[2] + s_sizes[3];
+            bool ok = s_sizes[0] && s_sizes[1] && s_sizes[2] && s_sizes[3] && s_sizes[0] < 65536 && s_sizes[1] < 65536 && s_sizes[2] < 65536;
+            const uint32_t lim = s_hdr == 3 ? 1024u : s_hdr == 4 ? 16384u : 262144u;
+            if (ok && comp < nlit - (nlit >> 6) && comp < lim) lit_sz = s_hdr + comp; else lm = 0;
+        }
+        if (lm == 1) lit_sz = raw_hdr + 1;
+        if (lm == 0) lit_sz = raw_hdr + nlit;
+        const uint32_t nh = nseq < 128 ? 1 : nseq < 0x7F00 ? 2 : 3;
+        total = lit_sz + nh + (nseq ? 1 + s_sizes[4] : 0);
+        if (nseq && s_sizes[4] == 0) total = 0xFFFFFFFFu;
+        if (s_all_same && bsz > 1) mode = 1;
+        else if (total >= bsz) mode = 0;
+        s_lit_mode = lm; s_mode = mode;
+        blk->mode = mode;
+        blk->csize = mode == 2 ? total : mode == 1 ? 1 : bsz;
+        blk->rle_byte = raw[0];
+    }
+    __syncthreads();
+    if (s_mode != 2) return;
+    // write the payload: literals section, Number_of_Sequences, modes byte, sequence bitstream
+    const uint32_t lm = s_lit_mode;
+    const uint32_t raw_hdr = nlit < 32 ? 1 : nlit < 4096 ? 2 : 3;
+    uint32_t p = 0;
+    if (lm == 2) {
+        const uint32_t hdr = s_hdr, tree = 1 + (s_tree + 1) / 2, mb = s_maxbits;
+        const uint32_t comp = tree + 6 + s_sizes[0] + s_sizes[1] + s_sizes[2] + s_sizes[3];
+        if (tid == 0) {
+            uint64_t h = hdr == 3 ? (2ull | (1 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 14))
+                       : hdr == 4 ? (2ull | (2 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 18))
+                                  : (2ull | (3 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 22));
+            for (uint32_t i = 0; i < hdr; i++) payload[i] = (uint8_t)(h >> (8 * i));
+            uint32_t w = hdr;
+            const uint32_t nw = s_tree;                            // number of explicit weights (symbols 0..maxsym-1)
+            payload[w++] = (uint8_t)(127 + nw);
+            for (uint32_t i = 0; i < nw; i += 2) {
+                const uint32_t w0 = hw.len[i] ? mb + 1 - hw.len[i] : 0;
+                const uint32_t w1 = (i + 1 < nw && hw.len[i + 1]) ? mb + 1 - hw.len[i + 1] : 0;
+                payload[w++] = (uint8_t)((w0 << 4) | w1);
+            }
+            for (int k = 0; k < 3; k++) { payload[w++] = (uint8_t)s_sizes[k]; payload[w++] = (uint8_t)(s_sizes[k] >> 8); }
+        }
+        p = hdr + tree + 6;
+        for (int k = 0; k < 4; k++) {
+            const uint8_t *sp = stemp + k * scap;
+            for (uint32_t i = tid; i < s_sizes[k]; i += ZKE_ENT_THREADS) payload[p + i] = sp[i];
+            p += s_sizes[k];
+        }
+    } else {
+        if (tid == 0) {
+            const uint32_t t = lm;                                 // 0 raw, 1 rle
+            if (raw_hdr == 1) payload[0] = (uint8_t)(t | (nlit << 3));
+            else if (raw_hdr == 2) { payload[0] = (uint8_t)(t | (1 << 2) | (nlit << 4)); payload[1] = (uint8_t)(nlit >> 4); }
+            else { payload[0] = (uint8_t)(t | (3 << 2) | (nlit << 4)); payload[1] = (uint8_t)(nlit >> 4); payload[2] = (uint8_t)(nlit >> 12); }
+            if (lm == 1) payload[raw_hdr] = lt[0];
+        }
+        p = raw_hdr;
+        if (lm == 1) p += 1;
+        else { for (uint32_t i = tid; i < nlit; i += ZKE_ENT_THREADS) payload[p + i] = lt[i]; p += nlit; }
+    }
+    if (tid == 0) {
+        if (nseq < 128) payload[p] = (uint8_t)nseq;
+        else if (nseq < 0x7F00) { payload[p] = (uint8_t)((nseq >> 8) + 128); payload[p + 1] = (uint8_t)nseq; }
+        else { payload[p] = 255; payload[p + 1] = (uint8_t)(nseq - 0x7F00); payload[p + 2] = (uint8_t)((nseq - 0x7F00) >> 8); }
+    }
+    p += nseq < 128 ? 1 : nseq < 0x7F00 ? 2 : 3;
+    if (nseq) {
+        if (tid == 0) payload[p] = 0;                              // predefined LL / OF / ML
+        p += 1;
+        for (uint32_t i = tid; i < s_sizes[4]; i += ZKE_ENT_THREADS) payload[p + i] = qtemp[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ frame sizes, scan, assemble
+__global__ __launch_bounds__(64) void zk_k_enc_sizes(const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, int checksum,
+                                                     uint64_t *c_size64, uint32_t *c_sizes, uint32_t *d_sizes)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    const ZkEncFrame fr = frames[f];
+    uint64_t c;
+    if (fr.d_size == 0) c = 9;                                      // 28 B5 2F FD 20 00 01 00 00
+    else {
+        c = 6;
+        for (uint32_t b = 0; b < fr.n_blocks; b++) c += 3 + blocks[fr.block_base + b].csize;
+    }
+    if (checksum) c += 4;
+    c_size64[f] = c;
+    if (c_sizes) c_sizes[f] = (uint32_t)c;
+    if (d_sizes) d_sizes[f] = fr.d_size;
+}
+
+// exclusive scan of n u64 values (one workgroup); out[n] = total
+__global__ __launch_bounds__(1024) void zk_k_scan64(const uint64_t *in, uint32_t n, uint64_t *out)
+{
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint64_t v = i < n ? in[i] : 0;
+        uint64_t x = v;
+        for (int d = 1; d < 64; d <<= 1) { uint64_t y = __shfl_up(x, d, 64); if ((int)lane >= d) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint64_t pre = carry;
+        for (uint32_t w = 0; w < wave; w++) pre += wsum[w];
+        if (i < n) out[i] = pre + x - v;
+        __syncthreads();
+        if (tid == 1023) carry = pre + x;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry;
+}
+
+__global__ __launch_bounds__(256) void zk_k_enc_assemble(const uint8_t *src, const ZkEncFrame *frames, const ZkEncBlock *blocks,
+                                                         const uint8_t *scratch, const uint64_t *out_off, const uint64_t *hashes,
+                                                         int checksum, uint8_t *dst)
+{
+    const uint32_t tid = threadIdx.x;
+    const ZkEncFrame fr = frames[blockIdx.x];
+    uint8_t *o = dst + out_off[blockIdx.x];
+    uint64_t p;
+    if (fr.d_size == 0) {
+        if (tid == 0) { const uint8_t e[9] = {0x28, 0xB5, 0x2F, 0xFD, (uint8_t)(checksum ? 0x24 : 0x20), 0x00, 0x01, 0x00, 0x00}; for (int i = 0; i < 9; i++) o[i] = e[i]; }
+        p = 9;
+    } else {
+        if (tid == 0) { o[0] = 0x28; o[1] = 0xB5; o[2] = 0x2F; o[3] = 0xFD; o[4] = checksum ? 0x04 : 0x00; o[5] = (uint8_t)((fr.window_log - 10) << 3); }
+        p = 6;
+        for (uint32_t b = 0; b < fr.n_blocks; b++) {
+            const ZkEncBlock &blk = blocks[fr.block_base + b];
+            const uint32_t last = b + 1 == fr.n_blocks;
+            const uint32_t field = blk.mode == 2 ? blk.csize : blk.bsz;     // Block_Size: regenerated size for raw / RLE
+            if (tid == 0) { const uint32_t h = last | (blk.mode << 1) | (field << 3); o[p] = (uint8_t)h; o[p + 1] = (uint8_t)(h >> 8); o[p + 2] = (uint8_t)(h >> 16); }
+            p += 3;
+            if (blk.mode == 1) { if (tid == 0) o[p] = blk.rle_byte; p += 1; }
+            else {
+                const uint8_t *from = blk.mode == 2 ? scratch + blk.scratch_base : src + fr.src_off + blk.bs;
+                const uint32_t n = blk.mode == 2 ? blk.csize : blk.bsz;
+                for (uint32_t i = tid; i < n; i += 256) o[p + i] = from[i];
+                p += n;
+            }
+        }
+    }
+    if (checksum && tid == 0) { const uint32_t h = (uint32_t)hashes[blockIdx.x]; o[p] = (uint8_t)h; o[p + 1] = (uint8_t)(h >> 8); o[p + 2] = (uint8_t)(h >> 16); o[p + 3] = (uint8_t)(h >> 24); }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, ZkEncBlock *blocks, uint64_t *seqs, uint8_t *lits)
+{
+    hipLaunchKernelGGL(zk_k_enc_match, dim3(nframes), dim3(ZKE_THREADS), 0, st, src, frames, blocks, seqs, lits);
+}
+void zk_launch_enc_entropy(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks, uint32_t nblocks,
+                           const uint64_t *seqs, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *tabs)
+{
+    if (!nblocks) return;
+    hipLaunchKernelGGL(zk_k_enc_entropy, dim3(nblocks), dim3(ZKE_ENT_THREADS), 0, st, src, frames, blocks, seqs, lits, scratch, tabs);
+}
+void zk_launch_enc_sizes(hipStream_t st, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, int checksum,
+                         uint64_t *c_size64, uint32_t *c_sizes, uint32_t *d_sizes)
+{
+    hipLaunchKernelGGL(zk_k_enc_sizes, dim3((nframes + 63) / 64), dim3(64), 0, st, frames, nframes, blocks, checksum, c_size64, c_sizes, d_sizes);
+}
+void zk_launch_scan64(hipStream_t st, const uint64_t *in, uint32_t n, uint64_t *out)
+{
+    hipLaunchKernelGGL(zk_k_scan64, dim3(1), dim3(1024), 0, st, in, n, out);
+}
+void zk_launch_enc_assemble(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks,
+                            const uint8_t *scratch, const uint64_t *out_off, const uint64_t *hashes, int checksum, uint8_t *dst)
+{
+    hipLaunchKernelGGL(zk_k_enc_assemble, dim3(nframes), dim3(256), 0, st, src, frames, blocks, scratch, out_off, hashes, checksum, dst);
+}

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include "zk_enc_device.h"
 
 enum { ZK_K_WALK_COUNT = 0, ZK_K_SCAN, ZK_K_WALK_FILL, ZK_K_HUF, ZK_K_FSE, ZK_K_EXEC, ZK_K_XXH64, ZK_K_STATUS,
        ZK_K_ENC_MATCH, ZK_K_ENC_ENTROPY, ZK_K_ENC_COMPACT, ZK_K_ENC_XXH64, ZK_NKERNELS };
@@ -26,6 +27,8 @@ struct zk_engine {
     float kernel_ms[ZK_NKERNELS] = {};
     // encode scratch
     zk_devbuf enc_a, enc_b, enc_c, enc_d;
+    ZkEncTables enc_tables;
+    bool enc_tables_ready = false;
 };
 
 int zk_devbuf_reserve(zk_engine *e, zk_devbuf &b, size_t bytes);

@@ -1,0 +1,176 @@
+// zk_engine_enc.hip -- encode half of the batch engine (Level A of include/zeekstd_amd.h).
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <vector>
+#include "../../include/zeekstd_amd.h"
+#include "zk_engine.h"
+#include "zk_kernels.h"
+
+#define ZK_HIP(call)                                                                                 \
+    do {                                                                                             \
+        hipError_t _e = (call);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            e->last_err = std::string(#call) + ": " + hipGetErrorString(_e);                         \
+            return ZK_ERR_HIP;                                                                       \
+        }                                                                                            \
+    } while (0)
+
+// ---------------------------------------------------------------- predefined FSE compression tables (host, once)
+static void build_ctable(const int16_t *norm, int nsym, int al, uint16_t *state, uint32_t *dfs, uint32_t *dnb)
+{
+    const int size = 1 << al, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    int high = size - 1;
+    uint8_t sym[512];
+    int cumul[66];
+    cumul[0] = 0;
+    for (int u = 1; u <= nsym; u++) {
+        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; sym[high--] = (uint8_t)(u - 1); }
+        else cumul[u] = cumul[u - 1] + norm[u - 1];
+    }
+    int pos = 0;
+    for (int s = 0; s < nsym; s++)
+        for (int i = 0; i < norm[s]; i++) { sym[pos] = (uint8_t)s; do pos = (pos + step) & mask; while (pos > high); }
+    for (int u = 0; u < size; u++) { int s = sym[u]; state[cumul[s]++] = (uint16_t)(size + u); }
+    int total = 0;
+    for (int s = 0; s < nsym; s++) {
+        if (norm[s] == 0) { dnb[s] = ((uint32_t)(al + 1) << 16) - (1u << al); dfs[s] = 0; }
+        else if (norm[s] == -1 || norm[s] == 1) { dnb[s] = ((uint32_t)al << 16) - (1u << al); dfs[s] = (uint32_t)(total - 1); total++; }
+        else {
+            const uint32_t mbo = (uint32_t)al - zk_highbit((uint32_t)norm[s] - 1), msp = (uint32_t)norm[s] << mbo;
+            dnb[s] = (mbo << 16) - msp; dfs[s] = (uint32_t)(total - norm[s]); total += norm[s];
+        }
+    }
+}
+
+void zk_build_enc_tables(ZkEncTables *t)
+{
+    static const int16_t ll[36] = ZK_LL_DEFNORM, of[29] = ZK_OF_DEFNORM, ml[53] = ZK_ML_DEFNORM;
+    static const uint32_t llv[36] = ZK_LL_TABLE, mlv[53] = ZK_ML_TABLE;
+    memset(t, 0, sizeof *t);
+    build_ctable(ll, 36, 6, t->ll_state, t->ll_dfs, t->ll_dnb);
+    build_ctable(of, 29, 5, t->of_state, t->of_dfs, t->of_dnb);
+    build_ctable(ml, 53, 6, t->ml_state, t->ml_dfs, t->ml_dnb);
+    for (int i = 0; i < 36; i++) t->ll_val[i] = llv[i];
+    for (int i = 0; i < 53; i++) t->ml_val[i] = mlv[i];
+}
+
+extern "C" uint64_t zk_compress_bound(uint64_t n, uint32_t frame_size)
+{
+    if (frame_size == 0) return 0;
+    const uint64_t nf = n == 0 ? 1 : (n + frame_size - 1) / frame_size;
+    const uint64_t blocks_per_frame = ((uint64_t)frame_size + 1023) / 1024 + 1;     // tiny frames have tiny blocks
+    return n + nf * (6 + 4 + 3 * blocks_per_frame) + 16;
+}
+
+extern "C" int zk_encode_frames_dev(zk_engine *e, const void *d_src, uint64_t n, uint32_t frame_size, int level, int checksum,
+                                    void *d_dst, uint64_t dst_cap, void *d_c_sizes, void *d_d_sizes, uint32_t *n_frames_out,
+                                    uint64_t *written_out, void *stream)
+{
+    (void)level;                                             // one strategy: every level maps to it
+    if (!e || frame_size == 0 || frame_size > ZK_SEEKABLE_MAX_FRAME_SIZE || !d_dst || (n && !d_src)) return ZK_ERR_ARGUMENT;
+    const uint64_t nf64 = n == 0 ? 1 : (n + frame_size - 1) / frame_size;
+    if (nf64 > ZK_SEEKABLE_MAX_FRAMES) return ZK_ERR_FRAME_INDEX_TOO_LARGE;
+    const uint32_t nf = (uint32_t)nf64;
+    ZK_HIP(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+
+    // frame / block lists (host arithmetic only: frame boundaries are the policy's, encode.rs:528-544)
+    std::vector<ZkEncFrame> frames(nf);
+    std::vector<ZkEncBlock> blocks;
+    uint64_t seq_total = 0, scratch_total = 0;
+    for (uint32_t f = 0; f < nf; f++) {
+        ZkEncFrame &fr = frames[f];
+        fr.src_off = (uint64_t)f * frame_size;
+        fr.d_size = (uint32_t)(n - fr.src_off < frame_size ? n - fr.src_off : frame_size);
+        uint32_t wlog = 10;
+        while ((1u << wlog) < fr.d_size && wlog < 17) wlog++;
+        fr.window_log = wlog;
+        fr.block_max = (1u << wlog) < ZKE_BLOCK ? (1u << wlog) : ZKE_BLOCK;
+        fr.n_blocks = fr.d_size ? (fr.d_size + fr.block_max - 1) / fr.block_max : 0;
+        fr.block_base = (uint32_t)blocks.size();
+        fr.pad = 0;
+        for (uint32_t b = 0; b < fr.n_blocks; b++) {
+            ZkEncBlock k;
+            memset(&k, 0, sizeof k);
+            k.frame = f; k.bs = b * fr.block_max;
+            k.bsz = fr.d_size - k.bs < fr.block_max ? fr.d_size - k.bs : fr.block_max;
+            k.seq_base = seq_total; seq_total += k.bsz / 4 + 2;
+            k.lit_base = fr.src_off + k.bs;
+            k.scratch_base = scratch_total;
+            const uint32_t q = (k.bsz + 3) / 4;
+            scratch_total += (uint64_t)k.bsz * 2 + 4ull * (q + (q >> 1) + 16) + 64;
+            blocks.push_back(k);
+        }
+    }
+    const uint32_t nb = (uint32_t)blocks.size();
+    const size_t frames_bytes = (frames.size() * sizeof(ZkEncFrame) + 63) & ~(size_t)63;
+    int rc;
+    if ((rc = zk_devbuf_reserve(e, e->enc_a, frames_bytes + (size_t)(nb + 1) * sizeof(ZkEncBlock) + 256))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->enc_b, (size_t)(seq_total + 1) * 8))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->enc_c, (size_t)n + 64))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->enc_d, (size_t)scratch_total + 64))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->infos, (size_t)(nf + 1) * 8 * 3 + 64 + sizeof(ZkEncTables)))) return rc;   // c_size64, out_off, hashes, tables
+    if ((rc = zk_devbuf_reserve(e, e->bases, (size_t)(nf + 1) * 8 + 16))) return rc;                             // d_off[nf+1] for the checksum kernel
+    ZkEncFrame *dfr = (ZkEncFrame *)e->enc_a.p;
+    ZkEncBlock *dbl = (ZkEncBlock *)((uint8_t *)e->enc_a.p + frames_bytes);
+    uint64_t *c64 = (uint64_t *)e->infos.p, *out_off = c64 + (nf + 1), *hashes = out_off + (nf + 1);
+    ZkEncTables *dtab = (ZkEncTables *)(hashes + (nf + 1));
+    if (!e->enc_tables_ready) { zk_build_enc_tables(&e->enc_tables); e->enc_tables_ready = true; }
+    ZK_HIP(hipMemcpyAsync(dfr, frames.data(), frames.size() * sizeof(ZkEncFrame), hipMemcpyHostToDevice, st));
+    if (nb) ZK_HIP(hipMemcpyAsync(dbl, blocks.data(), (size_t)nb * sizeof(ZkEncBlock), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(dtab, &e->enc_tables, sizeof(ZkEncTables), hipMemcpyHostToDevice, st));
+    std::vector<uint64_t> doff(nf + 1);
+    if (checksum) {
+        for (uint32_t f = 0; f <= nf; f++) doff[f] = f < nf ? frames[f].src_off : n;
+        ZK_HIP(hipMemcpyAsync(e->bases.p, doff.data(), doff.size() * 8, hipMemcpyHostToDevice, st));
+    }
+    zk_profile_begin(e);
+    const uint8_t *src = (const uint8_t *)d_src;
+    if (checksum) { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, (const uint64_t *)e->bases.p, 0, nf, nullptr, hashes); }
+    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, src, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint8_t *)e->enc_c.p); }
+    { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (const uint64_t *)e->enc_b.p, (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, dtab); }
+    zk_launch_enc_sizes(st, dfr, nf, dbl, checksum, c64, (uint32_t *)d_c_sizes, (uint32_t *)d_d_sizes);
+    zk_launch_scan64(st, c64, nf, out_off);
+    ZK_HIP(hipMemcpyAsync(e->h_words, out_off + nf, 8, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));                        // the uploads from frames / blocks / doff are done too
+    const uint64_t total = e->h_words[0];
+    if (total > dst_cap) return -(int)ZK_E_DST_TOO_SMALL;
+    { zk_kernel_timer t(e, ZK_K_ENC_COMPACT, st); zk_launch_enc_assemble(st, src, dfr, nf, dbl, (const uint8_t *)e->enc_d.p, out_off, hashes, checksum, (uint8_t *)d_dst); }
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+    zk_profile_collect(e);
+    if (n_frames_out) *n_frames_out = nf;
+    if (written_out) *written_out = total;
+    return 0;
+}
+
+extern "C" int zk_encode_frames(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_size, int level, int checksum,
+                                uint8_t *dst, uint64_t dst_cap, uint32_t *c_sizes, uint32_t *d_sizes, uint32_t frames_cap,
+                                uint32_t *n_frames_out, uint64_t *written_out)
+{
+    if (!e || frame_size == 0 || !dst || (n && !src)) return ZK_ERR_ARGUMENT;
+    const uint64_t nf = n == 0 ? 1 : (n + frame_size - 1) / frame_size;
+    if (nf > ZK_SEEKABLE_MAX_FRAMES) return ZK_ERR_FRAME_INDEX_TOO_LARGE;
+    if ((c_sizes || d_sizes) && frames_cap < nf) return ZK_ERR_ARGUMENT;
+    ZK_HIP(hipSetDevice(e->device));
+    const uint64_t bound = zk_compress_bound(n, frame_size);
+    const uint64_t cap = bound < dst_cap ? bound : dst_cap;
+    int rc;
+    if ((rc = zk_devbuf_reserve(e, e->st_comp, (size_t)n + 64))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->st_dst, (size_t)cap + 64))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->st_misc, (size_t)nf * 8 + 64))) return rc;
+    hipStream_t st = e->stream;
+    if (n) ZK_HIP(hipMemcpyAsync(e->st_comp.p, src, n, hipMemcpyHostToDevice, st));
+    uint32_t *dc = (uint32_t *)e->st_misc.p, *dd = dc + nf;
+    uint32_t nfo = 0;
+    uint64_t written = 0;
+    rc = zk_encode_frames_dev(e, e->st_comp.p, n, frame_size, level, checksum, e->st_dst.p, cap, dc, dd, &nfo, &written, st);
+    if (rc) return rc;
+    ZK_HIP(hipMemcpyAsync(dst, e->st_dst.p, written, hipMemcpyDeviceToHost, st));
+    if (c_sizes) ZK_HIP(hipMemcpyAsync(c_sizes, dc, (size_t)nfo * 4, hipMemcpyDeviceToHost, st));
+    if (d_sizes) ZK_HIP(hipMemcpyAsync(d_sizes, dd, (size_t)nfo * 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    if (n_frames_out) *n_frames_out = nfo;
+    if (written_out) *written_out = written;
+    return 0;
+}

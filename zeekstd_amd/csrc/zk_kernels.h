@@ -14,3 +14,14 @@ void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, 
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
                      ZkFrameInfo *infos, uint64_t *hashes);
 void zk_launch_status(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, uint64_t *first_err);
+
+// ---- encoder (zk_encode.hip)
+#include "zk_enc_device.h"
+void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, ZkEncBlock *blocks, uint64_t *seqs, uint8_t *lits);
+void zk_launch_enc_entropy(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks, uint32_t nblocks,
+                           const uint64_t *seqs, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *tabs);
+void zk_launch_enc_sizes(hipStream_t st, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, int checksum,
+                         uint64_t *c_size64, uint32_t *c_sizes, uint32_t *d_sizes);
+void zk_launch_scan64(hipStream_t st, const uint64_t *in, uint32_t n, uint64_t *out);
+void zk_launch_enc_assemble(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks,
+                            const uint8_t *scratch, const uint64_t *out_off, const uint64_t *hashes, int checksum, uint8_t *dst);

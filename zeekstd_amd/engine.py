@@ -74,6 +74,33 @@ class Engine:
             self._raise(rc)
         return out[:out_len].tobytes(), status[:count]
 
+    def encode_frames(self, data, frame_size=0x200000, level=1, checksum=False):
+        """Returns (compressed payload bytes, [(c_size, d_size), ...]) -- one zstd frame per frame_size bytes."""
+        data = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        n = int(data.size)
+        nf = max(1, -(-n // frame_size))
+        cap = int(lib.zk_compress_bound(n, frame_size))
+        out = np.empty(cap, dtype=np.uint8)
+        cs = np.zeros(nf, np.uint32)
+        ds = np.zeros(nf, np.uint32)
+        nfo = C.c_uint32()
+        wr = C.c_uint64()
+        rc = lib.zk_encode_frames(self._h, data.ctypes.data if n else None, n, frame_size, level, int(checksum),
+                                  out.ctypes.data, cap, cs.ctypes.data, ds.ctypes.data, nf, C.byref(nfo), C.byref(wr))
+        if rc != 0:
+            self._raise(rc)
+        return out[:wr.value].tobytes(), list(zip(cs[:nfo.value].tolist(), ds[:nfo.value].tolist()))
+
+    def encode_frames_dev(self, d_src, n, frame_size, level, checksum, d_dst, dst_cap, d_c_sizes=None, d_d_sizes=None, stream=None):
+        nfo = C.c_uint32()
+        wr = C.c_uint64()
+        rc = lib.zk_encode_frames_dev(self._h, self._ptr(d_src), n, frame_size, level, int(checksum), self._ptr(d_dst), dst_cap,
+                                      self._ptr(d_c_sizes) if d_c_sizes is not None else None,
+                                      self._ptr(d_d_sizes) if d_d_sizes is not None else None, C.byref(nfo), C.byref(wr), stream)
+        if rc != 0:
+            self._raise(rc)
+        return nfo.value, wr.value
+
     def xxh64_frames(self, data, off):
         data = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
         off = _u64(off)
