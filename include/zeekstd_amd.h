@@ -201,6 +201,39 @@ zk_seek_table *zk_decoder_seek_table(const zk_decoder *d);                      
 int zk_decoder_seek(zk_decoder *d, int whence, int64_t n, uint64_t *out);                      /* io::Seek :545-579 */
 uint64_t zk_decoder_gpu_submissions(const zk_decoder *d);                                      /* engine-specific counter */
 
+/* ---- EncodeOptions / RawEncoder / Encoder (lib/src/encode.rs) */
+typedef struct zk_raw_encoder zk_raw_encoder;
+typedef struct zk_encoder zk_encoder;
+#define ZK_POLICY_UNCOMPRESSED 0 /* FrameSizePolicy::Uncompressed(n), encode.rs:21-39 (default, n = 0x200000) */
+#define ZK_POLICY_COMPRESSED 1   /* FrameSizePolicy::Compressed(n): not on the GPU path yet -> -40 (parameter_unsupported) */
+typedef struct zk_encode_opts {  /* EncodeOptions builder fields, encode.rs:110-207 */
+    uint32_t policy, frame_size; /* frame_size 0 = default policy */
+    int32_t level;               /* compression_level :170 (default 0) */
+    int32_t checksum;            /* checksum_flag :164 (default false) */
+    uint32_t batch_frames;       /* engine-specific: frames per GPU submission gathered by Encoder (0 = 64) */
+} zk_encode_opts;
+/* e == NULL: the encoder creates (and owns) an engine on device 0, like EncodeOptions::new creating a CCtx (:129) */
+int zk_raw_encoder_new(zk_engine *e, const zk_encode_opts *o, zk_raw_encoder **out);                 /* with_opts :280 */
+void zk_raw_encoder_free(zk_raw_encoder *r);
+int zk_raw_encoder_compress(zk_raw_encoder *r, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len,
+                            size_t *in_progress, size_t *out_progress);                                /* :398 */
+int zk_raw_encoder_compress_with_prefix(zk_raw_encoder *r, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len,
+                                        const uint8_t *prefix, size_t plen, size_t *in_progress, size_t *out_progress); /* :311 */
+int zk_raw_encoder_end_frame(zk_raw_encoder *r, uint8_t *out, size_t out_len, size_t *out_progress, size_t *data_left); /* :438 */
+zk_seek_table *zk_raw_encoder_seek_table(const zk_raw_encoder *r);                                    /* :487 (a copy) */
+void zk_raw_encoder_reset_frame(zk_raw_encoder *r);                                                   /* :501 */
+void zk_raw_encoder_reset_seek_table(zk_raw_encoder *r);                                              /* :524 */
+/* Encoder<W>: W is a write callback (return 0 on success) = io::Write::write_all */
+typedef int (*zk_write_fn)(void *user, const uint8_t *data, size_t len);
+int zk_encoder_new(zk_engine *e, const zk_encode_opts *o, zk_write_fn write, void *user, zk_encoder **out);   /* with_opts :596 */
+void zk_encoder_free(zk_encoder *e);
+int64_t zk_encoder_compress(zk_encoder *e, const uint8_t *buf, size_t len);                           /* :692 / io::Write::write :791 */
+int64_t zk_encoder_end_frame(zk_encoder *e);                                                          /* :704 */
+int zk_encoder_flush(zk_encoder *e);                                                                  /* io::Write::flush :796 */
+int zk_encoder_finish(zk_encoder *e, int format, uint64_t *total);                                    /* finish_format :755 */
+uint64_t zk_encoder_written_compressed(const zk_encoder *e);                                          /* :615 */
+zk_seek_table *zk_encoder_seek_table(const zk_encoder *e);                                            /* :610 (a copy) */
+
 #ifdef __cplusplus
 }
 #endif

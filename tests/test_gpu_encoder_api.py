@@ -1,0 +1,219 @@
+"""zeekstd::RawEncoder / Encoder semantics on the GPU engine -- the reference's encode + round-trip tests
+restated: lib/src/encode.rs:802-871, lib/src/lib.rs:69-358, README doctests (encode.rs:220-265,
+decode.rs:520-542), fuzz/fuzz_targets/roundtrip_basic.rs."""
+import io
+
+import numpy as np
+import pytest
+
+import zeekstd_amd as zk
+from zeekstd_amd import (DecodeOptions, Decoder, EncodeOptions, Encoder, Format, FrameSizePolicy, RawEncoder, SeekFrom,
+                         SeekTable)
+from oracle import zko
+from oracle import libzstd_ref as Z
+
+pytestmark = pytest.mark.gpu
+
+INPUT = zko.gen_text(12345, 4242)
+
+
+def raw_roundtrip(eng, policy=None, checksum=False, scratch=None):
+    """lib.rs:82-134: raw API with a small scratch buffer so that every call is partial."""
+    opts = EncodeOptions().engine(eng).checksum_flag(checksum)
+    if policy:
+        opts.frame_size_policy(policy)
+    enc = opts.into_raw_encoder()
+    buf = bytearray(scratch or max(1, len(INPUT) // 500))
+    seekable = bytearray()
+    in_prog = 0
+    while in_prog < len(INPUT):
+        p = enc.compress(INPUT[in_prog:], buf)
+        seekable += buf[:p.out_progress()]
+        in_prog += p.in_progress()
+    while True:
+        p = enc.end_frame(buf)
+        seekable += buf[:p.out_progress()]
+        if p.data_left() == 0:
+            break
+    st = enc.into_seek_table()
+    assert st.size_comp() == len(seekable) and st.size_decomp() == len(INPUT)
+    ser = st.into_serializer()
+    while True:
+        n = ser.write_into(buf)
+        if n == 0:
+            break
+        seekable += buf[:n]
+    return bytes(seekable), st
+
+
+def test_raw_roundtrip_default_policy(engine):
+    seekable, st = raw_roundtrip(engine)
+    assert st.num_frames() == 1
+    d = DecodeOptions(seekable).engine(engine).into_decoder()
+    assert d.read_to_end() == INPUT
+    if Z.load("system") is not None:       # payload (without the skippable seek table) decodes under the real libzstd
+        assert Z.decode_stream(seekable, len(INPUT), "system") == INPUT
+
+
+@pytest.mark.parametrize("fs", [1, 7, 100, 1000, 1023, 4096])     # proptest lib.rs:315-357 (1..1023)
+def test_raw_roundtrip_frame_sizes(engine, fs):
+    seekable, st = raw_roundtrip(engine, FrameSizePolicy.Uncompressed(fs), checksum=bool(fs & 1), scratch=97)
+    assert st.num_frames() == -(-len(INPUT) // fs)
+    assert st.max_frame_size_decomp() == min(fs, len(INPUT))
+    d = DecodeOptions(seekable).engine(engine).into_decoder()
+    assert d.read_to_end() == INPUT
+
+
+def test_compress_never_closes_and_compresses_in_one_call(engine):
+    # encode.rs:317-353: a call either closes a completed frame (consuming no input) or compresses
+    enc = EncodeOptions().engine(engine).frame_size_policy(FrameSizePolicy.Uncompressed(100)).into_raw_encoder()
+    out = bytearray(4096)
+    p = enc.compress(INPUT[:250], out)
+    assert (p.in_progress(), p.out_progress()) == (100, 0)         # limited to the frame
+    p = enc.compress(INPUT[100:250], out)
+    assert p.in_progress() == 0 and p.out_progress() > 0           # frame complete: closed, no input consumed
+    assert enc.seek_table().num_frames() == 1
+    p = enc.compress(INPUT[100:250], out)
+    assert p.in_progress() == 100
+
+
+def test_checksum_flag_sets_header_bit(engine):                    # encode.rs:834-870
+    for flag in (False, True):
+        seekable, st = raw_roundtrip(engine, FrameSizePolicy.Uncompressed(len(INPUT) // 3), checksum=flag, scratch=5000)
+        for i in range(st.num_frames()):
+            assert bool(seekable[st.frame_start_comp(i) + 4] & 0x04) == flag
+
+
+def test_reset_frame_and_seek_table(engine):                       # encode.rs:811-831
+    enc = EncodeOptions().engine(engine).into_raw_encoder()
+    out = bytearray(1 << 16)
+    enc.compress(INPUT[:1000], out)
+    enc.reset_frame()                                              # in-flight frame discarded
+    enc.compress(INPUT, out)
+    a = bytearray()
+    while True:
+        p = enc.end_frame(out); a += out[:p.out_progress()]
+        if p.data_left() == 0:
+            break
+    assert enc.seek_table().num_frames() == 1 and enc.seek_table().size_decomp() == len(INPUT)
+    enc.reset_seek_table()
+    assert enc.seek_table().num_frames() == 0
+    enc.compress(INPUT, out)
+    b = bytearray()
+    while True:
+        p = enc.end_frame(out); b += out[:p.out_progress()]
+        if p.data_left() == 0:
+            break
+    assert bytes(a) == bytes(b)                                    # reproducible
+
+
+def test_end_frame_without_input_is_the_golden_empty_frame(engine):
+    enc = EncodeOptions().engine(engine).into_raw_encoder()
+    out = bytearray(64)
+    p = enc.end_frame(out)
+    assert bytes(out[:p.out_progress()]) == bytes.fromhex("28b52ffd2000010000") and p.data_left() == 0
+    assert enc.seek_table().num_frames() == 1 and enc.seek_table().frame_size_decomp(0) == 0
+
+
+def test_end_frame_with_tiny_buffers(engine):                      # the epilogue loop, encode.rs:442-464
+    enc = EncodeOptions().engine(engine).checksum_flag(True).into_raw_encoder()
+    enc.compress(INPUT, bytearray(0))
+    out = bytearray(3)
+    got = bytearray()
+    while True:
+        p = enc.end_frame(out)
+        got += out[:p.out_progress()]
+        if p.data_left() == 0:
+            break
+        assert p.out_progress() == 3
+    assert enc.seek_table().frame_size_comp(0) == len(got)
+    assert zko.frame_decode(bytes(got), len(INPUT), True)[0] == INPUT
+
+
+def test_std_encoder_io_copy_roundtrip(engine):                    # lib.rs:265-287
+    sink = io.BytesIO()
+    enc = EncodeOptions().engine(engine).frame_size_policy(FrameSizePolicy.Uncompressed(777)).into_encoder(sink)
+    for i in range(0, len(INPUT), 1000):
+        assert enc.write(INPUT[i:i + 1000]) == len(INPUT[i:i + 1000])
+    n = enc.finish()
+    seekable = sink.getvalue()
+    assert n == len(seekable)                                      # finish() returns the bytes written
+    d = DecodeOptions(seekable).engine(engine).into_decoder()
+    assert d.read_to_end() == INPUT
+    assert d.seek_table().num_frames() == -(-len(INPUT) // 777)
+
+
+def test_encoder_empty_input_yields_one_empty_frame(engine):       # encode.rs:755-757
+    sink = io.BytesIO()
+    n = EncodeOptions().engine(engine).into_encoder(sink).finish()
+    assert sink.getvalue() == bytes.fromhex("28b52ffd2000010000") + bytes.fromhex("5e2a4d1811000000" "09000000" "00000000" "01000000" "00" "b1ea928f")
+    assert n == 9 + 25
+
+
+def test_encoder_exact_multiple_has_no_trailing_empty_frame(engine):
+    sink = io.BytesIO()
+    enc = EncodeOptions().engine(engine).frame_size_policy(FrameSizePolicy.Uncompressed(1000)).batch_frames(2).into_encoder(sink)
+    enc.write(INPUT[:6000])
+    enc.finish()
+    st = SeekTable.from_seekable(sink.getvalue())
+    assert st.num_frames() == 6 and st.size_decomp() == 6000
+
+
+def test_encoder_explicit_end_frame_then_finish_adds_empty_frame(engine):
+    # the reference bench pattern: write_all + end_frame (benches/compress.rs:42-45); finish() then ends a new, empty frame
+    sink = io.BytesIO()
+    enc = EncodeOptions().engine(engine).into_encoder(sink)
+    enc.write(INPUT)
+    assert enc.end_frame() > 0
+    assert enc.seek_table().num_frames() == 1
+    enc.finish()
+    st = SeekTable.from_seekable(sink.getvalue())
+    assert st.num_frames() == 2 and st.frame_size_decomp(1) == 0 and st.frame_size_comp(1) == 9
+
+
+def test_stand_alone_seek_table_head_and_foot(engine):             # lib.rs:136-200
+    for fmt in (Format.Head, Format.Foot):
+        sink = io.BytesIO()
+        enc = EncodeOptions().engine(engine).frame_size_policy(FrameSizePolicy.Uncompressed(2000)).into_encoder(sink)
+        enc.write(INPUT)
+        enc.end_frame()
+        enc.flush()                                                   # push the 131 591-byte staging buffer out (encode.rs:796-799)
+        payload = sink.getvalue()
+        st = enc.seek_table()
+        table = st.to_bytes(fmt)
+        parsed = SeekTable.from_reader(table) if fmt == Format.Head else SeekTable.from_seekable(table)
+        assert parsed == st
+        d = DecodeOptions(payload).engine(engine).seek_table(parsed).into_decoder()     # payload without any seek table
+        assert d.read_to_end() == INPUT
+
+
+def test_readme_seek_example(engine):                              # decode.rs:533-540: seek(Start(7)) then read == "World!"
+    sink = io.BytesIO()
+    enc = Encoder(sink, EncodeOptions().engine(engine))
+    enc.write(b"Hello, World!")
+    enc.finish()
+    d = DecodeOptions(sink.getvalue()).engine(engine).into_decoder()
+    d.seek(SeekFrom.Start, 7)
+    assert d.read(100) == b"World!"
+
+
+def test_unsupported_parameters_fail_loudly(engine):
+    with pytest.raises(zk.Error) as e:                              # Compressed(n) policy is a "next" row
+        EncodeOptions().engine(engine).frame_size_policy(FrameSizePolicy.Compressed(1000)).into_raw_encoder()
+    assert e.value.code == -40
+    enc = EncodeOptions().engine(engine).into_raw_encoder()
+    with pytest.raises(zk.Error) as e:                              # prefix / patch mode
+        enc.compress_with_prefix(b"abc", bytearray(10), b"prefix")
+    assert e.value.code == -40
+
+
+def test_fuzz_roundtrip_basic(engine):                             # fuzz_targets/roundtrip_basic.rs: 100-byte frames
+    rng = np.random.default_rng(8)
+    for i in range(20):
+        n = int(rng.integers(0, 3000))
+        data = zko.gen_text(n, 50 + i) if i % 2 else zko.gen_random(n, 50 + i)
+        sink = io.BytesIO()
+        enc = EncodeOptions().engine(engine).frame_size_policy(FrameSizePolicy.Uncompressed(100)).into_encoder(sink)
+        enc.write(data)
+        enc.finish()
+        assert Decoder(DecodeOptions(sink.getvalue()).engine(engine)).read_to_end() == data

@@ -5,7 +5,8 @@ there is no CPU fallback (import fails loudly without libzeekstd_amd.so).
 """
 from ._lib import LIB_PATH, error_name, lib  # noqa: F401
 from .engine import Engine, ZkError  # noqa: F401
-from .api import DecodeOptions, Decoder, Error, Format, SeekFrom, SeekTable, Serializer  # noqa: F401,E402
+from .api import (CompressionProgress, DecodeOptions, Decoder, EncodeOptions, Encoder, EpilogueProgress, Error, Format,  # noqa: F401,E402
+                  FrameSizePolicy, RawEncoder, SeekFrom, SeekTable, Serializer)
 
 SEEKABLE_MAGIC_NUMBER = 0x8F92EAB1      # lib.rs:52-58
 SEEKABLE_MAX_FRAMES = 0x08000000

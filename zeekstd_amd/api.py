@@ -348,3 +348,222 @@ class Decoder:                         # decode.rs:117-579
         v = C.c_uint64()
         _chk(lib.zk_decoder_seek(self._h, int(whence), n, C.byref(v)))
         return v.value
+
+
+# ---------------------------------------------------------------- encode side (encode.rs)
+class FrameSizePolicy:                 # encode.rs:21-39
+    def __init__(self, kind, size):
+        self.kind, self.size = kind, size
+
+    @staticmethod
+    def Compressed(n):
+        return FrameSizePolicy(1, n)
+
+    @staticmethod
+    def Uncompressed(n):
+        return FrameSizePolicy(0, n)
+
+    @staticmethod
+    def default():
+        return FrameSizePolicy(0, 0x200000)
+
+
+class zk_encode_opts(C.Structure):
+    _fields_ = [("policy", C.c_uint32), ("frame_size", C.c_uint32), ("level", C.c_int32), ("checksum", C.c_int32),
+                ("batch_frames", C.c_uint32)]
+
+
+_WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+_szp = C.POINTER(C.c_size_t)
+for _n, _r, _a in [
+    ("zk_raw_encoder_new", C.c_int, [_P, C.POINTER(zk_encode_opts), C.POINTER(_P)]),
+    ("zk_raw_encoder_free", None, [_P]),
+    ("zk_raw_encoder_compress", C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _szp, _szp]),
+    ("zk_raw_encoder_compress_with_prefix", C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, _szp, _szp]),
+    ("zk_raw_encoder_end_frame", C.c_int, [_P, _P, C.c_size_t, _szp, _szp]),
+    ("zk_raw_encoder_seek_table", _P, [_P]),
+    ("zk_raw_encoder_reset_frame", None, [_P]), ("zk_raw_encoder_reset_seek_table", None, [_P]),
+    ("zk_encoder_new", C.c_int, [_P, C.POINTER(zk_encode_opts), _WRITE_FN, _P, C.POINTER(_P)]),
+    ("zk_encoder_free", None, [_P]),
+    ("zk_encoder_compress", C.c_int64, [_P, _P, C.c_size_t]),
+    ("zk_encoder_end_frame", C.c_int64, [_P]),
+    ("zk_encoder_flush", C.c_int, [_P]),
+    ("zk_encoder_finish", C.c_int, [_P, C.c_int, _u64p]),
+    ("zk_encoder_written_compressed", C.c_uint64, [_P]),
+    ("zk_encoder_seek_table", _P, [_P]),
+]:
+    declare(_n, _r, _a)
+
+
+class CompressionProgress:             # encode.rs:43-66
+    def __init__(self, i, o):
+        self._i, self._o = i, o
+
+    def in_progress(self): return self._i
+    def out_progress(self): return self._o
+
+
+class EpilogueProgress:                # encode.rs:69-92
+    def __init__(self, o, left):
+        self._o, self._l = o, left
+
+    def out_progress(self): return self._o
+    def data_left(self): return self._l
+
+
+class EncodeOptions:                   # encode.rs:110-207
+    def __init__(self):
+        self._o = zk_encode_opts(0, 0, 0, 0, 0)
+        self._engine = None
+
+    @staticmethod
+    def new():
+        return EncodeOptions()
+
+    def engine(self, e: Engine):       # with_cctx / cctx
+        self._engine = e
+        return self
+
+    def frame_size_policy(self, p: FrameSizePolicy):
+        self._o.policy, self._o.frame_size = p.kind, p.size
+        return self
+
+    def checksum_flag(self, flag: bool):
+        self._o.checksum = int(flag)
+        return self
+
+    def compression_level(self, level: int):
+        self._o.level = level
+        return self
+
+    def batch_frames(self, n: int):
+        self._o.batch_frames = n
+        return self
+
+    def into_raw_encoder(self):
+        return RawEncoder(self)
+
+    def into_encoder(self, writer):
+        return Encoder(writer, self)
+
+
+def _inbuf(b):
+    b = bytes(b) if not isinstance(b, (bytes, bytearray, memoryview)) else b
+    return b, len(b)
+
+
+class RawEncoder:                      # encode.rs:209-545
+    def __init__(self, opts: EncodeOptions = None):
+        opts = opts or EncodeOptions()
+        self._engine = opts._engine
+        h = _P()
+        _chk(lib.zk_raw_encoder_new(opts._engine._h if opts._engine else None, C.byref(opts._o), C.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def new():
+        return RawEncoder()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.zk_raw_encoder_free(self._h)
+            self._h = None
+
+    def compress(self, inp, out) -> CompressionProgress:
+        inp = bytes(inp)
+        n = len(out)
+        arr = (C.c_uint8 * n).from_buffer(out) if n else None
+        i, o = C.c_size_t(), C.c_size_t()
+        _chk(lib.zk_raw_encoder_compress(self._h, inp, len(inp), arr, n, C.byref(i), C.byref(o)))
+        return CompressionProgress(i.value, o.value)
+
+    def compress_with_prefix(self, inp, out, prefix) -> CompressionProgress:
+        inp = bytes(inp)
+        n = len(out)
+        arr = (C.c_uint8 * n).from_buffer(out) if n else None
+        i, o = C.c_size_t(), C.c_size_t()
+        p = bytes(prefix) if prefix is not None else None
+        _chk(lib.zk_raw_encoder_compress_with_prefix(self._h, inp, len(inp), arr, n, p, len(p) if p else 0, C.byref(i), C.byref(o)))
+        return CompressionProgress(i.value, o.value)
+
+    def end_frame(self, out) -> EpilogueProgress:
+        n = len(out)
+        arr = (C.c_uint8 * n).from_buffer(out) if n else None
+        o, left = C.c_size_t(), C.c_size_t()
+        _chk(lib.zk_raw_encoder_end_frame(self._h, arr, n, C.byref(o), C.byref(left)))
+        return EpilogueProgress(o.value, left.value)
+
+    def seek_table(self) -> SeekTable:
+        return SeekTable(lib.zk_raw_encoder_seek_table(self._h))
+
+    def into_seek_table(self) -> SeekTable:
+        return self.seek_table()
+
+    def reset_frame(self):
+        lib.zk_raw_encoder_reset_frame(self._h)
+
+    def reset_seek_table(self):
+        lib.zk_raw_encoder_reset_seek_table(self._h)
+
+
+class Encoder:                         # encode.rs:570-800
+    def __init__(self, writer, opts: EncodeOptions = None):
+        """writer: anything with .write(bytes) (and optionally .flush()) -- io::Write."""
+        opts = opts or EncodeOptions()
+        self._engine = opts._engine
+        self._writer = writer
+
+        def _cb(_user, data, n):
+            try:
+                writer.write(C.string_at(data, n))
+                return 0
+            except Exception:           # surfaces as Error::IO
+                return 1
+        self._cb = _WRITE_FN(_cb)
+        h = _P()
+        _chk(lib.zk_encoder_new(opts._engine._h if opts._engine else None, C.byref(opts._o), self._cb, None, C.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def new(writer):
+        return Encoder(writer)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.zk_encoder_free(self._h)
+            self._h = None
+
+    def compress(self, buf) -> int:
+        buf = bytes(buf)
+        return _chk(lib.zk_encoder_compress(self._h, buf, len(buf)))
+
+    write = compress                   # impl io::Write
+
+    def write_all(self, buf):
+        self.compress(buf)
+
+    def end_frame(self) -> int:
+        return _chk(lib.zk_encoder_end_frame(self._h))
+
+    def flush(self):
+        _chk(lib.zk_encoder_flush(self._h))
+        if hasattr(self._writer, "flush"):
+            self._writer.flush()
+
+    def finish(self) -> int:
+        return self.finish_format(Format.Foot)
+
+    def finish_format(self, fmt: Format) -> int:
+        v = C.c_uint64()
+        _chk(lib.zk_encoder_finish(self._h, int(fmt), C.byref(v)))
+        if hasattr(self._writer, "flush"):
+            self._writer.flush()
+        return v.value
+
+    def written_compressed(self) -> int:
+        return lib.zk_encoder_written_compressed(self._h)
+
+    def seek_table(self) -> SeekTable:
+        return SeekTable(lib.zk_encoder_seek_table(self._h))
+
+    into_seek_table = seek_table

@@ -10,6 +10,13 @@ using namespace zeekstd;
 struct zk_seek_table { SeekTable t; };
 struct zk_serializer { Serializer s; };
 struct zk_decoder { Decoder d; explicit zk_decoder(Decoder &&x) : d(std::move(x)) {} };
+struct zk_raw_encoder { RawEncoder r; explicit zk_raw_encoder(RawEncoder &&x) : r(std::move(x)) {} };
+struct CallbackWriter : Writer {
+    zk_write_fn fn; void *user;
+    CallbackWriter(zk_write_fn f, void *u) : fn(f), user(u) {}
+    void write_all(const uint8_t *p, size_t n) override { if (n && fn(user, p, n) != 0) throw Error::io("writer callback failed"); }
+};
+struct zk_encoder { Encoder e; zk_encoder(std::shared_ptr<Writer> w, EncodeOptions &&o) : e(std::move(w), std::move(o)) {} };
 
 static thread_local std::string g_last_error;
 
@@ -153,5 +160,71 @@ int zk_decoder_seek(zk_decoder *d, int whence, int64_t n, uint64_t *out)
         if (out) *out = v;
     });
 }
+
+// ---------------------------------------------------------------- RawEncoder / Encoder
+static EncodeOptions make_enc_opts(zk_engine *e, const zk_encode_opts *o)
+{
+    EncodeOptions opts;
+    if (e) opts.engine(e);
+    if (o) {
+        if (o->frame_size) opts.frame_size_policy(o->policy == ZK_POLICY_COMPRESSED ? FrameSizePolicy::Compressed(o->frame_size)
+                                                                                   : FrameSizePolicy::Uncompressed(o->frame_size));
+        opts.checksum_flag(o->checksum != 0).compression_level(o->level);
+        if (o->batch_frames) opts.batch_frames(o->batch_frames);
+    }
+    return opts;
+}
+
+int zk_raw_encoder_new(zk_engine *e, const zk_encode_opts *o, zk_raw_encoder **out)
+{
+    if (!out) return ZK_ERR_ARGUMENT;
+    *out = nullptr;
+    return guard([&] { *out = new zk_raw_encoder(RawEncoder(make_enc_opts(e, o))); });
+}
+void zk_raw_encoder_free(zk_raw_encoder *r) { delete r; }
+int zk_raw_encoder_compress(zk_raw_encoder *r, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, size_t *in_progress,
+                            size_t *out_progress)
+{
+    return guard([&] { CompressionProgress p = r->r.compress(in, in_len, out, out_len); *in_progress = p.in_progress(); *out_progress = p.out_progress(); });
+}
+int zk_raw_encoder_compress_with_prefix(zk_raw_encoder *r, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len,
+                                        const uint8_t *prefix, size_t plen, size_t *in_progress, size_t *out_progress)
+{
+    return guard([&] { CompressionProgress p = r->r.compress_with_prefix(in, in_len, out, out_len, prefix, plen); *in_progress = p.in_progress(); *out_progress = p.out_progress(); });
+}
+int zk_raw_encoder_end_frame(zk_raw_encoder *r, uint8_t *out, size_t out_len, size_t *out_progress, size_t *data_left)
+{
+    return guard([&] { EpilogueProgress p = r->r.end_frame(out, out_len); *out_progress = p.out_progress(); *data_left = p.data_left(); });
+}
+zk_seek_table *zk_raw_encoder_seek_table(const zk_raw_encoder *r) { return new (std::nothrow) zk_seek_table{r->r.seek_table()}; }
+void zk_raw_encoder_reset_frame(zk_raw_encoder *r) { r->r.reset_frame(); }
+void zk_raw_encoder_reset_seek_table(zk_raw_encoder *r) { r->r.reset_seek_table(); }
+
+int zk_encoder_new(zk_engine *e, const zk_encode_opts *o, zk_write_fn write, void *user, zk_encoder **out)
+{
+    if (!out || !write) return ZK_ERR_ARGUMENT;
+    *out = nullptr;
+    return guard([&] { *out = new zk_encoder(std::make_shared<CallbackWriter>(write, user), make_enc_opts(e, o)); });
+}
+void zk_encoder_free(zk_encoder *e) { delete e; }
+int64_t zk_encoder_compress(zk_encoder *e, const uint8_t *buf, size_t len)
+{
+    int64_t n = 0;
+    int rc = guard([&] { n = (int64_t)e->e.compress(buf, len); });
+    return rc ? rc : n;
+}
+int64_t zk_encoder_end_frame(zk_encoder *e)
+{
+    int64_t n = 0;
+    int rc = guard([&] { n = (int64_t)e->e.end_frame(); });
+    return rc ? rc : n;
+}
+int zk_encoder_flush(zk_encoder *e) { return guard([&] { e->e.flush(); }); }
+int zk_encoder_finish(zk_encoder *e, int format, uint64_t *total)
+{
+    return guard([&] { uint64_t t = e->e.finish_format(format == ZK_FORMAT_HEAD ? Format::Head : Format::Foot); if (total) *total = t; });
+}
+uint64_t zk_encoder_written_compressed(const zk_encoder *e) { return e->e.written_compressed(); }
+zk_seek_table *zk_encoder_seek_table(const zk_encoder *e) { return new (std::nothrow) zk_seek_table{e->e.seek_table()}; }
 
 }  // extern "C"

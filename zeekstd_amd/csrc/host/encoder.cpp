@@ -1,0 +1,211 @@
+// encoder.cpp -- zeekstd::RawEncoder / Encoder on the batch engine.  Mirrors /root/reference/lib/src/encode.rs.
+//
+// libzstd streams: every compress() call may emit output.  Here a frame is encoded by ONE engine
+// submission once it is complete, so RawEncoder::compress() only accepts input (out_progress = 0) and the
+// compressed bytes of a frame appear through end_frame() -- or through the compress() call that finds the
+// frame complete, exactly the call that runs the end_frame loop upstream (encode.rs:317-327).  Frame
+// boundaries, in/out accounting, the seek table and the "close OR compress, never both" rule are kept.
+// Encoder<W> additionally gathers `batch_frames` complete frames per submission (EncodeOptions::batch_frames).
+#include <string.h>
+#include <algorithm>
+#include "../../../include/zeekstd_amd.h"
+#include "zeekstd.hpp"
+
+namespace zeekstd {
+
+static const uint32_t MAX_FRAME_SIZE = (uint32_t)SEEKABLE_MAX_FRAME_SIZE;      // encode.rs:14
+
+RawEncoder EncodeOptions::into_raw_encoder() { return RawEncoder(std::move(*this)); }
+Encoder EncodeOptions::into_encoder(std::shared_ptr<Writer> writer) { return Encoder(std::move(writer), std::move(*this)); }
+
+RawEncoder::RawEncoder() : RawEncoder(EncodeOptions()) {}
+
+RawEncoder::RawEncoder(EncodeOptions &&opts)                                   // with_opts, encode.rs:280-293
+    : policy_(opts.policy_), checksum_(opts.checksum_), level_(opts.level_)
+{
+    if (policy_.kind == FrameSizePolicy::Kind::Compressed)
+        // frame boundaries that depend on the compressed size need incremental output ("next")
+        throw Error::zstd(40 /* parameter_unsupported */);
+    if (opts.engine_) engine_ = opts.engine_;
+    else {                                                                     // CCtx::create(), encode.rs:130
+        int rc = zk_engine_create(0, &engine_);
+        if (rc != 0) throw Error::from_engine_code(rc);
+        owns_engine_ = true;
+    }
+}
+
+RawEncoder::~RawEncoder() { if (owns_engine_ && engine_) zk_engine_destroy(engine_); }
+
+RawEncoder::RawEncoder(RawEncoder &&o) noexcept
+    : engine_(o.engine_), owns_engine_(o.owns_engine_), policy_(o.policy_), checksum_(o.checksum_), level_(o.level_),
+      frame_c_size_(o.frame_c_size_), frame_d_size_(o.frame_d_size_), seek_table_(std::move(o.seek_table_)),
+      frame_in_(std::move(o.frame_in_)), pending_(std::move(o.pending_)), pending_pos_(o.pending_pos_), encoded_(o.encoded_)
+{
+    o.engine_ = nullptr; o.owns_engine_ = false;
+}
+
+size_t RawEncoder::remaining_frame_size() const                                // encode.rs:528-535
+{
+    return std::min(MAX_FRAME_SIZE, policy_.size) - frame_d_size_;
+}
+
+bool RawEncoder::is_frame_complete() const                                     // encode.rs:537-544
+{
+    return std::min(MAX_FRAME_SIZE, policy_.size) <= frame_d_size_;
+}
+
+void RawEncoder::encode_pending()
+{
+    if (encoded_) return;
+    const size_t n = frame_in_.size();
+    pending_.resize((size_t)zk_compress_bound(n, n ? (uint32_t)n : 1));
+    uint32_t c = 0, d = 0, nf = 0;
+    uint64_t written = 0;
+    int rc = zk_encode_frames(engine_, frame_in_.data(), n, n ? (uint32_t)n : 1, level_, checksum_ ? 1 : 0, pending_.data(),
+                              pending_.size(), &c, &d, 1, &nf, &written);
+    if (rc != 0) throw Error::from_engine_code(rc, zk_engine_last_hip_error(engine_));
+    pending_.resize((size_t)written);
+    pending_pos_ = 0;
+    encoded_ = true;
+}
+
+CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len,
+                                                     const uint8_t *prefix, size_t)
+{
+    if (prefix) throw Error::zstd(40 /* parameter_unsupported: prefix/patch mode, SURVEY 8f-3 */);
+    if (is_frame_complete()) {                                                 // encode.rs:317-327
+        size_t out_progress = 0;
+        while (out_progress < out_len) {
+            EpilogueProgress p = end_frame(out + out_progress, out_len - out_progress);
+            out_progress += p.out_progress();
+            if (p.data_left() == 0) break;
+        }
+        return {0, out_progress};
+    }
+    const size_t limit = std::min(in_len, remaining_frame_size());             // encode.rs:329
+    frame_in_.insert(frame_in_.end(), in, in + limit);
+    frame_d_size_ += (uint32_t)limit;                                          // encode.rs:350
+    return {limit, 0};
+}
+
+EpilogueProgress RawEncoder::end_frame(uint8_t *out, size_t out_len)           // encode.rs:438-472
+{
+    encode_pending();
+    const size_t n = std::min(out_len, pending_.size() - pending_pos_);
+    memcpy(out, pending_.data() + pending_pos_, n);
+    pending_pos_ += n;
+    frame_c_size_ += (uint32_t)n;
+    const size_t left = pending_.size() - pending_pos_;
+    if (left) return {n, left};                                                // more buffer space is required
+    seek_table_.log_frame(frame_c_size_, frame_d_size_);                       // encode.rs:466-467
+    reset_frame();
+    return {n, 0};
+}
+
+void RawEncoder::reset_frame()                                                 // encode.rs:501-507
+{
+    frame_c_size_ = 0; frame_d_size_ = 0;
+    frame_in_.clear(); pending_.clear(); pending_pos_ = 0; encoded_ = false;
+}
+
+// ---------------------------------------------------------------- Encoder<W>
+Encoder::Encoder(std::shared_ptr<Writer> writer) : Encoder(std::move(writer), EncodeOptions()) {}
+
+Encoder::Encoder(std::shared_ptr<Writer> writer, EncodeOptions &&opts)         // with_opts, encode.rs:596-606
+    : raw_(EncodeOptions(opts)), writer_(std::move(writer)), out_buf_(131591 /* ZSTD_CStreamOutSize, encode.rs:599 */),
+      batch_frames_(opts.batch_frames_)
+{
+}
+
+void Encoder::emit(const uint8_t *p, size_t n)                                 // through the staging buffer, like encode.rs:641-665
+{
+    while (n) {
+        const size_t k = std::min(n, out_buf_.size() - out_buf_pos_);
+        memcpy(out_buf_.data() + out_buf_pos_, p, k);
+        out_buf_pos_ += k; p += k; n -= k;
+        flush_out_buf(false);
+    }
+}
+
+void Encoder::flush_out_buf(bool force)                                        // encode.rs:779-787
+{
+    if (out_buf_pos_ == out_buf_.size() || force) {
+        writer_->write_all(out_buf_.data(), out_buf_pos_);
+        written_compressed_ += out_buf_pos_;
+        out_buf_pos_ = 0;
+    }
+}
+
+// Encode the complete frames gathered so far (and the partial tail frame if asked) with one submission.
+void Encoder::submit_batch(bool include_partial)
+{
+    const uint32_t fs = std::min(MAX_FRAME_SIZE, raw_.policy_.size);
+    // without include_partial the trailing frame stays behind, full or not: it is still open upstream
+    size_t take = batch_in_.empty() ? 0 : ((batch_in_.size() - 1) / fs) * (size_t)fs;
+    if (include_partial) take = batch_in_.size();
+    if (take == 0 && !include_partial) return;
+    std::vector<uint8_t> out((size_t)zk_compress_bound(take, fs));
+    const size_t nf_cap = take == 0 ? 1 : (take + fs - 1) / fs;
+    std::vector<uint32_t> c(nf_cap), d(nf_cap);
+    uint32_t nf = 0;
+    uint64_t written = 0;
+    int rc = zk_encode_frames(raw_.engine_, batch_in_.data(), take, fs, raw_.level_, raw_.checksum_ ? 1 : 0, out.data(), out.size(),
+                              c.data(), d.data(), (uint32_t)nf_cap, &nf, &written);
+    if (rc != 0) throw Error::from_engine_code(rc, zk_engine_last_hip_error(raw_.engine_));
+    emit(out.data(), (size_t)written);
+    for (uint32_t i = 0; i < nf; i++) raw_.seek_table_.log_frame(c[i], d[i]);
+    batch_in_.erase(batch_in_.begin(), batch_in_.begin() + (ptrdiff_t)take);
+}
+
+size_t Encoder::compress_with_prefix(const uint8_t *buf, size_t len, const uint8_t *prefix, size_t)   // encode.rs:641-665
+{
+    if (prefix) throw Error::zstd(40 /* parameter_unsupported */);
+    const uint32_t fs = std::min(MAX_FRAME_SIZE, raw_.policy_.size);
+    batch_in_.insert(batch_in_.end(), buf, buf + len);
+    since_end_ += len;
+    // the last full frame stays open (upstream closes it on the NEXT call), so it is held back
+    if (batch_in_.size() > (size_t)fs * batch_frames_) submit_batch(false);
+    return len;
+}
+
+size_t Encoder::end_frame()                                                    // encode.rs:704-717
+{
+    // Upstream a frame stays open -- even when it is full -- until the next compress() call or end_frame():
+    // ending a frame that has received no byte since the last end_frame yields an EMPTY frame, anything
+    // else is exactly the frames already cut every frame_size bytes plus the partial tail.
+    const uint64_t before = written_compressed_ + out_buf_pos_;
+    if (since_end_ == 0 || !batch_in_.empty()) submit_batch(true);
+    since_end_ = 0;
+    return (size_t)(written_compressed_ + out_buf_pos_ - before);
+}
+
+uint64_t Encoder::finish_format(Format format)                                 // encode.rs:755-775
+{
+    end_frame();                                                               // always (encode.rs:756): an empty stream yields one empty frame
+    Serializer ser = raw_.seek_table_.into_format_serializer(format);
+    for (;;) {
+        size_t n = ser.write_into(out_buf_.data() + out_buf_pos_, out_buf_.size() - out_buf_pos_);
+        if (n == 0) {
+            writer_->write_all(out_buf_.data(), out_buf_pos_);
+            written_compressed_ += out_buf_pos_;
+            out_buf_pos_ = 0;
+            writer_->flush();
+            return written_compressed_;
+        }
+        out_buf_pos_ += n;
+        if (out_buf_pos_ == out_buf_.size()) {
+            writer_->write_all(out_buf_.data(), out_buf_pos_);
+            written_compressed_ += out_buf_pos_;
+            out_buf_pos_ = 0;
+        }
+    }
+}
+
+void Encoder::flush()                                                          // io::Write::flush, encode.rs:796-799
+{
+    submit_batch(false);                                                       // complete frames are pushed out
+    flush_out_buf(true);
+    writer_->flush();
+}
+
+}  // namespace zeekstd

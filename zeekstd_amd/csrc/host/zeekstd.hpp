@@ -345,6 +345,7 @@ private:
     size_t out_buf_pos_ = 0;
     uint64_t written_compressed_ = 0;
     uint32_t batch_frames_ = 64;
+    uint64_t since_end_ = 0;                  // bytes accepted since the last end_frame
     std::vector<uint8_t> batch_in_;           // whole frames (+ the partial one at the tail) awaiting submission
 };
 
