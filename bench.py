@@ -30,32 +30,43 @@ FRAME = 2 << 20
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
+_SHM = None
+
+
 def _make_part(job):
-    """Worker (forked, CPU only): generate chunks [k0, k0+n) and compress them with the reference loop."""
-    k0, n, level, cks = job
+    """Worker (forked, CPU only): generate chunks [k0+i0, k0+i0+n) into the shared buffer; optionally compress
+    them with the reference Encoder loop over the box's libzstd."""
+    k0, i0, n, level, cks, want_archive = job
     from oracle import zko, libzstd_ref as Z
-    data = zko.gen_chunks(n * FRAME, k0)
-    which = "system" if Z.load("system") is not None else None
-    if which is None:
-        raise RuntimeError("no libzstd on this box to prepare the archive")
-    comp, frames = Z.encode_seekable_frames(data, FRAME, level, cks, which)
+    data = zko.gen_chunks(n * FRAME, k0 + i0)
+    _SHM[i0 * FRAME:(i0 + n) * FRAME] = np.frombuffer(data, np.uint8)
     hashes = [zko.xxh64(data[i * FRAME:(i + 1) * FRAME]) for i in range(n)]
+    if not want_archive:
+        return b"", [], hashes
+    if Z.load("system") is None:
+        raise RuntimeError("no libzstd on this box to prepare the archive")
+    comp, frames = Z.encode_seekable_frames(data, FRAME, level, cks, "system")
     return comp, frames, hashes
 
 
-def build_archive(k0, nframes, level, cks, workers):
+def build_inputs(k0, nframes, level, cks, workers, want_archive, tag):
+    """Returns (data as a uint8 array backed by /dev/shm, libzstd payload, frames, per-frame XXH64)."""
+    global _SHM
+    path = f"/dev/shm/zk_bench_{os.getpid()}_{tag}.bin"
+    _SHM = np.memmap(path, dtype=np.uint8, mode="w+", shape=(nframes * FRAME,))
     per = max(1, min(16, nframes // max(1, workers)))
-    jobs = [(k0 + i, min(per, nframes - i), level, cks) for i in range(0, nframes, per)]
+    jobs = [(k0, i, min(per, nframes - i), level, cks, want_archive) for i in range(0, nframes, per)]
     with mp.get_context("fork").Pool(workers) as pool:
         parts = pool.map(_make_part, jobs)
+    os.unlink(path)                                    # the mapping stays valid until it is dropped
     comp = b"".join(p[0] for p in parts)
     frames = [f for p in parts for f in p[1]]
     hashes = [h for p in parts for h in p[2]]
-    return comp, frames, hashes
+    return _SHM, comp, frames, hashes
 
 
-def cpu_baseline(comp, frames, sample_frames, target_seconds=10.0):
-    """Reference CPU path (C restatement of zeekstd::Decoder's loop over the box's libzstd), 1 thread."""
+def cpu_baseline(comp, frames, data, sample_frames, level, cks, target_seconds=8.0):
+    """Reference CPU path (C restatement of zeekstd's Decoder / Encoder loops over the box's libzstd), 1 thread."""
     from oracle import zko, libzstd_ref as Z
     lib = zko.lib()
     path = next((p for p in Z._CANDIDATES["system"] if os.path.exists(p)), None)
@@ -64,6 +75,9 @@ def cpu_baseline(comp, frames, sample_frames, target_seconds=10.0):
     lib.zkb_version.restype = C.c_char_p
     lib.zkb_time_decode.restype = C.c_double
     lib.zkb_time_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+    lib.zkb_time_encode.restype = C.c_double
+    lib.zkb_time_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                    C.POINTER(C.c_int64)]
     n = min(sample_frames, len(frames))
     csz = sum(f[0] for f in frames[:n])
     dsz = sum(f[1] for f in frames[:n])
@@ -73,10 +87,20 @@ def cpu_baseline(comp, frames, sample_frames, target_seconds=10.0):
         return None
     reps = max(1, min(20, int(target_seconds / t1) - 1))
     best = min(t1, lib.zkb_time_decode(comp[:csz], csz, dsz, reps, C.byref(sink)))
-    return {"value": dsz / best / 2**30, "unit": "GiB/s", "cores": 1, "kind": "port",
-            "sample": f"zeekstd::Decoder loop (decode.rs:201-270, bench protocol decompress.rs:18-39) in C over dlopen'd "
-                      f"libzstd {lib.zkb_version().decode()}, first {n} frames ({dsz >> 20} MiB) of the same archive, "
-                      f"best of {reps + 1} passes, 1 thread"}
+    out = {"value": dsz / best / 2**30, "unit": "GiB/s", "cores": 1, "kind": "port",
+           "sample": f"zeekstd::Decoder loop (decode.rs:201-270, bench protocol decompress.rs:18-39) in C over dlopen'd "
+                     f"libzstd {lib.zkb_version().decode()}, first {n} frames ({dsz >> 20} MiB) of the same archive, "
+                     f"best of {reps + 1} passes, 1 thread"}
+    # encode side, for the record: zeekstd::Encoder loop at the same level on 128 frames
+    ne = min(128, len(frames))
+    src = np.ascontiguousarray(data[:ne * FRAME])
+    dst = np.empty(src.size + (src.size >> 6) + 65536, np.uint8)
+    csize = C.c_int64()
+    te = lib.zkb_time_encode(src.ctypes.data, src.size, FRAME, level, int(cks), 2, dst.ctypes.data, dst.size, C.byref(csize))
+    if te > 0:
+        out["encode"] = {"value": src.size / te / 2**30, "unit": "GiB/s", "ratio": round(src.size / csize.value, 3),
+                         "sample": f"zeekstd::Encoder loop (encode.rs:311-354,438-472) level {level}, {ne} frames, best of 2, 1 thread"}
+    return out
 
 
 def main():
@@ -87,6 +111,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c2"])
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--archive", default="auto", choices=["auto", "gpu", "libzstd"],
+                    help="who compresses the archive that is decoded: the GPU encoder (default for c3) or CPU libzstd (default for c2)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,12 +127,10 @@ def main():
     # ---- untimed setup on the host cores (before any HIP initialisation: workers are forked)
     cores = os.cpu_count() or 8
     workers = max(1, min(64, cores // max(1, world) - 1))
+    use_gpu_archive = args.archive == "gpu" or (args.archive == "auto" and args.workload == "c3")
     t0 = time.time()
-    comp, frames, hashes = build_archive(rank * nframes, nframes, level, cks, workers)
+    data, z_comp, z_frames, hashes = build_inputs(rank * nframes, nframes, level, cks, workers, not use_gpu_archive, rank)
     t_setup = time.time() - t0
-    base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_baseline(comp, frames, 512 if args.workload == "c3" else 128)
 
     import torch
     import torch.distributed as dist
@@ -116,13 +140,45 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     eng = zk.Engine(local_rank)
+    dsize = nframes * FRAME
+    d_src = torch.from_numpy(np.asarray(data)).to(dev)
 
+    # ---- the archive: produced by the GPU encoder (configs[2]) or by the CPU reference path (configs[1])
+    enc_info = None
+    if use_gpu_archive:
+        cap = int(zk.lib.zk_compress_bound(dsize, FRAME))
+        d_comp = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+        d_cs = torch.zeros(nframes, dtype=torch.int32, device=dev)
+        d_ds = torch.zeros(nframes, dtype=torch.int32, device=dev)
+        nf, csize = eng.encode_frames_dev(d_src, dsize, FRAME, level, cks, d_comp, cap, d_cs, d_ds)      # warm-up + the archive
+        torch.cuda.synchronize()
+        te = []
+        for _ in range(max(2, args.steps // 2)):
+            t = time.perf_counter()
+            eng.encode_frames_dev(d_src, dsize, FRAME, level, cks, d_comp, cap, d_cs, d_ds)
+            te.append(time.perf_counter() - t)
+        eng.set_profiling(True)
+        eng.encode_frames_dev(d_src, dsize, FRAME, level, cks, d_comp, cap, d_cs, d_ds)
+        ek = eng.kernel_times()
+        eng.set_profiling(False)
+        cs = d_cs.cpu().numpy().astype(np.uint64)
+        frames = [(int(c), FRAME) for c in cs]
+        comp = None
+        enc_info = {"value": round(dsize / min(te) / 2**30, 2), "unit": "GiB/s", "ratio": round(dsize / csize, 3),
+                    "ms": round(min(te) * 1e3, 2), "kernel_ms": {k: round(v, 3) for k, v in ek.items()}}
+    else:
+        frames, comp = z_frames, z_comp
+        d_comp = torch.from_numpy(np.frombuffer(comp + b"\0" * 64, np.uint8).copy()).to(dev)
     c = np.zeros(nframes + 1, np.uint64)
     d = np.zeros(nframes + 1, np.uint64)
     c[1:] = np.cumsum([f[0] for f in frames])
     d[1:] = np.cumsum([f[1] for f in frames])
-    csize, dsize = int(c[-1]), int(d[-1])
-    d_comp = torch.from_numpy(np.frombuffer(comp + b"\0" * 64, np.uint8).copy()).to(dev)
+    csize = int(c[-1])
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if comp is None:
+            comp = bytes(d_comp[:csize].cpu().numpy())             # CPU decodes the very same (GPU-made) archive
+        base = cpu_baseline(comp, frames, data, 512 if args.workload == "c3" else 128, level, cks)
     d_c = torch.from_numpy(c.view(np.int64)).to(dev)
     d_d = torch.from_numpy(d.view(np.int64)).to(dev)
     d_out = torch.empty(dsize + 64, dtype=torch.uint8, device=dev)
@@ -145,6 +201,8 @@ def main():
     got = d_hash.cpu().numpy().view(np.uint64)
     if not np.array_equal(got, np.array(hashes, dtype=np.uint64)) or int(d_st.abs().sum().item()) != 0:
         raise RuntimeError("GPU decode is not bit-exact against the generator bytes")
+    if not torch.equal(d_out[:dsize], d_src):
+        raise RuntimeError("GPU decode differs from the input bytes")
 
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -172,6 +230,22 @@ def main():
     algo_bytes = csize + dsize                    # decode = c_i + d_i per frame, summed over the launch
     achieved = algo_bytes / (acc[dom] * 1e-3) / 1e9
 
+    # ---- N > 1: the one exchange step of the path -- encode the local shard, gather stream + seek table on rank 0 (RCCL)
+    gather_info = None
+    if world > 1 and use_gpu_archive:
+        try:
+            from zeekstd_amd import parallel
+            tg = []
+            for _ in range(2):
+                barrier(); torch.cuda.synchronize(); t = time.perf_counter()
+                out, table = parallel.encode_sharded(eng, d_src, FRAME, level, cks, root=0)
+                torch.cuda.synchronize(); barrier(); tg.append(time.perf_counter() - t)
+            gather_info = {"encode_plus_gather_GiB_per_s": round(dsize * world / min(tg) / 2**30, 2), "ms": round(min(tg) * 1e3, 2),
+                           "frames_on_root": table.num_frames() if table is not None else None,
+                           "stream_bytes_on_root": int(out.numel()) if out is not None else None}
+        except Exception as ex:              # never lose the headline line to the optional leg
+            gather_info = {"error": repr(ex)[:200]}
+
     if rank == 0:
         line = {
             "metric": "decode_decompressed_GiB_per_s", "value": round(value, 3), "unit": "GiB/s",
@@ -181,13 +255,16 @@ def main():
             "config": {"workload": ("configs[2]: 4 GiB/GPU, 2048 x 2 MiB frames, level 1, XXH64 checksums verified"
                                     if args.workload == "c3" else "configs[1]: 256 MiB, 128 x 2 MiB frames, level 1, decode-only"),
                        "frames_per_gpu": nframes, "frame_size": FRAME, "compressed_bytes_per_gpu": csize,
-                       "archive": "CPU libzstd (reference Encoder loop), inputs from the SURVEY 8d generator",
+                       "archive": ("GPU encoder of this engine (zk_encode_frames_dev)" if use_gpu_archive else "CPU libzstd (reference Encoder loop)")
+                                  + ", inputs from the SURVEY 8d generator",
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",
                        "bit_exact": True},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": {k: round(v, 3) for k, v in acc.items()}},
             "cpu_baseline": base,
+            "encode": enc_info,
+            "rccl_gather": gather_info,
             "setup_s": round(t_setup, 1),
         }
         if base:

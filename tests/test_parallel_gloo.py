@@ -1,0 +1,86 @@
+"""The N>1 path on CPU: world_size-2 gloo processes run the same gather code the GPUs run over RCCL
+(zeekstd_amd/parallel.py): shard ranges, size exchange, point-to-point payload gather, seek-entry gather,
+seek table appended on the root.  The per-rank encoder here is the CPU oracle (test infrastructure) --
+the collective logic is what is under test; the GPU encoder is covered by tests/test_gpu_encode.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import zko
+
+FS = 1000
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zeekstd_amd import parallel
+    data = zko.gen_text(n_total, 99)
+    nframes = -(-n_total // FS)
+    lo, hi = parallel.shard_range(nframes, rank, world)
+    frames, payload = [], bytearray()
+    for f in range(lo, hi):
+        chunk = data[f * FS:(f + 1) * FS]
+        fr = zko.frame_encode(chunk, 1, True)
+        payload += fr
+        frames.append((len(fr), len(chunk)))
+    t = torch.frombuffer(bytearray(payload), dtype=torch.uint8) if payload else torch.zeros(0, dtype=torch.uint8)
+    cs = torch.tensor([f[0] for f in frames], dtype=torch.int32)
+    ds = torch.tensor([f[1] for f in frames], dtype=torch.int32)
+    out, table = parallel.gather_seekable(t, cs, ds, root=0)
+    if rank == 0:
+        q.put((bytes(out.numpy()), table.to_bytes()))
+    else:
+        assert out is None and table is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [7321, 1000, 999, 123456])
+def test_gather_seekable_world2(n_total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    stream, tbytes = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # the gathered stream is a valid seekable archive: table at the tail, frames in global order
+    import zeekstd_amd as zk
+    data = zko.gen_text(n_total, 99)
+    assert stream.endswith(tbytes)
+    st = zk.SeekTable.from_seekable(stream)
+    assert st.num_frames() == -(-n_total // FS) and st.size_decomp() == n_total
+    assert st.size_comp() + len(tbytes) == len(stream)
+    out = bytearray()
+    for i in range(st.num_frames()):
+        fr = stream[st.frame_start_comp(i):st.frame_end_comp(i)]
+        dec, used = zko.frame_decode(fr, st.frame_size_decomp(i), True)
+        assert used == len(fr)
+        out += dec
+    assert bytes(out) == data
+
+
+def test_shard_range_partitions_everything():
+    from zeekstd_amd import parallel
+    for n in (0, 1, 7, 8, 9, 2048, 16384, 16385):
+        for w in (1, 2, 3, 8):
+            got = [parallel.shard_range(n, r, w) for r in range(w)]
+            assert got[0][0] == 0 and got[-1][1] == n
+            assert all(got[i][1] == got[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in got]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,99 @@
+"""Frames sharded over the GPUs of one node (BASELINE.json configs[4]).
+
+Frames share no state, so the path shards with no data-path collective: rank r owns the contiguous frame
+range [r*F/W, (r+1)*F/W).  The ONE exchange step is the concatenation of the compressed stream and of the
+seek table on a root rank:
+   1. all_gather of one int64 per rank (its compressed byte total)  -> every rank knows every offset
+   2. payload gather to root: point-to-point isend / irecv straight into root_buf[offset_r : offset_r + c_r]
+      (RCCL has no gatherv; on xGMI every peer has its own link into the root, so the W-1 receives run
+      concurrently -- SURVEY 5 "distributed communication backend")
+   3. all_gather of the fixed-size (c_size, d_size) seek entries (padded to the largest shard)
+   4. root appends the serialised seek table (8n + 17 bytes)
+torch.distributed is plumbing here (backend "nccl" == RCCL on ROCm, "gloo" for the CPU tests); the codec work
+is the engine's.  Everything below is written against tensors so the same code runs on both backends.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .api import Format, SeekTable
+
+
+def shard_range(n_frames: int, rank: int, world: int):
+    """Contiguous frame range of `rank`: keeps the gathered stream a plain concatenation in rank order."""
+    per, extra = divmod(n_frames, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
+
+
+def gather_seekable(payload: torch.Tensor, c_sizes: torch.Tensor, d_sizes: torch.Tensor, root: int = 0, group=None,
+                    fmt: Format = Format.Foot):
+    """payload: uint8 tensor with this rank's concatenated frames; c_sizes / d_sizes: int32 tensors (one per frame).
+    Returns on root (stream tensor incl. the seek table, SeekTable); on the other ranks (None, None)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = payload.device
+    # 1. byte totals + frame counts
+    mine = torch.tensor([payload.numel(), c_sizes.numel()], dtype=torch.int64, device=dev)
+    allv = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(allv, mine, group=group)
+    totals = [int(v[0]) for v in allv]
+    counts = [int(v[1]) for v in allv]
+    offs = np.concatenate([[0], np.cumsum(totals)])
+    # 3. seek entries, padded to the largest shard
+    mx = max(max(counts), 1)
+    ent = torch.zeros(2 * mx, dtype=torch.int32, device=dev)
+    ent[:c_sizes.numel()] = c_sizes.to(torch.int32)
+    ent[mx:mx + d_sizes.numel()] = d_sizes.to(torch.int32)
+    ents = [torch.zeros(2 * mx, dtype=torch.int32, device=dev) for _ in range(world)]
+    dist.all_gather(ents, ent, group=group)
+    # 2. payload gather: every peer sends straight into its slot of the root buffer
+    table = None
+    out = None
+    if rank == root:
+        table = SeekTable.new()
+        for r in range(world):
+            e = ents[r].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            for i in range(counts[r]):
+                table.log_frame(int(e[i]), int(e[mx + i]))
+        tbytes = table.to_bytes(fmt)
+        out = torch.empty(int(offs[-1]) + len(tbytes), dtype=torch.uint8, device=dev)
+        reqs = []
+        for r in range(world):
+            dst = out[int(offs[r]):int(offs[r + 1])]
+            if r == rank:
+                dst.copy_(payload)
+            elif totals[r]:
+                reqs.append(dist.P2POp(dist.irecv, dst, r, group))
+        if reqs:
+            for w in dist.batch_isend_irecv(reqs):
+                w.wait()
+        out[int(offs[-1]):] = torch.frombuffer(bytearray(tbytes), dtype=torch.uint8).to(dev)
+    elif payload.numel():
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, payload.contiguous(), root, group)]):
+            w.wait()
+    return out, table
+
+
+def encode_sharded(engine, d_src: torch.Tensor, frame_size: int, level: int = 1, checksum: bool = False, root: int = 0,
+                   group=None, fmt: Format = Format.Foot):
+    """Each rank passes ITS shard of the input (whole frames except for the global tail); returns gather_seekable()."""
+    from . import lib
+    n = d_src.numel()
+    cap = int(lib.zk_compress_bound(n, frame_size))
+    nf = max(1, -(-n // frame_size))
+    dev = d_src.device
+    d_comp = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+    d_cs = torch.zeros(nf, dtype=torch.int32, device=dev)
+    d_ds = torch.zeros(nf, dtype=torch.int32, device=dev)
+    nfo, written = engine.encode_frames_dev(d_src, n, frame_size, level, checksum, d_comp, cap, d_cs, d_ds)
+    return gather_seekable(d_comp[:written], d_cs[:nfo], d_ds[:nfo], root, group, fmt)
+
+
+def decode_sharded(engine, comp: bytes, table: SeekTable, rank: int, world: int, verify: bool = True):
+    """Rank r decodes its contiguous frame range of a seekable archive; the output stays sharded.
+    Returns (first_frame, last_frame_exclusive, bytes)."""
+    lo, hi = shard_range(table.num_frames(), rank, world)
+    c, d = table.offsets()
+    out, st = engine.decode_frames(comp, c, d, first=lo, count=hi - lo, verify=verify)
+    return lo, hi, out
