@@ -47,9 +47,15 @@ def test_no_cpu_fallback_without_gpu():
 
 
 def test_product_never_imports_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may import / link / execute anything under oracle/."""
     pkg = os.path.join(ROOT, "zeekstd_amd")
+    bad = re.compile(r"(^\s*(from|import)\s+oracle\b)|(#\s*include\s*[\"<][^\">]*oracle)|(libzko)|(dlopen\([^)]*oracle)", re.M)
     for dp, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip")):
+            if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
-                assert "oracle" not in txt.lower() or f in ("zk_device.h",), (dp, f)
+                assert not bad.search(txt), (dp, f)
+    so = os.path.join(pkg, "libzeekstd_amd.so")
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "zko" not in needed and "libzstd" not in needed        # the product links neither the oracle nor libzstd
