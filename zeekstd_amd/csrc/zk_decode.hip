@@ -145,13 +145,18 @@ __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *com
         if (tid < 53) mlv[tid] = ml_init[tid];
     }
     __syncthreads();
-    if (lane >= ZK_FSE_PER_WAVE) return;
-    const uint32_t slot = wave * ZK_FSE_PER_WAVE + lane;
+    // gfx950 runs a wave with fewer than 16 active lanes ~3x slower per dependent instruction (measured:
+    // tools/ubench/lat3.hip), so lanes 7..20 shadow lanes 0..6: same block, same LDS tables (broadcast
+    // reads), identical LDS writes, no HBM writes.
+    if (lane >= 3 * ZK_FSE_PER_WAVE) return;
+    const bool real = lane < ZK_FSE_PER_WAVE;
+    const uint32_t slot = wave * ZK_FSE_PER_WAVE + lane % ZK_FSE_PER_WAVE;
     const uint32_t bi = blockIdx.x * ZK_FSE_BLOCKS + slot;
     if (bi >= nblocks) return;
     ZkBlock b = blocks[bi];
     if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK) return;
-    zk_decode_sequences(comp, blocks, b, &T[slot], seqs + b.seq_base, llv, mlv);
+    zk_decode_sequences(comp, blocks, b, &T[slot], seqs + b.seq_base, llv, mlv, real);
+    if (!real) return;
     ZkBlock *o = &blocks[bi];
     o->out_size = b.out_size;
     o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
@@ -354,7 +359,9 @@ __global__ __launch_bounds__(64) void zk_k_xxh64(const uint8_t *data, const uint
     const uint8_t *p = data + (d_off[first + f] - d_off[first]);
     const uint64_t len = d_off[first + f + 1] - d_off[first + f];
     const uint64_t nchunks = len >> 10;
-    uint64_t acc = lane == 0 ? XP1 + XP2 : lane == 1 ? XP2 : lane == 2 ? 0 : 0 - XP1;
+    // lanes 4..15 shadow lanes 0..3: a wave with < 16 active lanes runs ~3x slower on gfx950 (tools/ubench/lat3.hip)
+    const uint32_t kl = lane & 3;
+    uint64_t acc = kl == 0 ? XP1 + XP2 : kl == 1 ? XP2 : kl == 2 ? 0 : 0 - XP1;
     const bool aligned = (((uintptr_t)p) & 15) == 0;
     uint64_t a = 0, b = 0;
     auto ldpair = [&](uint64_t c) {
@@ -367,15 +374,15 @@ __global__ __launch_bounds__(64) void zk_k_xxh64(const uint8_t *data, const uint
         prod[2 * lane] = a * XP2; prod[2 * lane + 1] = b * XP2;
         if (c + 1 < nchunks) ldpair(c + 1);
         __syncthreads();
-        if (lane < 4) {
+        if (lane < 16) {
 #pragma unroll 8
-            for (int r = 0; r < 32; r++) acc = zk_rotl64(acc + prod[4 * r + lane], 31) * XP1;
+            for (int r = 0; r < 32; r++) acc = zk_rotl64(acc + prod[4 * r + kl], 31) * XP1;
         }
         __syncthreads();
     }
     // remaining whole stripes (< 32 of them), straight from memory
     const uint64_t nstripes = len >> 5;
-    if (lane < 4) for (uint64_t i = nchunks << 5; i < nstripes; i++) acc = zk_xround(acc, zk_ld64(p + (i << 5) + 8 * lane));
+    if (lane < 16) for (uint64_t i = nchunks << 5; i < nstripes; i++) acc = zk_xround(acc, zk_ld64(p + (i << 5) + 8 * kl));
     uint64_t v1 = __shfl(acc, 0, 64), v2 = __shfl(acc, 1, 64), v3 = __shfl(acc, 2, 64), v4 = __shfl(acc, 3, 64);
     if (lane != 0) return;
     uint64_t h;

@@ -626,8 +626,9 @@ ZK_HD uint32_t zk_rev_read_slow(ZkRev &r, uint32_t n)          // any n <= 31, r
 }
 
 // Decode all sequences of block b into seqs[]; fills b.out_size / b.rep_out / b.status.
+// store == false: a shadow lane (see zk_k_fse) -- it walks the same block as a real lane but never writes to HBM
 ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlock &b, ZkSeqTables *T, ZkSeq *seqs,
-                               const uint32_t *ll_values, const uint32_t *ml_values)
+                               const uint32_t *ll_values, const uint32_t *ml_values, bool store = true)
 {
     uint32_t al[3];
     uint32_t own = 0;                                   // bytes of table descriptions in this block
@@ -654,62 +655,80 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
     uint32_t out = 0, lit = 0;
     const uint32_t nseq = b.nseq;
     uint32_t bad = r.pos < 0;
-    // The loop body is branch-free apart from the (rare) wide-sequence path and the ring flush: errors
-    // only accumulate into `bad`; a corrupt stream keeps walking harmlessly (states stay inside their
-    // tables, window addresses are clamped) and is rejected after the loop.
-    for (uint32_t i = 0; i < nseq; i++) {
-        const uint32_t cl = T->ll[sl], co = T->of[so], cm = T->ml[sm];
-        const uint32_t nOf = zk_cell_sym(co), nMl = zk_cell_xbits(cm), nLl = zk_cell_xbits(cl);
-        const bool more = i + 1 < nseq;
-        const uint32_t nbl = more ? zk_cell_nb(cl) : 0, nbm = more ? zk_cell_nb(cm) : 0, nbo = more ? zk_cell_nb(co) : 0;
-        bad |= nOf > 30;
-        const int32_t npos = r.pos - (int32_t)(nOf + nMl + nLl + nbl + nbm + nbo);
-        // window of the NEXT sequence: its address only needs the bit counts, so the load is in
-        // flight while this sequence's fields are extracted
-        const int32_t nbyte = zk_rev_byte(npos);
-        const uint64_t Wn = zk_ld64(r.base + nbyte);
-        uint32_t ofx, mlx, llx;
-        if (npos >= r.wpos) {                           // every field lies inside the current window
-            uint64_t X = r.W << ((64 - (r.pos - r.wpos)) & 63);          // left-align the unread bits
-            ofx = nOf ? (uint32_t)(X >> 32) >> (32 - nOf) : 0; X <<= nOf;
-            mlx = nMl ? (uint32_t)(X >> 32) >> (32 - nMl) : 0; X <<= nMl;
-            llx = nLl ? (uint32_t)(X >> 32) >> (32 - nLl) : 0; X <<= nLl;
-            sl = zk_cell_base(cl) + (nbl ? (uint32_t)(X >> 32) >> (32 - nbl) : 0); X <<= nbl;
-            sm = zk_cell_base(cm) + (nbm ? (uint32_t)(X >> 32) >> (32 - nbm) : 0); X <<= nbm;
-            so = zk_cell_base(co) + (nbo ? (uint32_t)(X >> 32) >> (32 - nbo) : 0);
-        } else {                                        // > 57 bits in one sequence (or over-read): field by field
-            ofx = zk_rev_read_slow(r, nOf & 31); mlx = zk_rev_read_slow(r, nMl); llx = zk_rev_read_slow(r, nLl);
-            sl = zk_cell_base(cl) + zk_rev_read_slow(r, nbl);
-            sm = zk_cell_base(cm) + zk_rev_read_slow(r, nbm);
-            so = zk_cell_base(co) + zk_rev_read_slow(r, nbo);
+    // Sequences are decoded in groups of 16 (the LDS record ring).  The group body is one basic block:
+    // errors only accumulate into `bad` (a corrupt stream keeps walking harmlessly: states stay inside
+    // their tables, window addresses are clamped) and the rare sequence that needs more than the 57
+    // guaranteed window bits leaves the block for a field-by-field slow step.
+    uint32_t i = 0;
+    uint32_t cl = T->ll[sl], co = T->of[so], cm = T->ml[sm];
+    while (i < nseq) {
+        const uint32_t gend = i + 16 < nseq ? i + 16 : nseq;
+        while (i < gend) {
+            const uint32_t nOf = zk_cell_sym(co), nMl = zk_cell_xbits(cm), nLl = zk_cell_xbits(cl);
+            const bool more = i + 1 < nseq;
+            const uint32_t nbl = more ? zk_cell_nb(cl) : 0, nbm = more ? zk_cell_nb(cm) : 0, nbo = more ? zk_cell_nb(co) : 0;
+            const uint32_t nval = nOf + nMl + nLl;
+            const int32_t npos = r.pos - (int32_t)(nval + nbl + nbm + nbo);
+            uint32_t ofx, mlx, llx;
+            const uint32_t csl = cl, csm = cm;                                      // symbols of THIS sequence
+            if (npos >= r.wpos) {                                                   // every field lies inside the current window
+                // window of the NEXT sequence: its address only needs the bit counts
+                const int32_t nbyte = zk_rev_byte(npos);
+                const uint64_t Wn = zk_ld64(r.base + nbyte);
+                const uint64_t X = r.W << ((64 - (r.pos - r.wpos)) & 63);           // left-align the unread bits
+                // state bits first: they gate the next cell reads (the dependent chain of the walk)
+                uint64_t S = X << (nval & 63);
+                const uint32_t h0 = (uint32_t)(S >> 32); S <<= nbl;
+                const uint32_t h1 = (uint32_t)(S >> 32); S <<= nbm;
+                const uint32_t h2 = (uint32_t)(S >> 32);
+                sl = zk_cell_base(cl) + (nbl ? h0 >> (32 - nbl) : 0);
+                sm = zk_cell_base(cm) + (nbm ? h1 >> (32 - nbm) : 0);
+                so = zk_cell_base(co) + (nbo ? h2 >> (32 - nbo) : 0);
+                cl = T->ll[sl]; co = T->of[so]; cm = T->ml[sm];                     // issued early; used next iteration
+                // value bits (off the chain)
+                uint64_t V = X;
+                ofx = nOf ? (uint32_t)(V >> 32) >> (32 - nOf) : 0; V <<= nOf;
+                mlx = nMl ? (uint32_t)(V >> 32) >> (32 - nMl) : 0; V <<= nMl;
+                llx = nLl ? (uint32_t)(V >> 32) >> (32 - nLl) : 0;
+                r.pos = npos; r.W = Wn; r.wpos = nbyte * 8;
+                bad |= nOf > 30;
+            } else {                                                                // > 57 bits in one sequence (or over-read)
+                bad |= nOf > 30;
+                ofx = zk_rev_read_slow(r, nOf & 31); mlx = zk_rev_read_slow(r, nMl); llx = zk_rev_read_slow(r, nLl);
+                sl = zk_cell_base(cl) + zk_rev_read_slow(r, nbl);
+                sm = zk_cell_base(cm) + zk_rev_read_slow(r, nbm);
+                so = zk_cell_base(co) + zk_rev_read_slow(r, nbo);
+                bad |= r.pos < 0;
+                if (r.pos < 0) r.pos = 0;
+                zk_rev_load(r);
+                cl = T->ll[sl]; co = T->of[so]; cm = T->ml[sm];
+            }
+            const uint32_t ofv = (1u << (nOf & 31)) + ofx;
+            const uint32_t ml = (ml_values[zk_cell_sym(csm)] & 0xFFFFFFu) + mlx;
+            const uint32_t ll = (ll_values[zk_cell_sym(csl)] & 0xFFFFFFu) + llx;
+            // offset + repeat history, select form (A.8)
+            const bool is_rep = ofv <= 3;
+            const uint32_t idx = ofv - 1 + (ll == 0);                               // 0..3 when is_rep
+            const uint32_t r0m1 = zk_rep_is_sym(rep0) ? rep0 + 1 : rep0 - 1;        // "rep0 - 1" (symbolic: one more subtracted)
+            const uint32_t cand = idx == 0 ? rep0 : idx == 1 ? rep1 : idx == 2 ? rep2 : r0m1;
+            const uint32_t off = is_rep ? cand : ofv - 3;
+            bad |= off == 0;                                                        // concrete rep0 - 1 == 0
+            const bool sh1 = !is_rep || idx >= 1, sh2 = !is_rep || idx >= 2;
+            rep2 = sh2 ? rep1 : rep2;
+            rep1 = sh1 ? rep0 : rep1;
+            rep0 = off;
+            lit += ll; out += ll + ml;
+            bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX);
+            ZkSeq s; s.out_end = out; s.ml = ml; s.off = off; s.lit_end = lit;
+            T->ring[i & 15] = s;
+            i++;
         }
-        bad |= npos < 0;
-        r.pos = npos; r.W = Wn; r.wpos = nbyte * 8;
-        const uint32_t ofv = (1u << (nOf & 31)) + ofx;
-        const uint32_t ml = (ml_values[zk_cell_sym(cm)] & 0xFFFFFFu) + mlx;
-        const uint32_t ll = (ll_values[zk_cell_sym(cl)] & 0xFFFFFFu) + llx;
-        // offset + repeat history, select form (A.8)
-        const bool is_rep = ofv <= 3;
-        const uint32_t idx = ofv - 1 + (ll == 0);                    // 0..3 when is_rep
-        const uint32_t r0m1 = zk_rep_is_sym(rep0) ? rep0 + 1 : rep0 - 1;   // "rep0 - 1" (symbolic: one more subtracted)
-        const uint32_t cand = idx == 0 ? rep0 : idx == 1 ? rep1 : idx == 2 ? rep2 : r0m1;
-        const uint32_t off = is_rep ? cand : ofv - 3;
-        bad |= off == 0;                                             // concrete rep0 - 1 == 0
-        const bool sh1 = !is_rep || idx >= 1, sh2 = !is_rep || idx >= 2;
-        rep2 = sh2 ? rep1 : rep2;
-        rep1 = sh1 ? rep0 : rep1;
-        rep0 = off;
-        lit += ll; out += ll + ml;
-        bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX);
-        // Records are parked in LDS and written out 16 at a time (few, wide store bursts).
-        ZkSeq s; s.out_end = out; s.ml = ml; s.off = off; s.lit_end = lit;
-        T->ring[i & 15] = s;
-        if ((i & 15) == 15) {
-            for (uint32_t k = 0; k < 16; k++) seqs[i - 15 + k] = T->ring[k];
-        }
+        // records are parked in LDS and written out a group at a time (few, wide store bursts)
+        const uint32_t g0 = (i - 1) & ~15u;
+        if (store) for (uint32_t k = g0; k < i; k++) seqs[k] = T->ring[k & 15];
     }
-    if (bad || r.pos != 0) { b.status = ZK_E_CORRUPTION; return; }
-    for (uint32_t k = nseq & ~15u; k < nseq; k++) seqs[k] = T->ring[k & 15];
+    bad |= r.pos != 0;
+    if (bad) { b.status = ZK_E_CORRUPTION; return; }
     out += b.lit_regen - lit;
     if (out > ZK_BLOCK_MAX) { b.status = ZK_E_CORRUPTION; return; }
     b.out_size = out;

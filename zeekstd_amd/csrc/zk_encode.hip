@@ -142,20 +142,20 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
 // ------------------------------------------------------------------------------------------------ entropy stage
 // LSB-first bit writer into global scratch (one lane).
 struct ZkeBits {
-    uint8_t *p; uint32_t cap, pos; uint64_t acc; uint32_t n; bool ovf;
-    __device__ __forceinline__ void init(uint8_t *p_, uint32_t cap_) { p = p_; cap = cap_; pos = 0; acc = 0; n = 0; ovf = false; }
+    uint8_t *p; uint32_t cap, pos; uint64_t acc; uint32_t n; bool ovf, st;      // st == false: shadow lane, computes but never stores
+    __device__ __forceinline__ void init(uint8_t *p_, uint32_t cap_, bool st_) { p = p_; cap = cap_; pos = 0; acc = 0; n = 0; ovf = false; st = st_; }
     __device__ __forceinline__ void add(uint32_t v, uint32_t nb)
     {
         acc |= (uint64_t)(v & ((1u << nb) - 1u)) << n; n += nb;          // nb <= 24
         if (n >= 32) {
-            if (pos + 4 <= cap) { uint32_t w = (uint32_t)acc; memcpy(p + pos, &w, 4); } else ovf = true;
+            if (pos + 4 <= cap) { if (st) { uint32_t w = (uint32_t)acc; memcpy(p + pos, &w, 4); } } else ovf = true;
             pos += 4; acc >>= 32; n -= 32;
         }
     }
     __device__ __forceinline__ uint32_t close()
     {
         add(1, 1);
-        while (n > 0) { if (pos < cap) p[pos] = (uint8_t)acc; else ovf = true; pos++; acc >>= 8; n = n > 8 ? n - 8 : 0; }
+        while (n > 0) { if (pos < cap) { if (st) p[pos] = (uint8_t)acc; } else ovf = true; pos++; acc >>= 8; n = n > 8 ? n - 8 : 0; }
         return ovf ? 0u : pos;
     }
 };
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
         for (uint32_t i = tid; i < nlit; i += ZKE_ENT_THREADS) atomicAdd(&cnt[lt[i]], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 16) {                                        // 16 lanes redundantly (identical LDS writes), see above
         // literal mode: 1 = RLE, 2 = Huffman (4 streams), 0 = raw      (oracle encode_literals)
         uint32_t mode = 0, maxsym = 0, distinct = 0;
         for (uint32_t s = 0; s < 256; s++) if (cnt[s]) { maxsym = s; distinct++; }
@@ -214,18 +214,20 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
     __syncthreads();
     const uint32_t lit_mode = s_lit_mode;
     // literal streams (wave 0, lanes 0-3) and sequence bitstream (wave 1, lane 0) side by side
-    if (wave == 0 && lane < 4 && lit_mode == 2) {
-        const uint32_t k = lane;
+    // (serial lanes are shadowed up to 16 active lanes per wave: < 16 active lanes run ~3x slower on gfx950)
+    if (wave == 0 && lane < 16 && lit_mode == 2) {
+        const uint32_t k = lane & 3;
         const uint32_t n_k = k < 3 ? q : nlit - 3 * q;
         const uint8_t *sp = lt + k * q;
-        ZkeBits b; b.init(stemp + k * scap, scap);
+        ZkeBits b; b.init(stemp + k * scap, scap, lane < 4);
         for (uint32_t i = n_k; i-- > 0;) { const uint32_t s = sp[i]; b.add(hw.code[s], hw.len[s]); }   // last symbol first
-        s_sizes[k] = b.close();
+        const uint32_t sz = b.close();
+        if (lane < 4) s_sizes[k] = sz;
     }
-    if (wave == 1 && lane == 0) {
+    if (wave == 1 && lane < 16) {
         uint32_t sz = 0;
         if (nseq) {
-            ZkeBits b; b.init(qtemp, qcap);
+            ZkeBits b; b.init(qtemp, qcap, lane == 0);
             uint64_t s = sq[nseq - 1];
             uint32_t ll = (uint32_t)s & 0xFFFFF, ml = (uint32_t)(s >> 20) & 0xFFFFF, ob = (uint32_t)(s >> 40);
             uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             b.add(sm, 6); b.add(so, 5); b.add(sl, 6);
             sz = b.close();
         }
-        s_sizes[4] = sz;
+        if (lane == 0) s_sizes[4] = sz;
     }
     __syncthreads();
     // layout of the block payload
