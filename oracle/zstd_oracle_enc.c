@@ -5,10 +5,10 @@
  * compressed payload bytes are unpinned by the reference (libzstd 1.4.8 and 1.5.7 already
  * differ), only validity + round trip.  This file restates, sequentially, the algorithm the HIP kernels
  * run in parallel so that block/sequence/bitstream decisions can be compared kernel-vs-CPU byte for byte:
- *   match finder : positions in tiles of ZKE_TILE; phase 1: every position of a tile looks its 5-byte hash up
- *                  in a 2^14-entry table (window 64 KiB) as it was before the tile, and probes the offset of
- *                  the last match taken before the tile; lengths capped at 64; then the tile is inserted
- *   parse        : phase 2: greedy, left to right over the per-position results; capped matches are extended
+ *   match finder : positions in tiles of ZKE_TILE, groups of 4 tiles; phase 1: every position of a tile looks its
+ *                  5-byte hash up in a 2^14-entry table (window 64 KiB) as it was before the tile, and probes the
+ *                  offset of the last match taken before the group; lengths capped at 64; then the tile is inserted
+ *   parse        : phase 2: every tile on its own, greedy, left to right; matches end at the tile end; stitched
  *   literals     : Huffman (<= 11 bits, direct 4-bit weights) in 4 streams, or raw / RLE
  *   sequences    : FSE with the PREDEFINED LL/OF/ML tables (Symbol_Compression_Modes = 0)
  *   frame        : magic, FHD (checksum bit), Window_Descriptor, <=128 KiB blocks, optional XXH64
@@ -240,7 +240,8 @@ static size_t encode_literals(const u8 *lit, size_t n, u8 *dst, size_t cap)
 }
 
 /* ------------------------------------------------------------------ match finder + parse for one block */
-#define ZKE_PARCAP 64u              /* match length measured per position in the parallel phase; longer ones are extended by the parse */
+#define ZKE_PARCAP 64u              /* match length measured per position in phase 1; longer ones are extended by the parse */
+#define ZKE_GROUP 4u                /* tiles whose parses run side by side (one wave each on the GPU) */
 typedef struct { u32 table[1 << ZKE_HASH_LOG]; u32 probe; } enc_state;   /* table: frame-relative position + 1 (0 = empty) */
 
 static u32 match_len(const u8 *a, const u8 *b, const u8 *end)        /* b > a */
@@ -251,64 +252,61 @@ static u32 match_len(const u8 *a, const u8 *b, const u8 *end)        /* b > a */
     return (u32)(b - s);
 }
 
-/* offset -> Offset_Value.  rep[] is the history the DECODER will have; an entry of 0 means "not known to
- * the encoder": every block starts with an unknown history because the previous block may still be
- * emitted raw/RLE (which would leave the decoder's history untouched) -- the decision is taken after
- * all blocks of the frame have been parsed. */
-static u32 off_to_code(u32 off, u32 ll, u32 *rep)
-{
-    u32 code = off + 3;
-    if (ll) { if (off == rep[0]) code = 1; else if (off == rep[1] && rep[0]) code = 2; else if (off == rep[2] && rep[0] && rep[1]) code = 3; }
-    else { if (off == rep[1] && rep[0]) code = 1; else if (off == rep[2] && rep[0] && rep[1]) code = 2; else if (rep[0] > 1 && off == rep[0] - 1 && rep[1]) code = 3; }
-    if (code > 3) { rep[2] = rep[1]; rep[1] = rep[0]; rep[0] = off; }
-    else {
-        u32 idx = code - 1 + (ll == 0);
-        if (idx) { u32 v = idx == 3 ? rep[0] - 1 : rep[idx]; if (idx > 1) rep[2] = rep[1]; rep[1] = rep[0]; rep[0] = v; }
-    }
-    return code;
-}
-
-/* frame-relative positions; base = frame start. Emits sequences for block [bs, be). */
+/* frame-relative positions; base = frame start. Emits sequences for block [bs, be).
+ * Tiles are processed in groups of ZKE_GROUP: phase 1 (per-position candidates) runs tile after tile against
+ * the table as it was before each tile, all tiles of a group probing the same offset R (the last match offset
+ * before the group); then every tile is parsed on its own -- greedy, left to right, matches never cross the
+ * tile end -- and the per-tile results are stitched: literals left over at a tile's end join the next sequence.
+ * Offset_Value: 1 ("repeat the previous offset") when the offset equals the previous sequence's offset of the
+ * same block and the sequence has literals, else offset + 3.  (After any sequence the decoder's first history
+ * entry is that sequence's offset, so this needs no other state and a block never depends on how its
+ * predecessor was emitted.) */
 static u32 find_sequences(enc_state *st, const u8 *base, u32 bs, u32 be, u32 fend, seq_t *sq, u8 *lits, u32 *nlit_out)
 {
-    u32 nseq = 0, nlit = 0, anchor = bs, next = bs;                  /* next: first position the parse may still use */
-    static u32 blen[8192], boff[8192];
-    u32 rep[3] = {0, 0, 0};
-    const u8 *lim = base + be;                                       /* matches stop at the block end */
-    for (u32 ts = bs; ts < be; ts += (u32)g_tile) {
-        u32 te = ts + (u32)g_tile < be ? ts + (u32)g_tile : be;
-        const u32 R = st->probe;                                     /* offset of the last match taken before this tile */
-        /* phase 1 (parallel on the GPU): per position, the hash candidate from the table as it was BEFORE
-         * the tile, and the probe at offset R; lengths capped at ZKE_PARCAP */
-        for (u32 p = ts; p < te; p++) {
-            u32 l1 = 0, o1 = 0, l2 = 0;
-            if (p + 8 <= fend) {
-                u32 e = st->table[hash5(base + p)];
-                if (e && p - (e - 1) <= ZKE_WINDOW) { o1 = p - (e - 1); l1 = match_len(base + p - o1, base + p, base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim); }
+    u32 nseq = 0, nlit = 0, anchor = bs, prev_off = 0;
+    static u32 blen[ZKE_GROUP][8192], boff[ZKE_GROUP][8192];
+    const u32 T = (u32)g_tile;
+    for (u32 gs = bs; gs < be; gs += T * ZKE_GROUP) {
+        const u32 R = st->probe;
+        u32 ntiles = 0;
+        for (u32 ts = gs; ts < be && ntiles < ZKE_GROUP; ts += T, ntiles++) {
+            const u32 te = ts + T < be ? ts + T : be;
+            const u8 *lim = base + te;                               /* matches stop at the tile end */
+            for (u32 p = ts; p < te; p++) {
+                u32 l1 = 0, o1 = 0, l2 = 0;
+                const u8 *cap = base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim;
+                if (p + 8 <= fend) {
+                    u32 e = st->table[hash5(base + p)];
+                    if (e && p - (e - 1) <= ZKE_WINDOW) { o1 = p - (e - 1); l1 = match_len(base + p - o1, base + p, cap); }
+                }
+                if (R && R <= p) l2 = match_len(base + p - R, base + p, cap);
+                if (l1 < ZKE_MINMATCH) l1 = 0;
+                if (l2 < 4) l2 = 0;
+                if (l2 && l2 >= l1) { blen[ntiles][p - ts] = l2; boff[ntiles][p - ts] = R; }
+                else { blen[ntiles][p - ts] = l1; boff[ntiles][p - ts] = o1; }
             }
-            if (R && R <= p) l2 = match_len(base + p - R, base + p, base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim);
-            if (l1 < ZKE_MINMATCH) l1 = 0;
-            if (l2 < 4) l2 = 0;
-            if (l2 && l2 >= l1) { blen[p - ts] = l2; boff[p - ts] = R; }
-            else { blen[p - ts] = l1; boff[p - ts] = o1; }
+            for (u32 p = ts; p < te; p++) if (p + 8 <= fend) st->table[hash5(base + p)] = p + 1;   /* largest position wins a slot */
         }
-        /* phase 1b: insert the tile (largest position wins a slot) */
-        for (u32 p = ts; p < te; p++) if (p + 8 <= fend) st->table[hash5(base + p)] = p + 1;
-        /* phase 2: greedy parse of the tile */
-        u32 p = next > ts ? next : ts;
-        while (p < te) {
-            u32 len = blen[p - ts];
-            if (len) {
-                u32 off = boff[p - ts];
-                if (len == ZKE_PARCAP) len += match_len(base + p + len - off, base + p + len, lim);
-                u32 ll = p - anchor;
-                memcpy(lits + nlit, base + anchor, ll); nlit += ll;
-                sq[nseq].ll = ll; sq[nseq].ml = len; sq[nseq].offbase = off_to_code(off, ll, rep); nseq++;
-                st->probe = off;
-                p += len; anchor = p;
-            } else p++;
+        /* per-tile parses + stitching */
+        for (u32 t = 0; t < ntiles; t++) {
+            const u32 ts = gs + t * T, te = ts + T < be ? ts + T : be;
+            const u8 *lim = base + te;
+            u32 p = ts;
+            while (p < te) {
+                u32 len = blen[t][p - ts];
+                if (len) {
+                    u32 off = boff[t][p - ts];
+                    if (len == ZKE_PARCAP) len += match_len(base + p + len - off, base + p + len, lim);
+                    u32 ll = p - anchor;
+                    memcpy(lits + nlit, base + anchor, ll); nlit += ll;
+                    sq[nseq].ll = ll; sq[nseq].ml = len;
+                    sq[nseq].offbase = (ll && off == prev_off) ? 1 : off + 3;
+                    nseq++;
+                    prev_off = off; st->probe = off;
+                    p += len; anchor = p;
+                } else p++;
+            }
         }
-        next = p;
     }
     memcpy(lits + nlit, base + anchor, be - anchor); nlit += be - anchor;
     *nlit_out = nlit;

@@ -40,66 +40,75 @@ __device__ __forceinline__ uint32_t zke_match_len(const uint8_t *a, const uint8_
     return (uint32_t)(b - s);
 }
 
+// per-tile sequence as the parse leaves it in LDS: ll (12) | ml (11) << 12 | offset (17) << 23 | position in tile (10) << 40
+__device__ __forceinline__ uint64_t zke_tpack(uint32_t ll, uint32_t ml, uint32_t off, uint32_t pit) { return (uint64_t)ll | ((uint64_t)ml << 12) | ((uint64_t)off << 23) | ((uint64_t)pit << 40); }
+
 __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
-                                                              uint64_t *seqs, uint8_t *lits)
+                                                              uint64_t *seqs, uint32_t *mpos, uint8_t *lits)
 {
     __shared__ uint32_t table[1 << ZKE_HASH_LOG];          // frame-relative position + 1, 0 = empty
-    __shared__ uint32_t best[ZKE_TILE];                    // len (7 bits) | offset << 8
-    __shared__ uint32_t s_probe;
+    __shared__ uint32_t best[ZKE_GROUP][ZKE_TILE];         // len (7 bits) | offset << 8
+    __shared__ uint64_t tseq[ZKE_GROUP][ZKE_TILE / 4 + 4];
+    __shared__ uint32_t tcount[ZKE_GROUP], ttail[ZKE_GROUP];
+    __shared__ uint32_t s_scan[ZKE_THREADS];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ZkEncFrame fr = frames[blockIdx.x];
     const uint8_t *base = src + fr.src_off;
     const uint32_t fend = fr.d_size;
     for (uint32_t i = tid; i < (1u << ZKE_HASH_LOG); i += ZKE_THREADS) table[i] = 0;
-    if (tid == 0) s_probe = 1;
     __syncthreads();
-    // parse state, uniform over wave 0
-    uint32_t probe = 1;
+    uint32_t probe = 1;                                    // offset of the last match taken (same value in every thread)
     for (uint32_t bi = 0; bi < fr.n_blocks; bi++) {
         const uint32_t bs = bi * fr.block_max;
         const uint32_t be = bs + fr.block_max < fend ? bs + fr.block_max : fend;
         ZkEncBlock *blk = &blocks[fr.block_base + bi];
         uint64_t *sq = seqs + blk->seq_base;
+        uint32_t *mp = mpos + blk->seq_base;
         uint8_t *lt = lits + blk->lit_base;
-        const uint8_t *lim = base + be;
-        uint32_t nseq = 0, nlit = 0, anchor = bs, next = bs;
-        uint32_t rep0 = 0, rep1 = 0, rep2 = 0;
-        for (uint32_t ts = bs; ts < be; ts += ZKE_TILE) {
-            const uint32_t te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
-            const uint32_t R = s_probe;
-            // phase 1: candidates of every position, from the table as it was before this tile
-            uint32_t hsh[ZKE_TILE / ZKE_THREADS];
+        // block-level parse state, kept identical in every thread
+        uint32_t nseq = 0, carry = 0, prev_off = 0;
+        for (uint32_t gs = bs; gs < be; gs += ZKE_TILE * ZKE_GROUP) {
+            const uint32_t R = probe;
+            uint32_t ntiles = 0;
+            // phase 1 + insert, tile after tile
+            for (uint32_t ts = gs; ts < be && ntiles < ZKE_GROUP; ts += ZKE_TILE, ntiles++) {
+                const uint32_t te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
+                const uint8_t *lim = base + te;
+                uint32_t hsh[ZKE_TILE / ZKE_THREADS];
 #pragma unroll
-            for (int k = 0; k < ZKE_TILE / ZKE_THREADS; k++) {
-                const uint32_t p = ts + tid + k * ZKE_THREADS;
-                uint32_t l1 = 0, o1 = 0, l2 = 0;
-                hsh[k] = 0xFFFFFFFFu;
-                if (p < te) {
-                    const uint8_t *cap = base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim;
-                    if (p + 8 <= fend) {
-                        hsh[k] = zke_hash5(base + p);
-                        const uint32_t e = table[hsh[k]];
-                        if (e && p - (e - 1) <= ZKE_WINDOW) { o1 = p - (e - 1); l1 = zke_match_len(base + p - o1, base + p, cap); }
+                for (int k = 0; k < ZKE_TILE / ZKE_THREADS; k++) {
+                    const uint32_t p = ts + tid + k * ZKE_THREADS;
+                    uint32_t l1 = 0, o1 = 0, l2 = 0;
+                    hsh[k] = 0xFFFFFFFFu;
+                    if (p < te) {
+                        const uint8_t *cap = base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim;
+                        if (p + 8 <= fend) {
+                            hsh[k] = zke_hash5(base + p);
+                            const uint32_t e = table[hsh[k]];
+                            if (e && p - (e - 1) <= ZKE_WINDOW) { o1 = p - (e - 1); l1 = zke_match_len(base + p - o1, base + p, cap); }
+                        }
+                        if (R && R <= p) l2 = zke_match_len(base + p - R, base + p, cap);
+                        if (l1 < ZKE_MINMATCH) l1 = 0;
+                        if (l2 < 4) l2 = 0;
+                        best[ntiles][p - ts] = (l2 && l2 >= l1) ? (l2 | (R << 8)) : (l1 | (o1 << 8));
                     }
-                    if (R && R <= p) l2 = zke_match_len(base + p - R, base + p, cap);
-                    if (l1 < ZKE_MINMATCH) l1 = 0;
-                    if (l2 < 4) l2 = 0;
-                    best[p - ts] = (l2 && l2 >= l1) ? (l2 | (R << 8)) : (l1 | (o1 << 8));
                 }
-            }
-            __syncthreads();
-            // phase 1b: insert the tile, the largest position wins a slot
+                __syncthreads();
 #pragma unroll
-            for (int k = 0; k < ZKE_TILE / ZKE_THREADS; k++) {
-                const uint32_t p = ts + tid + k * ZKE_THREADS;
-                if (hsh[k] != 0xFFFFFFFFu) atomicMax(&table[hsh[k]], p + 1);
+                for (int k = 0; k < ZKE_TILE / ZKE_THREADS; k++) {
+                    const uint32_t p = ts + tid + k * ZKE_THREADS;
+                    if (hsh[k] != 0xFFFFFFFFu) atomicMax(&table[hsh[k]], p + 1);       // the largest position wins a slot
+                }
+                __syncthreads();
             }
-            // phase 2: greedy parse by wave 0
-            if (wave == 0) {
-                uint32_t p = next > ts ? next : ts;
+            // phase 2: wave w parses tile w on its own (greedy, matches end at the tile end)
+            if (wave < ntiles) {
+                const uint32_t ts = gs + wave * ZKE_TILE, te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
+                const uint8_t *lim = base + te;
+                uint32_t p = ts, anchor = ts, c = 0;
                 while (p < te) {
                     const uint32_t pos = p + lane;
-                    const uint32_t v = pos < te ? best[pos - ts] : 0;
+                    const uint32_t v = pos < te ? best[wave][pos - ts] : 0;
                     const uint64_t mask = __ballot((v & 0xFF) != 0);
                     if (mask == 0) { p = p + 64 < te ? p + 64 : te; continue; }
                     const int first = __builtin_ctzll(mask);
@@ -116,25 +125,57 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                             len += 64;
                         }
                     }
-                    const uint32_t ll = p - anchor;
-                    for (uint32_t i = lane; i < ll; i += 64) lt[nlit + i] = base[anchor + i];
-                    nlit += ll;
-                    const uint32_t code = zke_off_to_code(off, ll, rep0, rep1, rep2);
-                    if (lane == 0) sq[nseq] = (uint64_t)ll | ((uint64_t)len << 20) | ((uint64_t)code << 40);
-                    nseq++;
-                    probe = off;
+                    if (lane == 0) tseq[wave][c] = zke_tpack(p - anchor, len, off, p - ts);
+                    c++;
                     p += len; anchor = p;
                 }
-                next = p;
-                if (lane == 0) s_probe = probe;
+                if (lane == 0) { tcount[wave] = c; ttail[wave] = te - anchor; }
             }
             __syncthreads();
+            // stitch the tiles of the group: literals left over at a tile's end join the next sequence
+            uint32_t pend = carry, last_off = prev_off, outbase = nseq;
+            for (uint32_t t = 0; t < ntiles; t++) {
+                const uint32_t ts = gs + t * ZKE_TILE, te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
+                const uint32_t cnt = tcount[t];
+                for (uint32_t j = tid; j < cnt; j += ZKE_THREADS) {
+                    const uint64_t e = tseq[t][j];
+                    uint32_t ll = (uint32_t)e & 0xFFF;
+                    const uint32_t ml = (uint32_t)(e >> 12) & 0x7FF, off = (uint32_t)(e >> 23) & 0x1FFFF, pit = (uint32_t)(e >> 40);
+                    const uint32_t poff = j ? (uint32_t)(tseq[t][j - 1] >> 23) & 0x1FFFF : last_off;
+                    if (j == 0) ll += pend;
+                    const uint32_t code = (ll && off == poff) ? 1u : off + 3;
+                    sq[outbase + j] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)code << 40);
+                    mp[outbase + j] = ts + pit;
+                }
+                if (cnt) { pend = ttail[t]; last_off = (uint32_t)(tseq[t][cnt - 1] >> 23) & 0x1FFFF; probe = last_off; outbase += cnt; }
+                else pend += te - ts;
+            }
+            carry = pend; prev_off = last_off; nseq = outbase;
+            __syncthreads();                                 // tseq / tcount are reused; sq / mp visible to the gather pass
         }
-        if (wave == 0) {
-            const uint32_t tail = be - anchor;
-            for (uint32_t i = lane; i < tail; i += 64) lt[nlit + i] = base[anchor + i];
-            nlit += tail;
-            if (lane == 0) { blk->nseq = nseq; blk->nlit = nlit; }
+        // literal gather: literals of sequence i start at (mpos_i - bs) - ll_i - (match bytes before i)
+        {
+            const uint32_t chunk = (nseq + ZKE_THREADS - 1) / ZKE_THREADS;
+            const uint32_t i0 = tid * chunk < nseq ? tid * chunk : nseq, i1 = i0 + chunk < nseq ? i0 + chunk : nseq;
+            uint32_t msum = 0;
+            for (uint32_t i = i0; i < i1; i++) msum += (uint32_t)(sq[i] >> 20) & 0xFFFFF;
+            s_scan[tid] = msum;
+            __syncthreads();
+            uint32_t M = 0;
+            for (uint32_t k = 0; k < tid; k++) M += s_scan[k];
+            uint32_t total_m = 0;
+            for (uint32_t k = 0; k < ZKE_THREADS; k++) total_m += s_scan[k];
+            for (uint32_t i = i0; i < i1; i++) {
+                const uint64_t e = sq[i];
+                const uint32_t ll = (uint32_t)e & 0xFFFFF, ml = (uint32_t)(e >> 20) & 0xFFFFF;
+                const uint32_t from = mp[i] - ll, to = (mp[i] - bs) - ll - M;
+                for (uint32_t k = 0; k < ll; k++) lt[to + k] = base[from + k];
+                M += ml;
+            }
+            const uint32_t nlit = (be - bs) - total_m;
+            for (uint32_t k = tid; k < carry; k += ZKE_THREADS) lt[nlit - carry + k] = base[be - carry + k];
+            if (tid == 0) { blk->nseq = nseq; blk->nlit = nlit; }
+            __syncthreads();
         }
     }
 }
@@ -410,9 +451,9 @@ __global__ __launch_bounds__(256) void zk_k_enc_assemble(const uint8_t *src, con
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, ZkEncBlock *blocks, uint64_t *seqs, uint8_t *lits)
+void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, ZkEncBlock *blocks, uint64_t *seqs, uint32_t *mpos, uint8_t *lits)
 {
-    hipLaunchKernelGGL(zk_k_enc_match, dim3(nframes), dim3(ZKE_THREADS), 0, st, src, frames, blocks, seqs, lits);
+    hipLaunchKernelGGL(zk_k_enc_match, dim3(nframes), dim3(ZKE_THREADS), 0, st, src, frames, blocks, seqs, mpos, lits);
 }
 void zk_launch_enc_entropy(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks, uint32_t nblocks,
                            const uint64_t *seqs, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *tabs)

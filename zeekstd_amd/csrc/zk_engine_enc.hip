@@ -106,7 +106,7 @@ extern "C" int zk_encode_frames_dev(zk_engine *e, const void *d_src, uint64_t n,
     const size_t frames_bytes = (frames.size() * sizeof(ZkEncFrame) + 63) & ~(size_t)63;
     int rc;
     if ((rc = zk_devbuf_reserve(e, e->enc_a, frames_bytes + (size_t)(nb + 1) * sizeof(ZkEncBlock) + 256))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->enc_b, (size_t)(seq_total + 1) * 8))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->enc_b, (size_t)(seq_total + 1) * 12 + 64))) return rc;       // packed sequences (u64) + match positions (u32)
     if ((rc = zk_devbuf_reserve(e, e->enc_c, (size_t)n + 64))) return rc;
     if ((rc = zk_devbuf_reserve(e, e->enc_d, (size_t)scratch_total + 64))) return rc;
     if ((rc = zk_devbuf_reserve(e, e->infos, (size_t)(nf + 1) * 8 * 3 + 64 + sizeof(ZkEncTables)))) return rc;   // c_size64, out_off, hashes, tables
@@ -127,7 +127,7 @@ extern "C" int zk_encode_frames_dev(zk_engine *e, const void *d_src, uint64_t n,
     zk_profile_begin(e);
     const uint8_t *src = (const uint8_t *)d_src;
     if (checksum) { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, (const uint64_t *)e->bases.p, 0, nf, nullptr, hashes); }
-    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, src, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint8_t *)e->enc_c.p); }
+    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, src, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (uint8_t *)e->enc_c.p); }
     { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (const uint64_t *)e->enc_b.p, (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, dtab); }
     zk_launch_enc_sizes(st, dfr, nf, dbl, checksum, c64, (uint32_t *)d_c_sizes, (uint32_t *)d_d_sizes);
     zk_launch_scan64(st, c64, nf, out_off);
