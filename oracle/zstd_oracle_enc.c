@@ -241,7 +241,7 @@ static size_t encode_literals(const u8 *lit, size_t n, u8 *dst, size_t cap)
 
 /* ------------------------------------------------------------------ match finder + parse for one block */
 #define ZKE_PARCAP 64u              /* match length measured per position in phase 1; longer ones are extended by the parse */
-#define ZKE_GROUP 4u                /* tiles whose parses run side by side (one wave each on the GPU) */
+#define ZKE_GROUP 8u                /* tiles whose parses run side by side (one wave each on the GPU) */
 typedef struct { u32 table[1 << ZKE_HASH_LOG]; u32 probe; } enc_state;   /* table: frame-relative position + 1 (0 = empty) */
 
 static u32 match_len(const u8 *a, const u8 *b, const u8 *end)        /* b > a */

@@ -11,7 +11,7 @@ constexpr uint32_t ZKE_MINMATCH = 6;
 constexpr uint32_t ZKE_WINDOW = 65535;
 constexpr uint32_t ZKE_TILE = 1024;
 constexpr uint32_t ZKE_PARCAP = 64;
-constexpr uint32_t ZKE_GROUP = 4;                // tiles parsed side by side, one wave each
+constexpr uint32_t ZKE_GROUP = 8;                // tiles parsed side by side, one wave each
 
 struct ZkEncFrame {
     uint64_t src_off;           // where the frame's input starts in the source buffer

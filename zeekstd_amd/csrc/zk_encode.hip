@@ -26,7 +26,7 @@
 #include "zk_kernels.h"
 
 // ------------------------------------------------------------------------------------------------ match + parse
-constexpr int ZKE_THREADS = 256;
+constexpr int ZKE_THREADS = 512;                         // 8 waves: 8 tiles of a group are parsed side by side
 
 __device__ __forceinline__ uint32_t zke_match_len(const uint8_t *a, const uint8_t *b, const uint8_t *end)   // b > a
 {
@@ -74,23 +74,54 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
             for (uint32_t ts = gs; ts < be && ntiles < ZKE_GROUP; ts += ZKE_TILE, ntiles++) {
                 const uint32_t te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
                 const uint8_t *lim = base + te;
-                uint32_t hsh[ZKE_TILE / ZKE_THREADS];
+                constexpr int NP = ZKE_TILE / ZKE_THREADS;
+                uint32_t hsh[NP], o1[NP];
+                uint64_t w[NP], c1[NP], c2[NP];
+                // loads of all positions of the lane are issued together (three rounds of memory latency
+                // per tile instead of a dependent chain per position)
 #pragma unroll
-                for (int k = 0; k < ZKE_TILE / ZKE_THREADS; k++) {
+                for (int k = 0; k < NP; k++) {
                     const uint32_t p = ts + tid + k * ZKE_THREADS;
-                    uint32_t l1 = 0, o1 = 0, l2 = 0;
-                    hsh[k] = 0xFFFFFFFFu;
+                    w[k] = (p < te && p + 8 <= fend) ? zk_ld64(base + p) : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < NP; k++) {
+                    const uint32_t p = ts + tid + k * ZKE_THREADS;
+                    hsh[k] = 0xFFFFFFFFu; o1[k] = 0;
+                    if (p < te && p + 8 <= fend) {
+                        hsh[k] = (uint32_t)(((w[k] << 24) * 889523592379ull) >> (64 - ZKE_HASH_LOG));
+                        const uint32_t e = table[hsh[k]];
+                        if (e && p - (e - 1) <= ZKE_WINDOW) o1[k] = p - (e - 1);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NP; k++) {
+                    const uint32_t p = ts + tid + k * ZKE_THREADS;
+                    c1[k] = o1[k] ? zk_ld64(base + p - o1[k]) : 0;                    // p + 8 <= fend holds when o1 != 0
+                    c2[k] = (p < te && R && R <= p && p + 8 <= fend) ? zk_ld64(base + p - R) : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < NP; k++) {
+                    const uint32_t p = ts + tid + k * ZKE_THREADS;
                     if (p < te) {
                         const uint8_t *cap = base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim;
-                        if (p + 8 <= fend) {
-                            hsh[k] = zke_hash5(base + p);
-                            const uint32_t e = table[hsh[k]];
-                            if (e && p - (e - 1) <= ZKE_WINDOW) { o1 = p - (e - 1); l1 = zke_match_len(base + p - o1, base + p, cap); }
+                        uint32_t l1 = 0, l2 = 0;
+                        const bool wide = p + 8 <= fend && base + p + 8 <= cap;        // the first 8 bytes are already in registers
+                        if (o1[k]) {
+                            const uint64_t x = w[k] ^ c1[k];
+                            if (wide && x) l1 = (uint32_t)(__builtin_ctzll(x) >> 3);
+                            else if (wide) l1 = 8 + zke_match_len(base + p + 8 - o1[k], base + p + 8, cap);
+                            else l1 = zke_match_len(base + p - o1[k], base + p, cap);
                         }
-                        if (R && R <= p) l2 = zke_match_len(base + p - R, base + p, cap);
+                        if (R && R <= p) {
+                            const uint64_t x = w[k] ^ c2[k];
+                            if (wide && x) l2 = (uint32_t)(__builtin_ctzll(x) >> 3);
+                            else if (wide) l2 = 8 + zke_match_len(base + p + 8 - R, base + p + 8, cap);
+                            else l2 = zke_match_len(base + p - R, base + p, cap);
+                        }
                         if (l1 < ZKE_MINMATCH) l1 = 0;
                         if (l2 < 4) l2 = 0;
-                        best[ntiles][p - ts] = (l2 && l2 >= l1) ? (l2 | (R << 8)) : (l1 | (o1 << 8));
+                        best[ntiles][p - ts] = (l2 && l2 >= l1) ? (l2 | (R << 8)) : (l1 | (o1[k] << 8));
                     }
                 }
                 __syncthreads();
@@ -113,7 +144,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     if (mask == 0) { p = p + 64 < te ? p + 64 : te; continue; }
                     const int first = __builtin_ctzll(mask);
                     p += (uint32_t)first;
-                    const uint32_t e = __shfl(v, first, 64);
+                    const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)v, first);
                     uint32_t len = e & 0xFF;
                     const uint32_t off = e >> 8;
                     if (len == ZKE_PARCAP) {                 // capped in phase 1: extend, 64 bytes per step
@@ -201,76 +232,80 @@ struct ZkeBits {
     }
 };
 
-constexpr int ZKE_ENT_THREADS = 128;
+constexpr int ZKE_ENT_THREADS = 256;
+constexpr int ZKE_ENT_BLOCKS = 16;                       // blocks per workgroup: lanes = blocks for the serial bit writers
+static_assert(ZKE_THREADS / 64 == (int)ZKE_GROUP, "one parsing wave per tile of a group");
 
+// One workgroup handles 16 consecutive blocks so that the serial bit writers fill their waves with REAL work:
+// wave 0 = 16 blocks x 4 literal streams (64 lanes), wave 1 lanes 0-15 = the 16 sequence bitstreams (a wave with
+// fewer than 16 active lanes runs ~3x slower on gfx950, tools/ubench/lat3.hip).  Histograms, RLE detection and the
+// payload copies use all 256 lanes, block after block; the Huffman code of block j is built by lane j of wave 0.
 __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
-                                                                   const uint64_t *seqs, const uint8_t *lits, uint8_t *scratch,
-                                                                   const ZkEncTables *tabs)
+                                                                   uint32_t nblocks, const uint64_t *seqs, const uint8_t *lits,
+                                                                   uint8_t *scratch, const ZkEncTables *tabs)
 {
-    __shared__ uint32_t cnt[256];
+    __shared__ uint32_t cnt[ZKE_ENT_BLOCKS][256];
     __shared__ ZkEncTables T;                              // predefined FSE compression tables
-    __shared__ ZkHufWork hw;
-    __shared__ uint32_t s_sizes[5];                        // 4 literal streams + sequence bitstream
-    __shared__ uint32_t s_lit_mode, s_maxbits, s_hdr, s_tree, s_all_same, s_mode;
+    __shared__ ZkHufWork hw[ZKE_ENT_BLOCKS];
+    __shared__ uint32_t s_sizes[ZKE_ENT_BLOCKS][5];        // 4 literal streams + sequence bitstream
+    __shared__ uint32_t s_lit_mode[ZKE_ENT_BLOCKS], s_maxbits[ZKE_ENT_BLOCKS], s_tree[ZKE_ENT_BLOCKS], s_diff[ZKE_ENT_BLOCKS], s_mode[ZKE_ENT_BLOCKS];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    ZkEncBlock *blk = &blocks[blockIdx.x];
-    const ZkEncFrame fr = frames[blk->frame];
-    const uint8_t *raw = src + fr.src_off + blk->bs;
-    const uint32_t bsz = blk->bsz, nlit = blk->nlit, nseq = blk->nseq;
-    const uint8_t *lt = lits + blk->lit_base;
-    const uint64_t *sq = seqs + blk->seq_base;
-    uint8_t *scr = scratch + blk->scratch_base;            // [payload: bsz][stream temps][sequence temp]
-    uint8_t *payload = scr;
-    const uint32_t q = (nlit + 3) / 4;
-    const uint32_t scap = q + (q >> 1) + 16;               // per literal stream: 11 bits per symbol at most
-    uint8_t *stemp = scr + bsz;
-    uint8_t *qtemp = stemp + 4 * scap;
-    const uint32_t qcap = bsz;
+    const uint32_t b0 = blockIdx.x * ZKE_ENT_BLOCKS;
+    const uint32_t nb = nblocks - b0 < (uint32_t)ZKE_ENT_BLOCKS ? nblocks - b0 : (uint32_t)ZKE_ENT_BLOCKS;
 
-    for (uint32_t i = tid; i < 256; i += ZKE_ENT_THREADS) cnt[i] = 0;
+    for (uint32_t i = tid; i < ZKE_ENT_BLOCKS * 256; i += ZKE_ENT_THREADS) (&cnt[0][0])[i] = 0;
     for (uint32_t i = tid; i < sizeof(ZkEncTables) / 4; i += ZKE_ENT_THREADS) ((uint32_t *)&T)[i] = ((const uint32_t *)tabs)[i];
-    if (tid == 0) s_all_same = 1;
+    if (tid < ZKE_ENT_BLOCKS) s_diff[tid] = 0;
     __syncthreads();
-    // raw block all one byte?  literal histogram
-    {
-        const uint8_t b0 = raw[0];
+    // raw block all one byte?  literal histogram -- all lanes, block after block
+    for (uint32_t j = 0; j < nb; j++) {
+        const ZkEncBlock &blk = blocks[b0 + j];
+        const uint8_t *raw = src + frames[blk.frame].src_off + blk.bs;
+        const uint8_t *lt = lits + blk.lit_base;
+        const uint8_t first = raw[0];
         bool diff = false;
-        for (uint32_t i = tid; i < bsz; i += ZKE_ENT_THREADS) diff |= raw[i] != b0;
-        if (diff) s_all_same = 0;
-        for (uint32_t i = tid; i < nlit; i += ZKE_ENT_THREADS) atomicAdd(&cnt[lt[i]], 1u);
+        for (uint32_t i = tid; i < blk.bsz; i += ZKE_ENT_THREADS) diff |= raw[i] != first;
+        if (diff) s_diff[j] = 1;
+        for (uint32_t i = tid; i < blk.nlit; i += ZKE_ENT_THREADS) atomicAdd(&cnt[j][lt[i]], 1u);
     }
     __syncthreads();
-    if (tid < 16) {                                        // 16 lanes redundantly (identical LDS writes), see above
+    // literal mode + Huffman code of block j on lane j of wave 0 (16 active lanes)
+    if (tid < ZKE_ENT_BLOCKS && tid < nb) {
+        const uint32_t j = tid, nlit = blocks[b0 + j].nlit;
         // literal mode: 1 = RLE, 2 = Huffman (4 streams), 0 = raw      (oracle encode_literals)
         uint32_t mode = 0, maxsym = 0, distinct = 0;
-        for (uint32_t s = 0; s < 256; s++) if (cnt[s]) { maxsym = s; distinct++; }
+        for (uint32_t sy = 0; sy < 256; sy++) if (cnt[j][sy]) { maxsym = sy; distinct++; }
         if (nlit > 0 && distinct == 1) mode = 1;
         else if (nlit >= 64 && maxsym < 128) {
-            int mb = zke_huf_lengths(cnt, (int)maxsym + 1, &hw);
-            if (mb > 0) { zke_huf_codes(&hw, (int)maxsym + 1, mb); mode = 2; s_maxbits = (uint32_t)mb; s_tree = maxsym; }
+            int mb = zke_huf_lengths(cnt[j], (int)maxsym + 1, &hw[j]);
+            if (mb > 0) { zke_huf_codes(&hw[j], (int)maxsym + 1, mb); mode = 2; s_maxbits[j] = (uint32_t)mb; s_tree[j] = maxsym; }
         }
-        s_lit_mode = mode;
-        s_hdr = nlit < 1024 ? 3 : nlit < 16384 ? 4 : 5;
+        s_lit_mode[j] = mode;
     }
     __syncthreads();
-    const uint32_t lit_mode = s_lit_mode;
-    // literal streams (wave 0, lanes 0-3) and sequence bitstream (wave 1, lane 0) side by side
-    // (serial lanes are shadowed up to 16 active lanes per wave: < 16 active lanes run ~3x slower on gfx950)
-    if (wave == 0 && lane < 16 && lit_mode == 2) {
-        const uint32_t k = lane & 3;
-        const uint32_t n_k = k < 3 ? q : nlit - 3 * q;
-        const uint8_t *sp = lt + k * q;
-        ZkeBits b; b.init(stemp + k * scap, scap, lane < 4);
-        for (uint32_t i = n_k; i-- > 0;) { const uint32_t s = sp[i]; b.add(hw.code[s], hw.len[s]); }   // last symbol first
-        const uint32_t sz = b.close();
-        if (lane < 4) s_sizes[k] = sz;
-    }
-    if (wave == 1 && lane < 16) {
+    // serial bit writers: wave 0 = 4 literal streams of each block, wave 1 = the sequence bitstream of each block
+    if (wave == 0) {
+        const uint32_t j = lane >> 2, k = lane & 3;
+        if (j < nb && s_lit_mode[j] == 2) {
+            const ZkEncBlock &blk = blocks[b0 + j];
+            const uint32_t nlit = blk.nlit, q = (nlit + 3) / 4, scap = q + (q >> 1) + 16;
+            const uint32_t n_k = k < 3 ? q : nlit - 3 * q;
+            const uint8_t *sp = lits + blk.lit_base + k * q;
+            ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + k * scap, scap, true);
+            const ZkHufWork &h = hw[j];
+            for (uint32_t i = n_k; i-- > 0;) { const uint32_t sy = sp[i]; b.add(h.code[sy], h.len[sy]); }   // last symbol first
+            s_sizes[j][k] = b.close();
+        }
+    } else if (wave == 1 && lane < ZKE_ENT_BLOCKS) {
+        const uint32_t j = lane;
         uint32_t sz = 0;
-        if (nseq) {
-            ZkeBits b; b.init(qtemp, qcap, lane == 0);
-            uint64_t s = sq[nseq - 1];
-            uint32_t ll = (uint32_t)s & 0xFFFFF, ml = (uint32_t)(s >> 20) & 0xFFFFF, ob = (uint32_t)(s >> 40);
+        if (j < nb && blocks[b0 + j].nseq) {
+            const ZkEncBlock &blk = blocks[b0 + j];
+            const uint32_t nseq = blk.nseq, q = (blk.nlit + 3) / 4, scap = q + (q >> 1) + 16;
+            const uint64_t *sq = seqs + blk.seq_base;
+            ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + 4 * scap, blk.bsz, true);
+            uint64_t e = sq[nseq - 1];
+            uint32_t ll = (uint32_t)e & 0xFFFFF, ml = (uint32_t)(e >> 20) & 0xFFFFF, ob = (uint32_t)(e >> 40);
             uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
             uint32_t sm = zke_cinit(T.ml_state, T.ml_dnb[mlc], T.ml_dfs[mlc]);
             uint32_t so = zke_cinit(T.of_state, T.of_dnb[ofc], T.of_dfs[ofc]);
@@ -279,12 +314,12 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             b.add(ml - (T.ml_val[mlc] & 0xFFFFFF), T.ml_val[mlc] >> 24);
             b.add(ob - (1u << ofc), ofc);
             for (uint32_t i = nseq - 1; i-- > 0;) {
-                s = sq[i];
-                ll = (uint32_t)s & 0xFFFFF; ml = (uint32_t)(s >> 20) & 0xFFFFF; ob = (uint32_t)(s >> 40);
+                e = sq[i];
+                ll = (uint32_t)e & 0xFFFFF; ml = (uint32_t)(e >> 20) & 0xFFFFF; ob = (uint32_t)(e >> 40);
                 llc = zke_ll_code(ll); mlc = zke_ml_code(ml - 3); ofc = zk_highbit(ob);
-                { uint32_t nb = (so + T.of_dnb[ofc]) >> 16; b.add(so, nb); so = T.of_state[(so >> nb) + T.of_dfs[ofc]]; }
-                { uint32_t nb = (sm + T.ml_dnb[mlc]) >> 16; b.add(sm, nb); sm = T.ml_state[(sm >> nb) + T.ml_dfs[mlc]]; }
-                { uint32_t nb = (sl + T.ll_dnb[llc]) >> 16; b.add(sl, nb); sl = T.ll_state[(sl >> nb) + T.ll_dfs[llc]]; }
+                { uint32_t nbt = (so + T.of_dnb[ofc]) >> 16; b.add(so, nbt); so = T.of_state[(so >> nbt) + T.of_dfs[ofc]]; }
+                { uint32_t nbt = (sm + T.ml_dnb[mlc]) >> 16; b.add(sm, nbt); sm = T.ml_state[(sm >> nbt) + T.ml_dfs[mlc]]; }
+                { uint32_t nbt = (sl + T.ll_dnb[llc]) >> 16; b.add(sl, nbt); sl = T.ll_state[(sl >> nbt) + T.ll_dfs[llc]]; }
                 b.add(ll - (T.ll_val[llc] & 0xFFFFFF), T.ll_val[llc] >> 24);
                 b.add(ml - (T.ml_val[mlc] & 0xFFFFFF), T.ml_val[mlc] >> 24);
                 b.add(ob - (1u << ofc), ofc);
@@ -292,85 +327,99 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             b.add(sm, 6); b.add(so, 5); b.add(sl, 6);
             sz = b.close();
         }
-        if (lane == 0) s_sizes[4] = sz;
+        s_sizes[lane][4] = sz;
     }
     __syncthreads();
-    // layout of the block payload
-    if (tid == 0) {
+    // layout of every block payload (lane j of wave 0)
+    if (tid < ZKE_ENT_BLOCKS && tid < nb) {
+        const uint32_t j = tid;
+        ZkEncBlock *blk = &blocks[b0 + j];
+        const uint32_t nlit = blk->nlit, nseq = blk->nseq, bsz = blk->bsz;
+        const uint32_t hdr = nlit < 1024 ? 3 : nlit < 16384 ? 4 : 5;
         uint32_t mode = 2, total = 0;
         const uint32_t raw_hdr = nlit < 32 ? 1 : nlit < 4096 ? 2 : 3;
-        uint32_t lm = lit_mode, lit_sz = 0;
+        uint32_t lm = s_lit_mode[j], lit_sz = 0;
         if (lm == 2) {
-            const uint32_t tree = 1 + (s_tree + 1) / 2;            // weights of symbols 0..maxsym-1, two per byte
-            uint32_t comp = tree + 6 + s_sizes[0] + s_sizes[1] + s_sizes[2] + s_sizes[3];
-            bool ok = s_sizes[0] && s_sizes[1] && s_sizes[2] && s_sizes[3] && s_sizes[0] < 65536 && s_sizes[1] < 65536 && s_sizes[2] < 65536;
-            const uint32_t lim = s_hdr == 3 ? 1024u : s_hdr == 4 ? 16384u : 262144u;
-            if (ok && comp < nlit - (nlit >> 6) && comp < lim) lit_sz = s_hdr + comp; else lm = 0;
+            const uint32_t tree = 1 + (s_tree[j] + 1) / 2;         // weights of symbols 0..maxsym-1, two per byte
+            const uint32_t *z = s_sizes[j];
+            const uint32_t comp = tree + 6 + z[0] + z[1] + z[2] + z[3];
+            const bool ok = z[0] && z[1] && z[2] && z[3] && z[0] < 65536 && z[1] < 65536 && z[2] < 65536;
+            const uint32_t lim = hdr == 3 ? 1024u : hdr == 4 ? 16384u : 262144u;
+            if (ok && comp < nlit - (nlit >> 6) && comp < lim) lit_sz = hdr + comp; else lm = 0;
         }
         if (lm == 1) lit_sz = raw_hdr + 1;
         if (lm == 0) lit_sz = raw_hdr + nlit;
         const uint32_t nh = nseq < 128 ? 1 : nseq < 0x7F00 ? 2 : 3;
-        total = lit_sz + nh + (nseq ? 1 + s_sizes[4] : 0);
-        if (nseq && s_sizes[4] == 0) total = 0xFFFFFFFFu;
-        if (s_all_same && bsz > 1) mode = 1;
+        total = lit_sz + nh + (nseq ? 1 + s_sizes[j][4] : 0);
+        if (nseq && s_sizes[j][4] == 0) total = 0xFFFFFFFFu;
+        if (!s_diff[j] && bsz > 1) mode = 1;
         else if (total >= bsz) mode = 0;
-        s_lit_mode = lm; s_mode = mode;
+        s_lit_mode[j] = lm; s_mode[j] = mode;
         blk->mode = mode;
         blk->csize = mode == 2 ? total : mode == 1 ? 1 : bsz;
-        blk->rle_byte = raw[0];
+        blk->rle_byte = src[frames[blk->frame].src_off + blk->bs];
     }
     __syncthreads();
-    if (s_mode != 2) return;
-    // write the payload: literals section, Number_of_Sequences, modes byte, sequence bitstream
-    const uint32_t lm = s_lit_mode;
-    const uint32_t raw_hdr = nlit < 32 ? 1 : nlit < 4096 ? 2 : 3;
-    uint32_t p = 0;
-    if (lm == 2) {
-        const uint32_t hdr = s_hdr, tree = 1 + (s_tree + 1) / 2, mb = s_maxbits;
-        const uint32_t comp = tree + 6 + s_sizes[0] + s_sizes[1] + s_sizes[2] + s_sizes[3];
-        if (tid == 0) {
-            uint64_t h = hdr == 3 ? (2ull | (1 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 14))
-                       : hdr == 4 ? (2ull | (2 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 18))
-                                  : (2ull | (3 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 22));
-            for (uint32_t i = 0; i < hdr; i++) payload[i] = (uint8_t)(h >> (8 * i));
-            uint32_t w = hdr;
-            const uint32_t nw = s_tree;                            // number of explicit weights (symbols 0..maxsym-1)
-            payload[w++] = (uint8_t)(127 + nw);
-            for (uint32_t i = 0; i < nw; i += 2) {
-                const uint32_t w0 = hw.len[i] ? mb + 1 - hw.len[i] : 0;
-                const uint32_t w1 = (i + 1 < nw && hw.len[i + 1]) ? mb + 1 - hw.len[i + 1] : 0;
-                payload[w++] = (uint8_t)((w0 << 4) | w1);
+    // write the payloads: literals section, Number_of_Sequences, modes byte, sequence bitstream
+    for (uint32_t j = 0; j < nb; j++) {
+        if (s_mode[j] != 2) continue;
+        const ZkEncBlock &blk = blocks[b0 + j];
+        const uint32_t nlit = blk.nlit, nseq = blk.nseq, bsz = blk.bsz;
+        const uint32_t q = (nlit + 3) / 4, scap = q + (q >> 1) + 16;
+        uint8_t *payload = scratch + blk.scratch_base;
+        const uint8_t *stemp = payload + bsz, *qtemp = stemp + 4 * scap;
+        const uint8_t *lt = lits + blk.lit_base;
+        const uint32_t lm = s_lit_mode[j];
+        const uint32_t raw_hdr = nlit < 32 ? 1 : nlit < 4096 ? 2 : 3;
+        const uint32_t *z = s_sizes[j];
+        uint32_t p = 0;
+        if (lm == 2) {
+            const uint32_t hdr = nlit < 1024 ? 3 : nlit < 16384 ? 4 : 5, tree = 1 + (s_tree[j] + 1) / 2, mb = s_maxbits[j];
+            const uint32_t comp = tree + 6 + z[0] + z[1] + z[2] + z[3];
+            if (tid == 0) {
+                uint64_t h = hdr == 3 ? (2ull | (1 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 14))
+                           : hdr == 4 ? (2ull | (2 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 18))
+                                      : (2ull | (3 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 22));
+                for (uint32_t i = 0; i < hdr; i++) payload[i] = (uint8_t)(h >> (8 * i));
+                uint32_t w = hdr;
+                const uint32_t nw = s_tree[j];                     // number of explicit weights (symbols 0..maxsym-1)
+                payload[w++] = (uint8_t)(127 + nw);
+                for (uint32_t i = 0; i < nw; i += 2) {
+                    const uint32_t w0 = hw[j].len[i] ? mb + 1 - hw[j].len[i] : 0;
+                    const uint32_t w1 = (i + 1 < nw && hw[j].len[i + 1]) ? mb + 1 - hw[j].len[i + 1] : 0;
+                    payload[w++] = (uint8_t)((w0 << 4) | w1);
+                }
+                for (int k = 0; k < 3; k++) { payload[w++] = (uint8_t)z[k]; payload[w++] = (uint8_t)(z[k] >> 8); }
             }
-            for (int k = 0; k < 3; k++) { payload[w++] = (uint8_t)s_sizes[k]; payload[w++] = (uint8_t)(s_sizes[k] >> 8); }
+            p = hdr + tree + 6;
+            for (int k = 0; k < 4; k++) {
+                const uint8_t *sp = stemp + k * scap;
+                for (uint32_t i = tid; i < z[k]; i += ZKE_ENT_THREADS) payload[p + i] = sp[i];
+                p += z[k];
+            }
+        } else {
+            if (tid == 0) {
+                const uint32_t t = lm;                             // 0 raw, 1 rle
+                if (raw_hdr == 1) payload[0] = (uint8_t)(t | (nlit << 3));
+                else if (raw_hdr == 2) { payload[0] = (uint8_t)(t | (1 << 2) | (nlit << 4)); payload[1] = (uint8_t)(nlit >> 4); }
+                else { payload[0] = (uint8_t)(t | (3 << 2) | (nlit << 4)); payload[1] = (uint8_t)(nlit >> 4); payload[2] = (uint8_t)(nlit >> 12); }
+                if (lm == 1) payload[raw_hdr] = lt[0];
+            }
+            p = raw_hdr;
+            if (lm == 1) p += 1;
+            else { for (uint32_t i = tid; i < nlit; i += ZKE_ENT_THREADS) payload[p + i] = lt[i]; p += nlit; }
         }
-        p = hdr + tree + 6;
-        for (int k = 0; k < 4; k++) {
-            const uint8_t *sp = stemp + k * scap;
-            for (uint32_t i = tid; i < s_sizes[k]; i += ZKE_ENT_THREADS) payload[p + i] = sp[i];
-            p += s_sizes[k];
-        }
-    } else {
         if (tid == 0) {
-            const uint32_t t = lm;                                 // 0 raw, 1 rle
-            if (raw_hdr == 1) payload[0] = (uint8_t)(t | (nlit << 3));
-            else if (raw_hdr == 2) { payload[0] = (uint8_t)(t | (1 << 2) | (nlit << 4)); payload[1] = (uint8_t)(nlit >> 4); }
-            else { payload[0] = (uint8_t)(t | (3 << 2) | (nlit << 4)); payload[1] = (uint8_t)(nlit >> 4); payload[2] = (uint8_t)(nlit >> 12); }
-            if (lm == 1) payload[raw_hdr] = lt[0];
+            if (nseq < 128) payload[p] = (uint8_t)nseq;
+            else if (nseq < 0x7F00) { payload[p] = (uint8_t)((nseq >> 8) + 128); payload[p + 1] = (uint8_t)nseq; }
+            else { payload[p] = 255; payload[p + 1] = (uint8_t)(nseq - 0x7F00); payload[p + 2] = (uint8_t)((nseq - 0x7F00) >> 8); }
         }
-        p = raw_hdr;
-        if (lm == 1) p += 1;
-        else { for (uint32_t i = tid; i < nlit; i += ZKE_ENT_THREADS) payload[p + i] = lt[i]; p += nlit; }
-    }
-    if (tid == 0) {
-        if (nseq < 128) payload[p] = (uint8_t)nseq;
-        else if (nseq < 0x7F00) { payload[p] = (uint8_t)((nseq >> 8) + 128); payload[p + 1] = (uint8_t)nseq; }
-        else { payload[p] = 255; payload[p + 1] = (uint8_t)(nseq - 0x7F00); payload[p + 2] = (uint8_t)((nseq - 0x7F00) >> 8); }
-    }
-    p += nseq < 128 ? 1 : nseq < 0x7F00 ? 2 : 3;
-    if (nseq) {
-        if (tid == 0) payload[p] = 0;                              // predefined LL / OF / ML
-        p += 1;
-        for (uint32_t i = tid; i < s_sizes[4]; i += ZKE_ENT_THREADS) payload[p + i] = qtemp[i];
+        p += nseq < 128 ? 1 : nseq < 0x7F00 ? 2 : 3;
+        if (nseq) {
+            if (tid == 0) payload[p] = 0;                          // predefined LL / OF / ML
+            p += 1;
+            for (uint32_t i = tid; i < z[4]; i += ZKE_ENT_THREADS) payload[p + i] = qtemp[i];
+        }
     }
 }
 
@@ -459,7 +508,7 @@ void zk_launch_enc_entropy(hipStream_t st, const uint8_t *src, const ZkEncFrame 
                            const uint64_t *seqs, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *tabs)
 {
     if (!nblocks) return;
-    hipLaunchKernelGGL(zk_k_enc_entropy, dim3(nblocks), dim3(ZKE_ENT_THREADS), 0, st, src, frames, blocks, seqs, lits, scratch, tabs);
+    hipLaunchKernelGGL(zk_k_enc_entropy, dim3((nblocks + ZKE_ENT_BLOCKS - 1) / ZKE_ENT_BLOCKS), dim3(ZKE_ENT_THREADS), 0, st, src, frames, blocks, nblocks, seqs, lits, scratch, tabs);
 }
 void zk_launch_enc_sizes(hipStream_t st, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, int checksum,
                          uint64_t *c_size64, uint32_t *c_sizes, uint32_t *d_sizes)
