@@ -154,9 +154,43 @@ __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *com
     const uint32_t bi = blockIdx.x * ZK_FSE_BLOCKS + slot;
     if (bi >= nblocks) return;
     ZkBlock b = blocks[bi];
-    if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK) return;
+    if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK || b.seq_modes == 0) return;      // all-predefined blocks: zk_k_fse_predef
     zk_decode_sequences(comp, blocks, b, &T[slot], seqs + b.seq_base, llv, mlv, real);
     if (!real) return;
+    ZkBlock *o = &blocks[bi];
+    o->out_size = b.out_size;
+    o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
+    o->status = b.status;
+}
+
+// Blocks whose three tables are all Predefined_Mode (Symbol_Compression_Modes == 0: what this engine's own
+// encoder emits, and libzstd for small blocks) need no per-block tables: one copy of the predefined tables per
+// workgroup, one block per LANE, full waves -- the walk is then limited only by its dependent chain.
+constexpr int ZK_FSEP_THREADS = 256;
+__global__ __launch_bounds__(ZK_FSEP_THREADS) void zk_k_fse_predef(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
+{
+    __shared__ ZkSeqTables T;                              // shared, read-only after the build
+    __shared__ ZkSeq ring[ZK_FSEP_THREADS][4];             // 4-record staging per lane (64 B stores)
+    __shared__ uint32_t llv[36], mlv[53], s_al[3];
+    const uint32_t tid = threadIdx.x;
+    {
+        const uint32_t ll_init[36] = ZK_LL_TABLE;
+        const uint32_t ml_init[53] = ZK_ML_TABLE;
+        if (tid < 36) llv[tid] = ll_init[tid];
+        if (tid < 53) mlv[tid] = ml_init[tid];
+    }
+    __syncthreads();
+    if (tid < 16) {                                        // 16 lanes redundantly (identical LDS writes): >= 16 active lanes
+        ZkBlock fake;
+        fake.seq_modes = 0; fake.seq_off = 0; fake.bsize = 0; fake.src = 0;
+        for (int t = 0; t < 3; t++) { uint32_t a = 0; (void)zk_seq_table_setup(comp, fake, t, &T, &a, llv, mlv); s_al[t] = a; }
+    }
+    __syncthreads();
+    const uint32_t bi = blockIdx.x * ZK_FSEP_THREADS + tid;
+    if (bi >= nblocks) return;
+    ZkBlock b = blocks[bi];
+    if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK || b.seq_modes != 0) return;
+    zk_seq_walk<4>(comp, b, b.seq_off + 1, T.ll, T.of, T.ml, s_al, ring[tid], seqs + b.seq_base, llv, mlv, true);
     ZkBlock *o = &blocks[bi];
     o->out_size = b.out_size;
     o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
@@ -435,6 +469,7 @@ void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
 void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
 {
     if (!nblocks) return;
+    hipLaunchKernelGGL(zk_k_fse_predef, dim3((nblocks + ZK_FSEP_THREADS - 1) / ZK_FSEP_THREADS), dim3(ZK_FSEP_THREADS), 0, st, comp, blocks, nblocks, seqs);
     hipLaunchKernelGGL(zk_k_fse, dim3((nblocks + ZK_FSE_BLOCKS - 1) / ZK_FSE_BLOCKS), dim3(64 * ZK_FSE_WAVES), 0, st, comp, blocks, nblocks, seqs);
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,

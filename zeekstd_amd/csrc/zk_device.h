@@ -625,21 +625,15 @@ ZK_HD uint32_t zk_rev_read_slow(ZkRev &r, uint32_t n)          // any n <= 31, r
     return zk_rev_bits(r, r.pos, n);
 }
 
-// Decode all sequences of block b into seqs[]; fills b.out_size / b.rep_out / b.status.
+// The 3-state walk over the sequence bitstream of block b (tables already built: LL / OF / ML cells, accuracy
+// logs al[3], bitstream at offset bs_off of the block content).  ring: 16-record LDS staging of this lane.
+// Fills seqs[], b.out_size / b.rep_out / b.status.
 // store == false: a shadow lane (see zk_k_fse) -- it walks the same block as a real lane but never writes to HBM
-ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlock &b, ZkSeqTables *T, ZkSeq *seqs,
-                               const uint32_t *ll_values, const uint32_t *ml_values, bool store = true)
+template <int RING = 16>
+ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const uint32_t *LL, const uint32_t *OF, const uint32_t *ML,
+                       const uint32_t *al, ZkSeq *ring, ZkSeq *seqs, const uint32_t *ll_values, const uint32_t *ml_values,
+                       bool store = true)
 {
-    uint32_t al[3];
-    uint32_t own = 0;                                   // bytes of table descriptions in this block
-    for (int t = 0; t < 3; t++) {
-        uint32_t m = (b.seq_modes >> (6 - 2 * t)) & 3;
-        const ZkBlock &def = m == 3 ? blocks[b.tab_def[t]] : b;
-        int32_t r = zk_seq_table_setup(comp, def, t, T, &al[t], ll_values, ml_values);
-        if (r < 0) { b.status = ZK_E_CORRUPTION; return; }
-        if (m != 3) own += (uint32_t)r;
-    }
-    uint32_t bs_off = b.seq_off + 1 + own;
     if (bs_off >= b.bsize) { b.status = ZK_E_CORRUPTION; return; }
     const uint32_t blen = b.bsize - bs_off;
     ZkRev r;
@@ -660,9 +654,9 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
     // their tables, window addresses are clamped) and the rare sequence that needs more than the 57
     // guaranteed window bits leaves the block for a field-by-field slow step.
     uint32_t i = 0;
-    uint32_t cl = T->ll[sl], co = T->of[so], cm = T->ml[sm];
+    uint32_t cl = LL[sl], co = OF[so], cm = ML[sm];
     while (i < nseq) {
-        const uint32_t gend = i + 16 < nseq ? i + 16 : nseq;
+        const uint32_t gend = i + RING < nseq ? i + RING : nseq;
         while (i < gend) {
             const uint32_t nOf = zk_cell_sym(co), nMl = zk_cell_xbits(cm), nLl = zk_cell_xbits(cl);
             const bool more = i + 1 < nseq;
@@ -684,7 +678,7 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
                 sl = zk_cell_base(cl) + (nbl ? h0 >> (32 - nbl) : 0);
                 sm = zk_cell_base(cm) + (nbm ? h1 >> (32 - nbm) : 0);
                 so = zk_cell_base(co) + (nbo ? h2 >> (32 - nbo) : 0);
-                cl = T->ll[sl]; co = T->of[so]; cm = T->ml[sm];                     // issued early; used next iteration
+                cl = LL[sl]; co = OF[so]; cm = ML[sm];                     // issued early; used next iteration
                 // value bits (off the chain)
                 uint64_t V = X;
                 ofx = nOf ? (uint32_t)(V >> 32) >> (32 - nOf) : 0; V <<= nOf;
@@ -701,7 +695,7 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
                 bad |= r.pos < 0;
                 if (r.pos < 0) r.pos = 0;
                 zk_rev_load(r);
-                cl = T->ll[sl]; co = T->of[so]; cm = T->ml[sm];
+                cl = LL[sl]; co = OF[so]; cm = ML[sm];
             }
             const uint32_t ofv = (1u << (nOf & 31)) + ofx;
             const uint32_t ml = (ml_values[zk_cell_sym(csm)] & 0xFFFFFFu) + mlx;
@@ -720,12 +714,12 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
             lit += ll; out += ll + ml;
             bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX);
             ZkSeq s; s.out_end = out; s.ml = ml; s.off = off; s.lit_end = lit;
-            T->ring[i & 15] = s;
+            ring[i & (RING - 1)] = s;
             i++;
         }
         // records are parked in LDS and written out a group at a time (few, wide store bursts)
-        const uint32_t g0 = (i - 1) & ~15u;
-        if (store) for (uint32_t k = g0; k < i; k++) seqs[k] = T->ring[k & 15];
+        const uint32_t g0 = (i - 1) & ~(uint32_t)(RING - 1);
+        if (store) for (uint32_t k = g0; k < i; k++) seqs[k] = ring[k & (RING - 1)];
     }
     bad |= r.pos != 0;
     if (bad) { b.status = ZK_E_CORRUPTION; return; }
@@ -733,6 +727,23 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
     if (out > ZK_BLOCK_MAX) { b.status = ZK_E_CORRUPTION; return; }
     b.out_size = out;
     b.rep_out[0] = rep0; b.rep_out[1] = rep1; b.rep_out[2] = rep2;
+}
+
+
+// Decode all sequences of block b into seqs[]: builds the block's LL / OF / ML tables in T (per-lane LDS), then walks.
+ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlock &b, ZkSeqTables *T, ZkSeq *seqs,
+                               const uint32_t *ll_values, const uint32_t *ml_values, bool store = true)
+{
+    uint32_t al[3];
+    uint32_t own = 0;                                   // bytes of table descriptions in this block
+    for (int t = 0; t < 3; t++) {
+        uint32_t m = (b.seq_modes >> (6 - 2 * t)) & 3;
+        const ZkBlock &def = m == 3 ? blocks[b.tab_def[t]] : b;
+        int32_t r = zk_seq_table_setup(comp, def, t, T, &al[t], ll_values, ml_values);
+        if (r < 0) { b.status = ZK_E_CORRUPTION; return; }
+        if (m != 3) own += (uint32_t)r;
+    }
+    zk_seq_walk(comp, b, b.seq_off + 1 + own, T->ll, T->of, T->ml, al, T->ring, seqs, ll_values, ml_values, store);
 }
 
 // ---------------------------------------------------------------- sequence execution: byte-source resolver
