@@ -82,9 +82,9 @@ extern "C" int zk_sim_decode(const uint8_t *comp, const uint64_t *c_off, const u
         blocks[bi].status = b.status;
     }
     delete T;
-    // exec: one "workgroup" per frame
-    const uint32_t THREADS = 256, B = (uint32_t)exec_b, CH = (uint32_t)exec_chunk;
-    std::vector<uint32_t> oe(CH + 1), mlv(CH + 1), ofv(CH + 1), le(CH + 1);
+    // exec: one "workgroup" per frame; tiles of THREADS x B bytes, per-byte source map (zk_exec_fill_range / zk_exec_origin)
+    const uint32_t THREADS = 256, B = (uint32_t)exec_b, CAPS = (uint32_t)exec_chunk;      // CAPS: staged sequences per tile
+    std::vector<uint32_t> so(CAPS + 1), sm(CAPS + 1), sf(CAPS + 1), sl(CAPS + 1), srcmap(THREADS * B);
     std::vector<uint8_t> tile(THREADS * B);
     int first_err = 0;
     for (uint32_t f = 0; f < count; f++) {
@@ -107,41 +107,40 @@ extern "C" int zk_sim_decode(const uint8_t *comp, const uint64_t *c_off, const u
                     const ZkSeq *sq = seqs.data() + b.seq_base;
                     const uint8_t *l = b.lit_type >= 2 ? lit.data() + b.lit_base : comp + b.src + b.lit_off;
                     const uint32_t lit_stride = b.lit_type == 1 ? 0u : 1u;
-                    uint32_t s0 = 0, cpos = 0;
-                    for (;;) {
-                        const uint32_t nsq = b.nseq - s0 < CH ? b.nseq - s0 : CH;
-                        const bool lastchunk = s0 + nsq == b.nseq;
+                    const uint32_t nseq = b.nseq, out_size = b.out_size;
+                    uint32_t ja = 0, ts = 0, prev_end = 0;
+                    while (ts < out_size) {
+                        const uint32_t nl = nseq + 1 - ja < CAPS ? nseq + 1 - ja : CAPS;
                         int bad = 0;
-                        for (uint32_t i = 0; i < nsq; i++) {
-                            ZkSeq s = sq[s0 + i];
-                            uint32_t off = zk_rep_resolve(s.off, rep);
-                            oe[i] = s.out_end; mlv[i] = s.ml; ofv[i] = off; le[i] = s.lit_end;
-                            uint32_t mstart = s.out_end - s.ml;
-                            if (off == 0 || pos + mstart < off || off > fi.window) bad = 1;
+                        for (uint32_t i = 0; i < nl; i++) {
+                            const uint32_t idx = ja + i;
+                            if (idx < nseq) {
+                                ZkSeq s = sq[idx];
+                                uint32_t off = zk_rep_resolve(s.off, rep);
+                                uint32_t mstart = s.out_end - s.ml;
+                                if (off == 0 || pos + mstart < off || off > fi.window) bad = 1;
+                                so[i] = s.out_end; sm[i] = s.ml; sf[i] = off; sl[i] = s.lit_end;
+                            } else { so[i] = out_size; sm[i] = 0; sf[i] = 1; sl[i] = b.lit_regen; }
                         }
-                        if (lastchunk) { oe[nsq] = b.out_size; mlv[nsq] = 0; ofv[nsq] = 0; le[nsq] = b.lit_regen; }
                         if (bad) { err = ZK_E_CORRUPTION; break; }
-                        const uint32_t nent = nsq + (lastchunk ? 1u : 0u);
-                        const uint32_t cend = lastchunk ? b.out_size : oe[nsq - 1];
-                        for (uint32_t ts = cpos; ts < cend; ts += THREADS * B) {
-                            for (uint32_t tid = 0; tid < THREADS; tid++) {
-                                const uint32_t q0 = ts + tid * B;
-                                if (q0 >= cend) break;
-                                const uint32_t n = cend - q0 < B ? cend - q0 : B;
-                                uint32_t j = zk_seq_find(oe.data(), 0, nent, q0);
-                                for (uint32_t k = 0; k < n; k++) {
-                                    const uint32_t q = q0 + k;
-                                    while (oe[j] <= q) j++;
-                                    uint64_t src = zk_resolve_byte(oe.data(), mlv.data(), ofv.data(), le.data(), j, q, (int32_t)ts);
-                                    if (src & ZK_SRC_HIST) tile[tid * B + k] = bout[(int64_t)(int32_t)((uint32_t)src - 0x40000000u)];
-                                    else tile[tid * B + k] = l[(uint32_t)src * lit_stride];
-                                }
-                            }
-                            uint32_t tn = cend - ts < THREADS * B ? cend - ts : THREADS * B;
-                            memcpy(bout + ts, tile.data(), tn);        // commit the tile after all lanes ran
+                        const uint32_t cap_end = so[nl - 1];
+                        const uint32_t te = ts + THREADS * B < cap_end ? ts + THREADS * B : cap_end;
+                        uint32_t jn = 0;
+                        std::fill(srcmap.begin(), srcmap.end(), 0xDEADBEEFu);
+                        for (uint32_t i = 0; i < nl; i++) {                                  // "lane per sequence"
+                            const uint32_t start = i ? so[i - 1] : prev_end;
+                            const uint32_t lo = start > ts ? start : ts, hi = so[i] < te ? so[i] : te;
+                            if (lo < hi) zk_exec_fill_range(srcmap.data(), ts, lo, hi, 1, 0, so[i], sm[i], sf[i], sl[i]);
+                            if (so[i] <= te) jn = i + 1;
                         }
-                        cpos = cend; s0 += nsq;
-                        if (lastchunk) break;
+                        for (uint32_t q = ts; q < te; q++) {                                 // "lane per 16 bytes"
+                            const uint32_t s = zk_exec_origin(srcmap.data(), srcmap[q - ts], ts);
+                            tile[q - ts] = (s & ZK_SRC_LIT) ? l[(size_t)(s & ~ZK_SRC_LIT) * lit_stride]
+                                                            : bout[(int64_t)(int32_t)(s - ZK_SRC_BIAS)];
+                        }
+                        memcpy(bout + ts, tile.data(), te - ts);                             // commit the tile after all lanes ran
+                        if (jn) prev_end = so[jn - 1];
+                        ja += jn; ts = te;
                     }
                     if (err == ZK_OK) {
                         uint32_t r0 = zk_rep_resolve(b.rep_out[0], rep), r1 = zk_rep_resolve(b.rep_out[1], rep), r2 = zk_rep_resolve(b.rep_out[2], rep);

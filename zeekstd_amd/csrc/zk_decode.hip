@@ -198,40 +198,15 @@ __global__ __launch_bounds__(ZK_FSEP_THREADS) void zk_k_fse_predef(const uint8_t
 }
 
 // ------------------------------------------------------------------------------------------------ sequence execution
-// One workgroup (T lanes) per frame.  The output of a compressed block is produced in tiles of
-// T x 16 B.  Per tile:
-//   1. the sequences overlapping the tile are staged in LDS (16 B records, offsets resolved);
-//   2. every sequence drops a mark on the first 16 B bucket it covers; a prefix-max over the
-//      buckets gives each lane the sequence its 16 bytes start in (no searches);
-//   3. every lane resolves the source address of its 16 output bytes -- literal buffer, history
-//      before the tile (already in HBM/L2), or, for a source inside the tile, the source's own
-//      source (chase through the bucket table) -- then issues the 16 byte loads back to back;
-//   4. one coalesced 16 B store per lane; a workgroup barrier orders the tiles.
+// One workgroup (T lanes) per frame.  The output of a compressed block is produced in tiles of T x 16 B.  Per tile:
+//   1. the sequences overlapping the tile are staged in LDS (16 B records, offsets resolved, validated);
+//   2. lane-per-SEQUENCE: every staged sequence writes one 32-bit source word per output byte it covers into
+//      an LDS map (literal index, or history position); ranges longer than 48 B are filled by all lanes;
+//   3. lane-per-16-BYTES: every lane reads its 16 source words, follows in-tile sources to their origin
+//      (pointer jumps inside the LDS map), issues the 16 byte gathers back to back (literal buffer / history
+//      already in HBM-L2) and does one coalesced 16 B store;
+//   4. a workgroup barrier orders the tiles.
 constexpr int ZK_EXEC_B = 16;
-
-struct ZkChase {
-    const uint4 *S;
-    const uint16_t *jstart;
-    uint32_t ts;
-};
-
-// source address of block-relative position p (p >= ts), which lies inside the current tile
-__device__ __forceinline__ const uint8_t *zk_chase(const ZkChase &c, int32_t p, const uint8_t *lit, uint32_t lit_stride,
-                                                   const uint8_t *bout)
-{
-    for (;;) {
-        uint32_t j = c.jstart[((uint32_t)p - c.ts) >> 4];
-        uint4 s = c.S[j];
-        while ((uint32_t)p >= s.x) s = c.S[++j];
-        int32_t ms = (int32_t)(s.x - s.y);
-        if (p < ms) return lit + (size_t)(s.w - (uint32_t)(ms - p)) * lit_stride;
-        int32_t off = (int32_t)s.z;
-        int32_t p2 = p - off;
-        if (p2 >= ms) p2 = ms - off + (p - ms) % off;
-        if (p2 < (int32_t)c.ts) return bout + p2;
-        p = p2;
-    }
-}
 
 template <int T>
 __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
@@ -240,12 +215,11 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                                                const uint8_t *lit_scratch, uint8_t *dst)
 {
     constexpr int CAP = 2 * T;
-    constexpr int NW = T / 64;
     __shared__ uint4 S[CAP + 1];
-    __shared__ uint16_t mark[T], jstart[T];
-    __shared__ uint32_t wmax[NW];
-    __shared__ uint32_t s_jn;
-    const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t srcmap[T * ZK_EXEC_B];
+    __shared__ uint32_t longlist[CAP + 1];
+    __shared__ uint32_t s_jn, s_nlong;
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
     const ZkFrameInfo fi = infos[f];
     if (fi.status != ZK_OK) return;
     const uint64_t d_size = d_off[first + f + 1] - d_off[first + f];
@@ -271,7 +245,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
             const uint8_t *lit = b.lit_type >= 2 ? lit_scratch + b.lit_base : comp + b.src + b.lit_off;
             const uint32_t lit_stride = b.lit_type == 1 ? 0u : 1u;
             const uint32_t nseq = b.nseq, out_size = b.out_size;
-            uint32_t ja = 0, ts = 0;
+            uint32_t ja = 0, ts = 0, prev_end = 0;           // prev_end: out_end of sequence ja - 1
             while (ts < out_size) {
                 // 1. stage sequences [ja, ja + nl); index nseq is the trailing-literals pseudo sequence
                 const uint32_t nl = nseq + 1 - ja < (uint32_t)CAP ? nseq + 1 - ja : (uint32_t)CAP;
@@ -285,61 +259,54 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                         const uint32_t mstart = s.x - s.y;
                         if (off == 0 || pos + mstart < off || off > fi.window) bad = 1;
                         r = make_uint4(s.x, s.y, off, s.w);
-                    } else r = make_uint4(out_size, 0, 0, b.lit_regen);
+                    } else r = make_uint4(out_size, 0, 1, b.lit_regen);
                     S[i] = r;
                 }
-                mark[tid] = 0;
-                if (tid == 0) s_jn = 0;
+                if (tid == 0) { s_jn = 0; s_nlong = 0; }
                 if (__syncthreads_or(bad)) { err = ZK_E_CORRUPTION; break; }
                 const uint32_t cap_end = S[nl - 1].x;
                 const uint32_t te = ts + T * ZK_EXEC_B < cap_end ? ts + T * ZK_EXEC_B : cap_end;
-                // 2. bucket marks + number of sequences that end inside the tile
+                // 2. lane per sequence: source words of the bytes it covers inside [ts, te)
                 uint32_t done = 0;
                 for (uint32_t i = tid; i < nl; i += T) {
-                    const uint32_t e = S[i].x;
-                    uint32_t lo = i ? S[i - 1].x : ts;
-                    if (lo < ts) lo = ts;
-                    const uint32_t hi = e < te ? e : te;
+                    const uint4 e = S[i];
+                    const uint32_t start = i ? S[i - 1].x : prev_end;
+                    const uint32_t lo = start > ts ? start : ts, hi = e.x < te ? e.x : te;
                     if (lo < hi) {
-                        const uint32_t b0 = (lo - ts + 15) >> 4;
-                        if (ts + (b0 << 4) < hi) mark[b0] = (uint16_t)i;
+                        if (hi - lo > ZK_EXEC_LONG) longlist[atomicAdd(&s_nlong, 1u)] = i;
+                        else zk_exec_fill_range(srcmap, ts, lo, hi, 1, 0, e.x, e.y, e.z, e.w);
                     }
-                    if (e <= te) done = i + 1;
+                    if (e.x <= te) done = i + 1;
                 }
                 if (done) atomicMax(&s_jn, done);
                 __syncthreads();
-                // 3. prefix max over the buckets
-                uint32_t m = mark[tid];
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(m, d, 64); if ((int)lane >= d && y > m) m = y; }
-                if (lane == 63) wmax[wave] = m;
-                __syncthreads();
-                for (uint32_t w = 0; w < wave; w++) { uint32_t y = wmax[w]; if (y > m) m = y; }
-                jstart[tid] = (uint16_t)m;
-                const uint32_t jn = s_jn;
-                __syncthreads();
-                // 4. resolve + gather + store
+                const uint32_t nlong = s_nlong, jn = s_jn;
+                for (uint32_t k = 0; k < nlong; k++) {       // long ranges: all lanes
+                    const uint32_t i = longlist[k];
+                    const uint4 e = S[i];
+                    const uint32_t start = i ? S[i - 1].x : prev_end;
+                    const uint32_t lo = start > ts ? start : ts, hi = e.x < te ? e.x : te;
+                    zk_exec_fill_range(srcmap, ts, lo, hi, T, tid, e.x, e.y, e.z, e.w);
+                }
+                if (nlong) __syncthreads();
+                // 3. lane per 16 output bytes: origins, gathers, one coalesced store
                 const uint32_t q0 = ts + tid * ZK_EXEC_B;
                 if (q0 < te) {
                     const uint32_t nb = te - q0 < (uint32_t)ZK_EXEC_B ? te - q0 : (uint32_t)ZK_EXEC_B;
-                    ZkChase ch{S, jstart, ts};
-                    uint32_t j = m;
-                    uint4 s = S[j];
-                    int32_t ms = (int32_t)(s.x - s.y);
+                    uint32_t sw[ZK_EXEC_B];
+#pragma unroll
+                    for (int k = 0; k < ZK_EXEC_B; k += 4) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(&srcmap[tid * ZK_EXEC_B + k]);
+                        sw[k] = v.x; sw[k + 1] = v.y; sw[k + 2] = v.z; sw[k + 3] = v.w;
+                    }
                     const uint8_t *addr[ZK_EXEC_B];
 #pragma unroll
                     for (int k = 0; k < ZK_EXEC_B; k++) {
-                        const uint32_t q = q0 + k;
-                        const uint8_t *a = bout;                   // harmless default for k >= nb
+                        const uint8_t *a = bout;               // harmless default for k >= nb
                         if ((uint32_t)k < nb) {
-                            if (q >= s.x) { s = S[++j]; ms = (int32_t)(s.x - s.y); }
-                            if ((int32_t)q < ms) a = lit + (size_t)(s.w - (uint32_t)(ms - (int32_t)q)) * lit_stride;
-                            else {
-                                const int32_t off = (int32_t)s.z;
-                                int32_t p = (int32_t)q - off;
-                                if (p >= ms) p = ms - off + ((int32_t)q - ms) % off;
-                                a = p < (int32_t)ts ? bout + p : zk_chase(ch, p, lit, lit_stride, bout);
-                            }
+                            const uint32_t s = zk_exec_origin(srcmap, sw[k], ts);
+                            a = (s & ZK_SRC_LIT) ? lit + (size_t)(s & ~ZK_SRC_LIT) * lit_stride
+                                                 : bout + (int64_t)(int32_t)(s - ZK_SRC_BIAS);
                         }
                         addr[k] = a;
                     }
@@ -359,6 +326,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                         for (int k = 0; k < ZK_EXEC_B; k++) if ((uint32_t)k < nb) w[k] = (uint8_t)ob[k];
                     }
                 }
+                if (jn) prev_end = S[jn - 1].x;
                 __syncthreads();              // tile bytes visible to the next tile; LDS reuse
                 ja += jn; ts = te;
             }

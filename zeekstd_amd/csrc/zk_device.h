@@ -746,35 +746,35 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
     zk_seq_walk(comp, b, b.seq_off + 1 + own, T->ll, T->of, T->ml, al, T->ring, seqs, ll_values, ml_values, store);
 }
 
-// ---------------------------------------------------------------- sequence execution: byte-source resolver
-// Chunk of sequences staged in LDS: oe[i] (block-relative end), ml[i], of[i] (resolved), le[i].
-// Index n (one past the chunk) may be the trailing-literals pseudo sequence (ml = 0).
-// first index j with oe[j] > q, searching [lo, hi)
-ZK_HD uint32_t zk_seq_find(const uint32_t *oe, uint32_t lo, uint32_t hi, uint32_t q)
+// ---------------------------------------------------------------- sequence execution: per-byte source map
+// The executor produces a block's output in tiles.  For every output byte of the tile a 32-bit source word is
+// written to LDS by the lane that owns the byte's SEQUENCE (zk_exec_fill_seq), then the lane that owns the
+// byte's 16-B output slot follows in-tile sources to their origin (zk_exec_origin) and gathers.
+//   source word: bit 31 set -> literal index (block-relative);  else block-relative history position + 2^30
+constexpr uint32_t ZK_SRC_LIT = 0x80000000u;
+constexpr uint32_t ZK_SRC_BIAS = 0x40000000u;
+constexpr uint32_t ZK_EXEC_LONG = 48;        // ranges longer than this are filled by the whole workgroup
+
+// Source word of output byte q (block-relative) of the sequence (oe, ml, off, le) that starts at `start`.
+ZK_HD uint32_t zk_exec_src(uint32_t q, uint32_t oe, uint32_t ml, uint32_t off, uint32_t le)
 {
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (oe[mid] > q) hi = mid; else lo = mid + 1;
-    }
-    return lo;
+    const int32_t ms = (int32_t)(oe - ml);
+    if ((int32_t)q < ms) return ZK_SRC_LIT | (le - (uint32_t)(ms - (int32_t)q));
+    int32_t p = (int32_t)q - (int32_t)off;
+    if (p >= ms) p = ms - (int32_t)off + ((int32_t)q - ms) % (int32_t)off;          // overlapping match: periodic source
+    return (uint32_t)(p + (int32_t)ZK_SRC_BIAS);
 }
 
-// Where does output byte q (block-relative, inside the chunk) come from?
-// Returns: >= 0  -> literal index (block-relative) ;  < 0 -> -(1 + P) hmm see below
-// Encoded as int64: literal L -> L ; history byte at block-relative position P (P < tile_start, may be negative) -> ZK_SRC_HIST | (P + 2^31)
-constexpr uint64_t ZK_SRC_HIST = 1ull << 40;
-ZK_HD uint64_t zk_resolve_byte(const uint32_t *oe, const uint32_t *mlv, const uint32_t *ofv, const uint32_t *le,
-                               uint32_t j, uint32_t q, int32_t tile_start)
+// Fill srcmap[q - ts] for q in [lo, hi) (the part of the sequence that lies in the tile).
+ZK_HD void zk_exec_fill_range(uint32_t *srcmap, uint32_t ts, uint32_t lo, uint32_t hi, uint32_t step, uint32_t first,
+                              uint32_t oe, uint32_t ml, uint32_t off, uint32_t le)
 {
-    int32_t qq = (int32_t)q;
-    for (;;) {
-        int32_t mstart = (int32_t)(oe[j] - mlv[j]);
-        if (qq < mstart) return (uint64_t)(le[j] - (uint32_t)(mstart - qq));
-        int32_t off = (int32_t)ofv[j];
-        int32_t p = qq - off;
-        if (p >= mstart) p = mstart - off + (qq - mstart) % off;        // overlapping match: periodic source
-        if (p < tile_start) return ZK_SRC_HIST | (uint64_t)(uint32_t)(p + (int32_t)0x40000000);
-        qq = p;
-        j = zk_seq_find(oe, 0, j + 1, (uint32_t)qq);                     // in-tile dependency: chase the source
-    }
+    for (uint32_t q = lo + first; q < hi; q += step) srcmap[q - ts] = zk_exec_src(q, oe, ml, off, le);
+}
+
+// Follow in-tile sources: returns a word that is a literal or a history position before the tile.
+ZK_HD uint32_t zk_exec_origin(const uint32_t *srcmap, uint32_t s, uint32_t ts)
+{
+    while (!(s & ZK_SRC_LIT) && (int32_t)(s - ZK_SRC_BIAS) >= (int32_t)ts) s = srcmap[(s - ZK_SRC_BIAS) - ts];
+    return s;
 }
