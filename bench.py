@@ -103,6 +103,50 @@ def cpu_baseline(comp, frames, data, sample_frames, level, cks, target_seconds=8
     return out
 
 
+def seek_leg(eng, data, zk, nbytes=256 << 20, fsz=65536, nseeks=300):
+    """p50 / p95 of one random seek + read (len = 1 + r % 8192) on a 64 KiB-frame archive, GPU Decoder vs CPU loop."""
+    from oracle import zko, libzstd_ref as Z
+    src = np.ascontiguousarray(data[:nbytes])
+    comp, frames = eng.encode_frames(src, fsz, 1, True)
+    st = zk.SeekTable.new()
+    for c_, d_ in frames:
+        st.log_frame(c_, d_)
+    seekable = comp + st.to_bytes()
+    dec = zk.DecodeOptions(seekable).engine(eng).into_decoder()
+    rng = np.random.default_rng(0x5EED0003)
+    offs = rng.integers(0, nbytes - 8192, nseeks).astype(np.uint64)
+    lens = (1 + rng.integers(0, 8192, nseeks)).astype(np.uint32)
+    buf = bytearray(8192 + 8)
+    view = memoryview(buf)
+    ts = []
+    for o, l in zip(offs, lens):
+        t = time.perf_counter()
+        dec.set_offset_limit(nbytes)
+        dec.set_offset(int(o))
+        dec.set_offset_limit(int(o) + int(l))
+        n = dec.decompress(view[:int(l)])
+        ts.append((time.perf_counter() - t) * 1e6)
+        if n != int(l) or bytes(buf[:n]) != src[int(o):int(o) + n].tobytes():
+            raise RuntimeError("seek read mismatch")
+    out = {"frames": len(frames), "frame_size": fsz, "seeks": nseeks,
+           "gpu_decoder_us": {"p50": round(float(np.percentile(ts[20:], 50)), 1), "p95": round(float(np.percentile(ts[20:], 95)), 1)},
+           "note": "single seek = 1 frame on the GPU: launch + PCIe latency bound (SURVEY 0.2); host-buffer Decoder API"}
+    lib = zko.lib()
+    path = next((p for p in Z._CANDIDATES["system"] if os.path.exists(p)), None)
+    if path and lib.zkb_open(path.encode()) == 0:
+        c = np.zeros(len(frames) + 1, np.uint64); d = np.zeros(len(frames) + 1, np.uint64)
+        c[1:] = np.cumsum([f[0] for f in frames]); d[1:] = np.cumsum([f[1] for f in frames])
+        tus = np.zeros(nseeks, np.float64)
+        ob = np.zeros(8192 + 8, np.uint8)
+        cb = np.frombuffer(comp, np.uint8)
+        lib.zkb_time_seeks.restype = C.c_int
+        lib.zkb_time_seeks.argtypes = [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 2 + [C.c_uint32] + [C.c_void_p] * 2
+        if lib.zkb_time_seeks(cb.ctypes.data, c.ctypes.data, d.ctypes.data, len(frames), offs.ctypes.data, lens.ctypes.data,
+                              nseeks, tus.ctypes.data, ob.ctypes.data) == 0:
+            out["cpu_reference_us"] = {"p50": round(float(np.percentile(tus[20:], 50)), 1), "p95": round(float(np.percentile(tus[20:], 95)), 1)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +155,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c2"])
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-seek", action="store_true")
     ap.add_argument("--archive", default="auto", choices=["auto", "gpu", "libzstd"],
                     help="who compresses the archive that is decoded: the GPU encoder (default for c3) or CPU libzstd (default for c2)")
     args = ap.parse_args()
@@ -240,6 +285,15 @@ def main():
     except OSError:
         pass
 
+    # ---- seek-to-offset latency (BASELINE.json configs[3] shape at reduced size): 64 KiB frames, random
+    #      set_offset / set_offset_limit / read through the zeekstd Decoder API (host buffers: PCIe included)
+    seek_info = None
+    if rank == 0 and world == 1 and not args.no_seek:
+        try:
+            seek_info = seek_leg(eng, data, zk)
+        except Exception as ex:
+            seek_info = {"error": repr(ex)[:200]}
+
     # ---- N > 1: the one exchange step of the path -- encode the local shard, gather stream + seek table on rank 0 (RCCL)
     gather_info = None
     if world > 1 and use_gpu_archive:
@@ -275,6 +329,7 @@ def main():
             "cpu_baseline": base,
             "encode": enc_info,
             "rccl_gather": gather_info,
+            "seek": seek_info,
             "setup_s": round(t_setup, 1),
         }
         if base:

@@ -142,3 +142,38 @@ double zkb_time_encode(const uint8_t *src, size_t n, uint32_t frame_size, int le
     free(stage); Z.freeCCtx(cctx);
     return best;
 }
+
+/* Random-seek latency of the reference CPU path (BASELINE.json configs[3]): per seek, what
+ * Decoder::set_offset + set_offset_limit + decompress do (decode.rs:402-437, 201-270): locate the frame by binary
+ * search (seek_table.rs:916-934), reset the context, decode from the frame start, discard up to `offset`
+ * ("dummy decompression", decode.rs:228-231), stop at the limit.  times_us[i] receives the latency of seek i. */
+int zkb_time_seeks(const uint8_t *comp, const uint64_t *c_off, const uint64_t *d_off, uint32_t nframes,
+                   const uint64_t *offsets, const uint32_t *lens, uint32_t nseeks, double *times_us, uint8_t *out)
+{
+    void *dctx = Z.createDCtx();
+    uint8_t *dummy = malloc(131072);
+    for (uint32_t i = 0; i < nseeks; i++) {
+        double t0 = now();
+        uint64_t off = offsets[i], limit = off + lens[i];
+        uint32_t lo = 0, hi = nframes;                           /* frame_index_decomp */
+        while (lo + 1 < hi) { uint32_t mid = lo + (hi - lo) / 2; if (d_off[mid] <= off) lo = mid; else hi = mid; }
+        Z.DCtx_reset(dctx, 1);
+        uint64_t pos = d_off[lo];
+        in_buf_t ib = { comp + c_off[lo], (size_t)(c_off[nframes] - c_off[lo]), 0 };
+        size_t got = 0;
+        while (pos < limit) {
+            out_buf_t ob;
+            if (pos < off) { uint64_t n = off - pos; ob.dst = dummy; ob.size = n < 131072 ? (size_t)n : 131072; }
+            else { ob.dst = out + got; ob.size = (size_t)(limit - pos); }
+            ob.pos = 0;
+            size_t r = Z.decompressStream(dctx, &ob, &ib);
+            if (Z.isError(r)) { free(dummy); Z.freeDCtx(dctx); return -1; }
+            if (pos >= off) got += ob.pos;
+            pos += ob.pos;
+            if (ob.pos == 0 && ib.pos == ib.size) break;
+        }
+        times_us[i] = (now() - t0) * 1e6;
+    }
+    free(dummy); Z.freeDCtx(dctx);
+    return 0;
+}

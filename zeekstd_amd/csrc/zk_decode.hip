@@ -83,8 +83,14 @@ __global__ __launch_bounds__(64) void zk_k_huf(const uint8_t *comp, ZkBlock *blo
     __shared__ uint16_t tab[ZK_HUF_BLOCKS][2048];
     __shared__ ZkHufScratch sc[ZK_HUF_BLOCKS];
     __shared__ uint32_t s_maxbits[ZK_HUF_BLOCKS], s_desc[ZK_HUF_BLOCKS];
-    const uint32_t lane = threadIdx.x, slot = lane >> 2, stream = lane & 3;
-    const uint32_t bi = blockIdx.x * ZK_HUF_BLOCKS + slot;
+    // a workgroup with fewer than 4 blocks left keeps >= 16 lanes active: the extra lanes shadow valid streams
+    // (< 16 active lanes run ~3x slower on gfx950, tools/ubench/lat3.hip); shadows never store to HBM
+    const uint32_t wb = blockIdx.x * ZK_HUF_BLOCKS;
+    const uint32_t nvalid = nblocks - wb < (uint32_t)ZK_HUF_BLOCKS ? nblocks - wb : (uint32_t)ZK_HUF_BLOCKS;
+    const bool real = threadIdx.x < 4 * nvalid;
+    const uint32_t lane = real ? threadIdx.x : (threadIdx.x < 16 ? threadIdx.x % (4 * nvalid) : threadIdx.x);
+    const uint32_t slot = lane >> 2, stream = lane & 3;
+    const uint32_t bi = wb + slot;
     bool active = false;
     ZkBlock b;
     if (bi < nblocks) {
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(64) void zk_k_huf(const uint8_t *comp, ZkBlock *blo
         uint8_t *dst = lit_scratch + b.lit_base;
         const uint32_t mb = s_maxbits[slot], regen = b.lit_regen;
         if (b.lit_streams == 1) {
-            if (stream == 0) ok = zk_huf_decode_stream(tab[slot], mb, pay, size, dst, regen);
+            if (stream == 0) ok = zk_huf_decode_stream(tab[slot], mb, pay, size, dst, regen, real);
         } else if (size < 6) {
             ok = false;
         } else {
@@ -119,11 +125,11 @@ __global__ __launch_bounds__(64) void zk_k_huf(const uint8_t *comp, ZkBlock *blo
                 uint32_t start = 6 + (stream > 0 ? s1 : 0) + (stream > 1 ? s2 : 0) + (stream > 2 ? s3 : 0);
                 uint32_t len = stream == 0 ? s1 : stream == 1 ? s2 : stream == 2 ? s3 : s4;
                 uint32_t n = stream == 3 ? regen - 3 * q : q;
-                ok = zk_huf_decode_stream(tab[slot], mb, pay + start, len, dst + stream * q, n);
+                ok = zk_huf_decode_stream(tab[slot], mb, pay + start, len, dst + stream * q, n, real);
             }
         }
     }
-    if (!ok) blocks[bi].status = ZK_E_CORRUPTION;
+    if (!ok && real) blocks[bi].status = ZK_E_CORRUPTION;
 }
 
 // ------------------------------------------------------------------------------------------------ FSE sequences
@@ -149,10 +155,12 @@ __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *com
     // tools/ubench/lat3.hip), so lanes 7..20 shadow lanes 0..6: same block, same LDS tables (broadcast
     // reads), identical LDS writes, no HBM writes.
     if (lane >= 3 * ZK_FSE_PER_WAVE) return;
-    const bool real = lane < ZK_FSE_PER_WAVE;
-    const uint32_t slot = wave * ZK_FSE_PER_WAVE + lane % ZK_FSE_PER_WAVE;
+    const uint32_t wbase = blockIdx.x * ZK_FSE_BLOCKS + wave * ZK_FSE_PER_WAVE;        // first block of this wave
+    if (wbase >= nblocks) return;
+    const uint32_t nvalid = nblocks - wbase < (uint32_t)ZK_FSE_PER_WAVE ? nblocks - wbase : (uint32_t)ZK_FSE_PER_WAVE;
+    const bool real = lane < nvalid;
+    const uint32_t slot = wave * ZK_FSE_PER_WAVE + lane % nvalid;                      // shadows replicate valid blocks only
     const uint32_t bi = blockIdx.x * ZK_FSE_BLOCKS + slot;
-    if (bi >= nblocks) return;
     ZkBlock b = blocks[bi];
     if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK || b.seq_modes == 0) return;      // all-predefined blocks: zk_k_fse_predef
     zk_decode_sequences(comp, blocks, b, &T[slot], seqs + b.seq_base, llv, mlv, real);
@@ -186,11 +194,18 @@ __global__ __launch_bounds__(ZK_FSEP_THREADS) void zk_k_fse_predef(const uint8_t
         for (int t = 0; t < 3; t++) { uint32_t a = 0; (void)zk_seq_table_setup(comp, fake, t, &T, &a, llv, mlv); s_al[t] = a; }
     }
     __syncthreads();
-    const uint32_t bi = blockIdx.x * ZK_FSEP_THREADS + tid;
-    if (bi >= nblocks) return;
+    uint32_t bi = blockIdx.x * ZK_FSEP_THREADS + tid;
+    bool real = true;
+    if (bi >= nblocks) {                                   // tail of the block list: shadow a valid block of this wave (up to 16 lanes)
+        const uint32_t wfirst = blockIdx.x * ZK_FSEP_THREADS + (tid & ~63u);
+        if (wfirst >= nblocks || (tid & 63) >= 16) return;
+        bi = wfirst + (tid & 63) % (nblocks - wfirst);
+        real = false;
+    }
     ZkBlock b = blocks[bi];
     if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK || b.seq_modes != 0) return;
-    zk_seq_walk<4>(comp, b, b.seq_off + 1, T.ll, T.of, T.ml, s_al, ring[tid], seqs + b.seq_base, llv, mlv, true);
+    zk_seq_walk<4>(comp, b, b.seq_off + 1, T.ll, T.of, T.ml, s_al, ring[tid], seqs + b.seq_base, llv, mlv, real);
+    if (!real) return;
     ZkBlock *o = &blocks[bi];
     o->out_size = b.out_size;
     o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];

@@ -349,7 +349,7 @@ ZK_HD uint32_t zk_huf_build(const uint8_t *src, uint32_t len, uint16_t *table, Z
 // Decode n symbols of one Huffman stream into dst.  Returns false on corruption.
 // Eight symbols are packed into one 64-bit store (two refills of <= 4 x 11 bits).
 ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const uint8_t *src, uint32_t len,
-                                uint8_t *dst, uint32_t n)
+                                uint8_t *dst, uint32_t n, bool store = true)
 {
     ZkBwd b;
     if (!zk_bwd_init(b, src, len)) return false;
@@ -368,7 +368,7 @@ ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const u
             pack |= (uint64_t)(c & 0xff) << (8 * k);
             zk_bwd_skip(b, c >> 8);
         }
-        memcpy(dst + i, &pack, 8);
+        if (store) memcpy(dst + i, &pack, 8);
         i += 8;
     }
     while (i < n) {
@@ -376,7 +376,7 @@ ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const u
         uint32_t lim = n - i < 4 ? n - i : 4;
         for (uint32_t k = 0; k < lim; k++) {
             uint32_t c = table[zk_bwd_peek(b, maxbits)];
-            dst[i + k] = (uint8_t)c;
+            if (store) dst[i + k] = (uint8_t)c;
             zk_bwd_skip(b, c >> 8);
         }
         i += lim;
@@ -765,11 +765,23 @@ ZK_HD uint32_t zk_exec_src(uint32_t q, uint32_t oe, uint32_t ml, uint32_t off, u
     return (uint32_t)(p + (int32_t)ZK_SRC_BIAS);
 }
 
-// Fill srcmap[q - ts] for q in [lo, hi) (the part of the sequence that lies in the tile).
+// Fill srcmap[q - ts] for q = lo + first, lo + first + step, ... < hi (the part of the sequence inside the tile).
+// Literal part and non-overlapping match part are affine in q (2 instructions per byte); only a match that
+// overlaps its own output (offset < match length) needs the periodic form.
 ZK_HD void zk_exec_fill_range(uint32_t *srcmap, uint32_t ts, uint32_t lo, uint32_t hi, uint32_t step, uint32_t first,
                               uint32_t oe, uint32_t ml, uint32_t off, uint32_t le)
 {
-    for (uint32_t q = lo + first; q < hi; q += step) srcmap[q - ts] = zk_exec_src(q, oe, ml, off, le);
+    const uint32_t ms = oe - ml;
+    const uint32_t lit_hi = hi < ms ? hi : ms;
+    const uint32_t lit_word = (ZK_SRC_LIT | le) - ms;                    // + q  (le - (ms - q) never borrows into bit 31)
+    uint32_t q = lo + first;
+    for (; q < lit_hi; q += step) srcmap[q - ts] = lit_word + q;
+    if (off >= ml) {
+        const uint32_t m_word = ZK_SRC_BIAS - off;                       // + q
+        for (; q < hi; q += step) srcmap[q - ts] = m_word + q;
+    } else {
+        for (; q < hi; q += step) srcmap[q - ts] = zk_exec_src(q, oe, ml, off, le);
+    }
 }
 
 // Follow in-tile sources: returns a word that is a literal or a history position before the tile.
