@@ -205,7 +205,7 @@ uint64_t zk_decoder_gpu_submissions(const zk_decoder *d);                       
 typedef struct zk_raw_encoder zk_raw_encoder;
 typedef struct zk_encoder zk_encoder;
 #define ZK_POLICY_UNCOMPRESSED 0 /* FrameSizePolicy::Uncompressed(n), encode.rs:21-39 (default, n = 0x200000) */
-#define ZK_POLICY_COMPRESSED 1   /* FrameSizePolicy::Compressed(n): not on the GPU path yet -> -40 (parameter_unsupported) */
+#define ZK_POLICY_COMPRESSED 1   /* FrameSizePolicy::Compressed(n): frame closes once its encoding reaches n bytes (probed speculatively) */
 typedef struct zk_encode_opts {  /* EncodeOptions builder fields, encode.rs:110-207 */
     uint32_t policy, frame_size; /* frame_size 0 = default policy */
     int32_t level;               /* compression_level :170 (default 0) */

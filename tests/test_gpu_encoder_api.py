@@ -198,9 +198,6 @@ def test_readme_seek_example(engine):                              # decode.rs:5
 
 
 def test_unsupported_parameters_fail_loudly(engine):
-    with pytest.raises(zk.Error) as e:                              # Compressed(n) policy is a "next" row
-        EncodeOptions().engine(engine).frame_size_policy(FrameSizePolicy.Compressed(1000)).into_raw_encoder()
-    assert e.value.code == -40
     enc = EncodeOptions().engine(engine).into_raw_encoder()
     with pytest.raises(zk.Error) as e:                              # prefix / patch mode
         enc.compress_with_prefix(b"abc", bytearray(10), b"prefix")
@@ -217,3 +214,23 @@ def test_fuzz_roundtrip_basic(engine):                             # fuzz_target
         enc.write(data)
         enc.finish()
         assert Decoder(DecodeOptions(sink.getvalue()).engine(engine)).read_to_end() == data
+
+
+@pytest.mark.parametrize("n", [1, 60, 500, 1023, 4000])       # proptest lib.rs:317-319, 328-330: Compressed(1..1023)
+def test_compressed_frame_size_policy_roundtrip(engine, n):
+    seekable, st = raw_roundtrip(engine, FrameSizePolicy.Compressed(n), checksum=True, scratch=211)
+    assert st.size_decomp() == len(INPUT)
+    # every frame but the last reached the compressed-size threshold
+    for i in range(st.num_frames() - 1):
+        assert st.frame_size_comp(i) >= n
+    if n >= 500:
+        assert st.num_frames() < len(INPUT) // 100
+    d = DecodeOptions(seekable).engine(engine).into_decoder()
+    assert d.read_to_end() == INPUT
+    sink = io.BytesIO()
+    enc = EncodeOptions().engine(engine).frame_size_policy(FrameSizePolicy.Compressed(n)).into_encoder(sink)
+    for i in range(0, len(INPUT), 700):
+        enc.write(INPUT[i:i + 700])
+    total = enc.finish()
+    assert total == len(sink.getvalue())
+    assert Decoder(DecodeOptions(sink.getvalue()).engine(engine)).read_to_end() == INPUT

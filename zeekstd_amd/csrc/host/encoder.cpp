@@ -23,9 +23,6 @@ RawEncoder::RawEncoder() : RawEncoder(EncodeOptions()) {}
 RawEncoder::RawEncoder(EncodeOptions &&opts)                                   // with_opts, encode.rs:280-293
     : policy_(opts.policy_), checksum_(opts.checksum_), level_(opts.level_)
 {
-    if (policy_.kind == FrameSizePolicy::Kind::Compressed)
-        // frame boundaries that depend on the compressed size need incremental output ("next")
-        throw Error::zstd(40 /* parameter_unsupported */);
     if (opts.engine_) engine_ = opts.engine_;
     else {                                                                     // CCtx::create(), encode.rs:130
         int rc = zk_engine_create(0, &engine_);
@@ -46,11 +43,17 @@ RawEncoder::RawEncoder(RawEncoder &&o) noexcept
 
 size_t RawEncoder::remaining_frame_size() const                                // encode.rs:528-535
 {
+    if (policy_.kind == FrameSizePolicy::Kind::Compressed) return MAX_FRAME_SIZE - frame_d_size_;
     return std::min(MAX_FRAME_SIZE, policy_.size) - frame_d_size_;
 }
 
+// Compressed(n): upstream compares n with the bytes libzstd has emitted so far for the frame.  A frame is
+// encoded whole here, so the compressed size of the frame-so-far is obtained by encoding it speculatively
+// (at most once per 12.5 % of growth); the encoding is kept when it reaches n, otherwise dropped.
 bool RawEncoder::is_frame_complete() const                                     // encode.rs:537-544
 {
+    if (policy_.kind == FrameSizePolicy::Kind::Compressed)
+        return (encoded_ && policy_.size <= pending_.size()) || MAX_FRAME_SIZE <= frame_d_size_;
     return std::min(MAX_FRAME_SIZE, policy_.size) <= frame_d_size_;
 }
 
@@ -85,11 +88,17 @@ CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t i
     const size_t limit = std::min(in_len, remaining_frame_size());             // encode.rs:329
     frame_in_.insert(frame_in_.end(), in, in + limit);
     frame_d_size_ += (uint32_t)limit;                                          // encode.rs:350
+    if (policy_.kind == FrameSizePolicy::Kind::Compressed && limit && frame_in_.size() >= next_probe_) {
+        encoded_ = false;
+        encode_pending();                                                      // speculative: how large is the frame so far?
+        if (pending_.size() < policy_.size) { encoded_ = false; next_probe_ = frame_in_.size() + frame_in_.size() / 8 + 1; }
+    }
     return {limit, 0};
 }
 
 EpilogueProgress RawEncoder::end_frame(uint8_t *out, size_t out_len)           // encode.rs:438-472
 {
+    if (encoded_ && pending_pos_ == 0 && policy_.kind == FrameSizePolicy::Kind::Compressed && !is_frame_complete()) encoded_ = false;
     encode_pending();
     const size_t n = std::min(out_len, pending_.size() - pending_pos_);
     memcpy(out, pending_.data() + pending_pos_, n);
@@ -105,7 +114,7 @@ EpilogueProgress RawEncoder::end_frame(uint8_t *out, size_t out_len)           /
 void RawEncoder::reset_frame()                                                 // encode.rs:501-507
 {
     frame_c_size_ = 0; frame_d_size_ = 0;
-    frame_in_.clear(); pending_.clear(); pending_pos_ = 0; encoded_ = false;
+    frame_in_.clear(); pending_.clear(); pending_pos_ = 0; encoded_ = false; next_probe_ = 0;
 }
 
 // ---------------------------------------------------------------- Encoder<W>
@@ -160,6 +169,19 @@ void Encoder::submit_batch(bool include_partial)
 size_t Encoder::compress_with_prefix(const uint8_t *buf, size_t len, const uint8_t *prefix, size_t)   // encode.rs:641-665
 {
     if (prefix) throw Error::zstd(40 /* parameter_unsupported */);
+    if (raw_.policy_.kind == FrameSizePolicy::Kind::Compressed) {               // frame ends depend on output: the upstream loop, frame by frame
+        size_t input_progress = 0;
+        while (input_progress < len) {
+            CompressionProgress p = raw_.compress(buf + input_progress, len - input_progress, out_buf_.data() + out_buf_pos_,
+                                                  out_buf_.size() - out_buf_pos_);
+            if (p.in_progress() == 0 && p.out_progress() == 0) break;
+            out_buf_pos_ += p.out_progress();
+            flush_out_buf(false);
+            input_progress += p.in_progress();
+        }
+        since_end_ += input_progress;
+        return input_progress;
+    }
     const uint32_t fs = std::min(MAX_FRAME_SIZE, raw_.policy_.size);
     batch_in_.insert(batch_in_.end(), buf, buf + len);
     since_end_ += len;
@@ -174,7 +196,14 @@ size_t Encoder::end_frame()                                                    /
     // ending a frame that has received no byte since the last end_frame yields an EMPTY frame, anything
     // else is exactly the frames already cut every frame_size bytes plus the partial tail.
     const uint64_t before = written_compressed_ + out_buf_pos_;
-    if (since_end_ == 0 || !batch_in_.empty()) submit_batch(true);
+    if (raw_.policy_.kind == FrameSizePolicy::Kind::Compressed) {               // encode.rs:704-717 verbatim
+        for (;;) {
+            EpilogueProgress p = raw_.end_frame(out_buf_.data() + out_buf_pos_, out_buf_.size() - out_buf_pos_);
+            out_buf_pos_ += p.out_progress();
+            flush_out_buf(false);
+            if (p.data_left() == 0) break;
+        }
+    } else if (since_end_ == 0 || !batch_in_.empty()) submit_batch(true);
     since_end_ = 0;
     return (size_t)(written_compressed_ + out_buf_pos_ - before);
 }

@@ -318,6 +318,7 @@ private:
     std::vector<uint8_t> pending_;            // encoded frame being drained by end_frame
     size_t pending_pos_ = 0;
     bool encoded_ = false;
+    size_t next_probe_ = 0;                   // Compressed(n): buffered size at which the next speculative encode happens
 };
 
 class Encoder {                                                                      // encode.rs:570-800

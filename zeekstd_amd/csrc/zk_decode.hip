@@ -174,7 +174,8 @@ __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *com
 // Blocks whose three tables are all Predefined_Mode (Symbol_Compression_Modes == 0: what this engine's own
 // encoder emits, and libzstd for small blocks) need no per-block tables: one copy of the predefined tables per
 // workgroup, one block per LANE, full waves -- the walk is then limited only by its dependent chain.
-constexpr int ZK_FSEP_THREADS = 256;
+constexpr int ZK_FSEP_THREADS = 64;
+constexpr int ZK_FSEP_LANES = 64;                        // blocks per wave (measured on 4 GiB: 64 lanes x 64-thread workgroups 7.6 ms; 16 lanes 8.7; 256-thread workgroups 9.0)
 __global__ __launch_bounds__(ZK_FSEP_THREADS) void zk_k_fse_predef(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
 {
     __shared__ ZkSeqTables T;                              // shared, read-only after the build
@@ -194,12 +195,13 @@ __global__ __launch_bounds__(ZK_FSEP_THREADS) void zk_k_fse_predef(const uint8_t
         for (int t = 0; t < 3; t++) { uint32_t a = 0; (void)zk_seq_table_setup(comp, fake, t, &T, &a, llv, mlv); s_al[t] = a; }
     }
     __syncthreads();
-    uint32_t bi = blockIdx.x * ZK_FSEP_THREADS + tid;
+    if (tid >= ZK_FSEP_LANES) return;
+    uint32_t bi = blockIdx.x * ZK_FSEP_LANES + tid;
     bool real = true;
     if (bi >= nblocks) {                                   // tail of the block list: shadow a valid block of this wave (up to 16 lanes)
-        const uint32_t wfirst = blockIdx.x * ZK_FSEP_THREADS + (tid & ~63u);
-        if (wfirst >= nblocks || (tid & 63) >= 16) return;
-        bi = wfirst + (tid & 63) % (nblocks - wfirst);
+        const uint32_t wfirst = blockIdx.x * ZK_FSEP_LANES;
+        if (wfirst >= nblocks || tid >= 16) return;
+        bi = wfirst + tid % (nblocks - wfirst);
         real = false;
     }
     ZkBlock b = blocks[bi];
@@ -452,7 +454,7 @@ void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
 void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
 {
     if (!nblocks) return;
-    hipLaunchKernelGGL(zk_k_fse_predef, dim3((nblocks + ZK_FSEP_THREADS - 1) / ZK_FSEP_THREADS), dim3(ZK_FSEP_THREADS), 0, st, comp, blocks, nblocks, seqs);
+    hipLaunchKernelGGL(zk_k_fse_predef, dim3((nblocks + ZK_FSEP_LANES - 1) / ZK_FSEP_LANES), dim3(ZK_FSEP_THREADS), 0, st, comp, blocks, nblocks, seqs);
     hipLaunchKernelGGL(zk_k_fse, dim3((nblocks + ZK_FSE_BLOCKS - 1) / ZK_FSE_BLOCKS), dim3(64 * ZK_FSE_WAVES), 0, st, comp, blocks, nblocks, seqs);
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
