@@ -131,11 +131,33 @@ def seek_leg(eng, data, zk, nbytes=256 << 20, fsz=65536, nseeks=300):
     out = {"frames": len(frames), "frame_size": fsz, "seeks": nseeks,
            "gpu_decoder_us": {"p50": round(float(np.percentile(ts[20:], 50)), 1), "p95": round(float(np.percentile(ts[20:], 95)), 1)},
            "note": "single seek = 1 frame on the GPU: launch + PCIe latency bound (SURVEY 0.2); host-buffer Decoder API"}
+    c = np.zeros(len(frames) + 1, np.uint64); d = np.zeros(len(frames) + 1, np.uint64)
+    c[1:] = np.cumsum([f[0] for f in frames]); d[1:] = np.cumsum([f[1] for f in frames])
+    # batches of 1024 seeks against the archive resident in HBM (zk_decode_frame_list_dev): what the GPU is for
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_comp = torch.from_numpy(np.frombuffer(comp + b"\0" * 64, np.uint8).copy()).to(dev)
+    d_c = torch.from_numpy(c.view(np.int64)).to(dev); d_d = torch.from_numpy(d.view(np.int64)).to(dev)
+    B = 1024
+    boffs = rng.integers(0, nbytes - 8192, B).astype(np.uint64)
+    ids = (np.searchsorted(d, boffs, side="right") - 1).astype(np.uint32)
+    sizes = (d[ids.astype(np.int64) + 1] - d[ids.astype(np.int64)]).astype(np.uint64)
+    ooff = np.zeros(B + 1, np.uint64); ooff[1:] = np.cumsum(sizes)
+    d_ids = torch.from_numpy(ids.view(np.int32)).to(dev); d_oo = torch.from_numpy(ooff.view(np.int64)).to(dev)
+    d_o = torch.empty(int(ooff[-1]) + 64, dtype=torch.uint8, device=dev); d_s = torch.zeros(B, dtype=torch.int32, device=dev)
+    tb = []
+    for _ in range(7):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        rc = eng.decode_frame_list_dev(d_comp, len(comp), d_c, d_d, d_ids, d_oo, B, d_o, int(ooff[-1]), True, d_s)
+        torch.cuda.synchronize(); tb.append((time.perf_counter() - t) * 1e6)
+    got = bytes(d_o[:int(ooff[3])].cpu().numpy())
+    if rc != 0 or got != b"".join(src[int(d[i]):int(d[i + 1])].tobytes() for i in ids[:3]):
+        raise RuntimeError("batched seek mismatch")
+    out["gpu_batch_of_1024"] = {"batch_us_p50": round(float(np.median(tb[2:])), 1), "us_per_seek": round(float(np.median(tb[2:])) / B, 2),
+                                "note": "1024 random frames per submission, archive + outputs resident in HBM, checksums verified"}
     lib = zko.lib()
     path = next((p for p in Z._CANDIDATES["system"] if os.path.exists(p)), None)
     if path and lib.zkb_open(path.encode()) == 0:
-        c = np.zeros(len(frames) + 1, np.uint64); d = np.zeros(len(frames) + 1, np.uint64)
-        c[1:] = np.cumsum([f[0] for f in frames]); d[1:] = np.cumsum([f[1] for f in frames])
         tus = np.zeros(nseeks, np.float64)
         ob = np.zeros(8192 + 8, np.uint8)
         cb = np.frombuffer(comp, np.uint8)

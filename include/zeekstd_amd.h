@@ -97,6 +97,14 @@ int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, c
                          const void *d_d_off, uint32_t first, uint32_t count, void *d_dst, uint64_t dst_cap,
                          int verify, void *d_frame_status, void *stream);
 
+/* Random-access batch (many seeks per submission; engine-specific, no reference counterpart -- the reference serves one
+ * seek at a time, lib/src/decode.rs:402-437): decode archive frames d_ids[0..count) (uint32, any order, repeats allowed) of a
+ * device-resident archive; frame d_ids[i] lands at d_dst + d_out_off[i], d_out_off being the count + 1 prefix sums of the
+ * selected frames' decompressed sizes (uint64).  d_c_off / d_d_off are the archive's full n+1 prefix arrays. */
+int zk_decode_frame_list_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off, const void *d_d_off,
+                             const void *d_ids, const void *d_out_off, uint32_t count, void *d_dst, uint64_t dst_cap,
+                             int verify, void *d_frame_status, void *stream);
+
 /*
  * Encode src[0, n) as ceil(n / frame_size) independent zstd frames (FrameSizePolicy::Uncompressed(frame_size),
  * lib/src/encode.rs:21-39, 528-544; n == 0 yields one empty frame like Encoder::finish, encode.rs:755-757),

@@ -128,3 +128,29 @@ def test_baseline_config_2_decode_only(engine):
     assert out == data
     h = engine.xxh64_frames(out, d)
     assert int(h[0]) == 0xAD0311EAAD1ED582 and int(h[1]) == 0x8CC2C9BC11FFCCA2
+
+
+def test_random_access_batch(engine):
+    """zk_decode_frame_list_dev: many seeks per submission against a device-resident archive (BASELINE configs[3] shape)."""
+    import torch
+    g = next(x for x in GOLDENS if x.name == "text_100B_frames")
+    data = g.input()
+    c, d = g.offsets()
+    dev = torch.device("cuda:0")
+    d_comp = torch.from_numpy(np.frombuffer(g.comp + b"\0" * 64, np.uint8).copy()).to(dev)
+    d_c = torch.from_numpy(c.view(np.int64)).to(dev)
+    d_d = torch.from_numpy(d.view(np.int64)).to(dev)
+    rng = np.random.default_rng(2)
+    ids = rng.integers(0, len(g.frames), 500).astype(np.uint32)            # repeats and any order are allowed
+    sizes = (d[ids.astype(np.int64) + 1] - d[ids.astype(np.int64)]).astype(np.uint64)
+    off = np.zeros(len(ids) + 1, np.uint64)
+    off[1:] = np.cumsum(sizes)
+    d_ids = torch.from_numpy(ids.view(np.int32)).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_out = torch.zeros(int(off[-1]) + 64, dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(len(ids), dtype=torch.int32, device=dev)
+    rc = engine.decode_frame_list_dev(d_comp, len(g.comp), d_c, d_d, d_ids, d_off, len(ids), d_out, int(off[-1]), True, d_st)
+    assert rc == 0 and int(d_st.abs().sum()) == 0
+    out = bytes(d_out[:int(off[-1])].cpu().numpy())
+    for i, f in enumerate(ids):
+        assert out[int(off[i]):int(off[i + 1])] == data[int(d[f]):int(d[f + 1])]

@@ -46,6 +46,7 @@ _sig = {
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "zk_encode_frames_dev": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_int, C.c_int, _P, C.c_uint64, _P, _P,
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), _P]),
+    "zk_decode_frame_list_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint64, C.c_int, _P, _P]),
     "zk_xxh64_frames": (C.c_int, [_P, _P, _P, C.c_uint32, _P]),
     "zk_xxh64_frames_dev": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
 }

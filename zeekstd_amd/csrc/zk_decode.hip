@@ -18,14 +18,16 @@
 #include "zk_kernels.h"
 
 // ------------------------------------------------------------------------------------------------ walk
+// ids != nullptr: frame f of the batch is frame ids[f] of the archive (random-access batches: many seeks per submission)
 __global__ __launch_bounds__(64) void zk_k_walk(const uint8_t *comp, const uint64_t *c_off, const uint64_t *d_off,
-                                                uint32_t first, uint32_t count, const ZkFrameBase *bases,
+                                                uint32_t first, uint32_t count, const uint32_t *ids, const ZkFrameBase *bases,
                                                 ZkBlock *blocks, ZkFrameInfo *infos)
 {
     uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= count) return;
-    uint64_t cb = c_off[first + f], ce = c_off[first + f + 1];
-    uint64_t dsz = d_off[first + f + 1] - d_off[first + f];
+    const uint32_t id = ids ? ids[f] : first + f;
+    uint64_t cb = c_off[id], ce = c_off[id + 1];
+    uint64_t dsz = d_off[id + 1] - d_off[id];
     ZkFrameInfo fi;
     if (!bases) {                                   // pass 1: count
         zk_walk_frame(comp, cb, ce, dsz, f, nullptr, nullptr, fi);
@@ -227,6 +229,7 @@ constexpr int ZK_EXEC_B = 16;
 
 template <int T>
 __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
+                                               const uint32_t *ids, const uint64_t *out_off,
                                                const ZkBlock *blocks, const ZkFrameBase *bases,
                                                ZkFrameInfo *infos, const ZkSeq *seqs,
                                                const uint8_t *lit_scratch, uint8_t *dst)
@@ -239,8 +242,9 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
     const ZkFrameInfo fi = infos[f];
     if (fi.status != ZK_OK) return;
-    const uint64_t d_size = d_off[first + f + 1] - d_off[first + f];
-    uint8_t *out = dst + (d_off[first + f] - d_off[first]);
+    const uint32_t id = ids ? ids[f] : first + f;
+    const uint64_t d_size = d_off[id + 1] - d_off[id];
+    uint8_t *out = dst + (out_off ? out_off[f] : d_off[id] - d_off[first]);     // indexed batches are packed in list order
     const ZkBlock *fb = blocks + bases[f].block_base;
     uint64_t pos = 0;
     uint32_t rep[3] = {1, 4, 8};
@@ -438,9 +442,9 @@ void zk_launch_status(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, 
     hipLaunchKernelGGL(zk_k_status, dim3((count + 255) / 256), dim3(256), 0, st, infos, count, status_out, (unsigned long long *)first_err);
 }
 void zk_launch_walk(hipStream_t st, const uint8_t *comp, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
-                    uint32_t count, const ZkFrameBase *bases, ZkBlock *blocks, ZkFrameInfo *infos)
+                    uint32_t count, const uint32_t *ids, const ZkFrameBase *bases, ZkBlock *blocks, ZkFrameInfo *infos)
 {
-    hipLaunchKernelGGL(zk_k_walk, dim3((count + 63) / 64), dim3(64), 0, st, comp, c_off, d_off, first, count, bases, blocks, infos);
+    hipLaunchKernelGGL(zk_k_walk, dim3((count + 63) / 64), dim3(64), 0, st, comp, c_off, d_off, first, count, ids, bases, blocks, infos);
 }
 void zk_launch_scan(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals)
 {
@@ -458,12 +462,12 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     hipLaunchKernelGGL(zk_k_fse, dim3((nblocks + ZK_FSE_BLOCKS - 1) / ZK_FSE_BLOCKS), dim3(64 * ZK_FSE_WAVES), 0, st, comp, blocks, nblocks, seqs);
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
-                    const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeq *seqs,
+                    const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeq *seqs,
                     const uint8_t *lit, uint8_t *dst)
 {
     // few frames: big tiles (more bytes in flight per frame); many frames: 4-wave workgroups, 8 per CU
-    if (count >= 1024) hipLaunchKernelGGL(zk_k_exec<256>, dim3(count), dim3(256), 0, st, comp, d_off, first, blocks, bases, infos, seqs, lit, dst);
-    else hipLaunchKernelGGL(zk_k_exec<1024>, dim3(count), dim3(1024), 0, st, comp, d_off, first, blocks, bases, infos, seqs, lit, dst);
+    if (count >= 1024) hipLaunchKernelGGL(zk_k_exec<256>, dim3(count), dim3(256), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst);
+    else hipLaunchKernelGGL(zk_k_exec<1024>, dim3(count), dim3(1024), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst);
 }
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
                      ZkFrameInfo *infos, uint64_t *hashes)

@@ -135,11 +135,10 @@ extern "C" const char *zk_engine_last_hip_error(const zk_engine *e) { return e ?
 extern "C" const char *zk_engine_device_name(const zk_engine *e) { return e ? e->devname : ""; }
 
 // ---------------------------------------------------------------------------------------------- decode
-extern "C" int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off,
-                                    const void *d_d_off, uint32_t first, uint32_t count, void *d_dst, uint64_t dst_cap,
-                                    int verify, void *d_frame_status, void *stream)
+// ids / out_off (device arrays, both or neither): frame f of the batch is archive frame ids[f]; its bytes go to dst + out_off[f]
+static int zk_decode_impl(zk_engine *e, const void *d_comp, const void *d_c_off, const void *d_d_off, uint32_t first, uint32_t count,
+                          const uint32_t *ids, const uint64_t *out_off, void *d_dst, int verify, void *d_frame_status, void *stream)
 {
-    (void)comp_size; (void)dst_cap;
     if (!e || (count && (!d_comp || !d_c_off || !d_d_off || !d_dst))) return ZK_ERR_ARGUMENT;
     if (count == 0) return 0;
     ZK_HIP(hipSetDevice(e->device));
@@ -155,7 +154,7 @@ extern "C" int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t c
     uint64_t *words = (uint64_t *)e->words.p;          // [0..2] totals, [3] first error
 
     zk_profile_begin(e);
-    { zk_kernel_timer t(e, ZK_K_WALK_COUNT, st); zk_launch_walk(st, comp, c_off, d_off, first, count, nullptr, nullptr, infos); }
+    { zk_kernel_timer t(e, ZK_K_WALK_COUNT, st); zk_launch_walk(st, comp, c_off, d_off, first, count, ids, nullptr, nullptr, infos); }
     { zk_kernel_timer t(e, ZK_K_SCAN, st); zk_launch_scan(st, infos, count, bases, words); }
     ZK_HIP(hipMemcpyAsync(e->h_words, words, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
@@ -170,11 +169,12 @@ extern "C" int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t c
 
     e->h_words[3] = ~0ull;
     ZK_HIP(hipMemcpyAsync(words + 3, e->h_words + 3, sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    { zk_kernel_timer t(e, ZK_K_WALK_FILL, st); zk_launch_walk(st, comp, c_off, d_off, first, count, bases, blocks, infos); }
+    { zk_kernel_timer t(e, ZK_K_WALK_FILL, st); zk_launch_walk(st, comp, c_off, d_off, first, count, ids, bases, blocks, infos); }
     { zk_kernel_timer t(e, ZK_K_HUF, st); zk_launch_huf(st, comp, blocks, (uint32_t)nblocks, lit); }
     { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, seqs); }
-    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, blocks, bases, infos, seqs, lit, (uint8_t *)d_dst); }
-    if (verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)d_dst, d_off, first, count, infos, nullptr); }
+    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, ids, out_off, blocks, bases, infos, seqs, lit, (uint8_t *)d_dst); }
+    // packed indexed output: out_off (count + 1 prefix sums) doubles as the d_off of the checksum kernel
+    if (verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)d_dst, out_off ? out_off : d_off, out_off ? 0 : first, count, infos, nullptr); }
     { zk_kernel_timer t(e, ZK_K_STATUS, st); zk_launch_status(st, infos, count, (int32_t *)d_frame_status, words + 3); }
     ZK_HIP(hipMemcpyAsync(e->h_words + 3, words + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
@@ -182,6 +182,24 @@ extern "C" int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t c
     zk_profile_collect(e);
     if (e->h_words[3] != ~0ull) return -(int)(uint32_t)(e->h_words[3] & 0xFFFFFFFFu);
     return 0;
+}
+
+extern "C" int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off,
+                                    const void *d_d_off, uint32_t first, uint32_t count, void *d_dst, uint64_t dst_cap,
+                                    int verify, void *d_frame_status, void *stream)
+{
+    (void)comp_size; (void)dst_cap;
+    return zk_decode_impl(e, d_comp, d_c_off, d_d_off, first, count, nullptr, nullptr, d_dst, verify, d_frame_status, stream);
+}
+
+extern "C" int zk_decode_frame_list_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off, const void *d_d_off,
+                                        const void *d_ids, const void *d_out_off, uint32_t count, void *d_dst, uint64_t dst_cap,
+                                        int verify, void *d_frame_status, void *stream)
+{
+    (void)comp_size; (void)dst_cap;
+    if (count && (!d_ids || !d_out_off)) return ZK_ERR_ARGUMENT;
+    return zk_decode_impl(e, d_comp, d_c_off, d_d_off, 0, count, (const uint32_t *)d_ids, (const uint64_t *)d_out_off, d_dst, verify,
+                          d_frame_status, stream);
 }
 
 extern "C" int zk_decode_frames(zk_engine *e, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off,

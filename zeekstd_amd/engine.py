@@ -125,6 +125,16 @@ class Engine:
             self._raise(rc)
         return rc
 
+    def decode_frame_list_dev(self, d_comp, comp_size, d_c_off, d_d_off, d_ids, d_out_off, count, d_dst, dst_cap, verify=True,
+                              d_status=None, stream=None):
+        """Random-access batch: archive frames d_ids[i] -> d_dst + d_out_off[i] (all device-resident)."""
+        rc = lib.zk_decode_frame_list_dev(self._h, self._ptr(d_comp), comp_size, self._ptr(d_c_off), self._ptr(d_d_off),
+                                          self._ptr(d_ids), self._ptr(d_out_off), count, self._ptr(d_dst), dst_cap, int(verify),
+                                          self._ptr(d_status) if d_status is not None else None, stream)
+        if rc <= -1000:
+            self._raise(rc)
+        return rc
+
     def xxh64_frames_dev(self, d_data, d_off, count, d_out, stream=None):
         rc = lib.zk_xxh64_frames_dev(self._h, self._ptr(d_data), self._ptr(d_off), count, self._ptr(d_out), stream)
         if rc != 0:
