@@ -74,7 +74,7 @@ def test_compression_ratio_sanity(engine):
     comp, frames = engine.encode_frames(data, 2 << 20, 1, True)
     assert len(frames) == 4 and len(data) / len(comp) > 2.0          # text: libzstd level 1 gets ~2.5
     z, _ = engine.encode_frames(bytes(4 << 20), 2 << 20, 1, False)
-    assert len(z) < 200
+    assert len(z) < 1200                                             # 64 RLE blocks per 2 MiB frame (32 KiB blocks)
     r = zko.gen_random(1 << 20, 9)
     c, _ = engine.encode_frames(r, 2 << 20, 1, False)
     assert len(c) <= len(r) + 64                                      # incompressible: raw blocks

@@ -58,7 +58,7 @@ extern "C" uint64_t zk_compress_bound(uint64_t n, uint32_t frame_size)
 {
     if (frame_size == 0) return 0;
     const uint64_t nf = n == 0 ? 1 : (n + frame_size - 1) / frame_size;
-    const uint64_t blocks_per_frame = ((uint64_t)frame_size + 1023) / 1024 + 1;     // tiny frames have tiny blocks
+    const uint64_t blocks_per_frame = ((uint64_t)frame_size + 1023) / 1024 + 8;     // blocks are >= 1 KiB except in tiny frames
     return n + nf * (6 + 4 + 3 * blocks_per_frame) + 16;
 }
 
@@ -86,6 +86,9 @@ extern "C" int zk_encode_frames_dev(zk_engine *e, const void *d_src, uint64_t n,
         while ((1u << wlog) < fr.d_size && wlog < 17) wlog++;
         fr.window_log = wlog;
         fr.block_max = (1u << wlog) < ZKE_BLOCK ? (1u << wlog) : ZKE_BLOCK;
+        // blocks are cut smaller than the format's maximum on purpose: a block's sequence bitstream is one serial chain for
+        // the decoder, so more, shorter blocks = more parallel chains (32 KiB for large frames, >= 8 blocks per small frame)
+        { uint32_t t = 32768; while (t > 4096 && (uint64_t)t * 8 > fr.d_size) t >>= 1; if (t < fr.block_max) fr.block_max = t; }
         fr.n_blocks = fr.d_size ? (fr.d_size + fr.block_max - 1) / fr.block_max : 0;
         fr.block_base = (uint32_t)blocks.size();
         fr.pad = 0;
