@@ -77,7 +77,7 @@ def test_compression_ratio_sanity(engine):
     assert len(z) < 1200                                             # 64 RLE blocks per 2 MiB frame (32 KiB blocks)
     r = zko.gen_random(1 << 20, 9)
     c, _ = engine.encode_frames(r, 2 << 20, 1, False)
-    assert len(c) <= len(r) + 64                                      # incompressible: raw blocks
+    assert len(c) <= len(r) + 128                                     # incompressible: raw blocks (3 B header per 32 KiB block)
 
 
 def test_roundtrip_property(engine):         # fuzz/fuzz_targets/roundtrip_basic.rs at 100-byte frames
