@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Summarise two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/pmc_traffic.json.
+
+usage: pmc_summary.py <fetch_dir> <write_dir> <workload> [out.json]
+
+Each directory holds the `*_counter_collection.csv` of one pass of `python bench.py --steps 1 --warmup 1
+--no-cpu-baseline --no-seek`.  Values are KiB per dispatch (MI355X_MICROARCH.md, HBM section); the LAST dispatch of
+every kernel is used (the profiled decode step / the encode of the archive).  FETCH_SIZE is doubled only for kernels
+whose reads are known to be 16-byte wide streams (the gfx950 "half of wide reads" behaviour, calibrated on
+zk_k_xxh64, which reads exactly the archive's decompressed bytes).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+WIDE = {"zk_k_xxh64": 2.0}
+
+
+def short(name):
+    n = name.split("(")[0]
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0]
+
+
+def last_per_kernel(d, counter):
+    out = {}
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] != counter:
+                    continue
+                k = short(row["Kernel_Name"])
+                if not k.startswith("zk_"):
+                    continue
+                # several rows per dispatch (one per XCD / SE): sum them per dispatch id
+                did = int(row["Dispatch_Id"])
+                slot = out.setdefault(k, {})
+                slot[did] = slot.get(did, 0.0) + float(row["Counter_Value"])
+    return {k: v[max(v)] for k, v in out.items()}, {k: max(v.values()) for k, v in out.items()}
+
+
+def main():
+    fdir, wdir, workload = sys.argv[1:4]
+    outp = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(__file__), "..", "profiles",
+                                                              "pmc_traffic.json")
+    _, fetch = last_per_kernel(fdir, "FETCH_SIZE")
+    _, write = last_per_kernel(wdir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        corr = WIDE.get(k, 1.0)
+        fk, wk = fetch.get(k, 0.0), write.get(k, 0.0)
+        kernels[k] = {"fetch_kib": fk, "write_kib": wk, "fetch_correction": corr,
+                      "hbm_bytes": int((fk * corr + wk) * 1024)}
+    doc = {"workload": workload,
+           "note": "per launch (largest dispatch of each kernel); FETCH_SIZE x2 only where the access pattern was "
+                   "calibrated as wide (zk_k_xxh64); others uncorrected lower bounds",
+           "kernels": kernels}
+    with open(outp, "w") as f:
+        json.dump(doc, f, indent=1)
+    for k, v in kernels.items():
+        print(f"{k:24s} fetch {v['fetch_kib'] / 1048576:8.3f} GiB  write {v['write_kib'] / 1048576:8.3f} GiB"
+              f"  hbm {v['hbm_bytes'] / 1e9:8.3f} GB")
+
+
+if __name__ == "__main__":
+    main()
