@@ -82,9 +82,10 @@ extern "C" int zk_sim_decode(const uint8_t *comp, const uint64_t *c_off, const u
         blocks[bi].status = b.status;
     }
     delete T;
-    // exec: one "workgroup" per frame; tiles of THREADS x B bytes, per-byte source map (zk_exec_fill_range / zk_exec_origin)
+    // exec: one "workgroup" per frame; tiles of THREADS x B bytes, slot marking + per-byte source map (zk_exec_slot_span / zk_exec_slot_words)
     const uint32_t THREADS = 256, B = (uint32_t)exec_b, CAPS = (uint32_t)exec_chunk;      // CAPS: staged sequences per tile
-    std::vector<uint32_t> so(CAPS + 1), sm(CAPS + 1), sf(CAPS + 1), sl(CAPS + 1), srcmap(THREADS * B);
+    std::vector<ZkSeq> st(CAPS + 1);
+    std::vector<uint32_t> srcmap(THREADS * B), slot_seq(THREADS * B / ZK_EXEC_SLOT + 1);
     std::vector<uint8_t> tile(THREADS * B);
     int first_err = 0;
     for (uint32_t f = 0; f < count; f++) {
@@ -106,7 +107,7 @@ extern "C" int zk_sim_decode(const uint8_t *comp, const uint64_t *c_off, const u
                 else {
                     const ZkSeq *sq = seqs.data() + b.seq_base;
                     const uint8_t *l = b.lit_type >= 2 ? lit.data() + b.lit_base : comp + b.src + b.lit_off;
-                    const uint32_t lit_stride = b.lit_type == 1 ? 0u : 1u;
+                    const uint32_t lit_mask = b.lit_type == 1 ? 0u : 0x7fffffffu;
                     const uint32_t nseq = b.nseq, out_size = b.out_size;
                     uint32_t ja = 0, ts = 0, prev_end = 0;
                     while (ts < out_size) {
@@ -119,27 +120,39 @@ extern "C" int zk_sim_decode(const uint8_t *comp, const uint64_t *c_off, const u
                                 uint32_t off = zk_rep_resolve(s.off, rep);
                                 uint32_t mstart = s.out_end - s.ml;
                                 if (off == 0 || pos + mstart < off || off > fi.window) bad = 1;
-                                so[i] = s.out_end; sm[i] = s.ml; sf[i] = off; sl[i] = s.lit_end;
-                            } else { so[i] = out_size; sm[i] = 0; sf[i] = 1; sl[i] = b.lit_regen; }
+                                st[i].out_end = s.out_end; st[i].ml = s.ml; st[i].off = off; st[i].lit_end = s.lit_end;
+                            } else { st[i].out_end = out_size; st[i].ml = 0; st[i].off = 1; st[i].lit_end = b.lit_regen; }
                         }
                         if (bad) { err = ZK_E_CORRUPTION; break; }
-                        const uint32_t cap_end = so[nl - 1];
+                        const uint32_t cap_end = st[nl - 1].out_end;
                         const uint32_t te = ts + THREADS * B < cap_end ? ts + THREADS * B : cap_end;
-                        uint32_t jn = 0;
+                        uint32_t jn = nl;
                         std::fill(srcmap.begin(), srcmap.end(), 0xDEADBEEFu);
+                        std::fill(slot_seq.begin(), slot_seq.end(), 0xFFFFFFFFu);
                         for (uint32_t i = 0; i < nl; i++) {                                  // "lane per sequence"
-                            const uint32_t start = i ? so[i - 1] : prev_end;
-                            const uint32_t lo = start > ts ? start : ts, hi = so[i] < te ? so[i] : te;
-                            if (lo < hi) zk_exec_fill_range(srcmap.data(), ts, lo, hi, 1, 0, so[i], sm[i], sf[i], sl[i]);
-                            if (so[i] <= te) jn = i + 1;
+                            const uint32_t start = i ? st[i - 1].out_end : prev_end;
+                            const uint32_t lo = start > ts ? start : ts, hi = st[i].out_end < te ? st[i].out_end : te;
+                            if (lo < hi) {
+                                uint32_t s0, n;
+                                zk_exec_slot_span(ts, lo, hi, s0, n);
+                                for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = i;
+                            }
+                            if (st[i].out_end > te && start <= te) jn = i;
                         }
-                        for (uint32_t q = ts; q < te; q++) {                                 // "lane per 16 bytes"
-                            const uint32_t s = zk_exec_origin(srcmap.data(), srcmap[q - ts], ts);
-                            tile[q - ts] = (s & ZK_SRC_LIT) ? l[(size_t)(s & ~ZK_SRC_LIT) * lit_stride]
-                                                            : bout[(int64_t)(int32_t)(s - ZK_SRC_BIAS)];
+                        for (uint32_t q0 = ts; q0 < te; q0 += ZK_EXEC_SLOT) {                // "lane per slot"
+                            const uint32_t nb = te - q0 < ZK_EXEC_SLOT ? te - q0 : ZK_EXEC_SLOT;
+                            uint32_t sw[ZK_EXEC_SLOT];
+                            zk_exec_slot_words(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, sw);
+                            for (uint32_t k = 0; k < nb; k++) srcmap[q0 - ts + k] = sw[k];
+                        }
+                        const uint32_t mbase = ZK_SRC_BIAS + ts, span = te - ts;
+                        for (uint32_t q = ts; q < te; q++) {                                 // origins + gathers
+                            uint32_t s = srcmap[q - ts];
+                            while (s - mbase < span) s = srcmap[s - mbase];
+                            tile[q - ts] = (s & ZK_SRC_LIT) ? l[(s & lit_mask)] : bout[(int64_t)(int32_t)(s - ZK_SRC_BIAS)];
                         }
                         memcpy(bout + ts, tile.data(), te - ts);                             // commit the tile after all lanes ran
-                        if (jn) prev_end = so[jn - 1];
+                        if (jn) prev_end = st[jn - 1].out_end;
                         ja += jn; ts = te;
                     }
                     if (err == ZK_OK) {

@@ -219,13 +219,15 @@ __global__ __launch_bounds__(ZK_FSEP_THREADS) void zk_k_fse_predef(const uint8_t
 // ------------------------------------------------------------------------------------------------ sequence execution
 // One workgroup (T lanes) per frame.  The output of a compressed block is produced in tiles of T x 16 B.  Per tile:
 //   1. the sequences overlapping the tile are staged in LDS (16 B records, offsets resolved, validated);
-//   2. lane-per-SEQUENCE: every staged sequence writes one 32-bit source word per output byte it covers into
-//      an LDS map (literal index, or history position); ranges longer than 48 B are filled by all lanes;
-//   3. lane-per-16-BYTES: every lane reads its 16 source words, follows in-tile sources to their origin
-//      (pointer jumps inside the LDS map), issues the 16 byte gathers back to back (literal buffer / history
-//      already in HBM-L2) and does one coalesced 16 B store;
-//   4. a workgroup barrier orders the tiles.
-constexpr int ZK_EXEC_B = 16;
+//   2. lane-per-SEQUENCE: the sequence's staged index is written to every 16-B slot whose first byte it covers
+//      (usually 0 or 1 slots; sequences that start more than ZK_EXEC_LONG slots are marked by all lanes);
+//   3. lane-per-SLOT: walk the staged sequences over the slot's 16 bytes -> 16 source words (literal index or
+//      history position) in registers, mirrored in an LDS map;
+//   4. every lane follows in-tile sources to their origin through the map (all 16 chains advance together, the
+//      LDS reads of one pass are in flight at once), issues the 16 byte gathers back to back (literal buffer /
+//      history already in HBM-L2) and does one coalesced 16 B store;
+//   5. a workgroup barrier orders the tiles.
+constexpr int ZK_EXEC_B = (int)ZK_EXEC_SLOT;
 
 template <int T>
 __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
@@ -235,8 +237,9 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                                                const uint8_t *lit_scratch, uint8_t *dst)
 {
     constexpr int CAP = 2 * T;
-    __shared__ uint4 S[CAP + 1];
-    __shared__ uint32_t srcmap[T * ZK_EXEC_B];
+    __shared__ __attribute__((aligned(16))) ZkSeq S[CAP + 1];
+    __shared__ __attribute__((aligned(16))) uint32_t srcmap[T * ZK_EXEC_B];
+    __shared__ uint32_t slot_seq[T];
     __shared__ uint32_t longlist[CAP + 1];
     __shared__ uint32_t s_jn, s_nlong;
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
         } else {
             const ZkSeq *sq = seqs + b.seq_base;
             const uint8_t *lit = b.lit_type >= 2 ? lit_scratch + b.lit_base : comp + b.src + b.lit_off;
-            const uint32_t lit_stride = b.lit_type == 1 ? 0u : 1u;
+            const uint32_t lit_mask = b.lit_type == 1 ? 0u : 0x7fffffffu;       // RLE literals: every index reads byte 0
             const uint32_t nseq = b.nseq, out_size = b.out_size;
             uint32_t ja = 0, ts = 0, prev_end = 0;           // prev_end: out_end of sequence ja - 1
             while (ts < out_size) {
@@ -281,59 +284,68 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                         if (off == 0 || pos + mstart < off || off > fi.window) bad = 1;
                         r = make_uint4(s.x, s.y, off, s.w);
                     } else r = make_uint4(out_size, 0, 1, b.lit_regen);
-                    S[i] = r;
+                    reinterpret_cast<uint4 *>(S)[i] = r;
                 }
-                if (tid == 0) { s_jn = 0; s_nlong = 0; }
+                if (tid == 0) { s_jn = nl; s_nlong = 0; }
                 if (__syncthreads_or(bad)) { err = ZK_E_CORRUPTION; break; }
-                const uint32_t cap_end = S[nl - 1].x;
+                const uint32_t cap_end = S[nl - 1].out_end;
                 const uint32_t te = ts + T * ZK_EXEC_B < cap_end ? ts + T * ZK_EXEC_B : cap_end;
-                // 2. lane per sequence: source words of the bytes it covers inside [ts, te)
-                uint32_t done = 0;
+                // 2. lane per sequence: mark the slots it starts; the first sequence that outlives the tile sets jn
                 for (uint32_t i = tid; i < nl; i += T) {
-                    const uint4 e = S[i];
-                    const uint32_t start = i ? S[i - 1].x : prev_end;
-                    const uint32_t lo = start > ts ? start : ts, hi = e.x < te ? e.x : te;
+                    const uint32_t end = S[i].out_end;
+                    const uint32_t start = i ? S[i - 1].out_end : prev_end;
+                    const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
                     if (lo < hi) {
-                        if (hi - lo > ZK_EXEC_LONG) longlist[atomicAdd(&s_nlong, 1u)] = i;
-                        else zk_exec_fill_range(srcmap, ts, lo, hi, 1, 0, e.x, e.y, e.z, e.w);
+                        uint32_t s0, n;
+                        zk_exec_slot_span(ts, lo, hi, s0, n);
+                        if (n > ZK_EXEC_LONG) longlist[atomicAdd(&s_nlong, 1u)] = i;
+                        else for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = i;
                     }
-                    if (e.x <= te) done = i + 1;
+                    if (end > te && start <= te) s_jn = i;
                 }
-                if (done) atomicMax(&s_jn, done);
                 __syncthreads();
                 const uint32_t nlong = s_nlong, jn = s_jn;
-                for (uint32_t k = 0; k < nlong; k++) {       // long ranges: all lanes
+                for (uint32_t k = 0; k < nlong; k++) {       // sequences spanning many slots: all lanes
                     const uint32_t i = longlist[k];
-                    const uint4 e = S[i];
-                    const uint32_t start = i ? S[i - 1].x : prev_end;
-                    const uint32_t lo = start > ts ? start : ts, hi = e.x < te ? e.x : te;
-                    zk_exec_fill_range(srcmap, ts, lo, hi, T, tid, e.x, e.y, e.z, e.w);
+                    const uint32_t end = S[i].out_end;
+                    const uint32_t start = i ? S[i - 1].out_end : prev_end;
+                    const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
+                    uint32_t s0, n;
+                    zk_exec_slot_span(ts, lo, hi, s0, n);
+                    for (uint32_t j = tid; j < n; j += T) slot_seq[s0 + j] = i;
                 }
                 if (nlong) __syncthreads();
-                // 3. lane per 16 output bytes: origins, gathers, one coalesced store
+                // 3. lane per slot: source words of its 16 bytes
                 const uint32_t q0 = ts + tid * ZK_EXEC_B;
-                if (q0 < te) {
-                    const uint32_t nb = te - q0 < (uint32_t)ZK_EXEC_B ? te - q0 : (uint32_t)ZK_EXEC_B;
-                    uint32_t sw[ZK_EXEC_B];
+                const uint32_t nb = q0 >= te ? 0u : te - q0 < (uint32_t)ZK_EXEC_B ? te - q0 : (uint32_t)ZK_EXEC_B;
+                uint32_t sw[ZK_EXEC_B];
+                if (nb) {
+                    zk_exec_slot_words(S, slot_seq[tid], q0, nb, sw);
 #pragma unroll
-                    for (int k = 0; k < ZK_EXEC_B; k += 4) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(&srcmap[tid * ZK_EXEC_B + k]);
-                        sw[k] = v.x; sw[k + 1] = v.y; sw[k + 2] = v.z; sw[k + 3] = v.w;
-                    }
-                    const uint8_t *addr[ZK_EXEC_B];
+                    for (int k = 0; k < ZK_EXEC_B; k += 4)
+                        *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(sw[k], sw[k + 1], sw[k + 2], sw[k + 3]);
+                }
+                __syncthreads();
+                // 4. origins (in-tile history words are exactly [BIAS + ts, BIAS + te)), gathers, one coalesced store
+                if (nb) {
+                    const uint32_t mbase = ZK_SRC_BIAS + ts, span = te - ts;
+                    bool again;
+                    do {
+                        again = false;
 #pragma unroll
-                    for (int k = 0; k < ZK_EXEC_B; k++) {
-                        const uint8_t *a = bout;               // harmless default for k >= nb
-                        if ((uint32_t)k < nb) {
-                            const uint32_t s = zk_exec_origin(srcmap, sw[k], ts);
-                            a = (s & ZK_SRC_LIT) ? lit + (size_t)(s & ~ZK_SRC_LIT) * lit_stride
-                                                 : bout + (int64_t)(int32_t)(s - ZK_SRC_BIAS);
+                        for (int k = 0; k < ZK_EXEC_B; k++) {
+                            const uint32_t d = sw[k] - mbase;
+                            if (d < span) { sw[k] = srcmap[d]; again = true; }
                         }
-                        addr[k] = a;
-                    }
+                    } while (again);
                     uint32_t ob[ZK_EXEC_B];
 #pragma unroll
-                    for (int k = 0; k < ZK_EXEC_B; k++) ob[k] = *addr[k];
+                    for (int k = 0; k < ZK_EXEC_B; k++) {
+                        const uint32_t s = sw[k];
+                        const uint8_t *a = (s & ZK_SRC_LIT) ? lit + (s & lit_mask) : bout + (int64_t)(int32_t)(s - ZK_SRC_BIAS);
+                        if ((uint32_t)k >= nb) a = bout;     // harmless address for the bytes past the tile end
+                        ob[k] = *a;
+                    }
                     uint8_t *w = bout + q0;
                     if (nb == ZK_EXEC_B && (((uintptr_t)w) & 15) == 0) {
                         uint4 v;
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                         for (int k = 0; k < ZK_EXEC_B; k++) if ((uint32_t)k < nb) w[k] = (uint8_t)ob[k];
                     }
                 }
-                if (jn) prev_end = S[jn - 1].x;
+                if (jn) prev_end = S[jn - 1].out_end;
                 __syncthreads();              // tile bytes visible to the next tile; LDS reuse
                 ja += jn; ts = te;
             }

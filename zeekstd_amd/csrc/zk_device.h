@@ -747,40 +747,56 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
 }
 
 // ---------------------------------------------------------------- sequence execution: per-byte source map
-// The executor produces a block's output in tiles.  For every output byte of the tile a 32-bit source word is
-// written to LDS by the lane that owns the byte's SEQUENCE (zk_exec_fill_seq), then the lane that owns the
-// byte's 16-B output slot follows in-tile sources to their origin (zk_exec_origin) and gathers.
+// The executor produces a block's output in tiles of 16-byte slots.  Per tile:
+//   * lane per SEQUENCE: for every slot whose first byte the sequence covers, slot_seq[slot] = staged index
+//     (zk_exec_mark_slots);
+//   * lane per SLOT: starting from slot_seq[slot] the lane walks the staged sequences over its 16 bytes and
+//     produces one 32-bit source word per byte (zk_exec_slot_words), kept in registers and mirrored in LDS;
+//   * every lane follows in-tile sources to their origin through the LDS mirror and gathers.
 //   source word: bit 31 set -> literal index (block-relative);  else block-relative history position + 2^30
 constexpr uint32_t ZK_SRC_LIT = 0x80000000u;
 constexpr uint32_t ZK_SRC_BIAS = 0x40000000u;
-constexpr uint32_t ZK_EXEC_LONG = 48;        // ranges longer than this are filled by the whole workgroup
+constexpr uint32_t ZK_EXEC_SLOT = 16;        // bytes per slot (one 16-B store per lane)
+constexpr uint32_t ZK_EXEC_LONG = 4;         // a sequence that starts more slots than this is marked by all lanes
 
-// Source word of output byte q (block-relative) of the sequence (oe, ml, off, le) that starts at `start`.
-ZK_HD uint32_t zk_exec_src(uint32_t q, uint32_t oe, uint32_t ml, uint32_t off, uint32_t le)
+// Slots (16-B aligned to the tile start ts) whose first byte lies in [lo, hi): first index and count.
+ZK_HD void zk_exec_slot_span(uint32_t ts, uint32_t lo, uint32_t hi, uint32_t &s0, uint32_t &n)
 {
-    const int32_t ms = (int32_t)(oe - ml);
-    if ((int32_t)q < ms) return ZK_SRC_LIT | (le - (uint32_t)(ms - (int32_t)q));
-    int32_t p = (int32_t)q - (int32_t)off;
-    if (p >= ms) p = ms - (int32_t)off + ((int32_t)q - ms) % (int32_t)off;          // overlapping match: periodic source
-    return (uint32_t)(p + (int32_t)ZK_SRC_BIAS);
+    s0 = (lo - ts + (ZK_EXEC_SLOT - 1)) / ZK_EXEC_SLOT;
+    const uint32_t s1 = (hi - ts + (ZK_EXEC_SLOT - 1)) / ZK_EXEC_SLOT;      // first slot starting at or after hi
+    n = s1 > s0 ? s1 - s0 : 0;
 }
 
-// Fill srcmap[q - ts] for q = lo + first, lo + first + step, ... < hi (the part of the sequence inside the tile).
-// Literal part and non-overlapping match part are affine in q (2 instructions per byte); only a match that
-// overlaps its own output (offset < match length) needs the periodic form.
-ZK_HD void zk_exec_fill_range(uint32_t *srcmap, uint32_t ts, uint32_t lo, uint32_t hi, uint32_t step, uint32_t first,
-                              uint32_t oe, uint32_t ml, uint32_t off, uint32_t le)
+// Per-sequence constants of the slot walk.
+struct ZkSlotCur { uint32_t end, ms, litw, mbase, r, off; };
+ZK_HD void zk_exec_slot_seq(const ZkSeq &e, uint32_t q, ZkSlotCur &c)
 {
-    const uint32_t ms = oe - ml;
-    const uint32_t lit_hi = hi < ms ? hi : ms;
-    const uint32_t lit_word = (ZK_SRC_LIT | le) - ms;                    // + q  (le - (ms - q) never borrows into bit 31)
-    uint32_t q = lo + first;
-    for (; q < lit_hi; q += step) srcmap[q - ts] = lit_word + q;
-    if (off >= ml) {
-        const uint32_t m_word = ZK_SRC_BIAS - off;                       // + q
-        for (; q < hi; q += step) srcmap[q - ts] = m_word + q;
-    } else {
-        for (; q < hi; q += step) srcmap[q - ts] = zk_exec_src(q, oe, ml, off, le);
+    c.end = e.out_end; c.ms = e.out_end - e.ml; c.off = e.off;
+    c.litw = (ZK_SRC_LIT | e.lit_end) - c.ms;           // + q  (lit_end - (ms - q) never borrows into bit 31)
+    c.mbase = ZK_SRC_BIAS + c.ms - e.off;               // + phase; phase wraps at off (match overlapping itself)
+    uint32_t r = q > c.ms ? q - c.ms : 0;
+    if (r >= e.off) r %= e.off;
+    c.r = r;
+}
+
+// Source words of the bytes [q0, q0 + nb) (nb <= 16) given the staged sequence i that covers q0.
+// Every sequence covers >= 3 bytes (ML base), so at most one boundary is crossed per byte.
+ZK_HD void zk_exec_slot_words(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t nb, uint32_t *sw)
+{
+    ZkSlotCur c;
+    zk_exec_slot_seq(S[i], q0, c);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) {
+        const uint32_t q = q0 + k;
+        if (k < nb) {
+            if (q >= c.end) { i++; zk_exec_slot_seq(S[i], q, c); }
+            const bool m = q >= c.ms;
+            sw[k] = m ? c.mbase + c.r : c.litw + q;
+            c.r += m ? 1u : 0u;
+            if (c.r == c.off) c.r = 0;
+        } else sw[k] = ZK_SRC_LIT;
     }
 }
 
