@@ -477,8 +477,10 @@ void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, 
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeq *seqs,
                     const uint8_t *lit, uint8_t *dst)
 {
-    // few frames: big tiles (more bytes in flight per frame); many frames: 4-wave workgroups, 8 per CU
+    // one workgroup per frame: the tile width trades bytes in flight per frame against workgroups per CU
+    // (measured on 2 MiB frames: 2048 frames -> 256 lanes, 512 -> 512, 128 -> 1024)
     if (count >= 1024) hipLaunchKernelGGL(zk_k_exec<256>, dim3(count), dim3(256), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst);
+    else if (count >= 256) hipLaunchKernelGGL(zk_k_exec<512>, dim3(count), dim3(512), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst);
     else hipLaunchKernelGGL(zk_k_exec<1024>, dim3(count), dim3(1024), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst);
 }
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
