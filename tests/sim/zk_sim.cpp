@@ -39,15 +39,17 @@ extern "C" int zk_sim_decode(const uint8_t *comp, const uint64_t *c_off, const u
     }
     // huf: one "lane" per stream
     std::vector<uint16_t> tab(2048);
-    ZkHufScratch sc;
+    ZkHufHdr hd;
+    ZkHufTmp tmp;
     for (uint64_t bi = 0; bi < nb; bi++) {
         ZkBlock &b = blocks[bi];
         if (!(b.type == 2 && b.lit_type >= 2 && b.status == ZK_OK)) continue;
         const ZkBlock &def = blocks[b.huf_def];
-        uint32_t mb = 0;
-        uint32_t r = zk_huf_build(comp + def.src + def.lit_off, def.lit_comp, tab.data(), &sc, &mb);
+        uint32_t mb = 0, nsym = 0;
+        uint32_t r = zk_huf_read_weights(comp + def.src + def.lit_off, def.lit_comp, &hd, &tmp, &nsym, &mb);
         bool ok = r != 0;
         if (ok) {
+            zk_huf_fill_table(tab.data(), &hd, nsym, mb);
             const uint8_t *pay = comp + b.src + b.lit_off;
             uint32_t size = b.lit_comp;
             if (b.lit_type == 2) { pay += r; size -= r; }

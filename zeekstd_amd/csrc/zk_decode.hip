@@ -78,13 +78,19 @@ __global__ __launch_bounds__(1024) void zk_k_scan(const ZkFrameInfo *infos, uint
 }
 
 // ------------------------------------------------------------------------------------------------ Huffman literals
-// 64 lanes = 16 blocks x 4 streams.  Per block one 2^11-entry table (u16) in LDS.
+// 64 lanes = 16 blocks x 4 streams.  The decode tables live in a 16 KiB LDS pool that is carved up by each tree's
+// depth (2^maxbits u16 cells): sixteen 9-bit tables fit at once, deeper trees take the blocks in several passes.
+// A workgroup therefore needs ~21 KiB of LDS and 7 of them share a CU; the chain per symbol
+// (shift -> LDS cell -> shift) is latency bound, so lanes in flight per CU is what sets the speed.
 constexpr int ZK_HUF_BLOCKS = 16;
+constexpr uint32_t ZK_HUF_POOL = 8192;           // u16 cells
+static_assert(ZK_HUF_POOL >= 2048, "a maximum-depth table must fit");
+static_assert(ZK_HUF_BLOCKS * sizeof(ZkHufTmp) <= ZK_HUF_POOL * sizeof(uint16_t), "parse scratch aliases the pool");
 __global__ __launch_bounds__(64) void zk_k_huf(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint8_t *lit_scratch)
 {
-    __shared__ uint16_t tab[ZK_HUF_BLOCKS][2048];
-    __shared__ ZkHufScratch sc[ZK_HUF_BLOCKS];
-    __shared__ uint32_t s_maxbits[ZK_HUF_BLOCKS], s_desc[ZK_HUF_BLOCKS];
+    __shared__ __attribute__((aligned(16))) uint16_t pool[ZK_HUF_POOL];
+    __shared__ ZkHufHdr hdr[ZK_HUF_BLOCKS];
+    __shared__ uint32_t s_maxbits[ZK_HUF_BLOCKS], s_desc[ZK_HUF_BLOCKS], s_n[ZK_HUF_BLOCKS];
     // a workgroup with fewer than 4 blocks left keeps >= 16 lanes active: the extra lanes shadow valid streams
     // (< 16 active lanes run ~3x slower on gfx950, tools/ubench/lat3.hip); shadows never store to HBM
     const uint32_t wb = blockIdx.x * ZK_HUF_BLOCKS;
@@ -99,39 +105,61 @@ __global__ __launch_bounds__(64) void zk_k_huf(const uint8_t *comp, ZkBlock *blo
         b = blocks[bi];
         active = b.type == 2 && b.lit_type >= 2 && b.status == ZK_OK;
     }
-    if (active && stream == 0) {
-        const ZkBlock &def = blocks[b.huf_def];
-        uint32_t mb = 0;
-        uint32_t r = zk_huf_build(comp + def.src + def.lit_off, def.lit_comp, tab[slot], &sc[slot], &mb);
-        s_desc[slot] = r; s_maxbits[slot] = mb;
+    if (stream == 0) {
+        uint32_t r = 0, mb = 0, n = 0;
+        if (active) {
+            const ZkBlock &def = blocks[b.huf_def];
+            r = zk_huf_read_weights(comp + def.src + def.lit_off, def.lit_comp, &hdr[slot],
+                                    reinterpret_cast<ZkHufTmp *>(pool) + slot, &n, &mb);
+        }
+        s_desc[slot] = r; s_maxbits[slot] = mb; s_n[slot] = n;
     }
     __syncthreads();
-    if (!active) return;
-    bool ok = s_desc[slot] != 0;
-    if (ok) {
-        const uint8_t *pay = comp + b.src + b.lit_off;
-        uint32_t size = b.lit_comp;
-        if (b.lit_type == 2) { pay += s_desc[slot]; size -= s_desc[slot]; }      // own tree description precedes the streams
-        uint8_t *dst = lit_scratch + b.lit_base;
-        const uint32_t mb = s_maxbits[slot], regen = b.lit_regen;
-        if (b.lit_streams == 1) {
-            if (stream == 0) ok = zk_huf_decode_stream(tab[slot], mb, pay, size, dst, regen, real);
-        } else if (size < 6) {
-            ok = false;
-        } else {
-            uint32_t s1 = zk_rd16(pay), s2 = zk_rd16(pay + 2), s3 = zk_rd16(pay + 4);
-            uint32_t q = (regen + 3) / 4;
-            if (6 + s1 + s2 + s3 > size || 3 * q > regen) ok = false;
-            else {
-                uint32_t s4 = size - 6 - s1 - s2 - s3;
-                uint32_t start = 6 + (stream > 0 ? s1 : 0) + (stream > 1 ? s2 : 0) + (stream > 2 ? s3 : 0);
-                uint32_t len = stream == 0 ? s1 : stream == 1 ? s2 : stream == 2 ? s3 : s4;
-                uint32_t n = stream == 3 ? regen - 3 * q : q;
-                ok = zk_huf_decode_stream(tab[slot], mb, pay + start, len, dst + stream * q, n, real);
+    // pool layout: blocks in slot order, a new pass whenever the next table does not fit
+    uint32_t my_pass = 0, my_at = 0, npass;
+    {
+        uint32_t pass = 0, acc = 0;
+        for (uint32_t j = 0; j < (uint32_t)ZK_HUF_BLOCKS; j++) {
+            const uint32_t sz = s_desc[j] ? 1u << s_maxbits[j] : 0u;
+            if (acc + sz > ZK_HUF_POOL) { pass++; acc = 0; }
+            if (j == slot) { my_pass = pass; my_at = acc; }
+            acc += sz;
+        }
+        npass = pass + 1;
+    }
+    const uint32_t desc = s_desc[slot], mb = s_maxbits[slot];
+    bool ok = desc != 0;
+    uint16_t *tab = pool + my_at;
+    for (uint32_t p = 0; p < npass; p++) {
+        const bool mine = active && ok && my_pass == p;
+        if (mine && stream == 0) zk_huf_fill_table(tab, &hdr[slot], s_n[slot], mb);
+        __syncthreads();
+        if (mine) {
+            const uint8_t *pay = comp + b.src + b.lit_off;
+            uint32_t size = b.lit_comp;
+            if (b.lit_type == 2) { pay += desc; size -= desc; }      // own tree description precedes the streams
+            uint8_t *dst = lit_scratch + b.lit_base;
+            const uint32_t regen = b.lit_regen;
+            if (b.lit_streams == 1) {
+                if (stream == 0) ok = zk_huf_decode_stream(tab, mb, pay, size, dst, regen, real);
+            } else if (size < 6) {
+                ok = false;
+            } else {
+                uint32_t s1 = zk_rd16(pay), s2 = zk_rd16(pay + 2), s3 = zk_rd16(pay + 4);
+                uint32_t q = (regen + 3) / 4;
+                if (6 + s1 + s2 + s3 > size || 3 * q > regen) ok = false;
+                else {
+                    uint32_t s4 = size - 6 - s1 - s2 - s3;
+                    uint32_t start = 6 + (stream > 0 ? s1 : 0) + (stream > 1 ? s2 : 0) + (stream > 2 ? s3 : 0);
+                    uint32_t len = stream == 0 ? s1 : stream == 1 ? s2 : stream == 2 ? s3 : s4;
+                    uint32_t n = stream == 3 ? regen - 3 * q : q;
+                    ok = zk_huf_decode_stream(tab, mb, pay + start, len, dst + stream * q, n, real);
+                }
             }
         }
+        __syncthreads();
     }
-    if (!ok && real) blocks[bi].status = ZK_E_CORRUPTION;
+    if (active && !ok && real) blocks[bi].status = ZK_E_CORRUPTION;
 }
 
 // ------------------------------------------------------------------------------------------------ FSE sequences

@@ -275,22 +275,27 @@ ZK_HD bool zk_fse_build(uint32_t *cells, const int16_t *norm, uint32_t nsym, uin
 }
 
 // ---------------------------------------------------------------- Huffman (A.4)
-// table cell: sym | nbits << 8 (u16).  Scratch: weights[256] u8, rank[16] u32, fse cells[64] u32, norm[16], next[16].
-struct ZkHufScratch {
+// table cell: sym | nbits << 8 (u16).  A block's table is built in two steps so that the kernel can size the
+// LDS it needs from the tree's depth: zk_huf_read_weights (tree description -> weights + table layout), then
+// zk_huf_fill_table.
+struct ZkHufHdr {                    // survives until the table is filled
     uint8_t weights[256];
-    uint32_t rank[16];
+    uint32_t rank[16];               // first table index per weight
+};
+struct ZkHufTmp {                    // only while FSE-compressed weights are being read
     uint32_t fse[64];
     int16_t norm[16];
     uint16_t next[16];
 };
 
-// Parses the tree description at src (len = bytes available) and fills table[1 << maxbits].
-// Returns description size in bytes (0 on corruption); *maxbits_out receives the table log.
-ZK_HD uint32_t zk_huf_build(const uint8_t *src, uint32_t len, uint16_t *table, ZkHufScratch *sc, uint32_t *maxbits_out)
+// Parses the tree description at src (len = bytes available).  Returns the description size in bytes (0 on
+// corruption); *n_out = number of symbols with a weight entry (implied last one included), *maxbits_out = table log.
+ZK_HD uint32_t zk_huf_read_weights(const uint8_t *src, uint32_t len, ZkHufHdr *hd, ZkHufTmp *tmp, uint32_t *n_out,
+                                   uint32_t *maxbits_out)
 {
     if (len < 1) return 0;
     uint32_t h = src[0], n = 0, used;
-    uint8_t *w = sc->weights;
+    uint8_t *w = hd->weights;
     if (h >= 128) {
         n = h - 127;
         used = 1 + (n + 1) / 2;
@@ -300,50 +305,86 @@ ZK_HD uint32_t zk_huf_build(const uint8_t *src, uint32_t len, uint16_t *table, Z
         used = 1 + h;
         if (used > len || h < 2) return 0;
         uint32_t nsym, al;
-        uint32_t r = zk_fse_read_ncount(src + 1, h, 11, 6, sc->norm, &nsym, &al);
+        uint32_t r = zk_fse_read_ncount(src + 1, h, 11, 6, tmp->norm, &nsym, &al);
         if (r == 0 || r >= h) return 0;
-        if (!zk_fse_build(sc->fse, sc->norm, nsym, al, sc->next, nullptr)) return 0;
+        if (!zk_fse_build(tmp->fse, tmp->norm, nsym, al, tmp->next, nullptr)) return 0;
         ZkBwd b;
         if (!zk_bwd_init(b, src + 1 + r, h - r)) return 0;
         uint32_t s1 = zk_bwd_read(b, al), s2 = zk_bwd_read(b, al);
         for (;;) {                                        // two interleaved states, stop on over-read
             if (n >= 254) return 0;
             zk_bwd_refill(b);
-            uint32_t c1 = sc->fse[s1];
+            uint32_t c1 = tmp->fse[s1];
             w[n++] = (uint8_t)zk_cell_sym(c1);
-            if (b.bits_left < (int32_t)zk_cell_nb(c1)) { w[n++] = (uint8_t)zk_cell_sym(sc->fse[s2]); break; }
+            if (b.bits_left < (int32_t)zk_cell_nb(c1)) { w[n++] = (uint8_t)zk_cell_sym(tmp->fse[s2]); break; }
             s1 = zk_cell_base(c1) + zk_bwd_read(b, zk_cell_nb(c1));
             if (n >= 254) return 0;
-            uint32_t c2 = sc->fse[s2];
+            uint32_t c2 = tmp->fse[s2];
             w[n++] = (uint8_t)zk_cell_sym(c2);
-            if (b.bits_left < (int32_t)zk_cell_nb(c2)) { w[n++] = (uint8_t)zk_cell_sym(sc->fse[s1]); break; }
+            if (b.bits_left < (int32_t)zk_cell_nb(c2)) { w[n++] = (uint8_t)zk_cell_sym(tmp->fse[s1]); break; }
             s2 = zk_cell_base(c2) + zk_bwd_read(b, zk_cell_nb(c2));
         }
     }
     uint32_t sum = 0;
-    for (uint32_t i = 0; i < 13; i++) sc->rank[i] = 0;
-    for (uint32_t i = 0; i < n; i++) { uint32_t x = w[i]; if (x > 11) return 0; if (x) sum += 1u << (x - 1); sc->rank[x]++; }
+    for (uint32_t i = 0; i < 13; i++) hd->rank[i] = 0;
+    for (uint32_t i = 0; i < n; i++) { uint32_t x = w[i]; if (x > 11) return 0; if (x) sum += 1u << (x - 1); hd->rank[x]++; }
     if (sum == 0) return 0;
     uint32_t maxbits = zk_highbit(sum) + 1;
     if (maxbits > 11) return 0;
     uint32_t rest = (1u << maxbits) - sum;
     if (rest & (rest - 1)) return 0;
     uint32_t lastw = zk_highbit(rest) + 1;
-    w[n++] = (uint8_t)lastw; sc->rank[lastw]++;
+    w[n++] = (uint8_t)lastw; hd->rank[lastw]++;
     // rank[wt] -> first table index of weight wt (weight 1 first)
     uint32_t pos = 0;
-    for (uint32_t wt = 1; wt <= maxbits; wt++) { uint32_t c = sc->rank[wt]; sc->rank[wt] = pos; pos += c << (wt - 1); }
+    for (uint32_t wt = 1; wt <= maxbits; wt++) { uint32_t c = hd->rank[wt]; hd->rank[wt] = pos; pos += c << (wt - 1); }
     if (pos != (1u << maxbits)) return 0;
+    *n_out = n; *maxbits_out = maxbits;
+    return used;
+}
+
+// Fills table[1 << maxbits] from the weights (consumes hd->rank).
+ZK_HD void zk_huf_fill_table(uint16_t *table, ZkHufHdr *hd, uint32_t n, uint32_t maxbits)
+{
     for (uint32_t s = 0; s < n; s++) {
-        uint32_t wt = w[s];
+        uint32_t wt = hd->weights[s];
         if (!wt) continue;
-        uint32_t cnt = 1u << (wt - 1), at = sc->rank[wt];
+        uint32_t cnt = 1u << (wt - 1), at = hd->rank[wt];
         uint16_t cell = (uint16_t)(s | ((maxbits + 1 - wt) << 8));
         for (uint32_t k = 0; k < cnt; k++) table[at + k] = cell;
-        sc->rank[wt] = at + cnt;
+        hd->rank[wt] = at + cnt;
     }
-    *maxbits_out = maxbits;
-    return used;
+}
+
+// Stream word k (64 bits, little endian) of a backward bitstream: bytes [o, o + 8) with o = len - 8 (k + 1); bytes
+// below the stream start read as zero.  Branch-free (one unconditional 8-byte load from base + max(o, 0), so up to
+// 8 bytes past a stream shorter than 8 bytes are touched: ZK_COMP_PADDING covers the last stream of a buffer).
+ZK_HD uint64_t zk_ldword_bf(const uint8_t *base, int32_t o)
+{
+    const int32_t oo = o < 0 ? 0 : o;
+    uint64_t v;
+    memcpy(&v, base + oo, 8);
+    const uint32_t sh = o < 0 ? (uint32_t)(-o) * 8u : 0u;
+    return sh >= 64 ? 0 : v << sh;
+}
+
+// Huffman stream reader: three stream words in registers (A current, B, C) plus one load in flight (P), so that no
+// load's latency sits on the decode chain; `c` = bits of A already consumed.  All updates are selects: the loop
+// body is straight-line code and the compiler can leave the load pending until the next refill.
+struct ZkHufRd {
+    const uint8_t *base;
+    uint64_t A, B, C, P;
+    int32_t next_off;                // byte offset of the word after P
+    uint32_t c, words;               // words: stream words fully consumed
+};
+ZK_HD uint64_t zk_hufrd_refill(ZkHufRd &r)
+{
+    const bool adv = r.c >= 64;
+    r.A = adv ? r.B : r.A; r.B = adv ? r.C : r.B; r.C = adv ? r.P : r.C;
+    r.c -= adv ? 64u : 0u; r.words += adv ? 1u : 0u;
+    r.next_off -= adv ? 8 : 0;
+    r.P = zk_ldword_bf(r.base, r.next_off + 8);
+    return (r.A << r.c) | ((r.B >> 1) >> (63 - r.c));
 }
 
 // Decode n symbols of one Huffman stream into dst.  Returns false on corruption.
@@ -351,37 +392,54 @@ ZK_HD uint32_t zk_huf_build(const uint8_t *src, uint32_t len, uint16_t *table, Z
 ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const uint8_t *src, uint32_t len,
                                 uint8_t *dst, uint32_t n, bool store = true)
 {
-    ZkBwd b;
-    if (!zk_bwd_init(b, src, len)) return false;
+    if (len == 0) return false;
+    const uint32_t last = src[len - 1];
+    if (last == 0) return false;
+    ZkHufRd r;
+    r.base = src;
+    r.A = zk_ldword_bf(src, (int32_t)len - 8);
+    r.B = zk_ldword_bf(src, (int32_t)len - 16);
+    r.C = zk_ldword_bf(src, (int32_t)len - 24);
+    r.P = zk_ldword_bf(src, (int32_t)len - 32);
+    r.next_off = (int32_t)len - 40;
+    r.c = 8 - zk_highbit(last);                          // zero padding + the sentinel bit
+    r.words = 0;
+    const uint32_t sh = 64 - maxbits;
     uint32_t i = 0;
     while (i + 8 <= n) {
         uint64_t pack = 0;
-        zk_bwd_refill(b);
+        uint64_t cur = zk_hufrd_refill(r);
+        uint32_t used = 0;
         for (uint32_t k = 0; k < 4; k++) {
-            uint32_t c = table[zk_bwd_peek(b, maxbits)];
+            const uint32_t c = table[cur >> sh];
             pack |= (uint64_t)(c & 0xff) << (8 * k);
-            zk_bwd_skip(b, c >> 8);
+            cur <<= c >> 8; used += c >> 8;
         }
-        zk_bwd_refill(b);
+        r.c += used;
+        cur = zk_hufrd_refill(r);
+        used = 0;
         for (uint32_t k = 4; k < 8; k++) {
-            uint32_t c = table[zk_bwd_peek(b, maxbits)];
+            const uint32_t c = table[cur >> sh];
             pack |= (uint64_t)(c & 0xff) << (8 * k);
-            zk_bwd_skip(b, c >> 8);
+            cur <<= c >> 8; used += c >> 8;
         }
+        r.c += used;
         if (store) memcpy(dst + i, &pack, 8);
         i += 8;
     }
     while (i < n) {
-        zk_bwd_refill(b);
-        uint32_t lim = n - i < 4 ? n - i : 4;
+        uint64_t cur = zk_hufrd_refill(r);
+        const uint32_t lim = n - i < 4 ? n - i : 4;
+        uint32_t used = 0;
         for (uint32_t k = 0; k < lim; k++) {
-            uint32_t c = table[zk_bwd_peek(b, maxbits)];
+            const uint32_t c = table[cur >> sh];
             if (store) dst[i + k] = (uint8_t)c;
-            zk_bwd_skip(b, c >> 8);
+            cur <<= c >> 8; used += c >> 8;
         }
+        r.c += used;
         i += lim;
     }
-    return b.bits_left == 0;
+    return (uint64_t)r.words * 64 + r.c == (uint64_t)len * 8;
 }
 
 // ---------------------------------------------------------------- header parsing
