@@ -84,19 +84,46 @@ __global__ __launch_bounds__(1024) void zk_k_scan(const ZkFrameInfo *infos, uint
 // (shift -> LDS cell -> shift) is latency bound, so lanes in flight per CU is what sets the speed.
 constexpr int ZK_HUF_BLOCKS = 16;
 constexpr uint32_t ZK_HUF_POOL = 8192;           // u16 cells
+constexpr int32_t ZK_HUF_AHEAD = 192;            // bytes the companion wave stays ahead of a stream's read position
 static_assert(ZK_HUF_POOL >= 2048, "a maximum-depth table must fit");
 static_assert(ZK_HUF_BLOCKS * sizeof(ZkHufTmp) <= ZK_HUF_POOL * sizeof(uint16_t), "parse scratch aliases the pool");
-__global__ __launch_bounds__(64) void zk_k_huf(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint8_t *lit_scratch)
+
+// Companion of one decoding lane: touches the 128-B lines of the lane's (backward read) stream ZK_HUF_AHEAD bytes
+// before the decoder gets there, so that the decoder's in-order load queue only ever sees L2 hits.  Every wave of
+// 64 streams crosses ~6 new lines per 8 symbols; without this each crossing stalls the whole wave for an HBM miss.
+__device__ void zk_huf_touch_ahead(const uint8_t *base, uint32_t len, const volatile int32_t *progress,
+                                   const volatile uint32_t *done)
+{
+    const uintptr_t lo = (uintptr_t)base;
+    uintptr_t line = ((uintptr_t)base + len) & ~(uintptr_t)127;      // lowest line touched so far (the decoder's init loads cover it)
+    uint32_t sink = 0;
+    while (!*done) {
+        const int32_t want = *progress - ZK_HUF_AHEAD;
+        const uintptr_t wp = (lo + (uintptr_t)(want < 0 ? 0 : want)) & ~(uintptr_t)127;
+        if (line > wp && line > lo) {
+            line -= 128;
+            sink += *reinterpret_cast<const volatile uint8_t *>(line < lo ? lo : line);
+        } else __builtin_amdgcn_s_sleep(8);
+    }
+    asm volatile("" :: "v"(sink));
+}
+
+__global__ __launch_bounds__(128) void zk_k_huf(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint8_t *lit_scratch)
 {
     __shared__ __attribute__((aligned(16))) uint16_t pool[ZK_HUF_POOL];
     __shared__ ZkHufHdr hdr[ZK_HUF_BLOCKS];
     __shared__ uint32_t s_maxbits[ZK_HUF_BLOCKS], s_desc[ZK_HUF_BLOCKS], s_n[ZK_HUF_BLOCKS];
-    // a workgroup with fewer than 4 blocks left keeps >= 16 lanes active: the extra lanes shadow valid streams
+    __shared__ int32_t s_progress[64];
+    __shared__ uint32_t s_done;
+    // wave 0 decodes (lane = block slot x 4 streams), wave 1 mirrors it lane for lane and touches cache lines ahead.
+    // A workgroup with fewer than 4 blocks left keeps >= 16 lanes active: the extra lanes shadow valid streams
     // (< 16 active lanes run ~3x slower on gfx950, tools/ubench/lat3.hip); shadows never store to HBM
+    const uint32_t t = threadIdx.x & 63;
+    const bool decoder = threadIdx.x < 64;
     const uint32_t wb = blockIdx.x * ZK_HUF_BLOCKS;
     const uint32_t nvalid = nblocks - wb < (uint32_t)ZK_HUF_BLOCKS ? nblocks - wb : (uint32_t)ZK_HUF_BLOCKS;
-    const bool real = threadIdx.x < 4 * nvalid;
-    const uint32_t lane = real ? threadIdx.x : (threadIdx.x < 16 ? threadIdx.x % (4 * nvalid) : threadIdx.x);
+    const bool real = t < 4 * nvalid;
+    const uint32_t lane = real ? t : (t < 16 ? t % (4 * nvalid) : t);
     const uint32_t slot = lane >> 2, stream = lane & 3;
     const uint32_t bi = wb + slot;
     bool active = false;
@@ -105,7 +132,7 @@ __global__ __launch_bounds__(64) void zk_k_huf(const uint8_t *comp, ZkBlock *blo
         b = blocks[bi];
         active = b.type == 2 && b.lit_type >= 2 && b.status == ZK_OK;
     }
-    if (stream == 0) {
+    if (decoder && stream == 0) {
         uint32_t r = 0, mb = 0, n = 0;
         if (active) {
             const ZkBlock &def = blocks[b.huf_def];
@@ -132,8 +159,12 @@ __global__ __launch_bounds__(64) void zk_k_huf(const uint8_t *comp, ZkBlock *blo
     uint16_t *tab = pool + my_at;
     for (uint32_t p = 0; p < npass; p++) {
         const bool mine = active && ok && my_pass == p;
-        if (mine && stream == 0) zk_huf_fill_table(tab, &hdr[slot], s_n[slot], mb);
-        __syncthreads();
+        if (decoder && mine && stream == 0) zk_huf_fill_table(tab, &hdr[slot], s_n[slot], mb);
+        // this lane's stream
+        const uint8_t *sbase = nullptr;
+        uint8_t *sdst = nullptr;
+        uint32_t slen = 0, sn = 0;
+        bool have = false;
         if (mine) {
             const uint8_t *pay = comp + b.src + b.lit_off;
             uint32_t size = b.lit_comp;
@@ -141,7 +172,7 @@ __global__ __launch_bounds__(64) void zk_k_huf(const uint8_t *comp, ZkBlock *blo
             uint8_t *dst = lit_scratch + b.lit_base;
             const uint32_t regen = b.lit_regen;
             if (b.lit_streams == 1) {
-                if (stream == 0) ok = zk_huf_decode_stream(tab, mb, pay, size, dst, regen, real);
+                if (stream == 0) { sbase = pay; slen = size; sdst = dst; sn = regen; have = true; }
             } else if (size < 6) {
                 ok = false;
             } else {
@@ -151,15 +182,24 @@ __global__ __launch_bounds__(64) void zk_k_huf(const uint8_t *comp, ZkBlock *blo
                 else {
                     uint32_t s4 = size - 6 - s1 - s2 - s3;
                     uint32_t start = 6 + (stream > 0 ? s1 : 0) + (stream > 1 ? s2 : 0) + (stream > 2 ? s3 : 0);
-                    uint32_t len = stream == 0 ? s1 : stream == 1 ? s2 : stream == 2 ? s3 : s4;
-                    uint32_t n = stream == 3 ? regen - 3 * q : q;
-                    ok = zk_huf_decode_stream(tab, mb, pay + start, len, dst + stream * q, n, real);
+                    slen = stream == 0 ? s1 : stream == 1 ? s2 : stream == 2 ? s3 : s4;
+                    sn = stream == 3 ? regen - 3 * q : q;
+                    sbase = pay + start; sdst = dst + stream * q; have = true;
                 }
             }
         }
+        if (decoder) s_progress[t] = (int32_t)slen - 40;
+        if (threadIdx.x == 0) s_done = 0;
+        __syncthreads();
+        if (decoder) {
+            if (have) ok = zk_huf_decode_stream(tab, mb, sbase, slen, sdst, sn, real, &s_progress[t]);
+            *(volatile uint32_t *)&s_done = 1;
+        } else if (have && slen > 256) {
+            zk_huf_touch_ahead(sbase, slen, &s_progress[t], &s_done);
+        }
         __syncthreads();
     }
-    if (active && !ok && real) blocks[bi].status = ZK_E_CORRUPTION;
+    if (decoder && active && !ok && real) blocks[bi].status = ZK_E_CORRUPTION;
 }
 
 // ------------------------------------------------------------------------------------------------ FSE sequences
@@ -493,7 +533,7 @@ void zk_launch_scan(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, Zk
 void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint8_t *lit)
 {
     if (!nblocks) return;
-    hipLaunchKernelGGL(zk_k_huf, dim3((nblocks + ZK_HUF_BLOCKS - 1) / ZK_HUF_BLOCKS), dim3(64), 0, st, comp, blocks, nblocks, lit);
+    hipLaunchKernelGGL(zk_k_huf, dim3((nblocks + ZK_HUF_BLOCKS - 1) / ZK_HUF_BLOCKS), dim3(128), 0, st, comp, blocks, nblocks, lit);
 }
 void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
 {

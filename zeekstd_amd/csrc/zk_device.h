@@ -389,8 +389,10 @@ ZK_HD uint64_t zk_hufrd_refill(ZkHufRd &r)
 
 // Decode n symbols of one Huffman stream into dst.  Returns false on corruption.
 // Eight symbols are packed into one 64-bit store (two refills of <= 4 x 11 bits).
+// `progress` (optional, LDS): the byte offset of the next stream word to load is published once per 8 symbols so
+// that a companion wave can touch the cache lines ahead of it.
 ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const uint8_t *src, uint32_t len,
-                                uint8_t *dst, uint32_t n, bool store = true)
+                                uint8_t *dst, uint32_t n, bool store = true, volatile int32_t *progress = nullptr)
 {
     if (len == 0) return false;
     const uint32_t last = src[len - 1];
@@ -425,6 +427,7 @@ ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const u
         }
         r.c += used;
         if (store) memcpy(dst + i, &pack, 8);
+        if (progress) *progress = r.next_off;
         i += 8;
     }
     while (i < n) {
