@@ -88,23 +88,43 @@ constexpr int32_t ZK_HUF_AHEAD = 192;            // bytes the companion wave sta
 static_assert(ZK_HUF_POOL >= 2048, "a maximum-depth table must fit");
 static_assert(ZK_HUF_BLOCKS * sizeof(ZkHufTmp) <= ZK_HUF_POOL * sizeof(uint16_t), "parse scratch aliases the pool");
 
-// Companion of one decoding lane: touches the 128-B lines of the lane's (backward read) stream ZK_HUF_AHEAD bytes
-// before the decoder gets there, so that the decoder's in-order load queue only ever sees L2 hits.  Every wave of
-// 64 streams crosses ~6 new lines per 8 symbols; without this each crossing stalls the whole wave for an HBM miss.
-__device__ void zk_huf_touch_ahead(const uint8_t *base, uint32_t len, const volatile int32_t *progress,
-                                   const volatile uint32_t *done)
+// Companion of one decoding lane (ZkHufMail): stores the lane's packs to HBM and touches the 128-B lines of the
+// lane's (backward read) stream ZK_HUF_AHEAD bytes before the decoder gets there, so that the decoder's in-order
+// load queue only ever sees L2 hits.  Every wave of 64 streams crosses ~6 new lines per 8 symbols; without this
+// each crossing stalls the whole wave for an HBM miss.  The touches are fire-and-forget loads (inline asm into a
+// register nobody reads), so this wave never waits on memory and keeps up with 64 decoders.
+__device__ void zk_huf_companion(const uint8_t *base, uint32_t len, uint8_t *dst, volatile ZkHufMail *mail, uint32_t l,
+                                 const volatile uint32_t *done)
 {
     const uintptr_t lo = (uintptr_t)base;
     uintptr_t line = ((uintptr_t)base + len) & ~(uintptr_t)127;      // lowest line touched so far (the decoder's init loads cover it)
-    uint32_t sink = 0;
-    while (!*done) {
-        const int32_t want = *progress - ZK_HUF_AHEAD;
+    uint32_t stored = 0, sink = 0;
+    for (;;) {
+        const uint32_t fin = *done;                                  // read BEFORE the state: a pack published before `done` is seen
+        const uint32_t st = mail->state[l];
+        const uint32_t written = st & 0x3fffu;
+        bool idle = true;
+        if (((written - stored) & 0x3fffu) != 0) {
+            const uint64_t pack = mail->pack[stored & 1][l];
+            memcpy(dst + (size_t)stored * 8, &pack, 8);
+            stored++;
+            mail->consumed[l] = stored;
+            idle = false;
+        }
+        const int32_t want = (int32_t)(st >> 14) - 64 - ZK_HUF_AHEAD;
         const uintptr_t wp = (lo + (uintptr_t)(want < 0 ? 0 : want)) & ~(uintptr_t)127;
         if (line > wp && line > lo) {
             line -= 128;
-            sink += *reinterpret_cast<const volatile uint8_t *>(line < lo ? lo : line);
-        } else __builtin_amdgcn_s_sleep(8);
+            const uint8_t *a = reinterpret_cast<const uint8_t *>(line < lo ? lo : line);
+            asm volatile("global_load_ubyte %0, %1, off" : "+v"(sink) : "v"(a) : "memory");
+            idle = false;
+        }
+        if (idle) {
+            if (fin) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" :: "v"(sink));
 }
 
@@ -113,7 +133,7 @@ __global__ __launch_bounds__(128) void zk_k_huf(const uint8_t *comp, ZkBlock *bl
     __shared__ __attribute__((aligned(16))) uint16_t pool[ZK_HUF_POOL];
     __shared__ ZkHufHdr hdr[ZK_HUF_BLOCKS];
     __shared__ uint32_t s_maxbits[ZK_HUF_BLOCKS], s_desc[ZK_HUF_BLOCKS], s_n[ZK_HUF_BLOCKS];
-    __shared__ int32_t s_progress[64];
+    __shared__ ZkHufMail mail;
     __shared__ uint32_t s_done;
     // wave 0 decodes (lane = block slot x 4 streams), wave 1 mirrors it lane for lane and touches cache lines ahead.
     // A workgroup with fewer than 4 blocks left keeps >= 16 lanes active: the extra lanes shadow valid streams
@@ -188,14 +208,14 @@ __global__ __launch_bounds__(128) void zk_k_huf(const uint8_t *comp, ZkBlock *bl
                 }
             }
         }
-        if (decoder) s_progress[t] = (int32_t)slen - 40;
+        if (decoder) { mail.state[t] = zk_huf_mail_state(0, (int32_t)slen - 40); mail.consumed[t] = 0; }
         if (threadIdx.x == 0) s_done = 0;
         __syncthreads();
         if (decoder) {
-            if (have) ok = zk_huf_decode_stream(tab, mb, sbase, slen, sdst, sn, real, &s_progress[t]);
+            if (have) ok = zk_huf_decode_stream(tab, mb, sbase, slen, sdst, sn, real, &mail, t);
             *(volatile uint32_t *)&s_done = 1;
-        } else if (have && slen > 256) {
-            zk_huf_touch_ahead(sbase, slen, &s_progress[t], &s_done);
+        } else if (have && real) {
+            zk_huf_companion(sbase, slen, sdst, &mail, t, &s_done);
         }
         __syncthreads();
     }

@@ -280,7 +280,7 @@ ZK_HD bool zk_fse_build(uint32_t *cells, const int16_t *norm, uint32_t nsym, uin
 // zk_huf_fill_table.
 struct ZkHufHdr {                    // survives until the table is filled
     uint8_t weights[256];
-    uint32_t rank[16];               // first table index per weight
+    uint16_t rank[16];               // first table index per weight
 };
 struct ZkHufTmp {                    // only while FSE-compressed weights are being read
     uint32_t fse[64];
@@ -337,7 +337,7 @@ ZK_HD uint32_t zk_huf_read_weights(const uint8_t *src, uint32_t len, ZkHufHdr *h
     w[n++] = (uint8_t)lastw; hd->rank[lastw]++;
     // rank[wt] -> first table index of weight wt (weight 1 first)
     uint32_t pos = 0;
-    for (uint32_t wt = 1; wt <= maxbits; wt++) { uint32_t c = hd->rank[wt]; hd->rank[wt] = pos; pos += c << (wt - 1); }
+    for (uint32_t wt = 1; wt <= maxbits; wt++) { uint32_t c = hd->rank[wt]; hd->rank[wt] = (uint16_t)pos; pos += c << (wt - 1); }
     if (pos != (1u << maxbits)) return 0;
     *n_out = n; *maxbits_out = maxbits;
     return used;
@@ -352,7 +352,7 @@ ZK_HD void zk_huf_fill_table(uint16_t *table, ZkHufHdr *hd, uint32_t n, uint32_t
         uint32_t cnt = 1u << (wt - 1), at = hd->rank[wt];
         uint16_t cell = (uint16_t)(s | ((maxbits + 1 - wt) << 8));
         for (uint32_t k = 0; k < cnt; k++) table[at + k] = cell;
-        hd->rank[wt] = at + cnt;
+        hd->rank[wt] = (uint16_t)(at + cnt);
     }
 }
 
@@ -389,10 +389,24 @@ ZK_HD uint64_t zk_hufrd_refill(ZkHufRd &r)
 
 // Decode n symbols of one Huffman stream into dst.  Returns false on corruption.
 // Eight symbols are packed into one 64-bit store (two refills of <= 4 x 11 bits).
-// `progress` (optional, LDS): the byte offset of the next stream word to load is published once per 8 symbols so
-// that a companion wave can touch the cache lines ahead of it.
+// Hand-over between a decoding lane and its companion lane (LDS, one per workgroup; nullptr on the host).  The
+// decoder never issues a global store itself: it drops every 8-symbol pack into a 2-deep ring and publishes
+// (packs written, stream position); the companion wave stores the packs to HBM and touches the stream's cache
+// lines ahead.  gfx9 counts loads and stores in ONE in-order counter (vmcnt), so a store in the decode loop makes
+// every wait for a stream word also wait for the store's write acknowledgement.
+struct ZkHufMail {
+    uint64_t pack[2][64];
+    uint32_t state[64];              // packs written [13:0] | (next stream offset + 64) << 14
+    uint32_t consumed[64];           // packs stored by the companion
+};
+ZK_HD uint32_t zk_huf_mail_state(uint32_t written, int32_t next_off)
+{
+    const int32_t o = next_off + 64;
+    return (written & 0x3fffu) | ((uint32_t)(o < 0 ? 0 : o) << 14);
+}
+
 ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const uint8_t *src, uint32_t len,
-                                uint8_t *dst, uint32_t n, bool store = true, volatile int32_t *progress = nullptr)
+                                uint8_t *dst, uint32_t n, bool store = true, volatile ZkHufMail *mail = nullptr, uint32_t mlane = 0)
 {
     if (len == 0) return false;
     const uint32_t last = src[len - 1];
@@ -426,8 +440,14 @@ ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const u
             cur <<= c >> 8; used += c >> 8;
         }
         r.c += used;
-        if (store) memcpy(dst + i, &pack, 8);
-        if (progress) *progress = r.next_off;
+        if (mail) {
+            if (store) {
+                const uint32_t it = i >> 3;
+                while (((it - mail->consumed[mlane]) & 0x3fffu) >= 2) {}     // ring full: the companion is behind
+                mail->pack[it & 1][mlane] = pack;
+                mail->state[mlane] = zk_huf_mail_state(it + 1, r.next_off);
+            }
+        } else if (store) memcpy(dst + i, &pack, 8);
         i += 8;
     }
     while (i < n) {
