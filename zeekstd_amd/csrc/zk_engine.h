@@ -13,6 +13,8 @@ struct zk_devbuf { void *p = nullptr; size_t cap = 0; };
 struct zk_engine {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;              // second queue: kernels with no mutual dependency overlap (huf || fse)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     char devname[320] = {0};
     std::string last_err;
     uint64_t *h_words = nullptr;            // pinned: small read-backs (totals, first error)

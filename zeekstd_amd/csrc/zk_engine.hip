@@ -113,6 +113,9 @@ extern "C" int zk_engine_create(int device, zk_engine **out)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete e; return ZK_ERR_NO_DEVICE; }   // kernels are built for gfx950 only
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return ZK_ERR_NO_DEVICE; }
     if (hipHostMalloc((void **)&e->h_words, 16 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return ZK_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { zk_engine_destroy(e); return ZK_ERR_HIP; }
     *out = e;
     return 0;
 }
@@ -127,6 +130,9 @@ extern "C" void zk_engine_destroy(zk_engine *e)
     for (zk_devbuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (e->h_words) (void)hipHostFree(e->h_words);
     for (int k = 0; k < ZK_NKERNELS; k++) { if (e->ev_start[k]) (void)hipEventDestroy(e->ev_start[k]); if (e->ev_stop[k]) (void)hipEventDestroy(e->ev_stop[k]); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -170,8 +176,19 @@ static int zk_decode_impl(zk_engine *e, const void *d_comp, const void *d_c_off,
     e->h_words[3] = ~0ull;
     ZK_HIP(hipMemcpyAsync(words + 3, e->h_words + 3, sizeof(uint64_t), hipMemcpyHostToDevice, st));
     { zk_kernel_timer t(e, ZK_K_WALK_FILL, st); zk_launch_walk(st, comp, c_off, d_off, first, count, ids, bases, blocks, infos); }
-    { zk_kernel_timer t(e, ZK_K_HUF, st); zk_launch_huf(st, comp, blocks, (uint32_t)nblocks, lit); }
-    { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, seqs); }
+    // literals (huf) and sequences (fse) of a block are independent: the two kernels run side by side on two queues
+    // (latency-bound kernels with different bottlenecks); with per-kernel timing on they are serialised instead
+    if (e->profiling) {
+        { zk_kernel_timer t(e, ZK_K_HUF, st); zk_launch_huf(st, comp, blocks, (uint32_t)nblocks, lit); }
+        { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, seqs); }
+    } else {
+        ZK_HIP(hipEventRecord(e->ev_fork, st));
+        ZK_HIP(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+        zk_launch_huf(e->aux, comp, blocks, (uint32_t)nblocks, lit);
+        ZK_HIP(hipEventRecord(e->ev_join, e->aux));
+        zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, seqs);
+        ZK_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
+    }
     { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, ids, out_off, blocks, bases, infos, seqs, lit, (uint8_t *)d_dst); }
     // packed indexed output: out_off (count + 1 prefix sums) doubles as the d_off of the checksum kernel
     if (verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)d_dst, out_off ? out_off : d_off, out_off ? 0 : first, count, infos, nullptr); }
