@@ -215,7 +215,7 @@ __global__ __launch_bounds__(128) void zk_k_huf(const uint8_t *comp, ZkBlock *bl
             if (have) ok = zk_huf_decode_stream(tab, mb, sbase, slen, sdst, sn, real, &mail, t);
             *(volatile uint32_t *)&s_done = 1;
         } else if (have && real) {
-            zk_huf_companion(sbase, slen, sdst, &mail, t, &s_done);
+            zk_huf_companion(sbase, slen, sdst + ((0 - (uintptr_t)sdst) & 7), &mail, t, &s_done);     // packs start at the 8-byte aligned output position
         }
         __syncthreads();
     }

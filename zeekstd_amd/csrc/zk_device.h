@@ -356,39 +356,35 @@ ZK_HD void zk_huf_fill_table(uint16_t *table, ZkHufHdr *hd, uint32_t n, uint32_t
     }
 }
 
-// Stream word k (64 bits, little endian) of a backward bitstream: bytes [o, o + 8) with o = len - 8 (k + 1); bytes
-// below the stream start read as zero.  Branch-free (one unconditional 8-byte load from base + max(o, 0), so up to
-// 8 bytes past a stream shorter than 8 bytes are touched: ZK_COMP_PADDING covers the last stream of a buffer).
-ZK_HD uint64_t zk_ldword_bf(const uint8_t *base, int32_t o)
-{
-    const int32_t oo = o < 0 ? 0 : o;
-    uint64_t v;
-    memcpy(&v, base + oo, 8);
-    const uint32_t sh = o < 0 ? (uint32_t)(-o) * 8u : 0u;
-    return sh >= 64 ? 0 : v << sh;
-}
-
-// Huffman stream reader: three stream words in registers (A current, B, C) plus one load in flight (P), so that no
-// load's latency sits on the decode chain; `c` = bits of A already consumed.  All updates are selects: the loop
-// body is straight-line code and the compiler can leave the load pending until the next refill.
+// Huffman stream reader.  The backward bitstream is consumed through 8-byte ALIGNED words of the buffer it lives in
+// (an unaligned 8-byte access costs ~3.4 L1 tag lookups on gfx950 and the L1 lookup rate is what bounds this
+// kernel): W(j) = the aligned word at AE - 8 (j + 1), AE = stream end rounded up to 8.  The (AE - end) bytes above
+// the stream end are skipped like the final byte's padding.  Three words sit in registers (A current, B, C) and one
+// load is in flight (P); a word is loaded exactly once, when the window advances.  Words below the stream start
+// are clamped to the stream's lowest aligned word: they only matter for corrupt streams, which the final position
+// check rejects.
 struct ZkHufRd {
-    const uint8_t *base;
+    const uint8_t *ptr;              // address of the next aligned word to load
+    const uint8_t *lo;               // lowest aligned word touching the stream
     uint64_t A, B, C, P;
-    int32_t next_off;                // byte offset of the word after P
-    uint32_t c, words;               // words: stream words fully consumed
+    uint32_t c, words;               // bits of A consumed; words fully consumed
 };
+ZK_HD uint64_t zk_hufrd_load(ZkHufRd &r)
+{
+    const uint8_t *p = r.ptr < r.lo ? r.lo : r.ptr;
+    r.ptr -= 8;
+    return *reinterpret_cast<const uint64_t *>(p);
+}
 ZK_HD uint64_t zk_hufrd_refill(ZkHufRd &r)
 {
-    const bool adv = r.c >= 64;
-    r.A = adv ? r.B : r.A; r.B = adv ? r.C : r.B; r.C = adv ? r.P : r.C;
-    r.c -= adv ? 64u : 0u; r.words += adv ? 1u : 0u;
-    r.next_off -= adv ? 8 : 0;
-    r.P = zk_ldword_bf(r.base, r.next_off + 8);
+    if (r.c >= 64) {
+        r.A = r.B; r.B = r.C; r.C = r.P;
+        r.c -= 64; r.words++;
+        r.P = zk_hufrd_load(r);
+    }
     return (r.A << r.c) | ((r.B >> 1) >> (63 - r.c));
 }
 
-// Decode n symbols of one Huffman stream into dst.  Returns false on corruption.
-// Eight symbols are packed into one 64-bit store (two refills of <= 4 x 11 bits).
 // Hand-over between a decoding lane and its companion lane (LDS, one per workgroup; nullptr on the host).  The
 // decoder never issues a global store itself: it drops every 8-symbol pack into a 2-deep ring and publishes
 // (packs written, stream position); the companion wave stores the packs to HBM and touches the stream's cache
@@ -412,16 +408,33 @@ ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const u
     const uint32_t last = src[len - 1];
     if (last == 0) return false;
     ZkHufRd r;
-    r.base = src;
-    r.A = zk_ldword_bf(src, (int32_t)len - 8);
-    r.B = zk_ldword_bf(src, (int32_t)len - 16);
-    r.C = zk_ldword_bf(src, (int32_t)len - 24);
-    r.P = zk_ldword_bf(src, (int32_t)len - 32);
-    r.next_off = (int32_t)len - 40;
-    r.c = 8 - zk_highbit(last);                          // zero padding + the sentinel bit
+    const uintptr_t end = (uintptr_t)src + len, aend = (end + 7) & ~(uintptr_t)7;
+    r.lo = reinterpret_cast<const uint8_t *>((uintptr_t)src & ~(uintptr_t)7);
+    r.ptr = reinterpret_cast<const uint8_t *>(aend) - 8;
+    r.A = zk_hufrd_load(r); r.B = zk_hufrd_load(r); r.C = zk_hufrd_load(r); r.P = zk_hufrd_load(r);
+    const uint32_t skip = (uint32_t)(aend - end) * 8;    // bytes between the stream end and the aligned end
+    r.c = skip + 8 - zk_highbit(last);                   // + zero padding + the sentinel bit
     r.words = 0;
     const uint32_t sh = 64 - maxbits;
     uint32_t i = 0;
+    // head: single symbols until the output position is 8-byte aligned (aligned 8-byte stores: one L1 lookup each)
+    {
+        uint32_t head = (uint32_t)((0 - (uintptr_t)dst) & 7);
+        if (head > n) head = n;
+        while (i < head) {
+            uint64_t cur = zk_hufrd_refill(r);
+            const uint32_t lim = head - i < 4 ? head - i : 4;
+            uint32_t used = 0;
+            for (uint32_t k = 0; k < lim; k++) {
+                const uint32_t c = table[cur >> sh];
+                if (store) dst[i + k] = (uint8_t)c;
+                cur <<= c >> 8; used += c >> 8;
+            }
+            r.c += used;
+            i += lim;
+        }
+    }
+    const uint32_t i0 = i;                               // the mailbox counts packs from here
     while (i + 8 <= n) {
         uint64_t pack = 0;
         uint64_t cur = zk_hufrd_refill(r);
@@ -442,12 +455,12 @@ ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const u
         r.c += used;
         if (mail) {
             if (store) {
-                const uint32_t it = i >> 3;
+                const uint32_t it = (i - i0) >> 3;
                 while (((it - mail->consumed[mlane]) & 0x3fffu) >= 2) {}     // ring full: the companion is behind
                 mail->pack[it & 1][mlane] = pack;
-                mail->state[mlane] = zk_huf_mail_state(it + 1, r.next_off);
+                mail->state[mlane] = zk_huf_mail_state(it + 1, (int32_t)(r.ptr - src));
             }
-        } else if (store) memcpy(dst + i, &pack, 8);
+        } else if (store) *reinterpret_cast<uint64_t *>(dst + i) = pack;
         i += 8;
     }
     while (i < n) {
@@ -462,7 +475,7 @@ ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const u
         r.c += used;
         i += lim;
     }
-    return (uint64_t)r.words * 64 + r.c == (uint64_t)len * 8;
+    return (uint64_t)r.words * 64 + r.c == (uint64_t)len * 8 + skip;
 }
 
 // ---------------------------------------------------------------- header parsing
