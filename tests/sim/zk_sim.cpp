@@ -78,7 +78,9 @@ extern "C" int zk_sim_decode(const uint8_t *comp, const uint64_t *c_off, const u
     for (uint64_t bi = 0; bi < nb; bi++) {
         ZkBlock b = blocks[bi];
         if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK) continue;
-        zk_decode_sequences(comp, blocks.data(), b, T, seqs.data() + b.seq_base, LLV, MLV);
+        // like the device: all-predefined blocks go through the aligned-word reader, the rest through the unaligned one
+        if (b.seq_modes == 0) zk_decode_sequences<ZkRevA>(comp, blocks.data(), b, T, seqs.data() + b.seq_base, LLV, MLV);
+        else zk_decode_sequences<ZkRevU>(comp, blocks.data(), b, T, seqs.data() + b.seq_base, LLV, MLV);
         blocks[bi].out_size = b.out_size;
         for (int k = 0; k < 3; k++) blocks[bi].rep_out[k] = b.rep_out[k];
         blocks[bi].status = b.status;

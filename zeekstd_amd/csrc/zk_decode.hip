@@ -263,13 +263,15 @@ __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *com
 
 // Blocks whose three tables are all Predefined_Mode (Symbol_Compression_Modes == 0: what this engine's own
 // encoder emits, and libzstd for small blocks) need no per-block tables: one copy of the predefined tables per
-// workgroup, one block per LANE, full waves -- the walk is then limited only by its dependent chain.
-constexpr int ZK_FSEP_THREADS = 64;
-constexpr int ZK_FSEP_LANES = 64;                        // blocks per wave (measured on 4 GiB: 64 lanes x 64-thread workgroups 7.6 ms; 16 lanes 8.7; 256-thread workgroups 9.0)
-__global__ __launch_bounds__(ZK_FSEP_THREADS) void zk_k_fse_predef(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
+// workgroup, one block per LANE, full waves.  All 64 lanes walk in lock step so that the 16-B records can be
+// stored cooperatively (ZkCoopFlush: a quarter of the L2 write requests, which were 40% of the kernel's time).
+constexpr int ZK_FSEP_LANES = 64;                        // blocks per workgroup (one wave)
+template <typename RD>
+__global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_predef(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
 {
     __shared__ ZkSeqTables T;                              // shared, read-only after the build
-    __shared__ ZkSeq ring[ZK_FSEP_THREADS][4];             // 4-record staging per lane (64 B stores)
+    __shared__ __attribute__((aligned(16))) ZkSeq ring[ZK_FSEP_LANES][4];    // 4-record staging per lane (one 64-B line)
+    __shared__ ZkCoopFlush coop;
     __shared__ uint32_t llv[36], mlv[53], s_al[3];
     const uint32_t tid = threadIdx.x;
     {
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(ZK_FSEP_THREADS) void zk_k_fse_predef(const uint8_t
         const uint32_t ml_init[53] = ZK_ML_TABLE;
         if (tid < 36) llv[tid] = ll_init[tid];
         if (tid < 53) mlv[tid] = ml_init[tid];
+        if (tid == 0) { coop.ring = &ring[0][0]; coop.seqs = seqs; coop.nloop = 0; }
     }
     __syncthreads();
     if (tid < 16) {                                        // 16 lanes redundantly (identical LDS writes): >= 16 active lanes
@@ -284,20 +287,20 @@ __global__ __launch_bounds__(ZK_FSEP_THREADS) void zk_k_fse_predef(const uint8_t
         fake.seq_modes = 0; fake.seq_off = 0; fake.bsize = 0; fake.src = 0;
         for (int t = 0; t < 3; t++) { uint32_t a = 0; (void)zk_seq_table_setup(comp, fake, t, &T, &a, llv, mlv); s_al[t] = a; }
     }
-    __syncthreads();
-    if (tid >= ZK_FSEP_LANES) return;
-    uint32_t bi = blockIdx.x * ZK_FSEP_LANES + tid;
-    bool real = true;
-    if (bi >= nblocks) {                                   // tail of the block list: shadow a valid block of this wave (up to 16 lanes)
-        const uint32_t wfirst = blockIdx.x * ZK_FSEP_LANES;
-        if (wfirst >= nblocks || tid >= 16) return;
-        bi = wfirst + tid % (nblocks - wfirst);
-        real = false;
+    const uint32_t bi = blockIdx.x * ZK_FSEP_LANES + tid;
+    bool active = bi < nblocks;
+    ZkBlock b;
+    if (active) {
+        b = blocks[bi];
+        active = b.type == 2 && b.nseq != 0 && b.status == ZK_OK && b.seq_modes == 0;
     }
-    ZkBlock b = blocks[bi];
-    if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK || b.seq_modes != 0) return;
-    zk_seq_walk<4>(comp, b, b.seq_off + 1, T.ll, T.of, T.ml, s_al, ring[tid], seqs + b.seq_base, llv, mlv, real);
-    if (!real) return;
+    coop.base[tid] = active ? b.seq_base : 0;
+    coop.nseq[tid] = active ? b.nseq : 0;
+    if (active) atomicMax(&coop.nloop, b.nseq);
+    __syncthreads();
+    // every lane of the wave runs the walk in lock step (inactive ones only help storing the others' records)
+    zk_seq_walk<4, RD>(comp, b, active ? b.seq_off + 1 : 0, T.ll, T.of, T.ml, s_al, ring[tid], seqs, llv, mlv, true, &coop, active, tid);
+    if (!active) return;
     ZkBlock *o = &blocks[bi];
     o->out_size = b.out_size;
     o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
@@ -558,7 +561,12 @@ void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
 void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
 {
     if (!nblocks) return;
-    hipLaunchKernelGGL(zk_k_fse_predef, dim3((nblocks + ZK_FSEP_LANES - 1) / ZK_FSEP_LANES), dim3(ZK_FSEP_THREADS), 0, st, comp, blocks, nblocks, seqs);
+    // reader choice (zk_device.h): with >= 6 workgroups per CU the memory pipeline is the limit (aligned words, each
+    // loaded once); below that a lane's instruction count is (one unaligned load per sequence).  Measured crossover
+    // on 32 KiB blocks between 1024 and 2048 frames of 2 MiB.
+    const uint32_t wgs = (nblocks + ZK_FSEP_LANES - 1) / ZK_FSEP_LANES;
+    if (wgs >= 6 * 256) hipLaunchKernelGGL(zk_k_fse_predef<ZkRevA>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
+    else hipLaunchKernelGGL(zk_k_fse_predef<ZkRevU>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
     hipLaunchKernelGGL(zk_k_fse, dim3((nblocks + ZK_FSE_BLOCKS - 1) / ZK_FSE_BLOCKS), dim3(64 * ZK_FSE_WAVES), 0, st, comp, blocks, nblocks, seqs);
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,

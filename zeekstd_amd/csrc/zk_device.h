@@ -19,6 +19,11 @@
 #else
 #define ZK_HD static inline
 #endif
+#if defined(__HIPCC__)
+#define ZK_HDM __host__ __device__ __forceinline__      // member functions
+#else
+#define ZK_HDM inline
+#endif
 
 // ZSTD_ErrorCode values used on this path (per-frame status words; 0 = ok)
 enum : uint32_t {
@@ -701,69 +706,137 @@ ZK_HD int32_t zk_seq_table_setup(const uint8_t *comp, const ZkBlock &def, int t,
     return -1;   // a defining block never has Repeat_Mode for this table
 }
 
-// Reverse bit window for the sequence bitstream: W holds stream bits [wpos, wpos+64); pos = unread bits.
-// The window for bit position pos starts at byte max(0, (pos-57)>>3), so it always offers >= 57 bits
-// below pos (or everything that is left).  The 8-byte load may touch up to 7 bytes past a stream that
-// is shorter than 8 bytes: compressed buffers carry ZK_DEV_COMP_PADDING readable bytes at the end.
+// Reverse bit readers for the sequence bitstream: both present the next unread bits left-aligned in a 64-bit
+// window and guarantee a minimum number of them after every step.
+//   ZkRevU  one unaligned 8-byte load per sequence (window = bytes starting at max(0, (pos - 57) >> 3): >= 57
+//           bits or everything that is left).  Fewest instructions per sequence: used where a lane runs alone on
+//           its SIMD and every instruction is latency (zk_k_fse, per-block tables).
+//   ZkRevA  8-byte ALIGNED words of the compressed buffer, each loaded exactly once: A (current, c bits
+//           consumed), B, C in registers, one load in flight (P); 64 bits after every step.  An unaligned 8-byte
+//           access costs ~3.4 L1 tag lookups on gfx950 and every lookup that misses L1 is an L2 request: used
+//           where many waves share a CU and the memory pipeline is the limit (zk_k_fse_predef).
+// Both may touch a few bytes outside the bitstream (ZkRevU up to 7 after a stream shorter than 8 bytes, ZkRevA up
+// to 7 before and after): compressed buffers carry ZK_DEV_COMP_PADDING readable bytes at the end.
 constexpr uint32_t ZK_DEV_COMP_PADDING = 8;     // == ZK_COMP_PADDING of include/zeekstd_amd.h
-struct ZkRev { const uint8_t *base; uint64_t W; int32_t pos, wpos; };
 ZK_HD uint64_t zk_ld64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
-ZK_HD int32_t zk_rev_byte(int32_t pos) { int32_t b = (pos - 57) >> 3; return b < 0 ? 0 : b; }
-ZK_HD void zk_rev_load(ZkRev &r) { int32_t bo = zk_rev_byte(r.pos); r.W = zk_ld64(r.base + bo); r.wpos = bo * 8; }
-ZK_HD uint32_t zk_rev_bits(const ZkRev &r, int32_t at, uint32_t n) { return (uint32_t)(r.W >> ((at - r.wpos) & 63)) & ((1u << n) - 1u); }   // n <= 31
-ZK_HD uint32_t zk_rev_read_slow(ZkRev &r, uint32_t n)          // any n <= 31, reloads the window first
-{
-    zk_rev_load(r);
-    r.pos -= (int32_t)n;
-    if (r.pos < 0) return 0;                                    // over-read; caller checks pos
-    return zk_rev_bits(r, r.pos, n);
-}
+
+struct ZkRevU {
+    const uint8_t *base; uint64_t W; int32_t pos, wpos;      // W holds stream bits [wpos, wpos + 64); pos = unread bits
+    static ZK_HDM int32_t byte_of(int32_t pos) { int32_t b = (pos - 57) >> 3; return b < 0 ? 0 : b; }
+    ZK_HDM void reload() { const int32_t bo = byte_of(pos); W = zk_ld64(base + bo); wpos = bo * 8; }
+    ZK_HDM bool init(const uint8_t *b, uint32_t len)
+    {
+        const uint32_t last = b[len - 1];
+        if (last == 0) return false;
+        base = b; pos = (int32_t)((len - 1) * 8 + zk_highbit(last));
+        reload();
+        return true;
+    }
+    ZK_HDM uint32_t avail() const { return (uint32_t)(pos - wpos); }
+    ZK_HDM uint64_t window() const { return W << ((64 - (pos - wpos)) & 63); }
+    ZK_HDM void consume(uint32_t n) { pos -= (int32_t)n; reload(); }          // n <= avail()
+    ZK_HDM uint32_t read(uint32_t n)                                           // any n <= 31, reloads the window first; over-reads return 0
+    {
+        reload();
+        pos -= (int32_t)n;
+        if (pos < 0) return 0;
+        return (uint32_t)(W >> ((pos - wpos) & 63)) & ((1u << n) - 1u);
+    }
+    ZK_HDM int32_t remaining() const { return pos; }
+    ZK_HDM void clamp() { if (pos < 0) pos = 0; reload(); }                    // after a run of read()s
+};
+
+struct ZkRevA {
+    const uint8_t *ptr, *lo;         // next aligned word to load; lowest aligned word touching the stream
+    uint64_t A, B, C, P;
+    uint32_t c;                      // bits of A consumed (< 64 between steps)
+    int32_t rem;                     // unread stream bits; < 0 == over-read
+    ZK_HDM uint64_t load()
+    {
+        const uint8_t *p = ptr < lo ? lo : ptr;     // below the stream: only a corrupt stream gets here, rem goes negative
+        ptr -= 8;
+        return *reinterpret_cast<const uint64_t *>(p);
+    }
+    ZK_HDM void advance() { if (c >= 64) { A = B; B = C; C = P; c -= 64; P = load(); } }
+    ZK_HDM bool init(const uint8_t *b, uint32_t len)
+    {
+        const uint32_t last = b[len - 1];
+        if (last == 0) return false;
+        const uint32_t hb = zk_highbit(last);
+        const uintptr_t end = (uintptr_t)b + len, aend = (end + 7) & ~(uintptr_t)7;
+        lo = reinterpret_cast<const uint8_t *>((uintptr_t)b & ~(uintptr_t)7);
+        ptr = reinterpret_cast<const uint8_t *>(aend) - 8;
+        A = load(); B = load(); C = load(); P = load();
+        c = (uint32_t)(aend - end) * 8 + 8 - hb;             // bytes above the stream end + zero padding + sentinel
+        rem = (int32_t)((len - 1) * 8 + hb);
+        advance();                                           // c == 64: the top word holds no stream bit
+        return true;
+    }
+    ZK_HDM uint32_t avail() const { return 64; }
+    ZK_HDM uint64_t window() const { return (A << c) | ((B >> 1) >> (63 - c)); }
+    ZK_HDM void consume(uint32_t n) { c += n; rem -= (int32_t)n; advance(); }  // n <= 64
+    ZK_HDM uint32_t read(uint32_t n)                                            // n <= 32
+    {
+        const uint64_t X = window();
+        const uint32_t v = n ? (uint32_t)(X >> (64 - n)) : 0u;
+        consume(n);
+        return v;
+    }
+    ZK_HDM int32_t remaining() const { return rem; }
+    ZK_HDM void clamp() {}
+};
+
+// Wave-cooperative flush of the 4-record rings of a 64-lane wave (device only, zk_k_fse_predef): a lane's four
+// 16-B records are one 64-B line of its block's record array, so instead of every lane storing its own ring
+// (4 instructions x 64 separate L2 write requests) four neighbouring lanes store one ring per instruction
+// (4 x 16 requests of 64 B).  All 64 lanes must run the walk in lock step (nloop = the wave's longest block).
+struct ZkCoopFlush {
+    ZkSeq *ring;                     // [64][4]
+    ZkSeq *seqs;                     // the record array of the whole batch
+    uint64_t base[64];               // record index of each lane's block
+    uint32_t nseq[64];               // 0: lane stores nothing (shadow / inactive)
+    uint32_t nloop;
+};
 
 // The 3-state walk over the sequence bitstream of block b (tables already built: LL / OF / ML cells, accuracy
-// logs al[3], bitstream at offset bs_off of the block content).  ring: 16-record LDS staging of this lane.
+// logs al[3], bitstream at offset bs_off of the block content).  ring: RING-record LDS staging of this lane.
 // Fills seqs[], b.out_size / b.rep_out / b.status.
 // store == false: a shadow lane (see zk_k_fse) -- it walks the same block as a real lane but never writes to HBM
-template <int RING = 16>
+// active == false (cooperative mode only): the lane has no block but takes part in the flushes.
+template <int RING, typename RD>
 ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const uint32_t *LL, const uint32_t *OF, const uint32_t *ML,
                        const uint32_t *al, ZkSeq *ring, ZkSeq *seqs, const uint32_t *ll_values, const uint32_t *ml_values,
-                       bool store = true)
+                       bool store = true, ZkCoopFlush *coop = nullptr, bool active = true, uint32_t lane = 0)
 {
-    if (bs_off >= b.bsize) { b.status = ZK_E_CORRUPTION; return; }
-    const uint32_t blen = b.bsize - bs_off;
-    ZkRev r;
-    r.base = comp + b.src + bs_off;
-    {
-        uint32_t last = r.base[blen - 1];
-        if (last == 0) { b.status = ZK_E_CORRUPTION; return; }
-        r.pos = (int32_t)((blen - 1) * 8 + zk_highbit(last));
-    }
-    uint32_t sl = zk_rev_read_slow(r, al[0]), so = zk_rev_read_slow(r, al[1]), sm = zk_rev_read_slow(r, al[2]);
-    zk_rev_load(r);
+    RD r;
+    uint32_t bad = 0;
+    if (active && bs_off >= b.bsize) { bad = 1; active = false; }
+    if (active && !r.init(comp + b.src + bs_off, b.bsize - bs_off)) { bad = 1; active = false; }
+    const uint32_t nseq = active ? b.nseq : 0;
+    uint32_t sl = 0, so = 0, sm = 0;
+    if (active) { sl = r.read(al[0]); so = r.read(al[1]); sm = r.read(al[2]); bad |= r.remaining() < 0; r.clamp(); }
     uint32_t rep0 = zk_rep_sym(0), rep1 = zk_rep_sym(1), rep2 = zk_rep_sym(2);
     uint32_t out = 0, lit = 0;
-    const uint32_t nseq = b.nseq;
-    uint32_t bad = r.pos < 0;
-    // Sequences are decoded in groups of 16 (the LDS record ring).  The group body is one basic block:
+    // Sequences are decoded in groups of RING (the LDS record ring).  The step is one basic block:
     // errors only accumulate into `bad` (a corrupt stream keeps walking harmlessly: states stay inside
-    // their tables, window addresses are clamped) and the rare sequence that needs more than the 57
-    // guaranteed window bits leaves the block for a field-by-field slow step.
-    uint32_t i = 0;
+    // their tables, window addresses are clamped) and the rare sequence that needs more bits than the
+    // window guarantees leaves the block for a field-by-field slow step.
     uint32_t cl = LL[sl], co = OF[so], cm = ML[sm];
-    while (i < nseq) {
-        const uint32_t gend = i + RING < nseq ? i + RING : nseq;
-        while (i < gend) {
+    const uint32_t nloop = coop ? coop->nloop : nseq;
+    for (uint32_t g0 = 0; g0 < nloop; g0 += RING) {
+        for (uint32_t i = g0; i < g0 + RING; i++) {
+            if (i >= nseq) break;
             const uint32_t nOf = zk_cell_sym(co), nMl = zk_cell_xbits(cm), nLl = zk_cell_xbits(cl);
             const bool more = i + 1 < nseq;
             const uint32_t nbl = more ? zk_cell_nb(cl) : 0, nbm = more ? zk_cell_nb(cm) : 0, nbo = more ? zk_cell_nb(co) : 0;
             const uint32_t nval = nOf + nMl + nLl;
-            const int32_t npos = r.pos - (int32_t)(nval + nbl + nbm + nbo);
+            const uint32_t total = nval + nbl + nbm + nbo;
             uint32_t ofx, mlx, llx;
             const uint32_t csl = cl, csm = cm;                                      // symbols of THIS sequence
-            if (npos >= r.wpos) {                                                   // every field lies inside the current window
-                // window of the NEXT sequence: its address only needs the bit counts
-                const int32_t nbyte = zk_rev_byte(npos);
-                const uint64_t Wn = zk_ld64(r.base + nbyte);
-                const uint64_t X = r.W << ((64 - (r.pos - r.wpos)) & 63);           // left-align the unread bits
+            bad |= nOf > 30;
+            if (total <= r.avail()) {                                               // every field lies inside the window
+                const uint64_t X = r.window();
+                r.consume(total);                                                   // the next window's load only needs the bit counts
                 // state bits first: they gate the next cell reads (the dependent chain of the walk)
                 uint64_t S = X << (nval & 63);
                 const uint32_t h0 = (uint32_t)(S >> 32); S <<= nbl;
@@ -775,20 +848,16 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const u
                 cl = LL[sl]; co = OF[so]; cm = ML[sm];                     // issued early; used next iteration
                 // value bits (off the chain)
                 uint64_t V = X;
-                ofx = nOf ? (uint32_t)(V >> 32) >> (32 - nOf) : 0; V <<= nOf;
+                ofx = nOf ? (uint32_t)(V >> 32) >> (32 - (nOf & 31)) : 0; V <<= (nOf & 31);
                 mlx = nMl ? (uint32_t)(V >> 32) >> (32 - nMl) : 0; V <<= nMl;
                 llx = nLl ? (uint32_t)(V >> 32) >> (32 - nLl) : 0;
-                r.pos = npos; r.W = Wn; r.wpos = nbyte * 8;
-                bad |= nOf > 30;
-            } else {                                                                // > 57 bits in one sequence (or over-read)
-                bad |= nOf > 30;
-                ofx = zk_rev_read_slow(r, nOf & 31); mlx = zk_rev_read_slow(r, nMl); llx = zk_rev_read_slow(r, nLl);
-                sl = zk_cell_base(cl) + zk_rev_read_slow(r, nbl);
-                sm = zk_cell_base(cm) + zk_rev_read_slow(r, nbm);
-                so = zk_cell_base(co) + zk_rev_read_slow(r, nbo);
-                bad |= r.pos < 0;
-                if (r.pos < 0) r.pos = 0;
-                zk_rev_load(r);
+            } else {                                                                // more bits than the window guarantees (or over-read)
+                ofx = r.read(nOf & 31); mlx = r.read(nMl); llx = r.read(nLl);
+                sl = zk_cell_base(cl) + r.read(nbl);
+                sm = zk_cell_base(cm) + r.read(nbm);
+                so = zk_cell_base(co) + r.read(nbo);
+                bad |= r.remaining() < 0;
+                r.clamp();
                 cl = LL[sl]; co = OF[so]; cm = ML[sm];
             }
             const uint32_t ofv = (1u << (nOf & 31)) + ofx;
@@ -809,13 +878,26 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const u
             bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX);
             ZkSeq s; s.out_end = out; s.ml = ml; s.off = off; s.lit_end = lit;
             ring[i & (RING - 1)] = s;
-            i++;
         }
         // records are parked in LDS and written out a group at a time (few, wide store bursts)
-        const uint32_t g0 = (i - 1) & ~(uint32_t)(RING - 1);
-        if (store) for (uint32_t k = g0; k < i; k++) seqs[k] = ring[k & (RING - 1)];
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (coop) {
+            static_assert(RING == 4 || RING == 16, "ring");
+            if (RING == 4) {
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t m = 16 * j + (lane >> 2), k = g0 + (lane & 3);
+                    if (k < coop->nseq[m])
+                        reinterpret_cast<uint4 *>(coop->seqs)[coop->base[m] + k] = reinterpret_cast<const uint4 *>(coop->ring)[m * 4 + (lane & 3)];
+                }
+            }
+            continue;
+        }
+#endif
+        const uint32_t gend = g0 + RING < nseq ? g0 + RING : nseq;
+        if (store) for (uint32_t k = g0; k < gend; k++) seqs[k] = ring[k & (RING - 1)];
     }
-    bad |= r.pos != 0;
+    if (!active) { if (bad) b.status = ZK_E_CORRUPTION; return; }
+    bad |= r.remaining() != 0;
     if (bad) { b.status = ZK_E_CORRUPTION; return; }
     out += b.lit_regen - lit;
     if (out > ZK_BLOCK_MAX) { b.status = ZK_E_CORRUPTION; return; }
@@ -825,6 +907,7 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const u
 
 
 // Decode all sequences of block b into seqs[]: builds the block's LL / OF / ML tables in T (per-lane LDS), then walks.
+template <typename RD = ZkRevU>
 ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlock &b, ZkSeqTables *T, ZkSeq *seqs,
                                const uint32_t *ll_values, const uint32_t *ml_values, bool store = true)
 {
@@ -837,7 +920,7 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
         if (r < 0) { b.status = ZK_E_CORRUPTION; return; }
         if (m != 3) own += (uint32_t)r;
     }
-    zk_seq_walk(comp, b, b.seq_off + 1 + own, T->ll, T->of, T->ml, al, T->ring, seqs, ll_values, ml_values, store);
+    zk_seq_walk<16, RD>(comp, b, b.seq_off + 1 + own, T->ll, T->of, T->ml, al, T->ring, seqs, ll_values, ml_values, store);
 }
 
 // ---------------------------------------------------------------- sequence execution: per-byte source map
