@@ -105,6 +105,19 @@ int zk_decode_frame_list_dev(zk_engine *e, const void *d_comp, uint64_t comp_siz
                              const void *d_ids, const void *d_out_off, uint32_t count, void *d_dst, uint64_t dst_cap,
                              int verify, void *d_frame_status, void *stream);
 
+/* Two batches in flight.  zk_decode_submit_dev enqueues exactly what zk_decode_frames_dev runs, on one of the
+ * engine's two decode contexts (own HIP queues and scratch), and returns while the kernels are still running;
+ * *slot_out names the context.  zk_decode_wait(slot) blocks until that batch is complete and returns its status (0,
+ * or the first failing frame's code like zk_decode_frames_dev); d_frame_status is valid after the wait.  At most
+ * two batches may be outstanding (a third submit returns ZK_ERR_ARGUMENT until the older one was waited for) and
+ * all buffers of a batch must stay untouched until its wait.  The gain: the last stage of a batch (per-frame XXH64,
+ * a serial chain that leaves the GPU mostly idle) overlaps the first stages of the next.  No reference counterpart:
+ * zeekstd's Decoder is synchronous (lib/src/decode.rs:201-270); this is the batch engine's pipelining. */
+int zk_decode_submit_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off,
+                         const void *d_d_off, uint32_t first, uint32_t count, void *d_dst, uint64_t dst_cap,
+                         int verify, void *d_frame_status, int *slot_out);
+int zk_decode_wait(zk_engine *e, int slot);
+
 /*
  * Encode src[0, n) as ceil(n / frame_size) independent zstd frames (FrameSizePolicy::Uncompressed(frame_size),
  * lib/src/encode.rs:21-39, 528-544; n == 0 yields one empty frame like Encoder::finish, encode.rs:755-757),

@@ -154,3 +154,46 @@ def test_random_access_batch(engine):
     out = bytes(d_out[:int(off[-1])].cpu().numpy())
     for i, f in enumerate(ids):
         assert out[int(off[i]):int(off[i + 1])] == data[int(d[f]):int(d[f + 1])]
+
+
+def test_two_batches_in_flight(engine):
+    # zk_decode_submit_dev / zk_decode_wait: same results as the synchronous call, statuses per batch, depth 2
+    import torch
+    from zeekstd_amd.engine import ZkError
+    good = next(x for x in GOLDENS if x.name == "text_100B_frames")
+    other = next(x for x in GOLDENS if x.name != "text_100B_frames" and len(x.frames) >= 2 and x.input())
+    dev = torch.device("cuda:0")
+
+    def stage(g, comp=None):
+        c, d = g.offsets()
+        comp = g.comp if comp is None else comp
+        return dict(comp=torch.from_numpy(np.frombuffer(comp + b"\0" * 8, np.uint8).copy()).to(dev), n=len(comp),
+                    c=torch.from_numpy(c.view(np.int64)).to(dev), d=torch.from_numpy(d.view(np.int64)).to(dev),
+                    out=torch.zeros(int(d[-1]) + 64, dtype=torch.uint8, device=dev), dsize=int(d[-1]),
+                    st=torch.full((len(g.frames),), -1, dtype=torch.int32, device=dev), frames=len(g.frames))
+
+    a, b = stage(good), stage(other)
+    ck = next(x for x in GOLDENS if x.name == "text_l1_64k")
+    bad = bytearray(ck.comp)
+    bad[int(ck.offsets()[0][2]) - 1] ^= 0x40                         # last byte of frame 1 = its Content_Checksum
+    x = stage(ck, bytes(bad))
+    submit = lambda s: engine.decode_submit_dev(s["comp"], s["n"], s["c"], s["d"], 0, s["frames"], s["out"], s["dsize"], True, s["st"])
+    for _ in range(3):
+        s0, s1 = submit(a), submit(b)
+        assert {s0, s1} == {0, 1}
+        with pytest.raises(ZkError):
+            submit(x)                                                # both contexts busy
+        assert engine.decode_wait(s0) == 0 and engine.decode_wait(s1) == 0
+        assert bytes(a["out"][:a["dsize"]].cpu().numpy()) == good.input()
+        assert bytes(b["out"][:b["dsize"]].cpu().numpy()) == other.input()
+        assert not a["st"].any().item() and not b["st"].any().item()
+    s0, s1 = submit(x), submit(a)
+    rc = engine.decode_wait(s0)
+    assert rc == -22
+    assert list(x["st"].cpu().numpy()) == [0, 22, 0, 0]
+    assert engine.decode_wait(s1) == 0
+    with pytest.raises(ZkError):
+        engine.decode_wait(s1)                                       # nothing pending on that context
+    # the synchronous path still works afterwards
+    out, st = engine.decode_frames(good.comp + b"\0" * 8, *good.offsets(), verify=True)
+    assert out == good.input() and not st.any()

@@ -41,6 +41,8 @@ _sig = {
     "zk_engine_kernel_times": (C.c_int, [_P, _P, C.c_int]),
     "zk_decode_frames": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_int, _P]),
     "zk_decode_frames_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_int, _P, _P]),
+    "zk_decode_submit_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_int, _P, C.POINTER(C.c_int)]),
+    "zk_decode_wait": (C.c_int, [_P, C.c_int]),
     "zk_compress_bound": (C.c_uint64, [C.c_uint64, C.c_uint32]),
     "zk_encode_frames": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_int, C.c_int, _P, C.c_uint64, _P, _P, C.c_uint32,
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),

@@ -20,6 +20,14 @@ struct zk_engine {
     uint64_t *h_words = nullptr;            // pinned: small read-backs (totals, first error)
     // decode scratch
     zk_devbuf infos, bases, words, blocks, seqs, lit;
+    // second decode context (zk_decode_submit_dev): own queues, scratch and read-back words, so that two batches can
+    // be in flight -- the tail of one (checksum kernel: a per-frame serial chain) overlaps the head of the next
+    hipStream_t stream2 = nullptr, aux2 = nullptr;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
+    zk_devbuf infos2, bases2, words2, blocks2, seqs2, lit2;
+    uint64_t *h_words2 = nullptr;
+    bool slot_busy[2] = {false, false};
+    int next_slot = 0;
     // staging for the host-pointer entry points
     zk_devbuf st_comp, st_off, st_dst, st_misc;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)

@@ -115,7 +115,12 @@ extern "C" int zk_engine_create(int device, zk_engine **out)
     if (hipHostMalloc((void **)&e->h_words, 16 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return ZK_ERR_HIP; }
     if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { zk_engine_destroy(e); return ZK_ERR_HIP; }
+        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void **)&e->h_words2, 16 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { zk_engine_destroy(e); return ZK_ERR_HIP; }
     *out = e;
     return 0;
 }
@@ -125,7 +130,8 @@ extern "C" void zk_engine_destroy(zk_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    zk_devbuf *bufs[] = {&e->infos, &e->bases, &e->words, &e->blocks, &e->seqs, &e->lit, &e->st_comp, &e->st_off, &e->st_dst, &e->st_misc,
+    if (e->stream2) (void)hipStreamSynchronize(e->stream2);
+    zk_devbuf *bufs[] = {&e->infos, &e->bases, &e->words, &e->blocks, &e->seqs, &e->lit, &e->infos2, &e->bases2, &e->words2, &e->blocks2, &e->seqs2, &e->lit2, &e->st_comp, &e->st_off, &e->st_dst, &e->st_misc,
                          &e->enc_a, &e->enc_b, &e->enc_c, &e->enc_d};
     for (zk_devbuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (e->h_words) (void)hipHostFree(e->h_words);
@@ -133,6 +139,11 @@ extern "C" void zk_engine_destroy(zk_engine *e)
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->aux) (void)hipStreamDestroy(e->aux);
+    if (e->h_words2) (void)hipHostFree(e->h_words2);
+    if (e->ev_fork2) (void)hipEventDestroy(e->ev_fork2);
+    if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
+    if (e->aux2) (void)hipStreamDestroy(e->aux2);
+    if (e->stream2) (void)hipStreamDestroy(e->stream2);
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -142,63 +153,126 @@ extern "C" const char *zk_engine_device_name(const zk_engine *e) { return e ? e-
 
 // ---------------------------------------------------------------------------------------------- decode
 // ids / out_off (device arrays, both or neither): frame f of the batch is archive frame ids[f]; its bytes go to dst + out_off[f]
-static int zk_decode_impl(zk_engine *e, const void *d_comp, const void *d_c_off, const void *d_d_off, uint32_t first, uint32_t count,
-                          const uint32_t *ids, const uint64_t *out_off, void *d_dst, int verify, void *d_frame_status, void *stream)
+// One decode in flight: queues, scratch and pinned read-back words.  Context 0 is the engine's own (synchronous entry
+// points, optionally on the caller's stream), context 1 exists for zk_decode_submit_dev.
+struct zk_dec_ctx {
+    hipStream_t st, aux; hipEvent_t ev_fork, ev_join;
+    zk_devbuf &infos, &bases, &words, &blocks, &seqs, &lit;
+    uint64_t *h_words;
+};
+static zk_dec_ctx zk_dec_context(zk_engine *e, int slot, void *stream)
 {
-    if (!e || (count && (!d_comp || !d_c_off || !d_d_off || !d_dst))) return ZK_ERR_ARGUMENT;
-    if (count == 0) return 0;
-    ZK_HIP(hipSetDevice(e->device));
-    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    if (slot == 0) return zk_dec_ctx{stream ? (hipStream_t)stream : e->stream, e->aux, e->ev_fork, e->ev_join, e->infos, e->bases, e->words, e->blocks, e->seqs, e->lit, e->h_words};
+    return zk_dec_ctx{e->stream2, e->aux2, e->ev_fork2, e->ev_join2, e->infos2, e->bases2, e->words2, e->blocks2, e->seqs2, e->lit2, e->h_words2};
+}
+
+// Enqueue the whole decode on the context's queues.  Blocks the host once, for the block / sequence / literal totals
+// that size the scratch (24 bytes, after the two cheapest kernels); returns with the rest still running.
+static int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const void *d_comp, const void *d_c_off, const void *d_d_off, uint32_t first, uint32_t count,
+                             const uint32_t *ids, const uint64_t *out_off, void *d_dst, int verify, void *d_frame_status)
+{
+    hipStream_t st = c.st;
     const uint8_t *comp = (const uint8_t *)d_comp;
     const uint64_t *c_off = (const uint64_t *)d_c_off, *d_off = (const uint64_t *)d_d_off;
     int rc;
-    if ((rc = zk_devbuf_reserve(e, e->infos, (size_t)count * sizeof(ZkFrameInfo)))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->bases, (size_t)count * sizeof(ZkFrameBase)))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->words, 16 * sizeof(uint64_t)))) return rc;
-    ZkFrameInfo *infos = (ZkFrameInfo *)e->infos.p;
-    ZkFrameBase *bases = (ZkFrameBase *)e->bases.p;
-    uint64_t *words = (uint64_t *)e->words.p;          // [0..2] totals, [3] first error
+    if ((rc = zk_devbuf_reserve(e, c.infos, (size_t)count * sizeof(ZkFrameInfo)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.bases, (size_t)count * sizeof(ZkFrameBase)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.words, 16 * sizeof(uint64_t)))) return rc;
+    ZkFrameInfo *infos = (ZkFrameInfo *)c.infos.p;
+    ZkFrameBase *bases = (ZkFrameBase *)c.bases.p;
+    uint64_t *words = (uint64_t *)c.words.p;          // [0..2] totals, [3] first error
 
     zk_profile_begin(e);
     { zk_kernel_timer t(e, ZK_K_WALK_COUNT, st); zk_launch_walk(st, comp, c_off, d_off, first, count, ids, nullptr, nullptr, infos); }
     { zk_kernel_timer t(e, ZK_K_SCAN, st); zk_launch_scan(st, infos, count, bases, words); }
-    ZK_HIP(hipMemcpyAsync(e->h_words, words, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(c.h_words, words, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
-    const uint64_t nblocks = e->h_words[0], nseq = e->h_words[1], nlit = e->h_words[2];
+    const uint64_t nblocks = c.h_words[0], nseq = c.h_words[1], nlit = c.h_words[2];
     if (nblocks > 0xFFFFFFF0ull) return -(int)ZK_E_GENERIC;
-    if ((rc = zk_devbuf_reserve(e, e->blocks, (size_t)(nblocks + 1) * sizeof(ZkBlock)))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->seqs, (size_t)(nseq + 1) * sizeof(ZkSeq)))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->lit, (size_t)nlit + 64))) return rc;
-    ZkBlock *blocks = (ZkBlock *)e->blocks.p;
-    ZkSeq *seqs = (ZkSeq *)e->seqs.p;
-    uint8_t *lit = (uint8_t *)e->lit.p;
+    if ((rc = zk_devbuf_reserve(e, c.blocks, (size_t)(nblocks + 1) * sizeof(ZkBlock)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)(nseq + 1) * sizeof(ZkSeq)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.lit, (size_t)nlit + 64))) return rc;
+    ZkBlock *blocks = (ZkBlock *)c.blocks.p;
+    ZkSeq *seqs = (ZkSeq *)c.seqs.p;
+    uint8_t *lit = (uint8_t *)c.lit.p;
 
-    e->h_words[3] = ~0ull;
-    ZK_HIP(hipMemcpyAsync(words + 3, e->h_words + 3, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    c.h_words[3] = ~0ull;
+    ZK_HIP(hipMemcpyAsync(words + 3, c.h_words + 3, sizeof(uint64_t), hipMemcpyHostToDevice, st));
     { zk_kernel_timer t(e, ZK_K_WALK_FILL, st); zk_launch_walk(st, comp, c_off, d_off, first, count, ids, bases, blocks, infos); }
-    // literals (huf) and sequences (fse) of a block are independent: the two kernels run side by side on two queues
-    // (latency-bound kernels with different bottlenecks); with per-kernel timing on they are serialised instead
+    // literals (huf) and sequences (fse) of a block are independent: the two kernels run side by side on two queues;
+    // with per-kernel timing on they are serialised instead
     if (e->profiling) {
         { zk_kernel_timer t(e, ZK_K_HUF, st); zk_launch_huf(st, comp, blocks, (uint32_t)nblocks, lit); }
         { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, seqs); }
     } else {
-        ZK_HIP(hipEventRecord(e->ev_fork, st));
-        ZK_HIP(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
-        zk_launch_huf(e->aux, comp, blocks, (uint32_t)nblocks, lit);
-        ZK_HIP(hipEventRecord(e->ev_join, e->aux));
+        ZK_HIP(hipEventRecord(c.ev_fork, st));
+        ZK_HIP(hipStreamWaitEvent(c.aux, c.ev_fork, 0));
+        zk_launch_huf(c.aux, comp, blocks, (uint32_t)nblocks, lit);
+        ZK_HIP(hipEventRecord(c.ev_join, c.aux));
         zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, seqs);
-        ZK_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
+        ZK_HIP(hipStreamWaitEvent(st, c.ev_join, 0));
     }
     { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, ids, out_off, blocks, bases, infos, seqs, lit, (uint8_t *)d_dst); }
     // packed indexed output: out_off (count + 1 prefix sums) doubles as the d_off of the checksum kernel
     if (verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)d_dst, out_off ? out_off : d_off, out_off ? 0 : first, count, infos, nullptr); }
     { zk_kernel_timer t(e, ZK_K_STATUS, st); zk_launch_status(st, infos, count, (int32_t *)d_frame_status, words + 3); }
-    ZK_HIP(hipMemcpyAsync(e->h_words + 3, words + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipMemcpyAsync(c.h_words + 3, words + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    return 0;
+}
+static int zk_decode_finish(zk_engine *e, zk_dec_ctx &c)
+{
+    ZK_HIP(hipStreamSynchronize(c.st));
     ZK_HIP(hipGetLastError());
     zk_profile_collect(e);
-    if (e->h_words[3] != ~0ull) return -(int)(uint32_t)(e->h_words[3] & 0xFFFFFFFFu);
+    if (c.h_words[3] != ~0ull) return -(int)(uint32_t)(c.h_words[3] & 0xFFFFFFFFu);
     return 0;
+}
+
+static int zk_decode_impl(zk_engine *e, const void *d_comp, const void *d_c_off, const void *d_d_off, uint32_t first, uint32_t count,
+                          const uint32_t *ids, const uint64_t *out_off, void *d_dst, int verify, void *d_frame_status, void *stream)
+{
+    if (!e || (count && (!d_comp || !d_c_off || !d_d_off || !d_dst))) return ZK_ERR_ARGUMENT;
+    if (count == 0) return 0;
+    if (e->slot_busy[0]) return ZK_ERR_ARGUMENT;            // a submitted batch still owns context 0: zk_decode_wait first
+    ZK_HIP(hipSetDevice(e->device));
+    zk_dec_ctx c = zk_dec_context(e, 0, stream);
+    int rc = zk_decode_enqueue(e, c, d_comp, d_c_off, d_d_off, first, count, ids, out_off, d_dst, verify, d_frame_status);
+    if (rc) return rc;
+    return zk_decode_finish(e, c);
+}
+
+extern "C" int zk_decode_submit_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off,
+                                    const void *d_d_off, uint32_t first, uint32_t count, void *d_dst, uint64_t dst_cap,
+                                    int verify, void *d_frame_status, int *slot_out)
+{
+    (void)comp_size; (void)dst_cap;
+    if (!e || !slot_out || count == 0 || !d_comp || !d_c_off || !d_d_off || !d_dst) return ZK_ERR_ARGUMENT;
+    const int slot = e->next_slot;
+    if (e->slot_busy[slot]) return ZK_ERR_ARGUMENT;         // both contexts in flight: zk_decode_wait the older one first
+    ZK_HIP(hipSetDevice(e->device));
+    zk_dec_ctx c = zk_dec_context(e, slot, nullptr);
+    const bool prof = e->profiling;
+    e->profiling = false;                                   // per-kernel events belong to the synchronous path
+    int rc = zk_decode_enqueue(e, c, d_comp, d_c_off, d_d_off, first, count, nullptr, nullptr, d_dst, verify, d_frame_status);
+    e->profiling = prof;
+    if (rc) { (void)hipStreamSynchronize(c.st); return rc; }
+    e->slot_busy[slot] = true;
+    e->next_slot = slot ^ 1;
+    *slot_out = slot;
+    return 0;
+}
+
+extern "C" int zk_decode_wait(zk_engine *e, int slot)
+{
+    if (!e || slot < 0 || slot > 1 || !e->slot_busy[slot]) return ZK_ERR_ARGUMENT;
+    ZK_HIP(hipSetDevice(e->device));
+    zk_dec_ctx c = zk_dec_context(e, slot, nullptr);
+    const bool prof = e->profiling;
+    e->profiling = false;
+    const int rc = zk_decode_finish(e, c);
+    e->profiling = prof;
+    e->slot_busy[slot] = false;
+    return rc;
 }
 
 extern "C" int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off,

@@ -125,6 +125,24 @@ class Engine:
             self._raise(rc)
         return rc
 
+    def decode_submit_dev(self, d_comp, comp_size, d_c_off, d_d_off, first, count, d_dst, dst_cap, verify=True, d_status=None):
+        """Enqueue a batch on one of the engine's two decode contexts; returns the slot to pass to decode_wait()."""
+        slot = C.c_int(-1)
+        rc = lib.zk_decode_submit_dev(self._h, self._ptr(d_comp), comp_size, self._ptr(d_c_off), self._ptr(d_d_off),
+                                      first, count, self._ptr(d_dst), dst_cap, int(verify),
+                                      self._ptr(d_status) if d_status is not None else None, C.byref(slot))
+        if rc != 0:
+            if rc <= -1000:
+                self._raise(rc)
+            raise RuntimeError(f"zk_decode_submit_dev: {rc}")
+        return slot.value
+
+    def decode_wait(self, slot):
+        rc = lib.zk_decode_wait(self._h, int(slot))
+        if rc <= -1000:
+            self._raise(rc)
+        return rc
+
     def decode_frame_list_dev(self, d_comp, comp_size, d_c_off, d_d_off, d_ids, d_out_off, count, d_dst, dst_cap, verify=True,
                               d_status=None, stream=None):
         """Random-access batch: archive frames d_ids[i] -> d_dst + d_out_off[i] (all device-resident)."""
