@@ -56,8 +56,11 @@ def build_inputs(k0, nframes, level, cks, workers, want_archive, tag):
     _SHM = np.memmap(path, dtype=np.uint8, mode="w+", shape=(nframes * FRAME,))
     per = max(1, min(16, nframes // max(1, workers)))
     jobs = [(k0, i, min(per, nframes - i), level, cks, want_archive) for i in range(0, nframes, per)]
-    with mp.get_context("fork").Pool(workers) as pool:
-        parts = pool.map(_make_part, jobs)
+    if workers <= 1:                                   # --no-fork: rocprofv3's signal handler can hang on the pool's worker exits
+        parts = [_make_part(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(workers) as pool:
+            parts = pool.map(_make_part, jobs)
     os.unlink(path)                                    # the mapping stays valid until it is dropped
     comp = b"".join(p[0] for p in parts)
     frames = [f for p in parts for f in p[1]]
@@ -178,6 +181,10 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-seek", action="store_true")
+    ap.add_argument("--no-fork", action="store_true", help="generate the inputs in this process (profiling runs)")
+    ap.add_argument("--sync", action="store_true",
+                    help="time one batch at a time (zk_decode_frames_dev) instead of two batches in flight; the "
+                         "kernel-trace profile uses this so that kernel durations are not inflated by overlap")
     ap.add_argument("--archive", default="auto", choices=["auto", "gpu", "libzstd"],
                     help="who compresses the archive that is decoded: the GPU encoder (default for c3) or CPU libzstd (default for c2)")
     args = ap.parse_args()
@@ -193,7 +200,7 @@ def main():
 
     # ---- untimed setup on the host cores (before any HIP initialisation: workers are forked)
     cores = os.cpu_count() or 8
-    workers = max(1, min(64, cores // max(1, world) - 1))
+    workers = 1 if args.no_fork else max(1, min(64, cores // max(1, world) - 1))
     use_gpu_archive = args.archive == "gpu" or (args.archive == "auto" and args.workload == "c3")
     t0 = time.time()
     data, z_comp, z_frames, hashes = build_inputs(rank * nframes, nframes, level, cks, workers, not use_gpu_archive, rank)
@@ -290,10 +297,15 @@ def main():
             if rc != 0:
                 raise RuntimeError(f"decode failed: {zk.error_name(rc)}")
 
+    def run_sync(k):
+        for _ in range(k):
+            step()
+
+    run_timed = run_sync if args.sync else run_pipelined
     run_pipelined(2)                                           # sizes the second context's scratch (untimed)
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_pipelined(args.steps)
+    run_timed(args.steps)
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
     if not torch.equal(d_outs[1][:dsize], d_src) or int(d_sts[1].abs().sum().item()) != 0:
@@ -372,7 +384,7 @@ def main():
             "config": {"workload": ("configs[2]: 4 GiB/GPU, 2048 x 2 MiB frames, level 1, XXH64 checksums verified"
                                     if args.workload == "c3" else "configs[1]: 256 MiB, 128 x 2 MiB frames, level 1, decode-only"),
                        "frames_per_gpu": nframes, "frame_size": FRAME, "compressed_bytes_per_gpu": csize,
-                       "batches_in_flight": 2,
+                       "batches_in_flight": 1 if args.sync else 2,
                        "archive": ("GPU encoder of this engine (zk_encode_frames_dev)" if use_gpu_archive else "CPU libzstd (reference Encoder loop)")
                                   + ", inputs from the SURVEY 8d generator",
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",

@@ -5,7 +5,7 @@ usage: pmc_summary.py <fetch_dir> <write_dir> <workload> [out.json]
 
 Each directory holds the `*_counter_collection.csv` of one pass of `python bench.py --steps 1 --warmup 1
 --no-cpu-baseline --no-seek`.  Values are KiB per dispatch (MI355X_MICROARCH.md, HBM section); the LAST dispatch of
-every kernel is used (the profiled decode step / the encode of the archive).  FETCH_SIZE is doubled only for kernels
+every kernel is used (the serialised profiling step of the decode / the encode of the archive).  FETCH_SIZE is doubled only for kernels
 whose reads are known to be 16-byte wide streams (the gfx950 "half of wide reads" behaviour, calibrated on
 zk_k_xxh64, which reads exactly the archive's decompressed bytes).
 """
@@ -46,8 +46,10 @@ def main():
     fdir, wdir, workload = sys.argv[1:4]
     outp = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(__file__), "..", "profiles",
                                                               "pmc_traffic.json")
-    _, fetch = last_per_kernel(fdir, "FETCH_SIZE")
-    _, write = last_per_kernel(wdir, "WRITE_SIZE")
+    # LAST dispatch: bench.py ends with its per-kernel-timing steps, which run every kernel alone on the device; in the
+    # earlier steps huf and fse overlap and the (device-wide) L2 counters of one dispatch include the other's traffic
+    fetch, _ = last_per_kernel(fdir, "FETCH_SIZE")
+    write, _ = last_per_kernel(wdir, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         corr = WIDE.get(k, 1.0)
@@ -55,7 +57,7 @@ def main():
         kernels[k] = {"fetch_kib": fk, "write_kib": wk, "fetch_correction": corr,
                       "hbm_bytes": int((fk * corr + wk) * 1024)}
     doc = {"workload": workload,
-           "note": "per launch (largest dispatch of each kernel); FETCH_SIZE x2 only where the access pattern was "
+           "note": "per launch (last dispatch of each kernel = the serialised per-kernel-timing step of bench.py); FETCH_SIZE x2 only where the access pattern was "
                    "calibrated as wide (zk_k_xxh64); others uncorrected lower bounds",
            "kernels": kernels}
     with open(outp, "w") as f:
