@@ -146,7 +146,8 @@ extern "C" int zk_sim_decode(const uint8_t *comp, const uint64_t *c_off, const u
                         for (uint32_t q0 = ts; q0 < te; q0 += ZK_EXEC_SLOT) {                // "lane per slot"
                             const uint32_t nb = te - q0 < ZK_EXEC_SLOT ? te - q0 : ZK_EXEC_SLOT;
                             uint32_t sw[ZK_EXEC_SLOT];
-                            zk_exec_slot_words(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, sw);
+                            if (!zk_exec_slot_words_fast(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, sw))
+                                zk_exec_slot_words(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, sw);
                             for (uint32_t k = 0; k < nb; k++) srcmap[q0 - ts + k] = sw[k];
                         }
                         const uint32_t mbase = ZK_SRC_BIAS + ts, span = te - ts;

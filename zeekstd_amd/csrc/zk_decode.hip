@@ -411,7 +411,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                 const uint32_t nb = q0 >= te ? 0u : te - q0 < (uint32_t)ZK_EXEC_B ? te - q0 : (uint32_t)ZK_EXEC_B;
                 uint32_t sw[ZK_EXEC_B];
                 if (nb) {
-                    zk_exec_slot_words(S, slot_seq[tid], q0, nb, sw);
+                    if (!zk_exec_slot_words_fast(S, slot_seq[tid], q0, nb, sw)) zk_exec_slot_words(S, slot_seq[tid], q0, nb, sw);
 #pragma unroll
                     for (int k = 0; k < ZK_EXEC_B; k += 4)
                         *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(sw[k], sw[k + 1], sw[k + 2], sw[k + 3]);

@@ -956,6 +956,34 @@ ZK_HD void zk_exec_slot_seq(const ZkSeq &e, uint32_t q, ZkSlotCur &c)
     c.r = r;
 }
 
+// Fast form of zk_exec_slot_words for slots that contain no byte of a match overlapping its own output
+// (offset < match length): there both parts of a sequence are affine in q (literal: litw + q, match: BIAS - off + q),
+// 5 instructions per byte instead of 9.  Returns false when such a match was met: the caller falls back to
+// zk_exec_slot_words (rare outside run-length-like data).
+ZK_HD bool zk_exec_slot_words_fast(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t nb, uint32_t *sw)
+{
+    ZkSeq e = S[i];
+    uint32_t end = e.out_end, ms = e.out_end - e.ml, litw = (ZK_SRC_LIT | e.lit_end) - ms, mw = ZK_SRC_BIAS - e.off;
+    bool ovl = e.off < e.ml, hit = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) {
+        const uint32_t q = q0 + k;
+        if (k < nb) {
+            if (q >= end) {
+                e = S[++i];
+                end = e.out_end; ms = e.out_end - e.ml; litw = (ZK_SRC_LIT | e.lit_end) - ms; mw = ZK_SRC_BIAS - e.off;
+                ovl = e.off < e.ml;
+            }
+            const bool m = q >= ms;
+            sw[k] = (m ? mw : litw) + q;
+            hit |= m & ovl;
+        } else sw[k] = ZK_SRC_LIT;
+    }
+    return !hit;
+}
+
 // Source words of the bytes [q0, q0 + nb) (nb <= 16) given the staged sequence i that covers q0.
 // Every sequence covers >= 3 bytes (ML base), so at most one boundary is crossed per byte.
 ZK_HD void zk_exec_slot_words(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t nb, uint32_t *sw)
