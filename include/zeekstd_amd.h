@@ -101,6 +101,18 @@ int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, c
  * seek at a time, lib/src/decode.rs:402-437): decode archive frames d_ids[0..count) (uint32, any order, repeats allowed) of a
  * device-resident archive; frame d_ids[i] lands at d_dst + d_out_off[i], d_out_off being the count + 1 prefix sums of the
  * selected frames' decompressed sizes (uint64).  d_c_off / d_d_off are the archive's full n+1 prefix arrays. */
+/* Decode with a raw-content prefix (patch mode): what the reference does with ZSTD_DCtx_refPrefix before the first
+ * frame and again after every frame end (lib/src/decode.rs:212-214, 248-255) -- every frame of the batch sees the
+ * same prefix right before its first byte and a match may start up to prefix_len bytes before the frame.  With a
+ * prefix an offset is bounded by availability only (libzstd's ZSTD_execSequence), not by the frame's window.
+ * prefix_len may not exceed 2^30 - 2^27 bytes (-16 window_too_large otherwise); prefix_len == 0 is the plain call. */
+int zk_decode_frames_prefix_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off,
+                                const void *d_d_off, uint32_t first, uint32_t count, const void *d_prefix, uint64_t prefix_len,
+                                void *d_dst, uint64_t dst_cap, int verify, void *d_frame_status, void *stream);
+int zk_decode_frames_prefix(zk_engine *e, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off,
+                            const uint64_t *d_off, uint32_t first, uint32_t count, const uint8_t *prefix, uint64_t prefix_len,
+                            uint8_t *dst, uint64_t dst_cap, int verify, int32_t *frame_status);
+
 int zk_decode_frame_list_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off, const void *d_d_off,
                              const void *d_ids, const void *d_out_off, uint32_t count, void *d_dst, uint64_t dst_cap,
                              int verify, void *d_frame_status, void *stream);

@@ -58,6 +58,12 @@ def load(which="system"):
         l.ZSTD_compressStream2.argtypes = [C.c_void_p, C.POINTER(OutBuf), C.POINTER(InBuf), C.c_int]
         l.ZSTD_decompressStream.restype = C.c_size_t
         l.ZSTD_decompressStream.argtypes = [C.c_void_p, C.POINTER(OutBuf), C.POINTER(InBuf)]
+        l.ZSTD_CCtx_refPrefix.restype = C.c_size_t
+        l.ZSTD_CCtx_refPrefix.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        l.ZSTD_DCtx_refPrefix.restype = C.c_size_t
+        l.ZSTD_DCtx_refPrefix.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        l.ZSTD_DCtx_setParameter.restype = C.c_size_t
+        l.ZSTD_DCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
         l.ZSTD_isError.restype = C.c_uint
         l.ZSTD_isError.argtypes = [C.c_size_t]
         l.ZSTD_getErrorName.restype = C.c_char_p
@@ -82,14 +88,19 @@ def _chk(l, r):
 
 
 def encode_seekable_frames(data: bytes, frame_size: int, level: int = 1, checksum: bool = False,
-                           which: str = "system"):
+                           which: str = "system", prefix: bytes = None, window_log: int = 0):
     """Reference Encoder loop (Uncompressed(frame_size) policy). Returns (payload bytes, [(c,d)...]).
 
-    An empty input yields one empty frame (Encoder::finish always calls end_frame, encode.rs:755-757)."""
+    An empty input yields one empty frame (Encoder::finish always calls end_frame, encode.rs:755-757).
+    prefix: referenced at the start of every frame (encode.rs:334-338); window_log: ZSTD_c_windowLog, what the CLI
+    sets so that the window covers the prefix (cli/src/compress.rs:31-37)."""
     l = load(which)
     cctx = l.ZSTD_createCCtx()
     _chk(l, l.ZSTD_CCtx_setParameter(cctx, 100, level))
     _chk(l, l.ZSTD_CCtx_setParameter(cctx, 201, int(checksum)))
+    if window_log:
+        _chk(l, l.ZSTD_CCtx_setParameter(cctx, 101, window_log))
+    pbuf = C.create_string_buffer(bytes(prefix), len(prefix)) if prefix else None
     data = bytes(data)
     src = C.create_string_buffer(data, len(data)) if data else C.create_string_buffer(1)
     base = C.addressof(src)
@@ -104,6 +115,8 @@ def encode_seekable_frames(data: bytes, frame_size: int, level: int = 1, checksu
         d = min(frame_size, n - pos)
         c = 0
         inb = InBuf(base + pos, d, 0)
+        if pbuf is not None:                            # encode.rs:334-338
+            _chk(l, l.ZSTD_CCtx_refPrefix(cctx, C.addressof(pbuf), len(prefix)))
         while inb.pos < d:                              # encode.rs:340-346
             outb = OutBuf(C.addressof(ob), CSTREAM_OUT, 0)
             _chk(l, l.ZSTD_compressStream2(cctx, C.byref(outb), C.byref(inb), 0))
@@ -124,10 +137,16 @@ def encode_seekable_frames(data: bytes, frame_size: int, level: int = 1, checksu
     return bytes(out), frames
 
 
-def decode_stream(comp: bytes, expect: int = -1, which: str = "system") -> bytes:
-    """Reference Decoder hot loop over a whole payload (concatenated frames; skippable frames skipped)."""
+def decode_stream(comp: bytes, expect: int = -1, which: str = "system", prefix: bytes = None, window_log_max: int = 0) -> bytes:
+    """Reference Decoder hot loop over a whole payload (concatenated frames; skippable frames skipped).
+    prefix: referenced before the first frame and again after every frame end (decode.rs:212-214, 248-255)."""
     l = load(which)
     dctx = l.ZSTD_createDCtx()
+    if window_log_max:
+        _chk(l, l.ZSTD_DCtx_setParameter(dctx, 100, window_log_max))     # cli/src/decompress.rs:56
+    pbuf = C.create_string_buffer(bytes(prefix), len(prefix)) if prefix else None
+    if pbuf is not None:
+        _chk(l, l.ZSTD_DCtx_refPrefix(dctx, C.addressof(pbuf), len(prefix)))
     comp = bytes(comp)
     src = C.create_string_buffer(comp, len(comp)) if comp else C.create_string_buffer(1)
     base = C.addressof(src)
@@ -140,8 +159,11 @@ def decode_stream(comp: bytes, expect: int = -1, which: str = "system") -> bytes
             inb = InBuf(base + pos, take, 0)
             while inb.pos < take:                       # decode.rs:242-256
                 outb = OutBuf(C.addressof(ob), DSTREAM_OUT, 0)
-                _chk(l, l.ZSTD_decompressStream(dctx, C.byref(outb), C.byref(inb)))
+                r = _chk(l, l.ZSTD_decompressStream(dctx, C.byref(outb), C.byref(inb)))
                 out += ob.raw[:outb.pos]
+                if r == 0 and pbuf is not None:         # frame end: decode.rs:248-255
+                    _chk(l, l.ZSTD_DCtx_reset(dctx, 1))
+                    _chk(l, l.ZSTD_DCtx_refPrefix(dctx, C.addressof(pbuf), len(prefix)))
             pos += take
         while True:                                     # drain what is still buffered inside the DCtx
             inb = InBuf(base, 0, 0)

@@ -41,6 +41,9 @@ def lib():
         l.zko_frame_decode.restype = C.c_int64
         l.zko_frame_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                        C.POINTER(C.c_size_t), C.c_int, C.POINTER(FrameStats)]
+        l.zko_frame_decode_prefix.restype = C.c_int64
+        l.zko_frame_decode_prefix.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                              C.POINTER(C.c_size_t), C.c_int, C.POINTER(FrameStats), C.c_char_p, C.c_size_t]
         l.zko_gen_text.restype = None
         l.zko_gen_text.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
         l.zko_gen_chunks.restype = None
@@ -130,13 +133,18 @@ class OracleError(Exception):
         self.code = code
 
 
-def frame_decode(src: bytes, dst_cap: int, verify: bool = True, want_stats: bool = False):
-    """Decode ONE frame at the start of src. Returns (decoded bytes, consumed[, stats])."""
+def frame_decode(src: bytes, dst_cap: int, verify: bool = True, want_stats: bool = False, prefix: bytes = None):
+    """Decode ONE frame at the start of src. Returns (decoded bytes, consumed[, stats]).
+    prefix: raw-content prefix referenced for the frame (ZSTD_DCtx_refPrefix semantics)."""
     src = bytes(src)
     out = C.create_string_buffer(max(dst_cap, 1))
     used = C.c_size_t()
     st = FrameStats()
-    r = lib().zko_frame_decode(src, len(src), out, dst_cap, C.byref(used), int(verify), C.byref(st))
+    if prefix:
+        prefix = bytes(prefix)
+        r = lib().zko_frame_decode_prefix(src, len(src), out, dst_cap, C.byref(used), int(verify), C.byref(st), prefix, len(prefix))
+    else:
+        r = lib().zko_frame_decode(src, len(src), out, dst_cap, C.byref(used), int(verify), C.byref(st))
     if r < 0:
         raise OracleError(-r)
     if want_stats:

@@ -384,9 +384,12 @@ static i64 setup_seq_table(fse_table *t, int *valid, int mode, const u8 *src, si
     return 0;
 }
 
-/* decode one compressed block body into dst+pos.  frame_start = dst (no dictionary). */
+/* decode one compressed block body into dst+pos.  frame_start = dst; prefix (raw-content dictionary,
+ * ZSTD_DCtx_refPrefix: lib/src/decode.rs:212-214) sits virtually right before it: a match may start up to plen
+ * bytes before the frame.  With a prefix only availability bounds an offset (what libzstd's ZSTD_execSequence
+ * checks); without one the frame's window does too. */
 static i64 decode_compressed_block(dstate *st, const u8 *src, size_t len, u8 *dst, size_t pos, size_t cap,
-                                   u32 window, zko_frame_stats *fs)
+                                   u32 window, zko_frame_stats *fs, const u8 *prefix, size_t plen)
 {
     const u8 *lit; size_t nlit;
     i64 r = decode_literals(st, src, len, &nlit, &lit, fs);
@@ -444,10 +447,12 @@ static i64 decode_compressed_block(dstate *st, const u8 *src, size_t len, u8 *ds
         if (lpos + ll > nlit) return ERR(ZKO_E_CORRUPTION);
         if (out + ll + ml > cap) return ERR(ZKO_E_DST_TOO_SMALL);
         memcpy(dst + out, lit + lpos, ll); out += ll; lpos += ll;
-        if (off > out || off > window) return ERR(ZKO_E_CORRUPTION);
+        if (off > out + plen || (plen == 0 && off > window)) return ERR(ZKO_E_CORRUPTION);
         if (fs && off > fs->max_offset) fs->max_offset = off;
-        const u8 *m = dst + out - off;
-        for (u32 k = 0; k < ml; k++) dst[out + k] = m[k];
+        for (u32 k = 0; k < ml; k++) {
+            const size_t q = out + k;                       /* source = q - off, possibly inside the prefix */
+            dst[q] = q >= off ? dst[q - off] : prefix[plen - (off - q)];
+        }
         out += ml;
     }
     if (b.bitpos != 0) return ERR(ZKO_E_CORRUPTION);
@@ -463,9 +468,19 @@ static i64 decode_compressed_block(dstate *st, const u8 *src, size_t len, u8 *ds
  * Returns decompressed size (>=0) or -ZSTD_ErrorCode.  *consumed = bytes of src used.
  * verify != 0: check the content checksum when present.
  */
+i64 zko_frame_decode_prefix(const u8 *src, size_t src_size, u8 *dst, size_t dst_cap, size_t *consumed,
+                            int verify, zko_frame_stats *fs, const u8 *prefix, size_t plen);
 i64 zko_frame_decode(const u8 *src, size_t src_size, u8 *dst, size_t dst_cap, size_t *consumed,
                      int verify, zko_frame_stats *fs)
 {
+    return zko_frame_decode_prefix(src, src_size, dst, dst_cap, consumed, verify, fs, NULL, 0);
+}
+
+/* the same with a raw-content prefix referenced for this frame (ZSTD_DCtx_refPrefix semantics) */
+i64 zko_frame_decode_prefix(const u8 *src, size_t src_size, u8 *dst, size_t dst_cap, size_t *consumed,
+                            int verify, zko_frame_stats *fs, const u8 *prefix, size_t plen)
+{
+    if (!prefix) plen = 0;
     if (fs) memset(fs, 0, sizeof *fs);
     if (src_size < 4) return ERR(ZKO_E_SRC_SIZE_WRONG);
     u32 magic = rd32(src);
@@ -528,7 +543,7 @@ i64 zko_frame_decode(const u8 *src, size_t src_size, u8 *dst, size_t dst_cap, si
         } else {
             if (bsize > block_max || bsize < 2) { rc = ERR(ZKO_E_CORRUPTION); break; }
             if (p + bsize > src_size) { rc = ERR(ZKO_E_SRC_SIZE_WRONG); break; }
-            i64 r = decode_compressed_block(st, src + p, bsize, dst, out, dst_cap, (u32)(window > 0xFFFFFFFFu ? 0xFFFFFFFFu : window), fs);
+            i64 r = decode_compressed_block(st, src + p, bsize, dst, out, dst_cap, (u32)(window > 0xFFFFFFFFu ? 0xFFFFFFFFu : window), fs, prefix, plen);
             if (r < 0) { rc = r; break; }
             if ((u64)r > block_max) { rc = ERR(ZKO_E_CORRUPTION); break; }
             out += (size_t)r; p += bsize; if (fs) fs->n_comp++;

@@ -64,6 +64,33 @@ def load_goldens():
 GOLDENS = load_goldens()
 
 
+class PrefixGolden(Golden):
+    """Archive whose frames were compressed against a raw-content prefix (tools/make_prefix_goldens.py)."""
+
+    def prefix(self):
+        from oracle import zko
+        pre = zko.make_input(self.meta["prefix_recipe"])
+        assert len(pre) == self.meta["prefix_len"] and f"{zko.xxh64(pre):016x}" == self.meta["prefix_xxh64"]
+        return pre
+
+
+def load_prefix_goldens():
+    gdir = os.path.join(ROOT, "tests", "golden")
+    with open(os.path.join(gdir, "prefix_archives.json")) as f:
+        idx = json.load(f)
+    with open(os.path.join(gdir, "prefix_archives.bin"), "rb") as f:
+        blob = f.read()
+    return [PrefixGolden(m, blob) for m in idx["cases"]]
+
+
+PREFIX_GOLDENS = load_prefix_goldens()
+
+
+@pytest.fixture(params=PREFIX_GOLDENS, ids=[g.name for g in PREFIX_GOLDENS])
+def prefix_golden(request):
+    return request.param
+
+
 @pytest.fixture(params=GOLDENS, ids=[g.name for g in GOLDENS])
 def golden(request):
     return request.param
@@ -91,6 +118,9 @@ def sim_lib():
         if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
         l = C.CDLL(so)
+        l.zk_sim_decode_prefix.restype = C.c_int
+        l.zk_sim_decode_prefix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_void_p, C.c_uint64]
         l.zk_sim_decode.restype = C.c_int
         l.zk_sim_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int]
@@ -98,7 +128,7 @@ def sim_lib():
     return _SIM
 
 
-def sim_decode(comp, frames, first=0, count=None, B=16, CH=1024):
+def sim_decode(comp, frames, first=0, count=None, B=16, CH=1024, prefix=None):
     c, d = offsets_from_frames(frames)
     n = len(frames)
     if count is None:
@@ -107,8 +137,13 @@ def sim_decode(comp, frames, first=0, count=None, B=16, CH=1024):
     out = np.zeros(out_len + 1, np.uint8)
     st = np.zeros(max(count, 1), np.int32)
     buf = np.frombuffer(bytes(comp) + b"\0" * 8, np.uint8)
-    rc = sim_lib().zk_sim_decode(buf.ctypes.data, c.ctypes.data, d.ctypes.data, first, count, out.ctypes.data,
-                                 st.ctypes.data, B, CH)
+    if prefix:
+        pre = np.frombuffer(bytes(prefix), np.uint8)
+        rc = sim_lib().zk_sim_decode_prefix(buf.ctypes.data, c.ctypes.data, d.ctypes.data, first, count, out.ctypes.data,
+                                            st.ctypes.data, B, CH, pre.ctypes.data, len(pre))
+    else:
+        rc = sim_lib().zk_sim_decode(buf.ctypes.data, c.ctypes.data, d.ctypes.data, first, count, out.ctypes.data,
+                                     st.ctypes.data, B, CH)
     return rc, out[:out_len].tobytes(), st[:count]
 
 

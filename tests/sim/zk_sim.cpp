@@ -13,9 +13,21 @@
 static const uint32_t LLV[36] = ZK_LL_TABLE;
 static const uint32_t MLV[53] = ZK_ML_TABLE;
 
+extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
+                                    uint32_t count, uint8_t *dst, int32_t *status, int exec_b, int exec_chunk,
+                                    const uint8_t *prefix, uint64_t plen);
 extern "C" int zk_sim_decode(const uint8_t *comp, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
                              uint32_t count, uint8_t *dst, int32_t *status, int exec_b, int exec_chunk)
 {
+    return zk_sim_decode_prefix(comp, c_off, d_off, first, count, dst, status, exec_b, exec_chunk, nullptr, 0);
+}
+
+extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
+                                    uint32_t count, uint8_t *dst, int32_t *status, int exec_b, int exec_chunk,
+                                    const uint8_t *prefix, uint64_t plen)
+{
+    if (!prefix) plen = 0;
+    const bool PFX = plen != 0;
     std::vector<ZkFrameInfo> infos(count);
     std::vector<ZkFrameBase> bases(count);
     uint64_t nb = 0, ns = 0, nl = 0;
@@ -123,7 +135,8 @@ extern "C" int zk_sim_decode(const uint8_t *comp, const uint64_t *c_off, const u
                                 ZkSeq s = sq[idx];
                                 uint32_t off = zk_rep_resolve(s.off, rep);
                                 uint32_t mstart = s.out_end - s.ml;
-                                if (off == 0 || pos + mstart < off || off > fi.window) bad = 1;
+                                if (PFX ? (off == 0 || pos + mstart + plen < off) : (off == 0 || pos + mstart < off || off > fi.window)) bad = 1;
+                                if (off >= ZK_SRC_BIAS) bad = 1;
                                 st[i].out_end = s.out_end; st[i].ml = s.ml; st[i].off = off; st[i].lit_end = s.lit_end;
                             } else { st[i].out_end = out_size; st[i].ml = 0; st[i].off = 1; st[i].lit_end = b.lit_regen; }
                         }
@@ -154,7 +167,11 @@ extern "C" int zk_sim_decode(const uint8_t *comp, const uint64_t *c_off, const u
                         for (uint32_t q = ts; q < te; q++) {                                 // origins + gathers
                             uint32_t s = srcmap[q - ts];
                             while (s - mbase < span) s = srcmap[s - mbase];
-                            tile[q - ts] = (s & ZK_SRC_LIT) ? l[(s & lit_mask)] : bout[(int64_t)(int32_t)(s - ZK_SRC_BIAS)];
+                            if (s & ZK_SRC_LIT) tile[q - ts] = l[(s & lit_mask)];
+                            else {
+                                const int64_t rel = (int64_t)pos + (int32_t)(s - ZK_SRC_BIAS);
+                                tile[q - ts] = PFX && rel < 0 ? prefix[(int64_t)plen + rel] : out[rel];
+                            }
                         }
                         memcpy(bout + ts, tile.data(), te - ts);                             // commit the tile after all lanes ran
                         if (jn) prev_end = st[jn - 1].out_end;

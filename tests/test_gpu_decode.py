@@ -5,7 +5,7 @@ with the reference's Encoder loop.  Mirrors the scenarios of the reference's own
 import numpy as np
 import pytest
 
-from conftest import GOLDENS, offsets_from_frames
+from conftest import GOLDENS, PREFIX_GOLDENS, offsets_from_frames
 from oracle import zko
 from oracle import libzstd_ref as Z
 
@@ -197,3 +197,27 @@ def test_two_batches_in_flight(engine):
     # the synchronous path still works afterwards
     out, st = engine.decode_frames(good.comp + b"\0" * 8, *good.offsets(), verify=True)
     assert out == good.input() and not st.any()
+
+
+def test_prefix_goldens_bit_exact(engine, prefix_golden):
+    # zk_decode_frames_prefix: libzstd-1.5.7 archives made with ZSTD_CCtx_refPrefix per frame (encode.rs:334-338),
+    # incl. the CLI's patch shape (1 MiB prefix, windowLog 21, long-distance matching)
+    g = prefix_golden
+    c, d = g.offsets()
+    out, st = engine.decode_frames(g.comp + b"\0" * 8, c, d, verify=True, prefix=g.prefix())
+    assert not st.any()
+    assert out == g.input()
+    # a frame range in the middle
+    if len(g.frames) >= 3:
+        out, st = engine.decode_frames(g.comp + b"\0" * 8, c, d, first=1, count=2, verify=True, prefix=g.prefix())
+        assert out == g.input()[int(d[1]):int(d[3])] and not st.any()
+
+
+def test_prefix_missing_or_wrong_is_an_error(engine):
+    g = next(x for x in PREFIX_GOLDENS if x.name == "pfx_text_l1")
+    c, d = g.offsets()
+    _, st = engine.decode_frames(g.comp + b"\0" * 8, c, d, verify=True, raise_on_error=False)
+    assert st[0] in (20, 22)                                      # reaches before the frame: corruption without a prefix
+    wrong = bytearray(g.prefix()); wrong[-100] ^= 1
+    _, st = engine.decode_frames(g.comp + b"\0" * 8, c, d, verify=True, raise_on_error=False, prefix=bytes(wrong))
+    assert 22 in list(st)                                         # decodes, but some frame's checksum cannot match

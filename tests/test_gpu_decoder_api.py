@@ -195,11 +195,55 @@ def test_tiny_reads_and_streaming(eng):  # lib.rs:82-134: every call is partial 
     assert bytes(out) == INPUT
 
 
-def test_prefix_is_rejected_not_ignored(eng):
-    d = dec(new_seekable(), eng)
+def _prefix_seekable(prefix, data, frame_size, level=1, checksum=True):
+    comp, frames = Z.encode_seekable_frames(data, frame_size, level, checksum, "system", prefix=prefix)
+    st = SeekTable.new()
+    for c, d in frames:
+        st.log_frame(c, d)
+    return comp + st.to_bytes()
+
+
+def test_patch_cycle_decode_half(eng):   # lib.rs:202-263 (test_patch_cycle): decompress_with_prefix in partial calls
+    old = zko.gen_text(60000, 7)
+    new = old[:20000] + b"PATCHED" + old[20000:45000] + zko.gen_text(3000, 8) + old[45000:]
+    d = dec(_prefix_seekable(old, new, 4000), eng)
+    step = max(1, len(new) // 500)
+    out = bytearray()
+    buf = bytearray(step)
+    while True:
+        n = d.decompress_with_prefix(buf, old)
+        if n == 0:
+            break
+        out += buf[:n]
+    assert bytes(out) == new
+    # the wrong prefix (or none) must not pass silently: the frames carry checksums
+    d.reset()
     with pytest.raises(zk.Error) as e:
-        d.decompress_with_prefix(bytearray(10), b"some prefix")
-    assert e.value.code == -40          # parameter_unsupported: patch mode is out of scope
+        d.decompress_with_prefix(bytearray(len(new)), old[:-1] + b"x")
+    assert e.value.code in (-20, -22)
+    d.reset()
+    with pytest.raises(zk.Error) as e:
+        d.decompress(bytearray(len(new)))
+    assert e.value.code in (-20, -22)
+
+
+def test_prefix_with_seeks(eng):         # every frame sees the prefix again (decode.rs:248-255), also after set_offset
+    old = zko.gen_text(50000, 9)
+    new = old[10000:] + old[:10000]
+    d = dec(_prefix_seekable(old, new, 3000), eng)
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        a = int(rng.integers(0, len(new) - 1))
+        b = min(len(new), a + int(rng.integers(1, 9000)))
+        d.set_offset_limit(len(new)); d.set_offset(a); d.set_offset_limit(b)
+        buf = bytearray(b - a)
+        got = 0
+        while got < b - a:
+            n = d.decompress_with_prefix(memoryview(buf)[got:], old)
+            assert n > 0
+            got += n
+        assert bytes(buf) == new[a:b]
+        assert d.decompress_with_prefix(bytearray(8), old) == 0
 
 
 def test_checksum_of_cut_frame_is_not_verified(eng):    # doc decode.rs:425-427

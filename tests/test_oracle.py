@@ -107,3 +107,23 @@ def test_oracle_vs_live_libzstd(level):
             out, used = zko.frame_decode(comp[pos:pos + c], dd, True)
             assert used == c and out == d[dpos:dpos + dd]
             pos += c; dpos += dd
+
+
+def test_oracle_decodes_prefix_goldens(prefix_golden):
+    # patch mode: the same prefix is referenced for every frame (decode.rs:212-214, 248-255)
+    g = prefix_golden
+    data, pre = g.input(), g.prefix()
+    pos, out = 0, b""
+    for c, d in g.frames:
+        o, used = zko.frame_decode(g.comp[pos:pos + c], d, True, prefix=pre)
+        assert used == c and len(o) == d
+        out += o
+        pos += c
+    assert out == data
+    # without the prefix the first frame that reaches into it must fail (offset beyond the produced bytes)
+    if g.meta["length"] < g.meta["length_without_prefix"] // 2:
+        with pytest.raises(zko.OracleError):
+            pos = 0
+            for c, d in g.frames:
+                zko.frame_decode(g.comp[pos:pos + c], d, True)
+                pos += c

@@ -67,3 +67,10 @@ def test_sim_vs_live_libzstd(level):
         comp, frames = Z.encode_seekable_frames(d, fs, level, fs != 65536, "system")
         rc, out, st = sim_decode(comp, frames)
         assert rc == 0 and out == d
+
+
+def test_sim_prefix_goldens(prefix_golden):
+    g = prefix_golden
+    rc, out, st = sim_decode(g.comp, g.frames, prefix=g.prefix())
+    assert rc == 0 and not st.any()
+    assert out == g.input()

@@ -40,6 +40,8 @@ _sig = {
     "zk_engine_kernel_name": (C.c_char_p, [C.c_int]),
     "zk_engine_kernel_times": (C.c_int, [_P, _P, C.c_int]),
     "zk_decode_frames": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_int, _P]),
+    "zk_decode_frames_prefix": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, _P, C.c_uint64, C.c_int, _P]),
+    "zk_decode_frames_prefix_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, _P, C.c_uint64, C.c_int, _P, _P]),
     "zk_decode_frames_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_int, _P, _P]),
     "zk_decode_submit_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_int, _P, C.POINTER(C.c_int)]),
     "zk_decode_wait": (C.c_int, [_P, C.c_int]),

@@ -300,9 +300,19 @@ class Decoder:                         # decode.rs:117-579
         n = len(buf)
         arr = (C.c_uint8 * n).from_buffer(buf) if n else None
         out = C.c_size_t()
-        p = bytes(prefix) if prefix is not None else None
+        p = self._hold_prefix(prefix)
         _chk(lib.zk_decoder_decompress_with_prefix(self._h, arr, n, p, len(p) if p else 0, C.byref(out)))
         return out.value
+
+    def _hold_prefix(self, prefix):
+        """The native Decoder keeps only the address of the prefix (like libzstd, decode.rs:201 lifetime bound): the
+        same Python object maps to the same immutable copy for as long as this Decoder lives."""
+        if prefix is None or len(prefix) == 0:
+            return None
+        if getattr(self, "_prefix_src", None) is not prefix:
+            self._prefix_src = prefix
+            self._prefix_copy = prefix if isinstance(prefix, bytes) else bytes(prefix)
+        return self._prefix_copy
 
     def read(self, n: int) -> bytes:               # impl io::Read
         buf = bytearray(n)

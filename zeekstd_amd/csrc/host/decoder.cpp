@@ -46,6 +46,7 @@ Decoder::Decoder(Decoder &&o) noexcept
       cache_count_(o.cache_count_), cache_d_start_(o.cache_d_start_), cache_d_end_(o.cache_d_end_), last_end_(o.last_end_),
       submissions_(o.submissions_)
 {
+    cache_prefix_ = o.cache_prefix_; cache_prefix_len_ = o.cache_prefix_len_;
     o.engine_ = nullptr; o.owns_engine_ = false;
 }
 
@@ -55,7 +56,7 @@ void Decoder::check_offset(uint64_t offset) const                             //
 }
 
 // Decode the frames that cover [offset_, want_end) into the host cache with one engine submission.
-void Decoder::fill_cache(uint64_t want_end)
+void Decoder::fill_cache(uint64_t want_end, const uint8_t *prefix, size_t prefix_len)
 {
     const uint32_t first = seek_table_.frame_index_decomp(offset_);          // decode.rs:207
     uint32_t last = seek_table_.frame_index_decomp(want_end - 1);
@@ -76,8 +77,11 @@ void Decoder::fill_cache(uint64_t want_end)
     for (uint32_t i = 0; i <= count; i++) { c[i] = E[first + i].c_offset - c_lo; d[i] = E[first + i].d_offset - d_lo; }
     cache_.resize((size_t)(d_hi - d_lo) + 1);
     std::vector<int32_t> status(count);
-    int rc = zk_decode_frames(engine_, comp_buf_.data(), c_hi - c_lo, c.data(), d.data(), 0, count, cache_.data(), d_hi - d_lo,
-                              verify_ ? 1 : 0, status.data());
+    // every frame of the submission sees the prefix right before its first byte: ref_prefix before the first frame
+    // and again after each frame end, decode.rs:212-214, 248-255
+    int rc = zk_decode_frames_prefix(engine_, comp_buf_.data(), c_hi - c_lo, c.data(), d.data(), 0, count, prefix, prefix ? prefix_len : 0,
+                                     cache_.data(), d_hi - d_lo, verify_ ? 1 : 0, status.data());
+    cache_prefix_ = prefix; cache_prefix_len_ = prefix ? prefix_len : 0;
     submissions_++;
     if (rc != 0) {
         if (rc <= -1000) throw Error::from_engine_code(rc, zk_engine_last_hip_error(engine_));
@@ -93,10 +97,15 @@ void Decoder::fill_cache(uint64_t want_end)
     read_compressed_ += c_hi - c_lo;
 }
 
-size_t Decoder::decompress_with_prefix(uint8_t *buf, size_t len, const uint8_t *prefix, size_t)
+size_t Decoder::decompress_with_prefix(uint8_t *buf, size_t len, const uint8_t *prefix, size_t prefix_len)
 {
-    if (prefix) throw Error::zstd(40 /* parameter_unsupported: prefix/patch mode is not on the GPU path yet */);
+    if (!prefix) prefix_len = 0;
     if (read_compressed_ == 0) { cache_count_ = 0; cache_d_start_ = cache_d_end_ = 0; }   // fresh decode state, decode.rs:206-218
+    // frames are decoded ahead of the reads; the ones in the cache were decoded with the prefix of the call that
+    // filled it.  A different prefix (address or length: like libzstd, only the reference is kept) drops them.  The
+    // reference applies a new prefix at the next frame start (decode.rs:248-255); here a switch in the middle of a
+    // frame re-decodes that frame with the new one.
+    if (cache_count_ && (prefix != cache_prefix_ || prefix_len != cache_prefix_len_)) { cache_count_ = 0; cache_d_start_ = cache_d_end_ = 0; }
     size_t progress = 0;
     while (offset_ < offset_limit_ && progress < len) {                      // decode.rs:221
         if (!(cache_count_ && offset_ >= cache_d_start_ && offset_ < cache_d_end_)) {
@@ -105,7 +114,7 @@ size_t Decoder::decompress_with_prefix(uint8_t *buf, size_t len, const uint8_t *
             const bool sequential = cache_count_ && offset_ == cache_d_end_;
             if (sequential || len - progress >= batch_bytes_)
                 want = std::min<uint64_t>(offset_limit_, std::max<uint64_t>(want, offset_ + batch_bytes_));
-            fill_cache(want);
+            fill_cache(want, prefix, prefix_len);
         }
         size_t n = (size_t)std::min<uint64_t>({(uint64_t)(len - progress), offset_limit_ - offset_, cache_d_end_ - offset_});
         memcpy(buf + progress, cache_.data() + (offset_ - cache_d_start_), n);

@@ -191,7 +191,8 @@ public:
     Decoder(Decoder &&) noexcept;
     Decoder(const Decoder &) = delete;
 
-    // :201-270; prefix (patch mode) is not supported by the GPU path yet: a non-null prefix throws
+    // :201-270; prefix (patch mode): every frame sees the prefix right before its first byte (:212-214, 248-255);
+    // like libzstd only the reference is kept -- the buffer must stay unchanged while it is in use
     // Error::zstd(parameter_unsupported)
     size_t decompress_with_prefix(uint8_t *buf, size_t len, const uint8_t *prefix, size_t prefix_len);
     size_t decompress(uint8_t *buf, size_t len) { return decompress_with_prefix(buf, len, nullptr, 0); }   // :314
@@ -212,7 +213,8 @@ public:
 private:
     void check_offset(uint64_t offset) const;                                        // :439-445
     void reset_dctx();                                                               // :352-357
-    void fill_cache(uint64_t want_end);
+    void fill_cache(uint64_t want_end, const uint8_t *prefix, size_t prefix_len);
+    const uint8_t *cache_prefix_ = nullptr; size_t cache_prefix_len_ = 0;           // the prefix the cached frames were decoded with
     zk_engine *engine_ = nullptr;
     bool owns_engine_ = false;
     SeekTable seek_table_;

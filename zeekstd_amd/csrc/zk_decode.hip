@@ -320,12 +320,13 @@ __global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_predef(const uint8_t *
 //   5. a workgroup barrier orders the tiles.
 constexpr int ZK_EXEC_B = (int)ZK_EXEC_SLOT;
 
-template <int T>
+template <int T, bool PFX>
 __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
                                                const uint32_t *ids, const uint64_t *out_off,
                                                const ZkBlock *blocks, const ZkFrameBase *bases,
                                                ZkFrameInfo *infos, const ZkSeq *seqs,
-                                               const uint8_t *lit_scratch, uint8_t *dst)
+                                               const uint8_t *lit_scratch, uint8_t *dst,
+                                               const uint8_t *prefix, uint64_t plen)
 {
     constexpr int CAP = 2 * T;
     __shared__ __attribute__((aligned(16))) ZkSeq S[CAP + 1];
@@ -372,7 +373,11 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                         const uint4 s = reinterpret_cast<const uint4 *>(sq)[idx];      // out_end, ml, off, lit_end
                         const uint32_t off = zk_rep_resolve(s.z, rep);
                         const uint32_t mstart = s.x - s.y;
-                        if (off == 0 || pos + mstart < off || off > fi.window) bad = 1;
+                        // without a prefix an offset is bounded by the bytes produced so far and by the frame's window;
+                        // with one (ZSTD_DCtx_refPrefix: the prefix sits right before the frame) only by availability,
+                        // which is all libzstd's ZSTD_execSequence checks
+                        if (PFX ? (off == 0 || pos + mstart + plen < off) : (off == 0 || pos + mstart < off || off > fi.window)) bad = 1;
+                        if (off >= ZK_SRC_BIAS) bad = 1;     // source words carry positions down to -2^30 only
                         r = make_uint4(s.x, s.y, off, s.w);
                     } else r = make_uint4(out_size, 0, 1, b.lit_regen);
                     reinterpret_cast<uint4 *>(S)[i] = r;
@@ -434,6 +439,10 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                     for (int k = 0; k < ZK_EXEC_B; k++) {
                         const uint32_t s = sw[k];
                         const uint8_t *a = (s & ZK_SRC_LIT) ? lit + (s & lit_mask) : bout + (int64_t)(int32_t)(s - ZK_SRC_BIAS);
+                        if (PFX && !(s & ZK_SRC_LIT)) {      // a position before the frame's first byte lies in the prefix
+                            const int64_t rel = (int64_t)pos + (int32_t)(s - ZK_SRC_BIAS);
+                            if (rel < 0) a = prefix + plen + rel;
+                        }
                         if ((uint32_t)k >= nb) a = bout;     // harmless address for the bytes past the tile end
                         ob[k] = *a;
                     }
@@ -571,13 +580,17 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeq *seqs,
-                    const uint8_t *lit, uint8_t *dst)
+                    const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen)
 {
     // one workgroup per frame: the tile width trades bytes in flight per frame against workgroups per CU
     // (measured on 2 MiB frames: 2048 frames -> 256 lanes, 512 -> 512, 128 -> 1024)
-    if (count >= 1024) hipLaunchKernelGGL(zk_k_exec<256>, dim3(count), dim3(256), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst);
-    else if (count >= 256) hipLaunchKernelGGL(zk_k_exec<512>, dim3(count), dim3(512), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst);
-    else hipLaunchKernelGGL(zk_k_exec<1024>, dim3(count), dim3(1024), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst);
+#define ZK_EXEC_LAUNCH(TT, PP) hipLaunchKernelGGL((zk_k_exec<TT, PP>), dim3(count), dim3(TT), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst, prefix, plen)
+    if (prefix && plen) {
+        if (count >= 1024) ZK_EXEC_LAUNCH(256, true); else if (count >= 256) ZK_EXEC_LAUNCH(512, true); else ZK_EXEC_LAUNCH(1024, true);
+    } else {
+        if (count >= 1024) ZK_EXEC_LAUNCH(256, false); else if (count >= 256) ZK_EXEC_LAUNCH(512, false); else ZK_EXEC_LAUNCH(1024, false);
+    }
+#undef ZK_EXEC_LAUNCH
 }
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
                      ZkFrameInfo *infos, uint64_t *hashes)

@@ -933,6 +933,9 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
 //   source word: bit 31 set -> literal index (block-relative);  else block-relative history position + 2^30
 constexpr uint32_t ZK_SRC_LIT = 0x80000000u;
 constexpr uint32_t ZK_SRC_BIAS = 0x40000000u;
+// a raw-content prefix extends the history below the frame's first byte: positions down to -(2^30 - 2^27) stay
+// representable next to block-relative positions of frames up to 128 MiB in; larger frames reach less of it
+constexpr uint64_t ZK_MAX_PREFIX = (1ull << 30) - (1ull << 27);
 constexpr uint32_t ZK_EXEC_SLOT = 16;        // bytes per slot (one 16-B store per lane)
 constexpr uint32_t ZK_EXEC_LONG = 4;         // a sequence that starts more slots than this is marked by all lanes
 

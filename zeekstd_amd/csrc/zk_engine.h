@@ -30,6 +30,8 @@ struct zk_engine {
     int next_slot = 0;
     // staging for the host-pointer entry points
     zk_devbuf st_comp, st_off, st_dst, st_misc;
+    zk_devbuf st_prefix;                    // staged prefix of zk_decode_frames_prefix / zk_encode_frames_prefix, kept between calls
+    const void *st_prefix_src = nullptr; uint64_t st_prefix_len = 0, st_prefix_fp = 0;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool profiling = false;
     hipEvent_t ev_start[ZK_NKERNELS] = {}, ev_stop[ZK_NKERNELS] = {};

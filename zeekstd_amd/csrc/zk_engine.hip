@@ -131,7 +131,7 @@ extern "C" void zk_engine_destroy(zk_engine *e)
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
-    zk_devbuf *bufs[] = {&e->infos, &e->bases, &e->words, &e->blocks, &e->seqs, &e->lit, &e->infos2, &e->bases2, &e->words2, &e->blocks2, &e->seqs2, &e->lit2, &e->st_comp, &e->st_off, &e->st_dst, &e->st_misc,
+    zk_devbuf *bufs[] = {&e->infos, &e->bases, &e->words, &e->blocks, &e->seqs, &e->lit, &e->infos2, &e->bases2, &e->words2, &e->blocks2, &e->seqs2, &e->lit2, &e->st_prefix, &e->st_comp, &e->st_off, &e->st_dst, &e->st_misc,
                          &e->enc_a, &e->enc_b, &e->enc_c, &e->enc_d};
     for (zk_devbuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (e->h_words) (void)hipHostFree(e->h_words);
@@ -169,8 +169,11 @@ static zk_dec_ctx zk_dec_context(zk_engine *e, int slot, void *stream)
 // Enqueue the whole decode on the context's queues.  Blocks the host once, for the block / sequence / literal totals
 // that size the scratch (24 bytes, after the two cheapest kernels); returns with the rest still running.
 static int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const void *d_comp, const void *d_c_off, const void *d_d_off, uint32_t first, uint32_t count,
-                             const uint32_t *ids, const uint64_t *out_off, void *d_dst, int verify, void *d_frame_status)
+                             const uint32_t *ids, const uint64_t *out_off, void *d_dst, int verify, void *d_frame_status,
+                             const void *d_prefix = nullptr, uint64_t prefix_len = 0)
 {
+    // history positions are 32-bit words biased by 2^30 (zk_device.h): a frame plus its prefix must fit below that
+    if (d_prefix && prefix_len > ZK_MAX_PREFIX) return -(int)ZK_E_WINDOW_TOO_LARGE;
     hipStream_t st = c.st;
     const uint8_t *comp = (const uint8_t *)d_comp;
     const uint64_t *c_off = (const uint64_t *)d_c_off, *d_off = (const uint64_t *)d_d_off;
@@ -212,7 +215,7 @@ static int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const void *d_comp, co
         zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, seqs);
         ZK_HIP(hipStreamWaitEvent(st, c.ev_join, 0));
     }
-    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, ids, out_off, blocks, bases, infos, seqs, lit, (uint8_t *)d_dst); }
+    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, ids, out_off, blocks, bases, infos, seqs, lit, (uint8_t *)d_dst, (const uint8_t *)d_prefix, d_prefix ? prefix_len : 0); }
     // packed indexed output: out_off (count + 1 prefix sums) doubles as the d_off of the checksum kernel
     if (verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)d_dst, out_off ? out_off : d_off, out_off ? 0 : first, count, infos, nullptr); }
     { zk_kernel_timer t(e, ZK_K_STATUS, st); zk_launch_status(st, infos, count, (int32_t *)d_frame_status, words + 3); }
@@ -229,14 +232,15 @@ static int zk_decode_finish(zk_engine *e, zk_dec_ctx &c)
 }
 
 static int zk_decode_impl(zk_engine *e, const void *d_comp, const void *d_c_off, const void *d_d_off, uint32_t first, uint32_t count,
-                          const uint32_t *ids, const uint64_t *out_off, void *d_dst, int verify, void *d_frame_status, void *stream)
+                          const uint32_t *ids, const uint64_t *out_off, void *d_dst, int verify, void *d_frame_status, void *stream,
+                          const void *d_prefix = nullptr, uint64_t prefix_len = 0)
 {
     if (!e || (count && (!d_comp || !d_c_off || !d_d_off || !d_dst))) return ZK_ERR_ARGUMENT;
     if (count == 0) return 0;
     if (e->slot_busy[0]) return ZK_ERR_ARGUMENT;            // a submitted batch still owns context 0: zk_decode_wait first
     ZK_HIP(hipSetDevice(e->device));
     zk_dec_ctx c = zk_dec_context(e, 0, stream);
-    int rc = zk_decode_enqueue(e, c, d_comp, d_c_off, d_d_off, first, count, ids, out_off, d_dst, verify, d_frame_status);
+    int rc = zk_decode_enqueue(e, c, d_comp, d_c_off, d_d_off, first, count, ids, out_off, d_dst, verify, d_frame_status, d_prefix, prefix_len);
     if (rc) return rc;
     return zk_decode_finish(e, c);
 }
@@ -283,6 +287,15 @@ extern "C" int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t c
     return zk_decode_impl(e, d_comp, d_c_off, d_d_off, first, count, nullptr, nullptr, d_dst, verify, d_frame_status, stream);
 }
 
+extern "C" int zk_decode_frames_prefix_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off,
+                                           const void *d_d_off, uint32_t first, uint32_t count, const void *d_prefix, uint64_t prefix_len,
+                                           void *d_dst, uint64_t dst_cap, int verify, void *d_frame_status, void *stream)
+{
+    (void)comp_size; (void)dst_cap;
+    return zk_decode_impl(e, d_comp, d_c_off, d_d_off, first, count, nullptr, nullptr, d_dst, verify, d_frame_status, stream,
+                          prefix_len ? d_prefix : nullptr, prefix_len);
+}
+
 extern "C" int zk_decode_frame_list_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off, const void *d_d_off,
                                         const void *d_ids, const void *d_out_off, uint32_t count, void *d_dst, uint64_t dst_cap,
                                         int verify, void *d_frame_status, void *stream)
@@ -296,6 +309,28 @@ extern "C" int zk_decode_frame_list_dev(zk_engine *e, const void *d_comp, uint64
 extern "C" int zk_decode_frames(zk_engine *e, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off,
                                 const uint64_t *d_off, uint32_t first, uint32_t count, uint8_t *dst, uint64_t dst_cap,
                                 int verify, int32_t *frame_status)
+{
+    return zk_decode_frames_prefix(e, comp, comp_size, c_off, d_off, first, count, nullptr, 0, dst, dst_cap, verify, frame_status);
+}
+
+// The staged copy of the prefix is kept between calls: a zeekstd::Decoder passes the same prefix with every read
+// (the reference only keeps the pointer, decode.rs:201 lifetime bound).  Same address + length + fingerprint = no
+// upload.
+static uint64_t zk_prefix_fingerprint(const uint8_t *p, uint64_t n)
+{
+    uint64_t h = 0x9E3779B185EBCA87ull ^ n;
+    const uint64_t step = n > 65536 ? n / 64 : 1024;
+    for (uint64_t at = 0; at < n; at += step) {
+        const uint64_t take = n - at < 1024 ? n - at : 1024;
+        for (uint64_t i = 0; i < take; i++) h = (h ^ p[at + i]) * 0x100000001B3ull;
+    }
+    for (uint64_t i = n > 1024 ? n - 1024 : 0; i < n; i++) h = (h ^ p[i]) * 0x100000001B3ull;
+    return h;
+}
+
+extern "C" int zk_decode_frames_prefix(zk_engine *e, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off,
+                                       const uint64_t *d_off, uint32_t first, uint32_t count, const uint8_t *prefix, uint64_t prefix_len,
+                                       uint8_t *dst, uint64_t dst_cap, int verify, int32_t *frame_status)
 {
     if (!e || (count && (!comp || !c_off || !d_off))) return ZK_ERR_ARGUMENT;
     if (count == 0) return 0;
@@ -318,7 +353,19 @@ extern "C" int zk_decode_frames(zk_engine *e, const uint8_t *comp, uint64_t comp
     ZK_HIP(hipMemcpyAsync(e->st_off.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, st));
     ZK_HIP(hipStreamSynchronize(st));            // offs is a stack-lifetime vector
     const uint64_t *dc = (const uint64_t *)e->st_off.p, *dd = dc + count + 1;
-    rc = zk_decode_frames_dev(e, e->st_comp.p, c_hi - c_lo, dc, dd, 0, count, e->st_dst.p, d_hi - d_lo, verify, e->st_misc.p, st);
+    if (!prefix) prefix_len = 0;
+    if (prefix_len) {
+        if (prefix_len > ZK_MAX_PREFIX) return -(int)ZK_E_WINDOW_TOO_LARGE;
+        const uint64_t fp = zk_prefix_fingerprint(prefix, prefix_len);
+        if (e->st_prefix_src != prefix || e->st_prefix_len != prefix_len || e->st_prefix_fp != fp) {
+            if ((rc = zk_devbuf_reserve(e, e->st_prefix, (size_t)prefix_len + 64))) return rc;
+            ZK_HIP(hipMemcpyAsync(e->st_prefix.p, prefix, prefix_len, hipMemcpyHostToDevice, st));
+            ZK_HIP(hipStreamSynchronize(st));
+            e->st_prefix_src = prefix; e->st_prefix_len = prefix_len; e->st_prefix_fp = fp;
+        }
+    }
+    rc = zk_decode_frames_prefix_dev(e, e->st_comp.p, c_hi - c_lo, dc, dd, 0, count, prefix_len ? e->st_prefix.p : nullptr, prefix_len,
+                                     e->st_dst.p, d_hi - d_lo, verify, e->st_misc.p, st);
     if (rc == ZK_ERR_HIP || rc == ZK_ERR_ARGUMENT) return rc;
     if (d_hi > d_lo) ZK_HIP(hipMemcpyAsync(dst, e->st_dst.p, d_hi - d_lo, hipMemcpyDeviceToHost, st));
     if (frame_status) ZK_HIP(hipMemcpyAsync(frame_status, e->st_misc.p, (size_t)count * 4, hipMemcpyDeviceToHost, st));

@@ -59,8 +59,9 @@ class Engine:
         raise ZkError(rc, lib.zk_engine_last_hip_error(self._h).decode() if rc == -2001 else "")
 
     # ---- host-pointer entry points
-    def decode_frames(self, comp, c_off, d_off, first=0, count=None, verify=True, raise_on_error=True):
-        """Returns (bytes of frames [first, first+count), per-frame status array)."""
+    def decode_frames(self, comp, c_off, d_off, first=0, count=None, verify=True, raise_on_error=True, prefix=None):
+        """Returns (bytes of frames [first, first+count), per-frame status array).
+        prefix: raw-content prefix every frame was compressed against (patch mode)."""
         comp = np.frombuffer(comp, dtype=np.uint8) if not isinstance(comp, np.ndarray) else comp
         c_off, d_off = _u64(c_off), _u64(d_off)
         if count is None:
@@ -68,8 +69,14 @@ class Engine:
         out_len = int(d_off[first + count] - d_off[first])
         out = np.empty(max(out_len, 1), dtype=np.uint8)
         status = np.zeros(max(count, 1), dtype=np.int32)
-        rc = lib.zk_decode_frames(self._h, comp.ctypes.data, comp.size, c_off.ctypes.data, d_off.ctypes.data,
-                                  first, count, out.ctypes.data, out_len, int(verify), status.ctypes.data)
+        if prefix:
+            pre = np.frombuffer(bytes(prefix), dtype=np.uint8)
+            rc = lib.zk_decode_frames_prefix(self._h, comp.ctypes.data, comp.size, c_off.ctypes.data, d_off.ctypes.data,
+                                             first, count, pre.ctypes.data, pre.size, out.ctypes.data, out_len, int(verify),
+                                             status.ctypes.data)
+        else:
+            rc = lib.zk_decode_frames(self._h, comp.ctypes.data, comp.size, c_off.ctypes.data, d_off.ctypes.data,
+                                      first, count, out.ctypes.data, out_len, int(verify), status.ctypes.data)
         if rc != 0 and (raise_on_error or rc <= -1000):
             self._raise(rc)
         return out[:out_len].tobytes(), status[:count]
@@ -121,6 +128,16 @@ class Engine:
         rc = lib.zk_decode_frames_dev(self._h, self._ptr(d_comp), comp_size, self._ptr(d_c_off), self._ptr(d_d_off),
                                       first, count, self._ptr(d_dst), dst_cap, int(verify),
                                       self._ptr(d_status) if d_status is not None else None, stream)
+        if rc <= -1000:
+            self._raise(rc)
+        return rc
+
+    def decode_frames_prefix_dev(self, d_comp, comp_size, d_c_off, d_d_off, first, count, d_prefix, prefix_len, d_dst, dst_cap,
+                                 verify=True, d_status=None, stream=None):
+        rc = lib.zk_decode_frames_prefix_dev(self._h, self._ptr(d_comp), comp_size, self._ptr(d_c_off), self._ptr(d_d_off),
+                                             first, count, self._ptr(d_prefix) if prefix_len else None, prefix_len,
+                                             self._ptr(d_dst), dst_cap, int(verify),
+                                             self._ptr(d_status) if d_status is not None else None, stream)
         if rc <= -1000:
             self._raise(rc)
         return rc
