@@ -149,6 +149,17 @@ int zk_encode_frames_dev(zk_engine *e, const void *d_src, uint64_t n, uint32_t f
                          void *d_dst, uint64_t dst_cap, void *d_c_sizes, void *d_d_sizes, uint32_t *n_frames,
                          uint64_t *written, void *stream);
 
+/* Encode against a raw-content prefix: ZSTD_CCtx_refPrefix at the start of every frame (lib/src/encode.rs:334-338).
+ * The matcher reaches the last min(prefix_len, 65535) bytes of the prefix (its window); frames made this way declare a
+ * 128 KiB window and need the same prefix to decode (zk_decode_frames_prefix, or libzstd with ZSTD_DCtx_refPrefix).
+ * prefix_len == 0 is the plain call. */
+int zk_encode_frames_prefix_dev(zk_engine *e, const void *d_src, uint64_t n, uint32_t frame_size, int level, int checksum,
+                                const void *d_prefix, uint64_t prefix_len, void *d_dst, uint64_t dst_cap, void *d_c_sizes,
+                                void *d_d_sizes, uint32_t *n_frames_out, uint64_t *written_out, void *stream);
+int zk_encode_frames_prefix(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_size, int level, int checksum,
+                            const uint8_t *prefix, uint64_t prefix_len, uint8_t *dst, uint64_t dst_cap, uint32_t *c_sizes,
+                            uint32_t *d_sizes, uint32_t frames_cap, uint32_t *n_frames_out, uint64_t *written_out);
+
 /* XXH64(seed 0) of count byte ranges data[off[i], off[i+1]) -> out[i].  (The checksum libzstd
  * computes when ZSTD_c_checksumFlag is set: encode.rs:163-167, 283-284.) */
 int zk_xxh64_frames(zk_engine *e, const uint8_t *data, const uint64_t *off, uint32_t count, uint64_t *out);
@@ -261,6 +272,7 @@ typedef int (*zk_write_fn)(void *user, const uint8_t *data, size_t len);
 int zk_encoder_new(zk_engine *e, const zk_encode_opts *o, zk_write_fn write, void *user, zk_encoder **out);   /* with_opts :596 */
 void zk_encoder_free(zk_encoder *e);
 int64_t zk_encoder_compress(zk_encoder *e, const uint8_t *buf, size_t len);                           /* :692 / io::Write::write :791 */
+int64_t zk_encoder_compress_with_prefix(zk_encoder *e, const uint8_t *buf, size_t len, const uint8_t *prefix, size_t plen); /* :641; the prefix buffer must stay valid and unchanged until the frames begun under it are out (end_frame / flush / finish) */
 int64_t zk_encoder_end_frame(zk_encoder *e);                                                          /* :704 */
 int zk_encoder_flush(zk_encoder *e);                                                                  /* io::Write::flush :796 */
 int zk_encoder_finish(zk_encoder *e, int format, uint64_t *total);                                    /* finish_format :755 */

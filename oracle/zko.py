@@ -152,11 +152,18 @@ def frame_decode(src: bytes, dst_cap: int, verify: bool = True, want_stats: bool
     return out.raw[:r], used.value
 
 
-def frame_encode(src: bytes, level: int = 1, checksum: bool = False) -> bytes:
+def frame_encode(src: bytes, level: int = 1, checksum: bool = False, prefix: bytes = None) -> bytes:
     src = bytes(src)
     cap = len(src) + (len(src) >> 7) + 1024
     out = C.create_string_buffer(cap)
-    r = lib().zko_frame_encode(src, len(src), out, cap, level, int(checksum))
+    if prefix:
+        prefix = bytes(prefix)
+        l = lib()
+        l.zko_frame_encode_prefix.restype = C.c_int64
+        l.zko_frame_encode_prefix.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        r = l.zko_frame_encode_prefix(src, len(src), out, cap, level, int(checksum), prefix, len(prefix))
+    else:
+        r = lib().zko_frame_encode(src, len(src), out, cap, level, int(checksum))
     if r < 0:
         raise OracleError(-r)
     return out.raw[:r]

@@ -316,10 +316,22 @@ static u32 find_sequences(enc_state *st, const u8 *base, u32 bs, u32 be, u32 fen
 /* ------------------------------------------------------------------ frame */
 static size_t nseq_header(u8 *d, u32 n) { if (n < 128) { d[0] = (u8)n; return 1; } if (n < 0x7F00) { d[0] = (u8)((n >> 8) + 128); d[1] = (u8)n; return 2; } d[0] = 255; d[1] = (u8)(n - 0x7F00); d[2] = (u8)((n - 0x7F00) >> 8); return 3; }
 
+i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int level, int checksum, const u8 *prefix, size_t plen);
 /* Encode src[0..n) as ONE zstd frame. level is accepted for API symmetry (single strategy). Returns size or <0. */
 i64 zko_frame_encode(const u8 *src, size_t n, u8 *dst, size_t cap, int level, int checksum)
 {
+    return zko_frame_encode_prefix(src, n, dst, cap, level, checksum, NULL, 0);
+}
+
+/* The same against a raw-content prefix (ZSTD_CCtx_refPrefix at the frame start, lib/src/encode.rs:334-338): the last
+ * min(plen, 64 KiB window) bytes of the prefix are laid out right before the frame, their positions enter the hash
+ * table before the first block, and matches may start there (and run on into the frame).  The frame then declares
+ * a 128 KiB window, which covers every offset this matcher can produce. */
+i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int level, int checksum, const u8 *prefix, size_t plen)
+{
     (void)level;
+    if (!prefix) plen = 0;
+    const u32 hist = (u32)(plen < ZKE_WINDOW ? plen : ZKE_WINDOW);
     if (n > 0x40000000u) return -72;
     size_t p = 0;
     if (cap < 32) return -70;
@@ -332,9 +344,18 @@ i64 zko_frame_encode(const u8 *src, size_t n, u8 *dst, size_t cap, int level, in
     dst[0] = 0x28; dst[1] = 0xB5; dst[2] = 0x2F; dst[3] = 0xFD; dst[4] = checksum ? 0x04 : 0x00;
     /* Window_Descriptor: smallest power of two >= min(n, 64 KiB reach) but at least 1 KiB; blocks need window >= block size */
     u32 wlog = 10; while ((1u << wlog) < n && wlog < 17) wlog++;     /* <= 128 KiB: offsets never exceed 65535 */
+    if (hist) wlog = 17;
     dst[5] = (u8)((wlog - 10) << 3);
     p = 6;
     enc_state *st = calloc(1, sizeof *st);
+    const u8 *msrc = src;                                            /* what the matcher sees: [prefix tail | frame] */
+    u8 *cat = NULL;
+    if (hist) {
+        cat = malloc((size_t)hist + n + 8);
+        memcpy(cat, prefix + plen - hist, hist); memcpy(cat + hist, src, n);
+        msrc = cat;
+        for (u32 v = 0; v < hist; v++) if ((size_t)v + 8 <= (size_t)hist + n) st->table[hash5(msrc + v)] = v + 1;
+    }
     seq_t *sq = malloc(sizeof(seq_t) * (ZKE_BLOCK / 3 + 8));
     u8 *lits = malloc(ZKE_BLOCK + 64), *body = malloc(ZKE_BLOCK * 2);
     st->probe = 1;                                                   /* first probe: offset 1 (runs) */
@@ -347,7 +368,7 @@ i64 zko_frame_encode(const u8 *src, size_t n, u8 *dst, size_t cap, int level, in
         u32 be = bs + bmax < n ? bs + bmax : (u32)n;
         u32 bsz = be - bs, last = be == n;
         u32 nlit = 0;
-        u32 nseq = find_sequences(st, src, bs, be, (u32)n, sq, lits, &nlit);
+        u32 nseq = find_sequences(st, msrc, hist + bs, hist + be, hist + (u32)n, sq, lits, &nlit);
         size_t b = encode_literals(lits, nlit, body, ZKE_BLOCK * 2);
         size_t total = 0;
         if (b) {
@@ -372,6 +393,6 @@ i64 zko_frame_encode(const u8 *src, size_t n, u8 *dst, size_t cap, int level, in
         }
     }
     if (rc == 0 && checksum) { if (p + 4 > cap) rc = -70; else { u32 h = (u32)zko_xxh64(src, n, 0); memcpy(dst + p, &h, 4); p += 4; } }
-    free(st); free(sq); free(lits); free(body);
+    free(st); free(sq); free(lits); free(body); free(cat);
     return rc ? rc : (i64)p;
 }

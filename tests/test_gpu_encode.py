@@ -88,3 +88,41 @@ def test_roundtrip_property(engine):         # fuzz/fuzz_targets/roundtrip_basic
         data = zko.gen_text(n, i) if kind == 0 else zko.gen_random(n, i) if kind == 1 else (zko.gen_text(max(1, n // 7), i) * 7)[:n]
         comp, frames = engine.encode_frames(data, 100, 1, bool(i & 1))
         check_payload(engine, data, comp, frames, 100, bool(i & 1))
+
+
+PREFIX_CASES = {
+    # name: (prefix recipe, data recipe, frame size)
+    "shared_text": ([["text", 100000, 41]], [["text", 40000, 41], ["text", 60000, 42], ["text", 30000, 41]], 32768),
+    "tiny": ([["rep", b"hello world!".hex(), 1]], [["rep", b"hello world!".hex(), 9]], 2 << 20),
+    "long_prefix": ([["text", 300000, 43]], [["text", 200000, 43]], 65536),          # only the last 65535 bytes are reachable
+    "prefix_is_input": ([["chunks", 1 << 20, 5]], [["chunks", 1 << 20, 5]], 1 << 20),
+    "random_data": ([["text", 50000, 48]], [["random", 40000, 49], ["text", 20000, 48]], 16384),
+    "small_frames": ([["text", 20000, 50]], [["text", 12000, 50]], 1000),
+}
+
+
+@pytest.mark.parametrize("name", list(PREFIX_CASES))
+@pytest.mark.parametrize("checksum", [False, True])
+def test_encode_with_prefix_roundtrip_and_twin(engine, name, checksum):
+    # zk_encode_frames_prefix: ZSTD_CCtx_refPrefix at every frame start (encode.rs:334-338); the frames must decode
+    # with the same prefix through the oracle, the real libzstd (ZSTD_DCtx_refPrefix) and the GPU decoder, and be
+    # byte-identical to the CPU twin
+    pre_recipe, recipe, fs = PREFIX_CASES[name]
+    prefix, data = zko.make_input(pre_recipe), zko.make_input(recipe)
+    comp, frames = engine.encode_frames(data, fs, 1, checksum, prefix=prefix)
+    plain, _ = engine.encode_frames(data, fs, 1, checksum)
+    assert len(comp) <= len(plain) + 8 * len(frames)
+    assert sum(d for _, d in frames) == len(data) and sum(c for c, _ in frames) == len(comp)
+    pos = dpos = 0
+    for c, d in frames:
+        f = comp[pos:pos + c]
+        out, used = zko.frame_decode(f, d, True, prefix=prefix)
+        assert used == c and out == data[dpos:dpos + d]
+        assert f == zko.frame_encode(data[dpos:dpos + d], 1, checksum, prefix=prefix), (name, dpos)
+        pos += c; dpos += d
+    for which in ("system", "1.5.7"):
+        if Z.load(which) is not None:
+            assert Z.decode_stream(comp, len(data), which, prefix=prefix) == data
+    c_off, d_off = offsets_from_frames(frames)
+    out, st = engine.decode_frames(comp + b"\0" * 8, c_off, d_off, verify=True, prefix=prefix)
+    assert not st.any() and out == data

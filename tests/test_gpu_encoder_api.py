@@ -197,11 +197,60 @@ def test_readme_seek_example(engine):                              # decode.rs:5
     assert d.read(100) == b"World!"
 
 
-def test_unsupported_parameters_fail_loudly(engine):
-    enc = EncodeOptions().engine(engine).into_raw_encoder()
-    with pytest.raises(zk.Error) as e:                              # prefix / patch mode
-        enc.compress_with_prefix(b"abc", bytearray(10), b"prefix")
-    assert e.value.code == -40
+def test_patch_cycle(engine):                                       # lib.rs:202-263 (test_patch_cycle), both directions on the GPU
+    old = zko.gen_text(40000, 21)
+    new = old[:15000] + b"++inserted++" + old[15000:30000] + zko.gen_text(2000, 22) + old[30000:]
+    for policy in (FrameSizePolicy.Uncompressed(3000), FrameSizePolicy.Compressed(700)):
+        enc = EncodeOptions().engine(engine).checksum_flag(True).frame_size_policy(policy).into_raw_encoder()
+        out = bytearray()
+        scratch = bytearray(max(1, len(new) // 500))               # every call is partial (lib.rs:214-216)
+        pos = 0
+        while pos < len(new):
+            p = enc.compress_with_prefix(new[pos:pos + 777], scratch, old)
+            out += scratch[:p.out_progress()]
+            pos += p.in_progress()
+        while True:
+            p = enc.end_frame(scratch)
+            out += scratch[:p.out_progress()]
+            if p.data_left() == 0:
+                break
+        st = enc.seek_table()
+        seekable = bytes(out) + st.to_bytes()
+        d = DecodeOptions(seekable).engine(engine).into_decoder()
+        got = bytearray()
+        buf = bytearray(max(1, len(new) // 300))
+        while True:
+            n = d.decompress_with_prefix(buf, old)
+            if n == 0:
+                break
+            got += buf[:n]
+        assert bytes(got) == new
+        if Z.load("system") is not None:                            # and the real libzstd agrees, given the same prefix
+            assert Z.decode_stream(bytes(out), len(new), "system", prefix=old) == new
+        plain = EncodeOptions().engine(engine).checksum_flag(True).frame_size_policy(policy).into_raw_encoder()
+        assert st.num_frames() >= 1
+
+
+def test_encoder_prefix_switch_takes_effect_at_frame_start(engine):  # encode.rs:334-338: ref_prefix only when frame_d_size == 0
+    a, b = zko.gen_text(5000, 31), zko.gen_text(5000, 32)
+    data1, data2 = a[1000:3500], b[500:4200]                        # frame 1 (+ part of 2) under prefix a, the rest under b
+    sink = io.BytesIO()
+    enc = EncodeOptions().engine(engine).checksum_flag(True).frame_size_policy(FrameSizePolicy.Uncompressed(2000)).into_encoder(sink)
+    enc.compress_with_prefix(data1, a)                              # frames [0,2000) and the open frame [2000,2500) begin under a
+    enc.compress_with_prefix(data2, b)                              # fills the open frame (still a's), later frames begin under b
+    enc.finish()
+    seekable = sink.getvalue()
+    whole = data1 + data2
+    st = zk.SeekTable.from_seekable(seekable)
+    nf = st.num_frames()
+    assert nf == -(-len(whole) // 2000)
+    pos = 0
+    for i in range(nf):
+        c = st.frame_size_comp(i); dsz = st.frame_size_decomp(i)
+        pre = a if i < 2 else b
+        out, used = zko.frame_decode(seekable[pos:pos + c], dsz, True, prefix=pre)
+        assert used == c and out == whole[i * 2000:i * 2000 + dsz], i
+        pos += c
 
 
 def test_fuzz_roundtrip_basic(engine):                             # fuzz_targets/roundtrip_basic.rs: 100-byte frames

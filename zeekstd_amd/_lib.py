@@ -48,6 +48,8 @@ _sig = {
     "zk_compress_bound": (C.c_uint64, [C.c_uint64, C.c_uint32]),
     "zk_encode_frames": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_int, C.c_int, _P, C.c_uint64, _P, _P, C.c_uint32,
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "zk_encode_frames_prefix": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_int, C.c_int, _P, C.c_uint64, _P, C.c_uint64, _P, _P, C.c_uint32,
+                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "zk_encode_frames_dev": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_int, C.c_int, _P, C.c_uint64, _P, _P,
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), _P]),
     "zk_decode_frame_list_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint64, C.c_int, _P, _P]),

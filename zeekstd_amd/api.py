@@ -396,6 +396,7 @@ for _n, _r, _a in [
     ("zk_encoder_new", C.c_int, [_P, C.POINTER(zk_encode_opts), _WRITE_FN, _P, C.POINTER(_P)]),
     ("zk_encoder_free", None, [_P]),
     ("zk_encoder_compress", C.c_int64, [_P, _P, C.c_size_t]),
+    ("zk_encoder_compress_with_prefix", C.c_int64, [_P, _P, C.c_size_t, _P, C.c_size_t]),
     ("zk_encoder_end_frame", C.c_int64, [_P]),
     ("zk_encoder_flush", C.c_int, [_P]),
     ("zk_encoder_finish", C.c_int, [_P, C.c_int, _u64p]),
@@ -492,7 +493,14 @@ class RawEncoder:                      # encode.rs:209-545
         n = len(out)
         arr = (C.c_uint8 * n).from_buffer(out) if n else None
         i, o = C.c_size_t(), C.c_size_t()
-        p = bytes(prefix) if prefix is not None else None
+        p = None
+        if prefix is not None and len(prefix):
+            held = getattr(self, "_prefixes", None)        # the native side keeps only the address until the frame is encoded
+            if held is None:
+                held = self._prefixes = {}
+            if id(prefix) not in held or held[id(prefix)][0] is not prefix:
+                held[id(prefix)] = (prefix, prefix if isinstance(prefix, bytes) else bytes(prefix))
+            p = held[id(prefix)][1]
         _chk(lib.zk_raw_encoder_compress_with_prefix(self._h, inp, len(inp), arr, n, p, len(p) if p else 0, C.byref(i), C.byref(o)))
         return CompressionProgress(i.value, o.value)
 
@@ -546,6 +554,24 @@ class Encoder:                         # encode.rs:570-800
     def compress(self, buf) -> int:
         buf = bytes(buf)
         return _chk(lib.zk_encoder_compress(self._h, buf, len(buf)))
+
+    def compress_with_prefix(self, buf, prefix) -> int:            # encode.rs:641-665
+        buf = bytes(buf)
+        p = self._hold_prefix(prefix)
+        return _chk(lib.zk_encoder_compress_with_prefix(self._h, buf, len(buf), p, len(p) if p else 0))
+
+    def _hold_prefix(self, prefix):
+        """The native Encoder keeps only the address of a prefix until the frames begun under it are submitted: every
+        distinct prefix object is copied once and kept alive for the life of this Encoder."""
+        if prefix is None or len(prefix) == 0:
+            return None
+        held = getattr(self, "_prefixes", None)
+        if held is None:
+            held = self._prefixes = {}
+        key = id(prefix)
+        if key not in held or held[key][0] is not prefix:
+            held[key] = (prefix, prefix if isinstance(prefix, bytes) else bytes(prefix))
+        return held[key][1]
 
     write = compress                   # impl io::Write
 

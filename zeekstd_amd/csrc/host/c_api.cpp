@@ -213,6 +213,12 @@ int64_t zk_encoder_compress(zk_encoder *e, const uint8_t *buf, size_t len)
     int rc = guard([&] { n = (int64_t)e->e.compress(buf, len); });
     return rc ? rc : n;
 }
+int64_t zk_encoder_compress_with_prefix(zk_encoder *e, const uint8_t *buf, size_t len, const uint8_t *prefix, size_t plen)
+{
+    int64_t n = 0;
+    int rc = guard([&] { n = (int64_t)e->e.compress_with_prefix(buf, len, prefix, plen); });
+    return rc ? rc : n;
+}
 int64_t zk_encoder_end_frame(zk_encoder *e)
 {
     int64_t n = 0;

@@ -64,8 +64,8 @@ void RawEncoder::encode_pending()
     pending_.resize((size_t)zk_compress_bound(n, n ? (uint32_t)n : 1));
     uint32_t c = 0, d = 0, nf = 0;
     uint64_t written = 0;
-    int rc = zk_encode_frames(engine_, frame_in_.data(), n, n ? (uint32_t)n : 1, level_, checksum_ ? 1 : 0, pending_.data(),
-                              pending_.size(), &c, &d, 1, &nf, &written);
+    int rc = zk_encode_frames_prefix(engine_, frame_in_.data(), n, n ? (uint32_t)n : 1, level_, checksum_ ? 1 : 0, frame_prefix_,
+                                     frame_prefix_ ? frame_prefix_len_ : 0, pending_.data(), pending_.size(), &c, &d, 1, &nf, &written);
     if (rc != 0) throw Error::from_engine_code(rc, zk_engine_last_hip_error(engine_));
     pending_.resize((size_t)written);
     pending_pos_ = 0;
@@ -73,9 +73,8 @@ void RawEncoder::encode_pending()
 }
 
 CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len,
-                                                     const uint8_t *prefix, size_t)
+                                                     const uint8_t *prefix, size_t prefix_len)
 {
-    if (prefix) throw Error::zstd(40 /* parameter_unsupported: prefix/patch mode, SURVEY 8f-3 */);
     if (is_frame_complete()) {                                                 // encode.rs:317-327
         size_t out_progress = 0;
         while (out_progress < out_len) {
@@ -86,6 +85,9 @@ CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t i
         return {0, out_progress};
     }
     const size_t limit = std::min(in_len, remaining_frame_size());             // encode.rs:329
+    // the prefix of the call that starts a frame is the frame's prefix (ref_prefix only if frame_d_size == 0,
+    // encode.rs:334-338); like libzstd only the reference is kept until the frame is encoded
+    if (frame_d_size_ == 0) { frame_prefix_ = prefix; frame_prefix_len_ = prefix ? prefix_len : 0; }
     frame_in_.insert(frame_in_.end(), in, in + limit);
     frame_d_size_ += (uint32_t)limit;                                          // encode.rs:350
     if (policy_.kind == FrameSizePolicy::Kind::Compressed && limit && frame_in_.size() >= next_probe_) {
@@ -115,6 +117,7 @@ void RawEncoder::reset_frame()                                                 /
 {
     frame_c_size_ = 0; frame_d_size_ = 0;
     frame_in_.clear(); pending_.clear(); pending_pos_ = 0; encoded_ = false; next_probe_ = 0;
+    frame_prefix_ = nullptr; frame_prefix_len_ = 0;
 }
 
 // ---------------------------------------------------------------- Encoder<W>
@@ -158,22 +161,23 @@ void Encoder::submit_batch(bool include_partial)
     std::vector<uint32_t> c(nf_cap), d(nf_cap);
     uint32_t nf = 0;
     uint64_t written = 0;
-    int rc = zk_encode_frames(raw_.engine_, batch_in_.data(), take, fs, raw_.level_, raw_.checksum_ ? 1 : 0, out.data(), out.size(),
-                              c.data(), d.data(), (uint32_t)nf_cap, &nf, &written);
+    int rc = zk_encode_frames_prefix(raw_.engine_, batch_in_.data(), take, fs, raw_.level_, raw_.checksum_ ? 1 : 0, batch_prefix_,
+                                     batch_prefix_ ? batch_prefix_len_ : 0, out.data(), out.size(), c.data(), d.data(), (uint32_t)nf_cap,
+                                     &nf, &written);
     if (rc != 0) throw Error::from_engine_code(rc, zk_engine_last_hip_error(raw_.engine_));
     emit(out.data(), (size_t)written);
     for (uint32_t i = 0; i < nf; i++) raw_.seek_table_.log_frame(c[i], d[i]);
     batch_in_.erase(batch_in_.begin(), batch_in_.begin() + (ptrdiff_t)take);
 }
 
-size_t Encoder::compress_with_prefix(const uint8_t *buf, size_t len, const uint8_t *prefix, size_t)   // encode.rs:641-665
+size_t Encoder::compress_with_prefix(const uint8_t *buf, size_t len, const uint8_t *prefix, size_t prefix_len)   // encode.rs:641-665
 {
-    if (prefix) throw Error::zstd(40 /* parameter_unsupported */);
+    if (!prefix) prefix_len = 0;
     if (raw_.policy_.kind == FrameSizePolicy::Kind::Compressed) {               // frame ends depend on output: the upstream loop, frame by frame
         size_t input_progress = 0;
         while (input_progress < len) {
-            CompressionProgress p = raw_.compress(buf + input_progress, len - input_progress, out_buf_.data() + out_buf_pos_,
-                                                  out_buf_.size() - out_buf_pos_);
+            CompressionProgress p = raw_.compress_with_prefix(buf + input_progress, len - input_progress, out_buf_.data() + out_buf_pos_,
+                                                              out_buf_.size() - out_buf_pos_, prefix, prefix_len);
             if (p.in_progress() == 0 && p.out_progress() == 0) break;
             out_buf_pos_ += p.out_progress();
             flush_out_buf(false);
@@ -183,6 +187,26 @@ size_t Encoder::compress_with_prefix(const uint8_t *buf, size_t len, const uint8
         return input_progress;
     }
     const uint32_t fs = std::min(MAX_FRAME_SIZE, raw_.policy_.size);
+    // A batch is encoded against ONE prefix.  Upstream a new prefix takes effect at the next frame start
+    // (encode.rs:334-338); the frames gathered so far began under the old one, so they are cut and submitted first:
+    // complete frames as they are, and the open frame is filled up to its boundary from this call's bytes.
+    if (!batch_in_.empty() && (prefix != batch_prefix_ || prefix_len != batch_prefix_len_)) {
+        const size_t open = batch_in_.size() % fs;
+        const size_t fill = open ? std::min<size_t>(len, fs - open) : 0;
+        batch_in_.insert(batch_in_.end(), buf, buf + fill);
+        since_end_ += fill;
+        if (fill == len && batch_in_.size() % fs) return len;                    // still inside the old frame: nothing switches yet
+        const bool partial_tail = batch_in_.size() % fs != 0;
+        (void)partial_tail;
+        submit_batch(true);                                                     // every gathered frame is complete here
+        buf += fill; len -= fill;
+        batch_prefix_ = prefix; batch_prefix_len_ = prefix_len;
+        batch_in_.insert(batch_in_.end(), buf, buf + len);
+        since_end_ += len;
+        if (batch_in_.size() > (size_t)fs * batch_frames_) submit_batch(false);
+        return fill + len;
+    }
+    if (batch_in_.empty()) { batch_prefix_ = prefix; batch_prefix_len_ = prefix_len; }
     batch_in_.insert(batch_in_.end(), buf, buf + len);
     since_end_ += len;
     // the last full frame stays open (upstream closes it on the NEXT call), so it is held back

@@ -321,6 +321,8 @@ private:
     size_t pending_pos_ = 0;
     bool encoded_ = false;
     size_t next_probe_ = 0;                   // Compressed(n): buffered size at which the next speculative encode happens
+    const uint8_t *frame_prefix_ = nullptr;   // prefix referenced when the frame in progress began (encode.rs:334-338)
+    size_t frame_prefix_len_ = 0;
 };
 
 class Encoder {                                                                      // encode.rs:570-800
@@ -350,6 +352,8 @@ private:
     uint32_t batch_frames_ = 64;
     uint64_t since_end_ = 0;                  // bytes accepted since the last end_frame
     std::vector<uint8_t> batch_in_;           // whole frames (+ the partial one at the tail) awaiting submission
+    const uint8_t *batch_prefix_ = nullptr;   // the prefix the frames in batch_in_ began with
+    size_t batch_prefix_len_ = 0;
 };
 
 }  // namespace zeekstd

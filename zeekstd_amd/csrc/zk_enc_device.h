@@ -20,7 +20,8 @@ struct ZkEncFrame {
     uint32_t block_base;        // first entry of the frame in the block list
     uint32_t block_max;         // Block_Maximum_Size = min(window, 128 KiB)
     uint32_t window_log;
-    uint32_t pad;
+    uint32_t hist;              // bytes of history laid out before the frame in the matcher's source (prefix tail; 0 = none)
+    uint64_t m_off;             // where that history starts in the matcher's source (== src_off when hist == 0)
 };
 
 struct ZkEncBlock {

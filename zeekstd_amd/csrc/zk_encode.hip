@@ -43,6 +43,10 @@ __device__ __forceinline__ uint32_t zke_match_len(const uint8_t *a, const uint8_
 // per-tile sequence as the parse leaves it in LDS: ll (12) | ml (11) << 12 | offset (17) << 23 | position in tile (10) << 40
 __device__ __forceinline__ uint64_t zke_tpack(uint32_t ll, uint32_t ml, uint32_t off, uint32_t pit) { return (uint64_t)ll | ((uint64_t)ml << 12) | ((uint64_t)off << 23) | ((uint64_t)pit << 40); }
 
+// With a prefix (zk_encode_frames_prefix) the matcher does not read the frame in place: `src` is then a staging
+// buffer that holds, per frame, [last `hist` bytes of the prefix | the frame] (zk_k_enc_stage_hist), all positions
+// below are offsets into that record, and the history's positions enter the hash table before the first block --
+// so a match may start in the prefix and run on into the frame with no special case anywhere.
 __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
                                                               uint64_t *seqs, uint32_t *mpos, uint8_t *lits)
 {
@@ -53,13 +57,16 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
     __shared__ uint32_t s_scan[ZKE_THREADS];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ZkEncFrame fr = frames[blockIdx.x];
-    const uint8_t *base = src + fr.src_off;
-    const uint32_t fend = fr.d_size;
+    const uint8_t *base = src + fr.m_off;
+    const uint32_t hist = fr.hist, fend = hist + fr.d_size;
     for (uint32_t i = tid; i < (1u << ZKE_HASH_LOG); i += ZKE_THREADS) table[i] = 0;
     __syncthreads();
+    for (uint32_t v = tid; v < hist; v += ZKE_THREADS)               // history positions: the largest one wins a slot, as below
+        if (v + 8 <= fend) atomicMax(&table[(uint32_t)(((zk_ld64(base + v) << 24) * 889523592379ull) >> (64 - ZKE_HASH_LOG))], v + 1);
+    if (hist) __syncthreads();
     uint32_t probe = 1;                                    // offset of the last match taken (same value in every thread)
     for (uint32_t bi = 0; bi < fr.n_blocks; bi++) {
-        const uint32_t bs = bi * fr.block_max;
+        const uint32_t bs = hist + bi * fr.block_max;
         const uint32_t be = bs + fr.block_max < fend ? bs + fr.block_max : fend;
         ZkEncBlock *blk = &blocks[fr.block_base + bi];
         uint64_t *sq = seqs + blk->seq_base;
@@ -500,6 +507,19 @@ __global__ __launch_bounds__(256) void zk_k_enc_assemble(const uint8_t *src, con
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
+// [prefix tail | frame] records for the matcher (prefix mode only; not on the hot path)
+__global__ __launch_bounds__(256) void zk_k_enc_stage_hist(const uint8_t *src, const uint8_t *prefix_tail, const ZkEncFrame *frames, uint8_t *stage)
+{
+    const ZkEncFrame fr = frames[blockIdx.x];
+    uint8_t *rec = stage + fr.m_off;
+    for (uint32_t i = threadIdx.x; i < fr.hist; i += 256) rec[i] = prefix_tail[i];
+    const uint8_t *from = src + fr.src_off;
+    for (uint32_t i = threadIdx.x; i < fr.d_size; i += 256) rec[fr.hist + i] = from[i];
+}
+void zk_launch_enc_stage_hist(hipStream_t st, const uint8_t *src, const uint8_t *prefix_tail, const ZkEncFrame *frames, uint32_t nframes, uint8_t *stage)
+{
+    hipLaunchKernelGGL(zk_k_enc_stage_hist, dim3(nframes), dim3(256), 0, st, src, prefix_tail, frames, stage);
+}
 void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, ZkEncBlock *blocks, uint64_t *seqs, uint32_t *mpos, uint8_t *lits)
 {
     hipLaunchKernelGGL(zk_k_enc_match, dim3(nframes), dim3(ZKE_THREADS), 0, st, src, frames, blocks, seqs, mpos, lits);

@@ -39,6 +39,7 @@ struct zk_engine {
     float kernel_ms[ZK_NKERNELS] = {};
     // encode scratch
     zk_devbuf enc_a, enc_b, enc_c, enc_d;
+    zk_devbuf enc_hist;                     // prefix mode: [prefix tail | frame] records for the matcher
     ZkEncTables enc_tables;
     bool enc_tables_ready = false;
 };

@@ -132,7 +132,7 @@ extern "C" void zk_engine_destroy(zk_engine *e)
     (void)hipStreamSynchronize(e->stream);
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
     zk_devbuf *bufs[] = {&e->infos, &e->bases, &e->words, &e->blocks, &e->seqs, &e->lit, &e->infos2, &e->bases2, &e->words2, &e->blocks2, &e->seqs2, &e->lit2, &e->st_prefix, &e->st_comp, &e->st_off, &e->st_dst, &e->st_misc,
-                         &e->enc_a, &e->enc_b, &e->enc_c, &e->enc_d};
+                         &e->enc_a, &e->enc_b, &e->enc_c, &e->enc_d, &e->enc_hist};
     for (zk_devbuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (e->h_words) (void)hipHostFree(e->h_words);
     for (int k = 0; k < ZK_NKERNELS; k++) { if (e->ev_start[k]) (void)hipEventDestroy(e->ev_start[k]); if (e->ev_stop[k]) (void)hipEventDestroy(e->ev_stop[k]); }

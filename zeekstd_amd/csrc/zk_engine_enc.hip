@@ -66,6 +66,16 @@ extern "C" int zk_encode_frames_dev(zk_engine *e, const void *d_src, uint64_t n,
                                     void *d_dst, uint64_t dst_cap, void *d_c_sizes, void *d_d_sizes, uint32_t *n_frames_out,
                                     uint64_t *written_out, void *stream)
 {
+    return zk_encode_frames_prefix_dev(e, d_src, n, frame_size, level, checksum, nullptr, 0, d_dst, dst_cap, d_c_sizes, d_d_sizes,
+                                       n_frames_out, written_out, stream);
+}
+
+extern "C" int zk_encode_frames_prefix_dev(zk_engine *e, const void *d_src, uint64_t n, uint32_t frame_size, int level, int checksum,
+                                           const void *d_prefix, uint64_t prefix_len, void *d_dst, uint64_t dst_cap, void *d_c_sizes,
+                                           void *d_d_sizes, uint32_t *n_frames_out, uint64_t *written_out, void *stream)
+{
+    // the matcher sees the last `hist` bytes of the prefix right before every frame (its window is 64 KiB)
+    const uint32_t hist = d_prefix ? (uint32_t)(prefix_len < ZKE_WINDOW ? prefix_len : ZKE_WINDOW) : 0;
     (void)level;                                             // one strategy: every level maps to it
     if (!e || frame_size == 0 || frame_size > ZK_SEEKABLE_MAX_FRAME_SIZE || !d_dst || (n && !d_src)) return ZK_ERR_ARGUMENT;
     const uint64_t nf64 = n == 0 ? 1 : (n + frame_size - 1) / frame_size;
@@ -84,6 +94,7 @@ extern "C" int zk_encode_frames_dev(zk_engine *e, const void *d_src, uint64_t n,
         fr.d_size = (uint32_t)(n - fr.src_off < frame_size ? n - fr.src_off : frame_size);
         uint32_t wlog = 10;
         while ((1u << wlog) < fr.d_size && wlog < 17) wlog++;
+        if (hist) wlog = 17;                                 // covers every offset the matcher can produce, into the prefix too
         fr.window_log = wlog;
         fr.block_max = (1u << wlog) < ZKE_BLOCK ? (1u << wlog) : ZKE_BLOCK;
         // blocks are cut smaller than the format's maximum on purpose: a block's sequence bitstream is one serial chain for
@@ -91,7 +102,8 @@ extern "C" int zk_encode_frames_dev(zk_engine *e, const void *d_src, uint64_t n,
         { uint32_t t = 32768; while (t > 4096 && (uint64_t)t * 8 > fr.d_size) t >>= 1; if (t < fr.block_max) fr.block_max = t; }
         fr.n_blocks = fr.d_size ? (fr.d_size + fr.block_max - 1) / fr.block_max : 0;
         fr.block_base = (uint32_t)blocks.size();
-        fr.pad = 0;
+        fr.hist = fr.d_size ? hist : 0;
+        fr.m_off = hist ? (uint64_t)f * ((uint64_t)hist + frame_size) : fr.src_off;
         for (uint32_t b = 0; b < fr.n_blocks; b++) {
             ZkEncBlock k;
             memset(&k, 0, sizeof k);
@@ -129,8 +141,14 @@ extern "C" int zk_encode_frames_dev(zk_engine *e, const void *d_src, uint64_t n,
     }
     zk_profile_begin(e);
     const uint8_t *src = (const uint8_t *)d_src;
+    const uint8_t *msrc = src;                               // what the matcher reads
+    if (hist) {
+        if ((rc = zk_devbuf_reserve(e, e->enc_hist, (size_t)nf * ((size_t)hist + frame_size) + 64))) return rc;
+        zk_launch_enc_stage_hist(st, src, (const uint8_t *)d_prefix + (prefix_len - hist), dfr, nf, (uint8_t *)e->enc_hist.p);
+        msrc = (const uint8_t *)e->enc_hist.p;
+    }
     if (checksum) { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, (const uint64_t *)e->bases.p, 0, nf, nullptr, hashes); }
-    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, src, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (uint8_t *)e->enc_c.p); }
+    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (uint8_t *)e->enc_c.p); }
     { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (const uint64_t *)e->enc_b.p, (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, dtab); }
     zk_launch_enc_sizes(st, dfr, nf, dbl, checksum, c64, (uint32_t *)d_c_sizes, (uint32_t *)d_d_sizes);
     zk_launch_scan64(st, c64, nf, out_off);
@@ -151,6 +169,14 @@ extern "C" int zk_encode_frames(zk_engine *e, const uint8_t *src, uint64_t n, ui
                                 uint8_t *dst, uint64_t dst_cap, uint32_t *c_sizes, uint32_t *d_sizes, uint32_t frames_cap,
                                 uint32_t *n_frames_out, uint64_t *written_out)
 {
+    return zk_encode_frames_prefix(e, src, n, frame_size, level, checksum, nullptr, 0, dst, dst_cap, c_sizes, d_sizes, frames_cap,
+                                   n_frames_out, written_out);
+}
+
+extern "C" int zk_encode_frames_prefix(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_size, int level, int checksum,
+                                       const uint8_t *prefix, uint64_t prefix_len, uint8_t *dst, uint64_t dst_cap, uint32_t *c_sizes,
+                                       uint32_t *d_sizes, uint32_t frames_cap, uint32_t *n_frames_out, uint64_t *written_out)
+{
     if (!e || frame_size == 0 || !dst || (n && !src)) return ZK_ERR_ARGUMENT;
     const uint64_t nf = n == 0 ? 1 : (n + frame_size - 1) / frame_size;
     if (nf > ZK_SEEKABLE_MAX_FRAMES) return ZK_ERR_FRAME_INDEX_TOO_LARGE;
@@ -167,7 +193,15 @@ extern "C" int zk_encode_frames(zk_engine *e, const uint8_t *src, uint64_t n, ui
     uint32_t *dc = (uint32_t *)e->st_misc.p, *dd = dc + nf;
     uint32_t nfo = 0;
     uint64_t written = 0;
-    rc = zk_encode_frames_dev(e, e->st_comp.p, n, frame_size, level, checksum, e->st_dst.p, cap, dc, dd, &nfo, &written, st);
+    // only the tail the matcher can reach is staged
+    const uint64_t tail = prefix ? (prefix_len < ZKE_WINDOW ? prefix_len : ZKE_WINDOW) : 0;
+    if (tail) {
+        if ((rc = zk_devbuf_reserve(e, e->st_prefix, (size_t)tail + 64))) return rc;
+        ZK_HIP(hipMemcpyAsync(e->st_prefix.p, prefix + (prefix_len - tail), tail, hipMemcpyHostToDevice, st));
+        e->st_prefix_src = nullptr; e->st_prefix_len = 0; e->st_prefix_fp = 0;        // the decode side's cached copy is gone
+    }
+    rc = zk_encode_frames_prefix_dev(e, e->st_comp.p, n, frame_size, level, checksum, tail ? e->st_prefix.p : nullptr, tail,
+                                     e->st_dst.p, cap, dc, dd, &nfo, &written, st);
     if (rc) return rc;
     ZK_HIP(hipMemcpyAsync(dst, e->st_dst.p, written, hipMemcpyDeviceToHost, st));
     if (c_sizes) ZK_HIP(hipMemcpyAsync(c_sizes, dc, (size_t)nfo * 4, hipMemcpyDeviceToHost, st));

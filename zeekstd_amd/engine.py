@@ -81,8 +81,9 @@ class Engine:
             self._raise(rc)
         return out[:out_len].tobytes(), status[:count]
 
-    def encode_frames(self, data, frame_size=0x200000, level=1, checksum=False):
-        """Returns (compressed payload bytes, [(c_size, d_size), ...]) -- one zstd frame per frame_size bytes."""
+    def encode_frames(self, data, frame_size=0x200000, level=1, checksum=False, prefix=None):
+        """Returns (compressed payload bytes, [(c_size, d_size), ...]) -- one zstd frame per frame_size bytes.
+        prefix: raw-content prefix referenced at the start of every frame (patch mode)."""
         data = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
         n = int(data.size)
         nf = max(1, -(-n // frame_size))
@@ -92,8 +93,14 @@ class Engine:
         ds = np.zeros(nf, np.uint32)
         nfo = C.c_uint32()
         wr = C.c_uint64()
-        rc = lib.zk_encode_frames(self._h, data.ctypes.data if n else None, n, frame_size, level, int(checksum),
-                                  out.ctypes.data, cap, cs.ctypes.data, ds.ctypes.data, nf, C.byref(nfo), C.byref(wr))
+        if prefix:
+            pre = np.frombuffer(bytes(prefix), dtype=np.uint8)
+            rc = lib.zk_encode_frames_prefix(self._h, data.ctypes.data if n else None, n, frame_size, level, int(checksum),
+                                             pre.ctypes.data, pre.size, out.ctypes.data, cap, cs.ctypes.data, ds.ctypes.data, nf,
+                                             C.byref(nfo), C.byref(wr))
+        else:
+            rc = lib.zk_encode_frames(self._h, data.ctypes.data if n else None, n, frame_size, level, int(checksum),
+                                      out.ctypes.data, cap, cs.ctypes.data, ds.ctypes.data, nf, C.byref(nfo), C.byref(wr))
         if rc != 0:
             self._raise(rc)
         return out[:wr.value].tobytes(), list(zip(cs[:nfo.value].tolist(), ds[:nfo.value].tolist()))
