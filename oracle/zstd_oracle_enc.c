@@ -5,9 +5,9 @@
  * compressed payload bytes are unpinned by the reference (libzstd 1.4.8 and 1.5.7 already
  * differ), only validity + round trip.  This file restates, sequentially, the algorithm the HIP kernels
  * run in parallel so that block/sequence/bitstream decisions can be compared kernel-vs-CPU byte for byte:
- *   match finder : positions in tiles of ZKE_TILE, groups of 4 tiles; phase 1: every position of a tile looks its
- *                  5-byte hash up in a 2^14-entry table (window 64 KiB) as it was before the tile, and probes the
- *                  offset of the last match taken before the group; lengths capped at 64; then the tile is inserted
+ *   match finder : positions in tiles of 256, groups of 8 tiles; phase 1: two tiles at a time, every position looks its
+ *                  5-byte hash up in a 2^14-entry table (window 64 KiB) as it was before the step, and probes the
+ *                  offset of the last match taken before the group; lengths capped at 64; then the step is inserted
  *   parse        : phase 2: every tile on its own, greedy, left to right; matches end at the tile end; stitched
  *   literals     : Huffman (<= 11 bits, direct 4-bit weights) in 4 streams, or raw / RLE
  *   sequences    : FSE with the PREDEFINED LL/OF/ML tables (Symbol_Compression_Modes = 0)
@@ -27,7 +27,7 @@ u64 zko_xxh64(const u8 *p, size_t len, u64 seed);
 #define ZKE_MINMATCH 6
 #define ZKE_WINDOW 65535u          /* 16-bit positions in the hash table */
 
-static int g_tile = 1024;
+static int g_tile = 256;            /* parse tile; candidates are looked up ZKE_LSTEP tiles at a time */
 void zko_enc_set_tile(int t) { g_tile = t; }
 
 static inline u32 hb32(u32 v) { return 31 - (u32)__builtin_clz(v); }
@@ -242,6 +242,7 @@ static size_t encode_literals(const u8 *lit, size_t n, u8 *dst, size_t cap)
 /* ------------------------------------------------------------------ match finder + parse for one block */
 #define ZKE_PARCAP 64u              /* match length measured per position in phase 1; longer ones are extended by the parse */
 #define ZKE_GROUP 8u                /* tiles whose parses run side by side (one wave each on the GPU) */
+#define ZKE_LSTEP 2u                /* tiles per lookup step (the GPU looks up one position per lane: 512 lanes = 2 tiles of 256) */
 typedef struct { u32 table[1 << ZKE_HASH_LOG]; u32 probe; } enc_state;   /* table: frame-relative position + 1 (0 = empty) */
 
 static u32 match_len(const u8 *a, const u8 *b, const u8 *end)        /* b > a */
@@ -253,8 +254,8 @@ static u32 match_len(const u8 *a, const u8 *b, const u8 *end)        /* b > a */
 }
 
 /* frame-relative positions; base = frame start. Emits sequences for block [bs, be).
- * Tiles are processed in groups of ZKE_GROUP: phase 1 (per-position candidates) runs tile after tile against
- * the table as it was before each tile, all tiles of a group probing the same offset R (the last match offset
+ * Tiles are processed in groups of ZKE_GROUP: phase 1 (per-position candidates) runs ZKE_LSTEP tiles at a time against
+ * the table as it was before the step, all tiles of a group probing the same offset R (the last match offset
  * before the group); then every tile is parsed on its own -- greedy, left to right, matches never cross the
  * tile end -- and the per-tile results are stitched: literals left over at a tile's end join the next sequence.
  * Offset_Value: 1 ("repeat the previous offset") when the offset equals the previous sequence's offset of the
@@ -269,10 +270,13 @@ static u32 find_sequences(enc_state *st, const u8 *base, u32 bs, u32 be, u32 fen
     for (u32 gs = bs; gs < be; gs += T * ZKE_GROUP) {
         const u32 R = st->probe;
         u32 ntiles = 0;
-        for (u32 ts = gs; ts < be && ntiles < ZKE_GROUP; ts += T, ntiles++) {
-            const u32 te = ts + T < be ? ts + T : be;
-            const u8 *lim = base + te;                               /* matches stop at the tile end */
-            for (u32 p = ts; p < te; p++) {
+        /* lookup steps of ZKE_LSTEP tiles: every position of a step sees the table as it was before the step */
+        for (u32 ls = gs; ls < be && ntiles < ZKE_GROUP; ls += T * ZKE_LSTEP) {
+            const u32 le = ls + T * ZKE_LSTEP < be ? ls + T * ZKE_LSTEP : be;
+            for (u32 p = ls; p < le; p++) {
+                const u32 t = ntiles + (p - ls) / T, ts = ls + ((p - ls) / T) * T;
+                const u32 te = ts + T < be ? ts + T : be;
+                const u8 *lim = base + te;                           /* matches stop at the (parse) tile end */
                 u32 l1 = 0, o1 = 0, l2 = 0;
                 const u8 *cap = base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim;
                 if (p + 8 <= fend) {
@@ -282,10 +286,11 @@ static u32 find_sequences(enc_state *st, const u8 *base, u32 bs, u32 be, u32 fen
                 if (R && R <= p) l2 = match_len(base + p - R, base + p, cap);
                 if (l1 < ZKE_MINMATCH) l1 = 0;
                 if (l2 < 4) l2 = 0;
-                if (l2 && l2 >= l1) { blen[ntiles][p - ts] = l2; boff[ntiles][p - ts] = R; }
-                else { blen[ntiles][p - ts] = l1; boff[ntiles][p - ts] = o1; }
+                if (l2 && l2 >= l1) { blen[t][p - ts] = l2; boff[t][p - ts] = R; }
+                else { blen[t][p - ts] = l1; boff[t][p - ts] = o1; }
             }
-            for (u32 p = ts; p < te; p++) if (p + 8 <= fend) st->table[hash5(base + p)] = p + 1;   /* largest position wins a slot */
+            for (u32 p = ls; p < le; p++) if (p + 8 <= fend) st->table[hash5(base + p)] = p + 1;   /* largest position wins a slot */
+            ntiles += (le - ls + T - 1) / T;
         }
         /* per-tile parses + stitching */
         for (u32 t = 0; t < ntiles; t++) {

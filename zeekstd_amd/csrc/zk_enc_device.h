@@ -9,7 +9,8 @@ constexpr uint32_t ZKE_BLOCK = 131072;
 constexpr uint32_t ZKE_HASH_LOG = 14;
 constexpr uint32_t ZKE_MINMATCH = 6;
 constexpr uint32_t ZKE_WINDOW = 65535;
-constexpr uint32_t ZKE_TILE = 1024;
+constexpr uint32_t ZKE_TILE = 256;                // parse tile: matches never cross its end
+constexpr uint32_t ZKE_LSTEP = 2;                 // tiles per lookup step (one position per lane: 512 lanes)
 constexpr uint32_t ZKE_PARCAP = 64;
 constexpr uint32_t ZKE_GROUP = 8;                // tiles parsed side by side, one wave each
 

@@ -8,7 +8,7 @@
 //
 // Pipeline (one stream, everything resident in HBM):
 //   zk_k_xxh64        (checksum_flag) XXH64 of every frame's input
-//   zk_k_enc_match    one workgroup per frame: tiles of 1024 positions -- phase 1 all lanes: 5-byte hash
+//   zk_k_enc_match    one workgroup per frame: tiles of 256 positions, 8 per group -- phase 1 all lanes: 5-byte hash
 //                     lookup in a 2^14-entry LDS table + probe of the last offset, lengths capped at 64;
 //                     phase 1b insert (atomicMax); phase 2 wave 0: greedy parse with ballot skipping,
 //                     wave-wide literal copies -> packed sequences + literal buffer per <=128 KiB block
@@ -77,67 +77,49 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
         for (uint32_t gs = bs; gs < be; gs += ZKE_TILE * ZKE_GROUP) {
             const uint32_t R = probe;
             uint32_t ntiles = 0;
-            // phase 1 + insert, tile after tile
-            for (uint32_t ts = gs; ts < be && ntiles < ZKE_GROUP; ts += ZKE_TILE, ntiles++) {
+            // phase 1 + insert, one lookup step (ZKE_LSTEP tiles, one position per lane) after the other: every position
+            // of a step sees the table as it was before the step
+            for (uint32_t ls = gs; ls < be && ntiles < ZKE_GROUP; ls += ZKE_TILE * ZKE_LSTEP) {
+                const uint32_t le = ls + ZKE_TILE * ZKE_LSTEP < be ? ls + ZKE_TILE * ZKE_LSTEP : be;
+                const uint32_t p = ls + tid;
+                const uint32_t sub = tid / ZKE_TILE, ts = ls + sub * ZKE_TILE;
                 const uint32_t te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
                 const uint8_t *lim = base + te;
-                constexpr int NP = ZKE_TILE / ZKE_THREADS;
-                uint32_t hsh[NP], o1[NP];
-                uint64_t w[NP], c1[NP], c2[NP];
-                // loads of all positions of the lane are issued together (three rounds of memory latency
-                // per tile instead of a dependent chain per position)
-#pragma unroll
-                for (int k = 0; k < NP; k++) {
-                    const uint32_t p = ts + tid + k * ZKE_THREADS;
-                    w[k] = (p < te && p + 8 <= fend) ? zk_ld64(base + p) : 0;
+                const bool in = p < le, wide8 = in && p + 8 <= fend;
+                // the loads of a lane are issued together (three rounds of memory latency per step)
+                const uint64_t w = wide8 ? zk_ld64(base + p) : 0;
+                uint32_t hsh = 0xFFFFFFFFu, o1 = 0;
+                if (wide8) {
+                    hsh = (uint32_t)(((w << 24) * 889523592379ull) >> (64 - ZKE_HASH_LOG));
+                    const uint32_t e = table[hsh];
+                    if (e && p - (e - 1) <= ZKE_WINDOW) o1 = p - (e - 1);
                 }
-#pragma unroll
-                for (int k = 0; k < NP; k++) {
-                    const uint32_t p = ts + tid + k * ZKE_THREADS;
-                    hsh[k] = 0xFFFFFFFFu; o1[k] = 0;
-                    if (p < te && p + 8 <= fend) {
-                        hsh[k] = (uint32_t)(((w[k] << 24) * 889523592379ull) >> (64 - ZKE_HASH_LOG));
-                        const uint32_t e = table[hsh[k]];
-                        if (e && p - (e - 1) <= ZKE_WINDOW) o1[k] = p - (e - 1);
+                const uint64_t c1 = o1 ? zk_ld64(base + p - o1) : 0;                    // p + 8 <= fend holds when o1 != 0
+                const uint64_t c2 = (wide8 && R && R <= p) ? zk_ld64(base + p - R) : 0;
+                if (in) {
+                    const uint8_t *cap = base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim;
+                    uint32_t l1 = 0, l2 = 0;
+                    const bool wide = wide8 && base + p + 8 <= cap;                     // the first 8 bytes are already in registers
+                    if (o1) {
+                        const uint64_t x = w ^ c1;
+                        if (wide && x) l1 = (uint32_t)(__builtin_ctzll(x) >> 3);
+                        else if (wide) l1 = 8 + zke_match_len(base + p + 8 - o1, base + p + 8, cap);
+                        else l1 = zke_match_len(base + p - o1, base + p, cap);
                     }
-                }
-#pragma unroll
-                for (int k = 0; k < NP; k++) {
-                    const uint32_t p = ts + tid + k * ZKE_THREADS;
-                    c1[k] = o1[k] ? zk_ld64(base + p - o1[k]) : 0;                    // p + 8 <= fend holds when o1 != 0
-                    c2[k] = (p < te && R && R <= p && p + 8 <= fend) ? zk_ld64(base + p - R) : 0;
-                }
-#pragma unroll
-                for (int k = 0; k < NP; k++) {
-                    const uint32_t p = ts + tid + k * ZKE_THREADS;
-                    if (p < te) {
-                        const uint8_t *cap = base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim;
-                        uint32_t l1 = 0, l2 = 0;
-                        const bool wide = p + 8 <= fend && base + p + 8 <= cap;        // the first 8 bytes are already in registers
-                        if (o1[k]) {
-                            const uint64_t x = w[k] ^ c1[k];
-                            if (wide && x) l1 = (uint32_t)(__builtin_ctzll(x) >> 3);
-                            else if (wide) l1 = 8 + zke_match_len(base + p + 8 - o1[k], base + p + 8, cap);
-                            else l1 = zke_match_len(base + p - o1[k], base + p, cap);
-                        }
-                        if (R && R <= p) {
-                            const uint64_t x = w[k] ^ c2[k];
-                            if (wide && x) l2 = (uint32_t)(__builtin_ctzll(x) >> 3);
-                            else if (wide) l2 = 8 + zke_match_len(base + p + 8 - R, base + p + 8, cap);
-                            else l2 = zke_match_len(base + p - R, base + p, cap);
-                        }
-                        if (l1 < ZKE_MINMATCH) l1 = 0;
-                        if (l2 < 4) l2 = 0;
-                        best[ntiles][p - ts] = (l2 && l2 >= l1) ? (l2 | (R << 8)) : (l1 | (o1[k] << 8));
+                    if (R && R <= p) {
+                        const uint64_t x = w ^ c2;
+                        if (wide && x) l2 = (uint32_t)(__builtin_ctzll(x) >> 3);
+                        else if (wide) l2 = 8 + zke_match_len(base + p + 8 - R, base + p + 8, cap);
+                        else l2 = zke_match_len(base + p - R, base + p, cap);
                     }
+                    if (l1 < ZKE_MINMATCH) l1 = 0;
+                    if (l2 < 4) l2 = 0;
+                    best[ntiles + sub][p - ts] = (l2 && l2 >= l1) ? (l2 | (R << 8)) : (l1 | (o1 << 8));
                 }
                 __syncthreads();
-#pragma unroll
-                for (int k = 0; k < ZKE_TILE / ZKE_THREADS; k++) {
-                    const uint32_t p = ts + tid + k * ZKE_THREADS;
-                    if (hsh[k] != 0xFFFFFFFFu) atomicMax(&table[hsh[k]], p + 1);       // the largest position wins a slot
-                }
+                if (hsh != 0xFFFFFFFFu) atomicMax(&table[hsh], p + 1);                 // the largest position wins a slot
                 __syncthreads();
+                ntiles += (le - ls + ZKE_TILE - 1) / ZKE_TILE;
             }
             // phase 2: wave w parses tile w on its own (greedy, matches end at the tile end)
             if (wave < ntiles) {
@@ -242,6 +224,7 @@ struct ZkeBits {
 constexpr int ZKE_ENT_THREADS = 256;
 constexpr int ZKE_ENT_BLOCKS = 16;                       // blocks per workgroup: lanes = blocks for the serial bit writers
 static_assert(ZKE_THREADS / 64 == (int)ZKE_GROUP, "one parsing wave per tile of a group");
+static_assert(ZKE_THREADS == (int)(ZKE_TILE * ZKE_LSTEP), "one lookup position per lane");
 
 // One workgroup handles 16 consecutive blocks so that the serial bit writers fill their waves with REAL work:
 // wave 0 = 16 blocks x 4 literal streams (64 lanes), wave 1 lanes 0-15 = the 16 sequence bitstreams (a wave with
