@@ -44,12 +44,14 @@ struct ZkEncTables {
     uint32_t ll_val[36], ml_val[56];            // base | extra bits << 24
 };
 
-struct ZkHufWork {
-    uint32_t cnt[128];
+struct ZkHufCode {              // a block's literal code: kept until the block's streams are written
+    uint8_t len[128];
+    uint16_t code[128];
+};
+struct ZkHufBuild {             // scratch of one tree build
     uint32_t w[256];
     int16_t parent[256];
-    uint8_t idx[128], depth[256], len[128];
-    uint16_t code[128];
+    uint8_t idx[128], depth[256];
 };
 
 ZK_HD uint32_t zke_hash5(const uint8_t *p) { return (uint32_t)(((zk_ld64(p) << 24) * 889523592379ull) >> (64 - ZKE_HASH_LOG)); }
@@ -102,20 +104,21 @@ ZK_HD uint32_t zke_cinit(const uint16_t *state, uint32_t dnb, uint32_t dfs)
 
 // Huffman code lengths (<= 11) for symbols 0..nsym-1 (nsym <= 128); returns max length or -1.
 // Two-queue Huffman over symbols sorted by (count, symbol); counts are halved (rounding up) until the tree fits.
-ZK_HD int zke_huf_lengths(const uint32_t *cnt_in, int nsym, ZkHufWork *h)
+// Code lengths <= 11 from the symbol counts (two-queue Huffman; counts are halved in place until the tree fits).
+// cnt is modified.  Returns the deepest length, or -1 when fewer than two symbols occur.
+ZK_HD int zke_huf_lengths(uint32_t *cnt, int nsym, ZkHufBuild *h, uint8_t *len)
 {
-    for (int s = 0; s < nsym; s++) h->cnt[s] = cnt_in[s];
     for (;;) {
         int m = 0;
-        for (int s = 0; s < nsym; s++) if (h->cnt[s]) h->idx[m++] = (uint8_t)s;
+        for (int s = 0; s < nsym; s++) if (cnt[s]) h->idx[m++] = (uint8_t)s;
         if (m < 2) return -1;
         for (int i = 1; i < m; i++) {
             int k = h->idx[i], j = i - 1;
-            while (j >= 0 && (h->cnt[h->idx[j]] > h->cnt[k] || (h->cnt[h->idx[j]] == h->cnt[k] && h->idx[j] > k))) { h->idx[j + 1] = h->idx[j]; j--; }
+            while (j >= 0 && (cnt[h->idx[j]] > cnt[k] || (cnt[h->idx[j]] == cnt[k] && h->idx[j] > k))) { h->idx[j + 1] = h->idx[j]; j--; }
             h->idx[j + 1] = (uint8_t)k;
         }
         int nn = m;
-        for (int i = 0; i < m; i++) h->w[i] = h->cnt[h->idx[i]];
+        for (int i = 0; i < m; i++) h->w[i] = cnt[h->idx[i]];
         int a = 0, bq = m;
         while ((m - a) + (nn - bq) > 1) {
             int p[2];
@@ -129,16 +132,16 @@ ZK_HD int zke_huf_lengths(const uint32_t *cnt_in, int nsym, ZkHufWork *h)
         for (int i = nn - 2; i >= 0; i--) h->depth[i] = (uint8_t)(h->depth[h->parent[i]] + 1);
         for (int i = 0; i < m; i++) if (h->depth[i] > maxd) maxd = h->depth[i];
         if (maxd <= 11) {
-            for (int s = 0; s < nsym; s++) h->len[s] = 0;
-            for (int i = 0; i < m; i++) h->len[h->idx[i]] = h->depth[i];
+            for (int s = 0; s < nsym; s++) len[s] = 0;
+            for (int i = 0; i < m; i++) len[h->idx[i]] = h->depth[i];
             return maxd;
         }
-        for (int s = 0; s < nsym; s++) if (h->cnt[s]) h->cnt[s] = (h->cnt[s] + 1) >> 1;
+        for (int s = 0; s < nsym; s++) if (cnt[s]) cnt[s] = (cnt[s] + 1) >> 1;
     }
 }
 
 // canonical codes exactly as the decoder's table fill assigns them (weight 1 first, symbols ascending)
-ZK_HD void zke_huf_codes(ZkHufWork *h, int nsym, int maxbits)
+ZK_HD void zke_huf_codes(ZkHufCode *h, int nsym, int maxbits)
 {
     uint32_t pos = 0;
     for (int wt = 1; wt <= maxbits; wt++)

@@ -236,7 +236,8 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
 {
     __shared__ uint32_t cnt[ZKE_ENT_BLOCKS][256];
     __shared__ ZkEncTables T;                              // predefined FSE compression tables
-    __shared__ ZkHufWork hw[ZKE_ENT_BLOCKS];
+    __shared__ ZkHufCode hw[ZKE_ENT_BLOCKS];
+    __shared__ ZkHufBuild hbuild[ZKE_ENT_BLOCKS / 2];      // trees are built in two rounds of 8: a build needs 1.9 KiB, the codes 384 B
     __shared__ uint32_t s_sizes[ZKE_ENT_BLOCKS][5];        // 4 literal streams + sequence bitstream
     __shared__ uint32_t s_lit_mode[ZKE_ENT_BLOCKS], s_maxbits[ZKE_ENT_BLOCKS], s_tree[ZKE_ENT_BLOCKS], s_diff[ZKE_ENT_BLOCKS], s_mode[ZKE_ENT_BLOCKS];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -259,20 +260,26 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
         for (uint32_t i = tid; i < blk.nlit; i += ZKE_ENT_THREADS) atomicAdd(&cnt[j][lt[i]], 1u);
     }
     __syncthreads();
-    // literal mode + Huffman code of block j on lane j of wave 0 (16 active lanes)
-    if (tid < ZKE_ENT_BLOCKS && tid < nb) {
-        const uint32_t j = tid, nlit = blocks[b0 + j].nlit;
-        // literal mode: 1 = RLE, 2 = Huffman (4 streams), 0 = raw      (oracle encode_literals)
-        uint32_t mode = 0, maxsym = 0, distinct = 0;
-        for (uint32_t sy = 0; sy < 256; sy++) if (cnt[j][sy]) { maxsym = sy; distinct++; }
-        if (nlit > 0 && distinct == 1) mode = 1;
-        else if (nlit >= 64 && maxsym < 128) {
-            int mb = zke_huf_lengths(cnt[j], (int)maxsym + 1, &hw[j]);
-            if (mb > 0) { zke_huf_codes(&hw[j], (int)maxsym + 1, mb); mode = 2; s_maxbits[j] = (uint32_t)mb; s_tree[j] = maxsym; }
+    // literal mode + Huffman code: two rounds of 8 blocks, block j on lanes j % 8 and j % 8 + 8 of wave 0 (the second
+    // lane shadows the first with identical LDS writes: >= 16 active lanes, see zk_decode.hip)
+    for (uint32_t round = 0; round < 2; round++) {
+        if (tid < ZKE_ENT_BLOCKS) {
+            const uint32_t j = (tid & 7) + 8 * round;
+            if (j < nb) {
+                const uint32_t nlit = blocks[b0 + j].nlit;
+                // literal mode: 1 = RLE, 2 = Huffman (4 streams), 0 = raw      (oracle encode_literals)
+                uint32_t mode = 0, maxsym = 0, distinct = 0;
+                for (uint32_t sy = 0; sy < 256; sy++) if (cnt[j][sy]) { maxsym = sy; distinct++; }
+                if (nlit > 0 && distinct == 1) mode = 1;
+                else if (nlit >= 64 && maxsym < 128) {
+                    int mb = zke_huf_lengths(cnt[j], (int)maxsym + 1, &hbuild[tid & 7], hw[j].len);
+                    if (mb > 0) { zke_huf_codes(&hw[j], (int)maxsym + 1, mb); mode = 2; s_maxbits[j] = (uint32_t)mb; s_tree[j] = maxsym; }
+                }
+                s_lit_mode[j] = mode;
+            }
         }
-        s_lit_mode[j] = mode;
+        __syncthreads();
     }
-    __syncthreads();
     // serial bit writers: wave 0 = 4 literal streams of each block, wave 1 = the sequence bitstream of each block
     if (wave == 0) {
         const uint32_t j = lane >> 2, k = lane & 3;
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             const uint32_t n_k = k < 3 ? q : nlit - 3 * q;
             const uint8_t *sp = lits + blk.lit_base + k * q;
             ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + k * scap, scap, true);
-            const ZkHufWork &h = hw[j];
+            const ZkHufCode &h = hw[j];
             for (uint32_t i = n_k; i-- > 0;) { const uint32_t sy = sp[i]; b.add(h.code[sy], h.len[sy]); }   // last symbol first
             s_sizes[j][k] = b.close();
         }
