@@ -3,14 +3,18 @@
 // Replaces, for N frames at a time, what the reference does one 128 KiB step at a time
 // through ZSTD_decompressStream (lib/src/decode.rs:242-256; libzstd 1.5.7 underneath).
 //
-// Pipeline (all launches on one stream, data resident in HBM):
+// Pipeline (data resident in HBM; huf and fse run side by side on two queues, the rest in order):
 //   zk_k_walk (count)  one lane per frame: frame header + block chain -> ZkFrameInfo
 //   zk_k_scan          exclusive prefix sums over frames -> ZkFrameBase, totals
 //   zk_k_walk (fill)   one lane per frame -> ZkBlock[] (block list, table inheritance)
-//   zk_k_huf           one lane per Huffman stream (4 per block), tables in LDS -> literal scratch
-//   zk_k_fse           one lane per block: FSE tables in LDS, 3-state walk -> ZkSeq[] (+ out_size, symbolic reps)
-//   zk_k_exec          one workgroup per frame: byte-parallel sequence execution, coalesced 16 B stores
-//   zk_k_xxh64         4 lanes per frame (the 4 XXH64 accumulators), verifies Content_Checksum
+//   zk_k_huf           wave 0: one lane per Huffman stream (4 per block), tables in an LDS pool sized by tree depth;
+//                      wave 1: companion lanes (touch the stream ahead, store the decoded packs) -> literal scratch
+//   zk_k_fse_predef    blocks with predefined tables: one lane per block, 64 blocks per wave in lock step, shared
+//                      tables, cooperative 64-B record stores -> ZkSeq[] (+ out_size, symbolic reps)
+//   zk_k_fse           blocks with their own tables: one lane per block, FSE tables in LDS, 3-state walk -> ZkSeq[]
+//   zk_k_exec          one workgroup per frame: byte-parallel sequence execution through a per-byte source map,
+//                      coalesced 16 B stores; optional raw-content prefix before the frame
+//   zk_k_xxh64         one wave per frame (4 accumulator chains), verifies Content_Checksum
 //
 // No MFMA anywhere: this is byte-serial entropy decoding; the roofline is HBM (c_i + d_i bytes per frame).
 #include <hip/hip_runtime.h>

@@ -8,12 +8,13 @@
 //
 // Pipeline (one stream, everything resident in HBM):
 //   zk_k_xxh64        (checksum_flag) XXH64 of every frame's input
-//   zk_k_enc_match    one workgroup per frame: tiles of 256 positions, 8 per group -- phase 1 all lanes: 5-byte hash
-//                     lookup in a 2^14-entry LDS table + probe of the last offset, lengths capped at 64;
-//                     phase 1b insert (atomicMax); phase 2 wave 0: greedy parse with ballot skipping,
-//                     wave-wide literal copies -> packed sequences + literal buffer per <=128 KiB block
-//   zk_k_enc_entropy  one workgroup per block: literal histogram, Huffman lengths (<= 11 bits), 4 literal
-//                     streams (4 lanes) and the FSE sequence bitstream with the predefined tables (1 lane)
+//   zk_k_enc_match    one workgroup (8 waves) per frame: tiles of 256 positions, 8 per group -- phase 1 all lanes,
+//                     two tiles per step: 5-byte hash lookup in a 2^14-entry LDS table + probe of the last offset,
+//                     lengths capped at 64, then insert (atomicMax); phase 2: wave w parses tile w greedily
+//                     (ballot skipping), a stitch pass joins the tiles -> packed sequences + literal buffer per block.
+//                     Prefix mode: the matcher reads [prefix tail | frame] records (zk_k_enc_stage_hist)
+//   zk_k_enc_entropy  one workgroup per 16 blocks: literal histograms, Huffman lengths (<= 11 bits), 64 literal
+//                     streams (wave 0) and 16 FSE sequence bitstreams with the predefined tables (wave 1)
 //                     side by side, block payload assembled in scratch, raw / RLE fallbacks decided
 //   zk_k_enc_sizes    per frame: compressed size = header + blocks (+ checksum)   -> seek-table entries
 //   zk_k_scan64       exclusive scan of the frame sizes -> where each frame lands in the output stream
