@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-seek", action="store_true")
     ap.add_argument("--no-fork", action="store_true", help="generate the inputs in this process (profiling runs)")
+    ap.add_argument("--no-ref-archive", action="store_true", help="skip the secondary leg on a CPU-libzstd-made archive")
     ap.add_argument("--sync", action="store_true",
                     help="time one batch at a time (zk_decode_frames_dev) instead of two batches in flight; the "
                          "kernel-trace profile uses this so that kernel durations are not inflated by overlap")
@@ -203,7 +204,10 @@ def main():
     workers = 1 if args.no_fork else max(1, min(64, cores // max(1, world) - 1))
     use_gpu_archive = args.archive == "gpu" or (args.archive == "auto" and args.workload == "c3")
     t0 = time.time()
-    data, z_comp, z_frames, hashes = build_inputs(rank * nframes, nframes, level, cks, workers, not use_gpu_archive, rank)
+    # a reference-made archive of the same input is prepared too (single-GPU runs): its decode rate is reported beside the
+    # headline, because archives written by zeekstd's own CPU Encoder are what a drop-in user decodes first
+    want_ref_archive = (not use_gpu_archive) or (world == 1 and not args.no_ref_archive)
+    data, z_comp, z_frames, hashes = build_inputs(rank * nframes, nframes, level, cks, workers, want_ref_archive, rank)
     t_setup = time.time() - t0
 
     import torch
@@ -324,6 +328,43 @@ def main():
     total_bytes = dsize * world * args.steps
     value = total_bytes / elapsed / 2**30
 
+    # ---- secondary leg: the same steps on the archive the reference's CPU Encoder loop (libzstd) wrote for this input
+    ref_info = None
+    if use_gpu_archive and want_ref_archive and z_comp:
+        r_c = np.zeros(nframes + 1, np.uint64); r_c[1:] = np.cumsum([f[0] for f in z_frames])
+        r_csize = int(r_c[-1])
+        dr_comp = torch.from_numpy(np.frombuffer(z_comp + b"\0" * 64, np.uint8).copy()).to(dev)
+        dr_c = torch.from_numpy(r_c.view(np.int64)).to(dev)
+
+        def ref_pipelined(k):
+            pending = []
+            for i in range(k):
+                if len(pending) == 2:
+                    if eng.decode_wait(pending.pop(0)) != 0:
+                        raise RuntimeError("decode of the reference-made archive failed")
+                pending.append(eng.decode_submit_dev(dr_comp, r_csize, dr_c, d_d, 0, nframes, d_outs[i & 1], dsize, True, d_sts[i & 1]))
+            for sl in pending:
+                if eng.decode_wait(sl) != 0:
+                    raise RuntimeError("decode of the reference-made archive failed")
+
+        ref_pipelined(2)
+        if not torch.equal(d_outs[1][:dsize], d_src):
+            raise RuntimeError("decode of the reference-made archive differs from the input bytes")
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        ref_pipelined(args.steps)
+        torch.cuda.synchronize()
+        r_el = time.perf_counter() - t2
+        eng.set_profiling(True)
+        eng.decode_frames_dev(dr_comp, r_csize, dr_c, d_d, 0, nframes, d_out, dsize, True, d_st)
+        r_k = eng.kernel_times()
+        eng.set_profiling(False)
+        ref_info = {"value": round(dsize * args.steps / r_el / 2**30, 3), "unit": "GiB/s", "ms_per_step": round(r_el / args.steps * 1e3, 3),
+                    "compressed_bytes": r_csize, "kernel_ms": {k: round(v, 3) for k, v in r_k.items()},
+                    "note": "archive written by the reference Encoder loop over the box's libzstd (level 1: 128 KiB blocks with "
+                            "their own FSE tables -> zk_k_fse instead of zk_k_fse_predef); bit-exact, checksums verified"}
+        del dr_comp
+
     # ---- roofline of the dominant kernel: HIP events on the launch stream, live
     eng.set_profiling(True)
     acc = {}
@@ -378,6 +419,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "reference_made_archive": ref_info,
             "one_batch_at_a_time": {"value": round(dsize * args.steps / sync_elapsed / 2**30, 3), "unit": "GiB/s",
                                     "ms_per_step": round(sync_elapsed / args.steps * 1e3, 3),
                                     "note": "same steps through the synchronous zk_decode_frames_dev (rank-local, no overlap between batches)"},
