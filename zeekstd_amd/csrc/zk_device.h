@@ -786,6 +786,17 @@ struct ZkRevA {
     ZK_HDM void clamp() {}
 };
 
+// The n (<= 31) most significant bits of a 32-bit word, 0 for n == 0: one bit-field extract on the device (a width
+// of 0 yields 0), where the portable form needs a shift, a compare and a select.
+ZK_HD uint32_t zk_top_bits(uint32_t hi, uint32_t n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(hi, 32u - n, n);
+#else
+    return n ? hi >> (32 - n) : 0u;
+#endif
+}
+
 // Wave-cooperative flush of the 4-record rings of a 64-lane wave (device only, zk_k_fse_predef): a lane's four
 // 16-B records are one 64-B line of its block's record array, so instead of every lane storing its own ring
 // (4 instructions x 64 separate L2 write requests) four neighbouring lanes store one ring per instruction
@@ -842,15 +853,15 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const u
                 const uint32_t h0 = (uint32_t)(S >> 32); S <<= nbl;
                 const uint32_t h1 = (uint32_t)(S >> 32); S <<= nbm;
                 const uint32_t h2 = (uint32_t)(S >> 32);
-                sl = zk_cell_base(cl) + (nbl ? h0 >> (32 - nbl) : 0);
-                sm = zk_cell_base(cm) + (nbm ? h1 >> (32 - nbm) : 0);
-                so = zk_cell_base(co) + (nbo ? h2 >> (32 - nbo) : 0);
+                sl = zk_cell_base(cl) + zk_top_bits(h0, nbl);
+                sm = zk_cell_base(cm) + zk_top_bits(h1, nbm);
+                so = zk_cell_base(co) + zk_top_bits(h2, nbo);
                 cl = LL[sl]; co = OF[so]; cm = ML[sm];                     // issued early; used next iteration
                 // value bits (off the chain)
                 uint64_t V = X;
-                ofx = nOf ? (uint32_t)(V >> 32) >> (32 - (nOf & 31)) : 0; V <<= (nOf & 31);
-                mlx = nMl ? (uint32_t)(V >> 32) >> (32 - nMl) : 0; V <<= nMl;
-                llx = nLl ? (uint32_t)(V >> 32) >> (32 - nLl) : 0;
+                ofx = zk_top_bits((uint32_t)(V >> 32), nOf & 31); V <<= (nOf & 31);
+                mlx = zk_top_bits((uint32_t)(V >> 32), nMl); V <<= nMl;
+                llx = zk_top_bits((uint32_t)(V >> 32), nLl);
             } else {                                                                // more bits than the window guarantees (or over-read)
                 ofx = r.read(nOf & 31); mlx = r.read(nMl); llx = r.read(nLl);
                 sl = zk_cell_base(cl) + r.read(nbl);
