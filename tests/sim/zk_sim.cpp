@@ -87,17 +87,19 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
     }
     // fse: one "lane" per block
     ZkSeqTables *T = new ZkSeqTables;
+    ZkSeqTables16 *T16 = new ZkSeqTables16;
     for (uint64_t bi = 0; bi < nb; bi++) {
         ZkBlock b = blocks[bi];
         if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK) continue;
         // like the device: all-predefined blocks go through the aligned-word reader, the rest through the unaligned one
-        if (b.seq_modes == 0) zk_decode_sequences<ZkRevA>(comp, blocks.data(), b, T, seqs.data() + b.seq_base, LLV, MLV);
-        else zk_decode_sequences<ZkRevU>(comp, blocks.data(), b, T, seqs.data() + b.seq_base, LLV, MLV);
+        if (b.seq_modes == 0) zk_decode_sequences<ZkRevA, ZkCells32>(comp, blocks.data(), b, T, seqs.data() + b.seq_base, LLV, MLV);
+        else zk_decode_sequences<ZkRevU, ZkCells16>(comp, blocks.data(), b, T16, seqs.data() + b.seq_base, LLV, MLV);     // zk_k_fse: compact cells
         blocks[bi].out_size = b.out_size;
         for (int k = 0; k < 3; k++) blocks[bi].rep_out[k] = b.rep_out[k];
         blocks[bi].status = b.status;
     }
     delete T;
+    delete T16;
     // exec: one "workgroup" per frame; tiles of THREADS x B bytes, slot marking + per-byte source map (zk_exec_slot_span / zk_exec_slot_words)
     const uint32_t THREADS = 256, B = (uint32_t)exec_b, CAPS = (uint32_t)exec_chunk;      // CAPS: staged sequences per tile
     std::vector<ZkSeq> st(CAPS + 1);

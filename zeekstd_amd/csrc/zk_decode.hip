@@ -43,28 +43,29 @@ __global__ __launch_bounds__(64) void zk_k_walk(const uint8_t *comp, const uint6
     }
 }
 
-// exclusive scan of (n_blocks, n_seq, lit_bytes) over frames; one workgroup
+// exclusive scan of (n_blocks, n_seq, lit_bytes) over frames + the count of blocks with their own sequence tables;
+// one workgroup.  totals: [0..2] the three sums, [4] that count ([3] is the first-error word of zk_k_status)
 __global__ __launch_bounds__(1024) void zk_k_scan(const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals)
 {
-    __shared__ uint64_t wsum[16][3];
-    __shared__ uint64_t carry[3];
+    __shared__ uint64_t wsum[16][4];
+    __shared__ uint64_t carry[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 3) carry[tid] = 0;
+    if (tid < 4) carry[tid] = 0;
     __syncthreads();
     for (uint32_t base = 0; base < count; base += 1024) {
         uint32_t f = base + tid;
-        uint64_t v[3] = {0, 0, 0};
-        if (f < count) { v[0] = infos[f].n_blocks; v[1] = infos[f].n_seq; v[2] = infos[f].lit_bytes; }
-        uint64_t inc[3];
-        for (int k = 0; k < 3; k++) {
+        uint64_t v[4] = {0, 0, 0, 0};
+        if (f < count) { v[0] = infos[f].n_blocks; v[1] = infos[f].n_seq; v[2] = infos[f].lit_bytes; v[3] = infos[f].n_own_tables; }
+        uint64_t inc[4];
+        for (int k = 0; k < 4; k++) {
             uint64_t x = v[k];
             for (int d = 1; d < 64; d <<= 1) { uint64_t y = __shfl_up(x, d, 64); if ((int)lane >= d) x += y; }
             inc[k] = x;
             if (lane == 63) wsum[wave][k] = x;
         }
         __syncthreads();
-        uint64_t pre[3];
-        for (int k = 0; k < 3; k++) {
+        uint64_t pre[4];
+        for (int k = 0; k < 4; k++) {
             uint64_t s = carry[k];
             for (uint32_t w = 0; w < wave; w++) s += wsum[w][k];
             pre[k] = s;
@@ -75,10 +76,11 @@ __global__ __launch_bounds__(1024) void zk_k_scan(const ZkFrameInfo *infos, uint
             bases[f].lit_base = pre[2] + inc[2] - v[2];
         }
         __syncthreads();
-        if (tid == 1023) for (int k = 0; k < 3; k++) carry[k] = pre[k] + inc[k];
+        if (tid == 1023) for (int k = 0; k < 4; k++) carry[k] = pre[k] + inc[k];
         __syncthreads();
     }
     if (tid < 3) totals[tid] = carry[tid];
+    if (tid == 3) totals[4] = carry[3];
 }
 
 // ------------------------------------------------------------------------------------------------ Huffman literals
@@ -227,15 +229,18 @@ __global__ __launch_bounds__(128) void zk_k_huf(const uint8_t *comp, ZkBlock *bl
 }
 
 // ------------------------------------------------------------------------------------------------ FSE sequences
-// One lane per block; each lane owns 5.25 KiB of LDS (LL/ML 2^9 + OF 2^8 cells + build scratch), so a
-// CU holds 28 blocks.  The 3-state walk is a dependent chain (cells -> bit counts -> next states), so
-// the 28 lanes are spread over 4 waves (one per SIMD) instead of sitting in one.
-constexpr int ZK_FSE_BLOCKS = 28;
-constexpr int ZK_FSE_WAVES = 4;
-constexpr int ZK_FSE_PER_WAVE = ZK_FSE_BLOCKS / ZK_FSE_WAVES;
+// One lane per block, the block's LL / ML (2^9) and OF (2^8) tables + build scratch / record ring in LDS.  A block's
+// sequences are one serial chain (cells -> bit counts -> next states) of ~0.5 us per sequence, so the kernel's speed
+// is blocks in flight x instructions per sequence, and the table footprint sets the former:
+//   ZkCells32, 5.25 KiB per block: 28 blocks per CU on 4 waves (one per SIMD) -- fewest instructions per sequence;
+//   ZkCells16, 2.75 KiB per block: 56 blocks per CU on 8 waves -- ~18 more instructions per sequence and the value
+//              table's bit count on the chain (+50% per lane), twice the lanes: wins once the blocks no longer fit in
+//              one round of the 32-bit layout (measured: 4 GiB of libzstd frames 24.0 -> 20.8 ms, 256 MiB 4.6 -> 6.9).
+template <typename CP, int ZK_FSE_BLOCKS, int ZK_FSE_WAVES>
 __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
 {
-    __shared__ ZkSeqTables T[ZK_FSE_BLOCKS];
+    constexpr int ZK_FSE_PER_WAVE = ZK_FSE_BLOCKS / ZK_FSE_WAVES;
+    __shared__ ZkSeqTablesT<CP> T[ZK_FSE_BLOCKS];
     __shared__ uint32_t llv[36], mlv[53];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *com
     const uint32_t bi = blockIdx.x * ZK_FSE_BLOCKS + slot;
     ZkBlock b = blocks[bi];
     if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK || b.seq_modes == 0) return;      // all-predefined blocks: zk_k_fse_predef
-    zk_decode_sequences(comp, blocks, b, &T[slot], seqs + b.seq_base, llv, mlv, real);
+    zk_decode_sequences<ZkRevU, CP>(comp, blocks, b, &T[slot], seqs + b.seq_base, llv, mlv, real);
     if (!real) return;
     ZkBlock *o = &blocks[bi];
     o->out_size = b.out_size;
@@ -571,16 +576,21 @@ void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     if (!nblocks) return;
     hipLaunchKernelGGL(zk_k_huf, dim3((nblocks + ZK_HUF_BLOCKS - 1) / ZK_HUF_BLOCKS), dim3(128), 0, st, comp, blocks, nblocks, lit);
 }
-void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
+void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeq *seqs)
 {
     if (!nblocks) return;
     // reader choice (zk_device.h): with >= 6 workgroups per CU the memory pipeline is the limit (aligned words, each
     // loaded once); below that a lane's instruction count is (one unaligned load per sequence).  Measured crossover
     // on 32 KiB blocks between 1024 and 2048 frames of 2 MiB.
     const uint32_t wgs = (nblocks + ZK_FSEP_LANES - 1) / ZK_FSEP_LANES;
-    if (wgs >= 6 * 256) hipLaunchKernelGGL(zk_k_fse_predef<ZkRevA>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
-    else hipLaunchKernelGGL(zk_k_fse_predef<ZkRevU>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
-    hipLaunchKernelGGL(zk_k_fse, dim3((nblocks + ZK_FSE_BLOCKS - 1) / ZK_FSE_BLOCKS), dim3(64 * ZK_FSE_WAVES), 0, st, comp, blocks, nblocks, seqs);
+    if (n_own_tables < nblocks) {          // at least one block may be all-predefined
+        if (wgs >= 6 * 256) hipLaunchKernelGGL(zk_k_fse_predef<ZkRevA>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
+        else hipLaunchKernelGGL(zk_k_fse_predef<ZkRevU>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
+    }
+    // blocks with their own tables (every block is visited, the others return at once): cell format by how many
+    // rounds the 32-bit layout would need
+    if (n_own_tables > 28u * 256u) hipLaunchKernelGGL((zk_k_fse<ZkCells16, 56, 8>), dim3((nblocks + 55) / 56), dim3(512), 0, st, comp, blocks, nblocks, seqs);
+    else if (n_own_tables) hipLaunchKernelGGL((zk_k_fse<ZkCells32, 28, 4>), dim3((nblocks + 27) / 28), dim3(256), 0, st, comp, blocks, nblocks, seqs);
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeq *seqs,

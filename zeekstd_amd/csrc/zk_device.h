@@ -51,7 +51,7 @@ struct ZkFrameInfo {            // written by the frame walker, one per frame
     uint32_t checksum_flag;
     uint32_t checksum;          // stored Content_Checksum (valid if flag)
     uint32_t window;            // clamped to 2^31
-    uint32_t pad;
+    uint32_t n_own_tables;      // blocks whose sequences use tables of their own (not all-predefined): need zk_k_fse
 };
 
 struct ZkFrameBase {            // exclusive prefix sums over frames
@@ -182,6 +182,32 @@ ZK_HD uint32_t zk_cell_nb(uint32_t c) { return (c >> 8) & 0xf; }
 ZK_HD uint32_t zk_cell_xbits(uint32_t c) { return (c >> 12) & 0x1f; }
 ZK_HD uint32_t zk_cell_base(uint32_t c) { return c >> 17; }
 
+// Two cell formats behind one interface (what the table build writes, what the walk reads):
+//   ZkCells32  the packed 32-bit cell above (shared predefined tables, Huffman weight tables);
+//   ZkCells16  16 bits, for tables that live per block in LDS (zk_k_fse), where the table footprint sets how many
+//              blocks a CU decodes at once:  sym[15:10] | e[9:0].  e folds (nb, base): base is a multiple of 2^nb and
+//              base + 2^nb <= 512, so for nb >= 1 the number n = base + 2^(nb-1) < 512 has its lowest set bit at nb-1
+//              (nb = ctz(n) + 1, base = n with that bit cleared); nb == 0 cells take e = 512 + base.  The number of
+//              extra value bits is not stored: it comes from the symbol's entry in the value table (LL / ML) or is
+//              the symbol itself (OF).
+struct ZkCells32 {
+    typedef uint32_t cell_t;
+    static ZK_HDM cell_t make(uint32_t sym, uint32_t nb, uint32_t xbits, uint32_t base) { return zk_cell(sym, nb, xbits, base); }
+    static ZK_HDM uint32_t sym(cell_t c) { return zk_cell_sym(c); }
+    static ZK_HDM uint32_t nb(cell_t c) { return zk_cell_nb(c); }
+    static ZK_HDM uint32_t base(cell_t c) { return zk_cell_base(c); }
+    static ZK_HDM uint32_t xbits(cell_t c, const uint32_t *) { return zk_cell_xbits(c); }
+};
+struct ZkCells16 {
+    typedef uint16_t cell_t;
+    static ZK_HDM cell_t make(uint32_t sym, uint32_t nb, uint32_t, uint32_t base)
+    { return (cell_t)((sym << 10) | (nb ? base + (1u << (nb - 1)) : 512u + base)); }
+    static ZK_HDM uint32_t sym(cell_t c) { return (uint32_t)c >> 10; }
+    static ZK_HDM uint32_t nb(cell_t c) { const uint32_t e = c & 1023u; return e >= 512u ? 0u : (uint32_t)__builtin_ctz(e | 512u) + 1u; }
+    static ZK_HDM uint32_t base(cell_t c) { const uint32_t e = c & 1023u; return e >= 512u ? e - 512u : e & (e - 1u); }
+    static ZK_HDM uint32_t xbits(cell_t c, const uint32_t *value_table) { const uint32_t s = (uint32_t)c >> 10; return value_table ? value_table[s] >> 24 : s; }
+};
+
 // value tables: base | bits << 24
 #define ZK_LLV(b, n) ((uint32_t)(b) | ((uint32_t)(n) << 24))
 #define ZK_LL_TABLE { \
@@ -252,19 +278,20 @@ ZK_HD uint32_t zk_fse_read_ncount(const uint8_t *src, uint32_t len, uint32_t max
 }
 
 // A.6 decode-table build.  cells[1<<al]; next[] scratch of nsym u16.  kind selects the xbits column.
-ZK_HD bool zk_fse_build(uint32_t *cells, const int16_t *norm, uint32_t nsym, uint32_t al, uint16_t *next,
+template <typename CP = ZkCells32>
+ZK_HD bool zk_fse_build(typename CP::cell_t *cells, const int16_t *norm, uint32_t nsym, uint32_t al, uint16_t *next,
                         const uint32_t *value_table /* LL/ML value table or nullptr (OF / weights) */)
 {
     uint32_t size = 1u << al, mask = size - 1;
     int32_t high = (int32_t)size - 1;
     for (uint32_t s = 0; s < nsym; s++) {
-        if (norm[s] == -1) { if (high < 0) return false; cells[high--] = s; next[s] = 1; }
+        if (norm[s] == -1) { if (high < 0) return false; cells[high--] = (typename CP::cell_t)s; next[s] = 1; }
         else next[s] = (uint16_t)norm[s];
     }
     uint32_t step = (size >> 1) + (size >> 3) + 3, pos = 0;
     for (uint32_t s = 0; s < nsym; s++) {
         for (int32_t i = 0; i < norm[s]; i++) {
-            cells[pos] = s;
+            cells[pos] = (typename CP::cell_t)s;
             do { pos = (pos + step) & mask; } while ((int32_t)pos > high);
         }
     }
@@ -274,7 +301,7 @@ ZK_HD bool zk_fse_build(uint32_t *cells, const int16_t *norm, uint32_t nsym, uin
         uint32_t x = next[s]++;
         uint32_t nb = al - zk_highbit(x);
         uint32_t xb = value_table ? (value_table[s] >> 24) : s;
-        cells[i] = zk_cell(s, nb, xb & 31u, (x << nb) - size);
+        cells[i] = CP::make(s, nb, xb & 31u, (x << nb) - size);
     }
     return true;
 }
@@ -528,7 +555,7 @@ ZK_HD void zk_walk_frame(const uint8_t *comp, uint64_t c_begin, uint64_t c_end, 
                          uint32_t frame_idx, const ZkFrameBase *base, ZkBlock *blocks, ZkFrameInfo &fi)
 {
     fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; fi.status = ZK_OK;
-    fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.pad = 0;
+    fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.n_own_tables = 0;
     uint64_t csz = c_end - c_begin;
     const uint8_t *f = comp + c_begin;
     if (csz < 6) { fi.status = ZK_E_SRC_SIZE_WRONG; return; }
@@ -600,6 +627,7 @@ ZK_HD void zk_walk_frame(const uint8_t *comp, uint64_t c_begin, uint64_t c_end, 
                 uint32_t modes = c[so];
                 if (modes & 3) { fi.status = ZK_E_CORRUPTION; return; }
                 b.seq_modes = (uint8_t)modes; b.seq_off = so;
+                if (modes) fi.n_own_tables++;
                 for (int t = 0; t < 3; t++) {
                     uint32_t m = (modes >> (6 - 2 * t)) & 3;
                     if (m != 3) tab_def[t] = (uint32_t)blk;
@@ -642,19 +670,23 @@ ZK_HD uint32_t zk_rep_resolve(uint32_t v, const uint32_t init[3])
 }
 
 // ---------------------------------------------------------------- sequence section decode (one lane per block)
-struct ZkSeqTables {                 // LDS-resident, per lane
-    uint32_t ll[512];
-    uint32_t ml[512];
-    uint32_t of[256];
+template <typename CP>
+struct ZkSeqTablesT {                // LDS-resident, per lane
+    typename CP::cell_t ll[512];
+    typename CP::cell_t ml[512];
+    typename CP::cell_t of[256];
     union {                          // table-build scratch, later the output ring (16 x ZkSeq = 256 B)
         struct { int16_t norm[64]; uint16_t next[64]; };
         ZkSeq ring[16];
     };
 };
+typedef ZkSeqTablesT<ZkCells32> ZkSeqTables;       // 5.25 KiB
+typedef ZkSeqTablesT<ZkCells16> ZkSeqTables16;     // 2.75 KiB
 
 // Locate + build table t of block `def` (the block whose header defines the table in force).
 // comp: compressed buffer.  Returns bytes the description occupies in `def` (for own-block parsing), or -1.
-ZK_HD int32_t zk_seq_table_setup(const uint8_t *comp, const ZkBlock &def, int t, ZkSeqTables *T, uint32_t *al_out,
+template <typename CP = ZkCells32>
+ZK_HD int32_t zk_seq_table_setup(const uint8_t *comp, const ZkBlock &def, int t, ZkSeqTablesT<CP> *T, uint32_t *al_out,
                                  const uint32_t *ll_values, const uint32_t *ml_values)
 {
     const int16_t ll_def[36] = ZK_LL_DEFNORM;
@@ -676,14 +708,14 @@ ZK_HD int32_t zk_seq_table_setup(const uint8_t *comp, const ZkBlock &def, int t,
         }
     }
     uint32_t m = (modes >> (6 - 2 * t)) & 3;
-    uint32_t *cells = t == ZK_TAB_LL ? T->ll : t == ZK_TAB_OF ? T->of : T->ml;
+    typename CP::cell_t *cells = t == ZK_TAB_LL ? T->ll : t == ZK_TAB_OF ? T->of : T->ml;
     const uint32_t *vt = t == ZK_TAB_LL ? ll_values : t == ZK_TAB_ML ? ml_values : nullptr;
     if (m == 0) {
         const int16_t *d = t == ZK_TAB_LL ? ll_def : t == ZK_TAB_OF ? of_def : ml_def;
         nsym = t == ZK_TAB_LL ? 36 : t == ZK_TAB_OF ? 29 : 53;
         al = t == ZK_TAB_OF ? 5 : 6;
         for (uint32_t i = 0; i < nsym; i++) T->norm[i] = d[i];
-        if (!zk_fse_build(cells, T->norm, nsym, al, T->next, vt)) return -1;
+        if (!zk_fse_build<CP>(cells, T->norm, nsym, al, T->next, vt)) return -1;
         *al_out = al;
         return 0;
     }
@@ -691,7 +723,7 @@ ZK_HD int32_t zk_seq_table_setup(const uint8_t *comp, const ZkBlock &def, int t,
         if (p >= def.bsize) return -1;
         uint32_t s = c[p];
         if (s > zk_tab_maxsym(t)) return -1;
-        cells[0] = zk_cell(s, 0, (vt ? (vt[s] >> 24) : s) & 31u, 0);
+        cells[0] = CP::make(s, 0, (vt ? (vt[s] >> 24) : s) & 31u, 0);
         *al_out = 0;
         return 1;
     }
@@ -699,7 +731,7 @@ ZK_HD int32_t zk_seq_table_setup(const uint8_t *comp, const ZkBlock &def, int t,
         if (p >= def.bsize) return -1;
         uint32_t r = zk_fse_read_ncount(c + p, def.bsize - p, zk_tab_maxsym(t), zk_tab_maxal(t), T->norm, &nsym, &al);
         if (!r) return -1;
-        if (!zk_fse_build(cells, T->norm, nsym, al, T->next, vt)) return -1;
+        if (!zk_fse_build<CP>(cells, T->norm, nsym, al, T->next, vt)) return -1;
         *al_out = al;
         return (int32_t)r;
     }
@@ -814,8 +846,9 @@ struct ZkCoopFlush {
 // Fills seqs[], b.out_size / b.rep_out / b.status.
 // store == false: a shadow lane (see zk_k_fse) -- it walks the same block as a real lane but never writes to HBM
 // active == false (cooperative mode only): the lane has no block but takes part in the flushes.
-template <int RING, typename RD>
-ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const uint32_t *LL, const uint32_t *OF, const uint32_t *ML,
+template <int RING, typename RD, typename CP = ZkCells32>
+ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const typename CP::cell_t *LL, const typename CP::cell_t *OF,
+                       const typename CP::cell_t *ML,
                        const uint32_t *al, ZkSeq *ring, ZkSeq *seqs, const uint32_t *ll_values, const uint32_t *ml_values,
                        bool store = true, ZkCoopFlush *coop = nullptr, bool active = true, uint32_t lane = 0)
 {
@@ -832,18 +865,18 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const u
     // errors only accumulate into `bad` (a corrupt stream keeps walking harmlessly: states stay inside
     // their tables, window addresses are clamped) and the rare sequence that needs more bits than the
     // window guarantees leaves the block for a field-by-field slow step.
-    uint32_t cl = LL[sl], co = OF[so], cm = ML[sm];
+    typename CP::cell_t cl = LL[sl], co = OF[so], cm = ML[sm];
     const uint32_t nloop = coop ? coop->nloop : nseq;
     for (uint32_t g0 = 0; g0 < nloop; g0 += RING) {
         for (uint32_t i = g0; i < g0 + RING; i++) {
             if (i >= nseq) break;
-            const uint32_t nOf = zk_cell_sym(co), nMl = zk_cell_xbits(cm), nLl = zk_cell_xbits(cl);
+            const uint32_t nOf = CP::sym(co), nMl = CP::xbits(cm, ml_values), nLl = CP::xbits(cl, ll_values);
             const bool more = i + 1 < nseq;
-            const uint32_t nbl = more ? zk_cell_nb(cl) : 0, nbm = more ? zk_cell_nb(cm) : 0, nbo = more ? zk_cell_nb(co) : 0;
+            const uint32_t nbl = more ? CP::nb(cl) : 0, nbm = more ? CP::nb(cm) : 0, nbo = more ? CP::nb(co) : 0;
             const uint32_t nval = nOf + nMl + nLl;
             const uint32_t total = nval + nbl + nbm + nbo;
             uint32_t ofx, mlx, llx;
-            const uint32_t csl = cl, csm = cm;                                      // symbols of THIS sequence
+            const typename CP::cell_t csl = cl, csm = cm;                           // symbols of THIS sequence
             bad |= nOf > 30;
             if (total <= r.avail()) {                                               // every field lies inside the window
                 const uint64_t X = r.window();
@@ -853,9 +886,9 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const u
                 const uint32_t h0 = (uint32_t)(S >> 32); S <<= nbl;
                 const uint32_t h1 = (uint32_t)(S >> 32); S <<= nbm;
                 const uint32_t h2 = (uint32_t)(S >> 32);
-                sl = zk_cell_base(cl) + zk_top_bits(h0, nbl);
-                sm = zk_cell_base(cm) + zk_top_bits(h1, nbm);
-                so = zk_cell_base(co) + zk_top_bits(h2, nbo);
+                sl = CP::base(cl) + zk_top_bits(h0, nbl);
+                sm = CP::base(cm) + zk_top_bits(h1, nbm);
+                so = CP::base(co) + zk_top_bits(h2, nbo);
                 cl = LL[sl]; co = OF[so]; cm = ML[sm];                     // issued early; used next iteration
                 // value bits (off the chain)
                 uint64_t V = X;
@@ -864,16 +897,16 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const u
                 llx = zk_top_bits((uint32_t)(V >> 32), nLl);
             } else {                                                                // more bits than the window guarantees (or over-read)
                 ofx = r.read(nOf & 31); mlx = r.read(nMl); llx = r.read(nLl);
-                sl = zk_cell_base(cl) + r.read(nbl);
-                sm = zk_cell_base(cm) + r.read(nbm);
-                so = zk_cell_base(co) + r.read(nbo);
+                sl = CP::base(cl) + r.read(nbl);
+                sm = CP::base(cm) + r.read(nbm);
+                so = CP::base(co) + r.read(nbo);
                 bad |= r.remaining() < 0;
                 r.clamp();
                 cl = LL[sl]; co = OF[so]; cm = ML[sm];
             }
             const uint32_t ofv = (1u << (nOf & 31)) + ofx;
-            const uint32_t ml = (ml_values[zk_cell_sym(csm)] & 0xFFFFFFu) + mlx;
-            const uint32_t ll = (ll_values[zk_cell_sym(csl)] & 0xFFFFFFu) + llx;
+            const uint32_t ml = (ml_values[CP::sym(csm)] & 0xFFFFFFu) + mlx;
+            const uint32_t ll = (ll_values[CP::sym(csl)] & 0xFFFFFFu) + llx;
             // offset + repeat history, select form (A.8)
             const bool is_rep = ofv <= 3;
             const uint32_t idx = ofv - 1 + (ll == 0);                               // 0..3 when is_rep
@@ -918,8 +951,8 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const u
 
 
 // Decode all sequences of block b into seqs[]: builds the block's LL / OF / ML tables in T (per-lane LDS), then walks.
-template <typename RD = ZkRevU>
-ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlock &b, ZkSeqTables *T, ZkSeq *seqs,
+template <typename RD = ZkRevU, typename CP = ZkCells32>
+ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlock &b, ZkSeqTablesT<CP> *T, ZkSeq *seqs,
                                const uint32_t *ll_values, const uint32_t *ml_values, bool store = true)
 {
     uint32_t al[3];
@@ -927,11 +960,11 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
     for (int t = 0; t < 3; t++) {
         uint32_t m = (b.seq_modes >> (6 - 2 * t)) & 3;
         const ZkBlock &def = m == 3 ? blocks[b.tab_def[t]] : b;
-        int32_t r = zk_seq_table_setup(comp, def, t, T, &al[t], ll_values, ml_values);
+        int32_t r = zk_seq_table_setup<CP>(comp, def, t, T, &al[t], ll_values, ml_values);
         if (r < 0) { b.status = ZK_E_CORRUPTION; return; }
         if (m != 3) own += (uint32_t)r;
     }
-    zk_seq_walk<16, RD>(comp, b, b.seq_off + 1 + own, T->ll, T->of, T->ml, al, T->ring, seqs, ll_values, ml_values, store);
+    zk_seq_walk<16, RD, CP>(comp, b, b.seq_off + 1 + own, T->ll, T->of, T->ml, al, T->ring, seqs, ll_values, ml_values, store);
 }
 
 // ---------------------------------------------------------------- sequence execution: per-byte source map

@@ -188,9 +188,10 @@ static int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const void *d_comp, co
     zk_profile_begin(e);
     { zk_kernel_timer t(e, ZK_K_WALK_COUNT, st); zk_launch_walk(st, comp, c_off, d_off, first, count, ids, nullptr, nullptr, infos); }
     { zk_kernel_timer t(e, ZK_K_SCAN, st); zk_launch_scan(st, infos, count, bases, words); }
-    ZK_HIP(hipMemcpyAsync(c.h_words, words, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(c.h_words, words, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     const uint64_t nblocks = c.h_words[0], nseq = c.h_words[1], nlit = c.h_words[2];
+    const uint32_t n_own = (uint32_t)c.h_words[4];        // blocks that need per-block sequence tables
     if (nblocks > 0xFFFFFFF0ull) return -(int)ZK_E_GENERIC;
     if ((rc = zk_devbuf_reserve(e, c.blocks, (size_t)(nblocks + 1) * sizeof(ZkBlock)))) return rc;
     if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)(nseq + 1) * sizeof(ZkSeq)))) return rc;
@@ -206,13 +207,13 @@ static int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const void *d_comp, co
     // with per-kernel timing on they are serialised instead
     if (e->profiling) {
         { zk_kernel_timer t(e, ZK_K_HUF, st); zk_launch_huf(st, comp, blocks, (uint32_t)nblocks, lit); }
-        { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, seqs); }
+        { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs); }
     } else {
         ZK_HIP(hipEventRecord(c.ev_fork, st));
         ZK_HIP(hipStreamWaitEvent(c.aux, c.ev_fork, 0));
         zk_launch_huf(c.aux, comp, blocks, (uint32_t)nblocks, lit);
         ZK_HIP(hipEventRecord(c.ev_join, c.aux));
-        zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, seqs);
+        zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs);
         ZK_HIP(hipStreamWaitEvent(st, c.ev_join, 0));
     }
     { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, ids, out_off, blocks, bases, infos, seqs, lit, (uint8_t *)d_dst, (const uint8_t *)d_prefix, d_prefix ? prefix_len : 0); }
