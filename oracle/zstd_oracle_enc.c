@@ -243,7 +243,10 @@ static size_t encode_literals(const u8 *lit, size_t n, u8 *dst, size_t cap)
 #define ZKE_PARCAP 64u              /* match length measured per position in phase 1; longer ones are extended by the parse */
 #define ZKE_GROUP 8u                /* tiles whose parses run side by side (one wave each on the GPU) */
 #define ZKE_LSTEP 2u                /* tiles per lookup step (the GPU looks up one position per lane: 512 lanes = 2 tiles of 256) */
-typedef struct { u32 table[1 << ZKE_HASH_LOG]; u32 probe; } enc_state;   /* table: frame-relative position + 1 (0 = empty) */
+/* table: the low 16 bits of (position + 1).  A candidate is p - d with d = (p + 1 - entry) mod 2^16: entries older
+ * than the 64 KiB window alias to some position inside it (the byte comparison decides, as for any hash collision);
+ * d == 0 (incl. the never-written entry 0 at p == 65535 mod 2^16) and candidates before the first byte are no candidates */
+typedef struct { u16 table[1 << ZKE_HASH_LOG]; u32 probe; } enc_state;
 
 static u32 match_len(const u8 *a, const u8 *b, const u8 *end)        /* b > a */
 {
@@ -280,8 +283,8 @@ static u32 find_sequences(enc_state *st, const u8 *base, u32 bs, u32 be, u32 fen
                 u32 l1 = 0, o1 = 0, l2 = 0;
                 const u8 *cap = base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim;
                 if (p + 8 <= fend) {
-                    u32 e = st->table[hash5(base + p)];
-                    if (e && p - (e - 1) <= ZKE_WINDOW) { o1 = p - (e - 1); l1 = match_len(base + p - o1, base + p, cap); }
+                    const u32 d = (p + 1 - st->table[hash5(base + p)]) & 0xFFFFu;
+                    if (d && d <= p) { o1 = d; l1 = match_len(base + p - o1, base + p, cap); }
                 }
                 if (R && R <= p) l2 = match_len(base + p - R, base + p, cap);
                 if (l1 < ZKE_MINMATCH) l1 = 0;
@@ -289,7 +292,18 @@ static u32 find_sequences(enc_state *st, const u8 *base, u32 bs, u32 be, u32 fen
                 if (l2 && l2 >= l1) { blen[t][p - ts] = l2; boff[t][p - ts] = R; }
                 else { blen[t][p - ts] = l1; boff[t][p - ts] = o1; }
             }
-            for (u32 p = ls; p < le; p++) if (p + 8 <= fend) st->table[hash5(base + p)] = p + 1;   /* largest position wins a slot */
+            /* insertion: per slot the LARGEST position of the step wins -- a rule that does not depend on the order of the
+             * writers (the GPU's lanes race with compare-and-swap).  With 16-bit entries "of the step" means: entry - (ls+1)
+             * mod 2^16 is below the step length; everything else is an older entry and loses.  (An entry older than
+             * 2^16 - step positions aliases into the step and may survive it: harmless, the bytes are compared.) */
+            {
+                const u32 b16 = (ls + 1) & 0xFFFFu, span = le - ls;
+                for (u32 p = ls; p < le; p++) if (p + 8 <= fend) {
+                    u16 *slot = &st->table[hash5(base + p)];
+                    const u32 mine = (p + 1 - b16) & 0xFFFFu, cur = (*slot - b16) & 0xFFFFu;     /* step-relative */
+                    if (cur >= span || cur < mine) *slot = (u16)(p + 1);
+                }
+            }
             ntiles += (le - ls + T - 1) / T;
         }
         /* per-tile parses + stitching */
@@ -359,7 +373,7 @@ i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int le
         cat = malloc((size_t)hist + n + 8);
         memcpy(cat, prefix + plen - hist, hist); memcpy(cat + hist, src, n);
         msrc = cat;
-        for (u32 v = 0; v < hist; v++) if ((size_t)v + 8 <= (size_t)hist + n) st->table[hash5(msrc + v)] = v + 1;
+        for (u32 v = 0; v < hist; v++) if ((size_t)v + 8 <= (size_t)hist + n) st->table[hash5(msrc + v)] = (u16)(v + 1);
     }
     seq_t *sq = malloc(sizeof(seq_t) * (ZKE_BLOCK / 3 + 8));
     u8 *lits = malloc(ZKE_BLOCK + 64), *body = malloc(ZKE_BLOCK * 2);

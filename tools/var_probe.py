@@ -1,0 +1,27 @@
+import os, sys
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+from oracle import zko
+import zeekstd_amd as zk
+pad = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+nf = 2048; F = 2 << 20
+dev = torch.device("cuda:0")
+if pad: dummy = torch.empty(pad, dtype=torch.uint8, device=dev)
+eng = zk.Engine(0)
+data = np.frombuffer(zko.gen_chunks(64 * F), np.uint8)
+d_src = torch.from_numpy(np.tile(data, nf // 64)).to(dev)
+n = nf * F
+cap = int(zk.lib.zk_compress_bound(n, F))
+d_comp = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+d_cs = torch.zeros(nf, dtype=torch.int32, device=dev); d_ds = torch.zeros(nf, dtype=torch.int32, device=dev)
+_, csize = eng.encode_frames_dev(d_src, n, F, 1, True, d_comp, cap, d_cs, d_ds)
+cs = d_cs.cpu().numpy().astype(np.uint64)
+c = np.zeros(nf + 1, np.uint64); d = np.zeros(nf + 1, np.uint64); c[1:] = np.cumsum(cs); d[1:] = np.cumsum(np.full(nf, F, np.uint64))
+d_c = torch.from_numpy(c.view(np.int64)).to(dev); d_d = torch.from_numpy(d.view(np.int64)).to(dev)
+d_out = torch.empty(n + 64, dtype=torch.uint8, device=dev); d_st = torch.zeros(nf, dtype=torch.int32, device=dev)
+eng.set_profiling(True)
+res = []
+for r in range(4):
+    eng.decode_frames_dev(d_comp, csize, d_c, d_d, 0, nf, d_out, n, True, d_st)
+    k = eng.kernel_times(); res.append((round(k['zk_k_huf'],2), round(k['zk_k_fse'],2), round(k['zk_k_exec'],2)))
+print("pad", pad, "ptrs", hex(d_comp.data_ptr()), hex(d_out.data_ptr()), res)

@@ -44,14 +44,36 @@ __device__ __forceinline__ uint32_t zke_match_len(const uint8_t *a, const uint8_
 // per-tile sequence as the parse leaves it in LDS: ll (12) | ml (11) << 12 | offset (17) << 23 | position in tile (10) << 40
 __device__ __forceinline__ uint64_t zke_tpack(uint32_t ll, uint32_t ml, uint32_t off, uint32_t pit) { return (uint64_t)ll | ((uint64_t)ml << 12) | ((uint64_t)off << 23) | ((uint64_t)pit << 40); }
 
+// Insert position p into slot h of the 16-bit hash table.  Per slot the largest position of the step wins, whatever
+// the order of the writers: an entry counts as "of the step" when entry - b16 (mod 2^16) is below `span` (b16 = low
+// 16 bits of step start + 1), anything else is older and loses.  The lanes race with compare-and-swap on the word
+// that holds two entries; oracle/zstd_oracle_enc.c applies the same rule sequentially.
+__device__ __forceinline__ void zke_table_insert(uint32_t *table, uint32_t h, uint32_t p, uint32_t b16, uint32_t span)
+{
+    uint32_t *w = &table[h >> 1];
+    const uint32_t sh = 16 * (h & 1), mine16 = (p + 1) & 0xFFFFu, mrel = (mine16 - b16) & 0xFFFFu;
+    uint32_t old = *w;
+    for (;;) {
+        const uint32_t cur = (((old >> sh) & 0xFFFFu) - b16) & 0xFFFFu;
+        if (!(cur >= span || cur < mrel)) return;
+        const uint32_t seen = atomicCAS(w, old, (old & ~(0xFFFFu << sh)) | (mine16 << sh));
+        if (seen == old) return;
+        old = seen;
+    }
+}
+
 // With a prefix (zk_encode_frames_prefix) the matcher does not read the frame in place: `src` is then a staging
 // buffer that holds, per frame, [last `hist` bytes of the prefix | the frame] (zk_k_enc_stage_hist), all positions
 // below are offsets into that record, and the history's positions enter the hash table before the first block --
 // so a match may start in the prefix and run on into the frame with no special case anywhere.
-__global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
+__global__ __launch_bounds__(ZKE_THREADS) __attribute__((amdgpu_waves_per_eu(6))) void zk_k_enc_match(       // 47 KiB of LDS: three workgroups = 24 waves per CU need <= 80 VGPRs
+const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
                                                               uint64_t *seqs, uint32_t *mpos, uint8_t *lits)
 {
-    __shared__ uint32_t table[1 << ZKE_HASH_LOG];          // frame-relative position + 1, 0 = empty
+    // 16-bit entries, two per word: the low 16 bits of (position + 1).  A candidate is p - d with d = (p + 1 - entry)
+    // mod 2^16: entries older than the 64 KiB window alias to some position inside it and the byte comparison decides,
+    // as for any hash collision.  Half the LDS of 32-bit entries: three workgroups per CU instead of two.
+    __shared__ uint32_t table[1 << (ZKE_HASH_LOG - 1)];
     __shared__ uint32_t best[ZKE_GROUP][ZKE_TILE];         // len (7 bits) | offset << 8
     __shared__ uint64_t tseq[ZKE_GROUP][ZKE_TILE / 4 + 4];
     __shared__ uint32_t tcount[ZKE_GROUP], ttail[ZKE_GROUP];
@@ -60,10 +82,10 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
     const ZkEncFrame fr = frames[blockIdx.x];
     const uint8_t *base = src + fr.m_off;
     const uint32_t hist = fr.hist, fend = hist + fr.d_size;
-    for (uint32_t i = tid; i < (1u << ZKE_HASH_LOG); i += ZKE_THREADS) table[i] = 0;
+    for (uint32_t i = tid; i < (1u << (ZKE_HASH_LOG - 1)); i += ZKE_THREADS) table[i] = 0;
     __syncthreads();
-    for (uint32_t v = tid; v < hist; v += ZKE_THREADS)               // history positions: the largest one wins a slot, as below
-        if (v + 8 <= fend) atomicMax(&table[(uint32_t)(((zk_ld64(base + v) << 24) * 889523592379ull) >> (64 - ZKE_HASH_LOG))], v + 1);
+    for (uint32_t v = tid; v < hist; v += ZKE_THREADS)               // history positions (< 2^16, no wrap): the largest one wins a slot
+        if (v + 8 <= fend) zke_table_insert(table, (uint32_t)(((zk_ld64(base + v) << 24) * 889523592379ull) >> (64 - ZKE_HASH_LOG)), v, 0, 65536);       // b16 = 0: plain numeric maximum, the empty entry 0 loses
     if (hist) __syncthreads();
     uint32_t probe = 1;                                    // offset of the last match taken (same value in every thread)
     for (uint32_t bi = 0; bi < fr.n_blocks; bi++) {
@@ -92,8 +114,8 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                 uint32_t hsh = 0xFFFFFFFFu, o1 = 0;
                 if (wide8) {
                     hsh = (uint32_t)(((w << 24) * 889523592379ull) >> (64 - ZKE_HASH_LOG));
-                    const uint32_t e = table[hsh];
-                    if (e && p - (e - 1) <= ZKE_WINDOW) o1 = p - (e - 1);
+                    const uint32_t d = (p + 1 - (table[hsh >> 1] >> (16 * (hsh & 1)))) & 0xFFFFu;
+                    if (d && d <= p) o1 = d;
                 }
                 const uint64_t c1 = o1 ? zk_ld64(base + p - o1) : 0;                    // p + 8 <= fend holds when o1 != 0
                 const uint64_t c2 = (wide8 && R && R <= p) ? zk_ld64(base + p - R) : 0;
@@ -118,7 +140,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     best[ntiles + sub][p - ts] = (l2 && l2 >= l1) ? (l2 | (R << 8)) : (l1 | (o1 << 8));
                 }
                 __syncthreads();
-                if (hsh != 0xFFFFFFFFu) atomicMax(&table[hsh], p + 1);                 // the largest position wins a slot
+                if (hsh != 0xFFFFFFFFu) zke_table_insert(table, hsh, p, (ls + 1) & 0xFFFFu, le - ls);     // the largest position of the step wins a slot
                 __syncthreads();
                 ntiles += (le - ls + ZKE_TILE - 1) / ZKE_TILE;
             }
