@@ -50,10 +50,11 @@ def _make_part(job):
 
 
 def build_inputs(k0, nframes, level, cks, workers, want_archive, tag):
-    """Returns (data as a uint8 array backed by /dev/shm, libzstd payload, frames, per-frame XXH64)."""
+    """Returns (data as a uint8 array in an anonymous shared mapping, libzstd payload, frames, per-frame XXH64)."""
     global _SHM
-    path = f"/dev/shm/zk_bench_{os.getpid()}_{tag}.bin"
-    _SHM = np.memmap(path, dtype=np.uint8, mode="w+", shape=(nframes * FRAME,))
+    import mmap
+    _map = mmap.mmap(-1, max(1, nframes * FRAME))      # MAP_SHARED | MAP_ANONYMOUS: the forked workers fill it; no tmpfs quota involved
+    _SHM = np.frombuffer(_map, dtype=np.uint8)
     per = max(1, min(16, nframes // max(1, workers)))
     jobs = [(k0, i, min(per, nframes - i), level, cks, want_archive) for i in range(0, nframes, per)]
     if workers <= 1:                                   # --no-fork: rocprofv3's signal handler can hang on the pool's worker exits
@@ -61,7 +62,6 @@ def build_inputs(k0, nframes, level, cks, workers, want_archive, tag):
     else:
         with mp.get_context("fork").Pool(workers) as pool:
             parts = pool.map(_make_part, jobs)
-    os.unlink(path)                                    # the mapping stays valid until it is dropped
     comp = b"".join(p[0] for p in parts)
     frames = [f for p in parts for f in p[1]]
     hashes = [h for p in parts for h in p[2]]
