@@ -316,6 +316,70 @@ __global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_predef(const uint8_t *
     o->status = b.status;
 }
 
+// The same with a feeder wave: wave 0 walks (reader ZkRevL: stream words out of an LDS ring, no global load in the
+// walking wave), wave 1 feeds the ring lane for lane.  Used when the device is full of walkers (zk_launch_fse).
+__global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
+{
+    __shared__ ZkSeqTables T;
+    __shared__ __attribute__((aligned(16))) ZkSeq ring[ZK_FSEP_LANES][4];
+    __shared__ ZkCoopFlush coop;
+    __shared__ ZkRevLShared feed;
+    __shared__ uint32_t llv[36], mlv[53], s_al[3], s_done;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const bool walker = tid < 64;
+    {
+        const uint32_t ll_init[36] = ZK_LL_TABLE;
+        const uint32_t ml_init[53] = ZK_ML_TABLE;
+        if (tid < 36) llv[tid] = ll_init[tid];
+        if (tid < 53) mlv[tid] = ml_init[tid];
+        if (walker) { feed.filled[lane] = 0; feed.taken[lane] = 0; }
+        if (tid == 0) { coop.ring = &ring[0][0]; coop.seqs = seqs; coop.nloop = 0; s_done = 0; }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        ZkBlock fake;
+        fake.seq_modes = 0; fake.seq_off = 0; fake.bsize = 0; fake.src = 0;
+        for (int t = 0; t < 3; t++) { uint32_t a = 0; (void)zk_seq_table_setup(comp, fake, t, &T, &a, llv, mlv); s_al[t] = a; }
+    }
+    const uint32_t bi = blockIdx.x * ZK_FSEP_LANES + lane;
+    bool active = bi < nblocks;
+    ZkBlock b;
+    if (active) {
+        b = blocks[bi];
+        active = b.type == 2 && b.nseq != 0 && b.status == ZK_OK && b.seq_modes == 0;
+    }
+    if (walker) {
+        coop.base[lane] = active ? b.seq_base : 0;
+        coop.nseq[lane] = active ? b.nseq : 0;
+        if (active) atomicMax(&coop.nloop, b.nseq);
+    }
+    __syncthreads();
+    if (walker) {
+        zk_seq_walk<4, ZkRevL>(comp, b, active ? b.seq_off + 1 : 0, T.ll, T.of, T.ml, s_al, ring[lane], seqs, llv, mlv, true, &coop, active, lane, &feed);
+        *(volatile uint32_t *)&s_done = 1;
+        if (!active) return;
+        ZkBlock *o = &blocks[bi];
+        o->out_size = b.out_size;
+        o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
+        o->status = b.status;
+    } else if (active && b.seq_off + 1 < b.bsize) {
+        // feeder: aligned words of the lane's bitstream, last word first (ZkRevL::word_count / W(j))
+        const uint8_t *base = comp + b.src + b.seq_off + 1;
+        const uint32_t len = b.bsize - b.seq_off - 1, nwords = ZkRevL::word_count(base, len);
+        const uint8_t *ptr = reinterpret_cast<const uint8_t *>((((uintptr_t)base + len) + 7) & ~(uintptr_t)7) - 8;
+        volatile uint32_t *taken = &feed.taken[lane], *filled = &feed.filled[lane], *done = &s_done;
+        uint32_t f = 0;
+        while (f < nwords && !*done) {
+            if (f - *taken < ZK_REVL_RING) {
+                const uint64_t w = *reinterpret_cast<const uint64_t *>(ptr);
+                *(volatile uint64_t *)&feed.ring[f % ZK_REVL_RING][lane] = w;
+                f++; ptr -= 8;
+                *filled = f;
+            } else __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ sequence execution
 // One workgroup (T lanes) per frame.  The output of a compressed block is produced in tiles of T x 16 B.  Per tile:
 //   1. the sequences overlapping the tile are staged in LDS (16 B records, offsets resolved, validated);
@@ -584,7 +648,7 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     // on 32 KiB blocks between 1024 and 2048 frames of 2 MiB.
     const uint32_t wgs = (nblocks + ZK_FSEP_LANES - 1) / ZK_FSEP_LANES;
     if (n_own_tables < nblocks) {          // at least one block may be all-predefined
-        if (wgs >= 6 * 256) hipLaunchKernelGGL(zk_k_fse_predef<ZkRevA>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
+        if (wgs >= 6 * 256) hipLaunchKernelGGL(zk_k_fse_predef_fed, dim3(wgs), dim3(2 * ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
         else hipLaunchKernelGGL(zk_k_fse_predef<ZkRevU>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
     }
     // blocks with their own tables (every block is visited, the others return at once): cell format by how many

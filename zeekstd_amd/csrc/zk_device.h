@@ -776,6 +776,7 @@ struct ZkRevU {
     }
     ZK_HDM int32_t remaining() const { return pos; }
     ZK_HDM void clamp() { if (pos < 0) pos = 0; reload(); }                    // after a run of read()s
+    ZK_HDM void attach(void *, uint32_t) {}
 };
 
 struct ZkRevA {
@@ -816,6 +817,71 @@ struct ZkRevA {
     }
     ZK_HDM int32_t remaining() const { return rem; }
     ZK_HDM void clamp() {}
+    ZK_HDM void attach(void *, uint32_t) {}
+};
+
+// ZkRevL: like ZkRevA, but the aligned stream words come out of an LDS ring that a companion ("feeder") lane of
+// another wave fills (zk_k_fse_predef).  The walking wave then issues no global load at all.  Why: loads return in
+// order per wave (vmcnt), a wave of 64 streams has some lane fetching its next word at almost every step, and so every
+// step of the whole wave used to wait for one L2 round trip (~1 us under load) -- the floor of the sequence walk.
+// An LDS read is ~100 cycles.  Hand-over per lane: feeder writes word f to ring[f % R][lane] and then publishes
+// filled = f + 1; the walker spins until filled > k before it reads word k and publishes taken = k + 1 afterwards;
+// the feeder only writes while filled - taken < R.  Words past the stream's first byte are not waited for (a corrupt
+// stream reads zeros there and fails on `rem`).
+constexpr uint32_t ZK_REVL_RING = 8;             // words per lane
+struct ZkRevLShared {                            // LDS, one per walking wave
+    uint64_t ring[ZK_REVL_RING][64];
+    uint32_t filled[64], taken[64];
+};
+struct ZkRevL {
+    ZkRevLShared *sh;
+    uint64_t A, B;
+    uint32_t lane, c, k, nwords;                 // k: next word index to take
+    int32_t rem;
+    ZK_HDM void attach(ZkRevLShared *s, uint32_t l) { sh = s; lane = l; }
+    ZK_HDM uint64_t take()
+    {
+        if (k >= nwords) { k++; return 0; }
+        volatile uint32_t *f = &sh->filled[lane];
+        while (*f <= k) {}
+        const uint64_t w = *(volatile uint64_t *)&sh->ring[k % ZK_REVL_RING][lane];
+        k++;
+        *(volatile uint32_t *)&sh->taken[lane] = k;
+        return w;
+    }
+    ZK_HDM void advance() { if (c >= 64) { A = B; B = take(); c -= 64; } }
+    // words of the stream [b, b + len): W(j) = aligned 8 bytes at aend - 8 (j + 1), j < nwords
+    static ZK_HDM uint32_t word_count(const uint8_t *b, uint32_t len)
+    {
+        const uintptr_t end = (uintptr_t)b + len, aend = (end + 7) & ~(uintptr_t)7, lo = (uintptr_t)b & ~(uintptr_t)7;
+        return (uint32_t)((aend - lo) >> 3);
+    }
+    ZK_HDM bool init(const uint8_t *b, uint32_t len)
+    {
+        const uint32_t last = b[len - 1];
+        if (last == 0) return false;
+        const uint32_t hb = zk_highbit(last);
+        const uintptr_t end = (uintptr_t)b + len, aend = (end + 7) & ~(uintptr_t)7;
+        nwords = word_count(b, len);
+        k = 0;
+        A = take(); B = take();
+        c = (uint32_t)(aend - end) * 8 + 8 - hb;
+        rem = (int32_t)((len - 1) * 8 + hb);
+        advance();
+        return true;
+    }
+    ZK_HDM uint32_t avail() const { return 64; }
+    ZK_HDM uint64_t window() const { return (A << c) | ((B >> 1) >> (63 - c)); }
+    ZK_HDM void consume(uint32_t n) { c += n; rem -= (int32_t)n; advance(); }
+    ZK_HDM uint32_t read(uint32_t n)
+    {
+        const uint64_t X = window();
+        const uint32_t v = n ? (uint32_t)(X >> (64 - n)) : 0u;
+        consume(n);
+        return v;
+    }
+    ZK_HDM int32_t remaining() const { return rem; }
+    ZK_HDM void clamp() {}
 };
 
 // The n (<= 31) most significant bits of a 32-bit word, 0 for n == 0: one bit-field extract on the device (a width
@@ -828,6 +894,10 @@ ZK_HD uint32_t zk_top_bits(uint32_t hi, uint32_t n)
     return n ? hi >> (32 - n) : 0u;
 #endif
 }
+
+ZK_HD void *zk_rd_shared_type(const ZkRevU &) { return nullptr; }
+ZK_HD void *zk_rd_shared_type(const ZkRevA &) { return nullptr; }
+ZK_HD ZkRevLShared *zk_rd_shared_type(const ZkRevL &) { return nullptr; }
 
 // Wave-cooperative flush of the 4-record rings of a 64-lane wave (device only, zk_k_fse_predef): a lane's four
 // 16-B records are one 64-B line of its block's record array, so instead of every lane storing its own ring
@@ -850,9 +920,10 @@ template <int RING, typename RD, typename CP = ZkCells32>
 ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const typename CP::cell_t *LL, const typename CP::cell_t *OF,
                        const typename CP::cell_t *ML,
                        const uint32_t *al, ZkSeq *ring, ZkSeq *seqs, const uint32_t *ll_values, const uint32_t *ml_values,
-                       bool store = true, ZkCoopFlush *coop = nullptr, bool active = true, uint32_t lane = 0)
+                       bool store = true, ZkCoopFlush *coop = nullptr, bool active = true, uint32_t lane = 0, void *rd_shared = nullptr)
 {
     RD r;
+    r.attach(static_cast<decltype(zk_rd_shared_type(r))>(rd_shared), lane);
     uint32_t bad = 0;
     if (active && bs_off >= b.bsize) { bad = 1; active = false; }
     if (active && !r.init(comp + b.src + bs_off, b.bsize - bs_off)) { bad = 1; active = false; }
