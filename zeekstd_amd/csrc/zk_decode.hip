@@ -110,10 +110,14 @@ __device__ void zk_huf_companion(const uint8_t *base, uint32_t len, uint8_t *dst
         const uint32_t st = mail->state[l];
         const uint32_t written = st & 0x3fffu;
         bool idle = true;
-        if (((written - stored) & 0x3fffu) != 0) {
-            const uint64_t pack = mail->pack[stored & 1][l];
-            memcpy(dst + (size_t)stored * 8, &pack, 8);
-            stored++;
+        const uint32_t avail = (written - stored) & 0x3fffu;
+        if (avail >= ZK_HUF_BURST || (fin && avail)) {               // whole bursts while the decoder runs, the rest at its end
+            const uint32_t nb = avail < ZK_HUF_BURST ? avail : ZK_HUF_BURST;
+            for (uint32_t k = 0; k < nb; k++) {
+                const uint64_t pack = mail->pack[(stored + k) % ZK_HUF_RING][l];
+                memcpy(dst + (size_t)(stored + k) * 8, &pack, 8);
+            }
+            stored += nb;
             mail->consumed[l] = stored;
             idle = false;
         }
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_predef(const uint8_t *
 // walking wave), wave 1 feeds the ring lane for lane.  Used when the device is full of walkers (zk_launch_fse).
 __global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
 {
-    __shared__ ZkSeqTables T;
+    __shared__ ZkSeqTablesT<ZkCells64> T;                  // 64-bit cells: the value baseline rides along (shared tables, LDS is free)
     __shared__ __attribute__((aligned(16))) ZkSeq ring[ZK_FSEP_LANES][4];
     __shared__ ZkCoopFlush coop;
     __shared__ ZkRevLShared feed;
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const u
     if (tid < 16) {
         ZkBlock fake;
         fake.seq_modes = 0; fake.seq_off = 0; fake.bsize = 0; fake.src = 0;
-        for (int t = 0; t < 3; t++) { uint32_t a = 0; (void)zk_seq_table_setup(comp, fake, t, &T, &a, llv, mlv); s_al[t] = a; }
+        for (int t = 0; t < 3; t++) { uint32_t a = 0; (void)zk_seq_table_setup<ZkCells64>(comp, fake, t, &T, &a, llv, mlv); s_al[t] = a; }
     }
     const uint32_t bi = blockIdx.x * ZK_FSEP_LANES + lane;
     bool active = bi < nblocks;
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const u
     }
     __syncthreads();
     if (walker) {
-        zk_seq_walk<4, ZkRevL>(comp, b, active ? b.seq_off + 1 : 0, T.ll, T.of, T.ml, s_al, ring[lane], seqs, llv, mlv, true, &coop, active, lane, &feed);
+        zk_seq_walk<4, ZkRevL, ZkCells64>(comp, b, active ? b.seq_off + 1 : 0, T.ll, T.of, T.ml, s_al, ring[lane], seqs, llv, mlv, true, &coop, active, lane, &feed);
         *(volatile uint32_t *)&s_done = 1;
         if (!active) return;
         ZkBlock *o = &blocks[bi];

@@ -197,6 +197,23 @@ struct ZkCells32 {
     static ZK_HDM uint32_t nb(cell_t c) { return zk_cell_nb(c); }
     static ZK_HDM uint32_t base(cell_t c) { return zk_cell_base(c); }
     static ZK_HDM uint32_t xbits(cell_t c, const uint32_t *) { return zk_cell_xbits(c); }
+    static ZK_HDM uint32_t baseline(cell_t c, const uint32_t *value_table) { return value_table[zk_cell_sym(c)] & 0xFFFFFFu; }
+    static ZK_HDM cell_t tmp_sym(uint32_t s) { return s; }
+    static ZK_HDM uint32_t tmp_get(cell_t c) { return c; }
+    static ZK_HDM cell_t with_value(cell_t c, const uint32_t *, uint32_t) { return c; }
+};
+struct ZkCell64 { uint32_t c, v; };              // the 32-bit cell + the symbol's value baseline
+struct ZkCells64 {                               // for tables shared by a workgroup (zk_k_fse_predef*): LDS is no constraint
+    typedef ZkCell64 cell_t;                     // there, and the baseline in the cell saves two dependent LDS reads per sequence
+    static ZK_HDM cell_t make(uint32_t sym, uint32_t nb, uint32_t xbits, uint32_t base) { cell_t r; r.c = zk_cell(sym, nb, xbits, base); r.v = 0; return r; }
+    static ZK_HDM uint32_t sym(cell_t c) { return zk_cell_sym(c.c); }
+    static ZK_HDM uint32_t nb(cell_t c) { return zk_cell_nb(c.c); }
+    static ZK_HDM uint32_t base(cell_t c) { return zk_cell_base(c.c); }
+    static ZK_HDM uint32_t xbits(cell_t c, const uint32_t *) { return zk_cell_xbits(c.c); }
+    static ZK_HDM uint32_t baseline(cell_t c, const uint32_t *) { return c.v; }
+    static ZK_HDM cell_t tmp_sym(uint32_t s) { cell_t r; r.c = s; r.v = 0; return r; }
+    static ZK_HDM uint32_t tmp_get(cell_t c) { return c.c; }
+    static ZK_HDM cell_t with_value(cell_t c, const uint32_t *value_table, uint32_t s) { c.v = value_table ? value_table[s] & 0xFFFFFFu : 0u; return c; }
 };
 struct ZkCells16 {
     typedef uint16_t cell_t;
@@ -206,6 +223,10 @@ struct ZkCells16 {
     static ZK_HDM uint32_t nb(cell_t c) { const uint32_t e = c & 1023u; return e >= 512u ? 0u : (uint32_t)__builtin_ctz(e | 512u) + 1u; }
     static ZK_HDM uint32_t base(cell_t c) { const uint32_t e = c & 1023u; return e >= 512u ? e - 512u : e & (e - 1u); }
     static ZK_HDM uint32_t xbits(cell_t c, const uint32_t *value_table) { const uint32_t s = (uint32_t)c >> 10; return value_table ? value_table[s] >> 24 : s; }
+    static ZK_HDM uint32_t baseline(cell_t c, const uint32_t *value_table) { return value_table[(uint32_t)c >> 10] & 0xFFFFFFu; }
+    static ZK_HDM cell_t tmp_sym(uint32_t s) { return (cell_t)s; }
+    static ZK_HDM uint32_t tmp_get(cell_t c) { return c; }
+    static ZK_HDM cell_t with_value(cell_t c, const uint32_t *, uint32_t) { return c; }
 };
 
 // value tables: base | bits << 24
@@ -285,23 +306,23 @@ ZK_HD bool zk_fse_build(typename CP::cell_t *cells, const int16_t *norm, uint32_
     uint32_t size = 1u << al, mask = size - 1;
     int32_t high = (int32_t)size - 1;
     for (uint32_t s = 0; s < nsym; s++) {
-        if (norm[s] == -1) { if (high < 0) return false; cells[high--] = (typename CP::cell_t)s; next[s] = 1; }
+        if (norm[s] == -1) { if (high < 0) return false; cells[high--] = CP::tmp_sym(s); next[s] = 1; }
         else next[s] = (uint16_t)norm[s];
     }
     uint32_t step = (size >> 1) + (size >> 3) + 3, pos = 0;
     for (uint32_t s = 0; s < nsym; s++) {
         for (int32_t i = 0; i < norm[s]; i++) {
-            cells[pos] = (typename CP::cell_t)s;
+            cells[pos] = CP::tmp_sym(s);
             do { pos = (pos + step) & mask; } while ((int32_t)pos > high);
         }
     }
     if (pos != 0) return false;
     for (uint32_t i = 0; i < size; i++) {
-        uint32_t s = cells[i];
+        uint32_t s = CP::tmp_get(cells[i]);
         uint32_t x = next[s]++;
         uint32_t nb = al - zk_highbit(x);
         uint32_t xb = value_table ? (value_table[s] >> 24) : s;
-        cells[i] = CP::make(s, nb, xb & 31u, (x << nb) - size);
+        cells[i] = CP::with_value(CP::make(s, nb, xb & 31u, (x << nb) - size), value_table, s);
     }
     return true;
 }
@@ -422,8 +443,13 @@ ZK_HD uint64_t zk_hufrd_refill(ZkHufRd &r)
 // (packs written, stream position); the companion wave stores the packs to HBM and touches the stream's cache
 // lines ahead.  gfx9 counts loads and stores in ONE in-order counter (vmcnt), so a store in the decode loop makes
 // every wait for a stream word also wait for the store's write acknowledgement.
+constexpr uint32_t ZK_HUF_RING = 8;              // packs per lane in the hand-over ring
+constexpr uint32_t ZK_HUF_BURST = 4;             // the companion stores 4 packs = 32 contiguous bytes at a time: single 8-byte
+                                                 // pieces of a literal line were mostly evicted from L2 half-filled (WRITE_SIZE 5x the
+                                                 // payload).  Measured on 4 GiB (ring, burst): (2,1) 3.5-4.2 ms, (4,2) 3.27, (8,2) 3.57,
+                                                 // (8,4) 3.10, (8,6) 3.3, (16,8) 3.3, (32,16) 3.8 -- deeper rings cost LDS, i.e. decoders per CU
 struct ZkHufMail {
-    uint64_t pack[2][64];
+    uint64_t pack[ZK_HUF_RING][64];
     uint32_t state[64];              // packs written [13:0] | (next stream offset + 64) << 14
     uint32_t consumed[64];           // packs stored by the companion
 };
@@ -488,8 +514,8 @@ ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const u
         if (mail) {
             if (store) {
                 const uint32_t it = (i - i0) >> 3;
-                while (((it - mail->consumed[mlane]) & 0x3fffu) >= 2) {}     // ring full: the companion is behind
-                mail->pack[it & 1][mlane] = pack;
+                while (((it - mail->consumed[mlane]) & 0x3fffu) >= ZK_HUF_RING) {}     // ring full: the companion is behind
+                mail->pack[it % ZK_HUF_RING][mlane] = pack;
                 mail->state[mlane] = zk_huf_mail_state(it + 1, (int32_t)(r.ptr - src));
             }
         } else if (store) *reinterpret_cast<uint64_t *>(dst + i) = pack;
@@ -723,7 +749,7 @@ ZK_HD int32_t zk_seq_table_setup(const uint8_t *comp, const ZkBlock &def, int t,
         if (p >= def.bsize) return -1;
         uint32_t s = c[p];
         if (s > zk_tab_maxsym(t)) return -1;
-        cells[0] = CP::make(s, 0, (vt ? (vt[s] >> 24) : s) & 31u, 0);
+        cells[0] = CP::with_value(CP::make(s, 0, (vt ? (vt[s] >> 24) : s) & 31u, 0), vt, s);
         *al_out = 0;
         return 1;
     }
@@ -976,8 +1002,8 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const t
                 cl = LL[sl]; co = OF[so]; cm = ML[sm];
             }
             const uint32_t ofv = (1u << (nOf & 31)) + ofx;
-            const uint32_t ml = (ml_values[CP::sym(csm)] & 0xFFFFFFu) + mlx;
-            const uint32_t ll = (ll_values[CP::sym(csl)] & 0xFFFFFFu) + llx;
+            const uint32_t ml = CP::baseline(csm, ml_values) + mlx;
+            const uint32_t ll = CP::baseline(csl, ll_values) + llx;
             // offset + repeat history, select form (A.8)
             const bool is_rep = ofv <= 3;
             const uint32_t idx = ofv - 1 + (ll == 0);                               // 0..3 when is_rep
