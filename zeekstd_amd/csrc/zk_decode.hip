@@ -279,11 +279,12 @@ __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *com
 // workgroup, one block per LANE, full waves.  All 64 lanes walk in lock step so that the 16-B records can be
 // stored cooperatively (ZkCoopFlush: a quarter of the L2 write requests, which were 40% of the kernel's time).
 constexpr int ZK_FSEP_LANES = 64;                        // blocks per workgroup (one wave)
+constexpr int ZK_FSEP_RING = 4;                          // records per lane between two cooperative flushes (4 x 16 B = 64 B; 8 measured slower: 5.6 vs 4.1 ms)
 template <typename RD>
 __global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_predef(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
 {
     __shared__ ZkSeqTables T;                              // shared, read-only after the build
-    __shared__ __attribute__((aligned(16))) ZkSeq ring[ZK_FSEP_LANES][4];    // 4-record staging per lane (one 64-B line)
+    __shared__ __attribute__((aligned(16))) ZkSeq ring[ZK_FSEP_LANES][ZK_FSEP_RING];
     __shared__ ZkCoopFlush coop;
     __shared__ uint32_t llv[36], mlv[53], s_al[3];
     const uint32_t tid = threadIdx.x;
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_predef(const uint8_t *
     if (active) atomicMax(&coop.nloop, b.nseq);
     __syncthreads();
     // every lane of the wave runs the walk in lock step (inactive ones only help storing the others' records)
-    zk_seq_walk<4, RD>(comp, b, active ? b.seq_off + 1 : 0, T.ll, T.of, T.ml, s_al, ring[tid], seqs, llv, mlv, true, &coop, active, tid);
+    zk_seq_walk<ZK_FSEP_RING, RD>(comp, b, active ? b.seq_off + 1 : 0, T.ll, T.of, T.ml, s_al, ring[tid], seqs, llv, mlv, true, &coop, active, tid);
     if (!active) return;
     ZkBlock *o = &blocks[bi];
     o->out_size = b.out_size;
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_predef(const uint8_t *
 __global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
 {
     __shared__ ZkSeqTablesT<ZkCells64> T;                  // 64-bit cells: the value baseline rides along (shared tables, LDS is free)
-    __shared__ __attribute__((aligned(16))) ZkSeq ring[ZK_FSEP_LANES][4];
+    __shared__ __attribute__((aligned(16))) ZkSeq ring[ZK_FSEP_LANES][ZK_FSEP_RING];
     __shared__ ZkCoopFlush coop;
     __shared__ ZkRevLShared feed;
     __shared__ uint32_t llv[36], mlv[53], s_al[3], s_done;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const u
     }
     __syncthreads();
     if (walker) {
-        zk_seq_walk<4, ZkRevL, ZkCells64>(comp, b, active ? b.seq_off + 1 : 0, T.ll, T.of, T.ml, s_al, ring[lane], seqs, llv, mlv, true, &coop, active, lane, &feed);
+        zk_seq_walk<ZK_FSEP_RING, ZkRevL, ZkCells64>(comp, b, active ? b.seq_off + 1 : 0, T.ll, T.of, T.ml, s_al, ring[lane], seqs, llv, mlv, true, &coop, active, lane, &feed);
         *(volatile uint32_t *)&s_done = 1;
         if (!active) return;
         ZkBlock *o = &blocks[bi];

@@ -930,7 +930,7 @@ ZK_HD ZkRevLShared *zk_rd_shared_type(const ZkRevL &) { return nullptr; }
 // (4 instructions x 64 separate L2 write requests) four neighbouring lanes store one ring per instruction
 // (4 x 16 requests of 64 B).  All 64 lanes must run the walk in lock step (nloop = the wave's longest block).
 struct ZkCoopFlush {
-    ZkSeq *ring;                     // [64][4]
+    ZkSeq *ring;                     // [64][RING]
     ZkSeq *seqs;                     // the record array of the whole batch
     uint64_t base[64];               // record index of each lane's block
     uint32_t nseq[64];               // 0: lane stores nothing (shadow / inactive)
@@ -1023,13 +1023,12 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const t
         // records are parked in LDS and written out a group at a time (few, wide store bursts)
 #if defined(__HIP_DEVICE_COMPILE__)
         if (coop) {
-            static_assert(RING == 4 || RING == 16, "ring");
-            if (RING == 4) {
-                for (uint32_t j = 0; j < 4; j++) {
-                    const uint32_t m = 16 * j + (lane >> 2), k = g0 + (lane & 3);
-                    if (k < coop->nseq[m])
-                        reinterpret_cast<uint4 *>(coop->seqs)[coop->base[m] + k] = reinterpret_cast<const uint4 *>(coop->ring)[m * 4 + (lane & 3)];
-                }
+            // RING neighbouring lanes store one lane's ring (RING x 16 contiguous bytes), 64 / RING rings per instruction
+            static_assert(RING == 4 || RING == 8 || RING == 16, "ring");
+            for (uint32_t j = 0; j < (uint32_t)RING; j++) {
+                const uint32_t m = (64 / RING) * j + lane / RING, piece = lane % RING, k = g0 + piece;
+                if (k < coop->nseq[m])
+                    reinterpret_cast<uint4 *>(coop->seqs)[coop->base[m] + k] = reinterpret_cast<const uint4 *>(coop->ring)[m * RING + piece];
             }
             continue;
         }
