@@ -127,3 +127,27 @@ def test_oracle_decodes_prefix_goldens(prefix_golden):
             for c, d in g.frames:
                 zko.frame_decode(g.comp[pos:pos + c], d, True)
                 pos += c
+
+
+@pytest.mark.parametrize("which", ["1.5.7", "system"])
+def test_encoder_twin_frames_are_valid_zstd(which):
+    # The CPU twin of the GPU encoder (oracle/zstd_oracle_enc.c; the GPU output is byte-identical to it, tests/test_gpu_encode.py)
+    # must produce frames the real libzstd decodes -- with and without a prefix (ZSTD_DCtx_refPrefix).
+    if Z.load(which) is None:
+        pytest.skip(f"libzstd {which} not on this box")
+    cases = [zko.make_input([["text", 70000, 61]]), zko.make_input([["random", 5000, 62], ["zeros", 40000], ["text", 30000, 63]]),
+             zko.make_input([["rep", "616263", 9000]]), b"", b"x"]
+    for data in cases:
+        for cks in (False, True):
+            c = zko.frame_encode(data, 1, cks)
+            assert Z.decode_stream(c, len(data), which) == data
+            out, used = zko.frame_decode(c, len(data), True)
+            assert out == data and used == len(c)
+    prefix = zko.make_input([["text", 90000, 61]])                  # shares its generator seed with the first case
+    for data in cases[:3]:
+        c = zko.frame_encode(data, 1, True, prefix=prefix)
+        assert Z.decode_stream(c, len(data), which, prefix=prefix) == data
+        out, used = zko.frame_decode(c, len(data), True, prefix=prefix)
+        assert out == data and used == len(c)
+    shared = zko.frame_encode(cases[0], 1, True, prefix=prefix)
+    assert len(shared) < len(zko.frame_encode(cases[0], 1, True))   # the prefix tail is found
