@@ -224,25 +224,45 @@ const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
 }
 
 // ------------------------------------------------------------------------------------------------ entropy stage
-// LSB-first bit writer into global scratch (one lane).
+// LSB-first bit writer into global scratch (one lane), free of branches: put() collects at most 56 bits on top of
+// the < 8 left by the last flush(); flush() stores the accumulator's 8 bytes unconditionally and advances by the
+// whole bytes it held (the bytes behind them are rewritten by the next flush).  A conditional store would make
+// the number of stores in flight unknown to the compiler's s_waitcnt bookkeeping: loads and stores share one in-order
+// counter (vmcnt), and every wait for a prefetched load would then also wait for the stores issued after it.
+// The region must be cap + 8 bytes long.  Overflow (more than cap bytes) is remembered; close() then returns 0.
 struct ZkeBits {
-    uint8_t *p; uint32_t cap, pos; uint64_t acc; uint32_t n; bool ovf, st;      // st == false: shadow lane, computes but never stores
-    __device__ __forceinline__ void init(uint8_t *p_, uint32_t cap_, bool st_) { p = p_; cap = cap_; pos = 0; acc = 0; n = 0; ovf = false; st = st_; }
-    __device__ __forceinline__ void add(uint32_t v, uint32_t nb)
+    uint8_t *p; uint32_t cap, pos, n, ovf; uint64_t acc;
+    __device__ __forceinline__ void init(uint8_t *p_, uint32_t cap_) { p = p_; cap = cap_; pos = 0; acc = 0; n = 0; ovf = 0; }
+    __device__ __forceinline__ void put(uint32_t v, uint32_t nb) { acc |= (uint64_t)(v & ((1u << nb) - 1u)) << n; n += nb; }    // nb <= 24
+    __device__ __forceinline__ void flush()
     {
-        acc |= (uint64_t)(v & ((1u << nb) - 1u)) << n; n += nb;          // nb <= 24
-        if (n >= 32) {
-            if (pos + 4 <= cap) { if (st) { uint32_t w = (uint32_t)acc; memcpy(p + pos, &w, 4); } } else ovf = true;
-            pos += 4; acc >>= 32; n -= 32;
-        }
+        memcpy(p + pos, &acc, 8);
+        const uint32_t k = n >> 3;               // <= 7
+        pos += k; acc >>= 8 * k; n &= 7;
+        ovf |= pos > cap;
+        pos = pos > cap ? cap : pos;
     }
     __device__ __forceinline__ uint32_t close()
     {
-        add(1, 1);
-        while (n > 0) { if (pos < cap) { if (st) p[pos] = (uint8_t)acc; } else ovf = true; pos++; acc >>= 8; n = n > 8 ? n - 8 : 0; }
+        flush(); put(1, 1); flush();
+        if (n) { memcpy(p + pos, &acc, 8); pos++; ovf |= pos > cap; }
         return ovf ? 0u : pos;
     }
 };
+
+// Copy n bytes with all T lanes of the workgroup: eight loads per lane, then the eight stores (a load issued after a
+// store waits for the store's acknowledgement, so a byte-at-a-time loop pays one HBM write latency per byte).
+template <int T>
+__device__ __forceinline__ void zke_copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t tid)
+{
+    for (uint32_t b0 = 0; b0 < n; b0 += 8 * T) {
+        uint8_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * T + tid; v[u] = src[i < n ? i : 0]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * T + tid; if (i < n) dst[i] = v[u]; }
+    }
+}
 
 constexpr int ZKE_ENT_THREADS = 256;
 constexpr int ZKE_ENT_BLOCKS = 16;                       // blocks per workgroup: lanes = blocks for the serial bit writers
@@ -311,9 +331,30 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             const uint32_t nlit = blk.nlit, q = (nlit + 3) / 4, scap = q + (q >> 1) + 16;
             const uint32_t n_k = k < 3 ? q : nlit - 3 * q;
             const uint8_t *sp = lits + blk.lit_base + k * q;
-            ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + k * scap, scap, true);
+            // last symbol first; the stream is read 8 bytes at a time, three words ahead (the loads are unconditional --
+            // a clamped address reads the stream's first bytes again -- so the waits count the stores exactly)
+            ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + k * scap, scap - 8);
             const ZkHufCode &h = hw[j];
-            for (uint32_t i = n_k; i-- > 0;) { const uint32_t sy = sp[i]; b.add(h.code[sy], h.len[sy]); }   // last symbol first
+            uint32_t i = n_k;
+            for (uint32_t r = n_k & 7; r; r--) { const uint32_t sy = sp[--i]; b.put(h.code[sy], h.len[sy]); b.flush(); }
+            auto ldw = [&](uint32_t at) { return zk_ld64(sp + (at >= 8 ? at - 8 : 0)); };       // symbols [at - 8, at)
+            auto word = [&](uint64_t w) {
+#pragma unroll
+                for (int t = 7; t >= 0; t--) {
+                    const uint32_t sy = (uint32_t)(w >> (8 * t)) & 0xFF;
+                    b.put(h.code[sy], h.len[sy]);                                       // <= 11 bits each
+                    if ((t & 3) == 0) b.flush();
+                }
+            };
+            uint64_t w0 = ldw(i), w1 = ldw(i >= 8 ? i - 8 : 0), w2 = ldw(i >= 16 ? i - 16 : 0);
+            while (i >= 24) {
+                word(w0); w0 = ldw(i - 24);
+                word(w1); w1 = ldw(i >= 32 ? i - 32 : 0);
+                word(w2); w2 = ldw(i >= 40 ? i - 40 : 0);
+                i -= 24;
+            }
+            if (i >= 8) word(w0);
+            if (i >= 16) word(w1);
             s_sizes[j][k] = b.close();
         }
     } else if (wave == 1 && lane < ZKE_ENT_BLOCKS) {
@@ -323,28 +364,45 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             const ZkEncBlock &blk = blocks[b0 + j];
             const uint32_t nseq = blk.nseq, q = (blk.nlit + 3) / 4, scap = q + (q >> 1) + 16;
             const uint64_t *sq = seqs + blk.seq_base;
-            ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + 4 * scap, blk.bsz, true);
+            ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + 4 * scap, blk.bsz);       // + 64 bytes of slack behind it
             uint64_t e = sq[nseq - 1];
             uint32_t ll = (uint32_t)e & 0xFFFFF, ml = (uint32_t)(e >> 20) & 0xFFFFF, ob = (uint32_t)(e >> 40);
             uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
             uint32_t sm = zke_cinit(T.ml_state, T.ml_dnb[mlc], T.ml_dfs[mlc]);
             uint32_t so = zke_cinit(T.of_state, T.of_dnb[ofc], T.of_dfs[ofc]);
             uint32_t sl = zke_cinit(T.ll_state, T.ll_dnb[llc], T.ll_dfs[llc]);
-            b.add(ll - (T.ll_val[llc] & 0xFFFFFF), T.ll_val[llc] >> 24);
-            b.add(ml - (T.ml_val[mlc] & 0xFFFFFF), T.ml_val[mlc] >> 24);
-            b.add(ob - (1u << ofc), ofc);
-            for (uint32_t i = nseq - 1; i-- > 0;) {
-                e = sq[i];
-                ll = (uint32_t)e & 0xFFFFF; ml = (uint32_t)(e >> 20) & 0xFFFFF; ob = (uint32_t)(e >> 40);
-                llc = zke_ll_code(ll); mlc = zke_ml_code(ml - 3); ofc = zk_highbit(ob);
-                { uint32_t nbt = (so + T.of_dnb[ofc]) >> 16; b.add(so, nbt); so = T.of_state[(so >> nbt) + T.of_dfs[ofc]]; }
-                { uint32_t nbt = (sm + T.ml_dnb[mlc]) >> 16; b.add(sm, nbt); sm = T.ml_state[(sm >> nbt) + T.ml_dfs[mlc]]; }
-                { uint32_t nbt = (sl + T.ll_dnb[llc]) >> 16; b.add(sl, nbt); sl = T.ll_state[(sl >> nbt) + T.ll_dfs[llc]]; }
-                b.add(ll - (T.ll_val[llc] & 0xFFFFFF), T.ll_val[llc] >> 24);
-                b.add(ml - (T.ml_val[mlc] & 0xFFFFFF), T.ml_val[mlc] >> 24);
-                b.add(ob - (1u << ofc), ofc);
+            b.put(ll - (T.ll_val[llc] & 0xFFFFFF), T.ll_val[llc] >> 24);
+            b.put(ml - (T.ml_val[mlc] & 0xFFFFFF), T.ml_val[mlc] >> 24);
+            b.flush();
+            b.put(ob - (1u << ofc), ofc);
+            b.flush();
+            auto step = [&](uint64_t e) {
+                const uint32_t ll = (uint32_t)e & 0xFFFFF, ml = (uint32_t)(e >> 20) & 0xFFFFF, ob = (uint32_t)(e >> 40);
+                const uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
+                { uint32_t nbt = (so + T.of_dnb[ofc]) >> 16; b.put(so, nbt); so = T.of_state[(so >> nbt) + T.of_dfs[ofc]]; }
+                { uint32_t nbt = (sm + T.ml_dnb[mlc]) >> 16; b.put(sm, nbt); sm = T.ml_state[(sm >> nbt) + T.ml_dfs[mlc]]; }
+                { uint32_t nbt = (sl + T.ll_dnb[llc]) >> 16; b.put(sl, nbt); sl = T.ll_state[(sl >> nbt) + T.ll_dfs[llc]]; }
+                b.put(ll - (T.ll_val[llc] & 0xFFFFFF), T.ll_val[llc] >> 24);             // <= 17 + 16 bits since the flush
+                b.flush();
+                b.put(ml - (T.ml_val[mlc] & 0xFFFFFF), T.ml_val[mlc] >> 24);
+                b.put(ob - (1u << ofc), ofc);                                            // <= 16 + 24
+                b.flush();
+            };
+            // sequences nseq - 2 .. 0, read four ahead with unconditional (clamped) loads
+            auto lds = [&](int32_t k) { return sq[k < 0 ? 0 : k]; };
+            int32_t i = (int32_t)nseq - 2;
+            uint64_t e0 = lds(i), e1 = lds(i - 1), e2 = lds(i - 2), e3 = lds(i - 3);
+            while (i >= 3) {
+                step(e0); e0 = lds(i - 4);
+                step(e1); e1 = lds(i - 5);
+                step(e2); e2 = lds(i - 6);
+                step(e3); e3 = lds(i - 7);
+                i -= 4;
             }
-            b.add(sm, 6); b.add(so, 5); b.add(sl, 6);
+            if (i >= 0) step(e0);
+            if (i >= 1) step(e1);
+            if (i >= 2) step(e2);
+            b.put(sm, 6); b.put(so, 5); b.put(sl, 6);
             sz = b.close();
         }
         s_sizes[lane][4] = sz;
@@ -414,7 +472,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             p = hdr + tree + 6;
             for (int k = 0; k < 4; k++) {
                 const uint8_t *sp = stemp + k * scap;
-                for (uint32_t i = tid; i < z[k]; i += ZKE_ENT_THREADS) payload[p + i] = sp[i];
+                zke_copy<ZKE_ENT_THREADS>(payload + p, sp, z[k], tid);
                 p += z[k];
             }
         } else {
@@ -427,7 +485,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             }
             p = raw_hdr;
             if (lm == 1) p += 1;
-            else { for (uint32_t i = tid; i < nlit; i += ZKE_ENT_THREADS) payload[p + i] = lt[i]; p += nlit; }
+            else { zke_copy<ZKE_ENT_THREADS>(payload + p, lt, nlit, tid); p += nlit; }
         }
         if (tid == 0) {
             if (nseq < 128) payload[p] = (uint8_t)nseq;
@@ -438,7 +496,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
         if (nseq) {
             if (tid == 0) payload[p] = 0;                          // predefined LL / OF / ML
             p += 1;
-            for (uint32_t i = tid; i < z[4]; i += ZKE_ENT_THREADS) payload[p + i] = qtemp[i];
+            zke_copy<ZKE_ENT_THREADS>(payload + p, qtemp, z[4], tid);
         }
     }
 }
