@@ -27,7 +27,9 @@
 #include "zk_kernels.h"
 
 // ------------------------------------------------------------------------------------------------ match + parse
-constexpr int ZKE_THREADS = 512;                         // 8 waves: 8 tiles of a group are parsed side by side
+constexpr int ZKE_THREADS = 512;
+constexpr uint32_t ZKE_QCAP = 960;                       // <= 1024 (10-bit queue index)
+static_assert(ZKE_QCAP >= (uint32_t)ZKE_THREADS && ZKE_QCAP <= 1024, "queue");                         // 8 waves: 8 tiles of a group are parsed side by side
 
 __device__ __forceinline__ uint32_t zke_match_len(const uint8_t *a, const uint8_t *b, const uint8_t *end)   // b > a
 {
@@ -40,6 +42,27 @@ __device__ __forceinline__ uint32_t zke_match_len(const uint8_t *a, const uint8_
     while (b < end && *a == *b) { a++; b++; }
     return (uint32_t)(b - s);
 }
+
+// Common prefix of a.. and b.. (b > a) over at most n <= 56 bytes, the loads issued in two batches (32 + 24 bytes of
+// either side) instead of one dependent round trip per 8 bytes.  safe = bytes readable from b on (the comparison may
+// look past n, the result is clamped); short of 56 the byte-exact loop does it.
+__device__ __forceinline__ uint32_t zke_match_ext(const uint8_t *a, const uint8_t *b, uint32_t n, uint32_t safe)
+{
+    if (safe < 56) return zke_match_len(a, b, b + n);
+    const uint64_t x0 = zk_ld64(a) ^ zk_ld64(b), x1 = zk_ld64(a + 8) ^ zk_ld64(b + 8),
+                   x2 = zk_ld64(a + 16) ^ zk_ld64(b + 16), x3 = zk_ld64(a + 24) ^ zk_ld64(b + 24);
+    uint32_t l = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3) : x1 ? 8 + (uint32_t)(__builtin_ctzll(x1) >> 3)
+               : x2 ? 16 + (uint32_t)(__builtin_ctzll(x2) >> 3) : x3 ? 24 + (uint32_t)(__builtin_ctzll(x3) >> 3) : 32;
+    if (l == 32 && n > 32) {
+        const uint64_t y0 = zk_ld64(a + 32) ^ zk_ld64(b + 32), y1 = zk_ld64(a + 40) ^ zk_ld64(b + 40), y2 = zk_ld64(a + 48) ^ zk_ld64(b + 48);
+        l = y0 ? 32 + (uint32_t)(__builtin_ctzll(y0) >> 3) : y1 ? 40 + (uint32_t)(__builtin_ctzll(y1) >> 3)
+          : y2 ? 48 + (uint32_t)(__builtin_ctzll(y2) >> 3) : 56;
+    }
+    return l < n ? l : n;
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load in flight.
+__device__ __forceinline__ void zke_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // per-tile sequence as the parse leaves it in LDS: ll (12) | ml (11) << 12 | offset (17) << 23 | position in tile (10) << 40
 __device__ __forceinline__ uint64_t zke_tpack(uint32_t ll, uint32_t ml, uint32_t off, uint32_t pit) { return (uint64_t)ll | ((uint64_t)ml << 12) | ((uint64_t)off << 23) | ((uint64_t)pit << 40); }
@@ -77,7 +100,8 @@ const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
     __shared__ uint32_t best[ZKE_GROUP][ZKE_TILE];         // len (7 bits) | offset << 8
     __shared__ uint64_t tseq[ZKE_GROUP][ZKE_TILE / 4 + 4];
     __shared__ uint32_t tcount[ZKE_GROUP], ttail[ZKE_GROUP];
-    __shared__ uint32_t s_scan[ZKE_THREADS];
+    __shared__ uint32_t s_queue[ZKE_QCAP], s_qres[ZKE_QCAP], s_qn;       // matches of 8+ bytes waiting to be measured (compare phase)
+    uint32_t *s_scan = s_queue;                                         // the gather pass reuses it (ZKE_THREADS words)
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ZkEncFrame fr = frames[blockIdx.x];
     const uint8_t *base = src + fr.m_off;
@@ -99,51 +123,133 @@ const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
         uint32_t nseq = 0, carry = 0, prev_off = 0;
         for (uint32_t gs = bs; gs < be; gs += ZKE_TILE * ZKE_GROUP) {
             const uint32_t R = probe;
-            uint32_t ntiles = 0;
-            // phase 1 + insert, one lookup step (ZKE_LSTEP tiles, one position per lane) after the other: every position
-            // of a step sees the table as it was before the step
-            for (uint32_t ls = gs; ls < be && ntiles < ZKE_GROUP; ls += ZKE_TILE * ZKE_LSTEP) {
-                const uint32_t le = ls + ZKE_TILE * ZKE_LSTEP < be ? ls + ZKE_TILE * ZKE_LSTEP : be;
-                const uint32_t p = ls + tid;
-                const uint32_t sub = tid / ZKE_TILE, ts = ls + sub * ZKE_TILE;
-                const uint32_t te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
-                const uint8_t *lim = base + te;
-                const bool in = p < le, wide8 = in && p + 8 <= fend;
-                // the loads of a lane are issued together (three rounds of memory latency per step)
-                const uint64_t w = wide8 ? zk_ld64(base + p) : 0;
-                uint32_t hsh = 0xFFFFFFFFu, o1 = 0;
-                if (wide8) {
-                    hsh = (uint32_t)(((w << 24) * 889523592379ull) >> (64 - ZKE_HASH_LOG));
-                    const uint32_t d = (p + 1 - (table[hsh >> 1] >> (16 * (hsh & 1)))) & 0xFFFFu;
-                    if (d && d <= p) o1 = d;
-                }
-                const uint64_t c1 = o1 ? zk_ld64(base + p - o1) : 0;                    // p + 8 <= fend holds when o1 != 0
-                const uint64_t c2 = (wide8 && R && R <= p) ? zk_ld64(base + p - R) : 0;
-                if (in) {
-                    const uint8_t *cap = base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim;
-                    uint32_t l1 = 0, l2 = 0;
-                    const bool wide = wide8 && base + p + 8 <= cap;                     // the first 8 bytes are already in registers
-                    if (o1) {
-                        const uint64_t x = w ^ c1;
-                        if (wide && x) l1 = (uint32_t)(__builtin_ctzll(x) >> 3);
-                        else if (wide) l1 = 8 + zke_match_len(base + p + 8 - o1, base + p + 8, cap);
-                        else l1 = zke_match_len(base + p - o1, base + p, cap);
-                    }
-                    if (R && R <= p) {
-                        const uint64_t x = w ^ c2;
-                        if (wide && x) l2 = (uint32_t)(__builtin_ctzll(x) >> 3);
-                        else if (wide) l2 = 8 + zke_match_len(base + p + 8 - R, base + p + 8, cap);
-                        else l2 = zke_match_len(base + p - R, base + p, cap);
-                    }
-                    if (l1 < ZKE_MINMATCH) l1 = 0;
-                    if (l2 < 4) l2 = 0;
-                    best[ntiles + sub][p - ts] = (l2 && l2 >= l1) ? (l2 | (R << 8)) : (l1 | (o1 << 8));
-                }
-                __syncthreads();
-                if (hsh != 0xFFFFFFFFu) zke_table_insert(table, hsh, p, (ls + 1) & 0xFFFFu, le - ls);     // the largest position of the step wins a slot
-                __syncthreads();
-                ntiles += (le - ls + ZKE_TILE - 1) / ZKE_TILE;
+            // phase 1, one lookup step (ZKE_LSTEP tiles, one position per lane) after the other: every position of a step
+            // sees the table as it was before the step.  The candidate bytes (a divergent 8-byte load per lane somewhere in
+            // the last 64 KiB: the slowest of 512 such loads used to end every step) are only *requested* here; lookups and
+            // insertions of the group's steps go on behind barriers that wait for LDS alone, and the comparisons follow
+            // once all of the group's candidates are on their way.  All loads are unconditional (clamped addresses), so the
+            // waits count exactly.
+            constexpr int NSTEP = (int)(ZKE_GROUP / ZKE_LSTEP);
+            uint64_t W[NSTEP], C1[NSTEP];
+            uint32_t O1[NSTEP];
+            const uint32_t hi8 = fend >= 8 ? fend - 8 : 0;                               // last position with 8 readable bytes
+#pragma unroll
+            for (int st = 0; st < NSTEP; st++) {
+                const uint32_t p = gs + st * ZKE_THREADS + tid;
+                W[st] = fend >= 8 ? zk_ld64(base + (p < hi8 ? p : hi8)) : 0;
             }
+#pragma unroll
+            for (int st = 0; st < NSTEP; st++) {
+                const uint32_t ls = gs + st * ZKE_THREADS;
+                if (ls < be) {
+                    const uint32_t le = ls + ZKE_THREADS < be ? ls + ZKE_THREADS : be;
+                    const uint32_t p = ls + tid, pc = p < hi8 ? p : hi8;
+                    const bool wide8 = p < le && p + 8 <= fend;
+                    uint32_t hsh = 0xFFFFFFFFu, o1 = 0;
+                    if (wide8) {
+                        hsh = (uint32_t)(((W[st] << 24) * 889523592379ull) >> (64 - ZKE_HASH_LOG));
+                        const uint32_t d = (p + 1 - (table[hsh >> 1] >> (16 * (hsh & 1)))) & 0xFFFFu;
+                        if (d && d <= p) o1 = d;
+                    }
+                    O1[st] = o1;
+                    C1[st] = fend >= 8 ? zk_ld64(base + pc - o1) : 0;                    // o1 == 0: the lane's own bytes again (unused)
+                    zke_lds_barrier();
+                    if (hsh != 0xFFFFFFFFu) zke_table_insert(table, hsh, p, (ls + 1) & 0xFFFFu, le - ls);     // the largest position of the step wins a slot
+                    zke_lds_barrier();
+                }
+            }
+            // comparisons, from registers: 0..8 equal bytes per candidate.  A candidate that matches all 8 (and has room
+            // for more) is queued in LDS; the queue is then measured by all lanes together, one lane per 8-byte word of a
+            // queued match, four words in flight per lane -- one or two rounds of memory latency per GROUP instead of up
+            // to two per step.  LF[st]: per candidate 11 bits, the length so far or 0x400 | queue index.
+            uint32_t ntiles = 0;
+            uint32_t LF[NSTEP];
+            if (tid == 0) s_qn = 0;
+            zke_lds_barrier();
+            auto ldr = [&](int st) { const uint32_t p = gs + st * ZKE_THREADS + tid, pc = p < hi8 ? p : hi8; return fend >= 8 ? zk_ld64(base + pc - (R <= pc ? R : 0)) : 0; };
+            uint64_t c2n = ldr(0);                       // bytes at the previous offset R (coalesced, cheap): requested one step ahead
+#pragma unroll
+            for (int st = 0; st < NSTEP; st++) {
+                const uint32_t ls = gs + st * ZKE_THREADS;
+                const uint64_t c2 = c2n;
+                if (st + 1 < NSTEP) c2n = ldr(st + 1);
+                LF[st] = 0;
+                if (ls < be) {
+                    const uint32_t le = ls + ZKE_THREADS < be ? ls + ZKE_THREADS : be;
+                    const uint32_t p = ls + tid;
+                    const uint32_t ts = ls + (tid / ZKE_TILE) * ZKE_TILE, te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
+                    if (p < le) {
+                        const uint32_t n = te - p < ZKE_PARCAP ? te - p : ZKE_PARCAP;      // a match may not leave the tile
+                        if (O1[st] == R) O1[st] = 0;                                       // the same candidate twice: the R form wins a tie anyway
+                        uint32_t f[2] = {0, 0};
+                        if (p + 8 <= fend) {
+#pragma unroll
+                            for (int c = 0; c < 2; c++) {
+                                const uint32_t off = c == 0 ? O1[st] : R;
+                                if (c == 0 ? off != 0 : (R && R <= p)) {
+                                    const uint64_t x = W[st] ^ (c == 0 ? C1[st] : c2);
+                                    uint32_t l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8;
+                                    if (l == 8 && n > 8) {
+                                        const uint32_t qi = atomicAdd(&s_qn, 1u);
+                                        if (qi < ZKE_QCAP) { s_queue[qi] = (p - gs) | (off << 11); s_qres[qi] = n; l = 0x400 | qi; }
+                                        else l = 8 + zke_match_ext(base + p + 8 - off, base + p + 8, n - 8, fend - (p + 8));     // queue full (very repetitive data)
+                                    }
+                                    f[c] = l < n || l >= 0x400 ? l : n;
+                                }
+                            }
+                        } else if (R && R <= p) f[1] = zke_match_len(base + p - R, base + p, base + p + n);   // the frame's last 7 bytes
+                        LF[st] = f[0] | (f[1] << 11);
+                    }
+                    ntiles += (le - ls + ZKE_TILE - 1) / ZKE_TILE;
+                }
+            }
+            zke_lds_barrier();
+            {
+                const uint32_t nq = s_qn < ZKE_QCAP ? s_qn : ZKE_QCAP;
+                for (uint32_t i0 = tid; i0 < nq * 8; i0 += 4 * ZKE_THREADS) {
+                    uint64_t xa[4], xb[4];
+                    uint32_t lim[4], at[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {                                         // word k of queue entry e: bytes [8 + 8k, 16 + 8k) of the match
+                        const uint32_t it = i0 + u * ZKE_THREADS, e = (it >> 3) < nq ? it >> 3 : 0, k = it & 7;
+                        const uint32_t ent = s_queue[e], pos = gs + (ent & 0x7FF), off = ent >> 11;
+                        const uint32_t o = 8 + 8 * k;
+                        lim[u] = (it >> 3) < nq ? s_qres[e] : 0;                          // n of the entry (or a smaller mismatch already found)
+                        at[u] = o;
+                        const uint32_t q = pos + o < hi8 ? pos + o : hi8;                 // clamped: the frame's last bytes are compared bytewise below
+                        xa[u] = zk_ld64(base + q - off); xb[u] = zk_ld64(base + q);
+                        if (pos + o + 8 > fend && o < lim[u]) {                           // rare: word crosses the frame end
+                            const uint32_t m = o + zke_match_len(base + pos + o - off, base + pos + o, base + fend);
+                            if (m < lim[u]) atomicMin(&s_qres[e], m);
+                            lim[u] = 0;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint64_t x = xa[u] ^ xb[u];
+                        const uint32_t it = i0 + u * ZKE_THREADS;
+                        if (x && at[u] < lim[u]) { const uint32_t m = at[u] + (uint32_t)(__builtin_ctzll(x) >> 3); if (m < lim[u]) atomicMin(&s_qres[it >> 3], m); }
+                    }
+                }
+            }
+            zke_lds_barrier();
+#pragma unroll
+            for (int st = 0; st < NSTEP; st++) {
+                const uint32_t ls = gs + st * ZKE_THREADS;
+                if (ls < be) {
+                    const uint32_t le = ls + ZKE_THREADS < be ? ls + ZKE_THREADS : be;
+                    const uint32_t p = ls + tid, sub = tid / ZKE_TILE, ts = ls + sub * ZKE_TILE;
+                    if (p < le) {
+                        uint32_t l1 = LF[st] & 0x7FF, l2 = LF[st] >> 11;
+                        if (l1 & 0x400) l1 = s_qres[l1 & 0x3FF];
+                        if (l2 & 0x400) l2 = s_qres[l2 & 0x3FF];
+                        if (l1 < ZKE_MINMATCH) l1 = 0;
+                        if (l2 < 4) l2 = 0;
+                        best[2 * st + sub][p - ts] = (l2 && l2 >= l1) ? (l2 | (R << 8)) : (l1 | (O1[st] << 8));
+                    }
+                }
+            }
+            __syncthreads();
             // phase 2: wave w parses tile w on its own (greedy, matches end at the tile end)
             if (wave < ntiles) {
                 const uint32_t ts = gs + wave * ZKE_TILE, te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
@@ -194,9 +300,12 @@ const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
                 else pend += te - ts;
             }
             carry = pend; prev_off = last_off; nseq = outbase;
-            __syncthreads();                                 // tseq / tcount are reused; sq / mp visible to the gather pass
+            zke_lds_barrier();                               // tseq / tcount are reused (sq / mp: see the gather pass)
         }
-        // literal gather: literals of sequence i start at (mpos_i - bs) - ll_i - (match bytes before i)
+        // literal gather: literals of sequence i start at (mpos_i - bs) - ll_i - (match bytes before i).  A load issued
+        // after a store waits for the store's acknowledgement (one in-order counter), so a lane first requests the
+        // records of four sequences, then their first 8 literal bytes, and only then stores.
+        __syncthreads();                                     // sq / mp of the block's last groups are visible
         {
             const uint32_t chunk = (nseq + ZKE_THREADS - 1) / ZKE_THREADS;
             const uint32_t i0 = tid * chunk < nseq ? tid * chunk : nseq, i1 = i0 + chunk < nseq ? i0 + chunk : nseq;
@@ -208,12 +317,27 @@ const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
             for (uint32_t k = 0; k < tid; k++) M += s_scan[k];
             uint32_t total_m = 0;
             for (uint32_t k = 0; k < ZKE_THREADS; k++) total_m += s_scan[k];
-            for (uint32_t i = i0; i < i1; i++) {
-                const uint64_t e = sq[i];
-                const uint32_t ll = (uint32_t)e & 0xFFFFF, ml = (uint32_t)(e >> 20) & 0xFFFFF;
-                const uint32_t from = mp[i] - ll, to = (mp[i] - bs) - ll - M;
-                for (uint32_t k = 0; k < ll; k++) lt[to + k] = base[from + k];
-                M += ml;
+            const uint32_t hi8g = fend >= 8 ? fend - 8 : 0;
+            for (uint32_t i = i0; i < i1; i += 4) {
+                uint64_t e[4], w[4];
+                uint32_t m[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const uint32_t k = i + u < i1 ? i + u : i1 - 1; e[u] = sq[k]; m[u] = mp[k]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const uint32_t from = m[u] - ((uint32_t)e[u] & 0xFFFFF); w[u] = zk_ld64(base + (from < hi8g ? from : hi8g)); }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (i + u < i1) {
+                        const uint32_t ll = (uint32_t)e[u] & 0xFFFFF, ml = (uint32_t)(e[u] >> 20) & 0xFFFFF;
+                        const uint32_t from = m[u] - ll, to = (m[u] - bs) - ll - M;
+                        if (from <= hi8g && fend >= 8) {
+#pragma unroll
+                            for (uint32_t k = 0; k < 8; k++) if (k < ll) lt[to + k] = (uint8_t)(w[u] >> (8 * k));
+                            for (uint32_t k = 8; k < ll; k++) lt[to + k] = base[from + k];
+                        } else for (uint32_t k = 0; k < ll; k++) lt[to + k] = base[from + k];
+                        M += ml;
+                    }
+                }
             }
             const uint32_t nlit = (be - bs) - total_m;
             for (uint32_t k = tid; k < carry; k += ZKE_THREADS) lt[nlit - carry + k] = base[be - carry + k];
