@@ -281,23 +281,39 @@ const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
                 if (lane == 0) { tcount[wave] = c; ttail[wave] = te - anchor; }
             }
             __syncthreads();
-            // stitch the tiles of the group: literals left over at a tile's end join the next sequence
+            // stitch the tiles of the group: literals left over at a tile's end join the next sequence.  Every lane reads
+            // the eight tile summaries at once and runs the little scan itself; wave w then rewrites tile w's sequences
+            // (one LDS round trip for the group, not one per tile)
             uint32_t pend = carry, last_off = prev_off, outbase = nseq;
-            for (uint32_t t = 0; t < ntiles; t++) {
-                const uint32_t ts = gs + t * ZKE_TILE, te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
-                const uint32_t cnt = tcount[t];
-                for (uint32_t j = tid; j < cnt; j += ZKE_THREADS) {
-                    const uint64_t e = tseq[t][j];
+            uint32_t my_pend = 0, my_poff = 0, my_base = 0, my_cnt = 0;
+            {
+                uint32_t cn[ZKE_GROUP], tl[ZKE_GROUP], lo[ZKE_GROUP];
+#pragma unroll
+                for (uint32_t t = 0; t < ZKE_GROUP; t++) { cn[t] = t < ntiles ? tcount[t] : 0; tl[t] = ttail[t]; }
+#pragma unroll
+                for (uint32_t t = 0; t < ZKE_GROUP; t++) lo[t] = (uint32_t)(tseq[t][cn[t] ? cn[t] - 1 : 0] >> 23) & 0x1FFFF;
+#pragma unroll
+                for (uint32_t t = 0; t < ZKE_GROUP; t++) {
+                    if (t < ntiles) {
+                        const uint32_t ts = gs + t * ZKE_TILE, te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
+                        if (t == wave) { my_pend = pend; my_poff = last_off; my_base = outbase; my_cnt = cn[t]; }
+                        if (cn[t]) { pend = tl[t]; last_off = lo[t]; probe = last_off; outbase += cn[t]; }
+                        else pend += te - ts;
+                    }
+                }
+            }
+            {
+                const uint32_t ts = gs + wave * ZKE_TILE;
+                for (uint32_t j = lane; j < my_cnt; j += 64) {
+                    const uint64_t e = tseq[wave][j];
                     uint32_t ll = (uint32_t)e & 0xFFF;
                     const uint32_t ml = (uint32_t)(e >> 12) & 0x7FF, off = (uint32_t)(e >> 23) & 0x1FFFF, pit = (uint32_t)(e >> 40);
-                    const uint32_t poff = j ? (uint32_t)(tseq[t][j - 1] >> 23) & 0x1FFFF : last_off;
-                    if (j == 0) ll += pend;
+                    const uint32_t poff = j ? (uint32_t)(tseq[wave][j - 1] >> 23) & 0x1FFFF : my_poff;
+                    if (j == 0) ll += my_pend;
                     const uint32_t code = (ll && off == poff) ? 1u : off + 3;
-                    sq[outbase + j] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)code << 40);
-                    mp[outbase + j] = ts + pit;
+                    sq[my_base + j] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)code << 40);
+                    mp[my_base + j] = ts + pit;
                 }
-                if (cnt) { pend = ttail[t]; last_off = (uint32_t)(tseq[t][cnt - 1] >> 23) & 0x1FFFF; probe = last_off; outbase += cnt; }
-                else pend += te - ts;
             }
             carry = pend; prev_off = last_off; nseq = outbase;
             zke_lds_barrier();                               // tseq / tcount are reused (sq / mp: see the gather pass)
@@ -317,28 +333,46 @@ const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
             for (uint32_t k = 0; k < tid; k++) M += s_scan[k];
             uint32_t total_m = 0;
             for (uint32_t k = 0; k < ZKE_THREADS; k++) total_m += s_scan[k];
+            // the literals of a lane's consecutive sequences are contiguous in the literal buffer: they are collected in a
+            // 64-bit accumulator and leave 8 bytes at a time (a scattered byte store costs the memory pipeline as much
+            // as an 8-byte one)
             const uint32_t hi8g = fend >= 8 ? fend - 8 : 0;
+            uint64_t acc = 0;
+            uint32_t an = 0, wr = 0;                                                      // bytes waiting in acc; where they go
+            auto append = [&](uint64_t w, uint32_t cnt) {                                // 1 <= cnt <= 8 bytes of w
+                const uint64_t wm = cnt < 8 ? w & ((1ull << (8 * cnt)) - 1) : w;
+                acc |= wm << (8 * an);
+                if (an + cnt >= 8) {
+                    memcpy(lt + wr, &acc, 8); wr += 8;
+                    acc = an ? wm >> (8 * (8 - an)) : 0;
+                    an = an + cnt - 8;
+                } else an += cnt;
+            };
             for (uint32_t i = i0; i < i1; i += 4) {
                 uint64_t e[4], w[4];
                 uint32_t m[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) { const uint32_t k = i + u < i1 ? i + u : i1 - 1; e[u] = sq[k]; m[u] = mp[k]; }
 #pragma unroll
-                for (int u = 0; u < 4; u++) { const uint32_t from = m[u] - ((uint32_t)e[u] & 0xFFFFF); w[u] = zk_ld64(base + (from < hi8g ? from : hi8g)); }
+                for (int u = 0; u < 4; u++) { const uint32_t from = m[u] - ((uint32_t)e[u] & 0xFFFFF); w[u] = fend >= 8 ? zk_ld64(base + (from < hi8g ? from : hi8g)) : 0; }
+                if (i == i0) wr = (m[0] - bs) - ((uint32_t)e[0] & 0xFFFFF) - M;
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     if (i + u < i1) {
-                        const uint32_t ll = (uint32_t)e[u] & 0xFFFFF, ml = (uint32_t)(e[u] >> 20) & 0xFFFFF;
-                        const uint32_t from = m[u] - ll, to = (m[u] - bs) - ll - M;
-                        if (from <= hi8g && fend >= 8) {
-#pragma unroll
-                            for (uint32_t k = 0; k < 8; k++) if (k < ll) lt[to + k] = (uint8_t)(w[u] >> (8 * k));
-                            for (uint32_t k = 8; k < ll; k++) lt[to + k] = base[from + k];
-                        } else for (uint32_t k = 0; k < ll; k++) lt[to + k] = base[from + k];
-                        M += ml;
+                        const uint32_t ll = (uint32_t)e[u] & 0xFFFFF, from = m[u] - ll;
+                        if (ll) {
+                            if (from <= hi8g && fend >= 8) append(w[u], ll < 8 ? ll : 8);
+                            else for (uint32_t k = 0; k < ll && k < 8; k++) append(base[from + k], 1);       // the frame's last bytes
+                            for (uint32_t k = 8; k < ll; k += 8) {                        // long literal runs
+                                const uint32_t c = ll - k < 8 ? ll - k : 8;
+                                if (from + k <= hi8g && fend >= 8) append(zk_ld64(base + from + k), c);
+                                else for (uint32_t j = 0; j < c; j++) append(base[from + k + j], 1);
+                            }
+                        }
                     }
                 }
             }
+            for (uint32_t k = 0; k < an; k++) lt[wr + k] = (uint8_t)(acc >> (8 * k));
             const uint32_t nlit = (be - bs) - total_m;
             for (uint32_t k = tid; k < carry; k += ZKE_THREADS) lt[nlit - carry + k] = base[be - carry + k];
             if (tid == 0) { blk->nseq = nseq; blk->nlit = nlit; }
