@@ -27,9 +27,9 @@
 #include "zk_kernels.h"
 
 // ------------------------------------------------------------------------------------------------ match + parse
-constexpr int ZKE_THREADS = 512;
-constexpr uint32_t ZKE_QCAP = 960;                       // <= 1024 (10-bit queue index)
-static_assert(ZKE_QCAP >= (uint32_t)ZKE_THREADS && ZKE_QCAP <= 1024, "queue");                         // 8 waves: 8 tiles of a group are parsed side by side
+constexpr int ZKE_THREADS = 512;                         // 8 waves: 8 tiles of a group are parsed side by side
+constexpr uint32_t ZKE_QCAP = 960;                       // matches waiting to be measured; <= 1024 (10-bit queue index)
+static_assert(ZKE_QCAP >= (uint32_t)ZKE_THREADS && ZKE_QCAP <= 1024, "queue");
 
 __device__ __forceinline__ uint32_t zke_match_len(const uint8_t *a, const uint8_t *b, const uint8_t *end)   // b > a
 {
@@ -408,18 +408,21 @@ struct ZkeBits {
     }
 };
 
-// Copy n bytes with all T lanes of the workgroup: eight loads per lane, then the eight stores (a load issued after a
-// store waits for the store's acknowledgement, so a byte-at-a-time loop pays one HBM write latency per byte).
-template <int T>
-__device__ __forceinline__ void zke_copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t tid)
+// Copy n bytes with the 64 lanes of a wave, 8 bytes per lane and access (unaligned on both sides): eight loads per
+// lane, then the eight stores -- a load issued after a store waits for the store's acknowledgement, so a
+// byte-at-a-time loop pays one HBM write latency per byte.
+__device__ __forceinline__ void zke_copy_wave(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane)
 {
-    for (uint32_t b0 = 0; b0 < n; b0 += 8 * T) {
-        uint8_t v[8];
+    const uint32_t nw = n >> 3;
+    for (uint32_t b0 = 0; b0 < nw; b0 += 8 * 64) {
+        uint64_t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * T + tid; v[u] = src[i < n ? i : 0]; }
+        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * 64 + lane; v[u] = zk_ld64(src + 8 * (i < nw ? i : 0)); }
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * T + tid; if (i < n) dst[i] = v[u]; }
+        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * 64 + lane; if (i < nw) memcpy(dst + 8 * i, &v[u], 8); }
     }
+    const uint32_t t = 8 * nw + lane;
+    if (t < n) dst[t] = src[t];
 }
 
 constexpr int ZKE_ENT_THREADS = 256;
@@ -432,7 +435,7 @@ static_assert(ZKE_THREADS == (int)(ZKE_TILE * ZKE_LSTEP), "one lookup position p
 // fewer than 16 active lanes runs ~3x slower on gfx950, tools/ubench/lat3.hip).  Histograms, RLE detection and the
 // payload copies use all 256 lanes, block after block; the Huffman code of block j is built by lane j of wave 0.
 __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
-                                                                   uint32_t nblocks, const uint64_t *seqs, const uint8_t *lits,
+                                                                   uint32_t nblocks, uint64_t *seqs, uint32_t *mpos, const uint8_t *lits,
                                                                    uint8_t *scratch, const ZkEncTables *tabs)
 {
     __shared__ uint32_t cnt[ZKE_ENT_BLOCKS][256];
@@ -454,13 +457,63 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
         const ZkEncBlock &blk = blocks[b0 + j];
         const uint8_t *raw = src + frames[blk.frame].src_off + blk.bs;
         const uint8_t *lt = lits + blk.lit_base;
-        const uint8_t first = raw[0];
-        bool diff = false;
-        for (uint32_t i = tid; i < blk.bsz; i += ZKE_ENT_THREADS) diff |= raw[i] != first;
-        if (diff) s_diff[j] = 1;
-        for (uint32_t i = tid; i < blk.nlit; i += ZKE_ENT_THREADS) atomicAdd(&cnt[j][lt[i]], 1u);
+        // 8 bytes per load, four loads in flight per lane (a byte-at-a-time loop is one L1 round trip per byte)
+        const uint64_t first8 = raw[0] * 0x0101010101010101ull;
+        uint64_t dx = 0;
+        const uint32_t bw = blk.bsz >> 3, lw = blk.nlit >> 3;
+        for (uint32_t i = tid; i < bw; i += 4 * ZKE_ENT_THREADS) {
+            uint64_t w[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t k = i + u * ZKE_ENT_THREADS; w[u] = zk_ld64(raw + 8 * (k < bw ? k : i)); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) dx |= w[u] ^ first8;
+        }
+        for (uint32_t i = 8 * bw + tid; i < blk.bsz; i += ZKE_ENT_THREADS) dx |= raw[i] ^ raw[0];
+        if (dx) s_diff[j] = 1;
+        for (uint32_t i = tid; i < lw; i += 4 * ZKE_ENT_THREADS) {
+            uint64_t w[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t k = i + u * ZKE_ENT_THREADS; w[u] = zk_ld64(lt + 8 * (k < lw ? k : i)); }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i + u * ZKE_ENT_THREADS < lw) {
+#pragma unroll
+                    for (int t = 0; t < 8; t++) atomicAdd(&cnt[j][(w[u] >> (8 * t)) & 0xFF], 1u);
+                }
+        }
+        for (uint32_t i = 8 * lw + tid; i < blk.nlit; i += ZKE_ENT_THREADS) atomicAdd(&cnt[j][lt[i]], 1u);
     }
     __syncthreads();
+    // While 16 lanes of wave 0 build the Huffman codes, waves 1-3 rewrite every sequence of the 16 blocks into what
+    // its serial bit writer needs -- everything that does not depend on the FSE states:
+    //   seqs[i]  <- extra bits of LL | ML | OF back to back (<= 48 bits), their count << 56
+    //   mpos[i]  <- LL code | ML code << 8 | OF code << 16        (the match positions are not needed any more)
+    if (wave >= 1) {
+        for (uint32_t j = 0; j < nb; j++) {
+            const ZkEncBlock &blk = blocks[b0 + j];
+            uint64_t *sq = seqs + blk.seq_base;
+            uint32_t *cw = mpos + blk.seq_base;
+            const uint32_t nseq = blk.nseq, T3 = ZKE_ENT_THREADS - 64;
+            for (uint32_t i = tid - 64; i < nseq; i += 4 * T3) {
+                uint64_t e[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const uint32_t k = i + u * T3; e[u] = sq[k < nseq ? k : i]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t k = i + u * T3;
+                    if (k < nseq) {
+                        const uint32_t ll = (uint32_t)e[u] & 0xFFFFF, ml = (uint32_t)(e[u] >> 20) & 0xFFFFF, ob = (uint32_t)(e[u] >> 40);
+                        const uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
+                        const uint32_t lv = T.ll_val[llc], mv = T.ml_val[mlc];
+                        const uint32_t ln = lv >> 24, mn = mv >> 24;
+                        const uint64_t x = (uint64_t)(ll - (lv & 0xFFFFFF)) | ((uint64_t)(ml - (mv & 0xFFFFFF)) << ln) | ((uint64_t)(ob - (1u << ofc)) << (ln + mn));
+                        sq[k] = x | ((uint64_t)(ln + mn + ofc) << 56);
+                        cw[k] = llc | (mlc << 8) | (ofc << 16);
+                    }
+                }
+            }
+        }
+    }
     // literal mode + Huffman code: two rounds of 8 blocks, block j on lanes j % 8 and j % 8 + 8 of wave 0 (the second
     // lane shadows the first with identical LDS writes: >= 16 active lanes, see zk_decode.hip)
     for (uint32_t round = 0; round < 2; round++) {
@@ -523,43 +576,42 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             const uint32_t nseq = blk.nseq, q = (blk.nlit + 3) / 4, scap = q + (q >> 1) + 16;
             const uint64_t *sq = seqs + blk.seq_base;
             ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + 4 * scap, blk.bsz);       // + 64 bytes of slack behind it
-            uint64_t e = sq[nseq - 1];
-            uint32_t ll = (uint32_t)e & 0xFFFFF, ml = (uint32_t)(e >> 20) & 0xFFFFF, ob = (uint32_t)(e >> 40);
-            uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
-            uint32_t sm = zke_cinit(T.ml_state, T.ml_dnb[mlc], T.ml_dfs[mlc]);
-            uint32_t so = zke_cinit(T.of_state, T.of_dnb[ofc], T.of_dfs[ofc]);
-            uint32_t sl = zke_cinit(T.ll_state, T.ll_dnb[llc], T.ll_dfs[llc]);
-            b.put(ll - (T.ll_val[llc] & 0xFFFFFF), T.ll_val[llc] >> 24);
-            b.put(ml - (T.ml_val[mlc] & 0xFFFFFF), T.ml_val[mlc] >> 24);
-            b.flush();
-            b.put(ob - (1u << ofc), ofc);
-            b.flush();
-            auto step = [&](uint64_t e) {
-                const uint32_t ll = (uint32_t)e & 0xFFFFF, ml = (uint32_t)(e >> 20) & 0xFFFFF, ob = (uint32_t)(e >> 40);
-                const uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
+            const uint32_t *cw = mpos + blk.seq_base;
+            uint32_t sl, sm, so;
+            {
+                const uint64_t x = sq[nseq - 1];
+                const uint32_t c = cw[nseq - 1], llc = c & 0xFF, mlc = (c >> 8) & 0xFF, ofc = c >> 16;
+                sm = zke_cinit(T.ml_state, T.ml_dnb[mlc], T.ml_dfs[mlc]);
+                so = zke_cinit(T.of_state, T.of_dnb[ofc], T.of_dfs[ofc]);
+                sl = zke_cinit(T.ll_state, T.ll_dnb[llc], T.ll_dfs[llc]);
+                b.acc |= x & 0x00FFFFFFFFFFFFFFull; b.n += (uint32_t)(x >> 56);             // <= 48 bits
+                b.flush();
+            }
+            auto step = [&](uint64_t x, uint32_t c) {
+                const uint32_t llc = c & 0xFF, mlc = (c >> 8) & 0xFF, ofc = c >> 16;
                 { uint32_t nbt = (so + T.of_dnb[ofc]) >> 16; b.put(so, nbt); so = T.of_state[(so >> nbt) + T.of_dfs[ofc]]; }
                 { uint32_t nbt = (sm + T.ml_dnb[mlc]) >> 16; b.put(sm, nbt); sm = T.ml_state[(sm >> nbt) + T.ml_dfs[mlc]]; }
                 { uint32_t nbt = (sl + T.ll_dnb[llc]) >> 16; b.put(sl, nbt); sl = T.ll_state[(sl >> nbt) + T.ll_dfs[llc]]; }
-                b.put(ll - (T.ll_val[llc] & 0xFFFFFF), T.ll_val[llc] >> 24);             // <= 17 + 16 bits since the flush
-                b.flush();
-                b.put(ml - (T.ml_val[mlc] & 0xFFFFFF), T.ml_val[mlc] >> 24);
-                b.put(ob - (1u << ofc), ofc);                                            // <= 16 + 24
+                b.flush();                                                                // <= 7 + 17 bits were waiting
+                b.acc |= (x & 0x00FFFFFFFFFFFFFFull) << b.n; b.n += (uint32_t)(x >> 56);   // <= 7 + 48
                 b.flush();
             };
             // sequences nseq - 2 .. 0, read four ahead with unconditional (clamped) loads
-            auto lds = [&](int32_t k) { return sq[k < 0 ? 0 : k]; };
+            auto ldx = [&](int32_t k) { return sq[k < 0 ? 0 : k]; };
+            auto ldc = [&](int32_t k) { return cw[k < 0 ? 0 : k]; };
             int32_t i = (int32_t)nseq - 2;
-            uint64_t e0 = lds(i), e1 = lds(i - 1), e2 = lds(i - 2), e3 = lds(i - 3);
+            uint64_t e0 = ldx(i), e1 = ldx(i - 1), e2 = ldx(i - 2), e3 = ldx(i - 3);
+            uint32_t c0 = ldc(i), c1 = ldc(i - 1), c2 = ldc(i - 2), c3 = ldc(i - 3);
             while (i >= 3) {
-                step(e0); e0 = lds(i - 4);
-                step(e1); e1 = lds(i - 5);
-                step(e2); e2 = lds(i - 6);
-                step(e3); e3 = lds(i - 7);
+                step(e0, c0); e0 = ldx(i - 4); c0 = ldc(i - 4);
+                step(e1, c1); e1 = ldx(i - 5); c1 = ldc(i - 5);
+                step(e2, c2); e2 = ldx(i - 6); c2 = ldc(i - 6);
+                step(e3, c3); e3 = ldx(i - 7); c3 = ldc(i - 7);
                 i -= 4;
             }
-            if (i >= 0) step(e0);
-            if (i >= 1) step(e1);
-            if (i >= 2) step(e2);
+            if (i >= 0) step(e0, c0);
+            if (i >= 1) step(e1, c1);
+            if (i >= 2) step(e2, c2);
             b.put(sm, 6); b.put(so, 5); b.put(sl, 6);
             sz = b.close();
         }
@@ -597,7 +649,8 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
     }
     __syncthreads();
     // write the payloads: literals section, Number_of_Sequences, modes byte, sequence bitstream
-    for (uint32_t j = 0; j < nb; j++) {
+    // one wave per block: four blocks are assembled side by side
+    for (uint32_t j = wave; j < nb; j += ZKE_ENT_THREADS / 64) {
         if (s_mode[j] != 2) continue;
         const ZkEncBlock &blk = blocks[b0 + j];
         const uint32_t nlit = blk.nlit, nseq = blk.nseq, bsz = blk.bsz;
@@ -612,7 +665,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
         if (lm == 2) {
             const uint32_t hdr = nlit < 1024 ? 3 : nlit < 16384 ? 4 : 5, tree = 1 + (s_tree[j] + 1) / 2, mb = s_maxbits[j];
             const uint32_t comp = tree + 6 + z[0] + z[1] + z[2] + z[3];
-            if (tid == 0) {
+            if (lane == 0) {
                 uint64_t h = hdr == 3 ? (2ull | (1 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 14))
                            : hdr == 4 ? (2ull | (2 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 18))
                                       : (2ull | (3 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 22));
@@ -630,11 +683,11 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             p = hdr + tree + 6;
             for (int k = 0; k < 4; k++) {
                 const uint8_t *sp = stemp + k * scap;
-                zke_copy<ZKE_ENT_THREADS>(payload + p, sp, z[k], tid);
+                zke_copy_wave(payload + p, sp, z[k], lane);
                 p += z[k];
             }
         } else {
-            if (tid == 0) {
+            if (lane == 0) {
                 const uint32_t t = lm;                             // 0 raw, 1 rle
                 if (raw_hdr == 1) payload[0] = (uint8_t)(t | (nlit << 3));
                 else if (raw_hdr == 2) { payload[0] = (uint8_t)(t | (1 << 2) | (nlit << 4)); payload[1] = (uint8_t)(nlit >> 4); }
@@ -643,18 +696,18 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             }
             p = raw_hdr;
             if (lm == 1) p += 1;
-            else { zke_copy<ZKE_ENT_THREADS>(payload + p, lt, nlit, tid); p += nlit; }
+            else { zke_copy_wave(payload + p, lt, nlit, lane); p += nlit; }
         }
-        if (tid == 0) {
+        if (lane == 0) {
             if (nseq < 128) payload[p] = (uint8_t)nseq;
             else if (nseq < 0x7F00) { payload[p] = (uint8_t)((nseq >> 8) + 128); payload[p + 1] = (uint8_t)nseq; }
             else { payload[p] = 255; payload[p + 1] = (uint8_t)(nseq - 0x7F00); payload[p + 2] = (uint8_t)((nseq - 0x7F00) >> 8); }
         }
         p += nseq < 128 ? 1 : nseq < 0x7F00 ? 2 : 3;
         if (nseq) {
-            if (tid == 0) payload[p] = 0;                          // predefined LL / OF / ML
+            if (lane == 0) payload[p] = 0;                          // predefined LL / OF / ML
             p += 1;
-            zke_copy<ZKE_ENT_THREADS>(payload + p, qtemp, z[4], tid);
+            zke_copy_wave(payload + p, qtemp, z[4], lane);
         }
     }
 }
@@ -754,10 +807,10 @@ void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *f
     hipLaunchKernelGGL(zk_k_enc_match, dim3(nframes), dim3(ZKE_THREADS), 0, st, src, frames, blocks, seqs, mpos, lits);
 }
 void zk_launch_enc_entropy(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks, uint32_t nblocks,
-                           const uint64_t *seqs, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *tabs)
+                           uint64_t *seqs, uint32_t *mpos, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *tabs)
 {
     if (!nblocks) return;
-    hipLaunchKernelGGL(zk_k_enc_entropy, dim3((nblocks + ZKE_ENT_BLOCKS - 1) / ZKE_ENT_BLOCKS), dim3(ZKE_ENT_THREADS), 0, st, src, frames, blocks, nblocks, seqs, lits, scratch, tabs);
+    hipLaunchKernelGGL(zk_k_enc_entropy, dim3((nblocks + ZKE_ENT_BLOCKS - 1) / ZKE_ENT_BLOCKS), dim3(ZKE_ENT_THREADS), 0, st, src, frames, blocks, nblocks, seqs, mpos, lits, scratch, tabs);
 }
 void zk_launch_enc_sizes(hipStream_t st, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, int checksum,
                          uint64_t *c_size64, uint32_t *c_sizes, uint32_t *d_sizes)

@@ -149,7 +149,7 @@ extern "C" int zk_encode_frames_prefix_dev(zk_engine *e, const void *d_src, uint
     }
     if (checksum) { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, (const uint64_t *)e->bases.p, 0, nf, nullptr, hashes); }
     { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (uint8_t *)e->enc_c.p); }
-    { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (const uint64_t *)e->enc_b.p, (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, dtab); }
+    { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, dtab); }
     zk_launch_enc_sizes(st, dfr, nf, dbl, checksum, c64, (uint32_t *)d_c_sizes, (uint32_t *)d_d_sizes);
     zk_launch_scan64(st, c64, nf, out_off);
     ZK_HIP(hipMemcpyAsync(e->h_words, out_off + nf, 8, hipMemcpyDeviceToHost, st));
