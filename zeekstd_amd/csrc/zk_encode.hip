@@ -557,11 +557,15 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
                     if ((t & 3) == 0) b.flush();
                 }
             };
+            // the next iteration's three words are requested before this iteration's first store and moved over after its
+            // last one: the wait for them counts exactly the 6 stores in between, never a store's acknowledgement
+            // (rotating the registers instead lets the compiler hoist a use to the loop top, behind the previous stores)
             uint64_t w0 = ldw(i), w1 = ldw(i >= 8 ? i - 8 : 0), w2 = ldw(i >= 16 ? i - 16 : 0);
+            asm volatile("" :: "v"(w0), "v"(w1), "v"(w2));                                // arrived before the loop: no pending state to merge
             while (i >= 24) {
-                word(w0); w0 = ldw(i - 24);
-                word(w1); w1 = ldw(i >= 32 ? i - 32 : 0);
-                word(w2); w2 = ldw(i >= 40 ? i - 40 : 0);
+                const uint64_t n0 = ldw(i - 24), n1 = ldw(i >= 32 ? i - 32 : 0), n2 = ldw(i >= 40 ? i - 40 : 0);
+                word(w0); word(w1); word(w2);
+                w0 = n0; w1 = n1; w2 = n2;
                 i -= 24;
             }
             if (i >= 8) word(w0);
@@ -602,11 +606,12 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             int32_t i = (int32_t)nseq - 2;
             uint64_t e0 = ldx(i), e1 = ldx(i - 1), e2 = ldx(i - 2), e3 = ldx(i - 3);
             uint32_t c0 = ldc(i), c1 = ldc(i - 1), c2 = ldc(i - 2), c3 = ldc(i - 3);
-            while (i >= 3) {
-                step(e0, c0); e0 = ldx(i - 4); c0 = ldc(i - 4);
-                step(e1, c1); e1 = ldx(i - 5); c1 = ldc(i - 5);
-                step(e2, c2); e2 = ldx(i - 6); c2 = ldc(i - 6);
-                step(e3, c3); e3 = ldx(i - 7); c3 = ldc(i - 7);
+            asm volatile("" :: "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
+            while (i >= 3) {                                                              // same scheme as the literal streams
+                const uint64_t n0 = ldx(i - 4), n1 = ldx(i - 5), n2 = ldx(i - 6), n3 = ldx(i - 7);
+                const uint32_t d0 = ldc(i - 4), d1 = ldc(i - 5), d2 = ldc(i - 6), d3 = ldc(i - 7);
+                step(e0, c0); step(e1, c1); step(e2, c2); step(e3, c3);
+                e0 = n0; e1 = n1; e2 = n2; e3 = n3; c0 = d0; c1 = d1; c2 = d2; c3 = d3;
                 i -= 4;
             }
             if (i >= 0) step(e0, c0);
