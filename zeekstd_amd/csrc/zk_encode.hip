@@ -494,23 +494,30 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             uint64_t *sq = seqs + blk.seq_base;
             uint32_t *cw = mpos + blk.seq_base;
             const uint32_t nseq = blk.nseq, T3 = ZKE_ENT_THREADS - 64;
-            for (uint32_t i = tid - 64; i < nseq; i += 4 * T3) {
-                uint64_t e[4];
+            // four sequences per lane and pass; the next pass's records are requested before this pass's stores, and every
+            // store is unconditional (a lane without a sequence rewrites its first one), so no wait ever covers a store
+            auto ldq = [&](uint32_t i, int u) { const uint32_t k = i + u * T3; return sq[k < nseq ? k : (i < nseq ? i : 0)]; };
+            uint64_t e[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { const uint32_t k = i + u * T3; e[u] = sq[k < nseq ? k : i]; }
+            for (int u = 0; u < 4; u++) e[u] = nseq ? ldq(tid - 64, u) : 0;
+            asm volatile("" :: "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]));
+            for (uint32_t i = tid - 64; i < nseq; i += 4 * T3) {
+                uint64_t n[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) n[u] = ldq(i + 4 * T3, u);
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const uint32_t k = i + u * T3;
-                    if (k < nseq) {
-                        const uint32_t ll = (uint32_t)e[u] & 0xFFFFF, ml = (uint32_t)(e[u] >> 20) & 0xFFFFF, ob = (uint32_t)(e[u] >> 40);
-                        const uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
-                        const uint32_t lv = T.ll_val[llc], mv = T.ml_val[mlc];
-                        const uint32_t ln = lv >> 24, mn = mv >> 24;
-                        const uint64_t x = (uint64_t)(ll - (lv & 0xFFFFFF)) | ((uint64_t)(ml - (mv & 0xFFFFFF)) << ln) | ((uint64_t)(ob - (1u << ofc)) << (ln + mn));
-                        sq[k] = x | ((uint64_t)(ln + mn + ofc) << 56);
-                        cw[k] = llc | (mlc << 8) | (ofc << 16);
-                    }
+                    const uint32_t k = i + u * T3 < nseq ? i + u * T3 : i;
+                    const uint32_t ll = (uint32_t)e[u] & 0xFFFFF, ml = (uint32_t)(e[u] >> 20) & 0xFFFFF, ob = (uint32_t)(e[u] >> 40);
+                    const uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
+                    const uint32_t lv = T.ll_val[llc], mv = T.ml_val[mlc];
+                    const uint32_t ln = lv >> 24, mn = mv >> 24;
+                    const uint64_t x = (uint64_t)(ll - (lv & 0xFFFFFF)) | ((uint64_t)(ml - (mv & 0xFFFFFF)) << ln) | ((uint64_t)(ob - (1u << ofc)) << (ln + mn));
+                    sq[k] = x | ((uint64_t)(ln + mn + ofc) << 56);
+                    cw[k] = llc | (mlc << 8) | (ofc << 16);
                 }
+#pragma unroll
+                for (int u = 0; u < 4; u++) e[u] = n[u];
             }
         }
     }
