@@ -71,6 +71,10 @@ const char *zk_engine_device_name(const zk_engine *e);
  * bracketed by HIP events on the launch stream; zk_engine_kernel_times returns the last call's
  * durations in ms, indexed like zk_engine_kernel_name (0 <= k < zk_engine_kernel_count()). */
 int zk_engine_set_profiling(zk_engine *e, int on);
+/* Kernel selection of the sequence decoder for blocks that carry their own FSE tables (archives written by libzstd):
+ * 0 = by batch size (default), 1 = one lane per block (zk_k_fse), 2 = a quad of lanes per block (zk_k_fse_quad).
+ * Results are identical; the tests use it to run both kernels on small inputs. */
+int zk_engine_set_fse_kernel(zk_engine *e, int mode);
 int zk_engine_kernel_count(void);
 const char *zk_engine_kernel_name(int k);
 int zk_engine_kernel_times(const zk_engine *e, float *ms_out, int n);

@@ -116,6 +116,43 @@ def test_live_libzstd_archives(engine, level, fs, cks):
     assert not st.any() and out == data
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_both_sequence_kernels_on_every_golden(engine, mode):
+    """Blocks with their own FSE tables have two kernels (one lane per block / a quad of lanes per block, picked by
+    batch size): each is forced over every golden archive, the prefix archives, corrupted frames and a live archive."""
+    engine.set_fse_kernel(mode)
+    try:
+        for g in GOLDENS:
+            c, d = g.offsets()
+            out, st = engine.decode_frames(g.comp + b"\0" * 8, c, d, verify=True)
+            assert not st.any() and out == g.input(), g.name
+        for g in PREFIX_GOLDENS:
+            c, d = g.offsets()
+            out, st = engine.decode_frames(g.comp + b"\0" * 8, c, d, verify=True, prefix=g.prefix())
+            assert not st.any() and out == g.input(), g.name
+        g = next(x for x in GOLDENS if x.name == "text_l1_64k")
+        c, d = g.offsets()
+        data = g.input()
+        rng = np.random.default_rng(5 + mode)
+        for _ in range(40):
+            comp = bytearray(g.comp)
+            comp[int(rng.integers(0, len(comp)))] ^= 1 << int(rng.integers(0, 8))
+            out, st = engine.decode_frames(bytes(comp) + b"\0" * 8, c, d, verify=True, raise_on_error=False)
+            for f in range(len(g.frames)):
+                if st[f] == 0:
+                    assert out[int(d[f]):int(d[f + 1])] == data[int(d[f]):int(d[f + 1])]
+        if Z.load("system") is not None:
+            n = (9 << 20) + 4321
+            data = zko.make_input([["chunks", n // 2, 3], ["text", n - n // 2, 4]])
+            for level in (1, 3):
+                comp, frames = Z.encode_seekable_frames(data, 1 << 20, level, True, "system")
+                c, d = offsets_from_frames(frames)
+                out, st = engine.decode_frames(comp + b"\0" * 8, c, d, verify=True)
+                assert not st.any() and out == data
+    finally:
+        engine.set_fse_kernel(0)
+
+
 @pytest.mark.skipif(Z.load("system") is None, reason="no system libzstd on this box")
 def test_baseline_config_2_decode_only(engine):
     """BASELINE.json configs[1] at reduced size (32 MiB of the 256 MiB): 2 MiB frames, level 1, decode-only,

@@ -274,6 +274,158 @@ __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *com
     o->status = b.status;
 }
 
+// ---- three lanes per block ------------------------------------------------------------------------------------
+// zk_k_fse spends a full wave instruction per step of each of a block's three state machines although only 7 lanes of
+// the wave hold a block: the kernel is VALU bound with 11 % of the lanes doing anything.  Here a block takes a QUAD of
+// lanes: lane 0 walks the literal-length table, lane 1 the offset table, lane 2 the match-length table (lane 3 is
+// idle).  Each lane decodes one cell, the three (value bits, state bits) pairs are exchanged inside the quad with DPP
+// quad_perm moves (no LDS, no latency to speak of), every lane shifts the shared 64-bit window to its own two fields,
+// and the three values are exchanged again so that all lanes keep the repeat-offset history and the running sums in
+// step.  The step costs ~110 wave instructions instead of ~250.  Same LDS tables, same records, same results.
+__device__ __forceinline__ uint32_t zk_quad_bcast(uint32_t v, int k)            // value of quad lane k in every lane of the quad
+{
+    return k == 0 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, true)
+         : k == 1 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xF, 0xF, true)
+                  : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA, 0xF, 0xF, true);
+}
+
+// t = the lane's table (ZK_TAB_LL / ZK_TAB_OF / ZK_TAB_ML = its position in the quad); cells / vt: that table's cells
+// and value table (offsets: entries k << 24, the baseline 1 << k is formed here); al[3]: accuracy logs (LL, OF, ML).
+// All three lanes return the same b (out_size, rep_out, status); lane ZK_TAB_LL owns the ring.
+template <typename RD, typename CP>
+__device__ __forceinline__ void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, uint32_t t,
+                                                 const typename CP::cell_t *cells, const uint32_t *vt, const uint32_t *al,
+                                                 ZkSeq *ring, ZkSeq *seqs)
+{
+    RD r;
+    uint32_t bad = 0;
+    const bool ok = bs_off < b.bsize && r.init(comp + b.src + bs_off, b.bsize - bs_off);
+    if (!ok) { b.status = ZK_E_CORRUPTION; return; }
+    const uint32_t nseq = b.nseq;
+    uint32_t state;
+    {
+        const uint32_t s0 = r.read(al[0]), s1 = r.read(al[1]), s2 = r.read(al[2]);
+        bad |= r.remaining() < 0; r.clamp();
+        state = t == ZK_TAB_LL ? s0 : t == ZK_TAB_OF ? s1 : s2;
+    }
+    // where the lane's fields start: value bits come OF, ML, LL; state bits LL, ML, OF
+    const uint32_t kOfV = t == ZK_TAB_OF ? 0u : 0xFFu;              // OF value bits precede ML's and LL's
+    const uint32_t kMlV = t == ZK_TAB_LL ? 0xFFu : 0u;              // ML value bits precede LL's
+    const uint32_t kLlS = t == ZK_TAB_LL ? 0u : 0xFFu;              // LL state bits precede ML's and OF's
+    const uint32_t kMlS = t == ZK_TAB_OF ? 0xFFu : 0u;              // ML state bits precede OF's
+    uint32_t rep0 = zk_rep_sym(0), rep1 = zk_rep_sym(1), rep2 = zk_rep_sym(2);
+    uint32_t out = 0, lit = 0;
+    typename CP::cell_t c = cells[state];
+    for (uint32_t g0 = 0; g0 < nseq; g0 += 16) {
+        const uint32_t gend = g0 + 16 < nseq ? g0 + 16 : nseq;
+        for (uint32_t i = g0; i < gend; i++) {
+            const uint32_t vv = vt[CP::sym(c)];
+            const uint32_t xb = vv >> 24;
+            const uint32_t nb = i + 1 < nseq ? CP::nb(c) : 0;
+            const uint32_t pk = xb | (nb << 8);
+            const uint32_t pL = zk_quad_bcast(pk, ZK_TAB_LL), pO = zk_quad_bcast(pk, ZK_TAB_OF), pM = zk_quad_bcast(pk, ZK_TAB_ML);
+            const uint32_t sum = pL + pO + pM;                      // value bits in the low byte (<= 63), state bits above (<= 27)
+            const uint32_t nval = sum & 0xFF, total = nval + (sum >> 8);
+            const uint32_t voff = (pO & kOfV) + (pM & kMlV);
+            const uint32_t soff = nval + ((pL >> 8) & kLlS) + ((pM >> 8) & kMlS);
+            bad |= (pO & 0xFF) > 30;
+            uint32_t vbits, sbits;
+            if (total <= r.avail()) {
+                const uint64_t X = r.window();
+                r.consume(total);
+                sbits = zk_top_bits((uint32_t)((X << (soff & 63)) >> 32), nb);
+                vbits = zk_top_bits((uint32_t)((X << (voff & 63)) >> 32), xb & 31);
+            } else {                                                // more bits than one window guarantees: field by field
+                const uint32_t ofx = r.read(pO & 31), mlx = r.read(pM & 0xFF), llx = r.read(pL & 0xFF);
+                const uint32_t sL = r.read(pL >> 8), sM = r.read(pM >> 8), sO = r.read(pO >> 8);
+                bad |= r.remaining() < 0;
+                r.clamp();
+                vbits = t == ZK_TAB_LL ? llx : t == ZK_TAB_OF ? ofx : mlx;
+                sbits = t == ZK_TAB_LL ? sL : t == ZK_TAB_OF ? sO : sM;
+            }
+            state = CP::base(c) + sbits;
+            c = cells[state];                                       // issued early; used by the next step
+            const uint32_t val = (t == ZK_TAB_OF ? 1u << (xb & 31) : vv & 0xFFFFFFu) + vbits;
+            const uint32_t ll = zk_quad_bcast(val, ZK_TAB_LL), ofv = zk_quad_bcast(val, ZK_TAB_OF), ml = zk_quad_bcast(val, ZK_TAB_ML);
+            // offset + repeat history, select form (A.8) -- as zk_seq_walk
+            const bool is_rep = ofv <= 3;
+            const uint32_t idx = ofv - 1 + (ll == 0);
+            const uint32_t r0m1 = zk_rep_is_sym(rep0) ? rep0 + 1 : rep0 - 1;
+            const uint32_t cand = idx == 0 ? rep0 : idx == 1 ? rep1 : idx == 2 ? rep2 : r0m1;
+            const uint32_t off = is_rep ? cand : ofv - 3;
+            bad |= off == 0;
+            const bool sh1 = !is_rep || idx >= 1, sh2 = !is_rep || idx >= 2;
+            rep2 = sh2 ? rep1 : rep2;
+            rep1 = sh1 ? rep0 : rep1;
+            rep0 = off;
+            lit += ll; out += ll + ml;
+            bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX);
+            if (t == ZK_TAB_LL) { ZkSeq q; q.out_end = out; q.ml = ml; q.off = off; q.lit_end = lit; ring[i & 15] = q; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the quad's three lanes share the stores of the group's records
+        for (uint32_t k = g0 + t; k < gend; k += 3) {
+            const volatile uint32_t *w = reinterpret_cast<const volatile uint32_t *>(&ring[k & 15]);
+            reinterpret_cast<uint4 *>(seqs)[k] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    bad |= r.remaining() != 0;
+    if (bad) { b.status = ZK_E_CORRUPTION; return; }
+    out += b.lit_regen - lit;
+    if (out > ZK_BLOCK_MAX) { b.status = ZK_E_CORRUPTION; return; }
+    b.out_size = out;
+    b.rep_out[0] = rep0; b.rep_out[1] = rep1; b.rep_out[2] = rep2;
+}
+
+template <typename CP, int ZK_FSE_BLOCKS, int ZK_FSE_WAVES>
+__global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse_quad(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
+{
+    constexpr int PER_WAVE = ZK_FSE_BLOCKS / ZK_FSE_WAVES;
+    static_assert(PER_WAVE * 4 <= 64, "a quad of lanes per block");
+    __shared__ ZkSeqTablesT<CP> T[ZK_FSE_BLOCKS];
+    __shared__ uint32_t llv[36], mlv[53], ofv[32];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const uint32_t ll_init[36] = ZK_LL_TABLE;
+        const uint32_t ml_init[53] = ZK_ML_TABLE;
+        if (tid < 36) llv[tid] = ll_init[tid];
+        if (tid < 53) mlv[tid] = ml_init[tid];
+        if (tid < 32) ofv[tid] = tid << 24;
+    }
+    __syncthreads();
+    const uint32_t t = lane & 3;
+    if (lane >= 4 * PER_WAVE || t == 3) return;
+    const uint32_t slot = wave * PER_WAVE + (lane >> 2);
+    const uint32_t bi = blockIdx.x * ZK_FSE_BLOCKS + slot;
+    if (bi >= nblocks) return;
+    ZkBlock b = blocks[bi];
+    if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK || b.seq_modes == 0) return;      // all-predefined blocks: zk_k_fse_predef
+    // the three lanes build the block's tables together (identical LDS writes: more active lanes, see above)
+    ZkSeqTablesT<CP> *Tb = &T[slot];
+    uint32_t al[3], own = 0;
+    bool ok = true;
+    for (int u = 0; u < 3; u++) {
+        const uint32_t m = (b.seq_modes >> (6 - 2 * u)) & 3;
+        const ZkBlock &def = m == 3 ? blocks[b.tab_def[u]] : b;
+        const int32_t r = zk_seq_table_setup<CP>(comp, def, u, Tb, &al[u], llv, mlv);
+        if (r < 0) { ok = false; break; }
+        if (m != 3) own += (uint32_t)r;
+    }
+    if (!ok) b.status = ZK_E_CORRUPTION;
+    else {
+        __builtin_amdgcn_wave_barrier();
+        zk_seq_walk_quad<ZkRevU, CP>(comp, b, b.seq_off + 1 + own, t,
+                             t == ZK_TAB_LL ? Tb->ll : t == ZK_TAB_OF ? Tb->of : Tb->ml,
+                             t == ZK_TAB_LL ? llv : t == ZK_TAB_OF ? ofv : mlv, al, Tb->ring, seqs + b.seq_base);
+    }
+    if (t != ZK_TAB_LL) return;
+    ZkBlock *o = &blocks[bi];
+    o->out_size = b.out_size;
+    o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
+    o->status = b.status;
+}
+
 // Blocks whose three tables are all Predefined_Mode (Symbol_Compression_Modes == 0: what this engine's own
 // encoder emits, and libzstd for small blocks) need no per-block tables: one copy of the predefined tables per
 // workgroup, one block per LANE, full waves.  All 64 lanes walk in lock step so that the 16-B records can be
@@ -645,7 +797,7 @@ void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     if (!nblocks) return;
     hipLaunchKernelGGL(zk_k_huf, dim3((nblocks + ZK_HUF_BLOCKS - 1) / ZK_HUF_BLOCKS), dim3(128), 0, st, comp, blocks, nblocks, lit);
 }
-void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeq *seqs)
+void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeq *seqs, int own_kernel)
 {
     if (!nblocks) return;
     // reader choice (zk_device.h): with >= 6 workgroups per CU the memory pipeline is the limit (aligned words, each
@@ -656,9 +808,14 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
         if (wgs >= 6 * 256) hipLaunchKernelGGL(zk_k_fse_predef_fed, dim3(wgs), dim3(2 * ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
         else hipLaunchKernelGGL(zk_k_fse_predef<ZkRevU>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
     }
-    // blocks with their own tables (every block is visited, the others return at once): cell format by how many
-    // rounds the 32-bit layout would need
-    if (n_own_tables > 28u * 256u) hipLaunchKernelGGL((zk_k_fse<ZkCells16, 56, 8>), dim3((nblocks + 55) / 56), dim3(512), 0, st, comp, blocks, nblocks, seqs);
+    // blocks with their own tables (every block is visited, the others return at once).  Up to one round of the 32-bit
+    // layout (28 blocks per CU) a block's chain latency is all that counts: one lane per block, fewest dependent steps
+    // (measured, 2048 blocks: 3.67 ms per step against 3.91 with quads).  Beyond that the 16-bit cells (56 blocks per CU)
+    // and a quad of lanes per block: 32768 blocks 20.6 -> 16.5 ms.  own_kernel: zk_engine_set_fse_kernel.
+    if (!n_own_tables) return;
+    if (own_kernel == 2) { hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 8>), dim3((nblocks + 55) / 56), dim3(512), 0, st, comp, blocks, nblocks, seqs); return; }
+    if (own_kernel == 1) { hipLaunchKernelGGL((zk_k_fse<ZkCells16, 56, 8>), dim3((nblocks + 55) / 56), dim3(512), 0, st, comp, blocks, nblocks, seqs); return; }
+    if (n_own_tables > 28u * 256u) hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 8>), dim3((nblocks + 55) / 56), dim3(512), 0, st, comp, blocks, nblocks, seqs);
     else if (n_own_tables) hipLaunchKernelGGL((zk_k_fse<ZkCells32, 28, 4>), dim3((nblocks + 27) / 28), dim3(256), 0, st, comp, blocks, nblocks, seqs);
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,

@@ -34,6 +34,7 @@ struct zk_engine {
     const void *st_prefix_src = nullptr; uint64_t st_prefix_len = 0, st_prefix_fp = 0;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool profiling = false;
+    int fse_kernel = 0;              // zk_engine_set_fse_kernel
     hipEvent_t ev_start[ZK_NKERNELS] = {}, ev_stop[ZK_NKERNELS] = {};
     bool ev_used[ZK_NKERNELS] = {};
     float kernel_ms[ZK_NKERNELS] = {};

@@ -53,6 +53,12 @@ extern "C" int zk_engine_set_profiling(zk_engine *e, int on)
     e->profiling = on != 0;
     return 0;
 }
+extern "C" int zk_engine_set_fse_kernel(zk_engine *e, int mode)
+{
+    if (!e || mode < 0 || mode > 2) return ZK_ERR_ARGUMENT;
+    e->fse_kernel = mode;
+    return 0;
+}
 extern "C" int zk_engine_kernel_count(void) { return ZK_NKERNELS; }
 extern "C" const char *zk_engine_kernel_name(int k)
 {
@@ -207,13 +213,13 @@ static int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const void *d_comp, co
     // with per-kernel timing on they are serialised instead
     if (e->profiling) {
         { zk_kernel_timer t(e, ZK_K_HUF, st); zk_launch_huf(st, comp, blocks, (uint32_t)nblocks, lit); }
-        { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs); }
+        { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->fse_kernel); }
     } else {
         ZK_HIP(hipEventRecord(c.ev_fork, st));
         ZK_HIP(hipStreamWaitEvent(c.aux, c.ev_fork, 0));
         zk_launch_huf(c.aux, comp, blocks, (uint32_t)nblocks, lit);
         ZK_HIP(hipEventRecord(c.ev_join, c.aux));
-        zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs);
+        zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->fse_kernel);
         ZK_HIP(hipStreamWaitEvent(st, c.ev_join, 0));
     }
     { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, ids, out_off, blocks, bases, infos, seqs, lit, (uint8_t *)d_dst, (const uint8_t *)d_prefix, d_prefix ? prefix_len : 0); }

@@ -48,6 +48,12 @@ class Engine:
         if rc != 0:
             self._raise(rc)
 
+    def set_fse_kernel(self, mode: int):
+        """0 = by batch size, 1 = one lane per block, 2 = a quad of lanes per block (own-table blocks; same results)."""
+        rc = lib.zk_engine_set_fse_kernel(self._h, int(mode))
+        if rc != 0:
+            self._raise(rc)
+
     def kernel_times(self):
         """{kernel name: ms} of the last decode/encode call (profiling must be on)."""
         n = lib.zk_engine_kernel_count()
