@@ -295,7 +295,7 @@ __device__ __forceinline__ uint32_t zk_quad_bcast(uint32_t v, int k)            
 template <typename RD, typename CP>
 __device__ __forceinline__ void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, uint32_t t,
                                                  const typename CP::cell_t *cells, const uint32_t *vt, const uint32_t *al,
-                                                 ZkSeq *ring, ZkSeq *seqs)
+                                                 ZkSeq *ring, ZkSeq *seqs, volatile uint32_t *pos_pub)
 {
     RD r;
     uint32_t bad = 0;
@@ -316,8 +316,10 @@ __device__ __forceinline__ void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b
     uint32_t rep0 = zk_rep_sym(0), rep1 = zk_rep_sym(1), rep2 = zk_rep_sym(2);
     uint32_t out = 0, lit = 0;
     typename CP::cell_t c = cells[state];
+    asm volatile("" :: "v"((uint32_t)c));                      // arrived before the loop: its waits then only count what the loop issues
     for (uint32_t g0 = 0; g0 < nseq; g0 += 16) {
         const uint32_t gend = g0 + 16 < nseq ? g0 + 16 : nseq;
+        if (t == ZK_TAB_LL) *pos_pub = b.src + bs_off + (uint32_t)(r.remaining() >> 3);       // for the toucher wave (zk_k_fse_quad)
         for (uint32_t i = g0; i < gend; i++) {
             const uint32_t vv = vt[CP::sym(c)];
             const uint32_t xb = vv >> 24;
@@ -351,16 +353,18 @@ __device__ __forceinline__ void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b
             const bool is_rep = ofv <= 3;
             const uint32_t idx = ofv - 1 + (ll == 0);
             const uint32_t r0m1 = zk_rep_is_sym(rep0) ? rep0 + 1 : rep0 - 1;
-            const uint32_t cand = idx == 0 ? rep0 : idx == 1 ? rep1 : idx == 2 ? rep2 : r0m1;
+            uint32_t cand = idx == 0 ? rep0 : rep1;                 // plain selects: no control flow in the step
+            cand = idx == 2 ? rep2 : cand;
+            cand = idx == 3 ? r0m1 : cand;
             const uint32_t off = is_rep ? cand : ofv - 3;
             bad |= off == 0;
-            const bool sh1 = !is_rep || idx >= 1, sh2 = !is_rep || idx >= 2;
+            const bool sh1 = (!is_rep) | (idx >= 1), sh2 = (!is_rep) | (idx >= 2);
             rep2 = sh2 ? rep1 : rep2;
             rep1 = sh1 ? rep0 : rep1;
             rep0 = off;
             lit += ll; out += ll + ml;
             bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX);
-            if (t == ZK_TAB_LL) { ZkSeq q; q.out_end = out; q.ml = ml; q.off = off; q.lit_end = lit; ring[i & 15] = q; }
+            { ZkSeq q; q.out_end = out; q.ml = ml; q.off = off; q.lit_end = lit; ring[i & 15] = q; }     // all three lanes, same bytes: an unconditional write keeps the next step's wait for its cell from covering this store
         }
         __builtin_amdgcn_wave_barrier();
         // the quad's three lanes share the stores of the group's records
@@ -378,13 +382,18 @@ __device__ __forceinline__ void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b
     b.rep_out[0] = rep0; b.rep_out[1] = rep1; b.rep_out[2] = rep2;
 }
 
+// One more wave per workgroup keeps the bitstreams warm: a wave waits for its loads in order, and with 14 streams per
+// wave some lane crosses into a new cache line at almost every step -- without help every other step of the whole wave
+// waits for an L2 round trip.  The walkers publish their stream position once per 16 sequences; the toucher wave (its
+// own load counter, results never used) requests the two lines below it.
 template <typename CP, int ZK_FSE_BLOCKS, int ZK_FSE_WAVES>
-__global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse_quad(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
+__global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
 {
     constexpr int PER_WAVE = ZK_FSE_BLOCKS / ZK_FSE_WAVES;
-    static_assert(PER_WAVE * 4 <= 64, "a quad of lanes per block");
+    static_assert(PER_WAVE * 4 <= 64 && ZK_FSE_BLOCKS <= 64, "a quad of lanes per block; a toucher lane per block");
     __shared__ ZkSeqTablesT<CP> T[ZK_FSE_BLOCKS];
     __shared__ uint32_t llv[36], mlv[53], ofv[32];
+    __shared__ uint32_t s_pos[ZK_FSE_BLOCKS], s_live;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
         const uint32_t ll_init[36] = ZK_LL_TABLE;
@@ -392,15 +401,41 @@ __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse_quad(const uint8_t
         if (tid < 36) llv[tid] = ll_init[tid];
         if (tid < 53) mlv[tid] = ml_init[tid];
         if (tid < 32) ofv[tid] = tid << 24;
+        if (tid < (uint32_t)ZK_FSE_BLOCKS) s_pos[tid] = 0;
+        if (tid == 0) s_live = 0;
     }
     __syncthreads();
+    const bool toucher = wave == (uint32_t)ZK_FSE_WAVES;
     const uint32_t t = lane & 3;
-    if (lane >= 4 * PER_WAVE || t == 3) return;
-    const uint32_t slot = wave * PER_WAVE + (lane >> 2);
+    const uint32_t slot = toucher ? lane : wave * PER_WAVE + (lane >> 2);
     const uint32_t bi = blockIdx.x * ZK_FSE_BLOCKS + slot;
-    if (bi >= nblocks) return;
-    ZkBlock b = blocks[bi];
-    if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK || b.seq_modes == 0) return;      // all-predefined blocks: zk_k_fse_predef
+    ZkBlock b;
+    bool valid = toucher ? lane < (uint32_t)ZK_FSE_BLOCKS : (lane < 4 * PER_WAVE && t != 3);
+    valid = valid && bi < nblocks;
+    if (valid) {
+        b = blocks[bi];
+        valid = b.type == 2 && b.nseq != 0 && b.status == ZK_OK && b.seq_modes != 0;       // all-predefined blocks: zk_k_fse_predef
+    }
+    if (valid && !toucher && t == ZK_TAB_LL) atomicAdd(&s_live, 1u);
+    __syncthreads();
+    if (!valid) return;
+    if (toucher) {
+        volatile uint32_t *live = &s_live, *pp = &s_pos[slot];
+        uint32_t last = 0, sink = 0;
+        while (*live) {
+            const uint32_t p = *pp;
+            if (p != last) {
+                last = p;
+                const uint32_t lo = b.src + b.seq_off;                  // nothing of the stream lies below the sequence header
+                const uint8_t *a0 = comp + (p > lo + 128 ? p - 128 : lo), *a1 = comp + (p > lo + 256 ? p - 256 : lo);
+                asm volatile("global_load_ubyte %0, %1, off" : "+v"(sink) : "v"(a0) : "memory");
+                asm volatile("global_load_ubyte %0, %1, off" : "+v"(sink) : "v"(a1) : "memory");
+            } else __builtin_amdgcn_s_sleep(2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" :: "v"(sink));
+        return;
+    }
     // the three lanes build the block's tables together (identical LDS writes: more active lanes, see above)
     ZkSeqTablesT<CP> *Tb = &T[slot];
     uint32_t al[3], own = 0;
@@ -416,10 +451,11 @@ __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse_quad(const uint8_t
     else {
         __builtin_amdgcn_wave_barrier();
         zk_seq_walk_quad<ZkRevU, CP>(comp, b, b.seq_off + 1 + own, t,
-                             t == ZK_TAB_LL ? Tb->ll : t == ZK_TAB_OF ? Tb->of : Tb->ml,
-                             t == ZK_TAB_LL ? llv : t == ZK_TAB_OF ? ofv : mlv, al, Tb->ring, seqs + b.seq_base);
+                                     t == ZK_TAB_LL ? Tb->ll : t == ZK_TAB_OF ? Tb->of : Tb->ml,
+                                     t == ZK_TAB_LL ? llv : t == ZK_TAB_OF ? ofv : mlv, al, Tb->ring, seqs + b.seq_base, &s_pos[slot]);
     }
     if (t != ZK_TAB_LL) return;
+    atomicSub(&s_live, 1u);
     ZkBlock *o = &blocks[bi];
     o->out_size = b.out_size;
     o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
@@ -813,9 +849,9 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     // (measured, 2048 blocks: 3.67 ms per step against 3.91 with quads).  Beyond that the 16-bit cells (56 blocks per CU)
     // and a quad of lanes per block: 32768 blocks 20.6 -> 16.5 ms.  own_kernel: zk_engine_set_fse_kernel.
     if (!n_own_tables) return;
-    if (own_kernel == 2) { hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 8>), dim3((nblocks + 55) / 56), dim3(512), 0, st, comp, blocks, nblocks, seqs); return; }
+    if (own_kernel == 2) { hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 4>), dim3((nblocks + 55) / 56), dim3(320), 0, st, comp, blocks, nblocks, seqs); return; }
     if (own_kernel == 1) { hipLaunchKernelGGL((zk_k_fse<ZkCells16, 56, 8>), dim3((nblocks + 55) / 56), dim3(512), 0, st, comp, blocks, nblocks, seqs); return; }
-    if (n_own_tables > 28u * 256u) hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 8>), dim3((nblocks + 55) / 56), dim3(512), 0, st, comp, blocks, nblocks, seqs);
+    if (n_own_tables > 28u * 256u) hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 4>), dim3((nblocks + 55) / 56), dim3(320), 0, st, comp, blocks, nblocks, seqs);
     else if (n_own_tables) hipLaunchKernelGGL((zk_k_fse<ZkCells32, 28, 4>), dim3((nblocks + 27) / 28), dim3(256), 0, st, comp, blocks, nblocks, seqs);
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
