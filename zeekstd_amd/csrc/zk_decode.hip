@@ -315,6 +315,7 @@ __device__ __forceinline__ void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b
     const uint32_t kMlS = t == ZK_TAB_OF ? 0xFFu : 0u;              // ML state bits precede OF's
     uint32_t rep0 = zk_rep_sym(0), rep1 = zk_rep_sym(1), rep2 = zk_rep_sym(2);
     uint32_t out = 0, lit = 0;
+    ZkSeq qp; qp.out_end = 0; qp.ml = 0; qp.off = 0; qp.lit_end = 0;
     typename CP::cell_t c = cells[state];
     asm volatile("" :: "v"((uint32_t)c));                      // arrived before the loop: its waits then only count what the loop issues
     for (uint32_t g0 = 0; g0 < nseq; g0 += 16) {
@@ -322,6 +323,10 @@ __device__ __forceinline__ void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b
         if (t == ZK_TAB_LL) *pos_pub = b.src + bs_off + (uint32_t)(r.remaining() >> 3);       // for the toucher wave (zk_k_fse_quad)
         for (uint32_t i = g0; i < gend; i++) {
             const uint32_t vv = vt[CP::sym(c)];
+            // the previous step's record goes to the ring now, behind this step's first LDS read (all three lanes, same
+            // bytes, unconditional; the very first write of a group repeats a record that is already there): at the end
+            // of its own step it would sit between the cell read and the next step's wait for it
+            ring[(i - 1) & 15] = qp;
             const uint32_t xb = vv >> 24;
             const uint32_t nb = i + 1 < nseq ? CP::nb(c) : 0;
             const uint32_t pk = xb | (nb << 8);
@@ -364,8 +369,9 @@ __device__ __forceinline__ void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b
             rep0 = off;
             lit += ll; out += ll + ml;
             bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX);
-            { ZkSeq q; q.out_end = out; q.ml = ml; q.off = off; q.lit_end = lit; ring[i & 15] = q; }     // all three lanes, same bytes: an unconditional write keeps the next step's wait for its cell from covering this store
+            qp.out_end = out; qp.ml = ml; qp.off = off; qp.lit_end = lit;
         }
+        ring[(gend - 1) & 15] = qp;
         __builtin_amdgcn_wave_barrier();
         // the quad's three lanes share the stores of the group's records
         for (uint32_t k = g0 + t; k < gend; k += 3) {
@@ -844,15 +850,18 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
         if (wgs >= 6 * 256) hipLaunchKernelGGL(zk_k_fse_predef_fed, dim3(wgs), dim3(2 * ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
         else hipLaunchKernelGGL(zk_k_fse_predef<ZkRevU>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
     }
-    // blocks with their own tables (every block is visited, the others return at once).  Up to one round of the 32-bit
-    // layout (28 blocks per CU) a block's chain latency is all that counts: one lane per block, fewest dependent steps
-    // (measured, 2048 blocks: 3.67 ms per step against 3.91 with quads).  Beyond that the 16-bit cells (56 blocks per CU)
-    // and a quad of lanes per block: 32768 blocks 20.6 -> 16.5 ms.  own_kernel: zk_engine_set_fse_kernel.
+    // blocks with their own tables (every block is visited, the others return at once): a quad of lanes per block.
+    // While everything fits in one round, small workgroups (16 blocks, one walking wave + the toucher: 45 KiB of LDS,
+    // three per CU) spread the blocks over the CUs and a block's chain latency is all that counts (measured, 2048
+    // blocks of ~10 k sequences: 4.13 ms; 56-block workgroups 4.41; one lane per block 4.57).  Beyond that, 56 blocks
+    // per CU on four waves (32768 blocks: 20.6 ms with one lane per block, 13.2 with quads).
+    // own_kernel: zk_engine_set_fse_kernel (1 = the lane-per-block kernel, 2 = quads in the large layout).
     if (!n_own_tables) return;
-    if (own_kernel == 2) { hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 4>), dim3((nblocks + 55) / 56), dim3(320), 0, st, comp, blocks, nblocks, seqs); return; }
     if (own_kernel == 1) { hipLaunchKernelGGL((zk_k_fse<ZkCells16, 56, 8>), dim3((nblocks + 55) / 56), dim3(512), 0, st, comp, blocks, nblocks, seqs); return; }
-    if (n_own_tables > 28u * 256u) hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 4>), dim3((nblocks + 55) / 56), dim3(320), 0, st, comp, blocks, nblocks, seqs);
-    else if (n_own_tables) hipLaunchKernelGGL((zk_k_fse<ZkCells32, 28, 4>), dim3((nblocks + 27) / 28), dim3(256), 0, st, comp, blocks, nblocks, seqs);
+    if (own_kernel != 2 && n_own_tables <= 48u * 256u)
+        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 16, 1>), dim3((nblocks + 15) / 16), dim3(128), 0, st, comp, blocks, nblocks, seqs);
+    else
+        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 4>), dim3((nblocks + 55) / 56), dim3(320), 0, st, comp, blocks, nblocks, seqs);
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeq *seqs,
