@@ -11,7 +11,9 @@
 //                      wave 1: companion lanes (touch the stream ahead, store the decoded packs) -> literal scratch
 //   zk_k_fse_predef    blocks with predefined tables: one lane per block, 64 blocks per wave in lock step, shared
 //                      tables, cooperative 64-B record stores -> ZkSeq[] (+ out_size, symbolic reps)
-//   zk_k_fse           blocks with their own tables: one lane per block, FSE tables in LDS, 3-state walk -> ZkSeq[]
+//   zk_k_fse_quad      blocks with their own tables: FSE tables in LDS, a quad of lanes per block (one lane per state
+//                      machine, DPP exchanges), a toucher wave for the bitstreams -> ZkSeq[]
+//   zk_k_fse           the same with one lane per block (the form the CPU simulation of tests/sim mirrors; selectable)
 //   zk_k_exec          one workgroup per frame: byte-parallel sequence execution through a per-byte source map,
 //                      coalesced 16 B stores; optional raw-content prefix before the frame
 //   zk_k_xxh64         one wave per frame (4 accumulator chains), verifies Content_Checksum
