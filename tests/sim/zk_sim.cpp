@@ -7,11 +7,80 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <ucontext.h>
 #include <vector>
 #include "../../zeekstd_amd/csrc/zk_device.h"
 
+// ---- a quad of lanes on the CPU: three fibers in lock step ------------------------------------------------------
+// zk_seq_walk_quad (zk_device.h) is written for three lanes that meet in every XCH::bcast (a DPP move on the device).
+// Here each lane is a ucontext fiber; bcast parks the lane's value and yields, the scheduler resumes the lanes round
+// robin, so every lane reaches exchange r before any lane leaves it (values are double buffered by exchange parity).
+struct ZkQuadSim {
+    ucontext_t main_ctx, ctx[3];
+    std::vector<char> stack[3];
+    uint32_t buf[2][3], round[3];
+    int cur;
+    bool done[3];
+    // arguments of the walk
+    const uint8_t *comp; ZkBlock b[3]; uint32_t bs_off; ZkSeqTables16 *T; const uint32_t *al; ZkSeq *seqs; uint32_t pos_pub;
+};
+static ZkQuadSim *g_quad;
+static uint32_t g_ofv[32];
+static int g_fse_quad = 0;
+extern "C" void zk_sim_set_fse_quad(int on) { g_fse_quad = on; }
+struct ZkQuadFibers {
+    static uint32_t bcast(uint32_t v, int k)
+    {
+        ZkQuadSim *q = g_quad;
+        const int me = q->cur;
+        const uint32_t r = q->round[me]++;
+        q->buf[r & 1][me] = v;
+        swapcontext(&q->ctx[me], &q->main_ctx);
+        return q->buf[r & 1][k];
+    }
+};
+
 static const uint32_t LLV[36] = ZK_LL_TABLE;
 static const uint32_t MLV[53] = ZK_ML_TABLE;
+
+static const uint32_t LLV_[36] = ZK_LL_TABLE;
+static const uint32_t MLV_[53] = ZK_ML_TABLE;
+static void zk_quad_lane_main()
+{
+    ZkQuadSim *q = g_quad;
+    const int t = q->cur;
+    zk_seq_walk_quad<ZkRevU, ZkCells16, ZkQuadFibers>(q->comp, q->b[t], q->bs_off, (uint32_t)t,
+                                                      t == ZK_TAB_LL ? q->T->ll : t == ZK_TAB_OF ? q->T->of : q->T->ml,
+                                                      t == ZK_TAB_LL ? LLV_ : t == ZK_TAB_OF ? g_ofv : MLV_, q->al, q->T->ring, q->seqs, &q->pos_pub);
+    q->done[t] = true;
+}
+// the block's sequences through the quad walk (tables already built in T); false: the three lanes disagree
+static bool zk_quad_walk_sim(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, ZkSeqTables16 *T, const uint32_t *al, ZkSeq *seqs)
+{
+    ZkQuadSim q;
+    g_quad = &q;
+    for (uint32_t k = 0; k < 32; k++) g_ofv[k] = k << 24;
+    q.comp = comp; q.bs_off = bs_off; q.T = T; q.al = al; q.seqs = seqs; q.pos_pub = 0;
+    for (int l = 0; l < 3; l++) {
+        q.b[l] = b; q.round[l] = 0; q.done[l] = false;
+        q.stack[l].resize(256 << 10);
+        getcontext(&q.ctx[l]);
+        q.ctx[l].uc_stack.ss_sp = q.stack[l].data();
+        q.ctx[l].uc_stack.ss_size = q.stack[l].size();
+        q.ctx[l].uc_link = &q.main_ctx;
+        makecontext(&q.ctx[l], zk_quad_lane_main, 0);
+    }
+    while (!(q.done[0] && q.done[1] && q.done[2]))
+        for (int l = 0; l < 3; l++)
+            if (!q.done[l]) { q.cur = l; swapcontext(&q.main_ctx, &q.ctx[l]); }
+    g_quad = nullptr;
+    bool same = true;
+    for (int l = 1; l < 3; l++)
+        same = same && q.b[l].status == q.b[0].status && q.b[l].out_size == q.b[0].out_size && q.b[l].rep_out[0] == q.b[0].rep_out[0] &&
+               q.b[l].rep_out[1] == q.b[0].rep_out[1] && q.b[l].rep_out[2] == q.b[0].rep_out[2] && q.round[l] == q.round[0];
+    b = q.b[0];
+    return same;
+}
 
 extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
                                     uint32_t count, uint8_t *dst, int32_t *status, int exec_b, int exec_chunk,
@@ -93,7 +162,20 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
         if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK) continue;
         // like the device: all-predefined blocks go through the aligned-word reader, the rest through the unaligned one
         if (b.seq_modes == 0) zk_decode_sequences<ZkRevA, ZkCells32>(comp, blocks.data(), b, T, seqs.data() + b.seq_base, LLV, MLV);
-        else zk_decode_sequences<ZkRevU, ZkCells16>(comp, blocks.data(), b, T16, seqs.data() + b.seq_base, LLV, MLV);     // zk_k_fse: compact cells
+        else if (!g_fse_quad) zk_decode_sequences<ZkRevU, ZkCells16>(comp, blocks.data(), b, T16, seqs.data() + b.seq_base, LLV, MLV);     // zk_k_fse: compact cells
+        else {                                                      // zk_k_fse_quad: the kernel's table setup, then three lock-stepped lanes
+            uint32_t al[3], own = 0;
+            bool ok = true;
+            for (int u = 0; u < 3 && ok; u++) {
+                const uint32_t m = (b.seq_modes >> (6 - 2 * u)) & 3;
+                const ZkBlock &def = m == 3 ? blocks[b.tab_def[u]] : b;
+                const int32_t r = zk_seq_table_setup<ZkCells16>(comp, def, u, T16, &al[u], LLV, MLV);
+                if (r < 0) ok = false;
+                else if (m != 3) own += (uint32_t)r;
+            }
+            if (!ok) b.status = ZK_E_CORRUPTION;
+            else if (!zk_quad_walk_sim(comp, b, b.seq_off + 1 + own, T16, al, seqs.data() + b.seq_base)) b.status = ZK_E_CORRUPTION + 1000;   // lanes out of step: a bug, not an input error
+        }
         blocks[bi].out_size = b.out_size;
         for (int k = 0; k < 3; k++) blocks[bi].rep_out[k] = b.rep_out[k];
         blocks[bi].status = b.status;

@@ -74,3 +74,48 @@ def test_sim_prefix_goldens(prefix_golden):
     rc, out, st = sim_decode(g.comp, g.frames, prefix=g.prefix())
     assert rc == 0 and not st.any()
     assert out == g.input()
+
+
+# ---- zk_k_fse_quad: three lock-stepped lanes per block (zk_seq_walk_quad), fibers on the CPU ----------------------
+def test_sim_quad_goldens(golden):
+    rc, out, st = sim_decode(golden.comp, golden.frames, quad=True)
+    assert rc == 0 and not st.any()
+    assert out == golden.input()
+
+
+def test_sim_quad_prefix_goldens(prefix_golden):
+    g = prefix_golden
+    rc, out, st = sim_decode(g.comp, g.frames, prefix=g.prefix(), quad=True)
+    assert rc == 0 and not st.any()
+    assert out == g.input()
+
+
+def test_sim_quad_matches_lane_walk_on_corrupt_input():
+    """Both sequence walks must agree frame by frame on damaged archives too: same status words, same bytes where a
+    frame still decodes (status 1020 would mean the three lanes of a quad fell out of step)."""
+    from conftest import GOLDENS
+    rng = np.random.default_rng(23)
+    for name in ("text_l1_64k", "mixed_l19", "text_l3"):
+        g = next((x for x in GOLDENS if x.name == name), None)
+        if g is None:
+            continue
+        for _ in range(30):
+            comp = bytearray(g.comp)
+            comp[int(rng.integers(0, len(comp)))] ^= 1 << int(rng.integers(0, 8))
+            rc1, out1, st1 = sim_decode(bytes(comp), g.frames)
+            rc2, out2, st2 = sim_decode(bytes(comp), g.frames, quad=True)
+            assert list(st1) == list(st2) and rc1 == rc2
+            _, d = g.offsets()
+            for f in range(len(g.frames)):
+                if st1[f] == 0:
+                    assert out1[int(d[f]):int(d[f + 1])] == out2[int(d[f]):int(d[f + 1])]
+
+
+@pytest.mark.skipif(Z.load("system") is None, reason="no system libzstd")
+@pytest.mark.parametrize("level", [1, 3, 19])
+def test_sim_quad_vs_live_libzstd(level):
+    data = zko.make_input([["text", 300000, 80 + level], ["rep", "00", 200000], ["random", 20000, 7], ["text", 100000, 81]])
+    for fs in (2 << 20, 65536):
+        comp, frames = Z.encode_seekable_frames(data, fs, level, fs != 65536, "system")
+        rc, out, st = sim_decode(comp, frames, quad=True)
+        assert rc == 0 and out == data

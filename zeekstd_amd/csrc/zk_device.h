@@ -1063,6 +1063,118 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
     zk_seq_walk<16, RD, CP>(comp, b, b.seq_off + 1 + own, T->ll, T->of, T->ml, al, T->ring, seqs, ll_values, ml_values, store);
 }
 
+
+// ---------------------------------------------------------------- sequence section decode (a quad of lanes per block)
+// One lane per FSE state machine of a block; XCH::bcast(v, k) returns the value v of the quad's lane k (DPP quad_perm on
+// the device -- zk_decode.hip, zk_k_fse_quad; lock-stepped fibers in tests/sim).  All lanes of a quad run this function
+// with the same block and meet in every bcast.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZK_WAVE_BARRIER() __builtin_amdgcn_wave_barrier()
+#else
+#define ZK_WAVE_BARRIER() ((void)0)
+#endif
+// t = the lane's table (ZK_TAB_LL / ZK_TAB_OF / ZK_TAB_ML = its position in the quad); cells / vt: that table's cells
+// and value table (offsets: entries k << 24, the baseline 1 << k is formed here); al[3]: accuracy logs (LL, OF, ML).
+// All three lanes return the same b (out_size, rep_out, status); lane ZK_TAB_LL owns the ring.
+template <typename RD, typename CP, typename XCH>
+ZK_HD void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, uint32_t t,
+                                                 const typename CP::cell_t *cells, const uint32_t *vt, const uint32_t *al,
+                                                 ZkSeq *ring, ZkSeq *seqs, volatile uint32_t *pos_pub)
+{
+    RD r;
+    uint32_t bad = 0;
+    const bool ok = bs_off < b.bsize && r.init(comp + b.src + bs_off, b.bsize - bs_off);
+    if (!ok) { b.status = ZK_E_CORRUPTION; return; }
+    const uint32_t nseq = b.nseq;
+    uint32_t state;
+    {
+        const uint32_t s0 = r.read(al[0]), s1 = r.read(al[1]), s2 = r.read(al[2]);
+        bad |= r.remaining() < 0; r.clamp();
+        state = t == ZK_TAB_LL ? s0 : t == ZK_TAB_OF ? s1 : s2;
+    }
+    // where the lane's fields start: value bits come OF, ML, LL; state bits LL, ML, OF
+    const uint32_t kOfV = t == ZK_TAB_OF ? 0u : 0xFFu;              // OF value bits precede ML's and LL's
+    const uint32_t kMlV = t == ZK_TAB_LL ? 0xFFu : 0u;              // ML value bits precede LL's
+    const uint32_t kLlS = t == ZK_TAB_LL ? 0u : 0xFFu;              // LL state bits precede ML's and OF's
+    const uint32_t kMlS = t == ZK_TAB_OF ? 0xFFu : 0u;              // ML state bits precede OF's
+    uint32_t rep0 = zk_rep_sym(0), rep1 = zk_rep_sym(1), rep2 = zk_rep_sym(2);
+    uint32_t out = 0, lit = 0;
+    ZkSeq qp; qp.out_end = 0; qp.ml = 0; qp.off = 0; qp.lit_end = 0;
+    typename CP::cell_t c = cells[state];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" :: "v"((uint32_t)c));                      // arrived before the loop: its waits then only count what the loop issues
+#endif
+    for (uint32_t g0 = 0; g0 < nseq; g0 += 16) {
+        const uint32_t gend = g0 + 16 < nseq ? g0 + 16 : nseq;
+        if (t == ZK_TAB_LL) *pos_pub = b.src + bs_off + (uint32_t)(r.remaining() >> 3);       // for the toucher wave (zk_k_fse_quad)
+        for (uint32_t i = g0; i < gend; i++) {
+            const uint32_t vv = vt[CP::sym(c)];
+            // the previous step's record goes to the ring now, behind this step's first LDS read (all three lanes, same
+            // bytes, unconditional; the very first write of a group repeats a record that is already there): at the end
+            // of its own step it would sit between the cell read and the next step's wait for it
+            ring[(i - 1) & 15] = qp;
+            const uint32_t xb = vv >> 24;
+            const uint32_t nb = i + 1 < nseq ? CP::nb(c) : 0;
+            const uint32_t pk = xb | (nb << 8);
+            const uint32_t pL = XCH::bcast(pk, ZK_TAB_LL), pO = XCH::bcast(pk, ZK_TAB_OF), pM = XCH::bcast(pk, ZK_TAB_ML);
+            const uint32_t sum = pL + pO + pM;                      // value bits in the low byte (<= 63), state bits above (<= 27)
+            const uint32_t nval = sum & 0xFF, total = nval + (sum >> 8);
+            const uint32_t voff = (pO & kOfV) + (pM & kMlV);
+            const uint32_t soff = nval + ((pL >> 8) & kLlS) + ((pM >> 8) & kMlS);
+            bad |= (pO & 0xFF) > 30;
+            uint32_t vbits, sbits;
+            if (total <= r.avail()) {
+                const uint64_t X = r.window();
+                r.consume(total);
+                sbits = zk_top_bits((uint32_t)((X << (soff & 63)) >> 32), nb);
+                vbits = zk_top_bits((uint32_t)((X << (voff & 63)) >> 32), xb & 31);
+            } else {                                                // more bits than one window guarantees: field by field
+                const uint32_t ofx = r.read(pO & 31), mlx = r.read(pM & 0xFF), llx = r.read(pL & 0xFF);
+                const uint32_t sL = r.read(pL >> 8), sM = r.read(pM >> 8), sO = r.read(pO >> 8);
+                bad |= r.remaining() < 0;
+                r.clamp();
+                vbits = t == ZK_TAB_LL ? llx : t == ZK_TAB_OF ? ofx : mlx;
+                sbits = t == ZK_TAB_LL ? sL : t == ZK_TAB_OF ? sO : sM;
+            }
+            state = CP::base(c) + sbits;
+            c = cells[state];                                       // issued early; used by the next step
+            const uint32_t val = (t == ZK_TAB_OF ? 1u << (xb & 31) : vv & 0xFFFFFFu) + vbits;
+            const uint32_t ll = XCH::bcast(val, ZK_TAB_LL), ofv = XCH::bcast(val, ZK_TAB_OF), ml = XCH::bcast(val, ZK_TAB_ML);
+            // offset + repeat history, select form (A.8) -- as zk_seq_walk
+            const bool is_rep = ofv <= 3;
+            const uint32_t idx = ofv - 1 + (ll == 0);
+            const uint32_t r0m1 = zk_rep_is_sym(rep0) ? rep0 + 1 : rep0 - 1;
+            uint32_t cand = idx == 0 ? rep0 : rep1;                 // plain selects: no control flow in the step
+            cand = idx == 2 ? rep2 : cand;
+            cand = idx == 3 ? r0m1 : cand;
+            const uint32_t off = is_rep ? cand : ofv - 3;
+            bad |= off == 0;
+            const bool sh1 = (!is_rep) | (idx >= 1), sh2 = (!is_rep) | (idx >= 2);
+            rep2 = sh2 ? rep1 : rep2;
+            rep1 = sh1 ? rep0 : rep1;
+            rep0 = off;
+            lit += ll; out += ll + ml;
+            bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX);
+            qp.out_end = out; qp.ml = ml; qp.off = off; qp.lit_end = lit;
+        }
+        ring[(gend - 1) & 15] = qp;
+        ZK_WAVE_BARRIER();
+        // the quad's three lanes share the stores of the group's records
+        for (uint32_t k = g0 + t; k < gend; k += 3) {
+            const volatile uint32_t *w = reinterpret_cast<const volatile uint32_t *>(&ring[k & 15]);
+            ZkSeq q; q.out_end = w[0]; q.ml = w[1]; q.off = w[2]; q.lit_end = w[3];
+            seqs[k] = q;
+        }
+        ZK_WAVE_BARRIER();
+    }
+    bad |= r.remaining() != 0;
+    if (bad) { b.status = ZK_E_CORRUPTION; return; }
+    out += b.lit_regen - lit;
+    if (out > ZK_BLOCK_MAX) { b.status = ZK_E_CORRUPTION; return; }
+    b.out_size = out;
+    b.rep_out[0] = rep0; b.rep_out[1] = rep1; b.rep_out[2] = rep2;
+}
+
 // ---------------------------------------------------------------- sequence execution: per-byte source map
 // The executor produces a block's output in tiles of 16-byte slots.  Per tile:
 //   * lane per SEQUENCE: for every slot whose first byte the sequence covers, slot_seq[slot] = staged index
