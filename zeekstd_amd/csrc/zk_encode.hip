@@ -8,14 +8,17 @@
 //
 // Pipeline (one stream, everything resident in HBM):
 //   zk_k_xxh64        (checksum_flag) XXH64 of every frame's input
-//   zk_k_enc_match    one workgroup (8 waves) per frame: tiles of 256 positions, 8 per group -- phase 1 all lanes,
-//                     two tiles per step: 5-byte hash lookup in a 2^14-entry LDS table + probe of the last offset,
-//                     lengths capped at 64, then insert (atomicMax); phase 2: wave w parses tile w greedily
-//                     (ballot skipping), a stitch pass joins the tiles -> packed sequences + literal buffer per block.
+//   zk_k_enc_match    one workgroup (8 waves) per frame: tiles of 256 positions, 8 per group.  Per group: four lookup
+//                     steps (one position per lane: 5-byte hash into a 2^14-entry LDS table of 16-bit entries, candidate
+//                     bytes requested, compare-and-swap insertion) behind LDS-only barriers; comparisons from
+//                     registers (candidate + previous offset), matches of 8+ bytes measured from an LDS queue by all
+//                     lanes; wave w parses tile w greedily (ballot skipping); a stitch pass joins the tiles -> packed
+//                     sequences; per block the literals are gathered through a 64-bit accumulator.
 //                     Prefix mode: the matcher reads [prefix tail | frame] records (zk_k_enc_stage_hist)
-//   zk_k_enc_entropy  one workgroup per 16 blocks: literal histograms, Huffman lengths (<= 11 bits), 64 literal
-//                     streams (wave 0) and 16 FSE sequence bitstreams with the predefined tables (wave 1)
-//                     side by side, block payload assembled in scratch, raw / RLE fallbacks decided
+//   zk_k_enc_entropy  one workgroup per 16 blocks: literal histograms, Huffman lengths (<= 11 bits) while the other
+//                     waves precompute every sequence's codes and extra bits, then 64 literal streams (wave 0) and 16
+//                     FSE sequence bitstreams with the predefined tables (wave 1) side by side -- branch-free bit
+//                     writers --, block payload assembled in scratch one wave per block, raw / RLE fallbacks decided
 //   zk_k_enc_sizes    per frame: compressed size = header + blocks (+ checksum)   -> seek-table entries
 //   zk_k_scan64       exclusive scan of the frame sizes -> where each frame lands in the output stream
 //   zk_k_enc_assemble one workgroup per frame: frame header, block headers, payload copies into the
@@ -89,7 +92,7 @@ __device__ __forceinline__ void zke_table_insert(uint32_t *table, uint32_t h, ui
 // buffer that holds, per frame, [last `hist` bytes of the prefix | the frame] (zk_k_enc_stage_hist), all positions
 // below are offsets into that record, and the history's positions enter the hash table before the first block --
 // so a match may start in the prefix and run on into the frame with no special case anywhere.
-__global__ __launch_bounds__(ZKE_THREADS) __attribute__((amdgpu_waves_per_eu(6))) void zk_k_enc_match(       // 47 KiB of LDS: three workgroups = 24 waves per CU need <= 80 VGPRs
+__global__ __launch_bounds__(ZKE_THREADS) __attribute__((amdgpu_waves_per_eu(6))) void zk_k_enc_match(       // 52 KiB of LDS: three workgroups = 24 waves per CU need <= 80 VGPRs
 const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
                                                               uint64_t *seqs, uint32_t *mpos, uint8_t *lits)
 {
