@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/pmc_traffic.json.
 
-usage: pmc_summary.py <fetch_dir> <write_dir> <workload> [out.json]
+usage: pmc_summary.py <fetch_dir> <write_dir> <workload: c2|c3> [out.json]
 
 Each directory holds the `*_counter_collection.csv` of one pass of `python bench.py --steps 1 --warmup 1
 --no-cpu-baseline --no-seek`.  Values are KiB per dispatch (MI355X_MICROARCH.md, HBM section); the LAST dispatch of
@@ -44,6 +44,8 @@ def last_per_kernel(d, counter):
 
 def main():
     fdir, wdir, workload = sys.argv[1:4]
+    if workload not in ("c2", "c3"):
+        sys.exit("workload must be the bench.py --workload key (c2 / c3): bench.py matches it against its own flag")
     outp = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(__file__), "..", "profiles",
                                                               "pmc_traffic.json")
     # LAST dispatch: bench.py ends with its per-kernel-timing steps, which run every kernel alone on the device; in the
