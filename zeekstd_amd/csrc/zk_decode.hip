@@ -299,7 +299,7 @@ struct ZkQuadDpp {
 // waits for an L2 round trip.  The walkers publish their stream position once per 16 sequences; the toucher wave (its
 // own load counter, results never used) requests the two lines below it.
 template <typename CP, int ZK_FSE_BLOCKS, int ZK_FSE_WAVES>
-__global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
+__global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs, uint32_t all_blocks)
 {
     constexpr int PER_WAVE = ZK_FSE_BLOCKS / ZK_FSE_WAVES;
     static_assert(PER_WAVE * 4 <= 64 && ZK_FSE_BLOCKS <= 64, "a quad of lanes per block; a toucher lane per block");
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const u
     valid = valid && bi < nblocks;
     if (valid) {
         b = blocks[bi];
-        valid = b.type == 2 && b.nseq != 0 && b.status == ZK_OK && b.seq_modes != 0;       // all-predefined blocks: zk_k_fse_predef
+        valid = b.type == 2 && b.nseq != 0 && b.status == ZK_OK && (b.seq_modes != 0 || all_blocks);     // all-predefined blocks: zk_k_fse_predef, unless the batch is small
     }
     if (valid && !toucher && t == ZK_TAB_LL) atomicAdd(&s_live, 1u);
     __syncthreads();
@@ -752,6 +752,12 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     // loaded once); below that a lane's instruction count is (one unaligned load per sequence).  Measured crossover
     // on 32 KiB blocks between 1024 and 2048 frames of 2 MiB.
     const uint32_t wgs = (nblocks + ZK_FSEP_LANES - 1) / ZK_FSEP_LANES;
+    // a small batch (a seek, a handful of frames) is all chain latency: every block, predefined tables or not, takes a
+    // quad of lanes (each block builds its own copy of the tables: microseconds)
+    if (own_kernel == 0 && nblocks <= 16u * 256u) {
+        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 16, 1>), dim3((nblocks + 15) / 16), dim3(128), 0, st, comp, blocks, nblocks, seqs, 1u);
+        return;
+    }
     if (n_own_tables < nblocks) {          // at least one block may be all-predefined
         if (wgs >= 6 * 256) hipLaunchKernelGGL(zk_k_fse_predef_fed, dim3(wgs), dim3(2 * ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
         else hipLaunchKernelGGL(zk_k_fse_predef<ZkRevU>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
@@ -765,9 +771,9 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     if (!n_own_tables) return;
     if (own_kernel == 1) { hipLaunchKernelGGL((zk_k_fse<ZkCells16, 56, 8>), dim3((nblocks + 55) / 56), dim3(512), 0, st, comp, blocks, nblocks, seqs); return; }
     if (own_kernel != 2 && n_own_tables <= 48u * 256u)
-        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 16, 1>), dim3((nblocks + 15) / 16), dim3(128), 0, st, comp, blocks, nblocks, seqs);
+        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 16, 1>), dim3((nblocks + 15) / 16), dim3(128), 0, st, comp, blocks, nblocks, seqs, 0u);
     else
-        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 4>), dim3((nblocks + 55) / 56), dim3(320), 0, st, comp, blocks, nblocks, seqs);
+        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 4>), dim3((nblocks + 55) / 56), dim3(320), 0, st, comp, blocks, nblocks, seqs, 0u);
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeq *seqs,
