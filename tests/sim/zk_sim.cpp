@@ -161,7 +161,8 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
         ZkBlock b = blocks[bi];
         if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK) continue;
         // like the device: all-predefined blocks go through the aligned-word reader, the rest through the unaligned one
-        if (b.seq_modes == 0) zk_decode_sequences<ZkRevA, ZkCells32>(comp, blocks.data(), b, T, seqs.data() + b.seq_base, LLV, MLV);
+        // (with the quad flag every block takes the quad walk, as small batches do on the device)
+        if (b.seq_modes == 0 && !g_fse_quad) zk_decode_sequences<ZkRevA, ZkCells32>(comp, blocks.data(), b, T, seqs.data() + b.seq_base, LLV, MLV);
         else if (!g_fse_quad) zk_decode_sequences<ZkRevU, ZkCells16>(comp, blocks.data(), b, T16, seqs.data() + b.seq_base, LLV, MLV);     // zk_k_fse: compact cells
         else {                                                      // zk_k_fse_quad: the kernel's table setup, then three lock-stepped lanes
             uint32_t al[3], own = 0;
