@@ -104,6 +104,15 @@ def offsets_from_frames(frames):
     return c, d
 
 
+# ---------------------------------------------------------------- hand-written frames (tools/make_handmade_goldens.py)
+def _load_handmade():
+    with open(os.path.join(ROOT, "tests", "golden", "handmade.json")) as f:
+        return [(k, bytes.fromhex(v["frame"]), bytes.fromhex(v["output"])) for k, v in json.load(f).items()]
+
+
+HANDMADE = _load_handmade()
+
+
 # ---------------------------------------------------------------- CPU simulation of the device lane code
 _SIM = None
 

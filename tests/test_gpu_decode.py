@@ -5,7 +5,7 @@ with the reference's Encoder loop.  Mirrors the scenarios of the reference's own
 import numpy as np
 import pytest
 
-from conftest import GOLDENS, PREFIX_GOLDENS, offsets_from_frames
+from conftest import GOLDENS, HANDMADE, PREFIX_GOLDENS, offsets_from_frames
 from oracle import zko
 from oracle import libzstd_ref as Z
 
@@ -114,6 +114,23 @@ def test_live_libzstd_archives(engine, level, fs, cks):
     c, d = offsets_from_frames(frames)
     out, st = engine.decode_frames(comp + b"\0" * 8, c, d, verify=True)
     assert not st.any() and out == data
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_handmade_frames(engine, mode):
+    """RLE_Mode sequence tables (tests/golden/handmade.json: written by hand, accepted by libzstd 1.5.7), through every
+    sequence kernel; all frames in one batch and one by one."""
+    engine.set_fse_kernel(mode)
+    try:
+        comp = b"".join(f for _, f, _ in HANDMADE)
+        c, d = offsets_from_frames([(len(f), len(e)) for _, f, e in HANDMADE])
+        out, st = engine.decode_frames(comp + b"\0" * 8, c, d)
+        assert not st.any() and out == b"".join(e for _, _, e in HANDMADE)
+        for name, f, e in HANDMADE:
+            out, st = engine.decode_frames(f + b"\0" * 8, [0, len(f)], [0, len(e)])
+            assert not st.any() and out == e, name
+    finally:
+        engine.set_fse_kernel(0)
 
 
 @pytest.mark.parametrize("mode", [1, 2])

@@ -151,3 +151,16 @@ def test_encoder_twin_frames_are_valid_zstd(which):
         assert out == data and used == len(c)
     shared = zko.frame_encode(cases[0], 1, True, prefix=prefix)
     assert len(shared) < len(zko.frame_encode(cases[0], 1, True))   # the prefix tail is found
+
+
+def test_handmade_frames():
+    """Format corners libzstd's encoder never picked for the archives (RLE_Mode sequence tables): frames written by
+    hand, accepted by libzstd 1.5.7 when they were minted; the oracle and, where present, the box's libzstd agree."""
+    from conftest import HANDMADE
+    assert {n for n, _, _ in HANDMADE} >= {"rle_seq_tables", "rle_ll_ml_predef_of"}
+    for name, frame, expect in HANDMADE:
+        out, _ = zko.frame_decode(frame, len(expect), True)
+        assert out == expect, name
+        for which in ("1.5.7", "system"):
+            if Z.load(which) is not None:
+                assert Z.decode_stream(frame, len(expect), which) == expect, (name, which)

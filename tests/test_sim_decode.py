@@ -119,3 +119,12 @@ def test_sim_quad_vs_live_libzstd(level):
         comp, frames = Z.encode_seekable_frames(data, fs, level, fs != 65536, "system")
         rc, out, st = sim_decode(comp, frames, quad=True)
         assert rc == 0 and out == data
+
+
+@pytest.mark.parametrize("quad", [False, True])
+def test_sim_handmade_frames(quad):
+    """RLE_Mode sequence tables (hand-written frames): one-cell tables, accuracy log 0, through both sequence walks."""
+    from conftest import HANDMADE
+    for name, frame, expect in HANDMADE:
+        rc, out, st = sim_decode(frame, [(len(frame), len(expect))], quad=quad)
+        assert rc == 0 and not st.any() and out == expect, name

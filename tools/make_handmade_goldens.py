@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Mint tests/golden/handmade.json: frames written by hand for corners of the format that libzstd's encoder never
+produced for the archives of tools/make_goldens.py, each accepted by the real libzstd **1.5.7** (and the distro build)
+before it is stored -- the decoder of the pinned library is the judge of what the bytes mean, as for every other golden.
+
+  rle_seq_tables   Sequences_Section with RLE_Mode for all three tables (Symbol_Compression_Modes 0x54): the tables have
+                   one cell and accuracy log 0, so the bitstream carries no state bits at all (RFC 8878 3.1.1.3.2.1)
+  rle_ll_ml_fse_of RLE_Mode for LL / ML next to Predefined_Mode offsets (modes 0x44)
+
+Run in the BUILD container only.  Output: tests/golden/handmade.json ({name: {frame: hex, output: hex, note}}).
+"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import libzstd_ref as Z
+
+
+def frame(content_size, block_payload):
+    n = len(block_payload)
+    hdr = (n << 3) | (2 << 1) | 1                                  # Last_Block, Compressed_Block
+    return bytes.fromhex("28B52FFD") + bytes([0x20, content_size]) + hdr.to_bytes(3, "little") + block_payload
+
+
+def raw_literals(b):
+    assert len(b) < 32
+    return bytes([len(b) << 3]) + b
+
+
+CASES = {}
+# three sequences, each: 2 literals, then a match of length 4 at "repeat offset 1" (initially 1) -> the last literal four times
+CASES["rle_seq_tables"] = dict(
+    frame=frame(18, raw_literals(b"abcdef") + bytes([3, 0x54, 2, 0, 1]) + b"\x01"),
+    output=b"abbbbb" + b"cddddd" + b"efffff",
+    note="LL code 2, OF code 0, ML code 1, all RLE_Mode; bitstream = the padding marker only")
+# LL / ML RLE, offsets through the predefined table (accuracy log 5): two sequences with Offset_Value 1 (code 0, state 0
+# of the predefined OF table decodes symbol 0) -- initial OF state 0 (5 bits), update after sequence 1: code 0 at state 0
+# has nbBits 5 and baseline 0 -> 5 bits 00000 select state 0 again
+def backward_bitstream(fields):
+    """Bytes of a sequence bitstream whose reader meets `fields` [(value, width), ...] in this order: the first field
+    sits right below the padding marker, the stream is little endian with the marker in its last byte."""
+    acc, n = 1, 0
+    for v, w in fields:
+        acc = (acc << w) | v
+        n += w
+    return acc.to_bytes((n + 1 + 7) // 8, "little")
+
+
+CASES["rle_ll_ml_predef_of"] = dict(
+    frame=frame(12, raw_literals(b"wxyz") + bytes([2, 0x44, 2, 1]) + backward_bitstream([(0, 5), (0, 5)])),
+    output=b"wxxxxx" + b"yzzzzz",
+    note="LL code 2 / ML code 1 RLE_Mode, offsets Predefined_Mode: initial OF state 0 (5 bits), one 5-bit state update")
+
+out = {}
+for name, c in CASES.items():
+    for which in ("1.5.7", "system"):
+        if Z.load(which) is None:
+            assert which != "1.5.7", "libzstd 1.5.7 (pillow bundled) not found in this image"
+            continue
+        got = Z.decode_stream(c["frame"], len(c["output"]), which)
+        assert got == c["output"], (name, which, got)
+    out[name] = {"frame": c["frame"].hex(), "output": c["output"].hex(), "note": c["note"],
+                 "accepted_by": "libzstd 1.5.7 and the distro libzstd of the build container (ZSTD_decompressStream)"}
+with open(os.path.join(ROOT, "tests", "golden", "handmade.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print("wrote", len(out), "frames")
