@@ -5,7 +5,7 @@ with the reference's Encoder loop.  Mirrors the scenarios of the reference's own
 import numpy as np
 import pytest
 
-from conftest import GOLDENS, HANDMADE, PREFIX_GOLDENS, offsets_from_frames
+from conftest import GOLDENS, HANDMADE, HANDMADE_BAD, PREFIX_GOLDENS, offsets_from_frames
 from oracle import zko
 from oracle import libzstd_ref as Z
 
@@ -129,6 +129,9 @@ def test_handmade_frames(engine, mode):
         for name, f, e in HANDMADE:
             out, st = engine.decode_frames(f + b"\0" * 8, [0, len(f)], [0, len(e)])
             assert not st.any() and out == e, name
+        for name, f, dsize in HANDMADE_BAD:                # offset 0 out of the repeat history: corruption_detected (20), as libzstd 1.5.7
+            _, st = engine.decode_frames(f + b"\0" * 8, [0, len(f)], [0, dsize], raise_on_error=False)
+            assert st[0] == 20, name
     finally:
         engine.set_fse_kernel(0)
 

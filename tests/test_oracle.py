@@ -156,8 +156,14 @@ def test_encoder_twin_frames_are_valid_zstd(which):
 def test_handmade_frames():
     """Format corners libzstd's encoder never picked for the archives (RLE_Mode sequence tables): frames written by
     hand, accepted by libzstd 1.5.7 when they were minted; the oracle and, where present, the box's libzstd agree."""
-    from conftest import HANDMADE
-    assert {n for n, _, _ in HANDMADE} >= {"rle_seq_tables", "rle_ll_ml_predef_of"}
+    from conftest import HANDMADE, HANDMADE_BAD
+    assert {n for n, _, _ in HANDMADE} >= {"rle_seq_tables", "rle_ll_ml_predef_of", "rep_across_blocks_ll0"}
+    for name, frame, dsize in HANDMADE_BAD:                 # "Repeated_Offset1 - 1" == 0: libzstd 1.5.7 says corruption_detected
+        with pytest.raises(Exception):
+            zko.frame_decode(frame, dsize, True)
+        if Z.load("1.5.7") is not None:
+            with pytest.raises(Exception, match="orrupt"):
+                Z.decode_stream(frame, dsize, "1.5.7")
     for name, frame, expect in HANDMADE:
         out, _ = zko.frame_decode(frame, len(expect), True)
         assert out == expect, name

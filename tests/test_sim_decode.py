@@ -124,7 +124,10 @@ def test_sim_quad_vs_live_libzstd(level):
 @pytest.mark.parametrize("quad", [False, True])
 def test_sim_handmade_frames(quad):
     """RLE_Mode sequence tables (hand-written frames): one-cell tables, accuracy log 0, through both sequence walks."""
-    from conftest import HANDMADE
+    from conftest import HANDMADE, HANDMADE_BAD
     for name, frame, expect in HANDMADE:
         rc, out, st = sim_decode(frame, [(len(frame), len(expect))], quad=quad)
         assert rc == 0 and not st.any() and out == expect, name
+    for name, frame, dsize in HANDMADE_BAD:                 # offset 0 out of the repeat history: corruption_detected
+        rc, out, st = sim_decode(frame, [(len(frame), dsize)], quad=quad)
+        assert rc == -20 and st[0] == 20, name

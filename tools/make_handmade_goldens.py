@@ -5,7 +5,11 @@ before it is stored -- the decoder of the pinned library is the judge of what th
 
   rle_seq_tables   Sequences_Section with RLE_Mode for all three tables (Symbol_Compression_Modes 0x54): the tables have
                    one cell and accuracy log 0, so the bitstream carries no state bits at all (RFC 8878 3.1.1.3.2.1)
-  rle_ll_ml_fse_of RLE_Mode for LL / ML next to Predefined_Mode offsets (modes 0x44)
+  rle_ll_ml_predef_of  RLE_Mode for LL / ML next to Predefined_Mode offsets (modes 0x44)
+  rep_across_blocks_ll0  the repeat-offset history crosses a block boundary and is used with Literals_Length 0 and
+                   Offset_Value 3 ("Repeated_Offset1 - 1 byte", RFC 8878 3.1.1.5)
+  rep0_minus_1_is_zero  the same with Repeated_Offset1 == 1: the offset would be 0 -- libzstd rejects the frame
+                   (corruption_detected) and so must every decoder here            [stored with "error": true]
 
 Run in the BUILD container only.  Output: tests/golden/handmade.json ({name: {frame: hex, output: hex, note}}).
 """
@@ -15,10 +19,12 @@ sys.path.insert(0, ROOT)
 from oracle import libzstd_ref as Z
 
 
-def frame(content_size, block_payload):
-    n = len(block_payload)
-    hdr = (n << 3) | (2 << 1) | 1                                  # Last_Block, Compressed_Block
-    return bytes.fromhex("28B52FFD") + bytes([0x20, content_size]) + hdr.to_bytes(3, "little") + block_payload
+def frame(content_size, *block_payloads):
+    out = bytes.fromhex("28B52FFD") + bytes([0x20, content_size])   # Single_Segment, 1-byte Frame_Content_Size
+    for i, p in enumerate(block_payloads):
+        hdr = (len(p) << 3) | (2 << 1) | (1 if i + 1 == len(block_payloads) else 0)     # Compressed_Block, Last_Block on the last
+        out += hdr.to_bytes(3, "little") + p
+    return out
 
 
 def raw_literals(b):
@@ -50,8 +56,35 @@ CASES["rle_ll_ml_predef_of"] = dict(
     output=b"wxxxxx" + b"yzzzzz",
     note="LL code 2 / ML code 1 RLE_Mode, offsets Predefined_Mode: initial OF state 0 (5 bits), one 5-bit state update")
 
+# block 1: "abcd", match 4 @ offset 3 (Offset_Value 6 = code 2 + extra 0b10)          -> abcdbcdb, history {3, 1, 4}
+# block 2: no literals, Literals_Length 0, match 3, Offset_Value 3 (code 1 + extra 1) -> offset = 3 - 1 = 2 -> dbd
+CASES["rep_across_blocks_ll0"] = dict(
+    frame=frame(11, raw_literals(b"abcd") + bytes([1, 0x54, 4, 2, 1]) + backward_bitstream([(2, 2)]),
+                raw_literals(b"") + bytes([1, 0x54, 0, 1, 0]) + backward_bitstream([(1, 1)])),
+    output=b"abcdbcdb" + b"dbd",
+    note="two blocks, one RLE_Mode sequence each; block 2 uses Repeated_Offset1 - 1 with Literals_Length 0")
+# block 1: match 4 @ offset 1 (Offset_Value 4 = code 2 + extra 0b00) -> history {1, 1, 4}; block 2 as above -> offset 0
+CASES["rep0_minus_1_is_zero"] = dict(
+    frame=frame(11, raw_literals(b"abcd") + bytes([1, 0x54, 4, 2, 1]) + backward_bitstream([(0, 2)]),
+                raw_literals(b"") + bytes([1, 0x54, 0, 1, 0]) + backward_bitstream([(1, 1)])),
+    output=None,
+    note="Repeated_Offset1 - 1 == 0: corruption_detected in libzstd")
+
 out = {}
 for name, c in CASES.items():
+    if c["output"] is None:
+        # the pinned library decides: 1.5.7 makes the offset invalid on purpose ("temp -= !temp") and fails in
+        # ZSTD_execSequence; libzstd 1.4.8 still forced such an offset to 1 and went on
+        assert Z.load("1.5.7") is not None, "libzstd 1.5.7 (pillow bundled) not found in this image"
+        try:
+            Z.decode_stream(c["frame"], 11, "1.5.7")
+        except Exception as ex:
+            assert "orrupt" in str(ex), (name, ex)
+        else:
+            raise AssertionError((name, "libzstd 1.5.7 accepted the frame"))
+        out[name] = {"frame": c["frame"].hex(), "error": True, "content_size": 11, "note": c["note"],
+                     "rejected_by": "libzstd 1.5.7 (corruption_detected); 1.4.8 forced the offset to 1 instead"}
+        continue
     for which in ("1.5.7", "system"):
         if Z.load(which) is None:
             assert which != "1.5.7", "libzstd 1.5.7 (pillow bundled) not found in this image"
