@@ -111,9 +111,16 @@ def _load_handmade():
 
 
 _HM = _load_handmade()
-HANDMADE = [(k, bytes.fromhex(v["frame"]), bytes.fromhex(v["output"])) for k, v in _HM.items() if not v.get("error")]
-# frames libzstd 1.5.7 rejects with corruption_detected: (name, frame, Frame_Content_Size)
-HANDMADE_BAD = [(k, bytes.fromhex(v["frame"]), int(v["content_size"])) for k, v in _HM.items() if v.get("error")]
+def _hm_output(v):
+    if v.get("output") is not None:
+        return bytes.fromhex(v["output"])
+    import base64, zlib
+    return zlib.decompress(base64.b64decode(v["output_zlib"]))
+
+
+HANDMADE = [(k, bytes.fromhex(v["frame"]), _hm_output(v)) for k, v in _HM.items() if not v.get("error")]
+# frames libzstd 1.5.7 rejects: (name, frame, Frame_Content_Size, ZSTD_ErrorCode)
+HANDMADE_BAD = [(k, bytes.fromhex(v["frame"]), int(v["content_size"]), int(v["error_code"])) for k, v in _HM.items() if v.get("error")]
 
 
 # ---------------------------------------------------------------- CPU simulation of the device lane code

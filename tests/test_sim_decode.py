@@ -128,6 +128,6 @@ def test_sim_handmade_frames(quad):
     for name, frame, expect in HANDMADE:
         rc, out, st = sim_decode(frame, [(len(frame), len(expect))], quad=quad)
         assert rc == 0 and not st.any() and out == expect, name
-    for name, frame, dsize in HANDMADE_BAD:                 # offset 0 out of the repeat history: corruption_detected
+    for name, frame, dsize, code in HANDMADE_BAD:           # libzstd 1.5.7's verdict, code for code
         rc, out, st = sim_decode(frame, [(len(frame), dsize)], quad=quad)
-        assert rc == -20 and st[0] == 20, name
+        assert rc == -code and st[0] == code, name

@@ -19,11 +19,18 @@ sys.path.insert(0, ROOT)
 from oracle import libzstd_ref as Z
 
 
-def frame(content_size, *block_payloads):
-    out = bytes.fromhex("28B52FFD") + bytes([0x20, content_size])   # Single_Segment, 1-byte Frame_Content_Size
-    for i, p in enumerate(block_payloads):
-        hdr = (len(p) << 3) | (2 << 1) | (1 if i + 1 == len(block_payloads) else 0)     # Compressed_Block, Last_Block on the last
-        out += hdr.to_bytes(3, "little") + p
+def frame(content_size, *blocks, fhd_extra=0):
+    """blocks: bytes = payload of a Compressed_Block, ("raw", bytes) = Raw_Block.  Single_Segment frame."""
+    if content_size < 256:
+        out = bytes.fromhex("28B52FFD") + bytes([0x20 | fhd_extra, content_size])          # 1-byte Frame_Content_Size
+    else:
+        out = bytes.fromhex("28B52FFD") + bytes([0xA0 | fhd_extra]) + content_size.to_bytes(4, "little")     # 4-byte
+    for i, p in enumerate(blocks):
+        last = 1 if i + 1 == len(blocks) else 0
+        if isinstance(p, tuple):
+            out += ((len(p[1]) << 3) | (0 << 1) | last).to_bytes(3, "little") + p[1]
+        else:
+            out += ((len(p) << 3) | (2 << 1) | last).to_bytes(3, "little") + p
     return out
 
 
@@ -68,22 +75,47 @@ CASES["rep0_minus_1_is_zero"] = dict(
     frame=frame(11, raw_literals(b"abcd") + bytes([1, 0x54, 4, 2, 1]) + backward_bitstream([(0, 2)]),
                 raw_literals(b"") + bytes([1, 0x54, 0, 1, 0]) + backward_bitstream([(1, 1)])),
     output=None,
-    note="Repeated_Offset1 - 1 == 0: corruption_detected in libzstd")
+    note="Repeated_Offset1 - 1 == 0: corruption_detected (20) in libzstd 1.5.7")
+
+# a compressed block without sequences (Number_of_Sequences 0: the block is its literals)
+CASES["block_without_sequences"] = dict(
+    frame=frame(11, raw_literals(b"only") + bytes([0]), raw_literals(b"literal") + bytes([0])),
+    output=b"onlyliteral",
+    note="two Compressed_Blocks with Number_of_Sequences == 0")
+# 0x7F00 sequences in one block (the 3-byte Number_of_Sequences form), none of them with a single bit in the bitstream:
+# Literals_Length 0, Match_Length 3, Offset_Value 1 == "Repeated_Offset2" after a literal-less sequence, so the history
+# rotates between 4 and 1.  Whatever libzstd 1.5.7 makes of it is the expected output.
+N_TINY = 0x7F00
+CASES["many_tiny_sequences"] = dict(
+    frame=frame(4 + 3 * N_TINY, ("raw", b"wxyz"),
+                raw_literals(b"") + bytes([255]) + (N_TINY - 0x7F00).to_bytes(2, "little") + bytes([0x54, 0, 0, 0]) + b"\x01"),
+    output="libzstd",
+    note="Raw_Block 'wxyz', then 32512 RLE_Mode sequences (ll 0, ml 3, Offset_Value 1) and a 1-byte bitstream")
+# Reserved_bit of the Frame_Header_Descriptor set
+CASES["reserved_bit"] = dict(
+    frame=frame(18, raw_literals(b"abcdef") + bytes([3, 0x54, 2, 0, 1]) + b"\x01", fhd_extra=0x08),
+    output=None, error_code=14, error_match="nsupported",
+    note="Frame_Header_Descriptor with the Reserved_bit set: frameParameter_unsupported (14)")
 
 out = {}
 for name, c in CASES.items():
+    if c["output"] == "libzstd":
+        n = int.from_bytes(c["frame"][5:9], "little")
+        c["output"] = Z.decode_stream(c["frame"], n, "1.5.7")
+        assert len(c["output"]) == n
     if c["output"] is None:
         # the pinned library decides: 1.5.7 makes the offset invalid on purpose ("temp -= !temp") and fails in
         # ZSTD_execSequence; libzstd 1.4.8 still forced such an offset to 1 and went on
         assert Z.load("1.5.7") is not None, "libzstd 1.5.7 (pillow bundled) not found in this image"
         try:
-            Z.decode_stream(c["frame"], 11, "1.5.7")
+            Z.decode_stream(c["frame"], c["frame"][5], "1.5.7")
         except Exception as ex:
-            assert "orrupt" in str(ex), (name, ex)
+            assert c.get("error_match", "orrupt") in str(ex), (name, ex)
         else:
             raise AssertionError((name, "libzstd 1.5.7 accepted the frame"))
-        out[name] = {"frame": c["frame"].hex(), "error": True, "content_size": 11, "note": c["note"],
-                     "rejected_by": "libzstd 1.5.7 (corruption_detected); 1.4.8 forced the offset to 1 instead"}
+        out[name] = {"frame": c["frame"].hex(), "error": True, "error_code": c.get("error_code", 20),
+                     "content_size": c["frame"][5], "note": c["note"],
+                     "rejected_by": "libzstd 1.5.7" + ("; 1.4.8 forced the offset to 1 instead" if name == "rep0_minus_1_is_zero" else "")}
         continue
     for which in ("1.5.7", "system"):
         if Z.load(which) is None:
@@ -91,7 +123,9 @@ for name, c in CASES.items():
             continue
         got = Z.decode_stream(c["frame"], len(c["output"]), which)
         assert got == c["output"], (name, which, got)
-    out[name] = {"frame": c["frame"].hex(), "output": c["output"].hex(), "note": c["note"],
+    out[name] = {"frame": c["frame"].hex(), "output": c["output"].hex() if len(c["output"]) < 4096 else None,
+                 "output_zlib": None if len(c["output"]) < 4096 else __import__("base64").b64encode(__import__("zlib").compress(c["output"], 9)).decode(),
+                 "note": c["note"],
                  "accepted_by": "libzstd 1.5.7 and the distro libzstd of the build container (ZSTD_decompressStream)"}
 with open(os.path.join(ROOT, "tests", "golden", "handmade.json"), "w") as f:
     json.dump(out, f, indent=1)
