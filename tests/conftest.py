@@ -120,7 +120,11 @@ def _hm_output(v):
 
 HANDMADE = [(k, bytes.fromhex(v["frame"]), _hm_output(v)) for k, v in _HM.items() if not v.get("error")]
 # frames libzstd 1.5.7 rejects: (name, frame, Frame_Content_Size, ZSTD_ErrorCode)
-HANDMADE_BAD = [(k, bytes.fromhex(v["frame"]), int(v["content_size"]), int(v["error_code"])) for k, v in _HM.items() if v.get("error")]
+HANDMADE_BAD = [(k, bytes.fromhex(v["frame"]), int(v["content_size"]), int(v["error_code"])) for k, v in _HM.items()
+                if v.get("error") and not v.get("cpu_only")]
+# damaged frames checked on the CPU only (oracle + simulation of the device code)
+HANDMADE_BAD_CPU = [(k, bytes.fromhex(v["frame"]), int(v["content_size"]), int(v["error_code"])) for k, v in _HM.items()
+                    if v.get("error") and v.get("cpu_only")]
 
 
 # ---------------------------------------------------------------- CPU simulation of the device lane code

@@ -156,9 +156,9 @@ def test_encoder_twin_frames_are_valid_zstd(which):
 def test_handmade_frames():
     """Format corners libzstd's encoder never picked for the archives (RLE_Mode sequence tables): frames written by
     hand, accepted by libzstd 1.5.7 when they were minted; the oracle and, where present, the box's libzstd agree."""
-    from conftest import HANDMADE, HANDMADE_BAD
+    from conftest import HANDMADE, HANDMADE_BAD, HANDMADE_BAD_CPU
     assert {n for n, _, _ in HANDMADE} >= {"rle_seq_tables", "rle_ll_ml_predef_of", "rep_across_blocks_ll0", "block_without_sequences", "many_tiny_sequences"}
-    for name, frame, dsize, code in HANDMADE_BAD:           # rejected by libzstd 1.5.7 (offset 0 out of the history; reserved bit)
+    for name, frame, dsize, code in HANDMADE_BAD + HANDMADE_BAD_CPU:      # rejected by libzstd 1.5.7
         with pytest.raises(Exception):
             zko.frame_decode(frame, dsize, True)
         if Z.load("1.5.7") is not None:

@@ -127,6 +127,39 @@ for name, c in CASES.items():
                  "output_zlib": None if len(c["output"]) < 4096 else __import__("base64").b64encode(__import__("zlib").compress(c["output"], 9)).decode(),
                  "note": c["note"],
                  "accepted_by": "libzstd 1.5.7 and the distro libzstd of the build container (ZSTD_decompressStream)"}
+# ---- damaged variants of rle_seq_tables: each must be corruption_detected (20) in libzstd 1.5.7 (one-shot ZSTD_decompress,
+#      code read with ZSTD_getErrorCode).  Checked on the CPU only (oracle + simulation of the device code): "cpu_only".
+import ctypes as C
+_l = Z.load("1.5.7")
+_l.ZSTD_decompress.restype = C.c_size_t
+_l.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+_l.ZSTD_getErrorCode.restype = C.c_int
+_l.ZSTD_getErrorCode.argtypes = [C.c_size_t]
+
+
+def verdict(fr):
+    buf = C.create_string_buffer(1 << 16)
+    r = _l.ZSTD_decompress(buf, len(buf), fr, len(fr))
+    return _l.ZSTD_getErrorCode(r) if _l.ZSTD_isError(r) else 0
+
+
+SEQ3 = bytes([3, 0x54, 2, 0, 1]) + b"\x01"
+LIT6 = raw_literals(b"abcdef")
+NEG = {
+    "fcs_too_big": frame(19, LIT6 + SEQ3),
+    "fcs_too_small": frame(17, LIT6 + SEQ3),
+    "literals_exhausted": frame(18, raw_literals(b"abc") + SEQ3),
+    "bitstream_not_consumed": frame(18, LIT6 + bytes([3, 0x54, 2, 0, 1]) + b"\x00\x01"),
+    "bitstream_zero_last_byte": frame(18, LIT6 + bytes([3, 0x54, 2, 0, 1]) + b"\x00"),
+    "rle_symbol_out_of_range": frame(18, LIT6 + bytes([3, 0x54, 36, 0, 1]) + b"\x01"),
+    "modes_reserved_bits": frame(18, LIT6 + bytes([3, 0x55, 2, 0, 1]) + b"\x01"),
+}
+_f = bytearray(frame(18, LIT6 + SEQ3)); _f[6] |= 0x06
+NEG["block_type_reserved"] = bytes(_f)
+for name, fr in NEG.items():
+    assert verdict(fr) == 20, (name, verdict(fr))
+    out[name] = {"frame": fr.hex(), "error": True, "error_code": 20, "content_size": fr[5], "cpu_only": True,
+                 "note": "damaged variant of rle_seq_tables", "rejected_by": "libzstd 1.5.7 (corruption_detected)"}
 with open(os.path.join(ROOT, "tests", "golden", "handmade.json"), "w") as f:
     json.dump(out, f, indent=1)
 print("wrote", len(out), "frames")
