@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ZK_ABI_VERSION 1
+#define ZK_ABI_VERSION 2
 
 /* zeekstd error kinds (lib/src/error.rs:101-113) that are not ZSTD_ErrorCode values */
 #define ZK_ERR_OFFSET_OUT_OF_RANGE (-1001)
@@ -164,6 +164,15 @@ int zk_encode_frames_prefix(zk_engine *e, const uint8_t *src, uint64_t n, uint32
                             const uint8_t *prefix, uint64_t prefix_len, uint8_t *dst, uint64_t dst_cap, uint32_t *c_sizes,
                             uint32_t *d_sizes, uint32_t frames_cap, uint32_t *n_frames_out, uint64_t *written_out);
 
+/* Host memory the host-pointer entry points above move by DMA directly (pinned; hipHostMalloc underneath).  Buffers from
+ * anywhere else work too: they are staged through the engine's own pinned rings by worker threads, chunk by chunk, beside
+ * the kernels (the reference streams through 128 KiB buffers at no copy cost, lib/src/encode.rs:779-787,
+ * decode.rs:222-225; on a GPU the PCIe legs are part of the path and are overlapped instead). */
+void *zk_host_alloc(size_t bytes);
+void zk_host_free(void *p);
+/* worker threads of the host pipeline (parallel staging copies); 0 = default (hardware threads / 8, clamped to 2..16) */
+int zk_engine_set_host_threads(zk_engine *e, int n);
+
 /* XXH64(seed 0) of count byte ranges data[off[i], off[i+1]) -> out[i].  (The checksum libzstd
  * computes when ZSTD_c_checksumFlag is set: encode.rs:163-167, 283-284.) */
 int zk_xxh64_frames(zk_engine *e, const uint8_t *data, const uint64_t *off, uint32_t count, uint64_t *out);
@@ -234,6 +243,14 @@ typedef struct zk_decode_opts {          /* DecodeOptions builder fields, decode
  * The byte source is borrowed and must outlive the decoder (BytesWrapper<'a>). */
 int zk_decoder_open_bytes(zk_engine *e, const uint8_t *src, size_t len, const zk_decode_opts *o, zk_decoder **out);
 int zk_decoder_open_file(zk_engine *e, const char *path, const zk_decode_opts *o, zk_decoder **out);   /* Read+Seek source, seekable.rs:112-138 */
+/* Any `impl Seekable` of the host (lib/src/seekable.rs:16-39: set_offset + read; seek_table_integrity is the trait's provided
+ * method and is derived from the two).  set_offset: whence 0 = OffsetFrom::Start(value), 1 = OffsetFrom::End(value); returns
+ * the new position counted from the start, or a negative value on failure.  read: bytes delivered (0 = end of source), or
+ * negative on failure.  Failures surface as ZK_ERR_IO.  The engine pulls compressed bytes through `read` straight into its
+ * pinned staging buffers; calls come from the thread that calls the decoder. */
+typedef int64_t (*zk_seek_fn)(void *user, int whence, int64_t value);
+typedef int64_t (*zk_read_fn)(void *user, uint8_t *buf, size_t len);
+int zk_decoder_open_callbacks(zk_engine *e, zk_seek_fn set_offset, zk_read_fn read, void *user, const zk_decode_opts *o, zk_decoder **out);
 void zk_decoder_free(zk_decoder *d);
 int64_t zk_decoder_decompress(zk_decoder *d, uint8_t *buf, size_t len);                        /* :314; bytes written or <0 */
 int zk_decoder_decompress_with_prefix(zk_decoder *d, uint8_t *buf, size_t len, const uint8_t *prefix, size_t plen, size_t *out); /* :201 */

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_names():
     import zeekstd_amd as zk
-    assert zk.lib.zk_abi_version() == 1
+    assert zk.lib.zk_abi_version() == 2
     assert zk.error_name(-20) == "Data corruption detected"      # ZSTD_getErrorName strings (error.rs:68)
     assert zk.error_name(-22) == "Restored data doesn't match checksum"
     assert zk.error_name(-1001) == "offset out of range"          # error.rs:60-71

@@ -55,6 +55,9 @@ _sig = {
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), _P]),
     "zk_decode_frame_list_dev": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, _P, C.c_uint64, C.c_int, _P, _P]),
     "zk_xxh64_frames": (C.c_int, [_P, _P, _P, C.c_uint32, _P]),
+    "zk_host_alloc": (_P, [C.c_size_t]),
+    "zk_host_free": (None, [_P]),
+    "zk_engine_set_host_threads": (C.c_int, [_P, C.c_int]),
     "zk_xxh64_frames_dev": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
 }
 for _name, (_res, _args) in _sig.items():

@@ -73,6 +73,7 @@ for _n, _r, _a in [
     ("zk_serializer_reset", None, [_P]), ("zk_serializer_encoded_len", C.c_size_t, [_P]), ("zk_serializer_free", None, [_P]),
     ("zk_decoder_open_bytes", C.c_int, [_P, _P, C.c_size_t, C.POINTER(zk_decode_opts), C.POINTER(_P)]),
     ("zk_decoder_open_file", C.c_int, [_P, C.c_char_p, C.POINTER(zk_decode_opts), C.POINTER(_P)]),
+    ("zk_decoder_open_callbacks", C.c_int, [_P, _P, _P, _P, C.POINTER(zk_decode_opts), C.POINTER(_P)]),
     ("zk_decoder_free", None, [_P]),
     ("zk_decoder_decompress", C.c_int64, [_P, _P, C.c_size_t]),
     ("zk_decoder_decompress_with_prefix", C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -261,6 +262,10 @@ class DecodeOptions:                   # decode.rs:13-114
         return Decoder(self)
 
 
+_SEEK_FN = C.CFUNCTYPE(C.c_int64, _P, C.c_int, C.c_int64)
+_READ_FN = C.CFUNCTYPE(C.c_int64, _P, _P, C.c_size_t)
+
+
 class Decoder:                         # decode.rs:117-579
     def __init__(self, src_or_opts):
         opts = src_or_opts if isinstance(src_or_opts, DecodeOptions) else DecodeOptions(src_or_opts)
@@ -272,6 +277,26 @@ class Decoder:                         # decode.rs:117-579
         if isinstance(opts._src, (str,)):
             rc = lib.zk_decoder_open_file(e, opts._src.encode(), C.byref(opts._o), C.byref(h))
             self._keep = None
+        elif hasattr(opts._src, "read") and hasattr(opts._src, "seek"):
+            # any Read + Seek object: the blanket `impl<T: Read + Seek> Seekable for T` (seekable.rs:112-138) through the
+            # callback source of the C ABI
+            f = opts._src
+
+            def _seek(_user, whence, value):
+                try:
+                    return f.seek(value, 0 if whence == 0 else 2)
+                except Exception:
+                    return -1
+
+            def _read(_user, buf, n):
+                try:
+                    b = f.read(n)
+                    C.memmove(buf, b, len(b))
+                    return len(b)
+                except Exception:
+                    return -1
+            self._keep = (f, _SEEK_FN(_seek), _READ_FN(_read))
+            rc = lib.zk_decoder_open_callbacks(e, self._keep[1], self._keep[2], None, C.byref(opts._o), C.byref(h))
         else:
             self._keep = bytes(opts._src)          # the source must outlive the decoder
             rc = lib.zk_decoder_open_bytes(e, self._keep, len(self._keep), C.byref(opts._o), C.byref(h))

@@ -131,6 +131,13 @@ int zk_decoder_open_file(zk_engine *e, const char *path, const zk_decode_opts *o
     });
 }
 
+int zk_decoder_open_callbacks(zk_engine *e, zk_seek_fn set_offset, zk_read_fn read, void *user, const zk_decode_opts *o, zk_decoder **out)
+{
+    if (!out || !set_offset || !read) return ZK_ERR_ARGUMENT;
+    *out = nullptr;
+    return guard([&] { *out = new zk_decoder(Decoder(make_opts(std::make_shared<CallbackSeekable>(set_offset, read, user), e, o))); });
+}
+
 void zk_decoder_free(zk_decoder *d) { delete d; }
 int64_t zk_decoder_decompress(zk_decoder *d, uint8_t *buf, size_t len)
 {

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include "../../../include/zeekstd_amd.h"
 #include "zeekstd.hpp"
+#include "../zk_engine.h"
 
 namespace zeekstd {
 
@@ -36,7 +37,8 @@ RawEncoder::~RawEncoder() { if (owns_engine_ && engine_) zk_engine_destroy(engin
 RawEncoder::RawEncoder(RawEncoder &&o) noexcept
     : engine_(o.engine_), owns_engine_(o.owns_engine_), policy_(o.policy_), checksum_(o.checksum_), level_(o.level_),
       frame_c_size_(o.frame_c_size_), frame_d_size_(o.frame_d_size_), seek_table_(std::move(o.seek_table_)),
-      frame_in_(std::move(o.frame_in_)), pending_(std::move(o.pending_)), pending_pos_(o.pending_pos_), encoded_(o.encoded_)
+      frame_in_(std::move(o.frame_in_)), pending_(std::move(o.pending_)), pending_pos_(o.pending_pos_), encoded_(o.encoded_),
+      next_probe_(o.next_probe_), frame_prefix_(o.frame_prefix_), frame_prefix_len_(o.frame_prefix_len_)
 {
     o.engine_ = nullptr; o.owns_engine_ = false;
 }
@@ -129,9 +131,25 @@ Encoder::Encoder(std::shared_ptr<Writer> writer, EncodeOptions &&opts)         /
 {
 }
 
+Encoder::~Encoder() { if (batch_in_) zk_host_free(batch_in_); }
+
+Encoder::Encoder(Encoder &&o) noexcept
+    : raw_(std::move(o.raw_)), writer_(std::move(o.writer_)), out_buf_(std::move(o.out_buf_)), out_buf_pos_(o.out_buf_pos_),
+      written_compressed_(o.written_compressed_), batch_frames_(o.batch_frames_), since_end_(o.since_end_), batch_in_(o.batch_in_),
+      batch_len_(o.batch_len_), batch_cap_(o.batch_cap_), batch_prefix_(o.batch_prefix_), batch_prefix_len_(o.batch_prefix_len_)
+{
+    o.batch_in_ = nullptr; o.batch_len_ = o.batch_cap_ = 0;
+}
+
 void Encoder::emit(const uint8_t *p, size_t n)                                 // through the staging buffer, like encode.rs:641-665
 {
     while (n) {
+        // a large piece with nothing staged goes to the writer as it is (same byte stream, fewer write_all calls)
+        if (out_buf_pos_ == 0 && n >= out_buf_.size()) {
+            writer_->write_all(p, n);
+            written_compressed_ += n;
+            return;
+        }
         const size_t k = std::min(n, out_buf_.size() - out_buf_pos_);
         memcpy(out_buf_.data() + out_buf_pos_, p, k);
         out_buf_pos_ += k; p += k; n -= k;
@@ -148,26 +166,59 @@ void Encoder::flush_out_buf(bool force)                                        /
     }
 }
 
+void Encoder::batch_append(const uint8_t *p, size_t n)
+{
+    if (batch_len_ + n > batch_cap_) {
+        size_t want = std::max<size_t>(batch_len_ + n, batch_cap_ * 2);
+        want = std::max<size_t>(want, 1u << 20);
+        uint8_t *q = (uint8_t *)zk_host_alloc(want);     // pinned: the engine uploads it by DMA without staging
+        if (!q) throw std::bad_alloc();
+        if (batch_len_) memcpy(q, batch_in_, batch_len_);
+        if (batch_in_) zk_host_free(batch_in_);
+        batch_in_ = q; batch_cap_ = want;
+    }
+    if (n >= (8u << 20)) zk_host_copy(raw_.engine_, batch_in_ + batch_len_, p, n);
+    else memcpy(batch_in_ + batch_len_, p, n);
+    batch_len_ += n;
+}
+
+// what the engine's host pipeline hands back per chunk: compressed bytes (in order), then the chunk's seek entries
+int Encoder::sink(void *user, const uint8_t *data, uint64_t n, const uint32_t *c_sizes, const uint32_t *d_sizes, uint32_t n_frames)
+{
+    Encoder *self = (Encoder *)user;
+    try {
+        if (n) self->emit(data, (size_t)n);
+        for (uint32_t i = 0; i < n_frames; i++) self->raw_.seek_table_.log_frame(c_sizes[i], d_sizes[i]);
+    } catch (...) { self->sink_error_ = std::current_exception(); return 1; }
+    return 0;
+}
+
+// Encode src[0, take) (whole frames of fs bytes, the last one possibly short) with one pipelined engine call.
+void Encoder::encode_span(const uint8_t *src, size_t take)
+{
+    const uint32_t fs = std::min(MAX_FRAME_SIZE, raw_.policy_.size);
+    const void *d_prefix = nullptr;
+    const uint64_t tail = batch_prefix_ ? std::min<uint64_t>(batch_prefix_len_, ZKE_WINDOW) : 0;    // what the matcher can reach
+    int rc = zk_engine_stage_prefix(raw_.engine_, this, tail ? batch_prefix_ + (batch_prefix_len_ - tail) : nullptr, tail, prefix_dirty_, &d_prefix);
+    if (rc != 0) throw Error::from_engine_code(rc, zk_engine_last_hip_error(raw_.engine_));
+    prefix_dirty_ = false;
+    sink_error_ = nullptr;
+    rc = zk_host_encode(raw_.engine_, src, take, fs, raw_.level_, raw_.checksum_ ? 1 : 0, d_prefix, tail, &Encoder::sink, this);
+    if (sink_error_) std::rethrow_exception(sink_error_);
+    if (rc != 0) throw Error::from_engine_code(rc, zk_engine_last_hip_error(raw_.engine_));
+}
+
 // Encode the complete frames gathered so far (and the partial tail frame if asked) with one submission.
 void Encoder::submit_batch(bool include_partial)
 {
     const uint32_t fs = std::min(MAX_FRAME_SIZE, raw_.policy_.size);
     // without include_partial the trailing frame stays behind, full or not: it is still open upstream
-    size_t take = batch_in_.empty() ? 0 : ((batch_in_.size() - 1) / fs) * (size_t)fs;
-    if (include_partial) take = batch_in_.size();
+    size_t take = batch_len_ == 0 ? 0 : ((batch_len_ - 1) / fs) * (size_t)fs;
+    if (include_partial) take = batch_len_;
     if (take == 0 && !include_partial) return;
-    std::vector<uint8_t> out((size_t)zk_compress_bound(take, fs));
-    const size_t nf_cap = take == 0 ? 1 : (take + fs - 1) / fs;
-    std::vector<uint32_t> c(nf_cap), d(nf_cap);
-    uint32_t nf = 0;
-    uint64_t written = 0;
-    int rc = zk_encode_frames_prefix(raw_.engine_, batch_in_.data(), take, fs, raw_.level_, raw_.checksum_ ? 1 : 0, batch_prefix_,
-                                     batch_prefix_ ? batch_prefix_len_ : 0, out.data(), out.size(), c.data(), d.data(), (uint32_t)nf_cap,
-                                     &nf, &written);
-    if (rc != 0) throw Error::from_engine_code(rc, zk_engine_last_hip_error(raw_.engine_));
-    emit(out.data(), (size_t)written);
-    for (uint32_t i = 0; i < nf; i++) raw_.seek_table_.log_frame(c[i], d[i]);
-    batch_in_.erase(batch_in_.begin(), batch_in_.begin() + (ptrdiff_t)take);
+    encode_span(batch_in_, take);
+    if (take < batch_len_) memmove(batch_in_, batch_in_ + take, batch_len_ - take);
+    batch_len_ -= take;
 }
 
 size_t Encoder::compress_with_prefix(const uint8_t *buf, size_t len, const uint8_t *prefix, size_t prefix_len)   // encode.rs:641-665
@@ -187,31 +238,42 @@ size_t Encoder::compress_with_prefix(const uint8_t *buf, size_t len, const uint8
         return input_progress;
     }
     const uint32_t fs = std::min(MAX_FRAME_SIZE, raw_.policy_.size);
+    const size_t total_len = len;
     // A batch is encoded against ONE prefix.  Upstream a new prefix takes effect at the next frame start
     // (encode.rs:334-338); the frames gathered so far began under the old one, so they are cut and submitted first:
     // complete frames as they are, and the open frame is filled up to its boundary from this call's bytes.
-    if (!batch_in_.empty() && (prefix != batch_prefix_ || prefix_len != batch_prefix_len_)) {
-        const size_t open = batch_in_.size() % fs;
+    if (batch_len_ && (prefix != batch_prefix_ || prefix_len != batch_prefix_len_)) {
+        const size_t open = batch_len_ % fs;
         const size_t fill = open ? std::min<size_t>(len, fs - open) : 0;
-        batch_in_.insert(batch_in_.end(), buf, buf + fill);
+        batch_append(buf, fill);
         since_end_ += fill;
-        if (fill == len && batch_in_.size() % fs) return len;                    // still inside the old frame: nothing switches yet
-        const bool partial_tail = batch_in_.size() % fs != 0;
-        (void)partial_tail;
+        if (fill == len && batch_len_ % fs) return len;                         // still inside the old frame: nothing switches yet
         submit_batch(true);                                                     // every gathered frame is complete here
         buf += fill; len -= fill;
-        batch_prefix_ = prefix; batch_prefix_len_ = prefix_len;
-        batch_in_.insert(batch_in_.end(), buf, buf + len);
-        since_end_ += len;
-        if (batch_in_.size() > (size_t)fs * batch_frames_) submit_batch(false);
-        return fill + len;
     }
-    if (batch_in_.empty()) { batch_prefix_ = prefix; batch_prefix_len_ = prefix_len; }
-    batch_in_.insert(batch_in_.end(), buf, buf + len);
+    if (batch_len_ == 0 && (prefix != batch_prefix_ || prefix_len != batch_prefix_len_)) {
+        batch_prefix_ = prefix; batch_prefix_len_ = prefix_len; prefix_dirty_ = true;
+    }
     since_end_ += len;
+    // A large write is encoded where it lies: the open frame is completed from it, then every whole frame but the last goes
+    // to the engine straight from the caller's buffer (chunked and overlapped with the PCIe legs inside the engine); only the
+    // last frame -- still open upstream until the next call (encode.rs:317-327) -- is copied into the batch buffer.
+    if (len >= (size_t)fs * 4 || len >= (64u << 20)) {
+        if (batch_len_) {
+            const size_t fill = (fs - batch_len_ % fs) % fs;
+            batch_append(buf, fill);
+            buf += fill; len -= fill;
+            submit_batch(true);
+        }
+        const size_t take = ((len - 1) / fs) * (size_t)fs;
+        if (take) encode_span(buf, take);
+        batch_append(buf + take, len - take);
+        return total_len;
+    }
+    batch_append(buf, len);
     // the last full frame stays open (upstream closes it on the NEXT call), so it is held back
-    if (batch_in_.size() > (size_t)fs * batch_frames_) submit_batch(false);
-    return len;
+    if (batch_len_ > (size_t)fs * batch_frames_) submit_batch(false);
+    return total_len;
 }
 
 size_t Encoder::end_frame()                                                    // encode.rs:704-717
@@ -227,7 +289,7 @@ size_t Encoder::end_frame()                                                    /
             flush_out_buf(false);
             if (p.data_left() == 0) break;
         }
-    } else if (since_end_ == 0 || !batch_in_.empty()) submit_batch(true);
+    } else if (since_end_ == 0 || batch_len_) submit_batch(true);
     since_end_ = 0;
     return (size_t)(written_compressed_ + out_buf_pos_ - before);
 }

@@ -78,6 +78,36 @@ std::array<uint8_t, SEEK_TABLE_INTEGRITY_SIZE> BytesWrapper::seek_table_integrit
     return a;
 }
 
+// ---------------------------------------------------------------- CallbackSeekable (the trait itself, seekable.rs:16-39)
+uint64_t CallbackSeekable::set_offset(OffsetFrom offset)
+{
+    const int64_t r = so_(user_, offset.from == OffsetFrom::From::Start ? 0 : 1, offset.value);
+    if (r < 0) throw Error::io("set_offset callback failed");
+    return (uint64_t)r;
+}
+
+size_t CallbackSeekable::read(uint8_t *buf, size_t len)
+{
+    const int64_t r = rd_(user_, buf, len);
+    if (r < 0 || (uint64_t)r > len) throw Error::io("read callback failed");
+    return (size_t)r;
+}
+
+// the trait's provided method (seekable.rs:29-38): position at the integrity field, read_exact 9 bytes
+std::array<uint8_t, SEEK_TABLE_INTEGRITY_SIZE> CallbackSeekable::seek_table_integrity(Format format)
+{
+    if (format == Format::Head) set_offset(OffsetFrom::Start(SKIPPABLE_HEADER_SIZE));
+    else set_offset(OffsetFrom::End(-(int64_t)SEEK_TABLE_INTEGRITY_SIZE));
+    std::array<uint8_t, SEEK_TABLE_INTEGRITY_SIZE> a;
+    size_t got = 0;
+    while (got < a.size()) {
+        size_t n = read(a.data() + got, a.size() - got);
+        if (n == 0) throw Error::io("failed to fill whole buffer");
+        got += n;
+    }
+    return a;
+}
+
 // ---------------------------------------------------------------- FileSeekable (seekable.rs:112-138)
 uint64_t FileSeekable::set_offset(OffsetFrom offset)
 {

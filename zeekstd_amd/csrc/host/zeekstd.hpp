@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <array>
+#include <exception>
 #include <memory>
 #include <optional>
 #include <string>
@@ -72,6 +73,8 @@ public:
     virtual uint64_t set_offset(OffsetFrom offset) = 0;
     virtual size_t read(uint8_t *buf, size_t len) = 0;
     virtual std::array<uint8_t, SEEK_TABLE_INTEGRITY_SIZE> seek_table_integrity(Format format) = 0;
+    // engine-specific: a source that is one contiguous byte range says so, and the host pipeline reads it in place
+    virtual const uint8_t *contiguous(size_t *len) const { (void)len; return nullptr; }
 };
 
 class BytesWrapper : public Seekable {                              // seekable.rs:43-97
@@ -80,10 +83,28 @@ public:
     uint64_t set_offset(OffsetFrom offset) override;
     size_t read(uint8_t *buf, size_t len) override;
     std::array<uint8_t, SEEK_TABLE_INTEGRITY_SIZE> seek_table_integrity(Format format) override;
+    const uint8_t *contiguous(size_t *len) const override { *len = len_; return src_; }
 
 private:
     const uint8_t *src_;
     size_t len_, pos_;
+};
+
+// A Seekable made of three callbacks: what a host in another language plugs its own `impl Seekable` into
+// (seekable.rs:16-39; zk_decoder_open_callbacks of the C ABI).  whence: 0 = from the start, 1 = from the end.
+class CallbackSeekable : public Seekable {
+public:
+    typedef int64_t (*set_offset_fn)(void *user, int whence, int64_t value);      // new position from the start, or < 0
+    typedef int64_t (*read_fn)(void *user, uint8_t *buf, size_t len);             // bytes read (0 = end), or < 0
+    CallbackSeekable(set_offset_fn so, read_fn rd, void *user) : so_(so), rd_(rd), user_(user) {}
+    uint64_t set_offset(OffsetFrom offset) override;
+    size_t read(uint8_t *buf, size_t len) override;
+    std::array<uint8_t, SEEK_TABLE_INTEGRITY_SIZE> seek_table_integrity(Format format) override;
+
+private:
+    set_offset_fn so_;
+    read_fn rd_;
+    void *user_;
 };
 
 // The blanket `impl<T: Read + Seek> Seekable for T` (seekable.rs:112-138), for stdio files.
@@ -213,7 +234,9 @@ public:
 private:
     void check_offset(uint64_t offset) const;                                        // :439-445
     void reset_dctx();                                                               // :352-357
-    void fill_cache(uint64_t want_end, const uint8_t *prefix, size_t prefix_len);
+    void fill_cache(uint64_t want_end, uint64_t request_end, const uint8_t *prefix, size_t prefix_len);
+    void check_frames(uint32_t first, uint32_t count) const;
+    uint32_t decode_range(uint32_t first, uint32_t count, uint8_t *dst, uint64_t dst_cap, const uint8_t *prefix, size_t prefix_len, uint32_t *err);
     const uint8_t *cache_prefix_ = nullptr; size_t cache_prefix_len_ = 0;           // the prefix the cached frames were decoded with
     zk_engine *engine_ = nullptr;
     bool owns_engine_ = false;
@@ -223,10 +246,13 @@ private:
     uint64_t batch_bytes_ = 64ull << 20;
     bool verify_ = true;
     // decoded frames [cache_first_, cache_first_ + cache_count_) live in cache_
-    std::vector<uint8_t> cache_, comp_buf_;
+    // (pinned host memory: the engine's D2H lands in it without staging)
+    uint8_t *cache_ = nullptr; size_t cache_cap_ = 0;
     uint32_t cache_first_ = 0, cache_count_ = 0;
     uint64_t cache_d_start_ = 0, cache_d_end_ = 0;
-    uint64_t last_end_ = ~0ull;                // where the previous decompress call stopped (sequential-read detection)
+    uint64_t cache_unverified_end_ = 0;        // end offset of a cached frame whose checksum went unchecked (cut by offset_limit), or 0
+    uint64_t unverified_end_tmp_ = 0;
+    bool prefix_dirty_ = true;                 // the engine's staged copy of the prefix must be refreshed
     uint64_t submissions_ = 0;
 };
 
@@ -329,6 +355,9 @@ class Encoder {                                                                 
 public:
     explicit Encoder(std::shared_ptr<Writer> writer);                                // new, :587
     Encoder(std::shared_ptr<Writer> writer, EncodeOptions &&opts);                   // with_opts, :596
+    ~Encoder();
+    Encoder(Encoder &&) noexcept;
+    Encoder(const Encoder &) = delete;
     const SeekTable &seek_table() const { return raw_.seek_table_; }                 // :610
     uint64_t written_compressed() const { return written_compressed_; }              // :615
     SeekTable into_seek_table() { return raw_.into_seek_table(); }                   // :620
@@ -342,6 +371,9 @@ public:
 
 private:
     void submit_batch(bool include_partial);
+    void encode_span(const uint8_t *src, size_t take);
+    void batch_append(const uint8_t *p, size_t n);
+    static int sink(void *user, const uint8_t *data, uint64_t n, const uint32_t *c_sizes, const uint32_t *d_sizes, uint32_t n_frames);
     void emit(const uint8_t *p, size_t n);
     void flush_out_buf(bool force);                                                  // :779-787
     RawEncoder raw_;
@@ -351,9 +383,12 @@ private:
     uint64_t written_compressed_ = 0;
     uint32_t batch_frames_ = 64;
     uint64_t since_end_ = 0;                  // bytes accepted since the last end_frame
-    std::vector<uint8_t> batch_in_;           // whole frames (+ the partial one at the tail) awaiting submission
+    uint8_t *batch_in_ = nullptr;             // whole frames (+ the partial one at the tail) awaiting submission (pinned)
+    size_t batch_len_ = 0, batch_cap_ = 0;
     const uint8_t *batch_prefix_ = nullptr;   // the prefix the frames in batch_in_ began with
     size_t batch_prefix_len_ = 0;
+    bool prefix_dirty_ = true;                // the engine's staged copy of the prefix must be refreshed
+    std::exception_ptr sink_error_;           // a writer failure inside the engine's sink callback
 };
 
 }  // namespace zeekstd

@@ -25,9 +25,12 @@
 
 // ------------------------------------------------------------------------------------------------ walk
 // ids != nullptr: frame f of the batch is frame ids[f] of the archive (random-access batches: many seeks per submission)
-__global__ __launch_bounds__(64) void zk_k_walk(const uint8_t *comp, const uint64_t *c_off, const uint64_t *d_off,
-                                                uint32_t first, uint32_t count, const uint32_t *ids, const ZkFrameBase *bases,
-                                                ZkBlock *blocks, ZkFrameInfo *infos)
+// comp_size / dst_cap (the sizes the caller vouches for): a frame whose compressed range leaves the buffer, or whose output
+// range leaves the destination, is flagged (srcSize_wrong / dstSize_tooSmall) and contributes no work -- offset tables
+// that do not come from a SeekTable (arbitrary caller arrays) cannot drive reads or writes out of bounds.
+__global__ __launch_bounds__(64) void zk_k_walk(const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off, const uint64_t *d_off,
+                                                uint32_t first, uint32_t count, const uint32_t *ids, const uint64_t *out_off, uint64_t dst_cap,
+                                                const ZkFrameBase *bases, ZkBlock *blocks, ZkFrameInfo *infos)
 {
     uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= count) return;
@@ -36,7 +39,16 @@ __global__ __launch_bounds__(64) void zk_k_walk(const uint8_t *comp, const uint6
     uint64_t dsz = d_off[id + 1] - d_off[id];
     ZkFrameInfo fi;
     if (!bases) {                                   // pass 1: count
+        const uint64_t o = out_off ? out_off[f] : d_off[id] - d_off[first];
+        if (ce < cb || ce > comp_size || d_off[id + 1] < d_off[id]) {
+            fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; fi.status = ZK_E_SRC_SIZE_WRONG;
+            fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.n_own_tables = 0;
+            infos[f] = fi;
+            return;
+        }
         zk_walk_frame(comp, cb, ce, dsz, f, nullptr, nullptr, fi);
+        if (fi.status == ZK_OK && (d_off[id] < d_off[first] && !out_off)) fi.status = ZK_E_SRC_SIZE_WRONG;
+        if (fi.status == ZK_OK && (o > dst_cap || dsz > dst_cap - o)) fi.status = ZK_E_DST_TOO_SMALL;
         if (dsz > ZK_MAX_FRAME && fi.status == ZK_OK) fi.status = ZK_E_FRAMEPARAM_UNSUPPORTED;
         if (fi.status != ZK_OK) { fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; }   // contributes no work
         infos[f] = fi;
@@ -731,10 +743,10 @@ void zk_launch_status(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, 
 {
     hipLaunchKernelGGL(zk_k_status, dim3((count + 255) / 256), dim3(256), 0, st, infos, count, status_out, (unsigned long long *)first_err);
 }
-void zk_launch_walk(hipStream_t st, const uint8_t *comp, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
-                    uint32_t count, const uint32_t *ids, const ZkFrameBase *bases, ZkBlock *blocks, ZkFrameInfo *infos)
+void zk_launch_walk(hipStream_t st, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
+                    uint32_t count, const uint32_t *ids, const uint64_t *out_off, uint64_t dst_cap, const ZkFrameBase *bases, ZkBlock *blocks, ZkFrameInfo *infos)
 {
-    hipLaunchKernelGGL(zk_k_walk, dim3((count + 63) / 64), dim3(64), 0, st, comp, c_off, d_off, first, count, ids, bases, blocks, infos);
+    hipLaunchKernelGGL(zk_k_walk, dim3((count + 63) / 64), dim3(64), 0, st, comp, comp_size, c_off, d_off, first, count, ids, out_off, dst_cap, bases, blocks, infos);
 }
 void zk_launch_scan(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals)
 {

@@ -14,6 +14,20 @@ constexpr uint32_t ZKE_LSTEP = 2;                 // tiles per lookup step (one 
 constexpr uint32_t ZKE_PARCAP = 64;
 constexpr uint32_t ZKE_GROUP = 8;                // tiles parsed side by side, one wave each
 
+// Block size the encoder cuts a frame of d_size bytes into.  Blocks are cut smaller than the format's maximum on purpose:
+// a block's sequence bitstream is one serial chain for the decoder, so more, shorter blocks = more parallel chains
+// (32 KiB for large frames, >= 8 blocks per small frame, never below 4 KiB).
+ZK_HD uint32_t zke_block_max(uint32_t d_size, bool prefix)
+{
+    uint32_t wlog = 10;
+    while ((1u << wlog) < d_size && wlog < 17) wlog++;
+    if (prefix) wlog = 17;
+    uint32_t bm = (1u << wlog) < ZKE_BLOCK ? (1u << wlog) : ZKE_BLOCK;
+    uint32_t t = 32768;
+    while (t > 4096 && (uint64_t)t * 8 > d_size) t >>= 1;
+    return t < bm ? t : bm;
+}
+
 struct ZkEncFrame {
     uint64_t src_off;           // where the frame's input starts in the source buffer
     uint32_t d_size;            // uncompressed bytes

@@ -30,8 +30,14 @@ struct zk_engine {
     int next_slot = 0;
     // staging for the host-pointer entry points
     zk_devbuf st_comp, st_off, st_dst, st_misc;
-    zk_devbuf st_prefix;                    // staged prefix of zk_decode_frames_prefix / zk_encode_frames_prefix, kept between calls
-    const void *st_prefix_src = nullptr; uint64_t st_prefix_len = 0, st_prefix_fp = 0;
+    // staged device copy of a raw-content prefix.  The host-pointer Level-A calls upload it on EVERY call (no caching by
+    // address: a caller may reuse one buffer for different bases).  A zeekstd::Decoder / Encoder, whose contract is the
+    // reference's borrow ("the prefix stays unchanged while it is referenced", decode.rs:201), keeps its upload across its
+    // own calls through zk_engine_stage_prefix: owner + address + length name the staged bytes.
+    zk_devbuf st_prefix;
+    const void *st_prefix_owner = nullptr, *st_prefix_src = nullptr; uint64_t st_prefix_len = 0;
+    struct zk_hostpipe *hp = nullptr;       // host-pointer pipeline (pinned staging, copy queues, worker threads): zk_engine_host.hip
+    int host_threads = 0;                   // zk_engine_set_host_threads (0 = default)
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool profiling = false;
     int fse_kernel = 0;              // zk_engine_set_fse_kernel
@@ -39,13 +45,62 @@ struct zk_engine {
     bool ev_used[ZK_NKERNELS] = {};
     float kernel_ms[ZK_NKERNELS] = {};
     // encode scratch
-    zk_devbuf enc_a, enc_b, enc_c, enc_d;
+    zk_devbuf enc_a, enc_b, enc_c, enc_d, enc_e;
+    void *enc_pin = nullptr; size_t enc_pin_cap = 0;   // pinned host copy of the frame / block lists of the encode in flight
     zk_devbuf enc_hist;                     // prefix mode: [prefix tail | frame] records for the matcher
     ZkEncTables enc_tables;
     bool enc_tables_ready = false;
 };
 
 int zk_devbuf_reserve(zk_engine *e, zk_devbuf &b, size_t bytes);
+
+// ---- decode plumbing shared by zk_engine.hip (device-pointer entry points) and zk_engine_host.hip (host pipeline)
+struct zk_dec_ctx {
+    hipStream_t st, aux; hipEvent_t ev_fork, ev_join;
+    zk_devbuf &infos, &bases, &words, &blocks, &seqs, &lit;
+    uint64_t *h_words;
+};
+struct zk_dec_args {
+    const void *d_comp; uint64_t comp_size; const void *d_c_off, *d_d_off; uint32_t first, count;
+    const uint32_t *ids; const uint64_t *out_off;       // frame list (device arrays, both or neither)
+    void *d_dst; uint64_t dst_cap; int verify; void *d_frame_status;
+    const void *d_prefix; uint64_t prefix_len;
+};
+zk_dec_ctx zk_dec_context(zk_engine *e, int slot, void *stream);
+int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a);
+int zk_decode_finish(zk_engine *e, zk_dec_ctx &c);
+void zk_hostpipe_destroy(zk_engine *e);
+enum { ZK_HW_ENC_TOTAL = 8 };               // index into zk_engine::h_words of the encoder's total-size read-back
+struct zk_enc_args {
+    const void *d_src; uint64_t n; uint32_t frame_size; int level, checksum;
+    const void *d_prefix; uint64_t prefix_len; void *d_dst; uint64_t dst_cap; void *d_c_sizes, *d_d_sizes;
+};
+int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32_t *nf_out);
+int zk_encode_finish(zk_engine *e, hipStream_t st, uint64_t *written_out);
+
+// ---- host pipeline, C++ face (the C ABI's host-pointer functions and the zeekstd:: host classes sit on these)
+// Where the compressed bytes of a host decode come from: contiguous memory, or a pull callback that delivers the n bytes
+// at payload offset `off` straight into pinned staging (Seekable sources: files, callbacks).  Returns bytes delivered.
+struct zk_host_src {
+    const uint8_t *mem = nullptr;
+    size_t (*read)(void *user, uint64_t off, uint8_t *dst, size_t n) = nullptr;
+    void *user = nullptr;
+};
+// Decode frames [first, first + count) into dst (frame `first` at dst[0]); c_off / d_off are the archive's prefix sums and
+// the source is addressed with them.  d_prefix: DEVICE copy of the raw-content prefix (or nullptr).  n_ok (optional):
+// number of leading frames that decoded fine (bytes of those frames in dst are valid even when the call fails).
+int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, const uint64_t *d_off, uint32_t first, uint32_t count,
+                   const void *d_prefix, uint64_t prefix_len, uint8_t *dst, uint64_t dst_cap, int verify, int32_t *frame_status,
+                   uint32_t *n_ok);
+// Encode src[0, n) as frames of frame_size bytes; every finished chunk of frames is handed to `sink` (pinned memory,
+// valid during the call): the compressed bytes and the chunk's seek entries.  sink returns 0 to go on.
+typedef int (*zk_host_sink)(void *user, const uint8_t *data, uint64_t n, const uint32_t *c_sizes, const uint32_t *d_sizes, uint32_t n_frames);
+int zk_host_encode(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_size, int level, int checksum, const void *d_prefix,
+                   uint64_t prefix_len, zk_host_sink sink, void *user);
+// Upload (or reuse) the device copy of a prefix on behalf of `owner`; returns the device pointer in *d_out.
+int zk_engine_stage_prefix(zk_engine *e, const void *owner, const uint8_t *prefix, uint64_t len, bool force, const void **d_out);
+// multi-threaded memcpy on the engine's worker threads (large host-side copies of the zeekstd:: classes)
+void zk_host_copy(zk_engine *e, void *dst, const void *src, size_t n);
 
 // RAII-free helper: brackets one launch with events when profiling is on
 struct zk_kernel_timer {

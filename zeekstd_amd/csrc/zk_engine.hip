@@ -136,9 +136,11 @@ extern "C" void zk_engine_destroy(zk_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+    zk_hostpipe_destroy(e);
+    if (e->enc_pin) (void)hipHostFree(e->enc_pin);
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
     zk_devbuf *bufs[] = {&e->infos, &e->bases, &e->words, &e->blocks, &e->seqs, &e->lit, &e->infos2, &e->bases2, &e->words2, &e->blocks2, &e->seqs2, &e->lit2, &e->st_prefix, &e->st_comp, &e->st_off, &e->st_dst, &e->st_misc,
-                         &e->enc_a, &e->enc_b, &e->enc_c, &e->enc_d, &e->enc_hist};
+                         &e->enc_a, &e->enc_b, &e->enc_c, &e->enc_d, &e->enc_e, &e->enc_hist};
     for (zk_devbuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (e->h_words) (void)hipHostFree(e->h_words);
     for (int k = 0; k < ZK_NKERNELS; k++) { if (e->ev_start[k]) (void)hipEventDestroy(e->ev_start[k]); if (e->ev_stop[k]) (void)hipEventDestroy(e->ev_stop[k]); }
@@ -159,30 +161,25 @@ extern "C" const char *zk_engine_device_name(const zk_engine *e) { return e ? e-
 
 // ---------------------------------------------------------------------------------------------- decode
 // ids / out_off (device arrays, both or neither): frame f of the batch is archive frame ids[f]; its bytes go to dst + out_off[f]
-// One decode in flight: queues, scratch and pinned read-back words.  Context 0 is the engine's own (synchronous entry
-// points, optionally on the caller's stream), context 1 exists for zk_decode_submit_dev.
-struct zk_dec_ctx {
-    hipStream_t st, aux; hipEvent_t ev_fork, ev_join;
-    zk_devbuf &infos, &bases, &words, &blocks, &seqs, &lit;
-    uint64_t *h_words;
-};
-static zk_dec_ctx zk_dec_context(zk_engine *e, int slot, void *stream)
+// One decode in flight per context: queues, scratch and pinned read-back words.  Context 0 is the engine's own (synchronous
+// entry points, optionally on the caller's stream), context 1 exists for zk_decode_submit_dev; the host-pointer pipeline
+// (zk_engine_host.hip) alternates between the two.
+zk_dec_ctx zk_dec_context(zk_engine *e, int slot, void *stream)
 {
     if (slot == 0) return zk_dec_ctx{stream ? (hipStream_t)stream : e->stream, e->aux, e->ev_fork, e->ev_join, e->infos, e->bases, e->words, e->blocks, e->seqs, e->lit, e->h_words};
     return zk_dec_ctx{e->stream2, e->aux2, e->ev_fork2, e->ev_join2, e->infos2, e->bases2, e->words2, e->blocks2, e->seqs2, e->lit2, e->h_words2};
 }
 
 // Enqueue the whole decode on the context's queues.  Blocks the host once, for the block / sequence / literal totals
-// that size the scratch (24 bytes, after the two cheapest kernels); returns with the rest still running.
-static int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const void *d_comp, const void *d_c_off, const void *d_d_off, uint32_t first, uint32_t count,
-                             const uint32_t *ids, const uint64_t *out_off, void *d_dst, int verify, void *d_frame_status,
-                             const void *d_prefix = nullptr, uint64_t prefix_len = 0)
+// that size the scratch (40 bytes, after the two cheapest kernels); returns with the rest still running.
+int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
 {
     // history positions are 32-bit words biased by 2^30 (zk_device.h): a frame plus its prefix must fit below that
-    if (d_prefix && prefix_len > ZK_MAX_PREFIX) return -(int)ZK_E_WINDOW_TOO_LARGE;
+    if (a.d_prefix && a.prefix_len > ZK_MAX_PREFIX) return -(int)ZK_E_WINDOW_TOO_LARGE;
     hipStream_t st = c.st;
-    const uint8_t *comp = (const uint8_t *)d_comp;
-    const uint64_t *c_off = (const uint64_t *)d_c_off, *d_off = (const uint64_t *)d_d_off;
+    const uint8_t *comp = (const uint8_t *)a.d_comp;
+    const uint64_t *c_off = (const uint64_t *)a.d_c_off, *d_off = (const uint64_t *)a.d_d_off;
+    const uint32_t first = a.first, count = a.count;
     int rc;
     if ((rc = zk_devbuf_reserve(e, c.infos, (size_t)count * sizeof(ZkFrameInfo)))) return rc;
     if ((rc = zk_devbuf_reserve(e, c.bases, (size_t)count * sizeof(ZkFrameBase)))) return rc;
@@ -192,7 +189,7 @@ static int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const void *d_comp, co
     uint64_t *words = (uint64_t *)c.words.p;          // [0..2] totals, [3] first error
 
     zk_profile_begin(e);
-    { zk_kernel_timer t(e, ZK_K_WALK_COUNT, st); zk_launch_walk(st, comp, c_off, d_off, first, count, ids, nullptr, nullptr, infos); }
+    { zk_kernel_timer t(e, ZK_K_WALK_COUNT, st); zk_launch_walk(st, comp, a.comp_size, c_off, d_off, first, count, a.ids, a.out_off, a.dst_cap, nullptr, nullptr, infos); }
     { zk_kernel_timer t(e, ZK_K_SCAN, st); zk_launch_scan(st, infos, count, bases, words); }
     ZK_HIP(hipMemcpyAsync(c.h_words, words, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
@@ -208,7 +205,7 @@ static int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const void *d_comp, co
 
     c.h_words[3] = ~0ull;
     ZK_HIP(hipMemcpyAsync(words + 3, c.h_words + 3, sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    { zk_kernel_timer t(e, ZK_K_WALK_FILL, st); zk_launch_walk(st, comp, c_off, d_off, first, count, ids, bases, blocks, infos); }
+    { zk_kernel_timer t(e, ZK_K_WALK_FILL, st); zk_launch_walk(st, comp, a.comp_size, c_off, d_off, first, count, a.ids, a.out_off, a.dst_cap, bases, blocks, infos); }
     // literals (huf) and sequences (fse) of a block are independent: the two kernels run side by side on two queues;
     // with per-kernel timing on they are serialised instead
     if (e->profiling) {
@@ -222,14 +219,14 @@ static int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const void *d_comp, co
         zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->fse_kernel);
         ZK_HIP(hipStreamWaitEvent(st, c.ev_join, 0));
     }
-    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, ids, out_off, blocks, bases, infos, seqs, lit, (uint8_t *)d_dst, (const uint8_t *)d_prefix, d_prefix ? prefix_len : 0); }
+    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, a.ids, a.out_off, blocks, bases, infos, seqs, lit, (uint8_t *)a.d_dst, (const uint8_t *)a.d_prefix, a.d_prefix ? a.prefix_len : 0); }
     // packed indexed output: out_off (count + 1 prefix sums) doubles as the d_off of the checksum kernel
-    if (verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)d_dst, out_off ? out_off : d_off, out_off ? 0 : first, count, infos, nullptr); }
-    { zk_kernel_timer t(e, ZK_K_STATUS, st); zk_launch_status(st, infos, count, (int32_t *)d_frame_status, words + 3); }
+    if (a.verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)a.d_dst, a.out_off ? a.out_off : d_off, a.out_off ? 0 : first, count, infos, nullptr); }
+    { zk_kernel_timer t(e, ZK_K_STATUS, st); zk_launch_status(st, infos, count, (int32_t *)a.d_frame_status, words + 3); }
     ZK_HIP(hipMemcpyAsync(c.h_words + 3, words + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     return 0;
 }
-static int zk_decode_finish(zk_engine *e, zk_dec_ctx &c)
+int zk_decode_finish(zk_engine *e, zk_dec_ctx &c)
 {
     ZK_HIP(hipStreamSynchronize(c.st));
     ZK_HIP(hipGetLastError());
@@ -238,16 +235,14 @@ static int zk_decode_finish(zk_engine *e, zk_dec_ctx &c)
     return 0;
 }
 
-static int zk_decode_impl(zk_engine *e, const void *d_comp, const void *d_c_off, const void *d_d_off, uint32_t first, uint32_t count,
-                          const uint32_t *ids, const uint64_t *out_off, void *d_dst, int verify, void *d_frame_status, void *stream,
-                          const void *d_prefix = nullptr, uint64_t prefix_len = 0)
+static int zk_decode_impl(zk_engine *e, const zk_dec_args &a, void *stream)
 {
-    if (!e || (count && (!d_comp || !d_c_off || !d_d_off || !d_dst))) return ZK_ERR_ARGUMENT;
-    if (count == 0) return 0;
+    if (!e || (a.count && (!a.d_comp || !a.d_c_off || !a.d_d_off || !a.d_dst))) return ZK_ERR_ARGUMENT;
+    if (a.count == 0) return 0;
     if (e->slot_busy[0]) return ZK_ERR_ARGUMENT;            // a submitted batch still owns context 0: zk_decode_wait first
     ZK_HIP(hipSetDevice(e->device));
     zk_dec_ctx c = zk_dec_context(e, 0, stream);
-    int rc = zk_decode_enqueue(e, c, d_comp, d_c_off, d_d_off, first, count, ids, out_off, d_dst, verify, d_frame_status, d_prefix, prefix_len);
+    int rc = zk_decode_enqueue(e, c, a);
     if (rc) return rc;
     return zk_decode_finish(e, c);
 }
@@ -256,7 +251,6 @@ extern "C" int zk_decode_submit_dev(zk_engine *e, const void *d_comp, uint64_t c
                                     const void *d_d_off, uint32_t first, uint32_t count, void *d_dst, uint64_t dst_cap,
                                     int verify, void *d_frame_status, int *slot_out)
 {
-    (void)comp_size; (void)dst_cap;
     if (!e || !slot_out || count == 0 || !d_comp || !d_c_off || !d_d_off || !d_dst) return ZK_ERR_ARGUMENT;
     const int slot = e->next_slot;
     if (e->slot_busy[slot]) return ZK_ERR_ARGUMENT;         // both contexts in flight: zk_decode_wait the older one first
@@ -264,7 +258,8 @@ extern "C" int zk_decode_submit_dev(zk_engine *e, const void *d_comp, uint64_t c
     zk_dec_ctx c = zk_dec_context(e, slot, nullptr);
     const bool prof = e->profiling;
     e->profiling = false;                                   // per-kernel events belong to the synchronous path
-    int rc = zk_decode_enqueue(e, c, d_comp, d_c_off, d_d_off, first, count, nullptr, nullptr, d_dst, verify, d_frame_status);
+    zk_dec_args a{d_comp, comp_size, d_c_off, d_d_off, first, count, nullptr, nullptr, d_dst, dst_cap, verify, d_frame_status, nullptr, 0};
+    int rc = zk_decode_enqueue(e, c, a);
     e->profiling = prof;
     if (rc) { (void)hipStreamSynchronize(c.st); return rc; }
     e->slot_busy[slot] = true;
@@ -290,94 +285,27 @@ extern "C" int zk_decode_frames_dev(zk_engine *e, const void *d_comp, uint64_t c
                                     const void *d_d_off, uint32_t first, uint32_t count, void *d_dst, uint64_t dst_cap,
                                     int verify, void *d_frame_status, void *stream)
 {
-    (void)comp_size; (void)dst_cap;
-    return zk_decode_impl(e, d_comp, d_c_off, d_d_off, first, count, nullptr, nullptr, d_dst, verify, d_frame_status, stream);
+    zk_dec_args a{d_comp, comp_size, d_c_off, d_d_off, first, count, nullptr, nullptr, d_dst, dst_cap, verify, d_frame_status, nullptr, 0};
+    return zk_decode_impl(e, a, stream);
 }
 
 extern "C" int zk_decode_frames_prefix_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off,
                                            const void *d_d_off, uint32_t first, uint32_t count, const void *d_prefix, uint64_t prefix_len,
                                            void *d_dst, uint64_t dst_cap, int verify, void *d_frame_status, void *stream)
 {
-    (void)comp_size; (void)dst_cap;
-    return zk_decode_impl(e, d_comp, d_c_off, d_d_off, first, count, nullptr, nullptr, d_dst, verify, d_frame_status, stream,
-                          prefix_len ? d_prefix : nullptr, prefix_len);
+    zk_dec_args a{d_comp, comp_size, d_c_off, d_d_off, first, count, nullptr, nullptr, d_dst, dst_cap, verify, d_frame_status,
+                  prefix_len ? d_prefix : nullptr, prefix_len};
+    return zk_decode_impl(e, a, stream);
 }
 
 extern "C" int zk_decode_frame_list_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off, const void *d_d_off,
                                         const void *d_ids, const void *d_out_off, uint32_t count, void *d_dst, uint64_t dst_cap,
                                         int verify, void *d_frame_status, void *stream)
 {
-    (void)comp_size; (void)dst_cap;
     if (count && (!d_ids || !d_out_off)) return ZK_ERR_ARGUMENT;
-    return zk_decode_impl(e, d_comp, d_c_off, d_d_off, 0, count, (const uint32_t *)d_ids, (const uint64_t *)d_out_off, d_dst, verify,
-                          d_frame_status, stream);
-}
-
-extern "C" int zk_decode_frames(zk_engine *e, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off,
-                                const uint64_t *d_off, uint32_t first, uint32_t count, uint8_t *dst, uint64_t dst_cap,
-                                int verify, int32_t *frame_status)
-{
-    return zk_decode_frames_prefix(e, comp, comp_size, c_off, d_off, first, count, nullptr, 0, dst, dst_cap, verify, frame_status);
-}
-
-// The staged copy of the prefix is kept between calls: a zeekstd::Decoder passes the same prefix with every read
-// (the reference only keeps the pointer, decode.rs:201 lifetime bound).  Same address + length + fingerprint = no
-// upload.
-static uint64_t zk_prefix_fingerprint(const uint8_t *p, uint64_t n)
-{
-    uint64_t h = 0x9E3779B185EBCA87ull ^ n;
-    const uint64_t step = n > 65536 ? n / 64 : 1024;
-    for (uint64_t at = 0; at < n; at += step) {
-        const uint64_t take = n - at < 1024 ? n - at : 1024;
-        for (uint64_t i = 0; i < take; i++) h = (h ^ p[at + i]) * 0x100000001B3ull;
-    }
-    for (uint64_t i = n > 1024 ? n - 1024 : 0; i < n; i++) h = (h ^ p[i]) * 0x100000001B3ull;
-    return h;
-}
-
-extern "C" int zk_decode_frames_prefix(zk_engine *e, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off,
-                                       const uint64_t *d_off, uint32_t first, uint32_t count, const uint8_t *prefix, uint64_t prefix_len,
-                                       uint8_t *dst, uint64_t dst_cap, int verify, int32_t *frame_status)
-{
-    if (!e || (count && (!comp || !c_off || !d_off))) return ZK_ERR_ARGUMENT;
-    if (count == 0) return 0;
-    ZK_HIP(hipSetDevice(e->device));
-    const uint64_t c_lo = c_off[first], c_hi = c_off[first + count];
-    const uint64_t d_lo = d_off[first], d_hi = d_off[first + count];
-    if (c_hi < c_lo || c_hi > comp_size || d_hi < d_lo) return ZK_ERR_ARGUMENT;
-    if (d_hi - d_lo > dst_cap) return -(int)ZK_E_DST_TOO_SMALL;
-    if (d_hi > d_lo && !dst) return ZK_ERR_ARGUMENT;
-    // stage only the byte range of the requested frames; offsets are rebased to it
-    std::vector<uint64_t> offs(2 * ((size_t)count + 1));
-    for (uint32_t i = 0; i <= count; i++) { offs[i] = c_off[first + i] - c_lo; offs[count + 1 + i] = d_off[first + i] - d_lo; }
-    int rc;
-    if ((rc = zk_devbuf_reserve(e, e->st_comp, (size_t)(c_hi - c_lo) + 64))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->st_off, offs.size() * 8))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->st_dst, (size_t)(d_hi - d_lo) + 64))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->st_misc, (size_t)count * 4))) return rc;
-    hipStream_t st = e->stream;
-    ZK_HIP(hipMemcpyAsync(e->st_comp.p, comp + c_lo, c_hi - c_lo, hipMemcpyHostToDevice, st));
-    ZK_HIP(hipMemcpyAsync(e->st_off.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, st));
-    ZK_HIP(hipStreamSynchronize(st));            // offs is a stack-lifetime vector
-    const uint64_t *dc = (const uint64_t *)e->st_off.p, *dd = dc + count + 1;
-    if (!prefix) prefix_len = 0;
-    if (prefix_len) {
-        if (prefix_len > ZK_MAX_PREFIX) return -(int)ZK_E_WINDOW_TOO_LARGE;
-        const uint64_t fp = zk_prefix_fingerprint(prefix, prefix_len);
-        if (e->st_prefix_src != prefix || e->st_prefix_len != prefix_len || e->st_prefix_fp != fp) {
-            if ((rc = zk_devbuf_reserve(e, e->st_prefix, (size_t)prefix_len + 64))) return rc;
-            ZK_HIP(hipMemcpyAsync(e->st_prefix.p, prefix, prefix_len, hipMemcpyHostToDevice, st));
-            ZK_HIP(hipStreamSynchronize(st));
-            e->st_prefix_src = prefix; e->st_prefix_len = prefix_len; e->st_prefix_fp = fp;
-        }
-    }
-    rc = zk_decode_frames_prefix_dev(e, e->st_comp.p, c_hi - c_lo, dc, dd, 0, count, prefix_len ? e->st_prefix.p : nullptr, prefix_len,
-                                     e->st_dst.p, d_hi - d_lo, verify, e->st_misc.p, st);
-    if (rc == ZK_ERR_HIP || rc == ZK_ERR_ARGUMENT) return rc;
-    if (d_hi > d_lo) ZK_HIP(hipMemcpyAsync(dst, e->st_dst.p, d_hi - d_lo, hipMemcpyDeviceToHost, st));
-    if (frame_status) ZK_HIP(hipMemcpyAsync(frame_status, e->st_misc.p, (size_t)count * 4, hipMemcpyDeviceToHost, st));
-    ZK_HIP(hipStreamSynchronize(st));
-    return rc;
+    zk_dec_args a{d_comp, comp_size, d_c_off, d_d_off, 0, count, (const uint32_t *)d_ids, (const uint64_t *)d_out_off, d_dst, dst_cap, verify,
+                  d_frame_status, nullptr, 0};
+    return zk_decode_impl(e, a, stream);
 }
 
 // ---------------------------------------------------------------------------------------------- XXH64
@@ -393,25 +321,3 @@ extern "C" int zk_xxh64_frames_dev(zk_engine *e, const void *d_data, const void 
     return 0;
 }
 
-extern "C" int zk_xxh64_frames(zk_engine *e, const uint8_t *data, const uint64_t *off, uint32_t count, uint64_t *out)
-{
-    if (!e || (count && (!off || !out))) return ZK_ERR_ARGUMENT;
-    if (count == 0) return 0;
-    ZK_HIP(hipSetDevice(e->device));
-    const uint64_t lo = off[0], hi = off[count];
-    if (hi < lo || (hi > lo && !data)) return ZK_ERR_ARGUMENT;
-    std::vector<uint64_t> offs((size_t)count + 1);
-    for (uint32_t i = 0; i <= count; i++) offs[i] = off[i] - lo;
-    int rc;
-    if ((rc = zk_devbuf_reserve(e, e->st_dst, (size_t)(hi - lo) + 64))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->st_off, offs.size() * 8))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->st_misc, (size_t)count * 8))) return rc;
-    hipStream_t st = e->stream;
-    if (hi > lo) ZK_HIP(hipMemcpyAsync(e->st_dst.p, data + lo, hi - lo, hipMemcpyHostToDevice, st));
-    ZK_HIP(hipMemcpyAsync(e->st_off.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, st));
-    ZK_HIP(hipStreamSynchronize(st));
-    rc = zk_xxh64_frames_dev(e, e->st_dst.p, e->st_off.p, count, e->st_misc.p, st);
-    if (rc) return rc;
-    ZK_HIP(hipMemcpy(out, e->st_misc.p, (size_t)count * 8, hipMemcpyDeviceToHost));
-    return 0;
-}

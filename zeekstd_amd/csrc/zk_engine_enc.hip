@@ -70,24 +70,54 @@ extern "C" int zk_encode_frames_dev(zk_engine *e, const void *d_src, uint64_t n,
                                        n_frames_out, written_out, stream);
 }
 
-extern "C" int zk_encode_frames_prefix_dev(zk_engine *e, const void *d_src, uint64_t n, uint32_t frame_size, int level, int checksum,
-                                           const void *d_prefix, uint64_t prefix_len, void *d_dst, uint64_t dst_cap, void *d_c_sizes,
-                                           void *d_d_sizes, uint32_t *n_frames_out, uint64_t *written_out, void *stream)
+static int zk_pin_reserve(zk_engine *e, size_t bytes)
 {
+    if (bytes <= e->enc_pin_cap) return 0;
+    if (e->enc_pin) ZK_HIP(hipHostFree(e->enc_pin));
+    e->enc_pin = nullptr; e->enc_pin_cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    ZK_HIP(hipHostMalloc(&e->enc_pin, want, hipHostMallocDefault));
+    e->enc_pin_cap = want;
+    return 0;
+}
+
+// Enqueue one encode on `st`.  With dst_cap >= zk_compress_bound(n, frame_size) nothing blocks: the total size arrives in
+// the engine's pinned word ZK_HW_ENC_TOTAL once the stream has run (zk_encode_finish); a smaller destination needs the
+// total before the frames may be assembled, so the stream is synchronised once in the middle.
+// The frame / block lists are built in pinned host memory that stays untouched until the next enqueue: one encode in flight.
+int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32_t *nf_out)
+{
+    const uint64_t n = a.n;
+    const uint32_t frame_size = a.frame_size;
     // the matcher sees the last `hist` bytes of the prefix right before every frame (its window is 64 KiB)
-    const uint32_t hist = d_prefix ? (uint32_t)(prefix_len < ZKE_WINDOW ? prefix_len : ZKE_WINDOW) : 0;
-    (void)level;                                             // one strategy: every level maps to it
-    if (!e || frame_size == 0 || frame_size > ZK_SEEKABLE_MAX_FRAME_SIZE || !d_dst || (n && !d_src)) return ZK_ERR_ARGUMENT;
+    const uint32_t hist = a.d_prefix ? (uint32_t)(a.prefix_len < ZKE_WINDOW ? a.prefix_len : ZKE_WINDOW) : 0;
+    if (!e || frame_size == 0 || frame_size > ZK_SEEKABLE_MAX_FRAME_SIZE || !a.d_dst || (n && !a.d_src)) return ZK_ERR_ARGUMENT;
     const uint64_t nf64 = n == 0 ? 1 : (n + frame_size - 1) / frame_size;
     if (nf64 > ZK_SEEKABLE_MAX_FRAMES) return ZK_ERR_FRAME_INDEX_TOO_LARGE;
     const uint32_t nf = (uint32_t)nf64;
     ZK_HIP(hipSetDevice(e->device));
-    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
 
     // frame / block lists (host arithmetic only: frame boundaries are the policy's, encode.rs:528-544)
-    std::vector<ZkEncFrame> frames(nf);
-    std::vector<ZkEncBlock> blocks;
+    uint64_t nb64 = 0;
+    for (uint32_t f = 0; f < nf; f++) {
+        const uint64_t so = (uint64_t)f * frame_size;
+        const uint32_t dsz = (uint32_t)(n - so < frame_size ? n - so : frame_size);
+        uint32_t bm = zke_block_max(dsz, hist != 0);
+        nb64 += dsz ? (dsz + bm - 1) / bm : 0;
+    }
+    if (nb64 > 0xFFFFFFF0ull) return -(int)ZK_E_GENERIC;
+    const uint32_t nb = (uint32_t)nb64;
+    const size_t frames_bytes = ((size_t)nf * sizeof(ZkEncFrame) + 63) & ~(size_t)63;
+    const size_t blocks_bytes = ((size_t)(nb + 1) * sizeof(ZkEncBlock) + 63) & ~(size_t)63;
+    const size_t doff_bytes = ((size_t)(nf + 1) * 8 + 63) & ~(size_t)63;
+    int rc;
+    if ((rc = zk_pin_reserve(e, frames_bytes + blocks_bytes + doff_bytes + sizeof(ZkEncTables)))) return rc;
+    ZkEncFrame *frames = (ZkEncFrame *)e->enc_pin;
+    ZkEncBlock *blocks = (ZkEncBlock *)((uint8_t *)e->enc_pin + frames_bytes);
+    uint64_t *doff = (uint64_t *)((uint8_t *)e->enc_pin + frames_bytes + blocks_bytes);
+    ZkEncTables *htab = (ZkEncTables *)((uint8_t *)doff + doff_bytes);
     uint64_t seq_total = 0, scratch_total = 0;
+    uint32_t bcount = 0;
     for (uint32_t f = 0; f < nf; f++) {
         ZkEncFrame &fr = frames[f];
         fr.src_off = (uint64_t)f * frame_size;
@@ -96,16 +126,13 @@ extern "C" int zk_encode_frames_prefix_dev(zk_engine *e, const void *d_src, uint
         while ((1u << wlog) < fr.d_size && wlog < 17) wlog++;
         if (hist) wlog = 17;                                 // covers every offset the matcher can produce, into the prefix too
         fr.window_log = wlog;
-        fr.block_max = (1u << wlog) < ZKE_BLOCK ? (1u << wlog) : ZKE_BLOCK;
-        // blocks are cut smaller than the format's maximum on purpose: a block's sequence bitstream is one serial chain for
-        // the decoder, so more, shorter blocks = more parallel chains (32 KiB for large frames, >= 8 blocks per small frame)
-        { uint32_t t = 32768; while (t > 4096 && (uint64_t)t * 8 > fr.d_size) t >>= 1; if (t < fr.block_max) fr.block_max = t; }
+        fr.block_max = zke_block_max(fr.d_size, hist != 0);
         fr.n_blocks = fr.d_size ? (fr.d_size + fr.block_max - 1) / fr.block_max : 0;
-        fr.block_base = (uint32_t)blocks.size();
+        fr.block_base = bcount;
         fr.hist = fr.d_size ? hist : 0;
         fr.m_off = hist ? (uint64_t)f * ((uint64_t)hist + frame_size) : fr.src_off;
         for (uint32_t b = 0; b < fr.n_blocks; b++) {
-            ZkEncBlock k;
+            ZkEncBlock &k = blocks[bcount++];
             memset(&k, 0, sizeof k);
             k.frame = f; k.bs = b * fr.block_max;
             k.bsz = fr.d_size - k.bs < fr.block_max ? fr.d_size - k.bs : fr.block_max;
@@ -114,100 +141,69 @@ extern "C" int zk_encode_frames_prefix_dev(zk_engine *e, const void *d_src, uint
             k.scratch_base = scratch_total;
             const uint32_t q = (k.bsz + 3) / 4;
             scratch_total += (uint64_t)k.bsz * 2 + 4ull * (q + (q >> 1) + 16) + 64;
-            blocks.push_back(k);
         }
+        doff[f] = fr.src_off;
     }
-    const uint32_t nb = (uint32_t)blocks.size();
-    const size_t frames_bytes = (frames.size() * sizeof(ZkEncFrame) + 63) & ~(size_t)63;
-    int rc;
-    if ((rc = zk_devbuf_reserve(e, e->enc_a, frames_bytes + (size_t)(nb + 1) * sizeof(ZkEncBlock) + 256))) return rc;
+    doff[nf] = n;
+    if ((rc = zk_devbuf_reserve(e, e->enc_a, frames_bytes + blocks_bytes + 256))) return rc;
     if ((rc = zk_devbuf_reserve(e, e->enc_b, (size_t)(seq_total + 1) * 12 + 64))) return rc;       // packed sequences (u64) + match positions (u32)
     if ((rc = zk_devbuf_reserve(e, e->enc_c, (size_t)n + 64))) return rc;
     if ((rc = zk_devbuf_reserve(e, e->enc_d, (size_t)scratch_total + 64))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->infos, (size_t)(nf + 1) * 8 * 3 + 64 + sizeof(ZkEncTables)))) return rc;   // c_size64, out_off, hashes, tables
-    if ((rc = zk_devbuf_reserve(e, e->bases, (size_t)(nf + 1) * 8 + 16))) return rc;                             // d_off[nf+1] for the checksum kernel
+    if ((rc = zk_devbuf_reserve(e, e->enc_e, (size_t)(nf + 1) * 8 * 4 + 64 + sizeof(ZkEncTables)))) return rc;   // c_size64, out_off, hashes, d_off, tables
     ZkEncFrame *dfr = (ZkEncFrame *)e->enc_a.p;
     ZkEncBlock *dbl = (ZkEncBlock *)((uint8_t *)e->enc_a.p + frames_bytes);
-    uint64_t *c64 = (uint64_t *)e->infos.p, *out_off = c64 + (nf + 1), *hashes = out_off + (nf + 1);
-    ZkEncTables *dtab = (ZkEncTables *)(hashes + (nf + 1));
+    uint64_t *c64 = (uint64_t *)e->enc_e.p, *out_off = c64 + (nf + 1), *hashes = out_off + (nf + 1), *d_doff = hashes + (nf + 1);
+    ZkEncTables *dtab = (ZkEncTables *)(d_doff + (nf + 1));
     if (!e->enc_tables_ready) { zk_build_enc_tables(&e->enc_tables); e->enc_tables_ready = true; }
-    ZK_HIP(hipMemcpyAsync(dfr, frames.data(), frames.size() * sizeof(ZkEncFrame), hipMemcpyHostToDevice, st));
-    if (nb) ZK_HIP(hipMemcpyAsync(dbl, blocks.data(), (size_t)nb * sizeof(ZkEncBlock), hipMemcpyHostToDevice, st));
-    ZK_HIP(hipMemcpyAsync(dtab, &e->enc_tables, sizeof(ZkEncTables), hipMemcpyHostToDevice, st));
-    std::vector<uint64_t> doff(nf + 1);
-    if (checksum) {
-        for (uint32_t f = 0; f <= nf; f++) doff[f] = f < nf ? frames[f].src_off : n;
-        ZK_HIP(hipMemcpyAsync(e->bases.p, doff.data(), doff.size() * 8, hipMemcpyHostToDevice, st));
-    }
+    *htab = e->enc_tables;
+    ZK_HIP(hipMemcpyAsync(dfr, frames, frames_bytes + (size_t)nb * sizeof(ZkEncBlock), hipMemcpyHostToDevice, st));   // frames + blocks are contiguous
+    ZK_HIP(hipMemcpyAsync(d_doff, doff, (size_t)(nf + 1) * 8, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(dtab, htab, sizeof(ZkEncTables), hipMemcpyHostToDevice, st));
     zk_profile_begin(e);
-    const uint8_t *src = (const uint8_t *)d_src;
+    const uint8_t *src = (const uint8_t *)a.d_src;
     const uint8_t *msrc = src;                               // what the matcher reads
     if (hist) {
         if ((rc = zk_devbuf_reserve(e, e->enc_hist, (size_t)nf * ((size_t)hist + frame_size) + 64))) return rc;
-        zk_launch_enc_stage_hist(st, src, (const uint8_t *)d_prefix + (prefix_len - hist), dfr, nf, (uint8_t *)e->enc_hist.p);
+        zk_launch_enc_stage_hist(st, src, (const uint8_t *)a.d_prefix + (a.prefix_len - hist), dfr, nf, (uint8_t *)e->enc_hist.p);
         msrc = (const uint8_t *)e->enc_hist.p;
     }
-    if (checksum) { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, (const uint64_t *)e->bases.p, 0, nf, nullptr, hashes); }
+    if (a.checksum) { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, d_doff, 0, nf, nullptr, hashes); }
     { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (uint8_t *)e->enc_c.p); }
     { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, dtab); }
-    zk_launch_enc_sizes(st, dfr, nf, dbl, checksum, c64, (uint32_t *)d_c_sizes, (uint32_t *)d_d_sizes);
+    zk_launch_enc_sizes(st, dfr, nf, dbl, a.checksum, c64, (uint32_t *)a.d_c_sizes, (uint32_t *)a.d_d_sizes);
     zk_launch_scan64(st, c64, nf, out_off);
-    ZK_HIP(hipMemcpyAsync(e->h_words, out_off + nf, 8, hipMemcpyDeviceToHost, st));
-    ZK_HIP(hipStreamSynchronize(st));                        // the uploads from frames / blocks / doff are done too
-    const uint64_t total = e->h_words[0];
-    if (total > dst_cap) return -(int)ZK_E_DST_TOO_SMALL;
-    { zk_kernel_timer t(e, ZK_K_ENC_COMPACT, st); zk_launch_enc_assemble(st, src, dfr, nf, dbl, (const uint8_t *)e->enc_d.p, out_off, hashes, checksum, (uint8_t *)d_dst); }
-    ZK_HIP(hipStreamSynchronize(st));
-    ZK_HIP(hipGetLastError());
-    zk_profile_collect(e);
-    if (n_frames_out) *n_frames_out = nf;
-    if (written_out) *written_out = total;
+    ZK_HIP(hipMemcpyAsync(e->h_words + ZK_HW_ENC_TOTAL, out_off + nf, 8, hipMemcpyDeviceToHost, st));
+    if (a.dst_cap < zk_compress_bound(n, frame_size)) {      // the frames may not fit: the total decides before anything is written
+        ZK_HIP(hipStreamSynchronize(st));
+        if (e->h_words[ZK_HW_ENC_TOTAL] > a.dst_cap) return -(int)ZK_E_DST_TOO_SMALL;
+    }
+    { zk_kernel_timer t(e, ZK_K_ENC_COMPACT, st); zk_launch_enc_assemble(st, src, dfr, nf, dbl, (const uint8_t *)e->enc_d.p, out_off, hashes, a.checksum, (uint8_t *)a.d_dst); }
+    if (nf_out) *nf_out = nf;
     return 0;
 }
 
-extern "C" int zk_encode_frames(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_size, int level, int checksum,
-                                uint8_t *dst, uint64_t dst_cap, uint32_t *c_sizes, uint32_t *d_sizes, uint32_t frames_cap,
-                                uint32_t *n_frames_out, uint64_t *written_out)
+int zk_encode_finish(zk_engine *e, hipStream_t st, uint64_t *written_out)
 {
-    return zk_encode_frames_prefix(e, src, n, frame_size, level, checksum, nullptr, 0, dst, dst_cap, c_sizes, d_sizes, frames_cap,
-                                   n_frames_out, written_out);
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+    zk_profile_collect(e);
+    if (written_out) *written_out = e->h_words[ZK_HW_ENC_TOTAL];
+    return 0;
 }
 
-extern "C" int zk_encode_frames_prefix(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_size, int level, int checksum,
-                                       const uint8_t *prefix, uint64_t prefix_len, uint8_t *dst, uint64_t dst_cap, uint32_t *c_sizes,
-                                       uint32_t *d_sizes, uint32_t frames_cap, uint32_t *n_frames_out, uint64_t *written_out)
+extern "C" int zk_encode_frames_prefix_dev(zk_engine *e, const void *d_src, uint64_t n, uint32_t frame_size, int level, int checksum,
+                                           const void *d_prefix, uint64_t prefix_len, void *d_dst, uint64_t dst_cap, void *d_c_sizes,
+                                           void *d_d_sizes, uint32_t *n_frames_out, uint64_t *written_out, void *stream)
 {
-    if (!e || frame_size == 0 || !dst || (n && !src)) return ZK_ERR_ARGUMENT;
-    const uint64_t nf = n == 0 ? 1 : (n + frame_size - 1) / frame_size;
-    if (nf > ZK_SEEKABLE_MAX_FRAMES) return ZK_ERR_FRAME_INDEX_TOO_LARGE;
-    if ((c_sizes || d_sizes) && frames_cap < nf) return ZK_ERR_ARGUMENT;
-    ZK_HIP(hipSetDevice(e->device));
-    const uint64_t bound = zk_compress_bound(n, frame_size);
-    const uint64_t cap = bound < dst_cap ? bound : dst_cap;
-    int rc;
-    if ((rc = zk_devbuf_reserve(e, e->st_comp, (size_t)n + 64))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->st_dst, (size_t)cap + 64))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->st_misc, (size_t)nf * 8 + 64))) return rc;
-    hipStream_t st = e->stream;
-    if (n) ZK_HIP(hipMemcpyAsync(e->st_comp.p, src, n, hipMemcpyHostToDevice, st));
-    uint32_t *dc = (uint32_t *)e->st_misc.p, *dd = dc + nf;
-    uint32_t nfo = 0;
-    uint64_t written = 0;
-    // only the tail the matcher can reach is staged
-    const uint64_t tail = prefix ? (prefix_len < ZKE_WINDOW ? prefix_len : ZKE_WINDOW) : 0;
-    if (tail) {
-        if ((rc = zk_devbuf_reserve(e, e->st_prefix, (size_t)tail + 64))) return rc;
-        ZK_HIP(hipMemcpyAsync(e->st_prefix.p, prefix + (prefix_len - tail), tail, hipMemcpyHostToDevice, st));
-        e->st_prefix_src = nullptr; e->st_prefix_len = 0; e->st_prefix_fp = 0;        // the decode side's cached copy is gone
-    }
-    rc = zk_encode_frames_prefix_dev(e, e->st_comp.p, n, frame_size, level, checksum, tail ? e->st_prefix.p : nullptr, tail,
-                                     e->st_dst.p, cap, dc, dd, &nfo, &written, st);
+    if (!e) return ZK_ERR_ARGUMENT;
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    zk_enc_args a{d_src, n, frame_size, level, checksum, d_prefix, prefix_len, d_dst, dst_cap, d_c_sizes, d_d_sizes};
+    uint32_t nf = 0;
+    int rc = zk_encode_enqueue(e, a, st, &nf);
     if (rc) return rc;
-    ZK_HIP(hipMemcpyAsync(dst, e->st_dst.p, written, hipMemcpyDeviceToHost, st));
-    if (c_sizes) ZK_HIP(hipMemcpyAsync(c_sizes, dc, (size_t)nfo * 4, hipMemcpyDeviceToHost, st));
-    if (d_sizes) ZK_HIP(hipMemcpyAsync(d_sizes, dd, (size_t)nfo * 4, hipMemcpyDeviceToHost, st));
-    ZK_HIP(hipStreamSynchronize(st));
-    if (n_frames_out) *n_frames_out = nfo;
-    if (written_out) *written_out = written;
+    uint64_t total = 0;
+    if ((rc = zk_encode_finish(e, st, &total))) return rc;
+    if (n_frames_out) *n_frames_out = nf;
+    if (written_out) *written_out = total;
     return 0;
 }
