@@ -291,6 +291,11 @@ void zk_raw_encoder_reset_seek_table(zk_raw_encoder *r);                        
 /* Encoder<W>: W is a write callback (return 0 on success) = io::Write::write_all */
 typedef int (*zk_write_fn)(void *user, const uint8_t *data, size_t len);
 int zk_encoder_new(zk_engine *e, const zk_encode_opts *o, zk_write_fn write, void *user, zk_encoder **out);   /* with_opts :596 */
+/* A ready-made W for Encoder<W>: appends into caller memory like `Vec<u8>` does for the reference's benches
+ * (lib/benches/compress.rs:47-51).  zk_buffer_writer_write is a zk_write_fn, `user` = the zk_buffer_writer.  With
+ * `engine` set, large pieces are copied by the engine's worker threads.  A write past cap fails (-> ZK_ERR_IO). */
+typedef struct zk_buffer_writer { uint8_t *data; uint64_t cap, len; zk_engine *engine; } zk_buffer_writer;
+int zk_buffer_writer_write(void *user, const uint8_t *data, size_t len);
 void zk_encoder_free(zk_encoder *e);
 int64_t zk_encoder_compress(zk_encoder *e, const uint8_t *buf, size_t len);                           /* :692 / io::Write::write :791 */
 int64_t zk_encoder_compress_with_prefix(zk_encoder *e, const uint8_t *buf, size_t len, const uint8_t *prefix, size_t plen); /* :641; the prefix buffer must stay valid and unchanged until the frames begun under it are out (end_frame / flush / finish) */

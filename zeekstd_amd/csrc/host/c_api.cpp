@@ -4,6 +4,7 @@
 #include <new>
 #include "../../../include/zeekstd_amd.h"
 #include "zeekstd.hpp"
+#include "../zk_engine.h"
 
 using namespace zeekstd;
 
@@ -32,6 +33,16 @@ static int guard(F &&f)
 extern "C" {
 
 const char *zk_last_error_message(void) { return g_last_error.c_str(); }
+
+int zk_buffer_writer_write(void *user, const uint8_t *data, size_t len)
+{
+    zk_buffer_writer *w = (zk_buffer_writer *)user;
+    if (!w || w->len + len > w->cap) return 1;
+    if (w->engine) zk_host_copy(w->engine, w->data + w->len, data, len);
+    else memcpy(w->data + w->len, data, len);
+    w->len += len;
+    return 0;
+}
 
 // ---------------------------------------------------------------- SeekTable
 zk_seek_table *zk_seek_table_new(void) { return new (std::nothrow) zk_seek_table(); }

@@ -9,23 +9,25 @@ enum { ZK_K_WALK_COUNT = 0, ZK_K_SCAN, ZK_K_WALK_FILL, ZK_K_HUF, ZK_K_FSE, ZK_K_
        ZK_K_ENC_MATCH, ZK_K_ENC_ENTROPY, ZK_K_ENC_COMPACT, ZK_K_ENC_XXH64, ZK_NKERNELS };
 
 struct zk_devbuf { void *p = nullptr; size_t cap = 0; };
+enum { ZK_MAX_CTX = 6 };
 
 struct zk_engine {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t aux = nullptr;              // second queue: kernels with no mutual dependency overlap (huf || fse)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     char devname[320] = {0};
     std::string last_err;
-    uint64_t *h_words = nullptr;            // pinned: small read-backs (totals, first error)
-    // decode scratch
-    zk_devbuf infos, bases, words, blocks, seqs, lit;
-    // second decode context (zk_decode_submit_dev): own queues, scratch and read-back words, so that two batches can
-    // be in flight -- the tail of one (checksum kernel: a per-frame serial chain) overlaps the head of the next
-    hipStream_t stream2 = nullptr, aux2 = nullptr;
-    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
-    zk_devbuf infos2, bases2, words2, blocks2, seqs2, lit2;
-    uint64_t *h_words2 = nullptr;
+    uint64_t *h_words = nullptr;            // pinned: small read-backs of the encoder (total size)
+    // decode contexts: own queues (st + aux: kernels with no mutual dependency overlap, huf || fse), scratch and pinned
+    // read-back words, so that several batches can be in flight -- the tail of one (checksum kernel: a per-frame serial
+    // chain) overlaps the head of the next.  Context 0 serves the synchronous entry points (its main queue is the engine's
+    // `stream`), 0 and 1 zk_decode_submit_dev, all of them the host-pointer pipeline; created on first use.
+    struct DecCtx {
+        hipStream_t st = nullptr, aux = nullptr;
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_exec = nullptr;
+        zk_devbuf infos, bases, words, blocks, seqs, lit;
+        uint64_t *h_words = nullptr;
+        bool ready = false;
+    } dctx[ZK_MAX_CTX];
     bool slot_busy[2] = {false, false};
     int next_slot = 0;
     // staging for the host-pointer entry points
@@ -56,7 +58,7 @@ int zk_devbuf_reserve(zk_engine *e, zk_devbuf &b, size_t bytes);
 
 // ---- decode plumbing shared by zk_engine.hip (device-pointer entry points) and zk_engine_host.hip (host pipeline)
 struct zk_dec_ctx {
-    hipStream_t st, aux; hipEvent_t ev_fork, ev_join;
+    int slot; hipStream_t st; hipEvent_t ev_exec;
     zk_devbuf &infos, &bases, &words, &blocks, &seqs, &lit;
     uint64_t *h_words;
 };
@@ -65,7 +67,10 @@ struct zk_dec_args {
     const uint32_t *ids; const uint64_t *out_off;       // frame list (device arrays, both or neither)
     void *d_dst; uint64_t dst_cap; int verify; void *d_frame_status;
     const void *d_prefix; uint64_t prefix_len;
+    bool single_queue = false;                          // huf and fse on the context's main queue (the host pipeline overlaps whole chunks instead)
+    bool mark_exec = false;                             // record the context's ev_exec behind the executor (output bytes final, checksums pending)
 };
+int zk_dec_ctx_ready(zk_engine *e, int slot);           // creates the context's queues / events on first use
 zk_dec_ctx zk_dec_context(zk_engine *e, int slot, void *stream);
 int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a);
 int zk_decode_finish(zk_engine *e, zk_dec_ctx &c);

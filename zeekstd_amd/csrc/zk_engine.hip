@@ -119,14 +119,7 @@ extern "C" int zk_engine_create(int device, zk_engine **out)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete e; return ZK_ERR_NO_DEVICE; }   // kernels are built for gfx950 only
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return ZK_ERR_NO_DEVICE; }
     if (hipHostMalloc((void **)&e->h_words, 16 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return ZK_ERR_HIP; }
-    if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void **)&e->h_words2, 16 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { zk_engine_destroy(e); return ZK_ERR_HIP; }
+    if (zk_dec_ctx_ready(e, 0) != 0 || zk_dec_ctx_ready(e, 1) != 0) { zk_engine_destroy(e); return ZK_ERR_HIP; }
     *out = e;
     return 0;
 }
@@ -138,20 +131,20 @@ extern "C" void zk_engine_destroy(zk_engine *e)
     (void)hipStreamSynchronize(e->stream);
     zk_hostpipe_destroy(e);
     if (e->enc_pin) (void)hipHostFree(e->enc_pin);
-    if (e->stream2) (void)hipStreamSynchronize(e->stream2);
-    zk_devbuf *bufs[] = {&e->infos, &e->bases, &e->words, &e->blocks, &e->seqs, &e->lit, &e->infos2, &e->bases2, &e->words2, &e->blocks2, &e->seqs2, &e->lit2, &e->st_prefix, &e->st_comp, &e->st_off, &e->st_dst, &e->st_misc,
+    for (auto &c : e->dctx) if (c.st) (void)hipStreamSynchronize(c.st);
+    zk_devbuf *bufs[] = {&e->st_prefix, &e->st_comp, &e->st_off, &e->st_dst, &e->st_misc,
                          &e->enc_a, &e->enc_b, &e->enc_c, &e->enc_d, &e->enc_e, &e->enc_hist};
     for (zk_devbuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (e->h_words) (void)hipHostFree(e->h_words);
     for (int k = 0; k < ZK_NKERNELS; k++) { if (e->ev_start[k]) (void)hipEventDestroy(e->ev_start[k]); if (e->ev_stop[k]) (void)hipEventDestroy(e->ev_stop[k]); }
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    if (e->aux) (void)hipStreamDestroy(e->aux);
-    if (e->h_words2) (void)hipHostFree(e->h_words2);
-    if (e->ev_fork2) (void)hipEventDestroy(e->ev_fork2);
-    if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
-    if (e->aux2) (void)hipStreamDestroy(e->aux2);
-    if (e->stream2) (void)hipStreamDestroy(e->stream2);
+    for (int i = 0; i < ZK_MAX_CTX; i++) {
+        zk_engine::DecCtx &c = e->dctx[i];
+        for (zk_devbuf *b : {&c.infos, &c.bases, &c.words, &c.blocks, &c.seqs, &c.lit}) if (b->p) (void)hipFree(b->p);
+        if (c.h_words) (void)hipHostFree(c.h_words);
+        for (hipEvent_t ev : {c.ev_fork, c.ev_join, c.ev_exec}) if (ev) (void)hipEventDestroy(ev);
+        if (c.aux) (void)hipStreamDestroy(c.aux);
+        if (c.st && i != 0) (void)hipStreamDestroy(c.st);     // context 0 runs on the engine's own stream
+    }
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -164,10 +157,33 @@ extern "C" const char *zk_engine_device_name(const zk_engine *e) { return e ? e-
 // One decode in flight per context: queues, scratch and pinned read-back words.  Context 0 is the engine's own (synchronous
 // entry points, optionally on the caller's stream), context 1 exists for zk_decode_submit_dev; the host-pointer pipeline
 // (zk_engine_host.hip) alternates between the two.
+int zk_dec_ctx_ready(zk_engine *e, int slot)
+{
+    if (slot < 0 || slot >= ZK_MAX_CTX) return ZK_ERR_ARGUMENT;
+    zk_engine::DecCtx &c = e->dctx[slot];
+    if (c.ready) return 0;
+    if (slot == 0) c.st = e->stream;
+    else ZK_HIP(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
+    ZK_HIP(hipEventCreateWithFlags(&c.ev_exec, hipEventDisableTiming));
+    ZK_HIP(hipHostMalloc((void **)&c.h_words, 16 * sizeof(uint64_t), hipHostMallocDefault));
+    c.ready = true;
+    return 0;
+}
+// the second queue of a context (huf || fse of one batch) exists only once a batch asked for it: the host pipeline overlaps
+// whole chunks on one queue per context, and every stream the process owns competes for the runtime's few hardware queues
+static int zk_dec_ctx_aux(zk_engine *e, int slot)
+{
+    zk_engine::DecCtx &c = e->dctx[slot];
+    if (c.aux) return 0;
+    ZK_HIP(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
+    ZK_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+    ZK_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
+    return 0;
+}
 zk_dec_ctx zk_dec_context(zk_engine *e, int slot, void *stream)
 {
-    if (slot == 0) return zk_dec_ctx{stream ? (hipStream_t)stream : e->stream, e->aux, e->ev_fork, e->ev_join, e->infos, e->bases, e->words, e->blocks, e->seqs, e->lit, e->h_words};
-    return zk_dec_ctx{e->stream2, e->aux2, e->ev_fork2, e->ev_join2, e->infos2, e->bases2, e->words2, e->blocks2, e->seqs2, e->lit2, e->h_words2};
+    zk_engine::DecCtx &c = e->dctx[slot];
+    return zk_dec_ctx{slot, slot == 0 && stream ? (hipStream_t)stream : c.st, c.ev_exec, c.infos, c.bases, c.words, c.blocks, c.seqs, c.lit, c.h_words};
 }
 
 // Enqueue the whole decode on the context's queues.  Blocks the host once, for the block / sequence / literal totals
@@ -208,18 +224,21 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
     { zk_kernel_timer t(e, ZK_K_WALK_FILL, st); zk_launch_walk(st, comp, a.comp_size, c_off, d_off, first, count, a.ids, a.out_off, a.dst_cap, bases, blocks, infos); }
     // literals (huf) and sequences (fse) of a block are independent: the two kernels run side by side on two queues;
     // with per-kernel timing on they are serialised instead
-    if (e->profiling) {
+    if (e->profiling || a.single_queue) {
         { zk_kernel_timer t(e, ZK_K_HUF, st); zk_launch_huf(st, comp, blocks, (uint32_t)nblocks, lit); }
         { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->fse_kernel); }
     } else {
-        ZK_HIP(hipEventRecord(c.ev_fork, st));
-        ZK_HIP(hipStreamWaitEvent(c.aux, c.ev_fork, 0));
-        zk_launch_huf(c.aux, comp, blocks, (uint32_t)nblocks, lit);
-        ZK_HIP(hipEventRecord(c.ev_join, c.aux));
+        if ((rc = zk_dec_ctx_aux(e, c.slot))) return rc;
+        zk_engine::DecCtx &x = e->dctx[c.slot];
+        ZK_HIP(hipEventRecord(x.ev_fork, st));
+        ZK_HIP(hipStreamWaitEvent(x.aux, x.ev_fork, 0));
+        zk_launch_huf(x.aux, comp, blocks, (uint32_t)nblocks, lit);
+        ZK_HIP(hipEventRecord(x.ev_join, x.aux));
         zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->fse_kernel);
-        ZK_HIP(hipStreamWaitEvent(st, c.ev_join, 0));
+        ZK_HIP(hipStreamWaitEvent(st, x.ev_join, 0));
     }
     { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, a.ids, a.out_off, blocks, bases, infos, seqs, lit, (uint8_t *)a.d_dst, (const uint8_t *)a.d_prefix, a.d_prefix ? a.prefix_len : 0); }
+    if (a.mark_exec) ZK_HIP(hipEventRecord(c.ev_exec, st));
     // packed indexed output: out_off (count + 1 prefix sums) doubles as the d_off of the checksum kernel
     if (a.verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)a.d_dst, a.out_off ? a.out_off : d_off, a.out_off ? 0 : first, count, infos, nullptr); }
     { zk_kernel_timer t(e, ZK_K_STATUS, st); zk_launch_status(st, infos, count, (int32_t *)a.d_frame_status, words + 3); }

@@ -13,7 +13,11 @@
 // No CPU fallback anywhere: the threads only move bytes.
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <atomic>
+#include <chrono>
+#include <memory>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -146,15 +150,77 @@ struct ZkRing {
     }
 };
 
+// Caller memory pinned on the fly.  hipHostRegister costs ~3 ms per 256 MiB on this platform and DMA then runs at the
+// full PCIe rate straight from / into the caller's pages, so the staging copy through the pinned rings (and the worker
+// threads' memcpy, which a remote NUMA node can slow to a few GB/s per thread) is only the fallback.  The range is cut
+// into page-aligned units that worker threads register in order, ahead of the copies that need them; a unit that cannot
+// be registered (read-only mapping, already registered by the caller, ...) sends its copies through the rings.
+struct ZkRegWindow {
+    static constexpr size_t UNIT = 64u << 20;
+    uintptr_t base = 0;
+    size_t nunits = 0, bytes = 0;
+    std::vector<int> state;                      // 0 queued, 1 ok, 2 failed
+    std::mutex m;
+    std::condition_variable cv;
+    size_t done = 0;
+    bool active = false;
+
+    void start(ZkPool *pool, const void *p, size_t n)
+    {
+        if (!n) return;
+        const uintptr_t a = (uintptr_t)p & ~(uintptr_t)4095, b = ((uintptr_t)p + n + 4095) & ~(uintptr_t)4095;
+        base = a; bytes = b - a;
+        nunits = (bytes + UNIT - 1) / UNIT;
+        state.assign(nunits, 0);
+        active = true;
+        // one chain of tasks: unit k + 1 is queued when unit k is done, so registrations run in order, one at a time
+        // (they serialise inside the driver anyway) and never occupy more than one worker
+        post_unit(pool, 0);
+    }
+    void post_unit(ZkPool *pool, size_t k)
+    {
+        pool->post([this, pool, k] {
+            const size_t len = bytes - k * UNIT < UNIT ? bytes - k * UNIT : UNIT;
+            bool ok = k == 0 || state[k - 1] == 1;      // after a failure the rest is not even tried
+            if (ok) ok = hipHostRegister((void *)(base + k * UNIT), len, hipHostRegisterDefault) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            { std::lock_guard<std::mutex> g(m); state[k] = ok ? 1 : 2; done = k + 1; }
+            cv.notify_all();
+            if (k + 1 < nunits) post_unit(pool, k + 1);
+        });
+    }
+    size_t unit_of(const void *p) const { return ((uintptr_t)p - base) / UNIT; }
+    // bytes from p to the end of its unit
+    size_t span(const void *p) const { return (size_t)(base + (unit_of(p) + 1) * UNIT - (uintptr_t)p); }
+    bool ok(const void *p)
+    {
+        if (!active) return false;
+        const size_t k = unit_of(p);
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [&] { return done > k; });
+        return state[k] == 1;
+    }
+    void finish()                                 // every queue that used the window has been synchronised
+    {
+        if (!active) return;
+        { std::unique_lock<std::mutex> g(m); cv.wait(g, [&] { return done == nunits; }); }
+        for (size_t k = 0; k < nunits; k++) if (state[k] == 1) (void)hipHostUnregister((void *)(base + k * UNIT));
+        active = false;
+    }
+};
+
 }  // namespace
 
 struct zk_hostpipe {
-    static constexpr int NS = 3;                 // decode chunks whose HBM buffers exist at once
+    static constexpr int NS = ZK_MAX_CTX + 1;    // decode chunks whose HBM buffers can exist at once (contexts in use + 1)
+    int nctx = 2;                                // decode contexts the pipeline rotates through (ZK_PIPE_CTX)
+    uint64_t chunk_target = 0;                   // bytes of output per chunk (0 = by total size; ZK_PIPE_CHUNK_MB)
     static constexpr size_t PIECE = 32u << 20;   // pinned staging piece
     ZkPool *pool = nullptr;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     ZkRing ring_in, ring_out;                    // allocated on the first large call
     bool rings_ready = false;
+    bool trace = false;                          // ZK_TRACE_PIPE: host-side timeline of the chunks on stderr
     struct Slot {
         zk_devbuf d_in, d_out, d_off, d_st;
         hipEvent_t ev_in = nullptr, ev_dec = nullptr, ev_out = nullptr;
@@ -193,6 +259,9 @@ static int zk_hostpipe_get(zk_engine *e, zk_hostpipe **out)
     e->hp = hp;
     ZK_HIP(hipStreamCreateWithFlags(&hp->s_h2d, hipStreamNonBlocking));
     ZK_HIP(hipStreamCreateWithFlags(&hp->s_d2h, hipStreamNonBlocking));
+    hp->trace = getenv("ZK_TRACE_PIPE") != nullptr;
+    if (const char *v = getenv("ZK_PIPE_CTX")) { const int k = atoi(v); if (k >= 1 && k <= ZK_MAX_CTX) hp->nctx = k; }
+    if (const char *v = getenv("ZK_PIPE_CHUNK_MB")) { const long k = atol(v); if (k >= 1 && k <= 4096) hp->chunk_target = (uint64_t)k << 20; }
     for (auto &s : hp->slot) {
         ZK_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
         ZK_HIP(hipEventCreateWithFlags(&s.ev_dec, hipEventDisableTiming));
@@ -210,7 +279,7 @@ static int zk_hostpipe_get(zk_engine *e, zk_hostpipe **out)
 static int zk_hostpipe_rings(zk_engine *e, zk_hostpipe *hp)
 {
     if (hp->rings_ready) return 0;
-    if (hp->ring_in.init(4, zk_hostpipe::PIECE) != 0 || hp->ring_out.init(8, zk_hostpipe::PIECE) != 0) {
+    if (hp->ring_in.init(4, zk_hostpipe::PIECE) != 0 || hp->ring_out.init(16, zk_hostpipe::PIECE) != 0) {
         e->last_err = "hipHostMalloc of the pinned staging rings failed";
         return ZK_ERR_HIP;
     }
@@ -334,9 +403,12 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
 
     // ---- chunk list
     const uint64_t total_d = d_hi - d_lo;
-    uint64_t target = total_d / 6;
+    uint64_t target = total_d / 8;
     if (target < (16ull << 20)) target = 16ull << 20;
     if (target > (256ull << 20)) target = 256ull << 20;
+    if (hp->chunk_target) target = hp->chunk_target;
+    const int nctx = hp->nctx, nslots = nctx + 1;
+    for (int k = 0; k < nctx; k++) if ((rc = zk_dec_ctx_ready(e, k))) return rc;
     std::vector<ZkChunk> chunks;
     for (uint32_t f = 0; f < count;) {
         uint32_t g = f + 1;
@@ -351,7 +423,11 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
     for (auto &ck : chunks) if (ck.c1 - ck.c0 > max_c) max_c = ck.c1 - ck.c0;
     // a small request (a seek) is staged through one small pinned buffer by this thread: no rings, no hand-over
     const bool small = nchunks == 1 && total_d <= (4u << 20) && max_c <= (4u << 20);
-    if (!small && (!src_pinned || !dst_pinned)) { if ((rc = zk_hostpipe_rings(e, hp))) return rc; }
+    if (!small && !src.mem) { if ((rc = zk_hostpipe_rings(e, hp))) return rc; }     // a pull source is staged through the ring
+    // caller memory that is not pinned already is pinned on the fly, unit by unit, ahead of the copies (ZkRegWindow)
+    ZkRegWindow wsrc, wdst;
+    if (!small && src.mem && !src_pinned) wsrc.start(hp->pool, src.mem + c_lo, (size_t)(c_off[first + count] - c_lo));
+    if (!small && !dst_pinned) wdst.start(hp->pool, dst, (size_t)total_d);
 
     // ---- pinned meta: rebased offsets of every chunk + the status words of every frame
     const size_t off_bytes = ((size_t)(count + nchunks) * 16 + 63) & ~(size_t)63;
@@ -364,9 +440,13 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
     size_t offs_at = 0;
     std::atomic<int> copy_fail{0};
 
+    // Queues: one upload queue, one download queue, one compute queue per decode context (the contexts' second queues
+    // stay unused here: whole chunks overlap instead of huf || fse).  With two contexts that is four streams -- the
+    // runtime multiplexes streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES), and a copy queue that shares a
+    // hardware queue with a compute queue serialises behind its kernels (measured: 135 instead of 87 ms for 4 GiB).
     auto prep = [&](size_t i) -> int {                      // stage + upload the compressed bytes and offsets of chunk i
         const ZkChunk &ck = chunks[i];
-        zk_hostpipe::Slot &s = hp->slot[i % zk_hostpipe::NS];
+        zk_hostpipe::Slot &s = hp->slot[i % nslots];
         const uint32_t nf = ck.f1 - ck.f0;
         const uint64_t csz = ck.c1 - ck.c0;
         int r;
@@ -374,7 +454,7 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
         if ((r = zk_devbuf_reserve(e, s.d_out, (size_t)(ck.d1 - ck.d0) + 64))) return r;
         if ((r = zk_devbuf_reserve(e, s.d_off, (size_t)(nf + 1) * 16))) return r;
         if ((r = zk_devbuf_reserve(e, s.d_st, (size_t)nf * 4 + 16))) return r;
-        // the chunk's HBM buffers were last used by chunk i - NS: its D2H must have run
+        // the chunk's HBM buffers were last used by chunk i - nslots: its D2H must have run
         if (s.out_pending) ZK_HIP(hipStreamWaitEvent(hp->s_h2d, s.ev_out, 0));
         uint64_t *o = pin_offs + offs_at;
         offs_at += (size_t)(nf + 1) * 2;
@@ -386,7 +466,14 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
             if ((r = zk_src_fill(e, hp, src, ck.c0, hp->pin_small, (size_t)csz))) return r;
             if (csz) ZK_HIP(hipMemcpyAsync(s.d_in.p, hp->pin_small, csz, hipMemcpyHostToDevice, hp->s_h2d));
         } else {
-            for (uint64_t at = 0; at < csz; at += zk_hostpipe::PIECE) {
+            for (uint64_t at = 0; at < csz;) {
+                if (src.mem && wsrc.ok(src.mem + ck.c0 + at)) {             // straight from the caller's (now pinned) pages
+                    const size_t sp = wsrc.span(src.mem + ck.c0 + at), n = (size_t)(csz - at < sp ? csz - at : sp);
+                    ZK_HIP(hipMemcpyAsync((uint8_t *)s.d_in.p + at, src.mem + ck.c0 + at, n, hipMemcpyHostToDevice, hp->s_h2d));
+                    at += n;
+                    continue;
+                }
+                if ((r = zk_hostpipe_rings(e, hp))) return r;
                 const size_t n = (size_t)(csz - at < zk_hostpipe::PIECE ? csz - at : zk_hostpipe::PIECE);
                 const int k = hp->ring_in.acquire();
                 ZkRing::Piece &pc = hp->ring_in.pc[k];
@@ -394,6 +481,7 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
                 ZK_HIP(hipMemcpyAsync((uint8_t *)s.d_in.p + at, pc.p, n, hipMemcpyHostToDevice, hp->s_h2d));
                 ZK_HIP(hipEventRecord(pc.ev, hp->s_h2d));
                 pc.ev_pending = true;
+                at += n;
             }
         }
         ZK_HIP(hipMemsetAsync((uint8_t *)s.d_in.p + csz, 0, 16, hp->s_h2d));     // the readers may touch ZK_COMP_PADDING bytes past the end
@@ -403,22 +491,23 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
 
     auto run = [&](size_t i) -> int {                       // decode chunk i and queue its way back
         const ZkChunk &ck = chunks[i];
-        zk_hostpipe::Slot &s = hp->slot[i % zk_hostpipe::NS];
+        zk_hostpipe::Slot &s = hp->slot[i % nslots];
         const uint32_t nf = ck.f1 - ck.f0;
         const uint64_t dsz = ck.d1 - ck.d0;
-        zk_dec_ctx c = zk_dec_context(e, (int)(i & 1), nullptr);
+        zk_dec_ctx c = zk_dec_context(e, (int)(i % nctx), nullptr);
         ZK_HIP(hipStreamWaitEvent(c.st, s.ev_in, 0));
         if (s.out_pending) ZK_HIP(hipStreamWaitEvent(c.st, s.ev_out, 0));
         const uint64_t *dc = (const uint64_t *)s.d_off.p, *dd = dc + nf + 1;
         zk_dec_args a{s.d_in.p, ck.c1 - ck.c0, dc, dd, 0, nf, nullptr, nullptr, s.d_out.p, dsz, verify, s.d_st.p, d_prefix, d_prefix ? prefix_len : 0};
+        a.single_queue = nchunks > 1;                       // whole chunks overlap instead of huf || fse
+        a.mark_exec = true;                                 // the bytes travel back while the checksum chains still run; the status words follow them
         const bool prof = e->profiling;
         if (nchunks > 1) e->profiling = false;              // per-kernel events describe one synchronous batch
         int r = zk_decode_enqueue(e, c, a);
         e->profiling = prof;
         if (r) return r;
         ZK_HIP(hipEventRecord(s.ev_dec, c.st));
-        ZK_HIP(hipStreamWaitEvent(hp->s_d2h, s.ev_dec, 0));
-        ZK_HIP(hipMemcpyAsync(pin_status + ck.f0, s.d_st.p, (size_t)nf * 4, hipMemcpyDeviceToHost, hp->s_d2h));
+        ZK_HIP(hipStreamWaitEvent(hp->s_d2h, c.ev_exec, 0));
         uint8_t *out = dst + (ck.d0 - d_lo);
         if (dst_pinned) {
             if (dsz) ZK_HIP(hipMemcpyAsync(out, s.d_out.p, dsz, hipMemcpyDeviceToHost, hp->s_d2h));
@@ -426,7 +515,14 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
             uint8_t *stage = hp->pin_small + ((max_c + 63) & ~(uint64_t)63);
             if (dsz) ZK_HIP(hipMemcpyAsync(stage, s.d_out.p, dsz, hipMemcpyDeviceToHost, hp->s_d2h));
         } else {
-            for (uint64_t at = 0; at < dsz; at += zk_hostpipe::PIECE) {
+            for (uint64_t at = 0; at < dsz;) {
+                if (wdst.ok(out + at)) {                                     // straight into the caller's (now pinned) pages
+                    const size_t sp = wdst.span(out + at), n = (size_t)(dsz - at < sp ? dsz - at : sp);
+                    ZK_HIP(hipMemcpyAsync(out + at, (const uint8_t *)s.d_out.p + at, n, hipMemcpyDeviceToHost, hp->s_d2h));
+                    at += n;
+                    continue;
+                }
+                if ((r = zk_hostpipe_rings(e, hp))) return r;
                 const size_t n = (size_t)(dsz - at < zk_hostpipe::PIECE ? dsz - at : zk_hostpipe::PIECE);
                 const int k = hp->ring_out.acquire();
                 ZkRing::Piece &pc = hp->ring_out.pc[k];
@@ -436,10 +532,10 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
                 uint8_t *to = out + at;
                 ZkRing *ring = &hp->ring_out;
                 ZkPool *pool = hp->pool;
+                const size_t parts = n >= (8u << 20) && pool->size() >= 8 ? 4 : 1;
                 // copy-out: the first worker waits for the DMA, then the piece is split among the workers
                 pool->post([=, &copy_fail] {
                     if (hipEventSynchronize(ring->pc[k].ev) != hipSuccess) copy_fail.store(1);
-                    const size_t parts = n >= (8u << 20) ? 4 : 1;
                     const size_t per = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
                     auto left = std::make_shared<std::atomic<int>>((int)parts);
                     for (size_t q = 1; q < parts; q++) {
@@ -451,24 +547,36 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
                     memcpy(to, ring->pc[k].p, per < n ? per : n);
                     if (left->fetch_sub(1) == 1) ring->release(k);
                 });
+                at += n;
             }
         }
+        ZK_HIP(hipStreamWaitEvent(hp->s_d2h, s.ev_dec, 0));
+        ZK_HIP(hipMemcpyAsync(pin_status + ck.f0, s.d_st.p, (size_t)nf * 4, hipMemcpyDeviceToHost, hp->s_d2h));
         ZK_HIP(hipEventRecord(s.ev_out, hp->s_d2h));
         s.out_pending = true;
         return 0;
     };
 
+    const auto t00 = std::chrono::steady_clock::now();
+    auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t00).count(); };
     if ((fail = prep(0)) == 0) {
         for (size_t i = 0; i < nchunks; i++) {
+            const double ta = ms();
             if (i + 1 < nchunks && (fail = prep(i + 1))) break;       // the next chunk's upload is queued before this one's decode blocks the thread
+            const double tb = ms();
             if ((fail = run(i))) break;
+            if (hp->trace) fprintf(stderr, "[zk pipe] chunk %zu: prep(next) %.2f ms, run %.2f ms, at %.2f ms\n", i, tb - ta, ms() - tb, ms());
         }
     }
+    const double t_issue = ms();
     // ---- drain
-    hipError_t s1 = hipStreamSynchronize(hp->s_h2d), s2 = hipStreamSynchronize(e->stream), s3 = hipStreamSynchronize(e->stream2),
-               s4 = hipStreamSynchronize(hp->s_d2h);
-    if (hp->rings_ready) hp->ring_out.wait_all_released();
+    hipError_t s1 = hipStreamSynchronize(hp->s_h2d), s2 = hipSuccess, s3 = hipSuccess;
+    for (int k = 0; k < nctx; k++) { const hipError_t r = hipStreamSynchronize(e->dctx[k].st); if (r != hipSuccess) s2 = r; }
+    const hipError_t s4 = hipStreamSynchronize(hp->s_d2h);
     for (auto &s : hp->slot) s.out_pending = false;
+    if (hp->rings_ready) hp->ring_out.wait_all_released();
+    wsrc.finish(); wdst.finish();
+    if (hp->trace) fprintf(stderr, "[zk pipe] %zu chunks issued at %.2f ms, drained at %.2f ms\n", nchunks, t_issue, ms());
     if (fail) return fail;
     if (s1 != hipSuccess || s2 != hipSuccess || s3 != hipSuccess || s4 != hipSuccess || copy_fail.load()) {
         e->last_err = "host decode pipeline: a queue failed"; return ZK_ERR_HIP;
@@ -530,7 +638,9 @@ int zk_host_encode(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_
     const size_t nchunks = (size_t)((nf64 + per - 1) / per);
     const bool src_pinned = n == 0 || zk_is_pinned(src);
     const bool small = nchunks == 1 && n <= (4u << 20);
-    if (!small) { if ((rc = zk_hostpipe_rings(e, hp))) return rc; }
+    if (!small) { if ((rc = zk_hostpipe_rings(e, hp))) return rc; }                 // the compressed bytes travel back through the ring
+    ZkRegWindow wsrc;
+    if (!small && !src_pinned) wsrc.start(hp->pool, src, (size_t)n);
     const uint64_t max_in = per * frame_size < n ? per * frame_size : n;
     const uint64_t max_bound = zk_compress_bound(max_in, frame_size);
     if (small) { if ((rc = zk_pin_grow(e, hp->pin_small, hp->pin_small_cap, (size_t)max_in + (size_t)max_bound + 256))) return rc; }
@@ -550,7 +660,13 @@ int zk_host_encode(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_
         if ((r = zk_devbuf_reserve(e, s.d_sizes, (size_t)nf * 8 + 64))) return r;
         if (src_pinned) { if (bn) ZK_HIP(hipMemcpyAsync(s.d_src.p, src + b0, bn, hipMemcpyHostToDevice, hp->s_h2d)); }
         else if (small) { memcpy(hp->pin_small, src + b0, (size_t)bn); if (bn) ZK_HIP(hipMemcpyAsync(s.d_src.p, hp->pin_small, bn, hipMemcpyHostToDevice, hp->s_h2d)); }
-        else for (uint64_t at = 0; at < bn; at += zk_hostpipe::PIECE) {
+        else for (uint64_t at = 0; at < bn;) {
+            if (wsrc.ok(src + b0 + at)) {                                   // straight from the caller's (now pinned) pages
+                const size_t sp = wsrc.span(src + b0 + at), len = (size_t)(bn - at < sp ? bn - at : sp);
+                ZK_HIP(hipMemcpyAsync((uint8_t *)s.d_src.p + at, src + b0 + at, len, hipMemcpyHostToDevice, hp->s_h2d));
+                at += len;
+                continue;
+            }
             const size_t len = (size_t)(bn - at < zk_hostpipe::PIECE ? bn - at : zk_hostpipe::PIECE);
             const int k = hp->ring_in.acquire();
             ZkRing::Piece &pc = hp->ring_in.pc[k];
@@ -558,6 +674,7 @@ int zk_host_encode(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_
             ZK_HIP(hipMemcpyAsync((uint8_t *)s.d_src.p + at, pc.p, len, hipMemcpyHostToDevice, hp->s_h2d));
             ZK_HIP(hipEventRecord(pc.ev, hp->s_h2d));
             pc.ev_pending = true;
+            at += len;
         }
         ZK_HIP(hipEventRecord(s.ev_in, hp->s_h2d));
         return 0;
@@ -631,6 +748,7 @@ int zk_host_encode(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_
         fail = finish(i, i + 1 < nchunks);
     }
     (void)hipStreamSynchronize(hp->s_h2d); (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(hp->s_d2h);
+    wsrc.finish();
     for (auto &s : hp->es) s.out_pending = false;
     if (fail) return fail;
     ZK_HIP(hipGetLastError());
