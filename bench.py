@@ -68,8 +68,7 @@ def build_inputs(k0, nframes, level, cks, workers, want_archive, tag):
     return _SHM, comp, frames, hashes
 
 
-def cpu_baseline(comp, frames, data, sample_frames, level, cks, target_seconds=8.0):
-    """Reference CPU path (C restatement of zeekstd's Decoder / Encoder loops over the box's libzstd), 1 thread."""
+def _zkb():
     from oracle import zko, libzstd_ref as Z
     lib = zko.lib()
     path = next((p for p in Z._CANDIDATES["system"] if os.path.exists(p)), None)
@@ -77,23 +76,78 @@ def cpu_baseline(comp, frames, data, sample_frames, level, cks, target_seconds=8
         return None
     lib.zkb_version.restype = C.c_char_p
     lib.zkb_time_decode.restype = C.c_double
-    lib.zkb_time_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+    lib.zkb_time_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
     lib.zkb_time_encode.restype = C.c_double
     lib.zkb_time_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                     C.POINTER(C.c_int64)]
+    return lib
+
+
+def _cpu_decode_rate(lib, comp, frames, nthreads, target_seconds):
+    """GiB/s of the reference Decoder loop: `nthreads` independent Decoders, one per contiguous frame range (what a user of
+    the reference can do with set_lower_frame / set_upper_frame), wall clock over all of them."""
+    from concurrent.futures import ThreadPoolExecutor
+    cb = np.frombuffer(comp, np.uint8)
+    n = len(frames)
+    c = np.zeros(n + 1, np.int64); d = np.zeros(n + 1, np.int64)
+    c[1:] = np.cumsum([f[0] for f in frames]); d[1:] = np.cumsum([f[1] for f in frames])
+    nthreads = max(1, min(nthreads, n))
+    cuts = [n * k // nthreads for k in range(nthreads + 1)]
+
+    def one(k, reps):
+        lo, hi = cuts[k], cuts[k + 1]
+        sink = C.c_uint64(0)
+        return lib.zkb_time_decode(cb.ctypes.data + int(c[lo]), int(c[hi] - c[lo]), int(d[hi] - d[lo]), reps, C.byref(sink))
+
+    def run(reps):
+        t = time.perf_counter()
+        if nthreads == 1:
+            r = [one(0, reps)]
+        else:
+            with ThreadPoolExecutor(nthreads) as ex:
+                r = list(ex.map(lambda k: one(k, reps), range(nthreads)))
+        wall = time.perf_counter() - t
+        if min(r) <= 0:
+            return None
+        return wall / reps
+    t1 = run(1)
+    if t1 is None:
+        return None, 0
+    reps = max(1, min(20, int(target_seconds / t1)))
+    t2 = run(reps)
+    best = min(t1, t2) if t2 else t1
+    return int(d[-1]) / best / 2**30, reps + 1
+
+
+def cpu_baseline(comp, frames, data, sample_frames, level, cks, ref_comp=None, ref_frames=None):
+    """Reference CPU path (C restatement of zeekstd's Decoder / Encoder loops over the box's libzstd): 1 thread (the
+    reference's own semantics, the north-star comparison) and all host cores (independent Decoders per frame range)."""
+    lib = _zkb()
+    if lib is None:
+        return None
+    ver = lib.zkb_version().decode()
+    cores = os.cpu_count() or 1
     n = min(sample_frames, len(frames))
     csz = sum(f[0] for f in frames[:n])
     dsz = sum(f[1] for f in frames[:n])
-    sink = C.c_uint64(0)
-    t1 = lib.zkb_time_decode(comp[:csz], csz, dsz, 1, C.byref(sink))
-    if t1 <= 0:
+    v1, passes = _cpu_decode_rate(lib, comp[:csz], frames[:n], 1, 6.0)
+    if v1 is None:
         return None
-    reps = max(1, min(20, int(target_seconds / t1) - 1))
-    best = min(t1, lib.zkb_time_decode(comp[:csz], csz, dsz, reps, C.byref(sink)))
-    out = {"value": dsz / best / 2**30, "unit": "GiB/s", "cores": 1, "kind": "port",
-           "sample": f"zeekstd::Decoder loop (decode.rs:201-270, bench protocol decompress.rs:18-39) in C over dlopen'd "
-                     f"libzstd {lib.zkb_version().decode()}, first {n} frames ({dsz >> 20} MiB) of the same archive, "
-                     f"best of {reps + 1} passes, 1 thread"}
+    out = {"value": v1, "unit": "GiB/s", "cores": 1, "kind": f"port (zeekstd loops in C over dlopen'd libzstd {ver})",
+           "sample": f"zeekstd::Decoder loop (decode.rs:201-270, bench protocol decompress.rs:18-39), first {n} frames ({dsz >> 20} MiB) "
+                     f"of the same (GPU-made) archive, best of {passes} passes, 1 thread"}
+    va, passes = _cpu_decode_rate(lib, comp, frames, cores, 4.0)
+    if va:
+        out["all_cores"] = {"value": round(va, 2), "unit": "GiB/s", "cores": cores,
+                            "sample": f"{cores} threads (nproc), one independent Decoder per contiguous frame range over all {len(frames)} frames, "
+                                      f"wall clock, best of {passes} passes"}
+    if ref_comp is not None:
+        rn = min(sample_frames, len(ref_frames))
+        rc = sum(f[0] for f in ref_frames[:rn])
+        vr, passes = _cpu_decode_rate(lib, ref_comp[:rc], ref_frames[:rn], 1, 4.0)
+        if vr:
+            out["on_reference_made_archive"] = {"value": round(vr, 3), "unit": "GiB/s", "cores": 1,
+                                                "sample": f"same loop on the archive the reference Encoder loop wrote (libzstd {ver}, level {level}), first {rn} frames"}
     # encode side, for the record: zeekstd::Encoder loop at the same level on 128 frames
     ne = min(128, len(frames))
     src = np.ascontiguousarray(data[:ne * FRAME])
@@ -106,69 +160,223 @@ def cpu_baseline(comp, frames, data, sample_frames, level, cks, target_seconds=8
     return out
 
 
-def seek_leg(eng, data, zk, nbytes=256 << 20, fsz=65536, nseeks=300):
-    """p50 / p95 of one random seek + read (len = 1 + r % 8192) on a 64 KiB-frame archive, GPU Decoder vs CPU loop."""
-    from oracle import zko, libzstd_ref as Z
-    src = np.ascontiguousarray(data[:nbytes])
-    comp, frames = eng.encode_frames(src, fsz, 1, True)
+def end_to_end(eng, zk, data, nframes, cks, reps=3):
+    """Host buffers in, host buffers out, through the zeekstd API of the C ABI: zk_encoder_compress + zk_encoder_finish into a
+    buffer writer (Encoder<Vec<u8>> of lib/benches/compress.rs:47-51), zk_decoder_decompress into caller memory
+    (lib/benches/decompress.rs:18-25).  PCIe both ways is inside the timed span.  Bit-exact or it raises."""
+    from zeekstd_amd import api
+    lib = zk.lib
+    n = nframes * FRAME
+    src = np.ascontiguousarray(data[:n])
+
+    class BW(C.Structure):
+        _fields_ = [("data", C.c_void_p), ("cap", C.c_uint64), ("len", C.c_uint64), ("engine", C.c_void_p)]
+    cap = int(lib.zk_compress_bound(n, FRAME)) + nframes * 8 + 64
+    out = np.empty(cap, np.uint8); out[:] = 0
+    dec = np.empty(n, np.uint8); dec[:] = 0
+    wfn = C.cast(lib.zk_buffer_writer_write, C.c_void_p)
+    lib.zk_encoder_new.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.zk_encoder_compress.restype = C.c_int64
+    lib.zk_encoder_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.zk_encoder_finish.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.zk_encoder_free.argtypes = [C.c_void_p]
+    lib.zk_decoder_open_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.zk_decoder_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.zk_decoder_decompress.restype = C.c_int64
+    lib.zk_decoder_free.argtypes = [C.c_void_p]
+    te, td, total = [], [], 0
+    for _ in range(reps):
+        bw = BW(out.ctypes.data, cap, 0, eng._h)
+        o = api.zk_encode_opts(0, FRAME, 1, int(cks), 0)
+        h = C.c_void_p()
+        if lib.zk_encoder_new(eng._h, C.byref(o), wfn, C.byref(bw), C.byref(h)) != 0:
+            raise RuntimeError("zk_encoder_new failed")
+        t = time.perf_counter()
+        r = lib.zk_encoder_compress(h, src.ctypes.data, n)
+        tot = C.c_uint64()
+        rc = lib.zk_encoder_finish(h, 1, C.byref(tot))
+        te.append(time.perf_counter() - t)
+        lib.zk_encoder_free(h)
+        if r != n or rc != 0 or tot.value != bw.len:
+            raise RuntimeError(f"end-to-end encode failed ({r}, {rc})")
+        total = tot.value
+    for _ in range(reps):
+        o = api.zk_decode_opts()
+        h = C.c_void_p()
+        if lib.zk_decoder_open_bytes(eng._h, out.ctypes.data, total, C.byref(o), C.byref(h)) != 0:
+            raise RuntimeError("zk_decoder_open_bytes failed")
+        t = time.perf_counter()
+        got = 0
+        while got < n:
+            r = lib.zk_decoder_decompress(h, dec.ctypes.data + got, n - got)
+            if r <= 0:
+                break
+            got += r
+        td.append(time.perf_counter() - t)
+        lib.zk_decoder_free(h)
+        if got != n:
+            raise RuntimeError(f"end-to-end decode stopped at {got}")
+    if not np.array_equal(dec, src):
+        raise RuntimeError("end-to-end round trip differs from the input bytes")
+    return {"decode": {"value": round(n / min(td) / 2**30, 2), "unit": "GiB/s", "ms": round(min(td) * 1e3, 1)},
+            "encode": {"value": round(n / min(te) / 2**30, 2), "unit": "GiB/s", "ms": round(min(te) * 1e3, 1)},
+            "archive_bytes": int(total), "reps": reps, "bit_exact": True,
+            "note": "host buffers in, host buffers out (pageable numpy arrays) through zk_encoder_compress/zk_encoder_finish and "
+                    "zk_decoder_decompress: the engine pins the caller's pages on the fly and overlaps PCIe with the kernels; "
+                    "PCIe Gen5 x16 moves 4 GiB in ~75 ms, which bounds both directions"}
+
+
+def _splitmix_seed(seed):
+    """splitmix64(seed) once -> xorshift64* state."""
+    M = (1 << 64) - 1
+    x = (seed + 0x9E3779B97F4A7C15) & M
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    z ^= z >> 31
+    return z or 0x9E3779B97F4A7C15
+
+
+def seek_protocol(trials, total, seed=0x5EED0003):
+    """BASELINE configs[3] / SURVEY 8d: xorshift64* seeded through splitmix64; off = next() % total, len = 1 + next() % 8192."""
+    M = (1 << 64) - 1
+    x = _splitmix_seed(seed)
+    offs = np.zeros(trials, np.uint64)
+    lens = np.zeros(trials, np.uint32)
+    for i in range(trials):
+        v = []
+        for _ in range(2):
+            x ^= x >> 12
+            x ^= (x << 25) & M
+            x ^= x >> 27
+            v.append((x * 0x2545F4914F6CDD1D) & M)
+        off = v[0] % total
+        ln = 1 + v[1] % 8192
+        offs[i] = off
+        lens[i] = min(ln, total - off)
+    return offs, lens
+
+
+def _pct(ts, skip=0):
+    t = np.asarray(ts[skip:], np.float64)
+    return {"p50": round(float(np.percentile(t, 50)), 1), "p95": round(float(np.percentile(t, 95)), 1),
+            "p99": round(float(np.percentile(t, 99)), 1), "mean": round(float(t.mean()), 1)}
+
+
+def _z_part(job):
+    i0, n, fsz, level, cks = job
+    from oracle import libzstd_ref as Z
+    return Z.encode_seekable_frames(bytes(_SHM[i0:i0 + n]), fsz, level, cks, "system")
+
+
+def libzstd_archive_parallel(src, fsz, level, cks, workers):
+    """The reference Encoder loop over the box's libzstd at frame size fsz, frames spread over forked workers."""
+    global _SHM
+    _SHM = src
+    per = max(fsz, (src.size // max(1, workers * 4)) // fsz * fsz)
+    jobs = [(i, min(per, src.size - i), fsz, level, cks) for i in range(0, src.size, per)]
+    if workers <= 1:
+        parts = [_z_part(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(workers) as pool:
+            parts = pool.map(_z_part, jobs)
+    return b"".join(p[0] for p in parts), [f for p in parts for f in p[1]]
+
+
+def time_single_seeks(eng, zk, comp, frames, src, offs, lens):
+    """One seek at a time through the zeekstd Decoder API of the C ABI (host buffers; zk_decoder_time_seeks), every read
+    compared with the generator bytes; the reference's CPU loop on the same archive beside it."""
+    from zeekstd_amd import api
+    lib = zk.lib
     st = zk.SeekTable.new()
     for c_, d_ in frames:
         st.log_frame(c_, d_)
     seekable = comp + st.to_bytes()
-    dec = zk.DecodeOptions(seekable).engine(eng).into_decoder()
-    rng = np.random.default_rng(0x5EED0003)
-    offs = rng.integers(0, nbytes - 8192, nseeks).astype(np.uint64)
-    lens = (1 + rng.integers(0, 8192, nseeks)).astype(np.uint32)
-    buf = bytearray(8192 + 8)
-    view = memoryview(buf)
-    ts = []
-    for o, l in zip(offs, lens):
-        t = time.perf_counter()
-        dec.set_offset_limit(nbytes)
-        dec.set_offset(int(o))
-        dec.set_offset_limit(int(o) + int(l))
-        n = dec.decompress(view[:int(l)])
-        ts.append((time.perf_counter() - t) * 1e6)
-        if n != int(l) or bytes(buf[:n]) != src[int(o):int(o) + n].tobytes():
-            raise RuntimeError("seek read mismatch")
-    out = {"frames": len(frames), "frame_size": fsz, "seeks": nseeks,
-           "gpu_decoder_us": {"p50": round(float(np.percentile(ts[20:], 50)), 1), "p95": round(float(np.percentile(ts[20:], 95)), 1)},
-           "note": "single seek = 1 frame on the GPU: launch + PCIe latency bound (SURVEY 0.2); host-buffer Decoder API"}
-    c = np.zeros(len(frames) + 1, np.uint64); d = np.zeros(len(frames) + 1, np.uint64)
-    c[1:] = np.cumsum([f[0] for f in frames]); d[1:] = np.cumsum([f[1] for f in frames])
-    # batches of 1024 seeks against the archive resident in HBM (zk_decode_frame_list_dev): what the GPU is for
+    o = api.zk_decode_opts()
+    h = C.c_void_p()
+    lib.zk_decoder_open_bytes.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    rc = lib.zk_decoder_open_bytes(eng._h, seekable, len(seekable), C.byref(o), C.byref(h))
+    if rc != 0:
+        raise RuntimeError(f"zk_decoder_open_bytes: {rc}")
+    n = len(offs)
+    us = np.zeros(n, np.float64)
+    buf = np.zeros(8192 + 64, np.uint8)
+    lib.zk_decoder_time_seeks.argtypes = [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.zk_decoder_time_seeks.restype = C.c_int
+    rc = lib.zk_decoder_time_seeks(h, offs.ctypes.data, lens.ctypes.data, n, buf.ctypes.data, buf.size, src.ctypes.data, us.ctypes.data)
+    lib.zk_decoder_free.argtypes = [C.c_void_p]
+    lib.zk_decoder_free(h)
+    if rc != 0:
+        raise RuntimeError(f"seek read failed or differs from the generator bytes (rc {rc})")
+    out = {"gpu_decoder_us": _pct(us, min(50, n // 10))}
+    from oracle import zko, libzstd_ref as Z
+    zlib_ = zko.lib()
+    path = next((p for p in Z._CANDIDATES["system"] if os.path.exists(p)), None)
+    if path and zlib_.zkb_open(path.encode()) == 0:
+        c = np.zeros(len(frames) + 1, np.uint64); d = np.zeros(len(frames) + 1, np.uint64)
+        c[1:] = np.cumsum([f[0] for f in frames]); d[1:] = np.cumsum([f[1] for f in frames])
+        tus = np.zeros(n, np.float64)
+        ob = np.zeros(8192 + 64, np.uint8)
+        cb = np.frombuffer(comp, np.uint8)
+        zlib_.zkb_time_seeks.restype = C.c_int
+        zlib_.zkb_time_seeks.argtypes = [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 2 + [C.c_uint32] + [C.c_void_p] * 2
+        if zlib_.zkb_time_seeks(cb.ctypes.data, c.ctypes.data, d.ctypes.data, len(frames), offs.ctypes.data, lens.ctypes.data,
+                                n, tus.ctypes.data, ob.ctypes.data) == 0:
+            out["cpu_reference_us"] = _pct(tus, min(50, n // 10))
+    return out
+
+
+def batched_seeks(eng, comp, frames, src, offs, B=1024, reps=7):
+    """Batches of B seeks per submission against the archive resident in HBM (zk_decode_frame_list_dev)."""
     import torch
     dev = torch.device("cuda", torch.cuda.current_device())
+    c = np.zeros(len(frames) + 1, np.uint64); d = np.zeros(len(frames) + 1, np.uint64)
+    c[1:] = np.cumsum([f[0] for f in frames]); d[1:] = np.cumsum([f[1] for f in frames])
     d_comp = torch.from_numpy(np.frombuffer(comp + b"\0" * 64, np.uint8).copy()).to(dev)
     d_c = torch.from_numpy(c.view(np.int64)).to(dev); d_d = torch.from_numpy(d.view(np.int64)).to(dev)
-    B = 1024
-    boffs = rng.integers(0, nbytes - 8192, B).astype(np.uint64)
-    ids = (np.searchsorted(d, boffs, side="right") - 1).astype(np.uint32)
-    sizes = (d[ids.astype(np.int64) + 1] - d[ids.astype(np.int64)]).astype(np.uint64)
-    ooff = np.zeros(B + 1, np.uint64); ooff[1:] = np.cumsum(sizes)
-    d_ids = torch.from_numpy(ids.view(np.int32)).to(dev); d_oo = torch.from_numpy(ooff.view(np.int64)).to(dev)
-    d_o = torch.empty(int(ooff[-1]) + 64, dtype=torch.uint8, device=dev); d_s = torch.zeros(B, dtype=torch.int32, device=dev)
     tb = []
-    for _ in range(7):
-        torch.cuda.synchronize(); t = time.perf_counter()
-        rc = eng.decode_frame_list_dev(d_comp, len(comp), d_c, d_d, d_ids, d_oo, B, d_o, int(ooff[-1]), True, d_s)
-        torch.cuda.synchronize(); tb.append((time.perf_counter() - t) * 1e6)
-    got = bytes(d_o[:int(ooff[3])].cpu().numpy())
-    if rc != 0 or got != b"".join(src[int(d[i]):int(d[i + 1])].tobytes() for i in ids[:3]):
-        raise RuntimeError("batched seek mismatch")
-    out["gpu_batch_of_1024"] = {"batch_us_p50": round(float(np.median(tb[2:])), 1), "us_per_seek": round(float(np.median(tb[2:])) / B, 2),
-                                "note": "1024 random frames per submission, archive + outputs resident in HBM, checksums verified"}
-    lib = zko.lib()
-    path = next((p for p in Z._CANDIDATES["system"] if os.path.exists(p)), None)
-    if path and lib.zkb_open(path.encode()) == 0:
-        tus = np.zeros(nseeks, np.float64)
-        ob = np.zeros(8192 + 8, np.uint8)
-        cb = np.frombuffer(comp, np.uint8)
-        lib.zkb_time_seeks.restype = C.c_int
-        lib.zkb_time_seeks.argtypes = [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 2 + [C.c_uint32] + [C.c_void_p] * 2
-        if lib.zkb_time_seeks(cb.ctypes.data, c.ctypes.data, d.ctypes.data, len(frames), offs.ctypes.data, lens.ctypes.data,
-                              nseeks, tus.ctypes.data, ob.ctypes.data) == 0:
-            out["cpu_reference_us"] = {"p50": round(float(np.percentile(tus[20:], 50)), 1), "p95": round(float(np.percentile(tus[20:], 95)), 1)}
+    nb = max(1, min(reps, len(offs) // B))
+    for r in range(nb):
+        boffs = offs[r * B:(r + 1) * B]
+        ids = (np.searchsorted(d, boffs, side="right") - 1).astype(np.uint32)
+        sizes = (d[ids.astype(np.int64) + 1] - d[ids.astype(np.int64)]).astype(np.uint64)
+        ooff = np.zeros(len(ids) + 1, np.uint64); ooff[1:] = np.cumsum(sizes)
+        d_ids = torch.from_numpy(ids.view(np.int32)).to(dev); d_oo = torch.from_numpy(ooff.view(np.int64)).to(dev)
+        d_o = torch.empty(int(ooff[-1]) + 64, dtype=torch.uint8, device=dev); d_s = torch.zeros(len(ids), dtype=torch.int32, device=dev)
+        for k in range(2):
+            torch.cuda.synchronize(); t = time.perf_counter()
+            rc = eng.decode_frame_list_dev(d_comp, len(comp), d_c, d_d, d_ids, d_oo, len(ids), d_o, int(ooff[-1]), True, d_s)
+            torch.cuda.synchronize()
+            if k:
+                tb.append((time.perf_counter() - t) * 1e6)
+        got = bytes(d_o[:int(ooff[3])].cpu().numpy())
+        if rc != 0 or got != b"".join(src[int(d[i]):int(d[i + 1])].tobytes() for i in ids[:3]):
+            raise RuntimeError("batched seek mismatch")
+    return {"batch": B, "batches": nb, "batch_us_p50": round(float(np.median(tb)), 1), "us_per_seek": round(float(np.median(tb)) / B, 2)}
+
+
+def seek_leg(eng, data, zk, z64, nbytes, trials, fsz=65536):
+    """BASELINE configs[3] as written: nbytes of generator text in 64 KiB frames, `trials` random
+    set_offset / set_offset_limit / read-to-exhaustion seeks (xorshift64* protocol), on BOTH the archive this engine's encoder
+    writes and the archive the reference's CPU Encoder writes; p50 / p95 / p99 one at a time, and batches of 1024."""
+    from oracle import libzstd_ref as Z
+    src = np.ascontiguousarray(data[:nbytes])
+    offs, lens = seek_protocol(trials, nbytes)
+    out = {"config": f"configs[3]: {nbytes >> 20} MiB, {nbytes // fsz} x {fsz >> 10} KiB frames, {trials} seeks, xorshift64* seed 0x5EED0003",
+           "frames": nbytes // fsz, "frame_size": fsz, "seeks": trials}
+    comp, frames = eng.encode_frames(src, fsz, 1, True)
+    g = time_single_seeks(eng, zk, comp, frames, src, offs, lens)
+    g["batches_of_1024"] = batched_seeks(eng, comp, frames, src, offs)
+    g["compressed_bytes"] = len(comp)
+    out["gpu_made_archive"] = g
+    if z64 is not None:
+        comp, frames = z64
+        r = time_single_seeks(eng, zk, comp, frames, src, offs, lens)
+        r["batches_of_1024"] = batched_seeks(eng, comp, frames, src, offs)
+        r["compressed_bytes"] = len(comp)
+        out["reference_made_archive"] = r
+    out["note"] = ("one seek = set_offset + set_offset_limit + decompress through the zeekstd Decoder API (host buffers, PCIe included): "
+                   "one frame on the GPU is launch + chain latency bound; batches of seeks are what the GPU is for")
     return out
 
 
@@ -181,6 +389,8 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="override frames per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-seek", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host buffers) leg")
+    ap.add_argument("--seek-trials", type=int, default=10000)
     ap.add_argument("--no-fork", action="store_true", help="generate the inputs in this process (profiling runs)")
     ap.add_argument("--no-ref-archive", action="store_true", help="skip the secondary leg on a CPU-libzstd-made archive")
     ap.add_argument("--sync", action="store_true",
@@ -208,6 +418,10 @@ def main():
     # headline, because archives written by zeekstd's own CPU Encoder are what a drop-in user decodes first
     want_ref_archive = (not use_gpu_archive) or (world == 1 and not args.no_ref_archive)
     data, z_comp, z_frames, hashes = build_inputs(rank * nframes, nframes, level, cks, workers, want_ref_archive, rank)
+    do_seek = rank == 0 and world == 1 and not args.no_seek
+    z64 = None
+    if do_seek and want_ref_archive and z_comp:           # the reference-made 64 KiB-frame archive of configs[3] (forked workers: before HIP)
+        z64 = libzstd_archive_parallel(np.asarray(data), 65536, level, True, workers)
     t_setup = time.time() - t0
 
     import torch
@@ -243,7 +457,8 @@ def main():
         frames = [(int(c), FRAME) for c in cs]
         comp = None
         enc_info = {"value": round(dsize / min(te) / 2**30, 2), "unit": "GiB/s", "ratio": round(dsize / csize, 3),
-                    "ms": round(min(te) * 1e3, 2), "kernel_ms": {k: round(v, 3) for k, v in ek.items()}}
+                    "ms": round(min(te) * 1e3, 2), "kernel_ms": {k: round(v, 3) for k, v in ek.items()},
+                    "algorithmic_GBps_of_the_slowest_kernel": round((dsize + csize) / (max(ek.values()) * 1e-3) / 1e9, 1) if ek else None}
     else:
         frames, comp = z_frames, z_comp
         d_comp = torch.from_numpy(np.frombuffer(comp + b"\0" * 64, np.uint8).copy()).to(dev)
@@ -256,7 +471,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if comp is None:
             comp = bytes(d_comp[:csize].cpu().numpy())             # CPU decodes the very same (GPU-made) archive
-        base = cpu_baseline(comp, frames, data, 512 if args.workload == "c3" else 128, level, cks)
+        base = cpu_baseline(comp, frames, data, 512 if args.workload == "c3" else 128, level, cks,
+                            z_comp if (use_gpu_archive and z_comp) else None, z_frames)
     d_c = torch.from_numpy(c.view(np.int64)).to(dev)
     d_d = torch.from_numpy(d.view(np.int64)).to(dev)
     d_out = torch.empty(dsize + 64, dtype=torch.uint8, device=dev)
@@ -389,36 +605,36 @@ def main():
     except OSError:
         pass
 
-    # ---- seek-to-offset latency (BASELINE.json configs[3] shape at reduced size): 64 KiB frames, random
-    #      set_offset / set_offset_limit / read through the zeekstd Decoder API (host buffers: PCIe included)
+    # ---- end to end: host buffers in, host buffers out through the zeekstd Encoder / Decoder API (PCIe inside the span)
+    e2e_info = None
+    if rank == 0 and world == 1 and not args.no_e2e:
+        del d_outs, d_sts
+        e2e_info = end_to_end(eng, zk, np.asarray(data), nframes, cks)
+
+    # ---- seek-to-offset latency: BASELINE.json configs[3] as written (a failing leg fails the run)
     seek_info = None
-    if rank == 0 and world == 1 and not args.no_seek:
-        try:
-            seek_info = seek_leg(eng, data, zk)
-        except Exception as ex:
-            seek_info = {"error": repr(ex)[:200]}
+    if do_seek:
+        seek_info = seek_leg(eng, np.asarray(data), zk, z64, dsize, args.seek_trials)
 
     # ---- N > 1: the one exchange step of the path -- encode the local shard, gather stream + seek table on rank 0 (RCCL)
     gather_info = None
     if world > 1 and use_gpu_archive:
-        try:
-            from zeekstd_amd import parallel
-            tg = []
-            for _ in range(2):
-                barrier(); torch.cuda.synchronize(); t = time.perf_counter()
-                out, table = parallel.encode_sharded(eng, d_src, FRAME, level, cks, root=0)
-                torch.cuda.synchronize(); barrier(); tg.append(time.perf_counter() - t)
-            gather_info = {"encode_plus_gather_GiB_per_s": round(dsize * world / min(tg) / 2**30, 2), "ms": round(min(tg) * 1e3, 2),
-                           "frames_on_root": table.num_frames() if table is not None else None,
-                           "stream_bytes_on_root": int(out.numel()) if out is not None else None}
-        except Exception as ex:              # never lose the headline line to the optional leg
-            gather_info = {"error": repr(ex)[:200]}
+        from zeekstd_amd import parallel
+        tg = []
+        for _ in range(2):
+            barrier(); torch.cuda.synchronize(); t = time.perf_counter()
+            out, table = parallel.encode_sharded(eng, d_src, FRAME, level, cks, root=0)
+            torch.cuda.synchronize(); barrier(); tg.append(time.perf_counter() - t)
+        gather_info = {"encode_plus_gather_GiB_per_s": round(dsize * world / min(tg) / 2**30, 2), "ms": round(min(tg) * 1e3, 2),
+                       "frames_on_root": table.num_frames() if table is not None else None,
+                       "stream_bytes_on_root": int(out.numel()) if out is not None else None}
 
     if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
         line = {
             "metric": "decode_decompressed_GiB_per_s", "value": round(value, 3), "unit": "GiB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "reference_made_archive": ref_info,
             "one_batch_at_a_time": {"value": round(dsize * args.steps / sync_elapsed / 2**30, 3), "unit": "GiB/s",
@@ -437,12 +653,18 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": {k: round(v, 3) for k, v in acc.items()}},
             "cpu_baseline": base,
             "encode": enc_info,
+            "round_trip": ({"value": round(dsize / (enc_info["ms"] * 1e-3 + ms_step * 1e-3) / 2**30, 2), "unit": "GiB/s",
+                            "note": "HBM-resident encode + decode of the same 4 GiB, encode ms + decode ms_per_step (BASELINE metric: encode+decode)"}
+                           if enc_info else None),
+            "end_to_end": e2e_info,
             "rccl_gather": gather_info,
             "seek": seek_info,
             "setup_s": round(t_setup, 1),
         }
         if base:
             line["speedup_vs_cpu_1thread"] = round(value / base["value"], 1)
+            if base.get("all_cores"):
+                line["speedup_vs_cpu_all_cores"] = round(value / base["all_cores"]["value"], 2)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

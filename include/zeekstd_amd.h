@@ -265,6 +265,12 @@ uint64_t zk_decoder_offset_limit(const zk_decoder *d);                          
 zk_seek_table *zk_decoder_seek_table(const zk_decoder *d);                                     /* :453 (a copy; free it) */
 int zk_decoder_seek(zk_decoder *d, int whence, int64_t n, uint64_t *out);                      /* io::Seek :545-579 */
 uint64_t zk_decoder_gpu_submissions(const zk_decoder *d);                                      /* engine-specific counter */
+/* Measurement helper (BASELINE.json configs[3]): n seeks one at a time -- set_offset(offs[i]);
+ * set_offset_limit(offs[i] + lens[i]); decompress to exhaustion (decode.rs:402-437, 201-270) -- each timed on its own with
+ * the monotonic clock, microseconds into us_out[i].  expect (optional): the archive's uncompressed bytes; every read is
+ * compared with expect + offs[i] outside the timed span.  Returns 0, a decoder error, or ZK_ERR_ARGUMENT on a mismatch. */
+int zk_decoder_time_seeks(zk_decoder *d, const uint64_t *offs, const uint32_t *lens, uint32_t n, uint8_t *buf, size_t buf_len,
+                          const uint8_t *expect, double *us_out);
 
 /* ---- EncodeOptions / RawEncoder / Encoder (lib/src/encode.rs) */
 typedef struct zk_raw_encoder zk_raw_encoder;

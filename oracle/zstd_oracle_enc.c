@@ -382,7 +382,7 @@ i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int le
     u32 bmax = (1u << wlog) < ZKE_BLOCK ? (1u << wlog) : ZKE_BLOCK;
     /* blocks are cut smaller than the format's maximum on purpose: a block's sequence bitstream is one serial chain
      * for the decoder, so more, shorter blocks = more parallel chains (32 KiB for large frames, >= 8 blocks per small frame) */
-    { u32 t = 32768; while (t > 4096 && t * 8 > n) t >>= 1; if (t < bmax) bmax = t; }
+    { u32 t = 32768; while (t > 4096 && (u64)t * 16 > n) t >>= 1; if (t < bmax) bmax = t; }
     for (u32 bs = 0; bs < n; bs += bmax) {
         u32 be = bs + bmax < n ? bs + bmax : (u32)n;
         u32 bsz = be - bs, last = be == n;

@@ -1,0 +1,105 @@
+"""BASELINE.json configs[3] as a parity test: 64 KiB frames, random set_offset / set_offset_limit / read-to-exhaustion seeks
+(the xorshift64* protocol of SURVEY 8d, bench.seek_protocol) through the zeekstd Decoder API, every read compared with the
+generator bytes -- on the archive this engine's encoder writes and on the archive the reference's CPU Encoder writes.
+Mirrors lib/src/decode.rs:822-851 (byte ranges) and fuzz/fuzz_targets/roundtrip_seek.rs:7-43."""
+import ctypes as C
+import subprocess
+import sys
+import os
+
+import numpy as np
+import pytest
+
+import zeekstd_amd as zk
+from zeekstd_amd import DecodeOptions, SeekTable
+import bench
+from oracle import zko
+from oracle import libzstd_ref as Z
+
+pytestmark = pytest.mark.gpu
+FSZ = 65536
+NBYTES = 64 << 20                       # 1024 frames of 64 KiB
+
+
+@pytest.fixture(scope="module")
+def text():
+    return zko.gen_chunks(NBYTES, 40)
+
+
+def _archive(engine, text, who):
+    if who == "gpu":
+        return engine.encode_frames(np.frombuffer(text, np.uint8), FSZ, 1, True)
+    if Z.load("system") is None:
+        pytest.skip("needs a libzstd to build the reference-made archive")
+    return Z.encode_seekable_frames(text, FSZ, 1, True, "system")
+
+
+def _seekable(comp, frames):
+    st = SeekTable.new()
+    for c, d in frames:
+        st.log_frame(c, d)
+    return comp + st.to_bytes()
+
+
+@pytest.mark.parametrize("who", ["gpu", "libzstd"])
+def test_random_seeks_64k_frames(engine, text, who):
+    comp, frames = _archive(engine, text, who)
+    assert len(frames) == NBYTES // FSZ
+    d = DecodeOptions(_seekable(comp, frames)).engine(engine).into_decoder()
+    offs, lens = bench.seek_protocol(400, NBYTES)
+    buf = bytearray(8192)
+    for o, l in zip(offs.tolist(), lens.tolist()):
+        d.set_offset_limit(NBYTES)
+        d.set_offset(o)
+        d.set_offset_limit(o + l)
+        got = bytearray()
+        while True:
+            k = d.decompress(buf)
+            if k == 0:
+                break
+            got += buf[:k]
+        assert bytes(got) == text[o:o + l], (who, o, l)
+        assert d.offset() == o + l
+
+
+@pytest.mark.parametrize("who", ["gpu", "libzstd"])
+def test_seek_timing_helper_verifies(engine, text, who):
+    """zk_decoder_time_seeks (the bench's one-at-a-time leg) compares every read with the expected bytes."""
+    comp, frames = _archive(engine, text, who)
+    src = np.frombuffer(text, np.uint8)
+    offs, lens = bench.seek_protocol(300, NBYTES)
+    r = bench.time_single_seeks(engine, zk, comp, frames, src, offs, lens)
+    assert r["gpu_decoder_us"]["p50"] > 0
+    bad = src.copy(); bad[int(offs[7])] ^= 1            # a wrong expectation must be noticed
+    with pytest.raises(RuntimeError):
+        bench.time_single_seeks(engine, zk, comp, frames, bad, offs, lens)
+
+
+def test_batched_seeks(engine, text):
+    comp, frames = _archive(engine, text, "gpu")
+    src = np.frombuffer(text, np.uint8)
+    offs, _ = bench.seek_protocol(2048, NBYTES)
+    r = bench.batched_seeks(engine, comp, frames, src, offs, B=1024, reps=2)
+    assert r["batches"] == 2 and r["us_per_seek"] > 0
+
+
+def test_forward_seek_inside_the_cached_frame_costs_no_submission(engine, text):     # decode.rs:912-939
+    comp, frames = _archive(engine, text, "gpu")
+    d = DecodeOptions(_seekable(comp, frames)).engine(engine).into_decoder()
+    d.set_offset(5 * FSZ + 100); d.set_offset_limit(5 * FSZ + 200)
+    buf = bytearray(4096)
+    assert d.decompress(buf) == 100
+    n = d.gpu_submissions()
+    d.set_offset_limit(NBYTES); d.set_offset(5 * FSZ + 3000); d.set_offset_limit(5 * FSZ + 3500)
+    assert d.decompress(buf) == 500 and bytes(buf[:500]) == text[5 * FSZ + 3000:5 * FSZ + 3500]
+    assert d.gpu_submissions() == n and d.read_compressed() > 0
+
+
+def test_cpu_suites_also_pass_on_the_gpu_box():
+    """The seek-table golden bytes (tests/test_seek_table.py) and the ABI checks (tests/test_abi.py: every symbol of
+    include/zeekstd_amd.h is exported, the product never touches oracle/) are CPU tests; the driver's GPU pass selects
+    `-m gpu` only, so they are run from here as well."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "not gpu", "tests/test_seek_table.py", "tests/test_abi.py"],
+                       cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

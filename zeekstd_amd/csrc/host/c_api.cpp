@@ -1,6 +1,7 @@
 // c_api.cpp -- Level B of include/zeekstd_amd.h: C handles over the zeekstd:: host classes.
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include "../../../include/zeekstd_amd.h"
 #include "zeekstd.hpp"
@@ -150,6 +151,32 @@ int zk_decoder_open_callbacks(zk_engine *e, zk_seek_fn set_offset, zk_read_fn re
 }
 
 void zk_decoder_free(zk_decoder *d) { delete d; }
+
+int zk_decoder_time_seeks(zk_decoder *d, const uint64_t *offs, const uint32_t *lens, uint32_t n, uint8_t *buf, size_t buf_len,
+                          const uint8_t *expect, double *us_out)
+{
+    if (!d || !offs || !lens || !buf || !us_out) return ZK_ERR_ARGUMENT;
+    int bad = 0;
+    int rc = guard([&] {
+        const uint64_t total = d->d.seek_table().size_decomp();
+        for (uint32_t i = 0; i < n; i++) {
+            const uint64_t lim = std::min<uint64_t>(offs[i] + lens[i], total);
+            const auto t0 = std::chrono::steady_clock::now();
+            d->d.set_offset_limit(total);
+            d->d.set_offset(offs[i]);
+            d->d.set_offset_limit(lim);
+            size_t got = 0;
+            for (;;) {
+                const size_t k = d->d.decompress(buf + got, buf_len - got);
+                if (k == 0) break;
+                got += k;
+            }
+            us_out[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (got != lim - offs[i] || (expect && memcmp(buf, expect + offs[i], got) != 0)) { bad = 1; return; }
+        }
+    });
+    return rc ? rc : bad ? ZK_ERR_ARGUMENT : 0;
+}
 int64_t zk_decoder_decompress(zk_decoder *d, uint8_t *buf, size_t len)
 {
     int64_t n = 0;

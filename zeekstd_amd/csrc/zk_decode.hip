@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include "zk_device.h"
 #include "zk_kernels.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------ walk
 // ids != nullptr: frame f of the batch is frame ids[f] of the archive (random-access batches: many seeks per submission)
@@ -152,7 +153,8 @@ __device__ void zk_huf_companion(const uint8_t *base, uint32_t len, uint8_t *dst
     asm volatile("" :: "v"(sink));
 }
 
-__global__ __launch_bounds__(128) void zk_k_huf(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint8_t *lit_scratch)
+// The body of the kernel for block group `group` (16 blocks); also called in a loop by zk_k_small_entropy.
+__device__ __forceinline__ void zk_huf_group(uint32_t group, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint8_t *lit_scratch)
 {
     __shared__ __attribute__((aligned(16))) uint16_t pool[ZK_HUF_POOL];
     __shared__ ZkHufHdr hdr[ZK_HUF_BLOCKS];
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(128) void zk_k_huf(const uint8_t *comp, ZkBlock *bl
     // (< 16 active lanes run ~3x slower on gfx950, tools/ubench/lat3.hip); shadows never store to HBM
     const uint32_t t = threadIdx.x & 63;
     const bool decoder = threadIdx.x < 64;
-    const uint32_t wb = blockIdx.x * ZK_HUF_BLOCKS;
+    const uint32_t wb = group * ZK_HUF_BLOCKS;
     const uint32_t nvalid = nblocks - wb < (uint32_t)ZK_HUF_BLOCKS ? nblocks - wb : (uint32_t)ZK_HUF_BLOCKS;
     const bool real = t < 4 * nvalid;
     const uint32_t lane = real ? t : (t < 16 ? t % (4 * nvalid) : t);
@@ -245,6 +247,10 @@ __global__ __launch_bounds__(128) void zk_k_huf(const uint8_t *comp, ZkBlock *bl
     }
     if (decoder && active && !ok && real) blocks[bi].status = ZK_E_CORRUPTION;
 }
+__global__ __launch_bounds__(128) void zk_k_huf(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint8_t *lit_scratch)
+{
+    zk_huf_group(blockIdx.x, comp, blocks, nblocks, lit_scratch);
+}
 
 // ------------------------------------------------------------------------------------------------ FSE sequences
 // One lane per block, the block's LL / ML (2^9) and OF (2^8) tables + build scratch / record ring in LDS.  A block's
@@ -310,12 +316,15 @@ struct ZkQuadDpp {
 // wave some lane crosses into a new cache line at almost every step -- without help every other step of the whole wave
 // waits for an L2 round trip.  The walkers publish their stream position once per 16 sequences; the toucher wave (its
 // own load counter, results never used) requests the two lines below it.
-template <typename CP, int ZK_FSE_BLOCKS, int ZK_FSE_WAVES>
-__global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs, uint32_t all_blocks)
+// STAGE (small batches): the quad copies its block's bitstream (up to ZK_FSE_STAGE bytes) into LDS before the walk.
+constexpr uint32_t ZK_FSE_STAGE = 3072;
+template <typename CP, int ZK_FSE_BLOCKS, int ZK_FSE_WAVES, bool STAGE = false>
+__device__ __forceinline__ void zk_fse_quad_group(uint32_t group, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs, uint32_t all_blocks)
 {
     constexpr int PER_WAVE = ZK_FSE_BLOCKS / ZK_FSE_WAVES;
     static_assert(PER_WAVE * 4 <= 64 && ZK_FSE_BLOCKS <= 64, "a quad of lanes per block; a toucher lane per block");
     __shared__ ZkSeqTablesT<CP> T[ZK_FSE_BLOCKS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_bits[STAGE ? ZK_FSE_BLOCKS : 1][STAGE ? ZK_FSE_STAGE + 16 : 16];
     __shared__ uint32_t llv[36], mlv[53], ofv[32];
     __shared__ uint32_t s_pos[ZK_FSE_BLOCKS], s_live;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const u
     const bool toucher = wave == (uint32_t)ZK_FSE_WAVES;
     const uint32_t t = lane & 3;
     const uint32_t slot = toucher ? lane : wave * PER_WAVE + (lane >> 2);
-    const uint32_t bi = blockIdx.x * ZK_FSE_BLOCKS + slot;
+    const uint32_t bi = group * ZK_FSE_BLOCKS + slot;
     ZkBlock b;
     bool valid = toucher ? lane < (uint32_t)ZK_FSE_BLOCKS : (lane < 4 * PER_WAVE && t != 3);
     valid = valid && bi < nblocks;
@@ -373,10 +382,20 @@ __global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const u
     }
     if (!ok) b.status = ZK_E_CORRUPTION;
     else {
+        const uint8_t *bits = nullptr;
+        if (STAGE) {
+            const uint32_t bs = b.seq_off + 1 + own;
+            if (bs < b.bsize && b.bsize - bs <= ZK_FSE_STAGE) {
+                const uint32_t len = b.bsize - bs;
+                const uint8_t *g = comp + b.src + bs;
+                for (uint32_t o = t * 8; o < len + 8; o += 24) { const uint64_t w = zk_ld64(g + o); memcpy(&s_bits[slot][o], &w, 8); }
+                bits = s_bits[slot];
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         zk_seq_walk_quad<ZkRevU, CP, ZkQuadDpp>(comp, b, b.seq_off + 1 + own, t,
                                      t == ZK_TAB_LL ? Tb->ll : t == ZK_TAB_OF ? Tb->of : Tb->ml,
-                                     t == ZK_TAB_LL ? llv : t == ZK_TAB_OF ? ofv : mlv, al, Tb->ring, seqs + b.seq_base, &s_pos[slot]);
+                                     t == ZK_TAB_LL ? llv : t == ZK_TAB_OF ? ofv : mlv, al, Tb->ring, seqs + b.seq_base, &s_pos[slot], bits);
     }
     if (t != ZK_TAB_LL) return;
     atomicSub(&s_live, 1u);
@@ -384,6 +403,11 @@ __global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const u
     o->out_size = b.out_size;
     o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
     o->status = b.status;
+}
+template <typename CP, int ZK_FSE_BLOCKS, int ZK_FSE_WAVES>
+__global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs, uint32_t all_blocks)
+{
+    zk_fse_quad_group<CP, ZK_FSE_BLOCKS, ZK_FSE_WAVES>(blockIdx.x, comp, blocks, nblocks, seqs, all_blocks);
 }
 
 // Blocks whose three tables are all Predefined_Mode (Symbol_Compression_Modes == 0: what this engine's own
@@ -738,6 +762,129 @@ __global__ __launch_bounds__(256) void zk_k_status(const ZkFrameInfo *infos, uin
     if (st != ZK_OK) atomicMin(first_err, ((unsigned long long)f << 32) | st);
 }
 
+
+// ------------------------------------------------------------------------------------------------ small batches (a seek)
+// A handful of frames is all latency: launches, read-backs and copy commands cost more than the decoding.  The small path
+// therefore runs without a host round trip and without copy commands:
+//   zk_k_small_walk     one workgroup: pulls the staged compressed bytes + offsets out of PINNED HOST memory into HBM scratch
+//                       (the upload), walks the frames (count, scan, fill in one kernel) and leaves the totals in HBM;
+//   zk_k_small_entropy  Huffman groups and sequence groups (quads) in ONE launch, the group count read from HBM;
+//   zk_k_exec           as always; zk_k_xxh64 only for frames that are verified;
+//   zk_k_small_publish  writes the frames' bytes and status words into PINNED HOST memory (the download) and, last of all,
+//                       a completion word the host spins on.
+// Scratch is sized from bounds the host knows (sequences <= d / 3, literals <= d); the block list has a cap and a batch
+// that exceeds it reports ZK_SMALL_OVERFLOW, upon which the host takes the general path.
+constexpr uint32_t ZK_SMALL_OVERFLOW = 0xFFFFFFFFu;
+__global__ __launch_bounds__(256) void zk_k_small_walk(const uint8_t *h_comp, uint64_t comp_bytes, const uint64_t *h_offs, uint32_t count,
+                                                       uint64_t dst_cap, uint32_t block_cap, uint8_t *d_comp, uint64_t *d_offs,
+                                                       ZkFrameInfo *infos, ZkFrameBase *bases, ZkBlock *blocks, uint64_t *words)
+{
+    __shared__ uint32_t s_tot[4];
+    const uint32_t tid = threadIdx.x;
+    // upload: 16 bytes per lane and step, straight over PCIe (h_comp is 16-byte aligned, padded to a multiple of 16)
+    const uint64_t n16 = (comp_bytes + 15) >> 4;
+    for (uint64_t i = tid; i < n16; i += 256) reinterpret_cast<uint4 *>(d_comp)[i] = reinterpret_cast<const uint4 *>(h_comp)[i];
+    if (tid < 2) reinterpret_cast<uint64_t *>(d_comp + (n16 << 4))[tid] = 0;                 // readable padding behind the last frame
+    for (uint32_t i = tid; i < 2 * (count + 1); i += 256) d_offs[i] = h_offs[i];
+    __syncthreads();
+    const uint64_t *c_off = d_offs, *d_off = d_offs + count + 1;
+    ZkFrameInfo fi;
+    fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; fi.status = ZK_OK; fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.n_own_tables = 0;
+    uint64_t cb = 0, ce = 0, dsz = 0;
+    if (tid < count) {
+        cb = c_off[tid]; ce = c_off[tid + 1]; dsz = d_off[tid + 1] - d_off[tid];
+        if (ce < cb || ce > comp_bytes || d_off[tid + 1] < d_off[tid]) fi.status = ZK_E_SRC_SIZE_WRONG;
+        else {
+            zk_walk_frame(d_comp, cb, ce, dsz, tid, nullptr, nullptr, fi);
+            if (fi.status == ZK_OK && (d_off[tid] > dst_cap || dsz > dst_cap - d_off[tid])) fi.status = ZK_E_DST_TOO_SMALL;
+            if (dsz > ZK_MAX_FRAME && fi.status == ZK_OK) fi.status = ZK_E_FRAMEPARAM_UNSUPPORTED;
+        }
+        if (fi.status != ZK_OK) { fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; fi.n_own_tables = 0; }
+    }
+    if (tid < 64) {                                          // count <= 64: one wave scans
+        uint32_t v[4] = {fi.n_blocks, fi.n_seq, fi.lit_bytes, fi.n_own_tables}, inc[4];
+        for (int k = 0; k < 4; k++) {
+            uint32_t x = v[k];
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if ((int)tid >= d) x += y; }
+            inc[k] = x;
+            if (tid == 63) s_tot[k] = x;
+        }
+        if (tid < count) {
+            ZkFrameBase fb;
+            fb.block_base = inc[0] - v[0]; fb.seq_base = inc[1] - v[1]; fb.lit_base = inc[2] - v[2];
+            bases[tid] = fb;
+        }
+    }
+    __syncthreads();
+    const bool overflow = s_tot[0] > block_cap;
+    if (tid < count) {
+        if (overflow) { fi.status = ZK_E_GENERIC; fi.n_blocks = 0; }
+        infos[tid] = fi;
+        if (!overflow && fi.status == ZK_OK) { ZkFrameInfo f2; zk_walk_frame(d_comp, cb, ce, dsz, tid, &bases[tid], blocks, f2); }
+    }
+    if (tid == 0) {
+        words[0] = overflow ? 0 : s_tot[0]; words[1] = overflow ? 0 : s_tot[1]; words[2] = overflow ? 0 : s_tot[2];
+        words[3] = ~0ull; words[4] = s_tot[3]; words[5] = overflow ? 1 : 0; words[6] = 0;
+    }
+}
+
+// Huffman groups (role 0) and sequence groups (role 1) of a small batch in one launch; the number of blocks comes from HBM.
+__global__ __launch_bounds__(128) void zk_k_small_entropy(const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeq *seqs)
+{
+    const uint32_t nblocks = (uint32_t)words[0];
+    const uint32_t role = blockIdx.x & 1, stride = gridDim.x >> 1;
+    for (uint32_t g = blockIdx.x >> 1; g * 16 < nblocks; g += stride) {
+        if (role == 0) zk_huf_group(g, comp, blocks, nblocks, lit);
+        else zk_fse_quad_group<ZkCells16, 16, 1, true>(g, comp, blocks, nblocks, seqs, 1u);
+        __syncthreads();                                     // the group's LDS state is re-initialised by the next one
+    }
+}
+
+// the two roles as kernels of their own (diagnosis: ZK_SMALL_SPLIT=1 shows them separately in a kernel trace)
+__global__ __launch_bounds__(128) void zk_k_small_huf(const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit)
+{
+    const uint32_t nblocks = (uint32_t)words[0];
+    for (uint32_t g = blockIdx.x; g * 16 < nblocks; g += gridDim.x) { zk_huf_group(g, comp, blocks, nblocks, lit); __syncthreads(); }
+}
+__global__ __launch_bounds__(128) void zk_k_small_fse(const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, ZkSeq *seqs)
+{
+    const uint32_t nblocks = (uint32_t)words[0];
+    for (uint32_t g = blockIdx.x; g * 16 < nblocks; g += gridDim.x) { zk_fse_quad_group<ZkCells16, 16, 1, true>(g, comp, blocks, nblocks, seqs, 1u); __syncthreads(); }
+}
+
+// One workgroup per frame: the download.  h_out may be null (the caller wants the bytes in HBM only).
+__global__ __launch_bounds__(256) void zk_k_small_publish(const ZkFrameInfo *infos, const uint64_t *d_offs, uint32_t count, const uint8_t *dst,
+                                                          uint8_t *h_out, int32_t *d_status, int32_t *h_status, uint64_t *words,
+                                                          volatile uint32_t *h_flag, uint32_t gen)
+{
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const uint64_t *d_off = d_offs + count + 1;
+    const uint32_t st = words[5] ? ZK_SMALL_OVERFLOW : infos[f].status;
+    if (h_out && (st == ZK_OK || st == ZK_E_CHECKSUM_WRONG)) {      // a frame that fails its checksum is complete: a reader that
+        const uint64_t lo = d_off[f], hi = d_off[f + 1];          // offset_limit cut short ignores that verdict (decode.rs:425-427)
+        const uint8_t *s = dst + lo;
+        uint8_t *o = h_out + lo;
+        // 16-byte pieces where both sides allow it, bytes at the ragged ends
+        const uint64_t head = (0 - (uintptr_t)o) & 15, n = hi - lo;
+        if ((((uintptr_t)s + head) & 15) == 0 && n >= 64) {
+            for (uint64_t i = tid; i < head; i += 256) o[i] = s[i];
+            const uint64_t n16 = (n - head) >> 4;
+            for (uint64_t i = tid; i < n16; i += 256) reinterpret_cast<uint4 *>(o + head)[i] = reinterpret_cast<const uint4 *>(s + head)[i];
+            for (uint64_t i = head + (n16 << 4) + tid; i < n; i += 256) o[i] = s[i];
+        } else for (uint64_t i = tid; i < n; i += 256) o[i] = s[i];
+    }
+    if (tid == 0) {
+        if (d_status) d_status[f] = (int32_t)st;
+        h_status[f] = (int32_t)st;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long done = atomicAdd((unsigned long long *)&words[6], 1ull) + 1;
+        if (done == count) { __threadfence_system(); *h_flag = gen; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 void zk_launch_status(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, uint64_t *first_err)
 {
@@ -805,4 +952,25 @@ void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off,
                      ZkFrameInfo *infos, uint64_t *hashes)
 {
     hipLaunchKernelGGL(zk_k_xxh64, dim3(count), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
+}
+
+void zk_launch_small_walk(hipStream_t st, const uint8_t *h_comp, uint64_t comp_bytes, const uint64_t *h_offs, uint32_t count, uint64_t dst_cap,
+                          uint32_t block_cap, uint8_t *d_comp, uint64_t *d_offs, ZkFrameInfo *infos, ZkFrameBase *bases, ZkBlock *blocks, uint64_t *words)
+{
+    hipLaunchKernelGGL(zk_k_small_walk, dim3(1), dim3(256), 0, st, h_comp, comp_bytes, h_offs, count, dst_cap, block_cap, d_comp, d_offs, infos, bases, blocks, words);
+}
+void zk_launch_small_entropy(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeq *seqs, uint32_t groups)
+{
+    static const bool split = getenv("ZK_SMALL_SPLIT") != nullptr;
+    if (split) {
+        hipLaunchKernelGGL(zk_k_small_huf, dim3(groups), dim3(128), 0, st, comp, blocks, words, lit);
+        hipLaunchKernelGGL(zk_k_small_fse, dim3(groups), dim3(128), 0, st, comp, blocks, words, seqs);
+        return;
+    }
+    hipLaunchKernelGGL(zk_k_small_entropy, dim3(2 * groups), dim3(128), 0, st, comp, blocks, words, lit, seqs);
+}
+void zk_launch_small_publish(hipStream_t st, const ZkFrameInfo *infos, const uint64_t *d_offs, uint32_t count, const uint8_t *dst, uint8_t *h_out,
+                             int32_t *d_status, int32_t *h_status, uint64_t *words, uint32_t *h_flag, uint32_t gen)
+{
+    hipLaunchKernelGGL(zk_k_small_publish, dim3(count), dim3(256), 0, st, infos, d_offs, count, dst, h_out, d_status, h_status, words, h_flag, gen);
 }

@@ -1076,14 +1076,17 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
 // t = the lane's table (ZK_TAB_LL / ZK_TAB_OF / ZK_TAB_ML = its position in the quad); cells / vt: that table's cells
 // and value table (offsets: entries k << 24, the baseline 1 << k is formed here); al[3]: accuracy logs (LL, OF, ML).
 // All three lanes return the same b (out_size, rep_out, status); lane ZK_TAB_LL owns the ring.
+// bits: where the lane reads the bitstream from -- nullptr = in place (comp + b.src + bs_off), or a staged copy of its
+// b.bsize - bs_off bytes (LDS, readable 8 bytes past the end): the walk's one memory access per step then costs an LDS
+// round trip instead of an L2 one (small batches, where a block's chain is all that counts).
 template <typename RD, typename CP, typename XCH>
 ZK_HD void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, uint32_t t,
                                                  const typename CP::cell_t *cells, const uint32_t *vt, const uint32_t *al,
-                                                 ZkSeq *ring, ZkSeq *seqs, volatile uint32_t *pos_pub)
+                                                 ZkSeq *ring, ZkSeq *seqs, volatile uint32_t *pos_pub, const uint8_t *bits = nullptr)
 {
     RD r;
     uint32_t bad = 0;
-    const bool ok = bs_off < b.bsize && r.init(comp + b.src + bs_off, b.bsize - bs_off);
+    const bool ok = bs_off < b.bsize && r.init(bits ? bits : comp + b.src + bs_off, b.bsize - bs_off);
     if (!ok) { b.status = ZK_E_CORRUPTION; return; }
     const uint32_t nseq = b.nseq;
     uint32_t state;

@@ -16,7 +16,8 @@ constexpr uint32_t ZKE_GROUP = 8;                // tiles parsed side by side, o
 
 // Block size the encoder cuts a frame of d_size bytes into.  Blocks are cut smaller than the format's maximum on purpose:
 // a block's sequence bitstream is one serial chain for the decoder, so more, shorter blocks = more parallel chains
-// (32 KiB for large frames, >= 8 blocks per small frame, never below 4 KiB).
+// (32 KiB for large frames, >= 16 blocks per small frame, never below 4 KiB: a seek into a 64 KiB frame waits for ONE
+// block's chain, and at the idle clocks a sparse stream of seeks runs at that is ~40 us per KiB of block).
 ZK_HD uint32_t zke_block_max(uint32_t d_size, bool prefix)
 {
     uint32_t wlog = 10;
@@ -24,7 +25,7 @@ ZK_HD uint32_t zke_block_max(uint32_t d_size, bool prefix)
     if (prefix) wlog = 17;
     uint32_t bm = (1u << wlog) < ZKE_BLOCK ? (1u << wlog) : ZKE_BLOCK;
     uint32_t t = 32768;
-    while (t > 4096 && (uint64_t)t * 8 > d_size) t >>= 1;
+    while (t > 4096 && (uint64_t)t * 16 > d_size) t >>= 1;
     return t < bm ? t : bm;
 }
 

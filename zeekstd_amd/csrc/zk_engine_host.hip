@@ -229,6 +229,7 @@ struct zk_hostpipe {
     // small pinned areas: offsets / status words of the call in flight, and the staging of small requests
     uint8_t *pin_meta = nullptr; size_t pin_meta_cap = 0;
     uint8_t *pin_small = nullptr; size_t pin_small_cap = 0;
+    uint32_t *pin_flag = nullptr; uint32_t small_gen = 0;      // completion word of the small path, written by its last kernel
     // encode: double-buffered HBM chunk buffers
     struct ESlot { zk_devbuf d_src, d_dst, d_sizes; hipEvent_t ev_in = nullptr, ev_enc = nullptr, ev_out = nullptr; bool out_pending = false; } es[2];
 };
@@ -267,6 +268,8 @@ static int zk_hostpipe_get(zk_engine *e, zk_hostpipe **out)
         ZK_HIP(hipEventCreateWithFlags(&s.ev_dec, hipEventDisableTiming));
         ZK_HIP(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
     }
+    ZK_HIP(hipHostMalloc((void **)&hp->pin_flag, 64, hipHostMallocDefault));
+    *hp->pin_flag = 0;
     for (auto &s : hp->es) {
         ZK_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
         ZK_HIP(hipEventCreateWithFlags(&s.ev_enc, hipEventDisableTiming));
@@ -287,6 +290,8 @@ static int zk_hostpipe_rings(zk_engine *e, zk_hostpipe *hp)
     return 0;
 }
 
+int zk_hostpipe_create(zk_engine *e) { zk_hostpipe *hp = nullptr; return zk_hostpipe_get(e, &hp); }
+
 void zk_hostpipe_destroy(zk_engine *e)
 {
     zk_hostpipe *hp = e->hp;
@@ -305,6 +310,7 @@ void zk_hostpipe_destroy(zk_engine *e)
     }
     if (hp->pin_meta) (void)hipHostFree(hp->pin_meta);
     if (hp->pin_small) (void)hipHostFree(hp->pin_small);
+    if (hp->pin_flag) (void)hipHostFree(hp->pin_flag);
     if (hp->s_h2d) (void)hipStreamDestroy(hp->s_h2d);
     if (hp->s_d2h) (void)hipStreamDestroy(hp->s_d2h);
     delete hp;
@@ -382,6 +388,80 @@ static int zk_src_fill(zk_engine *e, zk_hostpipe *hp, const zk_host_src &src, ui
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- decode: the small path
+// A seek (one frame, a few): four or five kernel launches on one queue, no copy command, no read-back in the middle, and
+// the host spins on a pinned completion word instead of a stream synchronisation.  See zk_decode.hip (zk_k_small_*).
+// *fallback is set when the batch does not fit the small path's fixed scratch (the general path takes it then).
+static int zk_decode_small(zk_engine *e, zk_hostpipe *hp, const zk_host_src &src, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
+                           uint32_t count, const void *d_prefix, uint64_t prefix_len, uint8_t *dst, bool dst_pinned, int verify,
+                           int32_t *frame_status, uint32_t *n_ok, bool *fallback)
+{
+    *fallback = false;
+    const uint64_t c_lo = c_off[first], c_hi = c_off[first + count], d_lo = d_off[first], d_hi = d_off[first + count];
+    const uint64_t csz = c_hi - c_lo, dsz = d_hi - d_lo;
+    int rc;
+    // pinned staging: offsets | compressed bytes | status words | (output bytes when the caller's buffer is not pinned)
+    const size_t offs_bytes = ((size_t)(count + 1) * 16 + 63) & ~(size_t)63;
+    const size_t comp_bytes = ((size_t)csz + 15 + 64) & ~(size_t)63;
+    const size_t stat_bytes = ((size_t)count * 4 + 63) & ~(size_t)63;
+    if ((rc = zk_pin_grow(e, hp->pin_small, hp->pin_small_cap, offs_bytes + comp_bytes + stat_bytes + (dst_pinned ? 0 : (size_t)dsz + 64)))) return rc;
+    uint64_t *h_offs = (uint64_t *)hp->pin_small;
+    uint8_t *h_comp = hp->pin_small + offs_bytes;
+    int32_t *h_status = (int32_t *)(h_comp + comp_bytes);
+    uint8_t *h_out = dst_pinned ? dst : (uint8_t *)h_status + stat_bytes;
+    for (uint32_t k = 0; k <= count; k++) { h_offs[k] = c_off[first + k] - c_lo; h_offs[count + 1 + k] = d_off[first + k] - d_lo; }
+    if ((rc = zk_src_fill(e, hp, src, c_lo, h_comp, (size_t)csz))) return rc;
+    memset(h_comp + csz, 0, comp_bytes - (size_t)csz);
+    for (uint32_t k = 0; k < count; k++) h_status[k] = -1;
+
+    // scratch from bounds the host knows: every sequence regenerates >= 3 bytes, literals never exceed the output
+    zk_dec_ctx c = zk_dec_context(e, 0, nullptr);
+    zk_hostpipe::Slot &s = hp->slot[0];
+    const uint32_t block_cap = (uint32_t)(1024 + dsz / 1024 + 8ull * count);
+    if ((rc = zk_devbuf_reserve(e, c.infos, (size_t)count * sizeof(ZkFrameInfo)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.bases, (size_t)count * sizeof(ZkFrameBase)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.words, 16 * sizeof(uint64_t)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.blocks, (size_t)(block_cap + 1) * sizeof(ZkBlock)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)(dsz / 3 + count + 1) * sizeof(ZkSeq)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.lit, (size_t)dsz + 64))) return rc;
+    if ((rc = zk_devbuf_reserve(e, s.d_in, comp_bytes + 64))) return rc;
+    if ((rc = zk_devbuf_reserve(e, s.d_out, (size_t)dsz + 64))) return rc;
+    if ((rc = zk_devbuf_reserve(e, s.d_off, offs_bytes))) return rc;
+    if ((rc = zk_devbuf_reserve(e, s.d_st, stat_bytes))) return rc;
+    hipStream_t st = c.st;
+    ZkFrameInfo *infos = (ZkFrameInfo *)c.infos.p;
+    ZkBlock *blocks = (ZkBlock *)c.blocks.p;
+    uint64_t *words = (uint64_t *)c.words.p, *d_offs = (uint64_t *)s.d_off.p;
+    const uint8_t *comp = (const uint8_t *)s.d_in.p;
+    const uint32_t gen = ++hp->small_gen;
+    zk_launch_small_walk(st, h_comp, csz, h_offs, count, dsz, block_cap, (uint8_t *)s.d_in.p, d_offs, infos, (ZkFrameBase *)c.bases.p, blocks, words);
+    uint32_t groups = (block_cap + 15) / 16;
+    if (groups > 32) groups = 32;
+    zk_launch_small_entropy(st, comp, blocks, words, (uint8_t *)c.lit.p, (ZkSeq *)c.seqs.p, groups);
+    zk_launch_exec(st, comp, d_offs + count + 1, 0, count, nullptr, nullptr, blocks, (const ZkFrameBase *)c.bases.p, infos, (const ZkSeq *)c.seqs.p,
+                   (const uint8_t *)c.lit.p, (uint8_t *)s.d_out.p, (const uint8_t *)d_prefix, d_prefix ? prefix_len : 0);
+    if (verify) zk_launch_xxh64(st, (const uint8_t *)s.d_out.p, d_offs + count + 1, 0, count, infos, nullptr);
+    zk_launch_small_publish(st, infos, d_offs, count, (const uint8_t *)s.d_out.p, dsz ? h_out : nullptr, (int32_t *)s.d_st.p, h_status, words, hp->pin_flag, gen);
+    // completion: the last workgroup of the publish kernel writes the generation into pinned memory
+    volatile uint32_t *flag = hp->pin_flag;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; *flag != gen; spins++) {
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+            ZK_HIP(hipStreamSynchronize(st));              // something is slow or wrong: let the runtime tell
+            ZK_HIP(hipGetLastError());
+            if (*flag != gen) { e->last_err = "small decode path: completion word never arrived"; return ZK_ERR_HIP; }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (h_status[0] == (int32_t)0xFFFFFFFF) { *fallback = true; return 0; }
+    if (!dst_pinned && dsz) memcpy(dst, h_out, (size_t)dsz);
+    uint32_t ok = count;
+    for (uint32_t i = 0; i < count; i++) if (h_status[i] != 0) { ok = i; break; }
+    if (frame_status) memcpy(frame_status, h_status, (size_t)count * 4);
+    if (n_ok) *n_ok = ok;
+    return ok == count ? 0 : -(int)h_status[ok];
+}
+
 int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, const uint64_t *d_off, uint32_t first, uint32_t count,
                    const void *d_prefix, uint64_t prefix_len, uint8_t *dst, uint64_t dst_cap, int verify, int32_t *frame_status,
                    uint32_t *n_ok)
@@ -423,6 +503,11 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
     for (auto &ck : chunks) if (ck.c1 - ck.c0 > max_c) max_c = ck.c1 - ck.c0;
     // a small request (a seek) is staged through one small pinned buffer by this thread: no rings, no hand-over
     const bool small = nchunks == 1 && total_d <= (4u << 20) && max_c <= (4u << 20);
+    if (small && count <= 64 && !e->profiling && getenv("ZK_NO_SMALL_PATH") == nullptr) {
+        bool fallback = false;
+        rc = zk_decode_small(e, hp, src, c_off, d_off, first, count, d_prefix, prefix_len, dst, dst_pinned, verify, frame_status, n_ok, &fallback);
+        if (!fallback) return rc;
+    }
     if (!small && !src.mem) { if ((rc = zk_hostpipe_rings(e, hp))) return rc; }     // a pull source is staged through the ring
     // caller memory that is not pinned already is pinned on the fly, unit by unit, ahead of the copies (ZkRegWindow)
     ZkRegWindow wsrc, wdst;
