@@ -22,7 +22,7 @@ struct ZkQuadSim {
     int cur;
     bool done[3];
     // arguments of the walk
-    const uint8_t *comp; ZkBlock b[3]; uint32_t bs_off; ZkSeqTables16 *T; const uint32_t *al; ZkSeq *seqs; uint32_t pos_pub;
+    const uint8_t *comp; ZkBlock b[3]; uint32_t bs_off; ZkSeqTables16 *T; const uint32_t *al; ZkSeqP *seqs; uint32_t pos_pub;
 };
 static ZkQuadSim *g_quad;
 static uint32_t g_ofv[32];
@@ -55,7 +55,7 @@ static void zk_quad_lane_main()
     q->done[t] = true;
 }
 // the block's sequences through the quad walk (tables already built in T); false: the three lanes disagree
-static bool zk_quad_walk_sim(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, ZkSeqTables16 *T, const uint32_t *al, ZkSeq *seqs)
+static bool zk_quad_walk_sim(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, ZkSeqTables16 *T, const uint32_t *al, ZkSeqP *seqs)
 {
     ZkQuadSim q;
     g_quad = &q;
@@ -111,7 +111,7 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
         nb += fi.n_blocks; ns += fi.n_seq; nl += fi.lit_bytes;
     }
     std::vector<ZkBlock> blocks(nb + 1);
-    std::vector<ZkSeq> seqs(ns + 1);
+    std::vector<ZkSeqP> seqs(ns + 1);
     std::vector<uint8_t> lit(nl + 64);
     for (uint32_t f = 0; f < count; f++) {
         if (infos[f].status != ZK_OK) continue;
@@ -184,8 +184,13 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
     delete T;
     delete T16;
     // exec: one "workgroup" per frame; tiles of THREADS x B bytes, slot marking + per-byte source map (zk_exec_slot_span / zk_exec_slot_words)
-    const uint32_t THREADS = 256, B = (uint32_t)exec_b, CAPS = (uint32_t)exec_chunk;      // CAPS: staged sequences per tile
-    std::vector<ZkSeq> st(CAPS + 1);
+    // CAPS: sequences staged at once.  Like the kernel the staged records live in a ring (slot = block sequence index & mask):
+    // a tile retires the sequences it consumed and as many new records move into their slots.
+    const uint32_t THREADS = 256, B = (uint32_t)exec_b, CAPS = (uint32_t)exec_chunk;
+    uint32_t RING = 2;
+    while (RING < CAPS) RING <<= 1;
+    const uint32_t M = RING - 1;
+    std::vector<ZkSeq> st(RING);
     std::vector<uint32_t> srcmap(THREADS * B), slot_seq(THREADS * B / ZK_EXEC_SLOT + 1);
     std::vector<uint8_t> tile(THREADS * B);
     int first_err = 0;
@@ -206,46 +211,53 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
                 if (b.type == 0) memcpy(bout, comp + b.src, b.bsize);
                 else if (b.type == 1) memset(bout, comp[b.src], b.bsize);
                 else {
-                    const ZkSeq *sq = seqs.data() + b.seq_base;
+                    const ZkSeqP *sq = seqs.data() + b.seq_base;
                     const uint8_t *l = b.lit_type >= 2 ? lit.data() + b.lit_base : comp + b.src + b.lit_off;
                     const uint32_t lit_mask = b.lit_type == 1 ? 0u : 0x7fffffffu;
                     const uint32_t nseq = b.nseq, out_size = b.out_size;
-                    uint32_t ja = 0, ts = 0, prev_end = 0;
-                    while (ts < out_size) {
-                        const uint32_t nl = nseq + 1 - ja < CAPS ? nseq + 1 - ja : CAPS;
-                        int bad = 0;
-                        for (uint32_t i = 0; i < nl; i++) {
-                            const uint32_t idx = ja + i;
+                    int bad = 0;
+                    auto stage = [&](uint32_t from, uint32_t to) {                          // records [from, to) -> ring, as the kernel's fetch + settle
+                        for (uint32_t idx = from; idx < to; idx++) {
+                            ZkSeq r;
                             if (idx < nseq) {
-                                ZkSeq s = sq[idx];
-                                uint32_t off = zk_rep_resolve(s.off, rep);
-                                uint32_t mstart = s.out_end - s.ml;
+                                const ZkSeq q = zk_seq_unpack(idx ? sq[idx - 1] : 0, sq[idx], idx == 0);
+                                const uint32_t off = zk_rep_resolve(q.off, rep);
+                                const uint32_t mstart = q.out_end - q.ml;
                                 if (PFX ? (off == 0 || pos + mstart + plen < off) : (off == 0 || pos + mstart < off || off > fi.window)) bad = 1;
-                                if (off >= ZK_SRC_BIAS) bad = 1;
-                                st[i].out_end = s.out_end; st[i].ml = s.ml; st[i].off = off; st[i].lit_end = s.lit_end;
-                            } else { st[i].out_end = out_size; st[i].ml = 0; st[i].off = 1; st[i].lit_end = b.lit_regen; }
+                                if (off >= ZK_SRC_BIAS || q.ml > q.out_end) bad = 1;
+                                r.out_end = q.out_end; r.ml = q.ml; r.off = off; r.lit_end = q.lit_end;
+                            } else { r.out_end = out_size; r.ml = 0; r.off = 1; r.lit_end = b.lit_regen; }
+                            st[idx & M] = r;
                         }
-                        if (bad) { err = ZK_E_CORRUPTION; break; }
-                        const uint32_t cap_end = st[nl - 1].out_end;
+                    };
+                    uint32_t ja = 0, ts = 0, prev_end = 0;
+                    uint32_t staged_end = nseq + 1 < CAPS ? nseq + 1 : CAPS;
+                    stage(0, staged_end);
+                    if (bad) err = ZK_E_CORRUPTION;
+                    while (err == ZK_OK && ts < out_size) {
+                        const uint32_t nl = staged_end - ja;
+                        const uint32_t cap_end = st[(staged_end - 1) & M].out_end;
                         const uint32_t te = ts + THREADS * B < cap_end ? ts + THREADS * B : cap_end;
                         uint32_t jn = nl;
                         std::fill(srcmap.begin(), srcmap.end(), 0xDEADBEEFu);
                         std::fill(slot_seq.begin(), slot_seq.end(), 0xFFFFFFFFu);
                         for (uint32_t i = 0; i < nl; i++) {                                  // "lane per sequence"
-                            const uint32_t start = i ? st[i - 1].out_end : prev_end;
-                            const uint32_t lo = start > ts ? start : ts, hi = st[i].out_end < te ? st[i].out_end : te;
+                            const uint32_t idx = ja + i;
+                            const uint32_t end = st[idx & M].out_end;
+                            const uint32_t start = i ? st[(idx - 1) & M].out_end : prev_end;
+                            const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
                             if (lo < hi) {
                                 uint32_t s0, n;
                                 zk_exec_slot_span(ts, lo, hi, s0, n);
-                                for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = i;
+                                for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = idx;
                             }
-                            if (st[i].out_end > te && start <= te) jn = i;
+                            if (end > te && start <= te) jn = i;
                         }
                         for (uint32_t q0 = ts; q0 < te; q0 += ZK_EXEC_SLOT) {                // "lane per slot"
                             const uint32_t nb = te - q0 < ZK_EXEC_SLOT ? te - q0 : ZK_EXEC_SLOT;
                             uint32_t sw[ZK_EXEC_SLOT];
-                            if (!zk_exec_slot_words_fast(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, sw))
-                                zk_exec_slot_words(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, sw);
+                            if (!zk_exec_slot_words_fast(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, sw, M))
+                                zk_exec_slot_words(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, sw, M);
                             for (uint32_t k = 0; k < nb; k++) srcmap[q0 - ts + k] = sw[k];
                         }
                         const uint32_t mbase = ZK_SRC_BIAS + ts, span = te - ts;
@@ -259,8 +271,12 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
                             }
                         }
                         memcpy(bout + ts, tile.data(), te - ts);                             // commit the tile after all lanes ran
-                        if (jn) prev_end = st[jn - 1].out_end;
-                        ja += jn; ts = te;
+                        const uint32_t next_prev_end = jn ? st[(ja + jn - 1) & M].out_end : prev_end;
+                        const uint32_t fetch_end = staged_end + jn < nseq + 1 ? staged_end + jn : nseq + 1;
+                        stage(staged_end, fetch_end);                                        // the retired slots take the next records
+                        if (bad) { err = ZK_E_CORRUPTION; break; }
+                        prev_end = next_prev_end;
+                        ja += jn; staged_end = fetch_end; ts = te;
                     }
                     if (err == ZK_OK) {
                         uint32_t r0 = zk_rep_resolve(b.rep_out[0], rep), r1 = zk_rep_resolve(b.rep_out[1], rep), r2 = zk_rep_resolve(b.rep_out[2], rep);

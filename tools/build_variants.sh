@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B kernel experiments: builds zeekstd_amd/libzk_<tag>.so from extra -D flags (only zk_decode.hip is recompiled)
+#   tools/build_variants.sh w5:-DZK_EXEC_WAVES=5 w6:-DZK_EXEC_WAVES=6
+set -e
+cd "$(dirname "$0")/../zeekstd_amd/csrc"
+make -j8 >/dev/null
+for spec in "$@"; do
+  tag=${spec%%:*}; flags=${spec#*:}
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $flags -c zk_decode.hip -o build/zk_decode_$tag.o
+  objs=$(ls build/*.o | grep -v "zk_decode" | tr '\n' ' ')
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -Wl,--as-needed -pthread -o ../libzk_$tag.so build/zk_decode_$tag.o $objs
+done

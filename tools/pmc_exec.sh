@@ -1,0 +1,9 @@
+#!/bin/bash
+# PMC passes over tools/exec_probe.py (each pass = its own run; counters only, no trace domains beside kernel-trace)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+N=${1:-1024}
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" "GRBM_GUI_ACTIVE TA_BUSY_avr TCP_GATE_EN1_sum"; do
+  tag=$(echo $set | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $set --kernel-trace -d gpurun_out/pmcx/$tag -o p --output-format csv -- python tools/exec_probe.py $N > gpurun_out/pmcx_$tag.log 2>&1 || echo "pass failed: $set"
+done
+KERNELS=exec python tools/pmc_table.py gpurun_out/pmcx/*

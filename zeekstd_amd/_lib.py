@@ -8,7 +8,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzeekstd_amd.so")
+LIB_PATH = os.environ.get("ZEEKSTD_AMD_LIB") or os.path.join(_HERE, "libzeekstd_amd.so")   # the override is for A/B kernel experiments
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(128) void zk_k_huf(const uint8_t *comp, ZkBlock *bl
 //              table's bit count on the chain (+50% per lane), twice the lanes: wins once the blocks no longer fit in
 //              one round of the 32-bit layout (measured: 4 GiB of libzstd frames 24.0 -> 20.8 ms, 256 MiB 4.6 -> 6.9).
 template <typename CP, int ZK_FSE_BLOCKS, int ZK_FSE_WAVES>
-__global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
+__global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeqP *seqs)
 {
     constexpr int ZK_FSE_PER_WAVE = ZK_FSE_BLOCKS / ZK_FSE_WAVES;
     __shared__ ZkSeqTablesT<CP> T[ZK_FSE_BLOCKS];
@@ -319,7 +319,7 @@ struct ZkQuadDpp {
 // STAGE (small batches): the quad copies its block's bitstream (up to ZK_FSE_STAGE bytes) into LDS before the walk.
 constexpr uint32_t ZK_FSE_STAGE = 3072;
 template <typename CP, int ZK_FSE_BLOCKS, int ZK_FSE_WAVES, bool STAGE = false>
-__device__ __forceinline__ void zk_fse_quad_group(uint32_t group, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs, uint32_t all_blocks)
+__device__ __forceinline__ void zk_fse_quad_group(uint32_t group, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeqP *seqs, uint32_t all_blocks)
 {
     constexpr int PER_WAVE = ZK_FSE_BLOCKS / ZK_FSE_WAVES;
     static_assert(PER_WAVE * 4 <= 64 && ZK_FSE_BLOCKS <= 64, "a quad of lanes per block; a toucher lane per block");
@@ -405,7 +405,7 @@ __device__ __forceinline__ void zk_fse_quad_group(uint32_t group, const uint8_t 
     o->status = b.status;
 }
 template <typename CP, int ZK_FSE_BLOCKS, int ZK_FSE_WAVES>
-__global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs, uint32_t all_blocks)
+__global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeqP *seqs, uint32_t all_blocks)
 {
     zk_fse_quad_group<CP, ZK_FSE_BLOCKS, ZK_FSE_WAVES>(blockIdx.x, comp, blocks, nblocks, seqs, all_blocks);
 }
@@ -415,12 +415,12 @@ __global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const u
 // workgroup, one block per LANE, full waves.  All 64 lanes walk in lock step so that the 16-B records can be
 // stored cooperatively (ZkCoopFlush: a quarter of the L2 write requests, which were 40% of the kernel's time).
 constexpr int ZK_FSEP_LANES = 64;                        // blocks per workgroup (one wave)
-constexpr int ZK_FSEP_RING = 4;                          // records per lane between two cooperative flushes (4 x 16 B = 64 B; 8 measured slower: 5.6 vs 4.1 ms)
+constexpr int ZK_FSEP_RING = 8;                          // records per lane between two cooperative flushes (8 x 8 B = one 64-B burst; 128-B bursts measured slower)
 template <typename RD>
-__global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_predef(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
+__global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_predef(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeqP *seqs)
 {
     __shared__ ZkSeqTables T;                              // shared, read-only after the build
-    __shared__ __attribute__((aligned(16))) ZkSeq ring[ZK_FSEP_LANES][ZK_FSEP_RING];
+    __shared__ __attribute__((aligned(16))) ZkSeqP ring[ZK_FSEP_LANES][ZK_FSEP_RING];
     __shared__ ZkCoopFlush coop;
     __shared__ uint32_t llv[36], mlv[53], s_al[3];
     const uint32_t tid = threadIdx.x;
@@ -459,10 +459,10 @@ __global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_predef(const uint8_t *
 
 // The same with a feeder wave: wave 0 walks (reader ZkRevL: stream words out of an LDS ring, no global load in the
 // walking wave), wave 1 feeds the ring lane for lane.  Used when the device is full of walkers (zk_launch_fse).
-__global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeq *seqs)
+__global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeqP *seqs)
 {
     __shared__ ZkSeqTablesT<ZkCells64> T;                  // 64-bit cells: the value baseline rides along (shared tables, LDS is free)
-    __shared__ __attribute__((aligned(16))) ZkSeq ring[ZK_FSEP_LANES][ZK_FSEP_RING];
+    __shared__ __attribute__((aligned(16))) ZkSeqP ring[ZK_FSEP_LANES][ZK_FSEP_RING];
     __shared__ ZkCoopFlush coop;
     __shared__ ZkRevLShared feed;
     __shared__ uint32_t llv[36], mlv[53], s_al[3], s_done;
@@ -538,12 +538,19 @@ template <int T, bool PFX>
 __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
                                                const uint32_t *ids, const uint64_t *out_off,
                                                const ZkBlock *blocks, const ZkFrameBase *bases,
-                                               ZkFrameInfo *infos, const ZkSeq *seqs,
+                                               ZkFrameInfo *infos, const ZkSeqP *seqs,
                                                const uint8_t *lit_scratch, uint8_t *dst,
                                                const uint8_t *prefix, uint64_t plen)
 {
+    // The staged sequences live in an LDS RING of CAP records, slot = block sequence index & (CAP - 1).  A tile retires the
+    // jn sequences it has consumed and exactly as many new ones are fetched for the tiles to come -- requested right after
+    // the marking pass, written into the retired slots once the slot pass no longer reads them: the fetch (an HBM round
+    // trip that used to open every tile, in front of a barrier, for twice the records a tile needs) is off the critical
+    // path and every record is read once.
     constexpr int CAP = 2 * T;
-    __shared__ __attribute__((aligned(16))) ZkSeq S[CAP + 1];
+    constexpr uint32_t M = CAP - 1;
+    constexpr int NPF = CAP / T;                 // records a lane may have to fetch per tile
+    __shared__ __attribute__((aligned(16))) ZkSeq S[CAP];
     __shared__ __attribute__((aligned(16))) uint32_t srcmap[T * ZK_EXEC_B];
     __shared__ uint32_t slot_seq[T];
     __shared__ uint32_t longlist[CAP + 1];
@@ -571,58 +578,74 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
             const uint8_t v = comp[b.src];
             for (uint32_t i = tid; i < b.bsize; i += T) bout[i] = v;
         } else {
-            const ZkSeq *sq = seqs + b.seq_base;
+            const ZkSeqP *sq = seqs + b.seq_base;
             const uint8_t *lit = b.lit_type >= 2 ? lit_scratch + b.lit_base : comp + b.src + b.lit_off;
             const uint32_t lit_mask = b.lit_type == 1 ? 0u : 0x7fffffffu;       // RLE literals: every index reads byte 0
-            const uint32_t nseq = b.nseq, out_size = b.out_size;
+            const uint32_t nseq = b.nseq, out_size = b.out_size, lit_regen = b.lit_regen;
+            // record idx of the block (idx == nseq: the trailing-literals pseudo sequence) -> staged form, offsets resolved
+            // and validated.  Without a prefix an offset is bounded by the bytes produced so far and by the frame's window;
+            // with one (ZSTD_DCtx_refPrefix: the prefix sits right before the frame) only by availability, which is all
+            // libzstd's ZSTD_execSequence checks.
+            auto fetch = [&](uint32_t idx, ZkSeqP &p0, ZkSeqP &p1) {
+                p1 = idx < nseq ? sq[idx] : 0;
+                p0 = idx && idx < nseq ? sq[idx - 1] : 0;
+            };
+            auto settle = [&](uint32_t idx, ZkSeqP p0, ZkSeqP p1, int &bad) {
+                uint4 r;
+                if (idx < nseq) {
+                    const ZkSeq q = zk_seq_unpack(p0, p1, idx == 0);
+                    const uint32_t off = zk_rep_resolve(q.off, rep);
+                    const uint32_t mstart = q.out_end - q.ml;
+                    if (PFX ? (off == 0 || pos + mstart + plen < off) : (off == 0 || pos + mstart < off || off > fi.window)) bad = 1;
+                    if (off >= ZK_SRC_BIAS || q.ml > q.out_end) bad = 1;     // source words carry positions down to -2^30 only
+                    r = make_uint4(q.out_end, q.ml, off, q.lit_end);
+                } else r = make_uint4(out_size, 0, 1, lit_regen);
+                reinterpret_cast<uint4 *>(S)[idx & M] = r;
+            };
+            int bad = 0;
             uint32_t ja = 0, ts = 0, prev_end = 0;           // prev_end: out_end of sequence ja - 1
-            while (ts < out_size) {
-                // 1. stage sequences [ja, ja + nl); index nseq is the trailing-literals pseudo sequence
-                const uint32_t nl = nseq + 1 - ja < (uint32_t)CAP ? nseq + 1 - ja : (uint32_t)CAP;
-                int bad = 0;
-                for (uint32_t i = tid; i < nl; i += T) {
-                    const uint32_t idx = ja + i;
-                    uint4 r;
-                    if (idx < nseq) {
-                        const uint4 s = reinterpret_cast<const uint4 *>(sq)[idx];      // out_end, ml, off, lit_end
-                        const uint32_t off = zk_rep_resolve(s.z, rep);
-                        const uint32_t mstart = s.x - s.y;
-                        // without a prefix an offset is bounded by the bytes produced so far and by the frame's window;
-                        // with one (ZSTD_DCtx_refPrefix: the prefix sits right before the frame) only by availability,
-                        // which is all libzstd's ZSTD_execSequence checks
-                        if (PFX ? (off == 0 || pos + mstart + plen < off) : (off == 0 || pos + mstart < off || off > fi.window)) bad = 1;
-                        if (off >= ZK_SRC_BIAS) bad = 1;     // source words carry positions down to -2^30 only
-                        r = make_uint4(s.x, s.y, off, s.w);
-                    } else r = make_uint4(out_size, 0, 1, b.lit_regen);
-                    reinterpret_cast<uint4 *>(S)[i] = r;
-                }
-                if (tid == 0) { s_jn = nl; s_nlong = 0; }
-                if (__syncthreads_or(bad)) { err = ZK_E_CORRUPTION; break; }
-                const uint32_t cap_end = S[nl - 1].out_end;
+            uint32_t staged_end = nseq + 1 < (uint32_t)CAP ? nseq + 1 : (uint32_t)CAP;      // records [ja, staged_end) are in the ring
+            for (uint32_t idx = tid; idx < staged_end; idx += T) { ZkSeqP p0, p1; fetch(idx, p0, p1); settle(idx, p0, p1, bad); }
+            if (tid == 0) { s_jn = staged_end; s_nlong = 0; }        // s_jn starts at "every staged sequence ends inside the tile"
+            if (__syncthreads_or(bad)) { err = ZK_E_CORRUPTION; }
+            while (err == ZK_OK && ts < out_size) {
+                const uint32_t nl = staged_end - ja;
+                const uint32_t cap_end = S[(staged_end - 1) & M].out_end;
                 const uint32_t te = ts + T * ZK_EXEC_B < cap_end ? ts + T * ZK_EXEC_B : cap_end;
                 // 2. lane per sequence: mark the slots it starts; the first sequence that outlives the tile sets jn
                 for (uint32_t i = tid; i < nl; i += T) {
-                    const uint32_t end = S[i].out_end;
-                    const uint32_t start = i ? S[i - 1].out_end : prev_end;
+                    const uint32_t idx = ja + i;
+                    const uint32_t end = S[idx & M].out_end;
+                    const uint32_t start = i ? S[(idx - 1) & M].out_end : prev_end;
                     const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
                     if (lo < hi) {
                         uint32_t s0, n;
                         zk_exec_slot_span(ts, lo, hi, s0, n);
-                        if (n > ZK_EXEC_LONG) longlist[atomicAdd(&s_nlong, 1u)] = i;
-                        else for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = i;
+                        if (n > ZK_EXEC_LONG) longlist[atomicAdd(&s_nlong, 1u)] = idx;
+                        else for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = idx;
                     }
                     if (end > te && start <= te) s_jn = i;
                 }
                 __syncthreads();
                 const uint32_t nlong = s_nlong, jn = s_jn;
+                // the records that take the retired slots: requested now, needed two barriers from here
+                const uint32_t fetch_end = staged_end + jn < nseq + 1 ? staged_end + jn : nseq + 1;
+                ZkSeqP pf0[NPF], pf1[NPF];
+#pragma unroll
+                for (int u = 0; u < NPF; u++) {
+                    const uint32_t idx = staged_end + tid + (uint32_t)u * T;
+                    pf0[u] = 0; pf1[u] = 0;
+                    if (idx < fetch_end) fetch(idx, pf0[u], pf1[u]);
+                }
+                const uint32_t next_prev_end = jn ? S[(ja + jn - 1) & M].out_end : prev_end;
                 for (uint32_t k = 0; k < nlong; k++) {       // sequences spanning many slots: all lanes
-                    const uint32_t i = longlist[k];
-                    const uint32_t end = S[i].out_end;
-                    const uint32_t start = i ? S[i - 1].out_end : prev_end;
+                    const uint32_t idx = longlist[k];
+                    const uint32_t end = S[idx & M].out_end;
+                    const uint32_t start = idx != ja ? S[(idx - 1) & M].out_end : prev_end;
                     const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
                     uint32_t s0, n;
                     zk_exec_slot_span(ts, lo, hi, s0, n);
-                    for (uint32_t j = tid; j < n; j += T) slot_seq[s0 + j] = i;
+                    for (uint32_t j = tid; j < n; j += T) slot_seq[s0 + j] = idx;
                 }
                 if (nlong) __syncthreads();
                 // 3. lane per slot: source words of its 16 bytes
@@ -630,12 +653,19 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                 const uint32_t nb = q0 >= te ? 0u : te - q0 < (uint32_t)ZK_EXEC_B ? te - q0 : (uint32_t)ZK_EXEC_B;
                 uint32_t sw[ZK_EXEC_B];
                 if (nb) {
-                    if (!zk_exec_slot_words_fast(S, slot_seq[tid], q0, nb, sw)) zk_exec_slot_words(S, slot_seq[tid], q0, nb, sw);
+                    if (!zk_exec_slot_words_fast(S, slot_seq[tid], q0, nb, sw, M)) zk_exec_slot_words(S, slot_seq[tid], q0, nb, sw, M);
 #pragma unroll
                     for (int k = 0; k < ZK_EXEC_B; k += 4)
                         *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(sw[k], sw[k + 1], sw[k + 2], sw[k + 3]);
                 }
                 __syncthreads();
+                if (tid == 0) { s_jn = fetch_end - (ja + jn); s_nlong = 0; }      // the next tile's marking pass starts from these (every lane has read this tile's)
+                // the slot pass is done with the retired records: the fetched ones move in
+#pragma unroll
+                for (int u = 0; u < NPF; u++) {
+                    const uint32_t idx = staged_end + tid + (uint32_t)u * T;
+                    if (idx < fetch_end) settle(idx, pf0[u], pf1[u], bad);
+                }
                 // 4. origins (in-tile history words are exactly [BIAS + ts, BIAS + te)), gathers, one coalesced store
                 if (nb) {
                     const uint32_t mbase = ZK_SRC_BIAS + ts, span = te - ts;
@@ -673,9 +703,10 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                         for (int k = 0; k < ZK_EXEC_B; k++) if ((uint32_t)k < nb) w[k] = (uint8_t)ob[k];
                     }
                 }
-                if (jn) prev_end = S[jn - 1].out_end;
-                __syncthreads();              // tile bytes visible to the next tile; LDS reuse
-                ja += jn; ts = te;
+                prev_end = next_prev_end;
+                ja += jn; staged_end = fetch_end; ts = te;
+                // tile bytes visible to the next tile, the ring complete, the map free again
+                if (__syncthreads_or(bad)) { err = ZK_E_CORRUPTION; break; }
             }
             if (err == ZK_OK) {
                 uint32_t r0 = zk_rep_resolve(b.rep_out[0], rep), r1 = zk_rep_resolve(b.rep_out[1], rep), r2 = zk_rep_resolve(b.rep_out[2], rep);
@@ -829,7 +860,7 @@ __global__ __launch_bounds__(256) void zk_k_small_walk(const uint8_t *h_comp, ui
 }
 
 // Huffman groups (role 0) and sequence groups (role 1) of a small batch in one launch; the number of blocks comes from HBM.
-__global__ __launch_bounds__(128) void zk_k_small_entropy(const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeq *seqs)
+__global__ __launch_bounds__(128) void zk_k_small_entropy(const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeqP *seqs)
 {
     const uint32_t nblocks = (uint32_t)words[0];
     const uint32_t role = blockIdx.x & 1, stride = gridDim.x >> 1;
@@ -846,7 +877,7 @@ __global__ __launch_bounds__(128) void zk_k_small_huf(const uint8_t *comp, ZkBlo
     const uint32_t nblocks = (uint32_t)words[0];
     for (uint32_t g = blockIdx.x; g * 16 < nblocks; g += gridDim.x) { zk_huf_group(g, comp, blocks, nblocks, lit); __syncthreads(); }
 }
-__global__ __launch_bounds__(128) void zk_k_small_fse(const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, ZkSeq *seqs)
+__global__ __launch_bounds__(128) void zk_k_small_fse(const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, ZkSeqP *seqs)
 {
     const uint32_t nblocks = (uint32_t)words[0];
     for (uint32_t g = blockIdx.x; g * 16 < nblocks; g += gridDim.x) { zk_fse_quad_group<ZkCells16, 16, 1, true>(g, comp, blocks, nblocks, seqs, 1u); __syncthreads(); }
@@ -904,7 +935,7 @@ void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     if (!nblocks) return;
     hipLaunchKernelGGL(zk_k_huf, dim3((nblocks + ZK_HUF_BLOCKS - 1) / ZK_HUF_BLOCKS), dim3(128), 0, st, comp, blocks, nblocks, lit);
 }
-void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeq *seqs, int own_kernel)
+void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeqP *seqs, int own_kernel)
 {
     if (!nblocks) return;
     // reader choice (zk_device.h): with >= 6 workgroups per CU the memory pipeline is the limit (aligned words, each
@@ -935,16 +966,21 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
         hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 4>), dim3((nblocks + 55) / 56), dim3(320), 0, st, comp, blocks, nblocks, seqs, 0u);
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
-                    const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeq *seqs,
+                    const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeqP *seqs,
                     const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen)
 {
     // one workgroup per frame: the tile width trades bytes in flight per frame against workgroups per CU
-    // (measured on 2 MiB frames: 2048 frames -> 256 lanes, 512 -> 512, 128 -> 1024)
+    // (measured on 2 MiB frames: 2048 frames -> 128 lanes (8.86 ms; 256 lanes 9.47, 512 lanes 10.9 -- eight 2-wave workgroups
+    // per CU hold all 2048 frames in one round), 1024 frames -> 256 lanes (4.95 ms; 128 lanes 6.9), 512 -> 512, 128 -> 1024)
 #define ZK_EXEC_LAUNCH(TT, PP) hipLaunchKernelGGL((zk_k_exec<TT, PP>), dim3(count), dim3(TT), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst, prefix, plen)
+    static const int force_t = getenv("ZK_EXEC_T") ? atoi(getenv("ZK_EXEC_T")) : 0;      // experiments
     if (prefix && plen) {
         if (count >= 1024) ZK_EXEC_LAUNCH(256, true); else if (count >= 256) ZK_EXEC_LAUNCH(512, true); else ZK_EXEC_LAUNCH(1024, true);
-    } else {
-        if (count >= 1024) ZK_EXEC_LAUNCH(256, false); else if (count >= 256) ZK_EXEC_LAUNCH(512, false); else ZK_EXEC_LAUNCH(1024, false);
+    } else if (force_t == 128) ZK_EXEC_LAUNCH(128, false);
+    else if (force_t == 256) ZK_EXEC_LAUNCH(256, false);
+    else if (force_t == 512) ZK_EXEC_LAUNCH(512, false);
+    else {
+        if (count >= 1536) ZK_EXEC_LAUNCH(128, false); else if (count >= 1024) ZK_EXEC_LAUNCH(256, false); else if (count >= 256) ZK_EXEC_LAUNCH(512, false); else ZK_EXEC_LAUNCH(1024, false);
     }
 #undef ZK_EXEC_LAUNCH
 }
@@ -959,7 +995,7 @@ void zk_launch_small_walk(hipStream_t st, const uint8_t *h_comp, uint64_t comp_b
 {
     hipLaunchKernelGGL(zk_k_small_walk, dim3(1), dim3(256), 0, st, h_comp, comp_bytes, h_offs, count, dst_cap, block_cap, d_comp, d_offs, infos, bases, blocks, words);
 }
-void zk_launch_small_entropy(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeq *seqs, uint32_t groups)
+void zk_launch_small_entropy(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeqP *seqs, uint32_t groups)
 {
     static const bool split = getenv("ZK_SMALL_SPLIT") != nullptr;
     if (split) {

@@ -84,12 +84,42 @@ struct ZkBlock {                // one per block, contiguous per frame
 };
 static_assert(sizeof(ZkBlock) == 96, "ZkBlock layout");
 
-struct ZkSeq {                  // one per sequence, 16 B
+struct ZkSeq {                  // one per sequence, 16 B: the form the executor stages in LDS
     uint32_t out_end;           // block-relative output position after this sequence's match
     uint32_t ml;                // match length
     uint32_t off;               // offset, possibly symbolic (zk_rep_*)
     uint32_t lit_end;           // block-relative literal count after this sequence's literals
 };
+// The record as it travels through HBM between the sequence decoders and the executor: 8 bytes.
+//   lit_end[16:0] | (out_end - 1)[33:17] | off[63:34]
+// Both running sums stay absolute (block-relative), so the executor needs no prefix sum: a sequence's match length is
+// out_end - previous out_end - (lit_end - previous lit_end), one neighbour away.  out_end is in [3, 2^17] and lit_end
+// in [0, 2^17 - 3] for every valid block.  The 30-bit offset field holds concrete offsets up to ZK_OFF_MAX and, above
+// them, the symbolic ones (slot 0..2, delta < 2^16: a block has at most 43690 sequences).
+typedef uint64_t ZkSeqP;
+constexpr uint32_t ZK_OFF_SYM = 0x3FFC0000u;          // offset fields >= this are symbolic: ZK_OFF_SYM | slot << 16 | delta
+constexpr uint32_t ZK_OFF_MAX = ZK_OFF_SYM - 1;       // largest concrete offset (1 GiB - 256 KiB - 1)
+ZK_HD ZkSeqP zk_seq_pack(uint32_t out_end, uint32_t lit_end, uint32_t off)
+{
+    const uint32_t f = (off & 0x80000000u) ? (ZK_OFF_SYM | (((off >> 28) & 3u) << 16) | (off & 0xFFFFu)) : off;
+    return (uint64_t)(lit_end & 0x1FFFFu) | ((uint64_t)((out_end - 1u) & 0x1FFFFu) << 17) | ((uint64_t)f << 34);
+}
+ZK_HD uint32_t zk_seqp_lit_end(ZkSeqP p) { return (uint32_t)p & 0x1FFFFu; }
+ZK_HD uint32_t zk_seqp_out_end(ZkSeqP p) { return ((uint32_t)(p >> 17) & 0x1FFFFu) + 1u; }
+ZK_HD uint32_t zk_seqp_off(ZkSeqP p)             // back to the walk's form: concrete, or 0x80000000 | slot << 28 | delta
+{
+    const uint32_t f = (uint32_t)(p >> 34);
+    return f >= ZK_OFF_SYM ? (0x80000000u | (((f >> 16) & 3u) << 28) | (f & 0xFFFFu)) : f;
+}
+// records [idx - 1, idx] -> the staged form (prev = 0 for the block's first sequence)
+ZK_HD ZkSeq zk_seq_unpack(ZkSeqP prev, ZkSeqP cur, bool first)
+{
+    ZkSeq s;
+    const uint32_t po = first ? 0u : zk_seqp_out_end(prev), pl = first ? 0u : zk_seqp_lit_end(prev);
+    s.out_end = zk_seqp_out_end(cur); s.lit_end = zk_seqp_lit_end(cur); s.off = zk_seqp_off(cur);
+    s.ml = s.out_end - po - (s.lit_end - pl);
+    return s;
+}
 
 // ---------------------------------------------------------------- small helpers
 ZK_HD uint32_t zk_highbit(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
@@ -701,9 +731,9 @@ struct ZkSeqTablesT {                // LDS-resident, per lane
     typename CP::cell_t ll[512];
     typename CP::cell_t ml[512];
     typename CP::cell_t of[256];
-    union {                          // table-build scratch, later the output ring (16 x ZkSeq = 256 B)
+    union {                          // table-build scratch, later the output ring (16 packed records)
         struct { int16_t norm[64]; uint16_t next[64]; };
-        ZkSeq ring[16];
+        ZkSeqP ring[16];
     };
 };
 typedef ZkSeqTablesT<ZkCells32> ZkSeqTables;       // 5.25 KiB
@@ -930,8 +960,8 @@ ZK_HD ZkRevLShared *zk_rd_shared_type(const ZkRevL &) { return nullptr; }
 // (4 instructions x 64 separate L2 write requests) four neighbouring lanes store one ring per instruction
 // (4 x 16 requests of 64 B).  All 64 lanes must run the walk in lock step (nloop = the wave's longest block).
 struct ZkCoopFlush {
-    ZkSeq *ring;                     // [64][RING]
-    ZkSeq *seqs;                     // the record array of the whole batch
+    ZkSeqP *ring;                    // [64][RING]
+    ZkSeqP *seqs;                    // the record array of the whole batch
     uint64_t base[64];               // record index of each lane's block
     uint32_t nseq[64];               // 0: lane stores nothing (shadow / inactive)
     uint32_t nloop;
@@ -945,7 +975,7 @@ struct ZkCoopFlush {
 template <int RING, typename RD, typename CP = ZkCells32>
 ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const typename CP::cell_t *LL, const typename CP::cell_t *OF,
                        const typename CP::cell_t *ML,
-                       const uint32_t *al, ZkSeq *ring, ZkSeq *seqs, const uint32_t *ll_values, const uint32_t *ml_values,
+                       const uint32_t *al, ZkSeqP *ring, ZkSeqP *seqs, const uint32_t *ll_values, const uint32_t *ml_values,
                        bool store = true, ZkCoopFlush *coop = nullptr, bool active = true, uint32_t lane = 0, void *rd_shared = nullptr)
 {
     RD r;
@@ -1016,19 +1046,17 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const t
             rep1 = sh1 ? rep0 : rep1;
             rep0 = off;
             lit += ll; out += ll + ml;
-            bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX);
-            ZkSeq s; s.out_end = out; s.ml = ml; s.off = off; s.lit_end = lit;
-            ring[i & (RING - 1)] = s;
+            bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX) | (!zk_rep_is_sym(off) & (off > ZK_OFF_MAX));
+            ring[i & (RING - 1)] = zk_seq_pack(out, lit, off);
         }
         // records are parked in LDS and written out a group at a time (few, wide store bursts)
 #if defined(__HIP_DEVICE_COMPILE__)
         if (coop) {
-            // RING neighbouring lanes store one lane's ring (RING x 16 contiguous bytes), 64 / RING rings per instruction
+            // RING neighbouring lanes store one lane's ring (RING x 8 contiguous bytes), 64 / RING rings per instruction
             static_assert(RING == 4 || RING == 8 || RING == 16, "ring");
             for (uint32_t j = 0; j < (uint32_t)RING; j++) {
                 const uint32_t m = (64 / RING) * j + lane / RING, piece = lane % RING, k = g0 + piece;
-                if (k < coop->nseq[m])
-                    reinterpret_cast<uint4 *>(coop->seqs)[coop->base[m] + k] = reinterpret_cast<const uint4 *>(coop->ring)[m * RING + piece];
+                if (k < coop->nseq[m]) coop->seqs[coop->base[m] + k] = coop->ring[m * RING + piece];
             }
             continue;
         }
@@ -1048,7 +1076,7 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const t
 
 // Decode all sequences of block b into seqs[]: builds the block's LL / OF / ML tables in T (per-lane LDS), then walks.
 template <typename RD = ZkRevU, typename CP = ZkCells32>
-ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlock &b, ZkSeqTablesT<CP> *T, ZkSeq *seqs,
+ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlock &b, ZkSeqTablesT<CP> *T, ZkSeqP *seqs,
                                const uint32_t *ll_values, const uint32_t *ml_values, bool store = true)
 {
     uint32_t al[3];
@@ -1082,7 +1110,7 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
 template <typename RD, typename CP, typename XCH>
 ZK_HD void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, uint32_t t,
                                                  const typename CP::cell_t *cells, const uint32_t *vt, const uint32_t *al,
-                                                 ZkSeq *ring, ZkSeq *seqs, volatile uint32_t *pos_pub, const uint8_t *bits = nullptr)
+                                                 ZkSeqP *ring, ZkSeqP *seqs, volatile uint32_t *pos_pub, const uint8_t *bits = nullptr)
 {
     RD r;
     uint32_t bad = 0;
@@ -1102,7 +1130,7 @@ ZK_HD void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, ui
     const uint32_t kMlS = t == ZK_TAB_OF ? 0xFFu : 0u;              // ML state bits precede OF's
     uint32_t rep0 = zk_rep_sym(0), rep1 = zk_rep_sym(1), rep2 = zk_rep_sym(2);
     uint32_t out = 0, lit = 0;
-    ZkSeq qp; qp.out_end = 0; qp.ml = 0; qp.off = 0; qp.lit_end = 0;
+    ZkSeqP qp = 0;
     typename CP::cell_t c = cells[state];
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" :: "v"((uint32_t)c));                      // arrived before the loop: its waits then only count what the loop issues
@@ -1157,17 +1185,13 @@ ZK_HD void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, ui
             rep1 = sh1 ? rep0 : rep1;
             rep0 = off;
             lit += ll; out += ll + ml;
-            bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX);
-            qp.out_end = out; qp.ml = ml; qp.off = off; qp.lit_end = lit;
+            bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX) | (!zk_rep_is_sym(off) & (off > ZK_OFF_MAX));
+            qp = zk_seq_pack(out, lit, off);
         }
         ring[(gend - 1) & 15] = qp;
         ZK_WAVE_BARRIER();
         // the quad's three lanes share the stores of the group's records
-        for (uint32_t k = g0 + t; k < gend; k += 3) {
-            const volatile uint32_t *w = reinterpret_cast<const volatile uint32_t *>(&ring[k & 15]);
-            ZkSeq q; q.out_end = w[0]; q.ml = w[1]; q.off = w[2]; q.lit_end = w[3];
-            seqs[k] = q;
-        }
+        for (uint32_t k = g0 + t; k < gend; k += 3) seqs[k] = *reinterpret_cast<const volatile ZkSeqP *>(&ring[k & 15]);
         ZK_WAVE_BARRIER();
     }
     bad |= r.remaining() != 0;
@@ -1218,9 +1242,10 @@ ZK_HD void zk_exec_slot_seq(const ZkSeq &e, uint32_t q, ZkSlotCur &c)
 // (offset < match length): there both parts of a sequence are affine in q (literal: litw + q, match: BIAS - off + q),
 // 5 instructions per byte instead of 9.  Returns false when such a match was met: the caller falls back to
 // zk_exec_slot_words (rare outside run-length-like data).
-ZK_HD bool zk_exec_slot_words_fast(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t nb, uint32_t *sw)
+// S is addressed as a ring: entry i lives at S[i & ring_mask] (0xFFFFFFFF = a plain array)
+ZK_HD bool zk_exec_slot_words_fast(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t nb, uint32_t *sw, uint32_t ring_mask = 0xFFFFFFFFu)
 {
-    ZkSeq e = S[i];
+    ZkSeq e = S[i & ring_mask];
     uint32_t end = e.out_end, ms = e.out_end - e.ml, litw = (ZK_SRC_LIT | e.lit_end) - ms, mw = ZK_SRC_BIAS - e.off;
     bool ovl = e.off < e.ml, hit = false;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1230,7 +1255,7 @@ ZK_HD bool zk_exec_slot_words_fast(const ZkSeq *S, uint32_t i, uint32_t q0, uint
         const uint32_t q = q0 + k;
         if (k < nb) {
             if (q >= end) {
-                e = S[++i];
+                e = S[++i & ring_mask];
                 end = e.out_end; ms = e.out_end - e.ml; litw = (ZK_SRC_LIT | e.lit_end) - ms; mw = ZK_SRC_BIAS - e.off;
                 ovl = e.off < e.ml;
             }
@@ -1244,17 +1269,17 @@ ZK_HD bool zk_exec_slot_words_fast(const ZkSeq *S, uint32_t i, uint32_t q0, uint
 
 // Source words of the bytes [q0, q0 + nb) (nb <= 16) given the staged sequence i that covers q0.
 // Every sequence covers >= 3 bytes (ML base), so at most one boundary is crossed per byte.
-ZK_HD void zk_exec_slot_words(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t nb, uint32_t *sw)
+ZK_HD void zk_exec_slot_words(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t nb, uint32_t *sw, uint32_t ring_mask = 0xFFFFFFFFu)
 {
     ZkSlotCur c;
-    zk_exec_slot_seq(S[i], q0, c);
+    zk_exec_slot_seq(S[i & ring_mask], q0, c);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) {
         const uint32_t q = q0 + k;
         if (k < nb) {
-            if (q >= c.end) { i++; zk_exec_slot_seq(S[i], q, c); }
+            if (q >= c.end) { i++; zk_exec_slot_seq(S[i & ring_mask], q, c); }
             const bool m = q >= c.ms;
             sw[k] = m ? c.mbase + c.r : c.litw + q;
             c.r += m ? 1u : 0u;

@@ -222,10 +222,10 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
     const uint32_t n_own = (uint32_t)c.h_words[4];        // blocks that need per-block sequence tables
     if (nblocks > 0xFFFFFFF0ull) return -(int)ZK_E_GENERIC;
     if ((rc = zk_devbuf_reserve(e, c.blocks, (size_t)(nblocks + 1) * sizeof(ZkBlock)))) return rc;
-    if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)(nseq + 1) * sizeof(ZkSeq)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)(nseq + 1) * sizeof(ZkSeqP)))) return rc;
     if ((rc = zk_devbuf_reserve(e, c.lit, (size_t)nlit + 64))) return rc;
     ZkBlock *blocks = (ZkBlock *)c.blocks.p;
-    ZkSeq *seqs = (ZkSeq *)c.seqs.p;
+    ZkSeqP *seqs = (ZkSeqP *)c.seqs.p;
     uint8_t *lit = (uint8_t *)c.lit.p;
 
     c.h_words[3] = ~0ull;

@@ -422,7 +422,7 @@ static int zk_decode_small(zk_engine *e, zk_hostpipe *hp, const zk_host_src &src
     if ((rc = zk_devbuf_reserve(e, c.bases, (size_t)count * sizeof(ZkFrameBase)))) return rc;
     if ((rc = zk_devbuf_reserve(e, c.words, 16 * sizeof(uint64_t)))) return rc;
     if ((rc = zk_devbuf_reserve(e, c.blocks, (size_t)(block_cap + 1) * sizeof(ZkBlock)))) return rc;
-    if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)(dsz / 3 + count + 1) * sizeof(ZkSeq)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)(dsz / 3 + count + 1) * sizeof(ZkSeqP)))) return rc;
     if ((rc = zk_devbuf_reserve(e, c.lit, (size_t)dsz + 64))) return rc;
     if ((rc = zk_devbuf_reserve(e, s.d_in, comp_bytes + 64))) return rc;
     if ((rc = zk_devbuf_reserve(e, s.d_out, (size_t)dsz + 64))) return rc;
@@ -437,8 +437,8 @@ static int zk_decode_small(zk_engine *e, zk_hostpipe *hp, const zk_host_src &src
     zk_launch_small_walk(st, h_comp, csz, h_offs, count, dsz, block_cap, (uint8_t *)s.d_in.p, d_offs, infos, (ZkFrameBase *)c.bases.p, blocks, words);
     uint32_t groups = (block_cap + 15) / 16;
     if (groups > 32) groups = 32;
-    zk_launch_small_entropy(st, comp, blocks, words, (uint8_t *)c.lit.p, (ZkSeq *)c.seqs.p, groups);
-    zk_launch_exec(st, comp, d_offs + count + 1, 0, count, nullptr, nullptr, blocks, (const ZkFrameBase *)c.bases.p, infos, (const ZkSeq *)c.seqs.p,
+    zk_launch_small_entropy(st, comp, blocks, words, (uint8_t *)c.lit.p, (ZkSeqP *)c.seqs.p, groups);
+    zk_launch_exec(st, comp, d_offs + count + 1, 0, count, nullptr, nullptr, blocks, (const ZkFrameBase *)c.bases.p, infos, (const ZkSeqP *)c.seqs.p,
                    (const uint8_t *)c.lit.p, (uint8_t *)s.d_out.p, (const uint8_t *)d_prefix, d_prefix ? prefix_len : 0);
     if (verify) zk_launch_xxh64(st, (const uint8_t *)s.d_out.p, d_offs + count + 1, 0, count, infos, nullptr);
     zk_launch_small_publish(st, infos, d_offs, count, (const uint8_t *)s.d_out.p, dsz ? h_out : nullptr, (int32_t *)s.d_st.p, h_status, words, hp->pin_flag, gen);
