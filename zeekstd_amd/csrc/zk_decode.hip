@@ -970,8 +970,9 @@ void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, 
                     const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen)
 {
     // one workgroup per frame: the tile width trades bytes in flight per frame against workgroups per CU
-    // (measured on 2 MiB frames: 2048 frames -> 128 lanes (8.86 ms; 256 lanes 9.47, 512 lanes 10.9 -- eight 2-wave workgroups
-    // per CU hold all 2048 frames in one round), 1024 frames -> 256 lanes (4.95 ms; 128 lanes 6.9), 512 -> 512, 128 -> 1024)
+    // (measured on 2 MiB frames: 2048 frames -> 256 lanes.  128 lanes run the kernel alone in 8.9 instead of 9.5 ms -- eight
+    // 2-wave workgroups per CU hold all 2048 frames in one round -- but leave no room for the neighbouring batch: with two
+    // batches in flight the step is 18.8 ms against 17.2.  1024 frames: 256 lanes 4.95 ms, 128 lanes 6.9; 512 -> 512, 128 -> 1024)
 #define ZK_EXEC_LAUNCH(TT, PP) hipLaunchKernelGGL((zk_k_exec<TT, PP>), dim3(count), dim3(TT), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst, prefix, plen)
     static const int force_t = getenv("ZK_EXEC_T") ? atoi(getenv("ZK_EXEC_T")) : 0;      // experiments
     if (prefix && plen) {
@@ -980,7 +981,7 @@ void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, 
     else if (force_t == 256) ZK_EXEC_LAUNCH(256, false);
     else if (force_t == 512) ZK_EXEC_LAUNCH(512, false);
     else {
-        if (count >= 1536) ZK_EXEC_LAUNCH(128, false); else if (count >= 1024) ZK_EXEC_LAUNCH(256, false); else if (count >= 256) ZK_EXEC_LAUNCH(512, false); else ZK_EXEC_LAUNCH(1024, false);
+        if (count >= 1024) ZK_EXEC_LAUNCH(256, false); else if (count >= 256) ZK_EXEC_LAUNCH(512, false); else ZK_EXEC_LAUNCH(1024, false);
     }
 #undef ZK_EXEC_LAUNCH
 }
