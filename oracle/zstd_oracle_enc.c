@@ -85,8 +85,69 @@ void zko_enc_ctable(int which, u16 *state, int *dfs, u32 *dnb)
     memcpy(state, c->state, sizeof(u16) << c->al); memcpy(dfs, c->dfs, sizeof c->dfs); memcpy(dnb, c->dnb, sizeof c->dnb);
 }
 
-/* ------------------------------------------------------------------ forward bit writer (LSB first) */
+/* ------------------------------------------------------------------ per-frame FSE tables
+ * The predefined distributions fit this engine's sequences badly (short matches, short literal runs): tables measured from
+ * the frame's own sequences save ~20 % of the sequence section.  One set of tables per FRAME, not per block: the first
+ * compressed block with sequences carries the three descriptions (FSE_Compressed_Mode), every later block of the frame
+ * says Repeat_Mode -- so the decoder builds them once per frame and its blocks still decode independently.
+ * Normalisation (own rule, integer only, the GPU kernel zk_k_enc_fse_build runs the same): floor(count * 2^L / total), at
+ * least 1 for a symbol that occurs; the most frequent symbol (lowest index on ties) takes what is missing; a surplus is
+ * taken from the largest entries.  Accuracy logs: LL 9, OF 8, ML 9 (the format's maxima).  A table needs >= 2 symbols. */
+#define ZKE_FSE_MIN_SEQ 256u        /* frames with fewer sequences keep the predefined tables */
+static int fse_normalize(const u32 *cnt, int nsym, int L, short *norm)
+{
+    u64 total = 0; int distinct = 0, maxs = 0;
+    for (int s = 0; s < nsym; s++) { total += cnt[s]; if (cnt[s]) { distinct++; if (cnt[s] > cnt[maxs]) maxs = s; } }
+    if (distinct < 2) return 0;
+    const u32 size = 1u << L;
+    u32 sum = 0;
+    for (int s = 0; s < nsym; s++) {
+        u64 v = cnt[s] ? ((u64)cnt[s] << L) / total : 0;
+        if (cnt[s] && v == 0) v = 1;
+        norm[s] = (short)v; sum += (u32)v;
+    }
+    if (sum < size) norm[maxs] = (short)(norm[maxs] + (size - sum));
+    while (sum > size) {
+        int big = 0;
+        for (int s = 1; s < nsym; s++) if (norm[s] > norm[big]) big = s;
+        u32 d = (u32)norm[big] - 1 < sum - size ? (u32)norm[big] - 1 : sum - size;
+        if (d == 0) return 0;
+        norm[big] = (short)(norm[big] - d); sum -= d;
+    }
+    return 1;
+}
+
 typedef struct { u8 *p; size_t cap, pos; u64 acc; int n; int ovf; } bitw;
+static void bw_init(bitw *b, u8 *p, size_t cap);
+static void bw_add(bitw *b, u32 v, int n);
+/* FSE table description (RFC 8878 4.1.1), forward bits LSB first; returns bytes */
+static size_t fse_write_ncount(u8 *dst, size_t cap, const short *norm, int nsym, int L)
+{
+    bitw b; bw_init(&b, dst, cap);
+    bw_add(&b, (u32)(L - 5), 4);
+    int remaining = (1 << L) + 1, threshold = 1 << L, nbits = L + 1, sym = 0, prev0 = 0;
+    while (remaining > 1 && sym < nsym) {
+        if (prev0) {
+            int start = sym;
+            while (sym < nsym && norm[sym] == 0) sym++;
+            if (sym == nsym) break;
+            while (sym >= start + 3) { start += 3; bw_add(&b, 3, 2); }
+            bw_add(&b, (u32)(sym - start), 2);
+        }
+        int count = norm[sym++];
+        const int max = 2 * threshold - 1 - remaining;
+        remaining -= count < 0 ? -count : count;
+        count++;
+        if (count >= threshold) count += max;
+        bw_add(&b, (u32)count, nbits - (count < max ? 1 : 0));
+        prev0 = count == 1;
+        while (remaining < threshold) { nbits--; threshold >>= 1; }
+    }
+    while (b.n > 0) bw_add(&b, 0, 8 - b.n);                          /* pad the last byte */
+    return b.ovf ? 0 : b.pos;
+}
+
+/* ------------------------------------------------------------------ forward bit writer (LSB first) */
 static void bw_init(bitw *b, u8 *p, size_t cap) { b->p = p; b->cap = cap; b->pos = 0; b->acc = 0; b->n = 0; b->ovf = 0; }
 static void bw_add(bitw *b, u32 v, int n)
 {
@@ -99,9 +160,15 @@ static size_t bw_close(bitw *b) { bw_add(b, 1, 1); if (b->n) { if (b->pos < b->c
 /* ------------------------------------------------------------------ sequences */
 typedef struct { u32 ll, ml, offbase; } seq_t;      /* offbase = Offset_Value (>3: offset+3, 1..3: repeat codes) */
 
-static size_t encode_sequences(const seq_t *sq, u32 n, u8 *dst, size_t cap)
+/* the three compression tables in force for a frame + what its defining block has to carry */
+typedef struct { fse_ctable ll, of, ml; int custom[3]; u8 desc[3][80]; size_t dlen[3]; } frame_tables;
+
+static size_t encode_sequences(const frame_tables *ft, const seq_t *sq, u32 n, u8 *dst, size_t cap)
 {
     ct_init();
+#define CT_LL ft->ll
+#define CT_OF ft->of
+#define CT_ML ft->ml
     bitw b; bw_init(&b, dst, cap);
     u32 llc = ll_code(sq[n - 1].ll), mlc = ml_code(sq[n - 1].ml - 3), ofc = hb32(sq[n - 1].offbase);
 #define CINIT(ct, s, st) do { u32 nb = ((ct).dnb[s] + (1u << 15)) >> 16; u32 v = (nb << 16) - (ct).dnb[s]; st = (ct).state[(v >> nb) + (u32)(ct).dfs[s]]; } while (0)
@@ -120,6 +187,31 @@ static size_t encode_sequences(const seq_t *sq, u32 n, u8 *dst, size_t cap)
     }
     bw_add(&b, sm, CT_ML.al); bw_add(&b, so, CT_OF.al); bw_add(&b, sl, CT_LL.al);
     return bw_close(&b);
+#undef CT_LL
+#undef CT_OF
+#undef CT_ML
+}
+
+/* tables for a frame from the code histograms of all its sequences */
+static void frame_tables_build(frame_tables *ft, const u32 *hll, const u32 *hof, const u32 *hml, u32 nseq_frame)
+{
+    ct_init();
+    ft->ll = CT_LL; ft->of = CT_OF; ft->ml = CT_ML;
+    for (int t = 0; t < 3; t++) { ft->custom[t] = 0; ft->dlen[t] = 0; }
+    if (nseq_frame < ZKE_FSE_MIN_SEQ) return;
+    short norm[64];
+    const u32 *h[3] = {hll, hof, hml};
+    const int nsym[3] = {36, 32, 53}, L[3] = {9, 8, 9};
+    fse_ctable *ct[3] = {&ft->ll, &ft->of, &ft->ml};
+    for (int t = 0; t < 3; t++) {
+        if (!fse_normalize(h[t], nsym[t], L[t], norm)) continue;
+        int last = nsym[t];
+        while (last > 0 && norm[last - 1] == 0) last--;
+        size_t d = fse_write_ncount(ft->desc[t], sizeof ft->desc[t], norm, last, L[t]);
+        if (!d) continue;
+        build_ctable(ct[t], norm, nsym[t], L[t]);
+        ft->custom[t] = 1; ft->dlen[t] = d;
+    }
 }
 
 /* ------------------------------------------------------------------ Huffman */
@@ -375,42 +467,71 @@ i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int le
         msrc = cat;
         for (u32 v = 0; v < hist; v++) if ((size_t)v + 8 <= (size_t)hist + n) st->table[hash5(msrc + v)] = (u16)(v + 1);
     }
-    seq_t *sq = malloc(sizeof(seq_t) * (ZKE_BLOCK / 3 + 8));
-    u8 *lits = malloc(ZKE_BLOCK + 64), *body = malloc(ZKE_BLOCK * 2);
     st->probe = 1;                                                   /* first probe: offset 1 (runs) */
     i64 rc = 0;
     u32 bmax = (1u << wlog) < ZKE_BLOCK ? (1u << wlog) : ZKE_BLOCK;
     /* blocks are cut smaller than the format's maximum on purpose: a block's sequence bitstream is one serial chain
-     * for the decoder, so more, shorter blocks = more parallel chains (32 KiB for large frames, >= 8 blocks per small frame) */
+     * for the decoder, so more, shorter blocks = more parallel chains (32 KiB for large frames, >= 16 blocks per small frame) */
     { u32 t = 32768; while (t > 4096 && (u64)t * 16 > n) t >>= 1; if (t < bmax) bmax = t; }
-    for (u32 bs = 0; bs < n; bs += bmax) {
+    const u32 nblk = (u32)((n + bmax - 1) / bmax);
+    /* pass 1: sequences + literals of every block; code histograms of the frame */
+    seq_t *sq = malloc(sizeof(seq_t) * (n / 3 + 8 * (size_t)nblk + 8));
+    u8 *lits = malloc(n + 64), *body = malloc(ZKE_BLOCK * 2);
+    u32 *bseq = malloc(sizeof(u32) * (nblk + 1)), *blit = malloc(sizeof(u32) * (nblk + 1)), *bnlit = malloc(sizeof(u32) * (nblk + 1));
+    u32 hll[36] = {0}, hof[32] = {0}, hml[53] = {0}, nseq_frame = 0, nlit_frame = 0;
+    for (u32 k = 0, bs = 0; bs < n; bs += bmax, k++) {
+        u32 be = bs + bmax < n ? bs + bmax : (u32)n;
+        u32 nlit = 0;
+        bseq[k] = nseq_frame; blit[k] = nlit_frame;
+        u32 nseq = find_sequences(st, msrc, hist + bs, hist + be, hist + (u32)n, sq + nseq_frame, lits + nlit_frame, &nlit);
+        for (u32 i = 0; i < nseq; i++) { const seq_t *q = &sq[nseq_frame + i]; hll[ll_code(q->ll)]++; hml[ml_code(q->ml - 3)]++; hof[hb32(q->offbase)]++; }
+        bnlit[k] = nlit; nseq_frame += nseq; nlit_frame += nlit;
+    }
+    bseq[nblk] = nseq_frame;
+    frame_tables *ft = malloc(sizeof *ft);
+    frame_tables_build(ft, hll, hof, hml, nseq_frame);
+    const u8 modes_rep = (u8)((ft->custom[0] ? 3 << 6 : 0) | (ft->custom[1] ? 3 << 4 : 0) | (ft->custom[2] ? 3 << 2 : 0));
+    const u8 modes_def = (u8)((ft->custom[0] ? 2 << 6 : 0) | (ft->custom[1] ? 2 << 4 : 0) | (ft->custom[2] ? 2 << 2 : 0));
+    int defined = 0;                                                 /* the tables have been transmitted */
+    /* pass 2: every block with the frame's tables; whether a block is emitted compressed is decided on its Repeat_Mode
+     * form; the first one that is (and has sequences) becomes the defining block and grows by the descriptions */
+    for (u32 k = 0, bs = 0; bs < n && rc == 0; bs += bmax, k++) {
         u32 be = bs + bmax < n ? bs + bmax : (u32)n;
         u32 bsz = be - bs, last = be == n;
-        u32 nlit = 0;
-        u32 nseq = find_sequences(st, msrc, hist + bs, hist + be, hist + (u32)n, sq, lits, &nlit);
-        size_t b = encode_literals(lits, nlit, body, ZKE_BLOCK * 2);
-        size_t total = 0;
+        const u32 nlit = bnlit[k], nseq = bseq[k + 1] - bseq[k];
+        size_t b = encode_literals(lits + blit[k], nlit, body, ZKE_BLOCK * 2);
+        size_t total = 0, modes_at = 0;
         if (b) {
             b += nseq_header(body + b, nseq);
             if (nseq) {
-                body[b++] = 0;                                       /* predefined LL / OF / ML */
-                size_t s = encode_sequences(sq, nseq, body + b, ZKE_BLOCK * 2 - b);
+                modes_at = b;
+                body[b++] = modes_rep;
+                size_t s = encode_sequences(ft, sq + bseq[k], nseq, body + b, ZKE_BLOCK * 2 - b);
                 if (s) total = b + s;
             } else total = b;
         }
         int rle = 1;
         for (u32 i = 1; i < bsz && rle; i++) rle = src[bs + i] == src[bs];
-        if (p + 3 + bsz + 8 > cap) { rc = -70; break; }
+        if (p + 3 + bsz + 8 + 256 > cap) { rc = -70; break; }
         if (rle && bsz > 1) {                                        /* RLE block */
             u32 h = last | (1 << 1) | (bsz << 3); dst[p] = (u8)h; dst[p + 1] = (u8)(h >> 8); dst[p + 2] = (u8)(h >> 16); dst[p + 3] = src[bs]; p += 4;
         } else if (total && total < bsz) {
-            u32 h = last | (2 << 1) | ((u32)total << 3); dst[p] = (u8)h; dst[p + 1] = (u8)(h >> 8); dst[p + 2] = (u8)(h >> 16); p += 3;
-            memcpy(dst + p, body, total); p += total;
+            const int def = nseq && !defined && modes_rep;
+            const size_t extra = def ? ft->dlen[0] + ft->dlen[1] + ft->dlen[2] : 0;
+            u32 h = last | (2 << 1) | ((u32)(total + extra) << 3); dst[p] = (u8)h; dst[p + 1] = (u8)(h >> 8); dst[p + 2] = (u8)(h >> 16); p += 3;
+            if (def) {
+                memcpy(dst + p, body, modes_at); p += modes_at;
+                dst[p++] = modes_def;
+                for (int t = 0; t < 3; t++) { memcpy(dst + p, ft->desc[t], ft->dlen[t]); p += ft->dlen[t]; }
+                memcpy(dst + p, body + modes_at + 1, total - modes_at - 1); p += total - modes_at - 1;
+                defined = 1;
+            } else { memcpy(dst + p, body, total); p += total; }
         } else {                                                     /* raw block */
             u32 h = last | (bsz << 3); dst[p] = (u8)h; dst[p + 1] = (u8)(h >> 8); dst[p + 2] = (u8)(h >> 16); p += 3;
             memcpy(dst + p, src + bs, bsz); p += bsz;
         }
     }
+    free(ft); free(bseq); free(blit); free(bnlit);
     if (rc == 0 && checksum) { if (p + 4 > cap) rc = -70; else { u32 h = (u32)zko_xxh64(src, n, 0); memcpy(dst + p, &h, 4); p += 4; } }
     free(st); free(sq); free(lits); free(body); free(cat);
     return rc ? rc : (i64)p;

@@ -46,18 +46,111 @@ struct ZkEncBlock {
     uint64_t scratch_base;      // payload + bitstream temporaries
     uint32_t frame, bs, bsz;    // frame index, start inside the frame, size
     uint32_t nseq, nlit;
-    uint32_t csize;             // content bytes that follow the 3-byte block header
+    uint32_t csize;             // content bytes that follow the 3-byte block header (incl. the table descriptions of a defining block)
     uint32_t mode;              // Block_Type: 0 raw, 1 RLE, 2 compressed
-    uint8_t rle_byte, pad[3];
+    uint32_t modes_off;         // where Symbol_Compression_Modes sits in the payload (nseq > 0)
+    uint8_t rle_byte;
+    uint8_t is_def;             // this block carries the frame's FSE table descriptions (zk_k_enc_sizes decides)
+    uint8_t pad[2];
 };
 
-// predefined-distribution FSE compression tables (built on the host at engine creation)
+// FSE compression tables of one frame: the predefined distributions (built on the host at engine creation) or -- per
+// table -- the frame's own, measured from all its sequences by zk_k_enc_fse_build (accuracy logs 9 / 8 / 9).  One set per
+// FRAME: the first compressed block with sequences carries the descriptions (FSE_Compressed_Mode), the later ones say
+// Repeat_Mode, so a decoder builds them once per frame and still decodes the frame's blocks independently.
+constexpr uint32_t ZKE_FSE_MIN_SEQ = 256;       // frames with fewer sequences keep the predefined tables
+constexpr uint32_t ZKE_DESC_CAP = 80;           // bytes of one table description (53 symbols x <= 10 bits + repeats)
 struct ZkEncTables {
-    uint16_t ll_state[64], of_state[32], ml_state[64];
+    uint16_t ll_state[512], of_state[256], ml_state[512];
     uint32_t ll_dfs[36], of_dfs[32], ml_dfs[56];
     uint32_t ll_dnb[36], of_dnb[32], ml_dnb[56];
     uint32_t ll_val[36], ml_val[56];            // base | extra bits << 24
+    uint32_t al[3];                             // accuracy logs LL, OF, ML
+    uint32_t custom;                            // bit t: table t is the frame's own
+    uint32_t dlen[3];                           // bytes of the descriptions
+    uint8_t desc[3][ZKE_DESC_CAP];
 };
+ZK_HD uint32_t zke_modes_byte(uint32_t custom, uint32_t mode) { return ((custom & 1u) ? mode << 6 : 0u) | ((custom & 2u) ? mode << 4 : 0u) | ((custom & 4u) ? mode << 2 : 0u); }
+
+// ---- per-frame tables: normalisation, description, compression table (the CPU twin oracle/zstd_oracle_enc.c runs the same rules)
+// floor(count * 2^L / total), at least 1 for a symbol that occurs; the most frequent symbol (lowest index on ties) takes
+// what is missing; a surplus is taken from the largest entries.  false: fewer than two symbols.
+ZK_HD bool zke_fse_normalize(const uint32_t *cnt, int nsym, int L, int16_t *norm)
+{
+    uint64_t total = 0; int distinct = 0, maxs = 0;
+    for (int s = 0; s < nsym; s++) { total += cnt[s]; if (cnt[s]) { distinct++; if (cnt[s] > cnt[maxs]) maxs = s; } }
+    if (distinct < 2) return false;
+    const uint32_t size = 1u << L;
+    uint32_t sum = 0;
+    for (int s = 0; s < nsym; s++) {
+        uint64_t v = cnt[s] ? ((uint64_t)cnt[s] << L) / total : 0;
+        if (cnt[s] && v == 0) v = 1;
+        norm[s] = (int16_t)v; sum += (uint32_t)v;
+    }
+    if (sum < size) norm[maxs] = (int16_t)(norm[maxs] + (size - sum));
+    while (sum > size) {
+        int big = 0;
+        for (int s = 1; s < nsym; s++) if (norm[s] > norm[big]) big = s;
+        const uint32_t d = (uint32_t)norm[big] - 1 < sum - size ? (uint32_t)norm[big] - 1 : sum - size;
+        if (d == 0) return false;
+        norm[big] = (int16_t)(norm[big] - d); sum -= d;
+    }
+    return true;
+}
+// FSE table description (RFC 8878 4.1.1): forward bits, LSB first.  Returns bytes written (0: no room).
+ZK_HD uint32_t zke_fse_write_ncount(uint8_t *dst, uint32_t cap, const int16_t *norm, int nsym, int L)
+{
+    uint64_t acc = 0; uint32_t n = 0, pos = 0; bool ovf = false;
+#define ZKE_NC_ADD(v, nb) do { acc |= (uint64_t)((uint32_t)(v) & ((1u << (nb)) - 1u)) << n; n += (nb); \
+        while (n >= 8) { if (pos < cap) dst[pos] = (uint8_t)acc; else ovf = true; pos++; acc >>= 8; n -= 8; } } while (0)
+    ZKE_NC_ADD(L - 5, 4);
+    int remaining = (1 << L) + 1, threshold = 1 << L, nbits = L + 1, sym = 0;
+    bool prev0 = false;
+    while (remaining > 1 && sym < nsym) {
+        if (prev0) {
+            int start = sym;
+            while (sym < nsym && norm[sym] == 0) sym++;
+            if (sym == nsym) break;
+            while (sym >= start + 3) { start += 3; ZKE_NC_ADD(3, 2); }
+            ZKE_NC_ADD(sym - start, 2);
+        }
+        int count = norm[sym++];
+        const int max = 2 * threshold - 1 - remaining;
+        remaining -= count < 0 ? -count : count;
+        count++;
+        if (count >= threshold) count += max;
+        ZKE_NC_ADD(count, (uint32_t)(nbits - (count < max ? 1 : 0)));
+        prev0 = count == 1;
+        while (remaining < threshold) { nbits--; threshold >>= 1; }
+    }
+    if (n) ZKE_NC_ADD(0, 8 - n);
+#undef ZKE_NC_ADD
+    return ovf ? 0u : pos;
+}
+// compression table of a normalised distribution (sym[] = scratch of 1 << al bytes, cumul[] of nsym + 2 ints)
+ZK_HD void zke_build_ctable(const int16_t *norm, int nsym, int al, uint16_t *state, uint32_t *dfs, uint32_t *dnb, uint8_t *sym, int32_t *cumul)
+{
+    const int size = 1 << al, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    int high = size - 1;
+    cumul[0] = 0;
+    for (int u = 1; u <= nsym; u++) {
+        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; sym[high--] = (uint8_t)(u - 1); }
+        else cumul[u] = cumul[u - 1] + norm[u - 1];
+    }
+    int pos = 0;
+    for (int s = 0; s < nsym; s++)
+        for (int i = 0; i < norm[s]; i++) { sym[pos] = (uint8_t)s; do pos = (pos + step) & mask; while (pos > high); }
+    for (int u = 0; u < size; u++) { const int s = sym[u]; state[cumul[s]++] = (uint16_t)(size + u); }
+    int total = 0;
+    for (int s = 0; s < nsym; s++) {
+        if (norm[s] == 0) { dnb[s] = ((uint32_t)(al + 1) << 16) - (1u << al); dfs[s] = 0; }
+        else if (norm[s] == -1 || norm[s] == 1) { dnb[s] = ((uint32_t)al << 16) - (1u << al); dfs[s] = (uint32_t)(total - 1); total++; }
+        else {
+            const uint32_t mbo = (uint32_t)al - zk_highbit((uint32_t)norm[s] - 1), msp = (uint32_t)norm[s] << mbo;
+            dnb[s] = (mbo << 16) - msp; dfs[s] = (uint32_t)(total - norm[s]); total += norm[s];
+        }
+    }
+}
 
 struct ZkHufCode {              // a block's literal code: kept until the block's streams are written
     uint8_t len[128];

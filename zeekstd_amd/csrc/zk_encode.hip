@@ -428,10 +428,111 @@ __device__ __forceinline__ void zke_copy_wave(uint8_t *dst, const uint8_t *src, 
     if (t < n) dst[t] = src[t];
 }
 
+// ------------------------------------------------------------------------------------------------ the frame's FSE tables
+// One workgroup per frame: code histograms of all its sequences (LDS atomics), then one lane per table normalises,
+// writes the description and builds the compression table into the frame's ZkEncTables (HBM).  A table with fewer than
+// two symbols, or a frame with fewer than ZKE_FSE_MIN_SEQ sequences, keeps the predefined one.
+__global__ __launch_bounds__(256) void zk_k_enc_fse_build(const ZkEncFrame *frames, const ZkEncBlock *blocks, const uint64_t *seqs,
+                                                          const ZkEncTables *predef, ZkEncTables *ftab)
+{
+    __shared__ uint32_t h[3][64];
+    __shared__ int16_t norm[3][64];
+    __shared__ uint8_t sym[3][512];
+    __shared__ int32_t cumul[3][66];
+    __shared__ uint32_t s_nseq;
+    const uint32_t tid = threadIdx.x;
+    const ZkEncFrame fr = frames[blockIdx.x];
+    ZkEncTables *T = &ftab[blockIdx.x];
+    if (tid < 192) (&h[0][0])[tid] = 0;
+    if (tid == 0) s_nseq = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t b = 0; b < fr.n_blocks; b++) {
+        const ZkEncBlock &blk = blocks[fr.block_base + b];
+        const uint64_t *sq = seqs + blk.seq_base;
+        for (uint32_t i = tid; i < blk.nseq; i += 256) {
+            const uint64_t e = sq[i];
+            const uint32_t ll = (uint32_t)e & 0xFFFFF, ml = (uint32_t)(e >> 20) & 0xFFFFF, ob = (uint32_t)(e >> 40);
+            atomicAdd(&h[0][zke_ll_code(ll)], 1u); atomicAdd(&h[1][zk_highbit(ob)], 1u); atomicAdd(&h[2][zke_ml_code(ml - 3)], 1u);
+            mine++;
+        }
+    }
+    if (mine) atomicAdd(&s_nseq, mine);
+    // the predefined set is the starting point (value tables, and whatever stays predefined)
+    for (uint32_t i = tid; i < sizeof(ZkEncTables) / 4; i += 256) ((uint32_t *)T)[i] = ((const uint32_t *)predef)[i];
+    __syncthreads();
+    if (tid < 3 && s_nseq >= ZKE_FSE_MIN_SEQ) {
+        const int t = (int)tid;
+        const int nsym = t == 0 ? 36 : t == 1 ? 32 : 53, L = t == 1 ? 8 : 9;
+        if (zke_fse_normalize(h[t], nsym, L, norm[t])) {
+            int last = nsym;
+            while (last > 0 && norm[t][last - 1] == 0) last--;
+            const uint32_t d = zke_fse_write_ncount(T->desc[t], ZKE_DESC_CAP, norm[t], last, L);
+            if (d) {
+                uint16_t *st = t == 0 ? T->ll_state : t == 1 ? T->of_state : T->ml_state;
+                uint32_t *dfs = t == 0 ? T->ll_dfs : t == 1 ? T->of_dfs : T->ml_dfs;
+                uint32_t *dnb = t == 0 ? T->ll_dnb : t == 1 ? T->of_dnb : T->ml_dnb;
+                zke_build_ctable(norm[t], nsym, L, st, dfs, dnb, sym[t], cumul[t]);
+                T->al[t] = (uint32_t)L; T->dlen[t] = d;
+                atomicOr(&T->custom, 1u << t);
+            }
+        }
+    }
+}
+
 constexpr int ZKE_ENT_THREADS = 256;
 constexpr int ZKE_ENT_BLOCKS = 16;                       // blocks per workgroup: lanes = blocks for the serial bit writers
 static_assert(ZKE_THREADS / 64 == (int)ZKE_GROUP, "one parsing wave per tile of a group");
 static_assert(ZKE_THREADS == (int)(ZKE_TILE * ZKE_LSTEP), "one lookup position per lane");
+
+// The sequence bitstream of one block (one lane): three interleaved FSE states + the extra bits that the rewrite pass left
+// in seqs[] / mpos[].  T: the block's frame tables (LDS or HBM).
+template <typename TT>
+__device__ __forceinline__ uint32_t zke_write_sequences(const TT &T, const ZkEncBlock &blk, const uint64_t *seqs, const uint32_t *mpos, uint8_t *scratch)
+{
+    const uint32_t nseq = blk.nseq, q = (blk.nlit + 3) / 4, scap = q + (q >> 1) + 16;
+    const uint64_t *sq = seqs + blk.seq_base;
+    ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + 4 * scap, blk.bsz);       // + 64 bytes of slack behind it
+    const uint32_t *cw = mpos + blk.seq_base;
+    uint32_t sl, sm, so;
+    {
+        const uint64_t x = sq[nseq - 1];
+        const uint32_t c = cw[nseq - 1], llc = c & 0xFF, mlc = (c >> 8) & 0xFF, ofc = c >> 16;
+        sm = zke_cinit(T.ml_state, T.ml_dnb[mlc], T.ml_dfs[mlc]);
+        so = zke_cinit(T.of_state, T.of_dnb[ofc], T.of_dfs[ofc]);
+        sl = zke_cinit(T.ll_state, T.ll_dnb[llc], T.ll_dfs[llc]);
+        b.acc |= x & 0x00FFFFFFFFFFFFFFull; b.n += (uint32_t)(x >> 56);             // <= 48 bits
+        b.flush();
+    }
+    auto step = [&](uint64_t x, uint32_t c) {
+        const uint32_t llc = c & 0xFF, mlc = (c >> 8) & 0xFF, ofc = c >> 16;
+        { uint32_t nbt = (so + T.of_dnb[ofc]) >> 16; b.put(so, nbt); so = T.of_state[(so >> nbt) + T.of_dfs[ofc]]; }
+        { uint32_t nbt = (sm + T.ml_dnb[mlc]) >> 16; b.put(sm, nbt); sm = T.ml_state[(sm >> nbt) + T.ml_dfs[mlc]]; }
+        { uint32_t nbt = (sl + T.ll_dnb[llc]) >> 16; b.put(sl, nbt); sl = T.ll_state[(sl >> nbt) + T.ll_dfs[llc]]; }
+        b.flush();                                                                // <= 7 + 26 bits were waiting
+        b.acc |= (x & 0x00FFFFFFFFFFFFFFull) << b.n; b.n += (uint32_t)(x >> 56);   // <= 7 + 48
+        b.flush();
+    };
+    // sequences nseq - 2 .. 0, read four ahead with unconditional (clamped) loads
+    auto ldx = [&](int32_t k) { return sq[k < 0 ? 0 : k]; };
+    auto ldc = [&](int32_t k) { return cw[k < 0 ? 0 : k]; };
+    int32_t i = (int32_t)nseq - 2;
+    uint64_t e0 = ldx(i), e1 = ldx(i - 1), e2 = ldx(i - 2), e3 = ldx(i - 3);
+    uint32_t c0 = ldc(i), c1 = ldc(i - 1), c2 = ldc(i - 2), c3 = ldc(i - 3);
+    asm volatile("" :: "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
+    while (i >= 3) {                                                              // same scheme as the literal streams
+        const uint64_t n0 = ldx(i - 4), n1 = ldx(i - 5), n2 = ldx(i - 6), n3 = ldx(i - 7);
+        const uint32_t d0 = ldc(i - 4), d1 = ldc(i - 5), d2 = ldc(i - 6), d3 = ldc(i - 7);
+        step(e0, c0); step(e1, c1); step(e2, c2); step(e3, c3);
+        e0 = n0; e1 = n1; e2 = n2; e3 = n3; c0 = d0; c1 = d1; c2 = d2; c3 = d3;
+        i -= 4;
+    }
+    if (i >= 0) step(e0, c0);
+    if (i >= 1) step(e1, c1);
+    if (i >= 2) step(e2, c2);
+    b.put(sm, T.al[2]); b.flush(); b.put(so, T.al[1]); b.put(sl, T.al[0]);
+    return b.close();
+}
 
 // One workgroup handles 16 consecutive blocks so that the serial bit writers fill their waves with REAL work:
 // wave 0 = 16 blocks x 4 literal streams (64 lanes), wave 1 lanes 0-15 = the 16 sequence bitstreams (a wave with
@@ -439,10 +540,10 @@ static_assert(ZKE_THREADS == (int)(ZKE_TILE * ZKE_LSTEP), "one lookup position p
 // payload copies use all 256 lanes, block after block; the Huffman code of block j is built by lane j of wave 0.
 __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
                                                                    uint32_t nblocks, uint64_t *seqs, uint32_t *mpos, const uint8_t *lits,
-                                                                   uint8_t *scratch, const ZkEncTables *tabs)
+                                                                   uint8_t *scratch, const ZkEncTables *ftab)
 {
     __shared__ uint32_t cnt[ZKE_ENT_BLOCKS][256];
-    __shared__ ZkEncTables T;                              // predefined FSE compression tables
+    __shared__ ZkEncTables T;                              // the FSE compression tables of the frame of the workgroup's first block
     __shared__ ZkHufCode hw[ZKE_ENT_BLOCKS];
     __shared__ ZkHufBuild hbuild[ZKE_ENT_BLOCKS / 2];      // trees are built in two rounds of 8: a build needs 1.9 KiB, the codes 384 B
     __shared__ uint32_t s_sizes[ZKE_ENT_BLOCKS][5];        // 4 literal streams + sequence bitstream
@@ -452,7 +553,8 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
     const uint32_t nb = nblocks - b0 < (uint32_t)ZKE_ENT_BLOCKS ? nblocks - b0 : (uint32_t)ZKE_ENT_BLOCKS;
 
     for (uint32_t i = tid; i < ZKE_ENT_BLOCKS * 256; i += ZKE_ENT_THREADS) (&cnt[0][0])[i] = 0;
-    for (uint32_t i = tid; i < sizeof(ZkEncTables) / 4; i += ZKE_ENT_THREADS) ((uint32_t *)&T)[i] = ((const uint32_t *)tabs)[i];
+    const uint32_t frame_a = blocks[b0].frame;
+    for (uint32_t i = tid; i < sizeof(ZkEncTables) / 4; i += ZKE_ENT_THREADS) ((uint32_t *)&T)[i] = ((const uint32_t *)&ftab[frame_a])[i];
     if (tid < ZKE_ENT_BLOCKS) s_diff[tid] = 0;
     __syncthreads();
     // raw block all one byte?  literal histogram -- all lanes, block after block
@@ -586,49 +688,10 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
         const uint32_t j = lane;
         uint32_t sz = 0;
         if (j < nb && blocks[b0 + j].nseq) {
-            const ZkEncBlock &blk = blocks[b0 + j];
-            const uint32_t nseq = blk.nseq, q = (blk.nlit + 3) / 4, scap = q + (q >> 1) + 16;
-            const uint64_t *sq = seqs + blk.seq_base;
-            ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + 4 * scap, blk.bsz);       // + 64 bytes of slack behind it
-            const uint32_t *cw = mpos + blk.seq_base;
-            uint32_t sl, sm, so;
-            {
-                const uint64_t x = sq[nseq - 1];
-                const uint32_t c = cw[nseq - 1], llc = c & 0xFF, mlc = (c >> 8) & 0xFF, ofc = c >> 16;
-                sm = zke_cinit(T.ml_state, T.ml_dnb[mlc], T.ml_dfs[mlc]);
-                so = zke_cinit(T.of_state, T.of_dnb[ofc], T.of_dfs[ofc]);
-                sl = zke_cinit(T.ll_state, T.ll_dnb[llc], T.ll_dfs[llc]);
-                b.acc |= x & 0x00FFFFFFFFFFFFFFull; b.n += (uint32_t)(x >> 56);             // <= 48 bits
-                b.flush();
-            }
-            auto step = [&](uint64_t x, uint32_t c) {
-                const uint32_t llc = c & 0xFF, mlc = (c >> 8) & 0xFF, ofc = c >> 16;
-                { uint32_t nbt = (so + T.of_dnb[ofc]) >> 16; b.put(so, nbt); so = T.of_state[(so >> nbt) + T.of_dfs[ofc]]; }
-                { uint32_t nbt = (sm + T.ml_dnb[mlc]) >> 16; b.put(sm, nbt); sm = T.ml_state[(sm >> nbt) + T.ml_dfs[mlc]]; }
-                { uint32_t nbt = (sl + T.ll_dnb[llc]) >> 16; b.put(sl, nbt); sl = T.ll_state[(sl >> nbt) + T.ll_dfs[llc]]; }
-                b.flush();                                                                // <= 7 + 17 bits were waiting
-                b.acc |= (x & 0x00FFFFFFFFFFFFFFull) << b.n; b.n += (uint32_t)(x >> 56);   // <= 7 + 48
-                b.flush();
-            };
-            // sequences nseq - 2 .. 0, read four ahead with unconditional (clamped) loads
-            auto ldx = [&](int32_t k) { return sq[k < 0 ? 0 : k]; };
-            auto ldc = [&](int32_t k) { return cw[k < 0 ? 0 : k]; };
-            int32_t i = (int32_t)nseq - 2;
-            uint64_t e0 = ldx(i), e1 = ldx(i - 1), e2 = ldx(i - 2), e3 = ldx(i - 3);
-            uint32_t c0 = ldc(i), c1 = ldc(i - 1), c2 = ldc(i - 2), c3 = ldc(i - 3);
-            asm volatile("" :: "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
-            while (i >= 3) {                                                              // same scheme as the literal streams
-                const uint64_t n0 = ldx(i - 4), n1 = ldx(i - 5), n2 = ldx(i - 6), n3 = ldx(i - 7);
-                const uint32_t d0 = ldc(i - 4), d1 = ldc(i - 5), d2 = ldc(i - 6), d3 = ldc(i - 7);
-                step(e0, c0); step(e1, c1); step(e2, c2); step(e3, c3);
-                e0 = n0; e1 = n1; e2 = n2; e3 = n3; c0 = d0; c1 = d1; c2 = d2; c3 = d3;
-                i -= 4;
-            }
-            if (i >= 0) step(e0, c0);
-            if (i >= 1) step(e1, c1);
-            if (i >= 2) step(e2, c2);
-            b.put(sm, 6); b.put(so, 5); b.put(sl, 6);
-            sz = b.close();
+            // the tables come out of LDS when the block belongs to the workgroup's first frame (the rule: 16 blocks of one
+            // frame per workgroup), out of HBM for the blocks of another frame in a mixed workgroup
+            if (blocks[b0 + j].frame == frame_a) sz = zke_write_sequences(T, blocks[b0 + j], seqs, mpos, scratch);
+            else sz = zke_write_sequences(ftab[blocks[b0 + j].frame], blocks[b0 + j], seqs, mpos, scratch);
         }
         s_sizes[lane][4] = sz;
     }
@@ -720,7 +783,9 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
         }
         p += nseq < 128 ? 1 : nseq < 0x7F00 ? 2 : 3;
         if (nseq) {
-            if (lane == 0) payload[p] = 0;                          // predefined LL / OF / ML
+            // Symbol_Compression_Modes in its Repeat_Mode form (the frame's own tables: 3, predefined ones: 0); the block
+            // that turns out to be the frame's first compressed one gets FSE_Compressed_Mode + the descriptions at assembly
+            if (lane == 0) { payload[p] = (uint8_t)zke_modes_byte(ftab[blk.frame].custom, 3); blocks[b0 + j].modes_off = p; }
             p += 1;
             zke_copy_wave(payload + p, qtemp, z[4], lane);
         }
@@ -728,7 +793,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
 }
 
 // ------------------------------------------------------------------------------------------------ frame sizes, scan, assemble
-__global__ __launch_bounds__(64) void zk_k_enc_sizes(const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, int checksum,
+__global__ __launch_bounds__(64) void zk_k_enc_sizes(const ZkEncFrame *frames, uint32_t nframes, ZkEncBlock *blocks, const ZkEncTables *ftab, int checksum,
                                                      uint64_t *c_size64, uint32_t *c_sizes, uint32_t *d_sizes)
 {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -738,7 +803,17 @@ __global__ __launch_bounds__(64) void zk_k_enc_sizes(const ZkEncFrame *frames, u
     if (fr.d_size == 0) c = 9;                                      // 28 B5 2F FD 20 00 01 00 00
     else {
         c = 6;
-        for (uint32_t b = 0; b < fr.n_blocks; b++) c += 3 + blocks[fr.block_base + b].csize;
+        // the frame's first compressed block with sequences defines its tables: it grows by the descriptions
+        bool defined = ftab[f].custom == 0;
+        for (uint32_t b = 0; b < fr.n_blocks; b++) {
+            ZkEncBlock &blk = blocks[fr.block_base + b];
+            if (!defined && blk.mode == 2 && blk.nseq) {
+                blk.is_def = 1;
+                blk.csize += ftab[f].dlen[0] + ftab[f].dlen[1] + ftab[f].dlen[2];
+                defined = true;
+            }
+            c += 3 + blk.csize;
+        }
     }
     if (checksum) c += 4;
     c_size64[f] = c;
@@ -771,7 +846,7 @@ __global__ __launch_bounds__(1024) void zk_k_scan64(const uint64_t *in, uint32_t
     if (tid == 0) out[n] = carry;
 }
 
-__global__ __launch_bounds__(256) void zk_k_enc_assemble(const uint8_t *src, const ZkEncFrame *frames, const ZkEncBlock *blocks,
+__global__ __launch_bounds__(256) void zk_k_enc_assemble(const uint8_t *src, const ZkEncFrame *frames, const ZkEncBlock *blocks, const ZkEncTables *ftab,
                                                          const uint8_t *scratch, const uint64_t *out_off, const uint64_t *hashes,
                                                          int checksum, uint8_t *dst)
 {
@@ -792,7 +867,18 @@ __global__ __launch_bounds__(256) void zk_k_enc_assemble(const uint8_t *src, con
             if (tid == 0) { const uint32_t h = last | (blk.mode << 1) | (field << 3); o[p] = (uint8_t)h; o[p + 1] = (uint8_t)(h >> 8); o[p + 2] = (uint8_t)(h >> 16); }
             p += 3;
             if (blk.mode == 1) { if (tid == 0) o[p] = blk.rle_byte; p += 1; }
-            else {
+            else if (blk.mode == 2 && blk.is_def) {
+                // payload up to the modes byte, the modes byte in its defining form, the descriptions, the rest
+                const ZkEncTables &ft = ftab[blockIdx.x];
+                const uint8_t *from = scratch + blk.scratch_base;
+                const uint32_t extra = ft.dlen[0] + ft.dlen[1] + ft.dlen[2], body = blk.csize - extra, mo = blk.modes_off;
+                for (uint32_t i = tid; i < mo; i += 256) o[p + i] = from[i];
+                if (tid == 0) o[p + mo] = (uint8_t)zke_modes_byte(ft.custom, 2);
+                uint32_t w = mo + 1;
+                for (int t = 0; t < 3; t++) { for (uint32_t i = tid; i < ft.dlen[t]; i += 256) o[p + w + i] = ft.desc[t][i]; w += ft.dlen[t]; }
+                for (uint32_t i = mo + 1 + tid; i < body; i += 256) o[p + extra + i] = from[i];
+                p += blk.csize;
+            } else {
                 const uint8_t *from = blk.mode == 2 ? scratch + blk.scratch_base : src + fr.src_off + blk.bs;
                 const uint32_t n = blk.mode == 2 ? blk.csize : blk.bsz;
                 for (uint32_t i = tid; i < n; i += 256) o[p + i] = from[i];
@@ -821,23 +907,29 @@ void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *f
 {
     hipLaunchKernelGGL(zk_k_enc_match, dim3(nframes), dim3(ZKE_THREADS), 0, st, src, frames, blocks, seqs, mpos, lits);
 }
+void zk_launch_enc_fse_build(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, const uint64_t *seqs,
+                             const ZkEncTables *predef, ZkEncTables *ftab)
+{
+    (void)src;
+    hipLaunchKernelGGL(zk_k_enc_fse_build, dim3(nframes), dim3(256), 0, st, frames, blocks, seqs, predef, ftab);
+}
 void zk_launch_enc_entropy(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks, uint32_t nblocks,
-                           uint64_t *seqs, uint32_t *mpos, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *tabs)
+                           uint64_t *seqs, uint32_t *mpos, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *ftab)
 {
     if (!nblocks) return;
-    hipLaunchKernelGGL(zk_k_enc_entropy, dim3((nblocks + ZKE_ENT_BLOCKS - 1) / ZKE_ENT_BLOCKS), dim3(ZKE_ENT_THREADS), 0, st, src, frames, blocks, nblocks, seqs, mpos, lits, scratch, tabs);
+    hipLaunchKernelGGL(zk_k_enc_entropy, dim3((nblocks + ZKE_ENT_BLOCKS - 1) / ZKE_ENT_BLOCKS), dim3(ZKE_ENT_THREADS), 0, st, src, frames, blocks, nblocks, seqs, mpos, lits, scratch, ftab);
 }
-void zk_launch_enc_sizes(hipStream_t st, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, int checksum,
+void zk_launch_enc_sizes(hipStream_t st, const ZkEncFrame *frames, uint32_t nframes, ZkEncBlock *blocks, const ZkEncTables *ftab, int checksum,
                          uint64_t *c_size64, uint32_t *c_sizes, uint32_t *d_sizes)
 {
-    hipLaunchKernelGGL(zk_k_enc_sizes, dim3((nframes + 63) / 64), dim3(64), 0, st, frames, nframes, blocks, checksum, c_size64, c_sizes, d_sizes);
+    hipLaunchKernelGGL(zk_k_enc_sizes, dim3((nframes + 63) / 64), dim3(64), 0, st, frames, nframes, blocks, ftab, checksum, c_size64, c_sizes, d_sizes);
 }
 void zk_launch_scan64(hipStream_t st, const uint64_t *in, uint32_t n, uint64_t *out)
 {
     hipLaunchKernelGGL(zk_k_scan64, dim3(1), dim3(1024), 0, st, in, n, out);
 }
-void zk_launch_enc_assemble(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks,
+void zk_launch_enc_assemble(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, const ZkEncTables *ftab,
                             const uint8_t *scratch, const uint64_t *out_off, const uint64_t *hashes, int checksum, uint8_t *dst)
 {
-    hipLaunchKernelGGL(zk_k_enc_assemble, dim3(nframes), dim3(256), 0, st, src, frames, blocks, scratch, out_off, hashes, checksum, dst);
+    hipLaunchKernelGGL(zk_k_enc_assemble, dim3(nframes), dim3(256), 0, st, src, frames, blocks, ftab, scratch, out_off, hashes, checksum, dst);
 }

@@ -6,7 +6,7 @@
 #include "zk_enc_device.h"
 
 enum { ZK_K_WALK_COUNT = 0, ZK_K_SCAN, ZK_K_WALK_FILL, ZK_K_HUF, ZK_K_FSE, ZK_K_EXEC, ZK_K_XXH64, ZK_K_STATUS,
-       ZK_K_ENC_MATCH, ZK_K_ENC_ENTROPY, ZK_K_ENC_COMPACT, ZK_K_ENC_XXH64, ZK_NKERNELS };
+       ZK_K_ENC_MATCH, ZK_K_ENC_ENTROPY, ZK_K_ENC_COMPACT, ZK_K_ENC_XXH64, ZK_K_ENC_FSE_BUILD, ZK_NKERNELS };
 
 struct zk_devbuf { void *p = nullptr; size_t cap = 0; };
 enum { ZK_MAX_CTX = 6 };
@@ -47,7 +47,7 @@ struct zk_engine {
     bool ev_used[ZK_NKERNELS] = {};
     float kernel_ms[ZK_NKERNELS] = {};
     // encode scratch
-    zk_devbuf enc_a, enc_b, enc_c, enc_d, enc_e;
+    zk_devbuf enc_a, enc_b, enc_c, enc_d, enc_e, enc_f;
     void *enc_pin = nullptr; size_t enc_pin_cap = 0;   // pinned host copy of the frame / block lists of the encode in flight
     zk_devbuf enc_hist;                     // prefix mode: [prefix tail | frame] records for the matcher
     ZkEncTables enc_tables;

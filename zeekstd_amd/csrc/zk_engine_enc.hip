@@ -16,42 +16,18 @@
     } while (0)
 
 // ---------------------------------------------------------------- predefined FSE compression tables (host, once)
-static void build_ctable(const int16_t *norm, int nsym, int al, uint16_t *state, uint32_t *dfs, uint32_t *dnb)
-{
-    const int size = 1 << al, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
-    int high = size - 1;
-    uint8_t sym[512];
-    int cumul[66];
-    cumul[0] = 0;
-    for (int u = 1; u <= nsym; u++) {
-        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; sym[high--] = (uint8_t)(u - 1); }
-        else cumul[u] = cumul[u - 1] + norm[u - 1];
-    }
-    int pos = 0;
-    for (int s = 0; s < nsym; s++)
-        for (int i = 0; i < norm[s]; i++) { sym[pos] = (uint8_t)s; do pos = (pos + step) & mask; while (pos > high); }
-    for (int u = 0; u < size; u++) { int s = sym[u]; state[cumul[s]++] = (uint16_t)(size + u); }
-    int total = 0;
-    for (int s = 0; s < nsym; s++) {
-        if (norm[s] == 0) { dnb[s] = ((uint32_t)(al + 1) << 16) - (1u << al); dfs[s] = 0; }
-        else if (norm[s] == -1 || norm[s] == 1) { dnb[s] = ((uint32_t)al << 16) - (1u << al); dfs[s] = (uint32_t)(total - 1); total++; }
-        else {
-            const uint32_t mbo = (uint32_t)al - zk_highbit((uint32_t)norm[s] - 1), msp = (uint32_t)norm[s] << mbo;
-            dnb[s] = (mbo << 16) - msp; dfs[s] = (uint32_t)(total - norm[s]); total += norm[s];
-        }
-    }
-}
-
 void zk_build_enc_tables(ZkEncTables *t)
 {
     static const int16_t ll[36] = ZK_LL_DEFNORM, of[29] = ZK_OF_DEFNORM, ml[53] = ZK_ML_DEFNORM;
     static const uint32_t llv[36] = ZK_LL_TABLE, mlv[53] = ZK_ML_TABLE;
     memset(t, 0, sizeof *t);
-    build_ctable(ll, 36, 6, t->ll_state, t->ll_dfs, t->ll_dnb);
-    build_ctable(of, 29, 5, t->of_state, t->of_dfs, t->of_dnb);
-    build_ctable(ml, 53, 6, t->ml_state, t->ml_dfs, t->ml_dnb);
+    uint8_t sym[512]; int32_t cumul[66];
+    zke_build_ctable(ll, 36, 6, t->ll_state, t->ll_dfs, t->ll_dnb, sym, cumul);
+    zke_build_ctable(of, 29, 5, t->of_state, t->of_dfs, t->of_dnb, sym, cumul);
+    zke_build_ctable(ml, 53, 6, t->ml_state, t->ml_dfs, t->ml_dnb, sym, cumul);
     for (int i = 0; i < 36; i++) t->ll_val[i] = llv[i];
     for (int i = 0; i < 53; i++) t->ml_val[i] = mlv[i];
+    t->al[0] = 6; t->al[1] = 5; t->al[2] = 6;
 }
 
 extern "C" uint64_t zk_compress_bound(uint64_t n, uint32_t frame_size)
@@ -149,7 +125,8 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
     if ((rc = zk_devbuf_reserve(e, e->enc_b, (size_t)(seq_total + 1) * 12 + 64))) return rc;       // packed sequences (u64) + match positions (u32)
     if ((rc = zk_devbuf_reserve(e, e->enc_c, (size_t)n + 64))) return rc;
     if ((rc = zk_devbuf_reserve(e, e->enc_d, (size_t)scratch_total + 64))) return rc;
-    if ((rc = zk_devbuf_reserve(e, e->enc_e, (size_t)(nf + 1) * 8 * 4 + 64 + sizeof(ZkEncTables)))) return rc;   // c_size64, out_off, hashes, d_off, tables
+    if ((rc = zk_devbuf_reserve(e, e->enc_e, (size_t)(nf + 1) * 8 * 4 + 64 + sizeof(ZkEncTables)))) return rc;   // c_size64, out_off, hashes, d_off, predefined tables
+    if ((rc = zk_devbuf_reserve(e, e->enc_f, (size_t)nf * sizeof(ZkEncTables) + 64))) return rc;                  // the frames' tables
     ZkEncFrame *dfr = (ZkEncFrame *)e->enc_a.p;
     ZkEncBlock *dbl = (ZkEncBlock *)((uint8_t *)e->enc_a.p + frames_bytes);
     uint64_t *c64 = (uint64_t *)e->enc_e.p, *out_off = c64 + (nf + 1), *hashes = out_off + (nf + 1), *d_doff = hashes + (nf + 1);
@@ -169,15 +146,17 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
     }
     if (a.checksum) { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, d_doff, 0, nf, nullptr, hashes); }
     { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (uint8_t *)e->enc_c.p); }
-    { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, dtab); }
-    zk_launch_enc_sizes(st, dfr, nf, dbl, a.checksum, c64, (uint32_t *)a.d_c_sizes, (uint32_t *)a.d_d_sizes);
+    ZkEncTables *ftab = (ZkEncTables *)e->enc_f.p;
+    { zk_kernel_timer t(e, ZK_K_ENC_FSE_BUILD, st); zk_launch_enc_fse_build(st, src, dfr, nf, dbl, (const uint64_t *)e->enc_b.p, dtab, ftab); }
+    { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, ftab); }
+    zk_launch_enc_sizes(st, dfr, nf, dbl, ftab, a.checksum, c64, (uint32_t *)a.d_c_sizes, (uint32_t *)a.d_d_sizes);
     zk_launch_scan64(st, c64, nf, out_off);
     ZK_HIP(hipMemcpyAsync(e->h_words + ZK_HW_ENC_TOTAL, out_off + nf, 8, hipMemcpyDeviceToHost, st));
     if (a.dst_cap < zk_compress_bound(n, frame_size)) {      // the frames may not fit: the total decides before anything is written
         ZK_HIP(hipStreamSynchronize(st));
         if (e->h_words[ZK_HW_ENC_TOTAL] > a.dst_cap) return -(int)ZK_E_DST_TOO_SMALL;
     }
-    { zk_kernel_timer t(e, ZK_K_ENC_COMPACT, st); zk_launch_enc_assemble(st, src, dfr, nf, dbl, (const uint8_t *)e->enc_d.p, out_off, hashes, a.checksum, (uint8_t *)a.d_dst); }
+    { zk_kernel_timer t(e, ZK_K_ENC_COMPACT, st); zk_launch_enc_assemble(st, src, dfr, nf, dbl, ftab, (const uint8_t *)e->enc_d.p, out_off, hashes, a.checksum, (uint8_t *)a.d_dst); }
     if (nf_out) *nf_out = nf;
     return 0;
 }

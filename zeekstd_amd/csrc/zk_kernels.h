@@ -26,10 +26,12 @@ void zk_launch_small_publish(hipStream_t st, const ZkFrameInfo *infos, const uin
 #include "zk_enc_device.h"
 void zk_launch_enc_stage_hist(hipStream_t st, const uint8_t *src, const uint8_t *prefix_tail, const ZkEncFrame *frames, uint32_t nframes, uint8_t *stage);
 void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, ZkEncBlock *blocks, uint64_t *seqs, uint32_t *mpos, uint8_t *lits);
+void zk_launch_enc_fse_build(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, const uint64_t *seqs,
+                             const ZkEncTables *predef, ZkEncTables *ftab);
 void zk_launch_enc_entropy(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks, uint32_t nblocks,
-                           uint64_t *seqs, uint32_t *mpos, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *tabs);
-void zk_launch_enc_sizes(hipStream_t st, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, int checksum,
+                           uint64_t *seqs, uint32_t *mpos, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *ftab);
+void zk_launch_enc_sizes(hipStream_t st, const ZkEncFrame *frames, uint32_t nframes, ZkEncBlock *blocks, const ZkEncTables *ftab, int checksum,
                          uint64_t *c_size64, uint32_t *c_sizes, uint32_t *d_sizes);
 void zk_launch_scan64(hipStream_t st, const uint64_t *in, uint32_t n, uint64_t *out);
-void zk_launch_enc_assemble(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks,
+void zk_launch_enc_assemble(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, const ZkEncTables *ftab,
                             const uint8_t *scratch, const uint64_t *out_off, const uint64_t *hashes, int checksum, uint8_t *dst);
