@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *com
     const uint32_t slot = wave * ZK_FSE_PER_WAVE + lane % nvalid;                      // shadows replicate valid blocks only
     const uint32_t bi = blockIdx.x * ZK_FSE_BLOCKS + slot;
     ZkBlock b = blocks[bi];
-    if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK || b.seq_modes == 0) return;      // all-predefined blocks: zk_k_fse_predef
+    if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK || b.seq_modes == 0 || b.pad) return;      // all-predefined / shared-table blocks: zk_k_fse_predef
     zk_decode_sequences<ZkRevU, CP>(comp, blocks, b, &T[slot], seqs + b.seq_base, llv, mlv, real);
     if (!real) return;
     ZkBlock *o = &blocks[bi];
@@ -347,7 +347,7 @@ __device__ __forceinline__ void zk_fse_quad_group(uint32_t group, const uint8_t 
     valid = valid && bi < nblocks;
     if (valid) {
         b = blocks[bi];
-        valid = b.type == 2 && b.nseq != 0 && b.status == ZK_OK && (b.seq_modes != 0 || all_blocks);     // all-predefined blocks: zk_k_fse_predef, unless the batch is small
+        valid = b.type == 2 && b.nseq != 0 && b.status == ZK_OK && b.pad == 0 && (b.seq_modes != 0 || all_blocks);     // pad: done by the shared-table kernel; all-predefined blocks are its job too, unless the batch is small
     }
     if (valid && !toucher && t == ZK_TAB_LL) atomicAdd(&s_live, 1u);
     __syncthreads();
@@ -410,51 +410,110 @@ __global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const u
     zk_fse_quad_group<CP, ZK_FSE_BLOCKS, ZK_FSE_WAVES>(blockIdx.x, comp, blocks, nblocks, seqs, all_blocks);
 }
 
-// Blocks whose three tables are all Predefined_Mode (Symbol_Compression_Modes == 0: what this engine's own
-// encoder emits, and libzstd for small blocks) need no per-block tables: one copy of the predefined tables per
-// workgroup, one block per LANE, full waves.  All 64 lanes walk in lock step so that the 16-B records can be
-// stored cooperatively (ZkCoopFlush: a quarter of the L2 write requests, which were 40% of the kernel's time).
+// Blocks that SHARE their three tables need no per-block copy of them: one copy per workgroup, one block per LANE,
+// full waves.  That is the case for Predefined_Mode (libzstd's small blocks) and for what this engine's own encoder
+// writes: one set of FSE tables per frame -- the frame's first compressed block defines them, every later block says
+// Repeat_Mode (zk_encode.hip, zk_k_enc_fse_build).  A workgroup takes 64 consecutive blocks; the first of them that has
+// sequences sets the reference (per table: predefined, or the index of the defining block), the lanes whose blocks use
+// exactly those tables take part, the others are left to zk_k_fse_quad (which skips what is marked done).  All 64 lanes
+// walk in lock step so that the 8-B records can be stored cooperatively (ZkCoopFlush: fewer, fuller L2 write requests,
+// which were 40% of the kernel's time).  A reference with own tables that fewer than ZK_FSEP_MIN_SHARE lanes share is not
+// worth a lock-stepped wave (archives written by libzstd: every block its own tables): the workgroup leaves at once.
 constexpr int ZK_FSEP_LANES = 64;                        // blocks per workgroup (one wave)
 constexpr int ZK_FSEP_RING = 8;                          // records per lane between two cooperative flushes (8 x 8 B = one 64-B burst; 128-B bursts measured slower)
+constexpr uint32_t ZK_FSEP_MIN_SHARE = 8;
+constexpr uint32_t ZK_KEY_PREDEF = 0xFFFFFFFEu;
+struct ZkFseShare { uint32_t al[3]; int32_t own[3]; uint32_t ok; };
+
+// Wave-wide (64 lanes, all of them call it; deterministic, so every wave of a workgroup reaches the same verdict on its own):
+// picks the reference and tells every lane whether its block takes part.  go: the workgroup has something to share.
+struct ZkFsePick { uint32_t k0, k1, k2, r0, r1, r2; bool match, go; };
+__device__ __forceinline__ ZkFsePick zk_fse_share_pick(uint32_t nblocks, uint32_t bi, const ZkBlock &b)
+{
+    ZkFsePick p;
+    bool cand = bi < nblocks;
+    p.k0 = p.k1 = p.k2 = 0;                                // (scalars, no arrays: nothing here may end up in scratch memory)
+    if (cand) {
+        cand = b.type == 2 && b.nseq != 0 && b.status == ZK_OK && b.pad == 0;
+        const uint32_t m0 = (b.seq_modes >> 6) & 3, m1 = (b.seq_modes >> 4) & 3, m2 = (b.seq_modes >> 2) & 3;
+        if (m0 == 1 || m1 == 1 || m2 == 1) cand = false;                 // RLE_Mode tables are per block: zk_k_fse_quad
+        p.k0 = m0 == 0 ? ZK_KEY_PREDEF : m0 == 2 ? bi : b.tab_def[0];
+        p.k1 = m1 == 0 ? ZK_KEY_PREDEF : m1 == 2 ? bi : b.tab_def[1];
+        p.k2 = m2 == 0 ? ZK_KEY_PREDEF : m2 == 2 ? bi : b.tab_def[2];
+    }
+    const uint64_t cm = __ballot(cand);
+    const int ref = cm ? __builtin_ctzll(cm) : 0;
+    p.r0 = __shfl(p.k0, ref, 64); p.r1 = __shfl(p.k1, ref, 64); p.r2 = __shfl(p.k2, ref, 64);
+    p.match = cand && p.k0 == p.r0 && p.k1 == p.r1 && p.k2 == p.r2;
+    const bool predef = p.r0 == ZK_KEY_PREDEF && p.r1 == ZK_KEY_PREDEF && p.r2 == ZK_KEY_PREDEF;
+    p.go = cm != 0 && (predef || (uint32_t)__popcll(__ballot(p.match)) >= ZK_FSEP_MIN_SHARE);
+    return p;
+}
+// the reference's three tables (called by 16 lanes redundantly: identical LDS writes, >= 16 active lanes)
+template <typename CP>
+__device__ __forceinline__ void zk_fse_share_build(const uint8_t *comp, const ZkBlock *blocks, const ZkFsePick &p, ZkSeqTablesT<CP> *T, ZkFseShare *sh,
+                                                   const uint32_t *llv, const uint32_t *mlv)
+{
+    ZkBlock fake;
+    fake.seq_modes = 0; fake.seq_off = 0; fake.bsize = 0; fake.src = 0;
+    uint32_t ok = 1;
+#define ZK_SHARE_TABLE(t, rk) do { uint32_t a = 0; \
+        const int32_t r = (rk) == ZK_KEY_PREDEF ? zk_seq_table_setup<CP>(comp, fake, t, T, &a, llv, mlv) \
+                                                : zk_seq_table_setup<CP>(comp, blocks[rk], t, T, &a, llv, mlv); \
+        sh->al[t] = a; sh->own[t] = r; \
+        if (r < 0) ok = 0;                              /* a damaged description: zk_k_fse_quad reports it block by block */ \
+    } while (0)
+    ZK_SHARE_TABLE(0, p.r0); ZK_SHARE_TABLE(1, p.r1); ZK_SHARE_TABLE(2, p.r2);
+#undef ZK_SHARE_TABLE
+    sh->ok = ok;
+}
+// where the lane's bitstream starts: the defining block carries the descriptions itself
+__device__ __forceinline__ uint32_t zk_fse_share_offset(const ZkFsePick &p, uint32_t bi, const ZkBlock &b, const ZkFseShare *sh)
+{
+    uint32_t off = b.seq_off + 1;
+    if (p.k0 == bi) off += (uint32_t)sh->own[0];
+    if (p.k1 == bi) off += (uint32_t)sh->own[1];
+    if (p.k2 == bi) off += (uint32_t)sh->own[2];
+    return off;
+}
+
 template <typename RD>
 __global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_predef(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeqP *seqs)
 {
     __shared__ ZkSeqTables T;                              // shared, read-only after the build
     __shared__ __attribute__((aligned(16))) ZkSeqP ring[ZK_FSEP_LANES][ZK_FSEP_RING];
     __shared__ ZkCoopFlush coop;
-    __shared__ uint32_t llv[36], mlv[53], s_al[3];
+    __shared__ ZkFseShare share;
+    __shared__ uint32_t llv[36], mlv[53];
     const uint32_t tid = threadIdx.x;
     {
         const uint32_t ll_init[36] = ZK_LL_TABLE;
         const uint32_t ml_init[53] = ZK_ML_TABLE;
         if (tid < 36) llv[tid] = ll_init[tid];
         if (tid < 53) mlv[tid] = ml_init[tid];
-        if (tid == 0) { coop.ring = &ring[0][0]; coop.seqs = seqs; coop.nloop = 0; }
+        if (tid == 0) { coop.ring = &ring[0][0]; coop.seqs = seqs; coop.nloop = 0; share.ok = 0; }
     }
     __syncthreads();
-    if (tid < 16) {                                        // 16 lanes redundantly (identical LDS writes): >= 16 active lanes
-        ZkBlock fake;
-        fake.seq_modes = 0; fake.seq_off = 0; fake.bsize = 0; fake.src = 0;
-        for (int t = 0; t < 3; t++) { uint32_t a = 0; (void)zk_seq_table_setup(comp, fake, t, &T, &a, llv, mlv); s_al[t] = a; }
-    }
     const uint32_t bi = blockIdx.x * ZK_FSEP_LANES + tid;
-    bool active = bi < nblocks;
     ZkBlock b;
-    if (active) {
-        b = blocks[bi];
-        active = b.type == 2 && b.nseq != 0 && b.status == ZK_OK && b.seq_modes == 0;
-    }
+    if (bi < nblocks) b = blocks[bi];
+    const ZkFsePick pk = zk_fse_share_pick(nblocks, bi, b);
+    if (!pk.go) return;                                    // nothing shared here (wave-uniform)
+    if (tid < 16) zk_fse_share_build<ZkCells32>(comp, blocks, pk, &T, &share, llv, mlv);
+    bool active = pk.match;
     coop.base[tid] = active ? b.seq_base : 0;
     coop.nseq[tid] = active ? b.nseq : 0;
     if (active) atomicMax(&coop.nloop, b.nseq);
     __syncthreads();
+    if (!share.ok) return;
     // every lane of the wave runs the walk in lock step (inactive ones only help storing the others' records)
-    zk_seq_walk<ZK_FSEP_RING, RD>(comp, b, active ? b.seq_off + 1 : 0, T.ll, T.of, T.ml, s_al, ring[tid], seqs, llv, mlv, true, &coop, active, tid);
+    zk_seq_walk<ZK_FSEP_RING, RD>(comp, b, active ? zk_fse_share_offset(pk, bi, b, &share) : 0, T.ll, T.of, T.ml, share.al, ring[tid], seqs, llv, mlv, true, &coop, active, tid);
     if (!active) return;
     ZkBlock *o = &blocks[bi];
     o->out_size = b.out_size;
     o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
     o->status = b.status;
+    o->pad = 1;                                            // done: zk_k_fse_quad skips it
 }
 
 // The same with a feeder wave: wave 0 walks (reader ZkRevL: stream words out of an LDS ring, no global load in the
@@ -465,7 +524,8 @@ __global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const u
     __shared__ __attribute__((aligned(16))) ZkSeqP ring[ZK_FSEP_LANES][ZK_FSEP_RING];
     __shared__ ZkCoopFlush coop;
     __shared__ ZkRevLShared feed;
-    __shared__ uint32_t llv[36], mlv[53], s_al[3], s_done;
+    __shared__ ZkFseShare share;
+    __shared__ uint32_t llv[36], mlv[53], s_done;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const bool walker = tid < 64;
     {
@@ -474,39 +534,37 @@ __global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const u
         if (tid < 36) llv[tid] = ll_init[tid];
         if (tid < 53) mlv[tid] = ml_init[tid];
         if (walker) { feed.filled[lane] = 0; feed.taken[lane] = 0; }
-        if (tid == 0) { coop.ring = &ring[0][0]; coop.seqs = seqs; coop.nloop = 0; s_done = 0; }
+        if (tid == 0) { coop.ring = &ring[0][0]; coop.seqs = seqs; coop.nloop = 0; s_done = 0; share.ok = 0; }
     }
     __syncthreads();
-    if (tid < 16) {
-        ZkBlock fake;
-        fake.seq_modes = 0; fake.seq_off = 0; fake.bsize = 0; fake.src = 0;
-        for (int t = 0; t < 3; t++) { uint32_t a = 0; (void)zk_seq_table_setup<ZkCells64>(comp, fake, t, &T, &a, llv, mlv); s_al[t] = a; }
-    }
     const uint32_t bi = blockIdx.x * ZK_FSEP_LANES + lane;
-    bool active = bi < nblocks;
     ZkBlock b;
-    if (active) {
-        b = blocks[bi];
-        active = b.type == 2 && b.nseq != 0 && b.status == ZK_OK && b.seq_modes == 0;
-    }
+    if (bi < nblocks) b = blocks[bi];
+    const ZkFsePick pk = zk_fse_share_pick(nblocks, bi, b);          // both waves, same verdict
+    if (!pk.go) return;
+    if (tid < 16) zk_fse_share_build<ZkCells64>(comp, blocks, pk, &T, &share, llv, mlv);
+    const bool active = pk.match;
     if (walker) {
         coop.base[lane] = active ? b.seq_base : 0;
         coop.nseq[lane] = active ? b.nseq : 0;
         if (active) atomicMax(&coop.nloop, b.nseq);
     }
     __syncthreads();
+    if (!share.ok) return;
+    const uint32_t bs_off = active ? zk_fse_share_offset(pk, bi, b, &share) : 0;
     if (walker) {
-        zk_seq_walk<ZK_FSEP_RING, ZkRevL, ZkCells64>(comp, b, active ? b.seq_off + 1 : 0, T.ll, T.of, T.ml, s_al, ring[lane], seqs, llv, mlv, true, &coop, active, lane, &feed);
+        zk_seq_walk<ZK_FSEP_RING, ZkRevL, ZkCells64>(comp, b, bs_off, T.ll, T.of, T.ml, share.al, ring[lane], seqs, llv, mlv, true, &coop, active, lane, &feed);
         *(volatile uint32_t *)&s_done = 1;
         if (!active) return;
         ZkBlock *o = &blocks[bi];
         o->out_size = b.out_size;
         o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
         o->status = b.status;
-    } else if (active && b.seq_off + 1 < b.bsize) {
+        o->pad = 1;
+    } else if (active && bs_off < b.bsize) {
         // feeder: aligned words of the lane's bitstream, last word first (ZkRevL::word_count / W(j))
-        const uint8_t *base = comp + b.src + b.seq_off + 1;
-        const uint32_t len = b.bsize - b.seq_off - 1, nwords = ZkRevL::word_count(base, len);
+        const uint8_t *base = comp + b.src + bs_off;
+        const uint32_t len = b.bsize - bs_off, nwords = ZkRevL::word_count(base, len);
         const uint8_t *ptr = reinterpret_cast<const uint8_t *>((((uintptr_t)base + len) + 7) & ~(uintptr_t)7) - 8;
         volatile uint32_t *taken = &feed.taken[lane], *filled = &feed.filled[lane], *done = &s_done;
         uint32_t f = 0;
@@ -948,10 +1006,9 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
         hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 16, 1>), dim3((nblocks + 15) / 16), dim3(128), 0, st, comp, blocks, nblocks, seqs, 1u);
         return;
     }
-    if (n_own_tables < nblocks) {          // at least one block may be all-predefined
-        if (wgs >= 6 * 256) hipLaunchKernelGGL(zk_k_fse_predef_fed, dim3(wgs), dim3(2 * ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
-        else hipLaunchKernelGGL(zk_k_fse_predef<ZkRevU>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
-    }
+    // blocks that share their tables with their neighbours (predefined, or one set per frame): one lane each
+    if (wgs >= 6 * 256) hipLaunchKernelGGL(zk_k_fse_predef_fed, dim3(wgs), dim3(2 * ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
+    else hipLaunchKernelGGL(zk_k_fse_predef<ZkRevU>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
     // blocks with their own tables (every block is visited, the others return at once): a quad of lanes per block.
     // While everything fits in one round, small workgroups (16 blocks, one walking wave + the toucher: 45 KiB of LDS,
     // three per CU) spread the blocks over the CUs and a block's chain latency is all that counts (measured, 2048

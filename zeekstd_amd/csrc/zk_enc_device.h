@@ -59,6 +59,12 @@ struct ZkEncBlock {
 // FRAME: the first compressed block with sequences carries the descriptions (FSE_Compressed_Mode), the later ones say
 // Repeat_Mode, so a decoder builds them once per frame and still decodes the frame's blocks independently.
 constexpr uint32_t ZKE_FSE_MIN_SEQ = 256;       // frames with fewer sequences keep the predefined tables
+#ifndef ZKE_FSE_LOGS
+#define ZKE_FSE_LOGS 9, 8, 9
+#endif
+// accuracy logs LL, OF, ML of a frame's own tables: the format's maxima.  (7 / 7 / 7 would cost 0.55 % of ratio -- 2.430 vs
+// 2.443 on the 8d text -- and measured no faster in the decoder: zk_k_fse_predef_fed 3.5 ms either way.)
+constexpr int ZKE_FSE_LOG[3] = {ZKE_FSE_LOGS};
 constexpr uint32_t ZKE_DESC_CAP = 80;           // bytes of one table description (53 symbols x <= 10 bits + repeats)
 struct ZkEncTables {
     uint16_t ll_state[512], of_state[256], ml_state[512];

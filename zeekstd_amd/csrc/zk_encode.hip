@@ -25,6 +25,7 @@
 //                     final contiguous stream
 // HBM-bound integer/byte work; no MFMA.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "zk_device.h"
 #include "zk_enc_device.h"
 #include "zk_kernels.h"
@@ -433,7 +434,7 @@ __device__ __forceinline__ void zke_copy_wave(uint8_t *dst, const uint8_t *src, 
 // writes the description and builds the compression table into the frame's ZkEncTables (HBM).  A table with fewer than
 // two symbols, or a frame with fewer than ZKE_FSE_MIN_SEQ sequences, keeps the predefined one.
 __global__ __launch_bounds__(256) void zk_k_enc_fse_build(const ZkEncFrame *frames, const ZkEncBlock *blocks, const uint64_t *seqs,
-                                                          const ZkEncTables *predef, ZkEncTables *ftab)
+                                                          const ZkEncTables *predef, ZkEncTables *ftab, uint32_t min_seq)
 {
     __shared__ uint32_t h[3][64];
     __shared__ int16_t norm[3][64];
@@ -461,9 +462,9 @@ __global__ __launch_bounds__(256) void zk_k_enc_fse_build(const ZkEncFrame *fram
     // the predefined set is the starting point (value tables, and whatever stays predefined)
     for (uint32_t i = tid; i < sizeof(ZkEncTables) / 4; i += 256) ((uint32_t *)T)[i] = ((const uint32_t *)predef)[i];
     __syncthreads();
-    if (tid < 3 && s_nseq >= ZKE_FSE_MIN_SEQ) {
+    if (tid < 3 && s_nseq >= min_seq) {
         const int t = (int)tid;
-        const int nsym = t == 0 ? 36 : t == 1 ? 32 : 53, L = t == 1 ? 8 : 9;
+        const int nsym = t == 0 ? 36 : t == 1 ? 32 : 53, L = ZKE_FSE_LOG[t];
         if (zke_fse_normalize(h[t], nsym, L, norm[t])) {
             int last = nsym;
             while (last > 0 && norm[t][last - 1] == 0) last--;
@@ -911,7 +912,8 @@ void zk_launch_enc_fse_build(hipStream_t st, const uint8_t *src, const ZkEncFram
                              const ZkEncTables *predef, ZkEncTables *ftab)
 {
     (void)src;
-    hipLaunchKernelGGL(zk_k_enc_fse_build, dim3(nframes), dim3(256), 0, st, frames, blocks, seqs, predef, ftab);
+    static const bool only_predef = getenv("ZK_ENC_PREDEF") != nullptr;      // experiments: the predefined tables for every frame
+    hipLaunchKernelGGL(zk_k_enc_fse_build, dim3(nframes), dim3(256), 0, st, frames, blocks, seqs, predef, ftab, only_predef ? 0xFFFFFFFFu : ZKE_FSE_MIN_SEQ);
 }
 void zk_launch_enc_entropy(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks, uint32_t nblocks,
                            uint64_t *seqs, uint32_t *mpos, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *ftab)
