@@ -380,6 +380,57 @@ def seek_leg(eng, data, zk, z64, nbytes, trials, fsz=65536):
     return out
 
 
+def dry_run(args, rank, world):
+    """The N > 1 launch contract without a GPU (CI here: gloo): RANK / WORLD_SIZE / MASTER_* from the environment, the process
+    group, barriers, max-over-ranks timing, the shard + gather leg (zeekstd_amd/parallel.py) and rank 0's single JSON line.
+    The frames are stand-ins (one raw block each, written here): no codec runs and nothing is measured."""
+    import torch
+    import torch.distributed as dist
+    from zeekstd_amd import parallel
+    if world > 1:
+        dist.init_process_group("gloo")
+    nfr, fsz = 4, 1000
+
+    class StoredFrames:                               # engine stand-in: Frame_Header + one Raw_Block per frame
+        def encode_frames_dev(self, d_src, n, frame_size, level, checksum, d_comp, cap, d_cs, d_ds, stream=None):
+            pos = 0
+            nf = max(1, -(-n // frame_size))
+            for f in range(nf):
+                chunk = bytes(d_src[f * frame_size:min(n, (f + 1) * frame_size)].numpy())
+                h = 1 | (len(chunk) << 3)
+                fr = b"\x28\xb5\x2f\xfd\x00\x00" + bytes([h & 255, (h >> 8) & 255, (h >> 16) & 255]) + chunk
+                d_comp[pos:pos + len(fr)] = torch.frombuffer(bytearray(fr), dtype=torch.uint8)
+                d_cs[f] = len(fr); d_ds[f] = len(chunk)
+                pos += len(fr)
+            return nf, pos
+    d_src = torch.full((nfr * fsz,), rank, dtype=torch.uint8)
+    for _ in range(args.warmup):
+        pass
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    gather = None
+    if world > 1:
+        out, table = parallel.encode_sharded(StoredFrames(), d_src, fsz, 1, False, root=0)
+        gather = {"frames_on_root": table.num_frames() if table is not None else None,
+                  "stream_bytes_on_root": int(out.numel()) if out is not None else None}
+    if rank == 0:
+        print(json.dumps({"metric": "decode_decompressed_GiB_per_s", "value": 0.0, "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "u8", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "dry run (no GPU, nothing measured)", "frames_per_gpu": nfr, "frame_size": fsz},
+                          "rccl_gather": gather}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -396,6 +447,9 @@ def main():
     ap.add_argument("--sync", action="store_true",
                     help="time one batch at a time (zk_decode_frames_dev) instead of two batches in flight; the "
                          "kernel-trace profile uses this so that kernel durations are not inflated by overlap")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: run the launch contract (env, process group over gloo, shard + gather leg, the JSON line) on CPU "
+                         "tensors with stored-block stand-in frames; measures nothing")
     ap.add_argument("--archive", default="auto", choices=["auto", "gpu", "libzstd"],
                     help="who compresses the archive that is decoded: the GPU encoder (default for c3) or CPU libzstd (default for c2)")
     args = ap.parse_args()
@@ -408,6 +462,8 @@ def main():
     nframes = args.frames or (2048 if args.workload == "c3" else 128)
     cks = args.workload == "c3"
     level = 1
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     # ---- untimed setup on the host cores (before any HIP initialisation: workers are forked)
     cores = os.cpu_count() or 8

@@ -173,6 +173,19 @@ void zk_host_free(void *p);
 /* worker threads of the host pipeline (parallel staging copies); 0 = default (hardware threads / 8, clamped to 2..16) */
 int zk_engine_set_host_threads(zk_engine *e, int n);
 
+/* Sharded encode, the one exchange step (BASELINE.json configs[4]): frames are independent, so rank r of `world`
+ * encodes its contiguous frame range on its own GPU (zk_encode_frames_dev) and this call concatenates the ranks' compressed
+ * streams in rank order into d_out on `root` and appends the seek table -- an archive zeekstd's Decoder reads
+ * (seek_table.rs:379-436).  nccl_comm: the caller's RCCL communicator (ncclComm_t, one per rank); RCCL is resolved at run time.
+ * Steps: all-gather of (bytes, frames), all-gather of the padded (c_size, d_size) entries, grouped ncclSend / ncclRecv of the
+ * payloads straight into d_out + offset_r over xGMI, table serialised by the root.  d_payload / d_out: device memory;
+ * c_sizes / d_sizes: this rank's n_frames entries on the host (what zk_encode_frames_dev reported).  On the root *out_bytes
+ * receives stream + table bytes and *table_out (optional) the gathered SeekTable; the other ranks pass d_out = NULL. */
+typedef struct zk_seek_table zk_seek_table;
+int zk_gather_seekable(zk_engine *e, void *nccl_comm, int rank, int world, int root, const void *d_payload, uint64_t payload_bytes,
+                       const uint32_t *c_sizes, const uint32_t *d_sizes, uint32_t n_frames, int format, void *d_out, uint64_t out_cap,
+                       uint64_t *out_bytes, zk_seek_table **table_out, void *stream);
+
 /* XXH64(seed 0) of count byte ranges data[off[i], off[i+1]) -> out[i].  (The checksum libzstd
  * computes when ZSTD_c_checksumFlag is set: encode.rs:163-167, 283-284.) */
 int zk_xxh64_frames(zk_engine *e, const uint8_t *data, const uint64_t *off, uint32_t count, uint64_t *out);
@@ -189,7 +202,6 @@ const char *zk_last_error_message(void);
 #define ZK_FORMAT_FOOT 1
 
 /* ---- SeekTable (lib/src/seek_table.rs:243-935) */
-typedef struct zk_seek_table zk_seek_table;
 typedef struct zk_serializer zk_serializer;
 zk_seek_table *zk_seek_table_new(void);                                                        /* SeekTable::new :287 */
 zk_seek_table *zk_seek_table_clone(const zk_seek_table *t);

@@ -59,3 +59,31 @@ def test_product_never_imports_oracle():
     import subprocess
     needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
     assert "zko" not in needed and "libzstd" not in needed        # the product links neither the oracle nor libzstd
+
+
+def test_rust_binding_declares_every_symbol():
+    """rust/src/ffi.rs (what a zeekstd maintainer binds; uncompiled here -- no cargo in the image) is generated from the header
+    by tools/gen_rust_ffi.py: it is current, and declares every exported zk_* function with the header's number of arguments."""
+    import subprocess
+    import sys
+    import zeekstd_amd as zk
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_ffi as g
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--check"]).returncode == 0, \
+        "rust/src/ffi.rs is stale: run tools/gen_rust_ffi.py"
+    fns = g.parse_functions(open(os.path.join(ROOT, "include", "zeekstd_amd.h")).read())
+    rs = open(os.path.join(ROOT, "rust", "src", "ffi.rs")).read()
+    exported = {l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", zk.LIB_PATH], text=True).splitlines()
+                if l.split()[-1].startswith("zk_")}
+    assert {f[0] for f in fns} == exported                      # header == library
+    for name, _ret, params in fns:
+        m = re.search(r"pub fn %s\(([^)]*)\)" % name, rs)
+        assert m, name
+        assert len([a for a in m.group(1).split(",") if a.strip()]) == len(params), name
+    # the safe wrappers reach every Level-B entry point
+    lib_rs = open(os.path.join(ROOT, "rust", "src", "lib.rs")).read()
+    for name in exported:
+        if any(name.startswith(p) for p in ("zk_decoder_", "zk_encoder_", "zk_raw_encoder_", "zk_seek_table_", "zk_serializer_")) \
+                and name not in ("zk_decoder_open_bytes", "zk_decoder_open_file", "zk_decoder_gpu_submissions", "zk_decoder_time_seeks",
+                                 "zk_seek_table_from_reader_bytes", "zk_seek_table_entries", "zk_serializer_reset", "zk_raw_encoder_compress"):
+            assert "ffi::" + name in lib_rs, name

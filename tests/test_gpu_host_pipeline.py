@@ -254,3 +254,71 @@ def test_encoder_large_write_direct(engine, big):
     assert bytes(sink[:len(comp)]) == comp                 # same frames as the batch call
     out = bytearray(len(data))
     assert DecodeOptions(bytes(sink)).engine(engine).into_decoder().decompress(out) == len(data) and bytes(out) == data
+
+
+def test_encode_sharded_under_nccl_world1(engine, big):
+    """parallel.encode_sharded (the function every GPU rank runs) under a real RCCL process group of one rank: encode on the
+    device, gather, table appended; the archive decodes to the input."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from zeekstd_amd import parallel
+    data, _, _ = big
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        d_src = torch.frombuffer(bytearray(data[:32 << 20]), dtype=torch.uint8).to(dev)
+        out, table = parallel.encode_sharded(engine, d_src, 1 << 20, 1, True, root=0)
+        torch.cuda.synchronize()
+        stream = bytes(out.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+    assert table.num_frames() == 32 and table.size_decomp() == 32 << 20
+    d = DecodeOptions(stream).engine(engine).into_decoder()
+    got = bytearray(32 << 20)
+    assert d.decompress(got) == len(got) and bytes(got) == data[:32 << 20]
+
+
+def test_c_abi_gather_world1(engine, big):
+    """zk_gather_seekable (the sharded path for hosts without torch) with a one-rank RCCL communicator made through librccl."""
+    import torch
+    data, comp, frames = big
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        try:
+            rccl = C.CDLL("/opt/rocm/lib/librccl.so.1")
+        except OSError:
+            pytest.skip("librccl.so.1 not loadable")
+    uid = (C.c_char * 128)()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+
+    class Uid(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+    u = Uid(); C.memmove(C.byref(u), uid, 128)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, u, 0) == 0
+    dev = torch.device("cuda", 0)
+    d_pay = torch.frombuffer(bytearray(comp), dtype=torch.uint8).to(dev)
+    cs = np.array([f[0] for f in frames], np.uint32); ds = np.array([f[1] for f in frames], np.uint32)
+    cap = len(comp) + 8 * len(frames) + 64
+    d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    nbytes = C.c_uint64(); tab = C.c_void_p()
+    lib = zk.lib
+    lib.zk_gather_seekable.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32,
+                                       C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = lib.zk_gather_seekable(engine._h, comm, 0, 1, 0, d_pay.data_ptr(), len(comp), cs.ctypes.data, ds.ctypes.data, len(frames), 1,
+                                d_out.data_ptr(), cap, C.byref(nbytes), C.byref(tab), None)
+    assert rc == 0, zk.lib.zk_engine_last_hip_error(engine._h)
+    stream = bytes(d_out[:nbytes.value].cpu().numpy())
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
+    assert nbytes.value == len(comp) + 8 * len(frames) + 17 and stream[:len(comp)] == comp
+    st = SeekTable.from_seekable(stream)
+    assert st.num_frames() == len(frames) and st.size_decomp() == len(data)
+    lib.zk_seek_table_num_frames.argtypes = [C.c_void_p]
+    assert lib.zk_seek_table_num_frames(tab) == len(frames)
+    lib.zk_seek_table_free.argtypes = [C.c_void_p]
+    lib.zk_seek_table_free(tab)

@@ -84,3 +84,85 @@ def test_shard_range_partitions_everything():
             assert all(got[i][1] == got[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in got]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---------------------------------------------------------------- encode_sharded itself, on CPU
+class FakeEngine:
+    """Stands in for zeekstd_amd.Engine in the gloo tests: encode_frames_dev with the engine's signature, the frames made by
+    the CPU twin of the GPU encoder (test infrastructure).  What is under test is parallel.encode_sharded -- the function the
+    GPU ranks call -- not the codec."""
+
+    def encode_frames_dev(self, d_src, n, frame_size, level, checksum, d_comp, cap, d_cs, d_ds, stream=None):
+        data = bytes(d_src[:n].numpy())
+        nf = max(1, -(-n // frame_size))
+        pos = 0
+        for f in range(nf):
+            chunk = data[f * frame_size:(f + 1) * frame_size]
+            fr = zko.frame_encode(chunk, level, checksum)
+            assert pos + len(fr) <= cap
+            d_comp[pos:pos + len(fr)] = torch.frombuffer(bytearray(fr), dtype=torch.uint8)
+            d_cs[f] = len(fr); d_ds[f] = len(chunk)
+            pos += len(fr)
+        return nf, pos
+
+
+def _worker_sharded(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zeekstd_amd import parallel
+    data = zko.gen_text(n_total, 77)
+    nframes = -(-n_total // FS)
+    lo, hi = parallel.shard_range(nframes, rank, world)
+    shard = data[lo * FS:min(hi * FS, n_total)]
+    d_src = torch.frombuffer(bytearray(shard), dtype=torch.uint8) if shard else torch.zeros(0, dtype=torch.uint8)
+    if lo == hi:                                   # a rank without frames contributes nothing
+        out, table = parallel.gather_seekable(torch.zeros(0, dtype=torch.uint8), torch.zeros(0, dtype=torch.int32),
+                                              torch.zeros(0, dtype=torch.int32), root=0)
+    else:
+        out, table = parallel.encode_sharded(FakeEngine(), d_src, FS, 1, True, root=0)
+    if rank == 0:
+        q.put((bytes(out.numpy()), table.num_frames()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [5 * FS + 17, FS, 64 * FS])
+def test_encode_sharded_world2(n_total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    stream, nfr = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    import zeekstd_amd as zk
+    data = zko.gen_text(n_total, 77)
+    st = zk.SeekTable.from_seekable(stream)
+    assert st.num_frames() == nfr == -(-n_total // FS) and st.size_decomp() == n_total
+    out = bytearray()
+    for i in range(st.num_frames()):
+        fr = stream[st.frame_start_comp(i):st.frame_end_comp(i)]
+        out += zko.frame_decode(fr, st.frame_size_decomp(i), True)[0]
+    assert bytes(out) == data
+
+
+def test_bench_dry_run_world2():
+    """bench.py's N > 1 control flow (env parsing, process group, shard + gather leg, the JSON line) under gloo, no GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["dry_run"] is True and d["scaling"] == "weak"
+    assert d["rccl_gather"]["frames_on_root"] == 2 * d["config"]["frames_per_gpu"]

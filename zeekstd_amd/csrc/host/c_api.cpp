@@ -31,6 +31,9 @@ static int guard(F &&f)
     catch (const std::exception &e) { g_last_error = e.what(); return -1; }
 }
 
+// the gather of zk_engine_gather.hip hands its table over as a C handle
+zk_seek_table *zk_seek_table_from_cpp(const zeekstd::SeekTable *t) { return new (std::nothrow) zk_seek_table{*t}; }
+
 extern "C" {
 
 const char *zk_last_error_message(void) { return g_last_error.c_str(); }

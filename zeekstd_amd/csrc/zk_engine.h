@@ -74,6 +74,9 @@ int zk_dec_ctx_ready(zk_engine *e, int slot);           // creates the context's
 zk_dec_ctx zk_dec_context(zk_engine *e, int slot, void *stream);
 int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a);
 int zk_decode_finish(zk_engine *e, zk_dec_ctx &c);
+namespace zeekstd { class SeekTable; }
+struct zk_seek_table;
+zk_seek_table *zk_seek_table_from_cpp(const zeekstd::SeekTable *t);
 int zk_hostpipe_create(zk_engine *e);
 void zk_hostpipe_destroy(zk_engine *e);
 enum { ZK_HW_ENC_TOTAL = 8 };               // index into zk_engine::h_words of the encoder's total-size read-back

@@ -1,0 +1,126 @@
+// zk_engine_gather.hip -- the one exchange step of the sharded path (BASELINE configs[4]) at the C ABI, for hosts
+// without torch: every rank has encoded its contiguous range of frames (zk_encode_frames_dev); the compressed streams are
+// concatenated in rank order on `root` and the seek table (8n + 17 bytes) is appended.  RCCL over xGMI:
+//   1. ncclAllGather of (bytes, frames) per rank            -> every rank knows every offset
+//   2. ncclAllGather of the (c_size, d_size) entries, padded to the largest shard
+//   3. grouped ncclSend (peers) / ncclRecv (root) of the payload straight into root's buffer at offset_r: every peer has its
+//      own xGMI link into the root, so the receives run side by side; no padding, no staging
+//   4. root serialises the table behind the last frame
+// RCCL is resolved at run time (the library must not depend on it for single-GPU use): symbols already in the process first,
+// then librccl.so.1 (or ZK_RCCL_PATH).  The communicator is the caller's (ncclCommInitRank), one per rank as always.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../include/zeekstd_amd.h"
+#include "zk_engine.h"
+#include "host/zeekstd.hpp"
+
+#define ZK_HIP(call)                                                                                 \
+    do {                                                                                             \
+        hipError_t _e = (call);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            e->last_err = std::string(#call) + ": " + hipGetErrorString(_e);                         \
+            return ZK_ERR_HIP;                                                                       \
+        }                                                                                            \
+    } while (0)
+
+namespace {
+typedef int (*allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*sendrecv_fn)(void *, size_t, int, int, void *, hipStream_t);
+typedef int (*group_fn)(void);
+struct Rccl { allgather_fn all_gather = nullptr; sendrecv_fn send = nullptr, recv = nullptr; group_fn group_start = nullptr, group_end = nullptr; bool ok = false; };
+Rccl &rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    void *h = nullptr;
+    auto sym = [&](const char *n) { void *p = dlsym(RTLD_DEFAULT, n); if (!p && h) p = dlsym(h, n); return p; };
+    if (!dlsym(RTLD_DEFAULT, "ncclAllGather")) {
+        const char *path = getenv("ZK_RCCL_PATH");
+        h = dlopen(path ? path : "librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h && !path) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    }
+    r.all_gather = (allgather_fn)sym("ncclAllGather");
+    r.send = (sendrecv_fn)sym("ncclSend");
+    r.recv = (sendrecv_fn)sym("ncclRecv");
+    r.group_start = (group_fn)sym("ncclGroupStart");
+    r.group_end = (group_fn)sym("ncclGroupEnd");
+    r.ok = r.all_gather && r.send && r.recv && r.group_start && r.group_end;
+    return r;
+}
+enum { kUint8 = 1, kUint32 = 3, kUint64 = 5 };           // ncclDataType_t (rccl.h)
+}  // namespace
+
+extern "C" int zk_gather_seekable(zk_engine *e, void *nccl_comm, int rank, int world, int root, const void *d_payload, uint64_t payload_bytes,
+                                  const uint32_t *c_sizes, const uint32_t *d_sizes, uint32_t n_frames, int format, void *d_out, uint64_t out_cap,
+                                  uint64_t *out_bytes, zk_seek_table **table_out, void *stream)
+{
+    if (out_bytes) *out_bytes = 0;
+    if (table_out) *table_out = nullptr;
+    if (!e || !nccl_comm || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || (payload_bytes && !d_payload) ||
+        (n_frames && (!c_sizes || !d_sizes))) return ZK_ERR_ARGUMENT;
+    Rccl &R = rccl();
+    if (!R.ok) { e->last_err = "RCCL (librccl.so.1) could not be loaded"; return ZK_ERR_HIP; }
+    ZK_HIP(hipSetDevice(e->device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    int rc;
+    // 1. (bytes, frames) of every rank
+    if ((rc = zk_devbuf_reserve(e, e->st_misc, (size_t)(world + 1) * 16))) return rc;
+    uint64_t *d_mine = (uint64_t *)e->st_misc.p, *d_all = d_mine + 2;
+    e->h_words[10] = payload_bytes; e->h_words[11] = n_frames;
+    ZK_HIP(hipMemcpyAsync(d_mine, e->h_words + 10, 16, hipMemcpyHostToDevice, st));
+    if (R.all_gather(d_mine, d_all, 2, kUint64, nccl_comm, st) != 0) { e->last_err = "ncclAllGather failed"; return ZK_ERR_HIP; }
+    std::vector<uint64_t> all((size_t)world * 2);
+    ZK_HIP(hipMemcpyAsync(all.data(), d_all, all.size() * 8, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    std::vector<uint64_t> offs((size_t)world + 1, 0);
+    uint64_t mx = 1, total_frames = 0;
+    for (int r = 0; r < world; r++) { offs[r + 1] = offs[r] + all[2 * r]; if (all[2 * r + 1] > mx) mx = all[2 * r + 1]; total_frames += all[2 * r + 1]; }
+    if (total_frames > ZK_SEEKABLE_MAX_FRAMES) return ZK_ERR_FRAME_INDEX_TOO_LARGE;
+    // 2. seek entries, padded to the largest shard
+    std::vector<uint32_t> ent((size_t)mx * 2, 0), ents((size_t)world * mx * 2);
+    for (uint32_t i = 0; i < n_frames; i++) { ent[i] = c_sizes[i]; ent[mx + i] = d_sizes[i]; }
+    if ((rc = zk_devbuf_reserve(e, e->st_off, (size_t)(world + 1) * mx * 8))) return rc;
+    uint32_t *d_ent = (uint32_t *)e->st_off.p, *d_ents = d_ent + mx * 2;
+    ZK_HIP(hipMemcpyAsync(d_ent, ent.data(), ent.size() * 4, hipMemcpyHostToDevice, st));
+    if (R.all_gather(d_ent, d_ents, (size_t)mx * 2, kUint32, nccl_comm, st) != 0) { e->last_err = "ncclAllGather failed"; return ZK_ERR_HIP; }
+    if (rank == root) ZK_HIP(hipMemcpyAsync(ents.data(), d_ents, ents.size() * 4, hipMemcpyDeviceToHost, st));
+    // 3. the payload, peer to peer into the root's buffer
+    zeekstd::SeekTable table;
+    std::vector<uint8_t> tbytes;
+    if (rank == root) {
+        ZK_HIP(hipStreamSynchronize(st));                  // the entries
+        for (int r = 0; r < world; r++)
+            for (uint64_t i = 0; i < all[2 * r + 1]; i++) table.log_frame(ents[(size_t)r * mx * 2 + i], ents[(size_t)r * mx * 2 + mx + i]);
+        zeekstd::Serializer ser = table.into_format_serializer(format == ZK_FORMAT_HEAD ? zeekstd::Format::Head : zeekstd::Format::Foot);
+        tbytes.resize(ser.encoded_len());
+        size_t w = 0;
+        for (;;) { const size_t k = ser.write_into(tbytes.data() + w, tbytes.size() - w); if (!k) break; w += k; }
+        if (!d_out || offs[world] + tbytes.size() > out_cap) return -(int)ZK_E_DST_TOO_SMALL;
+    }
+    if (R.group_start() != 0) { e->last_err = "ncclGroupStart failed"; return ZK_ERR_HIP; }
+    int bad = 0;
+    if (rank == root) {
+        for (int r = 0; r < world; r++) {
+            if (r == rank || !all[2 * r]) continue;
+            bad |= R.recv((uint8_t *)d_out + offs[r], (size_t)all[2 * r], kUint8, r, nccl_comm, st);
+        }
+    } else if (payload_bytes) bad |= R.send(const_cast<void *>(d_payload), (size_t)payload_bytes, kUint8, root, nccl_comm, st);
+    bad |= R.group_end();
+    if (bad) { e->last_err = "ncclSend / ncclRecv failed"; return ZK_ERR_HIP; }
+    if (rank == root) {
+        if (payload_bytes) ZK_HIP(hipMemcpyAsync((uint8_t *)d_out + offs[rank], d_payload, payload_bytes, hipMemcpyDeviceToDevice, st));
+        // 4. the table behind the last frame
+        ZK_HIP(hipMemcpyAsync((uint8_t *)d_out + offs[world], tbytes.data(), tbytes.size(), hipMemcpyHostToDevice, st));
+    }
+    ZK_HIP(hipStreamSynchronize(st));
+    if (rank == root) {
+        if (out_bytes) *out_bytes = offs[world] + tbytes.size();
+        if (table_out) *table_out = zk_seek_table_from_cpp(&table);
+    }
+    return 0;
+}
