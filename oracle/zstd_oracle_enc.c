@@ -24,7 +24,7 @@ u64 zko_xxh64(const u8 *p, size_t len, u64 seed);
 
 #define ZKE_BLOCK 131072u
 #define ZKE_HASH_LOG 14
-#define ZKE_MINMATCH 6
+static u32 g_minmatch = 6;          /* zke_minmatch(level): 6 for level <= 1 (except 0 = default 3), else 5 */
 #define ZKE_WINDOW 65535u          /* 16-bit positions in the hash table */
 
 static int g_tile = 256;            /* parse tile; candidates are looked up ZKE_LSTEP tiles at a time */
@@ -382,7 +382,7 @@ static u32 find_sequences(enc_state *st, const u8 *base, u32 bs, u32 be, u32 fen
                     if (d && d <= p) { o1 = d; l1 = match_len(base + p - o1, base + p, cap); }
                 }
                 if (R && R <= p) l2 = match_len(base + p - R, base + p, cap);
-                if (l1 < ZKE_MINMATCH) l1 = 0;
+                if (l1 < g_minmatch) l1 = 0;
                 if (l2 < 4) l2 = 0;
                 if (l2 && l2 >= l1) { blen[t][p - ts] = l2; boff[t][p - ts] = R; }
                 else { blen[t][p - ts] = l1; boff[t][p - ts] = o1; }
@@ -443,7 +443,7 @@ i64 zko_frame_encode(const u8 *src, size_t n, u8 *dst, size_t cap, int level, in
  * a 128 KiB window, which covers every offset this matcher can produce. */
 i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int level, int checksum, const u8 *prefix, size_t plen)
 {
-    (void)level;
+    g_minmatch = (level == 0 || level >= 2) ? 5 : 6;
     if (!prefix) plen = 0;
     const u32 hist = (u32)(plen < ZKE_WINDOW ? plen : ZKE_WINDOW);
     if (n > 0x40000000u) return -72;

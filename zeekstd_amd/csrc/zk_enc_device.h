@@ -7,7 +7,10 @@
 
 constexpr uint32_t ZKE_BLOCK = 131072;
 constexpr uint32_t ZKE_HASH_LOG = 14;
-constexpr uint32_t ZKE_MINMATCH = 6;
+// ZSTD_c_compressionLevel (encode.rs:170, 281-282) maps to the shortest match the parser takes from the hash table:
+// level 1 and below (the "fast" end, what BASELINE.json's configs use) 6 bytes -- fewer, longer sequences; level 2 and up,
+// and 0 = libzstd's default 3 (cli/src/args.rs:192), 5 bytes: 2.468 instead of 2.443 on the 8d text for ~3 % more sequences.
+ZK_HD uint32_t zke_minmatch(int level) { return level == 0 || level >= 2 ? 5u : 6u; }
 constexpr uint32_t ZKE_WINDOW = 65535;
 constexpr uint32_t ZKE_TILE = 256;                // parse tile: matches never cross its end
 constexpr uint32_t ZKE_LSTEP = 2;                 // tiles per lookup step (one position per lane: 512 lanes)
@@ -38,6 +41,8 @@ struct ZkEncFrame {
     uint32_t window_log;
     uint32_t hist;              // bytes of history laid out before the frame in the matcher's source (prefix tail; 0 = none)
     uint64_t m_off;             // where that history starts in the matcher's source (== src_off when hist == 0)
+    uint32_t minmatch;          // zke_minmatch(level)
+    uint32_t pad;
 };
 
 struct ZkEncBlock {

@@ -247,7 +247,7 @@ const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
                         uint32_t l1 = LF[st] & 0x7FF, l2 = LF[st] >> 11;
                         if (l1 & 0x400) l1 = s_qres[l1 & 0x3FF];
                         if (l2 & 0x400) l2 = s_qres[l2 & 0x3FF];
-                        if (l1 < ZKE_MINMATCH) l1 = 0;
+                        if (l1 < fr.minmatch) l1 = 0;
                         if (l2 < 4) l2 = 0;
                         best[2 * st + sub][p - ts] = (l2 && l2 >= l1) ? (l2 | (R << 8)) : (l1 | (O1[st] << 8));
                     }

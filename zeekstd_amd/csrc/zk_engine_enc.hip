@@ -107,6 +107,7 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         fr.block_base = bcount;
         fr.hist = fr.d_size ? hist : 0;
         fr.m_off = hist ? (uint64_t)f * ((uint64_t)hist + frame_size) : fr.src_off;
+        fr.minmatch = zke_minmatch(a.level); fr.pad = 0;
         for (uint32_t b = 0; b < fr.n_blocks; b++) {
             ZkEncBlock &k = blocks[bcount++];
             memset(&k, 0, sizeof k);
