@@ -1015,12 +1015,15 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     // blocks of ~10 k sequences: 4.13 ms; 56-block workgroups 4.41; one lane per block 4.57).  Beyond that, 56 blocks
     // per CU on four waves (32768 blocks: 20.6 ms with one lane per block, 13.2 with quads).
     // own_kernel: zk_engine_set_fse_kernel (1 = the lane-per-block kernel, 2 = quads in the large layout).
-    if (!n_own_tables) return;
+    if (!n_own_tables) return;              // no block defines a table: everything was shared (predefined)
     if (own_kernel == 1) { hipLaunchKernelGGL((zk_k_fse<ZkCells16, 56, 8>), dim3((nblocks + 55) / 56), dim3(512), 0, st, comp, blocks, nblocks, seqs); return; }
+    // (every block the shared-table kernel has not marked done is taken, predefined tables or not.  n_own_tables counts the
+    // DEFINING blocks: an archive of this engine's encoder has one per frame, its blocks were all shared, and the pass that
+    // finds nothing left must not wait for a whole CU's LDS -- the small layout fits beside whatever else is resident)
     if (own_kernel != 2 && n_own_tables <= 48u * 256u)
-        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 16, 1>), dim3((nblocks + 15) / 16), dim3(128), 0, st, comp, blocks, nblocks, seqs, 0u);
+        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 16, 1>), dim3((nblocks + 15) / 16), dim3(128), 0, st, comp, blocks, nblocks, seqs, 1u);
     else
-        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 4>), dim3((nblocks + 55) / 56), dim3(320), 0, st, comp, blocks, nblocks, seqs, 0u);
+        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 4>), dim3((nblocks + 55) / 56), dim3(320), 0, st, comp, blocks, nblocks, seqs, 1u);
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeqP *seqs,

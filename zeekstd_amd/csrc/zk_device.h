@@ -51,7 +51,8 @@ struct ZkFrameInfo {            // written by the frame walker, one per frame
     uint32_t checksum_flag;
     uint32_t checksum;          // stored Content_Checksum (valid if flag)
     uint32_t window;            // clamped to 2^31
-    uint32_t n_own_tables;      // blocks whose sequences use tables of their own (not all-predefined): need zk_k_fse
+    uint32_t n_own_tables;      // blocks that DEFINE a sequence table (FSE_Compressed / RLE mode): how much zk_k_fse_quad may have to do
+                                // (blocks that only repeat or use predefined tables share them with their neighbours: zk_k_fse_predef)
 };
 
 struct ZkFrameBase {            // exclusive prefix sums over frames
@@ -683,7 +684,7 @@ ZK_HD void zk_walk_frame(const uint8_t *comp, uint64_t c_begin, uint64_t c_end, 
                 uint32_t modes = c[so];
                 if (modes & 3) { fi.status = ZK_E_CORRUPTION; return; }
                 b.seq_modes = (uint8_t)modes; b.seq_off = so;
-                if (modes) fi.n_own_tables++;
+                if ((modes ^ (modes >> 1)) & 0x54) fi.n_own_tables++;     // some table in mode 1 (RLE) or 2 (FSE_Compressed): the two bits of its field differ
                 for (int t = 0; t < 3; t++) {
                     uint32_t m = (modes >> (6 - 2 * t)) & 3;
                     if (m != 3) tab_def[t] = (uint32_t)blk;
