@@ -92,11 +92,9 @@ void zko_enc_ctable(int which, u16 *state, int *dfs, u32 *dnb)
  * says Repeat_Mode -- so the decoder builds them once per frame and its blocks still decode independently.
  * Normalisation (own rule, integer only, the GPU kernel zk_k_enc_fse_build runs the same): floor(count * 2^L / total), at
  * least 1 for a symbol that occurs; the most frequent symbol (lowest index on ties) takes what is missing; a surplus is
- * taken from the largest entries.  Accuracy logs: ZKE_FSE_LOGS.  A table needs >= 2 symbols. */
+ * taken from the largest entries.  Accuracy logs 9 / 8 / 9, or 6 / 6 / 6 for small frames.  A table needs >= 2 symbols. */
 #define ZKE_FSE_MIN_SEQ 256u        /* frames with fewer sequences keep the predefined tables */
-#ifndef ZKE_FSE_LOGS
-#define ZKE_FSE_LOGS 9, 8, 9         /* accuracy logs LL, OF, ML: the format's maxima (zk_enc_device.h) */
-#endif
+#define ZKE_FSE_SMALL_SEQ 16384u    /* fewer sequences than this in the frame: accuracy logs 6 / 6 / 6 instead of 9 / 8 / 9 (zk_enc_device.h) */
 static int fse_normalize(const u32 *cnt, int nsym, int L, short *norm)
 {
     u64 total = 0; int distinct = 0, maxs = 0;
@@ -204,7 +202,9 @@ static void frame_tables_build(frame_tables *ft, const u32 *hll, const u32 *hof,
     if (nseq_frame < ZKE_FSE_MIN_SEQ) return;
     short norm[64];
     const u32 *h[3] = {hll, hof, hml};
-    const int nsym[3] = {36, 32, 53}, L[3] = {ZKE_FSE_LOGS};
+    const int nsym[3] = {36, 32, 53};
+    const int small = nseq_frame < ZKE_FSE_SMALL_SEQ;
+    const int L[3] = {small ? 6 : 9, small ? 6 : 8, small ? 6 : 9};
     fse_ctable *ct[3] = {&ft->ll, &ft->of, &ft->ml};
     for (int t = 0; t < 3; t++) {
         if (!fse_normalize(h[t], nsym[t], L[t], norm)) continue;

@@ -64,13 +64,14 @@ struct ZkEncBlock {
 // FRAME: the first compressed block with sequences carries the descriptions (FSE_Compressed_Mode), the later ones say
 // Repeat_Mode, so a decoder builds them once per frame and still decodes the frame's blocks independently.
 constexpr uint32_t ZKE_FSE_MIN_SEQ = 256;       // frames with fewer sequences keep the predefined tables
-#ifndef ZKE_FSE_LOGS
-#define ZKE_FSE_LOGS 9, 8, 9
-#endif
-// accuracy logs LL, OF, ML of a frame's own tables: the format's maxima.  (7 / 7 / 7 would cost 0.55 % of ratio -- 2.430 vs
-// 2.443 on the 8d text -- and measured no faster in the decoder: zk_k_fse_predef_fed 3.5 ms either way.)
-constexpr int ZKE_FSE_LOG[3] = {ZKE_FSE_LOGS};
 constexpr uint32_t ZKE_DESC_CAP = 80;           // bytes of one table description (53 symbols x <= 10 bits + repeats)
+// Accuracy logs LL, OF, ML of a frame's own tables: the format's maxima (9 / 8 / 9) for frames with many sequences -- 7 / 7 / 7
+// would cost 0.55 % of ratio (2.430 vs 2.443 on the 8d text) and measured no faster in the batch decoder -- and 6 / 6 / 6 for
+// frames with fewer than ZKE_FSE_SMALL_SEQ sequences (frames up to ~190 KiB): a seek into such a frame waits for one serial
+// table build per block, 512-cell tables made that 235 us at the idle clock (single seek 397 -> 633 us), 64-cell tables cost
+// what the predefined ones cost; on 64 KiB frames 2.225 instead of 2.236.
+constexpr uint32_t ZKE_FSE_SMALL_SEQ = 16384;
+ZK_HD int zke_fse_log(int t, uint32_t nseq_frame) { return nseq_frame < ZKE_FSE_SMALL_SEQ ? 6 : t == 1 ? 8 : 9; }
 struct ZkEncTables {
     uint16_t ll_state[512], of_state[256], ml_state[512];
     uint32_t ll_dfs[36], of_dfs[32], ml_dfs[56];

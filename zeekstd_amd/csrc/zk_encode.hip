@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void zk_k_enc_fse_build(const ZkEncFrame *fram
     __syncthreads();
     if (tid < 3 && s_nseq >= min_seq) {
         const int t = (int)tid;
-        const int nsym = t == 0 ? 36 : t == 1 ? 32 : 53, L = ZKE_FSE_LOG[t];
+        const int nsym = t == 0 ? 36 : t == 1 ? 32 : 53, L = zke_fse_log(t, s_nseq);
         if (zke_fse_normalize(h[t], nsym, L, norm[t])) {
             int last = nsym;
             while (last > 0 && norm[t][last - 1] == 0) last--;
