@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../zeekstd_amd/csrc"
 make -j8 >/dev/null
 for spec in "$@"; do
   tag=${spec%%:*}; flags=${spec#*:}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $flags -c zk_decode.hip -o build/zk_decode_$tag.o
-  objs=$(ls build/*.o | grep -v "zk_decode" | tr '\n' ' ')
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -Wl,--as-needed -pthread -o ../libzk_$tag.so build/zk_decode_$tag.o $objs
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $flags -c zk_decode.hip -o build/var_$tag.o
+  objs=$(ls build/*.o | grep -v "zk_decode" | grep -v "/var_" | tr '\n' ' ')
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -Wl,--as-needed -pthread -ldl -o ../libzk_$tag.so build/var_$tag.o $objs
 done

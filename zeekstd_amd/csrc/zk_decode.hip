@@ -592,6 +592,18 @@ __global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const u
 //   5. a workgroup barrier orders the tiles.
 constexpr int ZK_EXEC_B = (int)ZK_EXEC_SLOT;
 
+#ifdef ZK_EXEC_CLOCKS
+// experiments: shader-clock totals per phase of the tile loop, summed over lane 0 of every workgroup (tools/exec_clocks.py)
+__device__ unsigned long long zk_dbg_clk[8];
+extern "C" void zk_debug_clocks(unsigned long long *out, int reset)
+{
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zk_dbg_clk), z, sizeof z); }
+    else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(zk_dbg_clk), 8 * sizeof(unsigned long long));
+}
+#define ZK_CLK(i) do { const unsigned long long now_ = clock64(); clk_[i] += now_ - t_; t_ = now_; } while (0)
+#else
+#define ZK_CLK(i) do { } while (0)
+#endif
 template <int T, bool PFX>
 __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
                                                const uint32_t *ids, const uint64_t *out_off,
@@ -623,6 +635,9 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
     uint64_t pos = 0;
     uint32_t rep[3] = {1, 4, 8};
     uint32_t err = ZK_OK;
+#ifdef ZK_EXEC_CLOCKS
+    unsigned long long clk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_ = clock64();
+#endif
 
     for (uint32_t bk = 0; bk < fi.n_blocks && err == ZK_OK; bk++) {
         const ZkBlock &b = fb[bk];
@@ -666,6 +681,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
             for (uint32_t idx = tid; idx < staged_end; idx += T) { ZkSeqP p0, p1; fetch(idx, p0, p1); settle(idx, p0, p1, bad); }
             if (tid == 0) { s_jn = staged_end; s_nlong = 0; }        // s_jn starts at "every staged sequence ends inside the tile"
             if (__syncthreads_or(bad)) { err = ZK_E_CORRUPTION; }
+            ZK_CLK(0);
             while (err == ZK_OK && ts < out_size) {
                 const uint32_t nl = staged_end - ja;
                 const uint32_t cap_end = S[(staged_end - 1) & M].out_end;
@@ -684,7 +700,9 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                     }
                     if (end > te && start <= te) s_jn = i;
                 }
+                ZK_CLK(1);
                 __syncthreads();
+                ZK_CLK(2);
                 const uint32_t nlong = s_nlong, jn = s_jn;
                 // the records that take the retired slots: requested now, needed two barriers from here
                 const uint32_t fetch_end = staged_end + jn < nseq + 1 ? staged_end + jn : nseq + 1;
@@ -716,7 +734,9 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                     for (int k = 0; k < ZK_EXEC_B; k += 4)
                         *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(sw[k], sw[k + 1], sw[k + 2], sw[k + 3]);
                 }
+                ZK_CLK(3);
                 __syncthreads();
+                ZK_CLK(2);
                 if (tid == 0) { s_jn = fetch_end - (ja + jn); s_nlong = 0; }      // the next tile's marking pass starts from these (every lane has read this tile's)
                 // the slot pass is done with the retired records: the fetched ones move in
 #pragma unroll
@@ -736,6 +756,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                             if (d < span) { sw[k] = srcmap[d]; again = true; }
                         }
                     } while (again);
+                    ZK_CLK(4);
                     uint32_t ob[ZK_EXEC_B];
 #pragma unroll
                     for (int k = 0; k < ZK_EXEC_B; k++) {
@@ -763,8 +784,10 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                 }
                 prev_end = next_prev_end;
                 ja += jn; staged_end = fetch_end; ts = te;
+                ZK_CLK(5);
                 // tile bytes visible to the next tile, the ring complete, the map free again
                 if (__syncthreads_or(bad)) { err = ZK_E_CORRUPTION; break; }
+                ZK_CLK(2);
             }
             if (err == ZK_OK) {
                 uint32_t r0 = zk_rep_resolve(b.rep_out[0], rep), r1 = zk_rep_resolve(b.rep_out[1], rep), r2 = zk_rep_resolve(b.rep_out[2], rep);
@@ -776,6 +799,10 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
     }
     if (err == ZK_OK && pos != d_size) err = ZK_E_CORRUPTION;
     if (tid == 0 && err != ZK_OK) infos[f].status = err;
+#ifdef ZK_EXEC_CLOCKS
+    ZK_CLK(0);
+    if ((tid & 63) == 0) for (int i = 0; i < 8; i++) atomicAdd(&zk_dbg_clk[i], clk_[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ XXH64
