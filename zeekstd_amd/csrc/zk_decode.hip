@@ -644,12 +644,27 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
         if (b.status != ZK_OK) { err = b.status; break; }
         if (pos + b.out_size > d_size) { err = ZK_E_CORRUPTION; break; }
         uint8_t *bout = out + pos;
-        if (b.type == 0) {
+        if (b.type <= 1) {
+            // raw / RLE block: bytes up to the first 16-byte boundary of the output, 16-byte stores (the source of a raw
+            // block is read with whatever alignment it has), bytes behind the last boundary
             const uint8_t *s = comp + b.src;
-            for (uint32_t i = tid; i < b.bsize; i += T) bout[i] = s[i];
-        } else if (b.type == 1) {
-            const uint8_t v = comp[b.src];
-            for (uint32_t i = tid; i < b.bsize; i += T) bout[i] = v;
+            const uint32_t n = b.bsize;
+            const uint32_t head0 = (uint32_t)((0 - (uintptr_t)bout) & 15), head = head0 < n ? head0 : n;
+            const uint32_t n16 = (n - head) >> 4;
+            if (b.type == 0) {
+                if (tid < head) bout[tid] = s[tid];
+                for (uint32_t i = tid; i < n16; i += T) {
+                    uint4 v;
+                    __builtin_memcpy(&v, s + head + (i << 4), 16);
+                    *reinterpret_cast<uint4 *>(bout + head + (i << 4)) = v;
+                }
+                for (uint32_t i = head + (n16 << 4) + tid; i < n; i += T) bout[i] = s[i];
+            } else {
+                const uint32_t v1 = s[0], v4 = v1 * 0x01010101u;
+                if (tid < head) bout[tid] = (uint8_t)v1;
+                for (uint32_t i = tid; i < n16; i += T) *reinterpret_cast<uint4 *>(bout + head + (i << 4)) = make_uint4(v4, v4, v4, v4);
+                for (uint32_t i = head + (n16 << 4) + tid; i < n; i += T) bout[i] = (uint8_t)v1;
+            }
         } else {
             const ZkSeqP *sq = seqs + b.seq_base;
             const uint8_t *lit = b.lit_type >= 2 ? lit_scratch + b.lit_base : comp + b.src + b.lit_off;

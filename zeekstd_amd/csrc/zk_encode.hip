@@ -158,7 +158,18 @@ const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
                     O1[st] = o1;
                     C1[st] = fend >= 8 ? zk_ld64(base + pc - o1) : 0;                    // o1 == 0: the lane's own bytes again (unused)
                     zke_lds_barrier();
-                    if (hsh != 0xFFFFFFFFu) zke_table_insert(table, hsh, p, (ls + 1) & 0xFFFFu, le - ls);     // the largest position of the step wins a slot
+                    // the largest position of the step wins a slot.  A lane that sees its own hash 1, 2, 3, 4, 6 or 8 lanes up
+                    // cannot win and stays out of the race: on a run of equal bytes (or a period of 2, 3, 4, 6, 8 bytes:
+                    // samples, pixels, words) all 512 lanes of a step would otherwise fight over a few LDS words, ~7 rounds
+                    // of serialised compare-and-swaps each (zero-filled input ran at 4 GiB/s).  The table ends the step in
+                    // the same state, so the output bytes do not change.
+                    // (row_shl:d inside the rows of 16 lanes -- one vector instruction per distance; the last lanes of a row see
+                    // no neighbour and race as before, a few dozen per step instead of 512.)
+                    bool ins = hsh != 0xFFFFFFFFu;
+#define ZKE_DOMINATED(D) if ((uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)hsh, 0x100 + (D), 0xF, 0xF, false) == hsh) ins = false;
+                    ZKE_DOMINATED(1) ZKE_DOMINATED(2) ZKE_DOMINATED(3) ZKE_DOMINATED(4) ZKE_DOMINATED(6) ZKE_DOMINATED(8)
+#undef ZKE_DOMINATED
+                    if (ins) zke_table_insert(table, hsh, p, (ls + 1) & 0xFFFFu, le - ls);
                     zke_lds_barrier();
                 }
             }
