@@ -187,6 +187,23 @@ def test_baseline_config_2_decode_only(engine):
     assert int(h[0]) == 0xAD0311EAAD1ED582 and int(h[1]) == 0x8CC2C9BC11FFCCA2
 
 
+@pytest.mark.parametrize("fs", [65536, 300000, 1 << 20])
+def test_frames_of_fewer_than_64_blocks_share_their_tables(engine, fs):
+    """More than 4096 blocks (past the small-batch path) in frames of 16 / 19 / 32 blocks: the 64 blocks of a sequence-kernel
+    workgroup span several frames, i.e. several sets of per-frame tables (zk_k_fse_sets), at every alignment (300 000-byte
+    frames: 19 blocks).  Bit-exact against the generator bytes; the frames also carry checksums."""
+    n = 136 << 20 if fs >= (1 << 20) else 72 << 20
+    data = zko.gen_chunks(n)
+    comp, frames = engine.encode_frames(data, fs, 1, True)
+    c, d = offsets_from_frames(frames)
+    out, st = engine.decode_frames(comp + b"\0" * 8, c, d, verify=True)
+    assert not st.any() and out == data
+    k = len(frames) // 2                                                   # one frame of the middle against the CPU oracle
+    f = comp[int(c[k]):int(c[k + 1])]
+    o, used = zko.frame_decode(f, int(d[k + 1] - d[k]), True)
+    assert used == len(f) and o == data[int(d[k]):int(d[k + 1])]
+
+
 def test_random_access_batch(engine):
     """zk_decode_frame_list_dev: many seeks per submission against a device-resident archive (BASELINE configs[3] shape)."""
     import torch

@@ -579,6 +579,94 @@ __global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const u
     }
 }
 
+// Several table sets per workgroup.  The kernels above serve ONE set per 64 consecutive blocks, which is a whole frame only
+// when a frame has >= 64 blocks (2 MiB at this encoder's 32 KiB blocks): with 1 MiB frames half of every workgroup's
+// blocks, with 64 KiB frames (16 blocks of 4 KiB) three quarters, fell through to the per-block kernel (1 GiB of 1 MiB
+// frames: 6.3 ms instead of 2.2).  Here up to ZK_FSEP_SETS sets live side by side in LDS -- set s is built by lanes
+// 16 s .. 16 s + 15 while the others build theirs -- and a lane walks with the tables of its own set (the table base is a
+// lane value either way: same instructions in the walk).
+constexpr int ZK_FSEP_SETS = 4;
+struct ZkFsePickSets { uint32_t k0, k1, k2; int32_t set; uint32_t nsets; };
+__device__ __forceinline__ ZkFsePickSets zk_fse_share_pick_sets(uint32_t nblocks, uint32_t bi, const ZkBlock &b)
+{
+    ZkFsePickSets p;
+    bool cand = bi < nblocks;
+    p.k0 = p.k1 = p.k2 = 0; p.set = -1; p.nsets = 0;
+    if (cand) {
+        cand = b.type == 2 && b.nseq != 0 && b.status == ZK_OK && b.pad == 0;
+        const uint32_t m0 = (b.seq_modes >> 6) & 3, m1 = (b.seq_modes >> 4) & 3, m2 = (b.seq_modes >> 2) & 3;
+        if (m0 == 1 || m1 == 1 || m2 == 1) cand = false;                 // RLE_Mode tables are per block: zk_k_fse_quad
+        p.k0 = m0 == 0 ? ZK_KEY_PREDEF : m0 == 2 ? bi : b.tab_def[0];
+        p.k1 = m1 == 0 ? ZK_KEY_PREDEF : m1 == 2 ? bi : b.tab_def[1];
+        p.k2 = m2 == 0 ? ZK_KEY_PREDEF : m2 == 2 ? bi : b.tab_def[2];
+    }
+    uint64_t rem = __ballot(cand);                          // lanes not yet assigned to a set (or found to have too few partners)
+    for (int it = 0; it < 2 * ZK_FSEP_SETS && rem && p.nsets < (uint32_t)ZK_FSEP_SETS; it++) {
+        const int ref = __builtin_ctzll(rem);
+        const uint32_t r0 = __shfl(p.k0, ref, 64), r1 = __shfl(p.k1, ref, 64), r2 = __shfl(p.k2, ref, 64);
+        const bool m = cand && p.k0 == r0 && p.k1 == r1 && p.k2 == r2;
+        const uint64_t mm = __ballot(m);
+        const bool predef = r0 == ZK_KEY_PREDEF && r1 == ZK_KEY_PREDEF && r2 == ZK_KEY_PREDEF;
+        if (predef || (uint32_t)__popcll(mm) >= ZK_FSEP_MIN_SHARE) { if (m) p.set = (int32_t)p.nsets; p.nsets++; }
+        rem &= ~mm;
+    }
+    return p;
+}
+__global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_sets(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeqP *seqs)
+{
+    __shared__ ZkSeqTables T[ZK_FSEP_SETS];                // read-only after the build
+    __shared__ __attribute__((aligned(16))) ZkSeqP ring[ZK_FSEP_LANES][ZK_FSEP_RING];
+    __shared__ ZkCoopFlush coop;
+    __shared__ ZkFseShare share[ZK_FSEP_SETS];
+    __shared__ uint32_t llv[36], mlv[53];
+    const uint32_t tid = threadIdx.x;
+    {
+        const uint32_t ll_init[36] = ZK_LL_TABLE;
+        const uint32_t ml_init[53] = ZK_ML_TABLE;
+        if (tid < 36) llv[tid] = ll_init[tid];
+        if (tid < 53) mlv[tid] = ml_init[tid];
+        if (tid < (uint32_t)ZK_FSEP_SETS) share[tid].ok = 0;
+        if (tid == 0) { coop.ring = &ring[0][0]; coop.seqs = seqs; coop.nloop = 0; }
+    }
+    __syncthreads();
+    const uint32_t bi = blockIdx.x * ZK_FSEP_LANES + tid;
+    ZkBlock b;
+    if (bi < nblocks) b = blocks[bi];
+    const ZkFsePickSets pk = zk_fse_share_pick_sets(nblocks, bi, b);
+    if (!pk.nsets) return;                                  // nothing shared here (wave-uniform)
+    for (int s = 0; s < ZK_FSEP_SETS; s++) {
+        const uint64_t mm = __ballot(pk.set == s);
+        if (!mm) continue;
+        const int ref = __builtin_ctzll(mm);
+        ZkFsePick one;
+        one.k0 = one.k1 = one.k2 = 0; one.match = false; one.go = true;
+        one.r0 = __shfl(pk.k0, ref, 64); one.r1 = __shfl(pk.k1, ref, 64); one.r2 = __shfl(pk.k2, ref, 64);
+        if ((int)(tid >> 4) == s) zk_fse_share_build<ZkCells32>(comp, blocks, one, &T[s], &share[s], llv, mlv);
+    }
+    __syncthreads();
+    const uint32_t ms = pk.set < 0 ? 0u : (uint32_t)pk.set;
+    const bool active = pk.set >= 0 && share[ms].ok;       // a damaged description: zk_k_fse_quad reports it block by block
+    coop.base[tid] = active ? b.seq_base : 0;
+    coop.nseq[tid] = active ? b.nseq : 0;
+    if (active) atomicMax(&coop.nloop, b.nseq);
+    if (!__syncthreads_or(active)) return;
+    uint32_t bs_off = 0;
+    if (active) {
+        bs_off = b.seq_off + 1;
+        if (pk.k0 == bi) bs_off += (uint32_t)share[ms].own[0];
+        if (pk.k1 == bi) bs_off += (uint32_t)share[ms].own[1];
+        if (pk.k2 == bi) bs_off += (uint32_t)share[ms].own[2];
+    }
+    // every lane of the wave runs the walk in lock step (inactive ones only help storing the others' records)
+    zk_seq_walk<ZK_FSEP_RING, ZkRevU>(comp, b, bs_off, T[ms].ll, T[ms].of, T[ms].ml, share[ms].al, ring[tid], seqs, llv, mlv, true, &coop, active, tid);
+    if (!active) return;
+    ZkBlock *o = &blocks[bi];
+    o->out_size = b.out_size;
+    o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
+    o->status = b.status;
+    o->pad = 1;                                            // done: zk_k_fse_quad skips it
+}
+
 // ------------------------------------------------------------------------------------------------ sequence execution
 // One workgroup (T lanes) per frame.  The output of a compressed block is produced in tiles of T x 16 B.  Per tile:
 //   1. the sequences overlapping the tile are staged in LDS (16 B records, offsets resolved, validated);
@@ -1035,7 +1123,7 @@ void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     if (!nblocks) return;
     hipLaunchKernelGGL(zk_k_huf, dim3((nblocks + ZK_HUF_BLOCKS - 1) / ZK_HUF_BLOCKS), dim3(128), 0, st, comp, blocks, nblocks, lit);
 }
-void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeqP *seqs, int own_kernel)
+void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeqP *seqs, int own_kernel, uint32_t frames)
 {
     if (!nblocks) return;
     // reader choice (zk_device.h): with >= 6 workgroups per CU the memory pipeline is the limit (aligned words, each
@@ -1049,7 +1137,11 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
         return;
     }
     // blocks that share their tables with their neighbours (predefined, or one set per frame): one lane each
-    if (wgs >= 6 * 256) hipLaunchKernelGGL(zk_k_fse_predef_fed, dim3(wgs), dim3(2 * ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
+    // frames of fewer than 64 blocks: a workgroup's 64 blocks span several frames = several table sets
+    static const int sets_env = getenv("ZK_FSE_SETS") ? atoi(getenv("ZK_FSE_SETS")) : -1;      // experiments: 0 never, 1 always
+    const bool small_frames = sets_env >= 0 ? sets_env != 0 : (frames && (uint64_t)nblocks < 64ull * frames);
+    if (small_frames) hipLaunchKernelGGL(zk_k_fse_sets, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
+    else if (wgs >= 6 * 256) hipLaunchKernelGGL(zk_k_fse_predef_fed, dim3(wgs), dim3(2 * ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
     else hipLaunchKernelGGL(zk_k_fse_predef<ZkRevU>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
     // blocks with their own tables (every block is visited, the others return at once): a quad of lanes per block.
     // While everything fits in one round, small workgroups (16 blocks, one walking wave + the toucher: 45 KiB of LDS,

@@ -235,7 +235,7 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
     // with per-kernel timing on they are serialised instead
     if (e->profiling || a.single_queue) {
         { zk_kernel_timer t(e, ZK_K_HUF, st); zk_launch_huf(st, comp, blocks, (uint32_t)nblocks, lit); }
-        { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->fse_kernel); }
+        { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->fse_kernel, count); }
     } else {
         if ((rc = zk_dec_ctx_aux(e, c.slot))) return rc;
         zk_engine::DecCtx &x = e->dctx[c.slot];
@@ -243,7 +243,7 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
         ZK_HIP(hipStreamWaitEvent(x.aux, x.ev_fork, 0));
         zk_launch_huf(x.aux, comp, blocks, (uint32_t)nblocks, lit);
         ZK_HIP(hipEventRecord(x.ev_join, x.aux));
-        zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->fse_kernel);
+        zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->fse_kernel, count);
         ZK_HIP(hipStreamWaitEvent(st, x.ev_join, 0));
     }
     { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, a.ids, a.out_off, blocks, bases, infos, seqs, lit, (uint8_t *)a.d_dst, (const uint8_t *)a.d_prefix, a.d_prefix ? a.prefix_len : 0); }
