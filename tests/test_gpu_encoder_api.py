@@ -283,3 +283,51 @@ def test_compressed_frame_size_policy_roundtrip(engine, n):
     total = enc.finish()
     assert total == len(sink.getvalue())
     assert Decoder(DecodeOptions(sink.getvalue()).engine(engine)).read_to_end() == INPUT
+
+
+def _compressed_policy_check(engine, data, n, writes):
+    """Encoder<W> under Compressed(n): every frame but the last ends inside upstream's window n <= c_size < n + 131 591
+    (encode.rs:341-347, 537-544: the size is compared after every call, a call emits at most the 131 591-byte buffer)."""
+    sink = io.BytesIO()
+    enc = EncodeOptions().engine(engine).frame_size_policy(FrameSizePolicy.Compressed(n)).checksum_flag(True).into_encoder(sink)
+    for piece in writes(data):
+        enc.write_all(piece)
+    total = enc.finish()
+    blob = sink.getvalue()
+    assert total == len(blob)
+    dec = Decoder(DecodeOptions(blob).engine(engine))
+    st = dec.seek_table()
+    assert st.size_decomp() == len(data)
+    sizes = [st.frame_size_comp(i) for i in range(st.num_frames())]
+    assert all(n <= c < n + 131591 for c in sizes[:-1]), (n, sizes[:8])
+    assert dec.read_to_end() == bytes(data)
+    return sizes
+
+
+def test_compressed_policy_one_large_write(engine):
+    # a single 96 MiB write must not become a single frame: ~90 frames of ~1 MiB compressed, cut and encoded in batches
+    data = zko.gen_chunks(96 << 20)
+    sizes = _compressed_policy_check(engine, data, 1 << 20, lambda d: [d])
+    assert 30 < len(sizes) < 50
+
+
+def test_compressed_policy_streamed_in_small_writes(engine):
+    data = zko.gen_chunks(40 << 20)
+    sizes = _compressed_policy_check(engine, data, 256 << 10, lambda d: (d[i:i + 8192] for i in range(0, len(d), 8192)))
+    assert len(sizes) > 40
+
+
+def test_compressed_policy_when_the_ratio_jumps(engine):
+    # text, random bytes, zeros, text: the predicted frame ends are wrong at every change and are cut again (or left to the
+    # exact path); zero-filled stretches never reach n and end with the stream
+    rng = np.random.default_rng(5)
+    text = zko.gen_chunks(24 << 20)
+    data = text[:12 << 20] + rng.integers(0, 256, 6 << 20, dtype=np.uint8).tobytes() + bytes(3 << 20) + text[12 << 20:]
+    _compressed_policy_check(engine, data, 512 << 10, lambda d: [d[:20 << 20], d[20 << 20:]])
+
+
+def test_compressed_policy_short_stream_exact_path(engine):
+    # too little input for a batch: the frame-by-frame path alone, same window
+    data = zko.gen_chunks(5 << 20)
+    sizes = _compressed_policy_check(engine, data, 300_000, lambda d: [d])
+    assert len(sizes) >= 5

@@ -38,7 +38,7 @@ RawEncoder::RawEncoder(RawEncoder &&o) noexcept
     : engine_(o.engine_), owns_engine_(o.owns_engine_), policy_(o.policy_), checksum_(o.checksum_), level_(o.level_),
       frame_c_size_(o.frame_c_size_), frame_d_size_(o.frame_d_size_), seek_table_(std::move(o.seek_table_)),
       frame_in_(std::move(o.frame_in_)), pending_(std::move(o.pending_)), pending_pos_(o.pending_pos_), encoded_(o.encoded_),
-      next_probe_(o.next_probe_), frame_prefix_(o.frame_prefix_), frame_prefix_len_(o.frame_prefix_len_)
+      next_probe_(o.next_probe_), ratio_(o.ratio_), frame_prefix_(o.frame_prefix_), frame_prefix_len_(o.frame_prefix_len_)
 {
     o.engine_ = nullptr; o.owns_engine_ = false;
 }
@@ -49,9 +49,14 @@ size_t RawEncoder::remaining_frame_size() const                                /
     return std::min(MAX_FRAME_SIZE, policy_.size) - frame_d_size_;
 }
 
-// Compressed(n): upstream compares n with the bytes libzstd has emitted so far for the frame.  A frame is
-// encoded whole here, so the compressed size of the frame-so-far is obtained by encoding it speculatively
-// (at most once per 12.5 % of growth); the encoding is kept when it reaches n, otherwise dropped.
+// Compressed(n): upstream compares n with the bytes libzstd has emitted so far for the frame, after every call, and a call
+// emits at most the caller's output buffer (encode.rs:341-347): its frames end with n <= c_size < n + out.len() (131 591
+// for Encoder<W>).  A frame is encoded whole here, so (1) a call takes no more input than the caller's output buffer could
+// hold, capped at 131 591 bytes -- a larger step could not overshoot less than upstream, and one huge write must not become
+// one huge frame -- and (2) the compressed size of the frame-so-far is obtained by encoding it speculatively: first where
+// the last frame's ratio says n will be reached, then as far ahead as the measured ratio says is still short of n (steps of
+// at least 32 KiB, never more than the missing bytes plus the window).  The encoding is kept when it reaches n, otherwise
+// dropped.  Bulk data does not come this way: Encoder cuts and encodes whole batches of frames (speculate_compressed).
 bool RawEncoder::is_frame_complete() const                                     // encode.rs:537-544
 {
     if (policy_.kind == FrameSizePolicy::Kind::Compressed)
@@ -86,16 +91,31 @@ CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t i
         }
         return {0, out_progress};
     }
-    const size_t limit = std::min(in_len, remaining_frame_size());             // encode.rs:329
+    size_t limit = std::min(in_len, remaining_frame_size());                   // encode.rs:329
+    const bool by_output = policy_.kind == FrameSizePolicy::Kind::Compressed;
+    if (by_output) limit = std::min(limit, std::min<size_t>(out_len, 131591));
     // the prefix of the call that starts a frame is the frame's prefix (ref_prefix only if frame_d_size == 0,
     // encode.rs:334-338); like libzstd only the reference is kept until the frame is encoded
     if (frame_d_size_ == 0) { frame_prefix_ = prefix; frame_prefix_len_ = prefix ? prefix_len : 0; }
     frame_in_.insert(frame_in_.end(), in, in + limit);
     frame_d_size_ += (uint32_t)limit;                                          // encode.rs:350
-    if (policy_.kind == FrameSizePolicy::Kind::Compressed && limit && frame_in_.size() >= next_probe_) {
-        encoded_ = false;
-        encode_pending();                                                      // speculative: how large is the frame so far?
-        if (pending_.size() < policy_.size) { encoded_ = false; next_probe_ = frame_in_.size() + frame_in_.size() / 8 + 1; }
+    if (by_output && limit) {
+        const size_t want = policy_.size;
+        // (b more compressed bytes need at least ~b more input bytes: a probe never lies further ahead than that plus the
+        // window, so even input that stops compressing cannot carry the frame past n + 131 591)
+        const size_t slack = 131072 - 4096;
+        if (next_probe_ == 0) next_probe_ = std::max<size_t>(1, std::min<size_t>(ratio_ > 0 ? (size_t)(0.97 * ratio_ * (double)want) : want, want + slack));
+        if (frame_in_.size() >= next_probe_) {
+            encoded_ = false;
+            encode_pending();                                                  // speculative: how large is the frame so far?
+            const size_t c = pending_.size(), d = frame_in_.size();
+            if (c < want) {
+                encoded_ = false;
+                const double r = std::max(1.0, (double)d / (double)std::max<size_t>(c, 1));
+                const size_t by_ratio = std::max<size_t>(32768, (size_t)(0.9 * r * (double)(want - c)));
+                next_probe_ = d + std::min<size_t>(by_ratio, (want - c) + slack);
+            } else ratio_ = (double)d / (double)c;
+        }
     }
     return {limit, 0};
 }
@@ -221,21 +241,98 @@ void Encoder::submit_batch(bool include_partial)
     batch_len_ -= take;
 }
 
+// Compressed(n) on a large write.  Where a frame ends depends on its compressed size, which upstream learns call by call; a
+// GPU learns it by encoding.  So the ends are PREDICTED from the running ratio -- every frame is given the input that should
+// compress to the middle of upstream's window [n, n + 131 591) -- a whole batch of such frames is encoded with one engine
+// call, and the frames are then accepted in order for as long as their compressed size lies inside that window.  The first
+// one that does not corrects the ratio and everything from it on is cut again; a position that fails three times is left to
+// the exact frame-by-frame path (RawEncoder).  Returns the bytes consumed = whole accepted frames; the rest of the write,
+// at least two frames' worth, stays with the caller's loop (the last frame is still open upstream).
+size_t Encoder::speculate_compressed(const uint8_t *buf, size_t len, const uint8_t *prefix, size_t prefix_len)
+{
+    const uint64_t want = raw_.policy_.size, window = out_buf_.size();
+    double ratio = raw_.ratio_ > 0 ? raw_.ratio_ : 2.0;
+    size_t pos = 0;
+    int failures = 0;
+    while (failures < 3) {
+        const uint64_t s64 = (uint64_t)(ratio * (double)(want + window / 2));
+        if (s64 == 0 || s64 >= MAX_FRAME_SIZE) break;                          // one frame per MAX_FRAME_SIZE: the exact path knows that rule
+        const size_t s = (size_t)s64;
+        if (len - pos < 3 * s) break;
+        size_t k = (len - pos) / s - 2;                                        // the tail (two frames' worth or more) is not speculated on
+        if (raw_.ratio_ <= 0 && pos == 0) k = std::min<size_t>(k, 4);          // no ratio yet: a small first batch measures it
+        k = std::min<size_t>(k, 8192);
+        spec_out_.resize((size_t)zk_compress_bound((uint64_t)k * s, (uint32_t)s));
+        spec_c_.resize(k); spec_d_.resize(k);
+        uint32_t nf = 0;
+        uint64_t written = 0;
+        const int rc = zk_encode_frames_prefix(raw_.engine_, buf + pos, (uint64_t)k * s, (uint32_t)s, raw_.level_, raw_.checksum_ ? 1 : 0,
+                                               prefix, prefix ? prefix_len : 0, spec_out_.data(), spec_out_.size(), spec_c_.data(), spec_d_.data(),
+                                               (uint32_t)k, &nf, &written);
+        if (rc != 0) throw Error::from_engine_code(rc, zk_engine_last_hip_error(raw_.engine_));
+        size_t at = 0, good = 0;
+        uint64_t sum_c = 0;
+        while (good < nf && spec_c_[good] >= want && spec_c_[good] < want + window) { sum_c += spec_c_[good]; at += spec_c_[good]; good++; }
+        if (good) {
+            emit(spec_out_.data(), at);
+            for (size_t i = 0; i < good; i++) raw_.seek_table_.log_frame(spec_c_[i], spec_d_[i]);
+            pos += good * s;
+            ratio = (double)(good * s) / (double)sum_c;
+            raw_.ratio_ = ratio;
+            failures = 0;
+        }
+        if (good < nf) {                                                       // the frame at pos missed the window: its own ratio cuts it again
+            ratio = (double)s / (double)std::max<uint32_t>(spec_c_[good], 1);
+            failures++;
+        }
+    }
+    return pos;
+}
+
+// Compressed(n): p[0, n) through the policy in order -- batches of predicted frames while no frame is open and plenty of
+// input is left, upstream's own loop (encode.rs:641-665) around the exact path for the rest.  The last frame stays open.
+void Encoder::process_compressed(const uint8_t *p, size_t n, const uint8_t *prefix, size_t prefix_len, bool speculate)
+{
+    size_t done = 0;
+    while (done < n) {
+        if (speculate && raw_.frame_d_size_ == 0 && !raw_.encoded_ && n - done >= (8u << 20)) {
+            const size_t took = speculate_compressed(p + done, n - done, prefix, prefix_len);
+            done += took;
+            if (took) continue;
+        }
+        CompressionProgress q = raw_.compress_with_prefix(p + done, n - done, out_buf_.data() + out_buf_pos_, out_buf_.size() - out_buf_pos_,
+                                                          prefix, prefix_len);
+        out_buf_pos_ += q.out_progress();
+        flush_out_buf(false);
+        done += q.in_progress();
+    }
+}
+
 size_t Encoder::compress_with_prefix(const uint8_t *buf, size_t len, const uint8_t *prefix, size_t prefix_len)   // encode.rs:641-665
 {
     if (!prefix) prefix_len = 0;
-    if (raw_.policy_.kind == FrameSizePolicy::Kind::Compressed) {               // frame ends depend on output: the upstream loop, frame by frame
-        size_t input_progress = 0;
-        while (input_progress < len) {
-            CompressionProgress p = raw_.compress_with_prefix(buf + input_progress, len - input_progress, out_buf_.data() + out_buf_pos_,
-                                                              out_buf_.size() - out_buf_pos_, prefix, prefix_len);
-            if (p.in_progress() == 0 && p.out_progress() == 0) break;
-            out_buf_pos_ += p.out_progress();
-            flush_out_buf(false);
-            input_progress += p.in_progress();
+    if (raw_.policy_.kind == FrameSizePolicy::Kind::Compressed) {               // frame ends depend on output
+        since_end_ += len;
+        const bool same_prefix = prefix == batch_prefix_ && prefix_len == batch_prefix_len_;
+        // (frames of tens of MiB compressed are not worth gathering three of: the exact path takes them as they come)
+        if (raw_.frame_d_size_ || raw_.encoded_ || (batch_len_ && !same_prefix) || raw_.policy_.size > (16u << 20)) {
+            // a frame is open in the exact path, or the prefix changes under gathered bytes (upstream: it takes effect at the
+            // next frame start, encode.rs:334-338): everything goes through in order, nothing is held back
+            const size_t held = batch_len_;
+            if (held) { process_compressed(batch_in_, held, batch_prefix_, batch_prefix_len_, true); batch_len_ = 0; }
+            batch_prefix_ = prefix; batch_prefix_len_ = prefix_len;
+            process_compressed(buf, len, prefix, prefix_len, true);
+            return len;
         }
-        since_end_ += input_progress;
-        return input_progress;
+        batch_prefix_ = prefix; batch_prefix_len_ = prefix_len;
+        size_t took = 0;
+        if (batch_len_ == 0 && len >= (32u << 20)) took = speculate_compressed(buf, len, prefix, prefix_len);     // where it lies
+        batch_append(buf + took, len - took);
+        if (batch_len_ >= (16u << 20)) {
+            const size_t t = speculate_compressed(batch_in_, batch_len_, prefix, prefix_len);
+            if (t) { memmove(batch_in_, batch_in_ + t, batch_len_ - t); batch_len_ -= t; }
+        }
+        return len;
     }
     const uint32_t fs = std::min(MAX_FRAME_SIZE, raw_.policy_.size);
     const size_t total_len = len;
@@ -282,7 +379,8 @@ size_t Encoder::end_frame()                                                    /
     // ending a frame that has received no byte since the last end_frame yields an EMPTY frame, anything
     // else is exactly the frames already cut every frame_size bytes plus the partial tail.
     const uint64_t before = written_compressed_ + out_buf_pos_;
-    if (raw_.policy_.kind == FrameSizePolicy::Kind::Compressed) {               // encode.rs:704-717 verbatim
+    if (raw_.policy_.kind == FrameSizePolicy::Kind::Compressed) {               // encode.rs:704-717 verbatim, after the gathered bytes
+        if (batch_len_) { const size_t held = batch_len_; process_compressed(batch_in_, held, batch_prefix_, batch_prefix_len_, true); batch_len_ = 0; }
         for (;;) {
             EpilogueProgress p = raw_.end_frame(out_buf_.data() + out_buf_pos_, out_buf_.size() - out_buf_pos_);
             out_buf_pos_ += p.out_progress();
@@ -318,7 +416,12 @@ uint64_t Encoder::finish_format(Format format)                                 /
 
 void Encoder::flush()                                                          // io::Write::flush, encode.rs:796-799
 {
-    submit_batch(false);                                                       // complete frames are pushed out
+    if (raw_.policy_.kind == FrameSizePolicy::Kind::Compressed) {
+        if (batch_len_ && !raw_.frame_d_size_ && !raw_.encoded_) {
+            const size_t t = speculate_compressed(batch_in_, batch_len_, batch_prefix_, batch_prefix_len_);
+            if (t) { memmove(batch_in_, batch_in_ + t, batch_len_ - t); batch_len_ -= t; }
+        }
+    } else submit_batch(false);                                                // complete frames are pushed out
     flush_out_buf(true);
     writer_->flush();
 }

@@ -347,6 +347,7 @@ private:
     size_t pending_pos_ = 0;
     bool encoded_ = false;
     size_t next_probe_ = 0;                   // Compressed(n): buffered size at which the next speculative encode happens
+    double ratio_ = 0;                        // Compressed(n): uncompressed / compressed of the last frame closed (0: none yet)
     const uint8_t *frame_prefix_ = nullptr;   // prefix referenced when the frame in progress began (encode.rs:334-338)
     size_t frame_prefix_len_ = 0;
 };
@@ -371,6 +372,8 @@ public:
 
 private:
     void submit_batch(bool include_partial);
+    size_t speculate_compressed(const uint8_t *buf, size_t len, const uint8_t *prefix, size_t prefix_len);
+    void process_compressed(const uint8_t *p, size_t n, const uint8_t *prefix, size_t prefix_len, bool speculate);
     void encode_span(const uint8_t *src, size_t take);
     void batch_append(const uint8_t *p, size_t n);
     static int sink(void *user, const uint8_t *data, uint64_t n, const uint32_t *c_sizes, const uint32_t *d_sizes, uint32_t n_frames);
@@ -389,6 +392,8 @@ private:
     size_t batch_prefix_len_ = 0;
     bool prefix_dirty_ = true;                // the engine's staged copy of the prefix must be refreshed
     std::exception_ptr sink_error_;           // a writer failure inside the engine's sink callback
+    std::vector<uint8_t> spec_out_;           // Compressed(n): the frames of one speculative batch
+    std::vector<uint32_t> spec_c_, spec_d_;
 };
 
 }  // namespace zeekstd
