@@ -140,9 +140,11 @@ int zk_decode_wait(zk_engine *e, int slot);
  * concatenated in dst, and report the seek-table entries: c_sizes[i] / d_sizes[i] are what
  * SeekTable::log_frame receives (seek_table.rs:513-525).  checksum != 0 appends the XXH64 Content_Checksum
  * (ZSTD_c_checksumFlag, encode.rs:283-284).  level is ZSTD_c_compressionLevel (encode.rs:281-282): one strategy
- * (greedy hash matching in a 64 KiB window, Huffman literals, FSE tables measured per frame) with two settings --
- * level <= 1 (negative levels included) takes matches of 6+ bytes, level >= 2 and 0 (= libzstd's default 3) of 5+ bytes
- * (ratio 2.44 / 2.47 on the survey's text).  Replaces the ZSTD_compressStream2 loops of encode.rs:340-346, 442-464.
+ * (greedy hash matching in a 64 KiB window, Huffman literals, FSE tables measured per frame) with three settings --
+ * level <= 1 (negative levels included): matches of 6+ bytes, 2^14 hash-table entries; levels 2..5 and 0 (= libzstd's
+ * default 3): 5+ bytes, 2^15 entries; level >= 6: 2^16 entries (ratio 2.44 / 2.57 / 2.63 on the survey's text at
+ * 50 / 43 / 28 GiB/s; libzstd: 2.49 at level 1, 2.77 at level 3).  Replaces the ZSTD_compressStream2 loops of
+ * encode.rs:340-346, 442-464.
  * dst_cap >= zk_compress_bound(n, frame_size) always suffices; otherwise -70 (dstSize_tooSmall) may come back.
  */
 uint64_t zk_compress_bound(uint64_t n, uint32_t frame_size);

@@ -23,7 +23,8 @@ typedef uint8_t u8; typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t
 u64 zko_xxh64(const u8 *p, size_t len, u64 seed);
 
 #define ZKE_BLOCK 131072u
-#define ZKE_HASH_LOG 14
+#define ZKE_HASH_LOG_MAX 16
+static u32 g_hash_log = 14;         /* zke_hash_log(level): 2^14 table entries at level <= 1, 2^15 at 2..5 and 0 (= default 3), 2^16 from 6 on */
 static u32 g_minmatch = 6;          /* zke_minmatch(level): 6 for level <= 1 (except 0 = default 3), else 5 */
 #define ZKE_WINDOW 65535u          /* 16-bit positions in the hash table */
 
@@ -32,7 +33,7 @@ void zko_enc_set_tile(int t) { g_tile = t; }
 
 static inline u32 hb32(u32 v) { return 31 - (u32)__builtin_clz(v); }
 static inline u64 ld64(const u8 *p) { u64 v; memcpy(&v, p, 8); return v; }
-static inline u32 hash5(const u8 *p) { return (u32)(((ld64(p) << 24) * 889523592379ULL) >> (64 - ZKE_HASH_LOG)); }
+static inline u32 hash5(const u8 *p) { return (u32)(((ld64(p) << 24) * 889523592379ULL) >> (64 - g_hash_log)); }
 
 /* ------------------------------------------------------------------ code tables (RFC 8878 3.1.1.3.2.1.1) */
 static const u8 LL_BITS[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
@@ -341,7 +342,7 @@ static size_t encode_literals(const u8 *lit, size_t n, u8 *dst, size_t cap)
 /* table: the low 16 bits of (position + 1).  A candidate is p - d with d = (p + 1 - entry) mod 2^16: entries older
  * than the 64 KiB window alias to some position inside it (the byte comparison decides, as for any hash collision);
  * d == 0 (incl. the never-written entry 0 at p == 65535 mod 2^16) and candidates before the first byte are no candidates */
-typedef struct { u16 table[1 << ZKE_HASH_LOG]; u32 probe; } enc_state;
+typedef struct { u16 table[1 << ZKE_HASH_LOG_MAX]; u32 probe; } enc_state;
 
 static u32 match_len(const u8 *a, const u8 *b, const u8 *end)        /* b > a */
 {
@@ -444,6 +445,7 @@ i64 zko_frame_encode(const u8 *src, size_t n, u8 *dst, size_t cap, int level, in
 i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int level, int checksum, const u8 *prefix, size_t plen)
 {
     g_minmatch = (level == 0 || level >= 2) ? 5 : 6;
+    g_hash_log = (level == 0 || (level >= 2 && level <= 5)) ? 15 : level >= 6 ? 16 : 14;
     if (!prefix) plen = 0;
     const u32 hist = (u32)(plen < ZKE_WINDOW ? plen : ZKE_WINDOW);
     if (n > 0x40000000u) return -72;

@@ -75,11 +75,12 @@ def test_compression_ratio_sanity(engine):
     assert len(frames) == 4 and len(data) / len(comp) > 2.4          # text: libzstd level 1 gets ~2.5; per-frame FSE tables: 2.44
 
 
-@pytest.mark.parametrize("level", [-5, 0, 1, 3, 19])
+@pytest.mark.parametrize("level", [-5, 0, 1, 2, 3, 5, 6, 19])
 def test_levels_are_honoured(engine, level):
-    """EncodeOptions::compression_level (encode.rs:170, 281-282; CLI default 3, cli/src/args.rs:192): level <= 1 parses matches
-    of 6+ bytes, level >= 2 and 0 (= the default 3) of 5+ -- byte-identical to the CPU twin at that level, valid zstd, and the
-    higher setting compresses the survey's text better."""
+    """EncodeOptions::compression_level (encode.rs:170, 281-282; CLI default 3, cli/src/args.rs:192): three settings of one
+    parse -- level <= 1: matches of 6+ bytes, 2^14 table entries; levels 2..5 and 0 (= the default 3): 5+ bytes, 2^15
+    entries; level >= 6: 2^16 entries.  Byte-identical to the CPU twin at that level, valid zstd, and every step up
+    compresses the survey's text better (2.44 / 2.57 / 2.63)."""
     data = zko.gen_chunks(4 << 20, 11)
     comp, frames = engine.encode_frames(data, 2 << 20, level, True)
     check_payload(engine, data, comp, frames, 2 << 20, True)
@@ -87,11 +88,26 @@ def test_levels_are_honoured(engine, level):
     for c, d in frames:
         assert comp[pos:pos + c] == zko.frame_encode(data[dpos:dpos + d], level, True), (level, dpos)
         pos += c; dpos += d
-    ref, _ = engine.encode_frames(data, 2 << 20, 1, True)
-    if level in (0, 3, 19):
-        assert len(comp) < len(ref)
+    low, _ = engine.encode_frames(data, 2 << 20, 1, True)
+    mid, _ = engine.encode_frames(data, 2 << 20, 3, True)
+    if level <= 1 and level != 0:
+        assert comp == low
+    elif level >= 6:
+        assert len(comp) < len(mid) < len(low) and len(data) / len(comp) > 2.6
     else:
-        assert comp == ref
+        assert comp == mid and len(mid) < len(low) and len(data) / len(mid) > 2.54
+
+
+@pytest.mark.parametrize("level", [3, 6])
+@pytest.mark.parametrize("name", ["zeros", "mixed", "binary", "records", "t131073"])
+def test_larger_tables_on_the_other_inputs(engine, name, level):
+    data = zko.make_input(CASES[name])
+    comp, frames = engine.encode_frames(data, 2 << 20, level, True)
+    check_payload(engine, data, comp, frames, 2 << 20, True)
+    pos = dpos = 0
+    for c, d in frames:
+        assert comp[pos:pos + c] == zko.frame_encode(data[dpos:dpos + d], level, True), (name, level, dpos)
+        pos += c; dpos += d
 
 
 def test_frame_tables_are_shared_by_the_frame(engine):

@@ -6,11 +6,14 @@
 #include "zk_device.h"
 
 constexpr uint32_t ZKE_BLOCK = 131072;
-constexpr uint32_t ZKE_HASH_LOG = 14;
+constexpr uint32_t ZKE_HASH_LOG = 14;             // level <= 1; zke_hash_log(level) otherwise
 // ZSTD_c_compressionLevel (encode.rs:170, 281-282) maps to the shortest match the parser takes from the hash table:
 // level 1 and below (the "fast" end, what BASELINE.json's configs use) 6 bytes -- fewer, longer sequences; level 2 and up,
 // and 0 = libzstd's default 3 (cli/src/args.rs:192), 5 bytes: 2.468 instead of 2.443 on the 8d text for ~3 % more sequences.
 ZK_HD uint32_t zke_minmatch(int level) { return level == 0 || level >= 2 ? 5u : 6u; }
+// ... and a larger hash table: the entries of the matcher's table, log2 (zk_k_enc_match: the table is the kernel's LDS, so a
+// level trades workgroups per CU for ratio: 2.57 at 2^15, 2.63 at 2^16 against 2.47 on the 8d text)
+ZK_HD uint32_t zke_hash_log(int level) { return level == 0 || (level >= 2 && level <= 5) ? 15u : level >= 6 ? 16u : 14u; }
 constexpr uint32_t ZKE_WINDOW = 65535;
 constexpr uint32_t ZKE_TILE = 256;                // parse tile: matches never cross its end
 constexpr uint32_t ZKE_LSTEP = 2;                 // tiles per lookup step (one position per lane: 512 lanes)

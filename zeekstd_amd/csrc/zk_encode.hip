@@ -32,8 +32,6 @@
 
 // ------------------------------------------------------------------------------------------------ match + parse
 constexpr int ZKE_THREADS = 512;                         // 8 waves: 8 tiles of a group are parsed side by side
-constexpr uint32_t ZKE_QCAP = 960;                       // matches waiting to be measured; <= 1024 (10-bit queue index)
-static_assert(ZKE_QCAP >= (uint32_t)ZKE_THREADS && ZKE_QCAP <= 1024, "queue");
 
 __device__ __forceinline__ uint32_t zke_match_len(const uint8_t *a, const uint8_t *b, const uint8_t *end)   // b > a
 {
@@ -93,18 +91,34 @@ __device__ __forceinline__ void zke_table_insert(uint32_t *table, uint32_t h, ui
 // buffer that holds, per frame, [last `hist` bytes of the prefix | the frame] (zk_k_enc_stage_hist), all positions
 // below are offsets into that record, and the history's positions enter the hash table before the first block --
 // so a match may start in the prefix and run on into the frame with no special case anywhere.
-__global__ __launch_bounds__(ZKE_THREADS) __attribute__((amdgpu_waves_per_eu(6))) void zk_k_enc_match(       // 52 KiB of LDS: three workgroups = 24 waves per CU need <= 80 VGPRs
+// HLOG: size of the hash table = what a level buys (zke_hash_log: 2^14 entries at level <= 1, 2^15 at levels 2-5 and at 0 =
+// the default, 2^16 from level 6 on; 2.44 / 2.57 / 2.63 on the 8d text at the same parse).  The table is the kernel's LDS:
+//   2^14: 52 KiB -> three workgroups = 24 waves per CU, <= 80 VGPRs (WAVES = 6 per SIMD)
+//   2^15: 76 KiB -> two workgroups per CU (the queue shrinks to 512 entries and shares its memory with the tile
+//         sequences, whose lifetimes do not overlap), <= 128 VGPRs
+//   2^16: 140 KiB -> one workgroup per CU
+template <int HLOG, int WAVES>
+__global__ __launch_bounds__(ZKE_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES))) void zk_k_enc_match(
 const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
                                                               uint64_t *seqs, uint32_t *mpos, uint8_t *lits)
 {
     // 16-bit entries, two per word: the low 16 bits of (position + 1).  A candidate is p - d with d = (p + 1 - entry)
     // mod 2^16: entries older than the 64 KiB window alias to some position inside it and the byte comparison decides,
     // as for any hash collision.  Half the LDS of 32-bit entries: three workgroups per CU instead of two.
+    constexpr uint32_t ZKE_HASH_LOG = (uint32_t)HLOG;
+    constexpr bool SHARE = HLOG > 14;                      // queue and tile sequences in the same LDS bytes
+    constexpr uint32_t ZKE_QCAP = SHARE ? 512u : 960u;     // matches waiting to be measured; <= 1024 (10-bit queue index)
+    static_assert(ZKE_QCAP >= (uint32_t)ZKE_THREADS && ZKE_QCAP <= 1024, "queue");
+    constexpr uint32_t TSEQ_N = ZKE_TILE / 4 + 4;
     __shared__ uint32_t table[1 << (ZKE_HASH_LOG - 1)];
     __shared__ uint32_t best[ZKE_GROUP][ZKE_TILE];         // len (7 bits) | offset << 8
-    __shared__ uint64_t tseq[ZKE_GROUP][ZKE_TILE / 4 + 4];
+    __shared__ uint64_t tseq_mem[ZKE_GROUP][TSEQ_N];
     __shared__ uint32_t tcount[ZKE_GROUP], ttail[ZKE_GROUP];
-    __shared__ uint32_t s_queue[ZKE_QCAP], s_qres[ZKE_QCAP], s_qn;       // matches of 8+ bytes waiting to be measured (compare phase)
+    __shared__ uint32_t queue_mem[SHARE ? 1 : 2 * ZKE_QCAP], s_qn;       // matches of 8+ bytes waiting to be measured (compare phase)
+    static_assert(!SHARE || sizeof(tseq_mem) >= 2 * ZKE_QCAP * sizeof(uint32_t), "the queue fits into the tile sequences' bytes");
+    uint64_t (*tseq)[TSEQ_N] = tseq_mem;
+    uint32_t *s_queue = SHARE ? reinterpret_cast<uint32_t *>(&tseq_mem[0][0]) : queue_mem;
+    uint32_t *s_qres = s_queue + ZKE_QCAP;
     uint32_t *s_scan = s_queue;                                         // the gather pass reuses it (ZKE_THREADS words)
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ZkEncFrame fr = frames[blockIdx.x];
@@ -915,9 +929,11 @@ void zk_launch_enc_stage_hist(hipStream_t st, const uint8_t *src, const uint8_t 
 {
     hipLaunchKernelGGL(zk_k_enc_stage_hist, dim3(nframes), dim3(256), 0, st, src, prefix_tail, frames, stage);
 }
-void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, ZkEncBlock *blocks, uint64_t *seqs, uint32_t *mpos, uint8_t *lits)
+void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, ZkEncBlock *blocks, uint64_t *seqs, uint32_t *mpos, uint8_t *lits, uint32_t hash_log)
 {
-    hipLaunchKernelGGL(zk_k_enc_match, dim3(nframes), dim3(ZKE_THREADS), 0, st, src, frames, blocks, seqs, mpos, lits);
+    if (hash_log >= 16) hipLaunchKernelGGL((zk_k_enc_match<16, 2>), dim3(nframes), dim3(ZKE_THREADS), 0, st, src, frames, blocks, seqs, mpos, lits);
+    else if (hash_log == 15) hipLaunchKernelGGL((zk_k_enc_match<15, 4>), dim3(nframes), dim3(ZKE_THREADS), 0, st, src, frames, blocks, seqs, mpos, lits);
+    else hipLaunchKernelGGL((zk_k_enc_match<14, 6>), dim3(nframes), dim3(ZKE_THREADS), 0, st, src, frames, blocks, seqs, mpos, lits);
 }
 void zk_launch_enc_fse_build(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, const uint64_t *seqs,
                              const ZkEncTables *predef, ZkEncTables *ftab)

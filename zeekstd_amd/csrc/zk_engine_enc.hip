@@ -146,7 +146,7 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         msrc = (const uint8_t *)e->enc_hist.p;
     }
     if (a.checksum) { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, d_doff, 0, nf, nullptr, hashes); }
-    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (uint8_t *)e->enc_c.p); }
+    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (uint8_t *)e->enc_c.p, zke_hash_log(a.level)); }
     ZkEncTables *ftab = (ZkEncTables *)e->enc_f.p;
     { zk_kernel_timer t(e, ZK_K_ENC_FSE_BUILD, st); zk_launch_enc_fse_build(st, src, dfr, nf, dbl, (const uint64_t *)e->enc_b.p, dtab, ftab); }
     { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, ftab); }
