@@ -24,6 +24,7 @@ u64 zko_xxh64(const u8 *p, size_t len, u64 seed);
 
 #define ZKE_BLOCK 131072u
 #define ZKE_HASH_LOG_MAX 16
+#define ZKE_SEGMENT (2u << 20)       /* zk_enc_device.h: bytes of a frame one matcher workgroup takes (a multiple of the 32 KiB blocks) */
 static u32 g_hash_log = 14;         /* zke_hash_log(level): 2^14 table entries at level <= 1, 2^15 at 2..5 and 0 (= default 3), 2^16 from 6 on */
 static u32 g_minmatch = 6;          /* zke_minmatch(level): 6 for level <= 1 (except 0 = default 3), else 5 */
 #define ZKE_WINDOW 65535u          /* 16-bit positions in the hash table */
@@ -484,11 +485,25 @@ i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int le
     u8 *lits = malloc(n + 64), *body = malloc(ZKE_BLOCK * 2);
     u32 *bseq = malloc(sizeof(u32) * (nblk + 1)), *blit = malloc(sizeof(u32) * (nblk + 1)), *bnlit = malloc(sizeof(u32) * (nblk + 1));
     u32 hll[36] = {0}, hof[32] = {0}, hml[53] = {0}, nseq_frame = 0, nlit_frame = 0;
+    /* The matcher works on segments of ZKE_SEGMENT bytes (one GPU workgroup each, so that a frame larger than that is not
+     * one serial job): a segment after the first starts with an empty table that receives the positions of the 65 535 bytes
+     * before it -- exactly what a prefix does for a frame -- its positions count from that history's start, and nothing of
+     * it looks past its own end.  Frames up to ZKE_SEGMENT bytes are one segment: nothing changes for them. */
+    const u8 *sbase = msrc;                                          /* the segment's position 0 */
+    u32 shist = hist, sstart = 0, send = n < ZKE_SEGMENT ? (u32)n : ZKE_SEGMENT;
     for (u32 k = 0, bs = 0; bs < n; bs += bmax, k++) {
         u32 be = bs + bmax < n ? bs + bmax : (u32)n;
         u32 nlit = 0;
+        if (bs == send) {                                            /* next segment */
+            sstart = bs; send = (u64)bs + ZKE_SEGMENT < n ? bs + ZKE_SEGMENT : (u32)n;
+            shist = ZKE_WINDOW;
+            sbase = msrc + hist + sstart - shist;
+            memset(st->table, 0, sizeof st->table);
+            for (u32 v = 0; v < shist; v++) if ((size_t)v + 8 <= (size_t)shist + (send - sstart)) st->table[hash5(sbase + v)] = (u16)(v + 1);
+            st->probe = 1;
+        }
         bseq[k] = nseq_frame; blit[k] = nlit_frame;
-        u32 nseq = find_sequences(st, msrc, hist + bs, hist + be, hist + (u32)n, sq + nseq_frame, lits + nlit_frame, &nlit);
+        u32 nseq = find_sequences(st, sbase, shist + (bs - sstart), shist + (be - sstart), shist + (send - sstart), sq + nseq_frame, lits + nlit_frame, &nlit);
         for (u32 i = 0; i < nseq; i++) { const seq_t *q = &sq[nseq_frame + i]; hll[ll_code(q->ll)]++; hml[ml_code(q->ml - 3)]++; hof[hb32(q->offbase)]++; }
         bnlit[k] = nlit; nseq_frame += nseq; nlit_frame += nlit;
     }

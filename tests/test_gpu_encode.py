@@ -191,3 +191,28 @@ def test_encode_with_prefix_roundtrip_and_twin(engine, name, checksum):
     c_off, d_off = offsets_from_frames(frames)
     out, st = engine.decode_frames(comp + b"\0" * 8, c_off, d_off, verify=True, prefix=prefix)
     assert not st.any() and out == data
+
+
+@pytest.mark.parametrize("level", [1, 3])
+@pytest.mark.parametrize("with_prefix", [False, True])
+def test_frames_above_the_matcher_segment(engine, level, with_prefix):
+    """Frames larger than ZKE_SEGMENT (2 MiB) are matched in segments, one workgroup each, every segment after the first
+    starting from the 65 535 bytes before it (zk_enc_device.h) -- the CPU twin cuts the same way: byte-identical, valid for
+    libzstd and for both decoders.  Frame size 5 MiB + 12 345 (three segments, the last one ragged) and a short last frame."""
+    data = zko.gen_chunks((17 << 20) + 77, 5)
+    fs = (5 << 20) + 12345
+    prefix = zko.gen_text(300000, 9) if with_prefix else None
+    comp, frames = engine.encode_frames(data, fs, level, True, prefix=prefix)
+    assert [d for _, d in frames] == [fs, fs, fs, len(data) - 3 * fs]
+    pos = dpos = 0
+    for c, d in frames:
+        f = comp[pos:pos + c]
+        assert f == zko.frame_encode(data[dpos:dpos + d], level, True, prefix=prefix), (level, with_prefix, dpos)
+        out, used = zko.frame_decode(f, d, True, prefix=prefix)
+        assert used == c and out == data[dpos:dpos + d]
+        pos += c; dpos += d
+    c_off, d_off = offsets_from_frames(frames)
+    out, st = engine.decode_frames(comp + b"\0" * 8, c_off, d_off, verify=True, prefix=prefix)
+    assert not st.any() and out == data
+    if not with_prefix and Z.load("system") is not None:
+        assert Z.decode_stream(comp, len(data), "system") == data

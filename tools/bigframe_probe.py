@@ -1,13 +1,17 @@
-import sys, time
-sys.path.insert(0,'/root/repo')
-import numpy as np
-from oracle import zko, libzstd_ref as Z
+import os, sys, time
+sys.path.insert(0, ".")
+import numpy as np, torch
+from oracle import zko
 import zeekstd_amd as zk
-eng = zk.Engine(0)
-N = 48 << 20
-data = zko.gen_chunks(N, 77)
-for name, (comp, frames) in {"gpu": eng.encode_frames(data, N, 1, True), "libzstd_l3": Z.encode_seekable_frames(data, N, 3, True, "system")}.items():
-    c = np.array([0, len(comp)], np.uint64); d = np.array([0, N], np.uint64)
-    t = time.time(); out, st = eng.decode_frames(comp + b"\0"*8, c, d, verify=True); dt = time.time() - t
-    print(name, "frames", frames, "ok", out == data, st, "decode s", round(dt, 3))
-    if name == "gpu": assert Z.decode_stream(comp, N, "system") == data
+dev = torch.device("cuda:0"); eng = zk.Engine(0)
+total = 1 << 30
+data = np.frombuffer(zko.gen_chunks(128 << 20), np.uint8)
+d_src = torch.from_numpy(np.tile(data, total // len(data))).to(dev)
+for fs in (16 << 20, 128 << 20):
+    for cks in (True, False):
+        cap = int(zk.lib.zk_compress_bound(total, fs))
+        d_comp = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+        eng.set_profiling(True)
+        eng.encode_frames_dev(d_src, total, fs, 1, cks, d_comp, cap)
+        eng.encode_frames_dev(d_src, total, fs, 1, cks, d_comp, cap)
+        print(fs >> 20, "MiB frames, checksum", cks, {k: round(v, 1) for k, v in eng.kernel_times().items() if "enc" in k})

@@ -19,6 +19,11 @@ constexpr uint32_t ZKE_TILE = 256;                // parse tile: matches never c
 constexpr uint32_t ZKE_LSTEP = 2;                 // tiles per lookup step (one position per lane: 512 lanes)
 constexpr uint32_t ZKE_PARCAP = 64;
 constexpr uint32_t ZKE_GROUP = 8;                // tiles parsed side by side, one wave each
+// The matcher's unit of work is a SEGMENT of a frame, one workgroup each: a frame larger than this is not one serial job.
+// A segment after a frame's first starts with an empty table that receives the positions of the ZKE_WINDOW bytes before it
+// (what a prefix does for a frame), counts its positions from that history's start and does not look past its own end; a
+// frame of up to ZKE_SEGMENT bytes is one segment.  (A multiple of the 32 KiB blocks every frame this large is cut into.)
+constexpr uint32_t ZKE_SEGMENT = 2u << 20;
 
 // Block size the encoder cuts a frame of d_size bytes into.  Blocks are cut smaller than the format's maximum on purpose:
 // a block's sequence bitstream is one serial chain for the decoder, so more, shorter blocks = more parallel chains
@@ -60,7 +65,9 @@ struct ZkEncBlock {
     uint8_t rle_byte;
     uint8_t is_def;             // this block carries the frame's FSE table descriptions (zk_k_enc_sizes decides)
     uint8_t pad[2];
+    uint32_t out_at;            // where the block's 3-byte header goes, from the frame's first byte (zk_k_enc_sizes)
 };
+static_assert(sizeof(ZkEncBlock) == 64, "one line per block record");
 
 // FSE compression tables of one frame: the predefined distributions (built on the host at engine creation) or -- per
 // table -- the frame's own, measured from all its sequences by zk_k_enc_fse_build (accuracy logs 9 / 8 / 9).  One set per

@@ -458,7 +458,7 @@ __device__ __forceinline__ void zke_copy_wave(uint8_t *dst, const uint8_t *src, 
 // One workgroup per frame: code histograms of all its sequences (LDS atomics), then one lane per table normalises,
 // writes the description and builds the compression table into the frame's ZkEncTables (HBM).  A table with fewer than
 // two symbols, or a frame with fewer than ZKE_FSE_MIN_SEQ sequences, keeps the predefined one.
-__global__ __launch_bounds__(256) void zk_k_enc_fse_build(const ZkEncFrame *frames, const ZkEncBlock *blocks, const uint64_t *seqs,
+__global__ __launch_bounds__(1024) void zk_k_enc_fse_build(const ZkEncFrame *frames, const ZkEncBlock *blocks, const uint64_t *seqs,
                                                           const ZkEncTables *predef, ZkEncTables *ftab, uint32_t min_seq)
 {
     __shared__ uint32_t h[3][64];
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void zk_k_enc_fse_build(const ZkEncFrame *fram
     for (uint32_t b = 0; b < fr.n_blocks; b++) {
         const ZkEncBlock &blk = blocks[fr.block_base + b];
         const uint64_t *sq = seqs + blk.seq_base;
-        for (uint32_t i = tid; i < blk.nseq; i += 256) {
+        for (uint32_t i = tid; i < blk.nseq; i += 1024) {
             const uint64_t e = sq[i];
             const uint32_t ll = (uint32_t)e & 0xFFFFF, ml = (uint32_t)(e >> 20) & 0xFFFFF, ob = (uint32_t)(e >> 40);
             atomicAdd(&h[0][zke_ll_code(ll)], 1u); atomicAdd(&h[1][zk_highbit(ob)], 1u); atomicAdd(&h[2][zke_ml_code(ml - 3)], 1u);
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void zk_k_enc_fse_build(const ZkEncFrame *fram
     }
     if (mine) atomicAdd(&s_nseq, mine);
     // the predefined set is the starting point (value tables, and whatever stays predefined)
-    for (uint32_t i = tid; i < sizeof(ZkEncTables) / 4; i += 256) ((uint32_t *)T)[i] = ((const uint32_t *)predef)[i];
+    for (uint32_t i = tid; i < sizeof(ZkEncTables) / 4; i += 1024) ((uint32_t *)T)[i] = ((const uint32_t *)predef)[i];
     __syncthreads();
     if (tid < 3 && s_nseq >= min_seq) {
         const int t = (int)tid;
@@ -838,6 +838,7 @@ __global__ __launch_bounds__(64) void zk_k_enc_sizes(const ZkEncFrame *frames, u
                 blk.csize += ftab[f].dlen[0] + ftab[f].dlen[1] + ftab[f].dlen[2];
                 defined = true;
             }
+            blk.out_at = (uint32_t)c;
             c += 3 + blk.csize;
         }
     }
@@ -872,47 +873,53 @@ __global__ __launch_bounds__(1024) void zk_k_scan64(const uint64_t *in, uint32_t
     if (tid == 0) out[n] = carry;
 }
 
-__global__ __launch_bounds__(256) void zk_k_enc_assemble(const uint8_t *src, const ZkEncFrame *frames, const ZkEncBlock *blocks, const ZkEncTables *ftab,
-                                                         const uint8_t *scratch, const uint64_t *out_off, const uint64_t *hashes,
+// Workgroups [0, nframes): what belongs to a frame as a whole (magic + header, the empty frame's bytes, the checksum).
+// Workgroups [nframes, nframes + nblocks): one block each -- its header and payload go to out_off[frame] + out_at (the
+// prefix sums of zk_k_enc_sizes), so a frame of 128 MiB is copied by 4096 workgroups, not by one.
+__global__ __launch_bounds__(256) void zk_k_enc_assemble(const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, const ZkEncTables *ftab,
+                                                         const uint8_t *scratch, const uint64_t *out_off, const uint64_t *c_size64, const uint64_t *hashes,
                                                          int checksum, uint8_t *dst)
 {
     const uint32_t tid = threadIdx.x;
-    const ZkEncFrame fr = frames[blockIdx.x];
-    uint8_t *o = dst + out_off[blockIdx.x];
-    uint64_t p;
-    if (fr.d_size == 0) {
-        if (tid == 0) { const uint8_t e[9] = {0x28, 0xB5, 0x2F, 0xFD, (uint8_t)(checksum ? 0x24 : 0x20), 0x00, 0x01, 0x00, 0x00}; for (int i = 0; i < 9; i++) o[i] = e[i]; }
-        p = 9;
-    } else {
-        if (tid == 0) { o[0] = 0x28; o[1] = 0xB5; o[2] = 0x2F; o[3] = 0xFD; o[4] = checksum ? 0x04 : 0x00; o[5] = (uint8_t)((fr.window_log - 10) << 3); }
-        p = 6;
-        for (uint32_t b = 0; b < fr.n_blocks; b++) {
-            const ZkEncBlock &blk = blocks[fr.block_base + b];
-            const uint32_t last = b + 1 == fr.n_blocks;
-            const uint32_t field = blk.mode == 2 ? blk.csize : blk.bsz;     // Block_Size: regenerated size for raw / RLE
-            if (tid == 0) { const uint32_t h = last | (blk.mode << 1) | (field << 3); o[p] = (uint8_t)h; o[p + 1] = (uint8_t)(h >> 8); o[p + 2] = (uint8_t)(h >> 16); }
-            p += 3;
-            if (blk.mode == 1) { if (tid == 0) o[p] = blk.rle_byte; p += 1; }
-            else if (blk.mode == 2 && blk.is_def) {
-                // payload up to the modes byte, the modes byte in its defining form, the descriptions, the rest
-                const ZkEncTables &ft = ftab[blockIdx.x];
-                const uint8_t *from = scratch + blk.scratch_base;
-                const uint32_t extra = ft.dlen[0] + ft.dlen[1] + ft.dlen[2], body = blk.csize - extra, mo = blk.modes_off;
-                for (uint32_t i = tid; i < mo; i += 256) o[p + i] = from[i];
-                if (tid == 0) o[p + mo] = (uint8_t)zke_modes_byte(ft.custom, 2);
-                uint32_t w = mo + 1;
-                for (int t = 0; t < 3; t++) { for (uint32_t i = tid; i < ft.dlen[t]; i += 256) o[p + w + i] = ft.desc[t][i]; w += ft.dlen[t]; }
-                for (uint32_t i = mo + 1 + tid; i < body; i += 256) o[p + extra + i] = from[i];
-                p += blk.csize;
-            } else {
-                const uint8_t *from = blk.mode == 2 ? scratch + blk.scratch_base : src + fr.src_off + blk.bs;
-                const uint32_t n = blk.mode == 2 ? blk.csize : blk.bsz;
-                for (uint32_t i = tid; i < n; i += 256) o[p + i] = from[i];
-                p += n;
-            }
+    if (blockIdx.x < nframes) {
+        if (tid) return;
+        const uint32_t f = blockIdx.x;
+        const ZkEncFrame fr = frames[f];
+        uint8_t *o = dst + out_off[f];
+        if (fr.d_size == 0) { const uint8_t e[9] = {0x28, 0xB5, 0x2F, 0xFD, (uint8_t)(checksum ? 0x24 : 0x20), 0x00, 0x01, 0x00, 0x00}; for (int i = 0; i < 9; i++) o[i] = e[i]; }
+        else { o[0] = 0x28; o[1] = 0xB5; o[2] = 0x2F; o[3] = 0xFD; o[4] = checksum ? 0x04 : 0x00; o[5] = (uint8_t)((fr.window_log - 10) << 3); }
+        if (checksum) {
+            const uint64_t p = c_size64[f] - 4;
+            const uint32_t h = (uint32_t)hashes[f];
+            o[p] = (uint8_t)h; o[p + 1] = (uint8_t)(h >> 8); o[p + 2] = (uint8_t)(h >> 16); o[p + 3] = (uint8_t)(h >> 24);
         }
+        return;
     }
-    if (checksum && tid == 0) { const uint32_t h = (uint32_t)hashes[blockIdx.x]; o[p] = (uint8_t)h; o[p + 1] = (uint8_t)(h >> 8); o[p + 2] = (uint8_t)(h >> 16); o[p + 3] = (uint8_t)(h >> 24); }
+    const uint32_t gb = blockIdx.x - nframes;
+    const ZkEncBlock &blk = blocks[gb];
+    const ZkEncFrame fr = frames[blk.frame];
+    uint8_t *o = dst + out_off[blk.frame];
+    uint64_t p = blk.out_at;
+    const uint32_t last = gb + 1 == fr.block_base + fr.n_blocks;
+    const uint32_t field = blk.mode == 2 ? blk.csize : blk.bsz;     // Block_Size: regenerated size for raw / RLE
+    if (tid == 0) { const uint32_t h = last | (blk.mode << 1) | (field << 3); o[p] = (uint8_t)h; o[p + 1] = (uint8_t)(h >> 8); o[p + 2] = (uint8_t)(h >> 16); }
+    p += 3;
+    if (blk.mode == 1) { if (tid == 0) o[p] = blk.rle_byte; }
+    else if (blk.mode == 2 && blk.is_def) {
+        // payload up to the modes byte, the modes byte in its defining form, the descriptions, the rest
+        const ZkEncTables &ft = ftab[blk.frame];
+        const uint8_t *from = scratch + blk.scratch_base;
+        const uint32_t extra = ft.dlen[0] + ft.dlen[1] + ft.dlen[2], body = blk.csize - extra, mo = blk.modes_off;
+        for (uint32_t i = tid; i < mo; i += 256) o[p + i] = from[i];
+        if (tid == 0) o[p + mo] = (uint8_t)zke_modes_byte(ft.custom, 2);
+        uint32_t w = mo + 1;
+        for (int t = 0; t < 3; t++) { for (uint32_t i = tid; i < ft.dlen[t]; i += 256) o[p + w + i] = ft.desc[t][i]; w += ft.dlen[t]; }
+        for (uint32_t i = mo + 1 + tid; i < body; i += 256) o[p + extra + i] = from[i];
+    } else {
+        const uint8_t *from = blk.mode == 2 ? scratch + blk.scratch_base : src + fr.src_off + blk.bs;
+        const uint32_t n = blk.mode == 2 ? blk.csize : blk.bsz;
+        for (uint32_t i = tid; i < n; i += 256) o[p + i] = from[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -940,7 +947,7 @@ void zk_launch_enc_fse_build(hipStream_t st, const uint8_t *src, const ZkEncFram
 {
     (void)src;
     static const bool only_predef = getenv("ZK_ENC_PREDEF") != nullptr;      // experiments: the predefined tables for every frame
-    hipLaunchKernelGGL(zk_k_enc_fse_build, dim3(nframes), dim3(256), 0, st, frames, blocks, seqs, predef, ftab, only_predef ? 0xFFFFFFFFu : ZKE_FSE_MIN_SEQ);
+    hipLaunchKernelGGL(zk_k_enc_fse_build, dim3(nframes), dim3(1024), 0, st, frames, blocks, seqs, predef, ftab, only_predef ? 0xFFFFFFFFu : ZKE_FSE_MIN_SEQ);
 }
 void zk_launch_enc_entropy(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks, uint32_t nblocks,
                            uint64_t *seqs, uint32_t *mpos, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *ftab)
@@ -957,8 +964,8 @@ void zk_launch_scan64(hipStream_t st, const uint64_t *in, uint32_t n, uint64_t *
 {
     hipLaunchKernelGGL(zk_k_scan64, dim3(1), dim3(1024), 0, st, in, n, out);
 }
-void zk_launch_enc_assemble(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, const ZkEncTables *ftab,
-                            const uint8_t *scratch, const uint64_t *out_off, const uint64_t *hashes, int checksum, uint8_t *dst)
+void zk_launch_enc_assemble(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, uint32_t nblocks, const ZkEncTables *ftab,
+                            const uint8_t *scratch, const uint64_t *out_off, const uint64_t *c_size64, const uint64_t *hashes, int checksum, uint8_t *dst)
 {
-    hipLaunchKernelGGL(zk_k_enc_assemble, dim3(nframes), dim3(256), 0, st, src, frames, blocks, ftab, scratch, out_off, hashes, checksum, dst);
+    hipLaunchKernelGGL(zk_k_enc_assemble, dim3(nframes + nblocks), dim3(256), 0, st, src, frames, nframes, blocks, ftab, scratch, out_off, c_size64, hashes, checksum, dst);
 }

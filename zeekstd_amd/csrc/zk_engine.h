@@ -50,6 +50,7 @@ struct zk_engine {
     zk_devbuf enc_a, enc_b, enc_c, enc_d, enc_e, enc_f;
     void *enc_pin = nullptr; size_t enc_pin_cap = 0;   // pinned host copy of the frame / block lists of the encode in flight
     zk_devbuf enc_hist;                     // prefix mode: [prefix tail | frame] records for the matcher
+    zk_devbuf enc_seg;                      // frames above ZKE_SEGMENT: the matcher's segment records
     ZkEncTables enc_tables;
     bool enc_tables_ready = false;
 };

@@ -86,12 +86,24 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
     const size_t frames_bytes = ((size_t)nf * sizeof(ZkEncFrame) + 63) & ~(size_t)63;
     const size_t blocks_bytes = ((size_t)(nb + 1) * sizeof(ZkEncBlock) + 63) & ~(size_t)63;
     const size_t doff_bytes = ((size_t)(nf + 1) * 8 + 63) & ~(size_t)63;
+    // frames above ZKE_SEGMENT: the matcher runs one workgroup per segment (zk_enc_device.h)
+    const bool segmented = frame_size > ZKE_SEGMENT;
+    uint64_t nseg64 = 0;
+    if (segmented) for (uint32_t f = 0; f < nf; f++) {
+        const uint64_t so = (uint64_t)f * frame_size;
+        const uint64_t dsz = n - so < frame_size ? n - so : frame_size;
+        nseg64 += (dsz + ZKE_SEGMENT - 1) / ZKE_SEGMENT;
+    }
+    if (nseg64 > 0xFFFFFFF0ull) return -(int)ZK_E_GENERIC;
+    const uint32_t nseg = (uint32_t)nseg64;
+    const size_t segs_bytes = ((size_t)nseg * sizeof(ZkEncFrame) + 63) & ~(size_t)63;
     int rc;
-    if ((rc = zk_pin_reserve(e, frames_bytes + blocks_bytes + doff_bytes + sizeof(ZkEncTables)))) return rc;
+    if ((rc = zk_pin_reserve(e, frames_bytes + blocks_bytes + doff_bytes + sizeof(ZkEncTables) + 64 + segs_bytes))) return rc;
     ZkEncFrame *frames = (ZkEncFrame *)e->enc_pin;
     ZkEncBlock *blocks = (ZkEncBlock *)((uint8_t *)e->enc_pin + frames_bytes);
     uint64_t *doff = (uint64_t *)((uint8_t *)e->enc_pin + frames_bytes + blocks_bytes);
     ZkEncTables *htab = (ZkEncTables *)((uint8_t *)doff + doff_bytes);
+    ZkEncFrame *segs = (ZkEncFrame *)((uint8_t *)e->enc_pin + ((frames_bytes + blocks_bytes + doff_bytes + sizeof(ZkEncTables) + 63) & ~(size_t)63));
     uint64_t seq_total = 0, scratch_total = 0;
     uint32_t bcount = 0;
     for (uint32_t f = 0; f < nf; f++) {
@@ -122,6 +134,21 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         doff[f] = fr.src_off;
     }
     doff[nf] = n;
+    if (segmented) {
+        uint32_t sc = 0;
+        for (uint32_t f = 0; f < nf; f++) {
+            const ZkEncFrame &fr = frames[f];
+            const uint32_t per = ZKE_SEGMENT / fr.block_max;              // blocks per segment (block_max is 32 KiB for frames this large)
+            for (uint32_t at = 0; at < fr.d_size; at += ZKE_SEGMENT) {
+                ZkEncFrame &sg = segs[sc++];
+                sg = fr;
+                sg.d_size = fr.d_size - at < ZKE_SEGMENT ? fr.d_size - at : ZKE_SEGMENT;
+                sg.n_blocks = (sg.d_size + fr.block_max - 1) / fr.block_max;
+                sg.block_base = fr.block_base + (at / ZKE_SEGMENT) * per;
+                if (at) { sg.hist = ZKE_WINDOW; sg.m_off = fr.m_off + fr.hist + at - ZKE_WINDOW; }
+            }
+        }
+    }
     if ((rc = zk_devbuf_reserve(e, e->enc_a, frames_bytes + blocks_bytes + 256))) return rc;
     if ((rc = zk_devbuf_reserve(e, e->enc_b, (size_t)(seq_total + 1) * 12 + 64))) return rc;       // packed sequences (u64) + match positions (u32)
     if ((rc = zk_devbuf_reserve(e, e->enc_c, (size_t)n + 64))) return rc;
@@ -146,7 +173,14 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         msrc = (const uint8_t *)e->enc_hist.p;
     }
     if (a.checksum) { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, d_doff, 0, nf, nullptr, hashes); }
-    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (uint8_t *)e->enc_c.p, zke_hash_log(a.level)); }
+    const ZkEncFrame *mfr = dfr;                             // what the matcher's workgroups are launched over
+    uint32_t nm = nf;
+    if (segmented) {
+        if ((rc = zk_devbuf_reserve(e, e->enc_seg, segs_bytes + 64))) return rc;
+        ZK_HIP(hipMemcpyAsync(e->enc_seg.p, segs, (size_t)nseg * sizeof(ZkEncFrame), hipMemcpyHostToDevice, st));
+        mfr = (const ZkEncFrame *)e->enc_seg.p; nm = nseg;
+    }
+    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, mfr, nm, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (uint8_t *)e->enc_c.p, zke_hash_log(a.level)); }
     ZkEncTables *ftab = (ZkEncTables *)e->enc_f.p;
     { zk_kernel_timer t(e, ZK_K_ENC_FSE_BUILD, st); zk_launch_enc_fse_build(st, src, dfr, nf, dbl, (const uint64_t *)e->enc_b.p, dtab, ftab); }
     { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, ftab); }
@@ -157,7 +191,7 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         ZK_HIP(hipStreamSynchronize(st));
         if (e->h_words[ZK_HW_ENC_TOTAL] > a.dst_cap) return -(int)ZK_E_DST_TOO_SMALL;
     }
-    { zk_kernel_timer t(e, ZK_K_ENC_COMPACT, st); zk_launch_enc_assemble(st, src, dfr, nf, dbl, ftab, (const uint8_t *)e->enc_d.p, out_off, hashes, a.checksum, (uint8_t *)a.d_dst); }
+    { zk_kernel_timer t(e, ZK_K_ENC_COMPACT, st); zk_launch_enc_assemble(st, src, dfr, nf, dbl, nb, ftab, (const uint8_t *)e->enc_d.p, out_off, c64, hashes, a.checksum, (uint8_t *)a.d_dst); }
     if (nf_out) *nf_out = nf;
     return 0;
 }
