@@ -239,7 +239,7 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
                         const uint32_t cap_end = st[(staged_end - 1) & M].out_end;
                         const uint32_t te = ts + THREADS * B < cap_end ? ts + THREADS * B : cap_end;
                         uint32_t jn = nl;
-                        std::fill(srcmap.begin(), srcmap.end(), 0xDEADBEEFu);
+                        std::fill(srcmap.begin(), srcmap.end(), 0u);                        // the map starts empty (run markers)
                         std::fill(slot_seq.begin(), slot_seq.end(), 0xFFFFFFFFu);
                         for (uint32_t i = 0; i < nl; i++) {                                  // "lane per sequence"
                             const uint32_t idx = ja + i;
@@ -250,14 +250,16 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
                                 uint32_t s0, n;
                                 zk_exec_slot_span(ts, lo, hi, s0, n);
                                 for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = idx;
+                                zk_exec_mark_runs(st[idx & M], start, ts, te, srcmap.data());
                             }
                             if (end > te && start <= te) jn = i;
                         }
                         for (uint32_t q0 = ts; q0 < te; q0 += ZK_EXEC_SLOT) {                // "lane per slot"
                             const uint32_t nb = te - q0 < ZK_EXEC_SLOT ? te - q0 : ZK_EXEC_SLOT;
                             uint32_t sw[ZK_EXEC_SLOT];
-                            if (!zk_exec_slot_words_fast(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, sw, M))
-                                zk_exec_slot_words(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, sw, M);
+                            uint32_t mk[ZK_EXEC_SLOT];
+                            for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) mk[k] = q0 - ts + k < srcmap.size() ? srcmap[q0 - ts + k] : 0u;
+                            zk_exec_slot_words_marked(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, mk, sw, M);
                             for (uint32_t k = 0; k < nb; k++) srcmap[q0 - ts + k] = sw[k];
                         }
                         const uint32_t mbase = ZK_SRC_BIAS + ts, span = te - ts;

@@ -789,10 +789,16 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                 const uint32_t nl = staged_end - ja;
                 const uint32_t cap_end = S[(staged_end - 1) & M].out_end;
                 const uint32_t te = ts + T * ZK_EXEC_B < cap_end ? ts + T * ZK_EXEC_B : cap_end;
+                // 1a. the map starts empty: the lane of a sequence leaves, at the bytes where its two runs start, the word that
+                //     run adds to a position (zk_exec_mark_runs); the slot pass below only carries them forward
+#pragma unroll
+                for (int k = 0; k < ZK_EXEC_B; k += 4) *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(0, 0, 0, 0);
+                __syncthreads();
                 // 2. lane per sequence: mark the slots it starts; the first sequence that outlives the tile sets jn
                 for (uint32_t i = tid; i < nl; i += T) {
                     const uint32_t idx = ja + i;
-                    const uint32_t end = S[idx & M].out_end;
+                    const ZkSeq me = S[idx & M];
+                    const uint32_t end = me.out_end;
                     const uint32_t start = i ? S[(idx - 1) & M].out_end : prev_end;
                     const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
                     if (lo < hi) {
@@ -800,6 +806,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                         zk_exec_slot_span(ts, lo, hi, s0, n);
                         if (n > ZK_EXEC_LONG) longlist[atomicAdd(&s_nlong, 1u)] = idx;
                         else for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = idx;
+                        zk_exec_mark_runs(me, start, ts, te, srcmap);
                     }
                     if (end > te && start <= te) s_jn = i;
                 }
@@ -832,7 +839,15 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                 const uint32_t nb = q0 >= te ? 0u : te - q0 < (uint32_t)ZK_EXEC_B ? te - q0 : (uint32_t)ZK_EXEC_B;
                 uint32_t sw[ZK_EXEC_B];
                 if (nb) {
-                    if (!zk_exec_slot_words_fast(S, slot_seq[tid], q0, nb, sw, M)) zk_exec_slot_words(S, slot_seq[tid], q0, nb, sw, M);
+                    {
+                        uint32_t mk[ZK_EXEC_B];
+#pragma unroll
+                        for (int k = 0; k < ZK_EXEC_B; k += 4) {
+                            const uint4 v = *reinterpret_cast<const uint4 *>(&srcmap[tid * ZK_EXEC_B + k]);
+                            mk[k] = v.x; mk[k + 1] = v.y; mk[k + 2] = v.z; mk[k + 3] = v.w;
+                        }
+                        zk_exec_slot_words_marked(S, slot_seq[tid], q0, nb, mk, sw, M);
+                    }
 #pragma unroll
                     for (int k = 0; k < ZK_EXEC_B; k += 4)
                         *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(sw[k], sw[k + 1], sw[k + 2], sw[k + 3]);

@@ -1239,38 +1239,46 @@ ZK_HD void zk_exec_slot_seq(const ZkSeq &e, uint32_t q, ZkSlotCur &c)
     c.r = r;
 }
 
-// Fast form of zk_exec_slot_words for slots that contain no byte of a match overlapping its own output
-// (offset < match length): there both parts of a sequence are affine in q (literal: litw + q, match: BIAS - off + q),
-// 5 instructions per byte instead of 9.  Returns false when such a match was met: the caller falls back to
-// zk_exec_slot_words (rare outside run-length-like data).
-// S is addressed as a ring: entry i lives at S[i & ring_mask] (0xFFFFFFFF = a plain array)
-ZK_HD bool zk_exec_slot_words_fast(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t nb, uint32_t *sw, uint32_t ring_mask = 0xFFFFFFFFu)
+ZK_HD void zk_exec_slot_words(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t nb, uint32_t *sw, uint32_t ring_mask);
+// The common form of a slot's 16 source words.  Within a run -- the literals of a sequence, or its match unless the match
+// overlaps its own output -- a byte's word is its position plus a constant: (LIT | lit_end) - ms for literals,
+// BIAS - off for a match.  The lane that owns a SEQUENCE leaves these constants in the (emptied) map at the bytes where its
+// two runs start (zk_exec_mark_runs, part of the marking pass); the lane that owns a SLOT then only carries the last
+// constant forward over its 16 bytes (zk_exec_slot_words_marked) -- no walk over sequence ends, which used to be 16 steps
+// with a divergent branch and an LDS round trip each (a third of the executor's time).  A match that overlaps itself
+// leaves ZK_MARK_SLOW: its slots take the general walk (zk_exec_slot_words).
+constexpr uint32_t ZK_MARK_SLOW = 0xFFFFFFFFu;          // no run constant has this value (literals: 0x7FFE0000..0x80020000, matches: 1..2^30)
+ZK_HD void zk_exec_mark_runs(const ZkSeq &e, uint32_t start, uint32_t ts, uint32_t te, uint32_t *map)
 {
-    ZkSeq e = S[i & ring_mask];
-    uint32_t end = e.out_end, ms = e.out_end - e.ml, litw = (ZK_SRC_LIT | e.lit_end) - ms, mw = ZK_SRC_BIAS - e.off;
-    bool ovl = e.off < e.ml, hit = false;
+    const uint32_t ms = e.out_end - e.ml;
+    if (ms > start && start >= ts && start < te) map[start - ts] = (ZK_SRC_LIT | e.lit_end) - ms;
+    if (e.ml && ms >= ts && ms < te) map[ms - ts] = e.off < e.ml ? ZK_MARK_SLOW : ZK_SRC_BIAS - e.off;
+}
+// mk: the slot's 16 words of the map after the marking pass (0 = no run starts here); i0: the sequence that covers q0
+ZK_HD void zk_exec_slot_words_marked(const ZkSeq *S, uint32_t i0, uint32_t q0, uint32_t nb, const uint32_t *mk, uint32_t *sw, uint32_t ring_mask = 0xFFFFFFFFu)
+{
+    const ZkSeq e0 = S[i0 & ring_mask];
+    const uint32_t ms0 = e0.out_end - e0.ml;
+    const bool inm = q0 >= ms0;
+    uint32_t c = inm ? ZK_SRC_BIAS - e0.off : (ZK_SRC_LIT | e0.lit_end) - ms0;
+    uint32_t top = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) {
-        const uint32_t q = q0 + k;
-        if (k < nb) {
-            if (q >= end) {
-                e = S[++i & ring_mask];
-                end = e.out_end; ms = e.out_end - e.ml; litw = (ZK_SRC_LIT | e.lit_end) - ms; mw = ZK_SRC_BIAS - e.off;
-                ovl = e.off < e.ml;
-            }
-            const bool m = q >= ms;
-            sw[k] = (m ? mw : litw) + q;
-            hit |= m & ovl;
-        } else sw[k] = ZK_SRC_LIT;
+    for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) top = mk[k] > top ? mk[k] : top;
+    if (top == ZK_MARK_SLOW || (inm && e0.off < e0.ml)) { zk_exec_slot_words(S, i0, q0, nb, sw, ring_mask); return; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) { c = mk[k] ? mk[k] : c; sw[k] = q0 + k + c; }
+    if (nb < ZK_EXEC_SLOT) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) sw[k] = k < nb ? sw[k] : ZK_SRC_LIT;
     }
-    return !hit;
 }
-
-// Source words of the bytes [q0, q0 + nb) (nb <= 16) given the staged sequence i that covers q0.
-// Every sequence covers >= 3 bytes (ML base), so at most one boundary is crossed per byte.
-ZK_HD void zk_exec_slot_words(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t nb, uint32_t *sw, uint32_t ring_mask = 0xFFFFFFFFu)
+ZK_HD void zk_exec_slot_words(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t nb, uint32_t *sw, uint32_t ring_mask)
 {
     ZkSlotCur c;
     zk_exec_slot_seq(S[i & ring_mask], q0, c);
