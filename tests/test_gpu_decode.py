@@ -94,6 +94,34 @@ def test_corruption_never_escapes(engine):
     assert e.value.code == -10                         # prefix_unknown
 
 
+def test_corruption_in_a_large_batch_of_small_frames(engine):
+    """The batch kernels proper (more than 4096 blocks: shared-table sequence kernels with several table sets per workgroup,
+    256-lane executor tiles): 300 flipped bits spread over an archive of 64 KiB frames written by this engine, checksums
+    on -- every frame either decodes to its bytes or is reported, and nothing spills into the neighbours."""
+    data = zko.gen_chunks(48 << 20, 3)
+    fs = 65536
+    comp, frames = engine.encode_frames(data, fs, 1, True)
+    c, d = offsets_from_frames(frames)
+    assert len(frames) * 16 > 4096
+    rng = np.random.default_rng(23)
+    bad = bytearray(comp)
+    hit = set()
+    for _ in range(300):
+        i = int(rng.integers(0, len(bad)))
+        bad[i] ^= 1 << int(rng.integers(0, 8))
+        hit.add(int(np.searchsorted(c, i, side="right")) - 1)
+    out, st = engine.decode_frames(bytes(bad) + b"\0" * 8, c, d, verify=True, raise_on_error=False)
+    reported = 0
+    for f in range(len(frames)):
+        lo, hi = int(d[f]), int(d[f + 1])
+        if st[f] == 0:
+            assert out[lo:hi] == data[lo:hi], f
+        else:
+            reported += 1
+            assert f in hit, f                                          # an untouched frame is never reported
+    assert reported >= len(hit) - 3                                     # (a flip in a frame's unused header bits may go unnoticed)
+
+
 def test_error_codes(engine):
     g = next(x for x in GOLDENS if x.name == "hello")
     _, st = engine.decode_frames(g.comp + b"\0" * 8, [0, 21], [0, 13], raise_on_error=False)
