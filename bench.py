@@ -723,10 +723,14 @@ def main():
             gather_info = {"encode_plus_gather_GiB_per_s": round(dsize * world / min(tg) / 2**30, 2), "ms": round(min(tg) * 1e3, 2),
                            "frames_on_root": table.num_frames() if table is not None else None,
                            "stream_bytes_on_root": int(out.numel()) if out is not None else None}
-        except Exception as ex:                            # noqa: BLE001 -- reported, the line above stands
+        except Exception as ex:                            # noqa: BLE001 -- reported, the line above stands, the run still fails
             gather_info = {"error": f"{type(ex).__name__}: {ex}"}
         if rank == 0:
             print("[bench] rccl_gather " + json.dumps(gather_info), file=sys.stderr, flush=True)
+        if "error" in gather_info:
+            if world > 1:
+                dist.destroy_process_group()
+            sys.exit(1)
     if world > 1:
         dist.destroy_process_group()
 
