@@ -331,3 +331,33 @@ def test_compressed_policy_short_stream_exact_path(engine):
     data = zko.gen_chunks(5 << 20)
     sizes = _compressed_policy_check(engine, data, 300_000, lambda d: [d])
     assert len(sizes) >= 5
+
+
+def test_compressed_policy_with_a_prefix_in_bulk(engine):
+    """lib.rs:350 (test_patch_cycle under Compressed(n)) at a size where the frames are cut and encoded in batches: every
+    batch goes against the same prefix, the frames end inside the window, the Decoder needs the prefix to get them back."""
+    old = zko.gen_text(400_000, 31)
+    new = zko.gen_chunks(40 << 20, 9)
+    n = 256 << 10
+    sink = io.BytesIO()
+    enc = EncodeOptions().engine(engine).frame_size_policy(FrameSizePolicy.Compressed(n)).checksum_flag(True).into_encoder(sink)
+    for i in range(0, len(new), 12 << 20):
+        piece = new[i:i + (12 << 20)]
+        done = 0
+        while done < len(piece):
+            done += enc.compress_with_prefix(piece[done:], old)
+    enc.finish()
+    blob = sink.getvalue()
+    dec = Decoder(DecodeOptions(blob).engine(engine))
+    st = dec.seek_table()
+    sizes = [st.frame_size_comp(i) for i in range(st.num_frames())]
+    assert len(sizes) > 40 and all(n <= c < n + 131591 for c in sizes[:-1])
+    out = bytearray(len(new))
+    got = 0
+    while got < len(new):
+        k = dec.decompress_with_prefix(memoryview(out)[got:], old)
+        assert k > 0
+        got += k
+    assert bytes(out) == new
+    with pytest.raises(zk.Error):                                   # without the prefix the first frame does not decode to anything valid
+        Decoder(DecodeOptions(blob).engine(engine)).read_to_end()
