@@ -444,6 +444,7 @@ def main():
     ap.add_argument("--seek-trials", type=int, default=10000)
     ap.add_argument("--no-fork", action="store_true", help="generate the inputs in this process (profiling runs)")
     ap.add_argument("--no-ref-archive", action="store_true", help="skip the secondary leg on a CPU-libzstd-made archive")
+    ap.add_argument("--no-ref-level3", action="store_true", help="skip the level-3 part of that leg")
     ap.add_argument("--sync", action="store_true",
                     help="time one batch at a time (zk_decode_frames_dev) instead of two batches in flight; the "
                          "kernel-trace profile uses this so that kernel durations are not inflated by overlap")
@@ -478,6 +479,9 @@ def main():
     z64 = None
     if do_seek and want_ref_archive and z_comp:           # the reference-made 64 KiB-frame archive of configs[3] (forked workers: before HIP)
         z64 = libzstd_archive_parallel(np.asarray(data), 65536, level, True, workers)
+    z3 = None
+    if world == 1 and want_ref_archive and z_comp and use_gpu_archive and not args.no_ref_level3:
+        z3 = libzstd_archive_parallel(np.asarray(data)[:nframes * FRAME], FRAME, 3, cks, workers)      # the reference CLI's default level (cli/src/args.rs:192)
     t_setup = time.time() - t0
 
     import torch
@@ -603,11 +607,10 @@ def main():
     value = total_bytes / elapsed / 2**30
 
     # ---- secondary leg: the same steps on the archive the reference's CPU Encoder loop (libzstd) wrote for this input
-    ref_info = None
-    if use_gpu_archive and want_ref_archive and z_comp:
-        r_c = np.zeros(nframes + 1, np.uint64); r_c[1:] = np.cumsum([f[0] for f in z_frames])
+    def ref_leg(rz_comp, rz_frames, note):
+        r_c = np.zeros(nframes + 1, np.uint64); r_c[1:] = np.cumsum([f[0] for f in rz_frames])
         r_csize = int(r_c[-1])
-        dr_comp = torch.from_numpy(np.frombuffer(z_comp + b"\0" * 64, np.uint8).copy()).to(dev)
+        dr_comp = torch.from_numpy(np.frombuffer(rz_comp + b"\0" * 64, np.uint8).copy()).to(dev)
         dr_c = torch.from_numpy(r_c.view(np.int64)).to(dev)
 
         def ref_pipelined(k):
@@ -633,11 +636,15 @@ def main():
         eng.decode_frames_dev(dr_comp, r_csize, dr_c, d_d, 0, nframes, d_out, dsize, True, d_st)
         r_k = eng.kernel_times()
         eng.set_profiling(False)
-        ref_info = {"value": round(dsize * args.steps / r_el / 2**30, 3), "unit": "GiB/s", "ms_per_step": round(r_el / args.steps * 1e3, 3),
-                    "compressed_bytes": r_csize, "kernel_ms": {k: round(v, 3) for k, v in r_k.items()},
-                    "note": "archive written by the reference Encoder loop over the box's libzstd (level 1: 128 KiB blocks with "
-                            "their own FSE tables -> zk_k_fse instead of zk_k_fse_predef); bit-exact, checksums verified"}
-        del dr_comp
+        return {"value": round(dsize * args.steps / r_el / 2**30, 3), "unit": "GiB/s", "ms_per_step": round(r_el / args.steps * 1e3, 3),
+                "compressed_bytes": r_csize, "kernel_ms": {k: round(v, 3) for k, v in r_k.items()}, "note": note}
+
+    ref_info = None
+    if use_gpu_archive and want_ref_archive and z_comp:
+        ref_info = ref_leg(z_comp, z_frames, "archive written by the reference Encoder loop over the box's libzstd (level 1: 128 KiB blocks with "
+                           "their own FSE tables -> zk_k_fse_quad instead of zk_k_fse_predef); bit-exact, checksums verified")
+        if z3:
+            ref_info["level_3"] = ref_leg(z3[0], z3[1], "the same at level 3, the reference CLI's default: ~60 % more sequences per frame, a 2 MiB window")
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, live
     eng.set_profiling(True)
