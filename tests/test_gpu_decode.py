@@ -232,6 +232,21 @@ def test_frames_of_fewer_than_64_blocks_share_their_tables(engine, fs):
     assert used == len(f) and o == data[int(d[k]):int(d[k + 1])]
 
 
+@pytest.mark.skipif(Z.load("system") is None, reason="no system libzstd on this box")
+def test_dense_sequence_streams_in_a_large_batch(engine):
+    """1100 frames of 256 KiB that libzstd wrote at level 3 (the reference CLI's default): fewer than 10 output bytes per
+    sequence, so the executor takes its 4 T-record ring (zk_launch_exec); every block has its own tables (per-block kernel)."""
+    fs = 262144
+    data = zko.gen_chunks(1100 * fs, 17)
+    comp, frames = Z.encode_seekable_frames(data, fs, 3, True, "system")
+    assert len(frames) == 1100
+    st0 = zko.frame_decode(comp[:frames[0][0]], fs, True, True)[2]
+    assert st0.n_seq * 10 > fs                                             # dense, or this test does not test what it says
+    c, d = offsets_from_frames(frames)
+    out, st = engine.decode_frames(comp + b"\0" * 8, c, d, verify=True)
+    assert not st.any() and out == data
+
+
 def test_random_access_batch(engine):
     """zk_decode_frame_list_dev: many seeks per submission against a device-resident archive (BASELINE configs[3] shape)."""
     import torch

@@ -60,8 +60,10 @@ __global__ __launch_bounds__(64) void zk_k_walk(const uint8_t *comp, uint64_t co
 
 // exclusive scan of (n_blocks, n_seq, lit_bytes) over frames + the count of blocks with their own sequence tables;
 // one workgroup.  totals: [0..2] the three sums, [4] that count ([3] is the first-error word of zk_k_status)
-__global__ __launch_bounds__(1024) void zk_k_scan(const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals)
+__global__ __launch_bounds__(1024) void zk_k_scan(const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals, const uint64_t *d_off, uint32_t first, const uint64_t *out_off)
 {
+    // [5]: output bytes of the batch (what the frames claim): the host sizes nothing from it, it only tells dense sequence streams from sparse ones
+    if (threadIdx.x == 0) totals[5] = out_off ? out_off[count] : d_off[first + count] - d_off[first];
     __shared__ uint64_t wsum[16][4];
     __shared__ uint64_t carry[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -692,7 +694,7 @@ extern "C" void zk_debug_clocks(unsigned long long *out, int reset)
 #else
 #define ZK_CLK(i) do { } while (0)
 #endif
-template <int T, bool PFX>
+template <int T, bool PFX, int CAPX = 2>
 __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
                                                const uint32_t *ids, const uint64_t *out_off,
                                                const ZkBlock *blocks, const ZkFrameBase *bases,
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
     // the marking pass, written into the retired slots once the slot pass no longer reads them: the fetch (an HBM round
     // trip that used to open every tile, in front of a barrier, for twice the records a tile needs) is off the critical
     // path and every record is read once.
-    constexpr int CAP = 2 * T;
+    constexpr int CAP = CAPX * T;                // 2 T records; 4 T where sequences are dense (zk_launch_exec)
     constexpr uint32_t M = CAP - 1;
     constexpr int NPF = CAP / T;                 // records a lane may have to fetch per tile
     __shared__ __attribute__((aligned(16))) ZkSeq S[CAP];
@@ -1129,9 +1131,9 @@ void zk_launch_walk(hipStream_t st, const uint8_t *comp, uint64_t comp_size, con
 {
     hipLaunchKernelGGL(zk_k_walk, dim3((count + 63) / 64), dim3(64), 0, st, comp, comp_size, c_off, d_off, first, count, ids, out_off, dst_cap, bases, blocks, infos);
 }
-void zk_launch_scan(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals)
+void zk_launch_scan(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals, const uint64_t *d_off, uint32_t first, const uint64_t *out_off)
 {
-    hipLaunchKernelGGL(zk_k_scan, dim3(1), dim3(1024), 0, st, infos, count, bases, totals);
+    hipLaunchKernelGGL(zk_k_scan, dim3(1), dim3(1024), 0, st, infos, count, bases, totals, d_off, first, out_off);
 }
 void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint8_t *lit)
 {
@@ -1176,7 +1178,7 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeqP *seqs,
-                    const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen)
+                    const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen, bool dense)
 {
     // one workgroup per frame: the tile width trades bytes in flight per frame against workgroups per CU
     // (measured on 2 MiB frames: 2048 frames -> 256 lanes.  128 lanes run the kernel alone in 8.9 instead of 9.5 ms -- eight
@@ -1190,7 +1192,10 @@ void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, 
     else if (force_t == 256) ZK_EXEC_LAUNCH(256, false);
     else if (force_t == 512) ZK_EXEC_LAUNCH(512, false);
     else {
-        if (count >= 1024) ZK_EXEC_LAUNCH(256, false); else if (count >= 256) ZK_EXEC_LAUNCH(512, false); else ZK_EXEC_LAUNCH(1024, false);
+        // fewer than 10 output bytes per sequence (libzstd from level 3 up: ~8): a ring of 2 T records ends most 4 KiB tiles
+        // early; 4 T keep them whole (executor -8.5 % there, +2 % on sparser streams, hence the switch)
+        if (count >= 1024 && dense) hipLaunchKernelGGL((zk_k_exec<256, false, 4>), dim3(count), dim3(256), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst, prefix, plen);
+        else if (count >= 1024) ZK_EXEC_LAUNCH(256, false); else if (count >= 256) ZK_EXEC_LAUNCH(512, false); else ZK_EXEC_LAUNCH(1024, false);
     }
 #undef ZK_EXEC_LAUNCH
 }

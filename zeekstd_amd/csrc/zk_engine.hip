@@ -215,11 +215,12 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
 
     zk_profile_begin(e);
     { zk_kernel_timer t(e, ZK_K_WALK_COUNT, st); zk_launch_walk(st, comp, a.comp_size, c_off, d_off, first, count, a.ids, a.out_off, a.dst_cap, nullptr, nullptr, infos); }
-    { zk_kernel_timer t(e, ZK_K_SCAN, st); zk_launch_scan(st, infos, count, bases, words); }
-    ZK_HIP(hipMemcpyAsync(c.h_words, words, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    { zk_kernel_timer t(e, ZK_K_SCAN, st); zk_launch_scan(st, infos, count, bases, words, d_off, first, a.out_off); }
+    ZK_HIP(hipMemcpyAsync(c.h_words, words, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     const uint64_t nblocks = c.h_words[0], nseq = c.h_words[1], nlit = c.h_words[2];
     const uint32_t n_own = (uint32_t)c.h_words[4];        // blocks that need per-block sequence tables
+    const bool dense = nseq * 10 > c.h_words[5];          // fewer than 10 output bytes per sequence (zk_launch_exec)
     if (nblocks > 0xFFFFFFF0ull) return -(int)ZK_E_GENERIC;
     if ((rc = zk_devbuf_reserve(e, c.blocks, (size_t)(nblocks + 1) * sizeof(ZkBlock)))) return rc;
     if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)(nseq + 1) * sizeof(ZkSeqP)))) return rc;
@@ -246,7 +247,7 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
         zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->fse_kernel, count);
         ZK_HIP(hipStreamWaitEvent(st, x.ev_join, 0));
     }
-    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, a.ids, a.out_off, blocks, bases, infos, seqs, lit, (uint8_t *)a.d_dst, (const uint8_t *)a.d_prefix, a.d_prefix ? a.prefix_len : 0); }
+    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, a.ids, a.out_off, blocks, bases, infos, seqs, lit, (uint8_t *)a.d_dst, (const uint8_t *)a.d_prefix, a.d_prefix ? a.prefix_len : 0, dense); }
     if (a.mark_exec) ZK_HIP(hipEventRecord(c.ev_exec, st));
     // packed indexed output: out_off (count + 1 prefix sums) doubles as the d_off of the checksum kernel
     if (a.verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)a.d_dst, a.out_off ? a.out_off : d_off, a.out_off ? 0 : first, count, infos, nullptr); }

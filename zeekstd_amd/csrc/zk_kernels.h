@@ -5,12 +5,12 @@
 
 void zk_launch_walk(hipStream_t st, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
                     uint32_t count, const uint32_t *ids, const uint64_t *out_off, uint64_t dst_cap, const ZkFrameBase *bases, ZkBlock *blocks, ZkFrameInfo *infos);
-void zk_launch_scan(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals);
+void zk_launch_scan(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals, const uint64_t *d_off, uint32_t first, const uint64_t *out_off);
 void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint8_t *lit);
 void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeqP *seqs, int own_kernel, uint32_t frames = 0);
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeqP *seqs,
-                    const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen);
+                    const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen, bool dense = false);
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
                      ZkFrameInfo *infos, uint64_t *hashes);
 void zk_launch_status(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, uint64_t *first_err);
