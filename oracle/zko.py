@@ -167,3 +167,26 @@ def frame_encode(src: bytes, level: int = 1, checksum: bool = False, prefix: byt
     if r < 0:
         raise OracleError(-r)
     return out.raw[:r]
+
+
+def enc_match_debug(src: bytes, level: int = 1, prefix: bytes = None):
+    """The twin's matcher result for ONE frame: list of (sequences as uint64 array in the GPU packing, literal bytes)
+    per block (zko_enc_match_debug)."""
+    import numpy as np
+    src = bytes(src)
+    n = len(src)
+    l = lib()
+    l.zko_enc_match_debug.restype = C.c_int64
+    l.zko_enc_match_debug.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    cap = n // 1024 + 64
+    nseq, nlit = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    seqs, lits = np.zeros(n // 3 + 64, np.uint64), np.zeros(n + 64, np.uint8)
+    prefix = bytes(prefix) if prefix else None
+    nb = l.zko_enc_match_debug(src, n, level, prefix, len(prefix) if prefix else 0, cap, nseq.ctypes.data, nlit.ctypes.data,
+                               seqs.ctypes.data, lits.ctypes.data)
+    assert nb >= 0
+    out, s0, l0 = [], 0, 0
+    for b in range(nb):
+        out.append((seqs[s0:s0 + int(nseq[b])].copy(), lits[l0:l0 + int(nlit[b])].tobytes()))
+        s0 += int(nseq[b]); l0 += int(nlit[b])
+    return out

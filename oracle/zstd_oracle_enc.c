@@ -24,17 +24,14 @@ u64 zko_xxh64(const u8 *p, size_t len, u64 seed);
 
 #define ZKE_BLOCK 131072u
 #define ZKE_HASH_LOG_MAX 16
-#define ZKE_SEGMENT (2u << 20)       /* zk_enc_device.h: bytes of a frame one matcher workgroup takes (a multiple of the 32 KiB blocks) */
+#define ZKE_SEGMENT (256u << 10)     /* zk_enc_device.h: bytes of a frame one matcher workgroup takes (a multiple of the 32 KiB blocks) */
 static u32 g_hash_log = 14;         /* zke_hash_log(level): 2^14 table entries at level <= 1, 2^15 at 2..5 and 0 (= default 3), 2^16 from 6 on */
 static u32 g_minmatch = 6;          /* zke_minmatch(level): 6 for level <= 1 (except 0 = default 3), else 5 */
-#define ZKE_WINDOW 65535u          /* 16-bit positions in the hash table */
+#define ZKE_WINDOW 61376u          /* 65536 - 4096 - 64: what the 64 KiB LDS ring of the GPU matcher still holds behind a group (zk_enc_device.h) */
 
-static int g_tile = 256;            /* parse tile; candidates are looked up ZKE_LSTEP tiles at a time */
-void zko_enc_set_tile(int t) { g_tile = t; }
 
 static inline u32 hb32(u32 v) { return 31 - (u32)__builtin_clz(v); }
 static inline u64 ld64(const u8 *p) { u64 v; memcpy(&v, p, 8); return v; }
-static inline u32 hash5(const u8 *p) { return (u32)(((ld64(p) << 24) * 889523592379ULL) >> (64 - g_hash_log)); }
 
 /* ------------------------------------------------------------------ code tables (RFC 8878 3.1.1.3.2.1.1) */
 static const u8 LL_BITS[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
@@ -337,13 +334,37 @@ static size_t encode_literals(const u8 *lit, size_t n, u8 *dst, size_t cap)
 }
 
 /* ------------------------------------------------------------------ match finder + parse for one block */
-#define ZKE_PARCAP 64u              /* match length measured per position in phase 1; longer ones are extended by the parse */
-#define ZKE_GROUP 8u                /* tiles whose parses run side by side (one wave each on the GPU) */
-#define ZKE_LSTEP 2u                /* tiles per lookup step (the GPU looks up one position per lane: 512 lanes = 2 tiles of 256) */
-/* table: the low 16 bits of (position + 1).  A candidate is p - d with d = (p + 1 - entry) mod 2^16: entries older
- * than the 64 KiB window alias to some position inside it (the byte comparison decides, as for any hash collision);
- * d == 0 (incl. the never-written entry 0 at p == 65535 mod 2^16) and candidates before the first byte are no candidates */
+/* The matcher of zk_k_enc_match (zeekstd_amd/csrc/zk_enc_match.h), restated sequentially.  Positions count from the start
+ * of the segment's record = [history | data]; the GPU keeps the last 64 KiB of the record in an LDS ring, so
+ *   - a table entry is the low 16 bits of a position (= its ring index), a candidate is p - d with d = (p - entry) mod 2^16,
+ *     valid when 1 <= d <= ZKE_WINDOW and d <= p (anything else is stale or aliased; the bytes decide as for any collision);
+ *   - ZKE_WINDOW = 65536 - ZKE_GROUP_POS - 64: the ring also holds the group being worked on and 64 bytes of lookahead.
+ * Work proceeds in GROUPS of 16 tiles x 256 positions.  Per group (STEP == group) or per step of ZKE_STEP positions:
+ *   1. every position looks its 5-byte hash up in the table as it was before the step          -> "far" candidate
+ *   2. the step's positions are inserted, the SMALLEST position of the step wins a slot (order-free rule: the GPU's lanes
+ *      race with compare-and-swap); an older entry always loses
+ *   3. every position looks its slot up again: an earlier position of the same step, if any      -> "near" candidate
+ *      (offsets below the step size, which the stale table of 1. cannot see)
+ *   4. two more candidates per position: offset 1 (byte runs) and R = the offset of the last sequence before the group
+ *   5. per position the longest candidate wins (capped at 64 bytes and at the tile end), ties in the order far < near <
+ *      offset 1 < R; table candidates need minmatch bytes (level), the other two 4.
+ * Then every tile is parsed on its own -- greedy or lazy (level), matches never cross the tile end -- and the tiles are
+ * stitched: literals left over at a tile's end join the next sequence.  Offset_Value: 1 ("repeat the previous offset") when
+ * the offset equals the previous sequence's offset of the same block and the sequence has literals, else offset + 3. */
+#define ZKE_PARCAP 64u              /* match length measured per position; longer ones are extended by the parse */
+#define ZKE_TILE 256u
+#define ZKE_GROUP 16u               /* tiles per group (one wave each on the GPU) */
+#define ZKE_GROUP_POS (ZKE_TILE * ZKE_GROUP)
 typedef struct { u16 table[1 << ZKE_HASH_LOG_MAX]; u32 probe; } enc_state;
+static u32 g_lazy = 0;              /* zke_lazy(level) */
+static u32 g_step = ZKE_GROUP_POS;  /* zke_step(level) */
+
+static inline u32 hashx(const u8 *p)                    /* 5 bytes; two 24-bit multiplies (full-rate v_mul_u32_u24 / v_mad_u32_u24) */
+{
+    u32 lo; memcpy(&lo, p, 4);
+    const u32 a = lo & 0xFFFFFFu, b = (lo >> 24) | ((u32)p[4] << 8);
+    return (u32)(a * 0x9E3779u + b * 0x85EBCBu) >> (32 - g_hash_log);
+}
 
 static u32 match_len(const u8 *a, const u8 *b, const u8 *end)        /* b > a */
 {
@@ -353,67 +374,64 @@ static u32 match_len(const u8 *a, const u8 *b, const u8 *end)        /* b > a */
     return (u32)(b - s);
 }
 
-/* frame-relative positions; base = frame start. Emits sequences for block [bs, be).
- * Tiles are processed in groups of ZKE_GROUP: phase 1 (per-position candidates) runs ZKE_LSTEP tiles at a time against
- * the table as it was before the step, all tiles of a group probing the same offset R (the last match offset
- * before the group); then every tile is parsed on its own -- greedy, left to right, matches never cross the
- * tile end -- and the per-tile results are stitched: literals left over at a tile's end join the next sequence.
- * Offset_Value: 1 ("repeat the previous offset") when the offset equals the previous sequence's offset of the
- * same block and the sequence has literals, else offset + 3.  (After any sequence the decoder's first history
- * entry is that sequence's offset, so this needs no other state and a block never depends on how its
- * predecessor was emitted.) */
+/* history positions [0, hist) enter an empty table, the largest position wins a slot */
+static void table_seed(enc_state *st, const u8 *base, u32 hist, u32 fend)
+{
+    memset(st->table, 0, sizeof st->table);
+    for (u32 v = 0; v < hist; v++) if ((size_t)v + 8 <= fend) st->table[hashx(base + v)] = (u16)v;
+    st->probe = 0;
+}
+
 static u32 find_sequences(enc_state *st, const u8 *base, u32 bs, u32 be, u32 fend, seq_t *sq, u8 *lits, u32 *nlit_out)
 {
     u32 nseq = 0, nlit = 0, anchor = bs, prev_off = 0;
-    static u32 blen[ZKE_GROUP][8192], boff[ZKE_GROUP][8192];
-    const u32 T = (u32)g_tile;
-    for (u32 gs = bs; gs < be; gs += T * ZKE_GROUP) {
+    static u32 blen[ZKE_GROUP_POS], boff[ZKE_GROUP_POS];
+    static u16 e0[ZKE_GROUP_POS];
+    const u32 T = ZKE_TILE;
+    for (u32 gs = bs; gs < be; gs += ZKE_GROUP_POS) {
+        const u32 ge = gs + ZKE_GROUP_POS < be ? gs + ZKE_GROUP_POS : be;
         const u32 R = st->probe;
-        u32 ntiles = 0;
-        /* lookup steps of ZKE_LSTEP tiles: every position of a step sees the table as it was before the step */
-        for (u32 ls = gs; ls < be && ntiles < ZKE_GROUP; ls += T * ZKE_LSTEP) {
-            const u32 le = ls + T * ZKE_LSTEP < be ? ls + T * ZKE_LSTEP : be;
-            for (u32 p = ls; p < le; p++) {
-                const u32 t = ntiles + (p - ls) / T, ts = ls + ((p - ls) / T) * T;
-                const u32 te = ts + T < be ? ts + T : be;
-                const u8 *lim = base + te;                           /* matches stop at the (parse) tile end */
-                u32 l1 = 0, o1 = 0, l2 = 0;
-                const u8 *cap = base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim;
-                if (p + 8 <= fend) {
-                    const u32 d = (p + 1 - st->table[hash5(base + p)]) & 0xFFFFu;
-                    if (d && d <= p) { o1 = d; l1 = match_len(base + p - o1, base + p, cap); }
-                }
-                if (R && R <= p) l2 = match_len(base + p - R, base + p, cap);
-                if (l1 < g_minmatch) l1 = 0;
-                if (l2 < 4) l2 = 0;
-                if (l2 && l2 >= l1) { blen[t][p - ts] = l2; boff[t][p - ts] = R; }
-                else { blen[t][p - ts] = l1; boff[t][p - ts] = o1; }
-            }
-            /* insertion: per slot the LARGEST position of the step wins -- a rule that does not depend on the order of the
-             * writers (the GPU's lanes race with compare-and-swap).  With 16-bit entries "of the step" means: entry - (ls+1)
-             * mod 2^16 is below the step length; everything else is an older entry and loses.  (An entry older than
-             * 2^16 - step positions aliases into the step and may survive it: harmless, the bytes are compared.) */
+        for (u32 ls = gs; ls < ge; ls += g_step) {
+            const u32 le = ls + g_step < ge ? ls + g_step : ge;
+            for (u32 p = ls; p < le; p++) e0[p - ls] = p + 8 <= fend ? st->table[hashx(base + p)] : 0;
             {
-                const u32 b16 = (ls + 1) & 0xFFFFu, span = le - ls;
+                const u32 b16 = ls & 0xFFFFu, span = le - ls;
                 for (u32 p = ls; p < le; p++) if (p + 8 <= fend) {
-                    u16 *slot = &st->table[hash5(base + p)];
-                    const u32 mine = (p + 1 - b16) & 0xFFFFu, cur = (*slot - b16) & 0xFFFFu;     /* step-relative */
-                    if (cur >= span || cur < mine) *slot = (u16)(p + 1);
+                    u16 *slot = &st->table[hashx(base + p)];
+                    const u32 mine = (p - b16) & 0xFFFFu, cur = (*slot - b16) & 0xFFFFu;     /* step-relative */
+                    if (cur >= span || cur > mine) *slot = (u16)p;
                 }
             }
-            ntiles += (le - ls + T - 1) / T;
+            for (u32 p = ls; p < le; p++) {
+                const u32 ts = gs + ((p - gs) / T) * T, te = ts + T < be ? ts + T : be;
+                const u8 *lim = base + te;
+                const u8 *cap = base + p + ZKE_PARCAP < lim ? base + p + ZKE_PARCAP : lim;
+                u32 bl = 0, bo = 0;
+                if (p + 8 <= fend) {
+                    u32 d = (p - e0[p - ls]) & 0xFFFFu;                                      /* far */
+                    if (d && d <= p && d <= ZKE_WINDOW) { const u32 l = match_len(base + p - d, base + p, cap); if (l >= g_minmatch) { bl = l; bo = d; } }
+                    d = (p - st->table[hashx(base + p)]) & 0xFFFFu;                           /* near: an earlier position of this step */
+                    if (d && d <= p - ls) { const u32 l = match_len(base + p - d, base + p, cap); if (l >= g_minmatch && l >= bl) { bl = l; bo = d; } }
+                }
+                if (p >= 1) { const u32 l = match_len(base + p - 1, base + p, cap); if (l >= 4 && l >= bl) { bl = l; bo = 1; } }
+                if (R > 1 && R <= p) { const u32 l = match_len(base + p - R, base + p, cap); if (l >= 4 && l >= bl) { bl = l; bo = R; } }
+                blen[p - gs] = bl; boff[p - gs] = bo;
+            }
         }
         /* per-tile parses + stitching */
-        for (u32 t = 0; t < ntiles; t++) {
-            const u32 ts = gs + t * T, te = ts + T < be ? ts + T : be;
+        for (u32 ts = gs; ts < ge; ts += T) {
+            const u32 te = ts + T < be ? ts + T : be;
             const u8 *lim = base + te;
             u32 p = ts;
             while (p < te) {
-                u32 len = blen[t][p - ts];
+                u32 len = blen[p - gs];
+                if (len && g_lazy) {          /* a longer match one position later, or a clearly longer one two later, wins */
+                    if ((p + 1 < te && blen[p + 1 - gs] > len) || (p + 2 < te && blen[p + 2 - gs] > len + 1)) { p++; continue; }
+                }
                 if (len) {
-                    u32 off = boff[t][p - ts];
+                    const u32 off = boff[p - gs];
                     if (len == ZKE_PARCAP) len += match_len(base + p + len - off, base + p + len, lim);
-                    u32 ll = p - anchor;
+                    const u32 ll = p - anchor;
                     memcpy(lits + nlit, base + anchor, ll); nlit += ll;
                     sq[nseq].ll = ll; sq[nseq].ml = len;
                     sq[nseq].offbase = (ll && off == prev_off) ? 1 : off + 3;
@@ -430,6 +448,63 @@ static u32 find_sequences(enc_state *st, const u8 *base, u32 bs, u32 be, u32 fen
 }
 
 /* ------------------------------------------------------------------ frame */
+/* what a level buys (zk_enc_device.h zke_minmatch / zke_hash_log / zke_lazy / zke_step): level <= 1: matches of 6+ bytes,
+ * 2^14 table entries, greedy parse; 2..5 and 0 (= libzstd's default 3): 5+ bytes, 2^15 entries, lazy parse; 6 and up: the
+ * same with lookup steps of 1024 positions instead of 4096 (fresher tables) */
+static void set_level(int level)
+{
+    const int fast = level != 0 && level < 2;
+    g_minmatch = fast ? 6 : 5;
+    g_hash_log = fast ? 14 : 15;
+    g_lazy = fast ? 0 : 1;
+    g_step = level >= 6 ? 1024 : ZKE_GROUP_POS;
+}
+static u32 block_max_of(size_t n, u32 hist)
+{
+    u32 wlog = 10; while ((1u << wlog) < n && wlog < 17) wlog++;
+    if (hist) wlog = 17;
+    u32 bmax = (1u << wlog) < ZKE_BLOCK ? (1u << wlog) : ZKE_BLOCK;
+    u32 t = 32768; while (t > 4096 && (u64)t * 16 > n) t >>= 1;
+    return t < bmax ? t : bmax;
+}
+
+/* TEST SUPPORT: the matcher's result for one frame, block by block, in the GPU kernel's packing (ll | ml << 20 |
+ * Offset_Value << 40), so that tests/sim (the kernel under a CPU emulator) and the GPU can be compared with it directly.
+ * seqs / lits are filled contiguously; returns the number of blocks (or -1: blk_cap too small). */
+i64 zko_enc_match_debug(const u8 *src, size_t n, int level, const u8 *prefix, size_t plen, u32 blk_cap, u32 *blk_nseq, u32 *blk_nlit, u64 *seqs, u8 *lits)
+{
+    set_level(level);
+    if (!prefix) plen = 0;
+    const u32 hist = (u32)(plen < ZKE_WINDOW ? plen : ZKE_WINDOW) & ~3u;
+    if (n == 0) return 0;
+    const u32 bmax = block_max_of(n, hist);
+    const u32 nblk = (u32)((n + bmax - 1) / bmax);
+    if (nblk > blk_cap) return -1;
+    enc_state *st = calloc(1, sizeof *st);
+    u8 *cat = malloc((size_t)hist + n + 8);
+    if (hist) memcpy(cat, prefix + plen - hist, hist);
+    memcpy(cat + hist, src, n);
+    seq_t *sq = malloc(sizeof(seq_t) * (bmax / 3 + 16));
+    const u8 *sbase = cat;
+    u32 shist = hist, sstart = 0, send = n < ZKE_SEGMENT ? (u32)n : ZKE_SEGMENT;
+    table_seed(st, sbase, shist, shist + send);
+    u64 ns = 0, nl = 0;
+    for (u32 k = 0, bs = 0; bs < n; bs += bmax, k++) {
+        const u32 be = bs + bmax < n ? bs + bmax : (u32)n;
+        if (bs == send) {
+            sstart = bs; send = (u64)bs + ZKE_SEGMENT < n ? bs + ZKE_SEGMENT : (u32)n;
+            shist = ZKE_WINDOW; sbase = cat + hist + sstart - shist;
+            table_seed(st, sbase, shist, shist + (send - sstart));
+        }
+        u32 nlit = 0;
+        const u32 nseq = find_sequences(st, sbase, shist + (bs - sstart), shist + (be - sstart), shist + (send - sstart), sq, lits + nl, &nlit);
+        for (u32 i = 0; i < nseq; i++) seqs[ns + i] = (u64)sq[i].ll | ((u64)sq[i].ml << 20) | ((u64)sq[i].offbase << 40);
+        blk_nseq[k] = nseq; blk_nlit[k] = nlit; ns += nseq; nl += nlit;
+    }
+    free(st); free(cat); free(sq);
+    return nblk;
+}
+
 static size_t nseq_header(u8 *d, u32 n) { if (n < 128) { d[0] = (u8)n; return 1; } if (n < 0x7F00) { d[0] = (u8)((n >> 8) + 128); d[1] = (u8)n; return 2; } d[0] = 255; d[1] = (u8)(n - 0x7F00); d[2] = (u8)((n - 0x7F00) >> 8); return 3; }
 
 i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int level, int checksum, const u8 *prefix, size_t plen);
@@ -445,10 +520,9 @@ i64 zko_frame_encode(const u8 *src, size_t n, u8 *dst, size_t cap, int level, in
  * a 128 KiB window, which covers every offset this matcher can produce. */
 i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int level, int checksum, const u8 *prefix, size_t plen)
 {
-    g_minmatch = (level == 0 || level >= 2) ? 5 : 6;
-    g_hash_log = (level == 0 || (level >= 2 && level <= 5)) ? 15 : level >= 6 ? 16 : 14;
+    set_level(level);
     if (!prefix) plen = 0;
-    const u32 hist = (u32)(plen < ZKE_WINDOW ? plen : ZKE_WINDOW);
+    const u32 hist = (u32)(plen < ZKE_WINDOW ? plen : ZKE_WINDOW) & ~3u;   /* a multiple of 4: the GPU's lanes take 4 positions from aligned ring words */
     if (n > 0x40000000u) return -72;
     size_t p = 0;
     if (cap < 32) return -70;
@@ -471,9 +545,8 @@ i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int le
         cat = malloc((size_t)hist + n + 8);
         memcpy(cat, prefix + plen - hist, hist); memcpy(cat + hist, src, n);
         msrc = cat;
-        for (u32 v = 0; v < hist; v++) if ((size_t)v + 8 <= (size_t)hist + n) st->table[hash5(msrc + v)] = (u16)(v + 1);
     }
-    st->probe = 1;                                                   /* first probe: offset 1 (runs) */
+    table_seed(st, msrc, hist, (u32)(hist + n < ZKE_SEGMENT + hist ? hist + n : ZKE_SEGMENT + hist));
     i64 rc = 0;
     u32 bmax = (1u << wlog) < ZKE_BLOCK ? (1u << wlog) : ZKE_BLOCK;
     /* blocks are cut smaller than the format's maximum on purpose: a block's sequence bitstream is one serial chain
@@ -486,7 +559,7 @@ i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int le
     u32 *bseq = malloc(sizeof(u32) * (nblk + 1)), *blit = malloc(sizeof(u32) * (nblk + 1)), *bnlit = malloc(sizeof(u32) * (nblk + 1));
     u32 hll[36] = {0}, hof[32] = {0}, hml[53] = {0}, nseq_frame = 0, nlit_frame = 0;
     /* The matcher works on segments of ZKE_SEGMENT bytes (one GPU workgroup each, so that a frame larger than that is not
-     * one serial job): a segment after the first starts with an empty table that receives the positions of the 65 535 bytes
+     * one serial job): a segment after the first starts with an empty table that receives the positions of the ZKE_WINDOW bytes
      * before it -- exactly what a prefix does for a frame -- its positions count from that history's start, and nothing of
      * it looks past its own end.  Frames up to ZKE_SEGMENT bytes are one segment: nothing changes for them. */
     const u8 *sbase = msrc;                                          /* the segment's position 0 */
@@ -498,9 +571,7 @@ i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int le
             sstart = bs; send = (u64)bs + ZKE_SEGMENT < n ? bs + ZKE_SEGMENT : (u32)n;
             shist = ZKE_WINDOW;
             sbase = msrc + hist + sstart - shist;
-            memset(st->table, 0, sizeof st->table);
-            for (u32 v = 0; v < shist; v++) if ((size_t)v + 8 <= (size_t)shist + (send - sstart)) st->table[hash5(sbase + v)] = (u16)(v + 1);
-            st->probe = 1;
+            table_seed(st, sbase, shist, shist + (send - sstart));
         }
         bseq[k] = nseq_frame; blit[k] = nlit_frame;
         u32 nseq = find_sequences(st, sbase, shist + (bs - sstart), shist + (be - sstart), shist + (send - sstart), sq + nseq_frame, lits + nlit_frame, &nlit);

@@ -173,6 +173,48 @@ def sim_decode(comp, frames, first=0, count=None, B=16, CH=1024, prefix=None, qu
     return rc, out[:out_len].tobytes(), st[:count]
 
 
+_ENC_SIM = None
+
+
+def enc_sim_lib():
+    """tests/sim/zk_enc_sim.cpp compiled with g++: the encoder's match + parse kernel (zk_enc_match.h, the source hipcc
+    compiles) run on the CPU, a fiber per lane."""
+    global _ENC_SIM
+    if _ENC_SIM is None:
+        sim = os.path.join(ROOT, "tests", "sim")
+        csrc = os.path.join(ROOT, "zeekstd_amd", "csrc")
+        so = os.path.join(sim, "libzk_enc_sim.so")
+        deps = [os.path.join(sim, "zk_enc_sim.cpp"), os.path.join(sim, "hip_wg_emu.h")] + \
+               [os.path.join(csrc, h) for h in ("zk_enc_match.h", "zk_enc_plan.h", "zk_enc_device.h", "zk_device.h")]
+        if not os.path.exists(so) or max(os.path.getmtime(d) for d in deps) > os.path.getmtime(so):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, deps[0]])
+        l = C.CDLL(so)
+        l.zk_enc_sim_match.restype = C.c_int
+        l.zk_enc_sim_match.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32] + [C.c_void_p] * 6 + \
+                                      [C.c_uint64, C.c_void_p, C.c_uint64]
+        _ENC_SIM = l
+    return _ENC_SIM
+
+
+def enc_sim_match(data, frame_size, level, prefix=None):
+    """-> list of (sequences as a uint64 array, literal bytes, block size) per block, from the emulated kernel"""
+    data = bytes(data)
+    n = len(data)
+    cap = n // 1024 + 64 * ((n + frame_size - 1) // frame_size) + 64
+    nseq, nlit, bsz = (np.zeros(cap, np.uint32) for _ in range(3))
+    seq_at, lit_at = (np.zeros(cap, np.uint64) for _ in range(2))
+    seqs = np.zeros(n // 4 + 2 * cap + 64, np.uint64)
+    lits = np.zeros(n + 64, np.uint8)
+    src = np.frombuffer(data + b"\0" * 8, np.uint8)
+    pre = np.frombuffer(bytes(prefix), np.uint8) if prefix else None
+    nb = enc_sim_lib().zk_enc_sim_match(src.ctypes.data, n, frame_size, level, pre.ctypes.data if prefix else None, len(prefix) if prefix else 0,
+                                        cap, nseq.ctypes.data, nlit.ctypes.data, bsz.ctypes.data, seq_at.ctypes.data, lit_at.ctypes.data,
+                                        seqs.ctypes.data, len(seqs), lits.ctypes.data, len(lits))
+    assert nb >= 0
+    return [(seqs[int(seq_at[b]):int(seq_at[b]) + int(nseq[b])].copy(), lits[int(lit_at[b]):int(lit_at[b]) + int(nlit[b])].tobytes(), int(bsz[b]))
+            for b in range(nb)]
+
+
 # ---------------------------------------------------------------- GPU engine
 @pytest.fixture(scope="session")
 def engine():

@@ -1,0 +1,50 @@
+// zk_enc_sim.cpp -- TEST HARNESS (never shipped, never linked into libzeekstd_amd.so).
+// Runs the encoder's match + parse kernel (zeekstd_amd/csrc/zk_enc_match.h, the very source hipcc compiles for gfx950)
+// on the CPU, one workgroup at a time, under the fiber emulator of hip_wg_emu.h, with the frame / block / segment plan the
+// engine uses (zk_enc_plan.h).  The -m "not gpu" suite compares its sequences and literals with the CPU twin
+// (oracle/zstd_oracle_enc.c) block by block -- the kernel's logic is checked before a GPU is involved.
+#include "hip_wg_emu.h"
+#include "../../zeekstd_amd/csrc/zk_enc_match.h"
+#include "../../zeekstd_amd/csrc/zk_enc_plan.h"
+
+// Encode plan + match kernel over src[0, n) cut into frames of frame_size bytes; prefix (may be null) is what
+// zk_encode_frames_prefix references.  Outputs, per block b (in plan order): blk_nseq[b], blk_nlit[b], blk_bsz[b]; the
+// block's sequences packed at seqs + seq_at[b] (ll | ml << 20 | Offset_Value << 40), its literals at lits + lit_at[b].
+// Returns the number of blocks, or -1 when an output array is too small.
+extern "C" int zk_enc_sim_match(const uint8_t *src, uint64_t n, uint32_t frame_size, int level, const uint8_t *prefix, uint64_t prefix_len,
+                                uint32_t blk_cap, uint32_t *blk_nseq, uint32_t *blk_nlit, uint32_t *blk_bsz, uint64_t *seq_at, uint64_t *lit_at,
+                                uint64_t *seqs, uint64_t seq_cap, uint8_t *lits, uint64_t lit_cap)
+{
+    const uint32_t hist = prefix ? zke_prefix_hist(prefix_len) : 0;
+    ZkEncPlan pl;
+    if (!zke_plan_count(n, frame_size, hist, &pl)) return -1;
+    if (pl.nb > blk_cap) return -1;
+    std::vector<ZkEncFrame> frames(pl.nf), segs(pl.nseg + 1);
+    std::vector<ZkEncBlock> blocks(pl.nb + 1);
+    zke_plan_fill(n, frame_size, level, &pl, frames.data(), blocks.data(), segs.data(), nullptr);
+    if (pl.seq_total > seq_cap || n > lit_cap) return -1;
+    // the matcher's source: the frames in place, or [prefix tail | frame] records (zk_k_enc_stage_hist)
+    std::vector<uint8_t> stage;
+    const uint8_t *msrc = src;
+    if (hist) {
+        stage.resize((size_t)pl.nf * ((size_t)hist + frame_size) + 64);
+        for (uint32_t f = 0; f < pl.nf; f++) {
+            memcpy(stage.data() + frames[f].m_off, prefix + (prefix_len - hist), hist);
+            memcpy(stage.data() + frames[f].m_off + hist, src + frames[f].src_off, frames[f].d_size);
+        }
+        msrc = stage.data();
+    }
+    for (uint32_t s = 0; s < pl.nseg; s++) {
+        auto run = [&]() {
+            if (zke_fast(level)) zk_k_enc_match<14, 0, 4096>(msrc, segs.data(), blocks.data(), seqs, lits);
+            else if (zke_step(level) == 1024) zk_k_enc_match<15, 1, 1024>(msrc, segs.data(), blocks.data(), seqs, lits);
+            else zk_k_enc_match<15, 1, 4096>(msrc, segs.data(), blocks.data(), seqs, lits);
+        };
+        emu_run_workgroup(ZKE_THREADS, s, run);
+    }
+    for (uint32_t b = 0; b < pl.nb; b++) {
+        blk_nseq[b] = blocks[b].nseq; blk_nlit[b] = blocks[b].nlit; blk_bsz[b] = blocks[b].bsz;
+        seq_at[b] = blocks[b].seq_base; lit_at[b] = blocks[b].lit_base;
+    }
+    return (int)pl.nb;
+}

@@ -6,24 +6,32 @@
 #include "zk_device.h"
 
 constexpr uint32_t ZKE_BLOCK = 131072;
-constexpr uint32_t ZKE_HASH_LOG = 14;             // level <= 1; zke_hash_log(level) otherwise
-// ZSTD_c_compressionLevel (encode.rs:170, 281-282) maps to the shortest match the parser takes from the hash table:
-// level 1 and below (the "fast" end, what BASELINE.json's configs use) 6 bytes -- fewer, longer sequences; level 2 and up,
-// and 0 = libzstd's default 3 (cli/src/args.rs:192), 5 bytes: 2.468 instead of 2.443 on the 8d text for ~3 % more sequences.
-ZK_HD uint32_t zke_minmatch(int level) { return level == 0 || level >= 2 ? 5u : 6u; }
-// ... and a larger hash table: the entries of the matcher's table, log2 (zk_k_enc_match: the table is the kernel's LDS, so a
-// level trades workgroups per CU for ratio: 2.57 at 2^15, 2.63 at 2^16 against 2.47 on the 8d text)
-ZK_HD uint32_t zke_hash_log(int level) { return level == 0 || (level >= 2 && level <= 5) ? 15u : level >= 6 ? 16u : 14u; }
-constexpr uint32_t ZKE_WINDOW = 65535;
-constexpr uint32_t ZKE_TILE = 256;                // parse tile: matches never cross its end
-constexpr uint32_t ZKE_LSTEP = 2;                 // tiles per lookup step (one position per lane: 512 lanes)
-constexpr uint32_t ZKE_PARCAP = 64;
-constexpr uint32_t ZKE_GROUP = 8;                // tiles parsed side by side, one wave each
-// The matcher's unit of work is a SEGMENT of a frame, one workgroup each: a frame larger than this is not one serial job.
-// A segment after a frame's first starts with an empty table that receives the positions of the ZKE_WINDOW bytes before it
-// (what a prefix does for a frame), counts its positions from that history's start and does not look past its own end; a
-// frame of up to ZKE_SEGMENT bytes is one segment.  (A multiple of the 32 KiB blocks every frame this large is cut into.)
-constexpr uint32_t ZKE_SEGMENT = 2u << 20;
+// What ZSTD_c_compressionLevel (encode.rs:170, 281-282) buys in the matcher (zk_enc_match.h; the CPU twin
+// oracle/zstd_oracle_enc.c applies the same table):
+//   level <= 1 (the "fast" end, what BASELINE.json's configs use): table matches of 6+ bytes, 2^14 table entries, greedy parse
+//   level 2..5 and 0 = libzstd's default 3 (cli/src/args.rs:192): 5+ bytes, 2^15 entries, lazy parse (a longer match one or
+//     two positions later wins)
+//   level >= 6: the same with lookup steps of 1024 positions instead of 4096 (fresher tables: +3 % on source code)
+// 8d text: 2.470 / 2.587 / 2.585; python sources: 3.29 / 3.46 / 3.57.
+ZK_HD bool zke_fast(int level) { return level != 0 && level < 2; }
+ZK_HD uint32_t zke_minmatch(int level) { return zke_fast(level) ? 6u : 5u; }
+ZK_HD uint32_t zke_hash_log(int level) { return zke_fast(level) ? 14u : 15u; }
+ZK_HD uint32_t zke_lazy(int level) { return zke_fast(level) ? 0u : 1u; }
+constexpr uint32_t ZKE_TILE = 256;                // parse tile: matches never cross its end; one wave each
+constexpr uint32_t ZKE_GROUP = 16;                // tiles per group = waves per workgroup
+constexpr uint32_t ZKE_GROUP_POS = ZKE_TILE * ZKE_GROUP;
+ZK_HD uint32_t zke_step(int level) { return level >= 6 ? 1024u : ZKE_GROUP_POS; }
+constexpr uint32_t ZKE_PARCAP = 64;               // match length measured per position; the parse extends longer ones
+// The matcher keeps the last 64 KiB of its input in an LDS ring: the group it works on, 64 bytes of lookahead, and the
+// window behind the group -- the largest offset it produces.
+constexpr uint32_t ZKE_RING = 65536;
+constexpr uint32_t ZKE_WINDOW = ZKE_RING - ZKE_GROUP_POS - 64;       // 61376
+// The matcher's unit of work is a SEGMENT of a frame, one workgroup each: a 2 MiB frame spreads over 8 CUs, and 2048 such
+// frames are 16384 workgroups.  A segment after a frame's first starts with an empty table that receives the positions of the
+// ZKE_WINDOW bytes before it (what a prefix does for a frame), counts its positions from that history's start and does not
+// look past its own end; a frame of up to ZKE_SEGMENT bytes is one segment.  (A multiple of the blocks every frame this
+// large is cut into: 16 KiB up to 512 KiB, 32 KiB above.)
+constexpr uint32_t ZKE_SEGMENT = 256u << 10;
 
 // Block size the encoder cuts a frame of d_size bytes into.  Blocks are cut smaller than the format's maximum on purpose:
 // a block's sequence bitstream is one serial chain for the decoder, so more, shorter blocks = more parallel chains
@@ -184,7 +192,8 @@ struct ZkHufBuild {             // scratch of one tree build
     uint8_t idx[128], depth[256];
 };
 
-ZK_HD uint32_t zke_hash5(const uint8_t *p) { return (uint32_t)(((zk_ld64(p) << 24) * 889523592379ull) >> (64 - ZKE_HASH_LOG)); }
+// hash of the 5 bytes lo (4) + b4: two 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 run at full rate, a 64-bit multiply at a quarter)
+ZK_HD uint32_t zke_hash(uint32_t lo, uint32_t b4, uint32_t hlog) { const uint32_t a = lo & 0xFFFFFFu, b = (lo >> 24) | (b4 << 8); return (a * 0x9E3779u + b * 0x85EBCBu) >> (32 - hlog); }
 
 ZK_HD uint32_t zke_ll_code(uint32_t ll)
 {

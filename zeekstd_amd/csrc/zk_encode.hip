@@ -8,12 +8,8 @@
 //
 // Pipeline (one stream, everything resident in HBM):
 //   zk_k_xxh64        (checksum_flag) XXH64 of every frame's input
-//   zk_k_enc_match    one workgroup (8 waves) per frame: tiles of 256 positions, 8 per group.  Per group: four lookup
-//                     steps (one position per lane: 5-byte hash into a 2^14-entry LDS table of 16-bit entries, candidate
-//                     bytes requested, compare-and-swap insertion) behind LDS-only barriers; comparisons from
-//                     registers (candidate + previous offset), matches of 8+ bytes measured from an LDS queue by all
-//                     lanes; wave w parses tile w greedily (ballot skipping); a stitch pass joins the tiles -> packed
-//                     sequences; per block the literals are gathered through a 64-bit accumulator.
+//   zk_k_enc_match    (zk_enc_match.h) one workgroup (16 waves) per segment of <= 256 KiB of a frame; the segment's last
+//                     64 KiB in an LDS ring, hash table, candidates and parse in LDS -> packed sequences + literals per block.
 //                     Prefix mode: the matcher reads [prefix tail | frame] records (zk_k_enc_stage_hist)
 //   zk_k_enc_entropy  one workgroup per 16 blocks: literal histograms, Huffman lengths (<= 11 bits) while the other
 //                     waves precompute every sequence's codes and extra bits, then 64 literal streams (wave 0) and 16
@@ -31,384 +27,7 @@
 #include "zk_kernels.h"
 
 // ------------------------------------------------------------------------------------------------ match + parse
-constexpr int ZKE_THREADS = 512;                         // 8 waves: 8 tiles of a group are parsed side by side
-
-__device__ __forceinline__ uint32_t zke_match_len(const uint8_t *a, const uint8_t *b, const uint8_t *end)   // b > a
-{
-    const uint8_t *s = b;
-    while (b + 8 <= end) {
-        uint64_t x = zk_ld64(a) ^ zk_ld64(b);
-        if (x) return (uint32_t)(b - s) + (uint32_t)(__builtin_ctzll(x) >> 3);
-        a += 8; b += 8;
-    }
-    while (b < end && *a == *b) { a++; b++; }
-    return (uint32_t)(b - s);
-}
-
-// Common prefix of a.. and b.. (b > a) over at most n <= 56 bytes, the loads issued in two batches (32 + 24 bytes of
-// either side) instead of one dependent round trip per 8 bytes.  safe = bytes readable from b on (the comparison may
-// look past n, the result is clamped); short of 56 the byte-exact loop does it.
-__device__ __forceinline__ uint32_t zke_match_ext(const uint8_t *a, const uint8_t *b, uint32_t n, uint32_t safe)
-{
-    if (safe < 56) return zke_match_len(a, b, b + n);
-    const uint64_t x0 = zk_ld64(a) ^ zk_ld64(b), x1 = zk_ld64(a + 8) ^ zk_ld64(b + 8),
-                   x2 = zk_ld64(a + 16) ^ zk_ld64(b + 16), x3 = zk_ld64(a + 24) ^ zk_ld64(b + 24);
-    uint32_t l = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3) : x1 ? 8 + (uint32_t)(__builtin_ctzll(x1) >> 3)
-               : x2 ? 16 + (uint32_t)(__builtin_ctzll(x2) >> 3) : x3 ? 24 + (uint32_t)(__builtin_ctzll(x3) >> 3) : 32;
-    if (l == 32 && n > 32) {
-        const uint64_t y0 = zk_ld64(a + 32) ^ zk_ld64(b + 32), y1 = zk_ld64(a + 40) ^ zk_ld64(b + 40), y2 = zk_ld64(a + 48) ^ zk_ld64(b + 48);
-        l = y0 ? 32 + (uint32_t)(__builtin_ctzll(y0) >> 3) : y1 ? 40 + (uint32_t)(__builtin_ctzll(y1) >> 3)
-          : y2 ? 48 + (uint32_t)(__builtin_ctzll(y2) >> 3) : 56;
-    }
-    return l < n ? l : n;
-}
-
-// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load in flight.
-__device__ __forceinline__ void zke_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// per-tile sequence as the parse leaves it in LDS: ll (12) | ml (11) << 12 | offset (17) << 23 | position in tile (10) << 40
-__device__ __forceinline__ uint64_t zke_tpack(uint32_t ll, uint32_t ml, uint32_t off, uint32_t pit) { return (uint64_t)ll | ((uint64_t)ml << 12) | ((uint64_t)off << 23) | ((uint64_t)pit << 40); }
-
-// Insert position p into slot h of the 16-bit hash table.  Per slot the largest position of the step wins, whatever
-// the order of the writers: an entry counts as "of the step" when entry - b16 (mod 2^16) is below `span` (b16 = low
-// 16 bits of step start + 1), anything else is older and loses.  The lanes race with compare-and-swap on the word
-// that holds two entries; oracle/zstd_oracle_enc.c applies the same rule sequentially.
-__device__ __forceinline__ void zke_table_insert(uint32_t *table, uint32_t h, uint32_t p, uint32_t b16, uint32_t span)
-{
-    uint32_t *w = &table[h >> 1];
-    const uint32_t sh = 16 * (h & 1), mine16 = (p + 1) & 0xFFFFu, mrel = (mine16 - b16) & 0xFFFFu;
-    uint32_t old = *w;
-    for (;;) {
-        const uint32_t cur = (((old >> sh) & 0xFFFFu) - b16) & 0xFFFFu;
-        if (!(cur >= span || cur < mrel)) return;
-        const uint32_t seen = atomicCAS(w, old, (old & ~(0xFFFFu << sh)) | (mine16 << sh));
-        if (seen == old) return;
-        old = seen;
-    }
-}
-
-// With a prefix (zk_encode_frames_prefix) the matcher does not read the frame in place: `src` is then a staging
-// buffer that holds, per frame, [last `hist` bytes of the prefix | the frame] (zk_k_enc_stage_hist), all positions
-// below are offsets into that record, and the history's positions enter the hash table before the first block --
-// so a match may start in the prefix and run on into the frame with no special case anywhere.
-// HLOG: size of the hash table = what a level buys (zke_hash_log: 2^14 entries at level <= 1, 2^15 at levels 2-5 and at 0 =
-// the default, 2^16 from level 6 on; 2.44 / 2.57 / 2.63 on the 8d text at the same parse).  The table is the kernel's LDS:
-//   2^14: 52 KiB -> three workgroups = 24 waves per CU, <= 80 VGPRs (WAVES = 6 per SIMD)
-//   2^15: 76 KiB -> two workgroups per CU (the queue shrinks to 512 entries and shares its memory with the tile
-//         sequences, whose lifetimes do not overlap), <= 128 VGPRs
-//   2^16: 140 KiB -> one workgroup per CU
-template <int HLOG, int WAVES>
-__global__ __launch_bounds__(ZKE_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES))) void zk_k_enc_match(
-const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
-                                                              uint64_t *seqs, uint32_t *mpos, uint8_t *lits)
-{
-    // 16-bit entries, two per word: the low 16 bits of (position + 1).  A candidate is p - d with d = (p + 1 - entry)
-    // mod 2^16: entries older than the 64 KiB window alias to some position inside it and the byte comparison decides,
-    // as for any hash collision.  Half the LDS of 32-bit entries: three workgroups per CU instead of two.
-    constexpr uint32_t ZKE_HASH_LOG = (uint32_t)HLOG;
-    constexpr bool SHARE = HLOG > 14;                      // queue and tile sequences in the same LDS bytes
-    constexpr uint32_t ZKE_QCAP = SHARE ? 512u : 960u;     // matches waiting to be measured; <= 1024 (10-bit queue index)
-    static_assert(ZKE_QCAP >= (uint32_t)ZKE_THREADS && ZKE_QCAP <= 1024, "queue");
-    constexpr uint32_t TSEQ_N = ZKE_TILE / 4 + 4;
-    __shared__ uint32_t table[1 << (ZKE_HASH_LOG - 1)];
-    __shared__ uint32_t best[ZKE_GROUP][ZKE_TILE];         // len (7 bits) | offset << 8
-    __shared__ uint64_t tseq_mem[ZKE_GROUP][TSEQ_N];
-    __shared__ uint32_t tcount[ZKE_GROUP], ttail[ZKE_GROUP];
-    __shared__ uint32_t queue_mem[SHARE ? 1 : 2 * ZKE_QCAP], s_qn;       // matches of 8+ bytes waiting to be measured (compare phase)
-    static_assert(!SHARE || sizeof(tseq_mem) >= 2 * ZKE_QCAP * sizeof(uint32_t), "the queue fits into the tile sequences' bytes");
-    uint64_t (*tseq)[TSEQ_N] = tseq_mem;
-    uint32_t *s_queue = SHARE ? reinterpret_cast<uint32_t *>(&tseq_mem[0][0]) : queue_mem;
-    uint32_t *s_qres = s_queue + ZKE_QCAP;
-    uint32_t *s_scan = s_queue;                                         // the gather pass reuses it (ZKE_THREADS words)
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const ZkEncFrame fr = frames[blockIdx.x];
-    const uint8_t *base = src + fr.m_off;
-    const uint32_t hist = fr.hist, fend = hist + fr.d_size;
-    for (uint32_t i = tid; i < (1u << (ZKE_HASH_LOG - 1)); i += ZKE_THREADS) table[i] = 0;
-    __syncthreads();
-    for (uint32_t v = tid; v < hist; v += ZKE_THREADS)               // history positions (< 2^16, no wrap): the largest one wins a slot
-        if (v + 8 <= fend) zke_table_insert(table, (uint32_t)(((zk_ld64(base + v) << 24) * 889523592379ull) >> (64 - ZKE_HASH_LOG)), v, 0, 65536);       // b16 = 0: plain numeric maximum, the empty entry 0 loses
-    if (hist) __syncthreads();
-    uint32_t probe = 1;                                    // offset of the last match taken (same value in every thread)
-    for (uint32_t bi = 0; bi < fr.n_blocks; bi++) {
-        const uint32_t bs = hist + bi * fr.block_max;
-        const uint32_t be = bs + fr.block_max < fend ? bs + fr.block_max : fend;
-        ZkEncBlock *blk = &blocks[fr.block_base + bi];
-        uint64_t *sq = seqs + blk->seq_base;
-        uint32_t *mp = mpos + blk->seq_base;
-        uint8_t *lt = lits + blk->lit_base;
-        // block-level parse state, kept identical in every thread
-        uint32_t nseq = 0, carry = 0, prev_off = 0;
-        for (uint32_t gs = bs; gs < be; gs += ZKE_TILE * ZKE_GROUP) {
-            const uint32_t R = probe;
-            // phase 1, one lookup step (ZKE_LSTEP tiles, one position per lane) after the other: every position of a step
-            // sees the table as it was before the step.  The candidate bytes (a divergent 8-byte load per lane somewhere in
-            // the last 64 KiB: the slowest of 512 such loads used to end every step) are only *requested* here; lookups and
-            // insertions of the group's steps go on behind barriers that wait for LDS alone, and the comparisons follow
-            // once all of the group's candidates are on their way.  All loads are unconditional (clamped addresses), so the
-            // waits count exactly.
-            constexpr int NSTEP = (int)(ZKE_GROUP / ZKE_LSTEP);
-            uint64_t W[NSTEP], C1[NSTEP];
-            uint32_t O1[NSTEP];
-            const uint32_t hi8 = fend >= 8 ? fend - 8 : 0;                               // last position with 8 readable bytes
-#pragma unroll
-            for (int st = 0; st < NSTEP; st++) {
-                const uint32_t p = gs + st * ZKE_THREADS + tid;
-                W[st] = fend >= 8 ? zk_ld64(base + (p < hi8 ? p : hi8)) : 0;
-            }
-#pragma unroll
-            for (int st = 0; st < NSTEP; st++) {
-                const uint32_t ls = gs + st * ZKE_THREADS;
-                if (ls < be) {
-                    const uint32_t le = ls + ZKE_THREADS < be ? ls + ZKE_THREADS : be;
-                    const uint32_t p = ls + tid, pc = p < hi8 ? p : hi8;
-                    const bool wide8 = p < le && p + 8 <= fend;
-                    uint32_t hsh = 0xFFFFFFFFu, o1 = 0;
-                    if (wide8) {
-                        hsh = (uint32_t)(((W[st] << 24) * 889523592379ull) >> (64 - ZKE_HASH_LOG));
-                        const uint32_t d = (p + 1 - (table[hsh >> 1] >> (16 * (hsh & 1)))) & 0xFFFFu;
-                        if (d && d <= p) o1 = d;
-                    }
-                    O1[st] = o1;
-                    C1[st] = fend >= 8 ? zk_ld64(base + pc - o1) : 0;                    // o1 == 0: the lane's own bytes again (unused)
-                    zke_lds_barrier();
-                    // the largest position of the step wins a slot.  A lane that sees its own hash 1, 2, 3, 4, 6 or 8 lanes up
-                    // cannot win and stays out of the race: on a run of equal bytes (or a period of 2, 3, 4, 6, 8 bytes:
-                    // samples, pixels, words) all 512 lanes of a step would otherwise fight over a few LDS words, ~7 rounds
-                    // of serialised compare-and-swaps each (zero-filled input ran at 4 GiB/s).  The table ends the step in
-                    // the same state, so the output bytes do not change.
-                    // (row_shl:d inside the rows of 16 lanes -- one vector instruction per distance; the last lanes of a row see
-                    // no neighbour and race as before, a few dozen per step instead of 512.)
-                    bool ins = hsh != 0xFFFFFFFFu;
-#define ZKE_DOMINATED(D) if ((uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)hsh, 0x100 + (D), 0xF, 0xF, false) == hsh) ins = false;
-                    ZKE_DOMINATED(1) ZKE_DOMINATED(2) ZKE_DOMINATED(3) ZKE_DOMINATED(4) ZKE_DOMINATED(6) ZKE_DOMINATED(8)
-#undef ZKE_DOMINATED
-                    if (ins) zke_table_insert(table, hsh, p, (ls + 1) & 0xFFFFu, le - ls);
-                    zke_lds_barrier();
-                }
-            }
-            // comparisons, from registers: 0..8 equal bytes per candidate.  A candidate that matches all 8 (and has room
-            // for more) is queued in LDS; the queue is then measured by all lanes together, one lane per 8-byte word of a
-            // queued match, four words in flight per lane -- one or two rounds of memory latency per GROUP instead of up
-            // to two per step.  LF[st]: per candidate 11 bits, the length so far or 0x400 | queue index.
-            uint32_t ntiles = 0;
-            uint32_t LF[NSTEP];
-            if (tid == 0) s_qn = 0;
-            zke_lds_barrier();
-            auto ldr = [&](int st) { const uint32_t p = gs + st * ZKE_THREADS + tid, pc = p < hi8 ? p : hi8; return fend >= 8 ? zk_ld64(base + pc - (R <= pc ? R : 0)) : 0; };
-            uint64_t c2n = ldr(0);                       // bytes at the previous offset R (coalesced, cheap): requested one step ahead
-#pragma unroll
-            for (int st = 0; st < NSTEP; st++) {
-                const uint32_t ls = gs + st * ZKE_THREADS;
-                const uint64_t c2 = c2n;
-                if (st + 1 < NSTEP) c2n = ldr(st + 1);
-                LF[st] = 0;
-                if (ls < be) {
-                    const uint32_t le = ls + ZKE_THREADS < be ? ls + ZKE_THREADS : be;
-                    const uint32_t p = ls + tid;
-                    const uint32_t ts = ls + (tid / ZKE_TILE) * ZKE_TILE, te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
-                    if (p < le) {
-                        const uint32_t n = te - p < ZKE_PARCAP ? te - p : ZKE_PARCAP;      // a match may not leave the tile
-                        if (O1[st] == R) O1[st] = 0;                                       // the same candidate twice: the R form wins a tie anyway
-                        uint32_t f[2] = {0, 0};
-                        if (p + 8 <= fend) {
-#pragma unroll
-                            for (int c = 0; c < 2; c++) {
-                                const uint32_t off = c == 0 ? O1[st] : R;
-                                if (c == 0 ? off != 0 : (R && R <= p)) {
-                                    const uint64_t x = W[st] ^ (c == 0 ? C1[st] : c2);
-                                    uint32_t l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8;
-                                    if (l == 8 && n > 8) {
-                                        const uint32_t qi = atomicAdd(&s_qn, 1u);
-                                        if (qi < ZKE_QCAP) { s_queue[qi] = (p - gs) | (off << 11); s_qres[qi] = n; l = 0x400 | qi; }
-                                        else l = 8 + zke_match_ext(base + p + 8 - off, base + p + 8, n - 8, fend - (p + 8));     // queue full (very repetitive data)
-                                    }
-                                    f[c] = l < n || l >= 0x400 ? l : n;
-                                }
-                            }
-                        } else if (R && R <= p) f[1] = zke_match_len(base + p - R, base + p, base + p + n);   // the frame's last 7 bytes
-                        LF[st] = f[0] | (f[1] << 11);
-                    }
-                    ntiles += (le - ls + ZKE_TILE - 1) / ZKE_TILE;
-                }
-            }
-            zke_lds_barrier();
-            {
-                const uint32_t nq = s_qn < ZKE_QCAP ? s_qn : ZKE_QCAP;
-                for (uint32_t i0 = tid; i0 < nq * 8; i0 += 4 * ZKE_THREADS) {
-                    uint64_t xa[4], xb[4];
-                    uint32_t lim[4], at[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {                                         // word k of queue entry e: bytes [8 + 8k, 16 + 8k) of the match
-                        const uint32_t it = i0 + u * ZKE_THREADS, e = (it >> 3) < nq ? it >> 3 : 0, k = it & 7;
-                        const uint32_t ent = s_queue[e], pos = gs + (ent & 0x7FF), off = ent >> 11;
-                        const uint32_t o = 8 + 8 * k;
-                        lim[u] = (it >> 3) < nq ? s_qres[e] : 0;                          // n of the entry (or a smaller mismatch already found)
-                        at[u] = o;
-                        const uint32_t q = pos + o < hi8 ? pos + o : hi8;                 // clamped: the frame's last bytes are compared bytewise below
-                        xa[u] = zk_ld64(base + q - off); xb[u] = zk_ld64(base + q);
-                        if (pos + o + 8 > fend && o < lim[u]) {                           // rare: word crosses the frame end
-                            const uint32_t m = o + zke_match_len(base + pos + o - off, base + pos + o, base + fend);
-                            if (m < lim[u]) atomicMin(&s_qres[e], m);
-                            lim[u] = 0;
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint64_t x = xa[u] ^ xb[u];
-                        const uint32_t it = i0 + u * ZKE_THREADS;
-                        if (x && at[u] < lim[u]) { const uint32_t m = at[u] + (uint32_t)(__builtin_ctzll(x) >> 3); if (m < lim[u]) atomicMin(&s_qres[it >> 3], m); }
-                    }
-                }
-            }
-            zke_lds_barrier();
-#pragma unroll
-            for (int st = 0; st < NSTEP; st++) {
-                const uint32_t ls = gs + st * ZKE_THREADS;
-                if (ls < be) {
-                    const uint32_t le = ls + ZKE_THREADS < be ? ls + ZKE_THREADS : be;
-                    const uint32_t p = ls + tid, sub = tid / ZKE_TILE, ts = ls + sub * ZKE_TILE;
-                    if (p < le) {
-                        uint32_t l1 = LF[st] & 0x7FF, l2 = LF[st] >> 11;
-                        if (l1 & 0x400) l1 = s_qres[l1 & 0x3FF];
-                        if (l2 & 0x400) l2 = s_qres[l2 & 0x3FF];
-                        if (l1 < fr.minmatch) l1 = 0;
-                        if (l2 < 4) l2 = 0;
-                        best[2 * st + sub][p - ts] = (l2 && l2 >= l1) ? (l2 | (R << 8)) : (l1 | (O1[st] << 8));
-                    }
-                }
-            }
-            __syncthreads();
-            // phase 2: wave w parses tile w on its own (greedy, matches end at the tile end)
-            if (wave < ntiles) {
-                const uint32_t ts = gs + wave * ZKE_TILE, te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
-                const uint8_t *lim = base + te;
-                uint32_t p = ts, anchor = ts, c = 0;
-                while (p < te) {
-                    const uint32_t pos = p + lane;
-                    const uint32_t v = pos < te ? best[wave][pos - ts] : 0;
-                    const uint64_t mask = __ballot((v & 0xFF) != 0);
-                    if (mask == 0) { p = p + 64 < te ? p + 64 : te; continue; }
-                    const int first = __builtin_ctzll(mask);
-                    p += (uint32_t)first;
-                    const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)v, first);
-                    uint32_t len = e & 0xFF;
-                    const uint32_t off = e >> 8;
-                    if (len == ZKE_PARCAP) {                 // capped in phase 1: extend, 64 bytes per step
-                        for (;;) {
-                            const uint8_t *q = base + p + len + lane;
-                            const bool diff = q >= lim || *q != *(q - off);
-                            const uint64_t m = __ballot(diff);
-                            if (m) { len += (uint32_t)__builtin_ctzll(m); break; }
-                            len += 64;
-                        }
-                    }
-                    if (lane == 0) tseq[wave][c] = zke_tpack(p - anchor, len, off, p - ts);
-                    c++;
-                    p += len; anchor = p;
-                }
-                if (lane == 0) { tcount[wave] = c; ttail[wave] = te - anchor; }
-            }
-            __syncthreads();
-            // stitch the tiles of the group: literals left over at a tile's end join the next sequence.  Every lane reads
-            // the eight tile summaries at once and runs the little scan itself; wave w then rewrites tile w's sequences
-            // (one LDS round trip for the group, not one per tile)
-            uint32_t pend = carry, last_off = prev_off, outbase = nseq;
-            uint32_t my_pend = 0, my_poff = 0, my_base = 0, my_cnt = 0;
-            {
-                uint32_t cn[ZKE_GROUP], tl[ZKE_GROUP], lo[ZKE_GROUP];
-#pragma unroll
-                for (uint32_t t = 0; t < ZKE_GROUP; t++) { cn[t] = t < ntiles ? tcount[t] : 0; tl[t] = ttail[t]; }
-#pragma unroll
-                for (uint32_t t = 0; t < ZKE_GROUP; t++) lo[t] = (uint32_t)(tseq[t][cn[t] ? cn[t] - 1 : 0] >> 23) & 0x1FFFF;
-#pragma unroll
-                for (uint32_t t = 0; t < ZKE_GROUP; t++) {
-                    if (t < ntiles) {
-                        const uint32_t ts = gs + t * ZKE_TILE, te = ts + ZKE_TILE < be ? ts + ZKE_TILE : be;
-                        if (t == wave) { my_pend = pend; my_poff = last_off; my_base = outbase; my_cnt = cn[t]; }
-                        if (cn[t]) { pend = tl[t]; last_off = lo[t]; probe = last_off; outbase += cn[t]; }
-                        else pend += te - ts;
-                    }
-                }
-            }
-            {
-                const uint32_t ts = gs + wave * ZKE_TILE;
-                for (uint32_t j = lane; j < my_cnt; j += 64) {
-                    const uint64_t e = tseq[wave][j];
-                    uint32_t ll = (uint32_t)e & 0xFFF;
-                    const uint32_t ml = (uint32_t)(e >> 12) & 0x7FF, off = (uint32_t)(e >> 23) & 0x1FFFF, pit = (uint32_t)(e >> 40);
-                    const uint32_t poff = j ? (uint32_t)(tseq[wave][j - 1] >> 23) & 0x1FFFF : my_poff;
-                    if (j == 0) ll += my_pend;
-                    const uint32_t code = (ll && off == poff) ? 1u : off + 3;
-                    sq[my_base + j] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)code << 40);
-                    mp[my_base + j] = ts + pit;
-                }
-            }
-            carry = pend; prev_off = last_off; nseq = outbase;
-            zke_lds_barrier();                               // tseq / tcount are reused (sq / mp: see the gather pass)
-        }
-        // literal gather: literals of sequence i start at (mpos_i - bs) - ll_i - (match bytes before i).  A load issued
-        // after a store waits for the store's acknowledgement (one in-order counter), so a lane first requests the
-        // records of four sequences, then their first 8 literal bytes, and only then stores.
-        __syncthreads();                                     // sq / mp of the block's last groups are visible
-        {
-            const uint32_t chunk = (nseq + ZKE_THREADS - 1) / ZKE_THREADS;
-            const uint32_t i0 = tid * chunk < nseq ? tid * chunk : nseq, i1 = i0 + chunk < nseq ? i0 + chunk : nseq;
-            uint32_t msum = 0;
-            for (uint32_t i = i0; i < i1; i++) msum += (uint32_t)(sq[i] >> 20) & 0xFFFFF;
-            s_scan[tid] = msum;
-            __syncthreads();
-            uint32_t M = 0;
-            for (uint32_t k = 0; k < tid; k++) M += s_scan[k];
-            uint32_t total_m = 0;
-            for (uint32_t k = 0; k < ZKE_THREADS; k++) total_m += s_scan[k];
-            // the literals of a lane's consecutive sequences are contiguous in the literal buffer: they are collected in a
-            // 64-bit accumulator and leave 8 bytes at a time (a scattered byte store costs the memory pipeline as much
-            // as an 8-byte one)
-            const uint32_t hi8g = fend >= 8 ? fend - 8 : 0;
-            uint64_t acc = 0;
-            uint32_t an = 0, wr = 0;                                                      // bytes waiting in acc; where they go
-            auto append = [&](uint64_t w, uint32_t cnt) {                                // 1 <= cnt <= 8 bytes of w
-                const uint64_t wm = cnt < 8 ? w & ((1ull << (8 * cnt)) - 1) : w;
-                acc |= wm << (8 * an);
-                if (an + cnt >= 8) {
-                    memcpy(lt + wr, &acc, 8); wr += 8;
-                    acc = an ? wm >> (8 * (8 - an)) : 0;
-                    an = an + cnt - 8;
-                } else an += cnt;
-            };
-            for (uint32_t i = i0; i < i1; i += 4) {
-                uint64_t e[4], w[4];
-                uint32_t m[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { const uint32_t k = i + u < i1 ? i + u : i1 - 1; e[u] = sq[k]; m[u] = mp[k]; }
-#pragma unroll
-                for (int u = 0; u < 4; u++) { const uint32_t from = m[u] - ((uint32_t)e[u] & 0xFFFFF); w[u] = fend >= 8 ? zk_ld64(base + (from < hi8g ? from : hi8g)) : 0; }
-                if (i == i0) wr = (m[0] - bs) - ((uint32_t)e[0] & 0xFFFFF) - M;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (i + u < i1) {
-                        const uint32_t ll = (uint32_t)e[u] & 0xFFFFF, from = m[u] - ll;
-                        if (ll) {
-                            if (from <= hi8g && fend >= 8) append(w[u], ll < 8 ? ll : 8);
-                            else for (uint32_t k = 0; k < ll && k < 8; k++) append(base[from + k], 1);       // the frame's last bytes
-                            for (uint32_t k = 8; k < ll; k += 8) {                        // long literal runs
-                                const uint32_t c = ll - k < 8 ? ll - k : 8;
-                                if (from + k <= hi8g && fend >= 8) append(zk_ld64(base + from + k), c);
-                                else for (uint32_t j = 0; j < c; j++) append(base[from + k + j], 1);
-                            }
-                        }
-                    }
-                }
-            }
-            for (uint32_t k = 0; k < an; k++) lt[wr + k] = (uint8_t)(acc >> (8 * k));
-            const uint32_t nlit = (be - bs) - total_m;
-            for (uint32_t k = tid; k < carry; k += ZKE_THREADS) lt[nlit - carry + k] = base[be - carry + k];
-            if (tid == 0) { blk->nseq = nseq; blk->nlit = nlit; }
-            __syncthreads();
-        }
-    }
-}
+#include "zk_enc_match.h"
 
 // ------------------------------------------------------------------------------------------------ entropy stage
 // LSB-first bit writer into global scratch (one lane), free of branches: put() collects at most 56 bits on top of
@@ -508,8 +127,6 @@ __global__ __launch_bounds__(1024) void zk_k_enc_fse_build(const ZkEncFrame *fra
 
 constexpr int ZKE_ENT_THREADS = 256;
 constexpr int ZKE_ENT_BLOCKS = 16;                       // blocks per workgroup: lanes = blocks for the serial bit writers
-static_assert(ZKE_THREADS / 64 == (int)ZKE_GROUP, "one parsing wave per tile of a group");
-static_assert(ZKE_THREADS == (int)(ZKE_TILE * ZKE_LSTEP), "one lookup position per lane");
 
 // The sequence bitstream of one block (one lane): three interleaved FSE states + the extra bits that the rewrite pass left
 // in seqs[] / mpos[].  T: the block's frame tables (LDS or HBM).
@@ -936,11 +553,13 @@ void zk_launch_enc_stage_hist(hipStream_t st, const uint8_t *src, const uint8_t 
 {
     hipLaunchKernelGGL(zk_k_enc_stage_hist, dim3(nframes), dim3(256), 0, st, src, prefix_tail, frames, stage);
 }
-void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, ZkEncBlock *blocks, uint64_t *seqs, uint32_t *mpos, uint8_t *lits, uint32_t hash_log)
+void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *segs, uint32_t nsegs, ZkEncBlock *blocks, uint64_t *seqs, uint8_t *lits, int level)
 {
-    if (hash_log >= 16) hipLaunchKernelGGL((zk_k_enc_match<16, 2>), dim3(nframes), dim3(ZKE_THREADS), 0, st, src, frames, blocks, seqs, mpos, lits);
-    else if (hash_log == 15) hipLaunchKernelGGL((zk_k_enc_match<15, 4>), dim3(nframes), dim3(ZKE_THREADS), 0, st, src, frames, blocks, seqs, mpos, lits);
-    else hipLaunchKernelGGL((zk_k_enc_match<14, 6>), dim3(nframes), dim3(ZKE_THREADS), 0, st, src, frames, blocks, seqs, mpos, lits);
+    if (!nsegs) return;
+    // one instance per setting of zk_enc_device.h (zke_hash_log / zke_lazy / zke_step)
+    if (zke_fast(level)) hipLaunchKernelGGL((zk_k_enc_match<14, 0, 4096>), dim3(nsegs), dim3(ZKE_THREADS), 0, st, src, segs, blocks, seqs, lits);
+    else if (zke_step(level) == 1024) hipLaunchKernelGGL((zk_k_enc_match<15, 1, 1024>), dim3(nsegs), dim3(ZKE_THREADS), 0, st, src, segs, blocks, seqs, lits);
+    else hipLaunchKernelGGL((zk_k_enc_match<15, 1, 4096>), dim3(nsegs), dim3(ZKE_THREADS), 0, st, src, segs, blocks, seqs, lits);
 }
 void zk_launch_enc_fse_build(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, const uint64_t *seqs,
                              const ZkEncTables *predef, ZkEncTables *ftab)

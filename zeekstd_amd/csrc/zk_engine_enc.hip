@@ -5,6 +5,7 @@
 #include "../../include/zeekstd_amd.h"
 #include "zk_engine.h"
 #include "zk_kernels.h"
+#include "zk_enc_plan.h"
 
 #define ZK_HIP(call)                                                                                 \
     do {                                                                                             \
@@ -65,38 +66,21 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
 {
     const uint64_t n = a.n;
     const uint32_t frame_size = a.frame_size;
-    // the matcher sees the last `hist` bytes of the prefix right before every frame (its window is 64 KiB)
-    const uint32_t hist = a.d_prefix ? (uint32_t)(a.prefix_len < ZKE_WINDOW ? a.prefix_len : ZKE_WINDOW) : 0;
+    // the matcher sees the last `hist` bytes of the prefix right before every frame
+    const uint32_t hist = a.d_prefix ? zke_prefix_hist(a.prefix_len) : 0;
     if (!e || frame_size == 0 || frame_size > ZK_SEEKABLE_MAX_FRAME_SIZE || !a.d_dst || (n && !a.d_src)) return ZK_ERR_ARGUMENT;
     const uint64_t nf64 = n == 0 ? 1 : (n + frame_size - 1) / frame_size;
     if (nf64 > ZK_SEEKABLE_MAX_FRAMES) return ZK_ERR_FRAME_INDEX_TOO_LARGE;
-    const uint32_t nf = (uint32_t)nf64;
     ZK_HIP(hipSetDevice(e->device));
 
-    // frame / block lists (host arithmetic only: frame boundaries are the policy's, encode.rs:528-544)
-    uint64_t nb64 = 0;
-    for (uint32_t f = 0; f < nf; f++) {
-        const uint64_t so = (uint64_t)f * frame_size;
-        const uint32_t dsz = (uint32_t)(n - so < frame_size ? n - so : frame_size);
-        uint32_t bm = zke_block_max(dsz, hist != 0);
-        nb64 += dsz ? (dsz + bm - 1) / bm : 0;
-    }
-    if (nb64 > 0xFFFFFFF0ull) return -(int)ZK_E_GENERIC;
-    const uint32_t nb = (uint32_t)nb64;
+    // frame / block / segment lists (host arithmetic only: zk_enc_plan.h)
+    ZkEncPlan pl;
+    if (!zke_plan_count(n, frame_size, hist, &pl)) return -(int)ZK_E_GENERIC;
+    const uint32_t nf = pl.nf, nb = pl.nb, nseg = pl.nseg;
     const size_t frames_bytes = ((size_t)nf * sizeof(ZkEncFrame) + 63) & ~(size_t)63;
     const size_t blocks_bytes = ((size_t)(nb + 1) * sizeof(ZkEncBlock) + 63) & ~(size_t)63;
     const size_t doff_bytes = ((size_t)(nf + 1) * 8 + 63) & ~(size_t)63;
-    // frames above ZKE_SEGMENT: the matcher runs one workgroup per segment (zk_enc_device.h)
-    const bool segmented = frame_size > ZKE_SEGMENT;
-    uint64_t nseg64 = 0;
-    if (segmented) for (uint32_t f = 0; f < nf; f++) {
-        const uint64_t so = (uint64_t)f * frame_size;
-        const uint64_t dsz = n - so < frame_size ? n - so : frame_size;
-        nseg64 += (dsz + ZKE_SEGMENT - 1) / ZKE_SEGMENT;
-    }
-    if (nseg64 > 0xFFFFFFF0ull) return -(int)ZK_E_GENERIC;
-    const uint32_t nseg = (uint32_t)nseg64;
-    const size_t segs_bytes = ((size_t)nseg * sizeof(ZkEncFrame) + 63) & ~(size_t)63;
+    const size_t segs_bytes = ((size_t)(nseg + 1) * sizeof(ZkEncFrame) + 63) & ~(size_t)63;
     int rc;
     if ((rc = zk_pin_reserve(e, frames_bytes + blocks_bytes + doff_bytes + sizeof(ZkEncTables) + 64 + segs_bytes))) return rc;
     ZkEncFrame *frames = (ZkEncFrame *)e->enc_pin;
@@ -104,51 +88,8 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
     uint64_t *doff = (uint64_t *)((uint8_t *)e->enc_pin + frames_bytes + blocks_bytes);
     ZkEncTables *htab = (ZkEncTables *)((uint8_t *)doff + doff_bytes);
     ZkEncFrame *segs = (ZkEncFrame *)((uint8_t *)e->enc_pin + ((frames_bytes + blocks_bytes + doff_bytes + sizeof(ZkEncTables) + 63) & ~(size_t)63));
-    uint64_t seq_total = 0, scratch_total = 0;
-    uint32_t bcount = 0;
-    for (uint32_t f = 0; f < nf; f++) {
-        ZkEncFrame &fr = frames[f];
-        fr.src_off = (uint64_t)f * frame_size;
-        fr.d_size = (uint32_t)(n - fr.src_off < frame_size ? n - fr.src_off : frame_size);
-        uint32_t wlog = 10;
-        while ((1u << wlog) < fr.d_size && wlog < 17) wlog++;
-        if (hist) wlog = 17;                                 // covers every offset the matcher can produce, into the prefix too
-        fr.window_log = wlog;
-        fr.block_max = zke_block_max(fr.d_size, hist != 0);
-        fr.n_blocks = fr.d_size ? (fr.d_size + fr.block_max - 1) / fr.block_max : 0;
-        fr.block_base = bcount;
-        fr.hist = fr.d_size ? hist : 0;
-        fr.m_off = hist ? (uint64_t)f * ((uint64_t)hist + frame_size) : fr.src_off;
-        fr.minmatch = zke_minmatch(a.level); fr.pad = 0;
-        for (uint32_t b = 0; b < fr.n_blocks; b++) {
-            ZkEncBlock &k = blocks[bcount++];
-            memset(&k, 0, sizeof k);
-            k.frame = f; k.bs = b * fr.block_max;
-            k.bsz = fr.d_size - k.bs < fr.block_max ? fr.d_size - k.bs : fr.block_max;
-            k.seq_base = seq_total; seq_total += k.bsz / 4 + 2;
-            k.lit_base = fr.src_off + k.bs;
-            k.scratch_base = scratch_total;
-            const uint32_t q = (k.bsz + 3) / 4;
-            scratch_total += (uint64_t)k.bsz * 2 + 4ull * (q + (q >> 1) + 16) + 64;
-        }
-        doff[f] = fr.src_off;
-    }
-    doff[nf] = n;
-    if (segmented) {
-        uint32_t sc = 0;
-        for (uint32_t f = 0; f < nf; f++) {
-            const ZkEncFrame &fr = frames[f];
-            const uint32_t per = ZKE_SEGMENT / fr.block_max;              // blocks per segment (block_max is 32 KiB for frames this large)
-            for (uint32_t at = 0; at < fr.d_size; at += ZKE_SEGMENT) {
-                ZkEncFrame &sg = segs[sc++];
-                sg = fr;
-                sg.d_size = fr.d_size - at < ZKE_SEGMENT ? fr.d_size - at : ZKE_SEGMENT;
-                sg.n_blocks = (sg.d_size + fr.block_max - 1) / fr.block_max;
-                sg.block_base = fr.block_base + (at / ZKE_SEGMENT) * per;
-                if (at) { sg.hist = ZKE_WINDOW; sg.m_off = fr.m_off + fr.hist + at - ZKE_WINDOW; }
-            }
-        }
-    }
+    zke_plan_fill(n, frame_size, a.level, &pl, frames, blocks, segs, doff);
+    const uint64_t seq_total = pl.seq_total, scratch_total = pl.scratch_total;
     if ((rc = zk_devbuf_reserve(e, e->enc_a, frames_bytes + blocks_bytes + 256))) return rc;
     if ((rc = zk_devbuf_reserve(e, e->enc_b, (size_t)(seq_total + 1) * 12 + 64))) return rc;       // packed sequences (u64) + match positions (u32)
     if ((rc = zk_devbuf_reserve(e, e->enc_c, (size_t)n + 64))) return rc;
@@ -173,14 +114,10 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         msrc = (const uint8_t *)e->enc_hist.p;
     }
     if (a.checksum) { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, d_doff, 0, nf, nullptr, hashes); }
-    const ZkEncFrame *mfr = dfr;                             // what the matcher's workgroups are launched over
-    uint32_t nm = nf;
-    if (segmented) {
-        if ((rc = zk_devbuf_reserve(e, e->enc_seg, segs_bytes + 64))) return rc;
-        ZK_HIP(hipMemcpyAsync(e->enc_seg.p, segs, (size_t)nseg * sizeof(ZkEncFrame), hipMemcpyHostToDevice, st));
-        mfr = (const ZkEncFrame *)e->enc_seg.p; nm = nseg;
-    }
-    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, mfr, nm, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (uint8_t *)e->enc_c.p, zke_hash_log(a.level)); }
+    // the matcher's workgroups are launched over the segments (one per <= 256 KiB of a frame)
+    if ((rc = zk_devbuf_reserve(e, e->enc_seg, segs_bytes + 64))) return rc;
+    ZK_HIP(hipMemcpyAsync(e->enc_seg.p, segs, (size_t)nseg * sizeof(ZkEncFrame), hipMemcpyHostToDevice, st));
+    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, (const ZkEncFrame *)e->enc_seg.p, nseg, dbl, (uint64_t *)e->enc_b.p, (uint8_t *)e->enc_c.p, a.level); }
     ZkEncTables *ftab = (ZkEncTables *)e->enc_f.p;
     { zk_kernel_timer t(e, ZK_K_ENC_FSE_BUILD, st); zk_launch_enc_fse_build(st, src, dfr, nf, dbl, (const uint64_t *)e->enc_b.p, dtab, ftab); }
     { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, ftab); }
