@@ -84,6 +84,8 @@ static inline void emu_wave_sync() { (void)emu_collect(0); }
 static inline uint32_t emu_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (s & 3))); }
 static inline uint32_t emu_atomic_cas(uint32_t *p, uint32_t cmp, uint32_t val) { const uint32_t old = *p; if (old == cmp) *p = val; return old; }
 
+static inline uint32_t emu_atomic_min(uint32_t *p, uint32_t v) { const uint32_t old = *p; if (v < old) *p = v; return old; }
+
 static void emu_entry()
 {
     g_emu.body();
@@ -136,4 +138,6 @@ static void emu_run_workgroup(uint32_t nthreads, uint32_t block, std::function<v
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_dpp((old), (src), (ctrl))
 #define __builtin_amdgcn_alignbyte(hi, lo, s) emu_alignbyte((hi), (lo), (s))
 #define __builtin_amdgcn_wave_barrier() emu_wave_sync()
+#define __builtin_amdgcn_readfirstlane(v) (v)          /* only used on values that are uniform across the wave */
 #define atomicCAS(p, c, v) emu_atomic_cas((p), (c), (v))
+#define atomicMin(p, v) emu_atomic_min((p), (v))

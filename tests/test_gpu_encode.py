@@ -72,15 +72,16 @@ def test_frame_sizes(engine, fs):            # lib.rs:315-357 (proptest 1..1023)
 def test_compression_ratio_sanity(engine):
     data = zko.gen_chunks(8 << 20)
     comp, frames = engine.encode_frames(data, 2 << 20, 1, True)
-    assert len(frames) == 4 and len(data) / len(comp) > 2.4          # text: libzstd level 1 gets ~2.5; per-frame FSE tables: 2.44
+    assert len(frames) == 4 and len(data) / len(comp) > 2.45         # text: libzstd level 1 gets 2.49; this encoder 2.47
 
 
 @pytest.mark.parametrize("level", [-5, 0, 1, 2, 3, 5, 6, 19])
 def test_levels_are_honoured(engine, level):
-    """EncodeOptions::compression_level (encode.rs:170, 281-282; CLI default 3, cli/src/args.rs:192): three settings of one
-    parse -- level <= 1: matches of 6+ bytes, 2^14 table entries; levels 2..5 and 0 (= the default 3): 5+ bytes, 2^15
-    entries; level >= 6: 2^16 entries.  Byte-identical to the CPU twin at that level, valid zstd, and every step up
-    compresses the survey's text better (2.44 / 2.57 / 2.63)."""
+    """EncodeOptions::compression_level (encode.rs:170, 281-282; CLI default 3, cli/src/args.rs:192): level <= 1: table
+    matches of 6+ bytes, 2^14 table entries, greedy parse; levels 2..5 and 0 (= the default 3): 5+ bytes, 2^15 entries, lazy
+    parse; level >= 6: the same with lookup steps of 1024 positions.  Byte-identical to the CPU twin at that level, valid
+    zstd, and the step from 1 to 3 compresses the survey's text better (2.47 -> 2.59; steps of 1024 pay on source code, not
+    on this text: within 0.2 %)."""
     data = zko.gen_chunks(4 << 20, 11)
     comp, frames = engine.encode_frames(data, 2 << 20, level, True)
     check_payload(engine, data, comp, frames, 2 << 20, True)
@@ -91,11 +92,43 @@ def test_levels_are_honoured(engine, level):
     low, _ = engine.encode_frames(data, 2 << 20, 1, True)
     mid, _ = engine.encode_frames(data, 2 << 20, 3, True)
     if level <= 1 and level != 0:
-        assert comp == low
+        assert comp == low and len(data) / len(low) > 2.45
     elif level >= 6:
-        assert len(comp) < len(mid) < len(low) and len(data) / len(comp) > 2.6
+        assert len(comp) < len(mid) * 1.002 and len(mid) < len(low)
     else:
-        assert comp == mid and len(mid) < len(low) and len(data) / len(mid) > 2.54
+        assert comp == mid and len(mid) < len(low) and len(data) / len(mid) > 2.56
+
+
+def _ratio_inputs():
+    rng = np.random.default_rng(77)
+    out = {}
+    for L in (10, 20, 50, 100, 300, 1000):
+        out[f"runs{L}"] = np.repeat(rng.integers(0, 256, (1 << 20) // L + 1, dtype=np.uint8), L)[:1 << 20].tobytes()
+    out["zeros"] = bytes(1 << 20)
+    out["records"] = zko.make_input([["records", 50000, 7, "000102030405060708090a0b0c0d0e0f"]])
+    out["period37"] = (zko.gen_random(37, 3) * 30000)[:1 << 20]
+    out["text"] = zko.gen_chunks(2 << 20, 7)
+    return out
+
+
+def test_ratio_ladder_on_structured_inputs(engine):
+    """with a probe frozen per group the default level (0 -> 3) compressed byte runs 6-14 x worse than
+    level 1.  Now every position probes offset 1 and the lazy parse defers a short table match to the run behind it: level 3
+    is never more than 2 % behind level 1, level 6 never more than 2 % behind level 3, and runs of 10 random bytes reach
+    5.4 (libzstd 1.5.7 level 1: 5.7).  The CPU twin holds the same floors in tests/test_oracle.py."""
+    for name, data in _ratio_inputs().items():
+        size = {}
+        for level in (1, 3, 6):
+            comp, frames = engine.encode_frames(data, 2 << 20, level, True)
+            assert comp == b"".join(zko.frame_encode(data[o:o + (2 << 20)], level, True) for o in range(0, len(data), 2 << 20)), (name, level)
+            size[level] = len(comp)
+        slack = len(data) // 1000                                     # 0.1 % of the input: the period-37 case is 13 KB per MiB
+        assert size[3] <= size[1] * 1.02 + slack, (name, size)
+        assert size[6] <= size[3] * 1.02 + slack, (name, size)
+        ratio = len(data) / size[1]
+        floor = {"runs10": 5.0, "runs20": 9.0, "runs50": 17.0, "runs100": 26.0, "runs300": 55.0, "runs1000": 100.0, "zeros": 1000.0,
+                 "records": 3.0, "period37": 60.0, "text": 2.45}[name]
+        assert ratio >= floor, (name, ratio)
 
 
 @pytest.mark.parametrize("level", [3, 6])
@@ -159,7 +192,7 @@ PREFIX_CASES = {
     # name: (prefix recipe, data recipe, frame size)
     "shared_text": ([["text", 100000, 41]], [["text", 40000, 41], ["text", 60000, 42], ["text", 30000, 41]], 32768),
     "tiny": ([["rep", b"hello world!".hex(), 1]], [["rep", b"hello world!".hex(), 9]], 2 << 20),
-    "long_prefix": ([["text", 300000, 43]], [["text", 200000, 43]], 65536),          # only the last 65535 bytes are reachable
+    "long_prefix": ([["text", 300000, 43]], [["text", 200000, 43]], 65536),          # only the last 61376 bytes are reachable
     "prefix_is_input": ([["chunks", 1 << 20, 5]], [["chunks", 1 << 20, 5]], 1 << 20),
     "random_data": ([["text", 50000, 48]], [["random", 40000, 49], ["text", 20000, 48]], 16384),
     "small_frames": ([["text", 20000, 50]], [["text", 12000, 50]], 1000),
@@ -196,9 +229,9 @@ def test_encode_with_prefix_roundtrip_and_twin(engine, name, checksum):
 @pytest.mark.parametrize("level", [1, 3])
 @pytest.mark.parametrize("with_prefix", [False, True])
 def test_frames_above_the_matcher_segment(engine, level, with_prefix):
-    """Frames larger than ZKE_SEGMENT (2 MiB) are matched in segments, one workgroup each, every segment after the first
-    starting from the 65 535 bytes before it (zk_enc_device.h) -- the CPU twin cuts the same way: byte-identical, valid for
-    libzstd and for both decoders.  Frame size 5 MiB + 12 345 (three segments, the last one ragged) and a short last frame."""
+    """Frames larger than ZKE_SEGMENT (256 KiB) are matched in segments, one workgroup each, every segment after the first
+    starting from the 61 376 bytes before it (zk_enc_device.h) -- the CPU twin cuts the same way: byte-identical, valid for
+    libzstd and for both decoders.  Frame size 5 MiB + 12 345 (21 segments, the last one ragged) and a short last frame."""
     data = zko.gen_chunks((17 << 20) + 77, 5)
     fs = (5 << 20) + 12345
     prefix = zko.gen_text(300000, 9) if with_prefix else None

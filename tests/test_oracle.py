@@ -153,6 +153,34 @@ def test_encoder_twin_frames_are_valid_zstd(which):
     assert len(shared) < len(zko.frame_encode(cases[0], 1, True))   # the prefix tail is found
 
 
+def test_encoder_twin_ratio_ladder():
+    """The twin's side of tests/test_gpu_encode.py::test_ratio_ladder_on_structured_inputs (VERDICT r2 #9): the default
+    level (0 -> 3) is never more than 2 % behind level 1 on byte runs, zeros, records, a period-37 pattern and the survey's
+    text; level 6 never more than 2 % behind level 3; every frame decodes through the oracle and the real libzstd."""
+    import numpy as np
+    rng = np.random.default_rng(77)
+    inputs = {f"runs{L}": np.repeat(rng.integers(0, 256, (1 << 19) // L + 1, dtype=np.uint8), L)[:1 << 19].tobytes() for L in (10, 20, 50, 100, 300, 1000)}
+    inputs["zeros"] = bytes(1 << 19)
+    inputs["records"] = zko.make_input([["records", 25000, 7, "000102030405060708090a0b0c0d0e0f"]])
+    inputs["period37"] = (zko.gen_random(37, 3) * 15000)[:1 << 19]
+    inputs["text"] = zko.gen_chunks(1 << 20, 7)
+    floors = {"runs10": 5.0, "runs20": 9.0, "runs50": 17.0, "runs100": 26.0, "runs300": 55.0, "runs1000": 100.0, "zeros": 1000.0,
+              "records": 3.0, "period37": 60.0, "text": 2.40}
+    for name, data in inputs.items():
+        size = {}
+        for level in (1, 0, 3, 6):
+            c = zko.frame_encode(data, level, True)
+            out, used = zko.frame_decode(c, len(data), True)
+            assert out == data and used == len(c), (name, level)
+            if Z.load("system") is not None:
+                assert Z.decode_stream(c, len(data), "system") == data, (name, level)
+            size[level] = len(c)
+        assert size[0] == size[3]                                   # level 0 = libzstd's default 3 (encode.rs:170)
+        slack = len(data) // 1000                                     # 0.1 % of the input: the period-37 case is 6 KB per 512 KiB
+        assert size[3] <= size[1] * 1.02 + slack and size[6] <= size[3] * 1.02 + slack, (name, size)
+        assert len(data) / size[1] >= floors[name], (name, len(data) / size[1])
+
+
 def test_handmade_frames():
     """Format corners libzstd's encoder never picked for the archives (RLE_Mode sequence tables): frames written by
     hand, accepted by libzstd 1.5.7 when they were minted; the oracle and, where present, the box's libzstd agree."""

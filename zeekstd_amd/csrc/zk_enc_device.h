@@ -21,7 +21,7 @@ constexpr uint32_t ZKE_TILE = 256;                // parse tile: matches never c
 constexpr uint32_t ZKE_GROUP = 16;                // tiles per group = waves per workgroup
 constexpr uint32_t ZKE_GROUP_POS = ZKE_TILE * ZKE_GROUP;
 ZK_HD uint32_t zke_step(int level) { return level >= 6 ? 1024u : ZKE_GROUP_POS; }
-constexpr uint32_t ZKE_PARCAP = 64;               // match length measured per position; the parse extends longer ones
+constexpr uint32_t ZKE_PARCAP = 16;               // match length measured per position (branch-free, 16 bytes per candidate); the parse extends longer ones
 // The matcher keeps the last 64 KiB of its input in an LDS ring: the group it works on, 64 bytes of lookahead, and the
 // window behind the group -- the largest offset it produces.
 constexpr uint32_t ZKE_RING = 65536;

@@ -8,119 +8,170 @@
 //
 // Everything the matcher touches while it works lives in LDS (HBM-bound byte work; no MFMA):
 //   ring   64 KiB  the last 65536 bytes of the segment's record [history | data], loaded ONCE from HBM, coalesced, one dword
-//                  per lane and group, a group ahead; position p sits at ring byte p mod 65536
+//                  per lane and group, a group ahead; position p sits at ring byte p mod 65536 (+ a 32-byte mirror of the
+//                  ring's start behind its end, so the 20 bytes at any position are one straight read)
 //   table  2^HLOG 16-bit entries = ring indices of earlier positions (32 / 64 KiB)
 //   best   16 KiB  per position of the group: length | offset << 8 of its best candidate; a tile's slice later holds the
 //                  tile's literal bytes
 //   tseq   8.3 KiB per tile: its sequences
-// so a candidate comparison, a match extension and a literal gather are LDS reads (32 lanes per clock), and HBM sees the
-// input once and the sequences / literals once, in full lines.
+// so a candidate comparison, a match extension and a literal gather are LDS reads, and HBM sees the input once and the
+// sequences / literals once.
 //
 // A group = 16 tiles x 256 positions.  Lane l of wave w owns positions 4l .. 4l + 3 of tile w (aligned ring words):
 //   1. lookup: hash of 5 bytes -> table entry as it was before the step ("far" candidate)            | barrier (LDS only)
 //   2. insert: compare-and-swap, the smallest position of the step wins a slot                       | barrier
-//   3. second lookup: an earlier position of the same step ("near" candidate); comparisons of far / near / offset 1 /
-//      previous offset R out of the ring -> best[]; then the wave parses ITS tile (the same wave wrote its best[] slice:
-//      no barrier): 64 positions per pass, candidates as a ballot mask consumed by a scalar loop, sequences and literal
-//      bytes emitted by all lanes at once                                                            | barrier
-//   4. the prefetched input of the next group enters the ring; the 16 tiles are stitched (every wave runs the little
-//      scan over the 16 tile summaries itself) and each wave stores its tile's sequences and literals | barrier
+//   3. second lookup: an earlier position of the same step ("near" candidate); far / near / offset 1 / previous offset R
+//      are compared over 16 bytes each, branch-free, all ring reads of a lane in flight together -> best[]; then the wave
+//      parses ITS tile (the same wave wrote its best[] slice: no barrier): 64 positions per pass, candidates as a ballot mask
+//      consumed by a short scalar loop, sequences and literal bytes emitted by all lanes at once      | barrier
+//   4. the prefetched input of the next group enters the ring; the 16 tiles are stitched (16-lane DPP scans over the tile
+//      summaries, every wave on its own) and each wave stores its tile's sequences and literals        | barrier
+// The scalar unit is one per CU and 16 waves share it: the loops are written to keep their scalar instruction count low.
 #pragma once
 #include <stdint.h>
 #include "zk_enc_device.h"
 
 constexpr int ZKE_THREADS = 1024;                      // 16 waves: one per tile of a group
 constexpr uint32_t ZKE_TSEQ_N = ZKE_TILE / 4 + 2;      // sequences of a tile (shortest match: 4 bytes)
+constexpr uint32_t ZKE_RING_WORDS = ZKE_RING / 4;
 static_assert(ZKE_THREADS * 4 == (int)ZKE_GROUP_POS && ZKE_THREADS / 64 == (int)ZKE_GROUP, "four positions per lane, one wave per tile");
+static_assert(ZKE_PARCAP == 16 && ZKE_TSEQ_N >= 64, "the comparisons measure 16 bytes; one sequence per lane in the stitch");
 
+#ifndef ZKE_CLK
+#define ZKE_CLK(i) do { } while (0)       // experiments: shader-clock totals per phase (zk_encode.hip with -DZKE_CLOCKS, tools/enc_clocks.py)
+#define ZKE_CLK_BEGIN() do { } while (0)
+#define ZKE_CLK_END() do { } while (0)
+#endif
 #ifndef ZKE_LDS_BARRIER
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load / store in flight
 #define ZKE_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+__device__ __forceinline__ void zke_ring_put(uint32_t *ring, uint32_t word, uint32_t v)   // word < 16384; the first 8 words are mirrored behind the end
+{
+    ring[word] = v;
+    if (word < 8) ring[word + ZKE_RING_WORDS] = v;
+}
 // 8 bytes of the record at position pos (any alignment) out of the ring
 __device__ __forceinline__ uint64_t zke_ring8(const uint32_t *ring, uint32_t pos)
 {
     const uint32_t i = (pos >> 2) & 16383u, sh = pos & 3u;
-    const uint32_t a = ring[i], b = ring[(i + 1) & 16383u], c = ring[(i + 2) & 16383u];
+    const uint32_t a = ring[i], b = ring[i + 1], c = ring[i + 2];
     return (uint64_t)__builtin_amdgcn_alignbyte(b, a, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, sh) << 32);
 }
 __device__ __forceinline__ uint32_t zke_ring1(const uint32_t *ring, uint32_t pos) { return ((const uint8_t *)ring)[pos & 0xFFFFu]; }
 
-// common prefix of the bytes at a and at b (a < b), at most n (>= 1); w = the 8 bytes at b
-__device__ __forceinline__ uint32_t zke_mlen(const uint32_t *ring, uint32_t a, uint32_t b, uint64_t w, uint32_t n)
+// bytes (<= 16) that the 16 bytes at ring position c share with (olo, ohi)
+__device__ __forceinline__ uint32_t zke_common16(const uint32_t *ring, uint32_t c, uint64_t olo, uint64_t ohi)
 {
-    uint64_t x = w ^ zke_ring8(ring, a);
-    uint32_t l = 0;
-    while (x == 0) {
-        l += 8;
-        if (l >= n) return n;
-        x = zke_ring8(ring, b + l) ^ zke_ring8(ring, a + l);
-    }
-    l += (uint32_t)__builtin_ctzll(x) >> 3;
-    return l < n ? l : n;
+    const uint32_t i = (c >> 2) & 16383u, sh = c & 3u;
+    const uint32_t a0 = ring[i], a1 = ring[i + 1], a2 = ring[i + 2], a3 = ring[i + 3], a4 = ring[i + 4];
+    const uint64_t x0 = olo ^ ((uint64_t)__builtin_amdgcn_alignbyte(a1, a0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(a2, a1, sh) << 32));
+    const uint64_t x1 = ohi ^ ((uint64_t)__builtin_amdgcn_alignbyte(a3, a2, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(a4, a3, sh) << 32));
+    return x0 ? (uint32_t)__builtin_ctzll(x0) >> 3 : x1 ? 8 + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16;
+}
+__device__ __forceinline__ uint32_t zke_common16r(uint64_t clo, uint64_t chi, uint64_t olo, uint64_t ohi)
+{
+    const uint64_t x0 = olo ^ clo, x1 = ohi ^ chi;
+    return x0 ? (uint32_t)__builtin_ctzll(x0) >> 3 : x1 ? 8 + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16;
 }
 
-__device__ __forceinline__ uint32_t zke_table_get(const uint32_t *table, uint32_t h) { return (table[h >> 1] >> (16 * (h & 1))) & 0xFFFFu; }
-
-// Insert position p into slot h.  mode 0: history -- the numerically largest position wins (positions < 65536, the empty
-// entry 0 loses).  mode 1: a step [ls, ls + span) -- the SMALLEST position of the step wins, any entry that is not of the
-// step (entry - ls mod 2^16 >= span) loses.  Order-free rules: the lanes race with compare-and-swap on the word that
-// holds two entries, oracle/zstd_oracle_enc.c applies them sequentially.
+// Table forms.
+// 16-bit entries, two per word (HLOG 15: what fits beside the ring): the low 16 bits of a position.  History: the numerically
+// largest position wins a slot (positions < 65536, the empty entry 0 loses).  A step [ls, ls + span): the SMALLEST position
+// of the step wins, any entry that is not of the step (entry - ls mod 2^16 >= span) loses.  The lanes race with
+// compare-and-swap on the word that holds two entries.
+// 32-bit entries (HLOG <= 14): (0xFFFF - step number) << 16 | (position + bias) mod 2^16, empty = 0xFFFFFFFF: an insertion is
+// ONE ds_min_u32 -- the latest step wins, inside a step the smallest position; "of this step" is a test on the upper half.
+// bias = -history mod 4096 aligns the steps so that none straddles a multiple of 2^16 (distances are unaffected).
+// Both rules are order-free; oracle/zstd_oracle_enc.c applies them sequentially.
+__device__ __forceinline__ bool zke_step_keeps(uint32_t word, uint32_t sh, uint32_t mine, uint32_t b16, uint32_t span)   // the entry in `word` beats position `mine`
+{
+    const uint32_t cur = (((word >> sh) & 0xFFFFu) - b16) & 0xFFFFu;
+    return cur < span && cur <= ((mine - b16) & 0xFFFFu);
+}
 template <int MODE>
-__device__ __forceinline__ void zke_table_put(uint32_t *table, uint32_t h, uint32_t p, uint32_t ls, uint32_t span)
+__device__ __forceinline__ void zke_table_put(uint32_t *table, uint32_t h, uint32_t p, uint32_t ls, uint32_t span, uint32_t old)
 {
     uint32_t *w = &table[h >> 1];
-    const uint32_t sh = 16 * (h & 1), mine = p & 0xFFFFu, b16 = ls & 0xFFFFu, mrel = (mine - b16) & 0xFFFFu;
-    uint32_t old = *w;
+    const uint32_t sh = 16 * (h & 1), mine = p & 0xFFFFu, b16 = ls & 0xFFFFu;
     for (;;) {
-        const uint32_t e = (old >> sh) & 0xFFFFu;
-        if (MODE == 0) { if (e >= mine) return; }
-        else { const uint32_t cur = (e - b16) & 0xFFFFu; if (cur < span && cur <= mrel) return; }
+        if (MODE == 0) { if (((old >> sh) & 0xFFFFu) >= mine) return; }
+        else if (zke_step_keeps(old, sh, mine, b16, span)) return;
         const uint32_t seen = atomicCAS(w, old, (old & ~(0xFFFFu << sh)) | (mine << sh));
         if (seen == old) return;
         old = seen;
     }
 }
 
-// the source dword at record position q (a multiple of 4); bytes at and past fend read as 0
+// The source dword at record position q (a multiple of 4, q < fend, fend >= 4); bytes at and past fend read as 0.  No branch:
+// the last, ragged dword is cut out of the four bytes that end at fend.
 __device__ __forceinline__ uint32_t zke_src_dword(const uint8_t *base, uint32_t q, uint32_t fend)
 {
-    if (q + 4 <= fend) { uint32_t v; memcpy(&v, base + q, 4); return v; }
-    uint32_t v = 0;
-    for (uint32_t k = 0; q + k < fend; k++) v |= (uint32_t)base[q + k] << (8 * k);
-    return v;
+    const uint32_t over = q + 4 > fend ? q + 4 - fend : 0;        // 0 .. 3 bytes of the dword lie past the end
+    uint32_t v;
+    memcpy(&v, base + (q - over), 4);
+    return v >> (8 * over);
 }
 
 __device__ __forceinline__ uint64_t zke_lowmask(uint32_t n) { return n >= 64 ? ~0ull : (1ull << n) - 1; }     // bits [0, n)
+// value of lane (l - d) of the row of 16 lanes; `fill` where the row has no such lane
+#define ZKE_ROW_SHR(v, d, fill) ((uint32_t)__builtin_amdgcn_update_dpp((int)(fill), (int)(v), 0x110 + (d), 0xF, 0xF, false))
 
-// HLOG: log2 of the table entries; LAZY: a longer match one (or a clearly longer one two) positions later wins;
-// STEP: positions per lookup step (4096 = the whole group at once, 1024 = four steps of 256 lanes each)
+// HLOG: log2 of the table entries (<= 14: 32-bit entries, 15: 16-bit entries); LAZY: a longer match one (or a clearly longer
+// one two) positions later wins; STEP: positions per lookup step (4096 = the whole group at once, 1024 = four steps of 256
+// lanes each)
 template <int HLOG, int LAZY, int STEP>
 __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src, const ZkEncFrame *segs, ZkEncBlock *blocks, uint64_t *seqs, uint8_t *lits)
 {
     static_assert(HLOG >= 10 && HLOG <= 15 && (STEP == 1024 || STEP == (int)ZKE_GROUP_POS), "parameters");
-    __shared__ uint32_t ring[ZKE_RING / 4];
-    __shared__ uint32_t table[1 << (HLOG - 1)];
+    constexpr bool T32 = HLOG <= 14;
+    constexpr uint32_t TWORDS = T32 ? (1u << HLOG) : (1u << (HLOG - 1)), DUMMY = TWORDS;   // table[DUMMY]: where lanes without a position read and write
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    __shared__ uint32_t ring[ZKE_RING_WORDS + 8];
+    __shared__ uint32_t table[TWORDS + 1];
     __shared__ uint32_t best[ZKE_GROUP_POS];
     __shared__ uint64_t tseq[ZKE_GROUP][ZKE_TSEQ_N];        // ll | ml << 12 | offset << 24
     __shared__ uint32_t tsum[ZKE_GROUP], tlast[ZKE_GROUP];   // count | trailing literals << 8 | literal bytes << 20;  offset of the tile's last sequence
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const ZkEncFrame fr = segs[blockIdx.x];
     const uint8_t *base = src + fr.m_off;
-    const uint32_t hist = fr.hist, fend = hist + fr.d_size, minmatch = fr.minmatch;
+    const uint32_t hist = fr.hist, fend = hist + fr.d_size, minmatch = fr.minmatch, fend4 = (fend + 3) & ~3u;
     const uint64_t lane_lt = zke_lowmask(lane);
+    const uint32_t bias = T32 ? (0u - hist) & (ZKE_GROUP_POS - 1) : 0u;
 
+    ZKE_CLK_BEGIN();
     // ---- segment start: empty table, history + the first group (+ lookahead) into the ring, history positions into the table
-    for (uint32_t i = tid; i < (1u << (HLOG - 1)); i += ZKE_THREADS) table[i] = 0;
+    for (uint32_t i = tid; i <= TWORDS; i += ZKE_THREADS) table[i] = T32 ? NONE : 0u;
     uint32_t loaded = hist + ZKE_GROUP_POS + 64;             // the ring holds the record up to here (or to its end)
-    if (loaded > ((fend + 3) & ~3u)) loaded = (fend + 3) & ~3u;
-    for (uint32_t q = 4 * tid; q < loaded; q += 4 * ZKE_THREADS) ring[q >> 2] = zke_src_dword(base, q, fend);
+    if (loaded > fend4) loaded = fend4;
+    if (fend >= 4) { for (uint32_t q = 4 * tid; q < loaded; q += 4 * ZKE_THREADS) zke_ring_put(ring, q >> 2, zke_src_dword(base, q, fend)); }
+    else if (tid == 0) { uint32_t v = 0; for (uint32_t k = 0; k < fend; k++) v |= (uint32_t)base[k] << (8 * k); zke_ring_put(ring, 0, v); }
     __syncthreads();
-    for (uint32_t v = tid; v < hist; v += ZKE_THREADS)
-        if (v + 8 <= fend) { const uint64_t w = zke_ring8(ring, v); zke_table_put<0>(table, zke_hash((uint32_t)w, (uint32_t)(w >> 32) & 0xFF, HLOG), v, 0, 0); }
+    uint32_t stepno = 0;                                     // steps of the segment so far (32-bit entries carry it)
+    if (T32) {
+        // history in steps of 4096 positions under the step rule; the keys order the steps, so no barrier separates them
+        for (uint32_t c0 = 0; c0 < hist; c0 += ZKE_GROUP_POS, stepno++) {
+            const uint32_t V0 = c0 + 4 * tid, i0 = (V0 >> 2) & 16383u;
+            const uint32_t d0 = ring[i0], d1 = ring[i0 + 1], d2 = ring[i0 + 2];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t v = V0 + k, lo = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)k), hi = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)k);
+                const bool ok = v < hist && v + 8 <= fend;
+                atomicMin(&table[ok ? zke_hash(lo, hi & 0xFF, HLOG) : DUMMY], ok ? ((0xFFFFu - stepno) << 16) | ((v + bias) & 0xFFFFu) : NONE);
+            }
+        }
+    } else {
+        for (uint32_t v = tid; v < hist; v += ZKE_THREADS)
+            if (v + 8 <= fend) {
+                const uint64_t w = zke_ring8(ring, v);
+                const uint32_t h = zke_hash((uint32_t)w, (uint32_t)(w >> 32) & 0xFF, HLOG);
+                zke_table_put<0>(table, h, v, 0, 0, table[h >> 1]);
+            }
+    }
     __syncthreads();
 
+    ZKE_CLK(0);
     uint32_t probe = 0;                                      // offset of the last sequence so far (same value in every lane)
     for (uint32_t bi = 0; bi < fr.n_blocks; bi++) {
         const uint32_t bs = hist + bi * fr.block_max;
@@ -133,24 +184,27 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
             const uint32_t ge = gs + ZKE_GROUP_POS < be ? gs + ZKE_GROUP_POS : be;
             const uint32_t R = probe;
             // the next group's input: requested now, stored into the ring after this group's comparisons (it overwrites the
-            // oldest bytes of this group's window)
+            // oldest bytes of this group's window).  A lane past the target repeats the last dword (no branch, unused).
             uint32_t target = ge + ZKE_GROUP_POS + 64;
-            if (target > ((fend + 3) & ~3u)) target = (fend + 3) & ~3u;
+            if (target > fend4) target = fend4;
             const uint32_t pq = loaded + 4 * tid;
-            const uint32_t pv = pq < target ? zke_src_dword(base, pq, fend) : 0;
+            const uint32_t pv = fend >= 4 ? zke_src_dword(base, pq < target ? pq : fend4 - 4, fend) : 0;
 
             // ---- 1 + 2: lookups and insertions, step by step
             const uint32_t P0 = gs + 4 * tid;                                       // my four positions: P0 .. P0 + 3, tile = wave
             const uint32_t i0 = (P0 >> 2) & 16383u;
-            const uint32_t dm1 = ring[(i0 - 1) & 16383u], d0 = ring[i0], d1 = ring[(i0 + 1) & 16383u], d2 = ring[(i0 + 2) & 16383u];
-            uint32_t wlo[4], whi[4], hsh[4], e0[4], e1[4];
+            const uint32_t dm1 = ring[(i0 - 1) & 16383u], d0 = ring[i0], d1 = ring[i0 + 1], d2 = ring[i0 + 2], d3 = ring[i0 + 3], d4 = ring[i0 + 4];
+            uint32_t wlo[4], whi[4], hsh[4], tix[4], tw[4], e1[4];
+            bool tabled[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 wlo[k] = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)k);
                 whi[k] = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)k);
                 const uint32_t p = P0 + k;
-                hsh[k] = p < ge && p + 8 <= fend ? zke_hash(wlo[k], whi[k] & 0xFF, HLOG) : 0xFFFFFFFFu;
-                e0[k] = 0; e1[k] = 0;
+                tabled[k] = p < ge && p + 8 <= fend;
+                hsh[k] = tabled[k] ? zke_hash(wlo[k], whi[k] & 0xFF, HLOG) : NONE;
+                tix[k] = tabled[k] ? (T32 ? hsh[k] : hsh[k] >> 1) : DUMMY;             // the table word of the position
+                tw[k] = 0; e1[k] = 0;
             }
             constexpr uint32_t LPS = STEP / 4;                                      // lanes per step
             const uint32_t mystep = tid / LPS;
@@ -158,63 +212,103 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
             for (uint32_t s = 0; s < ZKE_GROUP_POS / STEP; s++) {
                 const uint32_t ls = gs + s * STEP, le = ls + STEP < ge ? ls + STEP : ge;
                 if (ls < ge) {                                                     // uniform
-                    if (mystep == s) {
+                    if (STEP == (int)ZKE_GROUP_POS || mystep == s) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) if (hsh[k] != 0xFFFFFFFFu) e0[k] = zke_table_get(table, hsh[k]);
+                        for (int k = 0; k < 4; k++) tw[k] = table[tix[k]];             // far candidates; with 16-bit entries also what the insertion swaps against
                     }
+                    ZKE_CLK(1);
                     ZKE_LDS_BARRIER();
+                    ZKE_CLK(2);
                     // A position whose hash also belongs to one of the four positions before it cannot win its slot (the smaller
                     // position does): it stays out of the race.  On runs of equal bytes or short periods all lanes of a step
                     // would otherwise fight over a few LDS words.  The table ends the step in the same state.
-                    const uint32_t q0 = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)hsh[0], 0x111, 0xF, 0xF, false);
-                    const uint32_t q1 = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)hsh[1], 0x111, 0xF, 0xF, false);
-                    const uint32_t q2 = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)hsh[2], 0x111, 0xF, 0xF, false);
-                    const uint32_t q3 = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)hsh[3], 0x111, 0xF, 0xF, false);
-                    if (mystep == s) {
-                        const uint32_t span = le - ls;
-                        if (hsh[0] != 0xFFFFFFFFu && hsh[0] != q3 && hsh[0] != q2 && hsh[0] != q1 && hsh[0] != q0) zke_table_put<1>(table, hsh[0], P0, ls, span);
-                        if (hsh[1] != 0xFFFFFFFFu && hsh[1] != hsh[0] && hsh[1] != q3 && hsh[1] != q2 && hsh[1] != q1) zke_table_put<1>(table, hsh[1], P0 + 1, ls, span);
-                        if (hsh[2] != 0xFFFFFFFFu && hsh[2] != hsh[1] && hsh[2] != hsh[0] && hsh[2] != q3 && hsh[2] != q2) zke_table_put<1>(table, hsh[2], P0 + 2, ls, span);
-                        if (hsh[3] != 0xFFFFFFFFu && hsh[3] != hsh[2] && hsh[3] != hsh[1] && hsh[3] != hsh[0] && hsh[3] != q3) zke_table_put<1>(table, hsh[3], P0 + 3, ls, span);
-                    }
-                    ZKE_LDS_BARRIER();
-                    if (mystep == s) {
+                    const uint32_t q0 = ZKE_ROW_SHR(hsh[0], 1, NONE), q1 = ZKE_ROW_SHR(hsh[1], 1, NONE), q2 = ZKE_ROW_SHR(hsh[2], 1, NONE), q3 = ZKE_ROW_SHR(hsh[3], 1, NONE);
+                    bool go[4];
+                    go[0] = tabled[0] && hsh[0] != q3 && hsh[0] != q2 && hsh[0] != q1 && hsh[0] != q0;
+                    go[1] = tabled[1] && hsh[1] != hsh[0] && hsh[1] != q3 && hsh[1] != q2 && hsh[1] != q1;
+                    go[2] = tabled[2] && hsh[2] != hsh[1] && hsh[2] != hsh[0] && hsh[2] != q3 && hsh[2] != q2;
+                    go[3] = tabled[3] && hsh[3] != hsh[2] && hsh[3] != hsh[1] && hsh[3] != hsh[0] && hsh[3] != q3;
+                    if (T32) {
+                        const uint32_t khi = (0xFFFFu - stepno) << 16;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) if (hsh[k] != 0xFFFFFFFFu) e1[k] = zke_table_get(table, hsh[k]);
+                        for (int k = 0; k < 4; k++) {
+                            const bool g = go[k] && (STEP == (int)ZKE_GROUP_POS || mystep == s);
+                            atomicMin(&table[g ? tix[k] : DUMMY], g ? khi | ((P0 + k + bias) & 0xFFFFu) : NONE);
+                        }
+                    } else if (mystep == s) {
+                        // the four swaps leave together (against the words read before the barrier); what failed -- a neighbour
+                        // was faster on the same word -- goes round again on its own
+                        const uint32_t span = le - ls, b16 = ls & 0xFFFFu;
+                        uint32_t seen[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t sh = 16 * (hsh[k] & 1), mine = (P0 + k) & 0xFFFFu;
+                            go[k] = go[k] && !zke_step_keeps(tw[k], sh, mine, b16, span);
+                            seen[k] = tw[k];
+                            if (go[k]) seen[k] = atomicCAS(&table[tix[k]], tw[k], (tw[k] & ~(0xFFFFu << sh)) | (mine << sh));
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) if (go[k] && seen[k] != tw[k]) zke_table_put<1>(table, hsh[k], P0 + k, ls, span, seen[k]);
                     }
+                    ZKE_CLK(3);
+                    ZKE_LDS_BARRIER();
+                    ZKE_CLK(4);
+                    if (STEP == (int)ZKE_GROUP_POS || mystep == s) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) e1[k] = table[tix[k]];             // near candidates: what the step left in my slots
+                    }
+                    stepno++;
                 }
             }
 
-            // ---- 3a: comparisons out of the ring -> best[]
+            // ---- 3a: comparisons out of the ring -> best[].  16 bytes per candidate, no branches: an invalid candidate
+            // compares the position with itself and is dropped by its flag, so all ring reads of the lane are in flight together.
             const uint32_t ts = gs + wave * ZKE_TILE, te = ts + ZKE_TILE < ge ? ts + ZKE_TILE : ge;      // my tile
             {
                 const uint32_t ls = gs + mystep * STEP;
+                const uint32_t khi = (0xFFFFu - (stepno - ZKE_GROUP_POS / STEP + mystep)) << 16;       // the key half of my step (32-bit entries)
+                uint64_t olo[5], ohi[5];                                                // bytes p .. p + 15 of positions P0 - 1 .. P0 + 3
+                olo[0] = (uint64_t)__builtin_amdgcn_alignbyte(d0, dm1, 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(d1, d0, 3u) << 32);
+                ohi[0] = (uint64_t)__builtin_amdgcn_alignbyte(d2, d1, 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(d3, d2, 3u) << 32);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    olo[k + 1] = (uint64_t)wlo[k] | ((uint64_t)whi[k] << 32);
+                    ohi[k + 1] = (uint64_t)__builtin_amdgcn_alignbyte(d3, d2, (uint32_t)k) | ((uint64_t)__builtin_amdgcn_alignbyte(d4, d3, (uint32_t)k) << 32);
+                }
+                uint32_t lf[4], ln[4], lr[4], df[4], dn[4];
+                bool vf[4], vn[4];
+                const bool vr0 = R > 1;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t p = P0 + k;
-                    if (p < ge) {
-                        const uint64_t w = (uint64_t)wlo[k] | ((uint64_t)whi[k] << 32);
-                        const uint32_t n = te - p < ZKE_PARCAP ? te - p : ZKE_PARCAP;   // a match may not leave the tile
-                        uint32_t bl = 0, bo = 0;
-                        if (hsh[k] != 0xFFFFFFFFu) {
-                            uint32_t d = (p - e0[k]) & 0xFFFFu;                         // far: what the table held before the step
-                            if (d && d <= p && d <= ZKE_WINDOW) { const uint32_t l = zke_mlen(ring, p - d, p, w, n); if (l >= minmatch) { bl = l; bo = d; } }
-                            d = (p - e1[k]) & 0xFFFFu;                                  // near: an earlier position of this step
-                            if (d && d <= p - ls) { const uint32_t l = zke_mlen(ring, p - d, p, w, n); if (l >= minmatch && l >= bl) { bl = l; bo = d; } }
-                        }
-                        if (p >= 1) {                                                   // offset 1, out of registers: bytes p - 1 .. p + 6
-                            const uint64_t w1 = k == 0 ? ((uint64_t)__builtin_amdgcn_alignbyte(d0, dm1, 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(d1, d0, 3u) << 32))
-                                                       : ((uint64_t)wlo[k ? k - 1 : 0] | ((uint64_t)whi[k ? k - 1 : 0] << 32));
-                            const uint64_t x = w ^ w1;
-                            uint32_t l = x ? (uint32_t)__builtin_ctzll(x) >> 3 : zke_mlen(ring, p - 1, p, w, n);
-                            if (l > n) l = n;
-                            if (l >= 4 && l >= bl) { bl = l; bo = 1; }
-                        }
-                        if (R > 1 && R <= p) { const uint32_t l = zke_mlen(ring, p - R, p, w, n); if (l >= 4 && l >= bl) { bl = l; bo = R; } }
-                        best[4 * tid + k] = bl | (bo << 8);
-                    }
+                    const uint32_t ef = T32 ? tw[k] & 0xFFFFu : (tw[k] >> (16 * (hsh[k] & 1))) & 0xFFFFu;
+                    const uint32_t en = T32 ? e1[k] & 0xFFFFu : (e1[k] >> (16 * (hsh[k] & 1))) & 0xFFFFu;
+                    df[k] = (p + bias - ef) & 0xFFFFu;                                  // far: what the table held before the step
+                    vf[k] = tabled[k] && df[k] && df[k] <= p && df[k] <= ZKE_WINDOW;
+                    dn[k] = (p + bias - en) & 0xFFFFu;                                  // near: an earlier position of this step
+                    vn[k] = tabled[k] && dn[k] && (T32 ? (e1[k] & 0xFFFF0000u) == khi : dn[k] <= p - ls);
+#ifdef ZKE_EXP_NOCOMPARE
+                    lf[k] = ln[k] = lr[k] = (tw[k] ^ e1[k]) & 15;
+#else
+                    lf[k] = zke_common16(ring, vf[k] ? p - df[k] : p, olo[k + 1], ohi[k + 1]);
+                    ln[k] = zke_common16(ring, vn[k] ? p - dn[k] : p, olo[k + 1], ohi[k + 1]);
+                    lr[k] = zke_common16(ring, vr0 && R <= p ? p - R : p, olo[k + 1], ohi[k + 1]);
+#endif
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t p = P0 + k;
+                    const uint32_t n = p < te ? (te - p < ZKE_PARCAP ? te - p : ZKE_PARCAP) : 0;   // a match may not leave the tile
+                    uint32_t bl = 0, bo = 0, l;
+                    l = lf[k] < n ? lf[k] : n; if (vf[k] && l >= minmatch) { bl = l; bo = df[k]; }
+                    l = ln[k] < n ? ln[k] : n; if (vn[k] && l >= minmatch && l >= bl) { bl = l; bo = dn[k]; }
+                    l = zke_common16r(olo[k], ohi[k], olo[k + 1], ohi[k + 1]);          // offset 1, out of registers
+                    l = l < n ? l : n; if (p >= 1 && l >= 4 && l >= bl) { bl = l; bo = 1; }
+                    l = lr[k] < n ? lr[k] : n; if (vr0 && R <= p && l >= 4 && l >= bl) { bl = l; bo = R; }
+                    best[4 * tid + k] = bl | (bo << 8);                                 // positions past the tile's end: length 0
                 }
             }
+            ZKE_CLK(5);
             // ---- 3b: wave w parses tile w (it wrote that slice of best[] itself: LDS operations of a wave complete in order)
             __builtin_amdgcn_wave_barrier();
             if (ts < ge) {                                                              // uniform per wave
@@ -223,25 +317,25 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                 for (uint32_t wb = 0; ts + wb < te; wb += 64) {
                     const uint32_t pos = wb + lane, p = ts + pos;
                     const bool in = p < te;
-                    const uint32_t v = in ? best[wave * ZKE_TILE + pos] : 0;
+                    const uint32_t v = best[wave * ZKE_TILE + pos];                     // length 0 past the tile's end
                     uint32_t len = v & 0xFF;
                     bool cand = len != 0;
                     if (LAZY) {
-                        const uint32_t i1 = wave * ZKE_TILE + pos + 1, i2 = i1 + 1;
-                        const uint32_t l1 = p + 1 < te ? best[i1 < ZKE_GROUP_POS ? i1 : 0] & 0xFF : 0;
-                        const uint32_t l2 = p + 2 < te ? best[i2 < ZKE_GROUP_POS ? i2 : 0] & 0xFF : 0;
-                        if (l1 > len || l2 > len + 1) cand = false;
+                        const uint32_t l1 = best[wave * ZKE_TILE + pos + 1 < ZKE_GROUP_POS ? wave * ZKE_TILE + pos + 1 : 0] & 0xFF;
+                        const uint32_t l2 = best[wave * ZKE_TILE + pos + 2 < ZKE_GROUP_POS ? wave * ZKE_TILE + pos + 2 : 0] & 0xFF;
+                        if ((p + 1 < te && l1 > len) || (p + 2 < te && l2 > len + 1)) cand = false;
                     }
-                    const uint64_t inmask = __ballot(in);
-                    uint64_t m = __ballot(cand);
-                    const uint32_t pre = skip > wb ? skip - wb : 0;                     // positions of this pass a match from the pass before covers
-                    uint64_t covered = zke_lowmask(pre), taken = 0;
-                    m &= ~covered;
+                    const uint32_t skip0 = skip;                                        // positions below it are covered by a match of the pass before
+                    uint64_t m = skip0 >= wb + 64 ? 0 : __ballot(cand) & ~zke_lowmask(skip0 > wb ? skip0 - wb : 0), taken = 0;
+#ifdef ZKE_EXP_NOPARSE
+                    m &= 1;
+#endif
+                    const uint64_t capped = __ballot(len == ZKE_PARCAP);
                     while (m) {                                                         // uniform: every lane walks the same mask
                         const uint32_t f = (uint32_t)__builtin_ctzll(m);
-                        uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)f);
-                        if (L == ZKE_PARCAP) {                                          // capped by the comparisons: extend, 64 bytes per step
+                        if ((capped >> f) & 1) {                                        // capped by the comparisons: extend, 64 bytes per step
                             const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)f) >> 8;
+                            uint32_t L = ZKE_PARCAP;
                             for (;;) {
                                 const uint32_t q = ts + wb + f + L + lane;
                                 const bool diff = q >= te || zke_ring1(ring, q) != zke_ring1(ring, q - off);
@@ -251,19 +345,21 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                             }
                             if (lane == f) len = L;
                         }
+                        const uint32_t e = f + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)f);
                         taken |= 1ull << f;
-                        const uint32_t e = f + L;
-                        covered |= zke_lowmask(e) & ~zke_lowmask(f);
                         skip = wb + e;
-                        m = e >= 64 ? 0 : m & ~zke_lowmask(e);
+                        if (e >= 64) break;
+                        m = (m >> e) << e;
                     }
                     // emission, all lanes at once: a taken lane's sequence index = sequences so far + taken lanes below it; its
-                    // literal length = its position - the end of the taken lane before it
+                    // literal length = its position - the end of the taken lane before it; a lane is a literal unless a match of
+                    // an earlier pass, the taken lane before it, or its own match covers it
                     const uint64_t below = taken & lane_lt;
                     const uint32_t myend = pos + len;
                     const uint32_t prevlane = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
                     const uint32_t pe = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(prevlane << 2), (int)myend);
-                    if ((taken >> lane) & 1) {
+                    const bool mine = (taken >> lane) & 1;
+                    if (mine) {
                         const uint32_t prev_end = below ? pe : aend;
                         tseq[wave][c + (uint32_t)__builtin_popcountll(below)] = (uint64_t)(pos - prev_end) | ((uint64_t)len << 12) | ((uint64_t)(v >> 8) << 24);
                     }
@@ -271,7 +367,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                         c += (uint32_t)__builtin_popcountll(taken); aend = skip;
                         lastoff = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(63u - (uint32_t)__builtin_clzll(taken))) >> 8;
                     }
-                    const uint64_t litm = inmask & ~covered;
+                    const uint64_t litm = __ballot(in && !mine && pos >= skip0 && !(below && pos < pe));
                     if ((litm >> lane) & 1) tl[nl + (uint32_t)__builtin_popcountll(litm & lane_lt)] = (uint8_t)zke_ring1(ring, p);
                     nl += (uint32_t)__builtin_popcountll(litm);
                 }
@@ -280,42 +376,64 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     tlast[wave] = lastoff;
                 }
             }
+            ZKE_CLK(6);
             ZKE_LDS_BARRIER();
+            ZKE_CLK(7);
 
             // ---- 4: ring <- next group's input; stitch the tiles; store sequences and literals
-            if (pq < target) ring[(pq >> 2) & 16383u] = pv;
+            if (pq < target) zke_ring_put(ring, (pq >> 2) & 16383u, pv);
             loaded = target;
             const uint32_t ntiles = (ge - gs + ZKE_TILE - 1) / ZKE_TILE;
-            uint32_t my_base = 0, my_lit = 0, my_pend = 0, my_poff = 0, my_cnt = 0, my_nl = 0;
+            uint32_t my_base, my_lit, my_pend, my_poff, my_cnt, my_nl;
             {
-                const uint32_t sv = (lane & 15) < ntiles ? tsum[lane & 15] : 0, lv = (lane & 15) < ntiles ? tlast[lane & 15] : 0;
-#pragma unroll
-                for (uint32_t t = 0; t < ZKE_GROUP; t++) {
-                    const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)sv, (int)t), lo = (uint32_t)__builtin_amdgcn_readlane((int)lv, (int)t);
-                    if (t < ntiles) {
-                        const uint32_t cn = s & 0xFF, tail = (s >> 8) & 0xFFF, tnl = s >> 20;
-                        if (t == wave) { my_base = nseq; my_lit = nlit; my_pend = pend; my_poff = prev_off; my_cnt = cn; my_nl = tnl; }
-                        if (cn) { pend = tail; prev_off = lo; probe = lo; nseq += cn; }
-                        else pend += tail;
-                        nlit += tnl;
-                    }
-                }
+                // lane t of every row of 16 lanes takes tile t's summary; inclusive scans along the row:
+                //   counts and literal bytes            plain sums (count | bytes << 16)
+                //   literals pending behind tile t      tail(t) if the tile has sequences, else pending(t - 1) + tail(t): segmented sum, bit 31 = "a tile with sequences is inside"
+                //   offset of the last sequence so far  the last non-zero value
+                const uint32_t t = lane & 15;
+                const uint32_t sv = t < ntiles ? tsum[t] : 0, lv = t < ntiles ? tlast[t] : 0;
+                const uint32_t cn = sv & 0xFF, tail = (sv >> 8) & 0xFFF, tnl = sv >> 20;
+                uint32_t x = cn | (tnl << 16), y = tail | (cn ? 0x80000000u : 0u), z = cn ? lv : 0;
+#define ZKE_SCAN_STEP(d) { const uint32_t xs = ZKE_ROW_SHR(x, d, 0), ys = ZKE_ROW_SHR(y, d, 0), zs = ZKE_ROW_SHR(z, d, 0); \
+                           x += xs; y = (y & 0x80000000u) ? y : (y + (ys & 0x7FFFFFFFu)) | (ys & 0x80000000u); z = z ? z : zs; }
+                ZKE_SCAN_STEP(1) ZKE_SCAN_STEP(2) ZKE_SCAN_STEP(4) ZKE_SCAN_STEP(8)
+#undef ZKE_SCAN_STEP
+                // what is in front of my tile = the scans at lane wave - 1; the group's totals = lane 15
+                const uint32_t wm = wave ? wave - 1 : 0;
+                const uint32_t xp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)x, (int)wm) : 0, yp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)y, (int)wm) : 0,
+                               zp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)z, (int)wm) : 0;
+                const uint32_t me = (uint32_t)__builtin_amdgcn_readlane((int)sv, (int)wave);
+                const uint32_t xt = (uint32_t)__builtin_amdgcn_readlane((int)x, 15), yt = (uint32_t)__builtin_amdgcn_readlane((int)y, 15), zt = (uint32_t)__builtin_amdgcn_readlane((int)z, 15);
+                my_base = nseq + (xp & 0xFFFF); my_lit = nlit + (xp >> 16);
+                my_pend = (yp & 0x80000000u) ? yp & 0x7FFFFFFFu : pend + yp;
+                my_poff = zp ? zp : prev_off;
+                my_cnt = me & 0xFF; my_nl = me >> 20;
+                nseq += xt & 0xFFFF; nlit += xt >> 16;
+                pend = (yt & 0x80000000u) ? yt & 0x7FFFFFFFu : pend + yt;
+                if (zt) { prev_off = zt; probe = zt; }
             }
             if (wave < ntiles) {
-                for (uint32_t j = lane; j < my_cnt; j += 64) {
-                    const uint64_t e = tseq[wave][j];
+                if (lane < my_cnt) {                                                    // <= 64 sequences per tile: one per lane
+                    const uint64_t e = tseq[wave][lane];
                     uint32_t ll = (uint32_t)e & 0xFFF;
                     const uint32_t ml = (uint32_t)(e >> 12) & 0xFFF, off = (uint32_t)(e >> 24);
-                    const uint32_t poff = j ? (uint32_t)(tseq[wave][j - 1] >> 24) : my_poff;
-                    if (j == 0) ll += my_pend;
+                    const uint32_t poff = lane ? (uint32_t)(tseq[wave][lane - 1] >> 24) : my_poff;
+                    if (lane == 0) ll += my_pend;
                     const uint32_t code = (ll && off == poff) ? 1u : off + 3;
-                    sq[my_base + j] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)code << 40);
+                    sq[my_base + lane] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)code << 40);
                 }
-                const uint8_t *tl = (const uint8_t *)&best[wave * ZKE_TILE];
-                for (uint32_t i = lane; i < my_nl; i += 64) lt[my_lit + i] = tl[i];
+                // the tile's literals: four bytes per lane (an unaligned dword store), the last bytes one by one
+                const uint32_t *tw4 = &best[wave * ZKE_TILE];
+                const uint8_t *tl = (const uint8_t *)tw4;
+                uint8_t *o = lt + my_lit;
+                if (4 * lane + 4 <= my_nl) { const uint32_t w4 = tw4[lane]; memcpy(o + 4 * lane, &w4, 4); }
+                else for (uint32_t i = 4 * lane; i < my_nl; i++) o[i] = tl[i];
             }
+            ZKE_CLK(8);
             ZKE_LDS_BARRIER();                                 // the ring's new bytes are visible; best[] / tseq[] may be reused
+            ZKE_CLK(9);
         }
         if (tid == 0) { blk->nseq = nseq; blk->nlit = nlit; }
     }
+    ZKE_CLK_END();
 }

@@ -27,6 +27,18 @@
 #include "zk_kernels.h"
 
 // ------------------------------------------------------------------------------------------------ match + parse
+#ifdef ZKE_CLOCKS
+// experiments: shader-clock totals per phase of the match kernel, summed over lane 0 of every wave (tools/enc_clocks.py)
+__device__ unsigned long long zke_dbg_clk[16];
+extern "C" void zk_debug_enc_clocks(unsigned long long *out, int reset)
+{
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zke_dbg_clk), z, sizeof z); }
+    else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(zke_dbg_clk), 16 * sizeof(unsigned long long));
+}
+#define ZKE_CLK_BEGIN() unsigned long long clk_[16] = {0}, t_ = clock64()
+#define ZKE_CLK(i) do { const unsigned long long now_ = clock64(); clk_[i] += now_ - t_; t_ = now_; } while (0)
+#define ZKE_CLK_END() do { if ((threadIdx.x & 63) == 0) for (int i = 0; i < 16; i++) atomicAdd(&zke_dbg_clk[i], clk_[i]); } while (0)
+#endif
 #include "zk_enc_match.h"
 
 // ------------------------------------------------------------------------------------------------ entropy stage
