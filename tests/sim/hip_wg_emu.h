@@ -141,3 +141,4 @@ static void emu_run_workgroup(uint32_t nthreads, uint32_t block, std::function<v
 #define __builtin_amdgcn_readfirstlane(v) (v)          /* only used on values that are uniform across the wave */
 #define atomicCAS(p, c, v) emu_atomic_cas((p), (c), (v))
 #define atomicMin(p, v) emu_atomic_min((p), (v))
+#define __ffs(x) __builtin_ffs(x)

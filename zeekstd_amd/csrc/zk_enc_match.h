@@ -61,19 +61,22 @@ __device__ __forceinline__ uint64_t zke_ring8(const uint32_t *ring, uint32_t pos
 }
 __device__ __forceinline__ uint32_t zke_ring1(const uint32_t *ring, uint32_t pos) { return ((const uint8_t *)ring)[pos & 0xFFFFu]; }
 
-// bytes (<= 16) that the 16 bytes at ring position c share with (olo, ohi)
-__device__ __forceinline__ uint32_t zke_common16(const uint32_t *ring, uint32_t c, uint64_t olo, uint64_t ohi)
+// index of the first non-zero byte of the 16 bytes x0 .. x3 (16: none).  v_ffbl_b32 yields -1 for 0, and -1 | 32 stays -1.
+__device__ __forceinline__ uint32_t zke_first16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
+{
+    const uint32_t f0 = (uint32_t)(__ffs((int)x0) - 1), f1 = (uint32_t)(__ffs((int)x1) - 1) | 32u, f2 = (uint32_t)(__ffs((int)x2) - 1) | 64u, f3 = (uint32_t)(__ffs((int)x3) - 1) | 96u;
+    uint32_t r = f0 < f1 ? f0 : f1;
+    const uint32_t t = f2 < f3 ? f2 : f3;
+    r = r < t ? r : t;
+    return (r < 128u ? r : 128u) >> 3;
+}
+// bytes (<= 16) that the 16 bytes at ring position c share with the 16 bytes o0 .. o3
+__device__ __forceinline__ uint32_t zke_common16(const uint32_t *ring, uint32_t c, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3)
 {
     const uint32_t i = (c >> 2) & 16383u, sh = c & 3u;
     const uint32_t a0 = ring[i], a1 = ring[i + 1], a2 = ring[i + 2], a3 = ring[i + 3], a4 = ring[i + 4];
-    const uint64_t x0 = olo ^ ((uint64_t)__builtin_amdgcn_alignbyte(a1, a0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(a2, a1, sh) << 32));
-    const uint64_t x1 = ohi ^ ((uint64_t)__builtin_amdgcn_alignbyte(a3, a2, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(a4, a3, sh) << 32));
-    return x0 ? (uint32_t)__builtin_ctzll(x0) >> 3 : x1 ? 8 + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16;
-}
-__device__ __forceinline__ uint32_t zke_common16r(uint64_t clo, uint64_t chi, uint64_t olo, uint64_t ohi)
-{
-    const uint64_t x0 = olo ^ clo, x1 = ohi ^ chi;
-    return x0 ? (uint32_t)__builtin_ctzll(x0) >> 3 : x1 ? 8 + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16;
+    return zke_first16(o0 ^ __builtin_amdgcn_alignbyte(a1, a0, sh), o1 ^ __builtin_amdgcn_alignbyte(a2, a1, sh),
+                       o2 ^ __builtin_amdgcn_alignbyte(a3, a2, sh), o3 ^ __builtin_amdgcn_alignbyte(a4, a3, sh));
 }
 
 // Table forms.
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
     __shared__ uint32_t ring[ZKE_RING_WORDS + 8];
     __shared__ uint32_t table[TWORDS + 1];
     __shared__ uint32_t best[ZKE_GROUP_POS];
-    __shared__ uint64_t tseq[ZKE_GROUP][ZKE_TSEQ_N];        // ll | ml << 12 | offset << 24
+    __shared__ uint64_t tseq[ZKE_GROUP][ZKE_TSEQ_N];        // ll | ml << 12 in the low half, the offset in the high half
     __shared__ uint32_t tsum[ZKE_GROUP], tlast[ZKE_GROUP];   // count | trailing literals << 8 | literal bytes << 20;  offset of the tile's last sequence
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const ZkEncFrame fr = segs[blockIdx.x];
@@ -267,15 +270,18 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
             {
                 const uint32_t ls = gs + mystep * STEP;
                 const uint32_t khi = (0xFFFFu - (stepno - ZKE_GROUP_POS / STEP + mystep)) << 16;       // the key half of my step (32-bit entries)
-                uint64_t olo[5], ohi[5];                                                // bytes p .. p + 15 of positions P0 - 1 .. P0 + 3
-                olo[0] = (uint64_t)__builtin_amdgcn_alignbyte(d0, dm1, 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(d1, d0, 3u) << 32);
-                ohi[0] = (uint64_t)__builtin_amdgcn_alignbyte(d2, d1, 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(d3, d2, 3u) << 32);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    olo[k + 1] = (uint64_t)wlo[k] | ((uint64_t)whi[k] << 32);
-                    ohi[k + 1] = (uint64_t)__builtin_amdgcn_alignbyte(d3, d2, (uint32_t)k) | ((uint64_t)__builtin_amdgcn_alignbyte(d4, d3, (uint32_t)k) << 32);
+                // the 20 bytes of my four positions against the 20 bytes one byte / R bytes before them, once for all four
+                const uint32_t own[5] = {d0, d1, d2, d3, d4};
+                uint32_t x1[5], xr[5];                                                  // own ^ (own one byte earlier), own ^ (own R bytes earlier)
+                {
+                    const uint32_t rb = P0 - R, ri = (rb >> 2) & 16383u, rs = rb & 3u;  // R <= P0 is tested below; a wrong address reads some ring bytes
+                    const uint32_t r0 = ring[ri], r1 = ring[ri + 1], r2 = ring[ri + 2], r3 = ring[ri + 3], r4 = ring[ri + 4], r5 = ring[ri + 5];
+                    x1[0] = d0 ^ __builtin_amdgcn_alignbyte(d0, dm1, 3u); x1[1] = d1 ^ __builtin_amdgcn_alignbyte(d1, d0, 3u); x1[2] = d2 ^ __builtin_amdgcn_alignbyte(d2, d1, 3u);
+                    x1[3] = d3 ^ __builtin_amdgcn_alignbyte(d3, d2, 3u); x1[4] = d4 ^ __builtin_amdgcn_alignbyte(d4, d3, 3u);
+                    xr[0] = d0 ^ __builtin_amdgcn_alignbyte(r1, r0, rs); xr[1] = d1 ^ __builtin_amdgcn_alignbyte(r2, r1, rs); xr[2] = d2 ^ __builtin_amdgcn_alignbyte(r3, r2, rs);
+                    xr[3] = d3 ^ __builtin_amdgcn_alignbyte(r4, r3, rs); xr[4] = d4 ^ __builtin_amdgcn_alignbyte(r5, r4, rs);
                 }
-                uint32_t lf[4], ln[4], lr[4], df[4], dn[4];
+                uint32_t lf[4], ln[4], df[4], dn[4];
                 bool vf[4], vn[4];
                 const bool vr0 = R > 1;
 #pragma unroll
@@ -287,12 +293,12 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     vf[k] = tabled[k] && df[k] && df[k] <= p && df[k] <= ZKE_WINDOW;
                     dn[k] = (p + bias - en) & 0xFFFFu;                                  // near: an earlier position of this step
                     vn[k] = tabled[k] && dn[k] && (T32 ? (e1[k] & 0xFFFF0000u) == khi : dn[k] <= p - ls);
+                    const uint32_t o0 = wlo[k], o1 = whi[k], o2 = __builtin_amdgcn_alignbyte(own[3], own[2], (uint32_t)k), o3 = __builtin_amdgcn_alignbyte(own[4], own[3], (uint32_t)k);
 #ifdef ZKE_EXP_NOCOMPARE
-                    lf[k] = ln[k] = lr[k] = (tw[k] ^ e1[k]) & 15;
+                    lf[k] = ln[k] = (tw[k] ^ e1[k] ^ o2 ^ o3) & 15;
 #else
-                    lf[k] = zke_common16(ring, vf[k] ? p - df[k] : p, olo[k + 1], ohi[k + 1]);
-                    ln[k] = zke_common16(ring, vn[k] ? p - dn[k] : p, olo[k + 1], ohi[k + 1]);
-                    lr[k] = zke_common16(ring, vr0 && R <= p ? p - R : p, olo[k + 1], ohi[k + 1]);
+                    lf[k] = zke_common16(ring, vf[k] ? p - df[k] : p, o0, o1, o2, o3);
+                    ln[k] = zke_common16(ring, vn[k] ? p - dn[k] : p, o0, o1, o2, o3);
 #endif
                 }
 #pragma unroll
@@ -302,9 +308,12 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     uint32_t bl = 0, bo = 0, l;
                     l = lf[k] < n ? lf[k] : n; if (vf[k] && l >= minmatch) { bl = l; bo = df[k]; }
                     l = ln[k] < n ? ln[k] : n; if (vn[k] && l >= minmatch && l >= bl) { bl = l; bo = dn[k]; }
-                    l = zke_common16r(olo[k], ohi[k], olo[k + 1], ohi[k + 1]);          // offset 1, out of registers
+                    l = zke_first16(__builtin_amdgcn_alignbyte(x1[1], x1[0], (uint32_t)k), __builtin_amdgcn_alignbyte(x1[2], x1[1], (uint32_t)k),
+                                    __builtin_amdgcn_alignbyte(x1[3], x1[2], (uint32_t)k), __builtin_amdgcn_alignbyte(x1[4], x1[3], (uint32_t)k));   // offset 1
                     l = l < n ? l : n; if (p >= 1 && l >= 4 && l >= bl) { bl = l; bo = 1; }
-                    l = lr[k] < n ? lr[k] : n; if (vr0 && R <= p && l >= 4 && l >= bl) { bl = l; bo = R; }
+                    l = zke_first16(__builtin_amdgcn_alignbyte(xr[1], xr[0], (uint32_t)k), __builtin_amdgcn_alignbyte(xr[2], xr[1], (uint32_t)k),
+                                    __builtin_amdgcn_alignbyte(xr[3], xr[2], (uint32_t)k), __builtin_amdgcn_alignbyte(xr[4], xr[3], (uint32_t)k));   // offset R
+                    l = l < n ? l : n; if (vr0 && R <= p && l >= 4 && l >= bl) { bl = l; bo = R; }
                     best[4 * tid + k] = bl | (bo << 8);                                 // positions past the tile's end: length 0
                 }
             }
@@ -326,13 +335,21 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                         if ((p + 1 < te && l1 > len) || (p + 2 < te && l2 > len + 1)) cand = false;
                     }
                     const uint32_t skip0 = skip;                                        // positions below it are covered by a match of the pass before
-                    uint64_t m = skip0 >= wb + 64 ? 0 : __ballot(cand) & ~zke_lowmask(skip0 > wb ? skip0 - wb : 0), taken = 0;
+                    const uint64_t candm = __ballot(cand), capped = __ballot(cand && len == ZKE_PARCAP);
+                    // every lane: the first candidate at or behind the end of its own match (64: none in this pass); the walk
+                    // below then costs the scalar unit a handful of instructions per match
+                    const uint32_t el = lane + len;
+                    const uint64_t behind = candm & (el >= 64 ? 0ull : ~0ull << el);
+                    const uint32_t nx = behind ? (uint32_t)__builtin_ctzll(behind) : 64u;
+                    const uint32_t pre = skip0 > wb ? skip0 - wb : 0;
+                    const uint64_t open = candm & (pre >= 64 ? 0ull : ~0ull << pre);
+                    uint32_t f = open ? (uint32_t)__builtin_ctzll(open) : 64u, lastf = 64;
+                    uint64_t taken = 0;
 #ifdef ZKE_EXP_NOPARSE
-                    m &= 1;
+                    if (f < 64) { taken = 1ull << f; lastf = f; f = 64; }
 #endif
-                    const uint64_t capped = __ballot(len == ZKE_PARCAP);
-                    while (m) {                                                         // uniform: every lane walks the same mask
-                        const uint32_t f = (uint32_t)__builtin_ctzll(m);
+                    while (f < 64) {                                                    // uniform: every lane walks the same chain
+                        taken |= 1ull << f; lastf = f;
                         if ((capped >> f) & 1) {                                        // capped by the comparisons: extend, 64 bytes per step
                             const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)f) >> 8;
                             uint32_t L = ZKE_PARCAP;
@@ -344,13 +361,12 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                                 L += 64;
                             }
                             if (lane == f) len = L;
-                        }
-                        const uint32_t e = f + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)f);
-                        taken |= 1ull << f;
-                        skip = wb + e;
-                        if (e >= 64) break;
-                        m = (m >> e) << e;
+                            const uint32_t e = f + L;
+                            const uint64_t rest = candm & (e >= 64 ? 0ull : ~0ull << e);
+                            f = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+                        } else f = (uint32_t)__builtin_amdgcn_readlane((int)nx, (int)f);
                     }
+                    if (taken) skip = wb + lastf + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)lastf);
                     // emission, all lanes at once: a taken lane's sequence index = sequences so far + taken lanes below it; its
                     // literal length = its position - the end of the taken lane before it; a lane is a literal unless a match of
                     // an earlier pass, the taken lane before it, or its own match covers it
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     const bool mine = (taken >> lane) & 1;
                     if (mine) {
                         const uint32_t prev_end = below ? pe : aend;
-                        tseq[wave][c + (uint32_t)__builtin_popcountll(below)] = (uint64_t)(pos - prev_end) | ((uint64_t)len << 12) | ((uint64_t)(v >> 8) << 24);
+                        tseq[wave][c + (uint32_t)__builtin_popcountll(below)] = (uint64_t)((pos - prev_end) | (len << 12)) | ((uint64_t)(v >> 8) << 32);
                     }
                     if (taken) {
                         c += (uint32_t)__builtin_popcountll(taken); aend = skip;
@@ -416,8 +432,8 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                 if (lane < my_cnt) {                                                    // <= 64 sequences per tile: one per lane
                     const uint64_t e = tseq[wave][lane];
                     uint32_t ll = (uint32_t)e & 0xFFF;
-                    const uint32_t ml = (uint32_t)(e >> 12) & 0xFFF, off = (uint32_t)(e >> 24);
-                    const uint32_t poff = lane ? (uint32_t)(tseq[wave][lane - 1] >> 24) : my_poff;
+                    const uint32_t ml = (uint32_t)(e >> 12) & 0xFFF, off = (uint32_t)(e >> 32);
+                    const uint32_t poff = lane ? (uint32_t)(tseq[wave][lane - 1] >> 32) : my_poff;
                     if (lane == 0) ll += my_pend;
                     const uint32_t code = (ll && off == poff) ? 1u : off + 3;
                     sq[my_base + lane] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)code << 40);

@@ -53,6 +53,10 @@ struct zk_engine {
     zk_devbuf enc_seg;                      // frames above ZKE_SEGMENT: the matcher's segment records
     ZkEncTables enc_tables;
     bool enc_tables_ready = false;
+    // second queue of the encoder: the checksum kernel (one serial chain per frame) runs beside the matcher (one workgroup
+    // per CU, half of the CU's wave slots free); created on first use
+    hipStream_t enc_aux = nullptr;
+    hipEvent_t enc_ev_fork = nullptr, enc_ev_join = nullptr;
 };
 
 int zk_devbuf_reserve(zk_engine *e, zk_devbuf &b, size_t bytes);

@@ -154,6 +154,8 @@ extern "C" void zk_engine_destroy(zk_engine *e)
         if (c.aux) (void)hipStreamDestroy(c.aux);
         if (c.st && i != 0) (void)hipStreamDestroy(c.st);     // context 0 runs on the engine's own stream
     }
+    if (e->enc_aux) { (void)hipStreamSynchronize(e->enc_aux); (void)hipStreamDestroy(e->enc_aux); }
+    for (hipEvent_t ev : {e->enc_ev_fork, e->enc_ev_join}) if (ev) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(e->stream);
     delete e;
 }

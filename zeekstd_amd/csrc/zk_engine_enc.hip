@@ -113,7 +113,20 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         zk_launch_enc_stage_hist(st, src, (const uint8_t *)a.d_prefix + (a.prefix_len - hist), dfr, nf, (uint8_t *)e->enc_hist.p);
         msrc = (const uint8_t *)e->enc_hist.p;
     }
-    if (a.checksum) { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, d_doff, 0, nf, nullptr, hashes); }
+    bool cks_beside = false;                                 // the checksums run on the second queue and are joined before the assembly
+    if (a.checksum) {
+        if (!e->profiling && !e->enc_aux) {
+            if (hipStreamCreateWithFlags(&e->enc_aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->enc_ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&e->enc_ev_join, hipEventDisableTiming) != hipSuccess) { e->enc_aux = nullptr; (void)hipGetLastError(); }
+        }
+        if (!e->profiling && e->enc_aux) {
+            ZK_HIP(hipEventRecord(e->enc_ev_fork, st));
+            ZK_HIP(hipStreamWaitEvent(e->enc_aux, e->enc_ev_fork, 0));
+            zk_launch_xxh64(e->enc_aux, src, d_doff, 0, nf, nullptr, hashes);
+            ZK_HIP(hipEventRecord(e->enc_ev_join, e->enc_aux));
+            cks_beside = true;
+        } else { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, d_doff, 0, nf, nullptr, hashes); }
+    }
     // the matcher's workgroups are launched over the segments (one per <= 256 KiB of a frame)
     if ((rc = zk_devbuf_reserve(e, e->enc_seg, segs_bytes + 64))) return rc;
     ZK_HIP(hipMemcpyAsync(e->enc_seg.p, segs, (size_t)nseg * sizeof(ZkEncFrame), hipMemcpyHostToDevice, st));
@@ -128,6 +141,7 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         ZK_HIP(hipStreamSynchronize(st));
         if (e->h_words[ZK_HW_ENC_TOTAL] > a.dst_cap) return -(int)ZK_E_DST_TOO_SMALL;
     }
+    if (cks_beside) ZK_HIP(hipStreamWaitEvent(st, e->enc_ev_join, 0));
     { zk_kernel_timer t(e, ZK_K_ENC_COMPACT, st); zk_launch_enc_assemble(st, src, dfr, nf, dbl, nb, ftab, (const uint8_t *)e->enc_d.p, out_off, c64, hashes, a.checksum, (uint8_t *)a.d_dst); }
     if (nf_out) *nf_out = nf;
     return 0;
