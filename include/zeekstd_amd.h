@@ -189,6 +189,17 @@ int zk_gather_seekable(zk_engine *e, void *nccl_comm, int rank, int world, int r
                        const uint32_t *c_sizes, const uint32_t *d_sizes, uint32_t n_frames, int format, void *d_out, uint64_t out_cap,
                        uint64_t *out_bytes, zk_seek_table **table_out, void *stream);
 
+/* Sharded decode (the decode side): rank r of `world` owns the contiguous frame range zk_shard_range gives it,
+ * reads / receives the compressed bytes [c_off[first], c_off[first + count]) of the archive -- nothing else -- and decodes
+ * them into its own buffer; the output stays sharded, there is no collective.  zk_decode_shard does the arithmetic:
+ * comp_shard points at exactly those bytes (frame `first` at comp_shard[0]), table is the archive's seek table
+ * (zk_seek_table_from_bytes / _from_reader on the tail every rank can read: 8 n + 17 bytes), dst receives the frames'
+ * decompressed bytes, *first / *count / *written report the range and its size.  Returns 0 or -(code) of the first
+ * failing frame, like zk_decode_frames. */
+int zk_shard_range(uint32_t n_frames, int rank, int world, uint32_t *first, uint32_t *count);
+int zk_decode_shard(zk_engine *e, const uint8_t *comp_shard, uint64_t shard_bytes, const zk_seek_table *table, int rank, int world,
+                    uint8_t *dst, uint64_t dst_cap, int verify, uint32_t *first, uint32_t *count, uint64_t *written);
+
 /* XXH64(seed 0) of count byte ranges data[off[i], off[i+1]) -> out[i].  (The checksum libzstd
  * computes when ZSTD_c_checksumFlag is set: encode.rs:163-167, 283-284.) */
 int zk_xxh64_frames(zk_engine *e, const uint8_t *data, const uint64_t *off, uint32_t count, uint64_t *out);
@@ -258,14 +269,21 @@ typedef struct zk_decode_opts {          /* DecodeOptions builder fields, decode
  * The byte source is borrowed and must outlive the decoder (BytesWrapper<'a>). */
 int zk_decoder_open_bytes(zk_engine *e, const uint8_t *src, size_t len, const zk_decode_opts *o, zk_decoder **out);
 int zk_decoder_open_file(zk_engine *e, const char *path, const zk_decode_opts *o, zk_decoder **out);   /* Read+Seek source, seekable.rs:112-138 */
-/* Any `impl Seekable` of the host (lib/src/seekable.rs:16-39: set_offset + read; seek_table_integrity is the trait's provided
- * method and is derived from the two).  set_offset: whence 0 = OffsetFrom::Start(value), 1 = OffsetFrom::End(value); returns
- * the new position counted from the start, or a negative value on failure.  read: bytes delivered (0 = end of source), or
- * negative on failure.  Failures surface as ZK_ERR_IO.  The engine pulls compressed bytes through `read` straight into its
- * pinned staging buffers; calls come from the thread that calls the decoder. */
+/* Any `impl Seekable` of the host (lib/src/seekable.rs:16-39).  set_offset: whence 0 = OffsetFrom::Start(value), 1 =
+ * OffsetFrom::End(value); returns the new position counted from the start, or a negative value on failure.  read: bytes
+ * delivered (0 = end of source), or negative on failure.  Failures surface as ZK_ERR_IO.  The engine pulls compressed bytes
+ * through `read` straight into its pinned staging buffers; calls come from the thread that calls the decoder.
+ * seek_table_integrity is a REQUIRED method of the trait (seekable.rs:33-38; each impl supplies it, :84-96, :126-137):
+ * zk_decoder_open_seekable takes it as a third callback -- format 0 = Format::Head, 1 = Format::Foot; it fills the 9-byte
+ * integrity field and returns 0, or a negative value on failure -- so a source that keeps the field elsewhere plugs in.
+ * zk_decoder_open_callbacks is the two-callback form: the field is then read the way both of the reference's own impls
+ * read it (seek to SKIPPABLE_HEADER_SIZE, or to End(-9), and read 9 bytes). */
 typedef int64_t (*zk_seek_fn)(void *user, int whence, int64_t value);
 typedef int64_t (*zk_read_fn)(void *user, uint8_t *buf, size_t len);
+typedef int (*zk_integrity_fn)(void *user, int format, uint8_t out[9]);
 int zk_decoder_open_callbacks(zk_engine *e, zk_seek_fn set_offset, zk_read_fn read, void *user, const zk_decode_opts *o, zk_decoder **out);
+int zk_decoder_open_seekable(zk_engine *e, zk_seek_fn set_offset, zk_read_fn read, zk_integrity_fn seek_table_integrity, void *user,
+                             const zk_decode_opts *o, zk_decoder **out);
 void zk_decoder_free(zk_decoder *d);
 int64_t zk_decoder_decompress(zk_decoder *d, uint8_t *buf, size_t len);                        /* :314; bytes written or <0 */
 int zk_decoder_decompress_with_prefix(zk_decoder *d, uint8_t *buf, size_t len, const uint8_t *prefix, size_t plen, size_t *out); /* :201 */

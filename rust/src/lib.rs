@@ -111,10 +111,18 @@ pub enum OffsetFrom { Start(u64), End(i64) }
 pub trait Seekable {
     fn set_offset(&mut self, offset: OffsetFrom) -> Result<u64>;
     fn read(&mut self, buf: &mut [u8]) -> Result<usize>;
+    /// required, like upstream (seekable.rs:33-38): a source may keep its integrity field anywhere
+    fn seek_table_integrity(&mut self, format: Format) -> Result<[u8; 9]>;
 }
 impl<T: Read + Seek> Seekable for T {
     fn set_offset(&mut self, offset: OffsetFrom) -> Result<u64> {
         Ok(self.seek(match offset { OffsetFrom::Start(n) => SeekFrom::Start(n), OffsetFrom::End(n) => SeekFrom::End(n) })?)
+    }
+    fn seek_table_integrity(&mut self, format: Format) -> Result<[u8; 9]> {                                 // seekable.rs:126-137
+        match format { Format::Head => self.seek(SeekFrom::Start(8))?, Format::Foot => self.seek(SeekFrom::End(-9))? };
+        let mut buf = [0u8; 9];
+        self.read_exact(&mut buf)?;
+        Ok(buf)
     }
     fn read(&mut self, buf: &mut [u8]) -> Result<usize> { Ok(Read::read(self, buf)?) }
 }
@@ -125,6 +133,14 @@ unsafe extern "C" fn seek_cb<S: Seekable>(user: *mut c_void, whence: c_int, valu
 unsafe extern "C" fn read_cb<S: Seekable>(user: *mut c_void, buf: *mut u8, len: usize) -> i64 {
     let s = &mut *(user as *mut S);
     match s.read(core::slice::from_raw_parts_mut(buf, len)) { Ok(n) => n as i64, Err(_) => -1 }
+}
+/// Seekable::seek_table_integrity is a required method of the trait (seekable.rs:33-38): the source's own answer is used
+unsafe extern "C" fn integrity_cb<S: Seekable>(user: *mut c_void, format: c_int, out: *mut u8) -> c_int {
+    let s = &mut *(user as *mut S);
+    match s.seek_table_integrity(if format == 0 { Format::Head } else { Format::Foot }) {
+        Ok(a) => { core::ptr::copy_nonoverlapping(a.as_ptr(), out, a.len()); 0 }
+        Err(_) => -1,
+    }
 }
 
 /// decode.rs:13-114
@@ -160,8 +176,8 @@ impl<'a, S: Seekable> Decoder<'a, S> {
         };
         let mut h = core::ptr::null_mut();
         check(unsafe {
-            ffi::zk_decoder_open_callbacks(o.engine.map_or(core::ptr::null_mut(), |e| e.as_ptr()), Some(seek_cb::<S>), Some(read_cb::<S>),
-                                           &mut *src as *mut S as *mut c_void, &opts, &mut h)
+            ffi::zk_decoder_open_seekable(o.engine.map_or(core::ptr::null_mut(), |e| e.as_ptr()), Some(seek_cb::<S>), Some(read_cb::<S>),
+                                          Some(integrity_cb::<S>), &mut *src as *mut S as *mut c_void, &opts, &mut h)
         })?;
         Ok(Decoder { h, _src: src, _table: o.seek_table, _e: core::marker::PhantomData })
     }
@@ -286,6 +302,6 @@ impl<W: Write> Drop for Encoder<'_, W> { fn drop(&mut self) { unsafe { ffi::zk_e
 pub mod batch {
     pub use crate::ffi::{zk_compress_bound, zk_decode_frame_list_dev, zk_decode_frames, zk_decode_frames_dev, zk_decode_frames_prefix,
                          zk_decode_frames_prefix_dev, zk_decode_submit_dev, zk_decode_wait, zk_encode_frames, zk_encode_frames_dev,
-                         zk_encode_frames_prefix, zk_encode_frames_prefix_dev, zk_gather_seekable, zk_host_alloc, zk_host_free,
+                         zk_decode_shard, zk_encode_frames_prefix, zk_encode_frames_prefix_dev, zk_gather_seekable, zk_host_alloc, zk_host_free, zk_shard_range,
                          zk_xxh64_frames, zk_xxh64_frames_dev};
 }

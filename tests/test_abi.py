@@ -84,6 +84,6 @@ def test_rust_binding_declares_every_symbol():
     lib_rs = open(os.path.join(ROOT, "rust", "src", "lib.rs")).read()
     for name in exported:
         if any(name.startswith(p) for p in ("zk_decoder_", "zk_encoder_", "zk_raw_encoder_", "zk_seek_table_", "zk_serializer_")) \
-                and name not in ("zk_decoder_open_bytes", "zk_decoder_open_file", "zk_decoder_gpu_submissions", "zk_decoder_time_seeks",
+                and name not in ("zk_decoder_open_bytes", "zk_decoder_open_file", "zk_decoder_open_callbacks", "zk_decoder_gpu_submissions", "zk_decoder_time_seeks",
                                  "zk_seek_table_from_reader_bytes", "zk_seek_table_entries", "zk_serializer_reset", "zk_raw_encoder_compress"):
             assert "ffi::" + name in lib_rs, name

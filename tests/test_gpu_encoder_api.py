@@ -361,3 +361,54 @@ def test_compressed_policy_with_a_prefix_in_bulk(engine):
     assert bytes(out) == new
     with pytest.raises(zk.Error):                                   # without the prefix the first frame does not decode to anything valid
         Decoder(DecodeOptions(blob).engine(engine)).read_to_end()
+
+
+def test_large_writes_into_frames_larger_than_the_write(engine):
+    """Uncompressed(fs) with fs above 64 MiB fed by 64 MiB+ writes that are smaller than fs -- the large-write
+    branch computed how much of the write completes the open frame without clamping it to the write (it read past the
+    caller's buffer and its length arithmetic wrapped).  Frames: 160 MiB, 160 MiB, 16 MiB; the output round-trips."""
+    fs = 160 << 20
+    piece = np.frombuffer(zko.gen_chunks(8 << 20, 3), np.uint8)
+    w = np.tile(piece, 12)                                          # 96 MiB per write: >= 64 MiB and < fs
+    sink = io.BytesIO()
+    enc = EncodeOptions().engine(engine).frame_size_policy(FrameSizePolicy.Uncompressed(fs)).checksum_flag(True).into_encoder(sink)
+    total_in = 0
+    for k in range(3):
+        enc.write_all(w.tobytes())
+        total_in += len(w)
+    enc.write_all(w[:48 << 20].tobytes())                           # ends exactly ON a frame boundary?  no: 336 MiB = 2 fs + 16 MiB
+    total_in += 48 << 20
+    n = enc.finish()
+    blob = sink.getvalue()
+    assert n == len(blob)
+    dec = Decoder(DecodeOptions(blob).engine(engine))
+    st = dec.seek_table()
+    assert [st.frame_size_decomp(i) for i in range(st.num_frames())] == [fs, fs, total_in - 2 * fs]
+    out = dec.read_to_end()
+    assert len(out) == total_in
+    assert out[:len(w)] == w.tobytes() and out[3 * len(w):] == w[:48 << 20].tobytes()
+    # a write that ends exactly at the frame's end leaves that frame open (upstream closes it on the next call): no empty tail
+    sink = io.BytesIO()
+    enc = EncodeOptions().engine(engine).frame_size_policy(FrameSizePolicy.Uncompressed(96 << 20)).into_encoder(sink)
+    enc.write_all(w[:32 << 20].tobytes())
+    enc.write_all(w[:64 << 20].tobytes())                           # 64 MiB write, fills the 96 MiB frame to the byte
+    enc.finish()
+    st = Decoder(DecodeOptions(sink.getvalue()).engine(engine)).seek_table()
+    assert [st.frame_size_decomp(i) for i in range(st.num_frames())] == [96 << 20]
+
+
+def test_compressed_policy_on_input_that_barely_has_a_size(engine):
+    """under Compressed(n) zero-filled input never lets the speculative path cut a frame (a frame would
+    pass MAX_FRAME_SIZE before reaching n); the held bytes used to pile up in pinned memory until finish().  They are now
+    drained through the exact path once 64 MiB are held, whose probes step geometrically while far from n."""
+    sink = io.BytesIO()
+    enc = EncodeOptions().engine(engine).frame_size_policy(FrameSizePolicy.Compressed(1 << 20)).into_encoder(sink)
+    z = bytes(48 << 20)
+    for _ in range(4):
+        enc.write_all(z)                                            # 192 MiB of zeros: a few KiB compressed
+    enc.finish()
+    blob = sink.getvalue()
+    dec = Decoder(DecodeOptions(blob).engine(engine))
+    assert dec.seek_table().size_decomp() == 192 << 20 and len(blob) < 1 << 20
+    out = dec.read_to_end()
+    assert len(out) == 192 << 20 and not any(out[::4099])

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import zeekstd_amd as zk
-from zeekstd_amd import DecodeOptions, EncodeOptions, FrameSizePolicy, SeekTable
+from zeekstd_amd import DecodeOptions, EncodeOptions, Format, FrameSizePolicy, SeekTable
 from conftest import PREFIX_GOLDENS, offsets_from_frames
 from oracle import zko
 from oracle import libzstd_ref as Z
@@ -322,3 +322,88 @@ def test_c_abi_gather_world1(engine, big):
     assert lib.zk_seek_table_num_frames(tab) == len(frames)
     lib.zk_seek_table_free.argtypes = [C.c_void_p]
     lib.zk_seek_table_free(tab)
+
+
+def test_source_failure_after_the_first_chunk_is_reported_not_unwound(engine, big):
+    """a Seekable that fails in the middle (a file error, a host callback returning < 0) used to throw through the
+    engine's pipeline with DMA, kernels and worker tasks in flight on that frame.  The failure is parked, the pipeline fails
+    the chunk and drains, then the error surfaces -- and the decoder and the engine stay usable."""
+    data, comp, frames = big
+    arch = _seekable(comp, frames)
+
+    class Flaky(io.BytesIO):
+        budget = 3 << 20                                       # payload bytes delivered before read starts to fail
+        armed = False
+
+        def read(self, n=-1):
+            if self.armed and self.tell() < len(comp):
+                if self.budget <= 0:
+                    raise OSError("disk on fire")
+                self.budget -= n
+            return super().read(n)
+
+    f = Flaky(arch)
+    d = DecodeOptions(f).engine(engine).batch_bytes(64 << 20).into_decoder()
+    f.armed = True
+    out = bytearray(len(data))
+    with pytest.raises(zk.Error):
+        d.decompress(out)
+    f.armed = False                                            # the source recovers: the same decoder goes on
+    d.reset()
+    assert d.decompress(out) == len(data) and bytes(out) == data
+    out2, st = engine.decode_frames(comp + b"\0" * 8, *offsets_from_frames(frames), verify=True)
+    assert out2 == data and not st.any()
+
+
+def test_seekable_with_its_own_integrity_field(engine):
+    """Seekable::seek_table_integrity is a REQUIRED method of the trait (seekable.rs:33-38): zk_decoder_open_seekable asks the
+    source.  Here the source keeps the 9-byte field apart from the stream (its tail is zeroed), which the two-callback form
+    -- reading the field at End(-9) like the reference's own impls -- could not serve."""
+    data = zko.gen_text(90000, 12)
+    comp, frames = engine.encode_frames(np.frombuffer(data, np.uint8), 10000, 1, True)
+    arch = bytearray(_seekable(comp, frames))
+    field = bytes(arch[-9:])
+    arch[-9:] = bytes(9)
+
+    class Apart(io.BytesIO):
+        asked = []
+
+        def seek_table_integrity(self, fmt):
+            self.asked.append(fmt)
+            return field
+
+    f = Apart(bytes(arch))
+    d = DecodeOptions(f).engine(engine).into_decoder()
+    assert f.asked == [Format.Foot] and d.seek_table().num_frames() == len(frames)
+    out = bytearray(len(data))
+    assert d.decompress(out) == len(data) and bytes(out) == data
+    with pytest.raises(zk.Error):                              # without the hook the zeroed tail is what gets parsed
+        DecodeOptions(io.BytesIO(bytes(arch))).engine(engine).into_decoder()
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_decode_shard_at_the_c_abi(engine, world):
+    """SURVEY 8e, decode side, as a host without torch calls it: every rank takes ONLY the compressed bytes of its contiguous
+    frame range (zk_shard_range) and zk_decode_shard turns them into its slice of the output; no collective."""
+    import ctypes as C
+    from zeekstd_amd import parallel
+    data = zko.gen_text(11 * 7000 + 1234, 5)
+    comp, frames = engine.encode_frames(np.frombuffer(data, np.uint8), 7000, 1, True)
+    st = SeekTable.new()
+    for c, d in frames:
+        st.log_frame(c, d)
+    c_off, d_off = offsets_from_frames(frames)
+    got = bytearray()
+    for rank in range(world):
+        lo, hi = parallel.shard_range(len(frames), rank, world)
+        first, count = C.c_uint32(), C.c_uint32()
+        assert zk.lib.zk_shard_range(len(frames), rank, world, C.byref(first), C.byref(count)) == 0
+        assert (first.value, count.value) == (lo, hi - lo)
+        f, n, out = parallel.decode_shard(engine, comp[int(c_off[lo]):int(c_off[hi])], st, rank, world)
+        assert (f, n) == (lo, hi - lo) and out == data[int(d_off[lo]):int(d_off[hi])]
+        got += out
+    assert bytes(got) == data
+    # a shard that does not hold its frames is refused, not read past
+    lo, hi = parallel.shard_range(len(frames), 0, 2)
+    with pytest.raises(zk.Error):
+        parallel.decode_shard(engine, comp[:int(c_off[hi]) - 1], st, 0, 2)

@@ -166,3 +166,44 @@ def test_bench_dry_run_world2():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["dry_run"] is True and d["scaling"] == "weak"
     assert d["rccl_gather"]["frames_on_root"] == 2 * d["config"]["frames_per_gpu"]
+
+
+def _worker_too_small(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    from zeekstd_amd import parallel
+    payload = torch.full((5000 + 100 * rank,), rank, dtype=torch.uint8)
+    cs = torch.tensor([payload.numel()], dtype=torch.int32)
+    ds = torch.tensor([20000], dtype=torch.int32)
+    verdicts = []
+    # the root's room: too small by one byte, then exactly enough (5000 + 5100 bytes of payload + 8 * 2 + 17 of table)
+    for cap in (10132, 10133):
+        try:
+            out, table = parallel.gather_seekable(payload, cs, ds, root=0, out_cap=cap if rank == 0 else None)
+            verdicts.append("ok" if (out is not None) == (rank == 0) else "bad")
+            if rank == 0:
+                assert out.numel() == 10133 and table.num_frames() == 2
+        except parallel.GatherTooSmall:
+            verdicts.append("too_small")
+    q.put((rank, verdicts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_failure_is_agreed_on_by_every_rank():
+    """VERDICT r2 #14 / ADVICE: a root whose destination is too small used to return alone while its peers went on to send
+    (a hang until the communicator timed out).  The root's capacity now travels with the sizes: every rank raises the same
+    error before a send or receive is posted, and the next collective on the same group works."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_too_small, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == {0: ["too_small", "ok"], 1: ["too_small", "ok"]}

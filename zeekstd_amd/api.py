@@ -74,6 +74,10 @@ for _n, _r, _a in [
     ("zk_decoder_open_bytes", C.c_int, [_P, _P, C.c_size_t, C.POINTER(zk_decode_opts), C.POINTER(_P)]),
     ("zk_decoder_open_file", C.c_int, [_P, C.c_char_p, C.POINTER(zk_decode_opts), C.POINTER(_P)]),
     ("zk_decoder_open_callbacks", C.c_int, [_P, _P, _P, _P, C.POINTER(zk_decode_opts), C.POINTER(_P)]),
+    ("zk_decoder_open_seekable", C.c_int, [_P, _P, _P, _P, _P, C.POINTER(zk_decode_opts), C.POINTER(_P)]),
+    ("zk_shard_range", C.c_int, [C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("zk_decode_shard", C.c_int, [_P, _P, C.c_uint64, _P, C.c_int, C.c_int, _P, C.c_uint64, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_uint64)]),
     ("zk_decoder_free", None, [_P]),
     ("zk_decoder_decompress", C.c_int64, [_P, _P, C.c_size_t]),
     ("zk_decoder_decompress_with_prefix", C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -264,6 +268,7 @@ class DecodeOptions:                   # decode.rs:13-114
 
 _SEEK_FN = C.CFUNCTYPE(C.c_int64, _P, C.c_int, C.c_int64)
 _READ_FN = C.CFUNCTYPE(C.c_int64, _P, _P, C.c_size_t)
+_INTEGRITY_FN = C.CFUNCTYPE(C.c_int, _P, C.c_int, _P)
 
 
 class Decoder:                         # decode.rs:117-579
@@ -295,8 +300,22 @@ class Decoder:                         # decode.rs:117-579
                     return len(b)
                 except Exception:
                     return -1
-            self._keep = (f, _SEEK_FN(_seek), _READ_FN(_read))
-            rc = lib.zk_decoder_open_callbacks(e, self._keep[1], self._keep[2], None, C.byref(opts._o), C.byref(h))
+            if hasattr(f, "seek_table_integrity"):
+                # a source that answers Seekable::seek_table_integrity itself (a required method of the trait, seekable.rs:33-38)
+                def _integrity(_user, fmt, out):
+                    try:
+                        b = bytes(f.seek_table_integrity(Format.Head if fmt == 0 else Format.Foot))
+                        if len(b) != 9:
+                            return -1
+                        C.memmove(out, b, 9)
+                        return 0
+                    except Exception:
+                        return -1
+                self._keep = (f, _SEEK_FN(_seek), _READ_FN(_read), _INTEGRITY_FN(_integrity))
+                rc = lib.zk_decoder_open_seekable(e, self._keep[1], self._keep[2], self._keep[3], None, C.byref(opts._o), C.byref(h))
+            else:
+                self._keep = (f, _SEEK_FN(_seek), _READ_FN(_read))
+                rc = lib.zk_decoder_open_callbacks(e, self._keep[1], self._keep[2], None, C.byref(opts._o), C.byref(h))
         else:
             self._keep = bytes(opts._src)          # the source must outlive the decoder
             rc = lib.zk_decoder_open_bytes(e, self._keep, len(self._keep), C.byref(opts._o), C.byref(h))

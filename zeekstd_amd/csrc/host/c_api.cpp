@@ -153,7 +153,46 @@ int zk_decoder_open_callbacks(zk_engine *e, zk_seek_fn set_offset, zk_read_fn re
     return guard([&] { *out = new zk_decoder(Decoder(make_opts(std::make_shared<CallbackSeekable>(set_offset, read, user), e, o))); });
 }
 
+int zk_decoder_open_seekable(zk_engine *e, zk_seek_fn set_offset, zk_read_fn read, zk_integrity_fn integrity, void *user, const zk_decode_opts *o,
+                             zk_decoder **out)
+{
+    if (!out || !set_offset || !read) return ZK_ERR_ARGUMENT;
+    *out = nullptr;
+    return guard([&] { *out = new zk_decoder(Decoder(make_opts(std::make_shared<CallbackSeekable>(set_offset, read, user, integrity), e, o))); });
+}
+
 void zk_decoder_free(zk_decoder *d) { delete d; }
+
+// contiguous frame range of a rank (the same split as zeekstd_amd/parallel.py shard_range: the first n % world ranks take one more)
+int zk_shard_range(uint32_t n_frames, int rank, int world, uint32_t *first, uint32_t *count)
+{
+    if (world < 1 || rank < 0 || rank >= world || !first || !count) return ZK_ERR_ARGUMENT;
+    const uint32_t per = n_frames / (uint32_t)world, extra = n_frames % (uint32_t)world, r = (uint32_t)rank;
+    *first = r * per + (r < extra ? r : extra);
+    *count = per + (r < extra ? 1u : 0u);
+    return 0;
+}
+
+int zk_decode_shard(zk_engine *e, const uint8_t *comp_shard, uint64_t shard_bytes, const zk_seek_table *table, int rank, int world,
+                    uint8_t *dst, uint64_t dst_cap, int verify, uint32_t *first_out, uint32_t *count_out, uint64_t *written)
+{
+    if (written) *written = 0;
+    if (!e || !table || (shard_bytes && !comp_shard)) return ZK_ERR_ARGUMENT;
+    uint32_t first = 0, count = 0;
+    int rc = zk_shard_range(table->t.num_frames(), rank, world, &first, &count);
+    if (rc) return rc;
+    if (first_out) *first_out = first;
+    if (count_out) *count_out = count;
+    if (!count) return 0;
+    const auto &E = table->t.entries();
+    std::vector<uint64_t> c(count + 1), d(count + 1);
+    for (uint32_t i = 0; i <= count; i++) { c[i] = E[first + i].c_offset - E[first].c_offset; d[i] = E[first + i].d_offset - E[first].d_offset; }
+    if (c[count] > shard_bytes) return -72;                  /* srcSize_wrong: the shard does not hold its frames */
+    if (d[count] > dst_cap) return -70;                      /* dstSize_tooSmall */
+    rc = zk_decode_frames(e, comp_shard, c[count], c.data(), d.data(), 0, count, dst, dst_cap, verify, nullptr);
+    if (rc == 0 && written) *written = d[count];
+    return rc;
+}
 
 int zk_decoder_time_seeks(zk_decoder *d, const uint64_t *offs, const uint32_t *lens, uint32_t n, uint8_t *buf, size_t buf_len,
                           const uint8_t *expect, double *us_out)

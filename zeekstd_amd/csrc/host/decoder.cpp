@@ -7,6 +7,7 @@
 // nothing returned at or beyond offset_limit, offset advances by the bytes returned, a forward seek
 // inside the cached frame does not touch the decode state (decode.rs:407-410, test :912-939), a frame
 // cut short by offset_limit does not fail on its checksum (doc :425-427).
+#include <exception>
 #include <string.h>
 #include <algorithm>
 #include "../../../include/zeekstd_amd.h"
@@ -62,11 +63,18 @@ void Decoder::check_offset(uint64_t offset) const                             //
 
 // The source as the engine's host pipeline sees it: contiguous memory when the Seekable is a byte slice, otherwise a pull
 // callback that reads straight into the pipeline's pinned staging (set_offset + read, decode.rs:208-209, 222-225).
+// A Seekable may throw (a file error, a host callback that fails): the exception must not unwind through the engine's
+// pipeline, which has DMA, kernels and worker tasks in flight on its frame.  It is parked here, the pull reports "no bytes"
+// so that the pipeline fails the chunk and drains in its normal way, and decode_range rethrows it afterwards.
+struct SeekablePull { Seekable *src; std::exception_ptr error; };
 static size_t seekable_pull(void *user, uint64_t off, uint8_t *dst, size_t n)
 {
-    Seekable *s = (Seekable *)user;
-    s->set_offset(OffsetFrom::Start(off));
-    return s->read(dst, n);
+    SeekablePull *sp = (SeekablePull *)user;
+    if (sp->error) return 0;
+    try {
+        sp->src->set_offset(OffsetFrom::Start(off));
+        return sp->src->read(dst, n);
+    } catch (...) { sp->error = std::current_exception(); return 0; }
 }
 
 // A seek table is untrusted input: entries that cannot describe a zstd frame are refused before anything is sized from
@@ -96,7 +104,8 @@ uint32_t Decoder::decode_range(uint32_t first, uint32_t count, uint8_t *dst, uin
     size_t mem_len = 0;
     const uint8_t *mem = src_->contiguous(&mem_len);
     if (mem) { if (c[count] > mem_len) throw Error::zstd(72 /* srcSize_wrong */); hs.mem = mem; }
-    else { hs.read = seekable_pull; hs.user = src_.get(); }
+    SeekablePull pull{src_.get(), nullptr};
+    if (!mem) { hs.read = seekable_pull; hs.user = &pull; }
     const void *d_prefix = nullptr;
     int rc = zk_engine_stage_prefix(engine_, this, prefix, prefix ? prefix_len : 0, prefix_dirty_, &d_prefix);
     if (rc != 0) throw Error::from_engine_code(rc, zk_engine_last_hip_error(engine_));
@@ -108,6 +117,7 @@ uint32_t Decoder::decode_range(uint32_t first, uint32_t count, uint8_t *dst, uin
     uint32_t n_ok = 0;
     rc = zk_host_decode(engine_, hs, c.data(), d.data(), 0, count, d_prefix, prefix ? prefix_len : 0, dst, dst_cap, verify, status.data(), &n_ok);
     submissions_++;
+    if (pull.error) std::rethrow_exception(pull.error);                        // the source's own failure, after the pipeline has drained
     *err = 0;
     if (rc <= -1000) throw Error::from_engine_code(rc, zk_engine_last_hip_error(engine_));
     if (count == 1 && cut_tail && verify_ && n_ok == 1) unverified_end_tmp_ = E[first + 1].d_offset;     // not checked at all

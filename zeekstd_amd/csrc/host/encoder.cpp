@@ -113,7 +113,12 @@ CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t i
                 encoded_ = false;
                 const double r = std::max(1.0, (double)d / (double)std::max<size_t>(c, 1));
                 const size_t by_ratio = std::max<size_t>(32768, (size_t)(0.9 * r * (double)(want - c)));
-                next_probe_ = d + std::min<size_t>(by_ratio, (want - c) + slack);
+                size_t step = std::min<size_t>(by_ratio, (want - c) + slack);
+                // far from n on input that compresses very well (d >> c) that cap would mean a probe -- a full encode of the frame so
+                // far -- every ~1 MiB of a frame of hundreds of MiB: quadratic work.  While less than half of n is reached the step is
+                // at least an eighth of the frame so far (geometric: O(log) probes); the window holds again once c nears n.
+                if (2 * c < want) step = std::max(step, d / 8);
+                next_probe_ = d + step;
             } else ratio_ = (double)d / (double)c;
         }
     }
@@ -331,6 +336,14 @@ size_t Encoder::compress_with_prefix(const uint8_t *buf, size_t len, const uint8
         if (batch_len_ >= (16u << 20)) {
             const size_t t = speculate_compressed(batch_in_, batch_len_, prefix, prefix_len);
             if (t) { memmove(batch_in_, batch_in_ + t, batch_len_ - t); batch_len_ -= t; }
+            else if (batch_len_ >= (64u << 20)) {
+                // speculation takes nothing (input so compressible that a frame would pass MAX_FRAME_SIZE, or a position that
+                // keeps failing): the exact path drains what is held -- the pinned batch stays bounded -- and keeps the frame it
+                // opens, so the following writes go straight through it
+                const size_t held = batch_len_;
+                process_compressed(batch_in_, held, prefix, prefix_len, true);
+                batch_len_ = 0;
+            }
         }
         return len;
     }
@@ -357,10 +370,15 @@ size_t Encoder::compress_with_prefix(const uint8_t *buf, size_t len, const uint8
     // last frame -- still open upstream until the next call (encode.rs:317-327) -- is copied into the batch buffer.
     if (len >= (size_t)fs * 4 || len >= (64u << 20)) {
         if (batch_len_) {
-            const size_t fill = (fs - batch_len_ % fs) % fs;
+            // (with frames larger than the write -- fs > len is possible here from 64 MiB on -- the open frame may take all of it)
+            const size_t fill = std::min<size_t>(len, (fs - batch_len_ % fs) % fs);
             batch_append(buf, fill);
             buf += fill; len -= fill;
-            submit_batch(true);
+            if (len == 0) {                                                     // the write ended inside (or exactly at the end of) the open frame
+                if (batch_len_ > (size_t)fs * batch_frames_) submit_batch(false);
+                return total_len;
+            }
+            submit_batch(true);                                                 // every gathered frame is complete and more input follows
         }
         const size_t take = ((len - 1) / fs) * (size_t)fs;
         if (take) encode_span(buf, take);

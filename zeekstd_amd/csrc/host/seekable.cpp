@@ -93,9 +93,16 @@ size_t CallbackSeekable::read(uint8_t *buf, size_t len)
     return (size_t)r;
 }
 
-// the trait's provided method (seekable.rs:29-38): position at the integrity field, read_exact 9 bytes
+// Seekable::seek_table_integrity is a REQUIRED method of the trait (seekable.rs:33-38): a host source may keep its
+// integrity field anywhere, so its own callback is asked first.  Without one the field is read the way both of the
+// reference's impls read it (seekable.rs:84-96, 126-137): position at the field, read_exact 9 bytes.
 std::array<uint8_t, SEEK_TABLE_INTEGRITY_SIZE> CallbackSeekable::seek_table_integrity(Format format)
 {
+    if (ig_) {
+        std::array<uint8_t, SEEK_TABLE_INTEGRITY_SIZE> a;
+        if (ig_(user_, format == Format::Head ? 0 : 1, a.data()) < 0) throw Error::io("seek_table_integrity callback failed");
+        return a;
+    }
     if (format == Format::Head) set_offset(OffsetFrom::Start(SKIPPABLE_HEADER_SIZE));
     else set_offset(OffsetFrom::End(-(int64_t)SEEK_TABLE_INTEGRITY_SIZE));
     std::array<uint8_t, SEEK_TABLE_INTEGRITY_SIZE> a;

@@ -96,7 +96,8 @@ class CallbackSeekable : public Seekable {
 public:
     typedef int64_t (*set_offset_fn)(void *user, int whence, int64_t value);      // new position from the start, or < 0
     typedef int64_t (*read_fn)(void *user, uint8_t *buf, size_t len);             // bytes read (0 = end), or < 0
-    CallbackSeekable(set_offset_fn so, read_fn rd, void *user) : so_(so), rd_(rd), user_(user) {}
+    typedef int (*integrity_fn)(void *user, int format, uint8_t out[SEEK_TABLE_INTEGRITY_SIZE]);   // 0, or < 0 on failure
+    CallbackSeekable(set_offset_fn so, read_fn rd, void *user, integrity_fn ig = nullptr) : so_(so), rd_(rd), ig_(ig), user_(user) {}
     uint64_t set_offset(OffsetFrom offset) override;
     size_t read(uint8_t *buf, size_t len) override;
     std::array<uint8_t, SEEK_TABLE_INTEGRITY_SIZE> seek_table_integrity(Format format) override;
@@ -104,6 +105,7 @@ public:
 private:
     set_offset_fn so_;
     read_fn rd_;
+    integrity_fn ig_;
     void *user_;
 };
 

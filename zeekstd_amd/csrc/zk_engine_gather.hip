@@ -68,19 +68,23 @@ extern "C" int zk_gather_seekable(zk_engine *e, void *nccl_comm, int rank, int w
     ZK_HIP(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     int rc;
-    // 1. (bytes, frames) of every rank
-    if ((rc = zk_devbuf_reserve(e, e->st_misc, (size_t)(world + 1) * 16))) return rc;
-    uint64_t *d_mine = (uint64_t *)e->st_misc.p, *d_all = d_mine + 2;
-    e->h_words[10] = payload_bytes; e->h_words[11] = n_frames;
-    ZK_HIP(hipMemcpyAsync(d_mine, e->h_words + 10, 16, hipMemcpyHostToDevice, st));
-    if (R.all_gather(d_mine, d_all, 2, kUint64, nccl_comm, st) != 0) { e->last_err = "ncclAllGather failed"; return ZK_ERR_HIP; }
-    std::vector<uint64_t> all((size_t)world * 2);
-    ZK_HIP(hipMemcpyAsync(all.data(), d_all, all.size() * 8, hipMemcpyDeviceToHost, st));
+    // 1. (bytes, frames, room in the destination) of every rank.  The root's capacity travels with the sizes so that EVERY rank
+    // reaches the same verdict on "the gathered stream does not fit" before any send / receive is posted -- a root that
+    // returned alone would leave its peers inside ncclSend until the communicator times out.
+    if ((rc = zk_devbuf_reserve(e, e->st_misc, (size_t)(world + 1) * 32))) return rc;
+    uint64_t *d_mine = (uint64_t *)e->st_misc.p, *d_all = d_mine + 4;
+    e->h_words[10] = payload_bytes; e->h_words[11] = n_frames; e->h_words[12] = d_out ? out_cap : 0;
+    ZK_HIP(hipMemcpyAsync(d_mine, e->h_words + 10, 24, hipMemcpyHostToDevice, st));
+    if (R.all_gather(d_mine, d_all, 3, kUint64, nccl_comm, st) != 0) { e->last_err = "ncclAllGather failed"; return ZK_ERR_HIP; }
+    std::vector<uint64_t> all3((size_t)world * 3), all((size_t)world * 2);
+    ZK_HIP(hipMemcpyAsync(all3.data(), d_all, all3.size() * 8, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
+    for (int r = 0; r < world; r++) { all[2 * r] = all3[3 * r]; all[2 * r + 1] = all3[3 * r + 1]; }
     std::vector<uint64_t> offs((size_t)world + 1, 0);
     uint64_t mx = 1, total_frames = 0;
     for (int r = 0; r < world; r++) { offs[r + 1] = offs[r] + all[2 * r]; if (all[2 * r + 1] > mx) mx = all[2 * r + 1]; total_frames += all[2 * r + 1]; }
     if (total_frames > ZK_SEEKABLE_MAX_FRAMES) return ZK_ERR_FRAME_INDEX_TOO_LARGE;
+    if (offs[world] + 8 * total_frames + 17 > all3[3 * (size_t)root + 2]) return -(int)ZK_E_DST_TOO_SMALL;      // on every rank alike (8 n + 17: seekable_format.md)
     // 2. seek entries, padded to the largest shard
     std::vector<uint32_t> ent((size_t)mx * 2, 0), ents((size_t)world * mx * 2);
     for (uint32_t i = 0; i < n_frames; i++) { ent[i] = c_sizes[i]; ent[mx + i] = d_sizes[i]; }
@@ -100,7 +104,7 @@ extern "C" int zk_gather_seekable(zk_engine *e, void *nccl_comm, int rank, int w
         tbytes.resize(ser.encoded_len());
         size_t w = 0;
         for (;;) { const size_t k = ser.write_into(tbytes.data() + w, tbytes.size() - w); if (!k) break; w += k; }
-        if (!d_out || offs[world] + tbytes.size() > out_cap) return -(int)ZK_E_DST_TOO_SMALL;
+        if (!d_out || offs[world] + tbytes.size() > out_cap) { e->last_err = "gather: table size disagrees with 8 n + 17"; return -(int)ZK_E_GENERIC; }   // (cannot happen: checked collectively above)
     }
     if (R.group_start() != 0) { e->last_err = "ncclGroupStart failed"; return ZK_ERR_HIP; }
     int bad = 0;

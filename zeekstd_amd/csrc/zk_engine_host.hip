@@ -66,20 +66,24 @@ public:
         if (pieces > (size_t)size() + 1) pieces = (size_t)size() + 1;
         if (pieces <= 1) { memcpy(dst, src, n); return; }
         const size_t per = ((n + pieces - 1) / pieces + 4095) & ~(size_t)4095;
-        std::atomic<size_t> left{pieces - 1};
-        std::mutex dm; std::condition_variable dcv;
+        // the latch lives on the heap and is shared with the workers: the last worker may still be inside notify while the
+        // caller, woken by the count, has already returned (a latch on this frame would be dead by then)
+        struct Latch { std::mutex m; std::condition_variable cv; size_t left; };
+        auto latch = std::make_shared<Latch>();
+        latch->left = pieces - 1;
         for (size_t k = 1; k < pieces; k++) {
             const size_t at = k * per;
-            if (at >= n) { left.fetch_sub(1); continue; }
+            if (at >= n) { std::lock_guard<std::mutex> g(latch->m); latch->left--; continue; }
             const size_t len = n - at < per ? n - at : per;
-            post([=, &left, &dm, &dcv] {
+            post([=] {
                 memcpy((uint8_t *)dst + at, (const uint8_t *)src + at, len);
-                if (left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> g(dm); dcv.notify_one(); }
+                std::lock_guard<std::mutex> g(latch->m);
+                if (--latch->left == 0) latch->cv.notify_one();
             });
         }
         memcpy(dst, src, per < n ? per : n);
-        std::unique_lock<std::mutex> g(dm);
-        dcv.wait(g, [&] { return left.load() == 0; });
+        std::unique_lock<std::mutex> g(latch->m);
+        latch->cv.wait(g, [&] { return latch->left == 0; });
     }
 
 private:
@@ -509,17 +513,17 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
         if (!fallback) return rc;
     }
     if (!small && !src.mem) { if ((rc = zk_hostpipe_rings(e, hp))) return rc; }     // a pull source is staged through the ring
-    // caller memory that is not pinned already is pinned on the fly, unit by unit, ahead of the copies (ZkRegWindow)
-    ZkRegWindow wsrc, wdst;
-    if (!small && src.mem && !src_pinned) wsrc.start(hp->pool, src.mem + c_lo, (size_t)(c_off[first + count] - c_lo));
-    if (!small && !dst_pinned) wdst.start(hp->pool, dst, (size_t)total_d);
-
-    // ---- pinned meta: rebased offsets of every chunk + the status words of every frame
+    // ---- pinned meta: rebased offsets of every chunk + the status words of every frame (every allocation that can fail comes
+    // before the registration windows start: their pool tasks point at this frame's objects)
     const size_t off_bytes = ((size_t)(count + nchunks) * 16 + 63) & ~(size_t)63;
     if ((rc = zk_pin_grow(e, hp->pin_meta, hp->pin_meta_cap, off_bytes + (size_t)count * 4 + 64))) return rc;
     uint64_t *pin_offs = (uint64_t *)hp->pin_meta;
     int32_t *pin_status = (int32_t *)(hp->pin_meta + off_bytes);
     if (small) { if ((rc = zk_pin_grow(e, hp->pin_small, hp->pin_small_cap, (size_t)max_c + (size_t)total_d + 256))) return rc; }
+    // caller memory that is not pinned already is pinned on the fly, unit by unit, ahead of the copies (ZkRegWindow)
+    ZkRegWindow wsrc, wdst;
+    if (!small && src.mem && !src_pinned) wsrc.start(hp->pool, src.mem + c_lo, (size_t)(c_off[first + count] - c_lo));
+    if (!small && !dst_pinned) wdst.start(hp->pool, dst, (size_t)total_d);
 
     int fail = 0;                                           // first pipeline-level failure (HIP error, source ended, ...)
     size_t offs_at = 0;
@@ -724,12 +728,12 @@ int zk_host_encode(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_
     const bool src_pinned = n == 0 || zk_is_pinned(src);
     const bool small = nchunks == 1 && n <= (4u << 20);
     if (!small) { if ((rc = zk_hostpipe_rings(e, hp))) return rc; }                 // the compressed bytes travel back through the ring
-    ZkRegWindow wsrc;
-    if (!small && !src_pinned) wsrc.start(hp->pool, src, (size_t)n);
     const uint64_t max_in = per * frame_size < n ? per * frame_size : n;
     const uint64_t max_bound = zk_compress_bound(max_in, frame_size);
     if (small) { if ((rc = zk_pin_grow(e, hp->pin_small, hp->pin_small_cap, (size_t)max_in + (size_t)max_bound + 256))) return rc; }
     if ((rc = zk_pin_grow(e, hp->pin_meta, hp->pin_meta_cap, (size_t)per * 8 * 2 + 64))) return rc;     // (c, d) sizes of two chunks
+    ZkRegWindow wsrc;                                       // (after every allocation that can fail: its pool tasks point at this frame)
+    if (!small && !src_pinned) wsrc.start(hp->pool, src, (size_t)n);
     hipStream_t st = e->stream;
 
     auto chunk_range = [&](size_t i, uint64_t &f0, uint64_t &nf, uint64_t &b0, uint64_t &bn) {

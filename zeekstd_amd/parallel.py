@@ -26,20 +26,32 @@ def shard_range(n_frames: int, rank: int, world: int):
     return lo, lo + per + (1 if rank < extra else 0)
 
 
+class GatherTooSmall(RuntimeError):
+    """The root's destination cannot hold the gathered stream + seek table; raised on EVERY rank (nobody has posted a send)."""
+
+
 def gather_seekable(payload: torch.Tensor, c_sizes: torch.Tensor, d_sizes: torch.Tensor, root: int = 0, group=None,
-                    fmt: Format = Format.Foot):
+                    fmt: Format = Format.Foot, out_cap: int = None):
     """payload: uint8 tensor with this rank's concatenated frames; c_sizes / d_sizes: int32 tensors (one per frame).
-    Returns on root (stream tensor incl. the seek table, SeekTable); on the other ranks (None, None)."""
+    Returns on root (stream tensor incl. the seek table, SeekTable); on the other ranks (None, None).
+    out_cap (root only, optional): room the root has for the result.  It travels with the sizes in step 1, so that every
+    rank reaches the same verdict before any send / receive is posted (zk_gather_seekable at the C ABI does the same): a
+    root that bailed out alone would leave its peers inside their sends until the communicator times out."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = payload.device
-    # 1. byte totals + frame counts
-    mine = torch.tensor([payload.numel(), c_sizes.numel()], dtype=torch.int64, device=dev)
-    allv = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    # 1. byte totals + frame counts (+ the root's capacity, -1 = unlimited)
+    cap = -1 if out_cap is None or rank != root else int(out_cap)
+    mine = torch.tensor([payload.numel(), c_sizes.numel(), cap], dtype=torch.int64, device=dev)
+    allv = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(allv, mine, group=group)
     totals = [int(v[0]) for v in allv]
     counts = [int(v[1]) for v in allv]
     offs = np.concatenate([[0], np.cumsum(totals)])
+    root_cap = int(allv[root][2])
+    need = int(offs[-1]) + 8 * sum(counts) + 17                     # seekable_format.md: the table is 8 n + 17 bytes
+    if root_cap >= 0 and need > root_cap:
+        raise GatherTooSmall(f"gathered stream + seek table need {need} bytes, the root has {root_cap}")
     # 3. seek entries, padded to the largest shard
     mx = max(max(counts), 1)
     ent = torch.zeros(2 * mx, dtype=torch.int32, device=dev)
@@ -76,7 +88,7 @@ def gather_seekable(payload: torch.Tensor, c_sizes: torch.Tensor, d_sizes: torch
 
 
 def encode_sharded(engine, d_src: torch.Tensor, frame_size: int, level: int = 1, checksum: bool = False, root: int = 0,
-                   group=None, fmt: Format = Format.Foot):
+                   group=None, fmt: Format = Format.Foot, out_cap: int = None):
     """Each rank passes ITS shard of the input (whole frames except for the global tail); returns gather_seekable()."""
     from . import lib
     n = d_src.numel()
@@ -87,7 +99,7 @@ def encode_sharded(engine, d_src: torch.Tensor, frame_size: int, level: int = 1,
     d_cs = torch.zeros(nf, dtype=torch.int32, device=dev)
     d_ds = torch.zeros(nf, dtype=torch.int32, device=dev)
     nfo, written = engine.encode_frames_dev(d_src, n, frame_size, level, checksum, d_comp, cap, d_cs, d_ds)
-    return gather_seekable(d_comp[:written], d_cs[:nfo], d_ds[:nfo], root, group, fmt)
+    return gather_seekable(d_comp[:written], d_cs[:nfo], d_ds[:nfo], root, group, fmt, out_cap)
 
 
 def decode_sharded(engine, comp: bytes, table: SeekTable, rank: int, world: int, verify: bool = True):
@@ -97,3 +109,21 @@ def decode_sharded(engine, comp: bytes, table: SeekTable, rank: int, world: int,
     c, d = table.offsets()
     out, st = engine.decode_frames(comp, c, d, first=lo, count=hi - lo, verify=verify)
     return lo, hi, out
+
+
+def decode_shard(engine, comp_shard: bytes, table: SeekTable, rank: int, world: int, verify: bool = True):
+    """The same through the C ABI's zk_decode_shard (what a Rust / C++ host calls): comp_shard holds ONLY this rank's
+    compressed bytes [c_off[first], c_off[first + count]).  Returns (first_frame, count, bytes)."""
+    import ctypes as C
+    from . import lib
+    from .api import _chk
+    lo, hi = shard_range(table.num_frames(), rank, world)
+    _, d = table.offsets()
+    n = int(d[hi] - d[lo])
+    out = np.zeros(max(n, 1), np.uint8)
+    src = np.frombuffer(bytes(comp_shard) + b"\0" * 8, np.uint8)
+    first, count, written = C.c_uint32(), C.c_uint32(), C.c_uint64()
+    _chk(lib.zk_decode_shard(engine._h, src.ctypes.data, len(comp_shard), table._h, rank, world, out.ctypes.data, n, int(verify),
+                             C.byref(first), C.byref(count), C.byref(written)))
+    assert (first.value, first.value + count.value) == (lo, hi) and written.value == n
+    return first.value, count.value, out[:n].tobytes()
