@@ -119,7 +119,7 @@ def _cpu_decode_rate(lib, comp, frames, nthreads, target_seconds):
     return int(d[-1]) / best / 2**30, reps + 1
 
 
-def cpu_baseline(comp, frames, data, sample_frames, level, cks, ref_comp=None, ref_frames=None):
+def cpu_baseline(comp, frames, data, sample_frames, level, cks, ref_comp=None, ref_frames=None, ref3=None):
     """Reference CPU path (C restatement of zeekstd's Decoder / Encoder loops over the box's libzstd): 1 thread (the
     reference's own semantics, the north-star comparison) and all host cores (independent Decoders per frame range)."""
     lib = _zkb()
@@ -148,6 +148,21 @@ def cpu_baseline(comp, frames, data, sample_frames, level, cks, ref_comp=None, r
         if vr:
             out["on_reference_made_archive"] = {"value": round(vr, 3), "unit": "GiB/s", "cores": 1,
                                                 "sample": f"same loop on the archive the reference Encoder loop wrote (libzstd {ver}, level {level}), first {rn} frames"}
+            vra, passes = _cpu_decode_rate(lib, ref_comp, ref_frames, cores, 3.0)
+            if vra:
+                out["on_reference_made_archive"]["all_cores"] = {"value": round(vra, 2), "unit": "GiB/s", "cores": cores,
+                                                                 "sample": f"{cores} threads, one Decoder per frame range, all {len(ref_frames)} frames, best of {passes} passes"}
+        if ref3 is not None:
+            r3c, r3f = ref3
+            rn = min(sample_frames, len(r3f))
+            rc = sum(f[0] for f in r3f[:rn])
+            v3, passes = _cpu_decode_rate(lib, r3c[:rc], r3f[:rn], 1, 3.0)
+            v3a, passes_a = _cpu_decode_rate(lib, r3c, r3f, cores, 3.0)
+            if v3:
+                out["on_reference_made_archive"]["level_3"] = {
+                    "value": round(v3, 3), "unit": "GiB/s", "cores": 1, "sample": f"the same at level 3 (the reference CLI's default), first {rn} frames",
+                    "all_cores": ({"value": round(v3a, 2), "unit": "GiB/s", "cores": cores, "sample": f"{cores} threads, all {len(r3f)} frames, best of {passes_a} passes"}
+                                  if v3a else None)}
     # encode side, for the record: zeekstd::Encoder loop at the same level on 128 frames
     ne = min(128, len(frames))
     src = np.ascontiguousarray(data[:ne * FRAME])
@@ -224,6 +239,84 @@ def end_to_end(eng, zk, data, nframes, cks, reps=3):
             "note": "host buffers in, host buffers out (pageable numpy arrays) through zk_encoder_compress/zk_encoder_finish and "
                     "zk_decoder_decompress: the engine pins the caller's pages on the fly and overlaps PCIe with the kernels; "
                     "PCIe Gen5 x16 moves 4 GiB in ~75 ms, which bounds both directions"}
+
+
+def small_input_leg(eng, zk):
+    """configs[0] (BASELINE.json): the reference's own bench input -- assets/dickens.txt is absent, SURVEY 8d's stand-in is
+    gen(10 192 446 bytes) = 5 frames at the default policy -- through the RawEncoder, Encoder<Vec<u8>> and Decoder handles with
+    the reference's bench protocols (lib/benches/compress.rs:8-62: level 1, 131 591-byte output buffer, compress loop then
+    end_frame loop / write_all + end_frame; lib/benches/decompress.rs:18-39: 131 072-byte buffer until 0, then reset), beside
+    the same loops over the box's libzstd on one host thread.  A 10 MB input is latency-bound on a GPU: five frames, one engine
+    call each for the raw encoder.  Bit-exact round trip or it raises."""
+    from zeekstd_amd import EncodeOptions, DecodeOptions
+    from oracle import zko
+    n = 10192446
+    data = zko.gen_chunks(n)
+    reps = 5
+    out = bytearray(131591)
+
+    def raw_once():
+        enc = EncodeOptions().engine(eng).compression_level(1).into_raw_encoder()
+        t = time.perf_counter()
+        pos = 0
+        mv = memoryview(data)
+        while pos < n:
+            pos += enc.compress(mv[pos:pos + (4 << 20)], out).in_progress()      # (the binding copies its input: bounded slices)
+        while enc.end_frame(out).data_left():
+            pass
+        return time.perf_counter() - t
+    t_raw = min(raw_once() for _ in range(reps))
+
+    class Sink:
+        def __init__(self): self.parts = []
+        def write(self, b): self.parts.append(bytes(b)); return len(b)
+        def flush(self): pass
+    t_enc, arch = [], None
+    for _ in range(reps):
+        sink = Sink()
+        enc = EncodeOptions().engine(eng).compression_level(1).into_encoder(sink)
+        t = time.perf_counter()
+        enc.write_all(data)
+        enc.end_frame()
+        t_enc.append(time.perf_counter() - t)
+        enc.finish()
+        arch = b"".join(sink.parts)
+    dec = DecodeOptions(arch).engine(eng).into_decoder()
+    buf = bytearray(131072)
+    t_dec, got = [], None
+    for r in range(reps):
+        parts = []
+        t = time.perf_counter()
+        while True:
+            k = dec.decompress(buf)
+            if k == 0:
+                break
+            if r == 0:
+                parts.append(bytes(buf[:k]))
+        t_dec.append(time.perf_counter() - t)
+        dec.reset()
+        if r == 0:
+            got = b"".join(parts)
+    if got != data:
+        raise RuntimeError("configs[0] round trip differs from the input bytes")
+    gib = n / 2**30
+    res = {"input_bytes": n, "frames": dec.seek_table().num_frames(), "ratio": round(n / (len(arch) - 8 * 5 - 17), 3),
+           "raw_encoder": {"value": round(gib / t_raw, 3), "unit": "GiB/s", "ms": round(t_raw * 1e3, 2)},
+           "encoder": {"value": round(gib / min(t_enc), 3), "unit": "GiB/s", "ms": round(min(t_enc) * 1e3, 2)},
+           "decoder": {"value": round(gib / min(t_dec), 3), "unit": "GiB/s", "ms": round(min(t_dec) * 1e3, 2)},
+           "note": "host buffers through the Level-B handles (Python binding: its own copies are inside the spans); best of %d" % reps}
+    lib = _zkb()
+    if lib is not None:
+        src = np.frombuffer(data, np.uint8)
+        dst = np.empty(n + (n >> 6) + 65536, np.uint8)
+        csize = C.c_int64()
+        te = lib.zkb_time_encode(src.ctypes.data, n, FRAME, 1, 0, 3, dst.ctypes.data, dst.size, C.byref(csize))
+        sink = C.c_uint64(0)
+        td = lib.zkb_time_decode(dst.ctypes.data, csize.value, n, 3, C.byref(sink)) if te > 0 else -1
+        if te > 0 and td > 0:
+            res["cpu_1thread"] = {"encoder": round(gib / te, 3), "decoder": round(gib / td, 3), "unit": "GiB/s", "ratio": round(n / csize.value, 3),
+                                  "kind": "zeekstd loops in C over the box's libzstd " + lib.zkb_version().decode()}
+    return res
 
 
 def _splitmix_seed(seed):
@@ -418,8 +511,10 @@ def dry_run(args, rank, world):
         elapsed = float(t.item())
     gather = None
     if world > 1:
+        dist.barrier(); tg = time.perf_counter()
         out, table = parallel.encode_sharded(StoredFrames(), d_src, fsz, 1, False, root=0)
-        gather = {"frames_on_root": table.num_frames() if table is not None else None,
+        dist.barrier()
+        gather = {"ms": round((time.perf_counter() - tg) * 1e3, 2), "frames_on_root": table.num_frames() if table is not None else None,
                   "stream_bytes_on_root": int(out.numel()) if out is not None else None}
     if rank == 0:
         print(json.dumps({"metric": "decode_decompressed_GiB_per_s", "value": 0.0, "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
@@ -441,6 +536,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-seek", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host buffers) leg")
+    ap.add_argument("--no-c1", action="store_true", help="skip the configs[0] leg (the reference's own 10 MB bench input through the handles)")
     ap.add_argument("--seek-trials", type=int, default=10000)
     ap.add_argument("--no-fork", action="store_true", help="generate the inputs in this process (profiling runs)")
     ap.add_argument("--no-ref-archive", action="store_true", help="skip the secondary leg on a CPU-libzstd-made archive")
@@ -533,7 +629,7 @@ def main():
         if comp is None:
             comp = bytes(d_comp[:csize].cpu().numpy())             # CPU decodes the very same (GPU-made) archive
         base = cpu_baseline(comp, frames, data, 512 if args.workload == "c3" else 128, level, cks,
-                            z_comp if (use_gpu_archive and z_comp) else None, z_frames)
+                            z_comp if (use_gpu_archive and z_comp) else None, z_frames, z3)
     d_c = torch.from_numpy(c.view(np.int64)).to(dev)
     d_d = torch.from_numpy(d.view(np.int64)).to(dev)
     d_out = torch.empty(dsize + 64, dtype=torch.uint8, device=dev)
@@ -675,10 +771,48 @@ def main():
         del d_outs, d_sts
         e2e_info = end_to_end(eng, zk, np.asarray(data), nframes, cks)
 
+    # ---- configs[0]: the reference's own bench input through the RawEncoder / Encoder / Decoder handles
+    c1_info = None
+    if rank == 0 and world == 1 and not args.no_c1:
+        c1_info = small_input_leg(eng, zk)
+
     # ---- seek-to-offset latency: BASELINE.json configs[3] as written (a failing leg fails the run)
     seek_info = None
     if do_seek:
         seek_info = seek_leg(eng, np.asarray(data), zk, z64, dsize, args.seek_trials)
+
+    # ---- N > 1: the one exchange step of the path -- encode the local shard, gather stream + seek table on rank 0 (RCCL over
+    # xGMI).  It runs BEFORE the line is printed and its result (or its error) is part of the line; a watchdog bounds it, so a
+    # collective that hangs costs four minutes and an error field, not the line.
+    gather_info, gather_failed, gather_hung = None, False, False
+    if world > 1 and use_gpu_archive:
+        import threading
+        from zeekstd_amd import parallel
+        box = {}
+
+        def _gather_leg():
+            try:
+                torch.cuda.set_device(local_rank)
+                tg = []
+                for _ in range(2):
+                    barrier(); torch.cuda.synchronize(); t = time.perf_counter()
+                    out, table = parallel.encode_sharded(eng, d_src, FRAME, level, cks, root=0)
+                    torch.cuda.synchronize(); barrier(); tg.append(time.perf_counter() - t)
+                box["info"] = {"encode_plus_gather_GiB_per_s": round(dsize * world / min(tg) / 2**30, 2), "ms": round(min(tg) * 1e3, 2),
+                               "frames_on_root": table.num_frames() if table is not None else None,
+                               "stream_bytes_on_root": int(out.numel()) if out is not None else None,
+                               "note": "every rank encodes its 2048 frames, then all_gather of sizes, point-to-point payload gather into the "
+                                       "root's buffer, all_gather of the seek entries, table serialised by the root (zeekstd_amd/parallel.py)"}
+            except Exception as ex:                        # noqa: BLE001 -- reported in the line, the run then fails
+                box["info"] = {"error": f"{type(ex).__name__}: {ex}"}
+        th = threading.Thread(target=_gather_leg, daemon=True)
+        th.start()
+        th.join(240)
+        if th.is_alive():
+            gather_info, gather_failed, gather_hung = {"error": "timed out after 240 s: a collective did not complete"}, True, True
+        else:
+            gather_info = box.get("info", {"error": "no result"})
+            gather_failed = "error" in gather_info
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -708,7 +842,8 @@ def main():
                             "note": "HBM-resident encode + decode of the same 4 GiB, encode ms + decode ms_per_step (BASELINE metric: encode+decode)"}
                            if enc_info else None),
             "end_to_end": e2e_info,
-            "rccl_gather": ("reported on stderr after this line (a failure of the exchange leg must not cost the line)" if world > 1 and use_gpu_archive else None),
+            "configs0_small_input": c1_info,
+            "rccl_gather": gather_info,
             "seek": seek_info,
             "setup_s": round(t_setup, 1),
         }
@@ -717,27 +852,12 @@ def main():
             if base.get("all_cores"):
                 line["speedup_vs_cpu_all_cores"] = round(value / base["all_cores"]["value"], 2)
         print(json.dumps(line), flush=True)
-    # ---- N > 1: the one exchange step of the path -- encode the local shard, gather stream + seek table on rank 0 (RCCL).
-    # Runs after the line is out: it is the one leg no hardware run has covered yet, and its result goes to stderr.
-    if world > 1 and use_gpu_archive:
-        from zeekstd_amd import parallel
-        try:
-            tg = []
-            for _ in range(2):
-                barrier(); torch.cuda.synchronize(); t = time.perf_counter()
-                out, table = parallel.encode_sharded(eng, d_src, FRAME, level, cks, root=0)
-                torch.cuda.synchronize(); barrier(); tg.append(time.perf_counter() - t)
-            gather_info = {"encode_plus_gather_GiB_per_s": round(dsize * world / min(tg) / 2**30, 2), "ms": round(min(tg) * 1e3, 2),
-                           "frames_on_root": table.num_frames() if table is not None else None,
-                           "stream_bytes_on_root": int(out.numel()) if out is not None else None}
-        except Exception as ex:                            # noqa: BLE001 -- reported, the line above stands, the run still fails
-            gather_info = {"error": f"{type(ex).__name__}: {ex}"}
-        if rank == 0:
-            print("[bench] rccl_gather " + json.dumps(gather_info), file=sys.stderr, flush=True)
-        if "error" in gather_info:
-            if world > 1:
-                dist.destroy_process_group()
-            sys.exit(1)
+    if gather_failed:                                        # the line above carries the error; the run still fails
+        if gather_hung:
+            os._exit(1)                                       # a collective that never completes cannot be torn down politely
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(1)
     if world > 1:
         dist.destroy_process_group()
 

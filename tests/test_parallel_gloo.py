@@ -165,7 +165,9 @@ def test_bench_dry_run_world2():
     assert len(lines) == 1                                   # rank 0 prints ONE line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["dry_run"] is True and d["scaling"] == "weak"
-    assert d["rccl_gather"]["frames_on_root"] == 2 * d["config"]["frames_per_gpu"]
+    g = d["rccl_gather"]                                     # the exchange leg's result is IN the line: frames, bytes, ms
+    assert g["frames_on_root"] == 2 * d["config"]["frames_per_gpu"] and g["ms"] > 0
+    assert g["stream_bytes_on_root"] == 2 * 4 * (1000 + 9) + 8 * 8 + 17
 
 
 def _worker_too_small(rank, world, port, q):
