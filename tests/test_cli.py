@@ -18,6 +18,11 @@ FRAME_SIZES = ["10", "123", "3K", "2M", "1G"]                      # main.rs:10
 INPUT = zko.gen_chunks(1_200_000, 17)
 
 
+def _msgs(stderr: bytes):
+    """the command's own stderr lines (libdrm on the GPU box prints a line of its own about amdgpu.ids)"""
+    return [l for l in stderr.decode().splitlines() if "amdgpu.ids" not in l]
+
+
 def zeekstd(*args, stdin=b"", ok=True, cwd=None):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, "-m", "zeekstd_amd.cli", *map(str, args)], input=stdin, capture_output=True, env=env, cwd=cwd, timeout=600)
@@ -231,10 +236,10 @@ def test_list_on_an_engine_made_archive_and_summary_lines(test_input, tmp_path):
     s = tmp_path / "s.zst"
     r = zeekstd("-r", "compress", test_input, "--output-file", s, "--frame-size", len(INPUT) // 14)
     size = s.stat().st_size
-    assert r.stderr.decode().strip() == f"{test_input} : {100.0 / len(INPUT) * size:.2f}% ( {len(INPUT)} => {size}, {s})"     # command.rs:349-357
+    assert _msgs(r.stderr) == [f"{test_input} : {100.0 / len(INPUT) * size:.2f}% ( {len(INPUT)} => {size}, {s})"]     # command.rs:349-357
     assert zeekstd("list", s).stdout.count(b"\n") == 2 and zeekstd("list", "--detail", s).stdout.count(b"\n") == 16
-    assert zeekstd("decompress", s, "-c").stderr.decode().strip() == f"{s} : {INPUT and '1.14 MiB'}"
-    assert zeekstd("-q", "decompress", s, "-c").stderr == b""
+    assert _msgs(zeekstd("decompress", s, "-c").stderr) == [f"{s} : 1.14 MiB"]                                      # command.rs:372-378
+    assert _msgs(zeekstd("-q", "decompress", s, "-c").stderr) == []
 
 
 @pytest.mark.gpu
