@@ -27,7 +27,7 @@ u64 zko_xxh64(const u8 *p, size_t len, u64 seed);
 #define ZKE_SEGMENT (256u << 10)     /* zk_enc_device.h: bytes of a frame one matcher workgroup takes (a multiple of the 32 KiB blocks) */
 static u32 g_hash_log = 14;         /* zke_hash_log(level): 2^14 table entries at level <= 1, 2^15 at 2..5 and 0 (= default 3), 2^16 from 6 on */
 static u32 g_minmatch = 6;          /* zke_minmatch(level): 6 for level <= 1 (except 0 = default 3), else 5 */
-#define ZKE_WINDOW 61376u          /* 65536 - 4096 - 64: what the 64 KiB LDS ring of the GPU matcher still holds behind a group (zk_enc_device.h) */
+#define ZKE_WINDOW 57280u          /* 65536 - 2 * 4096 - 64: what the 64 KiB LDS ring of the GPU matcher still holds behind a group (zk_enc_device.h) */
 
 
 static inline u32 hb32(u32 v) { return 31 - (u32)__builtin_clz(v); }
@@ -338,7 +338,7 @@ static size_t encode_literals(const u8 *lit, size_t n, u8 *dst, size_t cap)
  * of the segment's record = [history | data]; the GPU keeps the last 64 KiB of the record in an LDS ring, so
  *   - a table entry is the low 16 bits of a position (= its ring index), a candidate is p - d with d = (p - entry) mod 2^16,
  *     valid when 1 <= d <= ZKE_WINDOW and d <= p (anything else is stale or aliased; the bytes decide as for any collision);
- *   - ZKE_WINDOW = 65536 - ZKE_GROUP_POS - 64: the ring also holds the group being worked on and 64 bytes of lookahead.
+ *   - ZKE_WINDOW = 65536 - 2 * ZKE_GROUP_POS - 64: the ring also holds the group being worked on, the next one and 64 bytes of lookahead.
  * Work proceeds in GROUPS of 16 tiles x 256 positions.  Per group (STEP == group) or per step of ZKE_STEP positions:
  *   1. every position looks its 5-byte hash up in the table as it was before the step          -> "far" candidate
  *   2. the step's positions are inserted, the SMALLEST position of the step wins a slot (order-free rule: the GPU's lanes

@@ -192,7 +192,7 @@ PREFIX_CASES = {
     # name: (prefix recipe, data recipe, frame size)
     "shared_text": ([["text", 100000, 41]], [["text", 40000, 41], ["text", 60000, 42], ["text", 30000, 41]], 32768),
     "tiny": ([["rep", b"hello world!".hex(), 1]], [["rep", b"hello world!".hex(), 9]], 2 << 20),
-    "long_prefix": ([["text", 300000, 43]], [["text", 200000, 43]], 65536),          # only the last 61376 bytes are reachable
+    "long_prefix": ([["text", 300000, 43]], [["text", 200000, 43]], 65536),          # only the last 57280 bytes are reachable
     "prefix_is_input": ([["chunks", 1 << 20, 5]], [["chunks", 1 << 20, 5]], 1 << 20),
     "random_data": ([["text", 50000, 48]], [["random", 40000, 49], ["text", 20000, 48]], 16384),
     "small_frames": ([["text", 20000, 50]], [["text", 12000, 50]], 1000),
@@ -230,7 +230,7 @@ def test_encode_with_prefix_roundtrip_and_twin(engine, name, checksum):
 @pytest.mark.parametrize("with_prefix", [False, True])
 def test_frames_above_the_matcher_segment(engine, level, with_prefix):
     """Frames larger than ZKE_SEGMENT (256 KiB) are matched in segments, one workgroup each, every segment after the first
-    starting from the 61 376 bytes before it (zk_enc_device.h) -- the CPU twin cuts the same way: byte-identical, valid for
+    starting from the 57 280 bytes before it (zk_enc_device.h) -- the CPU twin cuts the same way: byte-identical, valid for
     libzstd and for both decoders.  Frame size 5 MiB + 12 345 (21 segments, the last one ragged) and a short last frame."""
     data = zko.gen_chunks((17 << 20) + 77, 5)
     fs = (5 << 20) + 12345

@@ -49,7 +49,7 @@ def test_sim_match_small_frames_and_blocks():
 
 
 def test_sim_match_segments():
-    """a frame above ZKE_SEGMENT (256 KiB): the second segment starts from the 61376 bytes before it"""
+    """a frame above ZKE_SEGMENT (256 KiB): the second segment starts from the 57280 bytes before it"""
     data = zko.make_input([["text", 300000, 31], ["rep", "6162636465666768", 2000]])
     _compare(data, 1 << 21, 1)
 

@@ -22,10 +22,10 @@ constexpr uint32_t ZKE_GROUP = 16;                // tiles per group = waves per
 constexpr uint32_t ZKE_GROUP_POS = ZKE_TILE * ZKE_GROUP;
 ZK_HD uint32_t zke_step(int level) { return level >= 6 ? 1024u : ZKE_GROUP_POS; }
 constexpr uint32_t ZKE_PARCAP = 16;               // match length measured per position (branch-free, 16 bytes per candidate); the parse extends longer ones
-// The matcher keeps the last 64 KiB of its input in an LDS ring: the group it works on, 64 bytes of lookahead, and the
-// window behind the group -- the largest offset it produces.
+// The matcher keeps the last 64 KiB of its input in an LDS ring: the group it works on, the next group (loaded while this one is
+// worked on), 64 bytes of lookahead, and the window behind the group -- the largest offset it produces.
 constexpr uint32_t ZKE_RING = 65536;
-constexpr uint32_t ZKE_WINDOW = ZKE_RING - ZKE_GROUP_POS - 64;       // 61376
+constexpr uint32_t ZKE_WINDOW = ZKE_RING - 2 * ZKE_GROUP_POS - 64;   // 57280: the next group's bytes enter the ring while a group is still compared
 // The matcher's unit of work is a SEGMENT of a frame, one workgroup each: a 2 MiB frame spreads over 8 CUs, and 2048 such
 // frames are 16384 workgroups.  A segment after a frame's first starts with an empty table that receives the positions of the
 // ZKE_WINDOW bytes before it (what a prefix does for a frame), counts its positions from that history's start and does not

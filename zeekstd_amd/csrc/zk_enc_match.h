@@ -135,7 +135,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
     __shared__ uint32_t table[TWORDS + 1];
     __shared__ uint32_t best[ZKE_GROUP_POS];
     __shared__ uint64_t tseq[ZKE_GROUP][ZKE_TSEQ_N];        // ll | ml << 12 in the low half, the offset in the high half
-    __shared__ uint32_t tsum[ZKE_GROUP], tlast[ZKE_GROUP];   // count | trailing literals << 8 | literal bytes << 20;  offset of the tile's last sequence
+    __shared__ uint32_t tsum[2][ZKE_GROUP], tlast[2][ZKE_GROUP];   // per tile (two groups deep): count | trailing literals << 8 | literal bytes << 20;  offset of its last sequence
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const ZkEncFrame fr = segs[blockIdx.x];
     const uint8_t *base = src + fr.m_off;
@@ -176,18 +176,78 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
 
     ZKE_CLK(0);
     uint32_t probe = 0;                                      // offset of the last sequence so far (same value in every lane)
+    uint32_t nseq = 0, nlit = 0, pend = 0, prev_off = 0;     // parse state of the block being stitched, identical in every lane
+    uint32_t par = 0;                                        // which half of tsum / tlast the group at work writes
+    // A group's tiles are stitched and stored one group LATER (by the wave that parsed the tile, before it touches its slices
+    // of best[] / tseq[] again): what the stitch needs from the other waves -- their tile summaries -- is then two barriers
+    // old, so neither the parse nor the stitch ends in a barrier of its own and a wave that is slow in one group's parse
+    // catches up in the next group's lookups.
+    struct { bool valid; uint32_t gs, ge; ZkEncBlock *blk; uint64_t *sq; uint8_t *lt; bool last; } todo = {false, 0, 0, nullptr, nullptr, nullptr, false};
+    auto stitch = [&]() {
+        const uint32_t ntiles = (todo.ge - todo.gs + ZKE_TILE - 1) / ZKE_TILE;
+        const uint32_t *ts_ = tsum[par ^ 1], *tl_ = tlast[par ^ 1];
+        uint32_t my_base, my_lit, my_pend, my_poff, my_cnt, my_nl;
+        {
+            // lane t of every row of 16 lanes takes tile t's summary; inclusive scans along the row:
+            //   counts and literal bytes            plain sums (count | bytes << 16)
+            //   literals pending behind tile t      tail(t) if the tile has sequences, else pending(t - 1) + tail(t): segmented sum, bit 31 = "a tile with sequences is inside"
+            //   offset of the last sequence so far  the last non-zero value
+            const uint32_t t = lane & 15;
+            const uint32_t sv = t < ntiles ? ts_[t] : 0, lv = t < ntiles ? tl_[t] : 0;
+            const uint32_t cn = sv & 0xFF, tail = (sv >> 8) & 0xFFF, tnl = sv >> 20;
+            uint32_t x = cn | (tnl << 16), y = tail | (cn ? 0x80000000u : 0u), z = cn ? lv : 0;
+#define ZKE_SCAN_STEP(d) { const uint32_t xs = ZKE_ROW_SHR(x, d, 0), ys = ZKE_ROW_SHR(y, d, 0), zs = ZKE_ROW_SHR(z, d, 0); \
+                           x += xs; y = (y & 0x80000000u) ? y : (y + (ys & 0x7FFFFFFFu)) | (ys & 0x80000000u); z = z ? z : zs; }
+            ZKE_SCAN_STEP(1) ZKE_SCAN_STEP(2) ZKE_SCAN_STEP(4) ZKE_SCAN_STEP(8)
+#undef ZKE_SCAN_STEP
+            // what is in front of my tile = the scans at lane wave - 1; the group's totals = lane 15
+            const uint32_t wm = wave ? wave - 1 : 0;
+            const uint32_t xp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)x, (int)wm) : 0, yp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)y, (int)wm) : 0,
+                           zp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)z, (int)wm) : 0;
+            const uint32_t me = (uint32_t)__builtin_amdgcn_readlane((int)sv, (int)wave);
+            const uint32_t xt = (uint32_t)__builtin_amdgcn_readlane((int)x, 15), yt = (uint32_t)__builtin_amdgcn_readlane((int)y, 15), zt = (uint32_t)__builtin_amdgcn_readlane((int)z, 15);
+            my_base = nseq + (xp & 0xFFFF); my_lit = nlit + (xp >> 16);
+            my_pend = (yp & 0x80000000u) ? yp & 0x7FFFFFFFu : pend + yp;
+            my_poff = zp ? zp : prev_off;
+            my_cnt = me & 0xFF; my_nl = me >> 20;
+            nseq += xt & 0xFFFF; nlit += xt >> 16;
+            pend = (yt & 0x80000000u) ? yt & 0x7FFFFFFFu : pend + yt;
+            if (zt) { prev_off = zt; probe = zt; }
+        }
+        if (wave < ntiles) {
+            if (lane < my_cnt) {                                                    // <= 64 sequences per tile: one per lane
+                const uint64_t e = tseq[wave][lane];
+                uint32_t ll = (uint32_t)e & 0xFFF;
+                const uint32_t ml = (uint32_t)(e >> 12) & 0xFFF, off = (uint32_t)(e >> 32);
+                const uint32_t poff = lane ? (uint32_t)(tseq[wave][lane - 1] >> 32) : my_poff;
+                if (lane == 0) ll += my_pend;
+                const uint32_t code = (ll && off == poff) ? 1u : off + 3;
+                todo.sq[my_base + lane] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)code << 40);
+            }
+            // the tile's literals: four bytes per lane (an unaligned dword store), the last bytes one by one
+            const uint32_t *tw4 = &best[wave * ZKE_TILE];
+            const uint8_t *tl = (const uint8_t *)tw4;
+            uint8_t *o = todo.lt + my_lit;
+            if (4 * lane + 4 <= my_nl) { const uint32_t w4 = tw4[lane]; memcpy(o + 4 * lane, &w4, 4); }
+            else for (uint32_t i = 4 * lane; i < my_nl; i++) o[i] = tl[i];
+        }
+        if (todo.last) {                                                            // the block is complete
+            if (tid == 0) { todo.blk->nseq = nseq; todo.blk->nlit = nlit; }
+            nseq = 0; nlit = 0; pend = 0; prev_off = 0;
+        }
+        todo.valid = false;
+    };
     for (uint32_t bi = 0; bi < fr.n_blocks; bi++) {
         const uint32_t bs = hist + bi * fr.block_max;
         const uint32_t be = bs + fr.block_max < fend ? bs + fr.block_max : fend;
         ZkEncBlock *blk = &blocks[fr.block_base + bi];
         uint64_t *sq = seqs + blk->seq_base;
         uint8_t *lt = lits + blk->lit_base;
-        uint32_t nseq = 0, nlit = 0, pend = 0, prev_off = 0;     // block-level parse state, identical in every lane
         for (uint32_t gs = bs; gs < be; gs += ZKE_GROUP_POS) {
             const uint32_t ge = gs + ZKE_GROUP_POS < be ? gs + ZKE_GROUP_POS : be;
-            const uint32_t R = probe;
-            // the next group's input: requested now, stored into the ring after this group's comparisons (it overwrites the
-            // oldest bytes of this group's window).  A lane past the target repeats the last dword (no branch, unused).
+            // the next group's input: requested now, stored into the ring behind this group's first barrier, while only the
+            // insertions run (nobody reads the ring then; what it overwrites lies in front of this group's window).  A lane
+            // past the target repeats the last dword (no branch, unused).
             uint32_t target = ge + ZKE_GROUP_POS + 64;
             if (target > fend4) target = fend4;
             const uint32_t pq = loaded + 4 * tid;
@@ -222,6 +282,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     ZKE_CLK(1);
                     ZKE_LDS_BARRIER();
                     ZKE_CLK(2);
+                    if (s == 0) { if (pq < target) zke_ring_put(ring, (pq >> 2) & 16383u, pv); loaded = target; }
                     // A position whose hash also belongs to one of the four positions before it cannot win its slot (the smaller
                     // position does): it stays out of the race.  On runs of equal bytes or short periods all lanes of a step
                     // would otherwise fight over a few LDS words.  The table ends the step in the same state.
@@ -264,6 +325,11 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                 }
             }
 
+            // ---- the group before this one: stitch its tiles, store my tile's sequences and literals
+            if (todo.valid) stitch();
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t R = probe;
+            ZKE_CLK(8);
             // ---- 3a: comparisons out of the ring -> best[].  16 bytes per candidate, no branches: an invalid candidate
             // compares the position with itself and is dropped by its flag, so all ring reads of the lane are in flight together.
             const uint32_t ts = gs + wave * ZKE_TILE, te = ts + ZKE_TILE < ge ? ts + ZKE_TILE : ge;      // my tile
@@ -294,12 +360,8 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     dn[k] = (p + bias - en) & 0xFFFFu;                                  // near: an earlier position of this step
                     vn[k] = tabled[k] && dn[k] && (T32 ? (e1[k] & 0xFFFF0000u) == khi : dn[k] <= p - ls);
                     const uint32_t o0 = wlo[k], o1 = whi[k], o2 = __builtin_amdgcn_alignbyte(own[3], own[2], (uint32_t)k), o3 = __builtin_amdgcn_alignbyte(own[4], own[3], (uint32_t)k);
-#ifdef ZKE_EXP_NOCOMPARE
-                    lf[k] = ln[k] = (tw[k] ^ e1[k] ^ o2 ^ o3) & 15;
-#else
                     lf[k] = zke_common16(ring, vf[k] ? p - df[k] : p, o0, o1, o2, o3);
                     ln[k] = zke_common16(ring, vn[k] ? p - dn[k] : p, o0, o1, o2, o3);
-#endif
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -345,9 +407,6 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     const uint64_t open = candm & (pre >= 64 ? 0ull : ~0ull << pre);
                     uint32_t f = open ? (uint32_t)__builtin_ctzll(open) : 64u, lastf = 64;
                     uint64_t taken = 0;
-#ifdef ZKE_EXP_NOPARSE
-                    if (f < 64) { taken = 1ull << f; lastf = f; f = 64; }
-#endif
                     while (f < 64) {                                                    // uniform: every lane walks the same chain
                         taken |= 1ull << f; lastf = f;
                         if ((capped >> f) & 1) {                                        // capped by the comparisons: extend, 64 bytes per step
@@ -388,68 +447,15 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     nl += (uint32_t)__builtin_popcountll(litm);
                 }
                 if (lane == 0) {
-                    tsum[wave] = c | (((te - ts) - aend) << 8) | (nl << 20);
-                    tlast[wave] = lastoff;
+                    tsum[par][wave] = c | (((te - ts) - aend) << 8) | (nl << 20);
+                    tlast[par][wave] = lastoff;
                 }
             }
             ZKE_CLK(6);
-            ZKE_LDS_BARRIER();
-            ZKE_CLK(7);
-
-            // ---- 4: ring <- next group's input; stitch the tiles; store sequences and literals
-            if (pq < target) zke_ring_put(ring, (pq >> 2) & 16383u, pv);
-            loaded = target;
-            const uint32_t ntiles = (ge - gs + ZKE_TILE - 1) / ZKE_TILE;
-            uint32_t my_base, my_lit, my_pend, my_poff, my_cnt, my_nl;
-            {
-                // lane t of every row of 16 lanes takes tile t's summary; inclusive scans along the row:
-                //   counts and literal bytes            plain sums (count | bytes << 16)
-                //   literals pending behind tile t      tail(t) if the tile has sequences, else pending(t - 1) + tail(t): segmented sum, bit 31 = "a tile with sequences is inside"
-                //   offset of the last sequence so far  the last non-zero value
-                const uint32_t t = lane & 15;
-                const uint32_t sv = t < ntiles ? tsum[t] : 0, lv = t < ntiles ? tlast[t] : 0;
-                const uint32_t cn = sv & 0xFF, tail = (sv >> 8) & 0xFFF, tnl = sv >> 20;
-                uint32_t x = cn | (tnl << 16), y = tail | (cn ? 0x80000000u : 0u), z = cn ? lv : 0;
-#define ZKE_SCAN_STEP(d) { const uint32_t xs = ZKE_ROW_SHR(x, d, 0), ys = ZKE_ROW_SHR(y, d, 0), zs = ZKE_ROW_SHR(z, d, 0); \
-                           x += xs; y = (y & 0x80000000u) ? y : (y + (ys & 0x7FFFFFFFu)) | (ys & 0x80000000u); z = z ? z : zs; }
-                ZKE_SCAN_STEP(1) ZKE_SCAN_STEP(2) ZKE_SCAN_STEP(4) ZKE_SCAN_STEP(8)
-#undef ZKE_SCAN_STEP
-                // what is in front of my tile = the scans at lane wave - 1; the group's totals = lane 15
-                const uint32_t wm = wave ? wave - 1 : 0;
-                const uint32_t xp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)x, (int)wm) : 0, yp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)y, (int)wm) : 0,
-                               zp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)z, (int)wm) : 0;
-                const uint32_t me = (uint32_t)__builtin_amdgcn_readlane((int)sv, (int)wave);
-                const uint32_t xt = (uint32_t)__builtin_amdgcn_readlane((int)x, 15), yt = (uint32_t)__builtin_amdgcn_readlane((int)y, 15), zt = (uint32_t)__builtin_amdgcn_readlane((int)z, 15);
-                my_base = nseq + (xp & 0xFFFF); my_lit = nlit + (xp >> 16);
-                my_pend = (yp & 0x80000000u) ? yp & 0x7FFFFFFFu : pend + yp;
-                my_poff = zp ? zp : prev_off;
-                my_cnt = me & 0xFF; my_nl = me >> 20;
-                nseq += xt & 0xFFFF; nlit += xt >> 16;
-                pend = (yt & 0x80000000u) ? yt & 0x7FFFFFFFu : pend + yt;
-                if (zt) { prev_off = zt; probe = zt; }
-            }
-            if (wave < ntiles) {
-                if (lane < my_cnt) {                                                    // <= 64 sequences per tile: one per lane
-                    const uint64_t e = tseq[wave][lane];
-                    uint32_t ll = (uint32_t)e & 0xFFF;
-                    const uint32_t ml = (uint32_t)(e >> 12) & 0xFFF, off = (uint32_t)(e >> 32);
-                    const uint32_t poff = lane ? (uint32_t)(tseq[wave][lane - 1] >> 32) : my_poff;
-                    if (lane == 0) ll += my_pend;
-                    const uint32_t code = (ll && off == poff) ? 1u : off + 3;
-                    sq[my_base + lane] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)code << 40);
-                }
-                // the tile's literals: four bytes per lane (an unaligned dword store), the last bytes one by one
-                const uint32_t *tw4 = &best[wave * ZKE_TILE];
-                const uint8_t *tl = (const uint8_t *)tw4;
-                uint8_t *o = lt + my_lit;
-                if (4 * lane + 4 <= my_nl) { const uint32_t w4 = tw4[lane]; memcpy(o + 4 * lane, &w4, 4); }
-                else for (uint32_t i = 4 * lane; i < my_nl; i++) o[i] = tl[i];
-            }
-            ZKE_CLK(8);
-            ZKE_LDS_BARRIER();                                 // the ring's new bytes are visible; best[] / tseq[] may be reused
-            ZKE_CLK(9);
+            todo.valid = true; todo.gs = gs; todo.ge = ge; todo.blk = blk; todo.sq = sq; todo.lt = lt; todo.last = ge == be;
+            par ^= 1;
         }
-        if (tid == 0) { blk->nseq = nseq; blk->nlit = nlit; }
     }
+    if (todo.valid) { ZKE_LDS_BARRIER(); stitch(); }        // the segment's last group
     ZKE_CLK_END();
 }

@@ -200,7 +200,11 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
     __shared__ uint32_t cnt[ZKE_ENT_BLOCKS][256];
     __shared__ ZkEncTables T;                              // the FSE compression tables of the frame of the workgroup's first block
     __shared__ ZkHufCode hw[ZKE_ENT_BLOCKS];
-    __shared__ ZkHufBuild hbuild[ZKE_ENT_BLOCKS / 2];      // trees are built in two rounds of 8: a build needs 1.9 KiB, the codes 384 B
+#ifndef ZKE_HUF_BUILDS
+#define ZKE_HUF_BUILDS 8
+#endif
+    constexpr uint32_t NHB = ZKE_HUF_BUILDS;                // trees built side by side (a build needs 1.9 KiB of LDS, the codes 384 B): 16 / NHB rounds
+    __shared__ ZkHufBuild hbuild[NHB];
     __shared__ uint32_t s_sizes[ZKE_ENT_BLOCKS][5];        // 4 literal streams + sequence bitstream
     __shared__ uint32_t s_lit_mode[ZKE_ENT_BLOCKS], s_maxbits[ZKE_ENT_BLOCKS], s_tree[ZKE_ENT_BLOCKS], s_diff[ZKE_ENT_BLOCKS], s_mode[ZKE_ENT_BLOCKS];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -283,9 +287,9 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
     }
     // literal mode + Huffman code: two rounds of 8 blocks, block j on lanes j % 8 and j % 8 + 8 of wave 0 (the second
     // lane shadows the first with identical LDS writes: >= 16 active lanes, see zk_decode.hip)
-    for (uint32_t round = 0; round < 2; round++) {
+    for (uint32_t round = 0; round < ZKE_ENT_BLOCKS / NHB; round++) {
         if (tid < ZKE_ENT_BLOCKS) {
-            const uint32_t j = (tid & 7) + 8 * round;
+            const uint32_t j = (tid & (NHB - 1)) + NHB * round;
             if (j < nb) {
                 const uint32_t nlit = blocks[b0 + j].nlit;
                 // literal mode: 1 = RLE, 2 = Huffman (4 streams), 0 = raw      (oracle encode_literals)
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
                 for (uint32_t sy = 0; sy < 256; sy++) if (cnt[j][sy]) { maxsym = sy; distinct++; }
                 if (nlit > 0 && distinct == 1) mode = 1;
                 else if (nlit >= 64 && maxsym < 128) {
-                    int mb = zke_huf_lengths(cnt[j], (int)maxsym + 1, &hbuild[tid & 7], hw[j].len);
+                    int mb = zke_huf_lengths(cnt[j], (int)maxsym + 1, &hbuild[tid & (NHB - 1)], hw[j].len);
                     if (mb > 0) { zke_huf_codes(&hw[j], (int)maxsym + 1, mb); mode = 2; s_maxbits[j] = (uint32_t)mb; s_tree[j] = maxsym; }
                 }
                 s_lit_mode[j] = mode;
