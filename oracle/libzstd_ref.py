@@ -137,6 +137,30 @@ def encode_seekable_frames(data: bytes, frame_size: int, level: int = 1, checksu
     return bytes(out), frames
 
 
+def encode_oneshot_frames(data: bytes, frame_size: int, level: int = 3, checksum: bool = False, which: str = "system"):
+    """One ZSTD_compress2 call per frame: what tools other than zeekstd write (`zstd`, ZSTD_compress): frames that carry
+    Frame_Content_Size and, when small, the Single_Segment flag -- zeekstd's own streaming frames carry neither.
+    Returns (payload, [(c, d), ...])."""
+    l = load(which)
+    l.ZSTD_compress2.restype = C.c_size_t
+    l.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    l.ZSTD_compressBound.restype = C.c_size_t
+    l.ZSTD_compressBound.argtypes = [C.c_size_t]
+    cctx = l.ZSTD_createCCtx()
+    _chk(l, l.ZSTD_CCtx_setParameter(cctx, 100, level))
+    _chk(l, l.ZSTD_CCtx_setParameter(cctx, 201, int(checksum)))
+    data = bytes(data)
+    out, frames = bytearray(), []
+    for pos in range(0, max(len(data), 1), frame_size):
+        chunk = data[pos:pos + frame_size]
+        dst = C.create_string_buffer(l.ZSTD_compressBound(len(chunk)) + 64)
+        c = _chk(l, l.ZSTD_compress2(cctx, dst, len(dst), chunk, len(chunk)))
+        out += dst.raw[:c]
+        frames.append((c, len(chunk)))
+    l.ZSTD_freeCCtx(cctx)
+    return bytes(out), frames
+
+
 def decode_stream(comp: bytes, expect: int = -1, which: str = "system", prefix: bytes = None, window_log_max: int = 0) -> bytes:
     """Reference Decoder hot loop over a whole payload (concatenated frames; skippable frames skipped).
     prefix: referenced before the first frame and again after every frame end (decode.rs:212-214, 248-255)."""

@@ -95,6 +95,29 @@ def test_forward_seek_inside_the_cached_frame_costs_no_submission(engine, text):
     assert d.gpu_submissions() == n and d.read_compressed() > 0
 
 
+def test_seek_to_a_neighbouring_frame_in_the_read_ahead_costs_no_submission(engine, text):
+    """set_offset to another frame (or backwards) resets the decode state (decode.rs:408-410) -- but frames the
+    engine has already decoded ahead stay valid, so a seek into them is served without a new submission.  read_compressed
+    still restarts from 0 at the seek and counts the frames delivered, as upstream's re-read would."""
+    comp, frames = _archive(engine, text, "gpu")
+    d = DecodeOptions(_seekable(comp, frames)).engine(engine).batch_bytes(16 * FSZ).into_decoder()
+    d.set_offset(4 * FSZ + 10)
+    buf = bytearray(3 * FSZ)
+    assert d.decompress(buf) == 3 * FSZ                              # a streaming-size read: frames 4 .. 19 are decoded (read-ahead)
+    n = d.gpu_submissions()
+    for off in (9 * FSZ + 5, 6 * FSZ + 77, 12 * FSZ):                 # forwards to another frame, backwards, forwards again
+        d.set_offset(off); d.set_offset_limit(off + 300)
+        assert d.read_compressed() == 0                              # the state was reset (decode.rs:408-410)
+        small = bytearray(1000)
+        assert d.decompress(small) == 300 and bytes(small[:300]) == text[off:off + 300]
+        assert d.read_compressed() == frames[off // FSZ][0]          # one frame's worth, as a re-read would count
+        d.set_offset_limit(NBYTES)
+    assert d.gpu_submissions() == n
+    d.reset()                                                        # Decoder::reset drops the read-ahead like upstream's state
+    d.set_offset(9 * FSZ); d.set_offset_limit(9 * FSZ + 10)
+    assert d.decompress(bytearray(64)) == 10 and d.gpu_submissions() == n + 1
+
+
 def test_cpu_suites_also_pass_on_the_gpu_box():
     """The seek-table golden bytes (tests/test_seek_table.py) and the ABI checks (tests/test_abi.py: every symbol of
     include/zeekstd_amd.h is exported, the product never touches oracle/) are CPU tests; the driver's GPU pass selects

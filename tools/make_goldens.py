@@ -46,12 +46,23 @@ CASES = [
     ("slices_l19", [["slices", 100000, 77, 9000, 5, 8, 40, "ff"]], 2 << 20, 19, True),              # RLE literals, Repeat_Mode x3
     ("one_byte", [["rep", "41", 1]], 2 << 20, 1, True),
 ]
+# frames written by ONE ZSTD_compress2 call each (what `zstd` / ZSTD_compress write): Frame_Content_Size in the header and,
+# for small frames, Single_Segment -- zeekstd's own streaming frames carry neither, other writers of seekable archives do
+ONESHOT = [
+    ("oneshot_small", [["text", 300, 31]], 100, 3, False),                        # single-segment, 1-byte FCS
+    ("oneshot_text_l3", [["text", 150 * K, 32]], 50 * K, 3, True),                # 2-byte FCS (+256), three seek entries
+    ("oneshot_l19_4byte_fcs", [["text", 90 * K, 33], ["rep", "6162636465", 4000]], 2 << 20, 19, True),
+    ("oneshot_empty", [], 2 << 20, 3, False),
+]
 
 blob = bytearray()
 index = []
-for name, recipe, fs, level, cks in CASES:
+for name, recipe, fs, level, cks in CASES + ONESHOT:
     data = zko.make_input(recipe)
-    comp, frames = Z.encode_seekable_frames(data, fs, level, cks, "1.5.7")
+    if name.startswith("oneshot"):
+        comp, frames = Z.encode_oneshot_frames(data, fs, level, cks, "1.5.7")
+    else:
+        comp, frames = Z.encode_seekable_frames(data, fs, level, cks, "1.5.7")
     # self-check with BOTH real decoders before committing
     assert Z.decode_stream(comp, len(data), "1.5.7") == data
     assert Z.decode_stream(comp, len(data), "system") == data

@@ -130,7 +130,7 @@ uint32_t Decoder::decode_range(uint32_t first, uint32_t count, uint8_t *dst, uin
             break;
         }
     }
-    read_compressed_ += E[first + n_ok].c_offset - E[first].c_offset;
+    count_frames(first, first + n_ok);
     if (n_ok < count && *err == 0) *err = 1;
     return n_ok;
 }
@@ -168,7 +168,6 @@ void Decoder::fill_cache(uint64_t want_end, uint64_t request_end, const uint8_t 
 size_t Decoder::decompress_with_prefix(uint8_t *buf, size_t len, const uint8_t *prefix, size_t prefix_len)
 {
     if (!prefix) prefix_len = 0;
-    if (read_compressed_ == 0) { cache_count_ = 0; cache_d_start_ = cache_d_end_ = 0; }   // fresh decode state, decode.rs:206-218
     // frames are decoded ahead of the reads; the ones in the cache were decoded with the prefix of the call that
     // filled it.  A different prefix (address or length: like libzstd, only the reference is kept) drops them.  The
     // reference applies a new prefix at the next frame start (decode.rs:248-255); here a switch in the middle of a
@@ -186,6 +185,8 @@ size_t Decoder::decompress_with_prefix(uint8_t *buf, size_t len, const uint8_t *
             // its end since: the reference reaches the frame end now and verifies -- so the frame is decoded again
             if (cache_unverified_end_ && offset_limit_ >= cache_unverified_end_ && verify_) { cache_count_ = 0; continue; }
             size_t n = (size_t)std::min<uint64_t>({(uint64_t)(len - progress), offset_limit_ - offset_, cache_d_end_ - offset_});
+            // frames kept across a seek count as read when they are delivered (upstream reads them again after its reset)
+            count_frames(seek_table_.frame_index_decomp(offset_), seek_table_.frame_index_decomp(offset_ + n - 1) + 1);
             if (n >= (8u << 20)) zk_host_copy(engine_, buf + progress, cache_ + (offset_ - cache_d_start_), n);
             else memcpy(buf + progress, cache_ + (offset_ - cache_d_start_), n);
             offset_ += n; progress += n;                                      // decode.rs:263-266
@@ -224,11 +225,30 @@ void Decoder::reset()                                                         //
     offset_limit_ = seek_table_.size_decomp();
 }
 
-void Decoder::reset_dctx()                                                    // decode.rs:352-357
+void Decoder::reset_dctx(bool keep_cache)                                     // decode.rs:352-357
 {
     read_compressed_ = 0;
-    cache_count_ = 0; cache_d_start_ = cache_d_end_ = 0; cache_unverified_end_ = 0;
+    counted_lo_ = counted_hi_ = 0;
+    // The frames decoded ahead stay valid whatever the decode state (the source is borrowed unchanged, decode.rs:201): a seek
+    // into them is served from the cache instead of a new submission.  Decoder::reset() drops them like upstream's state.
+    if (!keep_cache) { cache_count_ = 0; cache_d_start_ = cache_d_end_ = 0; cache_unverified_end_ = 0; }
     prefix_dirty_ = true;                       // a reset decoder references its prefix anew (decode.rs:212-214)
+}
+
+// read_compressed (decode.rs:448): compressed bytes of the frames [first, end) are added unless the range counted since the
+// last reset already holds them
+void Decoder::count_frames(uint32_t first, uint32_t end)
+{
+    const auto &E = seek_table_.entries();
+    if (end > seek_table_.num_frames()) end = seek_table_.num_frames();
+    for (uint32_t f = first; f < end; f++) {
+        if (f >= counted_lo_ && f < counted_hi_) continue;
+        read_compressed_ += E[f + 1].c_offset - E[f].c_offset;
+        if (counted_lo_ == counted_hi_) { counted_lo_ = f; counted_hi_ = f + 1; }
+        else if (f == counted_hi_) counted_hi_++;
+        else if (f + 1 == counted_lo_) counted_lo_--;
+        else { counted_lo_ = f; counted_hi_ = f + 1; }
+    }
 }
 
 uint64_t Decoder::set_lower_frame(uint32_t index)                             // decode.rs:367-372
@@ -251,7 +271,7 @@ void Decoder::set_offset(uint64_t offset)                                     //
     const uint32_t current = seek_table_.frame_index_decomp(offset_);
     const uint32_t target = seek_table_.frame_index_decomp(offset);
     // only reset if we cannot continue from the previous decompression
-    if (current != target || offset < offset_) reset_dctx();
+    if (current != target || offset < offset_) reset_dctx(cache_count_ && offset >= cache_d_start_ && offset < cache_d_end_);
     offset_ = offset;
 }
 

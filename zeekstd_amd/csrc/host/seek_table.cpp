@@ -1,6 +1,8 @@
-// seek_table.cpp -- Zstandard Seekable Format seek table: in-memory index, resumable serializer,
-// streaming parser.  Host-side integer code; mirrors /root/reference/lib/src/seek_table.rs
-// (spec: /root/reference/seekable_format.md:45-157) behaviour for behaviour, including its quirks.
+// seek_table.cpp -- Zstandard Seekable Format seek table: in-memory index, serializer, parser.  Host-side integer code.
+// The wire format is the spec's (/root/reference/seekable_format.md:45-157) and the observable behaviour -- errors and their
+// order, partial reads and writes at any byte, legacy 12-byte entries -- is that of /root/reference/lib/src/seek_table.rs
+// (cited per function); the structure is this file's own: the parser is a byte-indexed state machine fed pieces of any
+// size, the serializer computes the table as a function of the byte position.
 #include <string.h>
 #include <algorithm>
 #include "zeekstd.hpp"
@@ -8,67 +10,95 @@
 namespace zeekstd {
 
 namespace {
-constexpr size_t SIZE_PER_FRAME = 8;                                  // seek_table.rs:87
 constexpr uint32_t ZSTD_error_prefix_unknown = 10, ZSTD_error_corruption_detected = 20;
 
-inline uint32_t read_le32(const uint8_t *b, size_t off)              // macro read_le32!, seek_table.rs:14-21
-{
-    return (uint32_t)b[off] | ((uint32_t)b[off + 1] << 8) | ((uint32_t)b[off + 2] << 16) | ((uint32_t)b[off + 3] << 24);
-}
-}  // namespace
+inline uint32_t le32(const uint8_t *b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); }
 
-// ---------------------------------------------------------------- Parser (seek_table.rs:134-225)
-class SeekTableParser {
-public:
-    size_t num_frames = 0, size_per_frame = 8, seek_table_size = 0;
-    std::vector<SeekTable::Entry> entries;
-    uint64_t c_offset = 0, d_offset = 0;
-
-    static SeekTableParser from_bytes(const uint8_t *buf)            // 9-byte integrity field, :144-172
+// What the 9-byte integrity field says about the table (seekable_format.md:116-157; checks and their order as in
+// seek_table.rs:144-172: magic, reserved descriptor bits, frame count).
+struct TableShape {
+    uint32_t frames = 0;
+    uint32_t entry_bytes = 8;            // 12 with the legacy per-frame checksum (descriptor bit 7): carried, never verified
+    uint64_t total = 0;                  // bytes of the whole skippable frame
+    explicit TableShape(const uint8_t integrity[SEEK_TABLE_INTEGRITY_SIZE])
     {
-        if (read_le32(buf, 5) != SEEKABLE_MAGIC_NUMBER) throw Error::zstd(ZSTD_error_prefix_unknown);
-        if (((buf[4] >> 2) & 0x1f) > 0) throw Error::zstd(ZSTD_error_corruption_detected);   // reserved descriptor bits
-        const bool with_checksum = (buf[4] & (1 << 7)) > 0;
-        const uint32_t n = read_le32(buf, 0);
-        if (n > SEEKABLE_MAX_FRAMES) throw Error::frame_index_too_large();
-        SeekTableParser p;
-        p.num_frames = n;
-        p.size_per_frame = with_checksum ? 12 : 8;
-        p.seek_table_size = p.num_frames * p.size_per_frame + SKIPPABLE_HEADER_SIZE + SEEK_TABLE_INTEGRITY_SIZE;
-        p.entries.reserve(std::max<size_t>(p.num_frames, 1) + 1);
-        return p;
+        if (le32(integrity + 5) != SEEKABLE_MAGIC_NUMBER) throw Error::zstd(ZSTD_error_prefix_unknown);
+        const uint8_t descriptor = integrity[4];
+        if (descriptor & 0x7C) throw Error::zstd(ZSTD_error_corruption_detected);
+        frames = le32(integrity);
+        if (frames > SEEKABLE_MAX_FRAMES) throw Error::frame_index_too_large();
+        entry_bytes = (descriptor & 0x80) ? 12 : 8;
+        total = (uint64_t)frames * entry_bytes + SKIPPABLE_HEADER_SIZE + SEEK_TABLE_INTEGRITY_SIZE;
     }
-    void verify_skippable_header(const uint8_t *buf) const           // :174-184
+    void check_header(const uint8_t header[SKIPPABLE_HEADER_SIZE]) const       // seek_table.rs:174-184
     {
-        if (read_le32(buf, 0) != SKIPPABLE_MAGIC_NUMBER) throw Error::zstd(ZSTD_error_prefix_unknown);
-        const size_t size = read_le32(buf, 4);
-        if (size + SKIPPABLE_HEADER_SIZE != seek_table_size) throw Error::zstd(ZSTD_error_corruption_detected);
-    }
-    size_t parse_entries(const uint8_t *buf, size_t len)             // :186-209
-    {
-        size_t pos = 0;
-        while (entries.size() < num_frames) {
-            if (pos + size_per_frame > len) return pos;
-            log_entry();
-            c_offset += read_le32(buf, pos);
-            d_offset += read_le32(buf, pos + 4);
-            pos += size_per_frame;                                    // a legacy per-frame checksum is skipped, not verified
-        }
-        log_entry();                                                  // final entry: end of the last frame
-        return pos;
-    }
-    void log_entry() { entries.push_back({c_offset, d_offset}); }
-    void verify() const                                              // :218-224
-    {
-        if (entries.size() != num_frames + 1) throw Error::zstd(ZSTD_error_corruption_detected);
-    }
-    SeekTable into_table()
-    {
-        SeekTable t;
-        t.entries_ = std::move(entries);
-        return t;
+        if (le32(header) != SKIPPABLE_MAGIC_NUMBER) throw Error::zstd(ZSTD_error_prefix_unknown);
+        if ((uint64_t)le32(header + 4) + SKIPPABLE_HEADER_SIZE != total) throw Error::zstd(ZSTD_error_corruption_detected);
     }
 };
+
+// The entries of a table as a byte-indexed state machine: bytes arrive in pieces of any size (a partial entry needs no
+// buffer shuffling), `at` is the index inside the entries region, and every completed little-endian word goes to the
+// running sum its place in the entry names (0: compressed size, 1: decompressed size, 2: legacy checksum -- dropped).
+class EntryScanner {
+public:
+    EntryScanner(uint32_t frames, uint32_t entry_bytes) : frames_(frames), entry_bytes_(entry_bytes)
+    {
+        out_.reserve((size_t)frames + 1);
+        out_.push_back({0, 0});
+    }
+    uint64_t missing() const { return (uint64_t)frames_ * entry_bytes_ - at_; }
+    void feed(const uint8_t *p, size_t n)
+    {
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t in_entry = (uint32_t)(at_ % entry_bytes_);
+            word_ |= (uint32_t)p[i] << (8 * (in_entry & 3));
+            at_++;
+            if ((in_entry & 3) != 3) continue;
+            if (in_entry == 3) c_ += word_;
+            else if (in_entry == 7) d_ += word_;
+            word_ = 0;
+            if (in_entry + 1 == entry_bytes_) out_.push_back({c_, d_});
+        }
+    }
+    std::vector<SeekTable::Entry> finish()                                     // seek_table.rs:218-224
+    {
+        if (out_.size() != (size_t)frames_ + 1) throw Error::zstd(ZSTD_error_corruption_detected);
+        return std::move(out_);
+    }
+
+private:
+    uint32_t frames_, entry_bytes_, word_ = 0;
+    uint64_t at_ = 0, c_ = 0, d_ = 0;
+    std::vector<SeekTable::Entry> out_;
+};
+
+// pulls exactly n bytes through `read` into dst (or discards them when dst is null); false when the source ends first
+template <typename ReadFn>
+bool pull(ReadFn &&read, uint8_t *dst, size_t n, uint8_t *scratch, size_t scratch_len)
+{
+    size_t got = 0;
+    while (got < n) {
+        const size_t k = dst ? read(dst + got, n - got) : read(scratch, std::min(scratch_len, n - got));
+        if (k == 0) return false;
+        got += k;
+    }
+    return true;
+}
+template <typename ReadFn>
+std::vector<SeekTable::Entry> scan_entries(ReadFn &&read, const TableShape &shape)
+{
+    EntryScanner scan(shape.frames, shape.entry_bytes);
+    std::vector<uint8_t> buf((size_t)std::min<uint64_t>(8192, std::max<uint64_t>(scan.missing(), 1)));
+    while (scan.missing()) {
+        // short reads are fine (a regression fixed upstream: CHANGELOG_LIB.md:14-15); a source that ends early is corruption
+        const size_t k = read(buf.data(), (size_t)std::min<uint64_t>(buf.size(), scan.missing()));
+        if (k == 0) throw Error::zstd(ZSTD_error_corruption_detected);
+        scan.feed(buf.data(), k);
+    }
+    return scan.finish();
+}
+}  // namespace
 
 // ---------------------------------------------------------------- SeekTable
 SeekTable::SeekTable() { entries_.push_back({0, 0}); }
@@ -83,82 +113,32 @@ bool SeekTable::operator==(const SeekTable &o) const
 
 SeekTable SeekTable::from_seekable_format(Seekable &src, Format format)      // seek_table.rs:379-436
 {
-    auto integrity = src.seek_table_integrity(format);
-    SeekTableParser parser = SeekTableParser::from_bytes(integrity.data());
+    const auto integrity = src.seek_table_integrity(format);
+    const TableShape shape(integrity.data());
     if (format == Format::Head) src.set_offset(OffsetFrom::Start(0));
-    else src.set_offset(OffsetFrom::End(-(int64_t)parser.seek_table_size));
-
-    const size_t len = std::min<size_t>(8192, parser.seek_table_size);
-    std::vector<uint8_t> buf(len);
-    size_t read = 0;
-    while (read < SKIPPABLE_HEADER_SIZE) {
-        // NB the reference reads into the start of buf on every iteration (seek_table.rs:391-399); with a
-        // source that returns fewer than 8 bytes at a time the header check would see a torn header.
-        // Reading at buf+read keeps the bytes it already has; identical for any source that delivers >= 8 bytes.
-        size_t n = src.read(buf.data() + read, buf.size() - read);
-        if (n == 0) throw Error::zstd(ZSTD_error_corruption_detected);
-        read += n;
-    }
-    parser.verify_skippable_header(buf.data());
-
-    size_t buf_start = SKIPPABLE_HEADER_SIZE;
-    if (format == Format::Head) buf_start += SEEK_TABLE_INTEGRITY_SIZE;
-    size_t remaining = parser.seek_table_size - SKIPPABLE_HEADER_SIZE - SEEK_TABLE_INTEGRITY_SIZE;
-    size_t buf_end = read;
-    if (buf_start > buf_end) {                                        // Head format with a short first read
-        while (buf_end < buf_start) {
-            size_t n = src.read(buf.data() + buf_end, buf.size() - buf_end);
-            if (n == 0) throw Error::zstd(ZSTD_error_corruption_detected);
-            buf_end += n;
-        }
-    }
-    for (;;) {
-        size_t n = parser.parse_entries(buf.data() + buf_start, buf_end - buf_start);
-        remaining -= n;
-        if (remaining == 0) break;
-        // move the unparsed tail (a partial entry) to the front, then read more
-        size_t offset = buf_end - (buf_start + n);
-        memmove(buf.data(), buf.data() + buf_start + n, offset);
-        size_t m = src.read(buf.data() + offset, buf.size() - offset);
-        if (remaining > 0 && m == 0) throw Error::zstd(ZSTD_error_corruption_detected);
-        buf_start = 0;
-        buf_end = offset + m;
-    }
-    parser.verify();
-    return parser.into_table();
+    else src.set_offset(OffsetFrom::End(-(int64_t)shape.total));
+    auto read = [&](uint8_t *p, size_t n) { return src.read(p, n); };
+    uint8_t header[SKIPPABLE_HEADER_SIZE], skip[SEEK_TABLE_INTEGRITY_SIZE];
+    // (the reference reads the header into the start of its buffer on every iteration, :391-399: a source that returns
+    //  fewer than 8 bytes at a time would tear it; the bytes already read are kept here -- identical for any other source)
+    if (!pull(read, header, sizeof header, nullptr, 0)) throw Error::zstd(ZSTD_error_corruption_detected);
+    shape.check_header(header);
+    if (format == Format::Head && !pull(read, nullptr, sizeof skip, skip, sizeof skip)) throw Error::zstd(ZSTD_error_corruption_detected);
+    SeekTable t;
+    t.entries_ = scan_entries(read, shape);
+    return t;
 }
 
 SeekTable SeekTable::from_reader(Reader &reader)                              // seek_table.rs:461-493 (Head format)
 {
+    auto read = [&](uint8_t *p, size_t n) { return reader.read(p, n); };
     uint8_t head[SKIPPABLE_HEADER_SIZE + SEEK_TABLE_INTEGRITY_SIZE];
-    size_t got = 0;
-    while (got < sizeof head) {                                       // read_exact
-        size_t n = reader.read(head + got, sizeof head - got);
-        if (n == 0) throw Error::io("failed to fill whole buffer");
-        got += n;
-    }
-    SeekTableParser parser = SeekTableParser::from_bytes(head + SKIPPABLE_HEADER_SIZE);
-    parser.verify_skippable_header(head);
-    size_t remaining = parser.seek_table_size - SKIPPABLE_HEADER_SIZE - SEEK_TABLE_INTEGRITY_SIZE;
-    std::vector<uint8_t> buf(std::min<size_t>(8192, remaining));
-    size_t have = 0;                                                  // bytes valid at the start of buf
-    size_t unread = remaining;                                        // bytes of the table not yet pulled from the reader
-    for (;;) {
-        if (unread > 0) {
-            // short reads are fine (regression fixed upstream: CHANGELOG_LIB.md:14-15)
-            size_t want = std::min(buf.size() - have, unread);
-            size_t n = reader.read(buf.data() + have, want);
-            if (n == 0) throw Error::zstd(ZSTD_error_corruption_detected);
-            have += n; unread -= n;
-        }
-        size_t n = parser.parse_entries(buf.data(), have);
-        remaining -= n;
-        if (remaining == 0) break;
-        memmove(buf.data(), buf.data() + n, have - n);
-        have -= n;
-    }
-    parser.verify();
-    return parser.into_table();
+    if (!pull(read, head, sizeof head, nullptr, 0)) throw Error::io("failed to fill whole buffer");      // read_exact
+    const TableShape shape(head + SKIPPABLE_HEADER_SIZE);
+    shape.check_header(head);
+    SeekTable t;
+    t.entries_ = scan_entries(read, shape);
+    return t;
 }
 
 SeekTable SeekTable::from_bytes_head(const uint8_t *p, size_t len)
@@ -226,58 +206,44 @@ Serializer SeekTable::into_format_serializer(Format format) const             //
     return s;
 }
 
-// ---------------------------------------------------------------- Serializer (seek_table.rs:23-84, 955-1059)
-// Resumable at byte granularity: write_pos_ counts the bytes of the table emitted so far; every field
-// emits only its not-yet-written bytes and returns as soon as the caller's buffer is full.
+// ---------------------------------------------------------------- Serializer (seek_table.rs:955-1059)
+// The table is a function of the byte position: header words, the 9-byte integrity field (in front of the entries in the
+// Head format, behind them in the Foot format) and 8 bytes per frame.  write_into fills the caller's buffer from the
+// position it stopped at -- resumable at any byte -- and the only state is that position.
+uint8_t Serializer::byte_at(size_t pos) const
+{
+    auto le = [](uint32_t v, size_t k) { return (uint8_t)(v >> (8 * k)); };
+    const size_t n = frames_.size();
+    if (pos < 4) return le(SKIPPABLE_MAGIC_NUMBER, pos);
+    if (pos < 8) return le((uint32_t)(encoded_len() - SKIPPABLE_HEADER_SIZE), pos - 4);
+    const size_t integrity_at = format_ == Format::Head ? SKIPPABLE_HEADER_SIZE : SKIPPABLE_HEADER_SIZE + 8 * n;
+    if (pos >= integrity_at && pos < integrity_at + SEEK_TABLE_INTEGRITY_SIZE) {
+        const size_t k = pos - integrity_at;                          // Number_Of_Frames, Seek_Table_Descriptor (0), Seekable_Magic_Number
+        return k < 4 ? le((uint32_t)n, k) : k == 4 ? 0 : le(SEEKABLE_MAGIC_NUMBER, k - 5);
+    }
+    const size_t e = pos - SKIPPABLE_HEADER_SIZE - (format_ == Format::Head ? SEEK_TABLE_INTEGRITY_SIZE : 0);
+    const Frame &f = frames_[e / 8];
+    return le((e & 4) ? f.d_size : f.c_size, e & 3);
+}
+
 size_t Serializer::write_into(uint8_t *buf, size_t len)
 {
-    size_t buf_pos = 0;
-    bool full = false;
-    auto write_le32 = [&](uint32_t value, size_t offset) {            // macro write_le32!, :23-43
-        if (full) return;
-        if (write_pos_ < offset + 4) {
-            size_t n = std::min(len - buf_pos, offset + 4 - write_pos_);
-            size_t val_offset = write_pos_ - offset;
-            uint8_t le[4] = {(uint8_t)value, (uint8_t)(value >> 8), (uint8_t)(value >> 16), (uint8_t)(value >> 24)};
-            memcpy(buf + buf_pos, le + val_offset, n);
-            buf_pos += n; write_pos_ += n;
-            if (buf_pos == len) full = true;
-        }
-    };
-    auto write_integrity = [&](uint32_t num_frames, size_t offset) {  // macro write_integrity!, :67-84
-        write_le32(num_frames, offset);
-        if (full) return;
-        if (write_pos_ < offset + 5) {                                // Seek_Table_Descriptor, always 0
-            // (upstream writes this byte unconditionally; it cannot overflow there because write_le32
-            //  returns when the buffer is full -- same here through `full`)
-            buf[buf_pos] = 0; buf_pos += 1; write_pos_ += 1;
-            if (buf_pos == len) { full = true; }
-        }
-        // upstream does not test "buffer full" after the descriptor byte: the next write_le32 sees a
-        // zero-length remainder, copies nothing and returns buf_pos -- equivalent
-        write_le32(SEEKABLE_MAGIC_NUMBER, offset + 5);
-    };
-    if (len == 0) return 0;
-    write_le32(SKIPPABLE_MAGIC_NUMBER, 0);
-    write_le32((uint32_t)(encoded_len() - SKIPPABLE_HEADER_SIZE), 4);
-    if (format_ == Format::Head) write_integrity((uint32_t)frames_.size(), SKIPPABLE_HEADER_SIZE);
-    while (!full && frame_index_ < frames_.size()) {
-        size_t offset = SKIPPABLE_HEADER_SIZE + SIZE_PER_FRAME * frame_index_;
-        if (format_ == Format::Head) offset += SEEK_TABLE_INTEGRITY_SIZE;
-        write_le32(frames_[frame_index_].c_size, offset);
-        write_le32(frames_[frame_index_].d_size, offset + 4);
-        if (!full || write_pos_ >= offset + 8) {
-            // the frame is complete once its 8 bytes are out (upstream advances frame_index only when both
-            // writes went through without an early return; a full buffer exactly at the frame end is picked
-            // up on the next call by the write_pos test)
-            if (write_pos_ >= offset + 8) frame_index_ += 1;
-        }
+    const size_t total = encoded_len();
+    const size_t n = std::min(len, total - std::min(total, write_pos_));
+    const size_t entries_at = SKIPPABLE_HEADER_SIZE + (format_ == Format::Head ? SEEK_TABLE_INTEGRITY_SIZE : 0), entries_end = entries_at + 8 * frames_.size();
+    size_t i = 0;
+    while (i < n) {
+        const size_t pos = write_pos_ + i;
+        if (pos >= entries_at && (pos - entries_at) % 8 == 0 && pos + 8 <= entries_end && i + 8 <= n) {      // whole entries: eight bytes at a time
+            const Frame &f = frames_[(pos - entries_at) / 8];
+            const uint8_t e[8] = {(uint8_t)f.c_size, (uint8_t)(f.c_size >> 8), (uint8_t)(f.c_size >> 16), (uint8_t)(f.c_size >> 24),
+                                  (uint8_t)f.d_size, (uint8_t)(f.d_size >> 8), (uint8_t)(f.d_size >> 16), (uint8_t)(f.d_size >> 24)};
+            memcpy(buf + i, e, 8);
+            i += 8;
+        } else { buf[i] = byte_at(pos); i++; }
     }
-    if (!full && format_ == Format::Foot) {
-        size_t offset = SKIPPABLE_HEADER_SIZE + SIZE_PER_FRAME * frames_.size();
-        write_integrity((uint32_t)frames_.size(), offset);
-    }
-    return buf_pos;
+    write_pos_ += n;
+    return n;
 }
 
 }  // namespace zeekstd

@@ -158,7 +158,6 @@ public:
     const std::vector<Entry> &entries() const { return entries_; }                   // n+1 prefix sums
 
 private:
-    friend class SeekTableParser;
     uint32_t frame_index_at(uint64_t offset, bool comp) const;                       // :916-934
     std::vector<Entry> entries_;
 };
@@ -166,7 +165,7 @@ private:
 class Serializer {                                                                   // seek_table.rs:937-1059
 public:
     size_t write_into(uint8_t *buf, size_t len);                                     // :967-1005 (0 == done)
-    void reset() { write_pos_ = 0; frame_index_ = 0; }                               // :1034
+    void reset() { write_pos_ = 0; }                                                 // :1034
     size_t encoded_len() const { return SKIPPABLE_HEADER_SIZE + SEEK_TABLE_INTEGRITY_SIZE + frames_.size() * 8; }   // :1042
     size_t read(uint8_t *buf, size_t len) { return write_into(buf, len); }           // impl io::Read, :1055-1059
 
@@ -174,7 +173,8 @@ private:
     friend class SeekTable;
     struct Frame { uint32_t c_size, d_size; };
     std::vector<Frame> frames_;
-    size_t frame_index_ = 0, write_pos_ = 0;
+    uint8_t byte_at(size_t pos) const;         // the table as a function of the byte position
+    size_t write_pos_ = 0;
     Format format_ = Format::Foot;
 };
 
@@ -235,7 +235,8 @@ public:
 
 private:
     void check_offset(uint64_t offset) const;                                        // :439-445
-    void reset_dctx();                                                               // :352-357
+    void reset_dctx(bool keep_cache = false);
+    void count_frames(uint32_t first, uint32_t end);                                                               // :352-357
     void fill_cache(uint64_t want_end, uint64_t request_end, const uint8_t *prefix, size_t prefix_len);
     void check_frames(uint32_t first, uint32_t count) const;
     uint32_t decode_range(uint32_t first, uint32_t count, uint8_t *dst, uint64_t dst_cap, const uint8_t *prefix, size_t prefix_len, uint32_t *err);
@@ -245,6 +246,7 @@ private:
     SeekTable seek_table_;
     std::shared_ptr<Seekable> src_;
     uint64_t offset_ = 0, offset_limit_ = 0, read_compressed_ = 0;
+    uint32_t counted_lo_ = 0, counted_hi_ = 0;                  // frames whose compressed bytes read_compressed_ holds since the last reset
     uint64_t batch_bytes_ = 64ull << 20;
     bool verify_ = true;
     // decoded frames [cache_first_, cache_first_ + cache_count_) live in cache_
