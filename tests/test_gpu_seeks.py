@@ -101,9 +101,10 @@ def test_seek_to_a_neighbouring_frame_in_the_read_ahead_costs_no_submission(engi
     still restarts from 0 at the seek and counts the frames delivered, as upstream's re-read would."""
     comp, frames = _archive(engine, text, "gpu")
     d = DecodeOptions(_seekable(comp, frames)).engine(engine).batch_bytes(16 * FSZ).into_decoder()
-    d.set_offset(4 * FSZ + 10)
-    buf = bytearray(3 * FSZ)
-    assert d.decompress(buf) == 3 * FSZ                              # a streaming-size read: frames 4 .. 19 are decoded (read-ahead)
+    d.set_offset(4 * FSZ)
+    buf = bytearray(FSZ)
+    assert d.decompress(buf) == FSZ                                  # frame 4 alone (too small for the decode-ahead)
+    assert d.decompress(bytearray(10)) == 10                         # a read that continues where the cache ends: frames 5 .. 20 are decoded ahead
     n = d.gpu_submissions()
     for off in (9 * FSZ + 5, 6 * FSZ + 77, 12 * FSZ):                 # forwards to another frame, backwards, forwards again
         d.set_offset(off); d.set_offset_limit(off + 300)

@@ -93,7 +93,15 @@ CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t i
     }
     size_t limit = std::min(in_len, remaining_frame_size());                   // encode.rs:329
     const bool by_output = policy_.kind == FrameSizePolicy::Kind::Compressed;
-    if (by_output) limit = std::min(limit, std::min<size_t>(out_len, 131591));
+    const size_t slack = 131072 - 4096;
+    if (by_output) {
+        limit = std::min(limit, std::min<size_t>(out_len, 131591));
+        // a call never takes input past the next probe: the frame-so-far is then measured exactly where the schedule says --
+        // taking a whole 131 591-byte call beyond it let incompressible input carry a frame past n + 131 591
+        const size_t want0 = policy_.size;
+        if (next_probe_ == 0) next_probe_ = std::max<size_t>(1, std::min<size_t>(ratio_ > 0 ? (size_t)(0.97 * ratio_ * (double)want0) : want0, want0 + slack));
+        if (next_probe_ > frame_in_.size()) limit = std::min(limit, next_probe_ - frame_in_.size());
+    }
     // the prefix of the call that starts a frame is the frame's prefix (ref_prefix only if frame_d_size == 0,
     // encode.rs:334-338); like libzstd only the reference is kept until the frame is encoded
     if (frame_d_size_ == 0) { frame_prefix_ = prefix; frame_prefix_len_ = prefix ? prefix_len : 0; }
@@ -103,8 +111,6 @@ CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t i
         const size_t want = policy_.size;
         // (b more compressed bytes need at least ~b more input bytes: a probe never lies further ahead than that plus the
         // window, so even input that stops compressing cannot carry the frame past n + 131 591)
-        const size_t slack = 131072 - 4096;
-        if (next_probe_ == 0) next_probe_ = std::max<size_t>(1, std::min<size_t>(ratio_ > 0 ? (size_t)(0.97 * ratio_ * (double)want) : want, want + slack));
         if (frame_in_.size() >= next_probe_) {
             encoded_ = false;
             encode_pending();                                                  // speculative: how large is the frame so far?
