@@ -717,9 +717,10 @@ int zk_host_encode(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_
     int rc;
     if ((rc = zk_hostpipe_get(e, &hp))) return rc;
 
-    // chunks: enough frames to fill the GPU (the match kernel runs one workgroup per frame, three per CU), at least
-    // 256 MiB, at most 2 GiB of input
-    uint64_t per = 768;
+    // chunks: at least 256 MiB and 128 frames, at most 2 GiB of input.  (The matcher works on 256 KiB segments, a workgroup
+    // each: 256 MiB already are four rounds of the whole chip; round 2's one workgroup per frame needed 768 frames = 1.5 GiB
+    // per chunk, which had to be uploaded before the first kernel ran.)
+    uint64_t per = 128;
     if (per * frame_size < (256ull << 20)) per = ((256ull << 20) + frame_size - 1) / frame_size;
     if (per * frame_size > (2048ull << 20)) per = (2048ull << 20) / frame_size;
     if (per < 1) per = 1;
@@ -744,9 +745,7 @@ int zk_host_encode(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_
         uint64_t f0, nf, b0, bn; chunk_range(i, f0, nf, b0, bn);
         zk_hostpipe::ESlot &s = hp->es[i & 1];
         int r;
-        if ((r = zk_devbuf_reserve(e, s.d_src, (size_t)bn + 64))) return r;
-        if ((r = zk_devbuf_reserve(e, s.d_dst, (size_t)zk_compress_bound(bn, frame_size) + 64))) return r;
-        if ((r = zk_devbuf_reserve(e, s.d_sizes, (size_t)nf * 8 + 64))) return r;
+        if ((r = zk_devbuf_reserve(e, s.d_src, (size_t)bn + 64))) return r;      // (d_dst / d_sizes of the slot may still be on their way down: enqueue() sizes them)
         if (src_pinned) { if (bn) ZK_HIP(hipMemcpyAsync(s.d_src.p, src + b0, bn, hipMemcpyHostToDevice, hp->s_h2d)); }
         else if (small) { memcpy(hp->pin_small, src + b0, (size_t)bn); if (bn) ZK_HIP(hipMemcpyAsync(s.d_src.p, hp->pin_small, bn, hipMemcpyHostToDevice, hp->s_h2d)); }
         else for (uint64_t at = 0; at < bn;) {
@@ -771,6 +770,9 @@ int zk_host_encode(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_
     auto enqueue = [&](size_t i) -> int {
         uint64_t f0, nf, b0, bn; chunk_range(i, f0, nf, b0, bn);
         zk_hostpipe::ESlot &s = hp->es[i & 1];
+        int r0;
+        if ((r0 = zk_devbuf_reserve(e, s.d_dst, (size_t)zk_compress_bound(bn, frame_size) + 64))) return r0;      // the chunk two back has been handed to the sink by now
+        if ((r0 = zk_devbuf_reserve(e, s.d_sizes, (size_t)nf * 8 + 64))) return r0;
         ZK_HIP(hipStreamWaitEvent(st, s.ev_in, 0));
         if (s.out_pending) ZK_HIP(hipStreamWaitEvent(st, s.ev_out, 0));       // the chunk two back has left d_dst
         uint32_t *dc = (uint32_t *)s.d_sizes.p, *dd = dc + nf;
@@ -794,6 +796,9 @@ int zk_host_encode(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_
         if (nchunks == 1) zk_profile_collect(e);
         int r = 0;
         if (more && (r = enqueue(i + 1))) return r;          // the GPU goes on with the next chunk while this one travels
+        // ... and the chunk after it starts its way up now: its source slot is the one this chunk's kernels have just left
+        // (issued behind this chunk's download and sink, its upload used to arrive after the GPU had run dry)
+        if (i + 2 < nchunks && (r = prep(i + 2))) return r;
         uint32_t *sizes = (uint32_t *)hp->pin_meta + (i & 1) * (size_t)per * 2;
         ZK_HIP(hipMemcpyAsync(sizes, s.d_sizes.p, (size_t)nf * 8, hipMemcpyDeviceToHost, hp->s_d2h));
         if (small) {
@@ -832,10 +837,8 @@ int zk_host_encode(zk_engine *e, const uint8_t *src, uint64_t n, uint32_t frame_
 
     int fail = prep(0);
     if (!fail) fail = enqueue(0);
-    for (size_t i = 0; i < nchunks && !fail; i++) {
-        if (i + 1 < nchunks && (fail = prep(i + 1))) break;  // upload of the next chunk runs beside this chunk's kernels
-        fail = finish(i, i + 1 < nchunks);
-    }
+    if (!fail && nchunks > 1) fail = prep(1);                // upload of the next chunk runs beside this chunk's kernels
+    for (size_t i = 0; i < nchunks && !fail; i++) fail = finish(i, i + 1 < nchunks);
     (void)hipStreamSynchronize(hp->s_h2d); (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(hp->s_d2h);
     wsrc.finish();
     for (auto &s : hp->es) s.out_pending = false;
