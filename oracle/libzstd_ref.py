@@ -88,7 +88,7 @@ def _chk(l, r):
 
 
 def encode_seekable_frames(data: bytes, frame_size: int, level: int = 1, checksum: bool = False,
-                           which: str = "system", prefix: bytes = None, window_log: int = 0):
+                           which: str = "system", prefix: bytes = None, window_log: int = 0, ldm: bool = False):
     """Reference Encoder loop (Uncompressed(frame_size) policy). Returns (payload bytes, [(c,d)...]).
 
     An empty input yields one empty frame (Encoder::finish always calls end_frame, encode.rs:755-757).
@@ -100,6 +100,8 @@ def encode_seekable_frames(data: bytes, frame_size: int, level: int = 1, checksu
     _chk(l, l.ZSTD_CCtx_setParameter(cctx, 201, int(checksum)))
     if window_log:
         _chk(l, l.ZSTD_CCtx_setParameter(cctx, 101, window_log))
+    if ldm:
+        _chk(l, l.ZSTD_CCtx_setParameter(cctx, 160, 1))             # ZSTD_c_enableLongDistanceMatching (cli/src/compress.rs:35-36)
     pbuf = C.create_string_buffer(bytes(prefix), len(prefix)) if prefix else None
     data = bytes(data)
     src = C.create_string_buffer(data, len(data)) if data else C.create_string_buffer(1)

@@ -355,7 +355,12 @@ static size_t encode_literals(const u8 *lit, size_t n, u8 *dst, size_t cap)
 #define ZKE_TILE 256u
 #define ZKE_GROUP 16u               /* tiles per group (one wave each on the GPU) */
 #define ZKE_GROUP_POS (ZKE_TILE * ZKE_GROUP)
-typedef struct { u16 table[1 << ZKE_HASH_LOG_MAX]; u32 t32[1 << 14]; u32 probe, stepno, bias; } enc_state;
+typedef struct {
+    u16 table[1 << ZKE_HASH_LOG_MAX]; u32 t32[1 << 14]; u32 probe, stepno, bias;
+    /* long-distance candidates into a prefix (patch mode; zk_enc_device.h "LDM") */
+    const u8 *pfx; u64 plen; u32 *ldm; u32 ldm_log; u64 ldm_u0;             /* the whole prefix, table over prefix[u0, plen) */
+    u64 abs0;                                                               /* stream coordinate of record position 0 (prefix byte i = i, frame byte x = plen + x) */
+} enc_state;
 static u32 g_lazy = 0;              /* zke_lazy(level) */
 /* Two forms of the table (zk_enc_match.h).  16-bit entries as described above: 2^15 of them are what fits beside the ring
  * at level >= 2.  At level <= 1 the 2^14 entries are 32 bits wide: (0xFFFF - step number) << 16 | position mod 2^16, the
@@ -380,6 +385,61 @@ static u32 match_len(const u8 *a, const u8 *b, const u8 *end)        /* b > a */
     while (b + 8 <= end) { u64 x = ld64(a) ^ ld64(b); if (x) return (u32)(b - s) + (u32)(__builtin_ctzll(x) >> 3); a += 8; b += 8; }
     while (b < end && *a == *b) { a++; b++; }
     return (u32)(b - s);
+}
+
+/* ---- long-distance matches into a prefix (cli/src/compress.rs:31-37: patch mode sets a window over the reference file and
+ * enables libzstd's long-distance matcher).  The ring of the GPU matcher reaches 57 280 bytes back; a prefix longer than that
+ * gets a coarse hash table over ALL of it: positions whose 8-byte hash has its top 6 bits clear (1 in 64, content-defined, so
+ * the old and the new file sample the same places) enter a table of first occurrences.  Every sampled position of the frame
+ * looks its slot up and compares 16 bytes against the prefix; a hit of >= 8 bytes is one more candidate with the offset
+ * "position + distance to the prefix byte".  Once such a match is taken its offset is the previous offset R of the next
+ * group: R beyond the ring is compared through memory instead, at every position, so an unchanged region costs one
+ * repeat-offset sequence per 256-byte tile.  Offsets are limited to 2^27 - 1 (the field best[] has for them). */
+#define ZKE_SEAM 32768u
+#define ZKE_LDM_MIN 16u
+#define ZKE_LDM_MAX_OFF ((1u << 27) - 1)
+static inline u32 ldm_hash(const u8 *p)
+{
+    u32 w[4]; memcpy(w, p, 16);
+    return ((w[0] * 0x9E3779B1u) ^ (w[1] * 0x85EBCA77u)) + ((w[2] * 0xC2B2AE3Du) ^ (w[3] * 0x27D4EB2Fu));
+}
+static inline int ldm_selected(u32 h) { return (h >> 26) == 0; }
+static u32 ldm_log_for(u64 usable) { u32 l = 10; while (l < 22 && (1ull << l) < usable / 32) l++; return l; }
+/* the table covers the last ZKE_LDM_MAX_OFF bytes of the prefix (all of a shorter one), whatever the frame's size: one
+ * table serves every frame of a stream; a position too far back for the offset field is turned down at the lookup */
+static void ldm_build(enc_state *st, const u8 *prefix, u64 plen)
+{
+    st->ldm = NULL; st->pfx = prefix; st->plen = plen;
+    if (plen <= ZKE_WINDOW) return;
+    const u64 usable = plen < ZKE_LDM_MAX_OFF ? plen : ZKE_LDM_MAX_OFF;
+    st->ldm_u0 = plen - usable; st->ldm_log = ldm_log_for(usable);
+    st->ldm = malloc(sizeof(u32) << st->ldm_log);
+    memset(st->ldm, 0xFF, sizeof(u32) << st->ldm_log);
+    for (u64 q = st->ldm_u0; q + ZKE_LDM_MIN <= plen; q++) {
+        const u32 h = ldm_hash(prefix + q);
+        if (!ldm_selected(h)) continue;
+        u32 *slot = &st->ldm[(h >> 2) & ((1u << st->ldm_log) - 1)];
+        if ((u32)(q - st->ldm_u0) < *slot) *slot = (u32)(q - st->ldm_u0);         /* the first occurrence keeps the slot */
+    }
+}
+
+/* the prefix position a sampled position p (stream coordinate ap) finds in the table, if at least ZKE_LDM_MIN of the fcap bytes agree; ~0: none */
+static u64 ldm_lookup(const enc_state *st, const u8 *p, u64 ap, u32 fcap)
+{
+    const u32 h = ldm_hash(p);
+    if (!ldm_selected(h)) return ~0ull;
+    const u32 e = st->ldm[(h >> 2) & ((1u << st->ldm_log) - 1)];
+    const u64 q = st->ldm_u0 + e;
+    if (e == 0xFFFFFFFFu || q + 16 > st->plen || ap - q > ZKE_LDM_MAX_OFF) return ~0ull;
+    return match_len(st->pfx + q, p, p + fcap) >= ZKE_LDM_MIN ? q : ~0ull;
+}
+
+/* a long-distance offset is compared at position p while the 20 bytes that p's aligned group of four positions reads at that
+ * distance lie inside the table's part of the prefix (the GPU lane loads them as five words, once for its four positions) */
+static int far_ok(const enc_state *st, u32 p, u32 off)
+{
+    const u64 a4 = st->abs0 + (p & ~3u);
+    return a4 >= st->ldm_u0 + off && a4 - off + 20 <= st->plen;
 }
 
 /* history positions [0, hist) enter an empty table, the largest position wins a slot */
@@ -409,6 +469,16 @@ static u32 find_sequences(enc_state *st, const u8 *base, u32 bs, u32 be, u32 fen
     for (u32 gs = bs; gs < be; gs += ZKE_GROUP_POS) {
         const u32 ge = gs + ZKE_GROUP_POS < be ? gs + ZKE_GROUP_POS : be;
         const u32 R = st->probe;
+        u32 tfar[ZKE_GROUP];                                                             /* per tile: the offset of its first long-distance hit */
+        for (u32 t = 0; t < ZKE_GROUP; t++) {
+            tfar[t] = 0;
+            const u32 ts = gs + t * T, te = ts + T < be ? ts + T : be;
+            if (st->ldm) for (u32 p = ts; p < te && !tfar[t]; p++) if (p + ZKE_LDM_MIN <= fend) {
+                const u32 fcap = te - p < 16 ? te - p : 16;
+                const u64 q = ldm_lookup(st, base + p, st->abs0 + p, fcap);
+                if (q != ~0ull) tfar[t] = (u32)(st->abs0 + p - q);
+            }
+        }
         for (u32 ls = gs; ls < ge; ls += g_step) {
             const u32 le = ls + g_step < ge ? ls + g_step : ge;
             const u32 khi = (0xFFFFu - st->stepno) << 16;
@@ -441,8 +511,25 @@ static u32 find_sequences(enc_state *st, const u8 *base, u32 bs, u32 be, u32 fen
                     else { d = (p - st->table[hashx(base + p)]) & 0xFFFFu; near_ok = d && d <= p - ls; }
                     if (near_ok) { const u32 l = match_len(base + p - d, base + p, cap); if (l >= g_minmatch && l >= bl) { bl = l; bo = d; } }
                 }
+                const u64 ap = st->abs0 + p;                                              /* my stream coordinate */
+                const u32 ncap = (u32)(cap - (base + p)), fcap = ncap < 16 ? ncap : 16;
+                /* long-distance candidates out of the prefix: the position's own table entry, and the offset of the tile's first
+                 * hit (positions in front of a sampled one, and the tiles of a group behind a change, find the copy that way) */
+                if (st->ldm && p + 8 <= fend) {
+                    const u64 q = p + ZKE_LDM_MIN <= fend ? ldm_lookup(st, base + p, ap, fcap) : ~0ull;
+                    if (q != ~0ull) { const u32 l = match_len(st->pfx + q, base + p, base + p + fcap); if (l > bl || l == ZKE_PARCAP) { bl = l; bo = (u32)(ap - q); } }
+                    const u32 R2 = tfar[(p - gs) / T];
+                    if (R2 && R2 != R && far_ok(st, p, R2)) {
+                        const u32 l = match_len(st->pfx + (ap - R2), base + p, base + p + fcap);
+                        if (l >= ZKE_LDM_MIN && (l > bl || l == ZKE_PARCAP)) { bl = l; bo = R2; }
+                    }
+                }
                 if (p >= 1) { const u32 l = match_len(base + p - 1, base + p, cap); if (l >= 4 && l >= bl) { bl = l; bo = 1; } }
-                if (R > 1 && R <= p) { const u32 l = match_len(base + p - R, base + p, cap); if (l >= 4 && l >= bl) { bl = l; bo = R; } }
+                if (R > 1 && R <= ZKE_WINDOW) { if (R <= p) { const u32 l = match_len(base + p - R, base + p, cap); if (l >= 4 && l >= bl) { bl = l; bo = R; } } }
+                else if (R > ZKE_WINDOW && far_ok(st, p, R)) {        /* a previous offset beyond the ring: through memory */
+                    const u32 l = match_len(st->pfx + (ap - R), base + p, base + p + fcap);
+                    if (l >= 4 && l >= bl) { bl = l; bo = R; }
+                }
                 blen[p - gs] = bl; boff[p - gs] = bo;
             }
         }
@@ -458,12 +545,25 @@ static u32 find_sequences(enc_state *st, const u8 *base, u32 bs, u32 be, u32 fen
                 }
                 if (len) {
                     const u32 off = boff[p - gs];
-                    if (len == ZKE_PARCAP) len += match_len(base + p + len - off, base + p + len, lim);
+                    if (len == ZKE_PARCAP) {
+                        if (off <= ZKE_WINDOW) len += match_len(base + p + len - off, base + p + len, lim);
+                        else {                                                            /* byte by byte through memory; stops where the source leaves the prefix */
+                            const u64 a0 = st->abs0 + p - off;
+                            while (base + p + len < lim && a0 + len < st->plen && st->pfx[a0 + len] == base[p + len]) len++;
+                        }
+                    }
                     const u32 ll = p - anchor;
-                    memcpy(lits + nlit, base + anchor, ll); nlit += ll;
-                    sq[nseq].ll = ll; sq[nseq].ml = len;
-                    sq[nseq].offbase = (ll && off == prev_off) ? 1 : off + 3;
-                    nseq++;
+                    if (p == ts && ll == 0 && off == prev_off && ((ts - bs) & (ZKE_SEAM - 1))) {
+                        /* the tile before ended in a match with this offset: one sequence goes on across the seam (a tile's
+                         * matches stop at its end; without this a long copy costs a sequence per 256 bytes).  No joining at
+                         * multiples of ZKE_SEAM inside the block: a match length stays below 2^16. */
+                        sq[nseq - 1].ml += len;
+                    } else {
+                        memcpy(lits + nlit, base + anchor, ll); nlit += ll;
+                        sq[nseq].ll = ll; sq[nseq].ml = len;
+                        sq[nseq].offbase = (ll && off == prev_off) ? 1 : off + 3;
+                        nseq++;
+                    }
                     prev_off = off; st->probe = off;
                     p += len; anchor = p;
                 } else p++;
@@ -497,8 +597,8 @@ static u32 block_max_of(size_t n, u32 hist)
     return t < bmax ? t : bmax;
 }
 
-/* TEST SUPPORT: the matcher's result for one frame, block by block, in the GPU kernel's packing (ll | ml << 20 |
- * Offset_Value << 40), so that tests/sim (the kernel under a CPU emulator) and the GPU can be compared with it directly.
+/* TEST SUPPORT: the matcher's result for one frame, block by block, in the GPU kernel's packing (ll | ml << 16 |
+ * Offset_Value << 32), so that tests/sim (the kernel under a CPU emulator) and the GPU can be compared with it directly.
  * seqs / lits are filled contiguously; returns the number of blocks (or -1: blk_cap too small). */
 i64 zko_enc_match_debug(const u8 *src, size_t n, int level, const u8 *prefix, size_t plen, u32 blk_cap, u32 *blk_nseq, u32 *blk_nlit, u64 *seqs, u8 *lits)
 {
@@ -517,6 +617,8 @@ i64 zko_enc_match_debug(const u8 *src, size_t n, int level, const u8 *prefix, si
     const u8 *sbase = cat;
     u32 shist = hist, sstart = 0, send = n < ZKE_SEGMENT ? (u32)n : ZKE_SEGMENT;
     table_seed(st, sbase, shist, shist + send);
+    if (prefix) ldm_build(st, prefix, plen);
+    st->abs0 = plen + sstart - shist;
     u64 ns = 0, nl = 0;
     for (u32 k = 0, bs = 0; bs < n; bs += bmax, k++) {
         const u32 be = bs + bmax < n ? bs + bmax : (u32)n;
@@ -524,13 +626,14 @@ i64 zko_enc_match_debug(const u8 *src, size_t n, int level, const u8 *prefix, si
             sstart = bs; send = (u64)bs + ZKE_SEGMENT < n ? bs + ZKE_SEGMENT : (u32)n;
             shist = ZKE_WINDOW; sbase = cat + hist + sstart - shist;
             table_seed(st, sbase, shist, shist + (send - sstart));
+            st->abs0 = plen + sstart - shist;
         }
         u32 nlit = 0;
         const u32 nseq = find_sequences(st, sbase, shist + (bs - sstart), shist + (be - sstart), shist + (send - sstart), sq, lits + nl, &nlit);
-        for (u32 i = 0; i < nseq; i++) seqs[ns + i] = (u64)sq[i].ll | ((u64)sq[i].ml << 20) | ((u64)sq[i].offbase << 40);
+        for (u32 i = 0; i < nseq; i++) seqs[ns + i] = (u64)sq[i].ll | ((u64)sq[i].ml << 16) | ((u64)sq[i].offbase << 32);
         blk_nseq[k] = nseq; blk_nlit[k] = nlit; ns += nseq; nl += nlit;
     }
-    free(st); free(cat); free(sq);
+    free(st->ldm); free(st); free(cat); free(sq);
     return nblk;
 }
 
@@ -565,6 +668,10 @@ i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int le
     /* Window_Descriptor: smallest power of two >= min(n, 64 KiB reach) but at least 1 KiB; blocks need window >= block size */
     u32 wlog = 10; while ((1u << wlog) < n && wlog < 17) wlog++;     /* <= 128 KiB: offsets never exceed 65535 */
     if (hist) wlog = 17;
+    /* long-distance matches reach anywhere into the prefix: the window covers prefix + frame, as the reference's patch mode sets
+     * it (cli/src/compress.rs:31-37: WindowLog(ilog2(prefix_len) + 1)) -- libzstd's streaming decoder keeps a prefix reachable
+     * only while the frame fits its window */
+    if (hist && plen > ZKE_WINDOW) while ((1ull << wlog) < plen + n && wlog < 27) wlog++;          /* long-distance offsets stay below 2^27 */
     dst[5] = (u8)((wlog - 10) << 3);
     p = 6;
     enc_state *st = calloc(1, sizeof *st);
@@ -576,6 +683,8 @@ i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int le
         msrc = cat;
     }
     table_seed(st, msrc, hist, (u32)(hist + n < ZKE_SEGMENT + hist ? hist + n : ZKE_SEGMENT + hist));
+    if (prefix) ldm_build(st, prefix, plen);
+    st->abs0 = plen - hist;
     i64 rc = 0;
     u32 bmax = (1u << wlog) < ZKE_BLOCK ? (1u << wlog) : ZKE_BLOCK;
     /* blocks are cut smaller than the format's maximum on purpose: a block's sequence bitstream is one serial chain
@@ -601,6 +710,7 @@ i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int le
             shist = ZKE_WINDOW;
             sbase = msrc + hist + sstart - shist;
             table_seed(st, sbase, shist, shist + (send - sstart));
+            st->abs0 = plen + sstart - shist;
         }
         bseq[k] = nseq_frame; blit[k] = nlit_frame;
         u32 nseq = find_sequences(st, sbase, shist + (bs - sstart), shist + (be - sstart), shist + (send - sstart), sq + nseq_frame, lits + nlit_frame, &nlit);
@@ -653,6 +763,6 @@ i64 zko_frame_encode_prefix(const u8 *src, size_t n, u8 *dst, size_t cap, int le
     }
     free(ft); free(bseq); free(blit); free(bnlit);
     if (rc == 0 && checksum) { if (p + 4 > cap) rc = -70; else { u32 h = (u32)zko_xxh64(src, n, 0); memcpy(dst + p, &h, 4); p += 4; } }
-    free(st); free(sq); free(lits); free(body); free(cat);
+    free(st->ldm); free(st); free(sq); free(lits); free(body); free(cat);
     return rc ? rc : (i64)p;
 }

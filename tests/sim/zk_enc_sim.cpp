@@ -21,7 +21,7 @@ extern "C" int zk_enc_sim_match(const uint8_t *src, uint64_t n, uint32_t frame_s
     if (pl.nb > blk_cap) return -1;
     std::vector<ZkEncFrame> frames(pl.nf), segs(pl.nseg + 1);
     std::vector<ZkEncBlock> blocks(pl.nb + 1);
-    zke_plan_fill(n, frame_size, level, &pl, frames.data(), blocks.data(), segs.data(), nullptr);
+    zke_plan_fill(n, frame_size, level, prefix ? prefix_len : 0, &pl, frames.data(), blocks.data(), segs.data(), nullptr);
     if (pl.seq_total > seq_cap || n > lit_cap) return -1;
     // the matcher's source: the frames in place, or [prefix tail | frame] records (zk_k_enc_stage_hist)
     std::vector<uint8_t> stage;
@@ -34,11 +34,36 @@ extern "C" int zk_enc_sim_match(const uint8_t *src, uint64_t n, uint32_t frame_s
         }
         msrc = stage.data();
     }
+    // long-distance table over the prefix (the engine builds it with zk_k_enc_ldm_build; here sequentially, same rule)
+    ZkEncLdm ldm = {nullptr, nullptr, 0, 0, 0, 0};
+    std::vector<uint32_t> table;
+    std::vector<uint8_t> pcopy;
+    if (prefix && prefix_len > ZKE_WINDOW) {
+        const uint64_t usable = zke_ldm_usable(prefix_len);
+        ldm.plen = prefix_len; ldm.u0 = prefix_len - usable; ldm.log = zke_ldm_log(usable);
+        pcopy.assign(16 + usable + ZKE_LDM_SLACK, 0);                 // what the engine keeps on the device: slack | prefix[u0, plen) | slack
+        memcpy(pcopy.data() + 16, prefix + ldm.u0, usable);
+        ldm.pfx = pcopy.data() + 16 - ldm.u0;
+        table.assign((size_t)1 << ldm.log, ZKE_LDM_NONE);
+        for (uint64_t i = 0; i + ZKE_LDM_MIN <= usable; i++) {
+            uint32_t w[4]; memcpy(w, pcopy.data() + 16 + i, 16);
+            const uint32_t h = zke_ldm_hash(w[0], w[1], w[2], w[3]);
+            if (!zke_ldm_selected(h)) continue;
+            uint32_t &slot = table[zke_ldm_slot(h, ldm.log)];
+            if ((uint32_t)i < slot) slot = (uint32_t)i;
+        }
+        ldm.table = table.data();
+    }
     for (uint32_t s = 0; s < pl.nseg; s++) {
         auto run = [&]() {
-            if (zke_fast(level)) zk_k_enc_match<14, 0, 4096>(msrc, segs.data(), blocks.data(), seqs, lits);
-            else if (zke_step(level) == 1024) zk_k_enc_match<15, 1, 1024>(msrc, segs.data(), blocks.data(), seqs, lits);
-            else zk_k_enc_match<15, 1, 4096>(msrc, segs.data(), blocks.data(), seqs, lits);
+            if (ldm.table) {
+                if (zke_fast(level)) zk_k_enc_match<14, 0, 4096, true>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
+                else if (zke_step(level) == 1024) zk_k_enc_match<15, 1, 1024, true>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
+                else zk_k_enc_match<15, 1, 4096, true>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
+            }
+            else if (zke_fast(level)) zk_k_enc_match<14, 0, 4096, false>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
+            else if (zke_step(level) == 1024) zk_k_enc_match<15, 1, 1024, false>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
+            else zk_k_enc_match<15, 1, 4096, false>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
         };
         emu_run_workgroup(ZKE_THREADS, s, run);
     }

@@ -203,16 +203,73 @@ def test_both_sequence_kernels_on_every_golden(engine, mode):
 
 @pytest.mark.skipif(Z.load("system") is None, reason="no system libzstd on this box")
 def test_baseline_config_2_decode_only(engine):
-    """BASELINE.json configs[1] at reduced size (32 MiB of the 256 MiB): 2 MiB frames, level 1, decode-only,
-    bit-exact vs the generator bytes; per-frame XXH64 KATs of SURVEY 8(d) as a size-independent check."""
-    n = 32 << 20
+    """BASELINE.json configs[1] as written: 256 MiB of the 8d text, 128 x 2 MiB frames written by the CPU reference path (the
+    Encoder loop over the box's libzstd, level 1), decode-only on the GPU, bit-exact against the generator bytes (full memcmp)
+    and the per-frame XXH64 KATs of SURVEY 8(d)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = 256 << 20
     data = zko.gen_chunks(n)
-    comp, frames = Z.encode_seekable_frames(data, 2 << 20, 1, False, "system")
+
+    def part(k):                                            # 8 host threads, 32 MiB = 16 frames each (ctypes releases the GIL)
+        return Z.encode_seekable_frames(data[k << 25:(k + 1) << 25], 2 << 20, 1, False, "system")
+    with ThreadPoolExecutor(8) as ex:
+        parts = list(ex.map(part, range(8)))
+    comp = b"".join(p[0] for p in parts)
+    frames = [f for p in parts for f in p[1]]
+    assert len(frames) == 128
     c, d = offsets_from_frames(frames)
     out, st = engine.decode_frames(comp + b"\0" * 8, c, d)
-    assert out == data
+    assert not st.any() and out == data
     h = engine.xxh64_frames(out, d)
     assert int(h[0]) == 0xAD0311EAAD1ED582 and int(h[1]) == 0x8CC2C9BC11FFCCA2
+
+
+def test_baseline_config_1_input_through_the_handles(engine):
+    """BASELINE.json configs[0] on the GPU: the stand-in for assets/dickens.txt (gen(10 192 446 bytes)) at level 1 and
+    the default 2 MiB frames -- 4 full frames + 1 803 838 bytes -- through RawEncoder (lib/benches/compress.rs:8-39), Encoder
+    (:41-62) and Decoder with reset (decompress.rs:18-39); the three archives round-trip bit-exact, and the box's libzstd reads them."""
+    from zeekstd_amd import DecodeOptions, EncodeOptions
+    n = 10192446
+    data = zko.gen_chunks(n)
+    enc = EncodeOptions().engine(engine).compression_level(1).into_raw_encoder()
+    out, arch, pos = bytearray(131591), bytearray(), 0
+    mv = memoryview(data)
+    while pos < n:
+        p = enc.compress(mv[pos:pos + (1 << 20)], out)
+        arch += out[:p.out_progress()]
+        pos += p.in_progress()
+    while True:
+        p = enc.end_frame(out)
+        arch += out[:p.out_progress()]
+        if p.data_left() == 0:
+            break
+    st = enc.into_seek_table()
+    assert [st.frame_size_decomp(i) for i in range(st.num_frames())] == [2 << 20] * 4 + [1803838]
+    assert st.size_comp() == len(arch) and 2.4 < n / len(arch) < 2.6
+
+    class Sink:
+        def __init__(self): self.b = bytearray()
+        def write(self, x): self.b += x; return len(x)
+    sink = Sink()
+    e2 = EncodeOptions().engine(engine).compression_level(1).into_encoder(sink)
+    e2.write_all(data)
+    e2.end_frame()
+    total = e2.finish()
+    assert total == len(sink.b) and bytes(sink.b[:len(arch)]) == bytes(arch)       # the same five frames, then (end_frame + finish) an empty one + the table
+    dec = DecodeOptions(bytes(sink.b)).engine(engine).into_decoder()
+    assert dec.seek_table().num_frames() == 6
+    buf, got = bytearray(131072), bytearray()
+    for rep in range(2):                                    # decompress to the end, reset, again (decompress.rs:35-39)
+        got.clear()
+        while True:
+            k = dec.decompress(buf)
+            if k == 0:
+                break
+            got += buf[:k]
+        assert bytes(got) == data
+        dec.reset()
+    if Z.load("system") is not None:
+        assert Z.decode_stream(bytes(arch), n, "system") == data
 
 
 @pytest.mark.parametrize("fs", [65536, 300000, 1 << 20])

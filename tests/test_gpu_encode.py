@@ -226,6 +226,57 @@ def test_encode_with_prefix_roundtrip_and_twin(engine, name, checksum):
     assert not st.any() and out == data
 
 
+def _edited(old, seed, n_edits):
+    """old with n_edits changes (replacements, insertions, deletions of about a KiB): the "new version" of a patch"""
+    rng = np.random.default_rng(seed)
+    pos = sorted(int(x) for x in rng.integers(0, len(old) - 4096, n_edits))
+    out, last = bytearray(), 0
+    for i, p in enumerate(pos):
+        if p < last:
+            continue
+        out += old[last:p]
+        if i % 3 == 0:
+            out += zko.gen_text(1000, 900 + i); last = p + 1000
+        elif i % 3 == 1:
+            out += zko.gen_text(700, 900 + i); last = p
+        else:
+            last = p + 900
+    out += old[last:]
+    return bytes(out)
+
+
+@pytest.mark.parametrize("level", [1, 3])
+@pytest.mark.parametrize("kind", ["text", "chunks"])
+def test_patch_encode_reaches_the_whole_prefix(engine, level, kind):
+    """the reference's --patch-from turns on libzstd's long-distance matcher and a window over the whole old
+    file (cli/src/compress.rs:31-37).  The matcher's ring reaches 57 280 bytes; beyond it a prefix is reached through the
+    long-distance table (zk_enc_device.h ZkEncLdm).  An 8 MiB file with 80 edits against its old version: the patch is
+    byte-identical to the CPU twin's, decodes with the oracle, libzstd and the GPU decoder, is a small fraction of the plain
+    encode, and within 2.2x of what libzstd makes of it with its long-distance matcher."""
+    old = zko.gen_text(8 << 20, 50) if kind == "text" else zko.gen_chunks(8 << 20, 50)
+    new = _edited(old, 3, 80)
+    fs = 2 << 20
+    comp, frames = engine.encode_frames(new, fs, level, True, prefix=old)
+    plain, _ = engine.encode_frames(new, fs, level, True)
+    assert len(comp) * 20 < len(plain)
+    pos = dpos = 0
+    for c, d in frames:
+        f = comp[pos:pos + c]
+        assert f == zko.frame_encode(new[dpos:dpos + d], level, True, prefix=old), dpos
+        out, used = zko.frame_decode(f, d, True, prefix=old)
+        assert used == c and out == new[dpos:dpos + d]
+        pos += c; dpos += d
+    for which in ("system", "1.5.7"):
+        if Z.load(which) is not None:
+            assert Z.decode_stream(comp, len(new), which, prefix=old) == new
+    c_off, d_off = offsets_from_frames(frames)
+    out, st = engine.decode_frames(comp + b"\0" * 8, c_off, d_off, verify=True, prefix=old)
+    assert not st.any() and out == new
+    if Z.load("1.5.7") is not None:
+        ref, _ = Z.encode_seekable_frames(new, fs, 3, True, "1.5.7", prefix=old, window_log=len(old).bit_length(), ldm=True)
+        assert len(comp) <= 2.2 * len(ref), (len(comp), len(ref))
+
+
 @pytest.mark.parametrize("level", [1, 3])
 @pytest.mark.parametrize("with_prefix", [False, True])
 def test_frames_above_the_matcher_segment(engine, level, with_prefix):

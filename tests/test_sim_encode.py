@@ -22,7 +22,7 @@ def _compare(data, frame_size, level, prefix=None):
         assert bad.size == 0, (b, int(bad[0]), hex(int(gs[bad[0]])), hex(int(ws[bad[0]])))
         assert gl == wl, b
         # the sequences + literals reproduce the block size
-        assert sum(int(x) & 0xFFFFF for x in gs) + sum((int(x) >> 20) & 0xFFFFF for x in gs) + (len(gl) - sum(int(x) & 0xFFFFF for x in gs)) == bsz
+        assert sum((int(x) >> 16) & 0xFFFF for x in gs) + len(gl) == bsz                     # match bytes + literals = the block
 
 
 CASES = {
@@ -59,3 +59,34 @@ def test_sim_match_prefix():
     data = prefix[1000:30000] + zko.make_input([["text", 9000, 42]])
     _compare(data, 1 << 21, 1, prefix)
     _compare(data[:5000], 1 << 21, 3, prefix[:1003])
+
+
+def _edited(old, seed, n_edits):
+    """old with n_edits changes: replacements, insertions, deletions of up to a KiB"""
+    rng = np.random.default_rng(seed)
+    pos = sorted(int(x) for x in rng.integers(0, len(old) - 2048, n_edits))
+    out, last = bytearray(), 0
+    for i, p in enumerate(pos):
+        if p < last:
+            continue
+        out += old[last:p]
+        if i % 3 == 0:
+            out += zko.gen_text(300 + 40 * i, 900 + i); last = p + 300 + 40 * i
+        elif i % 3 == 1:
+            out += zko.gen_text(100 + 30 * i, 900 + i); last = p
+        else:
+            last = p + 150 + 20 * i
+    out += old[last:]
+    return bytes(out)
+
+
+@pytest.mark.parametrize("level", [1, 3, 6])
+def test_sim_match_long_distance(level):
+    """patch mode: a prefix beyond the ring's reach is found through the long-distance table (sampled positions, the tile's
+    first hit as an offset for the whole tile, previous offsets compared through memory, joined across tiles)"""
+    old = zko.make_input([["text", 200000, 51], ["random", 30000, 52], ["text", 170000, 53]])
+    new = _edited(old, 7, 12)
+    _compare(new, 1 << 21, level, old)                 # one frame, two segments
+    if level == 1:
+        _compare(new, 150000, level, old)              # three frames against the same prefix
+        _compare(new[:70000], 1 << 21, level, old[:57284])      # a prefix four bytes beyond the ring's reach

@@ -229,7 +229,7 @@ void Encoder::encode_span(const uint8_t *src, size_t take)
 {
     const uint32_t fs = std::min(MAX_FRAME_SIZE, raw_.policy_.size);
     const void *d_prefix = nullptr;
-    const uint64_t tail = batch_prefix_ ? std::min<uint64_t>(batch_prefix_len_, ZKE_WINDOW) : 0;    // what the matcher can reach
+    const uint64_t tail = batch_prefix_ ? zke_ldm_usable(batch_prefix_len_) : 0;    // what the matcher can reach (ring window + long-distance table)
     int rc = zk_engine_stage_prefix(raw_.engine_, this, tail ? batch_prefix_ + (batch_prefix_len_ - tail) : nullptr, tail, prefix_dirty_, &d_prefix);
     if (rc != 0) throw Error::from_engine_code(rc, zk_engine_last_hip_error(raw_.engine_));
     prefix_dirty_ = false;

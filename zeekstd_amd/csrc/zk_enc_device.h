@@ -32,6 +32,7 @@ constexpr uint32_t ZKE_WINDOW = ZKE_RING - 2 * ZKE_GROUP_POS - 64;   // 57280: t
 // look past its own end; a frame of up to ZKE_SEGMENT bytes is one segment.  (A multiple of the blocks every frame this
 // large is cut into: 16 KiB up to 512 KiB, 32 KiB above.)
 constexpr uint32_t ZKE_SEGMENT = 256u << 10;
+constexpr uint32_t ZKE_SEAM = 32768;                // sequences of neighbouring tiles are joined except across multiples of this inside a block (match lengths < 2^16)
 
 // Block size the encoder cuts a frame of d_size bytes into.  Blocks are cut smaller than the format's maximum on purpose:
 // a block's sequence bitstream is one serial chain for the decoder, so more, shorter blocks = more parallel chains
@@ -58,11 +59,36 @@ struct ZkEncFrame {
     uint32_t hist;              // bytes of history laid out before the frame in the matcher's source (prefix tail; 0 = none)
     uint64_t m_off;             // where that history starts in the matcher's source (== src_off when hist == 0)
     uint32_t minmatch;          // zke_minmatch(level)
-    uint32_t pad;
+    uint32_t seg_at;            // a segment record: where the segment starts inside its frame
+};
+
+// LONG-DISTANCE MATCHES INTO A PREFIX (patch mode, cli/src/compress.rs:31-37: the reference turns on libzstd's long-distance
+// matcher and a window that covers the whole prefix).  The ring reaches ZKE_WINDOW bytes back; a prefix longer than that is
+// reached through a table in HBM over its last ZKE_LDM_MAX_OFF bytes: the positions whose 16-byte hash has six leading zeros
+// (one in 64, chosen by content, so the same text is sampled at the same places in the old and the new file), first
+// occurrence per slot.  A sampled position of the frame whose 16 bytes equal the entry's is a hit; the hit's offset is tried
+// at every position of its tile, and as "previous offset" from then on -- compared through HBM (L2), not the ring.
+constexpr uint32_t ZKE_LDM_MIN = 16;
+constexpr uint32_t ZKE_LDM_MAX_OFF = (1u << 27) - 1;          // offsets fit the 27 bits of a best[] entry; Window_Descriptor <= 2^27
+constexpr uint32_t ZKE_LDM_NONE = 0xFFFFFFFFu;
+constexpr uint32_t ZKE_LDM_SLACK = 64;                        // readable bytes behind the prefix copy on the device
+ZK_HD uint32_t zke_ldm_hash(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+    return ((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA77u)) + ((w2 * 0xC2B2AE3Du) ^ (w3 * 0x27D4EB2Fu));
+}
+ZK_HD bool zke_ldm_selected(uint32_t h) { return (h >> 26) == 0; }
+ZK_HD uint32_t zke_ldm_slot(uint32_t h, uint32_t log) { return (h >> 2) & ((1u << log) - 1); }
+ZK_HD uint64_t zke_ldm_usable(uint64_t plen) { return plen < ZKE_LDM_MAX_OFF ? plen : ZKE_LDM_MAX_OFF; }
+ZK_HD uint32_t zke_ldm_log(uint64_t usable) { uint32_t l = 10; while (l < 22 && (1ull << l) < usable / 32) l++; return l; }
+struct ZkEncLdm {
+    const uint8_t *pfx;         // prefix byte q is pfx[q] for q in [u0, plen) (+ ZKE_LDM_SLACK readable bytes); nullptr: no long-distance matching
+    const uint32_t *table;      // 2^log entries: position - u0 of the first sampled occurrence, ZKE_LDM_NONE = empty
+    uint64_t plen, u0;
+    uint32_t log, pad;
 };
 
 struct ZkEncBlock {
-    uint64_t seq_base;          // packed sequences (ll | ml << 20 | Offset_Value << 40)
+    uint64_t seq_base;          // packed sequences (ll | ml << 16 | Offset_Value << 32)
     uint64_t lit_base;          // literal bytes
     uint64_t scratch_base;      // payload + bitstream temporaries
     uint32_t frame, bs, bsz;    // frame index, start inside the frame, size

@@ -11,7 +11,7 @@
 //                  per lane and group, a group ahead; position p sits at ring byte p mod 65536 (+ a 32-byte mirror of the
 //                  ring's start behind its end, so the 20 bytes at any position are one straight read)
 //   table  2^HLOG 16-bit entries = ring indices of earlier positions (32 / 64 KiB)
-//   best   16 KiB  per position of the group: length | offset << 8 of its best candidate; a tile's slice later holds the
+//   best   16 KiB  per position of the group: length (5 bits) | offset << 5 of its best candidate; a tile's slice later holds the
 //                  tile's literal bytes
 //   tseq   8.3 KiB per tile: its sequences
 // so a candidate comparison, a match extension and a literal gather are LDS reads, and HBM sees the input once and the
@@ -120,12 +120,24 @@ __device__ __forceinline__ uint32_t zke_src_dword(const uint8_t *base, uint32_t 
 __device__ __forceinline__ uint64_t zke_lowmask(uint32_t n) { return n >= 64 ? ~0ull : (1ull << n) - 1; }     // bits [0, n)
 // value of lane (l - d) of the row of 16 lanes; `fill` where the row has no such lane
 #define ZKE_ROW_SHR(v, d, fill) ((uint32_t)__builtin_amdgcn_update_dpp((int)(fill), (int)(v), 0x110 + (d), 0xF, 0xF, false))
+// value of lane (l + d) of the row
+#define ZKE_ROW_SHL(v, d, fill) ((uint32_t)__builtin_amdgcn_update_dpp((int)(fill), (int)(v), 0x100 + (d), 0xF, 0xF, false))
+
+// own[0..4] ^ the 20 bytes at prefix byte a (long-distance compare of a lane's four positions through HBM).  ok: the 20 bytes
+// lie inside the prefix; a lane without reads the prefix's last 20 bytes, its flag drops the result.
+__device__ __forceinline__ void zke_far_xor(const ZkEncLdm &ldm, int64_t a, bool ok, const uint32_t own[5], uint32_t x[5])
+{
+    const uint8_t *s = ldm.pfx + (ok ? a : (int64_t)ldm.plen - 20);
+#pragma unroll
+    for (int i = 0; i < 5; i++) { uint32_t v; memcpy(&v, s + 4 * i, 4); x[i] = own[i] ^ v; }
+}
 
 // HLOG: log2 of the table entries (<= 14: 32-bit entries, 15: 16-bit entries); LAZY: a longer match one (or a clearly longer
 // one two) positions later wins; STEP: positions per lookup step (4096 = the whole group at once, 1024 = four steps of 256
 // lanes each)
-template <int HLOG, int LAZY, int STEP>
-__global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src, const ZkEncFrame *segs, ZkEncBlock *blocks, uint64_t *seqs, uint8_t *lits)
+// LDM: long-distance candidates out of a prefix (zk_enc_device.h ZkEncLdm)
+template <int HLOG, int LAZY, int STEP, bool LDM>
+__global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src, const ZkEncFrame *segs, ZkEncBlock *blocks, uint64_t *seqs, uint8_t *lits, ZkEncLdm ldm)
 {
     static_assert(HLOG >= 10 && HLOG <= 15 && (STEP == 1024 || STEP == (int)ZKE_GROUP_POS), "parameters");
     constexpr bool T32 = HLOG <= 14;
@@ -135,13 +147,14 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
     __shared__ uint32_t table[TWORDS + 1];
     __shared__ uint32_t best[ZKE_GROUP_POS];
     __shared__ uint64_t tseq[ZKE_GROUP][ZKE_TSEQ_N];        // ll | ml << 12 in the low half, the offset in the high half
-    __shared__ uint32_t tsum[2][ZKE_GROUP], tlast[2][ZKE_GROUP];   // per tile (two groups deep): count | trailing literals << 8 | literal bytes << 20;  offset of its last sequence
+    __shared__ uint32_t tsum[2][ZKE_GROUP], tlast[2][ZKE_GROUP], tfirst[2][ZKE_GROUP], tfml[2][ZKE_GROUP];   // per tile (two groups deep): count | trailing literals << 8 | literal bytes << 20;  offset of its last sequence
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const ZkEncFrame fr = segs[blockIdx.x];
     const uint8_t *base = src + fr.m_off;
     const uint32_t hist = fr.hist, fend = hist + fr.d_size, minmatch = fr.minmatch, fend4 = (fend + 3) & ~3u;
     const uint64_t lane_lt = zke_lowmask(lane);
     const uint32_t bias = T32 ? (0u - hist) & (ZKE_GROUP_POS - 1) : 0u;
+    const uint64_t abs0 = LDM ? ldm.plen + fr.seg_at - hist : 0;      // record position p = byte abs0 + p of [prefix | frame]
 
     ZKE_CLK_BEGIN();
     // ---- segment start: empty table, history + the first group (+ lookahead) into the ring, history positions into the table
@@ -182,47 +195,84 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
     // of best[] / tseq[] again): what the stitch needs from the other waves -- their tile summaries -- is then two barriers
     // old, so neither the parse nor the stitch ends in a barrier of its own and a wave that is slow in one group's parse
     // catches up in the next group's lookups.
-    struct { bool valid; uint32_t gs, ge; ZkEncBlock *blk; uint64_t *sq; uint8_t *lt; bool last; } todo = {false, 0, 0, nullptr, nullptr, nullptr, false};
+    struct { bool valid; uint32_t gs, ge, rel; ZkEncBlock *blk; uint64_t *sq; uint8_t *lt; bool last; } todo = {false, 0, 0, 0, nullptr, nullptr, nullptr, false};
+    // A sequence whose match ends exactly where its group ends may go on in the next group (see "seams" below): the lane that
+    // owns it keeps it back until the stitch that knows
+    bool held = false; uint64_t held_e = 0; uint64_t *held_at = nullptr;
     auto stitch = [&]() {
         const uint32_t ntiles = (todo.ge - todo.gs + ZKE_TILE - 1) / ZKE_TILE;
-        const uint32_t *ts_ = tsum[par ^ 1], *tl_ = tlast[par ^ 1];
-        uint32_t my_base, my_lit, my_pend, my_poff, my_cnt, my_nl;
+        const uint32_t *ts_ = tsum[par ^ 1], *tl_ = tlast[par ^ 1], *tf_ = tfirst[par ^ 1];
+        uint32_t my_base, my_lit, my_pend, my_poff, my_cnt, my_nl, my_join, my_more, me;
+        bool my_open;
         {
             // lane t of every row of 16 lanes takes tile t's summary; inclusive scans along the row:
-            //   counts and literal bytes            plain sums (count | bytes << 16)
             //   literals pending behind tile t      tail(t) if the tile has sequences, else pending(t - 1) + tail(t): segmented sum, bit 31 = "a tile with sequences is inside"
             //   offset of the last sequence so far  the last non-zero value
+            // SEAMS.  A tile's matches stop at its end.  Where the next tile opens with a match of the same offset at its first
+            // byte, the two are one sequence (`join`); a tile that is nothing but such a match is `whole` and hands on what
+            // follows it.  Not across multiples of ZKE_SEAM inside the block: a match length stays below 2^16.
+            //   counts and literal bytes            plain sums (count - join | bytes << 16)
+            //   what the tiles from t on add to the sequence in front of t     join(t) ? first_ml(t) + (whole(t) ? more(t + 1) : 0) : 0   (a segmented sum from the right)
             const uint32_t t = lane & 15;
-            const uint32_t sv = t < ntiles ? ts_[t] : 0, lv = t < ntiles ? tl_[t] : 0;
+            const uint32_t sv = t < ntiles ? ts_[t] : 0, lv = t < ntiles ? tl_[t] : 0, fo = t < ntiles ? tf_[t] : 0, fm = tfml[par ^ 1][t & 15];
             const uint32_t cn = sv & 0xFF, tail = (sv >> 8) & 0xFFF, tnl = sv >> 20;
-            uint32_t x = cn | (tnl << 16), y = tail | (cn ? 0x80000000u : 0u), z = cn ? lv : 0;
-#define ZKE_SCAN_STEP(d) { const uint32_t xs = ZKE_ROW_SHR(x, d, 0), ys = ZKE_ROW_SHR(y, d, 0), zs = ZKE_ROW_SHR(z, d, 0); \
-                           x += xs; y = (y & 0x80000000u) ? y : (y + (ys & 0x7FFFFFFFu)) | (ys & 0x80000000u); z = z ? z : zs; }
+            uint32_t y = tail | (cn ? 0x80000000u : 0u), z = cn ? lv : 0;
+#define ZKE_SCAN_STEP(d) { const uint32_t ys = ZKE_ROW_SHR(y, d, 0), zs = ZKE_ROW_SHR(z, d, 0); \
+                           y = (y & 0x80000000u) ? y : (y + (ys & 0x7FFFFFFFu)) | (ys & 0x80000000u); z = z ? z : zs; }
+            ZKE_SCAN_STEP(1) ZKE_SCAN_STEP(2) ZKE_SCAN_STEP(4) ZKE_SCAN_STEP(8)
+#undef ZKE_SCAN_STEP
+            const uint32_t ye = ZKE_ROW_SHR(y, 1, 0), ze = ZKE_ROW_SHR(z, 1, 0);            // what lies in front of tile t
+            const uint32_t pend_t = (ye & 0x80000000u) ? ye & 0x7FFFFFFFu : pend + ye, poff_t = ze ? ze : prev_off;
+            const bool join = fo && fo == poff_t && pend_t == 0 && ((todo.rel + t * ZKE_TILE) & (ZKE_SEAM - 1)) != 0;
+            uint32_t x = (cn - (join ? 1u : 0u)) | (tnl << 16);
+#define ZKE_SCAN_STEP(d) { x += ZKE_ROW_SHR(x, d, 0); }
             ZKE_SCAN_STEP(1) ZKE_SCAN_STEP(2) ZKE_SCAN_STEP(4) ZKE_SCAN_STEP(8)
 #undef ZKE_SCAN_STEP
             // what is in front of my tile = the scans at lane wave - 1; the group's totals = lane 15
-            const uint32_t wm = wave ? wave - 1 : 0;
+            const uint32_t wm = wave ? wave - 1 : 0, wn = wave < 15 ? wave + 1 : 15;
             const uint32_t xp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)x, (int)wm) : 0, yp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)y, (int)wm) : 0,
                            zp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)z, (int)wm) : 0;
-            const uint32_t me = (uint32_t)__builtin_amdgcn_readlane((int)sv, (int)wave);
+            me = (uint32_t)__builtin_amdgcn_readlane((int)sv, (int)wave);
             const uint32_t xt = (uint32_t)__builtin_amdgcn_readlane((int)x, 15), yt = (uint32_t)__builtin_amdgcn_readlane((int)y, 15), zt = (uint32_t)__builtin_amdgcn_readlane((int)z, 15);
+            my_join = 0; my_more = 0; my_open = wave == 15;
+            uint32_t more0 = 0, whole0 = 0;
+            if (__ballot(join)) {                                                   // (most groups have no seam to close)
+                uint32_t ev = join ? fm : 0, pw = join && cn == 1 && tail == 0 ? 1u : 0u;
+#define ZKE_SCAN_STEP(d) { const uint32_t es = ZKE_ROW_SHL(ev, d, 0), ps = ZKE_ROW_SHL(pw, d, 1); ev += pw ? es : 0; pw &= ps; }
+                ZKE_SCAN_STEP(1) ZKE_SCAN_STEP(2) ZKE_SCAN_STEP(4) ZKE_SCAN_STEP(8)
+#undef ZKE_SCAN_STEP
+                my_join = (uint32_t)__builtin_amdgcn_readlane((int)(join ? 1u : 0u), (int)wave);
+                my_more = wave < 15 ? (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)wn) : 0;
+                my_open = wave == 15 || __builtin_amdgcn_readlane((int)pw, (int)wn) != 0;   // every tile behind mine is whole
+                more0 = (uint32_t)__builtin_amdgcn_readlane((int)ev, 0); whole0 = (uint32_t)__builtin_amdgcn_readlane((int)pw, 0);
+            }
+            my_open = my_open && !todo.last;
             my_base = nseq + (xp & 0xFFFF); my_lit = nlit + (xp >> 16);
             my_pend = (yp & 0x80000000u) ? yp & 0x7FFFFFFFu : pend + yp;
             my_poff = zp ? zp : prev_off;
             my_cnt = me & 0xFF; my_nl = me >> 20;
+            if (held) {                                                             // (one lane of the workgroup at most)
+                held_e += (uint64_t)more0 << 16;
+                if (todo.last || !whole0) { *held_at = held_e; held = false; }
+            }
             nseq += xt & 0xFFFF; nlit += xt >> 16;
             pend = (yt & 0x80000000u) ? yt & 0x7FFFFFFFu : pend + yt;
             if (zt) { prev_off = zt; probe = zt; }
         }
         if (wave < ntiles) {
-            if (lane < my_cnt) {                                                    // <= 64 sequences per tile: one per lane
+            if (lane >= my_join && lane < my_cnt) {                                 // <= 64 sequences per tile: one per lane
                 const uint64_t e = tseq[wave][lane];
-                uint32_t ll = (uint32_t)e & 0xFFF;
-                const uint32_t ml = (uint32_t)(e >> 12) & 0xFFF, off = (uint32_t)(e >> 32);
+                uint32_t ll = (uint32_t)e & 0xFFF, ml = (uint32_t)(e >> 12) & 0xFFF;
+                const uint32_t off = (uint32_t)(e >> 32);
                 const uint32_t poff = lane ? (uint32_t)(tseq[wave][lane - 1] >> 32) : my_poff;
                 if (lane == 0) ll += my_pend;
                 const uint32_t code = (ll && off == poff) ? 1u : off + 3;
-                todo.sq[my_base + lane] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)code << 40);
+                const bool ends_tile = lane + 1 == my_cnt && ((me >> 8) & 0xFFF) == 0;
+                if (ends_tile) ml += my_more;
+                const uint64_t rec = (uint64_t)(ll | (ml << 16)) | ((uint64_t)code << 32);
+                uint64_t *at = &todo.sq[my_base + lane - my_join];
+                if (ends_tile && my_open) { held = true; held_e = rec; held_at = at; }
+                else *at = rec;
             }
             // the tile's literals: four bytes per lane (an unaligned dword store), the last bytes one by one
             const uint32_t *tw4 = &best[wave * ZKE_TILE];
@@ -339,13 +389,22 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                 // the 20 bytes of my four positions against the 20 bytes one byte / R bytes before them, once for all four
                 const uint32_t own[5] = {d0, d1, d2, d3, d4};
                 uint32_t x1[5], xr[5];                                                  // own ^ (own one byte earlier), own ^ (own R bytes earlier)
+                const bool farR = LDM && R > ZKE_WINDOW;                                // a previous offset beyond the ring: through memory
+                const int64_t ap0 = (int64_t)(abs0 + P0);
+                // a long-distance offset is usable at my four positions while the 20 bytes I read at that distance lie inside the
+                // table's part of the prefix
+                auto far_ok = [&](uint32_t off) { const int64_t a = ap0 - (int64_t)off; return a >= (int64_t)ldm.u0 && a + 20 <= (int64_t)ldm.plen; };
+                const bool okR = farR && far_ok(R);
                 {
                     const uint32_t rb = P0 - R, ri = (rb >> 2) & 16383u, rs = rb & 3u;  // R <= P0 is tested below; a wrong address reads some ring bytes
-                    const uint32_t r0 = ring[ri], r1 = ring[ri + 1], r2 = ring[ri + 2], r3 = ring[ri + 3], r4 = ring[ri + 4], r5 = ring[ri + 5];
                     x1[0] = d0 ^ __builtin_amdgcn_alignbyte(d0, dm1, 3u); x1[1] = d1 ^ __builtin_amdgcn_alignbyte(d1, d0, 3u); x1[2] = d2 ^ __builtin_amdgcn_alignbyte(d2, d1, 3u);
                     x1[3] = d3 ^ __builtin_amdgcn_alignbyte(d3, d2, 3u); x1[4] = d4 ^ __builtin_amdgcn_alignbyte(d4, d3, 3u);
-                    xr[0] = d0 ^ __builtin_amdgcn_alignbyte(r1, r0, rs); xr[1] = d1 ^ __builtin_amdgcn_alignbyte(r2, r1, rs); xr[2] = d2 ^ __builtin_amdgcn_alignbyte(r3, r2, rs);
-                    xr[3] = d3 ^ __builtin_amdgcn_alignbyte(r4, r3, rs); xr[4] = d4 ^ __builtin_amdgcn_alignbyte(r5, r4, rs);
+                    if (farR) zke_far_xor(ldm, ap0 - (int64_t)R, okR, own, xr);
+                    else {
+                        const uint32_t r0 = ring[ri], r1 = ring[ri + 1], r2 = ring[ri + 2], r3 = ring[ri + 3], r4 = ring[ri + 4], r5 = ring[ri + 5];
+                        xr[0] = d0 ^ __builtin_amdgcn_alignbyte(r1, r0, rs); xr[1] = d1 ^ __builtin_amdgcn_alignbyte(r2, r1, rs); xr[2] = d2 ^ __builtin_amdgcn_alignbyte(r3, r2, rs);
+                        xr[3] = d3 ^ __builtin_amdgcn_alignbyte(r4, r3, rs); xr[4] = d4 ^ __builtin_amdgcn_alignbyte(r5, r4, rs);
+                    }
                 }
                 uint32_t lf[4], ln[4], df[4], dn[4];
                 bool vf[4], vn[4];
@@ -363,6 +422,32 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     lf[k] = zke_common16(ring, vf[k] ? p - df[k] : p, o0, o1, o2, o3);
                     ln[k] = zke_common16(ring, vn[k] ? p - dn[k] : p, o0, o1, o2, o3);
                 }
+                // long-distance candidates: my sampled positions against their table entries; the tile's first hit lends its
+                // offset to every position of the tile (x2)
+                uint32_t hoff[4] = {0, 0, 0, 0}, x2[5] = {~0u, ~0u, ~0u, ~0u, ~0u}, tfar = 0;
+                bool ok2 = false;
+                if (LDM) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t p = P0 + k;
+                        const uint32_t o0 = wlo[k], o1 = whi[k], o2 = __builtin_amdgcn_alignbyte(own[3], own[2], (uint32_t)k), o3 = __builtin_amdgcn_alignbyte(own[4], own[3], (uint32_t)k);
+                        const uint32_t h = zke_ldm_hash(o0, o1, o2, o3);
+                        if (zke_ldm_selected(h) && p + ZKE_LDM_MIN <= te && p + ZKE_LDM_MIN <= fend) {
+                            const uint32_t e = ldm.table[zke_ldm_slot(h, ldm.log)];
+                            const uint64_t q = ldm.u0 + e, ap = abs0 + p;
+                            if (e != ZKE_LDM_NONE && q + 16 <= ldm.plen && ap - q <= ZKE_LDM_MAX_OFF) {
+                                uint32_t c[4];
+                                memcpy(c, ldm.pfx + q, 16);
+                                if (c[0] == o0 && c[1] == o1 && c[2] == o2 && c[3] == o3) hoff[k] = (uint32_t)(ap - q);
+                            }
+                        }
+                    }
+                    const uint32_t first = hoff[0] ? hoff[0] : hoff[1] ? hoff[1] : hoff[2] ? hoff[2] : hoff[3];
+                    const uint64_t hits = __ballot(first != 0);
+                    if (hits) tfar = (uint32_t)__builtin_amdgcn_readlane((int)first, (int)__builtin_ctzll(hits));
+                    if (tfar && tfar != R) { ok2 = far_ok(tfar); zke_far_xor(ldm, ap0 - (int64_t)tfar, ok2, own, x2); }      // uniform per wave
+                    else tfar = 0;
+                }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t p = P0 + k;
@@ -370,13 +455,19 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     uint32_t bl = 0, bo = 0, l;
                     l = lf[k] < n ? lf[k] : n; if (vf[k] && l >= minmatch) { bl = l; bo = df[k]; }
                     l = ln[k] < n ? ln[k] : n; if (vn[k] && l >= minmatch && l >= bl) { bl = l; bo = dn[k]; }
+                    if (LDM) {
+                        if (hoff[k]) { bl = ZKE_PARCAP; bo = hoff[k]; }                     // (16 equal bytes inside the tile)
+                        l = zke_first16(__builtin_amdgcn_alignbyte(x2[1], x2[0], (uint32_t)k), __builtin_amdgcn_alignbyte(x2[2], x2[1], (uint32_t)k),
+                                        __builtin_amdgcn_alignbyte(x2[3], x2[2], (uint32_t)k), __builtin_amdgcn_alignbyte(x2[4], x2[3], (uint32_t)k));
+                        if (tfar && ok2 && tabled[k] && n == ZKE_PARCAP && l == ZKE_PARCAP) { bl = ZKE_PARCAP; bo = tfar; }
+                    }
                     l = zke_first16(__builtin_amdgcn_alignbyte(x1[1], x1[0], (uint32_t)k), __builtin_amdgcn_alignbyte(x1[2], x1[1], (uint32_t)k),
                                     __builtin_amdgcn_alignbyte(x1[3], x1[2], (uint32_t)k), __builtin_amdgcn_alignbyte(x1[4], x1[3], (uint32_t)k));   // offset 1
                     l = l < n ? l : n; if (p >= 1 && l >= 4 && l >= bl) { bl = l; bo = 1; }
                     l = zke_first16(__builtin_amdgcn_alignbyte(xr[1], xr[0], (uint32_t)k), __builtin_amdgcn_alignbyte(xr[2], xr[1], (uint32_t)k),
                                     __builtin_amdgcn_alignbyte(xr[3], xr[2], (uint32_t)k), __builtin_amdgcn_alignbyte(xr[4], xr[3], (uint32_t)k));   // offset R
-                    l = l < n ? l : n; if (vr0 && R <= p && l >= 4 && l >= bl) { bl = l; bo = R; }
-                    best[4 * tid + k] = bl | (bo << 8);                                 // positions past the tile's end: length 0
+                    l = l < n ? l : n; if (vr0 && (farR ? okR : R <= p) && l >= 4 && l >= bl) { bl = l; bo = R; }
+                    best[4 * tid + k] = bl | (bo << 5);                                 // positions past the tile's end: length 0
                 }
             }
             ZKE_CLK(5);
@@ -389,11 +480,11 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     const uint32_t pos = wb + lane, p = ts + pos;
                     const bool in = p < te;
                     const uint32_t v = best[wave * ZKE_TILE + pos];                     // length 0 past the tile's end
-                    uint32_t len = v & 0xFF;
+                    uint32_t len = v & 0x1F;
                     bool cand = len != 0;
                     if (LAZY) {
-                        const uint32_t l1 = best[wave * ZKE_TILE + pos + 1 < ZKE_GROUP_POS ? wave * ZKE_TILE + pos + 1 : 0] & 0xFF;
-                        const uint32_t l2 = best[wave * ZKE_TILE + pos + 2 < ZKE_GROUP_POS ? wave * ZKE_TILE + pos + 2 : 0] & 0xFF;
+                        const uint32_t l1 = best[wave * ZKE_TILE + pos + 1 < ZKE_GROUP_POS ? wave * ZKE_TILE + pos + 1 : 0] & 0x1F;
+                        const uint32_t l2 = best[wave * ZKE_TILE + pos + 2 < ZKE_GROUP_POS ? wave * ZKE_TILE + pos + 2 : 0] & 0x1F;
                         if ((p + 1 < te && l1 > len) || (p + 2 < te && l2 > len + 1)) cand = false;
                     }
                     const uint32_t skip0 = skip;                                        // positions below it are covered by a match of the pass before
@@ -410,8 +501,19 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     while (f < 64) {                                                    // uniform: every lane walks the same chain
                         taken |= 1ull << f; lastf = f;
                         if ((capped >> f) & 1) {                                        // capped by the comparisons: extend, 64 bytes per step
-                            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)f) >> 8;
+                            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)f) >> 5;
                             uint32_t L = ZKE_PARCAP;
+                            if (LDM && off > ZKE_WINDOW) {                                  // the source lies in the prefix: byte by byte through memory, up to the prefix's end
+                                const uint64_t a0 = abs0 + ts + wb + f - off;
+                                for (;;) {
+                                    const uint32_t q = ts + wb + f + L + lane;
+                                    const uint64_t sa = a0 + L + lane;
+                                    const bool diff = q >= te || sa >= ldm.plen || zke_ring1(ring, q) != ldm.pfx[sa < ldm.plen ? sa : ldm.u0];
+                                    const uint64_t dm = __ballot(diff);
+                                    if (dm) { L += (uint32_t)__builtin_ctzll(dm); break; }
+                                    L += 64;
+                                }
+                            } else
                             for (;;) {
                                 const uint32_t q = ts + wb + f + L + lane;
                                 const bool diff = q >= te || zke_ring1(ring, q) != zke_ring1(ring, q - off);
@@ -436,11 +538,11 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     const bool mine = (taken >> lane) & 1;
                     if (mine) {
                         const uint32_t prev_end = below ? pe : aend;
-                        tseq[wave][c + (uint32_t)__builtin_popcountll(below)] = (uint64_t)((pos - prev_end) | (len << 12)) | ((uint64_t)(v >> 8) << 32);
+                        tseq[wave][c + (uint32_t)__builtin_popcountll(below)] = (uint64_t)((pos - prev_end) | (len << 12)) | ((uint64_t)(v >> 5) << 32);
                     }
                     if (taken) {
                         c += (uint32_t)__builtin_popcountll(taken); aend = skip;
-                        lastoff = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(63u - (uint32_t)__builtin_clzll(taken))) >> 8;
+                        lastoff = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(63u - (uint32_t)__builtin_clzll(taken))) >> 5;
                     }
                     const uint64_t litm = __ballot(in && !mine && pos >= skip0 && !(below && pos < pe));
                     if ((litm >> lane) & 1) tl[nl + (uint32_t)__builtin_popcountll(litm & lane_lt)] = (uint8_t)zke_ring1(ring, p);
@@ -449,10 +551,13 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                 if (lane == 0) {
                     tsum[par][wave] = c | (((te - ts) - aend) << 8) | (nl << 20);
                     tlast[par][wave] = lastoff;
+                    const uint64_t e0 = tseq[wave][0];                                  // a first sequence at the tile's first byte: its offset (else 0), its length
+                    tfirst[par][wave] = c && ((uint32_t)e0 & 0xFFF) == 0 ? (uint32_t)(e0 >> 32) : 0u;
+                    tfml[par][wave] = (uint32_t)(e0 >> 12) & 0xFFF;
                 }
             }
             ZKE_CLK(6);
-            todo.valid = true; todo.gs = gs; todo.ge = ge; todo.blk = blk; todo.sq = sq; todo.lt = lt; todo.last = ge == be;
+            todo.valid = true; todo.gs = gs; todo.ge = ge; todo.rel = gs - bs; todo.blk = blk; todo.sq = sq; todo.lt = lt; todo.last = ge == be;
             par ^= 1;
         }
     }

@@ -39,7 +39,9 @@ inline bool zke_plan_count(uint64_t n, uint32_t frame_size, uint32_t hist, ZkEnc
 
 // frames[nf], blocks[nb], segs[nseg] (a segment record is a ZkEncFrame that covers <= ZKE_SEGMENT bytes of its frame:
 // d_size / n_blocks / block_base are the segment's, hist / m_off its history), doff[nf + 1] (may be null)
-inline void zke_plan_fill(uint64_t n, uint32_t frame_size, int level, ZkEncPlan *pl, ZkEncFrame *frames, ZkEncBlock *blocks, ZkEncFrame *segs, uint64_t *doff)
+// prefix_len: the whole prefix (0: none); above ZKE_WINDOW the matcher also finds long-distance matches into it
+// (ZkEncLdm) and the frames' windows cover prefix + frame
+inline void zke_plan_fill(uint64_t n, uint32_t frame_size, int level, uint64_t prefix_len, ZkEncPlan *pl, ZkEncFrame *frames, ZkEncBlock *blocks, ZkEncFrame *segs, uint64_t *doff)
 {
     const uint32_t hist = pl->hist;
     uint64_t seq_total = 0, scratch_total = 0;
@@ -51,13 +53,14 @@ inline void zke_plan_fill(uint64_t n, uint32_t frame_size, int level, ZkEncPlan 
         uint32_t wlog = 10;
         while ((1u << wlog) < fr.d_size && wlog < 17) wlog++;
         if (hist) wlog = 17;                                 // covers every offset the matcher can produce, into the prefix too
+        if (hist && prefix_len > ZKE_WINDOW) while ((1ull << wlog) < prefix_len + fr.d_size && wlog < 27) wlog++;   // long-distance offsets: < 2^27
         fr.window_log = wlog;
         fr.block_max = zke_block_max(fr.d_size, hist != 0);
         fr.n_blocks = fr.d_size ? (fr.d_size + fr.block_max - 1) / fr.block_max : 0;
         fr.block_base = bcount;
         fr.hist = fr.d_size ? hist : 0;
         fr.m_off = hist ? (uint64_t)f * ((uint64_t)hist + frame_size) : fr.src_off;
-        fr.minmatch = zke_minmatch(level); fr.pad = 0;
+        fr.minmatch = zke_minmatch(level); fr.seg_at = 0;
         for (uint32_t b = 0; b < fr.n_blocks; b++) {
             ZkEncBlock &k = blocks[bcount++];
             memset(&k, 0, sizeof k);
@@ -77,6 +80,7 @@ inline void zke_plan_fill(uint64_t n, uint32_t frame_size, int level, ZkEncPlan 
             sg.d_size = fr.d_size - at < ZKE_SEGMENT ? fr.d_size - at : ZKE_SEGMENT;
             sg.n_blocks = (sg.d_size + fr.block_max - 1) / fr.block_max;
             sg.block_base = fr.block_base + (at / ZKE_SEGMENT) * per;
+            sg.seg_at = at;
             if (at) { sg.hist = ZKE_WINDOW; sg.m_off = fr.m_off + fr.hist + at - ZKE_WINDOW; }
         }
     }

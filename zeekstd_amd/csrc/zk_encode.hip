@@ -109,7 +109,7 @@ __global__ __launch_bounds__(1024) void zk_k_enc_fse_build(const ZkEncFrame *fra
         const uint64_t *sq = seqs + blk.seq_base;
         for (uint32_t i = tid; i < blk.nseq; i += 1024) {
             const uint64_t e = sq[i];
-            const uint32_t ll = (uint32_t)e & 0xFFFFF, ml = (uint32_t)(e >> 20) & 0xFFFFF, ob = (uint32_t)(e >> 40);
+            const uint32_t ll = (uint32_t)e & 0xFFFF, ml = (uint32_t)(e >> 16) & 0xFFFF, ob = (uint32_t)(e >> 32);
             atomicAdd(&h[0][zke_ll_code(ll)], 1u); atomicAdd(&h[1][zk_highbit(ob)], 1u); atomicAdd(&h[2][zke_ml_code(ml - 3)], 1u);
             mine++;
         }
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const uint32_t k = i + u * T3 < nseq ? i + u * T3 : i;
-                    const uint32_t ll = (uint32_t)e[u] & 0xFFFFF, ml = (uint32_t)(e[u] >> 20) & 0xFFFFF, ob = (uint32_t)(e[u] >> 40);
+                    const uint32_t ll = (uint32_t)e[u] & 0xFFFF, ml = (uint32_t)(e[u] >> 16) & 0xFFFF, ob = (uint32_t)(e[u] >> 32);
                     const uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
                     const uint32_t lv = T.ll_val[llc], mv = T.ml_val[mlc];
                     const uint32_t ln = lv >> 24, mn = mv >> 24;
@@ -569,13 +569,46 @@ void zk_launch_enc_stage_hist(hipStream_t st, const uint8_t *src, const uint8_t 
 {
     hipLaunchKernelGGL(zk_k_enc_stage_hist, dim3(nframes), dim3(256), 0, st, src, prefix_tail, frames, stage);
 }
-void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *segs, uint32_t nsegs, ZkEncBlock *blocks, uint64_t *seqs, uint8_t *lits, int level)
+// The long-distance table over prefix[u0, plen): every sampled position (zke_ldm_selected) enters, the smallest position keeps
+// a slot.  Four positions per lane and pass out of 20 bytes; the table was filled with ZKE_LDM_NONE.
+__global__ __launch_bounds__(256) void zk_k_enc_ldm_build(ZkEncLdm ldm, uint32_t *table)
+{
+    const uint64_t n = ldm.plen - ldm.u0;
+    const uint8_t *s = ldm.pfx + ldm.u0;
+    for (uint64_t i = 4ull * ((uint64_t)blockIdx.x * 256 + threadIdx.x); i + ZKE_LDM_MIN <= n; i += 4ull * gridDim.x * 256) {
+        uint32_t w[5];
+        memcpy(w, s + i, 16);
+        if (i + 20 <= n) memcpy(&w[4], s + i + 16, 4);
+        else { w[4] = 0; for (uint64_t j = i + 16; j < n; j++) w[4] |= (uint32_t)s[j] << (8 * (j - i - 16)); }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i + k + ZKE_LDM_MIN > n) break;
+            const uint32_t h = zke_ldm_hash(__builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)k), __builtin_amdgcn_alignbyte(w[2], w[1], (uint32_t)k),
+                                            __builtin_amdgcn_alignbyte(w[3], w[2], (uint32_t)k), __builtin_amdgcn_alignbyte(w[4], w[3], (uint32_t)k));
+            if (zke_ldm_selected(h)) atomicMin(&table[zke_ldm_slot(h, ldm.log)], (uint32_t)(i + k));
+        }
+    }
+}
+void zk_launch_enc_ldm_build(hipStream_t st, const ZkEncLdm &ldm, uint32_t *table)
+{
+    (void)hipMemsetAsync(table, 0xFF, sizeof(uint32_t) << ldm.log, st);
+    const uint64_t n = ldm.plen - ldm.u0, wgs = (n + 1023) / 1024;
+    hipLaunchKernelGGL(zk_k_enc_ldm_build, dim3((uint32_t)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, st, ldm, table);
+}
+void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *segs, uint32_t nsegs, ZkEncBlock *blocks, uint64_t *seqs, uint8_t *lits, int level, const ZkEncLdm &ldm)
 {
     if (!nsegs) return;
-    // one instance per setting of zk_enc_device.h (zke_hash_log / zke_lazy / zke_step)
-    if (zke_fast(level)) hipLaunchKernelGGL((zk_k_enc_match<14, 0, 4096>), dim3(nsegs), dim3(ZKE_THREADS), 0, st, src, segs, blocks, seqs, lits);
-    else if (zke_step(level) == 1024) hipLaunchKernelGGL((zk_k_enc_match<15, 1, 1024>), dim3(nsegs), dim3(ZKE_THREADS), 0, st, src, segs, blocks, seqs, lits);
-    else hipLaunchKernelGGL((zk_k_enc_match<15, 1, 4096>), dim3(nsegs), dim3(ZKE_THREADS), 0, st, src, segs, blocks, seqs, lits);
+    // one instance per setting of zk_enc_device.h (zke_hash_log / zke_lazy / zke_step), with and without long-distance matching
+#define ZKE_GO(H, L, S, D) hipLaunchKernelGGL((zk_k_enc_match<H, L, S, D>), dim3(nsegs), dim3(ZKE_THREADS), 0, st, src, segs, blocks, seqs, lits, ldm)
+    if (ldm.table) {
+        if (zke_fast(level)) ZKE_GO(14, 0, 4096, true);
+        else if (zke_step(level) == 1024) ZKE_GO(15, 1, 1024, true);
+        else ZKE_GO(15, 1, 4096, true);
+    }
+    else if (zke_fast(level)) ZKE_GO(14, 0, 4096, false);
+    else if (zke_step(level) == 1024) ZKE_GO(15, 1, 1024, false);
+    else ZKE_GO(15, 1, 4096, false);
+#undef ZKE_GO
 }
 void zk_launch_enc_fse_build(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, const uint64_t *seqs,
                              const ZkEncTables *predef, ZkEncTables *ftab)

@@ -51,6 +51,7 @@ struct zk_engine {
     void *enc_pin = nullptr; size_t enc_pin_cap = 0;   // pinned host copy of the frame / block lists of the encode in flight
     zk_devbuf enc_hist;                     // prefix mode: [prefix tail | frame] records for the matcher
     zk_devbuf enc_seg;                      // frames above ZKE_SEGMENT: the matcher's segment records
+    zk_devbuf enc_ldm;                      // prefix beyond the matcher's ring: the long-distance table (ZkEncLdm)
     ZkEncTables enc_tables;
     bool enc_tables_ready = false;
     // second queue of the encoder: the checksum kernel (one serial chain per frame) runs beside the matcher (one workgroup

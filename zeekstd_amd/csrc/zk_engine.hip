@@ -142,7 +142,7 @@ extern "C" void zk_engine_destroy(zk_engine *e)
     if (e->enc_pin) (void)hipHostFree(e->enc_pin);
     for (auto &c : e->dctx) if (c.st) (void)hipStreamSynchronize(c.st);
     zk_devbuf *bufs[] = {&e->st_prefix, &e->st_comp, &e->st_off, &e->st_dst, &e->st_misc,
-                         &e->enc_a, &e->enc_b, &e->enc_c, &e->enc_d, &e->enc_e, &e->enc_f, &e->enc_hist, &e->enc_seg};
+                         &e->enc_a, &e->enc_b, &e->enc_c, &e->enc_d, &e->enc_e, &e->enc_f, &e->enc_hist, &e->enc_seg, &e->enc_ldm};
     for (zk_devbuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (e->h_words) (void)hipHostFree(e->h_words);
     for (int k = 0; k < ZK_NKERNELS; k++) { if (e->ev_start[k]) (void)hipEventDestroy(e->ev_start[k]); if (e->ev_stop[k]) (void)hipEventDestroy(e->ev_stop[k]); }

@@ -88,7 +88,7 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
     uint64_t *doff = (uint64_t *)((uint8_t *)e->enc_pin + frames_bytes + blocks_bytes);
     ZkEncTables *htab = (ZkEncTables *)((uint8_t *)doff + doff_bytes);
     ZkEncFrame *segs = (ZkEncFrame *)((uint8_t *)e->enc_pin + ((frames_bytes + blocks_bytes + doff_bytes + sizeof(ZkEncTables) + 63) & ~(size_t)63));
-    zke_plan_fill(n, frame_size, a.level, &pl, frames, blocks, segs, doff);
+    zke_plan_fill(n, frame_size, a.level, a.d_prefix ? a.prefix_len : 0, &pl, frames, blocks, segs, doff);
     const uint64_t seq_total = pl.seq_total, scratch_total = pl.scratch_total;
     if ((rc = zk_devbuf_reserve(e, e->enc_a, frames_bytes + blocks_bytes + 256))) return rc;
     if ((rc = zk_devbuf_reserve(e, e->enc_b, (size_t)(seq_total + 1) * 12 + 64))) return rc;       // packed sequences (u64) + match positions (u32)
@@ -113,6 +113,15 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         zk_launch_enc_stage_hist(st, src, (const uint8_t *)a.d_prefix + (a.prefix_len - hist), dfr, nf, (uint8_t *)e->enc_hist.p);
         msrc = (const uint8_t *)e->enc_hist.p;
     }
+    // a prefix the ring cannot hold: its sampled positions enter a table in HBM (rebuilt per call: the bytes are the caller's)
+    ZkEncLdm ldm = {nullptr, nullptr, 0, 0, 0, 0};
+    if (hist && a.prefix_len > ZKE_WINDOW) {
+        const uint64_t usable = zke_ldm_usable(a.prefix_len);
+        ldm.pfx = (const uint8_t *)a.d_prefix; ldm.plen = a.prefix_len; ldm.u0 = a.prefix_len - usable; ldm.log = zke_ldm_log(usable);
+        if ((rc = zk_devbuf_reserve(e, e->enc_ldm, (sizeof(uint32_t) << ldm.log) + 64))) return rc;
+        zk_launch_enc_ldm_build(st, ldm, (uint32_t *)e->enc_ldm.p);
+        ldm.table = (const uint32_t *)e->enc_ldm.p;
+    }
     bool cks_beside = false;                                 // the checksums run on the second queue and are joined before the assembly
     if (a.checksum) {
         if (!e->profiling && !e->enc_aux) {
@@ -130,7 +139,7 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
     // the matcher's workgroups are launched over the segments (one per <= 256 KiB of a frame)
     if ((rc = zk_devbuf_reserve(e, e->enc_seg, segs_bytes + 64))) return rc;
     ZK_HIP(hipMemcpyAsync(e->enc_seg.p, segs, (size_t)nseg * sizeof(ZkEncFrame), hipMemcpyHostToDevice, st));
-    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, (const ZkEncFrame *)e->enc_seg.p, nseg, dbl, (uint64_t *)e->enc_b.p, (uint8_t *)e->enc_c.p, a.level); }
+    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, (const ZkEncFrame *)e->enc_seg.p, nseg, dbl, (uint64_t *)e->enc_b.p, (uint8_t *)e->enc_c.p, a.level, ldm); }
     ZkEncTables *ftab = (ZkEncTables *)e->enc_f.p;
     { zk_kernel_timer t(e, ZK_K_ENC_FSE_BUILD, st); zk_launch_enc_fse_build(st, src, dfr, nf, dbl, (const uint64_t *)e->enc_b.p, dtab, ftab); }
     { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, ftab); }

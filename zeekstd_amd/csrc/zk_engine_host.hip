@@ -886,7 +886,7 @@ extern "C" int zk_encode_frames_prefix(zk_engine *e, const uint8_t *src, uint64_
     if ((c_sizes || d_sizes) && frames_cap < nf) return ZK_ERR_ARGUMENT;
     // only the tail the matcher can reach is staged
     const void *d_prefix = nullptr;
-    const uint64_t tail = prefix ? (prefix_len < ZKE_WINDOW ? prefix_len : ZKE_WINDOW) : 0;
+    const uint64_t tail = prefix ? zke_ldm_usable(prefix_len) : 0;      // what the matcher can reach: its ring's window, and beyond it the long-distance table's span
     int rc = zk_engine_stage_prefix(e, nullptr, tail ? prefix + (prefix_len - tail) : nullptr, tail, true, &d_prefix);
     if (rc) return rc;
     ZkBufSink s{e, dst, dst_cap, 0, c_sizes, d_sizes, 0, false};
