@@ -157,8 +157,10 @@ int zk_encode_frames_dev(zk_engine *e, const void *d_src, uint64_t n, uint32_t f
                          uint64_t *written, void *stream);
 
 /* Encode against a raw-content prefix: ZSTD_CCtx_refPrefix at the start of every frame (lib/src/encode.rs:334-338).
- * The matcher reaches the last min(prefix_len, 65535) bytes of the prefix (its window); frames made this way declare a
- * 128 KiB window and need the same prefix to decode (zk_decode_frames_prefix, or libzstd with ZSTD_DCtx_refPrefix).
+ * The matcher's ring reaches the last 57280 bytes of the prefix; a longer prefix is also reached through a long-distance
+ * table over its last 2^27 - 1 bytes (what the reference CLI asks of libzstd for --patch-from, cli/src/compress.rs:31-37:
+ * long-distance matching + a window over the old file).  Frames made this way declare a window that covers prefix + frame
+ * (128 KiB .. 128 MiB) and need the same prefix to decode (zk_decode_frames_prefix, or libzstd with ZSTD_DCtx_refPrefix).
  * prefix_len == 0 is the plain call. */
 int zk_encode_frames_prefix_dev(zk_engine *e, const void *d_src, uint64_t n, uint32_t frame_size, int level, int checksum,
                                 const void *d_prefix, uint64_t prefix_len, void *d_dst, uint64_t dst_cap, void *d_c_sizes,

@@ -260,6 +260,20 @@ def test_patch_from_and_patch_apply(tmp_path):                      # cli/src/co
 
 
 @pytest.mark.gpu
+def test_patch_of_a_large_file_is_small(tmp_path):                  # cli/src/compress.rs:31-37: windowLog over the old file + long-distance matching
+    """The old file is far larger than the matcher's ring: the patch still costs about what the changes cost (long-distance
+    table over the prefix), and applies with this CLI."""
+    old = zko.gen_text(6 << 20, 60)
+    new = old[:1_000_000] + zko.gen_text(3000, 61) + old[1_000_400:4_000_000] + old[4_100_000:] + zko.gen_text(5000, 62)
+    o, n, p, r = tmp_path / "old", tmp_path / "new", tmp_path / "patch.zst", tmp_path / "restored"
+    o.write_bytes(old); n.write_bytes(new)
+    zeekstd("compress", n, "--patch-from", o, "--output-file", p)
+    assert p.stat().st_size < 16_000                                # 8 KB of new text, three seams, three frames
+    zeekstd("decompress", p, "--patch-apply", o, "--output-file", r)
+    assert r.read_bytes() == new
+
+
+@pytest.mark.gpu
 def test_levels_policy_and_checksum_flags(test_input, tmp_path):    # args.rs:185-207
     a, b, c = tmp_path / "l1.zst", tmp_path / "l19.zst", tmp_path / "nocks.zst"
     zeekstd("compress", test_input, "-l", 1, "-o", a)
