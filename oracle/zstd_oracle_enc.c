@@ -389,12 +389,13 @@ static u32 match_len(const u8 *a, const u8 *b, const u8 *end)        /* b > a */
 
 /* ---- long-distance matches into a prefix (cli/src/compress.rs:31-37: patch mode sets a window over the reference file and
  * enables libzstd's long-distance matcher).  The ring of the GPU matcher reaches 57 280 bytes back; a prefix longer than that
- * gets a coarse hash table over ALL of it: positions whose 8-byte hash has its top 6 bits clear (1 in 64, content-defined, so
- * the old and the new file sample the same places) enter a table of first occurrences.  Every sampled position of the frame
- * looks its slot up and compares 16 bytes against the prefix; a hit of >= 8 bytes is one more candidate with the offset
- * "position + distance to the prefix byte".  Once such a match is taken its offset is the previous offset R of the next
- * group: R beyond the ring is compared through memory instead, at every position, so an unchanged region costs one
- * repeat-offset sequence per 256-byte tile.  Offsets are limited to 2^27 - 1 (the field best[] has for them). */
+ * gets a coarse hash table over its last 2^27 - 1 bytes: positions whose 16-byte hash has its top 5 bits clear (1 in 32,
+ * content-defined, so the old and the new file sample the same places) enter a table of first occurrences.  A sampled
+ * position of the frame looks its slot up and compares 16 bytes against the prefix: all equal = a hit, a candidate of length
+ * 16 with the offset "position + distance to the prefix byte".  The offset of a tile's first hit is tried at every position
+ * of the tile; once such a match is taken its offset is the previous offset R of the next group, compared through memory
+ * instead of the ring.  Tiles that continue a match are joined into one sequence (ZKE_SEAM).  Offsets are limited to
+ * 2^27 - 1 (the field best[] has for them).  zeekstd_amd/csrc/zk_enc_device.h "ZkEncLdm" is the GPU side. */
 #define ZKE_SEAM 32768u
 #define ZKE_LDM_MIN 16u
 #define ZKE_LDM_MAX_OFF ((1u << 27) - 1)
@@ -403,8 +404,8 @@ static inline u32 ldm_hash(const u8 *p)
     u32 w[4]; memcpy(w, p, 16);
     return ((w[0] * 0x9E3779B1u) ^ (w[1] * 0x85EBCA77u)) + ((w[2] * 0xC2B2AE3Du) ^ (w[3] * 0x27D4EB2Fu));
 }
-static inline int ldm_selected(u32 h) { return (h >> 26) == 0; }
-static u32 ldm_log_for(u64 usable) { u32 l = 10; while (l < 22 && (1ull << l) < usable / 32) l++; return l; }
+static inline int ldm_selected(u32 h) { return (h >> 27) == 0; }
+static u32 ldm_log_for(u64 usable) { u32 l = 10; while (l < 23 && (1ull << l) < usable / 16) l++; return l; }
 /* the table covers the last ZKE_LDM_MAX_OFF bytes of the prefix (all of a shorter one), whatever the frame's size: one
  * table serves every frame of a stream; a position too far back for the offset field is turned down at the lookup */
 static void ldm_build(enc_state *st, const u8 *prefix, u64 plen)

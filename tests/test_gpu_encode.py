@@ -250,11 +250,12 @@ def _edited(old, seed, n_edits):
 def test_patch_encode_reaches_the_whole_prefix(engine, level, kind):
     """the reference's --patch-from turns on libzstd's long-distance matcher and a window over the whole old
     file (cli/src/compress.rs:31-37).  The matcher's ring reaches 57 280 bytes; beyond it a prefix is reached through the
-    long-distance table (zk_enc_device.h ZkEncLdm).  An 8 MiB file with 80 edits against its old version: the patch is
-    byte-identical to the CPU twin's, decodes with the oracle, libzstd and the GPU decoder, is a small fraction of the plain
-    encode, and within 2.2x of what libzstd makes of it with its long-distance matcher."""
-    old = zko.gen_text(8 << 20, 50) if kind == "text" else zko.gen_chunks(8 << 20, 50)
-    new = _edited(old, 3, 80)
+    long-distance table (zk_enc_device.h ZkEncLdm).  VERDICT's case: a 16 MiB file with 1 % of it edited (160 changes of about
+    a KiB) against its old version: the patch is byte-identical to the CPU twin's, decodes with the oracle, libzstd and the GPU
+    decoder, is a small fraction of the plain encode, and within 1.7x (asked: 2x) of what libzstd makes of it with its
+    long-distance matcher."""
+    old = zko.gen_text(16 << 20, 50) if kind == "text" else zko.gen_chunks(16 << 20, 50)
+    new = _edited(old, 3, 160)
     fs = 2 << 20
     comp, frames = engine.encode_frames(new, fs, level, True, prefix=old)
     plain, _ = engine.encode_frames(new, fs, level, True)
@@ -274,7 +275,7 @@ def test_patch_encode_reaches_the_whole_prefix(engine, level, kind):
     assert not st.any() and out == new
     if Z.load("1.5.7") is not None:
         ref, _ = Z.encode_seekable_frames(new, fs, 3, True, "1.5.7", prefix=old, window_log=len(old).bit_length(), ldm=True)
-        assert len(comp) <= 2.2 * len(ref), (len(comp), len(ref))
+        assert len(comp) <= 1.7 * len(ref), (len(comp), len(ref))
 
 
 @pytest.mark.parametrize("level", [1, 3])

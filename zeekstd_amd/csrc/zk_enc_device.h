@@ -64,8 +64,8 @@ struct ZkEncFrame {
 
 // LONG-DISTANCE MATCHES INTO A PREFIX (patch mode, cli/src/compress.rs:31-37: the reference turns on libzstd's long-distance
 // matcher and a window that covers the whole prefix).  The ring reaches ZKE_WINDOW bytes back; a prefix longer than that is
-// reached through a table in HBM over its last ZKE_LDM_MAX_OFF bytes: the positions whose 16-byte hash has six leading zeros
-// (one in 64, chosen by content, so the same text is sampled at the same places in the old and the new file), first
+// reached through a table in HBM over its last ZKE_LDM_MAX_OFF bytes: the positions whose 16-byte hash has five leading zeros
+// (one in 32, chosen by content, so the same text is sampled at the same places in the old and the new file), first
 // occurrence per slot.  A sampled position of the frame whose 16 bytes equal the entry's is a hit; the hit's offset is tried
 // at every position of its tile, and as "previous offset" from then on -- compared through HBM (L2), not the ring.
 constexpr uint32_t ZKE_LDM_MIN = 16;
@@ -76,10 +76,10 @@ ZK_HD uint32_t zke_ldm_hash(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
 {
     return ((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA77u)) + ((w2 * 0xC2B2AE3Du) ^ (w3 * 0x27D4EB2Fu));
 }
-ZK_HD bool zke_ldm_selected(uint32_t h) { return (h >> 26) == 0; }
+ZK_HD bool zke_ldm_selected(uint32_t h) { return (h >> 27) == 0; }
 ZK_HD uint32_t zke_ldm_slot(uint32_t h, uint32_t log) { return (h >> 2) & ((1u << log) - 1); }
 ZK_HD uint64_t zke_ldm_usable(uint64_t plen) { return plen < ZKE_LDM_MAX_OFF ? plen : ZKE_LDM_MAX_OFF; }
-ZK_HD uint32_t zke_ldm_log(uint64_t usable) { uint32_t l = 10; while (l < 22 && (1ull << l) < usable / 32) l++; return l; }
+ZK_HD uint32_t zke_ldm_log(uint64_t usable) { uint32_t l = 10; while (l < 23 && (1ull << l) < usable / 16) l++; return l; }
 struct ZkEncLdm {
     const uint8_t *pfx;         // prefix byte q is pfx[q] for q in [u0, plen) (+ ZKE_LDM_SLACK readable bytes); nullptr: no long-distance matching
     const uint32_t *table;      // 2^log entries: position - u0 of the first sampled occurrence, ZKE_LDM_NONE = empty
