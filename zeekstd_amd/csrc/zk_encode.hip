@@ -40,6 +40,22 @@ extern "C" void zk_debug_enc_clocks(unsigned long long *out, int reset)
 #define ZKE_CLK_END() do { if ((threadIdx.x & 63) == 0) for (int i = 0; i < 16; i++) atomicAdd(&zke_dbg_clk[i], clk_[i]); } while (0)
 #endif
 #include "zk_enc_match.h"
+#ifdef ZKE_ENT_CLOCKS
+// experiments: the same for the entropy kernel (per wave: slot = 4 * phase + wave; tools/ent_clocks.py)
+__device__ unsigned long long zke_dbg_clk[32];
+extern "C" void zk_debug_enc_clocks(unsigned long long *out, int reset)
+{
+    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zke_dbg_clk), z, sizeof z); }
+    else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(zke_dbg_clk), 32 * sizeof(unsigned long long));
+}
+#define ZKE_ECLK_BEGIN() unsigned long long eclk_[8] = {0}, et_ = clock64()
+#define ZKE_ECLK(i) do { const unsigned long long now_ = clock64(); eclk_[i] += now_ - et_; et_ = now_; } while (0)
+#define ZKE_ECLK_END() do { if ((threadIdx.x & 63) == 0) for (int i = 0; i < 8; i++) atomicAdd(&zke_dbg_clk[4 * i + (threadIdx.x >> 6)], eclk_[i]); } while (0)
+#else
+#define ZKE_ECLK_BEGIN() do { } while (0)
+#define ZKE_ECLK(i) do { } while (0)
+#define ZKE_ECLK_END() do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------ entropy stage
 // LSB-first bit writer into global scratch (one lane), free of branches: put() collects at most 56 bits on top of
@@ -211,6 +227,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
     const uint32_t b0 = blockIdx.x * ZKE_ENT_BLOCKS;
     const uint32_t nb = nblocks - b0 < (uint32_t)ZKE_ENT_BLOCKS ? nblocks - b0 : (uint32_t)ZKE_ENT_BLOCKS;
 
+    ZKE_ECLK_BEGIN();
     for (uint32_t i = tid; i < ZKE_ENT_BLOCKS * 256; i += ZKE_ENT_THREADS) (&cnt[0][0])[i] = 0;
     const uint32_t frame_a = blocks[b0].frame;
     for (uint32_t i = tid; i < sizeof(ZkEncTables) / 4; i += ZKE_ENT_THREADS) ((uint32_t *)&T)[i] = ((const uint32_t *)&ftab[frame_a])[i];
@@ -247,7 +264,9 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
         }
         for (uint32_t i = 8 * lw + tid; i < blk.nlit; i += ZKE_ENT_THREADS) atomicAdd(&cnt[j][lt[i]], 1u);
     }
+    ZKE_ECLK(0);
     __syncthreads();
+    ZKE_ECLK(1);
     // While 16 lanes of wave 0 build the Huffman codes, waves 1-3 rewrite every sequence of the 16 blocks into what
     // its serial bit writer needs -- everything that does not depend on the FSE states:
     //   seqs[i]  <- extra bits of LL | ML | OF back to back (<= 48 bits), their count << 56
@@ -285,6 +304,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             }
         }
     }
+    ZKE_ECLK(2);
     // literal mode + Huffman code: two rounds of 8 blocks, block j on lanes j % 8 and j % 8 + 8 of wave 0 (the second
     // lane shadows the first with identical LDS writes: >= 16 active lanes, see zk_decode.hip)
     for (uint32_t round = 0; round < ZKE_ENT_BLOCKS / NHB; round++) {
@@ -305,6 +325,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
         }
         __syncthreads();
     }
+    ZKE_ECLK(3);
     // serial bit writers: wave 0 = 4 literal streams of each block, wave 1 = the sequence bitstream of each block
     if (wave == 0) {
         const uint32_t j = lane >> 2, k = lane & 3;
@@ -354,7 +375,9 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
         }
         s_sizes[lane][4] = sz;
     }
+    ZKE_ECLK(4);
     __syncthreads();
+    ZKE_ECLK(5);
     // layout of every block payload (lane j of wave 0)
     if (tid < ZKE_ENT_BLOCKS && tid < nb) {
         const uint32_t j = tid;
@@ -449,6 +472,8 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             zke_copy_wave(payload + p, qtemp, z[4], lane);
         }
     }
+    ZKE_ECLK(6);
+    ZKE_ECLK_END();
 }
 
 // ------------------------------------------------------------------------------------------------ frame sizes, scan, assemble
