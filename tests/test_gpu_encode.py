@@ -278,6 +278,32 @@ def test_patch_encode_reaches_the_whole_prefix(engine, level, kind):
         assert len(comp) <= 1.7 * len(ref), (len(comp), len(ref))
 
 
+def test_patch_against_a_prefix_longer_than_the_long_distance_span(engine):
+    """The long-distance table covers the last 2^27 - 1 bytes of the prefix; offsets stay below 2^27 and the frames declare a
+    2^27 window.  A 136 MiB old file: a piece of its first megabytes is out of reach (encoded like fresh data), a piece of
+    its tail is found; GPU == twin (which sees the whole prefix while the engine is handed its last 2^27 - 1 bytes),
+    libzstd and the GPU decoder restore the input."""
+    unit = zko.gen_chunks(8 << 20, 70)
+    old = b"".join(zko.gen_text(1 << 20, 700 + i) + (unit[i << 18:] + unit[:i << 18])[:7 << 20] for i in range(17))   # 17 x 8 MiB
+    assert len(old) == 136 << 20
+    new = old[48_576:1_048_576] + zko.gen_text(5000, 71) + old[(130 << 20) + 777:(133 << 20) + 777]      # (the first MiB of every piece is unique text)
+    fs = 2 << 20
+    comp, frames = engine.encode_frames(new, fs, 1, True, prefix=old)
+    pos = dpos = 0
+    for c, d in frames:
+        f = comp[pos:pos + c]
+        assert f == zko.frame_encode(new[dpos:dpos + d], 1, True, prefix=old), dpos
+        assert (f[5] >> 3) + 10 == 27                                   # Window_Descriptor: 2^27
+        pos += c; dpos += d
+    assert sum(c for c, _ in frames[1:]) < 20_000                       # the tail piece is a copy; the first frame holds the out-of-reach megabyte
+    assert frames[0][0] > 300_000
+    if Z.load("1.5.7") is not None:
+        assert Z.decode_stream(comp, len(new), "1.5.7", prefix=old) == new
+    c_off, d_off = offsets_from_frames(frames)
+    out, st = engine.decode_frames(comp + b"\0" * 8, c_off, d_off, verify=True, prefix=old)
+    assert not st.any() and out == new
+
+
 @pytest.mark.parametrize("level", [1, 3])
 @pytest.mark.parametrize("with_prefix", [False, True])
 def test_frames_above_the_matcher_segment(engine, level, with_prefix):
