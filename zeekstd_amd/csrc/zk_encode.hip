@@ -76,6 +76,14 @@ struct ZkeBits {
         ovf |= pos > cap;
         pos = pos > cap ? cap : pos;
     }
+    // the same without the bound: the caller looks at it (check()) at least every 48 bytes, the region has that much slack
+    __device__ __forceinline__ void flush_fast()
+    {
+        memcpy(p + pos, &acc, 8);
+        const uint32_t k = n >> 3;
+        pos += k; acc >>= 8 * k; n &= 7;
+    }
+    __device__ __forceinline__ void check() { ovf |= pos > cap; pos = pos > cap ? cap : pos; }
     __device__ __forceinline__ uint32_t close()
     {
         flush(); put(1, 1); flush();
@@ -105,9 +113,14 @@ __device__ __forceinline__ void zke_copy_wave(uint8_t *dst, const uint8_t *src, 
 // One workgroup per frame: code histograms of all its sequences (LDS atomics), then one lane per table normalises,
 // writes the description and builds the compression table into the frame's ZkEncTables (HBM).  A table with fewer than
 // two symbols, or a frame with fewer than ZKE_FSE_MIN_SEQ sequences, keeps the predefined one.
-__global__ __launch_bounds__(1024) void zk_k_enc_fse_build(const ZkEncFrame *frames, const ZkEncBlock *blocks, const uint64_t *seqs,
+// It also rewrites every sequence into what its serial bit writer (zk_k_enc_entropy) needs -- everything that does not depend on
+// the FSE states -- so that the writers can start with the kernel:
+//   seqs[i]  <- extra bits of LL | ML | OF back to back (<= 48 bits), their count << 56
+//   mpos[i]  <- LL code | ML code << 8 | OF code << 16
+__global__ __launch_bounds__(1024) void zk_k_enc_fse_build(const ZkEncFrame *frames, const ZkEncBlock *blocks, uint64_t *seqs, uint32_t *mpos,
                                                           const ZkEncTables *predef, ZkEncTables *ftab, uint32_t min_seq)
 {
+    __shared__ uint32_t s_llv[36], s_mlv[56];              // base | extra bits << 24 (the same in every frame)
     __shared__ uint32_t h[3][64];
     __shared__ int16_t norm[3][64];
     __shared__ uint8_t sym[3][512];
@@ -118,15 +131,24 @@ __global__ __launch_bounds__(1024) void zk_k_enc_fse_build(const ZkEncFrame *fra
     ZkEncTables *T = &ftab[blockIdx.x];
     if (tid < 192) (&h[0][0])[tid] = 0;
     if (tid == 0) s_nseq = 0;
+    if (tid < 36) s_llv[tid] = predef->ll_val[tid];
+    if (tid >= 64 && tid < 64 + 56) s_mlv[tid - 64] = predef->ml_val[tid - 64];
     __syncthreads();
     uint32_t mine = 0;
     for (uint32_t b = 0; b < fr.n_blocks; b++) {
         const ZkEncBlock &blk = blocks[fr.block_base + b];
-        const uint64_t *sq = seqs + blk.seq_base;
+        uint64_t *sq = seqs + blk.seq_base;
+        uint32_t *cw = mpos + blk.seq_base;
         for (uint32_t i = tid; i < blk.nseq; i += 1024) {
             const uint64_t e = sq[i];
             const uint32_t ll = (uint32_t)e & 0xFFFF, ml = (uint32_t)(e >> 16) & 0xFFFF, ob = (uint32_t)(e >> 32);
-            atomicAdd(&h[0][zke_ll_code(ll)], 1u); atomicAdd(&h[1][zk_highbit(ob)], 1u); atomicAdd(&h[2][zke_ml_code(ml - 3)], 1u);
+            const uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
+            atomicAdd(&h[0][llc], 1u); atomicAdd(&h[1][ofc], 1u); atomicAdd(&h[2][mlc], 1u);
+            const uint32_t lv = s_llv[llc], mv = s_mlv[mlc];
+            const uint32_t ln = lv >> 24, mn = mv >> 24;
+            const uint64_t x = (uint64_t)(ll - (lv & 0xFFFFFF)) | ((uint64_t)(ml - (mv & 0xFFFFFF)) << ln) | ((uint64_t)(ob - (1u << ofc)) << (ln + mn));
+            sq[i] = x | ((uint64_t)(ln + mn + ofc) << 56);
+            cw[i] = llc | (mlc << 8) | (ofc << 16);
             mine++;
         }
     }
@@ -175,14 +197,20 @@ __device__ __forceinline__ uint32_t zke_write_sequences(const TT &T, const ZkEnc
         b.acc |= x & 0x00FFFFFFFFFFFFFFull; b.n += (uint32_t)(x >> 56);             // <= 48 bits
         b.flush();
     }
-    auto step = [&](uint64_t x, uint32_t c) {
+    // what a step needs of the tables besides the states' own cells: found by the codes alone, so fetched for four steps at once,
+    // off the chain (state -> bit count -> next state is then ONE dependent LDS lookup per state and step)
+    struct Pre { uint32_t odn, odf, mdn, mdf, ldn, ldf; };
+    auto pre = [&](uint32_t c) {
         const uint32_t llc = c & 0xFF, mlc = (c >> 8) & 0xFF, ofc = c >> 16;
-        { uint32_t nbt = (so + T.of_dnb[ofc]) >> 16; b.put(so, nbt); so = T.of_state[(so >> nbt) + T.of_dfs[ofc]]; }
-        { uint32_t nbt = (sm + T.ml_dnb[mlc]) >> 16; b.put(sm, nbt); sm = T.ml_state[(sm >> nbt) + T.ml_dfs[mlc]]; }
-        { uint32_t nbt = (sl + T.ll_dnb[llc]) >> 16; b.put(sl, nbt); sl = T.ll_state[(sl >> nbt) + T.ll_dfs[llc]]; }
-        b.flush();                                                                // <= 7 + 26 bits were waiting
+        return Pre{T.of_dnb[ofc], T.of_dfs[ofc], T.ml_dnb[mlc], T.ml_dfs[mlc], T.ll_dnb[llc], T.ll_dfs[llc]};
+    };
+    auto step = [&](uint64_t x, const Pre &p) {
+        { uint32_t nbt = (so + p.odn) >> 16; b.put(so, nbt); so = T.of_state[(so >> nbt) + p.odf]; }
+        { uint32_t nbt = (sm + p.mdn) >> 16; b.put(sm, nbt); sm = T.ml_state[(sm >> nbt) + p.mdf]; }
+        { uint32_t nbt = (sl + p.ldn) >> 16; b.put(sl, nbt); sl = T.ll_state[(sl >> nbt) + p.ldf]; }
+        b.flush_fast();                                                           // <= 7 + 26 bits were waiting
         b.acc |= (x & 0x00FFFFFFFFFFFFFFull) << b.n; b.n += (uint32_t)(x >> 56);   // <= 7 + 48
-        b.flush();
+        b.flush_fast();
     };
     // sequences nseq - 2 .. 0, read four ahead with unconditional (clamped) loads
     auto ldx = [&](int32_t k) { return sq[k < 0 ? 0 : k]; };
@@ -194,21 +222,25 @@ __device__ __forceinline__ uint32_t zke_write_sequences(const TT &T, const ZkEnc
     while (i >= 3) {                                                              // same scheme as the literal streams
         const uint64_t n0 = ldx(i - 4), n1 = ldx(i - 5), n2 = ldx(i - 6), n3 = ldx(i - 7);
         const uint32_t d0 = ldc(i - 4), d1 = ldc(i - 5), d2 = ldc(i - 6), d3 = ldc(i - 7);
-        step(e0, c0); step(e1, c1); step(e2, c2); step(e3, c3);
+        const Pre p0 = pre(c0), p1 = pre(c1), p2 = pre(c2), p3 = pre(c3);
+        step(e0, p0); step(e1, p1); step(e2, p2); step(e3, p3);
+        b.check();                                                                // <= 4 x 10 bytes since the last look: inside the slack
         e0 = n0; e1 = n1; e2 = n2; e3 = n3; c0 = d0; c1 = d1; c2 = d2; c3 = d3;
         i -= 4;
     }
-    if (i >= 0) step(e0, c0);
-    if (i >= 1) step(e1, c1);
-    if (i >= 2) step(e2, c2);
+    if (i >= 0) step(e0, pre(c0));
+    if (i >= 1) step(e1, pre(c1));
+    if (i >= 2) step(e2, pre(c2));
+    b.check();
     b.put(sm, T.al[2]); b.flush(); b.put(so, T.al[1]); b.put(sl, T.al[0]);
     return b.close();
 }
 
 // One workgroup handles 16 consecutive blocks so that the serial bit writers fill their waves with REAL work:
-// wave 0 = 16 blocks x 4 literal streams (64 lanes), wave 1 lanes 0-15 = the 16 sequence bitstreams (a wave with
-// fewer than 16 active lanes runs ~3x slower on gfx950, tools/ubench/lat3.hip).  Histograms, RLE detection and the
-// payload copies use all 256 lanes, block after block; the Huffman code of block j is built by lane j of wave 0.
+// wave 1 lanes 0-15 = the 16 sequence bitstreams -- the longest chain of the workgroup, so it starts with the kernel (its input
+// was rewritten by zk_k_enc_fse_build); meanwhile waves 0, 2, 3 detect RLE blocks and count literals, wave 0 builds the 16 Huffman
+// codes (lane j builds block j's) and then writes the 16 x 4 literal streams; all waves copy the payloads together at the end.
+// (A wave with fewer than 16 active lanes runs ~3x slower on gfx950, tools/ubench/lat3.hip.)
 __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
                                                                    uint32_t nblocks, uint64_t *seqs, uint32_t *mpos, const uint8_t *lits,
                                                                    uint8_t *scratch, const ZkEncTables *ftab)
@@ -223,7 +255,11 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
     __shared__ ZkHufBuild hbuild[NHB];
     __shared__ uint32_t s_sizes[ZKE_ENT_BLOCKS][5];        // 4 literal streams + sequence bitstream
     __shared__ uint32_t s_lit_mode[ZKE_ENT_BLOCKS], s_maxbits[ZKE_ENT_BLOCKS], s_tree[ZKE_ENT_BLOCKS], s_diff[ZKE_ENT_BLOCKS], s_mode[ZKE_ENT_BLOCKS];
+    __shared__ uint32_t s_hist_done;                       // waves 2, 3 -> wave 0: my histogram passes are done
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // roles: wave 0 = Huffman builds + literal writers, 1 = sequence writers, 2 / 3 = helpers.  (Rotating the roles over the waves from
+    // workgroup to workgroup -- so that the chains of the workgroups sharing a CU would not meet on one SIMD -- changed nothing: 11.1 / 11.2 / 11.6 ms.)
+    const uint32_t role = wave;
     const uint32_t b0 = blockIdx.x * ZKE_ENT_BLOCKS;
     const uint32_t nb = nblocks - b0 < (uint32_t)ZKE_ENT_BLOCKS ? nblocks - b0 : (uint32_t)ZKE_ENT_BLOCKS;
 
@@ -232,150 +268,129 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
     const uint32_t frame_a = blocks[b0].frame;
     for (uint32_t i = tid; i < sizeof(ZkEncTables) / 4; i += ZKE_ENT_THREADS) ((uint32_t *)&T)[i] = ((const uint32_t *)&ftab[frame_a])[i];
     if (tid < ZKE_ENT_BLOCKS) s_diff[tid] = 0;
+    if (tid == 0) s_hist_done = 0;
     __syncthreads();
-    // raw block all one byte?  literal histogram -- all lanes, block after block
-    for (uint32_t j = 0; j < nb; j++) {
-        const ZkEncBlock &blk = blocks[b0 + j];
-        const uint8_t *raw = src + frames[blk.frame].src_off + blk.bs;
-        const uint8_t *lt = lits + blk.lit_base;
-        // 8 bytes per load, four loads in flight per lane (a byte-at-a-time loop is one L1 round trip per byte)
-        const uint64_t first8 = raw[0] * 0x0101010101010101ull;
-        uint64_t dx = 0;
-        const uint32_t bw = blk.bsz >> 3, lw = blk.nlit >> 3;
-        for (uint32_t i = tid; i < bw; i += 4 * ZKE_ENT_THREADS) {
-            uint64_t w[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t k = i + u * ZKE_ENT_THREADS; w[u] = zk_ld64(raw + 8 * (k < bw ? k : i)); }
-#pragma unroll
-            for (int u = 0; u < 4; u++) dx |= w[u] ^ first8;
+    if (role == 1) {
+        // the sequence bit writers -- the longest chain of the workgroup (62 % of its life when they started last) -- start with
+        // the kernel: their input was rewritten by zk_k_enc_fse_build, they need nothing of what the other waves prepare
+        if (lane < ZKE_ENT_BLOCKS) {
+            const uint32_t j = lane;
+            uint32_t sz = 0;
+            if (j < nb && blocks[b0 + j].nseq) {
+                // the tables come out of LDS when the block belongs to the workgroup's first frame (the rule: 16 blocks of one
+                // frame per workgroup), out of HBM for the blocks of another frame in a mixed workgroup
+                if (blocks[b0 + j].frame == frame_a) sz = zke_write_sequences(T, blocks[b0 + j], seqs, mpos, scratch);
+                else sz = zke_write_sequences(ftab[blocks[b0 + j].frame], blocks[b0 + j], seqs, mpos, scratch);
+            }
+            s_sizes[lane][4] = sz;
         }
-        for (uint32_t i = 8 * bw + tid; i < blk.bsz; i += ZKE_ENT_THREADS) dx |= raw[i] ^ raw[0];
-        if (dx) s_diff[j] = 1;
-        for (uint32_t i = tid; i < lw; i += 4 * ZKE_ENT_THREADS) {
-            uint64_t w[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t k = i + u * ZKE_ENT_THREADS; w[u] = zk_ld64(lt + 8 * (k < lw ? k : i)); }
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (i + u * ZKE_ENT_THREADS < lw) {
-#pragma unroll
-                    for (int t = 0; t < 8; t++) atomicAdd(&cnt[j][(w[u] >> (8 * t)) & 0xFF], 1u);
-                }
-        }
-        for (uint32_t i = 8 * lw + tid; i < blk.nlit; i += ZKE_ENT_THREADS) atomicAdd(&cnt[j][lt[i]], 1u);
-    }
-    ZKE_ECLK(0);
-    __syncthreads();
-    ZKE_ECLK(1);
-    // While 16 lanes of wave 0 build the Huffman codes, waves 1-3 rewrite every sequence of the 16 blocks into what
-    // its serial bit writer needs -- everything that does not depend on the FSE states:
-    //   seqs[i]  <- extra bits of LL | ML | OF back to back (<= 48 bits), their count << 56
-    //   mpos[i]  <- LL code | ML code << 8 | OF code << 16        (the match positions are not needed any more)
-    if (wave >= 1) {
+        ZKE_ECLK(4);
+    } else {
+        constexpr uint32_t HT = ZKE_ENT_THREADS - 64;
+        const uint32_t ht = (role ? role - 1 : 0) * 64 + lane;  // my index among the lanes of roles 0, 2, 3
+        // raw block all one byte?  literal histogram -- waves 0, 2 and 3, block after block
         for (uint32_t j = 0; j < nb; j++) {
             const ZkEncBlock &blk = blocks[b0 + j];
-            uint64_t *sq = seqs + blk.seq_base;
-            uint32_t *cw = mpos + blk.seq_base;
-            const uint32_t nseq = blk.nseq, T3 = ZKE_ENT_THREADS - 64;
-            // four sequences per lane and pass; the next pass's records are requested before this pass's stores, and every
-            // store is unconditional (a lane without a sequence rewrites its first one), so no wait ever covers a store
-            auto ldq = [&](uint32_t i, int u) { const uint32_t k = i + u * T3; return sq[k < nseq ? k : (i < nseq ? i : 0)]; };
-            uint64_t e[4];
+            const uint8_t *raw = src + frames[blk.frame].src_off + blk.bs;
+            const uint8_t *lt = lits + blk.lit_base;
+            // 8 bytes per load, four loads in flight per lane (a byte-at-a-time loop is one L1 round trip per byte)
+            const uint64_t first8 = raw[0] * 0x0101010101010101ull;
+            uint64_t dx = 0;
+            const uint32_t bw = blk.bsz >> 3, lw = blk.nlit >> 3;
+            for (uint32_t i = ht; i < bw; i += 4 * HT) {
+                uint64_t w[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) e[u] = nseq ? ldq(tid - 64, u) : 0;
-            asm volatile("" :: "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]));
-            for (uint32_t i = tid - 64; i < nseq; i += 4 * T3) {
-                uint64_t n[4];
+                for (int u = 0; u < 4; u++) { const uint32_t k = i + u * HT; w[u] = zk_ld64(raw + 8 * (k < bw ? k : i)); }
 #pragma unroll
-                for (int u = 0; u < 4; u++) n[u] = ldq(i + 4 * T3, u);
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t k = i + u * T3 < nseq ? i + u * T3 : i;
-                    const uint32_t ll = (uint32_t)e[u] & 0xFFFF, ml = (uint32_t)(e[u] >> 16) & 0xFFFF, ob = (uint32_t)(e[u] >> 32);
-                    const uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
-                    const uint32_t lv = T.ll_val[llc], mv = T.ml_val[mlc];
-                    const uint32_t ln = lv >> 24, mn = mv >> 24;
-                    const uint64_t x = (uint64_t)(ll - (lv & 0xFFFFFF)) | ((uint64_t)(ml - (mv & 0xFFFFFF)) << ln) | ((uint64_t)(ob - (1u << ofc)) << (ln + mn));
-                    sq[k] = x | ((uint64_t)(ln + mn + ofc) << 56);
-                    cw[k] = llc | (mlc << 8) | (ofc << 16);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) e[u] = n[u];
+                for (int u = 0; u < 4; u++) dx |= w[u] ^ first8;
             }
+            for (uint32_t i = 8 * bw + ht; i < blk.bsz; i += HT) dx |= raw[i] ^ raw[0];
+            if (dx) s_diff[j] = 1;
+            for (uint32_t i = ht; i < lw; i += 4 * HT) {
+                uint64_t w[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const uint32_t k = i + u * HT; w[u] = zk_ld64(lt + 8 * (k < lw ? k : i)); }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (i + u * HT < lw) {
+#pragma unroll
+                        for (int t = 0; t < 8; t++) atomicAdd(&cnt[j][(w[u] >> (8 * t)) & 0xFF], 1u);
+                    }
+            }
+            for (uint32_t i = 8 * lw + ht; i < blk.nlit; i += HT) atomicAdd(&cnt[j][lt[i]], 1u);
+        }
+
+        ZKE_ECLK(0);
+        // the Huffman builds (wave 0) need every wave's counts: waves 2 and 3 sign off (a wave's LDS operations complete in
+        // order, so their counts are in place when the flag moves), wave 0 waits for both
+        if (role >= 2) { if (lane == 0) atomicAdd(&s_hist_done, 1u); }
+        else {
+            while (__hip_atomic_load(&s_hist_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2u) __builtin_amdgcn_s_sleep(2);
+            ZKE_ECLK(1);
+            // literal mode + Huffman code: two rounds of 8 blocks, block j on lanes j % 8 and j % 8 + 8 of wave 0 (the second
+            // lane shadows the first with identical LDS writes: >= 16 active lanes, see zk_decode.hip)
+            for (uint32_t round = 0; round < ZKE_ENT_BLOCKS / NHB; round++) {
+                if (lane < ZKE_ENT_BLOCKS) {
+                    const uint32_t j = (lane & (NHB - 1)) + NHB * round;
+                    if (j < nb) {
+                        const uint32_t nlit = blocks[b0 + j].nlit;
+                        // literal mode: 1 = RLE, 2 = Huffman (4 streams), 0 = raw      (oracle encode_literals)
+                        uint32_t mode = 0, maxsym = 0, distinct = 0;
+                        for (uint32_t sy = 0; sy < 256; sy++) if (cnt[j][sy]) { maxsym = sy; distinct++; }
+                        if (nlit > 0 && distinct == 1) mode = 1;
+                        else if (nlit >= 64 && maxsym < 128) {
+                            int mb = zke_huf_lengths(cnt[j], (int)maxsym + 1, &hbuild[lane & (NHB - 1)], hw[j].len);
+                            if (mb > 0) { zke_huf_codes(&hw[j], (int)maxsym + 1, mb); mode = 2; s_maxbits[j] = (uint32_t)mb; s_tree[j] = maxsym; }
+                        }
+                        s_lit_mode[j] = mode;
+                    }
+                }
+            }
+
+            ZKE_ECLK(3);
+            // serial bit writers of the literals: lane = (block, stream)
+            {
+                const uint32_t j = lane >> 2, k = lane & 3;
+                if (j < nb && s_lit_mode[j] == 2) {
+                    const ZkEncBlock &blk = blocks[b0 + j];
+                    const uint32_t nlit = blk.nlit, q = (nlit + 3) / 4, scap = q + (q >> 1) + 16;
+                    const uint32_t n_k = k < 3 ? q : nlit - 3 * q;
+                    const uint8_t *sp = lits + blk.lit_base + k * q;
+                    // last symbol first; the stream is read 8 bytes at a time, three words ahead (the loads are unconditional --
+                    // a clamped address reads the stream's first bytes again -- so the waits count the stores exactly)
+                    ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + k * scap, scap - 8);
+                    const ZkHufCode &h = hw[j];
+                    uint32_t i = n_k;
+                    for (uint32_t r = n_k & 7; r; r--) { const uint32_t sy = sp[--i]; b.put(h.code[sy], h.len[sy]); b.flush(); }
+                    auto ldw = [&](uint32_t at) { return zk_ld64(sp + (at >= 8 ? at - 8 : 0)); };       // symbols [at - 8, at)
+                    auto word = [&](uint64_t w) {
+#pragma unroll
+                        for (int t = 7; t >= 0; t--) {
+                            const uint32_t sy = (uint32_t)(w >> (8 * t)) & 0xFF;
+                            b.put(h.code[sy], h.len[sy]);                                       // <= 11 bits each
+                            if ((t & 3) == 0) b.flush();
+                        }
+                    };
+                    // the next iteration's three words are requested before this iteration's first store and moved over after its
+                    // last one: the wait for them counts exactly the 6 stores in between, never a store's acknowledgement
+                    // (rotating the registers instead lets the compiler hoist a use to the loop top, behind the previous stores)
+                    uint64_t w0 = ldw(i), w1 = ldw(i >= 8 ? i - 8 : 0), w2 = ldw(i >= 16 ? i - 16 : 0);
+                    asm volatile("" :: "v"(w0), "v"(w1), "v"(w2));                                // arrived before the loop: no pending state to merge
+                    while (i >= 24) {
+                        const uint64_t n0 = ldw(i - 24), n1 = ldw(i >= 32 ? i - 32 : 0), n2 = ldw(i >= 40 ? i - 40 : 0);
+                        word(w0); word(w1); word(w2);
+                        w0 = n0; w1 = n1; w2 = n2;
+                        i -= 24;
+                    }
+                    if (i >= 8) word(w0);
+                    if (i >= 16) word(w1);
+                    s_sizes[j][k] = b.close();
+                }
+
+            }
+            ZKE_ECLK(4);
         }
     }
-    ZKE_ECLK(2);
-    // literal mode + Huffman code: two rounds of 8 blocks, block j on lanes j % 8 and j % 8 + 8 of wave 0 (the second
-    // lane shadows the first with identical LDS writes: >= 16 active lanes, see zk_decode.hip)
-    for (uint32_t round = 0; round < ZKE_ENT_BLOCKS / NHB; round++) {
-        if (tid < ZKE_ENT_BLOCKS) {
-            const uint32_t j = (tid & (NHB - 1)) + NHB * round;
-            if (j < nb) {
-                const uint32_t nlit = blocks[b0 + j].nlit;
-                // literal mode: 1 = RLE, 2 = Huffman (4 streams), 0 = raw      (oracle encode_literals)
-                uint32_t mode = 0, maxsym = 0, distinct = 0;
-                for (uint32_t sy = 0; sy < 256; sy++) if (cnt[j][sy]) { maxsym = sy; distinct++; }
-                if (nlit > 0 && distinct == 1) mode = 1;
-                else if (nlit >= 64 && maxsym < 128) {
-                    int mb = zke_huf_lengths(cnt[j], (int)maxsym + 1, &hbuild[tid & (NHB - 1)], hw[j].len);
-                    if (mb > 0) { zke_huf_codes(&hw[j], (int)maxsym + 1, mb); mode = 2; s_maxbits[j] = (uint32_t)mb; s_tree[j] = maxsym; }
-                }
-                s_lit_mode[j] = mode;
-            }
-        }
-        __syncthreads();
-    }
-    ZKE_ECLK(3);
-    // serial bit writers: wave 0 = 4 literal streams of each block, wave 1 = the sequence bitstream of each block
-    if (wave == 0) {
-        const uint32_t j = lane >> 2, k = lane & 3;
-        if (j < nb && s_lit_mode[j] == 2) {
-            const ZkEncBlock &blk = blocks[b0 + j];
-            const uint32_t nlit = blk.nlit, q = (nlit + 3) / 4, scap = q + (q >> 1) + 16;
-            const uint32_t n_k = k < 3 ? q : nlit - 3 * q;
-            const uint8_t *sp = lits + blk.lit_base + k * q;
-            // last symbol first; the stream is read 8 bytes at a time, three words ahead (the loads are unconditional --
-            // a clamped address reads the stream's first bytes again -- so the waits count the stores exactly)
-            ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + k * scap, scap - 8);
-            const ZkHufCode &h = hw[j];
-            uint32_t i = n_k;
-            for (uint32_t r = n_k & 7; r; r--) { const uint32_t sy = sp[--i]; b.put(h.code[sy], h.len[sy]); b.flush(); }
-            auto ldw = [&](uint32_t at) { return zk_ld64(sp + (at >= 8 ? at - 8 : 0)); };       // symbols [at - 8, at)
-            auto word = [&](uint64_t w) {
-#pragma unroll
-                for (int t = 7; t >= 0; t--) {
-                    const uint32_t sy = (uint32_t)(w >> (8 * t)) & 0xFF;
-                    b.put(h.code[sy], h.len[sy]);                                       // <= 11 bits each
-                    if ((t & 3) == 0) b.flush();
-                }
-            };
-            // the next iteration's three words are requested before this iteration's first store and moved over after its
-            // last one: the wait for them counts exactly the 6 stores in between, never a store's acknowledgement
-            // (rotating the registers instead lets the compiler hoist a use to the loop top, behind the previous stores)
-            uint64_t w0 = ldw(i), w1 = ldw(i >= 8 ? i - 8 : 0), w2 = ldw(i >= 16 ? i - 16 : 0);
-            asm volatile("" :: "v"(w0), "v"(w1), "v"(w2));                                // arrived before the loop: no pending state to merge
-            while (i >= 24) {
-                const uint64_t n0 = ldw(i - 24), n1 = ldw(i >= 32 ? i - 32 : 0), n2 = ldw(i >= 40 ? i - 40 : 0);
-                word(w0); word(w1); word(w2);
-                w0 = n0; w1 = n1; w2 = n2;
-                i -= 24;
-            }
-            if (i >= 8) word(w0);
-            if (i >= 16) word(w1);
-            s_sizes[j][k] = b.close();
-        }
-    } else if (wave == 1 && lane < ZKE_ENT_BLOCKS) {
-        const uint32_t j = lane;
-        uint32_t sz = 0;
-        if (j < nb && blocks[b0 + j].nseq) {
-            // the tables come out of LDS when the block belongs to the workgroup's first frame (the rule: 16 blocks of one
-            // frame per workgroup), out of HBM for the blocks of another frame in a mixed workgroup
-            if (blocks[b0 + j].frame == frame_a) sz = zke_write_sequences(T, blocks[b0 + j], seqs, mpos, scratch);
-            else sz = zke_write_sequences(ftab[blocks[b0 + j].frame], blocks[b0 + j], seqs, mpos, scratch);
-        }
-        s_sizes[lane][4] = sz;
-    }
-    ZKE_ECLK(4);
     __syncthreads();
     ZKE_ECLK(5);
     // layout of every block payload (lane j of wave 0)
@@ -635,12 +650,12 @@ void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *s
     else ZKE_GO(15, 1, 4096, false);
 #undef ZKE_GO
 }
-void zk_launch_enc_fse_build(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, const uint64_t *seqs,
+void zk_launch_enc_fse_build(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, uint64_t *seqs, uint32_t *mpos,
                              const ZkEncTables *predef, ZkEncTables *ftab)
 {
     (void)src;
     static const bool only_predef = getenv("ZK_ENC_PREDEF") != nullptr;      // experiments: the predefined tables for every frame
-    hipLaunchKernelGGL(zk_k_enc_fse_build, dim3(nframes), dim3(1024), 0, st, frames, blocks, seqs, predef, ftab, only_predef ? 0xFFFFFFFFu : ZKE_FSE_MIN_SEQ);
+    hipLaunchKernelGGL(zk_k_enc_fse_build, dim3(nframes), dim3(1024), 0, st, frames, blocks, seqs, mpos, predef, ftab, only_predef ? 0xFFFFFFFFu : ZKE_FSE_MIN_SEQ);
 }
 void zk_launch_enc_entropy(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks, uint32_t nblocks,
                            uint64_t *seqs, uint32_t *mpos, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *ftab)

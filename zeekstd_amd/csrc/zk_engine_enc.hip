@@ -141,7 +141,7 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
     ZK_HIP(hipMemcpyAsync(e->enc_seg.p, segs, (size_t)nseg * sizeof(ZkEncFrame), hipMemcpyHostToDevice, st));
     { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, (const ZkEncFrame *)e->enc_seg.p, nseg, dbl, (uint64_t *)e->enc_b.p, (uint8_t *)e->enc_c.p, a.level, ldm); }
     ZkEncTables *ftab = (ZkEncTables *)e->enc_f.p;
-    { zk_kernel_timer t(e, ZK_K_ENC_FSE_BUILD, st); zk_launch_enc_fse_build(st, src, dfr, nf, dbl, (const uint64_t *)e->enc_b.p, dtab, ftab); }
+    { zk_kernel_timer t(e, ZK_K_ENC_FSE_BUILD, st); zk_launch_enc_fse_build(st, src, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), dtab, ftab); }
     { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, ftab); }
     zk_launch_enc_sizes(st, dfr, nf, dbl, ftab, a.checksum, c64, (uint32_t *)a.d_c_sizes, (uint32_t *)a.d_d_sizes);
     zk_launch_scan64(st, c64, nf, out_off);
