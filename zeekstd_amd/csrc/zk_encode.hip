@@ -549,6 +549,20 @@ __global__ __launch_bounds__(1024) void zk_k_scan64(const uint64_t *in, uint32_t
 // Workgroups [0, nframes): what belongs to a frame as a whole (magic + header, the empty frame's bytes, the checksum).
 // Workgroups [nframes, nframes + nblocks): one block each -- its header and payload go to out_off[frame] + out_at (the
 // prefix sums of zk_k_enc_sizes), so a frame of 128 MiB is copied by 4096 workgroups, not by one.
+// n bytes by the 256 lanes of a workgroup: 16 bytes per lane and step (any alignment), four steps in flight, the last bytes one by one
+__device__ __forceinline__ void zke_copy_wg(uint8_t *dst, const uint8_t *from, uint32_t n, uint32_t tid)
+{
+    const uint32_t nq = n >> 4;
+    for (uint32_t b0 = 0; b0 < nq; b0 += 4 * 256) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = b0 + u * 256 + tid; memcpy(&v[u], from + 16 * (size_t)(i < nq ? i : 0), 16); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = b0 + u * 256 + tid; if (i < nq) memcpy(dst + 16 * (size_t)i, &v[u], 16); }
+    }
+    const uint32_t t = 16 * nq + tid;
+    if (t < n) dst[t] = from[t];
+}
 __global__ __launch_bounds__(256) void zk_k_enc_assemble(const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, const ZkEncTables *ftab,
                                                          const uint8_t *scratch, const uint64_t *out_off, const uint64_t *c_size64, const uint64_t *hashes,
                                                          int checksum, uint8_t *dst)
@@ -583,15 +597,15 @@ __global__ __launch_bounds__(256) void zk_k_enc_assemble(const uint8_t *src, con
         const ZkEncTables &ft = ftab[blk.frame];
         const uint8_t *from = scratch + blk.scratch_base;
         const uint32_t extra = ft.dlen[0] + ft.dlen[1] + ft.dlen[2], body = blk.csize - extra, mo = blk.modes_off;
-        for (uint32_t i = tid; i < mo; i += 256) o[p + i] = from[i];
+        zke_copy_wg(o + p, from, mo, tid);
         if (tid == 0) o[p + mo] = (uint8_t)zke_modes_byte(ft.custom, 2);
         uint32_t w = mo + 1;
         for (int t = 0; t < 3; t++) { for (uint32_t i = tid; i < ft.dlen[t]; i += 256) o[p + w + i] = ft.desc[t][i]; w += ft.dlen[t]; }
-        for (uint32_t i = mo + 1 + tid; i < body; i += 256) o[p + extra + i] = from[i];
+        if (body > mo + 1) zke_copy_wg(o + p + extra + mo + 1, from + mo + 1, body - (mo + 1), tid);
     } else {
         const uint8_t *from = blk.mode == 2 ? scratch + blk.scratch_base : src + fr.src_off + blk.bs;
         const uint32_t n = blk.mode == 2 ? blk.csize : blk.bsz;
-        for (uint32_t i = tid; i < n; i += 256) o[p + i] = from[i];
+        zke_copy_wg(o + p, from, n, tid);
     }
 }
 
