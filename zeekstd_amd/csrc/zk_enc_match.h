@@ -79,6 +79,20 @@ __device__ __forceinline__ uint32_t zke_common16(const uint32_t *ring, uint32_t 
                        o2 ^ __builtin_amdgcn_alignbyte(a3, a2, sh), o3 ^ __builtin_amdgcn_alignbyte(a4, a3, sh));
 }
 
+// The 20 bytes x[0 .. 4] are a lane's own bytes xor the bytes some distance before them: out[k] = the number of zero bytes from byte
+// k on (k = 0 .. 3, at most 16) = how far the match at that distance goes from the lane's position k.
+__device__ __forceinline__ void zke_runs4(const uint32_t x[5], uint32_t out[4])
+{
+    const uint32_t g = zke_first16(x[1], x[2], x[3], x[4]) + 4;           // first non-zero byte at or behind byte 4 (20: none)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t w = k ? x[0] & (0xFFFFFFFFu << (8 * k)) : x[0];
+        const uint32_t f = (uint32_t)(__ffs((int)w) - 1) >> 3;            // first non-zero byte of the first word at or behind byte k (none: huge)
+        const uint32_t nz = f < g ? f : g;
+        out[k] = nz - k < ZKE_PARCAP ? nz - k : ZKE_PARCAP;
+    }
+}
+
 // Table forms.
 // 16-bit entries, two per word (HLOG 15: what fits beside the ring): the low 16 bits of a position.  History: the numerically
 // largest position wins a slot (positions < 65536, the empty entry 0 loses).  A step [ls, ls + span): the SMALLEST position
@@ -448,26 +462,35 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     if (tfar && tfar != R) { ok2 = far_ok(tfar); zke_far_xor(ldm, ap0 - (int64_t)tfar, ok2, own, x2); }      // uniform per wave
                     else tfar = 0;
                 }
+                // offset 1 and offset R: the run of equal bytes from each of my four positions out of the 20-byte windows, once per window
+                uint32_t r1[4], rr[4];
+                zke_runs4(x1, r1); zke_runs4(xr, rr);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t p = P0 + k;
                     const uint32_t n = p < te ? (te - p < ZKE_PARCAP ? te - p : ZKE_PARCAP) : 0;   // a match may not leave the tile
-                    uint32_t bl = 0, bo = 0, l;
-                    l = lf[k] < n ? lf[k] : n; if (vf[k] && l >= minmatch) { bl = l; bo = df[k]; }
-                    l = ln[k] < n ? ln[k] : n; if (vn[k] && l >= minmatch && l >= bl) { bl = l; bo = dn[k]; }
-                    if (LDM) {
+                    const uint32_t cf = lf[k] < n ? lf[k] : n, cn = ln[k] < n ? ln[k] : n, c1 = r1[k] < n ? r1[k] : n, cr = rr[k] < n ? rr[k] : n;
+                    const bool okf = vf[k] && cf >= minmatch, okn = vn[k] && cn >= minmatch, ok1 = p >= 1 && c1 >= 4,
+                               okr = vr0 && (farR ? okR : R <= p) && cr >= 4;
+                    if (!LDM) {
+                        // the longest wins, on ties the later of far, near, offset 1, R: one key per candidate (length | rank | offset), the largest key
+                        const uint32_t kf = okf ? (cf << 18) | df[k] : 0u, kn = okn ? (cn << 18) | (1u << 16) | dn[k] : 0u,
+                                       k1 = ok1 ? (c1 << 18) | (2u << 16) | 1u : 0u, kr = okr ? (cr << 18) | (3u << 16) | R : 0u;
+                        uint32_t m = kf > kn ? kf : kn;
+                        m = m > k1 ? m : k1; m = m > kr ? m : kr;
+                        best[4 * tid + k] = (m >> 18) | ((m & 0xFFFFu) << 5);           // positions past the tile's end: length 0
+                    } else {
+                        uint32_t bl = 0, bo = 0;
+                        if (okf) { bl = cf; bo = df[k]; }
+                        if (okn && cn >= bl) { bl = cn; bo = dn[k]; }
                         if (hoff[k]) { bl = ZKE_PARCAP; bo = hoff[k]; }                     // (16 equal bytes inside the tile)
-                        l = zke_first16(__builtin_amdgcn_alignbyte(x2[1], x2[0], (uint32_t)k), __builtin_amdgcn_alignbyte(x2[2], x2[1], (uint32_t)k),
-                                        __builtin_amdgcn_alignbyte(x2[3], x2[2], (uint32_t)k), __builtin_amdgcn_alignbyte(x2[4], x2[3], (uint32_t)k));
-                        if (tfar && ok2 && tabled[k] && n == ZKE_PARCAP && l == ZKE_PARCAP) { bl = ZKE_PARCAP; bo = tfar; }
+                        const uint32_t l2 = zke_first16(__builtin_amdgcn_alignbyte(x2[1], x2[0], (uint32_t)k), __builtin_amdgcn_alignbyte(x2[2], x2[1], (uint32_t)k),
+                                                        __builtin_amdgcn_alignbyte(x2[3], x2[2], (uint32_t)k), __builtin_amdgcn_alignbyte(x2[4], x2[3], (uint32_t)k));
+                        if (tfar && ok2 && tabled[k] && n == ZKE_PARCAP && l2 == ZKE_PARCAP) { bl = ZKE_PARCAP; bo = tfar; }
+                        if (ok1 && c1 >= bl) { bl = c1; bo = 1; }
+                        if (okr && cr >= bl) { bl = cr; bo = R; }
+                        best[4 * tid + k] = bl | (bo << 5);
                     }
-                    l = zke_first16(__builtin_amdgcn_alignbyte(x1[1], x1[0], (uint32_t)k), __builtin_amdgcn_alignbyte(x1[2], x1[1], (uint32_t)k),
-                                    __builtin_amdgcn_alignbyte(x1[3], x1[2], (uint32_t)k), __builtin_amdgcn_alignbyte(x1[4], x1[3], (uint32_t)k));   // offset 1
-                    l = l < n ? l : n; if (p >= 1 && l >= 4 && l >= bl) { bl = l; bo = 1; }
-                    l = zke_first16(__builtin_amdgcn_alignbyte(xr[1], xr[0], (uint32_t)k), __builtin_amdgcn_alignbyte(xr[2], xr[1], (uint32_t)k),
-                                    __builtin_amdgcn_alignbyte(xr[3], xr[2], (uint32_t)k), __builtin_amdgcn_alignbyte(xr[4], xr[3], (uint32_t)k));   // offset R
-                    l = l < n ? l : n; if (vr0 && (farR ? okR : R <= p) && l >= 4 && l >= bl) { bl = l; bo = R; }
-                    best[4 * tid + k] = bl | (bo << 5);                                 // positions past the tile's end: length 0
                 }
             }
             ZKE_CLK(5);
