@@ -142,3 +142,4 @@ static void emu_run_workgroup(uint32_t nthreads, uint32_t block, std::function<v
 #define atomicCAS(p, c, v) emu_atomic_cas((p), (c), (v))
 #define atomicMin(p, v) emu_atomic_min((p), (v))
 #define __ffs(x) __builtin_ffs(x)
+#define ZKE_FFBL(x) ((x) ? (uint32_t)__builtin_ctz(x) : 0xFFFFFFFFu)          /* v_ffbl_b32 */

@@ -61,10 +61,16 @@ __device__ __forceinline__ uint64_t zke_ring8(const uint32_t *ring, uint32_t pos
 }
 __device__ __forceinline__ uint32_t zke_ring1(const uint32_t *ring, uint32_t pos) { return ((const uint8_t *)ring)[pos & 0xFFFFu]; }
 
-// index of the first non-zero byte of the 16 bytes x0 .. x3 (16: none).  v_ffbl_b32 yields -1 for 0, and -1 | 32 stays -1.
+// v_ffbl_b32 itself: the index of the lowest set bit, 0xFFFFFFFF for 0 (__ffs() - 1 says the same, but the compiler guards the
+// zero case with a compare and a select of its own: two more instructions per word, 80 per lane and group in this kernel)
+#ifndef ZKE_FFBL
+__device__ __forceinline__ uint32_t zke_ffbl(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+#define ZKE_FFBL(x) zke_ffbl(x)
+#endif
+// index of the first non-zero byte of the 16 bytes x0 .. x3 (16: none): -1 | 32 stays -1.
 __device__ __forceinline__ uint32_t zke_first16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
 {
-    const uint32_t f0 = (uint32_t)(__ffs((int)x0) - 1), f1 = (uint32_t)(__ffs((int)x1) - 1) | 32u, f2 = (uint32_t)(__ffs((int)x2) - 1) | 64u, f3 = (uint32_t)(__ffs((int)x3) - 1) | 96u;
+    const uint32_t f0 = ZKE_FFBL(x0), f1 = ZKE_FFBL(x1) | 32u, f2 = ZKE_FFBL(x2) | 64u, f3 = ZKE_FFBL(x3) | 96u;
     uint32_t r = f0 < f1 ? f0 : f1;
     const uint32_t t = f2 < f3 ? f2 : f3;
     r = r < t ? r : t;
@@ -87,7 +93,7 @@ __device__ __forceinline__ void zke_runs4(const uint32_t x[5], uint32_t out[4])
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t w = k ? x[0] & (0xFFFFFFFFu << (8 * k)) : x[0];
-        const uint32_t f = (uint32_t)(__ffs((int)w) - 1) >> 3;            // first non-zero byte of the first word at or behind byte k (none: huge)
+        const uint32_t f = ZKE_FFBL(w) >> 3;                              // first non-zero byte of the first word at or behind byte k (none: huge)
         const uint32_t nz = f < g ? f : g;
         out[k] = nz - k < ZKE_PARCAP ? nz - k : ZKE_PARCAP;
     }
