@@ -141,6 +141,9 @@ __device__ __forceinline__ uint64_t zke_lowmask(uint32_t n) { return n >= 64 ? ~
 // value of lane (l - d) of the row of 16 lanes; `fill` where the row has no such lane
 #define ZKE_ROW_SHR(v, d, fill) ((uint32_t)__builtin_amdgcn_update_dpp((int)(fill), (int)(v), 0x110 + (d), 0xF, 0xF, false))
 // value of lane (l + d) of the row
+// the same with 0 for a lane the row does not have: bound_ctrl supplies it, the destination needs no value of its own first
+#define ZKE_ROW_SHR0(v, d) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x110 + (d), 0xF, 0xF, true))
+#define ZKE_ROW_SHL0(v, d) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x100 + (d), 0xF, 0xF, true))
 #define ZKE_ROW_SHL(v, d, fill) ((uint32_t)__builtin_amdgcn_update_dpp((int)(fill), (int)(v), 0x100 + (d), 0xF, 0xF, false))
 
 // own[0..4] ^ the 20 bytes at prefix byte a (long-distance compare of a lane's four positions through HBM).  ok: the 20 bytes
@@ -237,15 +240,15 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
             const uint32_t sv = t < ntiles ? ts_[t] : 0, lv = t < ntiles ? tl_[t] : 0, fo = t < ntiles ? tf_[t] : 0, fm = tfml[par ^ 1][t & 15];
             const uint32_t cn = sv & 0xFF, tail = (sv >> 8) & 0xFFF, tnl = sv >> 20;
             uint32_t y = tail | (cn ? 0x80000000u : 0u), z = cn ? lv : 0;
-#define ZKE_SCAN_STEP(d) { const uint32_t ys = ZKE_ROW_SHR(y, d, 0), zs = ZKE_ROW_SHR(z, d, 0); \
+#define ZKE_SCAN_STEP(d) { const uint32_t ys = ZKE_ROW_SHR0(y, d), zs = ZKE_ROW_SHR0(z, d); \
                            y = (y & 0x80000000u) ? y : (y + (ys & 0x7FFFFFFFu)) | (ys & 0x80000000u); z = z ? z : zs; }
             ZKE_SCAN_STEP(1) ZKE_SCAN_STEP(2) ZKE_SCAN_STEP(4) ZKE_SCAN_STEP(8)
 #undef ZKE_SCAN_STEP
-            const uint32_t ye = ZKE_ROW_SHR(y, 1, 0), ze = ZKE_ROW_SHR(z, 1, 0);            // what lies in front of tile t
+            const uint32_t ye = ZKE_ROW_SHR0(y, 1), ze = ZKE_ROW_SHR0(z, 1);            // what lies in front of tile t
             const uint32_t pend_t = (ye & 0x80000000u) ? ye & 0x7FFFFFFFu : pend + ye, poff_t = ze ? ze : prev_off;
             const bool join = fo && fo == poff_t && pend_t == 0 && ((todo.rel + t * ZKE_TILE) & (ZKE_SEAM - 1)) != 0;
             uint32_t x = (cn - (join ? 1u : 0u)) | (tnl << 16);
-#define ZKE_SCAN_STEP(d) { x += ZKE_ROW_SHR(x, d, 0); }
+#define ZKE_SCAN_STEP(d) { x += ZKE_ROW_SHR0(x, d); }
             ZKE_SCAN_STEP(1) ZKE_SCAN_STEP(2) ZKE_SCAN_STEP(4) ZKE_SCAN_STEP(8)
 #undef ZKE_SCAN_STEP
             // what is in front of my tile = the scans at lane wave - 1; the group's totals = lane 15
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
             uint32_t more0 = 0, whole0 = 0;
             if (__ballot(join)) {                                                   // (most groups have no seam to close)
                 uint32_t ev = join ? fm : 0, pw = join && cn == 1 && tail == 0 ? 1u : 0u;
-#define ZKE_SCAN_STEP(d) { const uint32_t es = ZKE_ROW_SHL(ev, d, 0), ps = ZKE_ROW_SHL(pw, d, 1); ev += pw ? es : 0; pw &= ps; }
+#define ZKE_SCAN_STEP(d) { const uint32_t es = ZKE_ROW_SHL0(ev, d), ps = ZKE_ROW_SHL(pw, d, 1); ev += pw ? es : 0; pw &= ps; }
                 ZKE_SCAN_STEP(1) ZKE_SCAN_STEP(2) ZKE_SCAN_STEP(4) ZKE_SCAN_STEP(8)
 #undef ZKE_SCAN_STEP
                 my_join = (uint32_t)__builtin_amdgcn_readlane((int)(join ? 1u : 0u), (int)wave);
