@@ -324,7 +324,14 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
             uint32_t target = ge + ZKE_GROUP_POS + 64;
             if (target > fend4) target = fend4;
             const uint32_t pq = loaded + 4 * tid;
-            const uint32_t pv = fend >= 4 ? zke_src_dword(base, pq < target ? pq : fend4 - 4, fend) : 0;
+            // (the dword is only REQUESTED here: what zke_src_dword does with it -- the shift of a ragged last dword -- waits until the
+            // ring write, or the wait for the load would sit right here, at the top of every group)
+            // No branch around it either (a record of fewer than 4 bytes reads the segment list instead: unused).
+            const uint32_t pq_ = pq < target ? pq : fend4 - 4;
+            const uint32_t pv_over = fend >= 4 && pq_ + 4 > fend ? pq_ + 4 - fend : 0;
+            const uint8_t *pv_at = fend >= 4 ? base + (pq_ - pv_over) : (const uint8_t *)segs;
+            uint32_t pv_raw;
+            memcpy(&pv_raw, pv_at, 4);
 
             // ---- 1 + 2: lookups and insertions, step by step
             const uint32_t P0 = gs + 4 * tid;                                       // my four positions: P0 .. P0 + 3, tile = wave
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     ZKE_CLK(1);
                     ZKE_LDS_BARRIER();
                     ZKE_CLK(2);
-                    if (s == 0) { if (pq < target) zke_ring_put(ring, (pq >> 2) & 16383u, pv); loaded = target; }
+                    if (s == 0) { if (pq < target) zke_ring_put(ring, (pq >> 2) & 16383u, pv_raw >> (8 * pv_over)); loaded = target; }
                     // A position whose hash also belongs to one of the four positions before it cannot win its slot (the smaller
                     // position does): it stays out of the race.  On runs of equal bytes or short periods all lanes of a step
                     // would otherwise fight over a few LDS words.  The table ends the step in the same state.
