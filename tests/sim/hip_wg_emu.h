@@ -138,6 +138,7 @@ static void emu_run_workgroup(uint32_t nthreads, uint32_t block, std::function<v
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_dpp((old), (src), (ctrl))
 #define __builtin_amdgcn_alignbyte(hi, lo, s) emu_alignbyte((hi), (lo), (s))
 #define __builtin_amdgcn_wave_barrier() emu_wave_sync()
+#define ZKE_WAVE_SYNC() emu_wave_sync()
 #define __builtin_amdgcn_readfirstlane(v) (v)          /* only used on values that are uniform across the wave */
 #define atomicCAS(p, c, v) emu_atomic_cas((p), (c), (v))
 #define atomicMin(p, v) emu_atomic_min((p), (v))

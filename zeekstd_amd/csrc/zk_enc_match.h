@@ -42,6 +42,12 @@ static_assert(ZKE_PARCAP == 16 && ZKE_TSEQ_N >= 64, "the comparisons measure 16 
 #define ZKE_CLK_BEGIN() do { } while (0)
 #define ZKE_CLK_END() do { } while (0)
 #endif
+#ifndef ZKE_WAVE_SYNC
+// Between a wave's LDS writes and its reads of what OTHER lanes of the same wave wrote: the hardware runs a wave's LDS operations in
+// order, so all that is needed is that the compiler keeps the order.  (__builtin_amdgcn_wave_barrier() also made the wave wait for
+// every global store it had in flight -- the stitch's -- once per group.)
+#define ZKE_WAVE_SYNC() asm volatile("" ::: "memory")
+#endif
 #ifndef ZKE_LDS_BARRIER
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load / store in flight
 #define ZKE_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -295,14 +301,18 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                 const uint64_t rec = (uint64_t)(ll | (ml << 16)) | ((uint64_t)code << 32);
                 uint64_t *at = &todo.sq[my_base + lane - my_join];
                 if (ends_tile && my_open) { held = true; held_e = rec; held_at = at; }
+#ifndef ZKE_KNOCK_STORES
                 else *at = rec;
+#endif
             }
             // the tile's literals: four bytes per lane (an unaligned dword store), the last bytes one by one
             const uint32_t *tw4 = &best[wave * ZKE_TILE];
             const uint8_t *tl = (const uint8_t *)tw4;
             uint8_t *o = todo.lt + my_lit;
+#ifndef ZKE_KNOCK_STORES
             if (4 * lane + 4 <= my_nl) { const uint32_t w4 = tw4[lane]; memcpy(o + 4 * lane, &w4, 4); }
             else for (uint32_t i = 4 * lane; i < my_nl; i++) o[i] = tl[i];
+#endif
         }
         if (todo.last) {                                                            // the block is complete
             if (tid == 0) { todo.blk->nseq = nseq; todo.blk->nlit = nlit; }
@@ -407,7 +417,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
 
             // ---- the group before this one: stitch its tiles, store my tile's sequences and literals
             if (todo.valid) stitch();
-            __builtin_amdgcn_wave_barrier();
+            ZKE_WAVE_SYNC();
             const uint32_t R = probe;
             ZKE_CLK(8);
             // ---- 3a: comparisons out of the ring -> best[].  16 bytes per candidate, no branches: an invalid candidate
@@ -511,7 +521,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
             }
             ZKE_CLK(5);
             // ---- 3b: wave w parses tile w (it wrote that slice of best[] itself: LDS operations of a wave complete in order)
-            __builtin_amdgcn_wave_barrier();
+            ZKE_WAVE_SYNC();
             if (ts < ge) {                                                              // uniform per wave
                 uint8_t *tl = (uint8_t *)&best[wave * ZKE_TILE];                        // the tile's literal bytes, behind the entries already read
                 uint32_t skip = 0, c = 0, nl = 0, aend = 0, lastoff = 0;                // tile-relative: first position not covered yet; sequences; literals; end / offset of the last match
