@@ -525,25 +525,41 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
             if (ts < ge) {                                                              // uniform per wave
                 uint8_t *tl = (uint8_t *)&best[wave * ZKE_TILE];                        // the tile's literal bytes, behind the entries already read
                 uint32_t skip = 0, c = 0, nl = 0, aend = 0, lastoff = 0;                // tile-relative: first position not covered yet; sequences; literals; end / offset of the last match
-                for (uint32_t wb = 0; ts + wb < te; wb += 64) {
-                    const uint32_t pos = wb + lane, p = ts + pos;
-                    const bool in = p < te;
+                // The tile in four passes of 64 positions, in three sweeps, so that what does not depend on the walk -- the LDS reads,
+                // the ballots, the emission -- is not strung between the walks of consecutive passes:
+                //   A  every pass: best[] entries, candidate masks, per-lane next-candidate table
+                //   B  the walk, pass after pass (the only serial part: where a match ends decides which candidate is next)
+                //   C  every pass: sequences and literal bytes, all lanes at once
+                // (a pass past the tile's end has no candidates and no literals: best[] holds length 0 there)
+                uint32_t pv[4], plen[4], pnx[4], pskip0[4];
+                uint64_t pcand[4], pcap[4], ptaken[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t pos = 64 * u + lane, p = ts + pos;
                     const uint32_t v = best[wave * ZKE_TILE + pos];                     // length 0 past the tile's end
-                    uint32_t len = v & 0x1F;
+                    const uint32_t len = v & 0x1F;
                     bool cand = len != 0;
                     if (LAZY) {
                         const uint32_t l1 = best[wave * ZKE_TILE + pos + 1 < ZKE_GROUP_POS ? wave * ZKE_TILE + pos + 1 : 0] & 0x1F;
                         const uint32_t l2 = best[wave * ZKE_TILE + pos + 2 < ZKE_GROUP_POS ? wave * ZKE_TILE + pos + 2 : 0] & 0x1F;
                         if ((p + 1 < te && l1 > len) || (p + 2 < te && l2 > len + 1)) cand = false;
                     }
-                    const uint32_t skip0 = skip;                                        // positions below it are covered by a match of the pass before
-                    const uint64_t candm = __ballot(cand), capped = __ballot(cand && len == ZKE_PARCAP);
+                    pv[u] = v; plen[u] = len;
+                    pcand[u] = __ballot(cand); pcap[u] = __ballot(cand && len == ZKE_PARCAP);
                     // every lane: the first candidate at or behind the end of its own match (64: none in this pass); the walk
                     // below then costs the scalar unit a handful of instructions per match
                     const uint32_t el = lane + len;
-                    const uint64_t behind = candm & (el >= 64 ? 0ull : ~0ull << el);
-                    const uint32_t nx = behind ? (uint32_t)__builtin_ctzll(behind) : 64u;
-                    const uint32_t pre = skip0 > wb ? skip0 - wb : 0;
+                    const uint64_t behind = pcand[u] & (el >= 64 ? 0ull : ~0ull << el);
+                    pnx[u] = behind ? (uint32_t)__builtin_ctzll(behind) : 64u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t wb = 64 * u;
+                    const uint64_t candm = pcand[u], capped = pcap[u];
+                    const uint32_t v = pv[u], nx = pnx[u];
+                    uint32_t len = plen[u];
+                    pskip0[u] = skip;                                                   // positions below it are covered by a match of the pass before
+                    const uint32_t pre = skip > wb ? skip - wb : 0;
                     const uint64_t open = candm & (pre >= 64 ? 0ull : ~0ull << pre);
                     uint32_t f = open ? (uint32_t)__builtin_ctzll(open) : 64u, lastf = 64;
                     uint64_t taken = 0;
@@ -577,9 +593,17 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                         } else f = (uint32_t)__builtin_amdgcn_readlane((int)nx, (int)f);
                     }
                     if (taken) skip = wb + lastf + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)lastf);
+                    ptaken[u] = taken; plen[u] = len;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
                     // emission, all lanes at once: a taken lane's sequence index = sequences so far + taken lanes below it; its
                     // literal length = its position - the end of the taken lane before it; a lane is a literal unless a match of
                     // an earlier pass, the taken lane before it, or its own match covers it
+                    const uint32_t pos = 64 * u + lane, p = ts + pos;
+                    const bool in = p < te;
+                    const uint64_t taken = ptaken[u];
+                    const uint32_t v = pv[u], len = plen[u], skip0 = pskip0[u];
                     const uint64_t below = taken & lane_lt;
                     const uint32_t myend = pos + len;
                     const uint32_t prevlane = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
@@ -590,8 +614,10 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                         tseq[wave][c + (uint32_t)__builtin_popcountll(below)] = (uint64_t)((pos - prev_end) | (len << 12)) | ((uint64_t)(v >> 5) << 32);
                     }
                     if (taken) {
-                        c += (uint32_t)__builtin_popcountll(taken); aend = skip;
-                        lastoff = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(63u - (uint32_t)__builtin_clzll(taken))) >> 5;
+                        const uint32_t lastl = 63u - (uint32_t)__builtin_clzll(taken);
+                        c += (uint32_t)__builtin_popcountll(taken);
+                        aend = 64 * u + lastl + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)lastl);
+                        lastoff = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lastl) >> 5;
                     }
                     const uint64_t litm = __ballot(in && !mine && pos >= skip0 && !(below && pos < pe));
                     if ((litm >> lane) & 1) tl[nl + (uint32_t)__builtin_popcountll(litm & lane_lt)] = (uint8_t)zke_ring1(ring, p);
