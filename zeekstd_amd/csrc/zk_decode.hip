@@ -241,7 +241,7 @@ __device__ __forceinline__ void zk_huf_group(uint32_t group, const uint8_t *comp
         __syncthreads();
         if (decoder) {
             if (have) ok = zk_huf_decode_stream(tab, mb, sbase, slen, sdst, sn, real, &mail, t);
-            *(volatile uint32_t *)&s_done = 1;
+            zk_lds_st<uint32_t>(&s_done, 1u);
         } else if (have && real) {
             zk_huf_companion(sbase, slen, sdst + ((0 - (uintptr_t)sdst) & 7), &mail, t, &s_done);     // packs start at the 8-byte aligned output position
         }
@@ -355,10 +355,9 @@ __device__ __forceinline__ void zk_fse_quad_group(uint32_t group, const uint8_t 
     __syncthreads();
     if (!valid) return;
     if (toucher) {
-        volatile uint32_t *live = &s_live, *pp = &s_pos[slot];
         uint32_t last = 0, sink = 0;
-        while (*live) {
-            const uint32_t p = *pp;
+        while (zk_lds_ld<uint32_t>(&s_live)) {
+            const uint32_t p = zk_lds_ld<uint32_t>(&s_pos[slot]);
             if (p != last) {
                 last = p;
                 const uint32_t lo = b.src + b.seq_off;                  // nothing of the stream lies below the sequence header
@@ -556,7 +555,7 @@ __global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const u
     const uint32_t bs_off = active ? zk_fse_share_offset(pk, bi, b, &share) : 0;
     if (walker) {
         zk_seq_walk<ZK_FSEP_RING, ZkRevL, ZkCells64>(comp, b, bs_off, T.ll, T.of, T.ml, share.al, ring[lane], seqs, llv, mlv, true, &coop, active, lane, &feed);
-        *(volatile uint32_t *)&s_done = 1;
+        zk_lds_st<uint32_t>(&s_done, 1u);
         if (!active) return;
         ZkBlock *o = &blocks[bi];
         o->out_size = b.out_size;
@@ -568,14 +567,13 @@ __global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const u
         const uint8_t *base = comp + b.src + bs_off;
         const uint32_t len = b.bsize - bs_off, nwords = ZkRevL::word_count(base, len);
         const uint8_t *ptr = reinterpret_cast<const uint8_t *>((((uintptr_t)base + len) + 7) & ~(uintptr_t)7) - 8;
-        volatile uint32_t *taken = &feed.taken[lane], *filled = &feed.filled[lane], *done = &s_done;
         uint32_t f = 0;
-        while (f < nwords && !*done) {
-            if (f - *taken < ZK_REVL_RING) {
+        while (f < nwords && !zk_lds_ld<uint32_t>(&s_done)) {
+            if (f - zk_lds_ld<uint32_t>(&feed.taken[lane]) < ZK_REVL_RING) {
                 const uint64_t w = *reinterpret_cast<const uint64_t *>(ptr);
-                *(volatile uint64_t *)&feed.ring[f % ZK_REVL_RING][lane] = w;
+                zk_lds_st<uint64_t>(&feed.ring[f % ZK_REVL_RING][lane], w);
                 f++; ptr -= 8;
-                *filled = f;
+                zk_lds_st<uint32_t>(&feed.filled[lane], f);
             } else __builtin_amdgcn_s_sleep(1);
         }
     }

@@ -25,6 +25,18 @@
 #define ZK_HDM inline
 #endif
 
+// Flags, mailboxes and rings that waves of one workgroup pass through LDS.  A `volatile` access through a generic pointer is a
+// FLAT instruction with system scope on the device: it counts on vmcnt as well as lgkmcnt, and the wait for it also waits for
+// every global store the wave has in flight (a store's acknowledgement is ~1 us away) -- the serial walkers issue such stores
+// all the time.  Through an LDS-typed pointer the same access is a ds_read / ds_write that knows lgkmcnt only.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZK_LDS_AS __attribute__((address_space(3)))
+#else
+#define ZK_LDS_AS
+#endif
+template <typename T> ZK_HD T zk_lds_ld(const volatile void *p) { return *(const volatile ZK_LDS_AS T *)(p); }
+template <typename T> ZK_HD void zk_lds_st(volatile void *p, T v) { *(volatile ZK_LDS_AS T *)(p) = v; }
+
 // ZSTD_ErrorCode values used on this path (per-frame status words; 0 = ok)
 enum : uint32_t {
     ZK_OK = 0,
@@ -899,11 +911,10 @@ struct ZkRevL {
     ZK_HDM uint64_t take()
     {
         if (k >= nwords) { k++; return 0; }
-        volatile uint32_t *f = &sh->filled[lane];
-        while (*f <= k) {}
-        const uint64_t w = *(volatile uint64_t *)&sh->ring[k % ZK_REVL_RING][lane];
+        while (zk_lds_ld<uint32_t>(&sh->filled[lane]) <= k) {}
+        const uint64_t w = zk_lds_ld<uint64_t>(&sh->ring[k % ZK_REVL_RING][lane]);
         k++;
-        *(volatile uint32_t *)&sh->taken[lane] = k;
+        zk_lds_st<uint32_t>(&sh->taken[lane], k);
         return w;
     }
     ZK_HDM void advance() { if (c >= 64) { A = B; B = take(); c -= 64; } }
@@ -1138,7 +1149,7 @@ ZK_HD void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, ui
 #endif
     for (uint32_t g0 = 0; g0 < nseq; g0 += 16) {
         const uint32_t gend = g0 + 16 < nseq ? g0 + 16 : nseq;
-        if (t == ZK_TAB_LL) *pos_pub = b.src + bs_off + (uint32_t)(r.remaining() >> 3);       // for the toucher wave (zk_k_fse_quad)
+        if (t == ZK_TAB_LL) zk_lds_st<uint32_t>(pos_pub, b.src + bs_off + (uint32_t)(r.remaining() >> 3));       // for the toucher wave (zk_k_fse_quad)
         for (uint32_t i = g0; i < gend; i++) {
             const uint32_t vv = vt[CP::sym(c)];
             // the previous step's record goes to the ring now, behind this step's first LDS read (all three lanes, same
@@ -1192,7 +1203,7 @@ ZK_HD void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, ui
         ring[(gend - 1) & 15] = qp;
         ZK_WAVE_BARRIER();
         // the quad's three lanes share the stores of the group's records
-        for (uint32_t k = g0 + t; k < gend; k += 3) seqs[k] = *reinterpret_cast<const volatile ZkSeqP *>(&ring[k & 15]);
+        for (uint32_t k = g0 + t; k < gend; k += 3) seqs[k] = zk_lds_ld<ZkSeqP>(&ring[k & 15]);
         ZK_WAVE_BARRIER();
     }
     bad |= r.remaining() != 0;
