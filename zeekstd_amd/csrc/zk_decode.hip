@@ -394,7 +394,10 @@ __device__ __forceinline__ void zk_fse_quad_group(uint32_t group, const uint8_t 
             }
         }
         __builtin_amdgcn_wave_barrier();
-        zk_seq_walk_quad<ZkRevU, CP, ZkQuadDpp>(comp, b, b.seq_off + 1 + own, t,
+#ifndef ZK_QUAD_RD
+#define ZK_QUAD_RD ZkRevU      // one unaligned 8-byte load per step.  (ZkRevA -- aligned words, three ahead, no wait for the step's own load -- is slower here: 12.9 vs 11.4 ms, its bookkeeping costs more than the load's latency)
+#endif
+        zk_seq_walk_quad<ZK_QUAD_RD, CP, ZkQuadDpp>(comp, b, b.seq_off + 1 + own, t,
                                      t == ZK_TAB_LL ? Tb->ll : t == ZK_TAB_OF ? Tb->of : Tb->ml,
                                      t == ZK_TAB_LL ? llv : t == ZK_TAB_OF ? ofv : mlv, al, Tb->ring, seqs + b.seq_base, &s_pos[slot], bits);
     }
