@@ -135,22 +135,41 @@ __global__ __launch_bounds__(1024) void zk_k_enc_fse_build(const ZkEncFrame *fra
     if (tid >= 64 && tid < 64 + 56) s_mlv[tid - 64] = predef->ml_val[tid - 64];
     __syncthreads();
     uint32_t mine = 0;
+    auto one = [&](uint64_t e, uint64_t *sq, uint32_t *cw, uint32_t k) {
+        const uint32_t ll = (uint32_t)e & 0xFFFF, ml = (uint32_t)(e >> 16) & 0xFFFF, ob = (uint32_t)(e >> 32);
+        const uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
+        atomicAdd(&h[0][llc], 1u); atomicAdd(&h[1][ofc], 1u); atomicAdd(&h[2][mlc], 1u);
+        const uint32_t lv = s_llv[llc], mv = s_mlv[mlc];
+        const uint32_t ln = lv >> 24, mn = mv >> 24;
+        const uint64_t x = (uint64_t)(ll - (lv & 0xFFFFFF)) | ((uint64_t)(ml - (mv & 0xFFFFFF)) << ln) | ((uint64_t)(ob - (1u << ofc)) << (ln + mn));
+        sq[k] = x | ((uint64_t)(ln + mn + ofc) << 56);
+        cw[k] = llc | (mlc << 8) | (ofc << 16);
+        mine++;
+    };
+    // A lane takes sequences tid, tid + 1024, tid + 2048, tid + 3072 of every block (a 32 KiB block of text has ~2300).  The next
+    // block's four records are requested BEFORE this block's stores: loads and stores share one in-order counter, and a load issued
+    // behind a store waits for the store's acknowledgement (64 blocks per frame, one such wait each, were most of this kernel).
+    auto first4 = [&](uint32_t b, uint64_t e4[4]) {
+        const ZkEncBlock &blk = blocks[fr.block_base + (b < fr.n_blocks ? b : 0)];
+        const uint64_t *sq = seqs + blk.seq_base;
+        const uint32_t nseq = b < fr.n_blocks ? blk.nseq : 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t k = tid + u * 1024u; e4[u] = sq[k < nseq ? k : 0]; }
+    };
+    uint64_t e4[4];
+    first4(0, e4);
     for (uint32_t b = 0; b < fr.n_blocks; b++) {
         const ZkEncBlock &blk = blocks[fr.block_base + b];
         uint64_t *sq = seqs + blk.seq_base;
         uint32_t *cw = mpos + blk.seq_base;
-        for (uint32_t i = tid; i < blk.nseq; i += 1024) {
-            const uint64_t e = sq[i];
-            const uint32_t ll = (uint32_t)e & 0xFFFF, ml = (uint32_t)(e >> 16) & 0xFFFF, ob = (uint32_t)(e >> 32);
-            const uint32_t llc = zke_ll_code(ll), mlc = zke_ml_code(ml - 3), ofc = zk_highbit(ob);
-            atomicAdd(&h[0][llc], 1u); atomicAdd(&h[1][ofc], 1u); atomicAdd(&h[2][mlc], 1u);
-            const uint32_t lv = s_llv[llc], mv = s_mlv[mlc];
-            const uint32_t ln = lv >> 24, mn = mv >> 24;
-            const uint64_t x = (uint64_t)(ll - (lv & 0xFFFFFF)) | ((uint64_t)(ml - (mv & 0xFFFFFF)) << ln) | ((uint64_t)(ob - (1u << ofc)) << (ln + mn));
-            sq[i] = x | ((uint64_t)(ln + mn + ofc) << 56);
-            cw[i] = llc | (mlc << 8) | (ofc << 16);
-            mine++;
-        }
+        const uint32_t nseq = blk.nseq;
+        uint64_t n4[4];
+        first4(b + 1, n4);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t k = tid + u * 1024u; if (k < nseq) one(e4[u], sq, cw, k); }
+        for (uint32_t k = tid + 4096; k < nseq; k += 1024) one(sq[k], sq, cw, k);          // (more than 4096 sequences in a block: rare)
+#pragma unroll
+        for (int u = 0; u < 4; u++) e4[u] = n4[u];
     }
     if (mine) atomicAdd(&s_nseq, mine);
     // the predefined set is the starting point (value tables, and whatever stays predefined)
