@@ -36,6 +36,14 @@
 #endif
 template <typename T> ZK_HD T zk_lds_ld(const volatile void *p) { return *(const volatile ZK_LDS_AS T *)(p); }
 template <typename T> ZK_HD void zk_lds_st(volatile void *p, T v) { *(volatile ZK_LDS_AS T *)(p) = v; }
+// a store through a pointer that was itself read from memory (a struct in LDS): the compiler cannot tell where it points and would
+// issue a FLAT store; this says "global"
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZK_GLB_AS __attribute__((address_space(1)))
+#else
+#define ZK_GLB_AS
+#endif
+template <typename T> ZK_HD void zk_glb_st(void *p, T v) { *(ZK_GLB_AS T *)(p) = v; }
 
 // ZSTD_ErrorCode values used on this path (per-frame status words; 0 = ok)
 enum : uint32_t {
@@ -1068,7 +1076,7 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const t
             static_assert(RING == 4 || RING == 8 || RING == 16, "ring");
             for (uint32_t j = 0; j < (uint32_t)RING; j++) {
                 const uint32_t m = (64 / RING) * j + lane / RING, piece = lane % RING, k = g0 + piece;
-                if (k < coop->nseq[m]) coop->seqs[coop->base[m] + k] = coop->ring[m * RING + piece];
+                if (k < coop->nseq[m]) zk_glb_st<ZkSeqP>(&coop->seqs[coop->base[m] + k], zk_lds_ld<ZkSeqP>(&coop->ring[m * RING + piece]));
             }
             continue;
         }
