@@ -123,19 +123,19 @@ __device__ void zk_huf_companion(const uint8_t *base, uint32_t len, uint8_t *dst
     uintptr_t line = ((uintptr_t)base + len) & ~(uintptr_t)127;      // lowest line touched so far (the decoder's init loads cover it)
     uint32_t stored = 0, sink = 0;
     for (;;) {
-        const uint32_t fin = *done;                                  // read BEFORE the state: a pack published before `done` is seen
-        const uint32_t st = mail->state[l];
+        const uint32_t fin = zk_lds_ld<uint32_t>(done);              // read BEFORE the state: a pack published before `done` is seen
+        const uint32_t st = zk_lds_ld<uint32_t>(&mail->state[l]);
         const uint32_t written = st & 0x3fffu;
         bool idle = true;
         const uint32_t avail = (written - stored) & 0x3fffu;
         if (avail >= ZK_HUF_BURST || (fin && avail)) {               // whole bursts while the decoder runs, the rest at its end
             const uint32_t nb = avail < ZK_HUF_BURST ? avail : ZK_HUF_BURST;
             for (uint32_t k = 0; k < nb; k++) {
-                const uint64_t pack = mail->pack[(stored + k) % ZK_HUF_RING][l];
+                const uint64_t pack = zk_lds_ld<uint64_t>(&mail->pack[(stored + k) % ZK_HUF_RING][l]);
                 memcpy(dst + (size_t)(stored + k) * 8, &pack, 8);
             }
             stored += nb;
-            mail->consumed[l] = stored;
+            zk_lds_st<uint32_t>(&mail->consumed[l], stored);
             idle = false;
         }
         const int32_t want = (int32_t)(st >> 14) - 64 - ZK_HUF_AHEAD;

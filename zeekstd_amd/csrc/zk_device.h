@@ -477,7 +477,7 @@ ZK_HD uint64_t zk_hufrd_load(ZkHufRd &r)
 {
     const uint8_t *p = r.ptr < r.lo ? r.lo : r.ptr;
     r.ptr -= 8;
-    return *reinterpret_cast<const uint64_t *>(p);
+    return *(const ZK_GLB_AS uint64_t *)(p);                        // (the compressed buffer: a global load, not a FLAT one)
 }
 ZK_HD uint64_t zk_hufrd_refill(ZkHufRd &r)
 {
@@ -565,9 +565,10 @@ ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const u
         if (mail) {
             if (store) {
                 const uint32_t it = (i - i0) >> 3;
-                while (((it - mail->consumed[mlane]) & 0x3fffu) >= ZK_HUF_RING) {}     // ring full: the companion is behind
-                mail->pack[it % ZK_HUF_RING][mlane] = pack;
-                mail->state[mlane] = zk_huf_mail_state(it + 1, (int32_t)(r.ptr - src));
+                // (LDS-typed accesses: through the generic pointer they were FLAT instructions, each followed by a wait for vmcnt)
+                while (((it - zk_lds_ld<uint32_t>(&mail->consumed[mlane])) & 0x3fffu) >= ZK_HUF_RING) {}     // ring full: the companion is behind
+                zk_lds_st<uint64_t>(&mail->pack[it % ZK_HUF_RING][mlane], pack);
+                zk_lds_st<uint32_t>(&mail->state[mlane], zk_huf_mail_state(it + 1, (int32_t)(r.ptr - src)));
             }
         } else if (store) *reinterpret_cast<uint64_t *>(dst + i) = pack;
         i += 8;
