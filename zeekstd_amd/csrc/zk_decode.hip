@@ -695,6 +695,8 @@ extern "C" void zk_debug_clocks(unsigned long long *out, int reset)
 #else
 #define ZK_CLK(i) do { } while (0)
 #endif
+// workgroup barrier that orders LDS traffic only (no wait for global loads / stores in flight)
+#define ZK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 template <int T, bool PFX, int CAPX = 2>
 __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
                                                const uint32_t *ids, const uint64_t *out_off,
@@ -716,6 +718,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
     __shared__ uint32_t slot_seq[T];
     __shared__ uint32_t longlist[CAP + 1];
     __shared__ uint32_t s_jn, s_nlong;
+    __shared__ uint32_t s_bad[2];                // a lane found a bad record in a tile of this parity (the tile loop's barriers order LDS only)
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
     const ZkFrameInfo fi = infos[f];
     if (fi.status != ZK_OK) return;
@@ -785,9 +788,14 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
             uint32_t ja = 0, ts = 0, prev_end = 0;           // prev_end: out_end of sequence ja - 1
             uint32_t staged_end = nseq + 1 < (uint32_t)CAP ? nseq + 1 : (uint32_t)CAP;      // records [ja, staged_end) are in the ring
             for (uint32_t idx = tid; idx < staged_end; idx += T) { ZkSeqP p0, p1; fetch(idx, p0, p1); settle(idx, p0, p1, bad); }
-            if (tid == 0) { s_jn = staged_end; s_nlong = 0; }        // s_jn starts at "every staged sequence ends inside the tile"
+            if (tid == 0) { s_jn = staged_end; s_nlong = 0; s_bad[0] = 0; s_bad[1] = 0; }        // s_jn starts at "every staged sequence ends inside the tile"
             if (__syncthreads_or(bad)) { err = ZK_E_CORRUPTION; }
             ZK_CLK(0);
+            // Barriers of the tile loop.  __syncthreads() makes a wave wait for everything it has in flight -- also for the
+            // acknowledgement of the tile's stores, about a microsecond away, at the barrier right behind them.  Only the gathers of
+            // the NEXT tile need those bytes (other waves' stores included), three barriers later: that one barrier stays a full one,
+            // the others order LDS only, and the stores settle while the next tile is staged, marked and mapped.
+            uint32_t tpar = 0;
             while (err == ZK_OK && ts < out_size) {
                 const uint32_t nl = staged_end - ja;
                 const uint32_t cap_end = S[(staged_end - 1) & M].out_end;
@@ -796,7 +804,8 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                 //     run adds to a position (zk_exec_mark_runs); the slot pass below only carries them forward
 #pragma unroll
                 for (int k = 0; k < ZK_EXEC_B; k += 4) *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(0, 0, 0, 0);
-                __syncthreads();
+                ZK_LDS_BARRIER();
+                if (tid == 0) s_bad[tpar ^ 1] = 0;                               // the flag of the tile before: every wave has read it (in front of this barrier); the next tile sets it
                 // 2. lane per sequence: mark the slots it starts; the first sequence that outlives the tile sets jn
                 for (uint32_t i = tid; i < nl; i += T) {
                     const uint32_t idx = ja + i;
@@ -814,7 +823,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                     if (end > te && start <= te) s_jn = i;
                 }
                 ZK_CLK(1);
-                __syncthreads();
+                ZK_LDS_BARRIER();
                 ZK_CLK(2);
                 const uint32_t nlong = s_nlong, jn = s_jn;
                 // the records that take the retired slots: requested now, needed two barriers from here
@@ -836,7 +845,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                     zk_exec_slot_span(ts, lo, hi, s0, n);
                     for (uint32_t j = tid; j < n; j += T) slot_seq[s0 + j] = idx;
                 }
-                if (nlong) __syncthreads();
+                if (nlong) ZK_LDS_BARRIER();
                 // 3. lane per slot: source words of its 16 bytes
                 const uint32_t q0 = ts + tid * ZK_EXEC_B;
                 const uint32_t nb = q0 >= te ? 0u : te - q0 < (uint32_t)ZK_EXEC_B ? te - q0 : (uint32_t)ZK_EXEC_B;
@@ -856,7 +865,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                         *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(sw[k], sw[k + 1], sw[k + 2], sw[k + 3]);
                 }
                 ZK_CLK(3);
-                __syncthreads();
+                __syncthreads();                                                 // the full one: every wave's stores of the tile before are in memory
                 ZK_CLK(2);
                 if (tid == 0) { s_jn = fetch_end - (ja + jn); s_nlong = 0; }      // the next tile's marking pass starts from these (every lane has read this tile's)
                 // the slot pass is done with the retired records: the fetched ones move in
@@ -906,8 +915,11 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                 prev_end = next_prev_end;
                 ja += jn; staged_end = fetch_end; ts = te;
                 ZK_CLK(5);
-                // tile bytes visible to the next tile, the ring complete, the map free again
-                if (__syncthreads_or(bad)) { err = ZK_E_CORRUPTION; break; }
+                // the ring complete, the map free again (the tile's bytes: see the barrier in front of the gathers)
+                if (bad) s_bad[tpar] = 1;
+                ZK_LDS_BARRIER();
+                if (s_bad[tpar]) { err = ZK_E_CORRUPTION; break; }
+                tpar ^= 1;
                 ZK_CLK(2);
             }
             if (err == ZK_OK) {
