@@ -122,7 +122,14 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         zk_launch_enc_ldm_build(st, ldm, (uint32_t *)e->enc_ldm.p);
         ldm.table = (const uint32_t *)e->enc_ldm.p;
     }
-    bool cks_beside = false;                                 // the checksums run on the second queue and are joined before the assembly
+    // the matcher's workgroups are launched over the segments (one per <= 256 KiB of a frame)
+    if ((rc = zk_devbuf_reserve(e, e->enc_seg, segs_bytes + 64))) return rc;
+    ZK_HIP(hipMemcpyAsync(e->enc_seg.p, segs, (size_t)nseg * sizeof(ZkEncFrame), hipMemcpyHostToDevice, st));
+    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, (const ZkEncFrame *)e->enc_seg.p, nseg, dbl, (uint64_t *)e->enc_b.p, (uint8_t *)e->enc_c.p, a.level, ldm); }
+    ZkEncTables *ftab = (ZkEncTables *)e->enc_f.p;
+    { zk_kernel_timer t(e, ZK_K_ENC_FSE_BUILD, st); zk_launch_enc_fse_build(st, src, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), dtab, ftab); }
+    bool cks_beside = false;                                 // the checksums run on the second queue beside the entropy stage (which waits on its own chains; beside the matcher they
+                                                             // cost it 2 ms of vector issue slots) and are joined before the assembly
     if (a.checksum) {
         if (!e->profiling && !e->enc_aux) {
             if (hipStreamCreateWithFlags(&e->enc_aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->enc_ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -136,12 +143,6 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
             cks_beside = true;
         } else { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, d_doff, 0, nf, nullptr, hashes); }
     }
-    // the matcher's workgroups are launched over the segments (one per <= 256 KiB of a frame)
-    if ((rc = zk_devbuf_reserve(e, e->enc_seg, segs_bytes + 64))) return rc;
-    ZK_HIP(hipMemcpyAsync(e->enc_seg.p, segs, (size_t)nseg * sizeof(ZkEncFrame), hipMemcpyHostToDevice, st));
-    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, (const ZkEncFrame *)e->enc_seg.p, nseg, dbl, (uint64_t *)e->enc_b.p, (uint8_t *)e->enc_c.p, a.level, ldm); }
-    ZkEncTables *ftab = (ZkEncTables *)e->enc_f.p;
-    { zk_kernel_timer t(e, ZK_K_ENC_FSE_BUILD, st); zk_launch_enc_fse_build(st, src, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), dtab, ftab); }
     { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, ftab); }
     zk_launch_enc_sizes(st, dfr, nf, dbl, ftab, a.checksum, c64, (uint32_t *)a.d_c_sizes, (uint32_t *)a.d_d_sizes);
     zk_launch_scan64(st, c64, nf, out_off);
