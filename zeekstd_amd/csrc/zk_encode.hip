@@ -92,6 +92,59 @@ struct ZkeBits {
     }
 };
 
+// The same stream through LDS: the lane's bits go to its own staging area in whole 32-bit words (the accumulator's two words are
+// stored at every flush(); the low one moves on once it is full), and drain() carries the complete 16-byte units to HBM.
+// Why: 16 lanes storing 8 bytes each at 16 places twice per sequence were 32 write requests per step and workgroup -- the CU's
+// write path was what every wave of the kernel waited for (without those stores: sequence writers 2.04 -> 1.32 M clocks, the
+// histogram passes 0.56 -> 0.40, the literal writers 0.55 -> 0.36).  A drain is one request per 16 bytes.
+// (ds_write_b64 at an address that is not a multiple of 8 does not write what it should -- tools/ubench/ldsun.hip -- hence words.)
+// st: LDS byte address of ZKE_STAGE bytes (a multiple of 16); the region at g must be cap + 64 bytes long.
+// LDS accesses by byte address (an integer made into an LDS pointer directly: through a generic pointer every access would start
+// with the null check of the address space cast)
+template <typename T> __device__ __forceinline__ T zke_lds_ld_at(uint32_t a) { return *(const volatile ZK_LDS_AS T *)a; }
+template <typename T> __device__ __forceinline__ void zke_lds_st_at(uint32_t a, T v) { *(volatile ZK_LDS_AS T *)a = v; }
+constexpr uint32_t ZKE_STAGE = 208;              // <= 4 rounds x 4 x 10 bytes + 15 left by the last drain + the accumulator's 8; 52 words: the 16 lanes start in 16 different banks
+typedef uint32_t zke_u32x4 __attribute__((ext_vector_type(4)));
+struct ZkeBitsL {
+    uint8_t *g; uint32_t cap, done, st, wa, n, ovf; uint64_t acc;      // done: bytes in HBM; wa: LDS byte address of the accumulator's low word
+    __device__ __forceinline__ void init(uint8_t *g_, uint32_t cap_, uint32_t st_) { g = g_; cap = cap_; done = 0; st = wa = st_; acc = 0; n = 0; ovf = 0; }
+    // v: nb <= 32 bits (nothing above them); < 32 bits are waiting, left by flush()
+    __device__ __forceinline__ void put(uint32_t v, uint32_t nb) { acc |= (uint64_t)v << n; n += nb; }
+    __device__ __forceinline__ void flush()
+    {
+        uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+        zke_lds_st_at<uint32_t>(wa, lo); zke_lds_st_at<uint32_t>((wa + 4), hi);
+        const bool full = n >= 32;               // the low word is complete: the high one takes its place (two selects: a 64-bit shift costs more)
+        lo = full ? hi : lo; hi = full ? 0u : hi;
+        acc = lo | (uint64_t)hi << 32;
+        wa += full ? 4u : 0u; n &= 31;
+    }
+    // whole 16-byte units to HBM, the rest moves to the front of the staging area
+    __device__ __forceinline__ void drain()
+    {
+        const uint32_t units = (wa - st) >> 4;
+        for (uint32_t u = 0; __ballot(u < units); u++)
+            if (u < units) {
+                const zke_u32x4 v = zke_lds_ld_at<zke_u32x4>((st + 16 * u));
+                if (done + 16 * u < cap + 48) zk_glb_st<zke_u32x4>(g + done + 16 * u, v); else ovf = 1;
+            }
+        const zke_u32x4 a = zke_lds_ld_at<zke_u32x4>((st + 16 * units)), b = zke_lds_ld_at<zke_u32x4>((st + 16 * units + 16));
+        zke_lds_st_at<zke_u32x4>(st, a); zke_lds_st_at<zke_u32x4>((st + 16), b);
+        done += 16 * units; wa -= 16 * units;
+    }
+    // end mark, the last bytes; returns the stream's size (0: it did not fit into cap bytes)
+    __device__ __forceinline__ uint32_t close()
+    {
+        flush(); put(1, 1); flush();
+        drain();
+        const uint32_t bytes = (wa - st) + ((n + 7) >> 3);                 // < 16 + 4
+        const zke_u32x4 a = zke_lds_ld_at<zke_u32x4>(st), b = zke_lds_ld_at<zke_u32x4>((st + 16));
+        if (done < cap + 16) { zk_glb_st<zke_u32x4>(g + done, a); zk_glb_st<zke_u32x4>(g + done + 16, b); } else ovf = 1;
+        const uint32_t total = done + bytes;
+        return ovf || total > cap ? 0u : total;
+    }
+};
+
 // Copy n bytes with the 64 lanes of a wave, 8 bytes per lane and access (unaligned on both sides): eight loads per
 // lane, then the eight stores -- a load issued after a store waits for the store's acknowledgement, so a
 // byte-at-a-time loop pays one HBM write latency per byte.
@@ -197,25 +250,65 @@ __global__ __launch_bounds__(1024) void zk_k_enc_fse_build(const ZkEncFrame *fra
 constexpr int ZKE_ENT_THREADS = 256;
 constexpr int ZKE_ENT_BLOCKS = 16;                       // blocks per workgroup: lanes = blocks for the serial bit writers
 
+// Memory -> LDS without a register in between (global_load_lds_dwordx4): every active lane's 16 bytes at g land at LDS byte address
+// lds + 16 * lane.  The compiler does not know of it -- neither of the LDS write nor of the entry in the wave's vmcnt queue: who
+// reads the bytes waits with ZKE_VM_WAIT(n), n = the vector memory operations issued after this one that may still be under way
+// (the queue completes in order; the compiler's own waits only ever get longer by the entries it does not know of).
+__device__ __forceinline__ void zke_dma16(const void *g, uint32_t lds)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off\n\ts_nop 1\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+#define ZKE_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+constexpr uint32_t ZKE_SEQ_SLOT = 3 * 16 * ZKE_ENT_BLOCKS;       // bytes of one round in the sequence writers' ring: 2 + 2 rewritten sequences and 4 code words of 16 lanes
+constexpr uint32_t ZKE_SEQ_SLOTS = 4;                            // three rounds under way + the one being consumed
+
 // The sequence bitstream of one block (one lane): three interleaved FSE states + the extra bits that the rewrite pass left
-// in seqs[] / mpos[].  T: the block's frame tables (LDS or HBM).
+// in seqs[] / mpos[].  T: the block's frame tables (LDS or HBM).  ring: LDS byte address of ZKE_SEQ_SLOTS x ZKE_SEQ_SLOT bytes
+// shared by the (<= 16, lanes 0-15) callers of the wave.
+// The 16 lanes walk 16 arrays: with the sequences loaded into registers a round ahead, nearly every round one lane starts a new
+// line and all wait for it -- a round (4 sequences) lasted as long as a memory access, 520 clocks per sequence on an empty CU,
+// 880 with three workgroups per CU.  Now the rounds are fetched three ahead, straight into LDS (registers would have to be
+// moved from round to round, and a move waits for its load): a round waits for nothing but its LDS reads.
 template <typename TT>
-__device__ __forceinline__ uint32_t zke_write_sequences(const TT &T, const ZkEncBlock &blk, const uint64_t *seqs, const uint32_t *mpos, uint8_t *scratch)
+__device__ __forceinline__ uint32_t zke_write_sequences(const TT &T, const ZkEncBlock &blk, const uint64_t *seqs, const uint32_t *mpos, uint8_t *scratch,
+                                                        uint8_t *ring_p, uint8_t *stage_p, uint32_t lane)
 {
     const uint32_t nseq = blk.nseq, q = (blk.nlit + 3) / 4, scap = q + (q >> 1) + 16;
     const uint64_t *sq = seqs + blk.seq_base;
-    ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + 4 * scap, blk.bsz);       // + 64 bytes of slack behind it
+    ZkeBitsL b; b.init(scratch + blk.scratch_base + blk.bsz + 4 * scap, blk.bsz, (uint32_t)(uintptr_t)stage_p + ZKE_STAGE * lane);   // + 64 bytes of slack behind it
     const uint32_t *cw = mpos + blk.seq_base;
+    const uint32_t ring = (uint32_t)(uintptr_t)ring_p;
+    int32_t i = (int32_t)nseq - 2;
+    // round r = sequences i - 4 r ... i - 4 r - 3 (while that is >= 0); fetched as 16 + 16 bytes of sq and 16 of cw from the lowest of
+    // them on, from the array's start for the rounds a lane does not have (it never reads those)
+    auto fetch = [&](int32_t top, uint32_t r) {
+        const int32_t lo = top >= 3 ? top - 3 : 0;
+        const uint32_t at = ring + (r & (ZKE_SEQ_SLOTS - 1)) * ZKE_SEQ_SLOT;
+        zke_dma16(sq + lo, at); zke_dma16(sq + lo + 2, at + 16 * ZKE_ENT_BLOCKS); zke_dma16(cw + lo, at + 32 * ZKE_ENT_BLOCKS);
+    };
+    fetch(i, 0); fetch(i - 4, 1); fetch(i - 8, 2);
+    // the last (lowest) three sequences are left to the tail: read now, used at the end
+    const uint64_t x0 = sq[0], x1 = sq[nseq > 1 ? 1 : 0], x2 = sq[nseq > 2 ? 2 : 0];
+    const uint32_t y0 = cw[0], y1 = cw[nseq > 1 ? 1 : 0], y2 = cw[nseq > 2 ? 2 : 0];
     uint32_t sl, sm, so;
+    // the extra bits of a sequence, in two parts of <= 32 (the second one is empty unless an offset beyond 2^16 meets long literal
+    // runs / matches)
+    auto extras = [&](uint64_t x) {
+        const uint32_t cnt = (uint32_t)(x >> 56), c0 = cnt > 32 ? 32 : cnt;
+        b.put((uint32_t)x, c0); b.flush(); b.put((uint32_t)(x >> 32) & 0xFFFFFFu, cnt - c0); b.flush();
+    };
     {
         const uint64_t x = sq[nseq - 1];
         const uint32_t c = cw[nseq - 1], llc = c & 0xFF, mlc = (c >> 8) & 0xFF, ofc = c >> 16;
         sm = zke_cinit(T.ml_state, T.ml_dnb[mlc], T.ml_dfs[mlc]);
         so = zke_cinit(T.of_state, T.of_dnb[ofc], T.of_dfs[ofc]);
         sl = zke_cinit(T.ll_state, T.ll_dnb[llc], T.ll_dfs[llc]);
-        b.acc |= x & 0x00FFFFFFFFFFFFFFull; b.n += (uint32_t)(x >> 56);             // <= 48 bits
-        b.flush();
+        extras(x);
     }
+    asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(y0), "v"(y1), "v"(y2));
+    ZKE_VM_WAIT(0);                                                               // the first three rounds are in the ring
     // what a step needs of the tables besides the states' own cells: found by the codes alone, so fetched for four steps at once,
     // off the chain (state -> bit count -> next state is then ONE dependent LDS lookup per state and step)
     struct Pre { uint32_t odn, odf, mdn, mdf, ldn, ldf; };
@@ -223,35 +316,38 @@ __device__ __forceinline__ uint32_t zke_write_sequences(const TT &T, const ZkEnc
         const uint32_t llc = c & 0xFF, mlc = (c >> 8) & 0xFF, ofc = c >> 16;
         return Pre{T.of_dnb[ofc], T.of_dfs[ofc], T.ml_dnb[mlc], T.ml_dfs[mlc], T.ll_dnb[llc], T.ll_dfs[llc]};
     };
-    auto step = [&](uint64_t x, const Pre &p) {
-        { uint32_t nbt = (so + p.odn) >> 16; b.put(so, nbt); so = T.of_state[(so >> nbt) + p.odf]; }
-        { uint32_t nbt = (sm + p.mdn) >> 16; b.put(sm, nbt); sm = T.ml_state[(sm >> nbt) + p.mdf]; }
-        { uint32_t nbt = (sl + p.ldn) >> 16; b.put(sl, nbt); sl = T.ll_state[(sl >> nbt) + p.ldf]; }
-        b.flush_fast();                                                           // <= 7 + 26 bits were waiting
-        b.acc |= (x & 0x00FFFFFFFFFFFFFFull) << b.n; b.n += (uint32_t)(x >> 56);   // <= 7 + 48
-        b.flush_fast();
+    // the three states' bits: one group of <= 26, put together in 32-bit arithmetic
+    auto states = [&](const Pre &p) {
+        const uint32_t no = (so + p.odn) >> 16, nm = (sm + p.mdn) >> 16, nl = (sl + p.ldn) >> 16;
+        uint32_t g = so & ((1u << no) - 1u);
+        g |= (sm & ((1u << nm) - 1u)) << no;
+        g |= (sl & ((1u << nl) - 1u)) << (no + nm);
+        so = T.of_state[(so >> no) + p.odf]; sm = T.ml_state[(sm >> nm) + p.mdf]; sl = T.ll_state[(sl >> nl) + p.ldf];
+        b.put(g, no + nm + nl); b.flush();
     };
-    // sequences nseq - 2 .. 0, read four ahead with unconditional (clamped) loads
-    auto ldx = [&](int32_t k) { return sq[k < 0 ? 0 : k]; };
-    auto ldc = [&](int32_t k) { return cw[k < 0 ? 0 : k]; };
-    int32_t i = (int32_t)nseq - 2;
-    uint64_t e0 = ldx(i), e1 = ldx(i - 1), e2 = ldx(i - 2), e3 = ldx(i - 3);
-    uint32_t c0 = ldc(i), c1 = ldc(i - 1), c2 = ldc(i - 2), c3 = ldc(i - 3);
-    asm volatile("" :: "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
-    while (i >= 3) {                                                              // same scheme as the literal streams
-        const uint64_t n0 = ldx(i - 4), n1 = ldx(i - 5), n2 = ldx(i - 6), n3 = ldx(i - 7);
-        const uint32_t d0 = ldc(i - 4), d1 = ldc(i - 5), d2 = ldc(i - 6), d3 = ldc(i - 7);
-        const Pre p0 = pre(c0), p1 = pre(c1), p2 = pre(c2), p3 = pre(c3);
-        step(e0, p0); step(e1, p1); step(e2, p2); step(e3, p3);
-        b.check();                                                                // <= 4 x 10 bytes since the last look: inside the slack
-        e0 = n0; e1 = n1; e2 = n2; e3 = n3; c0 = d0; c1 = d1; c2 = d2; c3 = d3;
-        i -= 4;
+    auto step = [&](uint64_t x, const Pre &p) { states(p); extras(x); };
+    auto step32 = [&](uint64_t x, const Pre &p) { states(p); b.put((uint32_t)x, (uint32_t)(x >> 56)); b.flush(); };      // a sequence with <= 32 extra bits
+    uint32_t r = 0;
+    while (i >= 3) {
+        // round r was fetched three rounds ago; the fetches of rounds r + 1 and r + 2 are behind it in the queue (always: every round
+        // issues its 3 fetches as long as one lane is in the loop) -- and the stores of the drains since, which only make the wait longer
+        ZKE_VM_WAIT(6);
+        const uint32_t slot = ring + (r & (ZKE_SEQ_SLOTS - 1)) * ZKE_SEQ_SLOT + 16 * lane;
+        const zke_u32x4 lo2 = zke_lds_ld_at<zke_u32x4>(slot), hi2 = zke_lds_ld_at<zke_u32x4>(slot + 16 * ZKE_ENT_BLOCKS), c4 = zke_lds_ld_at<zke_u32x4>(slot + 32 * ZKE_ENT_BLOCKS);
+        fetch(i - 12, r + 3);                                                     // into the slot of round r - 1
+        const uint64_t e0 = hi2.z | (uint64_t)hi2.w << 32, e1 = hi2.x | (uint64_t)hi2.y << 32, e2 = lo2.z | (uint64_t)lo2.w << 32, e3 = lo2.x | (uint64_t)lo2.y << 32;
+        const Pre p0 = pre(c4.w), p1 = pre(c4.z), p2 = pre(c4.y), p3 = pre(c4.x);
+        const uint32_t most = max(max(hi2.w, hi2.y), max(lo2.w, lo2.y)) >> 24;     // extra bits of the round's longest
+        if (__ballot(most > 32)) { step(e0, p0); step(e1, p1); step(e2, p2); step(e3, p3); }
+        else { step32(e0, p0); step32(e1, p1); step32(e2, p2); step32(e3, p3); }       // one basic block: the four steps' lookups overlap
+        if ((r & 3) == 3) b.drain();                                              // <= 4 x 37 bytes since the last one
+        i -= 4; r++;
     }
-    if (i >= 0) step(e0, pre(c0));
-    if (i >= 1) step(e1, pre(c1));
-    if (i >= 2) step(e2, pre(c2));
-    b.check();
-    b.put(sm, T.al[2]); b.flush(); b.put(so, T.al[1]); b.put(sl, T.al[0]);
+    b.drain();
+    if (i >= 2) step(x2, pre(y2));
+    if (i >= 1) step(x1, pre(y1));
+    if (i >= 0) step(x0, pre(y0));
+    { const uint32_t am = T.al[2], ao = T.al[1], al = T.al[0]; b.put(sm & ((1u << am) - 1u), am); b.flush(); b.put(so & ((1u << ao) - 1u), ao); b.put(sl & ((1u << al) - 1u), al); }
     return b.close();
 }
 
@@ -275,6 +371,8 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
     __shared__ uint32_t s_sizes[ZKE_ENT_BLOCKS][5];        // 4 literal streams + sequence bitstream
     __shared__ uint32_t s_lit_mode[ZKE_ENT_BLOCKS], s_maxbits[ZKE_ENT_BLOCKS], s_tree[ZKE_ENT_BLOCKS], s_diff[ZKE_ENT_BLOCKS], s_mode[ZKE_ENT_BLOCKS];
     __shared__ uint32_t s_hist_done;                       // waves 2, 3 -> wave 0: my histogram passes are done
+    __shared__ zke_u32x4 s_seq_ring[ZKE_SEQ_SLOTS * ZKE_SEQ_SLOT / 16];   // the sequence writers' rounds (zke_write_sequences)
+    __shared__ zke_u32x4 s_seq_stage[ZKE_ENT_BLOCKS * ZKE_STAGE / 16];    // and their output on its way to HBM (ZkeBitsL)
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // roles: wave 0 = Huffman builds + literal writers, 1 = sequence writers, 2 / 3 = helpers.  (Rotating the roles over the waves from
     // workgroup to workgroup -- so that the chains of the workgroups sharing a CU would not meet on one SIMD -- changed nothing: 11.1 / 11.2 / 11.6 ms.)
@@ -290,6 +388,9 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
     if (tid == 0) s_hist_done = 0;
     __syncthreads();
     if (role == 1) {
+#ifdef ZKE_SEQ_PRIO
+        __builtin_amdgcn_s_setprio(ZKE_SEQ_PRIO);
+#endif
         // the sequence bit writers -- the longest chain of the workgroup (62 % of its life when they started last) -- start with
         // the kernel: their input was rewritten by zk_k_enc_fse_build, they need nothing of what the other waves prepare
         if (lane < ZKE_ENT_BLOCKS) {
@@ -298,8 +399,8 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
             if (j < nb && blocks[b0 + j].nseq) {
                 // the tables come out of LDS when the block belongs to the workgroup's first frame (the rule: 16 blocks of one
                 // frame per workgroup), out of HBM for the blocks of another frame in a mixed workgroup
-                if (blocks[b0 + j].frame == frame_a) sz = zke_write_sequences(T, blocks[b0 + j], seqs, mpos, scratch);
-                else sz = zke_write_sequences(ftab[blocks[b0 + j].frame], blocks[b0 + j], seqs, mpos, scratch);
+                if (blocks[b0 + j].frame == frame_a) sz = zke_write_sequences(T, blocks[b0 + j], seqs, mpos, scratch, (uint8_t *)s_seq_ring, (uint8_t *)s_seq_stage, lane);
+                else sz = zke_write_sequences(ftab[blocks[b0 + j].frame], blocks[b0 + j], seqs, mpos, scratch, (uint8_t *)s_seq_ring, (uint8_t *)s_seq_stage, lane);
             }
             s_sizes[lane][4] = sz;
         }
