@@ -98,16 +98,18 @@ struct ZkeBits {
 // write path was what every wave of the kernel waited for (without those stores: sequence writers 2.04 -> 1.32 M clocks, the
 // histogram passes 0.56 -> 0.40, the literal writers 0.55 -> 0.36).  A drain is one request per 16 bytes.
 // (ds_write_b64 at an address that is not a multiple of 8 does not write what it should -- tools/ubench/ldsun.hip -- hence words.)
-// st: LDS byte address of ZKE_STAGE bytes (a multiple of 16); the region at g must be cap + 64 bytes long.
+// st: LDS byte address of the lane's staging area (a multiple of 16; ZKE_STAGE bytes for the sequence writers).
 // LDS accesses by byte address (an integer made into an LDS pointer directly: through a generic pointer every access would start
 // with the null check of the address space cast)
 template <typename T> __device__ __forceinline__ T zke_lds_ld_at(uint32_t a) { return *(const volatile ZK_LDS_AS T *)a; }
 template <typename T> __device__ __forceinline__ void zke_lds_st_at(uint32_t a, T v) { *(volatile ZK_LDS_AS T *)a = v; }
+constexpr uint32_t ZKE_LIT_STAGE = 192;          // the literal writers': <= 4 rounds x 33 bytes + 15 + 8, + the 7 odd symbols' <= 10 before the first round
 constexpr uint32_t ZKE_STAGE = 208;              // <= 4 rounds x 4 x 10 bytes + 15 left by the last drain + the accumulator's 8; 52 words: the 16 lanes start in 16 different banks
 typedef uint32_t zke_u32x4 __attribute__((ext_vector_type(4)));
 struct ZkeBitsL {
-    uint8_t *g; uint32_t cap, done, st, wa, n, ovf; uint64_t acc;      // done: bytes in HBM; wa: LDS byte address of the accumulator's low word
-    __device__ __forceinline__ void init(uint8_t *g_, uint32_t cap_, uint32_t st_) { g = g_; cap = cap_; done = 0; st = wa = st_; acc = 0; n = 0; ovf = 0; }
+    uint8_t *g; uint32_t cap, lim, done, st, wa, n, ovf; uint64_t acc;      // done: bytes in HBM; wa: LDS byte address of the accumulator's low word
+    // the stream may have cap bytes; lim >= cap bytes at g may be written
+    __device__ __forceinline__ void init(uint8_t *g_, uint32_t cap_, uint32_t lim_, uint32_t st_) { g = g_; cap = cap_; lim = lim_; done = 0; st = wa = st_; acc = 0; n = 0; ovf = 0; }
     // v: nb <= 32 bits (nothing above them); < 32 bits are waiting, left by flush()
     __device__ __forceinline__ void put(uint32_t v, uint32_t nb) { acc |= (uint64_t)v << n; n += nb; }
     __device__ __forceinline__ void flush()
@@ -126,7 +128,7 @@ struct ZkeBitsL {
         for (uint32_t u = 0; __ballot(u < units); u++)
             if (u < units) {
                 const zke_u32x4 v = zke_lds_ld_at<zke_u32x4>((st + 16 * u));
-                if (done + 16 * u < cap + 48) zk_glb_st<zke_u32x4>(g + done + 16 * u, v); else ovf = 1;
+                if (done + 16 * u + 16 <= lim) zk_glb_st<zke_u32x4>(g + done + 16 * u, v); else ovf = 1;
             }
         const zke_u32x4 a = zke_lds_ld_at<zke_u32x4>((st + 16 * units)), b = zke_lds_ld_at<zke_u32x4>((st + 16 * units + 16));
         zke_lds_st_at<zke_u32x4>(st, a); zke_lds_st_at<zke_u32x4>((st + 16), b);
@@ -139,7 +141,8 @@ struct ZkeBitsL {
         drain();
         const uint32_t bytes = (wa - st) + ((n + 7) >> 3);                 // < 16 + 4
         const zke_u32x4 a = zke_lds_ld_at<zke_u32x4>(st), b = zke_lds_ld_at<zke_u32x4>((st + 16));
-        if (done < cap + 16) { zk_glb_st<zke_u32x4>(g + done, a); zk_glb_st<zke_u32x4>(g + done + 16, b); } else ovf = 1;
+        if (done + 32 <= lim) { zk_glb_st<zke_u32x4>(g + done, a); zk_glb_st<zke_u32x4>(g + done + 16, b); }
+        else for (uint32_t t = 0; t < bytes; t++) { if (done + t < lim) g[done + t] = zke_lds_ld_at<uint8_t>(st + t); else ovf = 1; }   // the region ends here: byte by byte
         const uint32_t total = done + bytes;
         return ovf || total > cap ? 0u : total;
     }
@@ -277,7 +280,7 @@ __device__ __forceinline__ uint32_t zke_write_sequences(const TT &T, const ZkEnc
 {
     const uint32_t nseq = blk.nseq, q = (blk.nlit + 3) / 4, scap = q + (q >> 1) + 16;
     const uint64_t *sq = seqs + blk.seq_base;
-    ZkeBitsL b; b.init(scratch + blk.scratch_base + blk.bsz + 4 * scap, blk.bsz, (uint32_t)(uintptr_t)stage_p + ZKE_STAGE * lane);   // + 64 bytes of slack behind it
+    ZkeBitsL b; b.init(scratch + blk.scratch_base + blk.bsz + 4 * scap, blk.bsz, blk.bsz + 64, (uint32_t)(uintptr_t)stage_p + ZKE_STAGE * lane);
     const uint32_t *cw = mpos + blk.seq_base;
     const uint32_t ring = (uint32_t)(uintptr_t)ring_p;
     int32_t i = (int32_t)nseq - 2;
@@ -360,7 +363,8 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
                                                                    uint32_t nblocks, uint64_t *seqs, uint32_t *mpos, const uint8_t *lits,
                                                                    uint8_t *scratch, const ZkEncTables *ftab)
 {
-    __shared__ uint32_t cnt[ZKE_ENT_BLOCKS][256];
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[ZKE_ENT_BLOCKS][256];   // literal histograms; later the literal writers' staging areas
+    static_assert(64 * ZKE_LIT_STAGE <= sizeof(uint32_t) * ZKE_ENT_BLOCKS * 256, "the literal writers' staging areas take the histograms' place");
     __shared__ ZkEncTables T;                              // the FSE compression tables of the frame of the workgroup's first block
     __shared__ ZkHufCode hw[ZKE_ENT_BLOCKS];
 #ifndef ZKE_HUF_BUILDS
@@ -476,32 +480,32 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
                     const uint32_t nlit = blk.nlit, q = (nlit + 3) / 4, scap = q + (q >> 1) + 16;
                     const uint32_t n_k = k < 3 ? q : nlit - 3 * q;
                     const uint8_t *sp = lits + blk.lit_base + k * q;
-                    // last symbol first; the stream is read 8 bytes at a time, three words ahead (the loads are unconditional --
-                    // a clamped address reads the stream's first bytes again -- so the waits count the stores exactly)
-                    ZkeBits b; b.init(scratch + blk.scratch_base + blk.bsz + k * scap, scap - 8);
+                    // last symbol first; the stream is read 8 bytes at a time, three words ahead (unconditional loads: a clamped address
+                    // reads the stream's first bytes again).  The bits go through the lane's staging area in LDS (the histograms' space:
+                    // the codes are built) and reach HBM 16 bytes at a time, every fourth round
+                    ZkeBitsL b; b.init(scratch + blk.scratch_base + blk.bsz + k * scap, scap - 8, scap, (uint32_t)(uintptr_t)&cnt[0][0] + ZKE_LIT_STAGE * lane);
                     const ZkHufCode &h = hw[j];
                     uint32_t i = n_k;
+                    auto two = [&](uint32_t s0, uint32_t s1) {                                      // <= 22 bits
+                        const uint32_t l0 = h.len[s0];
+                        b.put(h.code[s0] | (uint32_t)h.code[s1] << l0, l0 + h.len[s1]); b.flush();
+                    };
                     for (uint32_t r = n_k & 7; r; r--) { const uint32_t sy = sp[--i]; b.put(h.code[sy], h.len[sy]); b.flush(); }
                     auto ldw = [&](uint32_t at) { return zk_ld64(sp + (at >= 8 ? at - 8 : 0)); };       // symbols [at - 8, at)
                     auto word = [&](uint64_t w) {
 #pragma unroll
-                        for (int t = 7; t >= 0; t--) {
-                            const uint32_t sy = (uint32_t)(w >> (8 * t)) & 0xFF;
-                            b.put(h.code[sy], h.len[sy]);                                       // <= 11 bits each
-                            if ((t & 3) == 0) b.flush();
-                        }
+                        for (int t = 7; t >= 0; t -= 2) two((uint32_t)(w >> (8 * t)) & 0xFF, (uint32_t)(w >> (8 * t - 8)) & 0xFF);
                     };
-                    // the next iteration's three words are requested before this iteration's first store and moved over after its
-                    // last one: the wait for them counts exactly the 6 stores in between, never a store's acknowledgement
-                    // (rotating the registers instead lets the compiler hoist a use to the loop top, behind the previous stores)
                     uint64_t w0 = ldw(i), w1 = ldw(i >= 8 ? i - 8 : 0), w2 = ldw(i >= 16 ? i - 16 : 0);
-                    asm volatile("" :: "v"(w0), "v"(w1), "v"(w2));                                // arrived before the loop: no pending state to merge
+                    uint32_t rounds = 0;
                     while (i >= 24) {
                         const uint64_t n0 = ldw(i - 24), n1 = ldw(i >= 32 ? i - 32 : 0), n2 = ldw(i >= 40 ? i - 40 : 0);
                         word(w0); word(w1); word(w2);
+                        if ((++rounds & 3) == 0) b.drain();                                         // <= 4 x 33 bytes since the last one
                         w0 = n0; w1 = n1; w2 = n2;
                         i -= 24;
                     }
+                    b.drain();
                     if (i >= 8) word(w0);
                     if (i >= 16) word(w1);
                     s_sizes[j][k] = b.close();
