@@ -24,14 +24,17 @@ eng.encode_frames_dev(d_src, n, F, level, False, d_comp, cap, d_cs, d_ds)
 raw.zk_debug_enc_clocks(None, 1)
 eng.encode_frames_dev(d_src, n, F, level, False, d_comp, cap, d_cs, d_ds)
 torch.cuda.synchronize()
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 48)()
 raw.zk_debug_enc_clocks(out, 0)
-v = np.array(list(out), dtype=np.float64).reshape(8, 4)
+res = list(out)[40:48]
+v = np.array(list(out)[:40], dtype=np.float64).reshape(8, 5)
 names = ["clear + tables + raw / literal histograms", "wait", "rewrite sequences (waves 1-3)", "huffman builds (+ waits)", "bit writers", "wait", "layout + payload copies", "-"]
 wgs = n / (16 * 32768)
 print("entropy ms", round(eng.kernel_times()["zk_k_enc_entropy"], 3))
-print(f"  {'phase':44s}" + "".join(f"   wave {w}" for w in range(4)) + "   (clocks per workgroup)")
+print(f"  {'phase':44s}" + "".join(f"   wave {w}" for w in range(5)) + "   (clocks per workgroup)")
 for nm, row in zip(names, v):
     if nm != "-":
         print(f"  {nm:44s}" + "".join(f" {x / wgs:8.0f}" for x in row))
-print(f"  {'total':44s}" + "".join(f" {x / wgs:8.0f}" for x in v.sum(axis=0)))
+print(f"  shader clock during the kernel: {v[7][0] / max(v[7][1], 1) * 100:.0f} MHz (clock64 / wall_clock64 of wave 0, 100 MHz reference)")
+print(f"  {'total':44s}" + "".join(f" {x / wgs:8.0f}" for x in v[:7].sum(axis=0)))
+print("  workgroups already on the CU when one starts (0, 1, 2, ...):", [int(x) for x in res])

@@ -271,17 +271,22 @@ ZK_HD uint32_t zke_cinit(const uint16_t *state, uint32_t dnb, uint32_t dfs)
 // Two-queue Huffman over symbols sorted by (count, symbol); counts are halved (rounding up) until the tree fits.
 // Code lengths <= 11 from the symbol counts (two-queue Huffman; counts are halved in place until the tree fits).
 // cnt is modified.  Returns the deepest length, or -1 when fewer than two symbols occur.
-ZK_HD int zke_huf_lengths(uint32_t *cnt, int nsym, ZkHufBuild *h, uint8_t *len)
+// sorted >= 0: h->idx already holds that many symbols in the order (count, symbol) -- the entropy kernel ranks them with all the
+// lanes of its wave; the insertion sort below is ~ m * m / 4 dependent LDS round trips, most of a build.
+ZK_HD int zke_huf_lengths(uint32_t *cnt, int nsym, ZkHufBuild *h, uint8_t *len, int sorted = -1)
 {
-    for (;;) {
+    for (;; sorted = -1) {
         int m = 0;
-        for (int s = 0; s < nsym; s++) if (cnt[s]) h->idx[m++] = (uint8_t)s;
-        if (m < 2) return -1;
-        for (int i = 1; i < m; i++) {
-            int k = h->idx[i], j = i - 1;
-            while (j >= 0 && (cnt[h->idx[j]] > cnt[k] || (cnt[h->idx[j]] == cnt[k] && h->idx[j] > k))) { h->idx[j + 1] = h->idx[j]; j--; }
-            h->idx[j + 1] = (uint8_t)k;
+        if (sorted >= 0) m = sorted;
+        else {
+            for (int s = 0; s < nsym; s++) if (cnt[s]) h->idx[m++] = (uint8_t)s;
+            for (int i = 1; i < m; i++) {
+                int k = h->idx[i], j = i - 1;
+                while (j >= 0 && (cnt[h->idx[j]] > cnt[k] || (cnt[h->idx[j]] == cnt[k] && h->idx[j] > k))) { h->idx[j + 1] = h->idx[j]; j--; }
+                h->idx[j + 1] = (uint8_t)k;
+            }
         }
+        if (m < 2) return -1;
         int nn = m;
         for (int i = 0; i < m; i++) h->w[i] = cnt[h->idx[i]];
         int a = 0, bq = m;

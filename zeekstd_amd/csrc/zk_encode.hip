@@ -42,15 +42,18 @@ extern "C" void zk_debug_enc_clocks(unsigned long long *out, int reset)
 #include "zk_enc_match.h"
 #ifdef ZKE_ENT_CLOCKS
 // experiments: the same for the entropy kernel (per wave: slot = 4 * phase + wave; tools/ent_clocks.py)
-__device__ unsigned long long zke_dbg_clk[32];
+__device__ unsigned long long zke_dbg_clk[48];
+__device__ unsigned int zke_dbg_cu[8 * 16 * 16];      // workgroups resident per (XCC, SE, CU)
 extern "C" void zk_debug_enc_clocks(unsigned long long *out, int reset)
 {
-    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zke_dbg_clk), z, sizeof z); }
-    else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(zke_dbg_clk), 32 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[48] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(zke_dbg_clk), z, sizeof z); }
+    else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(zke_dbg_clk), 48 * sizeof(unsigned long long));
 }
-#define ZKE_ECLK_BEGIN() unsigned long long eclk_[8] = {0}, et_ = clock64()
+#define ZKE_ECLK_BEGIN() unsigned long long eclk_[8] = {0}, et_ = clock64(), ec0_ = et_, ew0_ = wall_clock64(); uint32_t ecu_ = 0; \
+    if (threadIdx.x == 0) { uint32_t hw_, xc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc_)); \
+        ecu_ = ((xc_ & 7) << 8) | (((hw_ >> 13) & 7) << 4) | ((hw_ >> 8) & 15); const uint32_t was_ = atomicAdd(&zke_dbg_cu[ecu_], 1u); atomicAdd(&zke_dbg_clk[40 + (was_ < 7 ? was_ : 7)], 1ull); }
 #define ZKE_ECLK(i) do { const unsigned long long now_ = clock64(); eclk_[i] += now_ - et_; et_ = now_; } while (0)
-#define ZKE_ECLK_END() do { if ((threadIdx.x & 63) == 0) for (int i = 0; i < 8; i++) atomicAdd(&zke_dbg_clk[4 * i + (threadIdx.x >> 6)], eclk_[i]); } while (0)
+#define ZKE_ECLK_END() do { if ((threadIdx.x & 63) == 0) for (int i = 0; i < 8; i++) atomicAdd(&zke_dbg_clk[5 * i + (threadIdx.x >> 6)], eclk_[i]); if (threadIdx.x == 0) { atomicSub(&zke_dbg_cu[ecu_], 1u); atomicAdd(&zke_dbg_clk[35], clock64() - ec0_); atomicAdd(&zke_dbg_clk[36], wall_clock64() - ew0_); } } while (0)
 #else
 #define ZKE_ECLK_BEGIN() do { } while (0)
 #define ZKE_ECLK(i) do { } while (0)
@@ -104,7 +107,7 @@ struct ZkeBits {
 template <typename T> __device__ __forceinline__ T zke_lds_ld_at(uint32_t a) { return *(const volatile ZK_LDS_AS T *)a; }
 template <typename T> __device__ __forceinline__ void zke_lds_st_at(uint32_t a, T v) { *(volatile ZK_LDS_AS T *)a = v; }
 constexpr uint32_t ZKE_LIT_STAGE = 192;          // the literal writers': <= 4 rounds x 33 bytes + 15 + 8, + the 7 odd symbols' <= 10 before the first round
-constexpr uint32_t ZKE_STAGE = 208;              // <= 4 rounds x 4 x 10 bytes + 15 left by the last drain + the accumulator's 8; 52 words: the 16 lanes start in 16 different banks
+constexpr uint32_t ZKE_STAGE = 112;              // the sequence emitter's: <= 2 rounds x 42 bytes + 15 left by the last drain + the accumulator's 8; 28 words: the 16 lanes start in 16 different banks
 typedef uint32_t zke_u32x4 __attribute__((ext_vector_type(4)));
 struct ZkeBitsL {
     uint8_t *g; uint32_t cap, lim, done, st, wa, n, ovf; uint64_t acc;      // done: bytes in HBM; wa: LDS byte address of the accumulator's low word
@@ -171,7 +174,7 @@ __device__ __forceinline__ void zke_copy_wave(uint8_t *dst, const uint8_t *src, 
 // two symbols, or a frame with fewer than ZKE_FSE_MIN_SEQ sequences, keeps the predefined one.
 // It also rewrites every sequence into what its serial bit writer (zk_k_enc_entropy) needs -- everything that does not depend on
 // the FSE states -- so that the writers can start with the kernel:
-//   seqs[i]  <- extra bits of LL | ML | OF back to back (<= 48 bits), their count << 56
+//   seqs[i]  <- extra bits of LL | ML | OF back to back (<= 16 + 15 + 26 with long-distance offsets), their count << 58
 //   mpos[i]  <- LL code | ML code << 8 | OF code << 16
 __global__ __launch_bounds__(1024) void zk_k_enc_fse_build(const ZkEncFrame *frames, const ZkEncBlock *blocks, uint64_t *seqs, uint32_t *mpos,
                                                           const ZkEncTables *predef, ZkEncTables *ftab, uint32_t min_seq)
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(1024) void zk_k_enc_fse_build(const ZkEncFrame *fra
         const uint32_t lv = s_llv[llc], mv = s_mlv[mlc];
         const uint32_t ln = lv >> 24, mn = mv >> 24;
         const uint64_t x = (uint64_t)(ll - (lv & 0xFFFFFF)) | ((uint64_t)(ml - (mv & 0xFFFFFF)) << ln) | ((uint64_t)(ob - (1u << ofc)) << (ln + mn));
-        sq[k] = x | ((uint64_t)(ln + mn + ofc) << 56);
+        sq[k] = x | ((uint64_t)(ln + mn + ofc) << 58);
         cw[k] = llc | (mlc << 8) | (ofc << 16);
         mine++;
     };
@@ -250,7 +253,15 @@ __global__ __launch_bounds__(1024) void zk_k_enc_fse_build(const ZkEncFrame *fra
     }
 }
 
-constexpr int ZKE_ENT_THREADS = 256;
+#ifndef ZKE_ENT_WAVES
+#define ZKE_ENT_WAVES 4
+#endif
+// waves of a workgroup: 0 = literal counts, Huffman builds, literal writers; 1 = sequence chains; then the sequence emitter and the
+// helpers that count literals beside wave 0 (4 waves: 2 = emitter, 3 = helper; 5 waves: 2, 3 = helpers, 4 = emitter -- measured:
+// five-wave workgroups live shorter, 1.42 instead of ~1.45 M clocks, but fewer of them are on the machine at a time, 2.3 per CU
+// instead of 2.8)
+constexpr int ZKE_ENT_THREADS = 64 * ZKE_ENT_WAVES;
+constexpr uint32_t ZKE_ENT_EMITTER = ZKE_ENT_WAVES == 5 ? 4 : 2, ZKE_ENT_HELPERS = ZKE_ENT_WAVES == 5 ? 2 : 1;
 constexpr int ZKE_ENT_BLOCKS = 16;                       // blocks per workgroup: lanes = blocks for the serial bit writers
 
 // Memory -> LDS without a register in between (global_load_lds_dwordx4): every active lane's 16 bytes at g land at LDS byte address
@@ -260,97 +271,155 @@ constexpr int ZKE_ENT_BLOCKS = 16;                       // blocks per workgroup
 __device__ __forceinline__ void zke_dma16(const void *g, uint32_t lds)
 {
     uint32_t keep;
+    lds = __builtin_amdgcn_readfirstlane(lds);          // the same in every lane; the instruction wants it in a scalar register
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, off\n\ts_nop 1\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
 }
 #define ZKE_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-constexpr uint32_t ZKE_SEQ_SLOT = 3 * 16 * ZKE_ENT_BLOCKS;       // bytes of one round in the sequence writers' ring: 2 + 2 rewritten sequences and 4 code words of 16 lanes
-constexpr uint32_t ZKE_SEQ_SLOTS = 4;                            // three rounds under way + the one being consumed
+constexpr uint32_t ZKE_SEQ_SLOT = 3 * 16 * ZKE_ENT_BLOCKS;       // bytes of one round in the sequence ring: 2 + 2 rewritten sequences and 4 code words of 16 lanes
+constexpr uint32_t ZKE_SEQ_SLOTS = 6;                            // rounds between the fetch of a round and the emitter's last look at it (3 ahead of the chain, <= 2 behind)
 
-// The sequence bitstream of one block (one lane): three interleaved FSE states + the extra bits that the rewrite pass left
-// in seqs[] / mpos[].  T: the block's frame tables (LDS or HBM).  ring: LDS byte address of ZKE_SEQ_SLOTS x ZKE_SEQ_SLOT bytes
-// shared by the (<= 16, lanes 0-15) callers of the wave.
-// The 16 lanes walk 16 arrays: with the sequences loaded into registers a round ahead, nearly every round one lane starts a new
-// line and all wait for it -- a round (4 sequences) lasted as long as a memory access, 520 clocks per sequence on an empty CU,
-// 880 with three workgroups per CU.  Now the rounds are fetched three ahead, straight into LDS (registers would have to be
-// moved from round to round, and a move waits for its load): a round waits for nothing but its LDS reads.
-template <typename TT>
-__device__ __forceinline__ uint32_t zke_write_sequences(const TT &T, const ZkEncBlock &blk, const uint64_t *seqs, const uint32_t *mpos, uint8_t *scratch,
-                                                        uint8_t *ring_p, uint8_t *stage_p, uint32_t lane)
+// The sequence bitstreams of 16 blocks are written by TWO waves, lane j of each for block j:
+//   the chain wave walks the three FSE states (the one thing that is serial: state -> bit count -> next state, one dependent LDS
+//     lookup per state and step) and leaves every step's state bits -- one group of <= 26 -- in LDS;
+//   the emitter, a round (4 sequences) or more behind, puts the groups and the sequences' extra bits into the stream (ZkeBitsL).
+// Both are bound by the instructions they issue; as one wave a step took 76 of them.
+// The rounds are fetched three ahead, straight into LDS (zke_dma16; registers would have to be moved from round to round, and a move
+// waits for its load): 16 + 16 bytes of the rewritten sequences (the emitter's) and 16 of code words (the chain's).
+// Rounds are numbered through the workgroup's life (r, the same in both waves): the blocks of the workgroup's first frame are
+// written first, the others (their tables are read out of HBM) after them.
+struct ZkeSeqShared {
+    zke_u32x4 ring[ZKE_SEQ_SLOTS][3][ZKE_ENT_BLOCKS];    // [slot][sequences i-3, i-2 | i-1, i | codes][lane]
+    zke_u32x4 g[ZKE_SEQ_SLOTS][ZKE_ENT_BLOCKS];          // a round's four groups: bits | count << 26
+    uint32_t chain_round, emit_round;                     // rounds written by the chain wave / read by the emitter
+};
+__device__ __forceinline__ void zke_wait_round(uint32_t counter_at, int32_t need)
 {
-    const uint32_t nseq = blk.nseq, q = (blk.nlit + 3) / 4, scap = q + (q >> 1) + 16;
+    while ((int32_t)(zke_lds_ld_at<uint32_t>(counter_at) - (uint32_t)need) < 0) __builtin_amdgcn_s_sleep(1);
+}
+// full rounds of a block with nseq sequences: the last one is the initial state, the lowest <= 3 are left to the tail round
+__device__ __forceinline__ uint32_t zke_seq_rounds(uint32_t nseq) { return nseq >= 5 ? (nseq - 1) / 4 : 0; }
+
+// r0: the phase's first round; rmax: the phase's full rounds (the longest lane's); the tail round is r0 + rmax.
+template <typename TT>
+__device__ __forceinline__ void zke_seq_chain(const TT &T, const ZkEncBlock &blk, const uint64_t *seqs, const uint32_t *mpos, uint32_t sh, uint32_t lane,
+                                              uint32_t r0, uint32_t rmax)
+{
+    const uint32_t nseq = blk.nseq;
     const uint64_t *sq = seqs + blk.seq_base;
-    ZkeBitsL b; b.init(scratch + blk.scratch_base + blk.bsz + 4 * scap, blk.bsz, blk.bsz + 64, (uint32_t)(uintptr_t)stage_p + ZKE_STAGE * lane);
     const uint32_t *cw = mpos + blk.seq_base;
-    const uint32_t ring = (uint32_t)(uintptr_t)ring_p;
+    const uint32_t ring = sh + (uint32_t)offsetof(ZkeSeqShared, ring), gat = sh + (uint32_t)offsetof(ZkeSeqShared, g) + 16 * lane;
+    const uint32_t emit_at = sh + (uint32_t)offsetof(ZkeSeqShared, emit_round), chain_at = sh + (uint32_t)offsetof(ZkeSeqShared, chain_round);
     int32_t i = (int32_t)nseq - 2;
-    // round r = sequences i - 4 r ... i - 4 r - 3 (while that is >= 0); fetched as 16 + 16 bytes of sq and 16 of cw from the lowest of
-    // them on, from the array's start for the rounds a lane does not have (it never reads those)
+    // round r = sequences i - 4 (r - r0) ... - 3 (while that is >= 0); fetched from the lowest of them on, from the array's start
+    // for the rounds a lane does not have (it never reads those).  The slot was round r - 8's: the emitter must be past that
     auto fetch = [&](int32_t top, uint32_t r) {
         const int32_t lo = top >= 3 ? top - 3 : 0;
-        const uint32_t at = ring + (r & (ZKE_SEQ_SLOTS - 1)) * ZKE_SEQ_SLOT;
+        const uint32_t at = ring + (r % ZKE_SEQ_SLOTS) * ZKE_SEQ_SLOT;
         zke_dma16(sq + lo, at); zke_dma16(sq + lo + 2, at + 16 * ZKE_ENT_BLOCKS); zke_dma16(cw + lo, at + 32 * ZKE_ENT_BLOCKS);
     };
-    fetch(i, 0); fetch(i - 4, 1); fetch(i - 8, 2);
-    // the last (lowest) three sequences are left to the tail: read now, used at the end
-    const uint64_t x0 = sq[0], x1 = sq[nseq > 1 ? 1 : 0], x2 = sq[nseq > 2 ? 2 : 0];
-    const uint32_t y0 = cw[0], y1 = cw[nseq > 1 ? 1 : 0], y2 = cw[nseq > 2 ? 2 : 0];
+    zke_wait_round(emit_at, (int32_t)r0 + 2 - (int32_t)ZKE_SEQ_SLOTS + 1);
+    fetch(i, r0); fetch(i - 4, r0 + 1); fetch(i - 8, r0 + 2);
+    const uint32_t y0 = cw[0], y1 = cw[nseq > 1 ? 1 : 0], y2 = cw[nseq > 2 ? 2 : 0];     // the tail's codes
     uint32_t sl, sm, so;
-    // the extra bits of a sequence, in two parts of <= 32 (the second one is empty unless an offset beyond 2^16 meets long literal
-    // runs / matches)
-    auto extras = [&](uint64_t x) {
-        const uint32_t cnt = (uint32_t)(x >> 56), c0 = cnt > 32 ? 32 : cnt;
-        b.put((uint32_t)x, c0); b.flush(); b.put((uint32_t)(x >> 32) & 0xFFFFFFu, cnt - c0); b.flush();
-    };
     {
-        const uint64_t x = sq[nseq - 1];
         const uint32_t c = cw[nseq - 1], llc = c & 0xFF, mlc = (c >> 8) & 0xFF, ofc = c >> 16;
         sm = zke_cinit(T.ml_state, T.ml_dnb[mlc], T.ml_dfs[mlc]);
         so = zke_cinit(T.of_state, T.of_dnb[ofc], T.of_dfs[ofc]);
         sl = zke_cinit(T.ll_state, T.ll_dnb[llc], T.ll_dfs[llc]);
-        extras(x);
     }
-    asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(y0), "v"(y1), "v"(y2));
+    asm volatile("" :: "v"(y0), "v"(y1), "v"(y2));
     ZKE_VM_WAIT(0);                                                               // the first three rounds are in the ring
-    // what a step needs of the tables besides the states' own cells: found by the codes alone, so fetched for four steps at once,
-    // off the chain (state -> bit count -> next state is then ONE dependent LDS lookup per state and step)
+    // what a step needs of the tables besides the states' own cells: found by the codes alone, so fetched for four steps at once
     struct Pre { uint32_t odn, odf, mdn, mdf, ldn, ldf; };
     auto pre = [&](uint32_t c) {
         const uint32_t llc = c & 0xFF, mlc = (c >> 8) & 0xFF, ofc = c >> 16;
         return Pre{T.of_dnb[ofc], T.of_dfs[ofc], T.ml_dnb[mlc], T.ml_dfs[mlc], T.ll_dnb[llc], T.ll_dfs[llc]};
     };
-    // the three states' bits: one group of <= 26, put together in 32-bit arithmetic
+    // one step: the three states' bits as one group (OF, ML, LL from the low end) | their count << 26
     auto states = [&](const Pre &p) {
         const uint32_t no = (so + p.odn) >> 16, nm = (sm + p.mdn) >> 16, nl = (sl + p.ldn) >> 16;
         uint32_t g = so & ((1u << no) - 1u);
         g |= (sm & ((1u << nm) - 1u)) << no;
         g |= (sl & ((1u << nl) - 1u)) << (no + nm);
         so = T.of_state[(so >> no) + p.odf]; sm = T.ml_state[(sm >> nm) + p.mdf]; sl = T.ll_state[(sl >> nl) + p.ldf];
-        b.put(g, no + nm + nl); b.flush();
+        return g | (no + nm + nl) << 26;
     };
-    auto step = [&](uint64_t x, const Pre &p) { states(p); extras(x); };
-    auto step32 = [&](uint64_t x, const Pre &p) { states(p); b.put((uint32_t)x, (uint32_t)(x >> 56)); b.flush(); };      // a sequence with <= 32 extra bits
-    uint32_t r = 0;
+    uint32_t r = r0;
     while (i >= 3) {
-        // round r was fetched three rounds ago; the fetches of rounds r + 1 and r + 2 are behind it in the queue (always: every round
-        // issues its 3 fetches as long as one lane is in the loop) -- and the stores of the drains since, which only make the wait longer
+        // the fetch below overwrites round r - 5's slot; round r was fetched three rounds ago and only the fetches of rounds r + 1 and
+        // r + 2 are behind it in the queue (every round issues its 3 as long as one lane is in the loop; this wave stores nothing)
+        zke_wait_round(emit_at, (int32_t)r + 3 - (int32_t)ZKE_SEQ_SLOTS + 1);
         ZKE_VM_WAIT(6);
-        const uint32_t slot = ring + (r & (ZKE_SEQ_SLOTS - 1)) * ZKE_SEQ_SLOT + 16 * lane;
-        const zke_u32x4 lo2 = zke_lds_ld_at<zke_u32x4>(slot), hi2 = zke_lds_ld_at<zke_u32x4>(slot + 16 * ZKE_ENT_BLOCKS), c4 = zke_lds_ld_at<zke_u32x4>(slot + 32 * ZKE_ENT_BLOCKS);
-        fetch(i - 12, r + 3);                                                     // into the slot of round r - 1
-        const uint64_t e0 = hi2.z | (uint64_t)hi2.w << 32, e1 = hi2.x | (uint64_t)hi2.y << 32, e2 = lo2.z | (uint64_t)lo2.w << 32, e3 = lo2.x | (uint64_t)lo2.y << 32;
+        const uint32_t slot = (r % ZKE_SEQ_SLOTS);
+        const zke_u32x4 c4 = zke_lds_ld_at<zke_u32x4>(ring + slot * ZKE_SEQ_SLOT + 32 * ZKE_ENT_BLOCKS + 16 * lane);
+        fetch(i - 12, r + 3);
         const Pre p0 = pre(c4.w), p1 = pre(c4.z), p2 = pre(c4.y), p3 = pre(c4.x);
-        const uint32_t most = max(max(hi2.w, hi2.y), max(lo2.w, lo2.y)) >> 24;     // extra bits of the round's longest
-        if (__ballot(most > 32)) { step(e0, p0); step(e1, p1); step(e2, p2); step(e3, p3); }
-        else { step32(e0, p0); step32(e1, p1); step32(e2, p2); step32(e3, p3); }       // one basic block: the four steps' lookups overlap
-        if ((r & 3) == 3) b.drain();                                              // <= 4 x 37 bytes since the last one
+        zke_u32x4 g;
+        g.x = states(p0); g.y = states(p1); g.z = states(p2); g.w = states(p3);
+        zke_lds_st_at<zke_u32x4>(gat + slot * (16 * ZKE_ENT_BLOCKS), g);
+        zke_lds_st_at<uint32_t>(chain_at, r + 1);
+        i -= 4; r++;
+    }
+    // the tail round: the lowest <= 3 sequences, then the final states
+    r = r0 + rmax;
+    zke_wait_round(emit_at, (int32_t)r - (int32_t)ZKE_SEQ_SLOTS + 1);
+    zke_u32x4 g; g.x = g.y = g.z = 0;
+    if (i >= 2) g.x = states(pre(y2));
+    if (i >= 1) g.y = states(pre(y1));
+    if (i >= 0) g.z = states(pre(y0));
+    { const uint32_t am = T.al[2], ao = T.al[1], al = T.al[0];
+      g.w = (sm & ((1u << am) - 1u)) | (so & ((1u << ao) - 1u)) << am | (sl & ((1u << al) - 1u)) << (am + ao) | (am + ao + al) << 26; }
+    zke_lds_st_at<zke_u32x4>(gat + (r % ZKE_SEQ_SLOTS) * (16 * ZKE_ENT_BLOCKS), g);
+    zke_lds_st_at<uint32_t>(chain_at, r + 1);
+}
+
+// returns the stream's size (0: it does not fit into the block's bytes)
+__device__ __forceinline__ uint32_t zke_seq_emit(const ZkEncBlock &blk, const uint64_t *seqs, uint8_t *scratch, uint32_t sh, uint32_t stage, uint32_t lane,
+                                                 uint32_t r0, uint32_t rmax)
+{
+    const uint32_t nseq = blk.nseq, q = (blk.nlit + 3) / 4, scap = q + (q >> 1) + 16;
+    const uint64_t *sq = seqs + blk.seq_base;
+    ZkeBitsL b; b.init(scratch + blk.scratch_base + blk.bsz + 4 * scap, blk.bsz, blk.bsz + 64, stage + ZKE_STAGE * lane);
+    const uint32_t ring = sh + (uint32_t)offsetof(ZkeSeqShared, ring) + 16 * lane, gat = sh + (uint32_t)offsetof(ZkeSeqShared, g) + 16 * lane;
+    const uint32_t emit_at = sh + (uint32_t)offsetof(ZkeSeqShared, emit_round), chain_at = sh + (uint32_t)offsetof(ZkeSeqShared, chain_round);
+    int32_t i = (int32_t)nseq - 2;
+    const uint64_t x0 = sq[0], x1 = sq[nseq > 1 ? 1 : 0], x2 = sq[nseq > 2 ? 2 : 0];     // the tail's sequences
+    // the extra bits of a sequence, in two parts of <= 32 (the second one is empty unless an offset beyond 2^16 meets long literal
+    // runs / matches)
+    auto extras = [&](uint64_t x) {
+        const uint32_t cnt = (uint32_t)(x >> 58), c0 = cnt > 32 ? 32 : cnt;
+        b.put((uint32_t)x, c0); b.flush(); b.put((uint32_t)(x >> 32) & 0x3FFFFFFu, cnt - c0); b.flush();
+    };
+    auto group = [&](uint32_t g) { b.put(g & 0x3FFFFFFu, g >> 26); b.flush(); };
+    extras(sq[nseq - 1]);
+    uint32_t r = r0, since = 0;
+    while (i >= 3) {
+        zke_wait_round(chain_at, (int32_t)r + 1);
+        const uint32_t slot = (r % ZKE_SEQ_SLOTS);
+        const zke_u32x4 lo2 = zke_lds_ld_at<zke_u32x4>(ring + slot * ZKE_SEQ_SLOT), hi2 = zke_lds_ld_at<zke_u32x4>(ring + slot * ZKE_SEQ_SLOT + 16 * ZKE_ENT_BLOCKS);
+        const zke_u32x4 g = zke_lds_ld_at<zke_u32x4>(gat + slot * (16 * ZKE_ENT_BLOCKS));
+        zke_lds_st_at<uint32_t>(emit_at, r + 1);                                 // behind the reads in the LDS queue
+        const uint32_t most = max(max(hi2.w, hi2.y), max(lo2.w, lo2.y)) >> 26;     // extra bits of the round's longest
+        if (__ballot(most > 32)) {
+            group(g.x); extras(hi2.z | (uint64_t)hi2.w << 32); group(g.y); extras(hi2.x | (uint64_t)hi2.y << 32);
+            group(g.z); extras(lo2.z | (uint64_t)lo2.w << 32); group(g.w); extras(lo2.x | (uint64_t)lo2.y << 32);
+        } else {                                                                  // one basic block
+            group(g.x); b.put(hi2.z, hi2.w >> 26); b.flush(); group(g.y); b.put(hi2.x, hi2.y >> 26); b.flush();
+            group(g.z); b.put(lo2.z, lo2.w >> 26); b.flush(); group(g.w); b.put(lo2.x, lo2.y >> 26); b.flush();
+        }
+        if (++since == 2) { b.drain(); since = 0; }                               // <= 2 rounds x 4 x 83 bits since the last one
         i -= 4; r++;
     }
     b.drain();
-    if (i >= 2) step(x2, pre(y2));
-    if (i >= 1) step(x1, pre(y1));
-    if (i >= 0) step(x0, pre(y0));
-    { const uint32_t am = T.al[2], ao = T.al[1], al = T.al[0]; b.put(sm & ((1u << am) - 1u), am); b.flush(); b.put(so & ((1u << ao) - 1u), ao); b.put(sl & ((1u << al) - 1u), al); }
+    r = r0 + rmax;
+    zke_wait_round(chain_at, (int32_t)r + 1);
+    const zke_u32x4 g = zke_lds_ld_at<zke_u32x4>(gat + (r % ZKE_SEQ_SLOTS) * (16 * ZKE_ENT_BLOCKS));
+    zke_lds_st_at<uint32_t>(emit_at, r + 1);
+    if (i >= 2) { group(g.x); extras(x2); }
+    if (i >= 1) { group(g.y); extras(x1); }
+    if (i >= 0) { group(g.z); extras(x0); }
+    b.put(g.w & 0x3FFFFFFu, g.w >> 26);
     return b.close();
 }
 
@@ -359,26 +428,43 @@ __device__ __forceinline__ uint32_t zke_write_sequences(const TT &T, const ZkEnc
 // was rewritten by zk_k_enc_fse_build); meanwhile waves 0, 2, 3 detect RLE blocks and count literals, wave 0 builds the 16 Huffman
 // codes (lane j builds block j's) and then writes the 16 x 4 literal streams; all waves copy the payloads together at the end.
 // (A wave with fewer than 16 active lanes runs ~3x slower on gfx950, tools/ubench/lat3.hip.)
+#ifndef ZKE_HUF_BUILDS
+#define ZKE_HUF_BUILDS 8
+#endif
+// The workgroup's LDS.  It is passed as DYNAMIC shared memory: knowing its size the compiler concludes that four waves fit per SIMD
+// and rounds the kernel's register count up to the least that allows no more (97 instead of the 91 it uses) -- five-wave workgroups
+// with 104 allocated registers go two to a CU (tools/ubench/occ.hip), with 96 three.
+struct ZkeEntShared {
+    uint32_t cnt[ZKE_ENT_BLOCKS][256];                    // literal histograms; later the literal writers' staging areas
+    ZkeSeqShared seq;                                      // the sequence waves' rounds (zke_seq_chain / zke_seq_emit)
+    zke_u32x4 seq_stage[ZKE_ENT_BLOCKS * ZKE_STAGE / 16];  // the emitter's output on its way to HBM (ZkeBitsL)
+    ZkEncTables T;                                         // the FSE compression tables of the frame of the workgroup's first block
+    ZkHufCode hw[ZKE_ENT_BLOCKS];
+    ZkHufBuild hbuild[ZKE_HUF_BUILDS];                     // trees built side by side (a build needs 1.9 KiB of LDS, the codes 384 B): 16 / NHB rounds
+    uint32_t sizes[ZKE_ENT_BLOCKS][5];                     // 4 literal streams + sequence bitstream
+    uint32_t lit_mode[ZKE_ENT_BLOCKS], maxbits[ZKE_ENT_BLOCKS], tree[ZKE_ENT_BLOCKS], diff[ZKE_ENT_BLOCKS], mode[ZKE_ENT_BLOCKS];
+    uint32_t hist_done;                                    // waves 2, 3 -> wave 0: my histogram passes are done
+};
+static_assert(64 * ZKE_LIT_STAGE <= sizeof(uint32_t) * ZKE_ENT_BLOCKS * 256, "the literal writers' staging areas take the histograms' place");
+static_assert(sizeof(ZkeEntShared) <= 51200, "three workgroups per CU and room for the checksum kernel's eight waves beside them: 160 KiB in units of 1280 bytes");
+extern __shared__ __attribute__((aligned(16))) uint8_t zke_ent_lds[];
 __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks,
                                                                    uint32_t nblocks, uint64_t *seqs, uint32_t *mpos, const uint8_t *lits,
                                                                    uint8_t *scratch, const ZkEncTables *ftab)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[ZKE_ENT_BLOCKS][256];   // literal histograms; later the literal writers' staging areas
-    static_assert(64 * ZKE_LIT_STAGE <= sizeof(uint32_t) * ZKE_ENT_BLOCKS * 256, "the literal writers' staging areas take the histograms' place");
-    __shared__ ZkEncTables T;                              // the FSE compression tables of the frame of the workgroup's first block
-    __shared__ ZkHufCode hw[ZKE_ENT_BLOCKS];
-#ifndef ZKE_HUF_BUILDS
-#define ZKE_HUF_BUILDS 8
-#endif
-    constexpr uint32_t NHB = ZKE_HUF_BUILDS;                // trees built side by side (a build needs 1.9 KiB of LDS, the codes 384 B): 16 / NHB rounds
-    __shared__ ZkHufBuild hbuild[NHB];
-    __shared__ uint32_t s_sizes[ZKE_ENT_BLOCKS][5];        // 4 literal streams + sequence bitstream
-    __shared__ uint32_t s_lit_mode[ZKE_ENT_BLOCKS], s_maxbits[ZKE_ENT_BLOCKS], s_tree[ZKE_ENT_BLOCKS], s_diff[ZKE_ENT_BLOCKS], s_mode[ZKE_ENT_BLOCKS];
-    __shared__ uint32_t s_hist_done;                       // waves 2, 3 -> wave 0: my histogram passes are done
-    __shared__ zke_u32x4 s_seq_ring[ZKE_SEQ_SLOTS * ZKE_SEQ_SLOT / 16];   // the sequence writers' rounds (zke_write_sequences)
-    __shared__ zke_u32x4 s_seq_stage[ZKE_ENT_BLOCKS * ZKE_STAGE / 16];    // and their output on its way to HBM (ZkeBitsL)
+    ZkeEntShared &S = *reinterpret_cast<ZkeEntShared *>(zke_ent_lds);
+    uint32_t (&cnt)[ZKE_ENT_BLOCKS][256] = S.cnt;
+    ZkEncTables &T = S.T;
+    ZkHufCode (&hw)[ZKE_ENT_BLOCKS] = S.hw;
+    constexpr uint32_t NHB = ZKE_HUF_BUILDS;
+    ZkHufBuild (&hbuild)[NHB] = S.hbuild;
+    uint32_t (&s_sizes)[ZKE_ENT_BLOCKS][5] = S.sizes;
+    uint32_t (&s_lit_mode)[ZKE_ENT_BLOCKS] = S.lit_mode, (&s_maxbits)[ZKE_ENT_BLOCKS] = S.maxbits, (&s_tree)[ZKE_ENT_BLOCKS] = S.tree, (&s_diff)[ZKE_ENT_BLOCKS] = S.diff, (&s_mode)[ZKE_ENT_BLOCKS] = S.mode;
+    uint32_t &s_hist_done = S.hist_done;
+    ZkeSeqShared &s_seq = S.seq;
+    zke_u32x4 (&s_seq_stage)[ZKE_ENT_BLOCKS * ZKE_STAGE / 16] = S.seq_stage;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // roles: wave 0 = Huffman builds + literal writers, 1 = sequence writers, 2 / 3 = helpers.  (Rotating the roles over the waves from
+    // roles: see ZKE_ENT_WAVES.  (Rotating the roles over the waves from
     // workgroup to workgroup -- so that the chains of the workgroups sharing a CU would not meet on one SIMD -- changed nothing: 11.1 / 11.2 / 11.6 ms.)
     const uint32_t role = wave;
     const uint32_t b0 = blockIdx.x * ZKE_ENT_BLOCKS;
@@ -389,29 +475,35 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
     const uint32_t frame_a = blocks[b0].frame;
     for (uint32_t i = tid; i < sizeof(ZkEncTables) / 4; i += ZKE_ENT_THREADS) ((uint32_t *)&T)[i] = ((const uint32_t *)&ftab[frame_a])[i];
     if (tid < ZKE_ENT_BLOCKS) s_diff[tid] = 0;
-    if (tid == 0) s_hist_done = 0;
+    if (tid == 0) { s_hist_done = 0; s_seq.chain_round = 0; s_seq.emit_round = 0; }
     __syncthreads();
-    if (role == 1) {
-#ifdef ZKE_SEQ_PRIO
-        __builtin_amdgcn_s_setprio(ZKE_SEQ_PRIO);
-#endif
-        // the sequence bit writers -- the longest chain of the workgroup (62 % of its life when they started last) -- start with
-        // the kernel: their input was rewritten by zk_k_enc_fse_build, they need nothing of what the other waves prepare
-        if (lane < ZKE_ENT_BLOCKS) {
-            const uint32_t j = lane;
-            uint32_t sz = 0;
-            if (j < nb && blocks[b0 + j].nseq) {
-                // the tables come out of LDS when the block belongs to the workgroup's first frame (the rule: 16 blocks of one
-                // frame per workgroup), out of HBM for the blocks of another frame in a mixed workgroup
-                if (blocks[b0 + j].frame == frame_a) sz = zke_write_sequences(T, blocks[b0 + j], seqs, mpos, scratch, (uint8_t *)s_seq_ring, (uint8_t *)s_seq_stage, lane);
-                else sz = zke_write_sequences(ftab[blocks[b0 + j].frame], blocks[b0 + j], seqs, mpos, scratch, (uint8_t *)s_seq_ring, (uint8_t *)s_seq_stage, lane);
-            }
-            s_sizes[lane][4] = sz;
+    if (role == 1 || role == ZKE_ENT_EMITTER) {
+        // the sequence bitstreams (wave 1: the FSE chains, wave 4: the emitter; lane j of both = block j) -- the longest chain of the
+        // workgroup, so it starts with the kernel: the input was rewritten by zk_k_enc_fse_build, nothing of what the other waves
+        // prepare is needed.  The tables come out of LDS when the block belongs to the workgroup's first frame (the rule: 16 blocks
+        // of one frame per workgroup), out of HBM for the blocks of another frame in a mixed workgroup: two phases
+        const uint32_t j = lane;
+        const bool have = lane < (uint32_t)ZKE_ENT_BLOCKS && j < nb && blocks[b0 + (j < nb ? j : 0)].nseq != 0;
+        const bool own = have && blocks[b0 + j].frame == frame_a, other = have && !own;
+        const uint32_t myr = have ? zke_seq_rounds(blocks[b0 + j].nseq) : 0;
+        uint32_t r_own = own ? myr : 0, r_other = other ? myr : 0;
+#pragma unroll
+        for (int m = 1; m < ZKE_ENT_BLOCKS; m <<= 1) { r_own = max(r_own, (uint32_t)__shfl_xor((int)r_own, m, 64)); r_other = max(r_other, (uint32_t)__shfl_xor((int)r_other, m, 64)); }
+        const uint32_t r1 = __ballot(own) ? r_own + 1 : 0;                        // the second phase's first round
+        const uint32_t sh = (uint32_t)(uintptr_t)&s_seq;
+        uint32_t sz = 0;
+        if (role == 1) {
+            if (own) zke_seq_chain(T, blocks[b0 + j], seqs, mpos, sh, lane, 0, r_own);
+            if (other) zke_seq_chain(ftab[blocks[b0 + j].frame], blocks[b0 + j], seqs, mpos, sh, lane, r1, r_other);
+        } else {
+            if (own) sz = zke_seq_emit(blocks[b0 + j], seqs, scratch, sh, (uint32_t)(uintptr_t)s_seq_stage, lane, 0, r_own);
+            if (other) sz = zke_seq_emit(blocks[b0 + j], seqs, scratch, sh, (uint32_t)(uintptr_t)s_seq_stage, lane, r1, r_other);
+            if (lane < (uint32_t)ZKE_ENT_BLOCKS) s_sizes[lane][4] = sz;
         }
         ZKE_ECLK(4);
     } else {
-        constexpr uint32_t HT = ZKE_ENT_THREADS - 64;
-        const uint32_t ht = (role ? role - 1 : 0) * 64 + lane;  // my index among the lanes of roles 0, 2, 3
+        constexpr uint32_t HT = (1 + ZKE_ENT_HELPERS) * 64;     // the lanes of wave 0 and the helpers
+        const uint32_t ht = (role ? role - (3 - ZKE_ENT_HELPERS) : 0) * 64 + lane;  // my index among them
         // raw block all one byte?  literal histogram -- waves 0, 2 and 3, block after block
         for (uint32_t j = 0; j < nb; j++) {
             const ZkEncBlock &blk = blocks[b0 + j];
@@ -449,24 +541,63 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
         // order, so their counts are in place when the flag moves), wave 0 waits for both
         if (role >= 2) { if (lane == 0) atomicAdd(&s_hist_done, 1u); }
         else {
-            while (__hip_atomic_load(&s_hist_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2u) __builtin_amdgcn_s_sleep(2);
+            while (__hip_atomic_load(&s_hist_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ZKE_ENT_HELPERS) __builtin_amdgcn_s_sleep(2);
             ZKE_ECLK(1);
-            // literal mode + Huffman code: two rounds of 8 blocks, block j on lanes j % 8 and j % 8 + 8 of wave 0 (the second
-            // lane shadows the first with identical LDS writes: >= 16 active lanes, see zk_decode.hip)
+            // literal mode + Huffman code, NHB blocks at a time (a build's scratch is 1.9 KiB)
             for (uint32_t round = 0; round < ZKE_ENT_BLOCKS / NHB; round++) {
-                if (lane < ZKE_ENT_BLOCKS) {
-                    const uint32_t j = (lane & (NHB - 1)) + NHB * round;
-                    if (j < nb) {
-                        const uint32_t nlit = blocks[b0 + j].nlit;
-                        // literal mode: 1 = RLE, 2 = Huffman (4 streams), 0 = raw      (oracle encode_literals)
-                        uint32_t mode = 0, maxsym = 0, distinct = 0;
-                        for (uint32_t sy = 0; sy < 256; sy++) if (cnt[j][sy]) { maxsym = sy; distinct++; }
-                        if (nlit > 0 && distinct == 1) mode = 1;
-                        else if (nlit >= 64 && maxsym < 128) {
-                            int mb = zke_huf_lengths(cnt[j], (int)maxsym + 1, &hbuild[lane & (NHB - 1)], hw[j].len);
-                            if (mb > 0) { zke_huf_codes(&hw[j], (int)maxsym + 1, mb); mode = 2; s_maxbits[j] = (uint32_t)mb; s_tree[j] = maxsym; }
+                // (A) all lanes, block after block: the literal mode (1 = RLE, 2 = Huffman in 4 streams, 0 = raw; oracle encode_literals) and,
+                // for a block that gets a code, its symbols in the order (count, symbol): a lane ranks symbols lane and lane + 64 against all
+                for (uint32_t jj = 0; jj < NHB; jj++) {
+                    const uint32_t j = jj + NHB * round;
+                    if (j >= nb) break;
+                    const uint32_t c0 = cnt[j][lane], c1 = cnt[j][lane + 64], c2 = cnt[j][lane + 128], c3 = cnt[j][lane + 192];
+                    const uint64_t m0 = __ballot(c0 != 0), m1 = __ballot(c1 != 0), m2 = __ballot(c2 != 0), m3 = __ballot(c3 != 0);
+                    const uint32_t distinct = (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+                    const uint32_t maxsym = m3 ? 255u - (uint32_t)__builtin_clzll(m3) : m2 ? 191u - (uint32_t)__builtin_clzll(m2) : m1 ? 127u - (uint32_t)__builtin_clzll(m1)
+                                                                                        : m0 ? 63u - (uint32_t)__builtin_clzll(m0) : 0u;
+                    const uint32_t nlit = blocks[b0 + j].nlit;
+                    uint32_t mode = 0;
+                    if (nlit > 0 && distinct == 1) mode = 1;
+                    else if (nlit >= 64 && maxsym < 128) {
+                        mode = 3;                                                     // to be built
+                        const uint32_t key0 = c0 ? (c0 << 8) | lane : 0xFFFFFFFFu, key1 = c1 ? (c1 << 8) | (lane + 64) : 0xFFFFFFFFu;
+                        uint32_t r0 = 0, r1 = 0;
+#pragma unroll
+                        for (int t = 0; t < 64; t++) {
+                            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key0, t), k1 = (uint32_t)__builtin_amdgcn_readlane((int)key1, t);
+                            r0 += (k0 < key0) + (k1 < key0); r1 += (k0 < key1) + (k1 < key1);
                         }
-                        s_lit_mode[j] = mode;
+                        if (c0) hbuild[jj].idx[r0] = (uint8_t)lane;
+                        if (c1) hbuild[jj].idx[r1] = (uint8_t)(lane + 64);
+                    }
+                    if (lane == 0) { s_lit_mode[j] = mode; s_tree[j] = maxsym; s_maxbits[j] = distinct; }
+                }
+                // (B) one lane per block: the tree and the code lengths.  Block j on lanes j % NHB and j % NHB + NHB (the second lane
+                // shadows the first with identical LDS writes: >= 16 active lanes, see zk_decode.hip)
+                if (lane < 2 * NHB) {
+                    const uint32_t j = (lane & (NHB - 1)) + NHB * round;
+                    if (j < nb && s_lit_mode[j] == 3) {
+                        const int mb = zke_huf_lengths(cnt[j], (int)s_tree[j] + 1, &hbuild[lane & (NHB - 1)], hw[j].len, (int)s_maxbits[j]);
+                        s_lit_mode[j] = mb > 0 ? 2u : 0u; s_maxbits[j] = mb > 0 ? (uint32_t)mb : 0u;
+                    }
+                }
+                // (C) all lanes again: the canonical codes exactly as the decoder's table fill assigns them -- weight 1 first, symbols
+                // ascending (zke_huf_codes, here with ballots instead of 11 passes over the symbols)
+                for (uint32_t jj = 0; jj < NHB; jj++) {
+                    const uint32_t j = jj + NHB * round;
+                    if (j >= nb) break;
+                    if (s_lit_mode[j] != 2) continue;
+                    const uint32_t mb = s_maxbits[j];
+                    const uint32_t l0 = hw[j].len[lane], l1 = hw[j].len[lane + 64];
+                    const uint32_t w0 = l0 ? mb + 1 - l0 : 0, w1 = l1 ? mb + 1 - l1 : 0;
+                    const uint64_t below = (1ull << lane) - 1ull;
+                    uint32_t pos = 0;
+                    for (uint32_t wt = 1; wt <= mb; wt++) {
+                        const uint64_t b0m = __ballot(w0 == wt), b1m = __ballot(w1 == wt);
+                        const uint32_t n0 = (uint32_t)__popcll(b0m), n1 = (uint32_t)__popcll(b1m);
+                        if (w0 == wt) hw[j].code[lane] = (uint16_t)((pos >> (wt - 1)) + (uint32_t)__popcll(b0m & below));
+                        if (w1 == wt) hw[j].code[lane + 64] = (uint16_t)((pos >> (wt - 1)) + n0 + (uint32_t)__popcll(b1m & below));
+                        pos += (n0 + n1) << (wt - 1);
                     }
                 }
             }
@@ -799,7 +930,7 @@ void zk_launch_enc_entropy(hipStream_t st, const uint8_t *src, const ZkEncFrame 
                            uint64_t *seqs, uint32_t *mpos, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *ftab)
 {
     if (!nblocks) return;
-    hipLaunchKernelGGL(zk_k_enc_entropy, dim3((nblocks + ZKE_ENT_BLOCKS - 1) / ZKE_ENT_BLOCKS), dim3(ZKE_ENT_THREADS), 0, st, src, frames, blocks, nblocks, seqs, mpos, lits, scratch, ftab);
+    hipLaunchKernelGGL(zk_k_enc_entropy, dim3((nblocks + ZKE_ENT_BLOCKS - 1) / ZKE_ENT_BLOCKS), dim3(ZKE_ENT_THREADS), sizeof(ZkeEntShared), st, src, frames, blocks, nblocks, seqs, mpos, lits, scratch, ftab);
 }
 void zk_launch_enc_sizes(hipStream_t st, const ZkEncFrame *frames, uint32_t nframes, ZkEncBlock *blocks, const ZkEncTables *ftab, int checksum,
                          uint64_t *c_size64, uint32_t *c_sizes, uint32_t *d_sizes)
