@@ -87,10 +87,24 @@ struct ZkEncLdm {
     uint32_t log, pad;
 };
 
+// A compressed block's payload is put together by zk_k_enc_assemble out of the pieces the entropy stage leaves in the block's scratch:
+//   [0, 16)      ZkEncPieces
+//   [16, ...)    the literals section's head (header, tree description, jump table -- or the raw / RLE header and RLE byte), then the
+//                sequences section's head (Number_of_Sequences, Symbol_Compression_Modes)
+//   [ZKE_SMALL + k * scap, ...)   literal stream k (scap = q + q / 2 + 16, q = ceil(nlit / 4)),   [ZKE_SMALL + 4 * scap, ...)  the sequence bitstream
+constexpr uint32_t ZKE_SMALL = 128;
+struct ZkEncPieces {
+    uint16_t z[4];              // bytes of the 4 literal streams (lit_mode 2)
+    uint32_t zs;                // bytes of the sequence bitstream
+    uint8_t head_lit, head_seq; // bytes of the two heads
+    uint8_t lit_mode;           // 0 raw (the literal bytes follow the head: nlit of them out of the literal buffer), 1 RLE, 2 Huffman in 4 streams
+    uint8_t pad;
+};
+static_assert(sizeof(ZkEncPieces) == 16, "one 16-byte load");
 struct ZkEncBlock {
     uint64_t seq_base;          // packed sequences (ll | ml << 16 | Offset_Value << 32)
     uint64_t lit_base;          // literal bytes
-    uint64_t scratch_base;      // payload + bitstream temporaries
+    uint64_t scratch_base;      // the block's part of the entropy stage's scratch (ZKE_SMALL bytes of small parts, the 4 literal streams, the sequence stream)
     uint32_t frame, bs, bsz;    // frame index, start inside the frame, size
     uint32_t nseq, nlit;
     uint32_t csize;             // content bytes that follow the 3-byte block header (incl. the table descriptions of a defining block)

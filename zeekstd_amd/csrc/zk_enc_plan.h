@@ -70,7 +70,7 @@ inline void zke_plan_fill(uint64_t n, uint32_t frame_size, int level, uint64_t p
             k.lit_base = fr.src_off + k.bs;
             k.scratch_base = scratch_total;
             const uint32_t q = (k.bsz + 3) / 4;
-            scratch_total += (uint64_t)k.bsz * 2 + 4ull * (q + (q >> 1) + 16) + 64;
+            scratch_total += ZKE_SMALL + 4ull * (q + (q >> 1) + 16) + (uint64_t)k.bsz + 64;   // small parts, 4 literal streams, the sequence bitstream + its slack
         }
         if (doff) doff[f] = fr.src_off;
         const uint32_t per = ZKE_SEGMENT / fr.block_max;      // blocks per segment (frames above ZKE_SEGMENT have 16 or 32 KiB blocks)

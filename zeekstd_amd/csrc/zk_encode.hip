@@ -380,7 +380,7 @@ __device__ __forceinline__ uint32_t zke_seq_emit(const ZkEncBlock &blk, const ui
 {
     const uint32_t nseq = blk.nseq, q = (blk.nlit + 3) / 4, scap = q + (q >> 1) + 16;
     const uint64_t *sq = seqs + blk.seq_base;
-    ZkeBitsL b; b.init(scratch + blk.scratch_base + blk.bsz + 4 * scap, blk.bsz, blk.bsz + 64, stage + ZKE_STAGE * lane);
+    ZkeBitsL b; b.init(scratch + blk.scratch_base + ZKE_SMALL + 4 * scap, blk.bsz, blk.bsz + 64, stage + ZKE_STAGE * lane);
     const uint32_t ring = sh + (uint32_t)offsetof(ZkeSeqShared, ring) + 16 * lane, gat = sh + (uint32_t)offsetof(ZkeSeqShared, g) + 16 * lane;
     const uint32_t emit_at = sh + (uint32_t)offsetof(ZkeSeqShared, emit_round), chain_at = sh + (uint32_t)offsetof(ZkeSeqShared, chain_round);
     int32_t i = (int32_t)nseq - 2;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
                     // last symbol first; the stream is read 8 bytes at a time, three words ahead (unconditional loads: a clamped address
                     // reads the stream's first bytes again).  The bits go through the lane's staging area in LDS (the histograms' space:
                     // the codes are built) and reach HBM 16 bytes at a time, every fourth round
-                    ZkeBitsL b; b.init(scratch + blk.scratch_base + blk.bsz + k * scap, scap - 8, scap, (uint32_t)(uintptr_t)&cnt[0][0] + ZKE_LIT_STAGE * lane);
+                    ZkeBitsL b; b.init(scratch + blk.scratch_base + ZKE_SMALL + k * scap, scap - 8, scap, (uint32_t)(uintptr_t)&cnt[0][0] + ZKE_LIT_STAGE * lane);
                     const ZkHufCode &h = hw[j];
                     uint32_t i = n_k;
                     auto two = [&](uint32_t s0, uint32_t s1) {                                      // <= 22 bits
@@ -678,69 +678,58 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
         blk->rle_byte = src[frames[blk->frame].src_off + blk->bs];
     }
     __syncthreads();
-    // write the payloads: literals section, Number_of_Sequences, modes byte, sequence bitstream
-    // one wave per block: four blocks are assembled side by side
-    for (uint32_t j = wave; j < nb; j += ZKE_ENT_THREADS / 64) {
-        if (s_mode[j] != 2) continue;
+    // the small parts of every compressed block (lane j of wave 0): the piece table and the two heads.  The streams stay where their
+    // writers left them: zk_k_enc_assemble puts the payload together at its place in the output
+    if (tid < ZKE_ENT_BLOCKS && tid < nb && s_mode[tid] == 2) {
+        const uint32_t j = tid;
         const ZkEncBlock &blk = blocks[b0 + j];
-        const uint32_t nlit = blk.nlit, nseq = blk.nseq, bsz = blk.bsz;
-        const uint32_t q = (nlit + 3) / 4, scap = q + (q >> 1) + 16;
-        uint8_t *payload = scratch + blk.scratch_base;
-        const uint8_t *stemp = payload + bsz, *qtemp = stemp + 4 * scap;
+        const uint32_t nlit = blk.nlit, nseq = blk.nseq;
+        uint8_t *small = scratch + blk.scratch_base, *head = small + sizeof(ZkEncPieces);
         const uint8_t *lt = lits + blk.lit_base;
         const uint32_t lm = s_lit_mode[j];
         const uint32_t raw_hdr = nlit < 32 ? 1 : nlit < 4096 ? 2 : 3;
         const uint32_t *z = s_sizes[j];
-        uint32_t p = 0;
+        ZkEncPieces pc;
+        pc.z[0] = pc.z[1] = pc.z[2] = pc.z[3] = 0; pc.zs = nseq ? z[4] : 0; pc.lit_mode = (uint8_t)lm; pc.pad = 0;
+        uint32_t w = 0, lit_bytes = 0;
         if (lm == 2) {
             const uint32_t hdr = nlit < 1024 ? 3 : nlit < 16384 ? 4 : 5, tree = 1 + (s_tree[j] + 1) / 2, mb = s_maxbits[j];
             const uint32_t comp = tree + 6 + z[0] + z[1] + z[2] + z[3];
-            if (lane == 0) {
-                uint64_t h = hdr == 3 ? (2ull | (1 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 14))
-                           : hdr == 4 ? (2ull | (2 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 18))
-                                      : (2ull | (3 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 22));
-                for (uint32_t i = 0; i < hdr; i++) payload[i] = (uint8_t)(h >> (8 * i));
-                uint32_t w = hdr;
-                const uint32_t nw = s_tree[j];                     // number of explicit weights (symbols 0..maxsym-1)
-                payload[w++] = (uint8_t)(127 + nw);
-                for (uint32_t i = 0; i < nw; i += 2) {
-                    const uint32_t w0 = hw[j].len[i] ? mb + 1 - hw[j].len[i] : 0;
-                    const uint32_t w1 = (i + 1 < nw && hw[j].len[i + 1]) ? mb + 1 - hw[j].len[i + 1] : 0;
-                    payload[w++] = (uint8_t)((w0 << 4) | w1);
-                }
-                for (int k = 0; k < 3; k++) { payload[w++] = (uint8_t)z[k]; payload[w++] = (uint8_t)(z[k] >> 8); }
+            const uint64_t h = hdr == 3 ? (2ull | (1 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 14))
+                             : hdr == 4 ? (2ull | (2 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 18))
+                                        : (2ull | (3 << 2) | ((uint64_t)nlit << 4) | ((uint64_t)comp << 22));
+            for (uint32_t i = 0; i < hdr; i++) head[w++] = (uint8_t)(h >> (8 * i));
+            const uint32_t nw = s_tree[j];                         // number of explicit weights (symbols 0..maxsym-1)
+            head[w++] = (uint8_t)(127 + nw);
+            for (uint32_t i = 0; i < nw; i += 2) {
+                const uint32_t w0 = hw[j].len[i] ? mb + 1 - hw[j].len[i] : 0;
+                const uint32_t w1 = (i + 1 < nw && hw[j].len[i + 1]) ? mb + 1 - hw[j].len[i + 1] : 0;
+                head[w++] = (uint8_t)((w0 << 4) | w1);
             }
-            p = hdr + tree + 6;
-            for (int k = 0; k < 4; k++) {
-                const uint8_t *sp = stemp + k * scap;
-                zke_copy_wave(payload + p, sp, z[k], lane);
-                p += z[k];
-            }
+            for (int k = 0; k < 3; k++) { head[w++] = (uint8_t)z[k]; head[w++] = (uint8_t)(z[k] >> 8); }
+            for (int k = 0; k < 4; k++) pc.z[k] = (uint16_t)z[k];
+            lit_bytes = z[0] + z[1] + z[2] + z[3];
         } else {
-            if (lane == 0) {
-                const uint32_t t = lm;                             // 0 raw, 1 rle
-                if (raw_hdr == 1) payload[0] = (uint8_t)(t | (nlit << 3));
-                else if (raw_hdr == 2) { payload[0] = (uint8_t)(t | (1 << 2) | (nlit << 4)); payload[1] = (uint8_t)(nlit >> 4); }
-                else { payload[0] = (uint8_t)(t | (3 << 2) | (nlit << 4)); payload[1] = (uint8_t)(nlit >> 4); payload[2] = (uint8_t)(nlit >> 12); }
-                if (lm == 1) payload[raw_hdr] = lt[0];
-            }
-            p = raw_hdr;
-            if (lm == 1) p += 1;
-            else { zke_copy_wave(payload + p, lt, nlit, lane); p += nlit; }
+            const uint32_t t = lm;                                 // 0 raw, 1 rle
+            if (raw_hdr == 1) head[0] = (uint8_t)(t | (nlit << 3));
+            else if (raw_hdr == 2) { head[0] = (uint8_t)(t | (1 << 2) | (nlit << 4)); head[1] = (uint8_t)(nlit >> 4); }
+            else { head[0] = (uint8_t)(t | (3 << 2) | (nlit << 4)); head[1] = (uint8_t)(nlit >> 4); head[2] = (uint8_t)(nlit >> 12); }
+            w = raw_hdr;
+            if (lm == 1) head[w++] = lt[0]; else lit_bytes = nlit;
         }
-        if (lane == 0) {
-            if (nseq < 128) payload[p] = (uint8_t)nseq;
-            else if (nseq < 0x7F00) { payload[p] = (uint8_t)((nseq >> 8) + 128); payload[p + 1] = (uint8_t)nseq; }
-            else { payload[p] = 255; payload[p + 1] = (uint8_t)(nseq - 0x7F00); payload[p + 2] = (uint8_t)((nseq - 0x7F00) >> 8); }
-        }
-        p += nseq < 128 ? 1 : nseq < 0x7F00 ? 2 : 3;
+        pc.head_lit = (uint8_t)w;
+        uint32_t v = w;
+        if (nseq < 128) head[v++] = (uint8_t)nseq;
+        else if (nseq < 0x7F00) { head[v++] = (uint8_t)((nseq >> 8) + 128); head[v++] = (uint8_t)nseq; }
+        else { head[v++] = 255; head[v++] = (uint8_t)(nseq - 0x7F00); head[v++] = (uint8_t)((nseq - 0x7F00) >> 8); }
         if (nseq) {
             // Symbol_Compression_Modes in its Repeat_Mode form (the frame's own tables: 3, predefined ones: 0); the block
             // that turns out to be the frame's first compressed one gets FSE_Compressed_Mode + the descriptions at assembly
-            if (lane == 0) { payload[p] = (uint8_t)zke_modes_byte(ftab[blk.frame].custom, 3); blocks[b0 + j].modes_off = p; }
-            p += 1;
-            zke_copy_wave(payload + p, qtemp, z[4], lane);
+            blocks[b0 + j].modes_off = w + lit_bytes + (v - w);                       // where the byte sits in the payload
+            head[v++] = (uint8_t)zke_modes_byte(ftab[blk.frame].custom, 3);
         }
+        pc.head_seq = (uint8_t)(v - w);
+        memcpy(small, &pc, sizeof pc);
     }
     ZKE_ECLK(6);
     ZKE_ECLK_END();
@@ -819,7 +808,7 @@ __device__ __forceinline__ void zke_copy_wg(uint8_t *dst, const uint8_t *from, u
     if (t < n) dst[t] = from[t];
 }
 __global__ __launch_bounds__(256) void zk_k_enc_assemble(const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, const ZkEncTables *ftab,
-                                                         const uint8_t *scratch, const uint64_t *out_off, const uint64_t *c_size64, const uint64_t *hashes,
+                                                         const uint8_t *lits, const uint8_t *scratch, const uint64_t *out_off, const uint64_t *c_size64, const uint64_t *hashes,
                                                          int checksum, uint8_t *dst)
 {
     const uint32_t tid = threadIdx.x;
@@ -847,20 +836,44 @@ __global__ __launch_bounds__(256) void zk_k_enc_assemble(const uint8_t *src, con
     if (tid == 0) { const uint32_t h = last | (blk.mode << 1) | (field << 3); o[p] = (uint8_t)h; o[p + 1] = (uint8_t)(h >> 8); o[p + 2] = (uint8_t)(h >> 16); }
     p += 3;
     if (blk.mode == 1) { if (tid == 0) o[p] = blk.rle_byte; }
-    else if (blk.mode == 2 && blk.is_def) {
-        // payload up to the modes byte, the modes byte in its defining form, the descriptions, the rest
+    else if (blk.mode == 0) zke_copy_wg(o + p, src + fr.src_off + blk.bs, blk.bsz, tid);
+    else {
+        // the payload out of its pieces (ZkEncPieces): head of the literals section, the 4 literal streams (or the raw literal bytes), head of
+        // the sequences section -- in the frame's defining block with the modes byte in its defining form and the table descriptions
+        // behind it -- and the sequence bitstream
+        const uint8_t *small = scratch + blk.scratch_base;
+        ZkEncPieces pc; memcpy(&pc, small, sizeof pc);
+        const uint32_t q = (blk.nlit + 3) / 4, scap = q + (q >> 1) + 16;
+        const uint8_t *head = small + sizeof(ZkEncPieces), *stemp = small + ZKE_SMALL, *qtemp = stemp + 4 * scap;
+        if (tid < pc.head_lit) o[p + tid] = head[tid];
+        p += pc.head_lit;
+        // the five streams at once: a lane's loads of all of them are under way before its first store
+        const uint8_t *from[5]; uint32_t len[5]; uint64_t to[5];
+        uint64_t w = p;
+        for (int k = 0; k < 4; k++) { from[k] = pc.lit_mode == 2 ? stemp + k * scap : lits + blk.lit_base; len[k] = pc.lit_mode == 2 ? pc.z[k] : (k == 0 && pc.lit_mode == 0 ? blk.nlit : 0); to[k] = w; w += len[k]; }
         const ZkEncTables &ft = ftab[blk.frame];
-        const uint8_t *from = scratch + blk.scratch_base;
-        const uint32_t extra = ft.dlen[0] + ft.dlen[1] + ft.dlen[2], body = blk.csize - extra, mo = blk.modes_off;
-        zke_copy_wg(o + p, from, mo, tid);
-        if (tid == 0) o[p + mo] = (uint8_t)zke_modes_byte(ft.custom, 2);
-        uint32_t w = mo + 1;
-        for (int t = 0; t < 3; t++) { for (uint32_t i = tid; i < ft.dlen[t]; i += 256) o[p + w + i] = ft.desc[t][i]; w += ft.dlen[t]; }
-        if (body > mo + 1) zke_copy_wg(o + p + extra + mo + 1, from + mo + 1, body - (mo + 1), tid);
-    } else {
-        const uint8_t *from = blk.mode == 2 ? scratch + blk.scratch_base : src + fr.src_off + blk.bs;
-        const uint32_t n = blk.mode == 2 ? blk.csize : blk.bsz;
-        zke_copy_wg(o + p, from, n, tid);
+        if (blk.nseq && blk.is_def) {
+            const uint32_t nh = pc.head_seq - 1u;
+            if (tid < nh) o[w + tid] = head[pc.head_lit + tid];
+            if (tid == 0) o[w + nh] = (uint8_t)zke_modes_byte(ft.custom, 2);
+            w += pc.head_seq;
+            for (int t = 0; t < 3; t++) { for (uint32_t i = tid; i < ft.dlen[t]; i += 256) o[w + i] = ft.desc[t][i]; w += ft.dlen[t]; }
+        } else {
+            if (tid < pc.head_seq) o[w + tid] = head[pc.head_lit + tid];
+            w += pc.head_seq;
+        }
+        from[4] = qtemp; len[4] = pc.zs; to[4] = w;
+        uint32_t most = 0;
+        for (int k = 0; k < 5; k++) most = len[k] > most ? len[k] : most;
+        for (uint32_t b0 = 0; b0 < (most >> 4); b0 += 256) {
+            uint4 v[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) { const uint32_t i = b0 + tid; memcpy(&v[k], from[k] + 16 * (size_t)(i < (len[k] >> 4) ? i : 0), 16); }
+#pragma unroll
+            for (int k = 0; k < 5; k++) { const uint32_t i = b0 + tid; if (i < (len[k] >> 4)) memcpy(o + to[k] + 16 * (size_t)i, &v[k], 16); }
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) { const uint32_t t = (len[k] & ~15u) + (tid & 15); if ((tid >> 4) == (uint32_t)k && t < len[k]) o[to[k] + t] = from[k][t]; }
     }
 }
 
@@ -942,7 +955,7 @@ void zk_launch_scan64(hipStream_t st, const uint64_t *in, uint32_t n, uint64_t *
     hipLaunchKernelGGL(zk_k_scan64, dim3(1), dim3(1024), 0, st, in, n, out);
 }
 void zk_launch_enc_assemble(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, uint32_t nblocks, const ZkEncTables *ftab,
-                            const uint8_t *scratch, const uint64_t *out_off, const uint64_t *c_size64, const uint64_t *hashes, int checksum, uint8_t *dst)
+                            const uint8_t *lits, const uint8_t *scratch, const uint64_t *out_off, const uint64_t *c_size64, const uint64_t *hashes, int checksum, uint8_t *dst)
 {
-    hipLaunchKernelGGL(zk_k_enc_assemble, dim3(nframes + nblocks), dim3(256), 0, st, src, frames, nframes, blocks, ftab, scratch, out_off, c_size64, hashes, checksum, dst);
+    hipLaunchKernelGGL(zk_k_enc_assemble, dim3(nframes + nblocks), dim3(256), 0, st, src, frames, nframes, blocks, ftab, lits, scratch, out_off, c_size64, hashes, checksum, dst);
 }

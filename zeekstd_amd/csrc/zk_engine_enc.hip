@@ -152,7 +152,7 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         if (e->h_words[ZK_HW_ENC_TOTAL] > a.dst_cap) return -(int)ZK_E_DST_TOO_SMALL;
     }
     if (cks_beside) ZK_HIP(hipStreamWaitEvent(st, e->enc_ev_join, 0));
-    { zk_kernel_timer t(e, ZK_K_ENC_COMPACT, st); zk_launch_enc_assemble(st, src, dfr, nf, dbl, nb, ftab, (const uint8_t *)e->enc_d.p, out_off, c64, hashes, a.checksum, (uint8_t *)a.d_dst); }
+    { zk_kernel_timer t(e, ZK_K_ENC_COMPACT, st); zk_launch_enc_assemble(st, src, dfr, nf, dbl, nb, ftab, (const uint8_t *)e->enc_c.p, (const uint8_t *)e->enc_d.p, out_off, c64, hashes, a.checksum, (uint8_t *)a.d_dst); }
     if (nf_out) *nf_out = nf;
     return 0;
 }

@@ -35,4 +35,4 @@ void zk_launch_enc_sizes(hipStream_t st, const ZkEncFrame *frames, uint32_t nfra
                          uint64_t *c_size64, uint32_t *c_sizes, uint32_t *d_sizes);
 void zk_launch_scan64(hipStream_t st, const uint64_t *in, uint32_t n, uint64_t *out);
 void zk_launch_enc_assemble(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, uint32_t nblocks, const ZkEncTables *ftab,
-                            const uint8_t *scratch, const uint64_t *out_off, const uint64_t *c_size64, const uint64_t *hashes, int checksum, uint8_t *dst);
+                            const uint8_t *lits, const uint8_t *scratch, const uint64_t *out_off, const uint64_t *c_size64, const uint64_t *hashes, int checksum, uint8_t *dst);
