@@ -57,6 +57,17 @@ def test_xxh64_kernel(engine):
     assert int(h[-1]) == 0xAD0311EAAD1ED582          # SURVEY 8(d) KAT
 
 
+def test_xxh64_kernel_on_a_large_batch(engine):
+    """512 frames and more take the sixteen-frames-per-wave kernel (zk_k_xxh64_wide): ragged sizes, frames below one
+    stripe, a last frame shorter than the others, a count that is not a multiple of 16."""
+    for nf, fs, cut in [(768, 65536, 0), (600, 70001, 12345), (513, 31, 0), (520, 100, 7), (1030, 4096 + 9, 4000)]:
+        data = np.frombuffer(zko.gen_random(nf * fs - cut, nf), np.uint8)
+        off = np.arange(nf + 1, dtype=np.uint64) * fs
+        off[-1] -= cut
+        h = engine.xxh64_frames(data.tobytes(), off)
+        assert [int(x) for x in h] == [zko.xxh64(data[int(off[i]):int(off[i + 1])].tobytes()) for i in range(nf)], (nf, fs)
+
+
 def test_checksum_mismatch_is_reported(engine):
     g = next(x for x in GOLDENS if x.name == "text_l1_64k")
     c, d = g.offsets()

@@ -56,6 +56,19 @@ def test_encode_roundtrip_and_twin(engine, name, checksum):
         pos += c; dpos += d
 
 
+def test_many_small_frames_equal_the_twin(engine):
+    """768 frames of 64 KiB: 16-block workgroups of the entropy stage span eight frames each (the tables of all but the first come
+    out of HBM, the sequence waves run their two phases), thousands of Huffman codes are built -- two of these frames once came
+    out with codes assigned from stale lengths beyond a block's last symbol."""
+    data = zko.gen_chunks(48 << 20, 3)
+    fs = 65536
+    comp, frames = engine.encode_frames(data, fs, 1, True)
+    pos = dpos = 0
+    for c, d in frames:
+        assert comp[pos:pos + c] == zko.frame_encode(data[dpos:dpos + d], 1, True), dpos // fs
+        pos += c; dpos += d
+
+
 def test_empty_frame_golden_bytes(engine):
     # SURVEY Appendix B: what the reference emits for end_frame() without input
     assert engine.encode_frames(b"", 2 << 20, 1, False) == (bytes.fromhex("28b52ffd2000010000"), [(9, 0)])

@@ -1001,6 +1001,69 @@ __global__ __launch_bounds__(64) void zk_k_xxh64(const uint8_t *data, const uint
     if (infos && (uint32_t)h != infos[f].checksum) infos[f].status = ZK_E_CHECKSUM_WRONG;
 }
 
+// The same for a large batch: SIXTEEN frames per wave, lane = (frame, accumulator).  A frame's four chains are a latency floor
+// (65 536 dependent rounds per 2 MiB, ~110 clocks each) whatever runs them; one wave per frame spends a whole wave's instruction
+// slots on 4 (16) lanes -- 1.7 G wave instructions per 4 GiB, a twelfth of what the encoder's matcher issues, and whichever kernel
+// runs beside the checksums pays for them (the entropy stage: 6.3 -> 7.6 ms).  Here the same chains cost a sixteenth of that:
+// 128 waves for 2048 frames, a lane loading its own 8 bytes of every stripe, 24 stripes per batch, two batches under way.
+constexpr int ZK_XXW = 24;
+__global__ __launch_bounds__(64) void zk_k_xxh64_wide(const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
+                                                      ZkFrameInfo *infos, uint64_t *hashes)
+{
+    const uint32_t lane = threadIdx.x, f = blockIdx.x * 16 + (lane >> 2), kl = lane & 3;
+    bool live = f < count;
+    if (live && infos && !(infos[f].status == ZK_OK && infos[f].checksum_flag)) live = false;
+    const uint32_t fa = live ? f : 0;                       // (a lane without a frame reads frame 0 and keeps nothing)
+    const uint8_t *p = data + (d_off[first + fa] - d_off[first]);
+    const uint64_t len = d_off[first + fa + 1] - d_off[first + fa];
+    const uint64_t nstripes = live ? len >> 5 : 0;
+    uint64_t acc = kl == 0 ? XP1 + XP2 : kl == 1 ? XP2 : kl == 2 ? 0 : 0 - XP1;
+    // the stripes every live frame of the wave has, in whole double batches: no predicates
+    uint64_t least = live ? nstripes : ~0ull;
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) { const uint64_t o = __shfl_xor(least, m, 64); least = o < least ? o : least; }
+    if (least == ~0ull) return;                             // no frame to hash in this wave
+    const uint64_t common = least - least % (2 * ZK_XXW);
+    const uint8_t *q = p + 8 * kl;
+    uint64_t wa[ZK_XXW], wb[ZK_XXW];
+    if (common) {
+#pragma unroll
+        for (int u = 0; u < ZK_XXW; u++) wa[u] = zk_ld64(q + 32 * (uint64_t)u);
+        for (uint64_t s = 0; s < common; s += 2 * ZK_XXW) {
+#pragma unroll
+            for (int u = 0; u < ZK_XXW; u++) wb[u] = zk_ld64(q + 32 * (s + ZK_XXW + u));
+#pragma unroll
+            for (int u = 0; u < ZK_XXW; u++) acc = zk_xround(acc, wa[u]);
+            const uint64_t nx = s + 2 * ZK_XXW < common ? s + 2 * ZK_XXW : 0;     // (the last round reads the frame's first batch again)
+#pragma unroll
+            for (int u = 0; u < ZK_XXW; u++) wa[u] = zk_ld64(q + 32 * (nx + u));
+#pragma unroll
+            for (int u = 0; u < ZK_XXW; u++) acc = zk_xround(acc, wb[u]);
+        }
+    }
+    // what is left of the longer frames, stripe by stripe
+    for (uint64_t i = common; i < nstripes; i++) acc = zk_xround(acc, zk_ld64(q + (i << 5)));
+    const uint32_t base = lane & ~3u;
+    const uint64_t v1 = __shfl(acc, base, 64), v2 = __shfl(acc, base + 1, 64), v3 = __shfl(acc, base + 2, 64), v4 = __shfl(acc, base + 3, 64);
+    if (kl != 0 || !live) return;
+    uint64_t h;
+    if (len >= 32) {
+        h = zk_rotl64(v1, 1) + zk_rotl64(v2, 7) + zk_rotl64(v3, 12) + zk_rotl64(v4, 18);
+        h = (h ^ zk_xround(0, v1)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v2)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v3)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v4)) * XP1 + XP4;
+    } else h = XP5;
+    h += len;
+    const uint8_t *t = p + (nstripes << 5), *end = p + len;
+    while (t + 8 <= end) { h ^= zk_xround(0, zk_ld64(t)); h = zk_rotl64(h, 27) * XP1 + XP4; t += 8; }
+    if (t + 4 <= end) { h ^= (uint64_t)zk_rd32(t) * XP1; h = zk_rotl64(h, 23) * XP2 + XP3; t += 4; }
+    while (t < end) { h ^= (uint64_t)(*t) * XP5; h = zk_rotl64(h, 11) * XP1; t++; }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    if (hashes) hashes[f] = h;
+    if (infos && (uint32_t)h != infos[f].checksum) infos[f].status = ZK_E_CHECKSUM_WRONG;
+}
+
 // per-frame status words + first failing frame ((frame << 32) | code, min over frames)
 __global__ __launch_bounds__(256) void zk_k_status(const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, unsigned long long *first_err)
 {
@@ -1215,7 +1278,10 @@ void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, 
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
                      ZkFrameInfo *infos, uint64_t *hashes)
 {
-    hipLaunchKernelGGL(zk_k_xxh64, dim3(count), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
+    // a large batch: sixteen frames per wave (the chains' latency is the same, the instruction slots a sixteenth)
+    static const int wide_env = getenv("ZK_XXH_WIDE") ? atoi(getenv("ZK_XXH_WIDE")) : -1;     // experiments: 0 never, 1 always
+    if (wide_env >= 0 ? wide_env != 0 : count >= 512) hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
+    else hipLaunchKernelGGL(zk_k_xxh64, dim3(count), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
 }
 
 void zk_launch_small_walk(hipStream_t st, const uint8_t *h_comp, uint64_t comp_bytes, const uint64_t *h_offs, uint32_t count, uint64_t dst_cap,

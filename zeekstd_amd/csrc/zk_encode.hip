@@ -588,7 +588,8 @@ __global__ __launch_bounds__(ZKE_ENT_THREADS) void zk_k_enc_entropy(const uint8_
                     if (j >= nb) break;
                     if (s_lit_mode[j] != 2) continue;
                     const uint32_t mb = s_maxbits[j];
-                    const uint32_t l0 = hw[j].len[lane], l1 = hw[j].len[lane + 64];
+                    const uint32_t nsym = s_tree[j] + 1;                              // the lengths beyond the block's last symbol were never written
+                    const uint32_t l0 = lane < nsym ? hw[j].len[lane] : 0u, l1 = lane + 64 < nsym ? hw[j].len[lane + 64] : 0u;
                     const uint32_t w0 = l0 ? mb + 1 - l0 : 0, w1 = l1 ? mb + 1 - l1 : 0;
                     const uint64_t below = (1ull << lane) - 1ull;
                     uint32_t pos = 0;
