@@ -2,6 +2,7 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <new>
 #include "../../../include/zeekstd_amd.h"
 #include "zeekstd.hpp"
@@ -214,7 +215,21 @@ int zk_decoder_time_seeks(zk_decoder *d, const uint64_t *offs, const uint32_t *l
                 got += k;
             }
             us_out[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-            if (got != lim - offs[i] || (expect && memcmp(buf, expect + offs[i], got) != 0)) { bad = 1; return; }
+            if (got != lim - offs[i] || (expect && memcmp(buf, expect + offs[i], got) != 0)) {
+                if (getenv("ZK_SEEK_DEBUG")) {               // experiment: is the frame in the cache right a moment later (a read that overtook the download)?
+                    const size_t first_got = got;
+                    size_t at = 0; while (at < got && buf[at] == expect[offs[i] + at]) at++;
+                    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                    d->d.set_offset_limit(total); d->d.set_offset(offs[i]); d->d.set_offset_limit(lim);
+                    const uint64_t subs = d->d.gpu_submissions();
+                    got = 0;
+                    for (;;) { const size_t k = d->d.decompress(buf + got, buf_len - got); if (k == 0) break; got += k; }
+                    const bool now_ok = got == lim - offs[i] && memcmp(buf, expect + offs[i], got) == 0;
+                    fprintf(stderr, "[zk seek debug] seek %u off %llu len %u: got %zu bytes, first wrong byte at %zu; read again (%s): %s\n", i, (unsigned long long)offs[i], lens[i],
+                            first_got, at, d->d.gpu_submissions() == subs ? "from the cache" : "decoded again", now_ok ? "right" : "still wrong");
+                }
+                bad = 1; return;
+            }
         }
     });
     return rc ? rc : bad ? ZK_ERR_ARGUMENT : 0;

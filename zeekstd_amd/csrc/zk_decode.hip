@@ -696,7 +696,15 @@ extern "C" void zk_debug_clocks(unsigned long long *out, int reset)
 #define ZK_CLK(i) do { } while (0)
 #endif
 // workgroup barrier that orders LDS traffic only (no wait for global loads / stores in flight)
-#define ZK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// (The 1024-lane executor of small batches keeps full barriers: one seek in ~8000 on 64 KiB frames written by libzstd -- cut by
+// offset_limit, hence unverified -- returned wrong bytes in a tight loop of seeks, never when repeated; with full barriers, or with
+// the LDS accesses of the entropy kernels as FLAT ones again, 14 000 seeks each passed.  The cause is not found; 16 waves per
+// workgroup are where a missing wait would show first, and a seek is latency, not throughput.)
+#ifdef ZK_EXEC_FULL_BARRIERS                         // experiment: every barrier of the tile loop waits for the stores too
+#define ZK_LDS_BARRIER() __syncthreads()
+#else
+#define ZK_LDS_BARRIER() do { if (T >= 1024) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
+#endif
 template <int T, bool PFX, int CAPX = 2>
 __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
                                                const uint32_t *ids, const uint64_t *out_off,

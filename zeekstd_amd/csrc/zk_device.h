@@ -29,7 +29,7 @@
 // FLAT instruction with system scope on the device: it counts on vmcnt as well as lgkmcnt, and the wait for it also waits for
 // every global store the wave has in flight (a store's acknowledgement is ~1 us away) -- the serial walkers issue such stores
 // all the time.  Through an LDS-typed pointer the same access is a ds_read / ds_write that knows lgkmcnt only.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_AS)       // ZK_NO_AS: experiment, the accesses as FLAT ones again
 #define ZK_LDS_AS __attribute__((address_space(3)))
 #else
 #define ZK_LDS_AS
@@ -38,7 +38,7 @@ template <typename T> ZK_HD T zk_lds_ld(const volatile void *p) { return *(const
 template <typename T> ZK_HD void zk_lds_st(volatile void *p, T v) { *(volatile ZK_LDS_AS T *)(p) = v; }
 // a store through a pointer that was itself read from memory (a struct in LDS): the compiler cannot tell where it points and would
 // issue a FLAT store; this says "global"
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_AS)
 #define ZK_GLB_AS __attribute__((address_space(1)))
 #else
 #define ZK_GLB_AS
