@@ -73,3 +73,48 @@ extern "C" int zk_enc_sim_match(const uint8_t *src, uint64_t n, uint32_t frame_s
     }
     return (int)pl.nb;
 }
+
+// The entropy stage's Huffman build as the kernel does it (zk_k_enc_entropy): the symbols ranked by (count, symbol) beforehand
+// (there: by all lanes of the wave) and handed to zke_huf_lengths, the canonical codes from per-weight counts and ranks (there:
+// ballots) -- against the plain serial functions zke_huf_lengths / zke_huf_codes the twin's restatement follows.
+// cnt[nsym] (nsym <= 128); returns 0 when lengths, depth and codes agree, a positive code for the first disagreement.
+extern "C" int zk_enc_sim_huf(const uint32_t *cnt, int nsym)
+{
+    uint32_t c0[256] = {0}, c1[256] = {0};
+    for (int s = 0; s < nsym; s++) c0[s] = c1[s] = cnt[s];
+    static ZkHufBuild h0, h1;
+    ZkHufCode a, b;
+    memset(&a, 0xEE, sizeof a); memset(&b, 0xEE, sizeof b);                 // stale bytes beyond nsym, as in LDS
+    const int d0 = zke_huf_lengths(c0, nsym, &h0, a.len);
+    // the ranks: key = count << 8 | symbol, rank = keys below mine among the symbols that occur
+    int m = 0;
+    for (int s = 0; s < nsym; s++) {
+        if (!cnt[s]) continue;
+        const uint32_t key = (cnt[s] << 8) | (uint32_t)s;
+        int r = 0;
+        for (int t = 0; t < nsym; t++) if (cnt[t] && (((cnt[t] << 8) | (uint32_t)t) < key)) r++;
+        h1.idx[r] = (uint8_t)s; m++;
+    }
+    const int d1 = zke_huf_lengths(c1, nsym, &h1, b.len, m);
+    if (d0 != d1) return 1;
+    if (d0 <= 0) return 0;
+    for (int s = 0; s < nsym; s++) if (a.len[s] != b.len[s]) return 2;
+    zke_huf_codes(&a, nsym, d0);
+    // codes by weight: weight 1 first, symbols ascending; 64 "lanes" hold symbols lane and lane + 64
+    uint32_t pos = 0;
+    for (int wt = 1; wt <= d1; wt++) {
+        int n0 = 0, n1 = 0;
+        for (int s = 0; s < 64; s++) { const uint32_t l = s < nsym ? b.len[s] : 0; if (l && d1 + 1 - (int)l == wt) n0++; }
+        for (int s = 64; s < 128; s++) { const uint32_t l = s < nsym ? b.len[s] : 0; if (l && d1 + 1 - (int)l == wt) n1++; }
+        int r0 = 0, r1 = 0;
+        for (int s = 0; s < 128; s++) {
+            const uint32_t l = s < nsym ? b.len[s] : 0;
+            if (!(l && d1 + 1 - (int)l == wt)) continue;
+            if (s < 64) b.code[s] = (uint16_t)((pos >> (wt - 1)) + (uint32_t)r0++);
+            else b.code[s] = (uint16_t)((pos >> (wt - 1)) + (uint32_t)n0 + (uint32_t)r1++);
+        }
+        pos += (uint32_t)(n0 + n1) << (wt - 1);
+    }
+    for (int s = 0; s < nsym; s++) if (a.len[s] && a.code[s] != b.code[s]) return 3;
+    return 0;
+}

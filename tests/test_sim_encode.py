@@ -90,3 +90,29 @@ def test_sim_match_long_distance(level):
     if level == 1:
         _compare(new, 150000, level, old)              # three frames against the same prefix
         _compare(new[:70000], 1 << 21, level, old[:57284])      # a prefix four bytes beyond the ring's reach
+
+
+def test_huffman_build_as_the_kernel_does_it():
+    """zk_k_enc_entropy ranks a block's symbols with all lanes of the wave and hands them to zke_huf_lengths sorted, then assigns the
+    canonical codes from per-weight counts and ranks: the same lengths, depth and codes as the serial functions (random, skewed,
+    tied and degenerate histograms; counts that need the halving rounds to fit 11 bits)."""
+    import ctypes as C
+    from conftest import enc_sim_lib
+    lib = enc_sim_lib()
+    lib.zk_enc_sim_huf.restype = C.c_int
+    lib.zk_enc_sim_huf.argtypes = [C.c_void_p, C.c_int]
+    rng = np.random.default_rng(5)
+    cases = []
+    for _ in range(300):
+        nsym = int(rng.integers(2, 129))
+        kind = int(rng.integers(0, 5))
+        if kind == 0: c = rng.integers(0, 1000, nsym)
+        elif kind == 1: c = (rng.random(nsym) ** 8 * 100000).astype(np.int64)                 # skewed: deep trees, halving rounds
+        elif kind == 2: c = rng.integers(0, 3, nsym)                                           # ties
+        elif kind == 3: c = np.where(rng.random(nsym) < 0.1, rng.integers(1, 50, nsym), 0)     # few symbols
+        else: c = 2 ** rng.integers(0, 17, nsym)                                               # a Fibonacci-like spread
+        c = c.astype(np.uint32); c[-1] = max(int(c[-1]), 1)                                    # the last symbol occurs (nsym = maxsym + 1)
+        cases.append(c)
+    cases += [np.array([1, 1], np.uint32), np.array([5, 0, 0, 7], np.uint32), np.arange(1, 129, dtype=np.uint32), np.full(128, 9, np.uint32)]
+    for c in cases:
+        assert lib.zk_enc_sim_huf(c.ctypes.data, len(c)) == 0, c.tolist()
