@@ -61,41 +61,9 @@ extern "C" void zk_debug_enc_clocks(unsigned long long *out, int reset)
 #endif
 
 // ------------------------------------------------------------------------------------------------ entropy stage
-// LSB-first bit writer into global scratch (one lane), free of branches: put() collects at most 56 bits on top of
-// the < 8 left by the last flush(); flush() stores the accumulator's 8 bytes unconditionally and advances by the
-// whole bytes it held (the bytes behind them are rewritten by the next flush).  A conditional store would make
-// the number of stores in flight unknown to the compiler's s_waitcnt bookkeeping: loads and stores share one in-order
-// counter (vmcnt), and every wait for a prefetched load would then also wait for the stores issued after it.
-// The region must be cap + 8 bytes long.  Overflow (more than cap bytes) is remembered; close() then returns 0.
-struct ZkeBits {
-    uint8_t *p; uint32_t cap, pos, n, ovf; uint64_t acc;
-    __device__ __forceinline__ void init(uint8_t *p_, uint32_t cap_) { p = p_; cap = cap_; pos = 0; acc = 0; n = 0; ovf = 0; }
-    __device__ __forceinline__ void put(uint32_t v, uint32_t nb) { acc |= (uint64_t)(v & ((1u << nb) - 1u)) << n; n += nb; }    // nb <= 24
-    __device__ __forceinline__ void flush()
-    {
-        memcpy(p + pos, &acc, 8);
-        const uint32_t k = n >> 3;               // <= 7
-        pos += k; acc >>= 8 * k; n &= 7;
-        ovf |= pos > cap;
-        pos = pos > cap ? cap : pos;
-    }
-    // the same without the bound: the caller looks at it (check()) at least every 48 bytes, the region has that much slack
-    __device__ __forceinline__ void flush_fast()
-    {
-        memcpy(p + pos, &acc, 8);
-        const uint32_t k = n >> 3;
-        pos += k; acc >>= 8 * k; n &= 7;
-    }
-    __device__ __forceinline__ void check() { ovf |= pos > cap; pos = pos > cap ? cap : pos; }
-    __device__ __forceinline__ uint32_t close()
-    {
-        flush(); put(1, 1); flush();
-        if (n) { memcpy(p + pos, &acc, 8); pos++; ovf |= pos > cap; }
-        return ovf ? 0u : pos;
-    }
-};
-
-// The same stream through LDS: the lane's bits go to its own staging area in whole 32-bit words (the accumulator's two words are
+// LSB-first bit writer of one lane.  (Until round 3 it stored its accumulator's 8 bytes straight to HBM at every flush: 16 lanes
+// storing 8 bytes each at 16 places twice per sequence -- and 64 lanes once per 2-3 literals -- were what the CU's write path choked on.)
+// The stream goes through LDS: the lane's bits go to its own staging area in whole 32-bit words (the accumulator's two words are
 // stored at every flush(); the low one moves on once it is full), and drain() carries the complete 16-byte units to HBM.
 // Why: 16 lanes storing 8 bytes each at 16 places twice per sequence were 32 write requests per step and workgroup -- the CU's
 // write path was what every wave of the kernel waited for (without those stores: sequence writers 2.04 -> 1.32 M clocks, the
@@ -150,23 +118,6 @@ struct ZkeBitsL {
         return ovf || total > cap ? 0u : total;
     }
 };
-
-// Copy n bytes with the 64 lanes of a wave, 8 bytes per lane and access (unaligned on both sides): eight loads per
-// lane, then the eight stores -- a load issued after a store waits for the store's acknowledgement, so a
-// byte-at-a-time loop pays one HBM write latency per byte.
-__device__ __forceinline__ void zke_copy_wave(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane)
-{
-    const uint32_t nw = n >> 3;
-    for (uint32_t b0 = 0; b0 < nw; b0 += 8 * 64) {
-        uint64_t v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * 64 + lane; v[u] = zk_ld64(src + 8 * (i < nw ? i : 0)); }
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const uint32_t i = b0 + u * 64 + lane; if (i < nw) memcpy(dst + 8 * i, &v[u], 8); }
-    }
-    const uint32_t t = 8 * nw + lane;
-    if (t < n) dst[t] = src[t];
-}
 
 // ------------------------------------------------------------------------------------------------ the frame's FSE tables
 // One workgroup per frame: code histograms of all its sequences (LDS atomics), then one lane per table normalises,
