@@ -28,6 +28,16 @@ static ZkQuadSim *g_quad;
 static uint32_t g_ofv[32];
 static int g_fse_quad = 0;
 extern "C" void zk_sim_set_fse_quad(int on) { g_fse_quad = on; }
+// poison: the tables and scratch a block's lane builds and reads (on the device: LDS that holds whatever the workgroup before left
+// there) are filled with pseudo-random bytes before every block -- code that reads what it has not written shows up as a mismatch
+static uint64_t g_poison = 0;
+extern "C" void zk_sim_set_poison(uint64_t seed) { g_poison = seed; }
+static void zk_sim_poison(void *p, size_t n)
+{
+    if (!g_poison) return;
+    uint8_t *b = (uint8_t *)p;
+    for (size_t i = 0; i < n; i++) { g_poison = g_poison * 6364136223846793005ull + 1442695040888963407ull; b[i] = (uint8_t)(g_poison >> 56); }
+}
 struct ZkQuadFibers {
     static uint32_t bcast(uint32_t v, int k)
     {
@@ -127,6 +137,7 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
         if (!(b.type == 2 && b.lit_type >= 2 && b.status == ZK_OK)) continue;
         const ZkBlock &def = blocks[b.huf_def];
         uint32_t mb = 0, nsym = 0;
+        zk_sim_poison(tab.data(), tab.size() * 2); zk_sim_poison(&hd, sizeof hd); zk_sim_poison(&tmp, sizeof tmp);
         uint32_t r = zk_huf_read_weights(comp + def.src + def.lit_off, def.lit_comp, &hd, &tmp, &nsym, &mb);
         bool ok = r != 0;
         if (ok) {
@@ -160,6 +171,7 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
     for (uint64_t bi = 0; bi < nb; bi++) {
         ZkBlock b = blocks[bi];
         if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK) continue;
+        zk_sim_poison(T, sizeof *T); zk_sim_poison(T16, sizeof *T16);
         // like the device: all-predefined blocks go through the aligned-word reader, the rest through the unaligned one
         // (with the quad flag every block takes the quad walk, as small batches do on the device)
         if (b.seq_modes == 0 && !g_fse_quad) zk_decode_sequences<ZkRevA, ZkCells32>(comp, blocks.data(), b, T, seqs.data() + b.seq_base, LLV, MLV);

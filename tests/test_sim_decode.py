@@ -121,6 +121,29 @@ def test_sim_quad_vs_live_libzstd(level):
         assert rc == 0 and out == data
 
 
+@pytest.mark.skipif(Z.load("system") is None, reason="no system libzstd")
+@pytest.mark.parametrize("quad", [False, True])
+def test_sim_with_poisoned_tables(quad):
+    """Every table and scratch area a block's lane builds and then reads -- Huffman weights, decode table, FSE cells: on the device
+    LDS that still holds what the workgroup before left there -- is filled with pseudo-random bytes before each block: code that
+    reads what it has not written would show up as wrong bytes or a false corruption verdict (64 KiB frames written by libzstd at
+    levels 1 and 3: one large block with its own tables per frame, the shape a single seek decodes)."""
+    import ctypes as C
+    from conftest import sim_lib
+    lib = sim_lib()
+    lib.zk_sim_set_poison.argtypes = [C.c_uint64]
+    data = zko.gen_chunks(3 << 20, 5)
+    try:
+        for level in (1, 3):
+            comp, frames = Z.encode_seekable_frames(data, 65536, level, True)
+            for seed in (0x1234567, 0xDEADBEEF12345):
+                lib.zk_sim_set_poison(seed)
+                rc, out, st = sim_decode(comp, frames, quad=quad, CH=2048)
+                assert rc == 0 and not st.any() and out == data, (level, seed)
+    finally:
+        lib.zk_sim_set_poison(0)
+
+
 @pytest.mark.parametrize("quad", [False, True])
 def test_sim_handmade_frames(quad):
     """RLE_Mode sequence tables (hand-written frames): one-cell tables, accuracy log 0, through both sequence walks."""
