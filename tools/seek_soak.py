@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Scratch: many single seeks (the bench's configs[3] protocol) on an archive CPU libzstd wrote and on one this engine wrote; on a
-   failure the seek is found and repeated.   python tools/seek_soak.py [MiB] [trials]"""
+   failure the seek is found and repeated.   python tools/seek_soak.py [MiB] [trials] [only]
+   The decoder is opened WITHOUT verification (ZK_DEC_NO_VERIFY): with it the Decoder checks a frame that offset_limit cuts against its
+   checksum and decodes it once more on a mismatch (host/decoder.cpp), which hides the open defect this tool is for.
+   ZK_SEEK_DEBUG=1: the failing seek is read again from the decoder's cache (c_api.cpp)."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -26,6 +29,7 @@ def soak(name, comp, frames):
     for c_, d_ in frames: st.log_frame(c_, d_)
     seekable = comp + st.to_bytes()
     o = api.zk_decode_opts(); h = C.c_void_p()
+    o.flags = 16                                             # ZK_DEC_NO_VERIFY
     assert lib.zk_decoder_open_bytes(eng._h, seekable, len(seekable), C.byref(o), C.byref(h)) == 0
     buf = np.zeros(8192 + 64, np.uint8); us = np.zeros(trials, np.float64)
     def run(lo, cnt):
