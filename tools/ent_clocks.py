@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Scratch: per-phase, per-wave shader-clock totals inside zk_k_enc_entropy (tools/build_enc_variant.sh eclk:-DZKE_ENT_CLOCKS).
+"""Scratch: per-phase, per-wave shader-clock totals inside zk_k_enc_entropy, the shader clock and how many workgroups share a CU
+   (tools/build_enc_variant.sh eclk:-DZKE_ENT_CLOCKS).
    ZEEKSTD_AMD_LIB=zeekstd_amd/libzk_eclk.so python tools/ent_clocks.py [frames] [level]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,7 +29,7 @@ out = (C.c_ulonglong * 48)()
 raw.zk_debug_enc_clocks(out, 0)
 res = list(out)[40:48]
 v = np.array(list(out)[:40], dtype=np.float64).reshape(8, 5)
-names = ["clear + tables + raw / literal histograms", "wait", "rewrite sequences (waves 1-3)", "huffman builds (+ waits)", "bit writers", "wait", "layout + payload copies", "-"]
+names = ["clear + tables + raw / literal counts", "wait for the helper's counts", "-", "huffman builds", "bit writers (wave 0 literals, 1 FSE chains, 2 emitter)", "wait at the barrier", "layout + piece tables", "-"]
 wgs = n / (16 * 32768)
 print("entropy ms", round(eng.kernel_times()["zk_k_enc_entropy"], 3))
 print(f"  {'phase':44s}" + "".join(f"   wave {w}" for w in range(5)) + "   (clocks per workgroup)")
