@@ -74,7 +74,25 @@ int zk_engine_set_profiling(zk_engine *e, int on);
 /* Kernel selection of the sequence decoder for blocks that carry their own FSE tables (archives written by libzstd):
  * 0 = by batch size (default), 1 = one lane per block (zk_k_fse), 2 = a quad of lanes per block (zk_k_fse_quad).
  * Results are identical; the tests use it to run both kernels on small inputs. */
-int zk_engine_set_fse_kernel(zk_engine *e, int mode);
+int zk_engine_set_fse_kernel(zk_engine *e, int mode);                /* = zk_engine_set_kernel_choice(e, ZK_CHOICE_FSE_OWN, mode) */
+/* Pins one kernel variant whatever the batch looks like (value 0 = by batch shape, the default and what production runs).
+ * Every variant computes the same bytes: the point is that tests/ can put the kernels of the large-batch path (which a 4 GiB
+ * batch selects) under small, exhaustively checked inputs, and that tools/ can time one variant against another.  Replaces the
+ * environment switches of round 3.  ZK_ERR_ARGUMENT for an unknown key or value. */
+enum {
+    ZK_CHOICE_RESET = 0,          /* every key back to 0 (value ignored) */
+    ZK_CHOICE_FSE_OWN = 1,        /* blocks with own FSE tables: 1 zk_k_fse (a lane per block), 2 zk_k_fse_quad in its 56-block layout */
+    ZK_CHOICE_FSE_SHARED = 2,     /* blocks that share tables: 1 zk_k_fse_predef, 2 zk_k_fse_predef_fed, 3 zk_k_fse_sets (any of them
+                                   * also switches the small-batch shortcut "every block a quad" off) */
+    ZK_CHOICE_EXEC_LANES = 3,     /* zk_k_exec tile: 128 / 256 / 512 / 1024 lanes */
+    ZK_CHOICE_EXEC_RING = 4,      /* 256-lane tiles: 1 = a ring of 2 T records, 2 = 4 T */
+    ZK_CHOICE_XXH64 = 5,          /* 1 zk_k_xxh64 (a wave per frame), 2 zk_k_xxh64_wide (sixteen frames per wave) */
+    ZK_CHOICE_SMALL_PATH = 6,     /* host-pointer decode of <= 64 frames: 1 = through the general pipeline, 2 = the small path with its
+                                   * entropy roles as two kernels */
+    ZK_CHOICE_PIPE_CONTEXTS = 7,  /* host pipeline: decode contexts it rotates through (1..6; 0 = 2) */
+    ZK_CHOICE_PIPE_CHUNK_MIB = 8  /* host pipeline: output MiB per chunk (0 = by total size) */
+};
+int zk_engine_set_kernel_choice(zk_engine *e, int what, int value);
 int zk_engine_kernel_count(void);
 const char *zk_engine_kernel_name(int k);
 int zk_engine_kernel_times(const zk_engine *e, float *ms_out, int n);
@@ -227,6 +245,9 @@ int zk_seek_table_from_bytes(const uint8_t *src, size_t len, int format, zk_seek
 /* from_reader (Head format, :461-493); max_read > 0 makes the reader return at most that many bytes per read */
 int zk_seek_table_from_reader_bytes(const uint8_t *p, size_t len, size_t max_read, zk_seek_table **out);
 int zk_seek_table_log_frame(zk_seek_table *t, uint32_t c_size, uint32_t d_size);               /* :513-525 */
+/* the same for n frames in one call (the entries zk_encode_frames* returns, or a whole gathered shard: one call instead of one per
+ * frame from a host language).  Stops at the first frame that cannot be logged (:513-525's errors); the frames before it stay. */
+int zk_seek_table_log_frames(zk_seek_table *t, uint32_t n, const uint32_t *c_sizes, const uint32_t *d_sizes);
 uint32_t zk_seek_table_num_frames(const zk_seek_table *t);                                     /* :540 */
 uint32_t zk_seek_table_frame_index_comp(const zk_seek_table *t, uint64_t offset);              /* :560 */
 uint32_t zk_seek_table_frame_index_decomp(const zk_seek_table *t, uint64_t offset);            /* :579 */
@@ -303,7 +324,8 @@ uint64_t zk_decoder_gpu_submissions(const zk_decoder *d);                       
 /* Measurement helper (BASELINE.json configs[3]): n seeks one at a time -- set_offset(offs[i]);
  * set_offset_limit(offs[i] + lens[i]); decompress to exhaustion (decode.rs:402-437, 201-270) -- each timed on its own with
  * the monotonic clock, microseconds into us_out[i].  expect (optional): the archive's uncompressed bytes; every read is
- * compared with expect + offs[i] outside the timed span.  Returns 0, a decoder error, or ZK_ERR_ARGUMENT on a mismatch. */
+ * compared with expect + offs[i] outside the timed span.  Returns 0, a decoder error, or ZK_ERR_ARGUMENT on a mismatch: the
+ * loop stops there, us_out[i] of that seek is negated and buf holds what it delivered. */
 int zk_decoder_time_seeks(zk_decoder *d, const uint64_t *offs, const uint32_t *lens, uint32_t n, uint8_t *buf, size_t buf_len,
                           const uint8_t *expect, double *us_out);
 

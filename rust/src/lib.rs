@@ -73,6 +73,11 @@ impl SeekTable {
         Ok(SeekTable(t))
     }
     pub fn log_frame(&mut self, c_size: u32, d_size: u32) -> Result<()> { check(unsafe { ffi::zk_seek_table_log_frame(self.0, c_size, d_size) }) }   // :513
+    /// engine-specific: the entries of a whole batch (what `zk_encode_frames*` returns) in one call
+    pub fn log_frames(&mut self, c_sizes: &[u32], d_sizes: &[u32]) -> Result<()> {
+        assert_eq!(c_sizes.len(), d_sizes.len());
+        check(unsafe { ffi::zk_seek_table_log_frames(self.0, c_sizes.len() as u32, c_sizes.as_ptr(), d_sizes.as_ptr()) })
+    }
     pub fn num_frames(&self) -> u32 { unsafe { ffi::zk_seek_table_num_frames(self.0) } }                              // :540
     pub fn frame_index_comp(&self, offset: u64) -> u32 { unsafe { ffi::zk_seek_table_frame_index_comp(self.0, offset) } }     // :560
     pub fn frame_index_decomp(&self, offset: u64) -> u32 { unsafe { ffi::zk_seek_table_frame_index_decomp(self.0, offset) } } // :579

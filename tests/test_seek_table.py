@@ -159,3 +159,21 @@ def test_log_frame_limit_and_equality():
     b.log_frame(1, 1)
     assert a != b
     assert a.clone() == a
+
+
+def test_log_frames_equals_one_call_per_frame():
+    """zk_seek_table_log_frames (a whole batch's entries in one call) == seek_table.rs:513-525 applied frame by frame."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    c = rng.integers(0, 1 << 20, 5000).astype(np.uint32)
+    d = rng.integers(0, 1 << 22, 5000).astype(np.uint32)
+    a = SeekTable.new()
+    b = SeekTable.new()
+    for x, y in zip(c.tolist(), d.tolist()):
+        a.log_frame(x, y)
+    b.log_frames(c[:1234], d[:1234])
+    b.log_frames(c[1234:], d[1234:])
+    b.log_frames([], [])
+    assert b.num_frames() == 5000 and a.to_bytes() == b.to_bytes()
+    with pytest.raises(ValueError):
+        b.log_frames([1, 2], [1])

@@ -61,6 +61,7 @@ for _n, _r, _a in [
     ("zk_seek_table_from_bytes", C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(_P)]),
     ("zk_seek_table_from_reader_bytes", C.c_int, [_P, C.c_size_t, C.c_size_t, C.POINTER(_P)]),
     ("zk_seek_table_log_frame", C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    ("zk_seek_table_log_frames", C.c_int, [_P, C.c_uint32, _P, _P]),
     ("zk_seek_table_num_frames", C.c_uint32, [_P]),
     ("zk_seek_table_frame_index_comp", C.c_uint32, [_P, C.c_uint64]),
     ("zk_seek_table_frame_index_decomp", C.c_uint32, [_P, C.c_uint64]),
@@ -165,6 +166,14 @@ class SeekTable:                       # seek_table.rs:243-935
 
     def log_frame(self, c_size: int, d_size: int):
         _chk(lib.zk_seek_table_log_frame(self._h, c_size, d_size))
+
+    def log_frames(self, c_sizes, d_sizes):
+        """n frames in one call (zk_seek_table_log_frames): arrays of compressed / decompressed sizes."""
+        import numpy as np
+        c = np.ascontiguousarray(np.asarray(c_sizes, dtype=np.uint32)); d = np.ascontiguousarray(np.asarray(d_sizes, dtype=np.uint32))
+        if c.shape != d.shape or c.ndim != 1:
+            raise ValueError("log_frames: two equally long 1-d arrays")
+        _chk(lib.zk_seek_table_log_frames(self._h, c.size, c.ctypes.data if c.size else None, d.ctypes.data if d.size else None))
 
     def num_frames(self) -> int:
         return lib.zk_seek_table_num_frames(self._h)

@@ -114,21 +114,9 @@ uint32_t Decoder::decode_range(uint32_t first, uint32_t count, uint8_t *dst, uin
     // a single frame that offset_limit cuts short is not verified at all: the checksum kernel is a serial chain per frame
     const bool cut_tail = E[first + count].d_offset > offset_limit_;
     const int verify = verify_ && !(count == 1 && cut_tail) ? 1 : 0;
-    // ... for the READER.  The engine decodes whole frames, so the frame's checksum can still tell whether THIS decode went wrong:
-    // one seek in ~8000 on 64 KiB frames written by libzstd came back with wrong bytes in the middle of the frame (a tight loop of
-    // seeks, never the same seek twice; tools/seek_soak.py; the cause inside the small-batch kernels is not found yet).  A
-    // mismatch is therefore answered by decoding once more; a frame that really carries another checksum is delivered as upstream
-    // delivers it -- unchecked (decode.rs:425-427) -- and stays marked unverified for the reads that reach its end.
-    const bool self_check = verify_ && count == 1 && cut_tail;
     uint32_t n_ok = 0;
-    rc = zk_host_decode(engine_, hs, c.data(), d.data(), 0, count, d_prefix, prefix ? prefix_len : 0, dst, dst_cap, verify || self_check ? 1 : 0, status.data(), &n_ok);
+    rc = zk_host_decode(engine_, hs, c.data(), d.data(), 0, count, d_prefix, prefix ? prefix_len : 0, dst, dst_cap, verify, status.data(), &n_ok);
     submissions_++;
-    // (the same for the last frame of a longer read when the limit cuts it: its mismatch is tolerated below, so it is first made sure of)
-    auto cut_frame_mismatch = [&] { return verify_ && cut_tail && rc != 0 && rc > -1000 && n_ok == count - 1 && status[count - 1] == 22; };
-    if (cut_frame_mismatch()) {
-        rc = zk_host_decode(engine_, hs, c.data(), d.data(), 0, count, d_prefix, prefix ? prefix_len : 0, dst, dst_cap, 1, status.data(), &n_ok);
-        if (self_check && cut_frame_mismatch()) { rc = 0; n_ok = 1; status[0] = 0; }
-    }
     if (pull.error) std::rethrow_exception(pull.error);                        // the source's own failure, after the pipeline has drained
     *err = 0;
     if (rc <= -1000) throw Error::from_engine_code(rc, zk_engine_last_hip_error(engine_));

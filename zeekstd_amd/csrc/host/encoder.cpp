@@ -120,10 +120,11 @@ CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t i
                 const double r = std::max(1.0, (double)d / (double)std::max<size_t>(c, 1));
                 const size_t by_ratio = std::max<size_t>(32768, (size_t)(0.9 * r * (double)(want - c)));
                 size_t step = std::min<size_t>(by_ratio, (want - c) + slack);
-                // far from n on input that compresses very well (d >> c) that cap would mean a probe -- a full encode of the frame so
-                // far -- every ~1 MiB of a frame of hundreds of MiB: quadratic work.  While less than half of n is reached the step is
-                // at least an eighth of the frame so far (geometric: O(log) probes); the window holds again once c nears n.
-                if (2 * c < want) step = std::max(step, d / 8);
+                // far from n on input that compresses very well (d >> c) `by_ratio` is an estimate from a ratio that may not last: while
+                // less than half of n is reached the step is at least an eighth of the frame so far (fewer probes -- each one is a
+                // full encode of the frame so far) -- but never more than the missing bytes plus the window: input that stops
+                // compressing right behind this probe then still ends the frame inside [n, n + 131 591)
+                if (2 * c < want) step = std::max(step, std::min<size_t>(d / 8, (want - c) + slack));
                 next_probe_ = d + step;
             } else ratio_ = (double)d / (double)c;
         }

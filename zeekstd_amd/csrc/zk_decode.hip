@@ -22,7 +22,6 @@
 #include <hip/hip_runtime.h>
 #include "zk_device.h"
 #include "zk_kernels.h"
-#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------ walk
 // ids != nullptr: frame f of the batch is frame ids[f] of the archive (random-access batches: many seeks per submission)
@@ -122,11 +121,17 @@ __device__ void zk_huf_companion(const uint8_t *base, uint32_t len, uint8_t *dst
     const uintptr_t lo = (uintptr_t)base;
     uintptr_t line = ((uintptr_t)base + len) & ~(uintptr_t)127;      // lowest line touched so far (the decoder's init loads cover it)
     uint32_t stored = 0, sink = 0;
+    // The loop leaves as ONE wave, by a wave-uniform verdict: a pass in which `done` was read as set BEFORE every lane read its
+    // state and no lane found anything left to do.  (Round 3's form -- `if (idle) { if (fin) break; sleep; }` per lane -- was
+    // compiled into "idle lanes are parked until every lane of the wave is idle, then ALL of them leave if the LAST read of
+    // `done` was set": a lane parked with 1..3 packs waiting for the decoder's end left on a `done` it had never read its state
+    // behind whenever a neighbour was busy in the pass where `done` flipped, and its last packs never reached HBM -- stale
+    // literal bytes, status OK.  DESIGN.md section 8, "the small-batch defect".)
     for (;;) {
-        const uint32_t fin = zk_lds_ld<uint32_t>(done);              // read BEFORE the state: a pack published before `done` is seen
+        const uint32_t fin = __builtin_amdgcn_readfirstlane(zk_lds_ld<uint32_t>(done));     // read BEFORE the states: a pack published before `done` is seen
         const uint32_t st = zk_lds_ld<uint32_t>(&mail->state[l]);
         const uint32_t written = st & 0x3fffu;
-        bool idle = true;
+        bool busy = false;
         const uint32_t avail = (written - stored) & 0x3fffu;
         if (avail >= ZK_HUF_BURST || (fin && avail)) {               // whole bursts while the decoder runs, the rest at its end
             const uint32_t nb = avail < ZK_HUF_BURST ? avail : ZK_HUF_BURST;
@@ -136,7 +141,7 @@ __device__ void zk_huf_companion(const uint8_t *base, uint32_t len, uint8_t *dst
             }
             stored += nb;
             zk_lds_st<uint32_t>(&mail->consumed[l], stored);
-            idle = false;
+            busy = true;
         }
         const int32_t want = (int32_t)(st >> 14) - 64 - ZK_HUF_AHEAD;
         const uintptr_t wp = (lo + (uintptr_t)(want < 0 ? 0 : want)) & ~(uintptr_t)127;
@@ -144,9 +149,9 @@ __device__ void zk_huf_companion(const uint8_t *base, uint32_t len, uint8_t *dst
             line -= 128;
             const uint8_t *a = reinterpret_cast<const uint8_t *>(line < lo ? lo : line);
             asm volatile("global_load_ubyte %0, %1, off" : "+v"(sink) : "v"(a) : "memory");
-            idle = false;
+            busy = true;
         }
-        if (idle) {
+        if (__ballot(busy) == 0) {                                   // (the lanes of this call: the wave's active ones)
             if (fin) break;
             __builtin_amdgcn_s_sleep(2);
         }
@@ -696,14 +701,10 @@ extern "C" void zk_debug_clocks(unsigned long long *out, int reset)
 #define ZK_CLK(i) do { } while (0)
 #endif
 // workgroup barrier that orders LDS traffic only (no wait for global loads / stores in flight)
-// (The 1024-lane executor of small batches keeps full barriers: one seek in ~8000 on 64 KiB frames written by libzstd -- cut by
-// offset_limit, hence unverified -- returned wrong bytes in a tight loop of seeks, never when repeated; with full barriers, or with
-// the LDS accesses of the entropy kernels as FLAT ones again, 14 000 seeks each passed.  The cause is not found; 16 waves per
-// workgroup are where a missing wait would show first, and a seek is latency, not throughput.)
 #ifdef ZK_EXEC_FULL_BARRIERS                         // experiment: every barrier of the tile loop waits for the stores too
 #define ZK_LDS_BARRIER() __syncthreads()
 #else
-#define ZK_LDS_BARRIER() do { if (T >= 1024) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
+#define ZK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 template <int T, bool PFX, int CAPX = 2>
 __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
@@ -1224,25 +1225,25 @@ void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     if (!nblocks) return;
     hipLaunchKernelGGL(zk_k_huf, dim3((nblocks + ZK_HUF_BLOCKS - 1) / ZK_HUF_BLOCKS), dim3(128), 0, st, comp, blocks, nblocks, lit);
 }
-void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeqP *seqs, int own_kernel, uint32_t frames)
+void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeqP *seqs, const ZkKernelChoice &k, uint32_t frames)
 {
     if (!nblocks) return;
+    const int own_kernel = k.fse_own;
     // reader choice (zk_device.h): with >= 6 workgroups per CU the memory pipeline is the limit (aligned words, each
     // loaded once); below that a lane's instruction count is (one unaligned load per sequence).  Measured crossover
     // on 32 KiB blocks between 1024 and 2048 frames of 2 MiB.
     const uint32_t wgs = (nblocks + ZK_FSEP_LANES - 1) / ZK_FSEP_LANES;
     // a small batch (a seek, a handful of frames) is all chain latency: every block, predefined tables or not, takes a
     // quad of lanes (each block builds its own copy of the tables: microseconds)
-    if (own_kernel == 0 && nblocks <= 16u * 256u) {
+    if (own_kernel == 0 && k.fse_shared == 0 && nblocks <= 16u * 256u) {
         hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 16, 1>), dim3((nblocks + 15) / 16), dim3(128), 0, st, comp, blocks, nblocks, seqs, 1u);
         return;
     }
     // blocks that share their tables with their neighbours (predefined, or one set per frame): one lane each
     // frames of fewer than 64 blocks: a workgroup's 64 blocks span several frames = several table sets
-    static const int sets_env = getenv("ZK_FSE_SETS") ? atoi(getenv("ZK_FSE_SETS")) : -1;      // experiments: 0 never, 1 always
-    const bool small_frames = sets_env >= 0 ? sets_env != 0 : (frames && (uint64_t)nblocks < 64ull * frames);
-    if (small_frames) hipLaunchKernelGGL(zk_k_fse_sets, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
-    else if (wgs >= 6 * 256) hipLaunchKernelGGL(zk_k_fse_predef_fed, dim3(wgs), dim3(2 * ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
+    const int shared = k.fse_shared ? k.fse_shared : (frames && (uint64_t)nblocks < 64ull * frames) ? 3 : wgs >= 6 * 256 ? 2 : 1;
+    if (shared == 3) hipLaunchKernelGGL(zk_k_fse_sets, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
+    else if (shared == 2) hipLaunchKernelGGL(zk_k_fse_predef_fed, dim3(wgs), dim3(2 * ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
     else hipLaunchKernelGGL(zk_k_fse_predef<ZkRevU>, dim3(wgs), dim3(ZK_FSEP_LANES), 0, st, comp, blocks, nblocks, seqs);
     // blocks with their own tables (every block is visited, the others return at once): a quad of lanes per block.
     // While everything fits in one round, small workgroups (16 blocks, one walking wave + the toucher: 45 KiB of LDS,
@@ -1262,33 +1263,33 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeqP *seqs,
-                    const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen, bool dense)
+                    const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen, const ZkKernelChoice &k, bool dense)
 {
     // one workgroup per frame: the tile width trades bytes in flight per frame against workgroups per CU
     // (measured on 2 MiB frames: 2048 frames -> 256 lanes.  128 lanes run the kernel alone in 8.9 instead of 9.5 ms -- eight
     // 2-wave workgroups per CU hold all 2048 frames in one round -- but leave no room for the neighbouring batch: with two
     // batches in flight the step is 18.8 ms against 17.2.  1024 frames: 256 lanes 4.95 ms, 128 lanes 6.9; 512 -> 512, 128 -> 1024)
-#define ZK_EXEC_LAUNCH(TT, PP) hipLaunchKernelGGL((zk_k_exec<TT, PP>), dim3(count), dim3(TT), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst, prefix, plen)
-    static const int force_t = getenv("ZK_EXEC_T") ? atoi(getenv("ZK_EXEC_T")) : 0;      // experiments
+#define ZK_EXEC_LAUNCH(TT, PP, CC) hipLaunchKernelGGL((zk_k_exec<TT, PP, CC>), dim3(count), dim3(TT), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst, prefix, plen)
+    const int lanes = k.exec_lanes ? k.exec_lanes : count >= 1024 ? 256 : count >= 256 ? 512 : 1024;
     if (prefix && plen) {
-        if (count >= 1024) ZK_EXEC_LAUNCH(256, true); else if (count >= 256) ZK_EXEC_LAUNCH(512, true); else ZK_EXEC_LAUNCH(1024, true);
-    } else if (force_t == 128) ZK_EXEC_LAUNCH(128, false);
-    else if (force_t == 256) ZK_EXEC_LAUNCH(256, false);
-    else if (force_t == 512) ZK_EXEC_LAUNCH(512, false);
-    else {
-        // fewer than 10 output bytes per sequence (libzstd from level 3 up: ~8): a ring of 2 T records ends most 4 KiB tiles
-        // early; 4 T keep them whole (executor -8.5 % there, +2 % on sparser streams, hence the switch)
-        if (count >= 1024 && dense) hipLaunchKernelGGL((zk_k_exec<256, false, 4>), dim3(count), dim3(256), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst, prefix, plen);
-        else if (count >= 1024) ZK_EXEC_LAUNCH(256, false); else if (count >= 256) ZK_EXEC_LAUNCH(512, false); else ZK_EXEC_LAUNCH(1024, false);
+        if (lanes <= 256) ZK_EXEC_LAUNCH(256, true, 2); else if (lanes == 512) ZK_EXEC_LAUNCH(512, true, 2); else ZK_EXEC_LAUNCH(1024, true, 2);
+        return;
     }
+    // fewer than 10 output bytes per sequence (libzstd from level 3 up: ~8): a ring of 2 T records ends most 4 KiB tiles
+    // early; 4 T keep them whole (executor -8.5 % there, +2 % on sparser streams, hence the switch)
+    const bool ring4 = lanes == 256 && (k.exec_ring ? k.exec_ring == 2 : (count >= 1024 && dense));
+    if (ring4) ZK_EXEC_LAUNCH(256, false, 4);
+    else if (lanes == 128) ZK_EXEC_LAUNCH(128, false, 2);
+    else if (lanes == 256) ZK_EXEC_LAUNCH(256, false, 2);
+    else if (lanes == 512) ZK_EXEC_LAUNCH(512, false, 2);
+    else ZK_EXEC_LAUNCH(1024, false, 2);
 #undef ZK_EXEC_LAUNCH
 }
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
-                     ZkFrameInfo *infos, uint64_t *hashes)
+                     ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k)
 {
     // a large batch: sixteen frames per wave (the chains' latency is the same, the instruction slots a sixteenth)
-    static const int wide_env = getenv("ZK_XXH_WIDE") ? atoi(getenv("ZK_XXH_WIDE")) : -1;     // experiments: 0 never, 1 always
-    if (wide_env >= 0 ? wide_env != 0 : count >= 512) hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
+    if (k.xxh ? k.xxh == 2 : count >= 512) hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
     else hipLaunchKernelGGL(zk_k_xxh64, dim3(count), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
 }
 
@@ -1297,10 +1298,9 @@ void zk_launch_small_walk(hipStream_t st, const uint8_t *h_comp, uint64_t comp_b
 {
     hipLaunchKernelGGL(zk_k_small_walk, dim3(1), dim3(256), 0, st, h_comp, comp_bytes, h_offs, count, dst_cap, block_cap, d_comp, d_offs, infos, bases, blocks, words);
 }
-void zk_launch_small_entropy(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeqP *seqs, uint32_t groups)
+void zk_launch_small_entropy(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeqP *seqs, uint32_t groups, bool split)
 {
-    static const bool split = getenv("ZK_SMALL_SPLIT") != nullptr;
-    if (split) {
+    if (split) {                                             // (diagnosis: the two roles show separately in a kernel trace)
         hipLaunchKernelGGL(zk_k_small_huf, dim3(groups), dim3(128), 0, st, comp, blocks, words, lit);
         hipLaunchKernelGGL(zk_k_small_fse, dim3(groups), dim3(128), 0, st, comp, blocks, words, seqs);
         return;

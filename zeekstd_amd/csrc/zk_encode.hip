@@ -888,8 +888,7 @@ void zk_launch_enc_fse_build(hipStream_t st, const uint8_t *src, const ZkEncFram
                              const ZkEncTables *predef, ZkEncTables *ftab)
 {
     (void)src;
-    static const bool only_predef = getenv("ZK_ENC_PREDEF") != nullptr;      // experiments: the predefined tables for every frame
-    hipLaunchKernelGGL(zk_k_enc_fse_build, dim3(nframes), dim3(1024), 0, st, frames, blocks, seqs, mpos, predef, ftab, only_predef ? 0xFFFFFFFFu : ZKE_FSE_MIN_SEQ);
+    hipLaunchKernelGGL(zk_k_enc_fse_build, dim3(nframes), dim3(1024), 0, st, frames, blocks, seqs, mpos, predef, ftab, ZKE_FSE_MIN_SEQ);
 }
 void zk_launch_enc_entropy(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, ZkEncBlock *blocks, uint32_t nblocks,
                            uint64_t *seqs, uint32_t *mpos, const uint8_t *lits, uint8_t *scratch, const ZkEncTables *ftab)

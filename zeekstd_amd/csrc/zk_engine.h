@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include "zk_enc_device.h"
+#include "zk_kernels.h"
 
 enum { ZK_K_WALK_COUNT = 0, ZK_K_SCAN, ZK_K_WALK_FILL, ZK_K_HUF, ZK_K_FSE, ZK_K_EXEC, ZK_K_XXH64, ZK_K_STATUS,
        ZK_K_ENC_MATCH, ZK_K_ENC_ENTROPY, ZK_K_ENC_COMPACT, ZK_K_ENC_XXH64, ZK_K_ENC_FSE_BUILD, ZK_NKERNELS };
@@ -42,7 +43,9 @@ struct zk_engine {
     int host_threads = 0;                   // zk_engine_set_host_threads (0 = default)
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool profiling = false;
-    int fse_kernel = 0;              // zk_engine_set_fse_kernel
+    ZkKernelChoice choice;           // zk_engine_set_kernel_choice: all zero = by batch shape
+    int pipe_contexts = 0;           // host pipeline: decode contexts in flight (0 = default) and chunk size, zk_hostpipe_tune
+    uint64_t pipe_chunk_bytes = 0;
     hipEvent_t ev_start[ZK_NKERNELS] = {}, ev_stop[ZK_NKERNELS] = {};
     bool ev_used[ZK_NKERNELS] = {};
     float kernel_ms[ZK_NKERNELS] = {};
@@ -85,6 +88,7 @@ struct zk_seek_table;
 zk_seek_table *zk_seek_table_from_cpp(const zeekstd::SeekTable *t);
 int zk_hostpipe_create(zk_engine *e);
 void zk_hostpipe_destroy(zk_engine *e);
+void zk_hostpipe_tune(zk_engine *e);                    // applies zk_engine::pipe_contexts / pipe_chunk_bytes (between calls)
 enum { ZK_HW_ENC_TOTAL = 8 };               // index into zk_engine::h_words of the encoder's total-size read-back
 struct zk_enc_args {
     const void *d_src; uint64_t n; uint32_t frame_size; int level, checksum;

@@ -53,12 +53,24 @@ extern "C" int zk_engine_set_profiling(zk_engine *e, int on)
     e->profiling = on != 0;
     return 0;
 }
-extern "C" int zk_engine_set_fse_kernel(zk_engine *e, int mode)
+extern "C" int zk_engine_set_kernel_choice(zk_engine *e, int what, int value)
 {
-    if (!e || mode < 0 || mode > 2) return ZK_ERR_ARGUMENT;
-    e->fse_kernel = mode;
-    return 0;
+    if (!e) return ZK_ERR_ARGUMENT;
+    ZkKernelChoice &k = e->choice;
+    switch (what) {
+    case ZK_CHOICE_RESET: k = ZkKernelChoice(); return 0;
+    case ZK_CHOICE_FSE_OWN: if (value < 0 || value > 2) return ZK_ERR_ARGUMENT; k.fse_own = value; return 0;
+    case ZK_CHOICE_FSE_SHARED: if (value < 0 || value > 3) return ZK_ERR_ARGUMENT; k.fse_shared = value; return 0;
+    case ZK_CHOICE_EXEC_LANES: if (value != 0 && value != 128 && value != 256 && value != 512 && value != 1024) return ZK_ERR_ARGUMENT; k.exec_lanes = value; return 0;
+    case ZK_CHOICE_EXEC_RING: if (value < 0 || value > 2) return ZK_ERR_ARGUMENT; k.exec_ring = value; return 0;
+    case ZK_CHOICE_XXH64: if (value < 0 || value > 2) return ZK_ERR_ARGUMENT; k.xxh = value; return 0;
+    case ZK_CHOICE_SMALL_PATH: if (value < 0 || value > 2) return ZK_ERR_ARGUMENT; k.small_path = value; return 0;
+    case ZK_CHOICE_PIPE_CONTEXTS: if (value < 0 || value > ZK_MAX_CTX) return ZK_ERR_ARGUMENT; e->pipe_contexts = value; zk_hostpipe_tune(e); return 0;
+    case ZK_CHOICE_PIPE_CHUNK_MIB: if (value < 0 || value > 4096) return ZK_ERR_ARGUMENT; e->pipe_chunk_bytes = (uint64_t)value << 20; zk_hostpipe_tune(e); return 0;
+    default: return ZK_ERR_ARGUMENT;
+    }
 }
+extern "C" int zk_engine_set_fse_kernel(zk_engine *e, int mode) { return zk_engine_set_kernel_choice(e, ZK_CHOICE_FSE_OWN, mode); }
 extern "C" int zk_engine_kernel_count(void) { return ZK_NKERNELS; }
 extern "C" const char *zk_engine_kernel_name(int k)
 {
@@ -238,7 +250,7 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
     // with per-kernel timing on they are serialised instead
     if (e->profiling || a.single_queue) {
         { zk_kernel_timer t(e, ZK_K_HUF, st); zk_launch_huf(st, comp, blocks, (uint32_t)nblocks, lit); }
-        { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->fse_kernel, count); }
+        { zk_kernel_timer t(e, ZK_K_FSE, st); zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->choice, count); }
     } else {
         if ((rc = zk_dec_ctx_aux(e, c.slot))) return rc;
         zk_engine::DecCtx &x = e->dctx[c.slot];
@@ -246,13 +258,13 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
         ZK_HIP(hipStreamWaitEvent(x.aux, x.ev_fork, 0));
         zk_launch_huf(x.aux, comp, blocks, (uint32_t)nblocks, lit);
         ZK_HIP(hipEventRecord(x.ev_join, x.aux));
-        zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->fse_kernel, count);
+        zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->choice, count);
         ZK_HIP(hipStreamWaitEvent(st, x.ev_join, 0));
     }
-    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, a.ids, a.out_off, blocks, bases, infos, seqs, lit, (uint8_t *)a.d_dst, (const uint8_t *)a.d_prefix, a.d_prefix ? a.prefix_len : 0, dense); }
+    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, a.ids, a.out_off, blocks, bases, infos, seqs, lit, (uint8_t *)a.d_dst, (const uint8_t *)a.d_prefix, a.d_prefix ? a.prefix_len : 0, e->choice, dense); }
     if (a.mark_exec) ZK_HIP(hipEventRecord(c.ev_exec, st));
     // packed indexed output: out_off (count + 1 prefix sums) doubles as the d_off of the checksum kernel
-    if (a.verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)a.d_dst, a.out_off ? a.out_off : d_off, a.out_off ? 0 : first, count, infos, nullptr); }
+    if (a.verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)a.d_dst, a.out_off ? a.out_off : d_off, a.out_off ? 0 : first, count, infos, nullptr, e->choice); }
     { zk_kernel_timer t(e, ZK_K_STATUS, st); zk_launch_status(st, infos, count, (int32_t *)a.d_frame_status, words + 3); }
     ZK_HIP(hipMemcpyAsync(c.h_words + 3, words + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     return 0;
@@ -346,7 +358,7 @@ extern "C" int zk_xxh64_frames_dev(zk_engine *e, const void *d_data, const void 
     if (count == 0) return 0;
     ZK_HIP(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-    zk_launch_xxh64(st, (const uint8_t *)d_data, (const uint64_t *)d_off, 0, count, nullptr, (uint64_t *)d_out);
+    zk_launch_xxh64(st, (const uint8_t *)d_data, (const uint64_t *)d_off, 0, count, nullptr, (uint64_t *)d_out, e->choice);
     ZK_HIP(hipStreamSynchronize(st));
     ZK_HIP(hipGetLastError());
     return 0;

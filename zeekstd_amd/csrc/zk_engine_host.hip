@@ -217,14 +217,13 @@ struct ZkRegWindow {
 
 struct zk_hostpipe {
     static constexpr int NS = ZK_MAX_CTX + 1;    // decode chunks whose HBM buffers can exist at once (contexts in use + 1)
-    int nctx = 2;                                // decode contexts the pipeline rotates through (ZK_PIPE_CTX)
-    uint64_t chunk_target = 0;                   // bytes of output per chunk (0 = by total size; ZK_PIPE_CHUNK_MB)
+    int nctx = 2;                                // decode contexts the pipeline rotates through (ZK_CHOICE_PIPE_CONTEXTS)
+    uint64_t chunk_target = 0;                   // bytes of output per chunk (0 = by total size; ZK_CHOICE_PIPE_CHUNK_MIB)
     static constexpr size_t PIECE = 32u << 20;   // pinned staging piece
     ZkPool *pool = nullptr;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     ZkRing ring_in, ring_out;                    // allocated on the first large call
     bool rings_ready = false;
-    bool trace = false;                          // ZK_TRACE_PIPE: host-side timeline of the chunks on stderr
     struct Slot {
         zk_devbuf d_in, d_out, d_off, d_st;
         hipEvent_t ev_in = nullptr, ev_dec = nullptr, ev_out = nullptr;
@@ -264,9 +263,6 @@ static int zk_hostpipe_get(zk_engine *e, zk_hostpipe **out)
     e->hp = hp;
     ZK_HIP(hipStreamCreateWithFlags(&hp->s_h2d, hipStreamNonBlocking));
     ZK_HIP(hipStreamCreateWithFlags(&hp->s_d2h, hipStreamNonBlocking));
-    hp->trace = getenv("ZK_TRACE_PIPE") != nullptr;
-    if (const char *v = getenv("ZK_PIPE_CTX")) { const int k = atoi(v); if (k >= 1 && k <= ZK_MAX_CTX) hp->nctx = k; }
-    if (const char *v = getenv("ZK_PIPE_CHUNK_MB")) { const long k = atol(v); if (k >= 1 && k <= 4096) hp->chunk_target = (uint64_t)k << 20; }
     for (auto &s : hp->slot) {
         ZK_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
         ZK_HIP(hipEventCreateWithFlags(&s.ev_dec, hipEventDisableTiming));
@@ -295,6 +291,12 @@ static int zk_hostpipe_rings(zk_engine *e, zk_hostpipe *hp)
 }
 
 int zk_hostpipe_create(zk_engine *e) { zk_hostpipe *hp = nullptr; return zk_hostpipe_get(e, &hp); }
+void zk_hostpipe_tune(zk_engine *e)
+{
+    if (!e->hp) return;
+    e->hp->nctx = e->pipe_contexts ? e->pipe_contexts : 2;
+    e->hp->chunk_target = e->pipe_chunk_bytes;
+}
 
 void zk_hostpipe_destroy(zk_engine *e)
 {
@@ -441,10 +443,10 @@ static int zk_decode_small(zk_engine *e, zk_hostpipe *hp, const zk_host_src &src
     zk_launch_small_walk(st, h_comp, csz, h_offs, count, dsz, block_cap, (uint8_t *)s.d_in.p, d_offs, infos, (ZkFrameBase *)c.bases.p, blocks, words);
     uint32_t groups = (block_cap + 15) / 16;
     if (groups > 32) groups = 32;
-    zk_launch_small_entropy(st, comp, blocks, words, (uint8_t *)c.lit.p, (ZkSeqP *)c.seqs.p, groups);
+    zk_launch_small_entropy(st, comp, blocks, words, (uint8_t *)c.lit.p, (ZkSeqP *)c.seqs.p, groups, e->choice.small_path == 2);
     zk_launch_exec(st, comp, d_offs + count + 1, 0, count, nullptr, nullptr, blocks, (const ZkFrameBase *)c.bases.p, infos, (const ZkSeqP *)c.seqs.p,
-                   (const uint8_t *)c.lit.p, (uint8_t *)s.d_out.p, (const uint8_t *)d_prefix, d_prefix ? prefix_len : 0);
-    if (verify) zk_launch_xxh64(st, (const uint8_t *)s.d_out.p, d_offs + count + 1, 0, count, infos, nullptr);
+                   (const uint8_t *)c.lit.p, (uint8_t *)s.d_out.p, (const uint8_t *)d_prefix, d_prefix ? prefix_len : 0, e->choice);
+    if (verify) zk_launch_xxh64(st, (const uint8_t *)s.d_out.p, d_offs + count + 1, 0, count, infos, nullptr, e->choice);
     zk_launch_small_publish(st, infos, d_offs, count, (const uint8_t *)s.d_out.p, dsz ? h_out : nullptr, (int32_t *)s.d_st.p, h_status, words, hp->pin_flag, gen);
     // completion: the last workgroup of the publish kernel writes the generation into pinned memory
     volatile uint32_t *flag = hp->pin_flag;
@@ -507,7 +509,7 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
     for (auto &ck : chunks) if (ck.c1 - ck.c0 > max_c) max_c = ck.c1 - ck.c0;
     // a small request (a seek) is staged through one small pinned buffer by this thread: no rings, no hand-over
     const bool small = nchunks == 1 && total_d <= (4u << 20) && max_c <= (4u << 20);
-    if (small && count <= 64 && !e->profiling && getenv("ZK_NO_SMALL_PATH") == nullptr) {
+    if (small && count <= 64 && !e->profiling && e->choice.small_path != 1) {
         bool fallback = false;
         rc = zk_decode_small(e, hp, src, c_off, d_off, first, count, d_prefix, prefix_len, dst, dst_pinned, verify, frame_status, n_ok, &fallback);
         if (!fallback) return rc;
@@ -646,18 +648,12 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
         return 0;
     };
 
-    const auto t00 = std::chrono::steady_clock::now();
-    auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t00).count(); };
     if ((fail = prep(0)) == 0) {
         for (size_t i = 0; i < nchunks; i++) {
-            const double ta = ms();
             if (i + 1 < nchunks && (fail = prep(i + 1))) break;       // the next chunk's upload is queued before this one's decode blocks the thread
-            const double tb = ms();
             if ((fail = run(i))) break;
-            if (hp->trace) fprintf(stderr, "[zk pipe] chunk %zu: prep(next) %.2f ms, run %.2f ms, at %.2f ms\n", i, tb - ta, ms() - tb, ms());
         }
     }
-    const double t_issue = ms();
     // ---- drain
     hipError_t s1 = hipStreamSynchronize(hp->s_h2d), s2 = hipSuccess, s3 = hipSuccess;
     for (int k = 0; k < nctx; k++) { const hipError_t r = hipStreamSynchronize(e->dctx[k].st); if (r != hipSuccess) s2 = r; }
@@ -665,7 +661,6 @@ int zk_host_decode(zk_engine *e, const zk_host_src &src, const uint64_t *c_off, 
     for (auto &s : hp->slot) s.out_pending = false;
     if (hp->rings_ready) hp->ring_out.wait_all_released();
     wsrc.finish(); wdst.finish();
-    if (hp->trace) fprintf(stderr, "[zk pipe] %zu chunks issued at %.2f ms, drained at %.2f ms\n", nchunks, t_issue, ms());
     if (fail) return fail;
     if (s1 != hipSuccess || s2 != hipSuccess || s3 != hipSuccess || s4 != hipSuccess || copy_fail.load()) {
         e->last_err = "host decode pipeline: a queue failed"; return ZK_ERR_HIP;

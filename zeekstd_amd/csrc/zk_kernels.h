@@ -3,22 +3,34 @@
 #include <hip/hip_runtime.h>
 #include "zk_device.h"
 
+// Which kernel variant a launcher picks.  0 everywhere = by batch shape (what production runs); the other values pin one
+// variant whatever the batch looks like, so that tests/ can put every kernel of the large-batch path under a small, exhaustively
+// checked input (zk_engine_set_kernel_choice, include/zeekstd_amd.h) and tools/ can time one against the other.
+struct ZkKernelChoice {
+    int fse_own = 0;        // blocks with tables of their own: 1 zk_k_fse (a lane per block), 2 zk_k_fse_quad in the 56-block layout
+    int fse_shared = 0;     // blocks that share tables: 1 zk_k_fse_predef, 2 zk_k_fse_predef_fed, 3 zk_k_fse_sets
+    int exec_lanes = 0;     // zk_k_exec tile: 128 / 256 / 512 / 1024 lanes
+    int exec_ring = 0;      // 256-lane tiles: 1 a ring of 2 T records, 2 of 4 T
+    int xxh = 0;            // 1 zk_k_xxh64 (a wave per frame), 2 zk_k_xxh64_wide (sixteen frames per wave)
+    int small_path = 0;     // host-pointer decode of <= 64 frames: 1 the general pipeline instead, 2 the small path's entropy roles as two kernels
+};
+
 void zk_launch_walk(hipStream_t st, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
                     uint32_t count, const uint32_t *ids, const uint64_t *out_off, uint64_t dst_cap, const ZkFrameBase *bases, ZkBlock *blocks, ZkFrameInfo *infos);
 void zk_launch_scan(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals, const uint64_t *d_off, uint32_t first, const uint64_t *out_off);
 void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint8_t *lit);
-void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeqP *seqs, int own_kernel, uint32_t frames = 0);
+void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeqP *seqs, const ZkKernelChoice &k, uint32_t frames = 0);
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeqP *seqs,
-                    const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen, bool dense = false);
+                    const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen, const ZkKernelChoice &k, bool dense = false);
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
-                     ZkFrameInfo *infos, uint64_t *hashes);
+                     ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k);
 void zk_launch_status(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, uint64_t *first_err);
 
 // small batches (a seek): no host round trip, no copy commands -- see zk_decode.hip
 void zk_launch_small_walk(hipStream_t st, const uint8_t *h_comp, uint64_t comp_bytes, const uint64_t *h_offs, uint32_t count, uint64_t dst_cap,
                           uint32_t block_cap, uint8_t *d_comp, uint64_t *d_offs, ZkFrameInfo *infos, ZkFrameBase *bases, ZkBlock *blocks, uint64_t *words);
-void zk_launch_small_entropy(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeqP *seqs, uint32_t groups);
+void zk_launch_small_entropy(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeqP *seqs, uint32_t groups, bool split);
 void zk_launch_small_publish(hipStream_t st, const ZkFrameInfo *infos, const uint64_t *d_offs, uint32_t count, const uint8_t *dst, uint8_t *h_out,
                              int32_t *d_status, int32_t *h_status, uint64_t *words, uint32_t *h_flag, uint32_t gen);
 

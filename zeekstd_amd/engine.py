@@ -54,6 +54,17 @@ class Engine:
         if rc != 0:
             self._raise(rc)
 
+    CHOICES = {"reset": 0, "fse_own": 1, "fse_shared": 2, "exec_lanes": 3, "exec_ring": 4, "xxh64": 5, "small_path": 6,
+               "pipe_contexts": 7, "pipe_chunk_mib": 8}
+
+    def set_kernel_choice(self, **kw):
+        """Pins kernel variants (zk_engine_set_kernel_choice): e.g. set_kernel_choice(fse_shared=2, exec_lanes=256, xxh64=2) runs the
+        large-batch kernels on whatever is decoded next; set_kernel_choice(reset=0) returns to "by batch shape"."""
+        for key, value in kw.items():
+            rc = lib.zk_engine_set_kernel_choice(self._h, self.CHOICES[key], int(value))
+            if rc != 0:
+                self._raise(rc)
+
     def kernel_times(self):
         """{kernel name: ms} of the last decode/encode call (profiling must be on)."""
         n = lib.zk_engine_kernel_count()
