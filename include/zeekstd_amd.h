@@ -158,10 +158,12 @@ int zk_decode_wait(zk_engine *e, int slot);
  * concatenated in dst, and report the seek-table entries: c_sizes[i] / d_sizes[i] are what
  * SeekTable::log_frame receives (seek_table.rs:513-525).  checksum != 0 appends the XXH64 Content_Checksum
  * (ZSTD_c_checksumFlag, encode.rs:283-284).  level is ZSTD_c_compressionLevel (encode.rs:281-282): one strategy
- * (greedy hash matching in a 64 KiB window, Huffman literals, FSE tables measured per frame) with three settings --
- * level <= 1 (negative levels included): matches of 6+ bytes, 2^14 hash-table entries; levels 2..5 and 0 (= libzstd's
- * default 3): 5+ bytes, 2^15 entries; level >= 6: 2^16 entries (ratio 2.44 / 2.57 / 2.63 on the survey's text at
- * 50 / 43 / 28 GiB/s; libzstd: 2.49 at level 1, 2.77 at level 3).  Replaces the ZSTD_compressStream2 loops of
+ * (hash matching in a 57 280-byte window, Huffman literals, FSE tables measured per frame) with three settings
+ * (zk_enc_device.h: zke_fast / zke_minmatch / zke_hash_log / zke_lazy / zke_step) --
+ * level <= 1 (negative levels included): table matches of 6+ bytes, 2^14 table entries, greedy parse; levels 2..5 and 0
+ * (= libzstd's default 3, the reference CLI's default): 5+ bytes, 2^15 entries, lazy parse; level >= 6: the same with the
+ * table refreshed every 1024 instead of 4096 positions (ratio 2.47 / 2.59 / 2.59 on the survey's text, 3.29 / 3.46 / 3.57
+ * on Python sources; libzstd on the text: 2.49 at level 1, 2.77 at level 3).  Replaces the ZSTD_compressStream2 loops of
  * encode.rs:340-346, 442-464.
  * dst_cap >= zk_compress_bound(n, frame_size) always suffices; otherwise -70 (dstSize_tooSmall) may come back.
  */

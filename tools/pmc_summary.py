@@ -15,7 +15,7 @@ import json
 import os
 import sys
 
-WIDE = {"zk_k_xxh64": 2.0}
+WIDE = {"zk_k_xxh64": 2.0, "zk_k_xxh64_wide": 2.0}     # both read exactly the decompressed bytes, 8 / 16 bytes per lane and load
 
 
 def short(name):
@@ -58,9 +58,10 @@ def main():
         fk, wk = fetch.get(k, 0.0), write.get(k, 0.0)
         kernels[k] = {"fetch_kib": fk, "write_kib": wk, "fetch_correction": corr,
                       "hbm_bytes": int((fk * corr + wk) * 1024)}
-    doc = {"workload": workload,
+    import datetime
+    doc = {"workload": workload, "collected": datetime.date.today().isoformat() + " from " + os.path.basename(os.path.normpath(fdir)) + " / " + os.path.basename(os.path.normpath(wdir)),
            "note": "per launch (last dispatch of each kernel = the serialised per-kernel-timing step of bench.py); FETCH_SIZE x2 only where the access pattern was "
-                   "calibrated as wide (zk_k_xxh64); others uncorrected lower bounds",
+                   "calibrated as wide (zk_k_xxh64, zk_k_xxh64_wide); others uncorrected lower bounds",
            "kernels": kernels}
     with open(outp, "w") as f:
         json.dump(doc, f, indent=1)
