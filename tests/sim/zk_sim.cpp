@@ -11,18 +11,23 @@
 #include <vector>
 #include "../../zeekstd_amd/csrc/zk_device.h"
 
-// ---- a quad of lanes on the CPU: three fibers in lock step ------------------------------------------------------
-// zk_seq_walk_quad (zk_device.h) is written for three lanes that meet in every XCH::bcast (a DPP move on the device).
-// Here each lane is a ucontext fiber; bcast parks the lane's value and yields, the scheduler resumes the lanes round
+// ---- a quad of lanes on the CPU: fibers in lock step ---------------------------------------------------------------
+// zk_seq_walk_quad / zk_seq_finish_quad (zk_device.h) are written for lanes that meet in every XCH::bcast (a DPP move on the
+// device).  Here each lane is a ucontext fiber; bcast parks the lane's value and yields, the scheduler resumes the lanes round
 // robin, so every lane reaches exchange r before any lane leaves it (values are double buffered by exchange parity).
+// The device runs the two halves as two waves with an 8-entry LDS ring between them (zk_decode.hip, zk_fse_quad_group); here the
+// walk of a block runs to its end first (three lanes, values into an array), then the finisher (four lanes, rounds of four).
 struct ZkQuadSim {
-    ucontext_t main_ctx, ctx[3];
-    std::vector<char> stack[3];
-    uint32_t buf[2][3], round[3];
-    int cur;
-    bool done[3];
+    ucontext_t main_ctx, ctx[4];
+    std::vector<char> stack[4];
+    uint32_t buf[2][4], round[4];
+    int cur, nlanes;
+    bool done[4];
     // arguments of the walk
-    const uint8_t *comp; ZkBlock b[3]; uint32_t bs_off; ZkSeqTables16 *T; const uint32_t *al; ZkSeqP *seqs; uint32_t pos_pub;
+    const uint8_t *comp; ZkBlock b; uint32_t bs_off; ZkSeqTablesX16 *T; const uint32_t *al; ZkSeqP *seqs;
+    std::vector<uint32_t> vals;                  // [sequence][lane]
+    uint32_t walk_bad[3], gates;
+    ZkSeqCarry carry[4];
 };
 static ZkQuadSim *g_quad;
 static uint32_t g_ofv[32];
@@ -49,46 +54,79 @@ struct ZkQuadFibers {
         return q->buf[r & 1][k];
     }
 };
+struct ZkQuadSimOut {                            // OUT of zk_seq_walk_quad: the lane's column of the value array
+    ZkQuadSim *q; int t;
+    void gate(uint32_t i, uint32_t) { if (i % ZK_QUAD_ROUND != 0) q->gates |= 0x80000000u; q->gates++; }
+    void put(uint32_t i, uint32_t v) { q->vals[(size_t)i * 4 + (size_t)t] = v; }
+};
 
 static const uint32_t LLV[36] = ZK_LL_TABLE;
 static const uint32_t MLV[53] = ZK_ML_TABLE;
 
 static const uint32_t LLV_[36] = ZK_LL_TABLE;
 static const uint32_t MLV_[53] = ZK_ML_TABLE;
-static void zk_quad_lane_main()
+static void zk_quad_walk_lane_main()
 {
     ZkQuadSim *q = g_quad;
     const int t = q->cur;
-    zk_seq_walk_quad<ZkRevU, ZkCells16, ZkQuadFibers>(q->comp, q->b[t], q->bs_off, (uint32_t)t,
+    ZkQuadSimOut out{q, t};
+    q->walk_bad[t] = zk_seq_walk_quad<ZkRevU, ZkCellsX16, ZkQuadFibers>(q->comp, q->b, q->bs_off, (uint32_t)t,
                                                       t == ZK_TAB_LL ? q->T->ll : t == ZK_TAB_OF ? q->T->of : q->T->ml,
-                                                      t == ZK_TAB_LL ? LLV_ : t == ZK_TAB_OF ? g_ofv : MLV_, q->al, q->T->ring, q->seqs, &q->pos_pub);
+                                                      t == ZK_TAB_LL ? LLV_ : t == ZK_TAB_OF ? g_ofv : MLV_, q->al, out);
     q->done[t] = true;
 }
-// the block's sequences through the quad walk (tables already built in T); false: the three lanes disagree
-static bool zk_quad_walk_sim(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, ZkSeqTables16 *T, const uint32_t *al, ZkSeqP *seqs)
+static void zk_quad_finish_lane_main()
 {
-    ZkQuadSim q;
-    g_quad = &q;
-    for (uint32_t k = 0; k < 32; k++) g_ofv[k] = k << 24;
-    q.comp = comp; q.bs_off = bs_off; q.T = T; q.al = al; q.seqs = seqs; q.pos_pub = 0;
-    for (int l = 0; l < 3; l++) {
-        q.b[l] = b; q.round[l] = 0; q.done[l] = false;
+    ZkQuadSim *q = g_quad;
+    const int j = q->cur;
+    const uint32_t nseq = q->b.nseq;
+    ZkSeqCarry &c = q->carry[j];
+    zk_seq_carry_init(c);
+    for (uint32_t i0 = 0; i0 < nseq; i0 += ZK_QUAD_ROUND) {
+        const uint32_t nvalid = nseq - i0 < ZK_QUAD_ROUND ? nseq - i0 : ZK_QUAD_ROUND;
+        const bool have = (uint32_t)j < nvalid;
+        const uint32_t *v = &q->vals[(size_t)(i0 + (have ? j : 0)) * 4];
+        // a lane without a sequence brings garbage, as a stale ring entry would
+        const ZkSeqP rec = zk_seq_finish_quad<ZkQuadFibers>((uint32_t)j, nvalid, have ? v[0] : 0xDEADBEEFu, have ? v[1] : 0xDEADBEEFu, have ? v[2] : 0xDEADBEEFu, c, q->b.lit_regen);
+        if (have) q->seqs[i0 + j] = rec;
+    }
+    q->done[j] = true;
+}
+static void zk_quad_run(ZkQuadSim &q, int nlanes, void (*lane_main)())
+{
+    q.nlanes = nlanes;
+    for (int l = 0; l < nlanes; l++) {
+        q.round[l] = 0; q.done[l] = false;
         q.stack[l].resize(256 << 10);
         getcontext(&q.ctx[l]);
         q.ctx[l].uc_stack.ss_sp = q.stack[l].data();
         q.ctx[l].uc_stack.ss_size = q.stack[l].size();
         q.ctx[l].uc_link = &q.main_ctx;
-        makecontext(&q.ctx[l], zk_quad_lane_main, 0);
+        makecontext(&q.ctx[l], lane_main, 0);
     }
-    while (!(q.done[0] && q.done[1] && q.done[2]))
-        for (int l = 0; l < 3; l++)
-            if (!q.done[l]) { q.cur = l; swapcontext(&q.main_ctx, &q.ctx[l]); }
+    for (;;) {
+        bool any = false;
+        for (int l = 0; l < nlanes; l++)
+            if (!q.done[l]) { any = true; q.cur = l; swapcontext(&q.main_ctx, &q.ctx[l]); }
+        if (!any) break;
+    }
+}
+// the block's sequences through the quad walk (tables already built in T); false: the lanes disagree
+static bool zk_quad_walk_sim(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, ZkSeqTablesX16 *T, const uint32_t *al, ZkSeqP *seqs)
+{
+    ZkQuadSim q;
+    g_quad = &q;
+    for (uint32_t k = 0; k < 32; k++) g_ofv[k] = k << 24;
+    q.comp = comp; q.b = b; q.bs_off = bs_off; q.T = T; q.al = al; q.seqs = seqs; q.gates = 0;
+    q.vals.assign((size_t)b.nseq * 4 + 4, 0xA5A5A5A5u);
+    zk_quad_run(q, 3, zk_quad_walk_lane_main);
+    bool same = q.walk_bad[0] == q.walk_bad[1] && q.walk_bad[1] == q.walk_bad[2] && q.round[0] == q.round[1] && q.round[1] == q.round[2];
+    same = same && (q.walk_bad[0] || q.gates == 3 * ((b.nseq + ZK_QUAD_ROUND - 1) / ZK_QUAD_ROUND));       // a gate in front of every round, by every lane
+    zk_quad_run(q, 4, zk_quad_finish_lane_main);
+    for (int l = 1; l < 4; l++)
+        same = same && memcmp(&q.carry[l], &q.carry[0], sizeof(ZkSeqCarry)) == 0 && q.round[l] == q.round[0];
     g_quad = nullptr;
-    bool same = true;
-    for (int l = 1; l < 3; l++)
-        same = same && q.b[l].status == q.b[0].status && q.b[l].out_size == q.b[0].out_size && q.b[l].rep_out[0] == q.b[0].rep_out[0] &&
-               q.b[l].rep_out[1] == q.b[0].rep_out[1] && q.b[l].rep_out[2] == q.b[0].rep_out[2] && q.round[l] == q.round[0];
-    b = q.b[0];
+    zk_seq_finish_block(b, q.carry[0], q.walk_bad[0]);
     return same;
 }
 
@@ -168,10 +206,11 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
     // fse: one "lane" per block
     ZkSeqTables *T = new ZkSeqTables;
     ZkSeqTables16 *T16 = new ZkSeqTables16;
+    ZkSeqTablesX16 *TX16 = new ZkSeqTablesX16;
     for (uint64_t bi = 0; bi < nb; bi++) {
         ZkBlock b = blocks[bi];
         if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK) continue;
-        zk_sim_poison(T, sizeof *T); zk_sim_poison(T16, sizeof *T16);
+        zk_sim_poison(T, sizeof *T); zk_sim_poison(T16, sizeof *T16); zk_sim_poison(TX16, sizeof *TX16);
         // like the device: all-predefined blocks go through the aligned-word reader, the rest through the unaligned one
         // (with the quad flag every block takes the quad walk, as small batches do on the device)
         if (b.seq_modes == 0 && !g_fse_quad) zk_decode_sequences<ZkRevA, ZkCells32>(comp, blocks.data(), b, T, seqs.data() + b.seq_base, LLV, MLV);
@@ -182,12 +221,12 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
             for (int u = 0; u < 3 && ok; u++) {
                 const uint32_t m = (b.seq_modes >> (6 - 2 * u)) & 3;
                 const ZkBlock &def = m == 3 ? blocks[b.tab_def[u]] : b;
-                const int32_t r = zk_seq_table_setup<ZkCells16>(comp, def, u, T16, &al[u], LLV, MLV);
+                const int32_t r = zk_seq_table_setup<ZkCellsX16>(comp, def, u, TX16, &al[u], LLV, MLV);
                 if (r < 0) ok = false;
                 else if (m != 3) own += (uint32_t)r;
             }
             if (!ok) b.status = ZK_E_CORRUPTION;
-            else if (!zk_quad_walk_sim(comp, b, b.seq_off + 1 + own, T16, al, seqs.data() + b.seq_base)) b.status = ZK_E_CORRUPTION + 1000;   // lanes out of step: a bug, not an input error
+            else if (!zk_quad_walk_sim(comp, b, b.seq_off + 1 + own, TX16, al, seqs.data() + b.seq_base)) b.status = ZK_E_CORRUPTION + 1000;   // lanes out of step: a bug, not an input error
         }
         blocks[bi].out_size = b.out_size;
         for (int k = 0; k < 3; k++) blocks[bi].rep_out[k] = b.rep_out[k];
@@ -195,6 +234,7 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
     }
     delete T;
     delete T16;
+    delete TX16;
     // exec: one "workgroup" per frame; tiles of THREADS x B bytes, slot marking + per-byte source map (zk_exec_slot_span / zk_exec_slot_words)
     // CAPS: sequences staged at once.  Like the kernel the staged records live in a ring (slot = block sequence index & mask):
     // a tile retires the sequences it consumed and as many new records move into their slots.

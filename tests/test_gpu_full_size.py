@@ -73,8 +73,8 @@ def test_configs2_encode_decode_4gib(engine, big):
         if Z.load("system") is not None:
             assert Z.decode_stream(fr, FRAME, "system") == want, f
         return True
-    with ThreadPoolExecutor(8) as ex:
-        assert all(ex.map(check, sample))
+    for f in sample:                                     # (serially: the twin keeps its level settings and code tables in globals)
+        check(f)
     # decode: one batch, every checksum verified on the device
     d_c = torch.from_numpy(c.view(np.int64)).to(dev); d_d = torch.from_numpy(d.view(np.int64)).to(dev)
     d_out = torch.zeros(n + 64, dtype=torch.uint8, device=dev)

@@ -172,7 +172,7 @@ __device__ __forceinline__ void zk_huf_group(uint32_t group, const uint8_t *comp
     // A workgroup with fewer than 4 blocks left keeps >= 16 lanes active: the extra lanes shadow valid streams
     // (< 16 active lanes run ~3x slower on gfx950, tools/ubench/lat3.hip); shadows never store to HBM
     const uint32_t t = threadIdx.x & 63;
-    const bool decoder = threadIdx.x < 64;
+    const bool decoder = threadIdx.x < 64, companion = threadIdx.x >= 64 && threadIdx.x < 128;     // (further waves of a caller's workgroup only pass the barriers)
     const uint32_t wb = group * ZK_HUF_BLOCKS;
     const uint32_t nvalid = nblocks - wb < (uint32_t)ZK_HUF_BLOCKS ? nblocks - wb : (uint32_t)ZK_HUF_BLOCKS;
     const bool real = t < 4 * nvalid;
@@ -247,7 +247,7 @@ __device__ __forceinline__ void zk_huf_group(uint32_t group, const uint8_t *comp
         if (decoder) {
             if (have) ok = zk_huf_decode_stream(tab, mb, sbase, slen, sdst, sn, real, &mail, t);
             zk_lds_st<uint32_t>(&s_done, 1u);
-        } else if (have && real) {
+        } else if (companion && have && real) {
             zk_huf_companion(sbase, slen, sdst + ((0 - (uintptr_t)sdst) & 7), &mail, t, &s_done);     // packs start at the 8-byte aligned output position
         }
         __syncthreads();
@@ -292,7 +292,8 @@ __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *com
     const uint32_t slot = wave * ZK_FSE_PER_WAVE + lane % nvalid;                      // shadows replicate valid blocks only
     const uint32_t bi = blockIdx.x * ZK_FSE_BLOCKS + slot;
     ZkBlock b = blocks[bi];
-    if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK || b.seq_modes == 0 || b.pad) return;      // all-predefined / shared-table blocks: zk_k_fse_predef
+    if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK || b.pad) return;      // pad: done by a shared-table kernel.  (All-predefined blocks that kernel left behind -- a workgroup whose reference
+                                                                               // had own tables too few neighbours share -- are taken here like any other)
     zk_decode_sequences<ZkRevU, CP>(comp, blocks, b, &T[slot], seqs + b.seq_base, llv, mlv, real);
     if (!real) return;
     ZkBlock *o = &blocks[bi];
@@ -315,13 +316,43 @@ struct ZkQuadDpp {
     {
         return k == 0 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, true)
              : k == 1 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xF, 0xF, true)
-                      : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA, 0xF, 0xF, true);
+             : k == 2 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA, 0xF, 0xF, true)
+                      : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF, 0xF, 0xF, true);
+    }
+};
+
+// Round 4: the walk is two waves.  A lone wave issues in order, so every instruction of a step -- repeat offsets, running sums,
+// the record, its store -- used to sit on the chain's clock (~110 instructions, ~1000 clocks per sequence).  Now the WALKER wave
+// (a quad per block, as before) only advances the three states and leaves each sequence's three values in an LDS ring; the
+// FINISHER wave beside it (same lane layout: quad q = block q of the walker wave, lane j = the j-th sequence of a round of four)
+// turns them into records.  Hand-over per walker wave: the walker publishes "sequences < prod are in the ring" in front of every
+// fourth sequence and ZK_QUAD_DONE at its end (LDS accesses of a wave are ordered: the ring writes are in front of it); the
+// finisher publishes "sequences < cons are read" as soon as a round's values are in its registers, and the walker does not write
+// sequence i before cons >= i + 4 - ZK_QUAD_RING.  Both loops are wave-uniform (one counter per wave, a polling loop nobody
+// leaves alone -- see zk_huf_companion for what a per-lane exit cost).
+constexpr uint32_t ZK_QUAD_RING = 8;                     // sequences per block in the ring (16 B each: the 128 B that held 16 records)
+constexpr uint32_t ZK_QUAD_DONE = 0x7FFFFFFFu;
+static_assert(ZK_QUAD_RING * 16 == sizeof(((ZkSeqTablesX16 *)nullptr)->ring), "the hand-over ring takes the record ring's place");
+struct ZkQuadOut {                                       // OUT of zk_seq_walk_quad on the device
+    uint32_t ring;                                       // LDS byte address of the lane's word of entry 0
+    volatile uint32_t *prod, *cons, *pos_pub;
+    bool lead;                                           // the LL lane publishes for the toucher
+    __device__ __forceinline__ void gate(uint32_t i, uint32_t stream_pos)
+    {
+        zk_lds_st<uint32_t>(prod, i);
+        if (lead) zk_lds_st<uint32_t>(pos_pub, stream_pos);
+        if (i + ZK_QUAD_ROUND > ZK_QUAD_RING)
+            while ((uint32_t)__builtin_amdgcn_readfirstlane(zk_lds_ld<uint32_t>(cons)) + ZK_QUAD_RING < i + ZK_QUAD_ROUND) __builtin_amdgcn_s_sleep(1);
+    }
+    __device__ __forceinline__ void put(uint32_t i, uint32_t v)
+    {
+        zk_lds_st_at<uint32_t>(ring + (i & (ZK_QUAD_RING - 1)) * 16u, v);
     }
 };
 
 // One more wave per workgroup keeps the bitstreams warm: a wave waits for its loads in order, and with 14 streams per
 // wave some lane crosses into a new cache line at almost every step -- without help every other step of the whole wave
-// waits for an L2 round trip.  The walkers publish their stream position once per 16 sequences; the toucher wave (its
+// waits for an L2 round trip.  The walkers publish their stream position once per round; the toucher wave (its
 // own load counter, results never used) requests the two lines below it.
 // STAGE (small batches): the quad copies its block's bitstream (up to ZK_FSE_STAGE bytes) into LDS before the walk.
 constexpr uint32_t ZK_FSE_STAGE = 3072;
@@ -333,7 +364,8 @@ __device__ __forceinline__ void zk_fse_quad_group(uint32_t group, const uint8_t 
     __shared__ ZkSeqTablesT<CP> T[ZK_FSE_BLOCKS];
     __shared__ __attribute__((aligned(16))) uint8_t s_bits[STAGE ? ZK_FSE_BLOCKS : 1][STAGE ? ZK_FSE_STAGE + 16 : 16];
     __shared__ uint32_t llv[36], mlv[53], ofv[32];
-    __shared__ uint32_t s_pos[ZK_FSE_BLOCKS], s_live;
+    __shared__ uint32_t s_pos[ZK_FSE_BLOCKS], s_wbad[ZK_FSE_BLOCKS], s_live;
+    __shared__ uint32_t s_prod[ZK_FSE_WAVES], s_cons[ZK_FSE_WAVES], s_nloop[ZK_FSE_WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
         const uint32_t ll_init[36] = ZK_LL_TABLE;
@@ -341,25 +373,27 @@ __device__ __forceinline__ void zk_fse_quad_group(uint32_t group, const uint8_t 
         if (tid < 36) llv[tid] = ll_init[tid];
         if (tid < 53) mlv[tid] = ml_init[tid];
         if (tid < 32) ofv[tid] = tid << 24;
-        if (tid < (uint32_t)ZK_FSE_BLOCKS) s_pos[tid] = 0;
+        if (tid < (uint32_t)ZK_FSE_BLOCKS) { s_pos[tid] = 0; s_wbad[tid] = 0; }
+        if (tid < (uint32_t)ZK_FSE_WAVES) { s_prod[tid] = 0; s_cons[tid] = 0; s_nloop[tid] = 0; }
         if (tid == 0) s_live = 0;
     }
     __syncthreads();
-    const bool toucher = wave == (uint32_t)ZK_FSE_WAVES;
+    const bool toucher = wave == 2u * ZK_FSE_WAVES, finisher = !toucher && wave >= (uint32_t)ZK_FSE_WAVES;
+    const uint32_t w = finisher ? wave - ZK_FSE_WAVES : wave;          // the walker wave this lane walks / finishes for
     const uint32_t t = lane & 3;
-    const uint32_t slot = toucher ? lane : wave * PER_WAVE + (lane >> 2);
+    const uint32_t slot = toucher ? lane : w * PER_WAVE + (lane >> 2);
     const uint32_t bi = group * ZK_FSE_BLOCKS + slot;
     ZkBlock b;
-    bool valid = toucher ? lane < (uint32_t)ZK_FSE_BLOCKS : (lane < 4 * PER_WAVE && t != 3);
+    bool valid = toucher ? lane < (uint32_t)ZK_FSE_BLOCKS : (lane < 4 * PER_WAVE && (finisher || t != 3));
     valid = valid && bi < nblocks;
     if (valid) {
         b = blocks[bi];
         valid = b.type == 2 && b.nseq != 0 && b.status == ZK_OK && b.pad == 0 && (b.seq_modes != 0 || all_blocks);     // pad: done by the shared-table kernel; all-predefined blocks are its job too, unless the batch is small
     }
-    if (valid && !toucher && t == ZK_TAB_LL) atomicAdd(&s_live, 1u);
+    if (valid && !toucher && !finisher && t == ZK_TAB_LL) { atomicAdd(&s_live, 1u); atomicMax(&s_nloop[w], b.nseq); }
     __syncthreads();
-    if (!valid) return;
     if (toucher) {
+        if (!valid) return;
         uint32_t last = 0, sink = 0;
         while (zk_lds_ld<uint32_t>(&s_live)) {
             const uint32_t p = zk_lds_ld<uint32_t>(&s_pos[slot]);
@@ -375,46 +409,86 @@ __device__ __forceinline__ void zk_fse_quad_group(uint32_t group, const uint8_t 
         asm volatile("" :: "v"(sink));
         return;
     }
-    // the three lanes build the block's tables together (identical LDS writes: more active lanes, see above)
     ZkSeqTablesT<CP> *Tb = &T[slot];
-    uint32_t al[3], own = 0;
-    bool ok = true;
-    for (int u = 0; u < 3; u++) {
-        const uint32_t m = (b.seq_modes >> (6 - 2 * u)) & 3;
-        const ZkBlock &def = m == 3 ? blocks[b.tab_def[u]] : b;
-        const int32_t r = zk_seq_table_setup<CP>(comp, def, u, Tb, &al[u], llv, mlv);
-        if (r < 0) { ok = false; break; }
-        if (m != 3) own += (uint32_t)r;
-    }
-    if (!ok) b.status = ZK_E_CORRUPTION;
-    else {
-        const uint8_t *bits = nullptr;
-        if (STAGE) {
-            const uint32_t bs = b.seq_off + 1 + own;
-            if (bs < b.bsize && b.bsize - bs <= ZK_FSE_STAGE) {
-                const uint32_t len = b.bsize - bs;
-                const uint8_t *g = comp + b.src + bs;
-                for (uint32_t o = t * 8; o < len + 8; o += 24) { const uint64_t w = zk_ld64(g + o); memcpy(&s_bits[slot][o], &w, 8); }
-                bits = s_bits[slot];
+    if (finisher) {
+        // ---- the records: lane (quad q, j) = sequence i0 + j of the walker wave's block q
+        const uint32_t nloop = zk_lds_ld<uint32_t>(&s_nloop[w]);        // the walker wave's longest block (wave-uniform)
+        const uint32_t nseq = valid ? b.nseq : 0u;
+        ZkSeqCarry cy;
+        zk_seq_carry_init(cy);
+        const uint32_t ring = zk_lds_addr(Tb->ring);
+        ZkSeqP *out = seqs + (valid ? b.seq_base : 0);
+        for (uint32_t i0 = 0; i0 < nloop; i0 += ZK_QUAD_ROUND) {
+            const uint32_t need = i0 + ZK_QUAD_ROUND < nloop ? i0 + ZK_QUAD_ROUND : nloop;
+            for (;;) {                                                   // (wave-uniform: one counter, read by every lane alike)
+                const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane(zk_lds_ld<uint32_t>(&s_prod[w]));
+                if (p >= need) break;                                    // ZK_QUAD_DONE included
+                __builtin_amdgcn_s_sleep(1);
             }
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = zk_lds_ld_at<u32x4>(ring + ((i0 + t) & (ZK_QUAD_RING - 1)) * 16u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the values are in registers: the walker may have the entries back
+            zk_lds_st<uint32_t>(&s_cons[w], i0 + ZK_QUAD_ROUND);
+            const uint32_t nvalid = nseq > i0 ? (nseq - i0 < ZK_QUAD_ROUND ? nseq - i0 : ZK_QUAD_ROUND) : 0u;
+            const ZkSeqP rec = zk_seq_finish_quad<ZkQuadDpp>(t, nvalid, v.x, v.y, v.z, cy, b.lit_regen);
+            if (t < nvalid) out[i0 + t] = rec;
         }
-        __builtin_amdgcn_wave_barrier();
+        if (!valid || t != 0) return;
+        for (;;) {                                                       // the walker's verdict is written in front of its DONE
+            if ((uint32_t)zk_lds_ld<uint32_t>(&s_prod[w]) == ZK_QUAD_DONE) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        zk_seq_finish_block(b, cy, zk_lds_ld<uint32_t>(&s_wbad[slot]));
+        ZkBlock *o = &blocks[bi];
+        o->out_size = b.out_size;
+        o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
+        o->status = b.status;
+        return;
+    }
+    // ---- the walker wave.  The three lanes build the block's tables together (identical LDS writes: more active lanes, see above)
+    uint32_t wbad = 0;
+    if (valid) {
+        uint32_t al[3], own = 0;
+        bool ok = true;
+        for (int u = 0; u < 3; u++) {
+            const uint32_t m = (b.seq_modes >> (6 - 2 * u)) & 3;
+            const ZkBlock &def = m == 3 ? blocks[b.tab_def[u]] : b;
+            const int32_t r = zk_seq_table_setup<CP>(comp, def, u, Tb, &al[u], llv, mlv);
+            if (r < 0) { ok = false; break; }
+            if (m != 3) own += (uint32_t)r;
+        }
+        if (!ok) wbad = 1;
+        else {
+            const uint8_t *bits = nullptr;
+            if (STAGE) {
+                const uint32_t bs = b.seq_off + 1 + own;
+                if (bs < b.bsize && b.bsize - bs <= ZK_FSE_STAGE) {
+                    const uint32_t len = b.bsize - bs;
+                    const uint8_t *g = comp + b.src + bs;
+                    for (uint32_t o = t * 8; o < len + 8; o += 24) { const uint64_t wd = zk_ld64(g + o); memcpy(&s_bits[slot][o], &wd, 8); }
+                    bits = s_bits[slot];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
 #ifndef ZK_QUAD_RD
 #define ZK_QUAD_RD ZkRevU      // one unaligned 8-byte load per step.  (ZkRevA -- aligned words, three ahead, no wait for the step's own load -- is slower here: 12.9 vs 11.4 ms, its bookkeeping costs more than the load's latency)
 #endif
-        zk_seq_walk_quad<ZK_QUAD_RD, CP, ZkQuadDpp>(comp, b, b.seq_off + 1 + own, t,
+            ZkQuadOut qo;
+            qo.ring = zk_lds_addr(Tb->ring) + 4u * t;
+            qo.prod = &s_prod[w]; qo.cons = &s_cons[w]; qo.pos_pub = &s_pos[slot]; qo.lead = t == ZK_TAB_LL;
+            wbad = zk_seq_walk_quad<ZK_QUAD_RD, CP, ZkQuadDpp>(comp, b, b.seq_off + 1 + own, t,
                                      t == ZK_TAB_LL ? Tb->ll : t == ZK_TAB_OF ? Tb->of : Tb->ml,
-                                     t == ZK_TAB_LL ? llv : t == ZK_TAB_OF ? ofv : mlv, al, Tb->ring, seqs + b.seq_base, &s_pos[slot], bits);
+                                     t == ZK_TAB_LL ? llv : t == ZK_TAB_OF ? ofv : mlv, al, qo, bits);
+        }
+        if (t == ZK_TAB_LL) { zk_lds_st<uint32_t>(&s_wbad[slot], wbad); atomicSub(&s_live, 1u); }
     }
-    if (t != ZK_TAB_LL) return;
-    atomicSub(&s_live, 1u);
-    ZkBlock *o = &blocks[bi];
-    o->out_size = b.out_size;
-    o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
-    o->status = b.status;
+    // every lane of the wave is back here (the blocks' loops have different lengths): the ring holds every sequence.  The ballot is
+    // a convergent operation: the store that depends on it cannot be moved into one of the paths above (lanes without a block
+    // would otherwise be free to publish DONE while their neighbours still walk)
+    if (__ballot(1) != 0) zk_lds_st<uint32_t>(&s_prod[w], ZK_QUAD_DONE);
 }
 template <typename CP, int ZK_FSE_BLOCKS, int ZK_FSE_WAVES>
-__global__ __launch_bounds__(64 * (ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeqP *seqs, uint32_t all_blocks)
+__global__ __launch_bounds__(64 * (2 * ZK_FSE_WAVES + 1)) void zk_k_fse_quad(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeqP *seqs, uint32_t all_blocks)
 {
     zk_fse_quad_group<CP, ZK_FSE_BLOCKS, ZK_FSE_WAVES>(blockIdx.x, comp, blocks, nblocks, seqs, all_blocks);
 }
@@ -1150,13 +1224,13 @@ __global__ __launch_bounds__(256) void zk_k_small_walk(const uint8_t *h_comp, ui
 }
 
 // Huffman groups (role 0) and sequence groups (role 1) of a small batch in one launch; the number of blocks comes from HBM.
-__global__ __launch_bounds__(128) void zk_k_small_entropy(const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeqP *seqs)
+__global__ __launch_bounds__(192) void zk_k_small_entropy(const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeqP *seqs)
 {
     const uint32_t nblocks = (uint32_t)words[0];
     const uint32_t role = blockIdx.x & 1, stride = gridDim.x >> 1;
     for (uint32_t g = blockIdx.x >> 1; g * 16 < nblocks; g += stride) {
         if (role == 0) zk_huf_group(g, comp, blocks, nblocks, lit);
-        else zk_fse_quad_group<ZkCells16, 16, 1, true>(g, comp, blocks, nblocks, seqs, 1u);
+        else zk_fse_quad_group<ZkCellsX16, 16, 1, true>(g, comp, blocks, nblocks, seqs, 1u);
         __syncthreads();                                     // the group's LDS state is re-initialised by the next one
     }
 }
@@ -1167,10 +1241,10 @@ __global__ __launch_bounds__(128) void zk_k_small_huf(const uint8_t *comp, ZkBlo
     const uint32_t nblocks = (uint32_t)words[0];
     for (uint32_t g = blockIdx.x; g * 16 < nblocks; g += gridDim.x) { zk_huf_group(g, comp, blocks, nblocks, lit); __syncthreads(); }
 }
-__global__ __launch_bounds__(128) void zk_k_small_fse(const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, ZkSeqP *seqs)
+__global__ __launch_bounds__(192) void zk_k_small_fse(const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, ZkSeqP *seqs)
 {
     const uint32_t nblocks = (uint32_t)words[0];
-    for (uint32_t g = blockIdx.x; g * 16 < nblocks; g += gridDim.x) { zk_fse_quad_group<ZkCells16, 16, 1, true>(g, comp, blocks, nblocks, seqs, 1u); __syncthreads(); }
+    for (uint32_t g = blockIdx.x; g * 16 < nblocks; g += gridDim.x) { zk_fse_quad_group<ZkCellsX16, 16, 1, true>(g, comp, blocks, nblocks, seqs, 1u); __syncthreads(); }
 }
 
 // One workgroup per frame: the download.  h_out may be null (the caller wants the bytes in HBM only).
@@ -1236,7 +1310,7 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     // a small batch (a seek, a handful of frames) is all chain latency: every block, predefined tables or not, takes a
     // quad of lanes (each block builds its own copy of the tables: microseconds)
     if (own_kernel == 0 && k.fse_shared == 0 && nblocks <= 16u * 256u) {
-        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 16, 1>), dim3((nblocks + 15) / 16), dim3(128), 0, st, comp, blocks, nblocks, seqs, 1u);
+        hipLaunchKernelGGL((zk_k_fse_quad<ZkCellsX16, 16, 1>), dim3((nblocks + 15) / 16), dim3(192), 0, st, comp, blocks, nblocks, seqs, 1u);
         return;
     }
     // blocks that share their tables with their neighbours (predefined, or one set per frame): one lane each
@@ -1257,9 +1331,9 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     // DEFINING blocks: an archive of this engine's encoder has one per frame, its blocks were all shared, and the pass that
     // finds nothing left must not wait for a whole CU's LDS -- the small layout fits beside whatever else is resident)
     if (own_kernel != 2 && n_own_tables <= 48u * 256u)
-        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 16, 1>), dim3((nblocks + 15) / 16), dim3(128), 0, st, comp, blocks, nblocks, seqs, 1u);
+        hipLaunchKernelGGL((zk_k_fse_quad<ZkCellsX16, 16, 1>), dim3((nblocks + 15) / 16), dim3(192), 0, st, comp, blocks, nblocks, seqs, 1u);
     else
-        hipLaunchKernelGGL((zk_k_fse_quad<ZkCells16, 56, 4>), dim3((nblocks + 55) / 56), dim3(320), 0, st, comp, blocks, nblocks, seqs, 1u);
+        hipLaunchKernelGGL((zk_k_fse_quad<ZkCellsX16, 56, 4>), dim3((nblocks + 55) / 56), dim3(576), 0, st, comp, blocks, nblocks, seqs, 1u);
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeqP *seqs,
@@ -1302,10 +1376,10 @@ void zk_launch_small_entropy(hipStream_t st, const uint8_t *comp, ZkBlock *block
 {
     if (split) {                                             // (diagnosis: the two roles show separately in a kernel trace)
         hipLaunchKernelGGL(zk_k_small_huf, dim3(groups), dim3(128), 0, st, comp, blocks, words, lit);
-        hipLaunchKernelGGL(zk_k_small_fse, dim3(groups), dim3(128), 0, st, comp, blocks, words, seqs);
+        hipLaunchKernelGGL(zk_k_small_fse, dim3(groups), dim3(192), 0, st, comp, blocks, words, seqs);
         return;
     }
-    hipLaunchKernelGGL(zk_k_small_entropy, dim3(2 * groups), dim3(128), 0, st, comp, blocks, words, lit, seqs);
+    hipLaunchKernelGGL(zk_k_small_entropy, dim3(2 * groups), dim3(192), 0, st, comp, blocks, words, lit, seqs);
 }
 void zk_launch_small_publish(hipStream_t st, const ZkFrameInfo *infos, const uint64_t *d_offs, uint32_t count, const uint8_t *dst, uint8_t *h_out,
                              int32_t *d_status, int32_t *h_status, uint64_t *words, uint32_t *h_flag, uint32_t gen)

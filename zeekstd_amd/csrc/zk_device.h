@@ -36,6 +36,16 @@
 #endif
 template <typename T> ZK_HD T zk_lds_ld(const volatile void *p) { return *(const volatile ZK_LDS_AS T *)(p); }
 template <typename T> ZK_HD void zk_lds_st(volatile void *p, T v) { *(volatile ZK_LDS_AS T *)(p) = v; }
+// the same by LDS byte address (a 32-bit integer: no generic pointer, no null check of a generic -> LDS cast in front of the access)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_AS)
+ZK_HD uint32_t zk_lds_addr(const volatile void *p) { return (uint32_t)(uintptr_t)(const volatile ZK_LDS_AS uint8_t *)(p); }
+template <typename T> ZK_HD T zk_lds_ld_at(uint32_t a) { return *(const volatile ZK_LDS_AS T *)(a); }
+template <typename T> ZK_HD void zk_lds_st_at(uint32_t a, T v) { *(volatile ZK_LDS_AS T *)(a) = v; }
+#else                                                           // (the host pass of hipcc only parses these)
+ZK_HD uint32_t zk_lds_addr(const volatile void *p) { return (uint32_t)(uintptr_t)p; }
+template <typename T> ZK_HD T zk_lds_ld_at(uint32_t a) { return *(const volatile T *)(uintptr_t)(a); }
+template <typename T> ZK_HD void zk_lds_st_at(uint32_t a, T v) { *(volatile T *)(uintptr_t)(a) = v; }
+#endif
 // a store through a pointer that was itself read from memory (a struct in LDS): the compiler cannot tell where it points and would
 // issue a FLAT store; this says "global"
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_AS)
@@ -243,10 +253,10 @@ ZK_HD uint32_t zk_cell_base(uint32_t c) { return c >> 17; }
 //              the symbol itself (OF).
 struct ZkCells32 {
     typedef uint32_t cell_t;
-    static ZK_HDM cell_t make(uint32_t sym, uint32_t nb, uint32_t xbits, uint32_t base) { return zk_cell(sym, nb, xbits, base); }
+    static ZK_HDM cell_t make(uint32_t sym, uint32_t nb, uint32_t xbits, uint32_t base, uint32_t = 0) { return zk_cell(sym, nb, xbits, base); }
     static ZK_HDM uint32_t sym(cell_t c) { return zk_cell_sym(c); }
-    static ZK_HDM uint32_t nb(cell_t c) { return zk_cell_nb(c); }
-    static ZK_HDM uint32_t base(cell_t c) { return zk_cell_base(c); }
+    static ZK_HDM uint32_t nb(cell_t c, uint32_t = 0) { return zk_cell_nb(c); }
+    static ZK_HDM uint32_t base(cell_t c, uint32_t = 0, uint32_t = 0) { return zk_cell_base(c); }
     static ZK_HDM uint32_t xbits(cell_t c, const uint32_t *) { return zk_cell_xbits(c); }
     static ZK_HDM uint32_t baseline(cell_t c, const uint32_t *value_table) { return value_table[zk_cell_sym(c)] & 0xFFFFFFu; }
     static ZK_HDM cell_t tmp_sym(uint32_t s) { return s; }
@@ -256,10 +266,10 @@ struct ZkCells32 {
 struct ZkCell64 { uint32_t c, v; };              // the 32-bit cell + the symbol's value baseline
 struct ZkCells64 {                               // for tables shared by a workgroup (zk_k_fse_predef*): LDS is no constraint
     typedef ZkCell64 cell_t;                     // there, and the baseline in the cell saves two dependent LDS reads per sequence
-    static ZK_HDM cell_t make(uint32_t sym, uint32_t nb, uint32_t xbits, uint32_t base) { cell_t r; r.c = zk_cell(sym, nb, xbits, base); r.v = 0; return r; }
+    static ZK_HDM cell_t make(uint32_t sym, uint32_t nb, uint32_t xbits, uint32_t base, uint32_t = 0) { cell_t r; r.c = zk_cell(sym, nb, xbits, base); r.v = 0; return r; }
     static ZK_HDM uint32_t sym(cell_t c) { return zk_cell_sym(c.c); }
-    static ZK_HDM uint32_t nb(cell_t c) { return zk_cell_nb(c.c); }
-    static ZK_HDM uint32_t base(cell_t c) { return zk_cell_base(c.c); }
+    static ZK_HDM uint32_t nb(cell_t c, uint32_t = 0) { return zk_cell_nb(c.c); }
+    static ZK_HDM uint32_t base(cell_t c, uint32_t = 0, uint32_t = 0) { return zk_cell_base(c.c); }
     static ZK_HDM uint32_t xbits(cell_t c, const uint32_t *) { return zk_cell_xbits(c.c); }
     static ZK_HDM uint32_t baseline(cell_t c, const uint32_t *) { return c.v; }
     static ZK_HDM cell_t tmp_sym(uint32_t s) { cell_t r; r.c = s; r.v = 0; return r; }
@@ -268,11 +278,29 @@ struct ZkCells64 {                               // for tables shared by a workg
 };
 struct ZkCells16 {
     typedef uint16_t cell_t;
-    static ZK_HDM cell_t make(uint32_t sym, uint32_t nb, uint32_t, uint32_t base)
+    static ZK_HDM cell_t make(uint32_t sym, uint32_t nb, uint32_t, uint32_t base, uint32_t = 0)
     { return (cell_t)((sym << 10) | (nb ? base + (1u << (nb - 1)) : 512u + base)); }
     static ZK_HDM uint32_t sym(cell_t c) { return (uint32_t)c >> 10; }
-    static ZK_HDM uint32_t nb(cell_t c) { const uint32_t e = c & 1023u; return e >= 512u ? 0u : (uint32_t)__builtin_ctz(e | 512u) + 1u; }
-    static ZK_HDM uint32_t base(cell_t c) { const uint32_t e = c & 1023u; return e >= 512u ? e - 512u : e & (e - 1u); }
+    static ZK_HDM uint32_t nb(cell_t c, uint32_t = 0) { const uint32_t e = c & 1023u; return e >= 512u ? 0u : (uint32_t)__builtin_ctz(e | 512u) + 1u; }
+    static ZK_HDM uint32_t base(cell_t c, uint32_t = 0, uint32_t = 0) { const uint32_t e = c & 1023u; return e >= 512u ? e - 512u : e & (e - 1u); }
+    static ZK_HDM uint32_t xbits(cell_t c, const uint32_t *value_table) { const uint32_t s = (uint32_t)c >> 10; return value_table ? value_table[s] >> 24 : s; }
+    static ZK_HDM uint32_t baseline(cell_t c, const uint32_t *value_table) { return value_table[(uint32_t)c >> 10] & 0xFFFFFFu; }
+    static ZK_HDM cell_t tmp_sym(uint32_t s) { return (cell_t)s; }
+    static ZK_HDM uint32_t tmp_get(cell_t c) { return c; }
+    static ZK_HDM cell_t with_value(cell_t c, const uint32_t *, uint32_t) { return c; }
+};
+
+// ZkCellsX16: 16 bits again, for the chain walkers (zk_seq_walk_quad), where what counts is the number of DEPENDENT instructions
+// between one cell read and the next: sym[15:10] | x[9:0] with x = the cell's position in its symbol's run, count <= x < 2 count
+// (what the table build calls next[s]++).  With the table's accuracy log at hand -- a lane constant of the walker --
+// nb = al - highbit(x) and base = (x << nb) - 2^al: a count-leading-zeros, a shift and two subtractions, where ZkCells16's folded
+// field takes eleven instructions to take apart.
+struct ZkCellsX16 {
+    typedef uint16_t cell_t;
+    static ZK_HDM cell_t make(uint32_t sym, uint32_t, uint32_t, uint32_t, uint32_t x) { return (cell_t)((sym << 10) | x); }
+    static ZK_HDM uint32_t sym(cell_t c) { return (uint32_t)c >> 10; }
+    static ZK_HDM uint32_t nb(cell_t c, uint32_t al) { return al + (uint32_t)__builtin_clz((uint32_t)c & 1023u) - 31u; }
+    static ZK_HDM uint32_t base(cell_t c, uint32_t al, uint32_t nb) { return (((uint32_t)c & 1023u) << nb) - (1u << al); }
     static ZK_HDM uint32_t xbits(cell_t c, const uint32_t *value_table) { const uint32_t s = (uint32_t)c >> 10; return value_table ? value_table[s] >> 24 : s; }
     static ZK_HDM uint32_t baseline(cell_t c, const uint32_t *value_table) { return value_table[(uint32_t)c >> 10] & 0xFFFFFFu; }
     static ZK_HDM cell_t tmp_sym(uint32_t s) { return (cell_t)s; }
@@ -373,7 +401,7 @@ ZK_HD bool zk_fse_build(typename CP::cell_t *cells, const int16_t *norm, uint32_
         uint32_t x = next[s]++;
         uint32_t nb = al - zk_highbit(x);
         uint32_t xb = value_table ? (value_table[s] >> 24) : s;
-        cells[i] = CP::with_value(CP::make(s, nb, xb & 31u, (x << nb) - size), value_table, s);
+        cells[i] = CP::with_value(CP::make(s, nb, xb & 31u, (x << nb) - size, x), value_table, s);
     }
     return true;
 }
@@ -760,6 +788,7 @@ struct ZkSeqTablesT {                // LDS-resident, per lane
 };
 typedef ZkSeqTablesT<ZkCells32> ZkSeqTables;       // 5.25 KiB
 typedef ZkSeqTablesT<ZkCells16> ZkSeqTables16;     // 2.75 KiB
+typedef ZkSeqTablesT<ZkCellsX16> ZkSeqTablesX16;   // the same size
 
 // Locate + build table t of block `def` (the block whose header defines the table in force).
 // comp: compressed buffer.  Returns bytes the description occupies in `def` (for own-block parsing), or -1.
@@ -801,7 +830,7 @@ ZK_HD int32_t zk_seq_table_setup(const uint8_t *comp, const ZkBlock &def, int t,
         if (p >= def.bsize) return -1;
         uint32_t s = c[p];
         if (s > zk_tab_maxsym(t)) return -1;
-        cells[0] = CP::with_value(CP::make(s, 0, (vt ? (vt[s] >> 24) : s) & 31u, 0), vt, s);
+        cells[0] = CP::with_value(CP::make(s, 0, (vt ? (vt[s] >> 24) : s) & 31u, 0, 1), vt, s);       // accuracy log 0: x = 1
         *al_out = 0;
         return 1;
     }
@@ -1114,29 +1143,36 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
 
 
 // ---------------------------------------------------------------- sequence section decode (a quad of lanes per block)
-// One lane per FSE state machine of a block; XCH::bcast(v, k) returns the value v of the quad's lane k (DPP quad_perm on
-// the device -- zk_decode.hip, zk_k_fse_quad; lock-stepped fibers in tests/sim).  All lanes of a quad run this function
-// with the same block and meet in every bcast.
+// A block's sequences are ONE serial chain -- state -> cell -> bit counts -> state bits -> next state -- and a lone wave issues
+// in order: every instruction of the step is on the chain's clock whether it depends on it or not.  The work is therefore cut
+// in two (round 4; one function did both before, ~110 instructions per step):
+//   zk_seq_walk_quad    the chain.  One lane per FSE state machine of a block (XCH::bcast = a DPP quad_perm move on the device,
+//                       lock-stepped fibers in tests/sim); lane t leaves the VALUE of its field of every sequence -- literal
+//                       length, offset value, match length -- with OUT::put and nothing else: no repeat-offset history, no
+//                       running sums, no record.
+//   zk_seq_finish_quad  everything else, by another wave, four sequences of a block at a time (lane j of a quad = sequence
+//                       i0 + j): repeat offsets, the running sums, the 8-byte records.  Off the chain and amortised.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ZK_WAVE_BARRIER() __builtin_amdgcn_wave_barrier()
 #else
 #define ZK_WAVE_BARRIER() ((void)0)
 #endif
+constexpr uint32_t ZK_QUAD_ROUND = 4;            // sequences of a block that zk_seq_finish_quad takes at a time (= lanes of a quad)
 // t = the lane's table (ZK_TAB_LL / ZK_TAB_OF / ZK_TAB_ML = its position in the quad); cells / vt: that table's cells
 // and value table (offsets: entries k << 24, the baseline 1 << k is formed here); al[3]: accuracy logs (LL, OF, ML).
-// All three lanes return the same b (out_size, rep_out, status); lane ZK_TAB_LL owns the ring.
+// out.gate(i) is called by all three lanes in front of every sequence i that is a multiple of ZK_QUAD_ROUND (flow control of
+// the hand-over, the toucher's stream position), out.put(i, v) once per sequence and lane.  Returns 0, or 1 for a damaged
+// stream (over-read, bits left over) -- all three lanes return the same.
 // bits: where the lane reads the bitstream from -- nullptr = in place (comp + b.src + bs_off), or a staged copy of its
-// b.bsize - bs_off bytes (LDS, readable 8 bytes past the end): the walk's one memory access per step then costs an LDS
-// round trip instead of an L2 one (small batches, where a block's chain is all that counts).
-template <typename RD, typename CP, typename XCH>
-ZK_HD void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, uint32_t t,
-                                                 const typename CP::cell_t *cells, const uint32_t *vt, const uint32_t *al,
-                                                 ZkSeqP *ring, ZkSeqP *seqs, volatile uint32_t *pos_pub, const uint8_t *bits = nullptr)
+// b.bsize - bs_off bytes (LDS, readable 8 bytes past the end).
+template <typename RD, typename CP, typename XCH, typename OUT>
+ZK_HD uint32_t zk_seq_walk_quad(const uint8_t *comp, const ZkBlock &b, uint32_t bs_off, uint32_t t,
+                                const typename CP::cell_t *cells, const uint32_t *vt, const uint32_t *al, OUT &out, const uint8_t *bits = nullptr)
 {
     RD r;
     uint32_t bad = 0;
     const bool ok = bs_off < b.bsize && r.init(bits ? bits : comp + b.src + bs_off, b.bsize - bs_off);
-    if (!ok) { b.status = ZK_E_CORRUPTION; return; }
+    if (!ok) return 1;
     const uint32_t nseq = b.nseq;
     uint32_t state;
     {
@@ -1149,78 +1185,95 @@ ZK_HD void zk_seq_walk_quad(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, ui
     const uint32_t kMlV = t == ZK_TAB_LL ? 0xFFu : 0u;              // ML value bits precede LL's
     const uint32_t kLlS = t == ZK_TAB_LL ? 0u : 0xFFu;              // LL state bits precede ML's and OF's
     const uint32_t kMlS = t == ZK_TAB_OF ? 0xFFu : 0u;              // ML state bits precede OF's
-    uint32_t rep0 = zk_rep_sym(0), rep1 = zk_rep_sym(1), rep2 = zk_rep_sym(2);
-    uint32_t out = 0, lit = 0;
-    ZkSeqP qp = 0;
+    // the number of a symbol's extra bits without a table in the way of the chain (the value table's entry is still read, for the
+    // baseline, but nothing waits for it): 0 below code T1, a nibble of LUT up to T2, code - D from there; offsets: the code itself
+    const uint32_t al_t = al[t];
+    const uint32_t xT1 = t == ZK_TAB_LL ? 16u : t == ZK_TAB_ML ? 32u : 0u, xT2 = t == ZK_TAB_OF ? 0u : xT1 + 16u, xD = t == ZK_TAB_LL ? 19u : t == ZK_TAB_ML ? 36u : 0u;
+    const uint64_t xLUT = t == ZK_TAB_LL ? 0xCBA9876433221111ull : 0xBA98754433221111ull;       // codes 16..31 (LL) / 32..47 (ML), low nibble first
     typename CP::cell_t c = cells[state];
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" :: "v"((uint32_t)c));                      // arrived before the loop: its waits then only count what the loop issues
 #endif
-    for (uint32_t g0 = 0; g0 < nseq; g0 += 16) {
-        const uint32_t gend = g0 + 16 < nseq ? g0 + 16 : nseq;
-        if (t == ZK_TAB_LL) zk_lds_st<uint32_t>(pos_pub, b.src + bs_off + (uint32_t)(r.remaining() >> 3));       // for the toucher wave (zk_k_fse_quad)
-        for (uint32_t i = g0; i < gend; i++) {
-            const uint32_t vv = vt[CP::sym(c)];
-            // the previous step's record goes to the ring now, behind this step's first LDS read (all three lanes, same
-            // bytes, unconditional; the very first write of a group repeats a record that is already there): at the end
-            // of its own step it would sit between the cell read and the next step's wait for it
-            ring[(i - 1) & 15] = qp;
-            const uint32_t xb = vv >> 24;
-            const uint32_t nb = i + 1 < nseq ? CP::nb(c) : 0;
-            const uint32_t pk = xb | (nb << 8);
-            const uint32_t pL = XCH::bcast(pk, ZK_TAB_LL), pO = XCH::bcast(pk, ZK_TAB_OF), pM = XCH::bcast(pk, ZK_TAB_ML);
-            const uint32_t sum = pL + pO + pM;                      // value bits in the low byte (<= 63), state bits above (<= 27)
-            const uint32_t nval = sum & 0xFF, total = nval + (sum >> 8);
-            const uint32_t voff = (pO & kOfV) + (pM & kMlV);
-            const uint32_t soff = nval + ((pL >> 8) & kLlS) + ((pM >> 8) & kMlS);
-            bad |= (pO & 0xFF) > 30;
-            uint32_t vbits, sbits;
-            if (total <= r.avail()) {
-                const uint64_t X = r.window();
-                r.consume(total);
-                sbits = zk_top_bits((uint32_t)((X << (soff & 63)) >> 32), nb);
-                vbits = zk_top_bits((uint32_t)((X << (voff & 63)) >> 32), xb & 31);
-            } else {                                                // more bits than one window guarantees: field by field
-                const uint32_t ofx = r.read(pO & 31), mlx = r.read(pM & 0xFF), llx = r.read(pL & 0xFF);
-                const uint32_t sL = r.read(pL >> 8), sM = r.read(pM >> 8), sO = r.read(pO >> 8);
-                bad |= r.remaining() < 0;
-                r.clamp();
-                vbits = t == ZK_TAB_LL ? llx : t == ZK_TAB_OF ? ofx : mlx;
-                sbits = t == ZK_TAB_LL ? sL : t == ZK_TAB_OF ? sO : sM;
-            }
-            state = CP::base(c) + sbits;
-            c = cells[state];                                       // issued early; used by the next step
-            const uint32_t val = (t == ZK_TAB_OF ? 1u << (xb & 31) : vv & 0xFFFFFFu) + vbits;
-            const uint32_t ll = XCH::bcast(val, ZK_TAB_LL), ofv = XCH::bcast(val, ZK_TAB_OF), ml = XCH::bcast(val, ZK_TAB_ML);
-            // offset + repeat history, select form (A.8) -- as zk_seq_walk
-            const bool is_rep = ofv <= 3;
-            const uint32_t idx = ofv - 1 + (ll == 0);
-            const uint32_t r0m1 = zk_rep_is_sym(rep0) ? rep0 + 1 : rep0 - 1;
-            uint32_t cand = idx == 0 ? rep0 : rep1;                 // plain selects: no control flow in the step
-            cand = idx == 2 ? rep2 : cand;
-            cand = idx == 3 ? r0m1 : cand;
-            const uint32_t off = is_rep ? cand : ofv - 3;
-            bad |= off == 0;
-            const bool sh1 = (!is_rep) | (idx >= 1), sh2 = (!is_rep) | (idx >= 2);
-            rep2 = sh2 ? rep1 : rep2;
-            rep1 = sh1 ? rep0 : rep1;
-            rep0 = off;
-            lit += ll; out += ll + ml;
-            bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX) | (!zk_rep_is_sym(off) & (off > ZK_OFF_MAX));
-            qp = zk_seq_pack(out, lit, off);
+    for (uint32_t i = 0; i < nseq; i++) {
+        if ((i & (ZK_QUAD_ROUND - 1)) == 0) out.gate(i, b.src + bs_off + (uint32_t)(r.remaining() >> 3));
+        const uint32_t sy = CP::sym(c);
+        const uint32_t vv = vt[sy];
+        const uint32_t xb_mid = (uint32_t)(xLUT >> ((4u * (sy - xT1)) & 63u)) & 15u;
+        const uint32_t xb = sy < xT1 ? 0u : sy < xT2 ? xb_mid : sy - xD;
+        const uint32_t nbc = CP::nb(c, al_t);
+        const uint32_t nb = i + 1 < nseq ? nbc : 0;
+        const uint32_t pk = xb | (nb << 8);
+        const uint32_t pL = XCH::bcast(pk, ZK_TAB_LL), pO = XCH::bcast(pk, ZK_TAB_OF), pM = XCH::bcast(pk, ZK_TAB_ML);
+        const uint32_t sum = pL + pO + pM;                      // value bits in the low byte (<= 63), state bits above (<= 27)
+        const uint32_t nval = sum & 0xFF, total = nval + (sum >> 8);
+        const uint32_t voff = (pO & kOfV) + (pM & kMlV);
+        const uint32_t soff = nval + ((pL >> 8) & kLlS) + ((pM >> 8) & kMlS);
+        uint32_t vbits, sbits;                                  // (an offset code above 30 makes an offset value >= 2^31: zk_seq_finish_quad rejects it)
+        if (total <= r.avail()) {
+            const uint64_t X = r.window();
+            r.consume(total);
+            sbits = zk_top_bits((uint32_t)((X << (soff & 63)) >> 32), nb);
+            vbits = zk_top_bits((uint32_t)((X << (voff & 63)) >> 32), xb & 31);
+        } else {                                                // more bits than one window guarantees: field by field
+            const uint32_t ofx = r.read(pO & 31), mlx = r.read(pM & 0xFF), llx = r.read(pL & 0xFF);
+            const uint32_t sL = r.read(pL >> 8), sM = r.read(pM >> 8), sO = r.read(pO >> 8);
+            bad |= r.remaining() < 0;
+            r.clamp();
+            vbits = t == ZK_TAB_LL ? llx : t == ZK_TAB_OF ? ofx : mlx;
+            sbits = t == ZK_TAB_LL ? sL : t == ZK_TAB_OF ? sO : sM;
         }
-        ring[(gend - 1) & 15] = qp;
-        ZK_WAVE_BARRIER();
-        // the quad's three lanes share the stores of the group's records
-        for (uint32_t k = g0 + t; k < gend; k += 3) seqs[k] = zk_lds_ld<ZkSeqP>(&ring[k & 15]);
-        ZK_WAVE_BARRIER();
+        state = CP::base(c, al_t, nbc) + sbits;
+        c = cells[state];                                       // issued early; used by the next step
+        out.put(i, (t == ZK_TAB_OF ? 1u << (xb & 31) : vv & 0xFFFFFFu) + vbits);
     }
     bad |= r.remaining() != 0;
-    if (bad) { b.status = ZK_E_CORRUPTION; return; }
-    out += b.lit_regen - lit;
+    return bad ? 1u : 0u;
+}
+
+// What zk_seq_finish_quad carries from round to round (the same in all four lanes of a quad).
+struct ZkSeqCarry { uint32_t rep0, rep1, rep2, lit, out, bad; };
+ZK_HD void zk_seq_carry_init(ZkSeqCarry &c) { c.rep0 = zk_rep_sym(0); c.rep1 = zk_rep_sym(1); c.rep2 = zk_rep_sym(2); c.lit = 0; c.out = 0; c.bad = 0; }
+// One round: lane j (0..3) of the quad brings the three values of sequence i0 + j (anything when j >= nvalid); nvalid (0..4) is
+// the number of sequences of this round that exist, the same in all four lanes.  All four lanes run the block's recurrence over
+// the round's sequences together -- the values come round by XCH::bcast -- and lane k keeps what belongs to ITS sequence: the
+// record (returned; meaningless when j >= nvalid).  Offsets and the repeat history follow A.8 in select form, as zk_seq_walk.
+template <typename XCH>
+ZK_HD ZkSeqP zk_seq_finish_quad(uint32_t j, uint32_t nvalid, uint32_t ll, uint32_t ofv, uint32_t ml, ZkSeqCarry &c, uint32_t lit_regen)
+{
+    uint32_t my_out = 1, my_lit = 0, my_off = 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 0; k < ZK_QUAD_ROUND; k++) {
+        const uint32_t llk = XCH::bcast(ll, (int)k), ofk = XCH::bcast(ofv, (int)k), mlk = XCH::bcast(ml, (int)k);
+        const bool live = k < nvalid;
+        const bool is_rep = ofk <= 3;
+        const uint32_t idx = ofk - 1 + (llk == 0);
+        const uint32_t r0m1 = zk_rep_is_sym(c.rep0) ? c.rep0 + 1 : c.rep0 - 1;
+        uint32_t cand = idx == 0 ? c.rep0 : c.rep1;                 // plain selects: no control flow in the step
+        cand = idx == 2 ? c.rep2 : cand;
+        cand = idx == 3 ? r0m1 : cand;
+        const uint32_t off = is_rep ? cand : ofk - 3;
+        const bool sh1 = ((!is_rep) | (idx >= 1)) & live, sh2 = ((!is_rep) | (idx >= 2)) & live;
+        c.rep2 = sh2 ? c.rep1 : c.rep2;
+        c.rep1 = sh1 ? c.rep0 : c.rep1;
+        c.rep0 = live ? off : c.rep0;
+        c.lit += live ? llk : 0u;
+        c.out += live ? llk + mlk : 0u;
+        c.bad |= live & ((off == 0) | (c.lit > lit_regen) | (c.out > ZK_BLOCK_MAX) | (!zk_rep_is_sym(off) & (off > ZK_OFF_MAX)) | (ofk > 0x7FFFFFFFu));     // ofk >= 2^31: an offset code above 30
+        const bool mine = j == k;
+        my_out = mine ? c.out : my_out; my_lit = mine ? c.lit : my_lit; my_off = mine ? off : my_off;
+    }
+    return zk_seq_pack(my_out, my_lit, my_off);
+}
+// The block's verdict once every sequence went through zk_seq_finish_quad (walk_bad: what zk_seq_walk_quad returned).
+ZK_HD void zk_seq_finish_block(ZkBlock &b, const ZkSeqCarry &c, uint32_t walk_bad)
+{
+    if (walk_bad | c.bad) { b.status = ZK_E_CORRUPTION; return; }
+    const uint32_t out = c.out + (b.lit_regen - c.lit);
     if (out > ZK_BLOCK_MAX) { b.status = ZK_E_CORRUPTION; return; }
     b.out_size = out;
-    b.rep_out[0] = rep0; b.rep_out[1] = rep1; b.rep_out[2] = rep2;
+    b.rep_out[0] = c.rep0; b.rep_out[1] = c.rep1; b.rep_out[2] = c.rep2;
 }
 
 // ---------------------------------------------------------------- sequence execution: per-byte source map
