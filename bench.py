@@ -49,10 +49,21 @@ def _make_part(job):
     return comp, frames, hashes
 
 
-def build_inputs(k0, nframes, level, cks, workers, want_archive, tag):
-    """Returns (data as a uint8 array in an anonymous shared mapping, libzstd payload, frames, per-frame XXH64)."""
+def build_inputs(k0, nframes, level, cks, workers, want_archive, tag, cache=None):
+    """Returns (data as a uint8 array in an anonymous shared mapping, libzstd payload, frames, per-frame XXH64).
+    cache: a directory that keeps them between runs of the same configuration (profiling passes: the generator and the CPU
+    compression of 4 GiB otherwise run once per counter pass)."""
     global _SHM
     import mmap
+    key = None
+    if cache:
+        os.makedirs(cache, exist_ok=True)
+        key = os.path.join(cache, f"in_{k0}_{nframes}_{level}_{int(cks)}_{int(want_archive)}")
+        if os.path.exists(key + ".ok"):
+            data = np.fromfile(key + ".data", np.uint8)
+            comp = open(key + ".comp", "rb").read()
+            meta = np.load(key + ".npz")
+            return data, comp, [tuple(int(x) for x in f) for f in meta["frames"]], [int(h) for h in meta["hashes"]]
     _map = mmap.mmap(-1, max(1, nframes * FRAME))      # MAP_SHARED | MAP_ANONYMOUS: the forked workers fill it; no tmpfs quota involved
     _SHM = np.frombuffer(_map, dtype=np.uint8)
     per = max(1, min(16, nframes // max(1, workers)))
@@ -65,6 +76,11 @@ def build_inputs(k0, nframes, level, cks, workers, want_archive, tag):
     comp = b"".join(p[0] for p in parts)
     frames = [f for p in parts for f in p[1]]
     hashes = [h for p in parts for h in p[2]]
+    if key:
+        _SHM.tofile(key + ".data")
+        open(key + ".comp", "wb").write(comp)
+        np.savez(key + ".npz", frames=np.array(frames, np.uint64).reshape(-1, 2), hashes=np.array(hashes, np.uint64))
+        open(key + ".ok", "w").close()
     return _SHM, comp, frames, hashes
 
 
@@ -547,6 +563,11 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: run the launch contract (env, process group over gloo, shard + gather leg, the JSON line) on CPU "
                          "tensors with stored-block stand-in frames; measures nothing")
+    ap.add_argument("--level", type=int, default=1, help="compression level of the archive (1 = BASELINE's configs; 3 = the reference CLI's default: profiling runs with --archive libzstd)")
+    ap.add_argument("--cache", default=None, help="directory that keeps the generated input + the libzstd archive between runs (profiling passes)")
+    ap.add_argument("--choice", action="append", default=[], metavar="KEY=VALUE",
+                    help="pin a kernel variant for the whole run (zk_engine_set_kernel_choice: fse_own, fse_shared, exec_lanes, exec_ring, xxh64, "
+                         "small_path, pipe_contexts, pipe_chunk_mib); A/B runs of tools/, never the driver's line")
     ap.add_argument("--archive", default="auto", choices=["auto", "gpu", "libzstd"],
                     help="who compresses the archive that is decoded: the GPU encoder (default for c3) or CPU libzstd (default for c2)")
     args = ap.parse_args()
@@ -558,7 +579,7 @@ def main():
         args.gpus = world
     nframes = args.frames or (2048 if args.workload == "c3" else 128)
     cks = args.workload == "c3"
-    level = 1
+    level = args.level
     if args.dry_run:
         return dry_run(args, rank, world)
 
@@ -570,7 +591,7 @@ def main():
     # a reference-made archive of the same input is prepared too (single-GPU runs): its decode rate is reported beside the
     # headline, because archives written by zeekstd's own CPU Encoder are what a drop-in user decodes first
     want_ref_archive = (not use_gpu_archive) or (world == 1 and not args.no_ref_archive)
-    data, z_comp, z_frames, hashes = build_inputs(rank * nframes, nframes, level, cks, workers, want_ref_archive, rank)
+    data, z_comp, z_frames, hashes = build_inputs(rank * nframes, nframes, level, cks, workers, want_ref_archive, rank, args.cache)
     do_seek = rank == 0 and world == 1 and not args.no_seek
     z64 = None
     if do_seek and want_ref_archive and z_comp:           # the reference-made 64 KiB-frame archive of configs[3] (forked workers: before HIP)
@@ -589,6 +610,9 @@ def main():
         import datetime
         dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))      # a hung collective ends the run in minutes, not in half an hour
     eng = zk.Engine(local_rank)
+    for kv in args.choice:
+        key, _, val = kv.partition("=")
+        eng.set_kernel_choice(**{key: int(val)})
     dsize = nframes * FRAME
     d_src = torch.from_numpy(np.asarray(data)).to(dev)
 
@@ -827,14 +851,14 @@ def main():
             "one_batch_at_a_time": {"value": round(dsize * args.steps / sync_elapsed / 2**30, 3), "unit": "GiB/s",
                                     "ms_per_step": round(sync_elapsed / args.steps * 1e3, 3),
                                     "note": "same steps through the synchronous zk_decode_frames_dev (rank-local, no overlap between batches)"},
-            "config": {"workload": ("configs[2]: 4 GiB/GPU, 2048 x 2 MiB frames, level 1, XXH64 checksums verified"
-                                    if args.workload == "c3" else "configs[1]: 256 MiB, 128 x 2 MiB frames, level 1, decode-only"),
+            "config": {"workload": (f"configs[2]: 4 GiB/GPU, 2048 x 2 MiB frames, level {level}, XXH64 checksums verified"
+                                    if args.workload == "c3" else f"configs[1]: 256 MiB, 128 x 2 MiB frames, level {level}, decode-only"),
                        "frames_per_gpu": nframes, "frame_size": FRAME, "compressed_bytes_per_gpu": csize,
                        "batches_in_flight": 1 if args.sync else 2,
                        "archive": ("GPU encoder of this engine (zk_encode_frames_dev)" if use_gpu_archive else "CPU libzstd (reference Encoder loop)")
                                   + ", inputs from the SURVEY 8d generator",
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",
-                       "bit_exact": True},
+                       "bit_exact": True, **({"kernel_choice": args.choice} if args.choice else {})},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "step_frac": round(algo_bytes / (sync_elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),

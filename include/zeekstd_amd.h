@@ -86,7 +86,7 @@ enum {
                                    * also switches the small-batch shortcut "every block a quad" off) */
     ZK_CHOICE_EXEC_LANES = 3,     /* zk_k_exec tile: 128 / 256 / 512 / 1024 lanes */
     ZK_CHOICE_EXEC_RING = 4,      /* 256-lane tiles: 1 = a ring of 2 T records, 2 = 4 T */
-    ZK_CHOICE_XXH64 = 5,          /* 1 zk_k_xxh64 (a wave per frame), 2 zk_k_xxh64_wide (sixteen frames per wave) */
+    ZK_CHOICE_XXH64 = 5,          /* 1 zk_k_xxh64 (a wave per frame), 2 zk_k_xxh64_wide (sixteen frames per wave), 3 zk_k_xxh64_lean (the same in 64 registers) */
     ZK_CHOICE_SMALL_PATH = 6,     /* host-pointer decode of <= 64 frames: 1 = through the general pipeline, 2 = the small path with its
                                    * entropy roles as two kernels */
     ZK_CHOICE_PIPE_CONTEXTS = 7,  /* host pipeline: decode contexts it rotates through (1..6; 0 = 2) */

@@ -30,7 +30,7 @@ struct ZkQuadSim {
     ZkSeqCarry carry[4];
 };
 static ZkQuadSim *g_quad;
-static uint32_t g_ofv[32];
+static uint32_t g_ofv[32], g_llb[36], g_mlb[53];      // the walker's baseline tables (zk_fse_quad_group builds the same in LDS)
 static int g_fse_quad = 0;
 extern "C" void zk_sim_set_fse_quad(int on) { g_fse_quad = on; }
 // poison: the tables and scratch a block's lane builds and reads (on the device: LDS that holds whatever the workgroup before left
@@ -57,7 +57,7 @@ struct ZkQuadFibers {
 struct ZkQuadSimOut {                            // OUT of zk_seq_walk_quad: the lane's column of the value array
     ZkQuadSim *q; int t;
     void gate(uint32_t i, uint32_t) { if (i % ZK_QUAD_ROUND != 0) q->gates |= 0x80000000u; q->gates++; }
-    void put(uint32_t i, uint32_t v) { q->vals[(size_t)i * 4 + (size_t)t] = v; }
+    void put(uint32_t i0, uint32_t k, uint32_t v) { if (i0 % ZK_QUAD_ROUND != 0 || k >= ZK_QUAD_ROUND) q->gates |= 0x80000000u; q->vals[(size_t)(i0 + k) * 4 + (size_t)t] = v; }
 };
 
 static const uint32_t LLV[36] = ZK_LL_TABLE;
@@ -72,7 +72,7 @@ static void zk_quad_walk_lane_main()
     ZkQuadSimOut out{q, t};
     q->walk_bad[t] = zk_seq_walk_quad<ZkRevU, ZkCellsX16, ZkQuadFibers>(q->comp, q->b, q->bs_off, (uint32_t)t,
                                                       t == ZK_TAB_LL ? q->T->ll : t == ZK_TAB_OF ? q->T->of : q->T->ml,
-                                                      t == ZK_TAB_LL ? LLV_ : t == ZK_TAB_OF ? g_ofv : MLV_, q->al, out);
+                                                      t == ZK_TAB_LL ? g_llb : t == ZK_TAB_OF ? g_ofv : g_mlb, q->al, out);
     q->done[t] = true;
 }
 static void zk_quad_finish_lane_main()
@@ -116,7 +116,9 @@ static bool zk_quad_walk_sim(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, Z
 {
     ZkQuadSim q;
     g_quad = &q;
-    for (uint32_t k = 0; k < 32; k++) g_ofv[k] = k << 24;
+    for (uint32_t k = 0; k < 32; k++) g_ofv[k] = 1u << k;
+    for (uint32_t k = 0; k < 36; k++) g_llb[k] = LLV_[k] & 0xFFFFFFu;
+    for (uint32_t k = 0; k < 53; k++) g_mlb[k] = MLV_[k] & 0xFFFFFFu;
     q.comp = comp; q.b = b; q.bs_off = bs_off; q.T = T; q.al = al; q.seqs = seqs; q.gates = 0;
     q.vals.assign((size_t)b.nseq * 4 + 4, 0xA5A5A5A5u);
     zk_quad_run(q, 3, zk_quad_walk_lane_main);

@@ -37,7 +37,7 @@ def pinned(request, engine):
 
 def test_unknown_choices_are_refused(engine):
     import zeekstd_amd as zk
-    for key, value in [("exec_lanes", 64), ("fse_shared", 4), ("xxh64", 3), ("exec_ring", -1), ("pipe_contexts", 7)]:
+    for key, value in [("exec_lanes", 64), ("fse_shared", 4), ("xxh64", 4), ("exec_ring", -1), ("pipe_contexts", 7)]:
         with pytest.raises(zk.ZkError):
             engine.set_kernel_choice(**{key: value})
     assert zk.lib.zk_engine_set_kernel_choice(engine._h, 99, 0) != 0

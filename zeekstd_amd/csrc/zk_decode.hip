@@ -344,9 +344,9 @@ struct ZkQuadOut {                                       // OUT of zk_seq_walk_q
         if (i + ZK_QUAD_ROUND > ZK_QUAD_RING)
             while ((uint32_t)__builtin_amdgcn_readfirstlane(zk_lds_ld<uint32_t>(cons)) + ZK_QUAD_RING < i + ZK_QUAD_ROUND) __builtin_amdgcn_s_sleep(1);
     }
-    __device__ __forceinline__ void put(uint32_t i, uint32_t v)
+    __device__ __forceinline__ void put(uint32_t i0, uint32_t k, uint32_t v)     // sequence i0 + k; i0 a multiple of the round, k a constant
     {
-        zk_lds_st_at<uint32_t>(ring + (i & (ZK_QUAD_RING - 1)) * 16u, v);
+        zk_lds_st_at<uint32_t>(ring + (i0 & (ZK_QUAD_RING - ZK_QUAD_ROUND)) * 16u + k * 16u, v);
     }
 };
 
@@ -370,9 +370,9 @@ __device__ __forceinline__ void zk_fse_quad_group(uint32_t group, const uint8_t 
     {
         const uint32_t ll_init[36] = ZK_LL_TABLE;
         const uint32_t ml_init[53] = ZK_ML_TABLE;
-        if (tid < 36) llv[tid] = ll_init[tid];
-        if (tid < 53) mlv[tid] = ml_init[tid];
-        if (tid < 32) ofv[tid] = tid << 24;
+        if (tid < 36) llv[tid] = ll_init[tid] & 0xFFFFFFu;      // baselines only: the walker's cells (sym | x) keep no extra-bit count, and
+        if (tid < 53) mlv[tid] = ml_init[tid] & 0xFFFFFFu;      // the walk forms the counts by arithmetic (zk_seq_walk_quad)
+        if (tid < 32) ofv[tid] = 1u << tid;
         if (tid < (uint32_t)ZK_FSE_BLOCKS) { s_pos[tid] = 0; s_wbad[tid] = 0; }
         if (tid < (uint32_t)ZK_FSE_WAVES) { s_prod[tid] = 0; s_cons[tid] = 0; s_nloop[tid] = 0; }
         if (tid == 0) s_live = 0;
@@ -1147,6 +1147,74 @@ __global__ __launch_bounds__(64) void zk_k_xxh64_wide(const uint8_t *data, const
     if (infos && (uint32_t)h != infos[f].checksum) infos[f].status = ZK_E_CHECKSUM_WRONG;
 }
 
+// The same in 64 registers (12 stripes per batch under waves_per_eu(8); zk_k_xxh64_wide takes 78): what is left on a SIMD beside four
+// executor waves of 112, so that the checksums of one batch can run while the executor of the next batch in flight holds the CUs --
+// with 78 the checksum waves of batch A wait until executor workgroups of batch B retire.  (A template only for this kernel: the
+// same body as a template under zk_k_xxh64_wide made the compiler take 122 registers there.)
+template <int ZK_XXW>
+__device__ __forceinline__ void zk_xxh64_lean_body(const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
+                                                    ZkFrameInfo *infos, uint64_t *hashes)
+{
+    const uint32_t lane = threadIdx.x, f = blockIdx.x * 16 + (lane >> 2), kl = lane & 3;
+    bool live = f < count;
+    if (live && infos && !(infos[f].status == ZK_OK && infos[f].checksum_flag)) live = false;
+    const uint32_t fa = live ? f : 0;                       // (a lane without a frame reads frame 0 and keeps nothing)
+    const uint8_t *p = data + (d_off[first + fa] - d_off[first]);
+    const uint64_t len = d_off[first + fa + 1] - d_off[first + fa];
+    const uint64_t nstripes = live ? len >> 5 : 0;
+    uint64_t acc = kl == 0 ? XP1 + XP2 : kl == 1 ? XP2 : kl == 2 ? 0 : 0 - XP1;
+    // the stripes every live frame of the wave has, in whole double batches: no predicates
+    uint64_t least = live ? nstripes : ~0ull;
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) { const uint64_t o = __shfl_xor(least, m, 64); least = o < least ? o : least; }
+    if (least == ~0ull) return;                             // no frame to hash in this wave
+    const uint64_t common = least - least % (2 * ZK_XXW);
+    const uint8_t *q = p + 8 * kl;
+    uint64_t wa[ZK_XXW], wb[ZK_XXW];
+    if (common) {
+#pragma unroll
+        for (int u = 0; u < ZK_XXW; u++) wa[u] = zk_ld64(q + 32 * (uint64_t)u);
+        for (uint64_t s = 0; s < common; s += 2 * ZK_XXW) {
+#pragma unroll
+            for (int u = 0; u < ZK_XXW; u++) wb[u] = zk_ld64(q + 32 * (s + ZK_XXW + u));
+#pragma unroll
+            for (int u = 0; u < ZK_XXW; u++) acc = zk_xround(acc, wa[u]);
+            const uint64_t nx = s + 2 * ZK_XXW < common ? s + 2 * ZK_XXW : 0;     // (the last round reads the frame's first batch again)
+#pragma unroll
+            for (int u = 0; u < ZK_XXW; u++) wa[u] = zk_ld64(q + 32 * (nx + u));
+#pragma unroll
+            for (int u = 0; u < ZK_XXW; u++) acc = zk_xround(acc, wb[u]);
+        }
+    }
+    // what is left of the longer frames, stripe by stripe
+    for (uint64_t i = common; i < nstripes; i++) acc = zk_xround(acc, zk_ld64(q + (i << 5)));
+    const uint32_t base = lane & ~3u;
+    const uint64_t v1 = __shfl(acc, base, 64), v2 = __shfl(acc, base + 1, 64), v3 = __shfl(acc, base + 2, 64), v4 = __shfl(acc, base + 3, 64);
+    if (kl != 0 || !live) return;
+    uint64_t h;
+    if (len >= 32) {
+        h = zk_rotl64(v1, 1) + zk_rotl64(v2, 7) + zk_rotl64(v3, 12) + zk_rotl64(v4, 18);
+        h = (h ^ zk_xround(0, v1)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v2)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v3)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v4)) * XP1 + XP4;
+    } else h = XP5;
+    h += len;
+    const uint8_t *t = p + (nstripes << 5), *end = p + len;
+    while (t + 8 <= end) { h ^= zk_xround(0, zk_ld64(t)); h = zk_rotl64(h, 27) * XP1 + XP4; t += 8; }
+    if (t + 4 <= end) { h ^= (uint64_t)zk_rd32(t) * XP1; h = zk_rotl64(h, 23) * XP2 + XP3; t += 4; }
+    while (t < end) { h ^= (uint64_t)(*t) * XP5; h = zk_rotl64(h, 11) * XP1; t++; }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    if (hashes) hashes[f] = h;
+    if (infos && (uint32_t)h != infos[f].checksum) infos[f].status = ZK_E_CHECKSUM_WRONG;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void zk_k_xxh64_lean(const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
+                                                                                                  ZkFrameInfo *infos, uint64_t *hashes)
+{
+    zk_xxh64_lean_body<12>(data, d_off, first, count, infos, hashes);
+}
+
 // per-frame status words + first failing frame ((frame << 32) | code, min over frames)
 __global__ __launch_bounds__(256) void zk_k_status(const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, unsigned long long *first_err)
 {
@@ -1363,7 +1431,8 @@ void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off,
                      ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k)
 {
     // a large batch: sixteen frames per wave (the chains' latency is the same, the instruction slots a sixteenth)
-    if (k.xxh ? k.xxh == 2 : count >= 512) hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
+    if (k.xxh == 3) hipLaunchKernelGGL(zk_k_xxh64_lean, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
+    else if (k.xxh ? k.xxh == 2 : count >= 512) hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
     else hipLaunchKernelGGL(zk_k_xxh64, dim3(count), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
 }
 

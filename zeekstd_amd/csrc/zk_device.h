@@ -862,7 +862,11 @@ ZK_HD uint64_t zk_ld64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return 
 struct ZkRevU {
     const uint8_t *base; uint64_t W; int32_t pos, wpos;      // W holds stream bits [wpos, wpos + 64); pos = unread bits
     static ZK_HDM int32_t byte_of(int32_t pos) { int32_t b = (pos - 57) >> 3; return b < 0 ? 0 : b; }
+#ifdef ZK_KO_LOAD                                               // experiment (tools/variants): the walk's timing without its one load per step (wrong bytes)
+    ZK_HDM void reload() { const int32_t bo = byte_of(pos); W = 0x0123456789ABCDEFull; wpos = bo * 8; }
+#else
     ZK_HDM void reload() { const int32_t bo = byte_of(pos); W = zk_ld64(base + bo); wpos = bo * 8; }
+#endif
     ZK_HDM bool init(const uint8_t *b, uint32_t len)
     {
         const uint32_t last = b[len - 1];
@@ -1158,10 +1162,10 @@ ZK_HD void zk_decode_sequences(const uint8_t *comp, const ZkBlock *blocks, ZkBlo
 #define ZK_WAVE_BARRIER() ((void)0)
 #endif
 constexpr uint32_t ZK_QUAD_ROUND = 4;            // sequences of a block that zk_seq_finish_quad takes at a time (= lanes of a quad)
-// t = the lane's table (ZK_TAB_LL / ZK_TAB_OF / ZK_TAB_ML = its position in the quad); cells / vt: that table's cells
-// and value table (offsets: entries k << 24, the baseline 1 << k is formed here); al[3]: accuracy logs (LL, OF, ML).
-// out.gate(i) is called by all three lanes in front of every sequence i that is a multiple of ZK_QUAD_ROUND (flow control of
-// the hand-over, the toucher's stream position), out.put(i, v) once per sequence and lane.  Returns 0, or 1 for a damaged
+// t = the lane's table (ZK_TAB_LL / ZK_TAB_OF / ZK_TAB_ML = its position in the quad); cells: that table's cells; vt: that table's
+// BASELINES, nothing else in the words (literal lengths 0..65536, match lengths 3..65539, offsets 1 << code); al[3]: accuracy logs.
+// out.gate(i0, stream position) is called by all three lanes in front of every round of ZK_QUAD_ROUND sequences (flow control of
+// the hand-over, the toucher's cue), out.put(i0, k, v) once per sequence i0 + k and lane.  Returns 0, or 1 for a damaged
 // stream (over-read, bits left over) -- all three lanes return the same.
 // bits: where the lane reads the bitstream from -- nullptr = in place (comp + b.src + bs_off), or a staged copy of its
 // b.bsize - bs_off bytes (LDS, readable 8 bytes past the end).
@@ -1194,10 +1198,10 @@ ZK_HD uint32_t zk_seq_walk_quad(const uint8_t *comp, const ZkBlock &b, uint32_t 
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" :: "v"((uint32_t)c));                      // arrived before the loop: its waits then only count what the loop issues
 #endif
-    for (uint32_t i = 0; i < nseq; i++) {
-        if ((i & (ZK_QUAD_ROUND - 1)) == 0) out.gate(i, b.src + bs_off + (uint32_t)(r.remaining() >> 3));
+    // one sequence; k: its place in the round
+    auto step = [&](uint32_t i, uint32_t k) {
         const uint32_t sy = CP::sym(c);
-        const uint32_t vv = vt[sy];
+        const uint32_t vv = vt[sy];                             // the baseline (used at the end of the step: nothing waits for it)
         const uint32_t xb_mid = (uint32_t)(xLUT >> ((4u * (sy - xT1)) & 63u)) & 15u;
         const uint32_t xb = sy < xT1 ? 0u : sy < xT2 ? xb_mid : sy - xD;
         const uint32_t nbc = CP::nb(c, al_t);
@@ -1224,7 +1228,13 @@ ZK_HD uint32_t zk_seq_walk_quad(const uint8_t *comp, const ZkBlock &b, uint32_t 
         }
         state = CP::base(c, al_t, nbc) + sbits;
         c = cells[state];                                       // issued early; used by the next step
-        out.put(i, (t == ZK_TAB_OF ? 1u << (xb & 31) : vv & 0xFFFFFFu) + vbits);
+        out.put(i - k, k, vv + vbits);
+    };
+    // (a round unrolled by hand, the ring slots constants: the same speed -- the guards of the unrolled steps cost what the slot
+    // arithmetic saves; profiles/r04_fse_walk.txt)
+    for (uint32_t i = 0; i < nseq; i++) {
+        if ((i & (ZK_QUAD_ROUND - 1)) == 0) out.gate(i, b.src + bs_off + (uint32_t)(r.remaining() >> 3));
+        step(i, i & (ZK_QUAD_ROUND - 1));
     }
     bad |= r.remaining() != 0;
     return bad ? 1u : 0u;

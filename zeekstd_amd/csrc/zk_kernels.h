@@ -11,7 +11,7 @@ struct ZkKernelChoice {
     int fse_shared = 0;     // blocks that share tables: 1 zk_k_fse_predef, 2 zk_k_fse_predef_fed, 3 zk_k_fse_sets
     int exec_lanes = 0;     // zk_k_exec tile: 128 / 256 / 512 / 1024 lanes
     int exec_ring = 0;      // 256-lane tiles: 1 a ring of 2 T records, 2 of 4 T
-    int xxh = 0;            // 1 zk_k_xxh64 (a wave per frame), 2 zk_k_xxh64_wide (sixteen frames per wave)
+    int xxh = 0;            // 1 zk_k_xxh64 (a wave per frame), 2 zk_k_xxh64_wide (sixteen frames per wave), 3 zk_k_xxh64_lean (the same in 64 registers)
     int small_path = 0;     // host-pointer decode of <= 64 frames: 1 the general pipeline instead, 2 the small path's entropy roles as two kernels
 };
 
