@@ -107,6 +107,42 @@ def test_list_separate_seek_table(tmp_path):                        # main.rs:57
 
 
 # ------------------------------------------------------------------------------------------------ on the engine
+def test_progress_counter(monkeypatch, capsys):
+    """args.rs:122-135 + command.rs:190-204: "<done> of <total>", binary units unless --raw-bytes, nothing when quiet / --no-progress /
+    STDERR is no terminal, cleared at the end."""
+    import argparse
+    import time
+    from zeekstd_amd import cli
+
+    class Tty:
+        def __init__(self): self.s = ""
+        def isatty(self): return True
+        def write(self, x): self.s += x
+        def flush(self): pass
+    ns = argparse.Namespace(quiet=False, raw_bytes=False, no_progress=False)
+    tty = Tty()
+    monkeypatch.setattr(cli.sys, "stderr", tty)
+    bar = cli.Progress(10 << 20, 0, ns)
+    bar.inc(3 << 20)
+    assert tty.s.endswith("3.00 MiB of 10.00 MiB")
+    bar.inc(1 << 20)                                        # inside a fifth of a second: not redrawn
+    assert tty.s.endswith("3.00 MiB of 10.00 MiB")
+    bar.last -= 1.0
+    bar.inc(1 << 20)
+    assert tty.s.endswith("5.00 MiB of 10.00 MiB") and bar.pos == 5 << 20
+    bar.finish_and_clear()
+    assert tty.s.endswith("\r\x1b[2K")
+    tty.s = ""
+    raw = cli.Progress(None, 7, argparse.Namespace(quiet=False, raw_bytes=True, no_progress=False))
+    raw.inc(5)
+    assert tty.s.endswith("12")                              # STDIN: no total
+    for ns2 in (argparse.Namespace(quiet=True, raw_bytes=False, no_progress=False), argparse.Namespace(quiet=False, raw_bytes=False, no_progress=True)):
+        tty.s = ""
+        b2 = cli.Progress(100, 0, ns2)
+        b2.inc(50); b2.finish_and_clear()
+        assert tty.s == "" and b2.pos == 50
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fs", FRAME_SIZES)
 def test_cycle(test_input, tmp_path, fs):                           # main.rs:146-151

@@ -101,6 +101,37 @@ def raw_bytes(n: int) -> str:
     return str(n)
 
 
+class Progress:
+    """The reference's progress counter (cli/src/args.rs:122-135, command.rs:190-204, compress.rs:69-70, decompress.rs:39-48, 94-95):
+    "<done> of <total>" on STDERR, redrawn at most five times a second, cleared at the end; binary units unless --raw-bytes; not
+    drawn when quiet, with --no-progress, or when STDERR is not a terminal (indicatif's draw target hides itself then)."""
+
+    def __init__(self, total, pos, args):
+        self.total, self.pos = total, pos
+        self.fmt = raw_bytes if args.raw_bytes else human_bytes
+        self.on = not args.quiet and not getattr(args, "no_progress", False) and sys.stderr.isatty()
+        self.last = 0.0
+        self.drawn = False
+
+    def inc(self, n):
+        self.pos += n
+        if not self.on:
+            return
+        import time
+        now = time.monotonic()
+        if now - self.last >= 0.2:
+            self.last = now
+            total = f" of {self.fmt(self.total)}" if self.total is not None else ""
+            sys.stderr.write(f"\r\x1b[2K{self.fmt(self.pos)}{total}")
+            sys.stderr.flush()
+            self.drawn = True
+
+    def finish_and_clear(self):
+        if self.drawn:
+            sys.stderr.write("\r\x1b[2K")
+            sys.stderr.flush()
+
+
 # ---------------------------------------------------------------- arguments
 def build_parser():
     top = argparse.ArgumentParser(prog="zeekstd", description="Compress and decompress data using the Zstandard Seekable Format.")
@@ -297,6 +328,7 @@ def run_compress(args, api, lib, eng):
     if args.patch_from and prefix is None:
         raise CliError("Failed to load prefix (patch) file")
     read = 0
+    bar = Progress(src.n if src is not None else None, 0, args)
 
     def feed(ptr, n):
         done = 0
@@ -309,11 +341,13 @@ def run_compress(args, api, lib, eng):
                 raise CliError(f"Failed to compress data: {api.Error(int(k))}")
             done += k
     if src is not None:
-        # the whole mapping in pieces of 1 GiB: each call is encoded where it lies
-        for at in range(0, src.n, 1 << 30):
-            n = min(1 << 30, src.n - at)
+        # the whole mapping in pieces of 1 GiB (256 MiB while a progress counter is drawn): each call is encoded where it lies
+        piece_len = (256 << 20) if bar.on else (1 << 30)
+        for at in range(0, src.n, piece_len):
+            n = min(piece_len, src.n - at)
             feed(src.ptr + at, n)
             read += n
+            bar.inc(n)
     else:
         while True:
             piece = sys.stdin.buffer.read(CHUNK)
@@ -322,6 +356,8 @@ def run_compress(args, api, lib, eng):
             buf = C.create_string_buffer(piece, len(piece))
             feed(C.addressof(buf), len(piece))
             read += len(piece)
+            bar.inc(len(piece))
+    bar.finish_and_clear()
     if st_file is not None:                                  # compress.rs:86-96: frames to the output, the table (Head format) to its own file
         enc.end_frame()
         enc.flush()
@@ -389,6 +425,7 @@ def run_decompress(args, api, lib, eng):
     buf = bytearray(min(CHUNK, max(131072, limit - offset if limit > offset else 131072)))
     arr = (C.c_uint8 * len(buf)).from_buffer(buf)
     written = 0
+    bar = Progress(limit, offset, args)
     while True:
         got = C.c_size_t()
         if prefix is not None and prefix.n:
@@ -405,6 +442,8 @@ def run_decompress(args, api, lib, eng):
         except OSError as e:
             raise CliError(f"Failed to write decompressed data: {e}")
         written += n
+        bar.inc(n)
+    bar.finish_and_clear()
     del arr
     if writer is not sys.stdout.buffer:
         writer.close()

@@ -75,7 +75,7 @@ constexpr uint32_t ZK_MAX_FRAME = 0x40000000u;     // SEEKABLE_MAX_FRAME_SIZE (r
 // ---------------------------------------------------------------- data records in HBM
 struct ZkFrameInfo {            // written by the frame walker, one per frame
     uint32_t n_blocks;
-    uint32_t n_seq;             // total sequences in the frame
+    uint32_t n_seq;             // record slots of the frame: every block's sequences rounded up to 8 (zk_walk_frame)
     uint32_t lit_bytes;         // total Huffman-coded literal bytes (need literal scratch)
     uint32_t status;            // ZSTD_ErrorCode, 0 ok
     uint32_t checksum_flag;
@@ -739,7 +739,9 @@ ZK_HD void zk_walk_frame(const uint8_t *comp, uint64_t c_begin, uint64_t c_end, 
                     if (m != 3) tab_def[t] = (uint32_t)blk;
                     else if (tab_def[t] == 0xFFFFFFFFu) { fi.status = ZK_E_CORRUPTION; return; }
                 }
-                seqb += nseq; fi.n_seq += nseq;
+                // a block's records start on a 64-byte line of the record scratch (8 records): the sequence kernels' 32- and 64-byte bursts
+                // then never straddle a line (round 3: 4.26 GiB written for 2.57 GB of records)
+                seqb += (nseq + 7u) & ~7u; fi.n_seq += (nseq + 7u) & ~7u;
             }
         } else {
             out_known += bsize;

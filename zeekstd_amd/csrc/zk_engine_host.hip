@@ -428,7 +428,7 @@ static int zk_decode_small(zk_engine *e, zk_hostpipe *hp, const zk_host_src &src
     if ((rc = zk_devbuf_reserve(e, c.bases, (size_t)count * sizeof(ZkFrameBase)))) return rc;
     if ((rc = zk_devbuf_reserve(e, c.words, 16 * sizeof(uint64_t)))) return rc;
     if ((rc = zk_devbuf_reserve(e, c.blocks, (size_t)(block_cap + 1) * sizeof(ZkBlock)))) return rc;
-    if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)(dsz / 3 + count + 1) * sizeof(ZkSeqP)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)(dsz / 3 + count + 1 + 8ull * (block_cap + 1)) * sizeof(ZkSeqP)))) return rc;     // (+ 7 per block: a block's records start on a 64-byte line)
     if ((rc = zk_devbuf_reserve(e, c.lit, (size_t)dsz + 64))) return rc;
     if ((rc = zk_devbuf_reserve(e, s.d_in, comp_bytes + 64))) return rc;
     if ((rc = zk_devbuf_reserve(e, s.d_out, (size_t)dsz + 64))) return rc;
