@@ -1247,10 +1247,19 @@ __global__ __launch_bounds__(256) void zk_k_small_walk(const uint8_t *h_comp, ui
                                                        ZkFrameInfo *infos, ZkFrameBase *bases, ZkBlock *blocks, uint64_t *words)
 {
     __shared__ uint32_t s_tot[4];
+    // (r4) the bytes also stay in LDS when they fit (a seek: one or two frames of a few tens of KiB): the two header walks below are
+    // chains of dependent byte reads -- ~4 per block -- and cost an L2 round trip each out of HBM scratch, an LDS one out of here
+    __shared__ uint4 s_stage[3072];                          // 48 KiB
     const uint32_t tid = threadIdx.x;
     // upload: 16 bytes per lane and step, straight over PCIe (h_comp is 16-byte aligned, padded to a multiple of 16)
     const uint64_t n16 = (comp_bytes + 15) >> 4;
-    for (uint64_t i = tid; i < n16; i += 256) reinterpret_cast<uint4 *>(d_comp)[i] = reinterpret_cast<const uint4 *>(h_comp)[i];
+    const bool staged = n16 <= 3072;
+    for (uint64_t i = tid; i < n16; i += 256) {
+        const uint4 v = reinterpret_cast<const uint4 *>(h_comp)[i];
+        reinterpret_cast<uint4 *>(d_comp)[i] = v;
+        if (staged) s_stage[i] = v;
+    }
+    const uint8_t *wcomp = staged ? reinterpret_cast<const uint8_t *>(s_stage) : d_comp;
     if (tid < 2) reinterpret_cast<uint64_t *>(d_comp + (n16 << 4))[tid] = 0;                 // readable padding behind the last frame
     for (uint32_t i = tid; i < 2 * (count + 1); i += 256) d_offs[i] = h_offs[i];
     __syncthreads();
@@ -1262,7 +1271,7 @@ __global__ __launch_bounds__(256) void zk_k_small_walk(const uint8_t *h_comp, ui
         cb = c_off[tid]; ce = c_off[tid + 1]; dsz = d_off[tid + 1] - d_off[tid];
         if (ce < cb || ce > comp_bytes || d_off[tid + 1] < d_off[tid]) fi.status = ZK_E_SRC_SIZE_WRONG;
         else {
-            zk_walk_frame(d_comp, cb, ce, dsz, tid, nullptr, nullptr, fi);
+            zk_walk_frame(wcomp, cb, ce, dsz, tid, nullptr, nullptr, fi);
             if (fi.status == ZK_OK && (d_off[tid] > dst_cap || dsz > dst_cap - d_off[tid])) fi.status = ZK_E_DST_TOO_SMALL;
             if (dsz > ZK_MAX_FRAME && fi.status == ZK_OK) fi.status = ZK_E_FRAMEPARAM_UNSUPPORTED;
         }
@@ -1287,7 +1296,7 @@ __global__ __launch_bounds__(256) void zk_k_small_walk(const uint8_t *h_comp, ui
     if (tid < count) {
         if (overflow) { fi.status = ZK_E_GENERIC; fi.n_blocks = 0; }
         infos[tid] = fi;
-        if (!overflow && fi.status == ZK_OK) { ZkFrameInfo f2; zk_walk_frame(d_comp, cb, ce, dsz, tid, &bases[tid], blocks, f2); }
+        if (!overflow && fi.status == ZK_OK) { ZkFrameInfo f2; zk_walk_frame(wcomp, cb, ce, dsz, tid, &bases[tid], blocks, f2); }
     }
     if (tid == 0) {
         words[0] = overflow ? 0 : s_tot[0]; words[1] = overflow ? 0 : s_tot[1]; words[2] = overflow ? 0 : s_tot[2];
