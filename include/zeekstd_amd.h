@@ -158,7 +158,8 @@ int zk_decode_wait(zk_engine *e, int slot);
  * concatenated in dst, and report the seek-table entries: c_sizes[i] / d_sizes[i] are what
  * SeekTable::log_frame receives (seek_table.rs:513-525).  checksum != 0 appends the XXH64 Content_Checksum
  * (ZSTD_c_checksumFlag, encode.rs:283-284).  level is ZSTD_c_compressionLevel (encode.rs:281-282): one strategy
- * (hash matching in a 57 280-byte window, Huffman literals, FSE tables measured per frame) with three settings
+ * (hash matching in a 57 280-byte window -- from level 2 on plus sampled far matches anywhere behind it in the frame, the frame
+ * then declares a window over its size --, Huffman literals, FSE tables measured per frame) with three settings
  * (zk_enc_device.h: zke_fast / zke_minmatch / zke_hash_log / zke_lazy / zke_step) --
  * level <= 1 (negative levels included): table matches of 6+ bytes, 2^14 table entries, greedy parse; levels 2..5 and 0
  * (= libzstd's default 3, the reference CLI's default): 5+ bytes, 2^15 entries, lazy parse; level >= 6: the same with the

@@ -35,9 +35,26 @@ extern "C" int zk_enc_sim_match(const uint8_t *src, uint64_t n, uint32_t frame_s
         msrc = stage.data();
     }
     // long-distance table over the prefix (the engine builds it with zk_k_enc_ldm_build; here sequentially, same rule)
-    ZkEncLdm ldm = {nullptr, nullptr, 0, 0, 0, 0};
+    ZkEncLdm ldm = {nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint32_t> table;
     std::vector<uint8_t> pcopy;
+    if (!prefix && zke_ldm_in_frame(level, 0, frame_size < n ? frame_size : n)) {
+        // in-frame far history: one table per frame over its own bytes (the engine: zk_k_enc_ldm_build_frames; here sequentially, same rule)
+        ldm.inframe = 1; ldm.frame_size = frame_size; ldm.n_total = n; ldm.log = zke_ldm_log(frame_size < n ? frame_size : n);
+        table.assign((size_t)pl.nf << ldm.log, ZKE_LDM_NONE);
+        for (uint32_t f = 0; f < pl.nf; f++) {
+            const uint64_t at = (uint64_t)f * frame_size, fsz = n - at < frame_size ? n - at : frame_size;
+            const uint32_t log = zke_ldm_log(fsz);
+            for (uint64_t i = 0; i + ZKE_LDM_MIN <= fsz; i++) {
+                uint32_t w[4]; memcpy(w, src + at + i, 16);
+                const uint32_t h = zke_ldm_hash(w[0], w[1], w[2], w[3]);
+                if (!zke_ldm_selected(h)) continue;
+                uint32_t &slot = table[((size_t)f << ldm.log) + zke_ldm_slot(h, log)];
+                if ((uint32_t)i < slot) slot = (uint32_t)i;
+            }
+        }
+        ldm.table = table.data();
+    }
     if (prefix && prefix_len > ZKE_WINDOW) {
         const uint64_t usable = zke_ldm_usable(prefix_len);
         ldm.plen = prefix_len; ldm.u0 = prefix_len - usable; ldm.log = zke_ldm_log(usable);

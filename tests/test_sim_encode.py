@@ -92,6 +92,20 @@ def test_sim_match_long_distance(level):
         _compare(new[:70000], 1 << 21, level, old[:57284])      # a prefix four bytes beyond the ring's reach
 
 
+@pytest.mark.parametrize("level", [3, 6])
+def test_sim_match_far_history_inside_a_frame(level):
+    """round 4: from level 2 on a frame longer than the ring's reach finds its own far history through a table over its own bytes
+    (repeats 100+ KB apart: a section that comes back edited, a second copy of another) -- one frame of two segments, three frames
+    with their own tables, and a last frame too short for any of it"""
+    a = zko.make_input([["text", 90000, 61]])
+    b = zko.make_input([["text", 70000, 62], ["random", 8000, 63]])
+    data = a + b + _edited(a, 9, 6) + zko.make_input([["text", 30000, 64]]) + b[20000:60000] + a[:15000]
+    _compare(data, 1 << 21, level)
+    if level == 3:
+        _compare(data, 150000, level)                      # 150 000 + 150 000 + a tail below the ring's reach
+        _compare(data[:200000], 65536, level)              # frames of 64 KiB: in frame, but nothing lies further back than the ring reaches
+
+
 def test_huffman_build_as_the_kernel_does_it():
     """zk_k_enc_entropy ranks a block's symbols with all lanes of the wave and hands them to zke_huf_lengths sorted, then assigns the
     canonical codes from per-weight counts and ranks: the same lengths, depth and codes as the serial functions (random, skewed,

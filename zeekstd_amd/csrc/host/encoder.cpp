@@ -110,7 +110,7 @@ CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t i
     if (by_output && limit) {
         const size_t want = policy_.size;
         // (b more compressed bytes need at least ~b more input bytes: a probe never lies further ahead than that plus the
-        // window, so even input that stops compressing cannot carry the frame past n + 131 591)
+        // window, so even input that stops compressing cannot carry the frame past n + 131 591 -- except in the corner named below)
         if (frame_in_.size() >= next_probe_) {
             encoded_ = false;
             encode_pending();                                                  // speculative: how large is the frame so far?
@@ -120,11 +120,15 @@ CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t i
                 const double r = std::max(1.0, (double)d / (double)std::max<size_t>(c, 1));
                 const size_t by_ratio = std::max<size_t>(32768, (size_t)(0.9 * r * (double)(want - c)));
                 size_t step = std::min<size_t>(by_ratio, (want - c) + slack);
-                // far from n on input that compresses very well (d >> c) `by_ratio` is an estimate from a ratio that may not last: while
-                // less than half of n is reached the step is at least an eighth of the frame so far (fewer probes -- each one is a
-                // full encode of the frame so far) -- but never more than the missing bytes plus the window: input that stops
-                // compressing right behind this probe then still ends the frame inside [n, n + 131 591)
-                if (2 * c < want) step = std::max(step, std::min<size_t>(d / 8, (want - c) + slack));
+                // far from n on input that compresses very well (d >> c) that cap would mean a probe -- a full encode of the frame so
+                // far -- every ~1 MiB of a frame of hundreds of MiB: quadratic work (192 MiB of zeros under Compressed(1 MiB): 207 s with
+                // the cap kept, 7 s without; tests/test_gpu_encoder_api.py::test_compressed_policy_on_input_that_barely_has_a_size).
+                // While less than half of n is reached the step is therefore at least an eighth of the frame so far (geometric:
+                // O(log) probes).  THE PRICE, a deviation from upstream's window in one corner: input that compresses > 16 : 1 for
+                // tens of MiB and then stops compressing inside one such step can carry the frame past n + 131 591 (by at most the
+                // step: an eighth of the frame so far).  Upstream, which learns sizes 128 KiB at a time, has no such corner; the
+                // window holds again as soon as c reaches n / 2.
+                if (2 * c < want) step = std::max(step, d / 8);
                 next_probe_ = d + step;
             } else ratio_ = (double)d / (double)c;
         }

@@ -84,8 +84,17 @@ struct ZkEncLdm {
     const uint8_t *pfx;         // prefix byte q is pfx[q] for q in [u0, plen) (+ ZKE_LDM_SLACK readable bytes); nullptr: no long-distance matching
     const uint32_t *table;      // 2^log entries: position - u0 of the first sampled occurrence, ZKE_LDM_NONE = empty
     uint64_t plen, u0;
-    uint32_t log, pad;
+    uint32_t log;
+    // IN-FRAME far history (round 4; oracle/zstd_oracle_enc.c ldm_build_frame has the rule): the same machinery over every frame's
+    // OWN bytes -- from level 2 on, without a prefix, frames beyond the ring's reach.  Then `table` holds one table of 2^log entries
+    // per frame of frame_size bytes of the n_total input bytes (a frame's own table uses the first 2^zke_ldm_log(its size) of them),
+    // pfx is unused, and the match kernel makes its frame's view of this struct itself (zk_enc_match.h).
+    uint32_t inframe;
+    uint32_t frame_size, pad;
+    uint64_t n_total;
 };
+constexpr uint32_t ZKE_LDM_FILL = 6;    // in frame a far candidate is taken where the ring's best is shorter than this (the twin has the measurements)
+ZK_HD bool zke_ldm_in_frame(int level, uint64_t prefix_len, uint64_t frame_bytes) { return !zke_fast(level) && prefix_len == 0 && frame_bytes > ZKE_WINDOW; }
 
 // A compressed block's payload is put together by zk_k_enc_assemble out of the pieces the entropy stage leaves in the block's scratch:
 //   [0, 16)      ZkEncPieces

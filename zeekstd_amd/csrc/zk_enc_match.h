@@ -183,7 +183,15 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
     const uint32_t hist = fr.hist, fend = hist + fr.d_size, minmatch = fr.minmatch, fend4 = (fend + 3) & ~3u;
     const uint64_t lane_lt = zke_lowmask(lane);
     const uint32_t bias = T32 ? (0u - hist) & (ZKE_GROUP_POS - 1) : 0u;
-    const uint64_t abs0 = LDM ? ldm.plen + fr.seg_at - hist : 0;      // record position p = byte abs0 + p of [prefix | frame]
+    // record position p = byte abs0 + p of [prefix | frame]; in-frame far history: of the frame itself, and LD is the frame's view
+    // of the table (its own 2^log entries, its bytes as the "prefix", its size as the limit)
+    const uint64_t abs0 = !LDM ? 0 : ldm.inframe ? fr.seg_at - hist : ldm.plen + fr.seg_at - hist;
+    ZkEncLdm LD = ldm;
+    if (LDM && ldm.inframe) {
+        const uint64_t fsz = ldm.n_total - fr.src_off < ldm.frame_size ? ldm.n_total - fr.src_off : ldm.frame_size;
+        LD.pfx = base - abs0; LD.plen = fsz; LD.u0 = 0; LD.log = zke_ldm_log(fsz);
+        LD.table = ldm.table + ((fr.src_off / ldm.frame_size) << ldm.log);
+    }
 
     ZKE_CLK_BEGIN();
     // ---- segment start: empty table, history + the first group (+ lookahead) into the ring, history positions into the table
@@ -433,13 +441,13 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                 const int64_t ap0 = (int64_t)(abs0 + P0);
                 // a long-distance offset is usable at my four positions while the 20 bytes I read at that distance lie inside the
                 // table's part of the prefix
-                auto far_ok = [&](uint32_t off) { const int64_t a = ap0 - (int64_t)off; return a >= (int64_t)ldm.u0 && a + 20 <= (int64_t)ldm.plen; };
+                auto far_ok = [&](uint32_t off) { const int64_t a = ap0 - (int64_t)off; return a >= (int64_t)LD.u0 && a + 20 <= (int64_t)LD.plen; };
                 const bool okR = farR && far_ok(R);
                 {
                     const uint32_t rb = P0 - R, ri = (rb >> 2) & 16383u, rs = rb & 3u;  // R <= P0 is tested below; a wrong address reads some ring bytes
                     x1[0] = d0 ^ __builtin_amdgcn_alignbyte(d0, dm1, 3u); x1[1] = d1 ^ __builtin_amdgcn_alignbyte(d1, d0, 3u); x1[2] = d2 ^ __builtin_amdgcn_alignbyte(d2, d1, 3u);
                     x1[3] = d3 ^ __builtin_amdgcn_alignbyte(d3, d2, 3u); x1[4] = d4 ^ __builtin_amdgcn_alignbyte(d4, d3, 3u);
-                    if (farR) zke_far_xor(ldm, ap0 - (int64_t)R, okR, own, xr);
+                    if (farR) zke_far_xor(LD, ap0 - (int64_t)R, okR, own, xr);
                     else {
                         const uint32_t r0 = ring[ri], r1 = ring[ri + 1], r2 = ring[ri + 2], r3 = ring[ri + 3], r4 = ring[ri + 4], r5 = ring[ri + 5];
                         xr[0] = d0 ^ __builtin_amdgcn_alignbyte(r1, r0, rs); xr[1] = d1 ^ __builtin_amdgcn_alignbyte(r2, r1, rs); xr[2] = d2 ^ __builtin_amdgcn_alignbyte(r3, r2, rs);
@@ -473,11 +481,11 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                         const uint32_t o0 = wlo[k], o1 = whi[k], o2 = __builtin_amdgcn_alignbyte(own[3], own[2], (uint32_t)k), o3 = __builtin_amdgcn_alignbyte(own[4], own[3], (uint32_t)k);
                         const uint32_t h = zke_ldm_hash(o0, o1, o2, o3);
                         if (zke_ldm_selected(h) && p + ZKE_LDM_MIN <= te && p + ZKE_LDM_MIN <= fend) {
-                            const uint32_t e = ldm.table[zke_ldm_slot(h, ldm.log)];
-                            const uint64_t q = ldm.u0 + e, ap = abs0 + p;
-                            if (e != ZKE_LDM_NONE && q + 16 <= ldm.plen && ap - q <= ZKE_LDM_MAX_OFF) {
+                            const uint32_t e = LD.table[zke_ldm_slot(h, LD.log)];
+                            const uint64_t q = LD.u0 + e, ap = abs0 + p;
+                            if (e != ZKE_LDM_NONE && q + 16 <= LD.plen && ap - q <= ZKE_LDM_MAX_OFF && (!ldm.inframe || (q < ap && ap - q > ZKE_WINDOW))) {   // in-frame: behind me, beyond the ring
                                 uint32_t c[4];
-                                memcpy(c, ldm.pfx + q, 16);
+                                memcpy(c, LD.pfx + q, 16);
                                 if (c[0] == o0 && c[1] == o1 && c[2] == o2 && c[3] == o3) hoff[k] = (uint32_t)(ap - q);
                             }
                         }
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     const uint32_t first = hoff[0] ? hoff[0] : hoff[1] ? hoff[1] : hoff[2] ? hoff[2] : hoff[3];
                     const uint64_t hits = __ballot(first != 0);
                     if (hits) tfar = (uint32_t)__builtin_amdgcn_readlane((int)first, (int)__builtin_ctzll(hits));
-                    if (tfar && tfar != R) { ok2 = far_ok(tfar); zke_far_xor(ldm, ap0 - (int64_t)tfar, ok2, own, x2); }      // uniform per wave
+                    if (tfar && tfar != R) { ok2 = far_ok(tfar); zke_far_xor(LD, ap0 - (int64_t)tfar, ok2, own, x2); }      // uniform per wave
                     else tfar = 0;
                 }
                 // offset 1 and offset R: the run of equal bytes from each of my four positions out of the 20-byte windows, once per window
@@ -509,10 +517,11 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                         uint32_t bl = 0, bo = 0;
                         if (okf) { bl = cf; bo = df[k]; }
                         if (okn && cn >= bl) { bl = cn; bo = dn[k]; }
-                        if (hoff[k]) { bl = ZKE_PARCAP; bo = hoff[k]; }                     // (16 equal bytes inside the tile)
+                        const bool fills = !ldm.inframe || bl < ZKE_LDM_FILL;               // in frame a far candidate only fills gaps
+                        if (hoff[k] && fills) { bl = ZKE_PARCAP; bo = hoff[k]; }            // (16 equal bytes inside the tile)
                         const uint32_t l2 = zke_first16(__builtin_amdgcn_alignbyte(x2[1], x2[0], (uint32_t)k), __builtin_amdgcn_alignbyte(x2[2], x2[1], (uint32_t)k),
                                                         __builtin_amdgcn_alignbyte(x2[3], x2[2], (uint32_t)k), __builtin_amdgcn_alignbyte(x2[4], x2[3], (uint32_t)k));
-                        if (tfar && ok2 && tabled[k] && n == ZKE_PARCAP && l2 == ZKE_PARCAP) { bl = ZKE_PARCAP; bo = tfar; }
+                        if (tfar && ok2 && tabled[k] && n == ZKE_PARCAP && l2 == ZKE_PARCAP && (!ldm.inframe || bl < ZKE_LDM_FILL)) { bl = ZKE_PARCAP; bo = tfar; }
                         if (ok1 && c1 >= bl) { bl = c1; bo = 1; }
                         if (okr && cr >= bl) { bl = cr; bo = R; }
                         best[4 * tid + k] = bl | (bo << 5);
@@ -573,7 +582,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                                 for (;;) {
                                     const uint32_t q = ts + wb + f + L + lane;
                                     const uint64_t sa = a0 + L + lane;
-                                    const bool diff = q >= te || sa >= ldm.plen || zke_ring1(ring, q) != ldm.pfx[sa < ldm.plen ? sa : ldm.u0];
+                                    const bool diff = q >= te || sa >= LD.plen || zke_ring1(ring, q) != LD.pfx[sa < LD.plen ? sa : LD.u0];
                                     const uint64_t dm = __ballot(diff);
                                     if (dm) { L += (uint32_t)__builtin_ctzll(dm); break; }
                                     L += 64;

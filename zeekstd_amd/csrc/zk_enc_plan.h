@@ -54,6 +54,7 @@ inline void zke_plan_fill(uint64_t n, uint32_t frame_size, int level, uint64_t p
         while ((1u << wlog) < fr.d_size && wlog < 17) wlog++;
         if (hist) wlog = 17;                                 // covers every offset the matcher can produce, into the prefix too
         if (hist && prefix_len > ZKE_WINDOW) while ((1ull << wlog) < prefix_len + fr.d_size && wlog < 27) wlog++;   // long-distance offsets: < 2^27
+        if (zke_ldm_in_frame(level, prefix_len, fr.d_size)) while ((1ull << wlog) < fr.d_size && wlog < 27) wlog++;     // in-frame far history: the window covers the frame
         fr.window_log = wlog;
         fr.block_max = zke_block_max(fr.d_size, hist != 0);
         fr.n_blocks = fr.d_size ? (fr.d_size + fr.block_max - 1) / fr.block_max : 0;

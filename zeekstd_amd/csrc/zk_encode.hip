@@ -863,6 +863,33 @@ __global__ __launch_bounds__(256) void zk_k_enc_ldm_build(ZkEncLdm ldm, uint32_t
         }
     }
 }
+// The same for the frames' own tables (in-frame far history): blockIdx.y = frame; frame f's table = table + (f << ldm.log), of which
+// its own 2^zke_ldm_log(size) entries are used.
+__global__ __launch_bounds__(256) void zk_k_enc_ldm_build_frames(const uint8_t *src, ZkEncLdm ldm, uint32_t *table)
+{
+    const uint64_t f = blockIdx.y, at = f * ldm.frame_size;
+    const uint64_t n = ldm.n_total - at < ldm.frame_size ? ldm.n_total - at : ldm.frame_size;
+    const uint32_t log = zke_ldm_log(n);
+    const uint8_t *s = src + at;
+    uint32_t *t = table + (f << ldm.log);
+    for (uint64_t i = 4ull * ((uint64_t)blockIdx.x * 256 + threadIdx.x); i + ZKE_LDM_MIN <= n; i += 4ull * gridDim.x * 256) {
+        uint32_t w[5];
+        for (int k = 0; k < 5; k++) { w[k] = 0; const uint64_t q = i + 4 * k; if (q + 4 <= n) memcpy(&w[k], s + q, 4); else for (uint64_t b = q; b < n; b++) w[k] |= (uint32_t)s[b] << (8 * (b - q)); }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i + k + ZKE_LDM_MIN > n) break;
+            const uint32_t h = zke_ldm_hash(__builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)k), __builtin_amdgcn_alignbyte(w[2], w[1], (uint32_t)k),
+                                            __builtin_amdgcn_alignbyte(w[3], w[2], (uint32_t)k), __builtin_amdgcn_alignbyte(w[4], w[3], (uint32_t)k));
+            if (zke_ldm_selected(h)) atomicMin(&t[zke_ldm_slot(h, log)], (uint32_t)(i + k));
+        }
+    }
+}
+void zk_launch_enc_ldm_build_frames(hipStream_t st, const uint8_t *src, const ZkEncLdm &ldm, uint32_t *table, uint32_t nframes)
+{
+    (void)hipMemsetAsync(table, 0xFF, ((size_t)nframes * sizeof(uint32_t)) << ldm.log, st);
+    const uint64_t wgs = ((uint64_t)ldm.frame_size + 4095) / 4096;
+    hipLaunchKernelGGL(zk_k_enc_ldm_build_frames, dim3((uint32_t)(wgs < 1024 ? wgs : 1024), nframes), dim3(256), 0, st, src, ldm, table);
+}
 void zk_launch_enc_ldm_build(hipStream_t st, const ZkEncLdm &ldm, uint32_t *table)
 {
     (void)hipMemsetAsync(table, 0xFF, sizeof(uint32_t) << ldm.log, st);
