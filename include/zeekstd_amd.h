@@ -86,13 +86,19 @@ enum {
                                    * also switches the small-batch shortcut "every block a quad" off) */
     ZK_CHOICE_EXEC_LANES = 3,     /* zk_k_exec tile: 128 / 256 / 512 / 1024 lanes */
     ZK_CHOICE_EXEC_RING = 4,      /* 256-lane tiles: 1 = a ring of 2 T records, 2 = 4 T */
-    ZK_CHOICE_XXH64 = 5,          /* 1 zk_k_xxh64 (a wave per frame), 2 zk_k_xxh64_wide (sixteen frames per wave), 3 zk_k_xxh64_lean (the same in 64 registers) */
+    ZK_CHOICE_XXH64 = 5,          /* 1 zk_k_xxh64 (a wave per frame), 2 zk_k_xxh64_wide (sixteen frames per wave), 3 zk_k_xxh64_lean (the same in 64
+                                   * registers) -- behind the executor; 4 zk_k_xxh64_follow: BESIDE the executor, behind its progress words, on
+                                   * the decode's second queue (zk_engine_checksums_followed says how many frames it verified; what it leaves
+                                   * is checked behind the executor as with 2).  By batch shape: 4 for a synchronous decode of >= 512 frames */
     ZK_CHOICE_SMALL_PATH = 6,     /* host-pointer decode of <= 64 frames: 1 = through the general pipeline, 2 = the small path with its
                                    * entropy roles as two kernels */
     ZK_CHOICE_PIPE_CONTEXTS = 7,  /* host pipeline: decode contexts it rotates through (1..6; 0 = 2) */
-    ZK_CHOICE_PIPE_CHUNK_MIB = 8  /* host pipeline: output MiB per chunk (0 = by total size) */
+    ZK_CHOICE_PIPE_CHUNK_MIB = 8, /* host pipeline: output MiB per chunk (0 = by total size) */
+    ZK_CHOICE_EXEC_RESIDENT = 9   /* zk_k_exec with 256-lane tiles: at most this many workgroups per CU (4 or 5; the launch asks for LDS it does not use) */
 };
 int zk_engine_set_kernel_choice(zk_engine *e, int what, int value);
+/* Frames of the last finished decode whose Content_Checksum was verified by zk_k_xxh64_follow (beside the executor). */
+uint64_t zk_engine_checksums_followed(const zk_engine *e);
 int zk_engine_kernel_count(void);
 const char *zk_engine_kernel_name(int k);
 int zk_engine_kernel_times(const zk_engine *e, float *ms_out, int n);

@@ -24,6 +24,10 @@ VARIANTS = {
     "fed_quad56_exec1024": dict(fse_shared=2, fse_own=2, exec_lanes=1024, xxh64=2, small_path=1),
     "predef_lane_per_block_exec256": dict(fse_shared=1, fse_own=1, exec_lanes=256, exec_ring=2, xxh64=1, small_path=1),
     "small_path_split_roles": dict(small_path=2),
+    # the checksums beside the executor (zk_k_xxh64_follow behind the executor's progress words)
+    "fed_exec256_checksums_follow": dict(fse_shared=2, exec_lanes=256, exec_ring=1, xxh64=4, small_path=1),
+    "exec256_five_resident_checksums_follow": dict(exec_lanes=256, exec_resident=5, xxh64=4, small_path=1),
+    "exec1024_checksums_follow": dict(exec_lanes=1024, xxh64=4, small_path=1),
 }
 
 
@@ -37,7 +41,7 @@ def pinned(request, engine):
 
 def test_unknown_choices_are_refused(engine):
     import zeekstd_amd as zk
-    for key, value in [("exec_lanes", 64), ("fse_shared", 4), ("xxh64", 4), ("exec_ring", -1), ("pipe_contexts", 7)]:
+    for key, value in [("exec_lanes", 64), ("fse_shared", 4), ("xxh64", 5), ("exec_ring", -1), ("pipe_contexts", 7), ("exec_resident", 3)]:
         with pytest.raises(zk.ZkError):
             engine.set_kernel_choice(**{key: value})
     assert zk.lib.zk_engine_set_kernel_choice(engine._h, 99, 0) != 0
@@ -105,3 +109,46 @@ def test_engine_made_archives_under_every_variant(pinned, level, fsize):
     bad[int(c[lo + 1]) - 1] ^= 0x10
     out, st = pinned.decode_frames(bytes(bad) + b"\0" * 8, c, d, first=lo, count=hi - lo, verify=True, raise_on_error=False)
     assert st[0] == 22 and not st[1:].any()
+
+
+def test_checksums_beside_the_executor(engine):
+    """zk_k_xxh64_follow on device buffers that are REUSED for different contents (the hand-off crosses CUs and XCDs: a checksum wave
+    that read a stale line would not verify its frame -- the pass behind the executor would, and `checksums_followed` would say so).
+    Two archives of the same geometry decoded in turn into one output buffer: every byte, every status, and (nearly) every frame
+    verified by the waves beside the executor; then a damaged checksum and a damaged payload, which only the pass behind the executor may report."""
+    import torch
+    dev = torch.device("cuda", 0)
+    fs, nf = 1 << 20, 48
+    srcs = [zko.gen_chunks(nf * fs, 0x7100 + i) for i in range(2)]
+    arch = []
+    for data in srcs:
+        comp, frames = engine.encode_frames(data, fs, 1, True)
+        c, d = offsets_from_frames(frames)
+        arch.append((torch.from_numpy(np.frombuffer(comp + b"\0" * 64, np.uint8).copy()).to(dev), len(comp),
+                     torch.from_numpy(c.view(np.int64)).to(dev), torch.from_numpy(d.view(np.int64)).to(dev), c))
+    d_src = [torch.from_numpy(np.frombuffer(x, np.uint8).copy()).to(dev) for x in srcs]
+    d_out = torch.zeros(nf * fs + 64, dtype=torch.uint8, device=dev)
+    d_st = torch.full((nf,), -1, dtype=torch.int32, device=dev)
+    engine.set_kernel_choice(reset=0)
+    try:
+        engine.set_kernel_choice(xxh64=4)
+        for turn in range(6):
+            k = turn & 1
+            d_comp, csize, d_c, d_d, _ = arch[k]
+            assert engine.decode_frames_dev(d_comp, csize, d_c, d_d, 0, nf, d_out, nf * fs, True, d_st) == 0
+            assert int(d_st.abs().sum().item()) == 0 and torch.equal(d_out[:nf * fs], d_src[k])
+            # (how many frames the waves beside the executor get is the dispatcher's habit -- all of them, on every box so far --, not
+            #  a promise: what they leave is verified behind the executor)
+            assert engine.checksums_followed() >= nf * 3 // 4, (turn, engine.checksums_followed())
+        engine.set_kernel_choice(xxh64=4)
+        d_comp, csize, d_c, d_d, c = arch[0]
+        for at, code in ((int(c[8]) - 1, 22), (int(c[20]) - 9, None)):       # a stored checksum; a payload byte in front of it
+            d_comp[at] = d_comp[at] ^ 4
+            rc = engine.decode_frames_dev(d_comp, csize, d_c, d_d, 0, nf, d_out, nf * fs, True, d_st)
+            st = d_st.cpu().numpy()
+            f = 7 if code else 19
+            assert rc < 0 and st[f] != 0 and not np.delete(st, f).any() and (code is None or st[f] == code)
+            assert nf * 3 // 4 <= engine.checksums_followed() <= nf - 1
+            d_comp[at] = d_comp[at] ^ 4
+    finally:
+        engine.set_kernel_choice(reset=0)

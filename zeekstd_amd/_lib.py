@@ -38,6 +38,7 @@ _sig = {
     "zk_engine_set_profiling": (C.c_int, [_P, C.c_int]),
     "zk_engine_set_fse_kernel": (C.c_int, [_P, C.c_int]),
     "zk_engine_set_kernel_choice": (C.c_int, [_P, C.c_int, C.c_int]),
+    "zk_engine_checksums_followed": (C.c_uint64, [_P]),
     "zk_engine_kernel_count": (C.c_int, []),
     "zk_engine_kernel_name": (C.c_char_p, [C.c_int]),
     "zk_engine_kernel_times": (C.c_int, [_P, _P, C.c_int]),

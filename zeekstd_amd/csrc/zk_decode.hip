@@ -784,13 +784,46 @@ extern "C" void zk_debug_clocks(unsigned long long *out, int reset)
 #else
 #define ZK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
+// A value every lane of the wave holds alike, said so to the compiler: it lives in a scalar register from here on.  (What the executor
+// reads from the frame's and the block's descriptors arrives through vector loads -- the descriptors are written by other kernels,
+// nothing tells the compiler they are read-only -- and stayed in vector registers for the whole kernel: ~30 of them.)
+__device__ __forceinline__ uint32_t zk_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t zk_uni(uint64_t v) { return (uint64_t)zk_uni((uint32_t)v) | ((uint64_t)zk_uni((uint32_t)(v >> 32)) << 32); }
+template <typename P> __device__ __forceinline__ P *zk_uni(P *p) { return reinterpret_cast<P *>(zk_uni((uint64_t)(uintptr_t)p)); }
+
+// PROGRESS WORDS (zk_k_xxh64_follow): with `progress` set, lane 0 of a frame's workgroup publishes how many bytes of the frame are
+// complete -- whenever a block ends behind another 2^ZK_PUB_LOG bytes, and at the frame's end -- so that the checksum of a frame can
+// be computed WHILE the frame is being written, by a wave of another kernel on another queue.
+//   The XCDs' L2s are not coherent with each other (MI355X_MICROARCH.md): bytes that have to be seen anywhere on the device need an
+// agent-scope release, `buffer_wbl2 sc1`, the write-back of the whole L2's dirty lines.  Built and measured (16 of them per frame:
+// the executor 10.7 -> 14.0 ms in a kernel trace, everything the checksums gained and more).  ONE L2, though, is coherent by itself: a
+// store that has been acknowledged is in the XCD's L2, and a load from any CU of that XCD that misses its L1 finds it there.  So the
+// word carries the XCD the workgroup runs on (HW_REG_XCC_ID), the executor pays a wait for its own stores (behind the block's
+// barrier every wave has had that wait) and one 8-byte store, and a checksum wave follows exactly the frames whose executors turn out
+// to share ITS XCD -- the dispatcher's observed habit (workgroup b on XCD b % 8, which the checksum kernel's frame order is made for)
+// decides how many frames that is, never whether a byte is right: a frame from another XCD is left to the pass behind the executor.
+constexpr int ZK_PUB_LOG = 17;
+// the word: [31:0] bytes complete, [35:32] XCD + 1 (a word that is 0 says nothing yet), [60] the frame has failed,
+// [61] / [62] set by the checksum wave at its end: verified / hashed and found different
+constexpr uint64_t ZK_PROG_ABORT = 1ull << 60, ZK_PROG_VERIFIED = 1ull << 61, ZK_PROG_MISMATCH = 1ull << 62;
+__device__ __forceinline__ uint32_t zk_xcc_id()
+{
+    uint32_t x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    return x;
+}
+__device__ __forceinline__ void zk_publish(uint64_t *word, uint32_t bytes, uint64_t flags = 0)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(word, flags | ((uint64_t)(zk_xcc_id() + 1) << 32) | bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <int T, bool PFX, int CAPX = 2>
 __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
                                                const uint32_t *ids, const uint64_t *out_off,
                                                const ZkBlock *blocks, const ZkFrameBase *bases,
                                                ZkFrameInfo *infos, const ZkSeqP *seqs,
                                                const uint8_t *lit_scratch, uint8_t *dst,
-                                               const uint8_t *prefix, uint64_t plen)
+                                               const uint8_t *prefix, uint64_t plen, uint64_t *progress)
 {
     // The staged sequences live in an LDS RING of CAP records, slot = block sequence index & (CAP - 1).  A tile retires the
     // jn sequences it has consumed and exactly as many new ones are fetched for the tiles to come -- requested right after
@@ -807,12 +840,18 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
     __shared__ uint32_t s_jn, s_nlong;
     __shared__ uint32_t s_bad[2];                // a lane found a bad record in a tile of this parity (the tile loop's barriers order LDS only)
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
-    const ZkFrameInfo fi = infos[f];
-    if (fi.status != ZK_OK) return;
-    const uint32_t id = ids ? ids[f] : first + f;
-    const uint64_t d_size = d_off[id + 1] - d_off[id];
-    uint8_t *out = dst + (out_off ? out_off[f] : d_off[id] - d_off[first]);     // indexed batches are packed in list order
-    const ZkBlock *fb = blocks + bases[f].block_base;
+    ZkFrameInfo fi = infos[f];
+    fi.status = zk_uni(fi.status); fi.n_blocks = zk_uni(fi.n_blocks); fi.window = zk_uni(fi.window);
+    if (fi.status != ZK_OK) {
+        if (progress && tid == 0) zk_publish(progress + f, 0, ZK_PROG_ABORT);
+        return;
+    }
+    const uint32_t id = zk_uni(ids ? ids[f] : first + f);
+    const uint64_t d_size = zk_uni(d_off[id + 1] - d_off[id]);
+    uint32_t published = 0;                                  // the last published count >> ZK_PUB_LOG
+    if (progress && tid == 0) zk_publish(progress + f, 0);   // (which XCD this is: a checksum wave elsewhere stops waiting for the frame)
+    uint8_t *out = zk_uni(dst + (out_off ? out_off[f] : d_off[id] - d_off[first]));     // indexed batches are packed in list order
+    const ZkBlock *fb = zk_uni(blocks + bases[f].block_base);
     uint64_t pos = 0;
     uint32_t rep[3] = {1, 4, 8};
     uint32_t err = ZK_OK;
@@ -822,17 +861,18 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
 
     for (uint32_t bk = 0; bk < fi.n_blocks && err == ZK_OK; bk++) {
         const ZkBlock &b = fb[bk];
-        if (b.status != ZK_OK) { err = b.status; break; }
-        if (pos + b.out_size > d_size) { err = ZK_E_CORRUPTION; break; }
+        const uint32_t b_status = zk_uni(b.status), b_out_size = zk_uni(b.out_size), b_type = zk_uni((uint32_t)b.type);
+        if (b_status != ZK_OK) { err = b_status; break; }
+        if (pos + b_out_size > d_size) { err = ZK_E_CORRUPTION; break; }
         uint8_t *bout = out + pos;
-        if (b.type <= 1) {
+        if (b_type <= 1) {
             // raw / RLE block: bytes up to the first 16-byte boundary of the output, 16-byte stores (the source of a raw
             // block is read with whatever alignment it has), bytes behind the last boundary
-            const uint8_t *s = comp + b.src;
-            const uint32_t n = b.bsize;
+            const uint8_t *s = comp + zk_uni(b.src);
+            const uint32_t n = zk_uni(b.bsize);
             const uint32_t head0 = (uint32_t)((0 - (uintptr_t)bout) & 15), head = head0 < n ? head0 : n;
             const uint32_t n16 = (n - head) >> 4;
-            if (b.type == 0) {
+            if (b_type == 0) {
                 if (tid < head) bout[tid] = s[tid];
                 for (uint32_t i = tid; i < n16; i += T) {
                     uint4 v;
@@ -847,10 +887,11 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                 for (uint32_t i = head + (n16 << 4) + tid; i < n; i += T) bout[i] = (uint8_t)v1;
             }
         } else {
-            const ZkSeqP *sq = seqs + b.seq_base;
-            const uint8_t *lit = b.lit_type >= 2 ? lit_scratch + b.lit_base : comp + b.src + b.lit_off;
-            const uint32_t lit_mask = b.lit_type == 1 ? 0u : 0x7fffffffu;       // RLE literals: every index reads byte 0
-            const uint32_t nseq = b.nseq, out_size = b.out_size, lit_regen = b.lit_regen;
+            const ZkSeqP *sq = seqs + zk_uni(b.seq_base);
+            const uint32_t b_lit_type = zk_uni((uint32_t)b.lit_type);
+            const uint8_t *lit = b_lit_type >= 2 ? lit_scratch + zk_uni(b.lit_base) : comp + zk_uni(b.src) + zk_uni(b.lit_off);
+            const uint32_t lit_mask = b_lit_type == 1 ? 0u : 0x7fffffffu;       // RLE literals: every index reads byte 0
+            const uint32_t nseq = zk_uni(b.nseq), out_size = b_out_size, lit_regen = zk_uni(b.lit_regen);
             // record idx of the block (idx == nseq: the trailing-literals pseudo sequence) -> staged form, offsets resolved
             // and validated.  Without a prefix an offset is bounded by the bytes produced so far and by the frame's window;
             // with one (ZSTD_DCtx_refPrefix: the prefix sits right before the frame) only by availability, which is all
@@ -885,7 +926,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
             uint32_t tpar = 0;
             while (err == ZK_OK && ts < out_size) {
                 const uint32_t nl = staged_end - ja;
-                const uint32_t cap_end = S[(staged_end - 1) & M].out_end;
+                const uint32_t cap_end = zk_uni(S[(staged_end - 1) & M].out_end);
                 const uint32_t te = ts + T * ZK_EXEC_B < cap_end ? ts + T * ZK_EXEC_B : cap_end;
                 // 1a. the map starts empty: the lane of a sequence leaves, at the bytes where its two runs start, the word that
                 //     run adds to a position (zk_exec_mark_runs); the slot pass below only carries them forward
@@ -912,7 +953,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                 ZK_CLK(1);
                 ZK_LDS_BARRIER();
                 ZK_CLK(2);
-                const uint32_t nlong = s_nlong, jn = s_jn;
+                const uint32_t nlong = zk_uni(s_nlong), jn = zk_uni(s_jn);
                 // the records that take the retired slots: requested now, needed two barriers from here
                 const uint32_t fetch_end = staged_end + jn < nseq + 1 ? staged_end + jn : nseq + 1;
                 ZkSeqP pf0[NPF], pf1[NPF];
@@ -922,7 +963,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                     pf0[u] = 0; pf1[u] = 0;
                     if (idx < fetch_end) fetch(idx, pf0[u], pf1[u]);
                 }
-                const uint32_t next_prev_end = jn ? S[(ja + jn - 1) & M].out_end : prev_end;
+                const uint32_t next_prev_end = jn ? zk_uni(S[(ja + jn - 1) & M].out_end) : prev_end;
                 for (uint32_t k = 0; k < nlong; k++) {       // sequences spanning many slots: all lanes
                     const uint32_t idx = longlist[k];
                     const uint32_t end = S[idx & M].out_end;
@@ -1010,15 +1051,23 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                 ZK_CLK(2);
             }
             if (err == ZK_OK) {
-                uint32_t r0 = zk_rep_resolve(b.rep_out[0], rep), r1 = zk_rep_resolve(b.rep_out[1], rep), r2 = zk_rep_resolve(b.rep_out[2], rep);
+                uint32_t r0 = zk_rep_resolve(zk_uni(b.rep_out[0]), rep), r1 = zk_rep_resolve(zk_uni(b.rep_out[1]), rep), r2 = zk_rep_resolve(zk_uni(b.rep_out[2]), rep);
                 rep[0] = r0; rep[1] = r1; rep[2] = r2;
             }
         }
-        pos += b.out_size;
+        pos += b_out_size;
         __syncthreads();                      // block bytes visible before the next block reads history
+        if (progress && ((uint32_t)pos >> ZK_PUB_LOG) != published) {
+            published = (uint32_t)pos >> ZK_PUB_LOG;
+            if (tid == 0) zk_publish(progress + f, (uint32_t)pos);
+        }
     }
     if (err == ZK_OK && pos != d_size) err = ZK_E_CORRUPTION;
     if (tid == 0 && err != ZK_OK) infos[f].status = err;
+    if (progress && tid == 0) {                              // (a frame that ends well: behind the last block's barrier)
+        if (err == ZK_OK) zk_publish(progress + f, (uint32_t)d_size);
+        else zk_publish(progress + f, 0, ZK_PROG_ABORT);
+    }
 #ifdef ZK_EXEC_CLOCKS
     ZK_CLK(0);
     if ((tid & 63) == 0) for (int i = 0; i < 8; i++) atomicAdd(&zk_dbg_clk[i], clk_[i]);
@@ -1095,11 +1144,12 @@ __global__ __launch_bounds__(64) void zk_k_xxh64(const uint8_t *data, const uint
 // 128 waves for 2048 frames, a lane loading its own 8 bytes of every stripe, 24 stripes per batch, two batches under way.
 constexpr int ZK_XXW = 24;
 __global__ __launch_bounds__(64) void zk_k_xxh64_wide(const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
-                                                      ZkFrameInfo *infos, uint64_t *hashes)
+                                                      ZkFrameInfo *infos, uint64_t *hashes, const uint64_t *skip)
 {
     const uint32_t lane = threadIdx.x, f = blockIdx.x * 16 + (lane >> 2), kl = lane & 3;
     bool live = f < count;
     if (live && infos && !(infos[f].status == ZK_OK && infos[f].checksum_flag)) live = false;
+    if (live && skip && (skip[f] & ZK_PROG_VERIFIED)) live = false;       // zk_k_xxh64_follow has verified this frame
     const uint32_t fa = live ? f : 0;                       // (a lane without a frame reads frame 0 and keeps nothing)
     const uint8_t *p = data + (d_off[first + fa] - d_off[first]);
     const uint64_t len = d_off[first + fa + 1] - d_off[first + fa];
@@ -1219,14 +1269,160 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     zk_xxh64_lean_body<12>(data, d_off, first, count, infos, hashes);
 }
 
-// per-frame status words + first failing frame ((frame << 32) | code, min over frames)
-__global__ __launch_bounds__(256) void zk_k_status(const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, unsigned long long *first_err)
+// The checksums of a large batch WHILE the executor writes it (zk_engine.hip launches this kernel on the context's second queue
+// beside zk_k_exec).  A frame's four chains are 65 536 dependent rounds per 2 MiB whoever runs them (2.75 ms behind an 8 ms
+// executor: a fifth of the step); but the first byte of a frame is final milliseconds before its last one.  The layout of
+// zk_k_xxh64_lean -- sixteen frames per wave, 64 registers: a wave that fits beside four executor waves of 96 on a SIMD -- with the
+// sixteen frames advancing together behind the slowest of their executors' progress words (zk_publish above: relaxed agent-scope
+// polls, one invalidation of this CU's L1 per step forward, plain loads behind it).  Wave g takes the frames g % 8 + 8 k of its
+// group of 128: the frames whose executors the dispatcher puts on XCD g % 8, where it puts this wave too -- if it does (see above).
+//   Nothing depends on this kernel: a frame it verifies is marked ZK_PROG_VERIFIED in its progress word; every other frame --
+// its executor ran on another XCD, never came (the two kernels were serialised: a profiler, one hardware queue), the wave gave up
+// after ZK_FOLLOW_PATIENCE without any news, the hash differs from the frame's Content_Checksum for whatever reason -- is left to
+// the pass behind the executor (zk_k_xxh64_wide with `skip`), which alone reports ZK_E_CHECKSUM_WRONG.  All loops are left by the
+// whole wave on a wave-uniform verdict (the trap of the per-lane exit from a polling loop).
+#ifndef ZK_FOLLOW_W
+#define ZK_FOLLOW_W 7
+#endif
+constexpr uint64_t ZK_FOLLOW_PATIENCE = 5000000;             // wall_clock64 ticks (100 MHz): 50 ms without any progress
+template <int W>
+__device__ __forceinline__ void zk_xxh64_follow_body(const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
+                                                      const ZkFrameInfo *infos, uint64_t *progress)
+{
+    const uint32_t lane = threadIdx.x, g = blockIdx.x, kl = lane & 3;
+    const uint32_t here = zk_xcc_id() + 1;
+    uint64_t t_news = wall_clock64();
+    // Which frames run on this XCD?  The dispatcher deals a kernel's workgroups round the XCDs, b -> (b + r) % 8, with a start r that
+    // differs from launch to launch (tools/ubench/xcc_map.hip): the first executor whose word appears tells r, and of the 128 frames
+    // of this wave's group the class c = (this XCD - r) % 8 is the one to follow.  (A habit, not a promise: every frame's own word is
+    // checked again below.)
+    uint32_t rot;
+    for (;;) {
+        uint32_t cand = 0xFFFFFFFFu;
+        if (lane < count) {
+            const uint64_t w = __hip_atomic_load(progress + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (w != 0) cand = (((uint32_t)(w >> 32) & 15u) - 1u - lane) & 7u;
+        }
+        const unsigned long long m = __ballot(cand != 0xFFFFFFFFu);
+        if (m) { rot = (uint32_t)__builtin_amdgcn_readlane(cand, __builtin_ctzll(m)); break; }
+        const uint32_t waited = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wall_clock64() - t_news > ZK_FOLLOW_PATIENCE));
+        if (waited) return;
+        __builtin_amdgcn_s_sleep(20);
+    }
+    const uint32_t f = (g >> 3) * 128 + ((here - 1u - rot) & 7u) + 8 * (lane >> 2);
+    bool live = f < count;
+    if (live && !(infos[f].status == ZK_OK && infos[f].checksum_flag)) live = false;
+    const uint32_t fa = live ? f : 0;                       // (a lane without a frame reads frame 0 and keeps nothing)
+    const uint8_t *p = data + (d_off[first + fa] - d_off[first]);
+    const uint64_t len = d_off[first + fa + 1] - d_off[first + fa];
+    const uint32_t nstripes = live ? (uint32_t)(len >> 5) : 0;
+    uint64_t acc = kl == 0 ? XP1 + XP2 : kl == 1 ? XP2 : kl == 2 ? 0 : 0 - XP1;
+    auto wave_min = [](uint32_t v) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { const uint32_t o = __shfl_xor(v, m, 64); v = o < v ? o : v; }
+        return (uint32_t)__builtin_amdgcn_readfirstlane(v);
+    };
+    // the frame's word: bytes complete (0 before its executor has started), or 0xFFFFFFFF for "not mine (any more)": failed, or
+    // written through another XCD's L2
+    auto news = [&]() {
+        uint32_t have = 0xFFFFFFFFu;
+        if (live) {
+            const uint64_t w = __hip_atomic_load(progress + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((w & ZK_PROG_ABORT) || (w != 0 && ((uint32_t)(w >> 32) & 15u) != here)) live = false;
+            else have = (uint32_t)w;
+        }
+        return have;
+    };
+    uint32_t s = 0, common = 0;
+    {
+        const uint32_t least = wave_min(live ? nstripes : 0xFFFFFFFFu);
+        if (least == 0xFFFFFFFFu) return;                   // no frame to hash in this wave
+        common = least - least % (2 * W);                   // the stripes every frame has, in whole double batches (a frame that drops out later changes nothing)
+    }
+    const uint8_t *q = p + 8 * kl;
+    uint64_t wa[W], wb[W];
+    // A: the sixteen frames together, as far as the slowest executor has come
+    while (s < common) {
+        const uint32_t have = news();
+        if (__ballot(live) == 0) return;
+        uint32_t upto = wave_min(have == 0xFFFFFFFFu ? have : have >> 5);
+        upto = upto < common ? upto - upto % (2 * W) : common;
+        if (upto <= s) {
+            const uint32_t waited = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wall_clock64() - t_news > ZK_FOLLOW_PATIENCE));
+            if (waited) return;                             // (the whole wave: `waited` is scalar)
+            __builtin_amdgcn_s_sleep(100);
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (s_waitcnt vmcnt(0); buffer_inv sc1: this CU's L1 may hold the buffer's bytes of an earlier decode)
+        t_news = wall_clock64();
+#pragma unroll
+        for (int u = 0; u < W; u++) wa[u] = zk_ld64(q + 32 * (uint64_t)(s + u));
+        for (uint32_t x = s; x < upto; x += 2 * W) {
+#pragma unroll
+            for (int u = 0; u < W; u++) wb[u] = zk_ld64(q + 32 * (uint64_t)(x + W + u));
+#pragma unroll
+            for (int u = 0; u < W; u++) acc = zk_xround(acc, wa[u]);
+            const uint32_t nx = x + 2 * W < upto ? x + 2 * W : s;       // (the last round reads the step's first batch again)
+#pragma unroll
+            for (int u = 0; u < W; u++) wa[u] = zk_ld64(q + 32 * (uint64_t)(nx + u));
+#pragma unroll
+            for (int u = 0; u < W; u++) acc = zk_xround(acc, wb[u]);
+        }
+        s = upto;
+    }
+    // B: what is left of every frame once ALL of it is there
+    for (;;) {
+        const uint32_t have = news();
+        const bool pending = live && have < (uint32_t)len;
+        if (__ballot(pending) == 0) break;
+        const uint32_t waited = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wall_clock64() - t_news > ZK_FOLLOW_PATIENCE));
+        if (waited) return;
+        __builtin_amdgcn_s_sleep(100);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (uint32_t i = common; i < nstripes; i++) acc = zk_xround(acc, zk_ld64(q + ((uint64_t)i << 5)));
+    const uint32_t base = lane & ~3u;
+    const uint64_t v1 = __shfl(acc, base, 64), v2 = __shfl(acc, base + 1, 64), v3 = __shfl(acc, base + 2, 64), v4 = __shfl(acc, base + 3, 64);
+    if (kl != 0 || !live) return;
+    uint64_t h;
+    if (len >= 32) {
+        h = zk_rotl64(v1, 1) + zk_rotl64(v2, 7) + zk_rotl64(v3, 12) + zk_rotl64(v4, 18);
+        h = (h ^ zk_xround(0, v1)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v2)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v3)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v4)) * XP1 + XP4;
+    } else h = XP5;
+    h += len;
+    const uint8_t *t = p + ((uint64_t)nstripes << 5), *end = p + len;
+    while (t + 8 <= end) { h ^= zk_xround(0, zk_ld64(t)); h = zk_rotl64(h, 27) * XP1 + XP4; t += 8; }
+    if (t + 4 <= end) { h ^= (uint64_t)zk_rd32(t) * XP1; h = zk_rotl64(h, 23) * XP2 + XP3; t += 4; }
+    while (t < end) { h ^= (uint64_t)(*t) * XP5; h = zk_rotl64(h, 11) * XP1; t++; }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    progress[f] |= (uint32_t)h == infos[f].checksum ? ZK_PROG_VERIFIED : ZK_PROG_MISMATCH;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void zk_k_xxh64_follow(const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
+                                                                                                    const ZkFrameInfo *infos, uint64_t *progress)
+{
+    zk_xxh64_follow_body<ZK_FOLLOW_W>(data, d_off, first, count, infos, progress);
+}
+
+// per-frame status words + first failing frame ((frame << 32) | code, min over frames); with `followed`: the number of frames whose
+// checksums zk_k_xxh64_follow verified
+__global__ __launch_bounds__(256) void zk_k_status(const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, unsigned long long *first_err,
+                                                   const uint64_t *progress, unsigned long long *followed)
 {
     uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= count) return;
     uint32_t st = infos[f].status;
     if (status_out) status_out[f] = (int32_t)st;
     if (st != ZK_OK) atomicMin(first_err, ((unsigned long long)f << 32) | st);
+    if (progress) {
+        const uint64_t w = progress[f];
+        const unsigned long long m = __ballot((w & ZK_PROG_VERIFIED) != 0), m2 = __ballot((w & ZK_PROG_MISMATCH) != 0);
+        if ((threadIdx.x & 63) == (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x & 63) && (m | m2))
+            atomicAdd(followed, (unsigned long long)__popcll(m) + ((unsigned long long)__popcll(m2) << 32));
+    }
 }
 
 
@@ -1362,9 +1558,9 @@ __global__ __launch_bounds__(256) void zk_k_small_publish(const ZkFrameInfo *inf
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-void zk_launch_status(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, uint64_t *first_err)
+void zk_launch_status(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, uint64_t *first_err, const uint64_t *progress, uint64_t *followed)
 {
-    hipLaunchKernelGGL(zk_k_status, dim3((count + 255) / 256), dim3(256), 0, st, infos, count, status_out, (unsigned long long *)first_err);
+    hipLaunchKernelGGL(zk_k_status, dim3((count + 255) / 256), dim3(256), 0, st, infos, count, status_out, (unsigned long long *)first_err, progress, (unsigned long long *)followed);
 }
 void zk_launch_walk(hipStream_t st, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
                     uint32_t count, const uint32_t *ids, const uint64_t *out_off, uint64_t dst_cap, const ZkFrameBase *bases, ZkBlock *blocks, ZkFrameInfo *infos)
@@ -1418,14 +1614,17 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
 }
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeqP *seqs,
-                    const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen, const ZkKernelChoice &k, bool dense)
+                    const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen, const ZkKernelChoice &k, bool dense, uint64_t *progress)
 {
     // one workgroup per frame: the tile width trades bytes in flight per frame against workgroups per CU
     // (measured on 2 MiB frames: 2048 frames -> 256 lanes.  128 lanes run the kernel alone in 8.9 instead of 9.5 ms -- eight
     // 2-wave workgroups per CU hold all 2048 frames in one round -- but leave no room for the neighbouring batch: with two
     // batches in flight the step is 18.8 ms against 17.2.  1024 frames: 256 lanes 4.95 ms, 128 lanes 6.9; 512 -> 512, 128 -> 1024)
-#define ZK_EXEC_LAUNCH(TT, PP, CC) hipLaunchKernelGGL((zk_k_exec<TT, PP, CC>), dim3(count), dim3(TT), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst, prefix, plen)
+#define ZK_EXEC_LAUNCH(TT, PP, CC) hipLaunchKernelGGL((zk_k_exec<TT, PP, CC>), dim3(count), dim3(TT), (TT) == 256 ? pad : 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst, prefix, plen, progress)
     const int lanes = k.exec_lanes ? k.exec_lanes : count >= 1024 ? 256 : count >= 256 ? 512 : 1024;
+    // 93 registers and 31 000 bytes of LDS: five 256-lane workgroups per CU.  Four of them leave 128 registers on every SIMD (room for
+    // checksum waves, zk_k_xxh64_follow); a launch that asks for 2.5 KiB more LDS than the kernel uses gets four
+    const uint32_t pad = k.exec_resident == 4 ? 2560u : 0u;
     if (prefix && plen) {
         if (lanes <= 256) ZK_EXEC_LAUNCH(256, true, 2); else if (lanes == 512) ZK_EXEC_LAUNCH(512, true, 2); else ZK_EXEC_LAUNCH(1024, true, 2);
         return;
@@ -1441,12 +1640,18 @@ void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, 
 #undef ZK_EXEC_LAUNCH
 }
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
-                     ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k)
+                     ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k, const uint64_t *skip)
 {
     // a large batch: sixteen frames per wave (the chains' latency is the same, the instruction slots a sixteenth)
+    if (skip) { hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes, skip); return; }
     if (k.xxh == 3) hipLaunchKernelGGL(zk_k_xxh64_lean, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
-    else if (k.xxh ? k.xxh == 2 : count >= 512) hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
+    else if (k.xxh ? k.xxh == 2 || k.xxh >= 4 : count >= 512) hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes, (const uint64_t *)nullptr);
     else hipLaunchKernelGGL(zk_k_xxh64, dim3(count), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
+}
+void zk_launch_xxh64_follow(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count, const ZkFrameInfo *infos, uint64_t *progress)
+{
+    // eight waves per 128 frames: each takes the frames of one XCD
+    hipLaunchKernelGGL(zk_k_xxh64_follow, dim3(8 * ((count + 127) / 128)), dim3(64), 0, st, data, d_off, first, count, infos, progress);
 }
 
 void zk_launch_small_walk(hipStream_t st, const uint8_t *h_comp, uint64_t comp_bytes, const uint64_t *h_offs, uint32_t count, uint64_t dst_cap,

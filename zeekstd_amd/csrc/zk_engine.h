@@ -11,6 +11,9 @@ enum { ZK_K_WALK_COUNT = 0, ZK_K_SCAN, ZK_K_WALK_FILL, ZK_K_HUF, ZK_K_FSE, ZK_K_
 
 struct zk_devbuf { void *p = nullptr; size_t cap = 0; };
 enum { ZK_MAX_CTX = 6 };
+// synchronous decodes of at least this many frames get their checksums beside the executor (zk_k_xxh64_follow; ZK_CHOICE_XXH64 = 4
+// asks for it whatever the size and the entry point, 1..3 for one of the passes behind the executor)
+constexpr uint32_t ZK_FOLLOW_MIN_FRAMES = 512;
 
 struct zk_engine {
     int device = 0;
@@ -25,7 +28,7 @@ struct zk_engine {
     struct DecCtx {
         hipStream_t st = nullptr, aux = nullptr;
         hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_exec = nullptr;
-        zk_devbuf infos, bases, words, blocks, seqs, lit;
+        zk_devbuf infos, bases, words, blocks, seqs, lit, prog;     // prog: the executor's progress words (zk_k_xxh64_follow)
         uint64_t *h_words = nullptr;
         bool ready = false;
     } dctx[ZK_MAX_CTX];
@@ -44,6 +47,7 @@ struct zk_engine {
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool profiling = false;
     ZkKernelChoice choice;           // zk_engine_set_kernel_choice: all zero = by batch shape
+    uint64_t followed = 0;           // frames of the last finished decode whose checksums zk_k_xxh64_follow verified (zk_engine_checksums_followed)
     int pipe_contexts = 0;           // host pipeline: decode contexts in flight (0 = default) and chunk size, zk_hostpipe_tune
     uint64_t pipe_chunk_bytes = 0;
     hipEvent_t ev_start[ZK_NKERNELS] = {}, ev_stop[ZK_NKERNELS] = {};
@@ -76,6 +80,7 @@ struct zk_dec_args {
     const uint32_t *ids; const uint64_t *out_off;       // frame list (device arrays, both or neither)
     void *d_dst; uint64_t dst_cap; int verify; void *d_frame_status;
     const void *d_prefix; uint64_t prefix_len;
+    bool alone = false;                                 // nothing else of this engine is in flight (the synchronous entry points): zk_k_xxh64_follow
     bool single_queue = false;                          // huf and fse on the context's main queue (the host pipeline overlaps whole chunks instead)
     bool mark_exec = false;                             // record the context's ev_exec behind the executor (output bytes final, checksums pending)
 };

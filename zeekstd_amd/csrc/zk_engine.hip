@@ -63,7 +63,8 @@ extern "C" int zk_engine_set_kernel_choice(zk_engine *e, int what, int value)
     case ZK_CHOICE_FSE_SHARED: if (value < 0 || value > 3) return ZK_ERR_ARGUMENT; k.fse_shared = value; return 0;
     case ZK_CHOICE_EXEC_LANES: if (value != 0 && value != 128 && value != 256 && value != 512 && value != 1024) return ZK_ERR_ARGUMENT; k.exec_lanes = value; return 0;
     case ZK_CHOICE_EXEC_RING: if (value < 0 || value > 2) return ZK_ERR_ARGUMENT; k.exec_ring = value; return 0;
-    case ZK_CHOICE_XXH64: if (value < 0 || value > 3) return ZK_ERR_ARGUMENT; k.xxh = value; return 0;
+    case ZK_CHOICE_XXH64: if (value < 0 || value > 4) return ZK_ERR_ARGUMENT; k.xxh = value; return 0;
+    case ZK_CHOICE_EXEC_RESIDENT: if (value != 0 && value != 4 && value != 5) return ZK_ERR_ARGUMENT; k.exec_resident = value; return 0;
     case ZK_CHOICE_SMALL_PATH: if (value < 0 || value > 2) return ZK_ERR_ARGUMENT; k.small_path = value; return 0;
     case ZK_CHOICE_PIPE_CONTEXTS: if (value < 0 || value > ZK_MAX_CTX) return ZK_ERR_ARGUMENT; e->pipe_contexts = value; zk_hostpipe_tune(e); return 0;
     case ZK_CHOICE_PIPE_CHUNK_MIB: if (value < 0 || value > 4096) return ZK_ERR_ARGUMENT; e->pipe_chunk_bytes = (uint64_t)value << 20; zk_hostpipe_tune(e); return 0;
@@ -71,6 +72,7 @@ extern "C" int zk_engine_set_kernel_choice(zk_engine *e, int what, int value)
     }
 }
 extern "C" int zk_engine_set_fse_kernel(zk_engine *e, int mode) { return zk_engine_set_kernel_choice(e, ZK_CHOICE_FSE_OWN, mode); }
+extern "C" uint64_t zk_engine_checksums_followed(const zk_engine *e) { return e ? e->followed : 0; }
 extern "C" int zk_engine_kernel_count(void) { return ZK_NKERNELS; }
 extern "C" const char *zk_engine_kernel_name(int k)
 {
@@ -160,7 +162,7 @@ extern "C" void zk_engine_destroy(zk_engine *e)
     for (int k = 0; k < ZK_NKERNELS; k++) { if (e->ev_start[k]) (void)hipEventDestroy(e->ev_start[k]); if (e->ev_stop[k]) (void)hipEventDestroy(e->ev_stop[k]); }
     for (int i = 0; i < ZK_MAX_CTX; i++) {
         zk_engine::DecCtx &c = e->dctx[i];
-        for (zk_devbuf *b : {&c.infos, &c.bases, &c.words, &c.blocks, &c.seqs, &c.lit}) if (b->p) (void)hipFree(b->p);
+        for (zk_devbuf *b : {&c.infos, &c.bases, &c.words, &c.blocks, &c.seqs, &c.lit, &c.prog}) if (b->p) (void)hipFree(b->p);
         if (c.h_words) (void)hipHostFree(c.h_words);
         for (hipEvent_t ev : {c.ev_fork, c.ev_join, c.ev_exec}) if (ev) (void)hipEventDestroy(ev);
         if (c.aux) (void)hipStreamDestroy(c.aux);
@@ -245,6 +247,24 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
 
     c.h_words[3] = ~0ull;
     ZK_HIP(hipMemcpyAsync(words + 3, c.h_words + 3, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    // checksums WHILE the executor writes (zk_k_xxh64_follow, zk_decode.hip): the executor publishes a progress word per frame, the
+    // checksum waves run on the context's second queue beside it, the ordinary pass behind the executor takes what they left
+    // Who gets them: a batch that has the device to itself (the synchronous entry points) -- 16.5 -> 15.5 ms on 4 GiB; batches in
+    // flight (zk_decode_submit_dev, the host pipeline) hide the checksum pass of one behind the entropy stage of the next, and their
+    // executors keep five workgroups per CU instead of the four that leave room for a checksum wave.
+    const bool follow = a.verify && !e->profiling && !a.single_queue &&
+                        (e->choice.xxh == 4 || (e->choice.xxh == 0 && a.alone && count >= ZK_FOLLOW_MIN_FRAMES));
+    ZkKernelChoice kc = e->choice;
+    if (follow && !kc.exec_resident) kc.exec_resident = 4;
+    uint64_t *prog = nullptr;
+    if (follow) {
+        zk_engine::DecCtx &x = e->dctx[c.slot];
+        if ((rc = zk_devbuf_reserve(e, x.prog, (size_t)count * sizeof(uint64_t)))) return rc;
+        if ((rc = zk_dec_ctx_aux(e, c.slot))) return rc;
+        prog = (uint64_t *)x.prog.p;
+        ZK_HIP(hipMemsetAsync(prog, 0, (size_t)count * sizeof(uint64_t), st));
+    }
+    ZK_HIP(hipMemsetAsync(words + 6, 0, sizeof(uint64_t), st));
     { zk_kernel_timer t(e, ZK_K_WALK_FILL, st); zk_launch_walk(st, comp, a.comp_size, c_off, d_off, first, count, a.ids, a.out_off, a.dst_cap, bases, blocks, infos); }
     // literals (huf) and sequences (fse) of a block are independent: the two kernels run side by side on two queues;
     // with per-kernel timing on they are serialised instead
@@ -261,12 +281,26 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
         zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, n_own, seqs, e->choice, count);
         ZK_HIP(hipStreamWaitEvent(st, x.ev_join, 0));
     }
-    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, a.ids, a.out_off, blocks, bases, infos, seqs, lit, (uint8_t *)a.d_dst, (const uint8_t *)a.d_prefix, a.d_prefix ? a.prefix_len : 0, e->choice, dense); }
+    const uint64_t *x_off = a.out_off ? a.out_off : d_off;   // packed indexed output: out_off (count + 1 prefix sums) doubles as the d_off of the checksum kernels
+    const uint32_t x_first = a.out_off ? 0 : first;
+    if (follow) {
+        zk_engine::DecCtx &x = e->dctx[c.slot];
+        ZK_HIP(hipEventRecord(x.ev_fork, st));               // (in front of the executor: the checksum waves start with it)
+        ZK_HIP(hipStreamWaitEvent(x.aux, x.ev_fork, 0));
+    }
+    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, a.ids, a.out_off, blocks, bases, infos, seqs, lit, (uint8_t *)a.d_dst, (const uint8_t *)a.d_prefix, a.d_prefix ? a.prefix_len : 0, kc, dense, prog); }
     if (a.mark_exec) ZK_HIP(hipEventRecord(c.ev_exec, st));
-    // packed indexed output: out_off (count + 1 prefix sums) doubles as the d_off of the checksum kernel
-    if (a.verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)a.d_dst, a.out_off ? a.out_off : d_off, a.out_off ? 0 : first, count, infos, nullptr, e->choice); }
-    { zk_kernel_timer t(e, ZK_K_STATUS, st); zk_launch_status(st, infos, count, (int32_t *)a.d_frame_status, words + 3); }
-    ZK_HIP(hipMemcpyAsync(c.h_words + 3, words + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    if (follow) {
+        // enqueued BEHIND the executor's launch: were the two queues ever served one after the other, the checksum waves would find
+        // finished frames, not wait (ZK_FOLLOW_PATIENCE) for an executor that cannot start
+        zk_engine::DecCtx &x = e->dctx[c.slot];
+        zk_launch_xxh64_follow(x.aux, (const uint8_t *)a.d_dst, x_off, x_first, count, infos, prog);
+        ZK_HIP(hipEventRecord(x.ev_join, x.aux));
+        ZK_HIP(hipStreamWaitEvent(st, x.ev_join, 0));
+        zk_launch_xxh64(st, (const uint8_t *)a.d_dst, x_off, x_first, count, infos, nullptr, e->choice, prog);
+    } else if (a.verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)a.d_dst, x_off, x_first, count, infos, nullptr, e->choice); }
+    { zk_kernel_timer t(e, ZK_K_STATUS, st); zk_launch_status(st, infos, count, (int32_t *)a.d_frame_status, words + 3, prog, words + 6); }
+    ZK_HIP(hipMemcpyAsync(c.h_words + 3, words + 3, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     return 0;
 }
 int zk_decode_finish(zk_engine *e, zk_dec_ctx &c)
@@ -274,6 +308,7 @@ int zk_decode_finish(zk_engine *e, zk_dec_ctx &c)
     ZK_HIP(hipStreamSynchronize(c.st));
     ZK_HIP(hipGetLastError());
     zk_profile_collect(e);
+    e->followed = c.h_words[6] & 0xFFFFFFFFull;          // (the high half counts frames the checksum waves hashed and found different)
     if (c.h_words[3] != ~0ull) return -(int)(uint32_t)(c.h_words[3] & 0xFFFFFFFFu);
     return 0;
 }
@@ -285,7 +320,9 @@ static int zk_decode_impl(zk_engine *e, const zk_dec_args &a, void *stream)
     if (e->slot_busy[0]) return ZK_ERR_ARGUMENT;            // a submitted batch still owns context 0: zk_decode_wait first
     ZK_HIP(hipSetDevice(e->device));
     zk_dec_ctx c = zk_dec_context(e, 0, stream);
-    int rc = zk_decode_enqueue(e, c, a);
+    zk_dec_args b = a;
+    b.alone = !e->slot_busy[1];                             // (a batch submitted on the other context would be its neighbour)
+    int rc = zk_decode_enqueue(e, c, b);
     if (rc) return rc;
     return zk_decode_finish(e, c);
 }

@@ -11,7 +11,9 @@ struct ZkKernelChoice {
     int fse_shared = 0;     // blocks that share tables: 1 zk_k_fse_predef, 2 zk_k_fse_predef_fed, 3 zk_k_fse_sets
     int exec_lanes = 0;     // zk_k_exec tile: 128 / 256 / 512 / 1024 lanes
     int exec_ring = 0;      // 256-lane tiles: 1 a ring of 2 T records, 2 of 4 T
-    int xxh = 0;            // 1 zk_k_xxh64 (a wave per frame), 2 zk_k_xxh64_wide (sixteen frames per wave), 3 zk_k_xxh64_lean (the same in 64 registers)
+    int xxh = 0;            // 1 zk_k_xxh64 (a wave per frame), 2 zk_k_xxh64_wide (sixteen frames per wave), 3 zk_k_xxh64_lean (the same in 64 registers),
+                            // 4 zk_k_xxh64_follow beside the executor (zk_engine.hip)
+    int exec_resident = 0;  // zk_k_exec<256>: workgroups per CU (4 / 5) through LDS the launch asks for and does not use
     int small_path = 0;     // host-pointer decode of <= 64 frames: 1 the general pipeline instead, 2 the small path's entropy roles as two kernels
 };
 
@@ -22,10 +24,15 @@ void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
 void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeqP *seqs, const ZkKernelChoice &k, uint32_t frames = 0);
 void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeqP *seqs,
-                    const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen, const ZkKernelChoice &k, bool dense = false);
+                    const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen, const ZkKernelChoice &k, bool dense = false,
+                    uint64_t *progress = nullptr);      // progress: one word per frame for zk_launch_xxh64_follow (zk_decode.hip: zk_publish)
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
-                     ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k);
-void zk_launch_status(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, uint64_t *first_err);
+                     ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k, const uint64_t *skip = nullptr);
+// the checksums beside the executor that publishes `progress` (launched on another queue); frames it verifies are marked in `progress`,
+// zk_launch_xxh64(..., skip = progress) behind the executor takes the rest
+void zk_launch_xxh64_follow(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count, const ZkFrameInfo *infos, uint64_t *progress);
+void zk_launch_status(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, uint64_t *first_err,
+                      const uint64_t *progress = nullptr, uint64_t *followed = nullptr);
 
 // small batches (a seek): no host round trip, no copy commands -- see zk_decode.hip
 void zk_launch_small_walk(hipStream_t st, const uint8_t *h_comp, uint64_t comp_bytes, const uint64_t *h_offs, uint32_t count, uint64_t dst_cap,

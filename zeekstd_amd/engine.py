@@ -55,7 +55,11 @@ class Engine:
             self._raise(rc)
 
     CHOICES = {"reset": 0, "fse_own": 1, "fse_shared": 2, "exec_lanes": 3, "exec_ring": 4, "xxh64": 5, "small_path": 6,
-               "pipe_contexts": 7, "pipe_chunk_mib": 8}
+               "pipe_contexts": 7, "pipe_chunk_mib": 8, "exec_resident": 9}
+
+    def checksums_followed(self):
+        """Frames of the last finished decode that zk_k_xxh64_follow verified beside the executor (zk_engine_checksums_followed)."""
+        return int(lib.zk_engine_checksums_followed(self._h))
 
     def set_kernel_choice(self, **kw):
         """Pins kernel variants (zk_engine_set_kernel_choice): e.g. set_kernel_choice(fse_shared=2, exec_lanes=256, xxh64=2) runs the
