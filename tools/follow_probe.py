@@ -19,10 +19,10 @@ import bench  # noqa: E402
 
 CHOICES = [
     ("default", {}),
-    ("behind_resident5", {"xxh64": 2}),
-    ("behind_resident4", {"xxh64": 2, "exec_resident": 4}),
-    ("follow_resident4", {"xxh64": 4}),
-    ("follow_resident5", {"xxh64": 4, "exec_resident": 5}),
+    ("fse_beside", {"fse_late": 1}),
+    ("fse_behind", {"fse_late": 2}),
+    ("exec128", {"exec_lanes": 128}),
+    ("exec128_fse_behind", {"exec_lanes": 128, "fse_late": 2}),
 ]
 
 
