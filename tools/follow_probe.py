@@ -19,10 +19,9 @@ import bench  # noqa: E402
 
 CHOICES = [
     ("default", {}),
-    ("fse_beside", {"fse_late": 1}),
-    ("fse_behind", {"fse_late": 2}),
-    ("exec128", {"exec_lanes": 128}),
-    ("exec128_fse_behind", {"exec_lanes": 128, "fse_late": 2}),
+    ("behind_wide", {"xxh64": 2}),
+    ("behind_narrow", {"xxh64": 1}),
+    ("follow", {"xxh64": 4}),
 ]
 
 

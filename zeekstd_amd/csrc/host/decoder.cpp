@@ -210,7 +210,10 @@ size_t Decoder::decompress_with_prefix(uint8_t *buf, size_t len, const uint8_t *
         }
         uint64_t upto = want;
         // streaming reads (this call continues where the cache ends): decode ahead, a batch at a time
-        const bool sequential = cache_count_ && offset_ == cache_d_end_;
+        // (a read at the very start of the archive with nothing decoded yet is how a streaming reader opens -- upstream's Decoder
+        //  after new() / reset(), its bench protocol lib/benches/decompress.rs:27-39 --: it pays for one batch, not for a lone
+        //  first frame and then a batch; a seek sets an offset first)
+        const bool sequential = cache_count_ ? offset_ == cache_d_end_ : offset_ == 0;
         if (sequential || len - progress >= batch_bytes_)
             upto = std::min<uint64_t>(offset_limit_, std::max<uint64_t>(want, offset_ + batch_bytes_));
         fill_cache(upto, want, prefix, prefix_len);

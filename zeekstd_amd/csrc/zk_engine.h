@@ -11,9 +11,9 @@ enum { ZK_K_WALK_COUNT = 0, ZK_K_SCAN, ZK_K_WALK_FILL, ZK_K_HUF, ZK_K_FSE, ZK_K_
 
 struct zk_devbuf { void *p = nullptr; size_t cap = 0; };
 enum { ZK_MAX_CTX = 6 };
-// synchronous decodes of at least this many frames get their checksums beside the executor (zk_k_xxh64_follow; ZK_CHOICE_XXH64 = 4
-// asks for it whatever the size and the entry point, 1..3 for one of the passes behind the executor)
-constexpr uint32_t ZK_FOLLOW_MIN_FRAMES = 512;
+// the checksums of a verified batch beside its executor (zk_k_xxh64_follow) or behind it: zk_follow_wanted (zk_engine.hip);
+// ZK_CHOICE_XXH64 = 4 asks for "beside" whatever the batch looks like, 1..3 for one of the passes behind the executor
+constexpr uint64_t ZK_FOLLOW_MIN_FRAME_BYTES = 512u << 10;
 
 struct zk_engine {
     int device = 0;
@@ -84,6 +84,8 @@ struct zk_dec_args {
     bool single_queue = false;                          // huf and fse on the context's main queue (the host pipeline overlaps whole chunks instead)
     bool mark_exec = false;                             // record the context's ev_exec behind the executor (output bytes final, checksums pending)
 };
+bool zk_follow_wanted(const zk_engine *e, uint32_t count, uint64_t out_bytes, bool alone);
+int zk_dec_ctx_aux(zk_engine *e, int slot);             // the context's second queue + fork / join events, on first use
 int zk_dec_ctx_ready(zk_engine *e, int slot);           // creates the context's queues / events on first use
 zk_dec_ctx zk_dec_context(zk_engine *e, int slot, void *stream);
 int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a);

@@ -196,7 +196,7 @@ int zk_dec_ctx_ready(zk_engine *e, int slot)
 }
 // the second queue of a context (huf || fse of one batch) exists only once a batch asked for it: the host pipeline overlaps
 // whole chunks on one queue per context, and every stream the process owns competes for the runtime's few hardware queues
-static int zk_dec_ctx_aux(zk_engine *e, int slot)
+int zk_dec_ctx_aux(zk_engine *e, int slot)
 {
     zk_engine::DecCtx &c = e->dctx[slot];
     if (c.aux) return 0;
@@ -209,6 +209,22 @@ zk_dec_ctx zk_dec_context(zk_engine *e, int slot, void *stream)
 {
     zk_engine::DecCtx &c = e->dctx[slot];
     return zk_dec_ctx{slot, slot == 0 && stream ? (hipStream_t)stream : c.st, c.ev_exec, c.infos, c.bases, c.words, c.blocks, c.seqs, c.lit, c.h_words};
+}
+
+// Where the checksums of a verified batch run: beside the executor (zk_k_xxh64_follow) or behind it.  Measured on 16 / 128 / 512 /
+// 2048 frames of 2 MiB (profiles/r04_follow_by_batch_size.txt; ms one batch at a time | two in flight; behind = the better of
+// the two passes behind the executor):   16: 4.27 -> 3.50 | 2.19 -> 1.91     128: 5.20 -> 5.77 | 3.03 -> 3.07
+//                                       512: 6.48 -> 6.76 | 5.32 -> 5.13    2048: 16.7 -> 15.7 | 14.56 -> 14.49 (at four executor
+// workgroups per CU; five, the in-flight default, and a checksum wave do not fit a SIMD).  A few frames leave most CUs to the checksum
+// waves; a batch that fills the device alone trades 2.7 ms of an idle device for 1.7 ms of the executor; in between a frame IS a
+// workgroup and the slowest one -- the one that shares its SIMD -- ends the kernel.  Frames of less than 512 KiB are short chains.
+bool zk_follow_wanted(const zk_engine *e, uint32_t count, uint64_t out_bytes, bool alone)
+{
+    if (e->profiling) return false;                         // (per-kernel timing serialises the kernels)
+    if (e->choice.xxh) return e->choice.xxh == 4;
+    if (out_bytes < (uint64_t)count * ZK_FOLLOW_MIN_FRAME_BYTES) return false;
+    if (count <= 64) return true;
+    return alone ? count >= 1024 : count < 1024;
 }
 
 // Enqueue the whole decode on the context's queues.  Blocks the host once, for the block / sequence / literal totals
@@ -249,11 +265,7 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
     ZK_HIP(hipMemcpyAsync(words + 3, c.h_words + 3, sizeof(uint64_t), hipMemcpyHostToDevice, st));
     // checksums WHILE the executor writes (zk_k_xxh64_follow, zk_decode.hip): the executor publishes a progress word per frame, the
     // checksum waves run on the context's second queue beside it, the ordinary pass behind the executor takes what they left
-    // Who gets them: a batch that has the device to itself (the synchronous entry points) -- 16.5 -> 15.5 ms on 4 GiB; batches in
-    // flight (zk_decode_submit_dev, the host pipeline) hide the checksum pass of one behind the entropy stage of the next, and their
-    // executors keep five workgroups per CU instead of the four that leave room for a checksum wave.
-    const bool follow = a.verify && !e->profiling && !a.single_queue &&
-                        (e->choice.xxh == 4 || (e->choice.xxh == 0 && a.alone && count >= ZK_FOLLOW_MIN_FRAMES));
+    const bool follow = a.verify && zk_follow_wanted(e, count, c.h_words[5], a.alone);
     ZkKernelChoice kc = e->choice;
     if (follow && !kc.exec_resident) kc.exec_resident = 4;
     uint64_t *prog = nullptr;

@@ -444,9 +444,27 @@ static int zk_decode_small(zk_engine *e, zk_hostpipe *hp, const zk_host_src &src
     uint32_t groups = (block_cap + 15) / 16;
     if (groups > 32) groups = 32;
     zk_launch_small_entropy(st, comp, blocks, words, (uint8_t *)c.lit.p, (ZkSeqP *)c.seqs.p, groups, e->choice.small_path == 2);
+    // long frames (a handful of 2 MiB ones: configs[0]): their checksum chains -- 2.9 ms per 2 MiB, twice what the executor takes --
+    // start with the executor, on the context's second queue (zk_k_xxh64_follow; zk_follow_wanted)
+    uint64_t *prog = nullptr;
+    if (verify && zk_follow_wanted(e, count, dsz, true)) {
+        zk_engine::DecCtx &x = e->dctx[0];
+        if ((rc = zk_devbuf_reserve(e, x.prog, (size_t)count * sizeof(uint64_t)))) return rc;
+        if ((rc = zk_dec_ctx_aux(e, 0))) return rc;
+        prog = (uint64_t *)x.prog.p;
+        ZK_HIP(hipMemsetAsync(prog, 0, (size_t)count * sizeof(uint64_t), st));
+        ZK_HIP(hipEventRecord(x.ev_fork, st));
+        ZK_HIP(hipStreamWaitEvent(x.aux, x.ev_fork, 0));
+    }
     zk_launch_exec(st, comp, d_offs + count + 1, 0, count, nullptr, nullptr, blocks, (const ZkFrameBase *)c.bases.p, infos, (const ZkSeqP *)c.seqs.p,
-                   (const uint8_t *)c.lit.p, (uint8_t *)s.d_out.p, (const uint8_t *)d_prefix, d_prefix ? prefix_len : 0, e->choice);
-    if (verify) zk_launch_xxh64(st, (const uint8_t *)s.d_out.p, d_offs + count + 1, 0, count, infos, nullptr, e->choice);
+                   (const uint8_t *)c.lit.p, (uint8_t *)s.d_out.p, (const uint8_t *)d_prefix, d_prefix ? prefix_len : 0, e->choice, false, prog);
+    if (prog) {
+        zk_engine::DecCtx &x = e->dctx[0];
+        zk_launch_xxh64_follow(x.aux, (const uint8_t *)s.d_out.p, d_offs + count + 1, 0, count, infos, prog);
+        ZK_HIP(hipEventRecord(x.ev_join, x.aux));
+        ZK_HIP(hipStreamWaitEvent(st, x.ev_join, 0));
+        zk_launch_xxh64(st, (const uint8_t *)s.d_out.p, d_offs + count + 1, 0, count, infos, nullptr, e->choice, prog);
+    } else if (verify) zk_launch_xxh64(st, (const uint8_t *)s.d_out.p, d_offs + count + 1, 0, count, infos, nullptr, e->choice);
     zk_launch_small_publish(st, infos, d_offs, count, (const uint8_t *)s.d_out.p, dsz ? h_out : nullptr, (int32_t *)s.d_st.p, h_status, words, hp->pin_flag, gen);
     // completion: the last workgroup of the publish kernel writes the generation into pinned memory
     volatile uint32_t *flag = hp->pin_flag;
