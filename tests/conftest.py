@@ -154,7 +154,7 @@ def sim_lib():
 def sim_decode(comp, frames, first=0, count=None, B=16, CH=1024, prefix=None, quad=False):
     """quad: blocks with their own FSE tables go through zk_seq_walk_quad (three lock-stepped lanes per block, the
     device's zk_k_fse_quad) instead of the lane-per-block walk."""
-    sim_lib().zk_sim_set_fse_quad(1 if quad else 0)
+    sim_lib().zk_sim_set_fse_quad(int(quad))                # 2: the small-batch kernels' walk (8-byte cells, ZkCells64)
     c, d = offsets_from_frames(frames)
     n = len(frames)
     if count is None:

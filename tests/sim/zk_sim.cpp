@@ -24,7 +24,7 @@ struct ZkQuadSim {
     int cur, nlanes;
     bool done[4];
     // arguments of the walk
-    const uint8_t *comp; ZkBlock b; uint32_t bs_off; ZkSeqTablesX16 *T; const uint32_t *al; ZkSeqP *seqs;
+    const uint8_t *comp; ZkBlock b; uint32_t bs_off; ZkSeqTablesX16 *T; ZkSeqTablesT<ZkCells64> *T64; const uint32_t *al; ZkSeqP *seqs;
     std::vector<uint32_t> vals;                  // [sequence][lane]
     uint32_t walk_bad[3], gates;
     ZkSeqCarry carry[4];
@@ -70,7 +70,11 @@ static void zk_quad_walk_lane_main()
     ZkQuadSim *q = g_quad;
     const int t = q->cur;
     ZkQuadSimOut out{q, t};
-    q->walk_bad[t] = zk_seq_walk_quad<ZkRevU, ZkCellsX16, ZkQuadFibers>(q->comp, q->b, q->bs_off, (uint32_t)t,
+    if (q->T64)                                  // the small-batch kernels: 8-byte cells, no value tables
+        q->walk_bad[t] = zk_seq_walk_quad<ZkRevU, ZkCells64, ZkQuadFibers>(q->comp, q->b, q->bs_off, (uint32_t)t,
+                                                      t == ZK_TAB_LL ? q->T64->ll : t == ZK_TAB_OF ? q->T64->of : q->T64->ml, nullptr, q->al, out);
+    else
+        q->walk_bad[t] = zk_seq_walk_quad<ZkRevU, ZkCellsX16, ZkQuadFibers>(q->comp, q->b, q->bs_off, (uint32_t)t,
                                                       t == ZK_TAB_LL ? q->T->ll : t == ZK_TAB_OF ? q->T->of : q->T->ml,
                                                       t == ZK_TAB_LL ? g_llb : t == ZK_TAB_OF ? g_ofv : g_mlb, q->al, out);
     q->done[t] = true;
@@ -112,9 +116,10 @@ static void zk_quad_run(ZkQuadSim &q, int nlanes, void (*lane_main)())
     }
 }
 // the block's sequences through the quad walk (tables already built in T); false: the lanes disagree
-static bool zk_quad_walk_sim(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, ZkSeqTablesX16 *T, const uint32_t *al, ZkSeqP *seqs)
+static bool zk_quad_walk_sim(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, ZkSeqTablesX16 *T, const uint32_t *al, ZkSeqP *seqs, ZkSeqTablesT<ZkCells64> *T64 = nullptr)
 {
     ZkQuadSim q;
+    q.T64 = T64;
     g_quad = &q;
     for (uint32_t k = 0; k < 32; k++) g_ofv[k] = 1u << k;
     for (uint32_t k = 0; k < 36; k++) g_llb[k] = LLV_[k] & 0xFFFFFFu;
@@ -209,10 +214,11 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
     ZkSeqTables *T = new ZkSeqTables;
     ZkSeqTables16 *T16 = new ZkSeqTables16;
     ZkSeqTablesX16 *TX16 = new ZkSeqTablesX16;
+    ZkSeqTablesT<ZkCells64> *T64 = new ZkSeqTablesT<ZkCells64>;
     for (uint64_t bi = 0; bi < nb; bi++) {
         ZkBlock b = blocks[bi];
         if (b.type != 2 || b.nseq == 0 || b.status != ZK_OK) continue;
-        zk_sim_poison(T, sizeof *T); zk_sim_poison(T16, sizeof *T16); zk_sim_poison(TX16, sizeof *TX16);
+        zk_sim_poison(T, sizeof *T); zk_sim_poison(T16, sizeof *T16); zk_sim_poison(TX16, sizeof *TX16); zk_sim_poison(T64, sizeof *T64);
         // like the device: all-predefined blocks go through the aligned-word reader, the rest through the unaligned one
         // (with the quad flag every block takes the quad walk, as small batches do on the device)
         if (b.seq_modes == 0 && !g_fse_quad) zk_decode_sequences<ZkRevA, ZkCells32>(comp, blocks.data(), b, T, seqs.data() + b.seq_base, LLV, MLV);
@@ -223,12 +229,13 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
             for (int u = 0; u < 3 && ok; u++) {
                 const uint32_t m = (b.seq_modes >> (6 - 2 * u)) & 3;
                 const ZkBlock &def = m == 3 ? blocks[b.tab_def[u]] : b;
-                const int32_t r = zk_seq_table_setup<ZkCellsX16>(comp, def, u, TX16, &al[u], LLV, MLV);
+                const int32_t r = g_fse_quad == 2 ? zk_seq_table_setup<ZkCells64>(comp, def, u, T64, &al[u], LLV, MLV)
+                                                  : zk_seq_table_setup<ZkCellsX16>(comp, def, u, TX16, &al[u], LLV, MLV);
                 if (r < 0) ok = false;
                 else if (m != 3) own += (uint32_t)r;
             }
             if (!ok) b.status = ZK_E_CORRUPTION;
-            else if (!zk_quad_walk_sim(comp, b, b.seq_off + 1 + own, TX16, al, seqs.data() + b.seq_base)) b.status = ZK_E_CORRUPTION + 1000;   // lanes out of step: a bug, not an input error
+            else if (!zk_quad_walk_sim(comp, b, b.seq_off + 1 + own, TX16, al, seqs.data() + b.seq_base, g_fse_quad == 2 ? T64 : nullptr)) b.status = ZK_E_CORRUPTION + 1000;   // lanes out of step: a bug, not an input error
         }
         blocks[bi].out_size = b.out_size;
         for (int k = 0; k < 3; k++) blocks[bi].rep_out[k] = b.rep_out[k];
@@ -237,6 +244,7 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
     delete T;
     delete T16;
     delete TX16;
+    delete T64;
     // exec: one "workgroup" per frame; tiles of THREADS x B bytes, slot marking + per-byte source map (zk_exec_slot_span / zk_exec_slot_words)
     // CAPS: sequences staged at once.  Like the kernel the staged records live in a ring (slot = block sequence index & mask):
     // a tile retires the sequences it consumed and as many new records move into their slots.

@@ -77,15 +77,18 @@ def test_sim_prefix_goldens(prefix_golden):
 
 
 # ---- zk_k_fse_quad: three lock-stepped lanes per block (zk_seq_walk_quad), fibers on the CPU ----------------------
-def test_sim_quad_goldens(golden):
-    rc, out, st = sim_decode(golden.comp, golden.frames, quad=True)
+# quad = 1: 16-bit cells (sym | x), the large layouts; 2: 8-byte cells (ZkCells64), what the small-batch kernels walk
+@pytest.mark.parametrize("quad", [1, 2])
+def test_sim_quad_goldens(golden, quad):
+    rc, out, st = sim_decode(golden.comp, golden.frames, quad=quad)
     assert rc == 0 and not st.any()
     assert out == golden.input()
 
 
-def test_sim_quad_prefix_goldens(prefix_golden):
+@pytest.mark.parametrize("quad", [1, 2])
+def test_sim_quad_prefix_goldens(prefix_golden, quad):
     g = prefix_golden
-    rc, out, st = sim_decode(g.comp, g.frames, prefix=g.prefix(), quad=True)
+    rc, out, st = sim_decode(g.comp, g.frames, prefix=g.prefix(), quad=quad)
     assert rc == 0 and not st.any()
     assert out == g.input()
 
@@ -103,12 +106,13 @@ def test_sim_quad_matches_lane_walk_on_corrupt_input():
             comp = bytearray(g.comp)
             comp[int(rng.integers(0, len(comp)))] ^= 1 << int(rng.integers(0, 8))
             rc1, out1, st1 = sim_decode(bytes(comp), g.frames)
-            rc2, out2, st2 = sim_decode(bytes(comp), g.frames, quad=True)
-            assert list(st1) == list(st2) and rc1 == rc2
             _, d = g.offsets()
-            for f in range(len(g.frames)):
-                if st1[f] == 0:
-                    assert out1[int(d[f]):int(d[f + 1])] == out2[int(d[f]):int(d[f + 1])]
+            for quad in (1, 2):
+                rc2, out2, st2 = sim_decode(bytes(comp), g.frames, quad=quad)
+                assert list(st1) == list(st2) and rc1 == rc2
+                for f in range(len(g.frames)):
+                    if st1[f] == 0:
+                        assert out1[int(d[f]):int(d[f + 1])] == out2[int(d[f]):int(d[f + 1])]
 
 
 @pytest.mark.skipif(Z.load("system") is None, reason="no system libzstd")
@@ -117,12 +121,13 @@ def test_sim_quad_vs_live_libzstd(level):
     data = zko.make_input([["text", 300000, 80 + level], ["rep", "00", 200000], ["random", 20000, 7], ["text", 100000, 81]])
     for fs in (2 << 20, 65536):
         comp, frames = Z.encode_seekable_frames(data, fs, level, fs != 65536, "system")
-        rc, out, st = sim_decode(comp, frames, quad=True)
-        assert rc == 0 and out == data
+        for quad in (1, 2):
+            rc, out, st = sim_decode(comp, frames, quad=quad)
+            assert rc == 0 and out == data
 
 
 @pytest.mark.skipif(Z.load("system") is None, reason="no system libzstd")
-@pytest.mark.parametrize("quad", [False, True])
+@pytest.mark.parametrize("quad", [False, True, 2])
 def test_sim_with_poisoned_tables(quad):
     """Every table and scratch area a block's lane builds and then reads -- Huffman weights, decode table, FSE cells: on the device
     LDS that still holds what the workgroup before left there -- is filled with pseudo-random bytes before each block: code that
@@ -144,7 +149,7 @@ def test_sim_with_poisoned_tables(quad):
         lib.zk_sim_set_poison(0)
 
 
-@pytest.mark.parametrize("quad", [False, True])
+@pytest.mark.parametrize("quad", [False, True, 2])
 def test_sim_handmade_frames(quad):
     """RLE_Mode sequence tables (hand-written frames): one-cell tables, accuracy log 0, through both sequence walks."""
     from conftest import HANDMADE, HANDMADE_BAD, HANDMADE_BAD_CPU

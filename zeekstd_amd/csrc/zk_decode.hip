@@ -374,8 +374,8 @@ __device__ __forceinline__ void zk_fse_quad_group(uint32_t group, const uint8_t 
     {
         const uint32_t ll_init[36] = ZK_LL_TABLE;
         const uint32_t ml_init[53] = ZK_ML_TABLE;
-        if (tid < 36) llv[tid] = ll_init[tid] & 0xFFFFFFu;      // baselines only: the walker's cells (sym | x) keep no extra-bit count, and
-        if (tid < 53) mlv[tid] = ml_init[tid] & 0xFFFFFFu;      // the walk forms the counts by arithmetic (zk_seq_walk_quad)
+        if (tid < 36) llv[tid] = CP::kFat ? ll_init[tid] : ll_init[tid] & 0xFFFFFFu;      // baselines only: the walker's cells (sym | x) keep no extra-bit count, and
+        if (tid < 53) mlv[tid] = CP::kFat ? ml_init[tid] : ml_init[tid] & 0xFFFFFFu;      // the walk forms the counts by arithmetic (zk_seq_walk_quad); 8-byte cells: built from both
         if (tid < 32) ofv[tid] = 1u << tid;
         if (tid < (uint32_t)ZK_FSE_BLOCKS) { s_pos[tid] = 0; s_wbad[tid] = 0; }
         if (tid < (uint32_t)ZK_FSE_WAVES) { s_prod[tid] = 0; s_cons[tid] = 0; s_nloop[tid] = 0; }
@@ -1438,6 +1438,7 @@ __global__ __launch_bounds__(256) void zk_k_status(const ZkFrameInfo *infos, uin
 // Scratch is sized from bounds the host knows (sequences <= d / 3, literals <= d); the block list has a cap and a batch
 // that exceeds it reports ZK_SMALL_OVERFLOW, upon which the host takes the general path.
 constexpr uint32_t ZK_SMALL_OVERFLOW = 0xFFFFFFFFu;
+constexpr int ZK_SMALL_FSE_BLOCKS = 8;
 __global__ __launch_bounds__(256) void zk_k_small_walk(const uint8_t *h_comp, uint64_t comp_bytes, const uint64_t *h_offs, uint32_t count,
                                                        uint64_t dst_cap, uint32_t block_cap, uint8_t *d_comp, uint64_t *d_offs,
                                                        ZkFrameInfo *infos, ZkFrameBase *bases, ZkBlock *blocks, uint64_t *words)
@@ -1505,9 +1506,12 @@ __global__ __launch_bounds__(192) void zk_k_small_entropy(const uint8_t *comp, Z
 {
     const uint32_t nblocks = (uint32_t)words[0];
     const uint32_t role = blockIdx.x & 1, stride = gridDim.x >> 1;
-    for (uint32_t g = blockIdx.x >> 1; g * 16 < nblocks; g += stride) {
+    // (sequence groups: 8 blocks, 8-byte cells -- a seek's chain is ~63 instead of ~80 instructions per sequence, and 10 KiB of
+    //  tables per block do not matter where one or two blocks are all there is)
+    const uint32_t per = role == 0 ? 16u : (uint32_t)ZK_SMALL_FSE_BLOCKS;
+    for (uint32_t g = blockIdx.x >> 1; g * per < nblocks; g += stride) {
         if (role == 0) zk_huf_group(g, comp, blocks, nblocks, lit);
-        else zk_fse_quad_group<ZkCellsX16, 16, 1, true>(g, comp, blocks, nblocks, seqs, 1u);
+        else zk_fse_quad_group<ZkCells64, ZK_SMALL_FSE_BLOCKS, 1, true>(g, comp, blocks, nblocks, seqs, 1u);
         __syncthreads();                                     // the group's LDS state is re-initialised by the next one
     }
 }
@@ -1521,7 +1525,7 @@ __global__ __launch_bounds__(128) void zk_k_small_huf(const uint8_t *comp, ZkBlo
 __global__ __launch_bounds__(192) void zk_k_small_fse(const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, ZkSeqP *seqs)
 {
     const uint32_t nblocks = (uint32_t)words[0];
-    for (uint32_t g = blockIdx.x; g * 16 < nblocks; g += gridDim.x) { zk_fse_quad_group<ZkCellsX16, 16, 1, true>(g, comp, blocks, nblocks, seqs, 1u); __syncthreads(); }
+    for (uint32_t g = blockIdx.x; g * ZK_SMALL_FSE_BLOCKS < nblocks; g += gridDim.x) { zk_fse_quad_group<ZkCells64, ZK_SMALL_FSE_BLOCKS, 1, true>(g, comp, blocks, nblocks, seqs, 1u); __syncthreads(); }
 }
 
 // One workgroup per frame: the download.  h_out may be null (the caller wants the bytes in HBM only).

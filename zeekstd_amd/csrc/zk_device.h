@@ -253,6 +253,8 @@ ZK_HD uint32_t zk_cell_base(uint32_t c) { return c >> 17; }
 //              the symbol itself (OF).
 struct ZkCells32 {
     typedef uint32_t cell_t;
+    static constexpr bool kFat = false;          // (zk_seq_walk_quad: the cell alone tells bit counts and baseline)
+    static ZK_HDM uint32_t touch(cell_t c) { return c; }
     static ZK_HDM cell_t make(uint32_t sym, uint32_t nb, uint32_t xbits, uint32_t base, uint32_t = 0) { return zk_cell(sym, nb, xbits, base); }
     static ZK_HDM uint32_t sym(cell_t c) { return zk_cell_sym(c); }
     static ZK_HDM uint32_t nb(cell_t c, uint32_t = 0) { return zk_cell_nb(c); }
@@ -266,6 +268,8 @@ struct ZkCells32 {
 struct ZkCell64 { uint32_t c, v; };              // the 32-bit cell + the symbol's value baseline
 struct ZkCells64 {                               // for tables shared by a workgroup (zk_k_fse_predef*): LDS is no constraint
     typedef ZkCell64 cell_t;                     // there, and the baseline in the cell saves two dependent LDS reads per sequence
+    static constexpr bool kFat = true;
+    static ZK_HDM uint32_t touch(cell_t c) { return c.c; }
     static ZK_HDM cell_t make(uint32_t sym, uint32_t nb, uint32_t xbits, uint32_t base, uint32_t = 0) { cell_t r; r.c = zk_cell(sym, nb, xbits, base); r.v = 0; return r; }
     static ZK_HDM uint32_t sym(cell_t c) { return zk_cell_sym(c.c); }
     static ZK_HDM uint32_t nb(cell_t c, uint32_t = 0) { return zk_cell_nb(c.c); }
@@ -274,10 +278,13 @@ struct ZkCells64 {                               // for tables shared by a workg
     static ZK_HDM uint32_t baseline(cell_t c, const uint32_t *) { return c.v; }
     static ZK_HDM cell_t tmp_sym(uint32_t s) { cell_t r; r.c = s; r.v = 0; return r; }
     static ZK_HDM uint32_t tmp_get(cell_t c) { return c.c; }
-    static ZK_HDM cell_t with_value(cell_t c, const uint32_t *value_table, uint32_t s) { c.v = value_table ? value_table[s] & 0xFFFFFFu : 0u; return c; }
+    // (no value table = the offset table: the baseline of code s is 1 << s)
+    static ZK_HDM cell_t with_value(cell_t c, const uint32_t *value_table, uint32_t s) { c.v = value_table ? value_table[s] & 0xFFFFFFu : 1u << (s & 31u); return c; }
 };
 struct ZkCells16 {
     typedef uint16_t cell_t;
+    static constexpr bool kFat = false;
+    static ZK_HDM uint32_t touch(cell_t c) { return c; }
     static ZK_HDM cell_t make(uint32_t sym, uint32_t nb, uint32_t, uint32_t base, uint32_t = 0)
     { return (cell_t)((sym << 10) | (nb ? base + (1u << (nb - 1)) : 512u + base)); }
     static ZK_HDM uint32_t sym(cell_t c) { return (uint32_t)c >> 10; }
@@ -297,6 +304,8 @@ struct ZkCells16 {
 // field takes eleven instructions to take apart.
 struct ZkCellsX16 {
     typedef uint16_t cell_t;
+    static constexpr bool kFat = false;
+    static ZK_HDM uint32_t touch(cell_t c) { return c; }
     static ZK_HDM cell_t make(uint32_t sym, uint32_t, uint32_t, uint32_t, uint32_t x) { return (cell_t)((sym << 10) | x); }
     static ZK_HDM uint32_t sym(cell_t c) { return (uint32_t)c >> 10; }
     static ZK_HDM uint32_t nb(cell_t c, uint32_t al) { return al + (uint32_t)__builtin_clz((uint32_t)c & 1023u) - 31u; }
@@ -1198,15 +1207,22 @@ ZK_HD uint32_t zk_seq_walk_quad(const uint8_t *comp, const ZkBlock &b, uint32_t 
     const uint64_t xLUT = t == ZK_TAB_LL ? 0xCBA9876433221111ull : 0xBA98754433221111ull;       // codes 16..31 (LL) / 32..47 (ML), low nibble first
     typename CP::cell_t c = cells[state];
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" :: "v"((uint32_t)c));                      // arrived before the loop: its waits then only count what the loop issues
+    asm volatile("" :: "v"(CP::touch(c)));                     // arrived before the loop: its waits then only count what the loop issues
 #endif
     // one sequence; k: its place in the round
     auto step = [&](uint32_t i, uint32_t k) {
-        const uint32_t sy = CP::sym(c);
-        const uint32_t vv = vt[sy];                             // the baseline (used at the end of the step: nothing waits for it)
-        const uint32_t xb_mid = (uint32_t)(xLUT >> ((4u * (sy - xT1)) & 63u)) & 15u;
-        const uint32_t xb = sy < xT1 ? 0u : sy < xT2 ? xb_mid : sy - xD;
-        const uint32_t nbc = CP::nb(c, al_t);
+        uint32_t vv, xb, nbc;
+        if constexpr (CP::kFat) {                               // 8-byte cells (small batches: LDS is no constraint): three field extractions
+            vv = CP::baseline(c, nullptr);
+            xb = CP::xbits(c, nullptr);
+            nbc = CP::nb(c);
+        } else {
+            const uint32_t sy = CP::sym(c);
+            vv = vt[sy];                                        // the baseline (used at the end of the step: nothing waits for it)
+            const uint32_t xb_mid = (uint32_t)(xLUT >> ((4u * (sy - xT1)) & 63u)) & 15u;
+            xb = sy < xT1 ? 0u : sy < xT2 ? xb_mid : sy - xD;
+            nbc = CP::nb(c, al_t);
+        }
         const uint32_t nb = i + 1 < nseq ? nbc : 0;
         const uint32_t pk = xb | (nb << 8);
         const uint32_t pL = XCH::bcast(pk, ZK_TAB_LL), pO = XCH::bcast(pk, ZK_TAB_OF), pM = XCH::bcast(pk, ZK_TAB_ML);
