@@ -397,6 +397,34 @@ def test_large_writes_into_frames_larger_than_the_write(engine):
     assert [st.frame_size_decomp(i) for i in range(st.num_frames())] == [96 << 20]
 
 
+def test_compressed_policy_when_compressible_input_turns_random(engine):
+    """far from n on input that compresses very well the probes of the exact path used to step geometrically (an eighth
+    of the frame so far), and input that stopped compressing inside such a step carried the frame past n + 131 591.  The frame is now
+    measured piece by piece there (host/encoder.cpp, compress_with_prefix): 80 MiB of zeros -- a few KiB -- then random bytes."""
+    rng = np.random.default_rng(11)
+    data = bytes(80 << 20) + rng.integers(0, 256, 6 << 20, dtype=np.uint8).tobytes() + bytes(20 << 20) + zko.gen_chunks(4 << 20, 3)
+    sizes = _compressed_policy_check(engine, data, 1 << 20, lambda d: (d[i:i + (4 << 20)] for i in range(0, len(d), 4 << 20)))
+    assert len(sizes) >= 6
+    # the same through the RawEncoder alone (no batches: every frame end is found by the probes)
+    from zeekstd_amd import EncodeOptions as EO
+    raw = EO().engine(engine).frame_size_policy(FrameSizePolicy.Compressed(1 << 20)).checksum_flag(True).into_raw_encoder()
+    out = bytearray(131591)
+    blob = bytearray()
+    pos, mv = 0, memoryview(data)
+    while pos < len(data):
+        p = raw.compress(mv[pos:pos + (1 << 20)], out)
+        pos += p.in_progress(); blob += out[:p.out_progress()]
+    while True:
+        e = raw.end_frame(out)
+        blob += out[:e.out_progress()]
+        if not e.data_left():
+            break
+    st = raw.seek_table()
+    cs = [st.frame_size_comp(i) for i in range(st.num_frames())]
+    assert all((1 << 20) <= c < (1 << 20) + 131591 for c in cs[:-1]), cs[:8]
+    assert st.size_decomp() == len(data) and st.size_comp() == len(blob)
+
+
 def test_compressed_policy_on_input_that_barely_has_a_size(engine):
     """under Compressed(n) zero-filled input never lets the speculative path cut a frame (a frame would
     pass MAX_FRAME_SIZE before reaching n); the held bytes used to pile up in pinned memory until finish().  They are now

@@ -38,7 +38,8 @@ RawEncoder::RawEncoder(RawEncoder &&o) noexcept
     : engine_(o.engine_), owns_engine_(o.owns_engine_), policy_(o.policy_), checksum_(o.checksum_), level_(o.level_),
       frame_c_size_(o.frame_c_size_), frame_d_size_(o.frame_d_size_), seek_table_(std::move(o.seek_table_)),
       frame_in_(std::move(o.frame_in_)), pending_(std::move(o.pending_)), pending_pos_(o.pending_pos_), encoded_(o.encoded_),
-      next_probe_(o.next_probe_), ratio_(o.ratio_), frame_prefix_(o.frame_prefix_), frame_prefix_len_(o.frame_prefix_len_)
+      next_probe_(o.next_probe_), ratio_(o.ratio_), coarse_(o.coarse_), est_c_(o.est_c_), piece_start_(o.piece_start_),
+      frame_prefix_(o.frame_prefix_), frame_prefix_len_(o.frame_prefix_len_)
 {
     o.engine_ = nullptr; o.owns_engine_ = false;
 }
@@ -79,6 +80,19 @@ void RawEncoder::encode_pending()
     encoded_ = true;
 }
 
+size_t RawEncoder::encode_piece(size_t lo, size_t hi)
+{
+    const size_t n = hi - lo;
+    if (!n) return 0;
+    piece_out_.resize((size_t)zk_compress_bound(n, (uint32_t)n));
+    uint32_t c = 0, d = 0, nf = 0;
+    uint64_t written = 0;
+    int rc = zk_encode_frames_prefix(engine_, frame_in_.data() + lo, n, (uint32_t)n, level_, checksum_ ? 1 : 0, nullptr, 0, piece_out_.data(),
+                                     piece_out_.size(), &c, &d, 1, &nf, &written);
+    if (rc != 0) throw Error::from_engine_code(rc, zk_engine_last_hip_error(engine_));
+    return (size_t)written;
+}
+
 CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len,
                                                      const uint8_t *prefix, size_t prefix_len)
 {
@@ -110,27 +124,38 @@ CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t i
     if (by_output && limit) {
         const size_t want = policy_.size;
         // (b more compressed bytes need at least ~b more input bytes: a probe never lies further ahead than that plus the
-        // window, so even input that stops compressing cannot carry the frame past n + 131 591 -- except in the corner named below)
+        // window, so even input that stops compressing cannot carry the frame past n + 131 591)
         if (frame_in_.size() >= next_probe_) {
-            encoded_ = false;
-            encode_pending();                                                  // speculative: how large is the frame so far?
-            const size_t c = pending_.size(), d = frame_in_.size();
-            if (c < want) {
+            const size_t d = frame_in_.size();
+            bool exact = true;
+            if (coarse_) {
+                // Far from n on input that compresses very well (d >> c), a probe -- a full encode of the frame so far -- every
+                // (n - c) + slack bytes is quadratic work (192 MiB of zeros under Compressed(1 MiB): 207 s), and a geometric step
+                // instead (round 3: 7 s) gives up the window when the input stops compressing inside a step.  So, while
+                // less than half of n is reached, only the bytes since the last probe are encoded, as a frame of their own: what
+                // they add to the frame is at most that (they lose their history, nothing else), the sum stays an upper bound of
+                // the frame's size, every piece is O(its length), and the steps keep the cap that keeps the window.
+                est_c_ += encode_piece(piece_start_, d);
+                piece_start_ = d;
+                if (2 * est_c_ < want) {
+                    next_probe_ = d + (want - est_c_) + slack;
+                    exact = false;
+                } else coarse_ = false;                                          // (near n by the bound: time for the frame's real size)
+            }
+            if (exact) {
                 encoded_ = false;
-                const double r = std::max(1.0, (double)d / (double)std::max<size_t>(c, 1));
-                const size_t by_ratio = std::max<size_t>(32768, (size_t)(0.9 * r * (double)(want - c)));
-                size_t step = std::min<size_t>(by_ratio, (want - c) + slack);
-                // far from n on input that compresses very well (d >> c) that cap would mean a probe -- a full encode of the frame so
-                // far -- every ~1 MiB of a frame of hundreds of MiB: quadratic work (192 MiB of zeros under Compressed(1 MiB): 207 s with
-                // the cap kept, 7 s without; tests/test_gpu_encoder_api.py::test_compressed_policy_on_input_that_barely_has_a_size).
-                // While less than half of n is reached the step is therefore at least an eighth of the frame so far (geometric:
-                // O(log) probes).  THE PRICE, a deviation from upstream's window in one corner: input that compresses > 16 : 1 for
-                // tens of MiB and then stops compressing inside one such step can carry the frame past n + 131 591 (by at most the
-                // step: an eighth of the frame so far).  Upstream, which learns sizes 128 KiB at a time, has no such corner; the
-                // window holds again as soon as c reaches n / 2.
-                if (2 * c < want) step = std::max(step, d / 8);
-                next_probe_ = d + step;
-            } else ratio_ = (double)d / (double)c;
+                encode_pending();                                              // speculative: how large is the frame so far?
+                const size_t c = pending_.size();
+                if (c < want) {
+                    encoded_ = false;
+                    const double r = std::max(1.0, (double)d / (double)std::max<size_t>(c, 1));
+                    const size_t by_ratio = std::max<size_t>(32768, (size_t)(0.9 * r * (double)(want - c)));
+                    const size_t step = std::min<size_t>(by_ratio, (want - c) + slack);
+                    // whole-frame probes every `step` bytes from here would re-encode more than eight times what they add
+                    if (2 * c < want && d / 8 > step) { coarse_ = true; est_c_ = c; piece_start_ = d; }
+                    next_probe_ = d + step;
+                } else ratio_ = (double)d / (double)c;
+            }
         }
     }
     return {limit, 0};
@@ -155,6 +180,7 @@ void RawEncoder::reset_frame()                                                 /
 {
     frame_c_size_ = 0; frame_d_size_ = 0;
     frame_in_.clear(); pending_.clear(); pending_pos_ = 0; encoded_ = false; next_probe_ = 0;
+    coarse_ = false; est_c_ = 0; piece_start_ = 0;
     frame_prefix_ = nullptr; frame_prefix_len_ = 0;
 }
 

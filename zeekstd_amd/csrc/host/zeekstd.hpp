@@ -339,6 +339,7 @@ private:
     size_t remaining_frame_size() const;                                             // :528-535
     bool is_frame_complete() const;                                                  // :537-544
     void encode_pending();
+    size_t encode_piece(size_t lo, size_t hi);       // compressed size of frame_in_[lo, hi) as a frame of its own
     zk_engine *engine_ = nullptr;
     bool owns_engine_ = false;
     FrameSizePolicy policy_;
@@ -352,6 +353,11 @@ private:
     bool encoded_ = false;
     size_t next_probe_ = 0;                   // Compressed(n): buffered size at which the next speculative encode happens
     double ratio_ = 0;                        // Compressed(n): uncompressed / compressed of the last frame closed (0: none yet)
+    // Compressed(n), far from n on input that compresses very well: the frame is measured PIECE BY PIECE (each piece as a frame of
+    // its own: an upper bound of what it adds) instead of whole again at every probe -- see compress_with_prefix
+    bool coarse_ = false;
+    size_t est_c_ = 0, piece_start_ = 0;      // the bound so far; where the next piece starts
+    std::vector<uint8_t> piece_out_;
     const uint8_t *frame_prefix_ = nullptr;   // prefix referenced when the frame in progress began (encode.rs:334-338)
     size_t frame_prefix_len_ = 0;
 };
