@@ -87,3 +87,58 @@ def test_rust_binding_declares_every_symbol():
                 and name not in ("zk_decoder_open_bytes", "zk_decoder_open_file", "zk_decoder_open_callbacks", "zk_decoder_gpu_submissions", "zk_decoder_time_seeks",
                                  "zk_seek_table_from_reader_bytes", "zk_seek_table_entries", "zk_serializer_reset", "zk_raw_encoder_compress"):
             assert "ffi::" + name in lib_rs, name
+
+
+def test_python_binding_types_agree_with_the_header():
+    """names and arity alone say little.  Every ctypes signature the Python mirror declares (zeekstd_amd/_lib.py,
+    api.py -- written by hand) is compared with the C declaration in include/zeekstd_amd.h argument by argument: pointer against
+    pointer, integer against integer of the same width and signedness, double against double, and the return type.  (rust/src/ffi.rs
+    is generated from the same parse of the header, so a type that is right here is right there.)"""
+    import sys
+    import zeekstd_amd as zk
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_ffi as g
+    fns = g.parse_functions(open(os.path.join(ROOT, "include", "zeekstd_amd.h")).read())
+    ints = {"int": ("i", 4), "int32_t": ("i", 4), "uint32_t": ("u", 4), "int64_t": ("i", 8), "uint64_t": ("u", 8), "size_t": ("u", 8), "uint8_t": ("u", 1)}
+
+    def c_kind(t):
+        t = t.replace("const", "").strip()
+        if "*" in t or t.endswith("_fn"):                       # object pointers, handles, callback typedefs
+            return ("p", 8)
+        if t in ints:
+            return ints[t]
+        if t in ("double", "float"):
+            return ("f", 8 if t == "double" else 4)
+        if t == "void":
+            return None
+        raise AssertionError("type the test does not know: " + t)
+
+    def py_kind(t):
+        if t is None:
+            return None
+        if issubclass(t, (C._Pointer, C.c_void_p, C.c_char_p)) or hasattr(t, "_flags_") and not hasattr(t, "_type_") or issubclass(t, C._CFuncPtr):
+            return ("p", 8)
+        code = getattr(t, "_type_", None)
+        if code in ("P", "z", "Z"):
+            return ("p", 8)
+        if code in ("d", "f"):
+            return ("f", C.sizeof(t))
+        if isinstance(code, str) and code in "bBhHiIlLqQ?":
+            return ("i" if code in "bhilq" else "u", C.sizeof(t))
+        raise AssertionError("ctypes type the test does not know: %r" % (t,))
+
+    undeclared, checked = [], 0
+    for name, ret, params in fns:
+        f = getattr(zk.lib, name)
+        if f.argtypes is None:
+            undeclared.append(name)
+            continue
+        assert len(f.argtypes) == len(params), name
+        for i, ((ctype, pname), at) in enumerate(zip(params, f.argtypes)):
+            assert py_kind(at) == c_kind(ctype), (name, i, pname, ctype, at)
+        want = c_kind(ret)
+        got = py_kind(f.restype)
+        # (a C `int` status may be read as c_int only; pointers returned as c_char_p / c_void_p)
+        assert got == want, (name, "return", ret, f.restype)
+        checked += 1
+    assert checked >= len(fns) - 6, undeclared               # a handful of entry points are bound where they are used (bench.py, tests)
