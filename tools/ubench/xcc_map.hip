@@ -1,4 +1,4 @@
-// Where do the workgroups of two kernels on two queues land?  (HW_REG_XCC_ID per workgroup; tools/gpu_r4n.sh)
+// Where do the workgroups of two kernels on two queues land?  (HW_REG_XCC_ID per workgroup)
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/xcc_map.hip -o /tmp/xcc_map && /tmp/xcc_map
 #include <hip/hip_runtime.h>
 #include <cstdio>
