@@ -265,7 +265,9 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
     ZK_HIP(hipMemcpyAsync(words + 3, c.h_words + 3, sizeof(uint64_t), hipMemcpyHostToDevice, st));
     // checksums WHILE the executor writes (zk_k_xxh64_follow, zk_decode.hip): the executor publishes a progress word per frame, the
     // checksum waves run on the context's second queue beside it, the ordinary pass behind the executor takes what they left
-    const bool follow = a.verify && zk_follow_wanted(e, count, c.h_words[5], a.alone);
+    // (not in the host pipeline's chunks: they overlap whole chunks on one queue per context, PCIe bounds them, and the extra queues
+    //  cost the copy queues 1-2 %: 46.4 -> 45.3 GiB/s end to end)
+    const bool follow = a.verify && !a.single_queue && zk_follow_wanted(e, count, c.h_words[5], a.alone);
     ZkKernelChoice kc = e->choice;
     if (follow && !kc.exec_resident) kc.exec_resident = 4;
     uint64_t *prog = nullptr;
