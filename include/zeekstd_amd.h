@@ -97,7 +97,8 @@ enum {
     ZK_CHOICE_EXEC_RESIDENT = 9   /* zk_k_exec with 256-lane tiles: at most this many workgroups per CU (4 or 5; the launch asks for LDS it does not use) */
 };
 int zk_engine_set_kernel_choice(zk_engine *e, int what, int value);
-/* Frames of the last finished decode whose Content_Checksum was verified by zk_k_xxh64_follow (beside the executor). */
+/* Frames of the last finished device-pointer decode (zk_decode_frames_dev and its siblings, zk_decode_wait) whose Content_Checksum was
+ * verified by zk_k_xxh64_follow, beside the executor; the others were verified behind it.  A diagnostic: results do not depend on it. */
 uint64_t zk_engine_checksums_followed(const zk_engine *e);
 int zk_engine_kernel_count(void);
 const char *zk_engine_kernel_name(int k);
