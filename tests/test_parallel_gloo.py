@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size-2 gloo processes run the same gather code the GPUs run over RCCL
+"""The N>1 path on CPU: world_size-2 and world_size-8 gloo processes run the same gather code the GPUs run over RCCL
 (zeekstd_amd/parallel.py): shard ranges, size exchange, point-to-point payload gather, seek-entry gather,
 seek table appended on the root.  The per-rank encoder here is the CPU oracle (test infrastructure) --
 the collective logic is what is under test; the GPU encoder is covered by tests/test_gpu_encode.py."""
@@ -46,9 +46,10 @@ def _worker(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [7321, 1000, 999, 123456])
-def test_gather_seekable_world2(n_total):
-    world = 2
+# world 8 = configs[4]'s shape (BASELINE.json: frames sharded over the 8 GPUs of a node): more ranks than frames, ranks with nothing,
+# the root's slice at the front -- the rank arithmetic the 8-GPU run depends on and no 1-GPU box can exercise
+@pytest.mark.parametrize("n_total,world", [(7321, 2), (1000, 2), (999, 2), (123456, 2), (123456, 8), (2500, 8), (999, 8)])
+def test_gather_seekable_world2(n_total, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -126,9 +127,8 @@ def _worker_sharded(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [5 * FS + 17, FS, 64 * FS])
-def test_encode_sharded_world2(n_total):
-    world = 2
+@pytest.mark.parametrize("n_total,world", [(5 * FS + 17, 2), (FS, 2), (64 * FS, 2), (64 * FS + 5, 8), (3 * FS, 8)])
+def test_encode_sharded_world2(n_total, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -150,24 +150,26 @@ def test_encode_sharded_world2(n_total):
     assert bytes(out) == data
 
 
-def test_bench_dry_run_world2():
-    """bench.py's N > 1 control flow (env parsing, process group, shard + gather leg, the JSON line) under gloo, no GPU."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_dry_run_world2(world):
+    """bench.py's N > 1 control flow (env parsing, process group, shard + gather leg, the JSON line) under gloo, no GPU -- as the
+    driver launches it for N = 2 and for the node's 8."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = _free_port()
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--dry-run"],
                        cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # rank 0 prints ONE line
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["dry_run"] is True and d["scaling"] == "weak"
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["dry_run"] is True and d["scaling"] == "weak"
     g = d["rccl_gather"]                                     # the exchange leg's result is IN the line: frames, bytes, ms
-    assert g["frames_on_root"] == 2 * d["config"]["frames_per_gpu"] and g["ms"] > 0
-    assert g["stream_bytes_on_root"] == 2 * 4 * (1000 + 9) + 8 * 8 + 17
+    assert g["frames_on_root"] == world * d["config"]["frames_per_gpu"] and g["ms"] > 0
+    assert g["stream_bytes_on_root"] == world * 4 * (1000 + 9) + world * 4 * 8 + 17
 
 
 def _worker_too_small(rank, world, port, q):
