@@ -159,3 +159,67 @@ def test_sim_handmade_frames(quad):
     for name, frame, dsize, code in HANDMADE_BAD + HANDMADE_BAD_CPU:      # libzstd 1.5.7's verdict, code for code
         rc, out, st = sim_decode(frame, [(len(frame), dsize)], quad=quad)
         assert rc == -code and st[0] == code, name
+
+
+# ---- archives of THIS engine's encoder (its CPU twin writes the same bytes): one set of FSE tables per frame, Repeat_Mode in the later
+# blocks, 32 KiB blocks, from level 2 on offsets that reach back through the whole frame -- the shapes the shared-table walks and
+# the window check of the executor see on the device, here through the same lane code on the CPU
+def _doc_like_small(seed=5):
+    rng = np.random.default_rng(seed)
+    pool = [zko.gen_text(int(rng.integers(2000, 20000)), 300 + i) for i in range(6)]
+    out = bytearray()
+    for i in range(14):
+        out += zko.gen_text(int(rng.integers(20000, 90000)), 400 + i)
+        out += pool[int(rng.integers(0, len(pool)))]
+    return bytes(out)
+
+
+@pytest.mark.parametrize("level", [1, 3, 6])
+@pytest.mark.parametrize("quad", [0, 1, 2])
+def test_sim_twin_made_frames(level, quad):
+    rng = np.random.default_rng(17)
+    inputs = {
+        "text": zko.gen_chunks(700_000, 3),
+        "doc_like": _doc_like_small(),                               # repeats hundreds of KiB back: in-frame far matches from level 2
+        "runs": b"".join(bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 400)) for _ in range(3000)),
+        "period37": (bytes(range(37)) * 9000)[:300_000],
+        "mixed": zko.gen_text(150_000, 9) + rng.integers(0, 256, 40_000, dtype=np.uint8).tobytes() + bytes(70_000) + zko.gen_text(90_000, 10),
+    }
+    for name, data in inputs.items():
+        for fs in (len(data), 65536):
+            frames, comp = [], bytearray()
+            for o in range(0, len(data), fs):
+                fr = zko.frame_encode(data[o:o + fs], level, True)
+                frames.append((len(fr), len(data[o:o + fs])))
+                comp += fr
+            rc, out, st = sim_decode(bytes(comp), frames, quad=quad)
+            assert rc == 0 and not st.any(), (name, fs)
+            assert out == data, (name, fs)
+
+
+def test_sim_twin_made_frames_damaged():
+    """The three sequence walks and the executor's checks on damaged frames of the engine's own shape (far offsets, a declared
+    window over the frame, Repeat_Mode tables): the same verdict per frame from every walk, the same bytes where a frame still
+    decodes, and nothing that reads or writes where it should not (the harness runs under the allocator's guard of numpy buffers)."""
+    data = _doc_like_small(6)[:600_000]
+    fs = 200_000
+    frames, comp = [], bytearray()
+    for o in range(0, len(data), fs):
+        fr = zko.frame_encode(data[o:o + fs], 3, True)
+        frames.append((len(fr), len(data[o:o + fs])))
+        comp += fr
+    _, d = (np.cumsum([0] + [f[0] for f in frames]), np.cumsum([0] + [f[1] for f in frames]))
+    rng = np.random.default_rng(29)
+    seen_bad = 0
+    for _ in range(24):
+        bad = bytearray(comp)
+        bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        rc0, out0, st0 = sim_decode(bytes(bad), frames)
+        seen_bad += int(any(st0))
+        for quad in (1, 2):
+            rc, out, st = sim_decode(bytes(bad), frames, quad=quad)
+            assert list(st) == list(st0) and rc == rc0
+            for f in range(len(frames)):
+                if st0[f] == 0:
+                    assert out[int(d[f]):int(d[f + 1])] == out0[int(d[f]):int(d[f + 1])]
+    assert seen_bad >= 4                                             # (the harness does not compare checksums: structural damage only)
