@@ -130,3 +130,30 @@ def test_huffman_build_as_the_kernel_does_it():
     cases += [np.array([1, 1], np.uint32), np.array([5, 0, 0, 7], np.uint32), np.arange(1, 129, dtype=np.uint32), np.full(128, 9, np.uint32)]
     for c in cases:
         assert lib.zk_enc_sim_huf(c.ctypes.data, len(c)) == 0, c.tolist()
+
+
+def test_match_kernel_under_sanitizers(tmp_path):
+    """The match + parse kernel under the workgroup emulator, built with AddressSanitizer + UBSan (tests/sim/encode_san.cpp): the
+    kernel's `__shared__` arrays are real arrays on the CPU, so an index that leaves the ring, the table, `best[]` or a tile's sequence
+    area -- on the device silent corruption of whatever lies next to it in LDS -- is a report, as is an access outside the source /
+    prefix / output buffers (exact-size heap allocations).  Text with a prefix beyond the ring (the long-distance table), byte runs in
+    small frames at level 6, a frame larger than a segment with far history inside it at level 3.  (54 further shapes: DESIGN.md 3.)"""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "encsan")
+    cc = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                         os.path.join(ROOT, "tests", "sim", "encode_san.cpp"), "-o", exe], capture_output=True, text=True)
+    if cc.returncode != 0 and "sanitize" in cc.stderr and "cannot find" in cc.stderr:
+        pytest.skip("no sanitizer runtime for g++ here")
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    first = True
+    for cfg in (("1", "90000", "90000", "0", "200000"), ("6", "100000", "32768", "1", "20000"), ("3", "400000", "400000", "0")):
+        r = subprocess.run([exe, *cfg], capture_output=True, text=True, timeout=900)
+        if first and r.returncode != 0 and "AddressSanitizer" in r.stderr and "ERROR: AddressSanitizer:" not in r.stderr:
+            pytest.skip("the sanitizer runtime cannot start here")
+        first = False
+        assert r.returncode == 0, (cfg, r.stdout[-300:], r.stderr[-3000:])
