@@ -198,3 +198,37 @@ def test_handmade_frames():
         for which in ("1.5.7", "system"):
             if Z.load(which) is not None:
                 assert Z.decode_stream(frame, len(expect), which) == expect, (name, which)
+
+
+def test_oracle_decoder_under_sanitizers_on_damaged_frames(tmp_path):
+    """The checker must not leave its buffers either: oracle/zstd_oracle.c under AddressSanitizer + UBSan (tests/sim/oracle_fuzz.c),
+    damaged and truncated frames of six goldens in exact-size heap buffers (no padding at all)."""
+    import os
+    import shutil
+    import struct
+    import subprocess
+    from conftest import GOLDENS, ROOT
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "oracle_fuzz")
+    cc = subprocess.run(["gcc", "-O1", "-g", "-w", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                         os.path.join(ROOT, "tests", "sim", "oracle_fuzz.c"), "-o", exe], capture_output=True, text=True)
+    if cc.returncode != 0 and "sanitize" in cc.stderr and "cannot find" in cc.stderr:
+        pytest.skip("no sanitizer runtime for gcc here")
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    first = True
+    for name in ("text_l1_64k", "mixed_l19", "text_100B_frames", "long_offsets_l19", "oneshot_text_l3", "tiny_frames_10B"):
+        g = next(x for x in GOLDENS if x.name == name)
+        data = g.input()
+        path = str(tmp_path / (name + ".bin"))
+        with open(path, "wb") as f:
+            f.write(struct.pack("<IQQ", len(g.frames), len(g.comp), len(data)))
+            for c, d in g.frames:
+                f.write(struct.pack("<QQ", c, d))
+            f.write(g.comp); f.write(data)
+        r = subprocess.run([exe, path, "150", "3"], capture_output=True, text=True, timeout=600, env=env)
+        if first and r.returncode != 0 and "AddressSanitizer" in r.stderr and "ERROR: AddressSanitizer:" not in r.stderr:
+            pytest.skip("the sanitizer runtime cannot start here")
+        first = False
+        assert r.returncode == 0, (name, r.stdout[-300:], r.stderr[-3000:])
