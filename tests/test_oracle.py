@@ -232,3 +232,25 @@ def test_oracle_decoder_under_sanitizers_on_damaged_frames(tmp_path):
             pytest.skip("the sanitizer runtime cannot start here")
         first = False
         assert r.returncode == 0, (name, r.stdout[-300:], r.stderr[-3000:])
+
+
+def test_twin_round_trips_under_sanitizers(tmp_path):
+    """tests/sim/twin_san.c: the encoder's CPU twin + the oracle's decoder built with AddressSanitizer + UBSan, 120 round trips over
+    levels, kinds of input, sizes from 0 to 3.5 MB (far history inside a frame from level 2 on) and prefixes, exact-size buffers."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "twin_san")
+    cc = subprocess.run(["gcc", "-O1", "-g", "-w", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                         os.path.join(ROOT, "tests", "sim", "twin_san.c"), os.path.join(ROOT, "oracle", "zstd_oracle.c"),
+                         os.path.join(ROOT, "oracle", "zstd_oracle_enc.c"), "-ldl", "-o", exe], capture_output=True, text=True)
+    if cc.returncode != 0 and "sanitize" in cc.stderr and "cannot find" in cc.stderr:
+        pytest.skip("no sanitizer runtime for gcc here")
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    if r.returncode != 0 and "AddressSanitizer" in r.stderr and "ERROR: AddressSanitizer:" not in r.stderr:
+        pytest.skip("the sanitizer runtime cannot start here")
+    assert r.returncode == 0 and "120 round trips clean" in r.stdout, (r.stdout[-300:], r.stderr[-3000:])
