@@ -3,7 +3,7 @@
 // hands over is a heap allocation of exactly the size the C ABI promises -- compressed bytes + ZK_COMP_PADDING, output bytes -- so a
 // lane that follows a damaged header, table or offset out of its buffers is a sanitizer report.
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined tests/sim/decode_fuzz.cpp -o /tmp/decfuzz
-//   /tmp/decfuzz <case file> <iterations> <seed> <walk: 0 lane per block | 1 quad, 16-bit cells | 2 quad, 8-byte cells>
+//   /tmp/decfuzz <case file> <iterations> <seed> <walk: 0 lane per block | 1 quad, 16-bit cells | 2 quad, 8-byte cells> [prefix file]
 // case file (written by tests/test_sim_decode.py): u32 nframes, u64 comp_len, u64 out_len, (u64 c, u64 d) x nframes, comp, expected.
 // Exit 0: every mutated input produced statuses and bytes without leaving its buffers (and the unmutated one the expected bytes).
 #include "zk_sim.cpp"
@@ -32,6 +32,14 @@ int main(int argc, char **argv)
     std::vector<uint8_t> comp(clen), want(olen);
     if ((clen && fread(comp.data(), 1, clen, f) != clen) || (olen && fread(want.data(), 1, olen, f) != olen)) return 2;
     fclose(f);
+    std::vector<uint8_t> prefix;                            // a raw-content prefix the frames were made against (ZSTD_DCtx_refPrefix)
+    if (argc > 5) {
+        FILE *pf = fopen(argv[5], "rb");
+        if (!pf) return 2;
+        uint8_t tmp[65536];
+        for (size_t k; (k = fread(tmp, 1, sizeof tmp, pf)) > 0;) prefix.insert(prefix.end(), tmp, tmp + k);
+        fclose(pf);
+    }
     uint64_t flagged = 0;
     for (uint64_t it = 0; it <= iters; it++) {
         // exact-size heap buffers, fresh every round (what the previous round left must not help)
@@ -46,7 +54,11 @@ int main(int argc, char **argv)
             case 3: { const uint64_t a = f_rnd() % clen; memset(in + a, (int)(f_rnd() & 0xFF), (size_t)((clen - a) < 64 ? clen - a : 64)); break; }
             }
         }
-        const int rc = zk_sim_decode(in, c_off.data(), d_off.data(), 0, nf, out, st, 16, 1024);
+        uint8_t *pre = prefix.empty() ? nullptr : (uint8_t *)malloc(prefix.size());
+        if (pre) memcpy(pre, prefix.data(), prefix.size());
+        const int rc = pre ? zk_sim_decode_prefix(in, c_off.data(), d_off.data(), 0, nf, out, st, 16, 1024, pre, prefix.size())
+                           : zk_sim_decode(in, c_off.data(), d_off.data(), 0, nf, out, st, 16, 1024);
+        free(pre);
         bool any = rc != 0;
         for (uint32_t i = 0; i < nf; i++) any = any || st[i] != 0;
         if (!it && (any || (olen && memcmp(out, want.data(), olen) != 0))) { fprintf(stderr, "the undamaged archive does not decode\n"); return 3; }

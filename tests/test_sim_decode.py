@@ -264,3 +264,13 @@ def test_sim_under_sanitizers_on_damaged_archives(tmp_path):
                 pytest.skip("the sanitizer runtime cannot start here")             # (an environment without the address-space layout ASan needs)
             first = False
             assert r.returncode == 0, (name, walk, r.stdout[-300:], r.stderr[-3000:])
+    # frames made against a prefix (history positions below the frame's first byte: the executor's second address range)
+    from conftest import PREFIX_GOLDENS
+    for name, iters in (("pfx_small_frames", 400), ("pfx_patch_1m_ldm", 200), ("pfx_tiny", 200)):
+        g = next(x for x in PREFIX_GOLDENS if x.name == name)
+        path = case(g)
+        pre = str(tmp_path / (name + ".pre"))
+        open(pre, "wb").write(g.prefix())
+        for walk in (0, 2):
+            r = subprocess.run([exe, path, str(iters if walk == 0 else iters // 10), "6", str(walk), pre], capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (name, walk, r.stdout[-300:], r.stderr[-3000:])
