@@ -254,3 +254,25 @@ def test_twin_round_trips_under_sanitizers(tmp_path):
     if r.returncode != 0 and "AddressSanitizer" in r.stderr and "ERROR: AddressSanitizer:" not in r.stderr:
         pytest.skip("the sanitizer runtime cannot start here")
     assert r.returncode == 0 and "120 round trips clean" in r.stdout, (r.stdout[-300:], r.stderr[-3000:])
+
+
+def test_a_third_zstd_build_decodes_the_twins_frames():
+    """Interop beyond the two libzstd builds on the box (1.4.8 system, 1.5.7 bundled with pillow): the zstd statically linked into
+    pyarrow decodes the frames the encoder's twin writes -- the bytes the GPU encoder writes (tests/test_gpu_encode.py) -- at every
+    level setting, with and without checksums, incl. frames whose matches reach far back inside the frame (a declared window over the
+    frame) and the shapes that stress the format's corners (byte runs, short periods, random bytes, tiny inputs)."""
+    pa = pytest.importorskip("pyarrow")
+    if not pa.Codec.is_available("zstd"):
+        pytest.skip("pyarrow without zstd")
+    codec = pa.Codec("zstd")
+    rng = np.random.default_rng(41)
+    inputs = [zko.gen_chunks(2_500_000, 5), zko.gen_text(70_000, 2), bytes(300_000), (bytes(range(37)) * 9000)[:200_000],
+              rng.integers(0, 256, 100_000, dtype=np.uint8).tobytes(), b"", b"a", b"hello hello hello hello",
+              b"".join(bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 500)) for _ in range(2000))]
+    for data in inputs:
+        for level in (1, 3, 6):
+            for cks in (False, True):
+                fr = zko.frame_encode(data, level, cks)
+                if len(data) == 0:
+                    continue                                   # (pyarrow refuses a zero-size output buffer; the empty frame is golden bytes anyway)
+                assert codec.decompress(fr, decompressed_size=len(data)).to_pybytes() == data, (len(data), level, cks)
