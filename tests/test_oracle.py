@@ -261,6 +261,7 @@ def test_a_third_zstd_build_decodes_the_twins_frames():
     pyarrow decodes the frames the encoder's twin writes -- the bytes the GPU encoder writes (tests/test_gpu_encode.py) -- at every
     level setting, with and without checksums, incl. frames whose matches reach far back inside the frame (a declared window over the
     frame) and the shapes that stress the format's corners (byte runs, short periods, random bytes, tiny inputs)."""
+    import numpy as np
     pa = pytest.importorskip("pyarrow")
     if not pa.Codec.is_available("zstd"):
         pytest.skip("pyarrow without zstd")
