@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -142,3 +144,35 @@ def test_python_binding_types_agree_with_the_header():
         assert got == want, (name, "return", ret, f.restype)
         checked += 1
     assert checked >= len(fns) - 6, undeclared               # a handful of entry points are bound where they are used (bench.py, tests)
+
+
+def test_header_is_plain_c_and_a_c_client_links():
+    """include/zeekstd_amd.h is the boundary a cgo / JNI / Rust-bindgen host compiles: it must be plain C99 (and C++11) on its own,
+    and a C translation unit that names every declared function must link against the library (no GPU needed for either)."""
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    import zeekstd_amd as zk
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "zeekstd_amd.h")
+    for cc, std, lang in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "c++")):
+        r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", lang, hdr], capture_output=True, text=True)
+        assert r.returncode == 0, (cc, r.stderr[-2000:])
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_ffi as g
+    fns = g.parse_functions(open(hdr).read())
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "client.c")
+        with open(src, "w") as f:
+            f.write('#include "zeekstd_amd.h"\n#include <stdio.h>\nint main(void)\n{\n    const void *fn[] = {\n')
+            f.write("".join("        (const void *)(size_t)&%s,\n" % name for name, _, _ in fns))
+            f.write('    };\n    printf("%d %zu\\n", zk_abi_version(), sizeof fn / sizeof fn[0]);\n    return 0;\n}\n')
+        exe = os.path.join(td, "client")
+        libdir = os.path.dirname(zk.LIB_PATH)
+        r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", libdir, "-l:libzeekstd_amd.so",
+                            "-Wl,-rpath," + libdir], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.split() == [str(zk.lib.zk_abi_version()), str(len(fns))], (out.stdout, out.stderr[-500:])
