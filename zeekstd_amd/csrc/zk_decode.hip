@@ -1016,28 +1016,6 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                     } while (again);
                     ZK_CLK(4);
                     uint32_t ob[ZK_EXEC_B];
-#if defined(ZK_EXEC_GATHER2)
-                    // EXPERIMENT (prepared at the end of round 4, not measured yet; tools/build_variants.sh g2:-DZK_EXEC_GATHER2):
-                    // the two address ranges as two exec-masked loads with a SCALAR base and a 32-bit lane offset each, instead of
-                    // one load from a 64-bit lane address that costs ~6 vector instructions per byte to form (two 64-bit adds, two
-                    // selects).  Both bases are uniform since the descriptors moved to scalar registers: the literal buffer, and the
-                    // frame's first byte (pos + word - BIAS >= 0 without a prefix: the marking pass has checked every offset).
-                    if (!PFX) {
-#pragma unroll
-                        for (int k = 0; k < ZK_EXEC_B; k++) {
-                            const uint32_t s = sw[k];
-                            const bool is_lit = (s & ZK_SRC_LIT) != 0;
-                            const uint32_t o_lit = s & lit_mask, o_out = (uint32_t)pos + s - ZK_SRC_BIAS;
-                            uint32_t v = 0;                  // (bytes past the tile's end carry the word LIT | 0: the literal buffer's first byte, unused)
-                            if (is_lit) asm volatile("global_load_ubyte %0, %1, %2" : "=v"(v) : "v"(o_lit), "s"(lit) : "memory");
-                            else asm volatile("global_load_ubyte %0, %1, %2" : "=v"(v) : "v"(o_out), "s"(out) : "memory");
-                            ob[k] = v;
-                        }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                        for (int k = 0; k < ZK_EXEC_B; k++) asm volatile("" : "+v"(ob[k]));        // (the loads' results are used only behind the wait)
-                    } else
-#endif
 #pragma unroll
                     for (int k = 0; k < ZK_EXEC_B; k++) {
                         const uint32_t s = sw[k];
