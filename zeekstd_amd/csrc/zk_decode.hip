@@ -1644,13 +1644,15 @@ void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, 
 #undef ZK_EXEC_LAUNCH
 }
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
-                     ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k, const uint64_t *skip)
+                     ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k, const uint64_t *skip, uint32_t wide_from)
 {
-    // a large batch: sixteen frames per wave (the chains' latency is the same, the instruction slots a sixteenth; 512 frames of 2 MiB:
-    // a wave per frame 5.3 / 6.5 ms per step against 5.9 / 7.6, two batches in flight / one at a time)
+    // a large batch: sixteen frames per wave (the chains' latency is the same, the instruction slots a sixteenth).  From how many frames:
+    // the decoder's pass runs alone on the device or beside a neighbour's entropy stage -- 512 frames of 2 MiB: a wave per frame 5.3 / 6.5 ms
+    // per step against 5.9 / 7.6 (two batches in flight / one at a time), hence 1024; the encoder's runs beside its matcher, which pays for
+    // every instruction slot the checksums take -- measured from 512 frames in round 3, and left there
     if (skip) { hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes, skip); return; }
     if (k.xxh == 3) hipLaunchKernelGGL(zk_k_xxh64_lean, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
-    else if (k.xxh ? k.xxh == 2 || k.xxh >= 4 : count >= 1024) hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes, (const uint64_t *)nullptr);
+    else if (k.xxh ? k.xxh == 2 || k.xxh >= 4 : count >= wide_from) hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes, (const uint64_t *)nullptr);
     else hipLaunchKernelGGL(zk_k_xxh64, dim3(count), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
 }
 void zk_launch_xxh64_follow(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count, const ZkFrameInfo *infos, uint64_t *progress)

@@ -27,7 +27,8 @@ void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, 
                     const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen, const ZkKernelChoice &k, bool dense = false,
                     uint64_t *progress = nullptr);      // progress: one word per frame for zk_launch_xxh64_follow (zk_decode.hip: zk_publish)
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
-                     ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k, const uint64_t *skip = nullptr);
+                     ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k, const uint64_t *skip = nullptr,
+                     uint32_t wide_from = 1024);         // frames from which sixteen share a wave (the encoder passes 512: zk_decode.hip)
 // the checksums beside the executor that publishes `progress` (launched on another queue); frames it verifies are marked in `progress`,
 // zk_launch_xxh64(..., skip = progress) behind the executor takes the rest
 void zk_launch_xxh64_follow(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count, const ZkFrameInfo *infos, uint64_t *progress);
