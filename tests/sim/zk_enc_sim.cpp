@@ -5,6 +5,7 @@
 // (oracle/zstd_oracle_enc.c) block by block -- the kernel's logic is checked before a GPU is involved.
 #include "hip_wg_emu.h"
 #include "../../zeekstd_amd/csrc/zk_enc_match.h"
+#include "../../zeekstd_amd/csrc/zk_enc_match2.h"
 #include "../../zeekstd_amd/csrc/zk_enc_plan.h"
 
 // Encode plan + match kernel over src[0, n) cut into frames of frame_size bytes; prefix (may be null) is what
@@ -78,7 +79,7 @@ extern "C" int zk_enc_sim_match(const uint8_t *src, uint64_t n, uint32_t frame_s
                 else if (zke_step(level) == 1024) zk_k_enc_match<15, 1, 1024, true>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
                 else zk_k_enc_match<15, 1, 4096, true>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
             }
-            else if (zke_fast(level)) zk_k_enc_match<14, 0, 4096, false>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
+            else if (zke_fast(level)) zk_k_enc_match2<14>(msrc, segs.data(), blocks.data(), seqs, lits);
             else if (zke_step(level) == 1024) zk_k_enc_match<15, 1, 1024, false>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
             else zk_k_enc_match<15, 1, 4096, false>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
         };

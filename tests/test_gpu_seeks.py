@@ -127,3 +127,39 @@ def test_cpu_suites_also_pass_on_the_gpu_box():
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "not gpu", "tests/test_seek_table.py", "tests/test_abi.py"],
                        cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_a_frame_with_more_sequences_than_its_output_could_hold(engine):
+    """the small path sizes its record scratch from bounds the host knows (sequences <= d / 3); a crafted frame
+    declares 30 000 sequences in a dozen bytes (RLE_Mode for all three tables, 0-bit codes: RFC 8878 3.1.1.3.2.1) and claims
+    100 bytes of output.  zk_k_small_walk now counts the record slots against what was reserved and hands the frame to the general
+    path, which sizes the records from the real totals and gives libzstd's verdict: the frame is damaged.  (Before: the small
+    entropy kernel wrote 30 000 records into room for ~8 000.)  lib/src/decode.rs:242-256 is the loop this sits under."""
+    n = 30000
+    block = bytes([4 << 3]) + b"abcd" + bytes([(n >> 8) + 128, n & 0xFF, 0x54, 0, 0, 0]) + b"\x01"
+    frame = bytes.fromhex("28B52FFD") + bytes([0x20, 100]) + ((len(block) << 3) | (2 << 1) | 1).to_bytes(3, "little") + block
+    good = engine.encode_frames(np.frombuffer(zko.gen_chunks(3 * FSZ, 3), np.uint8), FSZ, 1, False)
+    comp = good[0][:good[1][0][0]] + frame + good[0][good[1][0][0]:]
+    frames = [good[1][0], (len(frame), 100)] + list(good[1][1:])
+    d = DecodeOptions(_seekable(comp, frames)).engine(engine).into_decoder()
+    buf = bytearray(FSZ)
+    d.set_offset(FSZ + 10)                                      # a seek into the crafted frame: the small path
+    d.set_offset_limit(FSZ + 60)
+    with pytest.raises(zk.Error):
+        while d.decompress(buf):
+            pass
+    # the frames around it still decode, through the same decoder
+    want = zko.gen_chunks(3 * FSZ, 3)
+    d2 = DecodeOptions(_seekable(comp, frames)).engine(engine).into_decoder()
+    d2.set_offset(FSZ + 100 + 5)
+    d2.set_offset_limit(FSZ + 100 + 4000)
+    got = bytearray()
+    while True:
+        k = d2.decompress(buf)
+        if not k:
+            break
+        got += buf[:k]
+    assert bytes(got) == want[FSZ + 5:FSZ + 4000]
+    # and the engine's own verdict on the frame alone
+    _, st = engine.decode_frames(frame + b"\0" * 8, [0, len(frame)], [0, 100], raise_on_error=False)
+    assert st[0] != 0

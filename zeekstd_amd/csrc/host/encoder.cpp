@@ -135,6 +135,9 @@ CompressionProgress RawEncoder::compress_with_prefix(const uint8_t *in, size_t i
                 // less than half of n is reached, only the bytes since the last probe are encoded, as a frame of their own: what
                 // they add to the frame is at most that (they lose their history, nothing else), the sum stays an upper bound of
                 // the frame's size, every piece is O(its length), and the steps keep the cap that keeps the window.
+                // ("upper bound" is a heuristic -- the FSE tables are fitted per frame, so pieces of heterogeneous input can
+                // come out a little smaller apart than together; coarse mode therefore ends at HALF of n by the bound, and the frame's
+                // real size decides from there on.)
                 est_c_ += encode_piece(piece_start_, d);
                 piece_start_ = d;
                 if (2 * est_c_ < want) {

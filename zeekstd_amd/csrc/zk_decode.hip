@@ -1056,6 +1056,12 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
             }
         }
         pos += b_out_size;
+        //  __syncthreads() orders what the waves of THIS workgroup see (one L1, processed in order: the compiler emits no
+        // vmcnt wait for it); the checksum wave of another kernel reads through the XCD's L2, where a store is only once it has been
+        // acknowledged -- so with progress words every wave waits out its own stores before the barrier in front of the publish, once
+        // per block.  (Otherwise bytes of lane 0's wave alone were known to have landed, and a decode repeated into the same buffer
+        // could be "verified" on the bytes of the decode before.)
+        if (progress) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                      // block bytes visible before the next block reads history
         if (progress && ((uint32_t)pos >> ZK_PUB_LOG) != published) {
             published = (uint32_t)pos >> ZK_PUB_LOG;
@@ -1440,7 +1446,7 @@ __global__ __launch_bounds__(256) void zk_k_status(const ZkFrameInfo *infos, uin
 constexpr uint32_t ZK_SMALL_OVERFLOW = 0xFFFFFFFFu;
 constexpr int ZK_SMALL_FSE_BLOCKS = 8;
 __global__ __launch_bounds__(256) void zk_k_small_walk(const uint8_t *h_comp, uint64_t comp_bytes, const uint64_t *h_offs, uint32_t count,
-                                                       uint64_t dst_cap, uint32_t block_cap, uint8_t *d_comp, uint64_t *d_offs,
+                                                       uint64_t dst_cap, uint32_t block_cap, uint64_t seq_cap, uint8_t *d_comp, uint64_t *d_offs,
                                                        ZkFrameInfo *infos, ZkFrameBase *bases, ZkBlock *blocks, uint64_t *words)
 {
     __shared__ uint32_t s_tot[4];
@@ -1489,7 +1495,10 @@ __global__ __launch_bounds__(256) void zk_k_small_walk(const uint8_t *h_comp, ui
         }
     }
     __syncthreads();
-    const bool overflow = s_tot[0] > block_cap;
+    // the scratch was sized from bounds the host knows; a crafted frame can declare more sequences than its output could hold
+    // (RLE tables, 0-bit codes: ~98 k sequences in a few bytes) -- more record slots than the host reserved is an overflow too, and
+    // the general path, which sizes the records from the real totals, gives the verdict
+    const bool overflow = s_tot[0] > block_cap || s_tot[1] > seq_cap;
     if (tid < count) {
         if (overflow) { fi.status = ZK_E_GENERIC; fi.n_blocks = 0; }
         infos[tid] = fi;
@@ -1662,9 +1671,9 @@ void zk_launch_xxh64_follow(hipStream_t st, const uint8_t *data, const uint64_t 
 }
 
 void zk_launch_small_walk(hipStream_t st, const uint8_t *h_comp, uint64_t comp_bytes, const uint64_t *h_offs, uint32_t count, uint64_t dst_cap,
-                          uint32_t block_cap, uint8_t *d_comp, uint64_t *d_offs, ZkFrameInfo *infos, ZkFrameBase *bases, ZkBlock *blocks, uint64_t *words)
+                          uint32_t block_cap, uint64_t seq_cap, uint8_t *d_comp, uint64_t *d_offs, ZkFrameInfo *infos, ZkFrameBase *bases, ZkBlock *blocks, uint64_t *words)
 {
-    hipLaunchKernelGGL(zk_k_small_walk, dim3(1), dim3(256), 0, st, h_comp, comp_bytes, h_offs, count, dst_cap, block_cap, d_comp, d_offs, infos, bases, blocks, words);
+    hipLaunchKernelGGL(zk_k_small_walk, dim3(1), dim3(256), 0, st, h_comp, comp_bytes, h_offs, count, dst_cap, block_cap, seq_cap, d_comp, d_offs, infos, bases, blocks, words);
 }
 void zk_launch_small_entropy(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeqP *seqs, uint32_t groups, bool split)
 {

@@ -26,6 +26,10 @@ constexpr uint32_t ZKE_PARCAP = 16;               // match length measured per p
 // worked on), 64 bytes of lookahead, and the window behind the group -- the largest offset it produces.
 constexpr uint32_t ZKE_RING = 65536;
 constexpr uint32_t ZKE_WINDOW = ZKE_RING - 2 * ZKE_GROUP_POS - 64;   // 57280: the next group's bytes enter the ring while a group is still compared
+// Round 5: the fast setting without a long-distance table (no prefix beyond the ring's reach) runs zk_enc_match2.h's kernel: candidates at
+// even positions only, table matches of 5+ bytes, taken matches caught up backwards by up to 4 bytes (the twin: g_stride == 2).
+ZK_HD bool zke_fast2(int level, uint64_t prefix_len) { return zke_fast(level) && prefix_len <= ZKE_WINDOW; }
+ZK_HD uint32_t zke_minmatch2(int level, uint64_t prefix_len) { return zke_fast2(level, prefix_len) ? 5u : zke_minmatch(level); }
 // The matcher's unit of work is a SEGMENT of a frame, one workgroup each: a 2 MiB frame spreads over 8 CUs, and 2048 such
 // frames are 16384 workgroups.  A segment after a frame's first starts with an empty table that receives the positions of the
 // ZKE_WINDOW bytes before it (what a prefix does for a frame), counts its positions from that history's start and does not

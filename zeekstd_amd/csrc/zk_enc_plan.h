@@ -61,7 +61,7 @@ inline void zke_plan_fill(uint64_t n, uint32_t frame_size, int level, uint64_t p
         fr.block_base = bcount;
         fr.hist = fr.d_size ? hist : 0;
         fr.m_off = hist ? (uint64_t)f * ((uint64_t)hist + frame_size) : fr.src_off;
-        fr.minmatch = zke_minmatch(level); fr.seg_at = 0;
+        fr.minmatch = zke_minmatch2(level, prefix_len); fr.seg_at = 0;
         for (uint32_t b = 0; b < fr.n_blocks; b++) {
             ZkEncBlock &k = blocks[bcount++];
             memset(&k, 0, sizeof k);

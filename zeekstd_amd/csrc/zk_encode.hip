@@ -40,6 +40,7 @@ extern "C" void zk_debug_enc_clocks(unsigned long long *out, int reset)
 #define ZKE_CLK_END() do { if ((threadIdx.x & 63) == 0) for (int i = 0; i < 16; i++) atomicAdd(&zke_dbg_clk[i], clk_[i]); } while (0)
 #endif
 #include "zk_enc_match.h"
+#include "zk_enc_match2.h"
 #ifdef ZKE_ENT_CLOCKS
 // experiments: the same for the entropy kernel (per wave: slot = 4 * phase + wave; tools/ent_clocks.py)
 __device__ unsigned long long zke_dbg_clk[48];
@@ -865,9 +866,9 @@ __global__ __launch_bounds__(256) void zk_k_enc_ldm_build(ZkEncLdm ldm, uint32_t
 }
 // The same for the frames' own tables (in-frame far history): blockIdx.y = frame; frame f's table = table + (f << ldm.log), of which
 // its own 2^zke_ldm_log(size) entries are used.
-__global__ __launch_bounds__(256) void zk_k_enc_ldm_build_frames(const uint8_t *src, ZkEncLdm ldm, uint32_t *table)
+__global__ __launch_bounds__(256) void zk_k_enc_ldm_build_frames(const uint8_t *src, ZkEncLdm ldm, uint32_t *table, uint32_t f0)
 {
-    const uint64_t f = blockIdx.y, at = f * ldm.frame_size;
+    const uint64_t f = (uint64_t)f0 + blockIdx.y, at = f * ldm.frame_size;
     const uint64_t n = ldm.n_total - at < ldm.frame_size ? ldm.n_total - at : ldm.frame_size;
     const uint32_t log = zke_ldm_log(n);
     const uint8_t *s = src + at;
@@ -888,7 +889,11 @@ void zk_launch_enc_ldm_build_frames(hipStream_t st, const uint8_t *src, const Zk
 {
     (void)hipMemsetAsync(table, 0xFF, ((size_t)nframes * sizeof(uint32_t)) << ldm.log, st);
     const uint64_t wgs = ((uint64_t)ldm.frame_size + 4095) / 4096;
-    hipLaunchKernelGGL(zk_k_enc_ldm_build_frames, dim3((uint32_t)(wgs < 1024 ? wgs : 1024), nframes), dim3(256), 0, st, src, ldm, table);
+    // a grid's y dimension ends at 65535 (4 GiB of 64 KiB frames are 65536 of them): frames in launches of at most that many
+    for (uint32_t f0 = 0; f0 < nframes; f0 += 65535u) {
+        const uint32_t cnt = nframes - f0 < 65535u ? nframes - f0 : 65535u;
+        hipLaunchKernelGGL(zk_k_enc_ldm_build_frames, dim3((uint32_t)(wgs < 1024 ? wgs : 1024), cnt), dim3(256), 0, st, src, ldm, table, f0);
+    }
 }
 void zk_launch_enc_ldm_build(hipStream_t st, const ZkEncLdm &ldm, uint32_t *table)
 {
@@ -906,7 +911,7 @@ void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *s
         else if (zke_step(level) == 1024) ZKE_GO(15, 1, 1024, true);
         else ZKE_GO(15, 1, 4096, true);
     }
-    else if (zke_fast(level)) ZKE_GO(14, 0, 4096, false);
+    else if (zke_fast(level)) hipLaunchKernelGGL((zk_k_enc_match2<14>), dim3(nsegs), dim3(ZKE_THREADS), 0, st, src, segs, blocks, seqs, lits);   // zke_fast2(): the plan set minmatch 5
     else if (zke_step(level) == 1024) ZKE_GO(15, 1, 1024, false);
     else ZKE_GO(15, 1, 4096, false);
 #undef ZKE_GO

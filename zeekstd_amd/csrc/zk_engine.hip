@@ -58,7 +58,7 @@ extern "C" int zk_engine_set_kernel_choice(zk_engine *e, int what, int value)
     if (!e) return ZK_ERR_ARGUMENT;
     ZkKernelChoice &k = e->choice;
     switch (what) {
-    case ZK_CHOICE_RESET: k = ZkKernelChoice(); return 0;
+    case ZK_CHOICE_RESET: k = ZkKernelChoice(); e->pipe_contexts = 0; e->pipe_chunk_bytes = 0; zk_hostpipe_tune(e); return 0;   // every key, the host pipeline's two included
     case ZK_CHOICE_FSE_OWN: if (value < 0 || value > 2) return ZK_ERR_ARGUMENT; k.fse_own = value; return 0;
     case ZK_CHOICE_FSE_SHARED: if (value < 0 || value > 3) return ZK_ERR_ARGUMENT; k.fse_shared = value; return 0;
     case ZK_CHOICE_EXEC_LANES: if (value != 0 && value != 128 && value != 256 && value != 512 && value != 1024) return ZK_ERR_ARGUMENT; k.exec_lanes = value; return 0;

@@ -428,7 +428,8 @@ static int zk_decode_small(zk_engine *e, zk_hostpipe *hp, const zk_host_src &src
     if ((rc = zk_devbuf_reserve(e, c.bases, (size_t)count * sizeof(ZkFrameBase)))) return rc;
     if ((rc = zk_devbuf_reserve(e, c.words, 16 * sizeof(uint64_t)))) return rc;
     if ((rc = zk_devbuf_reserve(e, c.blocks, (size_t)(block_cap + 1) * sizeof(ZkBlock)))) return rc;
-    if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)(dsz / 3 + count + 1 + 8ull * (block_cap + 1)) * sizeof(ZkSeqP)))) return rc;     // (+ 7 per block: a block's records start on a 64-byte line)
+    const uint64_t seq_cap = dsz / 3 + count + 1 + 8ull * (block_cap + 1);        // record slots: what the walk may hand out (it checks)
+    if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)seq_cap * sizeof(ZkSeqP)))) return rc;     // (+ 7 per block: a block's records start on a 64-byte line)
     if ((rc = zk_devbuf_reserve(e, c.lit, (size_t)dsz + 64))) return rc;
     if ((rc = zk_devbuf_reserve(e, s.d_in, comp_bytes + 64))) return rc;
     if ((rc = zk_devbuf_reserve(e, s.d_out, (size_t)dsz + 64))) return rc;
@@ -440,7 +441,7 @@ static int zk_decode_small(zk_engine *e, zk_hostpipe *hp, const zk_host_src &src
     uint64_t *words = (uint64_t *)c.words.p, *d_offs = (uint64_t *)s.d_off.p;
     const uint8_t *comp = (const uint8_t *)s.d_in.p;
     const uint32_t gen = ++hp->small_gen;
-    zk_launch_small_walk(st, h_comp, csz, h_offs, count, dsz, block_cap, (uint8_t *)s.d_in.p, d_offs, infos, (ZkFrameBase *)c.bases.p, blocks, words);
+    zk_launch_small_walk(st, h_comp, csz, h_offs, count, dsz, block_cap, seq_cap, (uint8_t *)s.d_in.p, d_offs, infos, (ZkFrameBase *)c.bases.p, blocks, words);
     uint32_t groups = (block_cap + 15) / 16;
     if (groups > 32) groups = 32;
     zk_launch_small_entropy(st, comp, blocks, words, (uint8_t *)c.lit.p, (ZkSeqP *)c.seqs.p, groups, e->choice.small_path == 2);

@@ -37,7 +37,7 @@ void zk_launch_status(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, 
 
 // small batches (a seek): no host round trip, no copy commands -- see zk_decode.hip
 void zk_launch_small_walk(hipStream_t st, const uint8_t *h_comp, uint64_t comp_bytes, const uint64_t *h_offs, uint32_t count, uint64_t dst_cap,
-                          uint32_t block_cap, uint8_t *d_comp, uint64_t *d_offs, ZkFrameInfo *infos, ZkFrameBase *bases, ZkBlock *blocks, uint64_t *words);
+                          uint32_t block_cap, uint64_t seq_cap, uint8_t *d_comp, uint64_t *d_offs, ZkFrameInfo *infos, ZkFrameBase *bases, ZkBlock *blocks, uint64_t *words);
 void zk_launch_small_entropy(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, const uint64_t *words, uint8_t *lit, ZkSeqP *seqs, uint32_t groups, bool split);
 void zk_launch_small_publish(hipStream_t st, const ZkFrameInfo *infos, const uint64_t *d_offs, uint32_t count, const uint8_t *dst, uint8_t *h_out,
                              int32_t *d_status, int32_t *h_status, uint64_t *words, uint32_t *h_flag, uint32_t gen);
