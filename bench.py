@@ -149,7 +149,12 @@ def cpu_baseline(comp, frames, data, sample_frames, level, cks, ref_comp=None, r
     v1, passes = _cpu_decode_rate(lib, comp[:csz], frames[:n], 1, 6.0)
     if v1 is None:
         return None
-    out = {"value": v1, "unit": "GiB/s", "cores": 1, "kind": f"port (zeekstd loops in C over dlopen'd libzstd {ver})",
+    pin_note = ("the reference pins libzstd 1.5.7 (Cargo.lock:1192-1193); " +
+                ("this box's libzstd is the pinned version" if ver.startswith("1.5.7") else
+                 f"this box's optimised libzstd is {ver}, whose decoder is slower than 1.5.7's by an unmeasured margin -- the speed-ups beside this value "
+                 f"are optimistic by that margin (the image's only 1.5.7 is pillow's bundled build, ~5x slower than a distro build: not used)"))
+    out = {"value": v1, "unit": "GiB/s", "cores": 1, "kind": f"port (zeekstd loops in C over dlopen'd libzstd {ver}); {pin_note}",
+           "libzstd_version": ver, "reference_pin": "1.5.7",
            "sample": f"zeekstd::Decoder loop (decode.rs:201-270, bench protocol decompress.rs:18-39), first {n} frames ({dsz >> 20} MiB) "
                      f"of the same (GPU-made) archive, best of {passes} passes, 1 thread"}
     va, passes = _cpu_decode_rate(lib, comp, frames, cores, 4.0)
@@ -189,6 +194,44 @@ def cpu_baseline(comp, frames, data, sample_frames, level, cks, ref_comp=None, r
         out["encode"] = {"value": src.size / te / 2**30, "unit": "GiB/s", "ratio": round(src.size / csize.value, 3),
                          "sample": f"zeekstd::Encoder loop (encode.rs:311-354,438-472) level {level}, {ne} frames, best of 2, 1 thread"}
     return out
+
+
+def _pmc(section):
+    """HBM bytes per kernel from the committed counter passes (profiles/pmc_traffic.json), or {}: constants of an earlier run of this
+    very command, labelled as such wherever they are quoted"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+    except OSError:
+        return {}, None
+    sec = pmc.get(section) if section != "kernels" else pmc.get("kernels")
+    if not isinstance(sec, dict):
+        return {}, None
+    return sec, f"profiles/pmc_traffic.json [{section}] ({pmc.get('collected', 'committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}), not this run"
+
+
+def roofline_of(kernel_ms, algo_bytes, step_ms=None, pmc_section=None, full_size=True):
+    """The roofline object of one leg: its slowest kernel against the HBM peak on the leg's ALGORITHMIC bytes (c_i + d_i per
+    frame, summed over the launch), measured with HIP events on the launch stream; `traffic` from the committed counter passes."""
+    if not kernel_ms:
+        return None
+    dom = max(kernel_ms, key=kernel_ms.get)
+    ach = algo_bytes / (kernel_ms[dom] * 1e-3) / 1e9
+    traffic, src = None, None
+    if pmc_section and full_size:
+        sec, src_ = _pmc(pmc_section)
+        traffic = sec.get(dom.split("(")[0], {}).get("hbm_bytes")
+        src = src_ if traffic is not None else None
+    out = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+           "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": int(algo_bytes)}
+    if step_ms:
+        out["step_frac"] = round(algo_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+    return out
+
+
+def _stats_ms(ts):
+    a = sorted(ts)
+    return {"n": len(a), "median": round(a[len(a) // 2] * 1e3, 3), "min": round(a[0] * 1e3, 3), "mean": round(sum(a) / len(a) * 1e3, 3)}
 
 
 def end_to_end(eng, zk, data, nframes, cks, reps=3):
@@ -626,7 +669,7 @@ def main():
         nf, csize = eng.encode_frames_dev(d_src, dsize, FRAME, level, cks, d_comp, cap, d_cs, d_ds)      # warm-up + the archive
         torch.cuda.synchronize()
         te = []
-        for _ in range(max(2, args.steps // 2)):
+        for _ in range(max(3, args.steps // 2)):
             t = time.perf_counter()
             eng.encode_frames_dev(d_src, dsize, FRAME, level, cks, d_comp, cap, d_cs, d_ds)
             te.append(time.perf_counter() - t)
@@ -639,7 +682,8 @@ def main():
         comp = None
         enc_info = {"value": round(dsize / min(te) / 2**30, 2), "unit": "GiB/s", "ratio": round(dsize / csize, 3),
                     "ms": round(min(te) * 1e3, 2), "kernel_ms": {k: round(v, 3) for k, v in ek.items()},
-                    "algorithmic_GBps_of_the_slowest_kernel": round((dsize + csize) / (max(ek.values()) * 1e-3) / 1e9, 1) if ek else None}
+                    "calls_ms": _stats_ms(te),
+                    "roofline": roofline_of(ek, dsize + csize, min(te) * 1e3, "kernels", nframes == 2048)}
     else:
         frames, comp = z_frames, z_comp
         d_comp = torch.from_numpy(np.frombuffer(comp + b"\0" * 64, np.uint8).copy()).to(dev)
@@ -715,10 +759,21 @@ def main():
     # the same K steps one batch at a time (zk_decode_frames_dev returns after each batch): reported beside the headline
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    sync_steps = []
     for _ in range(args.steps):
-        step()
+        ts_ = time.perf_counter()
+        step()                                                  # (returns when the batch is done: zk_decode_frames_dev synchronises its stream)
+        sync_steps.append(time.perf_counter() - ts_)
+    followed = eng.checksums_followed()                         # frames of the last lone batch whose checksums ran BESIDE the executor
     torch.cuda.synchronize()
     sync_elapsed = time.perf_counter() - t1
+    # SURVEY 8d's protocol asks for median and min beside the mean: the headline's K pipelined steps are one span by contract, so two more
+    # spans of K steps are timed the same way (rank-local, behind the contract's span) and every span's ms per step is listed
+    spans = [elapsed]
+    for _ in range(2):
+        torch.cuda.synchronize(); tsp = time.perf_counter()
+        run_timed(args.steps)
+        torch.cuda.synchronize(); spans.append(time.perf_counter() - tsp)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -727,7 +782,7 @@ def main():
     value = total_bytes / elapsed / 2**30
 
     # ---- secondary leg: the same steps on the archive the reference's CPU Encoder loop (libzstd) wrote for this input
-    def ref_leg(rz_comp, rz_frames, note):
+    def ref_leg(rz_comp, rz_frames, note, pmc_section):
         r_c = np.zeros(nframes + 1, np.uint64); r_c[1:] = np.cumsum([f[0] for f in rz_frames])
         r_csize = int(r_c[-1])
         dr_comp = torch.from_numpy(np.frombuffer(rz_comp + b"\0" * 64, np.uint8).copy()).to(dev)
@@ -757,14 +812,15 @@ def main():
         r_k = eng.kernel_times()
         eng.set_profiling(False)
         return {"value": round(dsize * args.steps / r_el / 2**30, 3), "unit": "GiB/s", "ms_per_step": round(r_el / args.steps * 1e3, 3),
-                "compressed_bytes": r_csize, "kernel_ms": {k: round(v, 3) for k, v in r_k.items()}, "note": note}
+                "compressed_bytes": r_csize, "kernel_ms": {k: round(v, 3) for k, v in r_k.items()},
+                "roofline": roofline_of(r_k, r_csize + dsize, r_el / args.steps * 1e3, pmc_section, nframes == 2048), "note": note}
 
     ref_info = None
     if use_gpu_archive and want_ref_archive and z_comp:
         ref_info = ref_leg(z_comp, z_frames, "archive written by the reference Encoder loop over the box's libzstd (level 1: 128 KiB blocks with "
-                           "their own FSE tables -> zk_k_fse_quad instead of zk_k_fse_predef); bit-exact, checksums verified")
+                           "their own FSE tables -> zk_k_fse_quad instead of zk_k_fse_predef); bit-exact, checksums verified", "reference_made_level_1")
         if z3:
-            ref_info["level_3"] = ref_leg(z3[0], z3[1], "the same at level 3, the reference CLI's default: ~60 % more sequences per frame, a 2 MiB window")
+            ref_info["level_3"] = ref_leg(z3[0], z3[1], "the same at level 3, the reference CLI's default: ~60 % more sequences per frame, a 2 MiB window", "reference_made_level_3")
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, live
     eng.set_profiling(True)
@@ -848,8 +904,14 @@ def main():
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "reference_made_archive": ref_info,
+            "spans_of_K_steps_ms_per_step": {"n": len(spans), "median": round(sorted(spans)[len(spans) // 2] / args.steps * 1e3, 3),
+                                             "min": round(min(spans) / args.steps * 1e3, 3), "mean": round(sum(spans) / len(spans) / args.steps * 1e3, 3),
+                                             "note": "the contract's span first (value / ms_per_step are its), then two more spans of K steps timed alike"},
             "one_batch_at_a_time": {"value": round(dsize * args.steps / sync_elapsed / 2**30, 3), "unit": "GiB/s",
-                                    "ms_per_step": round(sync_elapsed / args.steps * 1e3, 3),
+                                    "ms_per_step": round(sync_elapsed / args.steps * 1e3, 3), "steps_ms": _stats_ms(sync_steps),
+                                    "checksums_followed": followed,
+                                    "checksums_followed_note": "frames verified by zk_k_xxh64_follow beside the executor (same-XCD hand-off: depends on how the "
+                                                               "dispatcher deals workgroups to XCDs; the rest is verified behind the executor)",
                                     "note": "same steps through the synchronous zk_decode_frames_dev (rank-local, no overlap between batches)"},
             "config": {"workload": (f"configs[2]: 4 GiB/GPU, 2048 x 2 MiB frames, level {level}, XXH64 checksums verified"
                                     if args.workload == "c3" else f"configs[1]: 256 MiB, 128 x 2 MiB frames, level {level}, decode-only"),

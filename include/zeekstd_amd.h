@@ -146,6 +146,15 @@ int zk_decode_frame_list_dev(zk_engine *e, const void *d_comp, uint64_t comp_siz
                              const void *d_ids, const void *d_out_off, uint32_t count, void *d_dst, uint64_t dst_cap,
                              int verify, void *d_frame_status, void *stream);
 
+/* The decompressed sizes of frames whose seek entries the caller does not hold: header walk + sequence walks on the device, no output
+ * (a frame that carries Frame_Content_Size answers from its header).  What libzstd's streaming decoder needs no table for
+ * (lib/src/decode.rs:243-245: ZSTD_decompressStream is handed bytes, not entries); the Level-C shim asks here before
+ * it decodes.  sizes[count] (uint64), frame_status[count] (0 or -ZSTD_ErrorCode).  _dev: device pointers, c_off relative to d_comp. */
+int zk_frame_content_sizes(zk_engine *e, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off, uint32_t first, uint32_t count,
+                           uint64_t *sizes, int32_t *frame_status);
+int zk_frame_content_sizes_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off, uint32_t first, uint32_t count,
+                               void *d_sizes, void *d_frame_status, void *stream);
+
 /* Two batches in flight.  zk_decode_submit_dev enqueues exactly what zk_decode_frames_dev runs, on one of the
  * engine's two decode contexts (own HIP queues and scratch), and returns while the kernels are still running;
  * *slot_out names the context.  zk_decode_wait(slot) blocks until that batch is complete and returns its status (0,

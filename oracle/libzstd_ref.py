@@ -10,6 +10,7 @@ that must accept GPU-encoded frames.
 """
 import ctypes as C
 import glob
+import os
 
 CSTREAM_OUT = 131591   # ZSTD_CStreamOutSize  (encode.rs:599)
 DSTREAM_IN = 131075    # ZSTD_DStreamInSize   (decode.rs:181)
@@ -27,6 +28,9 @@ class OutBuf(C.Structure):
 _CANDIDATES = {
     "1.5.7": sorted(glob.glob("/usr/local/lib/python3*/dist-packages/pillow.libs/libzstd-*.so.1.5.7")),
     "system": ["/usr/lib/x86_64-linux-gnu/libzstd.so.1", "/opt/conda/lib/libzstd.so.1"],
+    # the library UNDER TEST where a test says so: the product's Level-C shim (libzstd's symbols over the GPU engine), driven with the very
+    # call sequences below -- the unmodified crate's FFI, exercised end to end (tests/test_gpu_levelc.py)
+    "shim": [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zeekstd_amd", "libzstd_zeekstd_amd.so")],
 }
 _cache = {}
 

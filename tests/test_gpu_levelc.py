@@ -1,0 +1,129 @@
+"""LEVEL C of the boundary (VERDICT r4 "next" 7b): zeekstd_amd/libzstd_zeekstd_amd.so exports the libzstd symbols the
+UNMODIFIED zeekstd crate binds (lib/src/encode.rs:281-284, 336, 341-345, 444-448, 504-506; decode.rs:213, 243-245, 250-253) over
+the GPU engine.  oracle/libzstd_ref.py drives a libzstd with the reference's exact call sequences and buffer sizes (131 591 /
+131 075 / 131 072 bytes); here the library it drives is the shim:
+  * the goldens' inputs go through ZSTD_compressStream2(e_continue ... e_end) frame by frame, and the REAL libzstd (and the oracle)
+    decodes what came out;
+  * the goldens -- archives libzstd 1.5.7 wrote -- go through ZSTD_decompressStream, no seek table anywhere (zeekstd's frames
+    carry no Frame_Content_Size: the shim asks the engine for every frame's size, zk_frame_content_sizes);
+  * prefixes (ZSTD_CCtx_refPrefix / ZSTD_DCtx_refPrefix, re-referenced after every frame as decode.rs:248-255 does).
+One engine call per frame: the compatibility proof, not the fast path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import GOLDENS, PREFIX_GOLDENS
+from oracle import zko
+from oracle import libzstd_ref as Z
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def shim(engine):
+    l = Z.load("shim")
+    assert l is not None, "zeekstd_amd/libzstd_zeekstd_amd.so is not built (make -C zeekstd_amd/csrc)"
+    assert Z.version("shim") == "1.5.7"                    # the API version the crate pins (Cargo.lock:1192-1193)
+    return l
+
+
+SMALL = [g for g in GOLDENS if g.meta["input_len"] <= 1 << 20]
+
+
+@pytest.mark.parametrize("g", SMALL, ids=[g.name for g in SMALL])
+def test_goldens_decode_through_ZSTD_decompressStream(shim, g):
+    assert Z.decode_stream(g.comp, g.meta["input_len"], "shim") == g.input()
+
+
+@pytest.mark.parametrize("g", PREFIX_GOLDENS, ids=[g.name for g in PREFIX_GOLDENS])
+def test_prefix_goldens_through_ZSTD_DCtx_refPrefix(shim, g):
+    assert Z.decode_stream(g.comp, g.meta["input_len"], "shim", prefix=g.prefix()) == g.input()
+
+
+@pytest.mark.parametrize("level,cks,fsz", [(1, True, 40000), (3, False, 100), (1, False, 1 << 20), (6, True, 300000)])
+def test_inputs_encode_through_ZSTD_compressStream2(shim, level, cks, fsz):
+    data = zko.make_input([["text", 150000, 5], ["zeros", 7000], ["random", 3000, 9], ["text", 60000, 6]])
+    if fsz == 100:
+        data = data[:5000]
+    comp, frames = Z.encode_seekable_frames(data, fsz, level, cks, "shim")
+    assert [d for _, d in frames] == [min(fsz, len(data) - o) for o in range(0, len(data), fsz)]
+    assert sum(c for c, _ in frames) == len(comp)
+    pos = dpos = 0
+    for c, d in frames:                                     # every frame: the checksum flag as asked (encode.rs:834-870), the oracle's decode
+        assert (comp[pos + 4] >> 2) & 1 == int(cks)
+        out, used = zko.frame_decode(comp[pos:pos + c], d, True)
+        assert used == c and out == data[dpos:dpos + d]
+        pos += c; dpos += d
+    for which in ("system", "1.5.7"):                       # the real libzstd reads it back
+        if Z.load(which) is not None:
+            assert Z.decode_stream(comp, len(data), which) == data, which
+    assert Z.decode_stream(comp, len(data), "shim") == data     # and so does the shim itself (frames without Frame_Content_Size)
+
+
+def test_an_empty_frame_has_the_reference_bytes(shim):
+    """Encoder::finish on no input: end_frame with nothing written (encode.rs:755-757) -- SURVEY Appendix B's 9 / 13 bytes"""
+    comp, frames = Z.encode_seekable_frames(b"", 1 << 21, 1, False, "shim")
+    assert comp == bytes.fromhex("28B52FFD2000010000") and frames == [(9, 0)]
+    comp, frames = Z.encode_seekable_frames(b"", 1 << 21, 1, True, "shim")
+    assert comp == bytes.fromhex("28B52FFD240001000099E9D851") and frames == [(13, 0)]
+    assert Z.decode_stream(comp, 0, "shim") == b""
+
+
+def test_prefix_round_trip_through_the_shim(shim):
+    prefix = zko.make_input([["text", 90000, 41]])
+    data = prefix[2000:50000] + zko.make_input([["text", 20000, 42]])
+    comp, frames = Z.encode_seekable_frames(data, 30000, 1, True, "shim", prefix=prefix)
+    plain, _ = Z.encode_seekable_frames(data, 30000, 1, True, "shim")
+    assert len(comp) < len(plain) // 2                      # the prefix is found
+    assert Z.decode_stream(comp, len(data), "shim", prefix=prefix) == data
+    if Z.load("system") is not None:
+        assert Z.decode_stream(comp, len(data), "system", prefix=prefix, window_log_max=27) == data
+
+
+def test_damage_is_reported_in_libzstds_codes(shim):
+    g = next(x for x in GOLDENS if x.name == "text_l1_64k")
+    bad = bytearray(g.comp)
+    bad[len(bad) // 2] ^= 0x55
+    with pytest.raises(Z.ZstdError):
+        Z.decode_stream(bytes(bad), -1, "shim")
+    with pytest.raises(Z.ZstdError, match="[Uu]nknown frame|prefix"):
+        Z.decode_stream(b"not a zstd frame at all", -1, "shim")
+    # parameters only between frames (zstd.h: stage_wrong), sizes as the crate's buffers expect them
+    assert shim.ZSTD_isError(shim.ZSTD_CCtx_setParameter(None, 100, 1))
+    for name, want in (("ZSTD_CStreamOutSize", 131591), ("ZSTD_CStreamInSize", 131072), ("ZSTD_DStreamInSize", 131075), ("ZSTD_DStreamOutSize", 131072)):
+        f = getattr(shim, name); f.restype = C.c_size_t
+        assert f() == want
+
+
+def test_tiny_output_buffers_and_split_inputs(shim):
+    """decompressStream with 1 ... 7-byte inputs and 5-byte outputs: it never takes a byte of the next frame, and a frame's last byte stays
+    with the caller until the frame's output is out (zeekstd's loop stops calling once its input is consumed, decode.rs:243)"""
+    g = next(x for x in GOLDENS if x.name == "text_100B_frames")
+    nfr = 12
+    comp = g.comp[:sum(f[0] for f in g.frames[:nfr])]
+    l = shim
+    dctx = l.ZSTD_createDCtx()
+    src = C.create_string_buffer(comp, len(comp))
+    ob = C.create_string_buffer(5)
+    out = bytearray()
+    pos, step, ends = 0, 1, 0
+    while pos < len(comp):
+        take = min(step, len(comp) - pos)
+        step = step % 7 + 1
+        inb = Z.InBuf(C.addressof(src) + pos, take, 0)
+        calls = 0
+        while inb.pos < take:
+            outb = Z.OutBuf(C.addressof(ob), 5, 0)
+            before = inb.pos
+            r = l.ZSTD_decompressStream(dctx, C.byref(outb), C.byref(inb))
+            assert not l.ZSTD_isError(r), l.ZSTD_getErrorName(r)
+            out += ob.raw[:outb.pos]
+            ends += r == 0
+            assert outb.pos or inb.pos > before, "a call without progress"
+            calls += 1
+            assert calls < 1000
+        pos += take
+    l.ZSTD_freeDCtx(dctx)
+    assert ends == nfr
+    assert bytes(out) == g.input()[:sum(f[1] for f in g.frames[:nfr])]

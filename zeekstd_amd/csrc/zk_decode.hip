@@ -36,9 +36,15 @@ __global__ __launch_bounds__(64) void zk_k_walk(const uint8_t *comp, uint64_t co
     if (f >= count) return;
     const uint32_t id = ids ? ids[f] : first + f;
     uint64_t cb = c_off[id], ce = c_off[id + 1];
-    uint64_t dsz = d_off[id + 1] - d_off[id];
+    // d_off == nullptr (zk_frame_content_sizes): nobody knows the frames' sizes yet, nothing is written
+    uint64_t dsz = d_off ? d_off[id + 1] - d_off[id] : ZK_SIZE_UNKNOWN;
     ZkFrameInfo fi;
-    if (!bases) {                                   // pass 1: count
+    if (!bases && !d_off) {
+        if (ce < cb || ce > comp_size) { fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; fi.status = ZK_E_SRC_SIZE_WRONG; fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.n_own_tables = 0; }
+        else zk_walk_frame(comp, cb, ce, dsz, f, nullptr, nullptr, fi);
+        if (fi.status != ZK_OK) { fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; }
+        infos[f] = fi;
+    } else if (!bases) {                            // pass 1: count
         const uint64_t o = out_off ? out_off[f] : d_off[id] - d_off[first];
         if (ce < cb || ce > comp_size || d_off[id + 1] < d_off[id]) {
             fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; fi.status = ZK_E_SRC_SIZE_WRONG;
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(64) void zk_k_walk(const uint8_t *comp, uint64_t co
 __global__ __launch_bounds__(1024) void zk_k_scan(const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals, const uint64_t *d_off, uint32_t first, const uint64_t *out_off)
 {
     // [5]: output bytes of the batch (what the frames claim): the host sizes nothing from it, it only tells dense sequence streams from sparse ones
-    if (threadIdx.x == 0) totals[5] = out_off ? out_off[count] : d_off[first + count] - d_off[first];
+    if (threadIdx.x == 0) totals[5] = out_off ? out_off[count] : d_off ? d_off[first + count] - d_off[first] : 0;
     __shared__ uint64_t wsum[16][4];
     __shared__ uint64_t carry[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1415,6 +1421,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
 // per-frame status words + first failing frame ((frame << 32) | code, min over frames); with `followed`: the number of frames whose
 // checksums zk_k_xxh64_follow verified
+// zk_frame_content_sizes: a frame's decompressed size = the regenerated sizes of its blocks, known once the sequence walks have run
+// (a compressed block's size is its literals + its match lengths: zk_k_fse_* leave it in ZkBlock::out_size).  One lane per frame.
+__global__ __launch_bounds__(256) void zk_k_frame_sizes(const ZkFrameInfo *infos, const ZkFrameBase *bases, const ZkBlock *blocks, uint32_t count, uint64_t *sizes, int32_t *status_out)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= count) return;
+    uint32_t st = infos[f].status;
+    uint64_t sum = 0;
+    if (st == ZK_OK) {
+        const ZkBlock *b = blocks + bases[f].block_base;
+        for (uint32_t i = 0; i < infos[f].n_blocks; i++) {
+            if (b[i].status != ZK_OK && st == ZK_OK) st = b[i].status;
+            sum += b[i].out_size;
+        }
+        if (st == ZK_OK && sum > ZK_MAX_FRAME) st = ZK_E_FRAMEPARAM_UNSUPPORTED;
+    }
+    sizes[f] = st == ZK_OK ? sum : 0;
+    status_out[f] = -(int32_t)st;
+}
+
 __global__ __launch_bounds__(256) void zk_k_status(const ZkFrameInfo *infos, uint32_t count, int32_t *status_out, unsigned long long *first_err,
                                                    const uint64_t *progress, unsigned long long *followed)
 {
@@ -1579,6 +1605,10 @@ void zk_launch_walk(hipStream_t st, const uint8_t *comp, uint64_t comp_size, con
                     uint32_t count, const uint32_t *ids, const uint64_t *out_off, uint64_t dst_cap, const ZkFrameBase *bases, ZkBlock *blocks, ZkFrameInfo *infos)
 {
     hipLaunchKernelGGL(zk_k_walk, dim3((count + 63) / 64), dim3(64), 0, st, comp, comp_size, c_off, d_off, first, count, ids, out_off, dst_cap, bases, blocks, infos);
+}
+void zk_launch_frame_sizes(hipStream_t st, const ZkFrameInfo *infos, const ZkFrameBase *bases, const ZkBlock *blocks, uint32_t count, uint64_t *sizes, int32_t *status_out)
+{
+    hipLaunchKernelGGL(zk_k_frame_sizes, dim3((count + 255) / 256), dim3(256), 0, st, infos, bases, blocks, count, sizes, status_out);
 }
 void zk_launch_scan(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals, const uint64_t *d_off, uint32_t first, const uint64_t *out_off)
 {

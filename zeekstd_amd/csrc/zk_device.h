@@ -71,6 +71,7 @@ enum : uint32_t {
 
 constexpr uint32_t ZK_BLOCK_MAX = 131072;          // Block_Maximum_Size upper bound
 constexpr uint32_t ZK_MAX_FRAME = 0x40000000u;     // SEEKABLE_MAX_FRAME_SIZE (reference lib.rs:58)
+constexpr uint64_t ZK_SIZE_UNKNOWN = ~0ull;        // zk_walk_frame: the frame's decompressed size is what is being asked for
 
 // ---------------------------------------------------------------- data records in HBM
 struct ZkFrameInfo {            // written by the frame walker, one per frame
@@ -697,7 +698,12 @@ ZK_HD void zk_walk_frame(const uint8_t *comp, uint64_t c_begin, uint64_t c_end, 
     if (fl == 2) fcs += 256;
     p += fl;
     if (single) window = fcs;
+    // d_size == ZK_SIZE_UNKNOWN: a frame nobody holds a seek entry for (zk_frame_content_sizes: the walk + the sequence walks then tell
+    // its size); the bounds below are taken against the largest frame the format of the reference allows
+    const bool unknown = d_size == ZK_SIZE_UNKNOWN;
+    if (unknown) d_size = fl ? fcs : (uint64_t)ZK_MAX_FRAME;
     if (fl && fcs != d_size) { fi.status = ZK_E_CORRUPTION; return; }
+    if (unknown && d_size > ZK_MAX_FRAME) { fi.status = ZK_E_FRAMEPARAM_UNSUPPORTED; return; }
     fi.checksum_flag = cks;
     fi.window = window > 0x80000000ull ? 0x80000000u : (uint32_t)window;
     uint32_t block_max = window < ZK_BLOCK_MAX ? (uint32_t)window : ZK_BLOCK_MAX;

@@ -402,6 +402,72 @@ extern "C" int zk_decode_frame_list_dev(zk_engine *e, const void *d_comp, uint64
     return zk_decode_impl(e, a, stream);
 }
 
+// ---------------------------------------------------------------------------------------------- frame sizes nobody knows yet
+// What libzstd's streaming decoder needs no table for -- how many bytes a frame decodes to -- this engine is told by the seek table
+// (lib/src/seek_table.rs:750).  A host that holds frames WITHOUT their entries (the Level-C shim under an unmodified zeekstd hands
+// over what ZSTD_decompressStream receives, lib/src/decode.rs:243-245) asks first: header walk + sequence walks, no literals, no
+// output.  Frames that carry Frame_Content_Size answer from their header.
+extern "C" int zk_frame_content_sizes_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off, uint32_t first, uint32_t count,
+                                          void *d_sizes, void *d_frame_status, void *stream)
+{
+    if (!e || (count && (!d_comp || !d_c_off || !d_sizes || !d_frame_status))) return ZK_ERR_ARGUMENT;
+    if (count == 0) return 0;
+    if (e->slot_busy[0]) return ZK_ERR_ARGUMENT;
+    ZK_HIP(hipSetDevice(e->device));
+    zk_dec_ctx c = zk_dec_context(e, 0, stream);
+    hipStream_t st = c.st;
+    const uint8_t *comp = (const uint8_t *)d_comp;
+    const uint64_t *c_off = (const uint64_t *)d_c_off;
+    int rc;
+    if ((rc = zk_devbuf_reserve(e, c.infos, (size_t)count * sizeof(ZkFrameInfo)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.bases, (size_t)count * sizeof(ZkFrameBase)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.words, 16 * sizeof(uint64_t)))) return rc;
+    ZkFrameInfo *infos = (ZkFrameInfo *)c.infos.p;
+    ZkFrameBase *bases = (ZkFrameBase *)c.bases.p;
+    uint64_t *words = (uint64_t *)c.words.p;
+    zk_launch_walk(st, comp, comp_size, c_off, nullptr, first, count, nullptr, nullptr, 0, nullptr, nullptr, infos);
+    zk_launch_scan(st, infos, count, bases, words, nullptr, first, nullptr);
+    ZK_HIP(hipMemcpyAsync(c.h_words, words, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    const uint64_t nblocks = c.h_words[0], nseq = c.h_words[1];
+    if (nblocks > 0xFFFFFFF0ull) return -(int)ZK_E_GENERIC;
+    if ((rc = zk_devbuf_reserve(e, c.blocks, (size_t)(nblocks + 1) * sizeof(ZkBlock)))) return rc;
+    if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)(nseq + 1) * sizeof(ZkSeqP)))) return rc;
+    ZkBlock *blocks = (ZkBlock *)c.blocks.p;
+    zk_launch_walk(st, comp, comp_size, c_off, nullptr, first, count, nullptr, nullptr, 0, bases, blocks, infos);
+    zk_launch_fse(st, comp, blocks, (uint32_t)nblocks, (uint32_t)c.h_words[4], (ZkSeqP *)c.seqs.p, e->choice, count);
+    zk_launch_frame_sizes(st, infos, bases, blocks, count, (uint64_t *)d_sizes, (int32_t *)d_frame_status);
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_HIP(hipGetLastError());
+    return 0;
+}
+// host pointers: comp[c_off[first] .. c_off[first + count]) is uploaded, sizes[count] and frame_status[count] come back
+extern "C" int zk_frame_content_sizes(zk_engine *e, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off, uint32_t first, uint32_t count,
+                                      uint64_t *sizes, int32_t *frame_status)
+{
+    if (!e || (count && (!comp || !c_off || !sizes || !frame_status))) return ZK_ERR_ARGUMENT;
+    if (count == 0) return 0;
+    const uint64_t lo = c_off[first], hi = c_off[first + count];
+    if (hi < lo || hi > comp_size) return -(int)ZK_E_SRC_SIZE_WRONG;
+    ZK_HIP(hipSetDevice(e->device));
+    int rc;
+    std::vector<uint64_t> rel(count + 1);
+    for (uint32_t i = 0; i <= count; i++) rel[i] = c_off[first + i] - lo;
+    if ((rc = zk_devbuf_reserve(e, e->st_comp, (size_t)(hi - lo) + 64))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->st_off, (size_t)(count + 1) * 8))) return rc;
+    if ((rc = zk_devbuf_reserve(e, e->st_misc, (size_t)count * 12))) return rc;
+    hipStream_t st = e->stream;
+    ZK_HIP(hipMemsetAsync((uint8_t *)e->st_comp.p + (hi - lo), 0, 64, st));                  // readable padding behind the last frame
+    ZK_HIP(hipMemcpyAsync(e->st_comp.p, comp + lo, hi - lo, hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(e->st_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, st));
+    uint64_t *d_sizes = (uint64_t *)e->st_misc.p;
+    int32_t *d_stat = (int32_t *)(d_sizes + count);
+    if ((rc = zk_frame_content_sizes_dev(e, e->st_comp.p, hi - lo, e->st_off.p, 0, count, d_sizes, d_stat, nullptr))) return rc;
+    ZK_HIP(hipMemcpy(sizes, d_sizes, (size_t)count * 8, hipMemcpyDeviceToHost));
+    ZK_HIP(hipMemcpy(frame_status, d_stat, (size_t)count * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- XXH64
 extern "C" int zk_xxh64_frames_dev(zk_engine *e, const void *d_data, const void *d_off, uint32_t count, void *d_out, void *stream)
 {

@@ -19,6 +19,7 @@ struct ZkKernelChoice {
 
 void zk_launch_walk(hipStream_t st, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
                     uint32_t count, const uint32_t *ids, const uint64_t *out_off, uint64_t dst_cap, const ZkFrameBase *bases, ZkBlock *blocks, ZkFrameInfo *infos);
+void zk_launch_frame_sizes(hipStream_t st, const ZkFrameInfo *infos, const ZkFrameBase *bases, const ZkBlock *blocks, uint32_t count, uint64_t *sizes, int32_t *status_out);
 void zk_launch_scan(hipStream_t st, const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals, const uint64_t *d_off, uint32_t first, const uint64_t *out_off);
 void zk_launch_huf(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint8_t *lit);
 void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, uint32_t n_own_tables, ZkSeqP *seqs, const ZkKernelChoice &k, uint32_t frames = 0);
