@@ -4,6 +4,9 @@
 //! does through `ZSTD_compressStream2` / `ZSTD_decompressStream` (encode.rs:340-346, decode.rs:242-256) -- runs as HIP
 //! kernels; seek table, offsets and sources keep their reference semantics.
 //!
+//! Upstream's public surface is complete here: the crate-root types, `seek_table::{Format, Serializer}`, `BytesWrapper`,
+//! the four constants, `Error`'s predicates and `Display` -- tests/test_abi.py diffs this file's public items against that list.
+//!
 //! NOT COMPILED in the build image (no cargo / rustc there): kept in step with the header by tools/gen_rust_ffi.py and
 //! tests/test_abi.py.  The C++ classes in zeekstd_amd/csrc/host/zeekstd.hpp are the compiled twin of this file.
 pub mod ffi;
@@ -21,11 +24,24 @@ pub enum Error {
     Zstd(usize),
 }
 pub type Result<T> = core::result::Result<T, Error>;
+/// re-exported from zstd-safe upstream (lib.rs:49): the level is what `ZSTD_c_compressionLevel` takes
+pub type CompressionLevel = i32;
+
+/// lib.rs:52-58
+pub const SEEKABLE_MAGIC_NUMBER: u32 = 0x8F92_EAB1;
+pub const SEEKABLE_MAX_FRAMES: u32 = 0x0800_0000;
+pub const SEEK_TABLE_INTEGRITY_SIZE: usize = 9;
+pub const SEEKABLE_MAX_FRAME_SIZE: usize = 0x4000_0000;
+pub(crate) const SKIPPABLE_HEADER_SIZE: usize = 8;      // lib.rs:62
+const SKIPPABLE_MAGIC: u32 = 0x184D_2A5E;               // seekable_format.md:59-70
 
 impl Error {
     pub fn is_offset_out_of_range(&self) -> bool { matches!(self, Error::OffsetOutOfRange) }       // error.rs:25
     pub fn is_frame_index_too_large(&self) -> bool { matches!(self, Error::FrameIndexTooLarge) }   // error.rs:36
     pub fn is_zstd(&self) -> bool { matches!(self, Error::Zstd(_)) }                               // error.rs:55
+    pub fn is_number_conversion_failed(&self) -> bool { matches!(self, Error::NumberConversionFailed) }   // error.rs:14
+    pub fn is_io(&self) -> bool { matches!(self, Error::IO(_)) }                                   // error.rs:50
+    fn zstd(code: usize) -> Error { Error::Zstd(0usize.wrapping_sub(code)) }                       // error.rs:40-45: the wrapped value is 0 - code
     fn from_code(rc: i64) -> Error {
         match rc {
             -1001 => Error::OffsetOutOfRange,
@@ -39,7 +55,24 @@ impl Error {
         }
     }
 }
-impl From<io::Error> for Error { fn from(e: io::Error) -> Self { Error::IO(e) } }
+impl From<io::Error> for Error { fn from(e: io::Error) -> Self { Error::IO(e) } }                // error.rs:85
+impl From<core::num::TryFromIntError> for Error { fn from(_: core::num::TryFromIntError) -> Self { Error::NumberConversionFailed } }   // error.rs:75
+/// error.rs:60-71: the kinds in words, a zstd code by its name
+impl core::fmt::Display for Error {
+    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
+        match self {
+            Error::OffsetOutOfRange => f.write_str("offset out of range"),
+            Error::FrameIndexTooLarge => f.write_str("frame index too large"),
+            Error::NumberConversionFailed => f.write_str("number conversion failed"),
+            Error::IO(e) => write!(f, "io error: {e}"),
+            Error::Zstd(w) => {
+                let code = 0usize.wrapping_sub(*w) as c_int;
+                f.write_str(&unsafe { CStr::from_ptr(ffi::zk_error_name(-code)) }.to_string_lossy())
+            }
+        }
+    }
+}
+impl std::error::Error for Error {}
 fn check(rc: c_int) -> Result<()> { if rc == 0 { Ok(()) } else { Err(Error::from_code(rc as i64)) } }
 fn check_len(rc: i64) -> Result<usize> { if rc >= 0 { Ok(rc as usize) } else { Err(Error::from_code(rc)) } }
 
@@ -91,6 +124,53 @@ impl SeekTable {
     pub fn max_frame_size_decomp(&self) -> u64 { unsafe { ffi::zk_seek_table_max_frame_size_decomp(self.0) } }        // :799
     pub fn size_comp(&self) -> u64 { unsafe { ffi::zk_seek_table_size_comp(self.0) } }                                // :827
     pub fn size_decomp(&self) -> u64 { unsafe { ffi::zk_seek_table_size_decomp(self.0) } }                            // :853
+    /// seek_table.rs:338: the table at the END of a seekable source
+    pub fn from_seekable(src: &mut impl Seekable) -> Result<Self> { Self::from_seekable_format(src, Format::Foot) }
+    /// seek_table.rs:379-436.  The integrity field is the source's to find (`Seekable::seek_table_integrity`); its checks come in
+    /// upstream's order (magic -> prefix_unknown, reserved descriptor bits -> corruption_detected, frame count), then the table's
+    /// bytes are read where the count says they lie and parsed by the engine's host side (every remaining check: host/seek_table.cpp).
+    pub fn from_seekable_format(src: &mut impl Seekable, format: Format) -> Result<Self> {
+        let integ = src.seek_table_integrity(format)?;
+        let (n, entry) = Self::integrity(&integ)?;
+        let size = entry * n as usize + SKIPPABLE_HEADER_SIZE + SEEK_TABLE_INTEGRITY_SIZE;
+        match format {
+            Format::Head => src.set_offset(OffsetFrom::Start(0))?,
+            Format::Foot => src.set_offset(OffsetFrom::End(-i64::try_from(size)?))?,
+        };
+        let mut bytes = vec![0u8; size];
+        let mut at = 0;
+        while at < size {
+            let k = src.read(&mut bytes[at..])?;
+            if k == 0 { return Err(Error::zstd(20)); }                  // the source ends inside the table: corruption_detected
+            at += k;
+        }
+        Self::from_bytes(&bytes, format)
+    }
+    /// seek_table.rs:461-493: a table in Head format out of a plain reader (a side file, cli/src/compress.rs:86-96)
+    pub fn from_reader(reader: &mut impl Read) -> Result<Self> {
+        let mut bytes = vec![0u8; SKIPPABLE_HEADER_SIZE + SEEK_TABLE_INTEGRITY_SIZE];
+        reader.read_exact(&mut bytes)?;
+        let mut integ = [0u8; SEEK_TABLE_INTEGRITY_SIZE];
+        integ.copy_from_slice(&bytes[SKIPPABLE_HEADER_SIZE..]);
+        let (n, entry) = Self::integrity(&integ)?;
+        let at = bytes.len();
+        bytes.resize(at + entry * n as usize, 0);
+        reader.read_exact(&mut bytes[at..])?;
+        Self::from_bytes(&bytes, Format::Head)
+    }
+    /// the integrity field (seekable_format.md:96-132): Number_Of_Frames | Seek_Table_Descriptor | Seekable_Magic_Number -> (frames, bytes per entry)
+    fn integrity(f: &[u8; SEEK_TABLE_INTEGRITY_SIZE]) -> Result<(u32, usize)> {
+        if u32::from_le_bytes([f[5], f[6], f[7], f[8]]) != SEEKABLE_MAGIC_NUMBER { return Err(Error::zstd(10)); }   // prefix_unknown (seek_table.rs:146)
+        if (f[4] >> 2) & 0x1f != 0 { return Err(Error::zstd(20)); }                                              // corruption_detected (:151)
+        let n = u32::from_le_bytes([f[0], f[1], f[2], f[3]]);
+        if n > SEEKABLE_MAX_FRAMES { return Err(Error::FrameIndexTooLarge); }
+        Ok((n, if f[4] & 0x80 != 0 { 12 } else { 8 }))                                                            // legacy entries carry a checksum (:154-160)
+    }
+    /// seek_table.rs:883 / 907: the table turned into its serializer (Foot unless told otherwise)
+    pub fn into_serializer(self) -> seek_table::Serializer { self.into_format_serializer(Format::Foot) }
+    pub fn into_format_serializer(self, format: Format) -> seek_table::Serializer {
+        seek_table::Serializer(unsafe { ffi::zk_seek_table_serializer(self.0, format.raw()) })
+    }
     /// into_format_serializer(..) drained into a Vec (seek_table.rs:907, 967-1005)
     pub fn to_bytes(&self, format: Format) -> Vec<u8> {
         let s = unsafe { ffi::zk_seek_table_serializer(self.0, format.raw()) };
@@ -106,12 +186,73 @@ impl SeekTable {
     }
 }
 impl Clone for SeekTable { fn clone(&self) -> Self { SeekTable(unsafe { ffi::zk_seek_table_clone(self.0) }) } }
+impl Default for SeekTable { fn default() -> Self { Self::new() } }                                                  // :271
+impl Eq for SeekTable {}                                                                                           // :266
+impl core::fmt::Debug for SeekTable {
+    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
+        f.debug_struct("SeekTable").field("num_frames", &self.num_frames()).field("size_comp", &self.size_comp()).field("size_decomp", &self.size_decomp()).finish()
+    }
+}
+/// the public module of upstream (lib.rs:36: `pub mod seek_table`): `Format`, `SeekTable` and the `Serializer`
+pub mod seek_table {
+    pub use super::{Format, SeekTable};
+    use super::ffi;
+    use std::io;
+    /// seek_table.rs:955-1059: the table's bytes, handed out piece by piece into buffers of any size
+    pub struct Serializer(pub(super) *mut ffi::ZkSerializer);
+    unsafe impl Send for Serializer {}
+    impl Serializer {
+        /// :967-1005 -- fills `buf` as far as it goes; 0 = everything has been written
+        pub fn write_into(&mut self, buf: &mut [u8]) -> usize { unsafe { ffi::zk_serializer_write_into(self.0, buf.as_mut_ptr(), buf.len()) } }
+        pub fn reset(&mut self) { unsafe { ffi::zk_serializer_reset(self.0) } }                        // :1034
+        pub fn encoded_len(&self) -> usize { unsafe { ffi::zk_serializer_encoded_len(self.0) } }       // :1042
+    }
+    impl io::Read for Serializer { fn read(&mut self, buf: &mut [u8]) -> io::Result<usize> { Ok(self.write_into(buf)) } }   // :1055-1059
+    impl Drop for Serializer { fn drop(&mut self) { unsafe { ffi::zk_serializer_free(self.0) } } }
+}
 impl PartialEq for SeekTable { fn eq(&self, o: &Self) -> bool { unsafe { ffi::zk_seek_table_equal(self.0, o.0) != 0 } } }
 impl Drop for SeekTable { fn drop(&mut self) { unsafe { ffi::zk_seek_table_free(self.0) } } }
 
 // ------------------------------------------------------------------------------------------------ decode (decode.rs)
 /// seekable.rs:8-13
+#[derive(Debug, Clone, Copy)]
 pub enum OffsetFrom { Start(u64), End(i64) }
+impl From<OffsetFrom> for SeekFrom {                                                                    // seekable.rs:100-109
+    fn from(o: OffsetFrom) -> Self { match o { OffsetFrom::Start(n) => SeekFrom::Start(n), OffsetFrom::End(n) => SeekFrom::End(n) } }
+}
+/// seekable.rs:42-97: a byte slice as a seekable source (what `Decoder::new(BytesWrapper::new(&archive))` reads from)
+#[derive(Debug, Clone)]
+pub struct BytesWrapper<'a> { bytes: &'a [u8], at: usize }
+impl<'a> BytesWrapper<'a> {
+    pub fn new(src: &'a [u8]) -> Self { BytesWrapper { bytes: src, at: 0 } }                                 // :50
+}
+impl Seekable for BytesWrapper<'_> {
+    /// an offset outside [0, len] is `OffsetOutOfRange`, from either end (seekable.rs:56-74)
+    fn set_offset(&mut self, offset: OffsetFrom) -> Result<u64> {
+        let len = self.bytes.len() as i128;
+        let target = match offset { OffsetFrom::Start(n) => n as i128, OffsetFrom::End(d) => len + d as i128 };
+        if target < 0 || target > len { return Err(Error::OffsetOutOfRange); }
+        self.at = target as usize;
+        Ok(target as u64)
+    }
+    fn read(&mut self, buf: &mut [u8]) -> Result<usize> {                                                 // :76-82
+        let k = buf.len().min(self.bytes.len() - self.at);
+        buf[..k].copy_from_slice(&self.bytes[self.at..self.at + k]);
+        self.at += k;
+        Ok(k)
+    }
+    /// Head: the 9 bytes behind the skippable header; Foot: the last 9 bytes; a slice too short for them is out of range (:84-96)
+    fn seek_table_integrity(&mut self, format: Format) -> Result<[u8; SEEK_TABLE_INTEGRITY_SIZE]> {
+        let start = match format {
+            Format::Head if self.bytes.len() >= SKIPPABLE_HEADER_SIZE + SEEK_TABLE_INTEGRITY_SIZE => SKIPPABLE_HEADER_SIZE,
+            Format::Foot if self.bytes.len() >= SEEK_TABLE_INTEGRITY_SIZE => self.bytes.len() - SEEK_TABLE_INTEGRITY_SIZE,
+            _ => return Err(Error::OffsetOutOfRange),
+        };
+        let mut out = [0u8; SEEK_TABLE_INTEGRITY_SIZE];
+        out.copy_from_slice(&self.bytes[start..start + SEEK_TABLE_INTEGRITY_SIZE]);
+        Ok(out)
+    }
+}
 /// seekable.rs:16-39.  The blanket impl below gives it to every `Read + Seek` (seekable.rs:112-138).
 pub trait Seekable {
     fn set_offset(&mut self, offset: OffsetFrom) -> Result<u64>;
@@ -155,6 +296,7 @@ pub struct DecodeOptions<'a, S: Seekable> {
 }
 impl<'a, S: Seekable> DecodeOptions<'a, S> {
     pub fn new(src: S) -> Self { DecodeOptions { src, engine: None, seek_table: None, lower_frame: None, upper_frame: None, offset: None, offset_limit: None } }   // :30
+    pub fn try_new(src: S) -> Option<Self> { Some(Self::new(src)) }                                         // :37 (nothing to create yet: see EncodeOptions::try_new)
     pub fn engine(mut self, e: &'a Engine) -> Self { self.engine = Some(e); self }                          // with_dctx :43
     pub fn seek_table(mut self, t: SeekTable) -> Self { self.seek_table = Some(t); self }                   // :65
     pub fn lower_frame(mut self, i: u32) -> Self { self.lower_frame = Some(i); self }                       // :73
@@ -227,6 +369,9 @@ impl Default for FrameSizePolicy { fn default() -> Self { FrameSizePolicy::Uncom
 pub struct EncodeOptions<'a> { engine: Option<&'a Engine>, policy: FrameSizePolicy, checksum: bool, level: i32 }
 impl<'a> EncodeOptions<'a> {
     pub fn new() -> Self { Self::default() }                                                            // :129
+    /// :136 -- upstream's fallible constructor creates the compression context; here the engine is created (or injected) when the
+    /// encoder is made, so there is nothing that can fail yet
+    pub fn try_new() -> Option<Self> { Some(Self::default()) }
     pub fn engine(mut self, e: &'a Engine) -> Self { self.engine = Some(e); self }                       // with_cctx :142
     pub fn frame_size_policy(mut self, p: FrameSizePolicy) -> Self { self.policy = p; self }             // :158
     pub fn checksum_flag(mut self, f: bool) -> Self { self.checksum = f; self }                          // :164
@@ -261,6 +406,9 @@ impl EpilogueProgress { pub fn out_progress(&self) -> usize { self.out_progress 
 /// encode.rs:209-545
 pub struct RawEncoder<'a> { h: *mut ffi::ZkRawEncoder, _e: core::marker::PhantomData<&'a Engine> }
 impl<'a> RawEncoder<'a> {
+    pub fn new() -> Result<Self> { EncodeOptions::new().into_raw_encoder() }                              // :365
+    pub fn with_opts(opts: EncodeOptions<'a>) -> Result<Self> { opts.into_raw_encoder() }                 // :280
+    pub fn into_seek_table(self) -> SeekTable { self.seek_table() }                                       // :492
     pub fn compress(&mut self, input: &[u8], output: &mut [u8]) -> Result<CompressionProgress> { self.compress_with_prefix(input, output, None) }   // :398
     pub fn compress_with_prefix<'b: 'a>(&mut self, input: &[u8], output: &mut [u8], prefix: Option<&'b [u8]>) -> Result<CompressionProgress> {      // :311
         let (p, n) = prefix.map_or((core::ptr::null(), 0), |p| (p.as_ptr(), p.len()));
@@ -283,6 +431,8 @@ impl Drop for RawEncoder<'_> { fn drop(&mut self) { unsafe { ffi::zk_raw_encoder
 pub struct Encoder<'a, W: Write> { h: *mut ffi::ZkEncoder, writer: Box<W>, _e: core::marker::PhantomData<&'a Engine> }
 impl<'a, W: Write> Encoder<'a, W> {
     pub fn new(writer: W) -> Result<Self> { EncodeOptions::new().into_encoder(writer) }                   // :587
+    pub fn with_opts(writer: W, opts: EncodeOptions<'a>) -> Result<Self> { opts.into_encoder(writer) }    // :596
+    pub fn into_seek_table(self) -> SeekTable { self.seek_table() }                                       // :620
     pub fn compress(&mut self, buf: &[u8]) -> Result<usize> { check_len(unsafe { ffi::zk_encoder_compress(self.h, buf.as_ptr(), buf.len()) }) }     // :692
     pub fn compress_with_prefix<'b: 'a>(&mut self, buf: &[u8], prefix: Option<&'b [u8]>) -> Result<usize> {                                     // :641
         let (p, n) = prefix.map_or((core::ptr::null(), 0), |p| (p.as_ptr(), p.len()));
