@@ -224,6 +224,10 @@ int zk_engine_set_host_threads(zk_engine *e, int n);
  * c_sizes / d_sizes: this rank's n_frames entries on the host (what zk_encode_frames_dev reported).  On the root *out_bytes
  * receives stream + table bytes and *table_out (optional) the gathered SeekTable; the other ranks pass d_out = NULL. */
 typedef struct zk_seek_table zk_seek_table;
+/* The shared library that provides ncclAllGather / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd for zk_gather_seekable; NULL or ""
+ * = RCCL (symbols already in the process, else librccl.so.1).  Process-wide; call it before the first gather.  (The library reads no
+ * environment variable.)  The tests name a shared-memory transport between processes that share one GPU here. */
+int zk_set_collective_library(const char *path);
 int zk_gather_seekable(zk_engine *e, void *nccl_comm, int rank, int world, int root, const void *d_payload, uint64_t payload_bytes,
                        const uint32_t *c_sizes, const uint32_t *d_sizes, uint32_t n_frames, int format, void *d_out, uint64_t out_cap,
                        uint64_t *out_bytes, zk_seek_table **table_out, void *stream);

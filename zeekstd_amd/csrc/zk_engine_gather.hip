@@ -7,11 +7,13 @@
 //      own xGMI link into the root, so the receives run side by side; no padding, no staging
 //   4. root serialises the table behind the last frame
 // RCCL is resolved at run time (the library must not depend on it for single-GPU use): symbols already in the process first,
-// then librccl.so.1 (or ZK_RCCL_PATH).  The communicator is the caller's (ncclCommInitRank), one per rank as always.
+// then librccl.so.1 -- or the library named with zk_set_collective_library (tests: a shared-memory transport between processes that
+// share one GPU, tests/sim/zk_shm_collectives.cpp).  The communicator is the caller's (ncclCommInitRank), one per rank as always.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 #include <vector>
 #include "../../include/zeekstd_amd.h"
 #include "zk_engine.h"
@@ -31,18 +33,21 @@ typedef int (*allgather_fn)(const void *, void *, size_t, int, void *, hipStream
 typedef int (*sendrecv_fn)(void *, size_t, int, int, void *, hipStream_t);
 typedef int (*group_fn)(void);
 struct Rccl { allgather_fn all_gather = nullptr; sendrecv_fn send = nullptr, recv = nullptr; group_fn group_start = nullptr, group_end = nullptr; bool ok = false; };
+std::string g_collective_path;            // zk_set_collective_library: which library provides the five entry points ("" = RCCL)
+bool g_tried = false;
 Rccl &rccl()
 {
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+    if (g_tried) return r;
+    g_tried = true;
     void *h = nullptr;
-    auto sym = [&](const char *n) { void *p = dlsym(RTLD_DEFAULT, n); if (!p && h) p = dlsym(h, n); return p; };
-    if (!dlsym(RTLD_DEFAULT, "ncclAllGather")) {
-        const char *path = getenv("ZK_RCCL_PATH");
-        h = dlopen(path ? path : "librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!h && !path) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    const bool named = !g_collective_path.empty();
+    // a named library is asked first and alone; otherwise symbols already in the process (a host that linked RCCL), then librccl.so.1
+    auto sym = [&](const char *n) { void *p = named ? nullptr : dlsym(RTLD_DEFAULT, n); if (!p && h) p = dlsym(h, n); return p; };
+    if (named) h = dlopen(g_collective_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    else if (!dlsym(RTLD_DEFAULT, "ncclAllGather")) {
+        h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     }
     r.all_gather = (allgather_fn)sym("ncclAllGather");
     r.send = (sendrecv_fn)sym("ncclSend");
@@ -54,6 +59,16 @@ Rccl &rccl()
 }
 enum { kUint8 = 1, kUint32 = 3, kUint64 = 5 };           // ncclDataType_t (rccl.h)
 }  // namespace
+
+// Which shared library provides ncclAllGather / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd for zk_gather_seekable: NULL or ""
+// = RCCL (the default).  Process-wide, to be called before the first gather (later calls re-resolve).  Replaces round 4's environment
+// variable: the library reads no environment.
+extern "C" int zk_set_collective_library(const char *path)
+{
+    g_collective_path = path ? path : "";
+    g_tried = false;
+    return 0;
+}
 
 extern "C" int zk_gather_seekable(zk_engine *e, void *nccl_comm, int rank, int world, int root, const void *d_payload, uint64_t payload_bytes,
                                   const uint32_t *c_sizes, const uint32_t *d_sizes, uint32_t n_frames, int format, void *d_out, uint64_t out_cap,
