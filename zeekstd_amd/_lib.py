@@ -61,6 +61,10 @@ _sig = {
     "zk_host_free": (None, [_P]),
     "zk_engine_set_host_threads": (C.c_int, [_P, C.c_int]),
     "zk_xxh64_frames_dev": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
+    "zk_frame_content_sizes": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, C.c_uint32, _P, _P]),
+    "zk_frame_content_sizes_dev": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    "zk_set_collective_library": (C.c_int, [C.c_char_p]),
+    "zk_gather_seekable": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_uint64, _P, _P, C.c_uint32, C.c_int, _P, C.c_uint64, _P, _P, _P]),
 }
 for _name, (_res, _args) in _sig.items():
     _f = getattr(lib, _name)

@@ -73,6 +73,11 @@ __device__ __forceinline__ uint32_t zke_ring1(const uint32_t *ring, uint32_t pos
 __device__ __forceinline__ uint32_t zke_ffbl(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 #define ZKE_FFBL(x) zke_ffbl(x)
 #endif
+#ifndef ZKE_FFBH
+// v_ffbh_u32: the number of leading zero bits, 0xFFFFFFFF for 0
+__device__ __forceinline__ uint32_t zke_ffbh(uint32_t x) { uint32_t r; asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+#define ZKE_FFBH(x) zke_ffbh(x)
+#endif
 // index of the first non-zero byte of the 16 bytes x0 .. x3 (16: none): -1 | 32 stays -1.
 __device__ __forceinline__ uint32_t zke_first16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
 {
@@ -176,6 +181,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
     __shared__ uint32_t table[TWORDS + 1];
     __shared__ uint32_t best[ZKE_GROUP_POS];
     __shared__ uint64_t tseq[ZKE_GROUP][ZKE_TSEQ_N];        // ll | ml << 12 in the low half, the offset in the high half
+    __shared__ uint32_t bkb[ZKE_GROUP_POS / 4];             // (round 5) per position: how many of the bytes in front of it agree at its best candidate's offset (<= 4): catch-up
     __shared__ uint32_t tsum[2][ZKE_GROUP], tlast[2][ZKE_GROUP], tfirst[2][ZKE_GROUP], tfml[2][ZKE_GROUP];   // per tile (two groups deep): count | trailing literals << 8 | literal bytes << 20;  offset of its last sequence
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const ZkEncFrame fr = segs[blockIdx.x];
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                         xr[3] = d3 ^ __builtin_amdgcn_alignbyte(r4, r3, rs); xr[4] = d4 ^ __builtin_amdgcn_alignbyte(r5, r4, rs);
                     }
                 }
-                uint32_t lf[4], ln[4], df[4], dn[4];
+                uint32_t lf[4], ln[4], df[4], dn[4], wl[4], wo[4];              // ... and every position's winner: length, offset
                 bool vf[4], vn[4];
                 const bool vr0 = R > 1;
 #pragma unroll
@@ -509,10 +515,12 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     if (!LDM) {
                         // the longest wins, on ties the later of far, near, offset 1, R: one key per candidate (length | rank | offset), the largest key
                         const uint32_t kf = okf ? (cf << 18) | df[k] : 0u, kn = okn ? (cn << 18) | (1u << 16) | dn[k] : 0u,
-                                       k1 = ok1 ? (c1 << 18) | (2u << 16) | 1u : 0u, kr = okr ? (cr << 18) | (3u << 16) | R : 0u;
+                                       k1 = ok1 ? (c1 << 18) | (2u << 16) | 1u : 0u, kr = okr ? ((cr + 1) << 18) | (3u << 16) | R : 0u;    // (round 5: the previous offset is cheap to code, it also wins one byte short)
                         uint32_t m = kf > kn ? kf : kn;
                         m = m > k1 ? m : k1; m = m > kr ? m : kr;
+                        if (m == kr && okr) m -= 1u << 18;
                         best[4 * tid + k] = (m >> 18) | ((m & 0xFFFFu) << 5);           // positions past the tile's end: length 0
+                        wl[k] = m >> 18; wo[k] = m & 0xFFFFu;
                     } else {
                         uint32_t bl = 0, bo = 0;
                         if (okf) { bl = cf; bo = df[k]; }
@@ -523,10 +531,30 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                                                         __builtin_amdgcn_alignbyte(x2[3], x2[2], (uint32_t)k), __builtin_amdgcn_alignbyte(x2[4], x2[3], (uint32_t)k));
                         if (tfar && ok2 && tabled[k] && n == ZKE_PARCAP && l2 == ZKE_PARCAP && (!ldm.inframe || bl < ZKE_LDM_FILL)) { bl = ZKE_PARCAP; bo = tfar; }
                         if (ok1 && c1 >= bl) { bl = c1; bo = 1; }
-                        if (okr && cr >= bl) { bl = cr; bo = R; }
+                        if (okr && cr + 1 >= bl) { bl = cr; bo = R; }
                         best[4 * tid + k] = bl | (bo << 5);
+                        wl[k] = bl; wo[k] = bo;
                     }
                 }
+                // (round 5) catch-up: how many of the four bytes in front of each position agree with the four bytes in front of its
+                // winner's source -- out of the ring, which holds them while offset + 4 <= ZKE_WINDOW (a source in the prefix or far back in
+                // the frame: none); not past the tile's start, not before the record's first byte.  The parse cuts it down to the literals
+                // the match really has in front of it (zk_enc_match2.h has the measurements: the stale table finds many a match late).
+                uint32_t bk4 = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t p = P0 + k, off = wo[k];
+                    const uint32_t cb = p - off - 4, ci = (cb >> 2) & 16383u;
+                    const uint32_t b0 = ring[ci], b1 = ring[ci + 1];
+                    const uint32_t mine4 = k ? __builtin_amdgcn_alignbyte(d0, dm1, (uint32_t)k) : dm1;          // the four bytes that end at p
+                    uint32_t bk = ZKE_FFBH(mine4 ^ __builtin_amdgcn_alignbyte(b1, b0, cb & 3u));
+                    bk = (bk < 32u ? bk : 32u) >> 3;
+                    const uint32_t room = p - ts < p - off ? p - ts : p - off;
+                    bk = bk < room ? bk : room;
+                    if (!wl[k] || off + 4 > ZKE_WINDOW || p < ts) bk = 0;
+                    bk4 |= bk << (8 * k);
+                }
+                bkb[tid] = bk4;
             }
             ZKE_CLK(5);
             // ---- 3b: wave w parses tile w (it wrote that slice of best[] itself: LDS operations of a wave complete in order)
@@ -540,7 +568,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                 //   B  the walk, pass after pass (the only serial part: where a match ends decides which candidate is next)
                 //   C  every pass: sequences and literal bytes, all lanes at once
                 // (a pass past the tile's end has no candidates and no literals: best[] holds length 0 there)
-                uint32_t pv[4], plen[4], pnx[4], pskip0[4];
+                uint32_t pv[4], plen[4], pnx[4], pbk[4], ppe[4], pst[4], first_s[5];
                 uint64_t pcand[4], pcap[4], ptaken[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -549,11 +577,15 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     const uint32_t len = v & 0x1F;
                     bool cand = len != 0;
                     if (LAZY) {
-                        const uint32_t l1 = best[wave * ZKE_TILE + pos + 1 < ZKE_GROUP_POS ? wave * ZKE_TILE + pos + 1 : 0] & 0x1F;
+                        const uint32_t n1 = best[wave * ZKE_TILE + pos + 1 < ZKE_GROUP_POS ? wave * ZKE_TILE + pos + 1 : 0], l1 = n1 & 0x1F;
                         const uint32_t l2 = best[wave * ZKE_TILE + pos + 2 < ZKE_GROUP_POS ? wave * ZKE_TILE + pos + 2 : 0] & 0x1F;
                         if ((p + 1 < te && l1 > len) || (p + 2 < te && l2 > len + 1)) cand = false;
+                        // (round 5) a CHEAP offset one position later -- the previous offset or offset 1 -- wins against a fresh one even one byte shorter
+                        // (the twin has the measurements: runs of 10 bytes 5.5 -> 8.8)
+                        if ((v >> 5) != R && (v >> 5) != 1 && p + 1 < te && l1 && ((n1 >> 5) == R || (n1 >> 5) == 1) && l1 + 1 >= len) cand = false;
                     }
                     pv[u] = v; plen[u] = len;
+                    pbk[u] = ((const uint8_t *)bkb)[wave * ZKE_TILE + pos];
                     pcand[u] = __ballot(cand); pcap[u] = __ballot(cand && len == ZKE_PARCAP);
                     // every lane: the first candidate at or behind the end of its own match (64: none in this pass); the walk
                     // below then costs the scalar unit a handful of instructions per match
@@ -567,7 +599,6 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     const uint64_t candm = pcand[u], capped = pcap[u];
                     const uint32_t v = pv[u], nx = pnx[u];
                     uint32_t len = plen[u];
-                    pskip0[u] = skip;                                                   // positions below it are covered by a match of the pass before
                     const uint32_t pre = skip > wb ? skip - wb : 0;
                     const uint64_t open = candm & (pre >= 64 ? 0ull : ~0ull << pre);
                     uint32_t f = open ? (uint32_t)__builtin_ctzll(open) : 64u, lastf = 64;
@@ -604,31 +635,47 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     if (taken) skip = wb + lastf + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)lastf);
                     ptaken[u] = taken; plen[u] = len;
                 }
+                first_s[4] = 0xFFFFu;
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    // emission, all lanes at once: a taken lane's sequence index = sequences so far + taken lanes below it; its
-                    // literal length = its position - the end of the taken lane before it; a lane is a literal unless a match of
-                    // an earlier pass, the taken lane before it, or its own match covers it
-                    const uint32_t pos = 64 * u + lane, p = ts + pos;
-                    const bool in = p < te;
+                    // C1, all lanes at once: a taken lane's sequence index = sequences so far + taken lanes below it; its match starts up to
+                    // `catch-up` bytes in front of its position, but not before the end of the match before it (round 5); its literal
+                    // length = that start - that end
+                    const uint32_t pos = 64 * u + lane;
                     const uint64_t taken = ptaken[u];
-                    const uint32_t v = pv[u], len = plen[u], skip0 = pskip0[u];
+                    const uint32_t v = pv[u], len = plen[u];
                     const uint64_t below = taken & lane_lt;
                     const uint32_t myend = pos + len;
                     const uint32_t prevlane = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-                    const uint32_t pe = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(prevlane << 2), (int)myend);
+                    const uint32_t pe_ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(prevlane << 2), (int)myend);
+                    const uint32_t pe = below ? pe_ : aend;                             // end of the last match in front of me
                     const bool mine = (taken >> lane) & 1;
-                    if (mine) {
-                        const uint32_t prev_end = below ? pe : aend;
-                        tseq[wave][c + (uint32_t)__builtin_popcountll(below)] = (uint64_t)((pos - prev_end) | (len << 12)) | ((uint64_t)(v >> 5) << 32);
-                    }
+                    uint32_t bk = pbk[u];
+                    bk = bk < pos - pe ? bk : pos - pe;                                 // (a taken lane: pos >= pe)
+                    const uint32_t st = pos - bk;
+                    if (mine) tseq[wave][c + (uint32_t)__builtin_popcountll(below)] = (uint64_t)((st - pe) | ((len + bk) << 12)) | ((uint64_t)(v >> 5) << 32);
+                    ppe[u] = pe; pst[u] = st;
+                    first_s[u] = 0xFFFFu;
                     if (taken) {
                         const uint32_t lastl = 63u - (uint32_t)__builtin_clzll(taken);
                         c += (uint32_t)__builtin_popcountll(taken);
                         aend = 64 * u + lastl + (uint32_t)__builtin_amdgcn_readlane((int)len, (int)lastl);
                         lastoff = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lastl) >> 5;
+                        first_s[u] = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)__builtin_ctzll(taken));
                     }
-                    const uint64_t litm = __ballot(in && !mine && pos >= skip0 && !(below && pos < pe));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    // C2: a lane is a literal unless a match covers it -- the one in front of it (ends at pe), its own, or the catch-up of
+                    // the next taken match (starts at sn: in this pass, else the first one of the next pass -- a later one is too far away)
+                    const uint32_t pos = 64 * u + lane, p = ts + pos;
+                    const uint64_t taken = ptaken[u];
+                    const uint64_t above = taken & ~lane_lt & ~(1ull << lane);
+                    const uint32_t nextlane = above ? (uint32_t)__builtin_ctzll(above) : 0u;
+                    const uint32_t sn_ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nextlane << 2), (int)pst[u]);
+                    const uint32_t sn = above ? sn_ : first_s[u + 1];
+                    const bool mine = (taken >> lane) & 1;
+                    const uint64_t litm = __ballot(p < te && !mine && pos >= ppe[u] && pos < sn);
                     if ((litm >> lane) & 1) tl[nl + (uint32_t)__builtin_popcountll(litm & lane_lt)] = (uint8_t)zke_ring1(ring, p);
                     nl += (uint32_t)__builtin_popcountll(litm);
                 }

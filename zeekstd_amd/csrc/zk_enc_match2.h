@@ -46,6 +46,10 @@ __device__ __forceinline__ void zke_runs2(const uint32_t x[5], uint32_t &r0, uin
 // match that needs the long extension).  Sixteen waves of a CU share ONE scalar unit and all of them walk at the same time: a step
 // costs 16 x its scalar instructions (measured: 216 clocks per step with the compiler's 14), so the loop is written out -- four
 // instructions and the wait state v_readlane needs between a scalar write of its lane select and itself.  f < 64 on entry.
+#ifndef ZKE_DBG_SLOW
+#define ZKE_DBG_SLOW() do { } while (0)     // experiments: how often the walk leaves its inner loop (tests/sim, -DZKE_DBG_COUNTS)
+#define ZKE_DBG_TILE(n) do { } while (0)
+#endif
 #ifndef ZKE_WALK
 #define ZKE_WALK(taken, f, nx) asm volatile("1:\n\ts_bitset1_b64 %0, %1\n\ts_nop 0\n\tv_readlane_b32 %1, %2, %1\n\ts_cmp_lt_u32 %1, 64\n\ts_cbranch_scc1 1b" \
                                             : "+s"(taken), "+s"(f) : "v"(nx) : "scc")
@@ -281,9 +285,10 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match2(const uint8_t *sr
                     const bool okf = vf && cf >= minmatch, okn = vn && cn >= minmatch, ok1 = p >= 1 && c1 >= 4, okr = vr0 && R <= p && cr >= 4;
                     // the longest wins, on ties the later of far, near, offset 1, R: one key per candidate (length | rank | offset), the largest key
                     const uint32_t kf = okf ? (cf << 18) | df : 0u, kn = okn ? (cn << 18) | (1u << 16) | dn : 0u,
-                                   k1 = ok1 ? (c1 << 18) | (2u << 16) | 1u : 0u, kr = okr ? (cr << 18) | (3u << 16) | R : 0u;
+                                   k1 = ok1 ? (c1 << 18) | (2u << 16) | 1u : 0u, kr = okr ? ((cr + 1) << 18) | (3u << 16) | R : 0u;    // (the previous offset is cheap to code: it also wins one byte short)
                     uint32_t m = kf > kn ? kf : kn;
                     m = m > k1 ? m : k1; m = m > kr ? m : kr;
+                    if (m == kr && okr) m -= 1u << 18;
                     // catch-up: how many of the four bytes in front of the position agree with the four bytes in front of the winner's
                     // source (out of the ring, which holds them while offset + 4 <= ZKE_WINDOW); not past the tile's start, not before
                     // the record's first byte.  The parse cuts it down to the literals the match really has in front of it.
@@ -318,7 +323,12 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match2(const uint8_t *sr
                 for (int u = 0; u < 2; u++) {
                     const uint32_t v = best[wave * ZKE2_SLOTS + 64 * u + lane];         // length 0 past the tile's end
                     uint32_t len = v & 0x1F;
-                    const bool cand = len != 0;
+                    // a CHEAP offset at the next slot -- the previous offset R or offset 1 -- wins against a fresh offset here even two bytes
+                    // shorter (the twin has the measurements: runs of 10 equal bytes 5.5 -> 8.8, of 100: 30 -> 55; the text unchanged)
+                    const uint32_t s1 = 64 * u + lane + 1;
+                    const uint32_t v1 = best[wave * ZKE2_SLOTS + (s1 < ZKE2_SLOTS ? s1 : 0)];
+                    const uint32_t l1 = s1 < ZKE2_SLOTS ? v1 & 0x1F : 0, o0 = v >> 8, o1 = v1 >> 8;
+                    const bool cand = len != 0 && !(l1 && o0 != R && o0 != 1 && (o1 == R || o1 == 1) && l1 + 2 >= len);
                     pcand[u] = __ballot(cand);
                     // A match the comparisons capped (16 bytes) usually goes on with the SAME offset at the slot 16 bytes on (every slot inside a
                     // long match is a candidate of it): then its length is 16 + that slot's, exact when that one is not capped itself.  What
@@ -356,6 +366,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match2(const uint8_t *sr
                         if (f < 64) ZKE_WALK(taken, f, nx);
                         if (f == 64) break;
                         // slot f & 0x7F is to be measured: take it and extend, 64 bytes per step (rare)
+                        ZKE_DBG_SLOW();
                         f &= 0x7Fu;
                         taken |= 1ull << f;
                         const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)f) >> 8;
@@ -426,6 +437,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match2(const uint8_t *sr
                     nl += (uint32_t)__builtin_popcountll(m0) + (uint32_t)__builtin_popcountll(m1);
                 }
                 ZKE_CLK(12);
+                ZKE_DBG_TILE(c);
                 if (lane == 0) {
                     tsum[par][wave] = c | (((te - ts) - aend) << 8) | (nl << 20);
                     tlast[par][wave] = lastoff;

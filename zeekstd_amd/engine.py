@@ -57,6 +57,19 @@ class Engine:
     CHOICES = {"reset": 0, "fse_own": 1, "fse_shared": 2, "exec_lanes": 3, "exec_ring": 4, "xxh64": 5, "small_path": 6,
                "pipe_contexts": 7, "pipe_chunk_mib": 8, "exec_resident": 9}
 
+    def frame_content_sizes(self, comp: bytes, c_off, first=0, count=None):
+        """zk_frame_content_sizes: the decompressed sizes of frames nobody holds seek entries for (header walk + sequence walks on the device,
+        no output) -> (uint64 array, int32 status array: 0 or -ZSTD_ErrorCode per frame)"""
+        c = _u64(c_off)
+        count = len(c) - 1 - first if count is None else count
+        src = np.frombuffer(bytes(comp) + b"\0" * 8, np.uint8)
+        sizes = np.zeros(max(count, 1), np.uint64)
+        st = np.zeros(max(count, 1), np.int32)
+        rc = lib.zk_frame_content_sizes(self._h, src.ctypes.data, len(comp), c.ctypes.data, first, count, sizes.ctypes.data, st.ctypes.data)
+        if rc != 0:
+            self._raise(rc)
+        return sizes[:count], st[:count]
+
     def checksums_followed(self):
         """Frames of the last finished decode that zk_k_xxh64_follow verified beside the executor (zk_engine_checksums_followed)."""
         return int(lib.zk_engine_checksums_followed(self._h))
