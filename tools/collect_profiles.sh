@@ -13,7 +13,9 @@ one() {   # $1 = suffix, rest = extra bench flags
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace -d gpurun_out/pmc_${tag}${sfx}_$c -o p --output-format csv -- python bench.py --steps 1 --warmup 1 $common > gpurun_out/pmc_${tag}${sfx}_$c.json 2> gpurun_out/pmc_${tag}${sfx}_$c.err
   done
-  python tools/pmc_summary.py gpurun_out/pmc_${tag}${sfx}_FETCH_SIZE gpurun_out/pmc_${tag}${sfx}_WRITE_SIZE c3 gpurun_out/${tag}${sfx}_pmc_traffic.json > gpurun_out/${tag}${sfx}_pmc_fetch_write.txt
+  if [ -z "$sfx" ]; then python tools/pmc_summary.py gpurun_out/pmc_${tag}${sfx}_FETCH_SIZE gpurun_out/pmc_${tag}${sfx}_WRITE_SIZE c3 gpurun_out/${tag}_pmc_traffic.json > gpurun_out/${tag}${sfx}_pmc_fetch_write.txt
+  else sec=reference_made_level_1; [ "$sfx" = "_ref3" ] && sec=reference_made_level_3
+       python tools/pmc_summary.py gpurun_out/pmc_${tag}${sfx}_FETCH_SIZE gpurun_out/pmc_${tag}${sfx}_WRITE_SIZE c3 gpurun_out/${tag}_pmc_traffic.json $sec > gpurun_out/${tag}${sfx}_pmc_fetch_write.txt; fi
   echo "== $tag$sfx"; head -24 gpurun_out/${tag}${sfx}_bench_c3_kernel_trace_stats.txt; cat gpurun_out/${tag}${sfx}_pmc_fetch_write.txt
   rm -rf gpurun_out/prof_$tag$sfx gpurun_out/pmc_${tag}${sfx}_FETCH_SIZE gpurun_out/pmc_${tag}${sfx}_WRITE_SIZE     # raw traces: tens of MiB
 }
