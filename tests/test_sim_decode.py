@@ -211,7 +211,7 @@ def test_sim_twin_made_frames_damaged():
     _, d = (np.cumsum([0] + [f[0] for f in frames]), np.cumsum([0] + [f[1] for f in frames]))
     rng = np.random.default_rng(29)
     seen_bad = 0
-    for _ in range(24):
+    for _ in range(60):                                                  # (round 5's level-3 bytes: one flip in twelve is structural damage, the rest is wrong bytes)
         bad = bytearray(comp)
         bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
         rc0, out0, st0 = sim_decode(bytes(bad), frames)
@@ -222,7 +222,7 @@ def test_sim_twin_made_frames_damaged():
             for f in range(len(frames)):
                 if st0[f] == 0:
                     assert out[int(d[f]):int(d[f + 1])] == out0[int(d[f]):int(d[f + 1])]
-    assert seen_bad >= 4                                             # (the harness does not compare checksums: structural damage only)
+    assert seen_bad >= 3                                             # (the harness does not compare checksums: structural damage only)
 
 
 def test_sim_under_sanitizers_on_damaged_archives(tmp_path):
