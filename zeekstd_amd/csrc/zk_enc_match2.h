@@ -110,7 +110,11 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match2(const uint8_t *sr
         bool my_open;
         {
             const uint32_t t = lane & 15;
-            const uint32_t sv = t < ntiles ? ts_[t] : 0, lv = t < ntiles ? tl_[t] : 0, fo = t < ntiles ? tf_[t] : 0, fm = tfml[par ^ 1][t & 15];
+            // (the loads are unconditional -- all sixteen entries exist -- and the selects vector ones: a load behind a condition is a branch
+            //  around it, five scalar instructions each, and this block is the scalar unit's: see the walk)
+            const bool in = t < ntiles;
+            const uint32_t sv_ = ts_[t], lv_ = tl_[t], fo_ = tf_[t], fm = tfml[par ^ 1][t];
+            const uint32_t sv = in ? sv_ : 0, lv = in ? lv_ : 0, fo = in ? fo_ : 0;
             const uint32_t cn = sv & 0xFF, tail = (sv >> 8) & 0xFFF, tnl = sv >> 20;
             uint32_t y = tail | (cn ? 0x80000000u : 0u), z = cn ? lv : 0;
 #define ZKE_SCAN_STEP(d) { const uint32_t ys = ZKE_ROW_SHR0(y, d), zs = ZKE_ROW_SHR0(z, d); \
@@ -119,26 +123,28 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match2(const uint8_t *sr
 #undef ZKE_SCAN_STEP
             const uint32_t ye = ZKE_ROW_SHR0(y, 1), ze = ZKE_ROW_SHR0(z, 1);            // what lies in front of tile t
             const uint32_t pend_t = (ye & 0x80000000u) ? ye & 0x7FFFFFFFu : pend + ye, poff_t = ze ? ze : prev_off;
-            const bool join = fo && fo == poff_t && pend_t == 0 && ((todo.rel + t * ZKE_TILE) & (ZKE_SEAM - 1)) != 0;
+            const bool join = (fo != 0) & (fo == poff_t) & (pend_t == 0) & (((todo.rel + t * ZKE_TILE) & (ZKE_SEAM - 1)) != 0);
             uint32_t x = (cn - (join ? 1u : 0u)) | (tnl << 16);
 #define ZKE_SCAN_STEP(d) { x += ZKE_ROW_SHR0(x, d); }
             ZKE_SCAN_STEP(1) ZKE_SCAN_STEP(2) ZKE_SCAN_STEP(4) ZKE_SCAN_STEP(8)
 #undef ZKE_SCAN_STEP
             const uint32_t wm = wave ? wave - 1 : 0, wn = wave < 15 ? wave + 1 : 15;
-            const uint32_t xp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)x, (int)wm) : 0, yp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)y, (int)wm) : 0,
-                           zp = wave ? (uint32_t)__builtin_amdgcn_readlane((int)z, (int)wm) : 0;
+            const uint32_t xp_ = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)wm), yp_ = (uint32_t)__builtin_amdgcn_readlane((int)y, (int)wm),
+                           zp_ = (uint32_t)__builtin_amdgcn_readlane((int)z, (int)wm);
+            const uint32_t xp = wave ? xp_ : 0, yp = wave ? yp_ : 0, zp = wave ? zp_ : 0;
             me = (uint32_t)__builtin_amdgcn_readlane((int)sv, (int)wave);
             const uint32_t xt = (uint32_t)__builtin_amdgcn_readlane((int)x, 15), yt = (uint32_t)__builtin_amdgcn_readlane((int)y, 15), zt = (uint32_t)__builtin_amdgcn_readlane((int)z, 15);
             my_join = 0; my_more = 0; my_open = wave == 15;
             uint32_t more0 = 0, whole0 = 0;
             if (__ballot(join)) {                                                   // (most groups have no seam to close)
-                uint32_t ev = join ? fm : 0, pw = join && cn == 1 && tail == 0 ? 1u : 0u;
+                uint32_t ev = join ? fm : 0, pw = (join & (cn == 1) & (tail == 0)) ? 1u : 0u;
 #define ZKE_SCAN_STEP(d) { const uint32_t es = ZKE_ROW_SHL0(ev, d), ps = ZKE_ROW_SHL(pw, d, 1); ev += pw ? es : 0; pw &= ps; }
                 ZKE_SCAN_STEP(1) ZKE_SCAN_STEP(2) ZKE_SCAN_STEP(4) ZKE_SCAN_STEP(8)
 #undef ZKE_SCAN_STEP
                 my_join = (uint32_t)__builtin_amdgcn_readlane((int)(join ? 1u : 0u), (int)wave);
-                my_more = wave < 15 ? (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)wn) : 0;
-                my_open = wave == 15 || __builtin_amdgcn_readlane((int)pw, (int)wn) != 0;   // every tile behind mine is whole
+                const uint32_t ev_n = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)wn), pw_n = (uint32_t)__builtin_amdgcn_readlane((int)pw, (int)wn);
+                my_more = wave < 15 ? ev_n : 0;
+                my_open = (wave == 15) | (pw_n != 0);                                       // every tile behind mine is whole
                 more0 = (uint32_t)__builtin_amdgcn_readlane((int)ev, 0); whole0 = (uint32_t)__builtin_amdgcn_readlane((int)pw, 0);
             }
             my_open = my_open && !todo.last;
@@ -155,18 +161,18 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match2(const uint8_t *sr
             if (zt) { prev_off = zt; probe = zt; }
         }
         if (wave < ntiles) {
-            if (lane >= my_join && lane < my_cnt) {                                 // <= 64 sequences per tile: one per lane
+            if ((lane >= my_join) & (lane < my_cnt)) {                              // <= 64 sequences per tile: one per lane
                 const uint64_t e = tseq[wave][lane];
                 uint32_t ll = (uint32_t)e & 0xFFF, ml = (uint32_t)(e >> 12) & 0xFFF;
                 const uint32_t off = (uint32_t)(e >> 32);
-                const uint32_t poff = lane ? (uint32_t)(tseq[wave][lane - 1] >> 32) : my_poff;
+                const uint32_t poff_ = (uint32_t)(tseq[wave][lane ? lane - 1 : 0] >> 32), poff = lane ? poff_ : my_poff;
                 if (lane == 0) ll += my_pend;
-                const uint32_t code = (ll && off == poff) ? 1u : off + 3;
-                const bool ends_tile = lane + 1 == my_cnt && ((me >> 8) & 0xFFF) == 0;
+                const uint32_t code = ((ll != 0) & (off == poff)) ? 1u : off + 3;
+                const bool ends_tile = (lane + 1 == my_cnt) & (((me >> 8) & 0xFFF) == 0);
                 if (ends_tile) ml += my_more;
                 const uint64_t rec = (uint64_t)(ll | (ml << 16)) | ((uint64_t)code << 32);
                 uint64_t *at = &todo.sq[my_base + lane - my_join];
-                if (ends_tile && my_open) { held = true; held_e = rec; held_at = at; }
+                if (ends_tile & my_open) { held = true; held_e = rec; held_at = at; }
 #ifndef ZKE_KNOCK_STORES
                 else *at = rec;
 #endif
