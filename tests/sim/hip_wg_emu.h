@@ -146,3 +146,4 @@ static void emu_run_workgroup(uint32_t nthreads, uint32_t block, std::function<v
 #define ZKE_FFBL(x) ((x) ? (uint32_t)__builtin_ctz(x) : 0xFFFFFFFFu)          /* v_ffbl_b32 */
 #define ZKE_FFBH(x) ((x) ? (uint32_t)__builtin_clz(x) : 0xFFFFFFFFu)          /* v_ffbh_u32 */
 #define ZKE_WALK(taken, f, nx) do { taken |= 1ull << f; f = (uint32_t)emu_readlane((int)(nx), (int)f); } while (f < 64)     /* zk_enc_match2.h: the walk's inner loop */
+#define ZKE_KEEP(x) do { } while (0)

@@ -50,6 +50,10 @@ __device__ __forceinline__ void zke_runs2(const uint32_t x[5], uint32_t &r0, uin
 #define ZKE_DBG_SLOW() do { } while (0)     // experiments: how often the walk leaves its inner loop (tests/sim, -DZKE_DBG_COUNTS)
 #define ZKE_DBG_TILE(n) do { } while (0)
 #endif
+#ifndef ZKE_KEEP
+// keeps a value's computation where it is written (the compiler otherwise sinks it behind the condition that selects it: a branch)
+#define ZKE_KEEP(x) asm volatile("" : "+v"(x))
+#endif
 #ifndef ZKE_WALK
 #define ZKE_WALK(taken, f, nx) asm volatile("1:\n\ts_bitset1_b64 %0, %1\n\ts_nop 0\n\tv_readlane_b32 %1, %2, %1\n\ts_cmp_lt_u32 %1, 64\n\ts_cbranch_scc1 1b" \
                                             : "+s"(taken), "+s"(f) : "v"(nx) : "scc")
@@ -216,14 +220,17 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match2(const uint8_t *sr
             const uint32_t dm1 = ring[(i0 - 1) & 16383u], d0 = ring[i0], d1 = ring[i0 + 1], d2 = ring[i0 + 2], d3 = ring[i0 + 3], d4 = ring[i0 + 4];
             uint32_t wlo[4], whi[4], hsh[4], tix[4], tw[2], e1[2];
             bool tabled[4];
+            const uint32_t plim = fend >= 7 && fend - 7 < ge ? fend - 7 : (fend >= 7 ? ge : 0);      // positions below it have their 8 bytes and lie in the group
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 wlo[k] = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)k);
                 whi[k] = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)k);
                 const uint32_t p = P0 + k;
-                tabled[k] = p < ge && p + 8 <= fend;
-                hsh[k] = tabled[k] ? zke_hash(wlo[k], whi[k] & 0xFF, HLOG) : NONE;
-                tix[k] = tabled[k] ? hsh[k] : DUMMY;
+                tabled[k] = p < plim;                                                // p < ge && p + 8 <= fend
+                uint32_t h = zke_hash(wlo[k], whi[k] & 0xFF, HLOG);
+                ZKE_KEEP(h);                                                         // (computed for every lane: behind the condition it is a branch around five instructions)
+                hsh[k] = tabled[k] ? h : NONE;
+                tix[k] = tabled[k] ? h : DUMMY;
             }
             tw[0] = table[tix[0]]; tw[1] = table[tix[2]];                            // far candidates: the table as it was before the step
             ZKE_CLK(1);
