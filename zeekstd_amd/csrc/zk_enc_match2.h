@@ -261,6 +261,8 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match2(const uint8_t *sr
             // (Measured and dropped: half of the waves comparing before they stitch, so that the scalar work of the one and the vector
             //  work of the other overlap -- 30.6 instead of 29.6 ms.  A wave issues an instruction every ~8.5 clocks whatever its kind;
             //  with four waves per SIMD that is about one vector and one scalar instruction per turn already.)
+            // (Also measured and dropped: the stitch BETWEEN the two barriers, behind the insertions' LDS atomics -- its phase 3.0 k -> 1.9 k clocks,
+            //  the comparisons 3.2 k -> 4.0 k, the kernel 30.1 -> 30.5 ms: the time is the instructions, wherever they stand.)
             if (todo.valid) stitch();
             ZKE_WAVE_SYNC();
             const uint32_t R = probe;
