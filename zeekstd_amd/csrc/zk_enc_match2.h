@@ -270,22 +270,25 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match2(const uint8_t *sr
             const uint32_t ts = gs + wave * ZKE_TILE, te = ts + ZKE_TILE < ge ? ts + ZKE_TILE : ge;      // my tile
             {
                 // the 20 bytes at my four bytes against the 20 bytes one byte / R bytes before them, once for both positions
-                uint32_t x1[5], xr[5];
+                uint32_t x1[5], xr[5], r1[2] = {0, 0}, rr[2] = {0, 0};
                 {
                     const uint32_t rb = P0 - R, ri = (rb >> 2) & 16383u, rs = rb & 3u;  // R <= P0 is tested below; a wrong address reads some ring bytes
                     x1[0] = d0 ^ __builtin_amdgcn_alignbyte(d0, dm1, 3u); x1[1] = d1 ^ __builtin_amdgcn_alignbyte(d1, d0, 3u);
-                    const uint32_t r0 = ring[ri], r1 = ring[ri + 1], r2 = ring[ri + 2], r3 = ring[ri + 3], r4 = ring[ri + 4], r5 = ring[ri + 5];
-                    xr[0] = d0 ^ __builtin_amdgcn_alignbyte(r1, r0, rs); xr[1] = d1 ^ __builtin_amdgcn_alignbyte(r2, r1, rs); xr[2] = d2 ^ __builtin_amdgcn_alignbyte(r3, r2, rs);
-                    xr[3] = d3 ^ __builtin_amdgcn_alignbyte(r4, r3, rs); xr[4] = d4 ^ __builtin_amdgcn_alignbyte(r5, r4, rs);
+                    const uint32_t r0 = ring[ri], r1 = ring[ri + 1], r2 = ring[ri + 2];
+                    xr[0] = d0 ^ __builtin_amdgcn_alignbyte(r1, r0, rs); xr[1] = d1 ^ __builtin_amdgcn_alignbyte(r2, r1, rs);
+                    // ... and the previous offset needs four equal bytes as well: the rest of its window only where some lane of the wave has them
+                    if (__ballot(xr[0] == 0 || ((xr[0] >> 16) | (xr[1] << 16)) == 0)) {
+                        const uint32_t r3 = ring[ri + 3], r4 = ring[ri + 4], r5 = ring[ri + 5];
+                        xr[2] = d2 ^ __builtin_amdgcn_alignbyte(r3, r2, rs); xr[3] = d3 ^ __builtin_amdgcn_alignbyte(r4, r3, rs); xr[4] = d4 ^ __builtin_amdgcn_alignbyte(r5, r4, rs);
+                        zke_runs2(xr, rr[0], rr[1]);
+                    }
                 }
-                uint32_t r1[2] = {0, 0}, rr[2];
                 // offset 1 needs four equal bytes to count: x1[0] == 0 at my first position, bytes 2 .. 5 of the window at my second.  On text
                 // no lane of the wave has them most of the time -- then the rest of the window and its run lengths are skipped (uniform branch)
                 if (__ballot(x1[0] == 0 || ((x1[0] >> 16) | (x1[1] << 16)) == 0)) {
                     x1[2] = d2 ^ __builtin_amdgcn_alignbyte(d2, d1, 3u); x1[3] = d3 ^ __builtin_amdgcn_alignbyte(d3, d2, 3u); x1[4] = d4 ^ __builtin_amdgcn_alignbyte(d4, d3, 3u);
                     zke_runs2(x1, r1[0], r1[1]);
                 }
-                zke_runs2(xr, rr[0], rr[1]);
                 const bool vr0 = R > 1;
                 uint32_t entry[2];
 #pragma unroll
