@@ -1483,10 +1483,17 @@ __global__ __launch_bounds__(256) void zk_k_small_walk(const uint8_t *h_comp, ui
     // upload: 16 bytes per lane and step, straight over PCIe (h_comp is 16-byte aligned, padded to a multiple of 16)
     const uint64_t n16 = (comp_bytes + 15) >> 4;
     const bool staged = n16 <= 3072;
-    for (uint64_t i = tid; i < n16; i += 256) {
-        const uint4 v = reinterpret_cast<const uint4 *>(h_comp)[i];
-        reinterpret_cast<uint4 *>(d_comp)[i] = v;
-        if (staged) s_stage[i] = v;
+    // (r5) eight loads per lane in flight before the first store: the loop used to be load -> wait -> store, one PCIe round trip (2-3 us) per
+    // 4 KiB of compressed bytes -- seven in a row for a 64 KiB frame, a third of this kernel's 50 us
+    for (uint64_t base = 0; base < n16; base += 8 * 256) {
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const uint64_t i = base + (uint64_t)k * 256 + tid; v[k] = reinterpret_cast<const uint4 *>(h_comp)[i < n16 ? i : 0]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint64_t i = base + (uint64_t)k * 256 + tid;
+            if (i < n16) { reinterpret_cast<uint4 *>(d_comp)[i] = v[k]; if (staged) s_stage[i] = v[k]; }
+        }
     }
     const uint8_t *wcomp = staged ? reinterpret_cast<const uint8_t *>(s_stage) : d_comp;
     if (tid < 2) reinterpret_cast<uint64_t *>(d_comp + (n16 << 4))[tid] = 0;                 // readable padding behind the last frame
