@@ -880,7 +880,31 @@ def main():
                     barrier(); torch.cuda.synchronize(); t = time.perf_counter()
                     out, table = parallel.encode_sharded(eng, d_src, FRAME, level, cks, root=0)
                     torch.cuda.synchronize(); barrier(); tg.append(time.perf_counter() - t)
+                # (r5) the gathered archive is one archive: the root decodes the LAST rank's last four frames out of it -- bytes that crossed a
+                # link, located through the gathered table -- and compares them with the generator's bytes for those chunks.  No collective
+                # here (nothing that could hang a peer); a failure is a field of the line, not the end of the run.
+                remote = None
+                if rank == 0 and out is not None and table is not None:
+                    try:
+                        from oracle import zko as _zko                     # untimed: the generator, as for the inputs
+                        nf_all = table.num_frames()
+                        first_f = nf_all - 4
+                        tc, td = table.offsets()
+                        c0, c1 = int(tc[first_f]), int(tc[nf_all])
+                        rel_c = torch.from_numpy((tc[first_f:] - tc[first_f]).astype(np.int64)).to(dev)
+                        rel_d = torch.from_numpy((td[first_f:] - td[first_f]).astype(np.int64)).to(dev)
+                        piece = torch.empty(c1 - c0 + 64, dtype=torch.uint8, device=dev)
+                        piece[:c1 - c0] = out[c0:c1]
+                        piece[c1 - c0:] = 0
+                        o4 = torch.empty(4 * FRAME + 64, dtype=torch.uint8, device=dev)
+                        s4 = torch.zeros(4, dtype=torch.int32, device=dev)
+                        eng.decode_frames_dev(piece, c1 - c0, rel_c, rel_d, 0, 4, o4, 4 * FRAME, True, s4)
+                        want4 = _zko.gen_chunks(4 * FRAME, first_f)       # rank r's chunk k is generator chunk r * nframes + k
+                        remote = {"frames": [first_f, nf_all], "bit_exact": bytes(o4[:4 * FRAME].cpu().numpy()) == want4 and int(s4.abs().sum().item()) == 0}
+                    except Exception as ex:                               # noqa: BLE001
+                        remote = {"error": f"{type(ex).__name__}: {ex}"}
                 box["info"] = {"encode_plus_gather_GiB_per_s": round(dsize * world / min(tg) / 2**30, 2), "ms": round(min(tg) * 1e3, 2),
+                               "last_ranks_frames_decoded_from_the_gathered_archive": remote,
                                "frames_on_root": table.num_frames() if table is not None else None,
                                "stream_bytes_on_root": int(out.numel()) if out is not None else None,
                                "note": "every rank encodes its 2048 frames, then all_gather of sizes, point-to-point payload gather into the "
