@@ -82,10 +82,9 @@ __device__ __forceinline__ uint32_t zke_ffbh(uint32_t x) { uint32_t r; asm("v_ff
 __device__ __forceinline__ uint32_t zke_first16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
 {
     const uint32_t f0 = ZKE_FFBL(x0), f1 = ZKE_FFBL(x1) | 32u, f2 = ZKE_FFBL(x2) | 64u, f3 = ZKE_FFBL(x3) | 96u;
-    uint32_t r = f0 < f1 ? f0 : f1;
-    const uint32_t t = f2 < f3 ? f2 : f3;
-    r = r < t ? r : t;
-    return (r < 128u ? r : 128u) >> 3;
+    // (a chain, not a tree: two v_min3_u32 instead of four v_min_u32)
+    const uint32_t a = f0 < f1 ? f0 : f1, b = a < f2 ? a : f2, c = b < f3 ? b : f3;
+    return (c < 128u ? c : 128u) >> 3;
 }
 // bytes (<= 16) that the 16 bytes at ring position c share with the 16 bytes o0 .. o3
 __device__ __forceinline__ uint32_t zke_common16(const uint32_t *ring, uint32_t c, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3)
