@@ -220,7 +220,11 @@ def roofline_of(kernel_ms, algo_bytes, step_ms=None, pmc_section=None, full_size
     traffic, src = None, None
     if pmc_section and full_size:
         sec, src_ = _pmc(pmc_section)
-        traffic = sec.get(dom.split("(")[0], {}).get("hbm_bytes")
+        key = dom.split("(")[0]
+        traffic = sec.get(key, {}).get("hbm_bytes")
+        if traffic is None and key in ("zk_k_fse", "zk_k_xxh64"):      # the engine's timer covers a family of kernels (zk_k_fse_quad / _sets / _predef_fed; zk_k_xxh64_wide ...): their sum
+            fam = [v.get("hbm_bytes", 0) for k, v in sec.items() if k.startswith(key)]
+            traffic = sum(fam) if fam else None
         src = src_ if traffic is not None else None
     out = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
            "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": int(algo_bytes)}
