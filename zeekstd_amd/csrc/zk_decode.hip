@@ -1486,14 +1486,16 @@ __global__ __launch_bounds__(256) void zk_k_small_walk(const uint8_t *h_comp, ui
     // (r5) eight loads per lane in flight before the first store: the loop used to be load -> wait -> store, one PCIe round trip (2-3 us) per
     // 4 KiB of compressed bytes -- seven in a row for a 64 KiB frame, a third of this kernel's 50 us
     for (uint64_t base = 0; base < n16; base += 8 * 256) {
-        uint4 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { const uint64_t i = base + (uint64_t)k * 256 + tid; v[k] = reinterpret_cast<const uint4 *>(h_comp)[i < n16 ? i : 0]; }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint64_t i = base + (uint64_t)k * 256 + tid;
-            if (i < n16) { reinterpret_cast<uint4 *>(d_comp)[i] = v[k]; if (staged) s_stage[i] = v[k]; }
-        }
+        const uint4 *h16 = reinterpret_cast<const uint4 *>(h_comp);
+        uint4 *d16 = reinterpret_cast<uint4 *>(d_comp);
+        const uint64_t i0 = base + tid;
+        // (eight named values, not an array: indexed it went to scratch memory)
+#define ZK_UP_LD(k) const uint4 v##k = h16[i0 + (k) * 256 < n16 ? i0 + (k) * 256 : 0];
+#define ZK_UP_ST(k) if (i0 + (k) * 256 < n16) { d16[i0 + (k) * 256] = v##k; if (staged) s_stage[i0 + (k) * 256] = v##k; }
+        ZK_UP_LD(0) ZK_UP_LD(1) ZK_UP_LD(2) ZK_UP_LD(3) ZK_UP_LD(4) ZK_UP_LD(5) ZK_UP_LD(6) ZK_UP_LD(7)
+        ZK_UP_ST(0) ZK_UP_ST(1) ZK_UP_ST(2) ZK_UP_ST(3) ZK_UP_ST(4) ZK_UP_ST(5) ZK_UP_ST(6) ZK_UP_ST(7)
+#undef ZK_UP_LD
+#undef ZK_UP_ST
     }
     const uint8_t *wcomp = staged ? reinterpret_cast<const uint8_t *>(s_stage) : d_comp;
     if (tid < 2) reinterpret_cast<uint64_t *>(d_comp + (n16 << 4))[tid] = 0;                 // readable padding behind the last frame
