@@ -206,3 +206,53 @@ def decode_stream(comp: bytes, expect: int = -1, which: str = "system", prefix: 
         l.ZSTD_freeDCtx(dctx)
     assert expect < 0 or len(out) == expect, (len(out), expect)
     return bytes(out)
+
+
+def decode_stream_verdict(comp: bytes, which: str = "system"):
+    """The same loop for input that may be DAMAGED: (bytes handed out so far, state) with state "end" (the last call returned 0: the input
+    ends on a frame end), "more" (the input ran out inside a frame -- the library still waits) or the error's text."""
+    l = load(which)
+    dctx = l.ZSTD_createDCtx()
+    comp = bytes(comp)
+    src = C.create_string_buffer(comp, len(comp)) if comp else C.create_string_buffer(1)
+    base = C.addressof(src)
+    ob = C.create_string_buffer(DSTREAM_OUT)
+    out = bytearray()
+    pos, r = 0, 0
+    try:
+        while pos < len(comp):
+            take = min(DSTREAM_IN, len(comp) - pos)
+            inb = InBuf(base + pos, take, 0)
+            while inb.pos < take:
+                outb = OutBuf(C.addressof(ob), DSTREAM_OUT, 0)
+                r = _chk(l, l.ZSTD_decompressStream(dctx, C.byref(outb), C.byref(inb)))
+                out += ob.raw[:outb.pos]
+            pos += take
+        while r != 0:                                   # what the context still holds
+            inb = InBuf(base, 0, 0)
+            outb = OutBuf(C.addressof(ob), DSTREAM_OUT, 0)
+            r = _chk(l, l.ZSTD_decompressStream(dctx, C.byref(outb), C.byref(inb)))
+            if outb.pos == 0:
+                break
+            out += ob.raw[:outb.pos]
+    except ZstdError as e:
+        return bytes(out), str(e)
+    finally:
+        l.ZSTD_freeDCtx(dctx)
+    return bytes(out), "end" if r == 0 else "more"
+
+
+def judge_damaged(a, b, original: bytes):
+    """a, b: decode_stream_verdict of the real libzstd and of a library under test that decodes WHOLE frames (the Level-C shim), on the same
+    damaged stream of which `original` is the undamaged content.  None when b behaves like a, else what is wrong:
+       a reaches the end of the stream -> so does b, with the same bytes;
+       a still waits for input         -> b waits too or refuses, and what it handed out is a prefix of a's bytes;
+       a refuses                       -> b refuses or still waits, and handed out no byte a did not (or: the damaged bit is one the distro's
+                                          1.4.8 is stricter about than the format -- b's bytes are then the archive's own)."""
+    (oa, sa), (ob, sb) = a, b
+    if sa == "end":
+        return None if (sb == "end" and ob == oa) else "libzstd decodes the stream; under test: %s, %d bytes of %d" % (sb, len(ob), len(oa))
+    if sb == "end":
+        return None if (sa != "more" and ob == original) else "decodes a stream libzstd does not (%s)" % sa
+    return None if oa[:len(ob)] == ob else "handed out bytes libzstd did not"
+

@@ -162,6 +162,25 @@ int main(int argc, char **argv)
         if (kind == 3) for (size_t i = rnd() % s.size(); i < s.size() && (rnd() % 50); i++) s[i] = (uint8_t)rnd();
         (void)run_decode(s, false);
     }
+    // 4. verdicts the header walk owes at once -- before the bytes a damaged header asks for are waited for (libzstd refuses there too)
+    {
+        auto first_call = [](std::vector<uint8_t> v) {
+            ZSTD_DCtx *d = ZSTD_createDCtx();
+            uint8_t ob[64];
+            ZSTD_inBuffer in{v.data(), v.size(), 0};
+            ZSTD_outBuffer out{ob, sizeof ob, 0};
+            const size_t r = ZSTD_decompressStream(d, &out, &in);
+            ZSTD_freeDCtx(d);
+            return r;
+        };
+        const size_t big = first_call({0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x58, 0x08, 0x00, 0x10});          // window 1 MiB; a raw block of 2^17 + 1 bytes
+        const size_t okb = first_call({0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x58, 0x00, 0x00, 0x10});          // ... of 2^17 bytes: waits for them
+        const size_t win = first_call({0x28, 0xB5, 0x2F, 0xFD, 0x20, 0x05, 0x31, 0x00, 0x00});          // single segment, 5 bytes of content; a raw block of 6
+        const size_t rsv = first_call({0x28, 0xB5, 0x2F, 0xFD, 0x08, 0x58, 0x01, 0x00, 0x00});          // the reserved bit of the descriptor
+        const size_t typ = first_call({0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x58, 0x07, 0x00, 0x00});          // block type 3
+        if (!ZSTD_isError(big) || ZSTD_getErrorCode(big) != 20 || ZSTD_isError(okb) || okb == 0 || !ZSTD_isError(win) || ZSTD_getErrorCode(win) != 20 ||
+            !ZSTD_isError(rsv) || ZSTD_getErrorCode(rsv) != 14 || !ZSTD_isError(typ) || ZSTD_getErrorCode(typ) != 20) { fprintf(stderr, "header verdicts\n"); return 12; }
+    }
     printf("shim fuzz: %d damaged streams, %llu frames shown to the engine, no report\n", cases, (unsigned long long)g_seen_frames);
     return 0;
 }

@@ -38,7 +38,7 @@ typedef struct { void *dst; size_t size; size_t pos; } ZSTD_outBuffer;
 }
 
 namespace {
-constexpr size_t ZERR_GENERIC = 1, ZERR_PREFIX_UNKNOWN = 10, ZERR_PARAM_UNSUPPORTED = 40, ZERR_PARAM_OOB = 42, ZERR_STAGE_WRONG = 60,
+constexpr size_t ZERR_GENERIC = 1, ZERR_PREFIX_UNKNOWN = 10, ZERR_FRAMEPARAM_UNSUPPORTED = 14, ZERR_PARAM_UNSUPPORTED = 40, ZERR_PARAM_OOB = 42, ZERR_STAGE_WRONG = 60,
                  ZERR_MEMORY = 64, ZERR_DST_TOO_SMALL = 70, ZERR_SRC_SIZE_WRONG = 72, ZERR_CORRUPTION = 20, ZERR_MAXCODE = 120;
 inline size_t zerr(size_t code) { return (size_t)0 - code; }
 inline size_t from_zk(int rc) { return rc == 0 ? 0 : zerr(rc < 0 && (size_t)(-rc) < ZERR_MAXCODE ? (size_t)(-rc) : ZERR_GENERIC); }   // Level A: -(ZSTD_ErrorCode); its own -1000.. codes -> GENERIC
@@ -73,6 +73,7 @@ struct ZSTD_DCtx_s {
     bool have = false;                                   // `out` holds the frame (its last input byte is still the caller's)
     bool skippable = false, cks = false;
     uint64_t fcs = ~0ull;
+    uint32_t block_max = 131072;                         // Block_Maximum_Size of the frame on hand: min(window, 128 KiB) (RFC 8878 3.1.1.2.3)
     const uint8_t *prefix = nullptr; size_t plen = 0;
 };
 typedef ZSTD_CCtx_s ZSTD_CCtx;
@@ -169,6 +170,7 @@ size_t ZSTD_freeDCtx(ZSTD_DCtx *d) { delete d; return 0; }
 static void dctx_next_frame(ZSTD_DCtx *d)
 {
     d->acc.clear(); d->out.clear(); d->out_pos = 0; d->next_hdr = 0; d->total = 0; d->have = false; d->skippable = false; d->cks = false; d->fcs = ~0ull;
+    d->block_max = 131072;
 }
 size_t ZSTD_DCtx_reset(ZSTD_DCtx *d, int directive)
 {
@@ -216,19 +218,25 @@ static size_t frame_need(ZSTD_DCtx *d, const View &a, size_t *err)
         const uint32_t fhd = a[4], fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
         const size_t dl = did == 3 ? 4 : did, fl = fcs_flag == 0 ? single : (size_t)1 << fcs_flag, hdr = 5 + (single ? 0 : 1) + dl + fl;
         if (a.size() < hdr) return hdr;
+        if (fhd & 8) { *err = zerr(ZERR_FRAMEPARAM_UNSUPPORTED); return 0; }   // the reserved bit: refused before a byte of the frame is waited for, as libzstd does
         d->cks = (fhd >> 2) & 1;
         if (fl) {
             uint64_t v = 0;
             for (size_t i = 0; i < fl; i++) v |= (uint64_t)a[hdr - fl + i] << (8 * i);
             d->fcs = fl == 2 ? v + 256 : v;
         }
+        // a block header that asks for more than Block_Maximum_Size is damage, known the moment the header is read -- not a reason to
+        // wait for that many bytes (a flipped size bit would otherwise swallow the rest of the stream as "input still to come")
+        uint64_t window = d->fcs;
+        if (!single) { const uint32_t wd = a[5], e = wd >> 3, m = wd & 7; window = (1ull << (10 + e)); window += (window >> 3) * m; }
+        d->block_max = window < 131072 ? (uint32_t)window : 131072;
         d->next_hdr = hdr;
     }
     for (;;) {
         if (a.size() < d->next_hdr + 3) return d->next_hdr + 3;
         const uint32_t h = (uint32_t)a[d->next_hdr] | (uint32_t)a[d->next_hdr + 1] << 8 | (uint32_t)a[d->next_hdr + 2] << 16;
         const uint32_t last = h & 1, type = (h >> 1) & 3, size = h >> 3;
-        if (type == 3) { *err = zerr(ZERR_CORRUPTION); return 0; }
+        if (type == 3 || size > d->block_max) { *err = zerr(ZERR_CORRUPTION); return 0; }
         d->next_hdr += 3 + (type == 1 ? 1 : size);
         if (last) { d->total = d->next_hdr + (d->cks ? 4 : 0); return d->total; }
     }

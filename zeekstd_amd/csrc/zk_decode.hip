@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * ZK_FSE_WAVES) void zk_k_fse(const uint8_t *com
     ZkBlock *o = &blocks[bi];
     o->out_size = b.out_size;
     o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
-    o->status = b.status;
+    if (b.status != ZK_OK) o->status = b.status;      // (never OK over the literal kernel's verdict: the two run side by side)
 }
 
 // ---- three lanes per block ------------------------------------------------------------------------------------
@@ -452,7 +452,7 @@ __device__ __forceinline__ void zk_fse_quad_group(uint32_t group, const uint8_t 
         ZkBlock *o = &blocks[bi];
         o->out_size = b.out_size;
         o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
-        o->status = b.status;
+        if (b.status != ZK_OK) o->status = b.status;      // (never OK over the literal kernel's verdict: the two run side by side)
         return;
     }
     // ---- the walker wave.  The three lanes build the block's tables together (identical LDS writes: more active lanes, see above)
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_predef(const uint8_t *
     ZkBlock *o = &blocks[bi];
     o->out_size = b.out_size;
     o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
-    o->status = b.status;
+    if (b.status != ZK_OK) o->status = b.status;      // (never OK over the literal kernel's verdict: the two run side by side)
     o->pad = 1;                                            // done: zk_k_fse_quad skips it
 }
 
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const u
         ZkBlock *o = &blocks[bi];
         o->out_size = b.out_size;
         o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
-        o->status = b.status;
+        if (b.status != ZK_OK) o->status = b.status;      // (never OK over the literal kernel's verdict: the two run side by side)
         o->pad = 1;
     } else if (active && bs_off < b.bsize) {
         // feeder: aligned words of the lane's bitstream, last word first (ZkRevL::word_count / W(j))
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_sets(const uint8_t *co
     ZkBlock *o = &blocks[bi];
     o->out_size = b.out_size;
     o->rep_out[0] = b.rep_out[0]; o->rep_out[1] = b.rep_out[1]; o->rep_out[2] = b.rep_out[2];
-    o->status = b.status;
+    if (b.status != ZK_OK) o->status = b.status;      // (never OK over the literal kernel's verdict: the two run side by side)
     o->pad = 1;                                            // done: zk_k_fse_quad skips it
 }
 
