@@ -269,6 +269,7 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
                 const ZkBlock &b = fb[bk];
                 if (b.status != ZK_OK) { err = b.status; break; }
                 if (pos + b.out_size > d_size) { err = ZK_E_CORRUPTION; break; }
+                if (b.out_size > (fi.window < ZK_BLOCK_MAX ? fi.window : ZK_BLOCK_MAX)) { err = ZK_E_CORRUPTION; break; }
                 uint8_t *bout = out + pos;
                 if (b.type == 0) memcpy(bout, comp + b.src, b.bsize);
                 else if (b.type == 1) memset(bout, comp[b.src], b.bsize);

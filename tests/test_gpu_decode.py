@@ -198,6 +198,21 @@ def test_batch_kernels_verdicts_on_damaged_frames_without_checksums(engine, make
     assert refused > 40
 
 
+def test_block_regenerates_more_than_the_window_allows(engine):
+    """tests/test_sim_decode.py::test_sim_block_regenerates_more_than_the_window_allows on the device: the executor and zk_frame_content_sizes
+    hold a block's regenerated size against min(Window_Size, 128 KiB)."""
+    data = b"ab" * 50000
+    f = bytearray(zko.frame_encode(data, 1, False))
+    c, d = [0, len(f)], [0, len(data)]
+    out, st = engine.decode_frames(bytes(f) + b"\0" * 8, c, d, verify=False)
+    assert out == data
+    f[5] = 0x00                                           # Window_Descriptor: 1 KiB
+    out, st = engine.decode_frames(bytes(f) + b"\0" * 8, c, d, verify=False, raise_on_error=False)
+    assert st[0] == 20
+    sizes, st = engine.frame_content_sizes(bytes(f), c)
+    assert st[0] == -20
+
+
 def test_error_codes(engine):
     g = next(x for x in GOLDENS if x.name == "hello")
     _, st = engine.decode_frames(g.comp + b"\0" * 8, [0, 21], [0, 13], raise_on_error=False)

@@ -135,7 +135,8 @@ def test_damaged_streams_are_treated_as_libzstd_treats_them(shim):
     hands out nothing libzstd did not (oracle/libzstd_ref.py judge_damaged).  Round 5 found two gaps with this: a block header asking for
     more than Block_Maximum_Size made the shim wait for input instead of refusing, and -- in the engine itself -- the sequence kernels'
     write-back of a block's status could put OK over the literal kernel's verdict (frames without a checksum then decoded to wrong bytes)."""
-    if Z.load("system") is None:
+    ref = "1.5.7" if Z.load("1.5.7") is not None else "system"     # the version the reference pins, where the image has it
+    if Z.load(ref) is None:
         pytest.skip("no libzstd in the image")
     rng = np.random.default_rng(3)
     small = [g for g in GOLDENS if 0 < g.meta["input_len"] <= 400000]
@@ -145,7 +146,18 @@ def test_damaged_streams_are_treated_as_libzstd_treats_them(shim):
         bad = bytearray(g.comp)
         for _ in range(int(rng.integers(1, 4))):
             bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
-        a, b = Z.decode_stream_verdict(bytes(bad), "system"), Z.decode_stream_verdict(bytes(bad), "shim")
-        assert Z.judge_damaged(a, b, g.input()) is None, (c, g.name, a[1], b[1])
+        a, b = Z.decode_stream_verdict(bytes(bad), ref), Z.decode_stream_verdict(bytes(bad), "shim")
+
+        def format_refuses():                               # libzstd is laxer than the format in two places (judge_damaged): the oracle decides
+            pos = 0
+            for cs, ds in g.frames:
+                try:
+                    if zko.frame_decode(bytes(bad[pos:pos + cs]), ds + 64, True)[1] != cs:
+                        return True
+                except zko.OracleError:
+                    return True
+                pos += cs
+            return False
+        assert Z.judge_damaged(a, b, g.input(), format_refuses) is None, (c, g.name, a[1], b[1])
         seen.add((a[1] in ("end", "more"), b[1] in ("end", "more")))
     assert (True, True) in seen and (False, False) in seen

@@ -274,3 +274,22 @@ def test_sim_under_sanitizers_on_damaged_archives(tmp_path):
         for walk in (0, 2):
             r = subprocess.run([exe, path, str(iters if walk == 0 else iters // 10), "6", str(walk), pre], capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, (name, walk, r.stdout[-300:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("quad", [False, True, 2])
+def test_sim_block_regenerates_more_than_the_window_allows(quad):
+    """Block_Maximum_Size = min(Window_Size, 128 KiB) bounds what a block REGENERATES, not only what it holds (RFC 8878 3.1.1.2.4): a frame
+    whose Window_Descriptor is turned down to 1 KiB while its blocks regenerate 32 KiB (offsets of 2: inside any window) is refused -- by the
+    oracle, by libzstd's buffer sizing, and by the executor (round 5: it compared against 128 KiB only; found with a flipped descriptor bit
+    in a prefix archive, where offsets are not held against the window)."""
+    data = b"ab" * 50000
+    f = bytearray(zko.frame_encode(data, 1, False))
+    assert not f[4] & 0x20                                # not single segment: byte 5 is the Window_Descriptor
+    rc, out, st = sim_decode(bytes(f), [(len(f), len(data))], quad=quad)
+    assert rc == 0 and out == data
+    f[5] = 0x00                                           # 1 KiB
+    with pytest.raises(zko.OracleError):
+        zko.frame_decode(bytes(f), len(data), False)
+    rc, out, st = sim_decode(bytes(f), [(len(f), len(data))], quad=quad)
+    assert rc == -20 and st[0] == 20
+

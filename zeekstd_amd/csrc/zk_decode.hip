@@ -861,6 +861,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
     uint64_t pos = 0;
     uint32_t rep[3] = {1, 4, 8};
     uint32_t err = ZK_OK;
+    const uint32_t block_max = fi.window < ZK_BLOCK_MAX ? fi.window : ZK_BLOCK_MAX;
 #ifdef ZK_EXEC_CLOCKS
     unsigned long long clk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_ = clock64();
 #endif
@@ -870,6 +871,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
         const uint32_t b_status = zk_uni(b.status), b_out_size = zk_uni(b.out_size), b_type = zk_uni((uint32_t)b.type);
         if (b_status != ZK_OK) { err = b_status; break; }
         if (pos + b_out_size > d_size) { err = ZK_E_CORRUPTION; break; }
+        if (b_out_size > block_max) { err = ZK_E_CORRUPTION; break; }       // Block_Maximum_Size = min(Window_Size, 128 KiB) also bounds what a compressed block regenerates (RFC 8878 3.1.1.2.4; raw / RLE: zk_walk_frame)
         uint8_t *bout = out + pos;
         if (b_type <= 1) {
             // raw / RLE block: bytes up to the first 16-byte boundary of the output, 16-byte stores (the source of a raw
@@ -1433,6 +1435,7 @@ __global__ __launch_bounds__(256) void zk_k_frame_sizes(const ZkFrameInfo *infos
         const ZkBlock *b = blocks + bases[f].block_base;
         for (uint32_t i = 0; i < infos[f].n_blocks; i++) {
             if (b[i].status != ZK_OK && st == ZK_OK) st = b[i].status;
+            if (b[i].out_size > (infos[f].window < ZK_BLOCK_MAX ? infos[f].window : ZK_BLOCK_MAX) && st == ZK_OK) st = ZK_E_CORRUPTION;    // as the executor
             sum += b[i].out_size;
         }
         if (st == ZK_OK && sum > ZK_MAX_FRAME) st = ZK_E_FRAMEPARAM_UNSUPPORTED;
