@@ -1,0 +1,66 @@
+"""Frames no encoder here writes (tests/helpers/zstd_gen.py: every choice RFC 8878 leaves open drawn at random -- header forms, block types,
+literal modes and header sizes, Treeless literals, the four modes per sequence table with random FSE distributions, repeat codes with and without
+Literals_Length 0) through the real libzstd 1.5.7, the oracle and the kernels' lane code on the CPU (tests/sim/zk_sim.cpp, all three sequence
+walks).  libzstd decides what a frame means; the generator's own model, the oracle and the lane code have to agree with it.  The kernels themselves:
+tests/test_gpu_generated_frames.py.  (The goldens are what libzstd's encoder emits; this is the rest of the format.)"""
+import collections
+
+import pytest
+
+from conftest import sim_decode
+from helpers import zstd_gen
+from oracle import zko
+from oracle import libzstd_ref as Z
+
+WANTED = {"raw", "rle", "compressed", "single", "windowed", "fcs0", "fcs1", "fcs2", "fcs3", "checksum", "lit_raw", "lit_rle", "lit_huf", "lit_treeless",
+          "lit_hdr1", "lit_hdr2", "lit_hdr3", "huf_streams1", "huf_streams4", "huf_fmt0", "huf_fmt1", "huf_fmt2", "huf_fmt3", "huf_weights_direct", "huf_weights_fse", "fse_lowprob",
+          "nseq_form1", "nseq_form2", "off_new", "rep_idx0", "rep_idx1", "rep_idx2", "rep_idx3"} | {"%s_mode%d" % (t, m) for t in ("ll", "of", "ml") for m in range(4)}
+
+
+def test_generated_frames_mean_what_libzstd_says():
+    ref = "1.5.7" if Z.load("1.5.7") is not None else "system"
+    if Z.load(ref) is None:
+        pytest.skip("no libzstd in the image")
+    seen = collections.Counter()
+    for seed in range(1500):
+        f, out, feats = zstd_gen.generate(seed, zko.xxh64)
+        got, state = Z.decode_stream_verdict(f, ref)
+        assert state == "end" and got == out, (seed, state, len(got), len(out), sorted(feats))
+        o, used = zko.frame_decode(f, len(out) + 64, True)
+        assert used == len(f) and o == out, (seed, sorted(feats))
+        seen.update(feats)
+    assert not WANTED - set(seen), WANTED - set(seen)
+
+
+@pytest.mark.parametrize("quad", [False, True, 2])
+def test_generated_frames_through_the_lane_code(quad):
+    for seed in range(600):
+        f, out, feats = zstd_gen.generate(seed, zko.xxh64)
+        rc, o, st = sim_decode(f, [(len(f), len(out))], quad=quad)
+        assert rc == 0 and o == out, (seed, rc, sorted(feats))
+
+
+def test_generated_frames_side_by_side_in_one_archive():
+    """many of them in one call: the block records of different frames sit side by side, Repeat / Treeless reach back inside their own frame only"""
+    frames, comp, data = [], bytearray(), bytearray()
+    for seed in range(2000, 2300):
+        f, out, _ = zstd_gen.generate(seed, zko.xxh64)
+        frames.append((len(f), len(out))); comp += f; data += out
+    for quad in (False, 2):
+        rc, o, st = sim_decode(bytes(comp), frames, quad=quad)
+        assert rc == 0 and not st.any() and o == bytes(data)
+
+
+def test_generated_frames_with_long_blocks():
+    """thousands of sequences per block, literal sections of tens of KiB (4-stream Huffman with the wide header forms), ten blocks per frame"""
+    ref = "1.5.7" if Z.load("1.5.7") is not None else "system"
+    for seed in range(150):
+        f, out, feats = zstd_gen.generate(100000 + seed, zko.xxh64, max_blocks=10, max_seq=4000, max_lit=100000)
+        if Z.load(ref) is not None:
+            assert Z.decode_stream_verdict(f, ref) == (out, "end"), seed
+        o, used = zko.frame_decode(f, len(out) + 64, True)
+        assert used == len(f) and o == out, seed
+        for quad in (False, True, 2):
+            rc, so, st = sim_decode(f, [(len(f), len(out))], quad=quad)
+            assert rc == 0 and so == out, (seed, quad)
+
