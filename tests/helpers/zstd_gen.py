@@ -204,8 +204,9 @@ class HufCode:
 
 
 class FrameGen:
-    def __init__(self, seed, max_blocks=6, max_seq=300, max_lit=3000):
+    def __init__(self, seed, max_blocks=6, max_seq=300, max_lit=3000, prefix=b""):
         self.rng = random.Random(seed)
+        self.prefix = bytes(prefix)                          # a raw-content prefix the frame is written against (ZSTD_CCtx_refPrefix): offsets reach into it
         self.max_blocks, self.max_seq, self.max_lit = max_blocks, max_seq, max_lit
         self.features = set()
 
@@ -337,18 +338,19 @@ class FrameGen:
             ll = 0 if rng.random() < 0.3 else rng.choice([rng.randint(1, 8), rng.randint(1, 40), rng.randint(1, 2000 if style < 0.1 else 60)])
             ml = rng.choice([3, rng.randint(3, 12), rng.randint(3, 130), rng.randint(3, 3000 if style < 0.1 else 200)])
             if len(lits) + ll > self.max_lit or produced + ll + ml > block_max: break
-            here = len(out) + ll                              # bytes available behind the literals
+            here = len(self.prefix) + len(out) + ll           # bytes available behind the literals
+            reach = min(here, window)                         # (an offset beyond the window into a prefix: libzstd takes it until its ring wraps -- not valid zstd, not drawn)
             r = rng.random()
             ofv = None
             if r < 0.45:                                      # a repeat code
                 code = rng.randint(1, 3)
                 idx = code - 1 + (1 if ll == 0 else 0)
                 off = rep[0] if idx == 0 else (rep[0] - 1 if idx == 3 else rep[idx])
-                if 0 < off <= min(here, window): ofv = code
+                if 0 < off <= reach: ofv = code
             if ofv is None:
                 if here == 0: continue
-                hi = min(here, window)
-                off = rng.choice([1, rng.randint(1, min(hi, 16)), rng.randint(1, hi), hi])
+                hi = reach
+                off = rng.choice([1, rng.randint(1, min(hi, 16)), rng.randint(1, hi), hi, max(1, min(hi, len(out) + ll + rng.randint(0, 40)))])   # (the last: around the frame's first byte, where a prefix begins)
                 ofv = off + 3
             if ofv > 3: rep = [ofv - 3, rep[0], rep[1]]; self.features.add("off_new")
             else:
@@ -359,7 +361,11 @@ class FrameGen:
                     rep = [off, rep[0], rep[1]] if idx > 1 else [off, rep[0], rep[2]]
             new = bytes(rng.choice(alpha) for _ in range(ll))
             lits += new; out += new
-            for _ in range(ml): out.append(out[-off])
+            self.max_off = max(self.max_off, off)
+            if off > len(out): self.features.add("off_into_prefix")
+            for _ in range(ml):
+                i = len(out) - off
+                out.append(out[i] if i >= 0 else self.prefix[len(self.prefix) + i])
             produced += ll + ml
             seqs.append((ll, ml, ofv))
         tail = rng.randint(0, min(self.max_lit - len(lits), block_max - produced, rng.choice([0, 5, 300, 3000])))
@@ -377,6 +383,7 @@ class FrameGen:
         while True:
             self.huf, self.tables, self.alpha = None, {}, None
             self.features = set()
+            self.max_off = 0
             exp, mant = rng.choice([0, 0, 1, 3, 7, rng.randint(0, 10)]), rng.randint(0, 7)
             window = (1 << (10 + exp)) + ((1 << (10 + exp)) >> 3) * mant
             block_max = min(window, 1 << 17)
@@ -404,7 +411,7 @@ class FrameGen:
             if not blocks: continue
             total = len(out)
             # Single_Segment: the window IS the content size, and Block_Maximum_Size follows it -- also for what a block holds
-            single = total <= window and rng.random() < 0.4 and all(n <= min(total, 1 << 17) for t, n, _ in blocks if t == 2)
+            single = total <= window and rng.random() < 0.4 and all(n <= min(total, 1 << 17) for t, n, _ in blocks if t == 2) and self.max_off <= total
             cks = rng.random() < 0.5
             if single:
                 flags = [f for f, lo, hi in ((0, 0, 255), (1, 256, 65791), (2, 0, (1 << 32) - 1), (3, 0, (1 << 64) - 1)) if lo <= total <= hi]

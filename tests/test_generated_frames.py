@@ -64,3 +64,20 @@ def test_generated_frames_with_long_blocks():
             rc, so, st = sim_decode(f, [(len(f), len(out))], quad=quad)
             assert rc == 0 and so == out, (seed, quad)
 
+
+def test_generated_frames_against_a_prefix():
+    """the same against a raw-content prefix (ZSTD_DCtx_refPrefix): offsets reach across the frame's first byte into it, within the window"""
+    ref = "1.5.7" if Z.load("1.5.7") is not None else "system"
+    into = 0
+    for seed in range(500):
+        prefix = zko.gen_text(1 + (seed * 7919) % 90000, seed % 7)
+        f, out, feats = zstd_gen.generate(300000 + seed, zko.xxh64, prefix=prefix)
+        if Z.load(ref) is not None:
+            assert Z.decode_stream(f, -1, ref, prefix=prefix, window_log_max=31) == out, seed
+        o, used = zko.frame_decode(f, len(out) + 64, True, prefix=prefix)
+        assert used == len(f) and o == out, seed
+        rc, so, st = sim_decode(f, [(len(f), len(out))], prefix=prefix, quad=(False, True, 2)[seed % 3])
+        assert rc == 0 and so == out, seed
+        into += "off_into_prefix" in feats
+    assert into > 100
+

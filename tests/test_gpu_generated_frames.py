@@ -117,3 +117,17 @@ def test_generated_frames_with_long_blocks(engine):
     sizes, st = engine.frame_content_sizes(comp, c)
     assert not st.any() and [int(x) for x in sizes] == [ds for _, ds in frames]
 
+
+def test_generated_frames_against_a_prefix(engine):
+    """offsets across the frame's first byte into a raw-content prefix: one frame at a time, and 300 frames written against ONE prefix in one call"""
+    for seed in range(300):
+        prefix = zko.gen_text(1 + (seed * 7919) % 90000, seed % 7)
+        f, out, feats = zstd_gen.generate(300000 + seed, zko.xxh64, prefix=prefix)
+        o, st = engine.decode_frames(f + b"\0" * 8, [0, len(f)], [0, len(out)], verify=True, raise_on_error=False, prefix=prefix)
+        assert st[0] == 0 and o == out, (seed, int(st[0]), sorted(feats))
+    prefix = zko.gen_text(70000, 3)
+    comp, frames, data = archive(range(310000, 310300), prefix=prefix)
+    c, d = offsets_from_frames(frames)
+    out, st = engine.decode_frames(comp + b"\0" * 8, c, d, verify=True, raise_on_error=False, prefix=prefix)
+    assert not st.any() and out == data
+
