@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE -- a generator of VALID zstd frames that no encoder here would write: every choice the format leaves open (RFC 8878) is
 drawn at random, so that the decoders meet corners the libzstd-made goldens only reach by chance:
 
-  frame header   Single_Segment or a Window_Descriptor (exponent + mantissa), Frame_Content_Size of 0 / 1 / 2 / 4 / 8 bytes, checksum or not
+  frame header   Single_Segment or a Window_Descriptor (exponent + mantissa), Frame_Content_Size of 0 / 1 / 2 / 4 / 8 bytes, checksum or not,
+                 a Dictionary_ID field of any width holding 0, the Unused_Bit
   blocks         Raw, RLE, Compressed in any order; empty blocks; a last block of any type
   literals       Raw / RLE (1-, 2-, 3-byte headers), Huffman with 1 or 4 streams (a random complete code of depth <= 11; weights direct or FSE-compressed),
                  Treeless (the table of an earlier block)
@@ -204,8 +205,9 @@ class HufCode:
 
 
 class FrameGen:
-    def __init__(self, seed, max_blocks=6, max_seq=300, max_lit=3000, prefix=b""):
+    def __init__(self, seed, max_blocks=6, max_seq=300, max_lit=3000, prefix=b"", dense=False):
         self.rng = random.Random(seed)
+        self.want_dense = dense                              # one block of the frame with more than 0x7F00 sequences
         self.prefix = bytes(prefix)                          # a raw-content prefix the frame is written against (ZSTD_CCtx_refPrefix): offsets reach into it
         self.max_blocks, self.max_seq, self.max_lit = max_blocks, max_seq, max_lit
         self.features = set()
@@ -304,13 +306,15 @@ class FrameGen:
 
         def chain(cells, codes):
             """states[i] of a decoder that sees codes[i] in state i, and the bits that take it from i to i + 1"""
-            last = [k for k, cell in enumerate(cells) if cell[0] == codes[-1]]
-            states, bits = [rng.choice(last)], []
+            by_sym = {}
+            for k, cell in enumerate(cells): by_sym.setdefault(cell[0], []).append(k)
+            states, bits = [rng.choice(by_sym[codes[-1]])], []
             for c in reversed(codes[:-1]):
-                nxt = states[0]
-                k = next(k for k, cell in enumerate(cells) if cell[0] == c and cell[2] <= nxt < cell[2] + (1 << cell[1]))
-                bits.insert(0, (nxt - cells[k][2], cells[k][1]))
-                states.insert(0, k)
+                nxt = states[-1]
+                k = next(k for k in by_sym[c] if cells[k][2] <= nxt < cells[k][2] + (1 << cells[k][1]))
+                bits.append((nxt - cells[k][2], cells[k][1]))
+                states.append(k)
+            states.reverse(); bits.reverse()
             return states, bits
         s_ll, b_ll = chain(c_ll, [x[0] for x in ll])
         s_of, b_of = chain(c_of, [x[0] for x in of])
@@ -328,6 +332,9 @@ class FrameGen:
         rng = self.rng
         nseq = 0 if rng.random() < 0.15 else rng.randint(1, rng.choice([3, 20, self.max_seq]))
         style = rng.random()
+        dense = self.dense and block_max == 1 << 17 and len(out) >= 8
+        if dense: nseq = rng.randint(0x7F00, 0x7F00 + 6000)     # the three-byte Number_of_Sequences: matches of 3 ... 4 bytes back to back
+        self.dense = self.dense and not dense
         if self.alpha is not None and rng.random() < 0.4: alpha = bytes(rng.sample(list(self.alpha), rng.randint(1, len(self.alpha))))   # (a block the table of the one before fits: Treeless)
         else: alpha = bytes(rng.sample(range(0, rng.choice([129, 256])), rng.randint(1, rng.choice([2, 6, 40, 100])))) if rng.random() < 0.8 else bytes(range(256))
         self.alpha = alpha
@@ -337,6 +344,7 @@ class FrameGen:
         for _ in range(nseq):
             ll = 0 if rng.random() < 0.3 else rng.choice([rng.randint(1, 8), rng.randint(1, 40), rng.randint(1, 2000 if style < 0.1 else 60)])
             ml = rng.choice([3, rng.randint(3, 12), rng.randint(3, 130), rng.randint(3, 3000 if style < 0.1 else 200)])
+            if dense: ll, ml = (1 if rng.random() < 0.02 else 0), (3 if rng.random() < 0.9 else 4)
             if len(lits) + ll > self.max_lit or produced + ll + ml > block_max: break
             here = len(self.prefix) + len(out) + ll           # bytes available behind the literals
             reach = min(here, window)                         # (an offset beyond the window into a prefix: libzstd takes it until its ring wraps -- not valid zstd, not drawn)
@@ -384,6 +392,7 @@ class FrameGen:
             self.huf, self.tables, self.alpha = None, {}, None
             self.features = set()
             self.max_off = 0
+            self.dense = self.want_dense
             exp, mant = rng.choice([0, 0, 1, 3, 7, rng.randint(0, 10)]), rng.randint(0, 7)
             window = (1 << (10 + exp)) + ((1 << (10 + exp)) >> 3) * mant
             block_max = min(window, 1 << 17)
@@ -408,7 +417,7 @@ class FrameGen:
                         continue
                     rep = rep2
                     blocks.append((2, len(body), body)); self.features.add("compressed")
-            if not blocks: continue
+            if not blocks or self.dense: continue               # (a dense block was asked for and did not come about: window too small, ...)
             total = len(out)
             # Single_Segment: the window IS the content size, and Block_Maximum_Size follows it -- also for what a block holds
             single = total <= window and rng.random() < 0.4 and all(n <= min(total, 1 << 17) for t, n, _ in blocks if t == 2) and self.max_off <= total
@@ -418,8 +427,12 @@ class FrameGen:
                 fcs_flag = rng.choice(flags)
             else:
                 fcs_flag = rng.choice([0, 0] + [f for f, lo, hi in ((1, 256, 65791), (2, 0, (1 << 32) - 1), (3, 0, (1 << 64) - 1)) if lo <= total <= hi])
-            fhd = (fcs_flag << 6) | (0x20 if single else 0) | (4 if cks else 0)
-            hdr = bytes.fromhex("28B52FFD") + bytes([fhd]) + (b"" if single else bytes([(exp << 3) | mant]))
+            did = rng.choice([0, 0, 0, 1, 2, 3])              # a Dictionary_ID field of 1 / 2 / 4 bytes holding 0 = "no dictionary" (RFC 8878 3.1.1.1.3)
+            unused = 0x10 if rng.random() < 0.2 else 0         # Unused_Bit: a decoder shall not interpret it
+            fhd = (fcs_flag << 6) | (0x20 if single else 0) | unused | (4 if cks else 0) | did
+            hdr = bytes.fromhex("28B52FFD") + bytes([fhd]) + (b"" if single else bytes([(exp << 3) | mant])) + bytes((0, 1, 2, 4)[did])
+            if did: self.features.add("did_field")
+            if unused: self.features.add("unused_bit")
             if single and fcs_flag == 0: hdr += bytes([total])
             elif fcs_flag == 1: hdr += struct.pack("<H", total - 256)
             elif fcs_flag == 2: hdr += struct.pack("<I", total)

@@ -12,7 +12,7 @@ from helpers import zstd_gen
 from oracle import zko
 from oracle import libzstd_ref as Z
 
-WANTED = {"raw", "rle", "compressed", "single", "windowed", "fcs0", "fcs1", "fcs2", "fcs3", "checksum", "lit_raw", "lit_rle", "lit_huf", "lit_treeless",
+WANTED = {"raw", "rle", "compressed", "single", "windowed", "fcs0", "fcs1", "fcs2", "fcs3", "checksum", "did_field", "unused_bit", "lit_raw", "lit_rle", "lit_huf", "lit_treeless",
           "lit_hdr1", "lit_hdr2", "lit_hdr3", "huf_streams1", "huf_streams4", "huf_fmt0", "huf_fmt1", "huf_fmt2", "huf_fmt3", "huf_weights_direct", "huf_weights_fse", "fse_lowprob",
           "nseq_form1", "nseq_form2", "off_new", "rep_idx0", "rep_idx1", "rep_idx2", "rep_idx3"} | {"%s_mode%d" % (t, m) for t in ("ll", "of", "ml") for m in range(4)}
 
@@ -80,4 +80,19 @@ def test_generated_frames_against_a_prefix():
         assert rc == 0 and so == out, seed
         into += "off_into_prefix" in feats
     assert into > 100
+
+
+def test_generated_frames_with_more_than_0x7F00_sequences_in_a_block():
+    """the three-byte Number_of_Sequences: 32 512 ... 38 000 matches of three or four bytes back to back (the densest a block can be)"""
+    ref = "1.5.7" if Z.load("1.5.7") is not None else "system"
+    for seed in range(4):
+        f, out, feats = zstd_gen.generate(500000 + seed, zko.xxh64, dense=True, max_blocks=8)
+        assert "nseq_form3" in feats
+        if Z.load(ref) is not None:
+            assert Z.decode_stream_verdict(f, ref) == (out, "end"), seed
+        o, used = zko.frame_decode(f, len(out) + 64, True)
+        assert used == len(f) and o == out, seed
+        for quad in (False, True, 2):
+            rc, so, st = sim_decode(f, [(len(f), len(out))], quad=quad)
+            assert rc == 0 and so == out, (seed, quad)
 

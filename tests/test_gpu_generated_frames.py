@@ -131,3 +131,22 @@ def test_generated_frames_against_a_prefix(engine):
     out, st = engine.decode_frames(comp + b"\0" * 8, c, d, verify=True, raise_on_error=False, prefix=prefix)
     assert not st.any() and out == data
 
+
+def test_generated_frames_with_more_than_0x7F00_sequences_in_a_block(engine):
+    """the three-byte Number_of_Sequences (a block of 32 512+ three-byte matches: a sequence per three bytes is what the small path's record
+    scratch is sized for): one at a time, then together with 200 ordinary frames in one call"""
+    dense = [zstd_gen.generate(500000 + seed, zko.xxh64, dense=True, max_blocks=8) for seed in range(5)]
+    for f, out, feats in dense:
+        assert "nseq_form3" in feats
+        o, st = engine.decode_frames(f + b"\0" * 8, [0, len(f)], [0, len(out)], verify=True, raise_on_error=False)
+        assert st[0] == 0 and o == out
+        sizes, st = engine.frame_content_sizes(f, [0, len(f)])
+        assert st[0] == 0 and int(sizes[0]) == len(out)
+    comp, frames, data = archive(range(600000, 600200))
+    comp, data = bytearray(comp), bytearray(data)
+    for f, out, _ in dense:
+        frames.append((len(f), len(out))); comp += f; data += out
+    c, d = offsets_from_frames(frames)
+    out, st = engine.decode_frames(bytes(comp) + b"\0" * 8, c, d, verify=True, raise_on_error=False)
+    assert not st.any() and out == bytes(data)
+
