@@ -178,6 +178,17 @@ int main(int argc, char **argv)
         const size_t win = first_call({0x28, 0xB5, 0x2F, 0xFD, 0x20, 0x05, 0x31, 0x00, 0x00});          // single segment, 5 bytes of content; a raw block of 6
         const size_t rsv = first_call({0x28, 0xB5, 0x2F, 0xFD, 0x08, 0x58, 0x01, 0x00, 0x00});          // the reserved bit of the descriptor
         const size_t typ = first_call({0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x58, 0x07, 0x00, 0x00});          // block type 3
+        {   // ZSTD_d_windowLogMax: a window of 2^27 (+ 1 for a Single_Segment size) is the default limit; the parameter moves it; a parameter reset restores it
+            const std::vector<uint8_t> w27 = {0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x88, 0x09, 0x00, 0x00}, w27m = {0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x89, 0x09, 0x00, 0x00};   // 2^27; 2^27 * 9 / 8
+            auto call = [](ZSTD_DCtx *d, std::vector<uint8_t> v) { uint8_t ob[8]; ZSTD_inBuffer in{v.data(), v.size(), 0}; ZSTD_outBuffer out{ob, sizeof ob, 0}; const size_t r = ZSTD_decompressStream(d, &out, &in); ZSTD_DCtx_reset(d, 1); return r; };
+            ZSTD_DCtx *d = ZSTD_createDCtx();
+            bool ok = !ZSTD_isError(call(d, w27)) && ZSTD_getErrorCode(call(d, w27m)) == 16;
+            ok = ok && !ZSTD_isError(ZSTD_DCtx_setParameter(d, 100, 28)) && !ZSTD_isError(call(d, w27m));
+            ok = ok && !ZSTD_isError(ZSTD_DCtx_setParameter(d, 100, 20)) && ZSTD_getErrorCode(call(d, w27)) == 16;
+            ok = ok && !ZSTD_isError(ZSTD_DCtx_reset(d, 2)) && !ZSTD_isError(call(d, w27)) && ZSTD_getErrorCode(ZSTD_DCtx_setParameter(d, 100, 32)) == 42;
+            ZSTD_freeDCtx(d);
+            if (!ok) { fprintf(stderr, "window limit\n"); return 13; }
+        }
         if (!ZSTD_isError(big) || ZSTD_getErrorCode(big) != 20 || ZSTD_isError(okb) || okb == 0 || !ZSTD_isError(win) || ZSTD_getErrorCode(win) != 20 ||
             !ZSTD_isError(rsv) || ZSTD_getErrorCode(rsv) != 14 || !ZSTD_isError(typ) || ZSTD_getErrorCode(typ) != 20) { fprintf(stderr, "header verdicts\n"); return 12; }
     }

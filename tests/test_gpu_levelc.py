@@ -161,3 +161,20 @@ def test_damaged_streams_are_treated_as_libzstd_treats_them(shim):
         assert Z.judge_damaged(a, b, g.input(), format_refuses) is None, (c, g.name, a[1], b[1])
         seen.add((a[1] in ("end", "more"), b[1] in ("end", "more")))
     assert (True, True) in seen and (False, False) in seen
+
+
+def test_window_log_max_as_libzstd(shim):
+    """ZSTD_d_windowLogMax (cli/src/decompress.rs:56): a frame that declares more than 2^27 (+ 1) bytes of window is refused with libzstd's
+    frameParameter_windowTooLarge until the parameter allows it -- the engine itself would not mind, the shim holds the header against the
+    limit as ZSTD_decompressStream does."""
+    f = bytes.fromhex("28B52FFD") + bytes([0x00, (17 << 3) | 1, 0x09, 0, 0]) + b"a"          # Window_Size 2^27 * 9 / 8, one raw byte
+    ok = bytes.fromhex("28B52FFD") + bytes([0x00, (17 << 3) | 0, 0x09, 0, 0]) + b"a"         # 2^27: inside the default limit
+    for which in ("shim", "1.5.7", "system"):
+        if Z.load(which) is None:
+            continue
+        assert Z.decode_stream(ok, 1, which) == b"a", which
+        with pytest.raises(Z.ZstdError, match="too much memory"):
+            Z.decode_stream(f, 1, which)
+        assert Z.decode_stream(f, 1, which, window_log_max=28) == b"a", which
+        with pytest.raises(Z.ZstdError, match="too much memory"):
+            Z.decode_stream(ok, 1, which, window_log_max=20)

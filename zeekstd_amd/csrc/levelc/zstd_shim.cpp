@@ -38,7 +38,7 @@ typedef struct { void *dst; size_t size; size_t pos; } ZSTD_outBuffer;
 }
 
 namespace {
-constexpr size_t ZERR_GENERIC = 1, ZERR_PREFIX_UNKNOWN = 10, ZERR_FRAMEPARAM_UNSUPPORTED = 14, ZERR_PARAM_UNSUPPORTED = 40, ZERR_PARAM_OOB = 42, ZERR_STAGE_WRONG = 60,
+constexpr size_t ZERR_GENERIC = 1, ZERR_PREFIX_UNKNOWN = 10, ZERR_FRAMEPARAM_UNSUPPORTED = 14, ZERR_WINDOW_TOO_LARGE = 16, ZERR_PARAM_UNSUPPORTED = 40, ZERR_PARAM_OOB = 42, ZERR_STAGE_WRONG = 60,
                  ZERR_MEMORY = 64, ZERR_DST_TOO_SMALL = 70, ZERR_SRC_SIZE_WRONG = 72, ZERR_CORRUPTION = 20, ZERR_MAXCODE = 120;
 inline size_t zerr(size_t code) { return (size_t)0 - code; }
 inline size_t from_zk(int rc) { return rc == 0 ? 0 : zerr(rc < 0 && (size_t)(-rc) < ZERR_MAXCODE ? (size_t)(-rc) : ZERR_GENERIC); }   // Level A: -(ZSTD_ErrorCode); its own -1000.. codes -> GENERIC
@@ -74,6 +74,7 @@ struct ZSTD_DCtx_s {
     bool skippable = false, cks = false;
     uint64_t fcs = ~0ull;
     uint32_t block_max = 131072;                         // Block_Maximum_Size of the frame on hand: min(window, 128 KiB) (RFC 8878 3.1.1.2.3)
+    int wlog_max = 27;                                   // ZSTD_d_windowLogMax (default ZSTD_WINDOWLOG_LIMIT_DEFAULT): a frame may declare a window of (1 << wlog_max) + 1 at most
     const uint8_t *prefix = nullptr; size_t plen = 0;
 };
 typedef ZSTD_CCtx_s ZSTD_CCtx;
@@ -176,6 +177,7 @@ size_t ZSTD_DCtx_reset(ZSTD_DCtx *d, int directive)
 {
     if (!d) return zerr(ZERR_GENERIC);
     if (directive == 1 || directive == 3) { dctx_next_frame(d); d->prefix = nullptr; d->plen = 0; }
+    if (directive == 2 || directive == 3) d->wlog_max = 27;                  // ZSTD_reset_parameters
     return 0;
 }
 size_t ZSTD_DCtx_refPrefix(ZSTD_DCtx *d, const void *prefix, size_t len)
@@ -188,7 +190,11 @@ size_t ZSTD_DCtx_refPrefix(ZSTD_DCtx *d, const void *prefix, size_t len)
 size_t ZSTD_DCtx_setParameter(ZSTD_DCtx *d, int param, int value)
 {
     if (!d) return zerr(ZERR_GENERIC);
-    if (param == 100) return value == 0 || (value >= 10 && value <= 31) ? 0 : zerr(ZERR_PARAM_OOB);   // ZSTD_d_windowLogMax: the engine's own limits hold (ZK_MAX_PREFIX, 2^31)
+    if (param == 100) {                                                      // ZSTD_d_windowLogMax (cli/src/decompress.rs:56 raises it for patches): held against the frame header as libzstd
+        if (value != 0 && (value < 10 || value > 31)) return zerr(ZERR_PARAM_OOB);   // does -- the engine itself would take any window up to 2^31
+        d->wlog_max = value ? value : 27;
+        return 0;
+    }
     return zerr(ZERR_PARAM_UNSUPPORTED);
 }
 
@@ -230,6 +236,7 @@ static size_t frame_need(ZSTD_DCtx *d, const View &a, size_t *err)
         uint64_t window = d->fcs;
         if (!single) { const uint32_t wd = a[5], e = wd >> 3, m = wd & 7; window = (1ull << (10 + e)); window += (window >> 3) * m; }
         d->block_max = window < 131072 ? (uint32_t)window : 131072;
+        if (window > (1ull << d->wlog_max) + 1) { *err = zerr(ZERR_WINDOW_TOO_LARGE); return 0; }   // "Frame requires too much memory for decoding" (ZSTD_decompressStream: windowSize > maxWindowSize)
         d->next_hdr = hdr;
     }
     for (;;) {
