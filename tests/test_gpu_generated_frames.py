@@ -150,3 +150,20 @@ def test_generated_frames_with_more_than_0x7F00_sequences_in_a_block(engine):
     out, st = engine.decode_frames(bytes(comp) + b"\0" * 8, c, d, verify=True, raise_on_error=False)
     assert not st.any() and out == bytes(data)
 
+
+
+def test_generated_frames_behind_a_seek_table_through_the_decoder(engine):
+    """a seekable archive of foreign frames (400 generated ones + a Foot seek table): zeekstd's Decoder reads it whole, from any offset, between limits"""
+    import zeekstd_amd as zk
+    comp, frames, data = archive(range(700000, 700400))
+    st = zk.SeekTable.new()
+    for cs, ds in frames:
+        st.log_frame(cs, ds)
+    seekable = comp + st.to_bytes()
+    d = zk.DecodeOptions(seekable).engine(engine).into_decoder()
+    assert d.read_to_end() == data
+    rng = np.random.default_rng(4)
+    for _ in range(30):
+        lo = int(rng.integers(0, len(data) + 1)); hi = int(rng.integers(lo, len(data) + 1))
+        d.set_offset(lo); d.set_offset_limit(hi)
+        assert d.read_to_end() == data[lo:hi], (lo, hi)
