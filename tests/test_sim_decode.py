@@ -274,6 +274,22 @@ def test_sim_under_sanitizers_on_damaged_archives(tmp_path):
         for walk in (0, 2):
             r = subprocess.run([exe, path, str(iters if walk == 0 else iters // 10), "6", str(walk), pre], capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, (name, walk, r.stdout[-300:], r.stderr[-3000:])
+    # frames no encoder here writes (tests/helpers/zstd_gen.py: Treeless and RLE literals, RLE / Repeat sequence tables, FSE-compressed weights, every header
+    # form), damaged: the corners of the lane code that libzstd-made archives reach least
+    from helpers import zstd_gen
+    frames, comp, data = [], bytearray(), bytearray()
+    for seed in range(800000, 800040):
+        f, out, _ = zstd_gen.generate(seed, zko.xxh64)
+        frames.append((len(f), len(out))); comp += f; data += out
+    path = str(tmp_path / "generated.bin")
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<IQQ", len(frames), len(comp), len(data)))
+        for c, d in frames:
+            fh.write(struct.pack("<QQ", c, d))
+        fh.write(comp); fh.write(data)
+    for walk, iters in ((0, 500), (1, 30), (2, 30)):
+        r = subprocess.run([exe, path, str(iters), "7", str(walk)], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, ("generated", walk, r.stdout[-300:], r.stderr[-3000:])
 
 
 @pytest.mark.parametrize("quad", [False, True, 2])
