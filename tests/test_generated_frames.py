@@ -96,3 +96,40 @@ def test_generated_frames_with_more_than_0x7F00_sequences_in_a_block():
             rc, so, st = sim_decode(f, [(len(f), len(out))], quad=quad)
             assert rc == 0 and so == out, (seed, quad)
 
+
+
+@pytest.mark.parametrize("quad", [False, 2])
+def test_damaged_generated_frames_the_lane_code_against_the_oracle(quad):
+    """one to three flipped bits per hit frame, checksums not verified: the lane code refuses exactly the frames the oracle refuses and yields its
+    bytes otherwise (tests/test_gpu_generated_frames.py does this with the kernels)"""
+    import numpy as np
+    frames, comp, data = [], bytearray(), bytearray()
+    for seed in range(20000, 20400):
+        f, out, _ = zstd_gen.generate(seed, zko.xxh64)
+        frames.append((len(f), len(out))); comp += f; data += out
+    c = np.concatenate([[0], np.cumsum([f[0] for f in frames])]); d = np.concatenate([[0], np.cumsum([f[1] for f in frames])])
+    rng = np.random.default_rng(9)
+    bad = bytearray(comp)
+    hit = set()
+    for _ in range(300):
+        i = int(rng.integers(0, len(bad)))
+        bad[i] ^= 1 << int(rng.integers(0, 8))
+        hit.add(int(np.searchsorted(c, i, side="right")) - 1)
+    # checksum verification off: the simulator's checksum pass is separate (sim_decode runs the format checks only)
+    rc, out, st = sim_decode(bytes(bad), frames, quad=quad)
+    refused = 0
+    for f in range(len(frames)):
+        lo, hi = int(d[f]), int(d[f + 1])
+        if f not in hit:
+            assert st[f] == 0 and out[lo:hi] == bytes(data[lo:hi]), f
+            continue
+        try:
+            o, used = zko.frame_decode(bytes(bad[int(c[f]):int(c[f + 1])]), hi - lo + 64, False)
+            ok = len(o) == hi - lo and used == int(c[f + 1] - c[f])
+        except zko.OracleError:
+            ok = False
+        assert ok == (st[f] == 0), (f, int(st[f]), ok)
+        if ok:
+            assert out[lo:hi] == o, f
+        refused += not ok
+    assert refused > 50
