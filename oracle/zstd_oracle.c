@@ -12,6 +12,14 @@
  * 1.5.7 binary generated in the build container (tests/golden/, made by
  * tools/make_goldens.py) and against the golden bytes of SURVEY.md Appendix B.
  *
+ * Pinned further (round 5) on frames NO libzstd encoder writes: tests/helpers/zstd_gen.py
+ * draws valid frames from everything the format leaves open, the real libzstd 1.5.7 decodes
+ * them, and this decoder has to agree (tests/test_generated_frames.py).  On DAMAGED input it
+ * follows the format where libzstd's decoder is laxer -- a Huffman stream must end exactly
+ * on its first bit (RFC 8878 4.2.2), the reserved mode bits must be zero (checked by
+ * libzstd only since 1.5.6), a block regenerates at most min(Window_Size, 128 KiB):
+ * tests/test_oracle.py::test_where_the_oracle_is_stricter_than_libzstd pins those deltas.
+ *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * call into this file.  The product (zeekstd_amd/csrc) never links it.
  *

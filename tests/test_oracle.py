@@ -278,3 +278,31 @@ def test_a_third_zstd_build_decodes_the_twins_frames():
                 if len(data) == 0:
                     continue                                   # (pyarrow refuses a zero-size output buffer; the empty frame is golden bytes anyway)
                 assert codec.decompress(fr, decompressed_size=len(data)).to_pybytes() == data, (len(data), level, cks)
+
+
+def test_where_the_oracle_is_stricter_than_libzstd():
+    """The oracle restates the FORMAT; libzstd's decoder is laxer than RFC 8878 in a few places, and the engine sides with the oracle there
+    (Level C).  Pinned here so that the deltas are known ones, each on a golden with one flipped bit:
+      * a Huffman stream that does not end exactly on its first bit (RFC 8878 4.2.2 "...the decoding process is considered faulty"): libzstd's
+        fast 4-stream loops do not check, HUF_decodeLastSymbolX2 clamps the last symbol's bit count -- 1.4.8 and 1.5.7 decode (to other bytes),
+        the oracle refuses;
+      * reserved bits of the Symbol_Compression_Modes byte (3.1.1.3.2.1 "must be all zeroes"): checked by libzstd since 1.5.6, not by 1.4.8."""
+    from conftest import GOLDENS
+    g = next(x for x in GOLDENS if x.name == "text_l9")
+    bad = bytearray(g.comp); bad[12520] ^= 1                                        # inside the fourth Huffman stream of a block: five bits stay unread
+    with pytest.raises(zko.OracleError) as e:
+        zko.frame_decode(bytes(bad), g.meta["input_len"] + 64, True)
+    assert e.value.code == 20
+    for which in ("1.5.7", "system"):
+        if Z.load(which) is not None:
+            out, state = Z.decode_stream_verdict(bytes(bad), which)
+            assert state == "end" and len(out) == g.meta["input_len"] and out != g.input(), which     # decoded, to other bytes (the golden carries no checksum)
+    g = next(x for x in GOLDENS if x.name == "zeros")
+    bad = bytearray(g.comp); bad[13] ^= 1                                           # the modes byte of the frame's compressed block: a reserved bit
+    with pytest.raises(zko.OracleError) as e:
+        zko.frame_decode(bytes(bad), g.meta["input_len"] + 64, True)
+    assert e.value.code == 20
+    if Z.load("1.5.7") is not None:
+        assert Z.decode_stream_verdict(bytes(bad), "1.5.7")[1] == "Data corruption detected"
+    if Z.load("system") is not None and Z.version("system") < "1.5.6":
+        assert Z.decode_stream_verdict(bytes(bad), "system") == (g.input(), "end")
