@@ -94,7 +94,11 @@ enum {
                                    * entropy roles as two kernels */
     ZK_CHOICE_PIPE_CONTEXTS = 7,  /* host pipeline: decode contexts it rotates through (1..6; 0 = 2) */
     ZK_CHOICE_PIPE_CHUNK_MIB = 8, /* host pipeline: output MiB per chunk (0 = by total size) */
-    ZK_CHOICE_EXEC_RESIDENT = 9   /* zk_k_exec with 256-lane tiles: at most this many workgroups per CU (4 or 5; the launch asks for LDS it does not use) */
+    ZK_CHOICE_EXEC_RESIDENT = 9,  /* zk_k_exec with 256-lane tiles: at most this many workgroups per CU (4 or 5; the launch asks for LDS it does not use) */
+    ZK_CHOICE_EXEC_SEG = 10,      /* the executor in segments, several workgroups per frame (zk_k_seg_prep / zk_k_exec_seg / zk_k_exec_fill): 1 never, 2 always
+                                     (decodes without a prefix); 0 = by batch shape */
+    ZK_CHOICE_SEG_KIB = 11,       /* ... output KiB per segment (1..128; 0 = 128) */
+    ZK_CHOICE_SEG_FILL = 12       /* ... its fill pass: 1 zk_k_exec_fill<1024> (rounds through memory), 2 zk_k_exec_fill<256>, 3 zk_k_exec_fill_lds (holes in LDS); 0 by batch size */
 };
 int zk_engine_set_kernel_choice(zk_engine *e, int what, int value);
 /* Frames of the last finished device-pointer decode (zk_decode_frames_dev and its siblings, zk_decode_wait) whose Content_Checksum was

@@ -151,10 +151,13 @@ def sim_lib():
     return _SIM
 
 
-def sim_decode(comp, frames, first=0, count=None, B=16, CH=1024, prefix=None, quad=False):
+def sim_decode(comp, frames, first=0, count=None, B=16, CH=1024, prefix=None, quad=False, seg=None):
     """quad: blocks with their own FSE tables go through zk_seq_walk_quad (three lock-stepped lanes per block, the
-    device's zk_k_fse_quad) instead of the lane-per-block walk."""
+    device's zk_k_fse_quad) instead of the lane-per-block walk.
+    seg = (segment bytes, lanes of the fill pass, log2 of output bytes per hole-record slot): the executor in segments
+    (zk_k_seg_prep / zk_k_exec_seg / zk_k_exec_fill) instead of one workgroup per frame."""
     sim_lib().zk_sim_set_fse_quad(int(quad))                # 2: the small-batch kernels' walk (8-byte cells, ZkCells64)
+    sim_lib().zk_sim_set_exec_seg(*(seg if seg else (0, 64, 2)))
     c, d = offsets_from_frames(frames)
     n = len(frames)
     if count is None:

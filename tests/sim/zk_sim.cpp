@@ -33,6 +33,11 @@ static ZkQuadSim *g_quad;
 static uint32_t g_ofv[32], g_llb[36], g_mlb[53];      // the walker's baseline tables (zk_fse_quad_group builds the same in LDS)
 static int g_fse_quad = 0;
 extern "C" void zk_sim_set_fse_quad(int on) { g_fse_quad = on; }
+// segmented execution (zk_k_seg_prep / zk_k_exec_seg / zk_k_exec_fill): seg_bytes == 0 -> one workgroup per frame (zk_k_exec)
+static uint32_t g_seg_bytes = 0, g_fill_lanes = 64, g_seg_cap_shift = 2;
+static uint64_t g_seg_stats[4];                 // holes records, hole bytes, fill steps, frames that overflowed (executed again)
+extern "C" void zk_sim_set_exec_seg(uint32_t seg_bytes, uint32_t fill_lanes, uint32_t cap_shift) { g_seg_bytes = seg_bytes; g_fill_lanes = fill_lanes ? fill_lanes : 64; g_seg_cap_shift = cap_shift; }
+extern "C" void zk_sim_seg_stats(uint64_t *out, int reset) { for (int i = 0; i < 4; i++) { out[i] = g_seg_stats[i]; if (reset) g_seg_stats[i] = 0; } }
 // poison: the tables and scratch a block's lane builds and reads (on the device: LDS that holds whatever the workgroup before left
 // there) are filled with pseudo-random bytes before every block -- code that reads what it has not written shows up as a mismatch
 static uint64_t g_poison = 0;
@@ -255,94 +260,210 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
     std::vector<ZkSeq> st(RING);
     std::vector<uint32_t> srcmap(THREADS * B), slot_seq(THREADS * B / ZK_EXEC_SLOT + 1);
     std::vector<uint8_t> tile(THREADS * B);
+    // SEGMENT MODE (sg != nullptr): the bytes whose origin lies before the segment, or at a tainted byte of it, are not written
+    // (poisoned here); their runs go to the hole list, their taint bits are set once the tile is done
+    struct SegCtx { int32_t seg_lo; uint32_t seg_done; std::vector<uint32_t> *taint; std::vector<ZkHole> *holes; std::vector<uint32_t> *tiles; uint32_t cap; bool overflow; };
+    // one compressed block: bout = its first output byte, pos = that byte's place in the frame
+    auto exec_block = [&](const ZkBlock &b, const ZkFrameInfo &fi, uint8_t *out, uint64_t pos, const uint32_t rep[3], SegCtx *sg) -> uint32_t {
+        uint32_t err = ZK_OK;
+        uint8_t *bout = out + pos;
+        const ZkSeqP *sq = seqs.data() + b.seq_base;
+        const uint8_t *l = b.lit_type >= 2 ? lit.data() + b.lit_base : comp + b.src + b.lit_off;
+        const uint32_t lit_mask = b.lit_type == 1 ? 0u : 0x7fffffffu;
+        const uint32_t nseq = b.nseq, out_size = b.out_size;
+        int bad = 0;
+        auto stage = [&](uint32_t from, uint32_t to) {                          // records [from, to) -> ring, as the kernel's fetch + settle
+            for (uint32_t idx = from; idx < to; idx++) {
+                ZkSeq r;
+                if (idx < nseq) {
+                    const ZkSeq q = zk_seq_unpack(idx ? sq[idx - 1] : 0, sq[idx], idx == 0);
+                    const uint32_t off = zk_rep_resolve(q.off, rep);
+                    const uint32_t mstart = q.out_end - q.ml;
+                    if (PFX ? (off == 0 || pos + mstart + plen < off) : (off == 0 || pos + mstart < off || off > fi.window)) bad = 1;
+                    if (off >= ZK_SRC_BIAS || q.ml > q.out_end) bad = 1;
+                    r.out_end = q.out_end; r.ml = q.ml; r.off = off; r.lit_end = q.lit_end;
+                } else { r.out_end = out_size; r.ml = 0; r.off = 1; r.lit_end = b.lit_regen; }
+                st[idx & M] = r;
+            }
+        };
+        uint32_t ja = 0, ts = 0, prev_end = 0;
+        uint32_t staged_end = nseq + 1 < CAPS ? nseq + 1 : CAPS;
+        stage(0, staged_end);
+        if (bad) err = ZK_E_CORRUPTION;
+        while (err == ZK_OK && ts < out_size) {
+            const uint32_t nl = staged_end - ja;
+            const uint32_t cap_end = st[(staged_end - 1) & M].out_end;
+            const uint32_t te = ts + THREADS * B < cap_end ? ts + THREADS * B : cap_end;
+            uint32_t jn = nl;
+            std::fill(srcmap.begin(), srcmap.end(), 0u);                        // the map starts empty (run markers)
+            std::fill(slot_seq.begin(), slot_seq.end(), 0xFFFFFFFFu);
+            for (uint32_t i = 0; i < nl; i++) {                                  // "lane per sequence"
+                const uint32_t idx = ja + i;
+                const uint32_t end = st[idx & M].out_end;
+                const uint32_t start = i ? st[(idx - 1) & M].out_end : prev_end;
+                const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
+                if (lo < hi) {
+                    uint32_t s0, n;
+                    zk_exec_slot_span(ts, lo, hi, s0, n);
+                    for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = idx;
+                    zk_exec_mark_runs(st[idx & M], start, ts, te, srcmap.data());
+                }
+                if (end > te && start <= te) jn = i;
+            }
+            for (uint32_t q0 = ts; q0 < te; q0 += ZK_EXEC_SLOT) {                // "lane per slot"
+                const uint32_t nb = te - q0 < ZK_EXEC_SLOT ? te - q0 : ZK_EXEC_SLOT;
+                uint32_t sw[ZK_EXEC_SLOT];
+                uint32_t mk[ZK_EXEC_SLOT];
+                for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) mk[k] = q0 - ts + k < srcmap.size() ? srcmap[q0 - ts + k] : 0u;
+                zk_exec_slot_words_marked(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, mk, sw, M);
+                for (uint32_t k = 0; k < nb; k++) srcmap[q0 - ts + k] = sw[k];
+            }
+            const uint32_t mbase = ZK_SRC_BIAS + ts, span = te - ts;
+            if (!sg) {
+                for (uint32_t q = ts; q < te; q++) {                             // origins + gathers
+                    uint32_t s = srcmap[q - ts];
+                    while (s - mbase < span) s = srcmap[s - mbase];
+                    if (s & ZK_SRC_LIT) tile[q - ts] = l[(s & lit_mask)];
+                    else {
+                        const int64_t rel = (int64_t)pos + (int32_t)(s - ZK_SRC_BIAS);
+                        tile[q - ts] = PFX && rel < 0 ? prefix[(int64_t)plen + rel] : out[rel];
+                    }
+                }
+            } else {
+                // lane per slot again, the waves of the workgroup in REVERSE order (the order of a tile's records is whatever the waves'
+                // atomics make it: nothing may depend on it)
+                const uint32_t nslots = (span + ZK_EXEC_SLOT - 1) / ZK_EXEC_SLOT;
+                std::vector<std::pair<uint32_t, uint32_t>> taint_or;             // (segment-relative first byte, 16 hole bits): set behind the tile
+                const size_t nrec0 = sg->holes->size();
+                for (int32_t wv = (int32_t)((nslots + 63) / 64) - 1; wv >= 0; wv--)
+                    for (uint32_t sl = (uint32_t)wv * 64; sl < nslots && sl < (uint32_t)(wv + 1) * 64; sl++) {
+                        const uint32_t q0 = ts + sl * ZK_EXEC_SLOT;
+                        const uint32_t nb = te - q0 < ZK_EXEC_SLOT ? te - q0 : ZK_EXEC_SLOT;
+                        uint32_t sw[ZK_EXEC_SLOT], len[ZK_EXEC_SLOT];
+                        for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) {
+                            uint32_t s = k < nb ? srcmap[q0 - ts + k] : ZK_SRC_LIT;
+                            while (s - mbase < span) s = srcmap[s - mbase];
+                            sw[k] = s;
+                        }
+                        const std::vector<uint32_t> &tb = *sg->taint;
+                        const uint32_t hm = zk_seg_slot_holes(sw, nb, sg->seg_lo, [&](uint32_t p) { return (bool)((tb[p >> 5] >> (p & 31)) & 1u); });
+                        const uint32_t starts = zk_seg_slot_runs(sw, hm, len);
+                        for (uint32_t k = 0; k < nb; k++) {
+                            const uint32_t s = sw[k];
+                            if ((hm >> k) & 1u) tile[q0 - ts + k] = 0xEE;            // (the kernel leaves the byte alone)
+                            else if (s & ZK_SRC_LIT) tile[q0 - ts + k] = l[(s & lit_mask)];
+                            else tile[q0 - ts + k] = out[(int64_t)pos + (int32_t)(s - ZK_SRC_BIAS)];
+                            if ((starts >> k) & 1u) {
+                                if (sg->holes->size() >= sg->cap) sg->overflow = true;
+                                else sg->holes->push_back(zk_hole_pack((uint32_t)pos + q0 + k, len[k], q0 + k + ZK_SRC_BIAS - s));
+                            }
+                        }
+                        if (hm) taint_or.push_back({sg->seg_done + q0, hm});
+                    }
+                for (auto &t : taint_or)
+                    for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++)
+                        if ((t.second >> k) & 1u) { const uint32_t p = t.first + k; (*sg->taint)[p >> 5] |= 1u << (p & 31); }
+                if (sg->holes->size() > nrec0) sg->tiles->push_back((uint32_t)(sg->holes->size() - nrec0));      // the tile's count (zk_k_exec_fill: one round per tile)
+            }
+            memcpy(bout + ts, tile.data(), te - ts);                             // commit the tile after all lanes ran
+            const uint32_t next_prev_end = jn ? st[(ja + jn - 1) & M].out_end : prev_end;
+            const uint32_t fetch_end = staged_end + jn < nseq + 1 ? staged_end + jn : nseq + 1;
+            stage(staged_end, fetch_end);                                        // the retired slots take the next records
+            if (bad) { err = ZK_E_CORRUPTION; break; }
+            prev_end = next_prev_end;
+            ja += jn; staged_end = fetch_end; ts = te;
+        }
+        return err;
+    };
     int first_err = 0;
+    const bool seg_mode = g_seg_bytes != 0 && !PFX;
     for (uint32_t f = 0; f < count; f++) {
         const ZkFrameInfo fi = infos[f];
         uint32_t err = fi.status;
-        if (err == ZK_OK) {
-            const uint64_t d_size = d_off[first + f + 1] - d_off[first + f];
-            uint8_t *out = dst + (d_off[first + f] - d_off[first]);
-            const ZkBlock *fb = blocks.data() + bases[f].block_base;
+        const uint64_t d_size = d_off[first + f + 1] - d_off[first + f];
+        uint8_t *out = dst + (d_off[first + f] - d_off[first]);
+        const ZkBlock *fb = blocks.data() + bases[f].block_base;
+        const uint32_t block_max = fi.window < ZK_BLOCK_MAX ? fi.window : ZK_BLOCK_MAX;
+        bool redo = false;
+        if (err == ZK_OK && seg_mode) {
+            // ---- zk_k_seg_prep: the frame cut into segments
+            const uint32_t max_segs = 2 * (uint32_t)((d_size + g_seg_bytes - 1) / g_seg_bytes) + 1;
+            std::vector<ZkSeg> segs(max_segs);
+            ZkSegWalk w;
+            zk_seg_walk_init(w);
+            for (uint32_t bk = 0; bk < fi.n_blocks; bk++) zk_seg_step(w, bk, fb[bk].status, fb[bk].out_size, fb[bk].rep_out, d_size, block_max, g_seg_bytes, segs.data(), max_segs);
+            zk_seg_walk_end(w, d_size, segs.data(), max_segs);
+            err = w.err;
+            // ---- zk_k_exec_seg: every segment on its own (here: LAST segment first -- no segment may need another one's bytes)
+            std::vector<std::vector<ZkHole>> holes(w.nsegs);
+            std::vector<std::vector<uint32_t>> tiles(w.nsegs);
+            if (err == ZK_OK) memset(out, 0xDD, d_size);                         // whatever the buffer held: nothing may be read before it is written
+            for (int32_t j = (int32_t)w.nsegs - 1; j >= 0 && err == ZK_OK; j--) {
+                const ZkSeg &s = segs[j];
+                std::vector<uint32_t> taint((s.out >> 5) + 2, 0u);
+                SegCtx sg{0, 0, &taint, &holes[j], &tiles[j], ((s.out >> g_seg_cap_shift) + 8u), false};
+                uint64_t pos = s.pos;
+                uint32_t rep[3] = {s.rep[0], s.rep[1], s.rep[2]};
+                uint32_t serr = ZK_OK;
+                for (uint32_t bk = s.b0; bk < s.b0 + s.nb && serr == ZK_OK; bk++) {
+                    const ZkBlock &b = fb[bk];
+                    sg.seg_done = (uint32_t)(pos - s.pos); sg.seg_lo = -(int32_t)sg.seg_done;
+                    if (b.type == 0) memcpy(out + pos, comp + b.src, b.bsize);
+                    else if (b.type == 1) memset(out + pos, comp[b.src], b.bsize);
+                    else {
+                        serr = exec_block(b, fi, out, pos, rep, &sg);
+                        if (serr == ZK_OK) {
+                            uint32_t r0 = zk_rep_resolve(b.rep_out[0], rep), r1 = zk_rep_resolve(b.rep_out[1], rep), r2 = zk_rep_resolve(b.rep_out[2], rep);
+                            rep[0] = r0; rep[1] = r1; rep[2] = r2;
+                        }
+                    }
+                    pos += b.out_size;
+                }
+                if (serr != ZK_OK) err = serr;
+                else if (sg.overflow) redo = true;
+            }
+            // ---- zk_k_exec_fill: segment after segment, tile after tile; a tile's records in rounds of L lanes (every lane loads, then
+            //      every lane stores).  What makes a tile one round: no record's source overlaps a destination of the tile (checked here)
+            if (err == ZK_OK && !redo) {
+                const uint32_t L = g_fill_lanes;
+                for (uint32_t j = 0; j < w.nsegs && err == ZK_OK; j++) {
+                    const std::vector<ZkHole> &h = holes[j];
+                    g_seg_stats[0] += h.size();
+                    size_t i = 0;
+                    for (uint32_t cnt : tiles[j]) {
+                        uint32_t dmin = 0xFFFFFFFFu;
+                        for (size_t k = 0; k < cnt; k++) dmin = zk_hole_dst(h[i + k]) < dmin ? zk_hole_dst(h[i + k]) : dmin;
+                        for (size_t k = 0; k < cnt; k++) if (!zk_fill_ready(h[i + k], dmin)) err = ZK_E_GENERIC + 2000;   // a bug, not an input error
+                        // the rounds run in REVERSE order, lanes too: nothing may depend on the order inside a tile
+                        for (size_t r0 = (cnt + L - 1) / L; r0-- > 0;) {
+                            const size_t lo = r0 * L, n = cnt - lo < L ? cnt - lo : L;
+                            std::vector<uint8_t> got(n * 16);
+                            for (size_t k = 0; k < n; k++)
+                                for (uint32_t x = 0; x < zk_hole_len(h[i + lo + k]); x++) got[k * 16 + x] = out[zk_hole_dst(h[i + lo + k]) - zk_hole_off(h[i + lo + k]) + x];
+                            for (size_t k = n; k-- > 0;)
+                                for (uint32_t x = 0; x < zk_hole_len(h[i + lo + k]); x++) { out[zk_hole_dst(h[i + lo + k]) + x] = got[k * 16 + x]; g_seg_stats[1]++; }
+                        }
+                        i += cnt;
+                        g_seg_stats[2]++;
+                    }
+                    if (i != h.size()) err = ZK_E_GENERIC + 2001;
+                }
+            }
+            if (redo) g_seg_stats[3]++;
+        }
+        if (err == ZK_OK && (!seg_mode || redo)) {
             uint64_t pos = 0;
             uint32_t rep[3] = {1, 4, 8};
             for (uint32_t bk = 0; bk < fi.n_blocks && err == ZK_OK; bk++) {
                 const ZkBlock &b = fb[bk];
                 if (b.status != ZK_OK) { err = b.status; break; }
                 if (pos + b.out_size > d_size) { err = ZK_E_CORRUPTION; break; }
-                if (b.out_size > (fi.window < ZK_BLOCK_MAX ? fi.window : ZK_BLOCK_MAX)) { err = ZK_E_CORRUPTION; break; }
+                if (b.out_size > block_max) { err = ZK_E_CORRUPTION; break; }
                 uint8_t *bout = out + pos;
                 if (b.type == 0) memcpy(bout, comp + b.src, b.bsize);
                 else if (b.type == 1) memset(bout, comp[b.src], b.bsize);
                 else {
-                    const ZkSeqP *sq = seqs.data() + b.seq_base;
-                    const uint8_t *l = b.lit_type >= 2 ? lit.data() + b.lit_base : comp + b.src + b.lit_off;
-                    const uint32_t lit_mask = b.lit_type == 1 ? 0u : 0x7fffffffu;
-                    const uint32_t nseq = b.nseq, out_size = b.out_size;
-                    int bad = 0;
-                    auto stage = [&](uint32_t from, uint32_t to) {                          // records [from, to) -> ring, as the kernel's fetch + settle
-                        for (uint32_t idx = from; idx < to; idx++) {
-                            ZkSeq r;
-                            if (idx < nseq) {
-                                const ZkSeq q = zk_seq_unpack(idx ? sq[idx - 1] : 0, sq[idx], idx == 0);
-                                const uint32_t off = zk_rep_resolve(q.off, rep);
-                                const uint32_t mstart = q.out_end - q.ml;
-                                if (PFX ? (off == 0 || pos + mstart + plen < off) : (off == 0 || pos + mstart < off || off > fi.window)) bad = 1;
-                                if (off >= ZK_SRC_BIAS || q.ml > q.out_end) bad = 1;
-                                r.out_end = q.out_end; r.ml = q.ml; r.off = off; r.lit_end = q.lit_end;
-                            } else { r.out_end = out_size; r.ml = 0; r.off = 1; r.lit_end = b.lit_regen; }
-                            st[idx & M] = r;
-                        }
-                    };
-                    uint32_t ja = 0, ts = 0, prev_end = 0;
-                    uint32_t staged_end = nseq + 1 < CAPS ? nseq + 1 : CAPS;
-                    stage(0, staged_end);
-                    if (bad) err = ZK_E_CORRUPTION;
-                    while (err == ZK_OK && ts < out_size) {
-                        const uint32_t nl = staged_end - ja;
-                        const uint32_t cap_end = st[(staged_end - 1) & M].out_end;
-                        const uint32_t te = ts + THREADS * B < cap_end ? ts + THREADS * B : cap_end;
-                        uint32_t jn = nl;
-                        std::fill(srcmap.begin(), srcmap.end(), 0u);                        // the map starts empty (run markers)
-                        std::fill(slot_seq.begin(), slot_seq.end(), 0xFFFFFFFFu);
-                        for (uint32_t i = 0; i < nl; i++) {                                  // "lane per sequence"
-                            const uint32_t idx = ja + i;
-                            const uint32_t end = st[idx & M].out_end;
-                            const uint32_t start = i ? st[(idx - 1) & M].out_end : prev_end;
-                            const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
-                            if (lo < hi) {
-                                uint32_t s0, n;
-                                zk_exec_slot_span(ts, lo, hi, s0, n);
-                                for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = idx;
-                                zk_exec_mark_runs(st[idx & M], start, ts, te, srcmap.data());
-                            }
-                            if (end > te && start <= te) jn = i;
-                        }
-                        for (uint32_t q0 = ts; q0 < te; q0 += ZK_EXEC_SLOT) {                // "lane per slot"
-                            const uint32_t nb = te - q0 < ZK_EXEC_SLOT ? te - q0 : ZK_EXEC_SLOT;
-                            uint32_t sw[ZK_EXEC_SLOT];
-                            uint32_t mk[ZK_EXEC_SLOT];
-                            for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) mk[k] = q0 - ts + k < srcmap.size() ? srcmap[q0 - ts + k] : 0u;
-                            zk_exec_slot_words_marked(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, mk, sw, M);
-                            for (uint32_t k = 0; k < nb; k++) srcmap[q0 - ts + k] = sw[k];
-                        }
-                        const uint32_t mbase = ZK_SRC_BIAS + ts, span = te - ts;
-                        for (uint32_t q = ts; q < te; q++) {                                 // origins + gathers
-                            uint32_t s = srcmap[q - ts];
-                            while (s - mbase < span) s = srcmap[s - mbase];
-                            if (s & ZK_SRC_LIT) tile[q - ts] = l[(s & lit_mask)];
-                            else {
-                                const int64_t rel = (int64_t)pos + (int32_t)(s - ZK_SRC_BIAS);
-                                tile[q - ts] = PFX && rel < 0 ? prefix[(int64_t)plen + rel] : out[rel];
-                            }
-                        }
-                        memcpy(bout + ts, tile.data(), te - ts);                             // commit the tile after all lanes ran
-                        const uint32_t next_prev_end = jn ? st[(ja + jn - 1) & M].out_end : prev_end;
-                        const uint32_t fetch_end = staged_end + jn < nseq + 1 ? staged_end + jn : nseq + 1;
-                        stage(staged_end, fetch_end);                                        // the retired slots take the next records
-                        if (bad) { err = ZK_E_CORRUPTION; break; }
-                        prev_end = next_prev_end;
-                        ja += jn; staged_end = fetch_end; ts = te;
-                    }
+                    err = exec_block(b, fi, out, pos, rep, nullptr);
                     if (err == ZK_OK) {
                         uint32_t r0 = zk_rep_resolve(b.rep_out[0], rep), r1 = zk_rep_resolve(b.rep_out[1], rep), r2 = zk_rep_resolve(b.rep_out[2], rep);
                         rep[0] = r0; rep[1] = r1; rep[2] = r2;

@@ -40,6 +40,16 @@ def test_generated_frames_through_the_lane_code(quad):
         assert rc == 0 and o == out, (seed, rc, sorted(feats))
 
 
+def test_generated_frames_through_the_executor_in_segments():
+    """several "workgroups" per frame (zk_k_seg_prep / zk_k_exec_seg / zk_k_exec_fill): segments of one block or a few, of a few hundred
+    bytes (a segment per block: every offset across a block's first byte is a hole), fill rounds of 3 ... 1024 lanes"""
+    for seed in range(600):
+        f, out, feats = zstd_gen.generate(seed, zko.xxh64)
+        seg = ((131072, 64, 2), (1 + seed % 5000, 3 + seed % 200, 2), (65536, 1024, 1))[seed % 3]
+        rc, o, st = sim_decode(f, [(len(f), len(out))], seg=seg)
+        assert rc == 0 and o == out, (seed, rc, seg, sorted(feats))
+
+
 def test_generated_frames_side_by_side_in_one_archive():
     """many of them in one call: the block records of different frames sit side by side, Repeat / Treeless reach back inside their own frame only"""
     frames, comp, data = [], bytearray(), bytearray()
@@ -63,6 +73,12 @@ def test_generated_frames_with_long_blocks():
         for quad in (False, True, 2):
             rc, so, st = sim_decode(f, [(len(f), len(out))], quad=quad)
             assert rc == 0 and so == out, (seed, quad)
+        rc, so, st = sim_decode(f, [(len(f), len(out))], seg=(131072, 256, 1))
+        assert rc == 0 and so == out, seed
+        # the executor in segments (several workgroups per frame): segments of 128 KiB and of a few hundred bytes
+        for seg in ((131072, 64, 2), (700 + seed % 3000, 16, 2)):
+            rc, so, st = sim_decode(f, [(len(f), len(out))], seg=seg)
+            assert rc == 0 and so == out, (seed, seg)
 
 
 def test_generated_frames_against_a_prefix():

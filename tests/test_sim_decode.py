@@ -309,3 +309,68 @@ def test_sim_block_regenerates_more_than_the_window_allows(quad):
     rc, out, st = sim_decode(bytes(f), [(len(f), len(data))], quad=quad)
     assert rc == -20 and st[0] == 20
 
+
+
+# ---- the executor in segments (zk_k_seg_prep / zk_k_exec_seg / zk_k_exec_fill): the same lane code, several "workgroups" per frame ------
+# seg = (segment bytes, lanes of a fill round, log2 of output bytes per hole-record slot).  The simulation runs a frame's segments LAST
+# first over a poisoned output buffer (no segment may need another one's bytes), a tile's waves in reverse order (the order of a tile's
+# records is whatever the waves' atomics make it), the fill rounds and their lanes in reverse too, and checks that no record of a tile
+# reads what another record of the tile writes.
+SEGS = [(131072, 64, 2), (4096, 7, 2), (300, 1024, 2), (65536, 256, 1)]
+
+
+@pytest.mark.parametrize("seg", SEGS, ids=[f"seg{s[0]}_L{s[1]}" for s in SEGS])
+def test_sim_goldens_in_segments(golden, seg):
+    rc, out, st = sim_decode(golden.comp, golden.frames, seg=seg)
+    assert rc == 0 and not st.any()
+    assert out == golden.input()
+
+
+def test_sim_segments_that_overflow_are_executed_again(golden):
+    """A region of one record slot per 2^20 bytes: every segment with a hole overflows, the frame goes through the frame executor."""
+    from conftest import sim_lib
+    import ctypes as C
+    a = (C.c_uint64 * 4)()
+    sim_lib().zk_sim_seg_stats(a, 1)
+    rc, out, st = sim_decode(golden.comp, golden.frames, seg=(131072, 64, 20))
+    assert rc == 0 and not st.any() and out == golden.input()
+    sim_lib().zk_sim_seg_stats(a, 1)
+    assert a[0] == 0 or a[3] > 0                       # records were only copied where nothing overflowed
+
+
+@pytest.mark.skipif(Z.load("system") is None, reason="no system libzstd")
+@pytest.mark.parametrize("level", [1, 3, 19])
+def test_sim_segments_vs_live_libzstd(level):
+    """2 MiB frames of 128 KiB blocks: at level 1 two fifths of a segment's bytes are holes (their origin lies before the segment), at
+    level 3 nearly nine tenths."""
+    from conftest import sim_lib
+    import ctypes as C
+    data = zko.make_input([["text", 700000, 170 + level], ["rep", "00", 200000], ["random", 20000, 6], ["text", 400000, 171]])
+    a = (C.c_uint64 * 4)()
+    for fs in (2 << 20, 300000):
+        comp, frames = Z.encode_seekable_frames(data, fs, level, True, "system")
+        sim_lib().zk_sim_seg_stats(a, 1)
+        rc, out, st = sim_decode(comp, frames, seg=(131072, 256, 2))
+        assert rc == 0 and out == data
+        sim_lib().zk_sim_seg_stats(a, 1)
+        assert a[0] > 0 and a[3] == 0                  # holes were left and filled; nothing had to be executed again
+
+
+def test_sim_segments_match_the_frame_executor_on_corrupt_input():
+    from conftest import GOLDENS
+    rng = np.random.default_rng(29)
+    for name in ("text_l1_64k", "mixed_l19", "text_l3", "mixed"):
+        g = next((x for x in GOLDENS if x.name == name), None)
+        if g is None:
+            continue
+        _, d = g.offsets()
+        for _ in range(40):
+            comp = bytearray(g.comp)
+            comp[int(rng.integers(0, len(comp)))] ^= 1 << int(rng.integers(0, 8))
+            rc1, out1, st1 = sim_decode(bytes(comp), g.frames)
+            for seg in ((131072, 64, 2), (2048, 16, 2)):
+                rc2, out2, st2 = sim_decode(bytes(comp), g.frames, seg=seg)
+                assert [bool(x) for x in st1] == [bool(x) for x in st2]
+                for f in range(len(g.frames)):
+                    if st1[f] == 0:
+                        assert out1[int(d[f]):int(d[f + 1])] == out2[int(d[f]):int(d[f + 1])]

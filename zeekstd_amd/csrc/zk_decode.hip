@@ -68,12 +68,23 @@ __global__ __launch_bounds__(64) void zk_k_walk(const uint8_t *comp, uint64_t co
 __global__ __launch_bounds__(1024) void zk_k_scan(const ZkFrameInfo *infos, uint32_t count, ZkFrameBase *bases, uint64_t *totals, const uint64_t *d_off, uint32_t first, const uint64_t *out_off)
 {
     // [5]: output bytes of the batch (what the frames claim): the host sizes nothing from it, it only tells dense sequence streams from sparse ones
+    // [7]: the largest frame (what it claims to decode to): how many segments a frame can have (zk_k_exec_seg's grid)
     if (threadIdx.x == 0) totals[5] = out_off ? out_off[count] : d_off ? d_off[first + count] - d_off[first] : 0;
     __shared__ uint64_t wsum[16][4];
     __shared__ uint64_t carry[4];
+    __shared__ unsigned long long s_maxd;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 4) carry[tid] = 0;
+    if (tid == 0) s_maxd = 0;
     __syncthreads();
+    {
+        unsigned long long mx = 0;
+        for (uint32_t f = tid; f < count; f += 1024) {
+            const unsigned long long dsz = out_off ? out_off[f + 1] - out_off[f] : d_off ? d_off[first + f + 1] - d_off[first + f] : 0;
+            mx = dsz > mx ? dsz : mx;
+        }
+        if (mx) atomicMax(&s_maxd, mx);
+    }
     for (uint32_t base = 0; base < count; base += 1024) {
         uint32_t f = base + tid;
         uint64_t v[4] = {0, 0, 0, 0};
@@ -103,6 +114,7 @@ __global__ __launch_bounds__(1024) void zk_k_scan(const ZkFrameInfo *infos, uint
     }
     if (tid < 3) totals[tid] = carry[tid];
     if (tid == 3) totals[4] = carry[3];
+    if (tid == 4) totals[7] = s_maxd;
 }
 
 // ------------------------------------------------------------------------------------------------ Huffman literals
@@ -823,7 +835,8 @@ __device__ __forceinline__ void zk_publish(uint64_t *word, uint32_t bytes, uint6
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(word, flags | ((uint64_t)(zk_xcc_id() + 1) << 32) | bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <int T, bool PFX, int CAPX = 2>
+// REDO: only the frames zk_k_exec_seg gave up on (ZK_E_SEG_OVERFLOW: more hole records than their region holds) are executed, from scratch
+template <int T, bool PFX, int CAPX = 2, bool REDO = false>
 __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
                                                const uint32_t *ids, const uint64_t *out_off,
                                                const ZkBlock *blocks, const ZkFrameBase *bases,
@@ -848,7 +861,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
     ZkFrameInfo fi = infos[f];
     fi.status = zk_uni(fi.status); fi.n_blocks = zk_uni(fi.n_blocks); fi.window = zk_uni(fi.window);
-    if (fi.status != ZK_OK) {
+    if (REDO ? fi.status != ZK_E_SEG_OVERFLOW : fi.status != ZK_OK) {
         if (progress && tid == 0) zk_publish(progress + f, 0, ZK_PROG_ABORT);
         return;
     }
@@ -1077,7 +1090,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
         }
     }
     if (err == ZK_OK && pos != d_size) err = ZK_E_CORRUPTION;
-    if (tid == 0 && err != ZK_OK) infos[f].status = err;
+    if (tid == 0 && (err != ZK_OK || REDO)) infos[f].status = err;
     if (progress && tid == 0) {                              // (a frame that ends well: behind the last block's barrier)
         if (err == ZK_OK) zk_publish(progress + f, (uint32_t)d_size);
         else zk_publish(progress + f, 0, ZK_PROG_ABORT);
@@ -1086,6 +1099,507 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
     ZK_CLK(0);
     if ((tid & 63) == 0) for (int i = 0; i < 8; i++) atomicAdd(&zk_dbg_clk[i], clk_[i]);
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------ sequence execution in segments
+// (zk_device.h, "sequence execution in SEGMENTS", has the scheme.)  Three kernels behind the entropy stage:
+//   zk_k_seg_prep   one wave per frame: the frame's blocks cut into segments (each block's first byte and repeat offsets are a
+//                   serial walk over ~16-64 block descriptors), the frame-level checks of zk_k_exec;
+//   zk_k_exec_seg   one workgroup per SEGMENT: zk_k_exec's tile loop; bytes that depend on anything before the segment are left
+//                   as hole records (per tile: how many), everything else is final;
+//   zk_k_exec_fill  one workgroup per frame: the hole records tile by tile (a tile's holes copy from before the tile: independent).
+// A segment whose records do not fit its region marks its frame ZK_E_SEG_OVERFLOW; zk_k_exec<REDO> executes those frames again.
+__global__ __launch_bounds__(64) void zk_k_seg_prep(const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const uint64_t *d_off, uint32_t first,
+                                                    const uint32_t *ids, uint32_t seg_bytes, ZkSeg *segs, uint32_t *nsegs, uint32_t max_segs)
+{
+    const uint32_t f = blockIdx.x, lane = threadIdx.x;
+    const ZkFrameInfo fi = infos[f];
+    if (fi.status != ZK_OK) { if (lane == 0) nsegs[f] = 0; return; }
+    const uint32_t id = ids ? ids[f] : first + f;
+    const uint64_t d_size = d_off[id + 1] - d_off[id];
+    const uint32_t block_max = fi.window < ZK_BLOCK_MAX ? fi.window : ZK_BLOCK_MAX;
+    const ZkBlock *fb = blocks + bases[f].block_base;
+    ZkSeg *fs = segs + (size_t)f * max_segs;
+    ZkSegWalk w;
+    zk_seg_walk_init(w);
+    for (uint32_t base = 0; base < fi.n_blocks; base += 64) {
+        const uint32_t bk = base + lane;
+        uint32_t st = 0, out = 0, r0 = 0, r1 = 0, r2 = 0;
+        if (bk < fi.n_blocks) { const ZkBlock &b = fb[bk]; st = b.status; out = b.out_size; r0 = b.rep_out[0]; r1 = b.rep_out[1]; r2 = b.rep_out[2]; }
+        const uint32_t n = fi.n_blocks - base < 64u ? fi.n_blocks - base : 64u;
+        for (uint32_t i = 0; i < n; i++) {                   // every lane runs the same walk (the values come out of lane i's registers); all write the same records
+            const uint32_t rp[3] = {(uint32_t)__shfl(r0, (int)i, 64), (uint32_t)__shfl(r1, (int)i, 64), (uint32_t)__shfl(r2, (int)i, 64)};
+            zk_seg_step(w, base + i, (uint32_t)__shfl(st, (int)i, 64), (uint32_t)__shfl(out, (int)i, 64), rp, d_size, block_max, seg_bytes, fs, max_segs);
+        }
+    }
+    zk_seg_walk_end(w, d_size, fs, max_segs);
+    if (lane == 0) {
+        nsegs[f] = w.err == ZK_OK ? w.nsegs : 0u;
+        if (w.err != ZK_OK) infos[f].status = w.err;
+    }
+}
+
+// where a segment's tile counts live (u32 entries) and how many it may leave: at most one per 4 KiB of output plus one per 512
+// sequences... bounded by out / 1024 + 2 per block (a tile ends early only when its ring of >= 512 records covers less than the tile)
+__device__ __forceinline__ uint64_t zk_seg_tile_region(uint64_t frame_off, uint32_t pos, uint64_t first_block, uint64_t seg_no) { return ((frame_off + pos) >> 10) + 2u * first_block + seg_no * 8u; }
+__device__ __forceinline__ uint32_t zk_seg_tile_cap(uint32_t out, uint32_t nb) { return (out >> 10) + 2u * nb + 8u; }
+
+template <int T, int CAPX>
+__global__ __launch_bounds__(T) void zk_k_exec_seg(const uint8_t *comp, const uint64_t *d_off, uint32_t first, const uint32_t *ids, const uint64_t *out_off,
+                                                   const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeqP *seqs,
+                                                   const uint8_t *lit_scratch, uint8_t *dst, const ZkSeg *segs, const uint32_t *nsegs, uint32_t max_segs,
+                                                   ZkHole *holes, uint32_t *tilecnt, uint32_t *segn)
+{
+    constexpr int CAP = CAPX * T;
+    constexpr uint32_t M = CAP - 1;
+    constexpr int NPF = CAP / T;
+    __shared__ __attribute__((aligned(16))) ZkSeq S[CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t srcmap[T * ZK_EXEC_B];
+    __shared__ __attribute__((aligned(16))) uint32_t taint[ZK_SEG_BYTES / 32 + 4];      // one bit per byte of the segment: the byte is a hole
+    __shared__ uint32_t slot_seq[T];
+    __shared__ uint32_t longlist[CAP + 1];
+    __shared__ uint32_t s_jn, s_nlong, s_nrec;
+    __shared__ uint32_t s_bad[2];
+    const uint32_t f = blockIdx.x, sgi = blockIdx.y, tid = threadIdx.x;
+    ZkFrameInfo fi = infos[f];
+    fi.status = zk_uni(fi.status); fi.window = zk_uni(fi.window);
+    if (fi.status != ZK_OK) return;                          // (refused by the walk or by zk_k_seg_prep; or another segment has just found an error)
+    if (sgi >= zk_uni(nsegs[f])) return;
+    const uint64_t seg_no = (uint64_t)f * max_segs + sgi;
+    const ZkSeg &sg = segs[seg_no];
+    const uint32_t seg_pos = zk_uni(sg.pos), seg_out = zk_uni(sg.out), seg_nb = zk_uni(sg.nb), seg_b0 = zk_uni(sg.b0);
+    const uint32_t id = zk_uni(ids ? ids[f] : first + f);
+    const uint64_t frame_off = zk_uni(out_off ? out_off[f] : d_off[id] - d_off[first]);
+    uint8_t *out = zk_uni(dst + frame_off);
+    const uint64_t block_base = zk_uni(bases[f].block_base);
+    const ZkBlock *fb = zk_uni(blocks + block_base + seg_b0);
+    ZkHole *rec = zk_uni(holes + zk_seg_region(frame_off, seg_pos, seg_no));
+    const uint32_t rec_cap = zk_seg_region_cap(seg_out);
+    uint32_t *tc = zk_uni(tilecnt + zk_seg_tile_region(frame_off, seg_pos, block_base + seg_b0, seg_no));
+    const uint32_t tc_cap = zk_seg_tile_cap(seg_out, seg_nb);
+    uint32_t nrec = 0, ntile = 0;                            // records / tile counts left so far (uniform)
+    bool overflow = false;
+    for (uint32_t i = tid; i < (seg_out >> 5) + 2u; i += T) taint[i] = 0;
+    uint64_t pos = seg_pos;
+    uint32_t rep[3] = {zk_uni(sg.rep[0]), zk_uni(sg.rep[1]), zk_uni(sg.rep[2])};
+    uint32_t err = ZK_OK;
+    __syncthreads();
+
+    for (uint32_t bk = 0; bk < seg_nb && err == ZK_OK; bk++) {
+        const ZkBlock &b = fb[bk];
+        const uint32_t b_out_size = zk_uni(b.out_size), b_type = zk_uni((uint32_t)b.type);      // (status and sizes: zk_k_seg_prep has checked them)
+        uint8_t *bout = out + pos;
+        const uint32_t seg_done = (uint32_t)(pos - seg_pos);  // bytes of the segment in front of this block
+        if (b_type <= 1) {
+            const uint8_t *s = comp + zk_uni(b.src);
+            const uint32_t n = zk_uni(b.bsize);
+            const uint32_t head0 = (uint32_t)((0 - (uintptr_t)bout) & 15), head = head0 < n ? head0 : n;
+            const uint32_t n16 = (n - head) >> 4;
+            if (b_type == 0) {
+                if (tid < head) bout[tid] = s[tid];
+                for (uint32_t i = tid; i < n16; i += T) {
+                    uint4 v;
+                    __builtin_memcpy(&v, s + head + (i << 4), 16);
+                    *reinterpret_cast<uint4 *>(bout + head + (i << 4)) = v;
+                }
+                for (uint32_t i = head + (n16 << 4) + tid; i < n; i += T) bout[i] = s[i];
+            } else {
+                const uint32_t v1 = s[0], v4 = v1 * 0x01010101u;
+                if (tid < head) bout[tid] = (uint8_t)v1;
+                for (uint32_t i = tid; i < n16; i += T) *reinterpret_cast<uint4 *>(bout + head + (i << 4)) = make_uint4(v4, v4, v4, v4);
+                for (uint32_t i = head + (n16 << 4) + tid; i < n; i += T) bout[i] = (uint8_t)v1;
+            }
+        } else {
+            const ZkSeqP *sq = seqs + zk_uni(b.seq_base);
+            const uint32_t b_lit_type = zk_uni((uint32_t)b.lit_type);
+            const uint8_t *lit = b_lit_type >= 2 ? lit_scratch + zk_uni(b.lit_base) : comp + zk_uni(b.src) + zk_uni(b.lit_off);
+            const uint32_t lit_mask = b_lit_type == 1 ? 0u : 0x7fffffffu;
+            const uint32_t nseq = zk_uni(b.nseq), out_size = b_out_size, lit_regen = zk_uni(b.lit_regen);
+            const int32_t seg_lo = -(int32_t)seg_done;       // block-relative position of the segment's first byte
+            auto fetch = [&](uint32_t idx, ZkSeqP &p0, ZkSeqP &p1) {
+                p1 = idx < nseq ? sq[idx] : 0;
+                p0 = idx && idx < nseq ? sq[idx - 1] : 0;
+            };
+            auto settle = [&](uint32_t idx, ZkSeqP p0, ZkSeqP p1, int &bad) {
+                uint4 r;
+                if (idx < nseq) {
+                    const ZkSeq q = zk_seq_unpack(p0, p1, idx == 0);
+                    const uint32_t off = zk_rep_resolve(q.off, rep);
+                    const uint32_t mstart = q.out_end - q.ml;
+                    if (off == 0 || pos + mstart < off || off > fi.window) bad = 1;
+                    if (off >= ZK_SRC_BIAS || q.ml > q.out_end) bad = 1;
+                    r = make_uint4(q.out_end, q.ml, off, q.lit_end);
+                } else r = make_uint4(out_size, 0, 1, lit_regen);
+                reinterpret_cast<uint4 *>(S)[idx & M] = r;
+            };
+            int bad = 0;
+            uint32_t ja = 0, ts = 0, prev_end = 0;
+            uint32_t staged_end = nseq + 1 < (uint32_t)CAP ? nseq + 1 : (uint32_t)CAP;
+            for (uint32_t idx = tid; idx < staged_end; idx += T) { ZkSeqP p0, p1; fetch(idx, p0, p1); settle(idx, p0, p1, bad); }
+            if (tid == 0) { s_jn = staged_end; s_nlong = 0; s_bad[0] = 0; s_bad[1] = 0; s_nrec = 0; }
+            if (__syncthreads_or(bad)) { err = ZK_E_CORRUPTION; }
+            uint32_t tpar = 0;
+            while (err == ZK_OK && ts < out_size) {
+                const uint32_t nl = staged_end - ja;
+                const uint32_t cap_end = zk_uni(S[(staged_end - 1) & M].out_end);
+                const uint32_t te = ts + T * ZK_EXEC_B < cap_end ? ts + T * ZK_EXEC_B : cap_end;
+#pragma unroll
+                for (int k = 0; k < ZK_EXEC_B; k += 4) *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(0, 0, 0, 0);
+                ZK_LDS_BARRIER();
+                if (tid == 0) { s_bad[tpar ^ 1] = 0; s_nrec = 0; }                // (the tile before: every wave has read both in front of this barrier)
+                for (uint32_t i = tid; i < nl; i += T) {
+                    const uint32_t idx = ja + i;
+                    const ZkSeq me = S[idx & M];
+                    const uint32_t end = me.out_end;
+                    const uint32_t start = i ? S[(idx - 1) & M].out_end : prev_end;
+                    const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
+                    if (lo < hi) {
+                        uint32_t s0, n;
+                        zk_exec_slot_span(ts, lo, hi, s0, n);
+                        if (n > ZK_EXEC_LONG) longlist[atomicAdd(&s_nlong, 1u)] = idx;
+                        else for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = idx;
+                        zk_exec_mark_runs(me, start, ts, te, srcmap);
+                    }
+                    if (end > te && start <= te) s_jn = i;
+                }
+                ZK_LDS_BARRIER();
+                const uint32_t nlong = zk_uni(s_nlong), jn = zk_uni(s_jn);
+                const uint32_t fetch_end = staged_end + jn < nseq + 1 ? staged_end + jn : nseq + 1;
+                ZkSeqP pf0[NPF], pf1[NPF];
+#pragma unroll
+                for (int u = 0; u < NPF; u++) {
+                    const uint32_t idx = staged_end + tid + (uint32_t)u * T;
+                    pf0[u] = 0; pf1[u] = 0;
+                    if (idx < fetch_end) fetch(idx, pf0[u], pf1[u]);
+                }
+                const uint32_t next_prev_end = jn ? zk_uni(S[(ja + jn - 1) & M].out_end) : prev_end;
+                for (uint32_t k = 0; k < nlong; k++) {
+                    const uint32_t idx = longlist[k];
+                    const uint32_t end = S[idx & M].out_end;
+                    const uint32_t start = idx != ja ? S[(idx - 1) & M].out_end : prev_end;
+                    const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
+                    uint32_t s0, n;
+                    zk_exec_slot_span(ts, lo, hi, s0, n);
+                    for (uint32_t j = tid; j < n; j += T) slot_seq[s0 + j] = idx;
+                }
+                if (nlong) ZK_LDS_BARRIER();
+                const uint32_t q0 = ts + tid * ZK_EXEC_B;
+                const uint32_t nb = q0 >= te ? 0u : te - q0 < (uint32_t)ZK_EXEC_B ? te - q0 : (uint32_t)ZK_EXEC_B;
+                uint32_t sw[ZK_EXEC_B];
+                if (nb) {
+                    {
+                        uint32_t mk[ZK_EXEC_B];
+#pragma unroll
+                        for (int k = 0; k < ZK_EXEC_B; k += 4) {
+                            const uint4 v = *reinterpret_cast<const uint4 *>(&srcmap[tid * ZK_EXEC_B + k]);
+                            mk[k] = v.x; mk[k + 1] = v.y; mk[k + 2] = v.z; mk[k + 3] = v.w;
+                        }
+                        zk_exec_slot_words_marked(S, slot_seq[tid], q0, nb, mk, sw, M);
+                    }
+#pragma unroll
+                    for (int k = 0; k < ZK_EXEC_B; k += 4)
+                        *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(sw[k], sw[k + 1], sw[k + 2], sw[k + 3]);
+                }
+                __syncthreads();                                                 // the full one: every wave's stores of the tile before are in memory
+                if (tid == 0) { s_jn = fetch_end - (ja + jn); s_nlong = 0; }
+#pragma unroll
+                for (int u = 0; u < NPF; u++) {
+                    const uint32_t idx = staged_end + tid + (uint32_t)u * T;
+                    if (idx < fetch_end) settle(idx, pf0[u], pf1[u], bad);
+                }
+                // 4. origins, then: which bytes are holes (their origin lies before the segment, or at a hole of an earlier tile), gathers for
+                //    the others, one coalesced store (a hole's byte of the store is whatever: zk_k_exec_fill writes it), the holes' runs as records
+                uint32_t hm = 0, starts = 0, len[ZK_EXEC_B];
+                if (nb) {
+                    const uint32_t mbase = ZK_SRC_BIAS + ts, span = te - ts;
+                    bool again;
+                    do {
+                        again = false;
+#pragma unroll
+                        for (int k = 0; k < ZK_EXEC_B; k++) {
+                            const uint32_t d = sw[k] - mbase;
+                            if (d < span) { sw[k] = srcmap[d]; again = true; }
+                        }
+                    } while (again);
+                    hm = zk_seg_slot_holes(sw, nb, seg_lo, [&](uint32_t p) { return (bool)((taint[p >> 5] >> (p & 31u)) & 1u); });
+                    starts = zk_seg_slot_runs(sw, hm, len);
+                    uint32_t ob[ZK_EXEC_B];
+#pragma unroll
+                    for (int k = 0; k < ZK_EXEC_B; k++) {
+                        const uint32_t s = sw[k];
+                        const uint8_t *a = (s & ZK_SRC_LIT) ? lit + (s & lit_mask) : bout + (int64_t)(int32_t)(s - ZK_SRC_BIAS);
+                        if ((uint32_t)k >= nb || ((hm >> k) & 1u)) a = bout;       // harmless address: bytes past the tile end, holes
+                        ob[k] = *a;
+                    }
+                    uint8_t *w = bout + q0;
+                    if (nb == ZK_EXEC_B && (((uintptr_t)w) & 15) == 0) {
+                        uint4 v;
+                        v.x = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+                        v.y = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+                        v.z = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+                        v.w = ob[12] | (ob[13] << 8) | (ob[14] << 16) | (ob[15] << 24);
+                        *reinterpret_cast<uint4 *>(w) = v;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < ZK_EXEC_B; k++) if ((uint32_t)k < nb) w[k] = (uint8_t)ob[k];
+                    }
+                    if (hm) {                                                    // the slot's taint bits (readers: later tiles, behind this tile's last barrier)
+                        const uint32_t p0 = seg_done + q0, sh = p0 & 31u;
+                        atomicOr(&taint[p0 >> 5], hm << sh);
+                        if (sh > 16u) atomicOr(&taint[(p0 >> 5) + 1u], hm >> (32u - sh));
+                    }
+                }
+                // the tile's records: a wave reserves its lanes' records with ONE LDS atomic (the order of a tile's records is whatever the
+                // waves make it: zk_k_exec_fill copies a tile's records in any order)
+                {
+                    const uint32_t cnt = (uint32_t)__popc(starts);
+                    uint32_t inc = cnt;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d, 64); if ((int)(tid & 63) >= d) inc += y; }
+                    const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                    if (wtot) {
+                        uint32_t wbase = 0;
+                        if ((tid & 63) == 0) wbase = atomicAdd(&s_nrec, wtot);
+                        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+                        uint32_t at = nrec + wbase + inc - cnt;
+                        const uint32_t dpos = (uint32_t)pos + q0;                  // frame-relative position of the slot's first byte
+#pragma unroll
+                        for (int k = 0; k < ZK_EXEC_B; k++)
+                            if ((starts >> k) & 1u) {
+                                if (at < rec_cap) rec[at] = zk_hole_pack(dpos + (uint32_t)k, len[k], q0 + (uint32_t)k + ZK_SRC_BIAS - sw[k]);
+                                at++;
+                            }
+                    }
+                }
+                prev_end = next_prev_end;
+                ja += jn; staged_end = fetch_end; ts = te;
+                if (bad) s_bad[tpar] = 1;
+                ZK_LDS_BARRIER();
+                if (s_bad[tpar]) { err = ZK_E_CORRUPTION; break; }
+                {
+                    const uint32_t tn = zk_uni(s_nrec);
+                    if (tn) {
+                        if (nrec + tn > rec_cap || ntile >= tc_cap) overflow = true;
+                        else if (tid == 0) tc[ntile] = tn;
+                        nrec += tn; ntile++;
+                    }
+                }
+                tpar ^= 1;
+            }
+            if (err == ZK_OK) {
+                uint32_t r0 = zk_rep_resolve(zk_uni(b.rep_out[0]), rep), r1 = zk_rep_resolve(zk_uni(b.rep_out[1]), rep), r2 = zk_rep_resolve(zk_uni(b.rep_out[2]), rep);
+                rep[0] = r0; rep[1] = r1; rep[2] = r2;
+            }
+        }
+        pos += b_out_size;
+        __syncthreads();                      // block bytes visible before the next block reads history
+    }
+    if (tid == 0) {
+        segn[seg_no] = overflow ? 0u : ntile;
+        if (err != ZK_OK) atomicCAS(&infos[f].status, (uint32_t)ZK_OK, err);
+        else if (overflow) atomicCAS(&infos[f].status, (uint32_t)ZK_OK, ZK_E_SEG_OVERFLOW);
+    }
+}
+
+// pass 2: one workgroup of L lanes per frame.  Segment after segment, tile after tile: a tile's records are independent of each other
+// (their sources lie before the tile) -- one round of loads, one of stores, and the stores are waited out before the next tile reads.
+template <int L>
+__global__ __launch_bounds__(L) void zk_k_exec_fill(const uint64_t *d_off, uint32_t first, const uint32_t *ids, const uint64_t *out_off, const ZkFrameBase *bases,
+                                                    const ZkFrameInfo *infos, uint8_t *dst, const ZkSeg *segs, const uint32_t *nsegs, uint32_t max_segs,
+                                                    const ZkHole *holes, const uint32_t *tilecnt, const uint32_t *segn, uint64_t *progress)
+{
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    if (zk_uni(infos[f].status) != ZK_OK) {
+        if (progress && tid == 0) zk_publish(progress + f, 0, ZK_PROG_ABORT);
+        return;
+    }
+    const uint32_t id = zk_uni(ids ? ids[f] : first + f);
+    const uint64_t frame_off = zk_uni(out_off ? out_off[f] : d_off[id] - d_off[first]);
+    uint8_t *out = zk_uni(dst + frame_off);
+    const uint64_t block_base = zk_uni(bases[f].block_base);
+    const uint32_t ns = zk_uni(nsegs[f]);
+    if (progress && tid == 0) zk_publish(progress + f, 0);   // (which XCD this is)
+    for (uint32_t j = 0; j < ns; j++) {
+        const uint64_t seg_no = (uint64_t)f * max_segs + j;
+        const ZkSeg &sg = segs[seg_no];
+        const uint32_t seg_pos = zk_uni(sg.pos);
+        const uint32_t nt = zk_uni(segn[seg_no]);
+        const ZkHole *rec = zk_uni(holes + zk_seg_region(frame_off, seg_pos, seg_no));
+        const uint32_t *tc = zk_uni(tilecnt + zk_seg_tile_region(frame_off, seg_pos, block_base + zk_uni(sg.b0), seg_no));
+        if (progress && j && tid == 0) zk_publish(progress + f, seg_pos);        // everything in front of this segment is final (every wave has waited out its stores at the tile barriers)
+        for (uint32_t t = 0; t < nt; t++) {
+            const uint32_t cnt = zk_uni(tc[t]);
+            for (uint32_t i = tid; i < cnt; i += L) {
+                const ZkHole r = rec[i];
+                uint8_t *d = out + zk_hole_dst(r);
+                const uint8_t *s = d - zk_hole_off(r);
+                const uint32_t n = zk_hole_len(r);
+                uint32_t v[ZK_EXEC_B];
+#pragma unroll
+                for (int k = 0; k < ZK_EXEC_B; k++) v[k] = (uint32_t)k < n ? s[k] : 0u;
+#pragma unroll
+                for (int k = 0; k < ZK_EXEC_B; k++) if ((uint32_t)k < n) d[k] = (uint8_t)v[k];
+            }
+            rec += cnt;
+            __syncthreads();                  // (waits out the stores: the next tile's sources may be these bytes)
+        }
+    }
+    if (progress && tid == 0) zk_publish(progress + f, (uint32_t)(d_off[id + 1] - d_off[id]));
+}
+
+// The same with the SEGMENT in LDS (a handful of long frames: a round of zk_k_exec_fill is a trip to memory and back, ~1.4-3 us, and a
+// 2 MiB frame has 128 ... 512 of them).  A hole's source is either final (before the segment: memory) or a hole of an earlier tile of
+// the segment.  Per segment:
+//   0  the segment as pass 1 left it: memory -> a 128 KiB image in LDS (16 bytes per lane and step);
+//   A  its records: requested at once, kept in registers (the common shape: at most ZK_FILL_NT tiles of at most 2 L records);
+//   B  every byte whose source lies before the segment: memory -> image, no order among them;
+//   C  tile after tile, the bytes whose source is a hole of the segment: image -> image behind an LDS barrier (no memory on the path);
+//   E  the image -> memory.
+// A record moves as two 8-byte reads and its bytes as byte writes (a run is 1 ... 16 bytes at any alignment; the image's neighbours
+// belong to other lanes).  Other shapes take the tile loop with their records from memory.  One workgroup of L = 1024 lanes per frame.
+constexpr int ZK_FILL_NT = 12;
+constexpr uint32_t ZK_FILL_IMG = ZK_SEG_BYTES + 48;                              // up to 15 bytes of alignment in front, 16-byte reads behind
+// bytes [lo, hi) of the 16-byte value (w0, w1) -> img[at + lo .. at + hi)
+__device__ __forceinline__ void zk_img_put(uint8_t *img, uint32_t at, uint32_t lo, uint32_t hi, uint64_t w0, uint64_t w1)
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) if ((uint32_t)k >= lo && (uint32_t)k < hi) img[at + k] = (uint8_t)(w0 >> (8 * k));
+    if (__ballot(hi > 8u) == 0) return;                                          // (runs are ~5 bytes on average: the upper half is rare)
+#pragma unroll
+    for (int k = 8; k < 16; k++) if ((uint32_t)k >= lo && (uint32_t)k < hi) img[at + k] = (uint8_t)(w1 >> (8 * (k - 8)));
+}
+// B: the part of a record whose source lies before the segment.  flimit: the frame's size (a 16-byte read must not leave the frame)
+__device__ __forceinline__ void zk_fill_from_memory(ZkHole r, uint32_t seg_pos, uint32_t ibase, uint32_t flimit, const uint8_t *out, uint8_t *img)
+{
+    const uint32_t d = zk_hole_dst(r), sp = d - zk_hole_off(r), n = zk_hole_len(r);
+    const bool mine = r != 0 && sp < seg_pos;
+    if (__ballot(mine) == 0) return;
+    uint64_t w0 = 0, w1 = 0;
+    if (mine) {
+        if (sp + 16u <= flimit) { w0 = zk_ld64(out + sp); w1 = zk_ld64(out + sp + 8); }
+        else for (uint32_t k = 0; k < n; k++) { const uint64_t b = out[sp + k]; if (k < 8) w0 |= b << (8 * k); else w1 |= b << (8 * (k - 8)); }
+    }
+    const uint32_t hi = mine ? (seg_pos - sp < n ? seg_pos - sp : n) : 0u;
+    zk_img_put(img, d - ibase, 0u, hi, w0, w1);
+}
+// C: the part whose source is a hole of the segment (an earlier tile: in the image by now)
+__device__ __forceinline__ void zk_fill_from_image(ZkHole r, uint32_t seg_pos, uint32_t ibase, uint8_t *img)
+{
+    const uint32_t d = zk_hole_dst(r), sp = d - zk_hole_off(r), n = zk_hole_len(r);
+    const bool mine = r != 0 && sp + n > seg_pos;
+    if (__ballot(mine) == 0) return;
+    const uint32_t lo = mine ? (sp < seg_pos ? seg_pos - sp : 0u) : 16u;
+    uint64_t w0 = 0, w1 = 0;
+    if (mine) {                                                                  // (bytes below lo are not used: read from where the segment starts)
+        const uint32_t a = sp + lo - ibase;
+        uint64_t x0, x1;
+        __builtin_memcpy(&x0, img + a, 8); __builtin_memcpy(&x1, img + a + 8, 8);
+        // the value as if read from sp: shifted up by lo bytes
+        if (lo == 0) { w0 = x0; w1 = x1; }
+        else if (lo < 8) { w0 = x0 << (8 * lo); w1 = (x1 << (8 * lo)) | (x0 >> (64 - 8 * lo)); }
+        else { w0 = 0; w1 = x0 << (8 * (lo - 8)); }
+    }
+    zk_img_put(img, d - ibase, lo, mine ? n : 0u, w0, w1);
+}
+template <int L>
+__global__ __launch_bounds__(L) void zk_k_exec_fill_lds(const uint64_t *d_off, uint32_t first, const uint32_t *ids, const uint64_t *out_off, const ZkFrameBase *bases,
+                                                        const ZkFrameInfo *infos, uint8_t *dst, const ZkSeg *segs, const uint32_t *nsegs, uint32_t max_segs,
+                                                        const ZkHole *holes, const uint32_t *tilecnt, const uint32_t *segn, uint64_t *progress)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t img[ZK_FILL_IMG];            // frame byte p of the segment at [p - ibase]
+    __shared__ uint32_t s_cnt[L];
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    if (zk_uni(infos[f].status) != ZK_OK) {
+        if (progress && tid == 0) zk_publish(progress + f, 0, ZK_PROG_ABORT);
+        return;
+    }
+    if (progress && tid == 0) zk_publish(progress + f, 0);   // (which XCD this is)
+    uint32_t final_to = 0;                                   // bytes in front of this position are final once the stores in flight have landed
+    const uint32_t id = zk_uni(ids ? ids[f] : first + f);
+    const uint64_t frame_off = zk_uni(out_off ? out_off[f] : d_off[id] - d_off[first]);
+    const uint32_t flimit = (uint32_t)zk_uni(d_off[id + 1] - d_off[id]);
+    uint8_t *out = zk_uni(dst + frame_off);
+    const uint64_t block_base = zk_uni(bases[f].block_base);
+    const uint32_t ns = zk_uni(nsegs[f]);
+    for (uint32_t j = 0; j < ns; j++) {
+        const uint64_t seg_no = (uint64_t)f * max_segs + j;
+        const ZkSeg &sg = segs[seg_no];
+        const uint32_t seg_pos = zk_uni(sg.pos), seg_out = zk_uni(sg.out);
+        const uint32_t nt = zk_uni(segn[seg_no]);
+        if (!nt) { final_to = seg_pos + seg_out; continue; }                     // (no holes: pass 1 left it complete)
+        const ZkHole *rec = zk_uni(holes + zk_seg_region(frame_off, seg_pos, seg_no));
+        const uint32_t *tc = zk_uni(tilecnt + zk_seg_tile_region(frame_off, seg_pos, block_base + zk_uni(sg.b0), seg_no));
+        const uint32_t shift = (uint32_t)((uintptr_t)(out + seg_pos) & 15u), ibase = seg_pos - shift, total = shift + seg_out;
+        const uint8_t *A = out + seg_pos - shift;                                // 16-byte aligned; image byte i <-> A[i]
+        uint8_t *Aw = out + seg_pos - shift;
+        __syncthreads();                                                         // (the segment before: its image stored and the stores waited out, s_cnt read)
+        if (progress && final_to && tid == 0) zk_publish(progress + f, final_to);
+        s_cnt[tid] = tid < nt ? tc[tid] : 0u;
+        // 0: whole 16-byte units inside the segment; the ragged ends byte by byte (bytes outside the segment are not this workgroup's)
+        for (uint32_t u = tid; u * 16u < total; u += L) {
+            const uint32_t i0 = u * 16u;
+            if (i0 >= shift && i0 + 16u <= total) *reinterpret_cast<uint4 *>(img + i0) = *reinterpret_cast<const uint4 *>(A + i0);
+            else for (uint32_t k = 0; k < 16u; k++) if (i0 + k >= shift && i0 + k < total) img[i0 + k] = A[i0 + k];
+        }
+        __syncthreads();
+        bool fast = nt <= (uint32_t)ZK_FILL_NT;
+        if (fast) {
+            ZkHole r0[ZK_FILL_NT], r1[ZK_FILL_NT];
+            uint32_t base = 0;
+#pragma unroll
+            for (int t = 0; t < ZK_FILL_NT; t++) {                               // A
+                const uint32_t cnt = zk_uni(s_cnt[t]);
+                fast = fast && cnt <= 2u * L;
+                r0[t] = tid < cnt ? rec[base + tid] : 0;
+                r1[t] = tid + L < cnt ? rec[base + tid + L] : 0;
+                base += cnt;
+            }
+            if (fast) {
+#pragma unroll
+                for (int t = 0; t < ZK_FILL_NT; t++) {                           // B
+                    zk_fill_from_memory(r0[t], seg_pos, ibase, flimit, out, img);
+                    zk_fill_from_memory(r1[t], seg_pos, ibase, flimit, out, img);
+                }
+                ZK_LDS_BARRIER();
+#pragma unroll
+                for (int t = 0; t < ZK_FILL_NT; t++) {                           // C
+                    if ((uint32_t)t < nt) {
+                        zk_fill_from_image(r0[t], seg_pos, ibase, img);
+                        zk_fill_from_image(r1[t], seg_pos, ibase, img);
+                        ZK_LDS_BARRIER();
+                    }
+                }
+            }
+        }
+        if (!fast) {                                                             // any other shape: the tiles in order, their records from memory
+            uint32_t base = 0;
+            for (uint32_t t0 = 0; t0 < nt; t0 += L) {                            // (the tile counts, L at a time)
+                if (t0) { __syncthreads(); s_cnt[tid] = t0 + tid < nt ? tc[t0 + tid] : 0u; __syncthreads(); }
+                const uint32_t nchunk = nt - t0 < (uint32_t)L ? nt - t0 : (uint32_t)L;
+                for (uint32_t t = 0; t < nchunk; t++) {
+                    const uint32_t cnt = zk_uni(s_cnt[t]);
+                    for (uint32_t i0 = 0; i0 < cnt; i0 += L) {                   // (all lanes: the helpers vote)
+                        const ZkHole r = i0 + tid < cnt ? rec[base + i0 + tid] : 0;
+                        zk_fill_from_memory(r, seg_pos, ibase, flimit, out, img);
+                        zk_fill_from_image(r, seg_pos, ibase, img);
+                    }
+                    base += cnt;
+                    ZK_LDS_BARRIER();
+                }
+            }
+        }
+        // E
+        for (uint32_t u = tid; u * 16u < total; u += L) {
+            const uint32_t i0 = u * 16u;
+            if (i0 >= shift && i0 + 16u <= total) *reinterpret_cast<uint4 *>(Aw + i0) = *reinterpret_cast<const uint4 *>(img + i0);
+            else for (uint32_t k = 0; k < 16u; k++) if (i0 + k >= shift && i0 + k < total) Aw[i0 + k] = img[i0 + k];
+        }
+        final_to = seg_pos + seg_out;
+    }
+    if (progress) {
+        __syncthreads();
+        if (tid == 0) zk_publish(progress + f, flimit);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ XXH64
@@ -1693,6 +2207,29 @@ void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, 
     else if (lanes == 512) ZK_EXEC_LAUNCH(512, false, 2);
     else ZK_EXEC_LAUNCH(1024, false, 2);
 #undef ZK_EXEC_LAUNCH
+}
+void zk_launch_exec_seg(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
+                        const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeqP *seqs,
+                        const uint8_t *lit, uint8_t *dst, const ZkSegScratch &sg, const ZkKernelChoice &k, bool dense, uint64_t *progress)
+{
+    hipLaunchKernelGGL(zk_k_seg_prep, dim3(count), dim3(64), 0, st, blocks, bases, infos, d_off, first, ids, sg.seg_bytes, sg.segs, sg.nsegs, sg.max_segs);
+    // a segment is a workgroup: wide tiles while the segments alone do not fill the device (a lone frame of 2 MiB: 16 segments), the
+    // executor's 256 lanes beyond that
+    const uint64_t wgs = (uint64_t)count * sg.max_segs;
+    const int lanes = k.exec_lanes == 256 || k.exec_lanes == 1024 ? k.exec_lanes : wgs >= 1024 ? 256 : 1024;
+    const dim3 grid(count, sg.max_segs);
+#define ZK_SEG_LAUNCH(TT, CC) hipLaunchKernelGGL((zk_k_exec_seg<TT, CC>), grid, dim3(TT), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst, \
+                                                 sg.segs, sg.nsegs, sg.max_segs, sg.holes, sg.tilecnt, sg.segn)
+    if (lanes == 1024) ZK_SEG_LAUNCH(1024, 2);
+    else if (k.exec_ring ? k.exec_ring == 2 : dense) ZK_SEG_LAUNCH(256, 4);
+    else ZK_SEG_LAUNCH(256, 2);
+#undef ZK_SEG_LAUNCH
+    if (k.seg_fill ? k.seg_fill == 2 : count >= 512) hipLaunchKernelGGL((zk_k_exec_fill<256>), dim3(count), dim3(256), 0, st, d_off, first, ids, out_off, bases, infos, dst, sg.segs, sg.nsegs, sg.max_segs, sg.holes, sg.tilecnt, sg.segn, progress);
+    else if (k.seg_fill == 1) hipLaunchKernelGGL((zk_k_exec_fill<1024>), dim3(count), dim3(1024), 0, st, d_off, first, ids, out_off, bases, infos, dst, sg.segs, sg.nsegs, sg.max_segs, sg.holes, sg.tilecnt, sg.segn, progress);
+    else hipLaunchKernelGGL((zk_k_exec_fill_lds<1024>), dim3(count), dim3(1024), 0, st, d_off, first, ids, out_off, bases, infos, dst, sg.segs, sg.nsegs, sg.max_segs, sg.holes, sg.tilecnt, sg.segn, progress);
+    // frames a segment gave up on (more hole records than its region holds): executed again, a workgroup per frame
+    hipLaunchKernelGGL((zk_k_exec<256, false, 2, true>), dim3(count), dim3(256), 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst,
+                       (const uint8_t *)nullptr, (uint64_t)0, (uint64_t *)nullptr);
 }
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
                      ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k, const uint64_t *skip, uint32_t wide_from)

@@ -1410,3 +1410,117 @@ ZK_HD uint32_t zk_exec_origin(const uint32_t *srcmap, uint32_t s, uint32_t ts)
     while (!(s & ZK_SRC_LIT) && (int32_t)(s - ZK_SRC_BIAS) >= (int32_t)ts) s = srcmap[(s - ZK_SRC_BIAS) - ts];
     return s;
 }
+
+// ---------------------------------------------------------------- sequence execution in SEGMENTS (two passes)
+// One workgroup per frame makes a frame a serial chain of tiles: a handful of frames leaves the device idle, and 1 280 resident frames
+// of a 2 MiB window keep 2.5 GB of history live (every far match a line from HBM).  Blocks cannot simply be dealt to several
+// workgroups -- a block's first bytes copy from the END of the block before it -- so the split is by DEPENDENCE:
+//   pass 1 (zk_k_exec_seg): a frame is cut into SEGMENTS of whole blocks (<= ZK_SEG_BYTES of output each, zk_seg_step), every segment
+//     a workgroup of its own, all at once.  It runs the tile machinery above with one change: a byte whose origin lies BEFORE its
+//     segment -- or in an earlier tile of the segment at a byte that is itself such a byte (one taint bit per byte of the segment, in
+//     LDS) -- is a HOLE: it is not written, a record (dst, offset, length <= 16) per run of holes is left in HBM.  Everything else of
+//     the segment (literals and whatever copies from them, however indirectly) is final after this pass;
+//   pass 2 (zk_k_exec_fill): one workgroup per frame walks the frame's hole records in order, L at a time, and copies the runs.  A
+//     record's source lies before its own TILE (in-tile sources were followed to their origin by pass 1) and the list is in tile
+//     order, so of a group of L records every one whose source ends at or below the group's lowest destination is independent of the
+//     group; the group is cut at the first one that is not (the first lane never is: zk_fill_ready).
+// Hole record: dst[29:0] (frame-relative) | (len - 1)[33:30] | off[63:34] (dst - src, 1 .. 2^30 - 1).
+typedef uint64_t ZkHole;
+constexpr uint32_t ZK_SEG_BYTES = 131072;          // a segment's output never exceeds this unless a single block does (and none does)
+constexpr uint32_t ZK_E_SEG_OVERFLOW = 0x5E60u;    // internal: a segment left more hole records than its region holds -- the frame is executed again by zk_k_exec
+struct ZkSeg {                   // one per segment, written by zk_k_seg_prep
+    uint32_t b0, nb;             // blocks [b0, b0 + nb) of the frame
+    uint32_t pos, out;           // frame-relative first byte, bytes
+    uint32_t rep[3];             // repeat offsets at the segment's first block (concrete)
+    uint32_t pad;
+};
+static_assert(sizeof(ZkSeg) == 32, "ZkSeg layout");
+ZK_HD ZkHole zk_hole_pack(uint32_t dst, uint32_t len, uint32_t off) { return (uint64_t)dst | ((uint64_t)(len - 1u) << 30) | ((uint64_t)off << 34); }
+ZK_HD uint32_t zk_hole_dst(ZkHole r) { return (uint32_t)r & 0x3FFFFFFFu; }
+ZK_HD uint32_t zk_hole_len(ZkHole r) { return ((uint32_t)(r >> 30) & 15u) + 1u; }
+ZK_HD uint32_t zk_hole_off(ZkHole r) { return (uint32_t)(r >> 34); }
+// where segment j's records live: region index (in records) and capacity, from the frame's place in the batch's output (frame_off),
+// the segment's place in the frame and its running number in the batch (f * max_segs + j)
+// (a slot per 4 bytes of output: at the start of a segment nearly every match is a hole, a run per ~7 bytes on text; archives of
+//  libzstd's level 3 leave a run per 5.9 bytes of a whole 128 KiB segment)
+ZK_HD uint64_t zk_seg_region(uint64_t frame_off, uint32_t pos, uint64_t seg_no) { return ((frame_off + pos) >> 2) + seg_no * 16u; }
+ZK_HD uint32_t zk_seg_region_cap(uint32_t out) { return (out >> 2) + 8u; }
+
+// The serial walk over a frame's blocks that cuts it into segments (one lane's work; zk_k_seg_prep feeds it from a wave's registers).
+struct ZkSegWalk { uint32_t pos, rep[3], b0, nb, seg_pos, seg_rep[3], nsegs, err; };
+ZK_HD void zk_seg_walk_init(ZkSegWalk &w)
+{
+    w.pos = 0; w.rep[0] = 1; w.rep[1] = 4; w.rep[2] = 8; w.b0 = 0; w.nb = 0; w.seg_pos = 0;
+    w.seg_rep[0] = 1; w.seg_rep[1] = 4; w.seg_rep[2] = 8; w.nsegs = 0; w.err = ZK_OK;
+}
+ZK_HD void zk_seg_emit(ZkSegWalk &w, ZkSeg *segs, uint32_t max_segs)
+{
+    if (w.nsegs < max_segs) {
+        ZkSeg s;
+        s.b0 = w.b0; s.nb = w.nb; s.pos = w.seg_pos; s.out = w.pos - w.seg_pos;
+        s.rep[0] = w.seg_rep[0]; s.rep[1] = w.seg_rep[1]; s.rep[2] = w.seg_rep[2]; s.pad = 0;
+        segs[w.nsegs] = s;
+    } else w.err = ZK_E_GENERIC;                            // (cannot happen: max_segs is 2 * ceil(largest frame / seg_bytes) + 1)
+    w.nsegs++;
+}
+// block bk of the frame: its status / regenerated size / symbolic repeat history as the entropy stage left them
+ZK_HD void zk_seg_step(ZkSegWalk &w, uint32_t bk, uint32_t b_status, uint32_t b_out, const uint32_t b_rep[3], uint64_t d_size, uint32_t block_max,
+                       uint32_t seg_bytes, ZkSeg *segs, uint32_t max_segs)
+{
+    if (w.err != ZK_OK) return;
+    if (b_status != ZK_OK) { w.err = b_status; return; }
+    if ((uint64_t)w.pos + b_out > d_size || b_out > block_max) { w.err = ZK_E_CORRUPTION; return; }     // as zk_k_exec
+    if (w.nb && w.pos - w.seg_pos + b_out > seg_bytes) {    // the segment is full: this block opens the next one
+        zk_seg_emit(w, segs, max_segs);
+        w.b0 = bk; w.nb = 0; w.seg_pos = w.pos;
+        w.seg_rep[0] = w.rep[0]; w.seg_rep[1] = w.rep[1]; w.seg_rep[2] = w.rep[2];
+    }
+    w.nb++;
+    w.pos += b_out;
+    const uint32_t r0 = zk_rep_resolve(b_rep[0], w.rep), r1 = zk_rep_resolve(b_rep[1], w.rep), r2 = zk_rep_resolve(b_rep[2], w.rep);
+    w.rep[0] = r0; w.rep[1] = r1; w.rep[2] = r2;
+}
+ZK_HD void zk_seg_walk_end(ZkSegWalk &w, uint64_t d_size, ZkSeg *segs, uint32_t max_segs)
+{
+    if (w.err != ZK_OK) return;
+    if (w.pos != d_size) { w.err = ZK_E_CORRUPTION; return; }
+    if (w.nb) zk_seg_emit(w, segs, max_segs);
+}
+
+// A slot's 16 source words after the chase (each a literal or a history position before the tile) -> which bytes are holes.
+// seg_lo: block-relative position of the segment's first byte (<= 0); tainted(p): the taint bit of segment-relative byte p.
+template <typename TAINT>
+ZK_HD uint32_t zk_seg_slot_holes(const uint32_t *sw, uint32_t nb, int32_t seg_lo, TAINT tainted)
+{
+    uint32_t hm = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) {
+        const uint32_t s = sw[k];
+        const int32_t rel = (int32_t)(s - ZK_SRC_BIAS);
+        bool h = false;
+        if (k < nb && !(s & ZK_SRC_LIT)) h = rel < seg_lo ? true : tainted((uint32_t)(rel - seg_lo));
+        hm |= h ? 1u << k : 0u;
+    }
+    return hm;
+}
+// Runs of holes with consecutive sources: bit k of the result = a run starts at byte k, len[k] its length (defined where the bit is set).
+ZK_HD uint32_t zk_seg_slot_runs(const uint32_t *sw, uint32_t hm, uint32_t *len)
+{
+    uint32_t starts = 0, run = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = (int)ZK_EXEC_SLOT - 1; k >= 0; k--) {
+        const bool h = (hm >> k) & 1u;
+        const bool next_joins = k + 1 < (int)ZK_EXEC_SLOT && ((hm >> (k + 1)) & 1u) && sw[(k + 1) & 15] == sw[k] + 1u;
+        const bool joins_prev = k > 0 && ((hm >> (k - 1)) & 1u) && sw[k] == sw[(k - 1) & 15] + 1u;
+        run = h ? (next_joins ? run + 1u : 1u) : 0u;
+        len[k] = run;
+        starts |= (h && !joins_prev) ? 1u << k : 0u;
+    }
+    return starts;
+}
+// pass 2, one record of a group whose lowest destination is dmin: may it be copied before the group's other records have been?
+ZK_HD bool zk_fill_ready(ZkHole r, uint32_t dmin) { return zk_hole_dst(r) - zk_hole_off(r) + zk_hole_len(r) <= dmin; }

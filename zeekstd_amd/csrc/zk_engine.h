@@ -29,6 +29,7 @@ struct zk_engine {
         hipStream_t st = nullptr, aux = nullptr;
         hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_exec = nullptr;
         zk_devbuf infos, bases, words, blocks, seqs, lit, prog;     // prog: the executor's progress words (zk_k_xxh64_follow)
+        zk_devbuf seg_tab, seg_cnt, seg_holes, seg_tiles;            // the executor in segments: ZkSeg records, per-frame / per-segment counts, hole records, tile counts
         uint64_t *h_words = nullptr;
         bool ready = false;
     } dctx[ZK_MAX_CTX];

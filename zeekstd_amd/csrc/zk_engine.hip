@@ -66,6 +66,9 @@ extern "C" int zk_engine_set_kernel_choice(zk_engine *e, int what, int value)
     case ZK_CHOICE_XXH64: if (value < 0 || value > 4) return ZK_ERR_ARGUMENT; k.xxh = value; return 0;
     case ZK_CHOICE_EXEC_RESIDENT: if (value != 0 && value != 4 && value != 5) return ZK_ERR_ARGUMENT; k.exec_resident = value; return 0;
     case ZK_CHOICE_SMALL_PATH: if (value < 0 || value > 2) return ZK_ERR_ARGUMENT; k.small_path = value; return 0;
+    case ZK_CHOICE_EXEC_SEG: if (value < 0 || value > 2) return ZK_ERR_ARGUMENT; k.exec_seg = value; return 0;
+    case ZK_CHOICE_SEG_KIB: if (value < 0 || value > 128) return ZK_ERR_ARGUMENT; k.seg_kib = value; return 0;
+    case ZK_CHOICE_SEG_FILL: if (value < 0 || value > 3) return ZK_ERR_ARGUMENT; k.seg_fill = value; return 0;
     case ZK_CHOICE_PIPE_CONTEXTS: if (value < 0 || value > ZK_MAX_CTX) return ZK_ERR_ARGUMENT; e->pipe_contexts = value; zk_hostpipe_tune(e); return 0;
     case ZK_CHOICE_PIPE_CHUNK_MIB: if (value < 0 || value > 4096) return ZK_ERR_ARGUMENT; e->pipe_chunk_bytes = (uint64_t)value << 20; zk_hostpipe_tune(e); return 0;
     default: return ZK_ERR_ARGUMENT;
@@ -162,7 +165,7 @@ extern "C" void zk_engine_destroy(zk_engine *e)
     for (int k = 0; k < ZK_NKERNELS; k++) { if (e->ev_start[k]) (void)hipEventDestroy(e->ev_start[k]); if (e->ev_stop[k]) (void)hipEventDestroy(e->ev_stop[k]); }
     for (int i = 0; i < ZK_MAX_CTX; i++) {
         zk_engine::DecCtx &c = e->dctx[i];
-        for (zk_devbuf *b : {&c.infos, &c.bases, &c.words, &c.blocks, &c.seqs, &c.lit, &c.prog}) if (b->p) (void)hipFree(b->p);
+        for (zk_devbuf *b : {&c.infos, &c.bases, &c.words, &c.blocks, &c.seqs, &c.lit, &c.prog, &c.seg_tab, &c.seg_cnt, &c.seg_holes, &c.seg_tiles}) if (b->p) (void)hipFree(b->p);
         if (c.h_words) (void)hipHostFree(c.h_words);
         for (hipEvent_t ev : {c.ev_fork, c.ev_join, c.ev_exec}) if (ev) (void)hipEventDestroy(ev);
         if (c.aux) (void)hipStreamDestroy(c.aux);
@@ -227,6 +230,21 @@ bool zk_follow_wanted(const zk_engine *e, uint32_t count, uint64_t out_bytes, bo
     return alone ? count >= 1024 : count < 1024;
 }
 
+// Several workgroups per frame (zk_k_exec_seg + zk_k_exec_fill) instead of one (zk_k_exec)?  Never with a prefix (history below the frame's
+// first byte is the serial kernel's), never when a frame could have more segments than a grid has rows.
+static bool zk_seg_wanted(const zk_engine *e, const zk_dec_args &a, uint32_t count, uint64_t out_bytes, uint64_t max_frame, uint64_t nblocks, bool follow)
+{
+    if (a.d_prefix || e->choice.exec_seg == 1 || !count || !nblocks) return false;
+    const uint32_t seg_bytes = e->choice.seg_kib ? (uint32_t)e->choice.seg_kib << 10 : ZK_SEG_BYTES;
+    if (2 * ((max_frame + seg_bytes - 1) / seg_bytes) + 1 > 65535) return false;
+    if (e->choice.exec_seg == 2) return true;
+    // by batch shape: a handful of long frames, where a frame as ONE workgroup leaves the device idle (2 MiB frames, HBM-resident,
+    // unverified, ms: 1 / 5 / 16 / 32 frames 2.58 / 2.60 / 2.62 / 2.65 -> 1.79 / 1.83 / 1.85 / 2.39; 64 frames 2.80 -> 2.88: profiles/r06_seg_probe.txt).
+    // Not where the checksums run beside the executor: a frame's four XXH64 chains (1.7-2.3 ms per 2 MiB, whoever runs them) then end
+    // the decode, not the executor (verified, 16 frames: 3.52 ms either way).
+    return !follow && count <= 32 && out_bytes >= (uint64_t)count * (4u * ZK_SEG_BYTES);
+}
+
 // Enqueue the whole decode on the context's queues.  Blocks the host once, for the block / sequence / literal totals
 // that size the scratch (40 bytes, after the two cheapest kernels); returns with the rest still running.
 int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
@@ -248,11 +266,12 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
     zk_profile_begin(e);
     { zk_kernel_timer t(e, ZK_K_WALK_COUNT, st); zk_launch_walk(st, comp, a.comp_size, c_off, d_off, first, count, a.ids, a.out_off, a.dst_cap, nullptr, nullptr, infos); }
     { zk_kernel_timer t(e, ZK_K_SCAN, st); zk_launch_scan(st, infos, count, bases, words, d_off, first, a.out_off); }
-    ZK_HIP(hipMemcpyAsync(c.h_words, words, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(c.h_words, words, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     const uint64_t nblocks = c.h_words[0], nseq = c.h_words[1], nlit = c.h_words[2];
     const uint32_t n_own = (uint32_t)c.h_words[4];        // blocks that need per-block sequence tables
     const bool dense = nseq * 10 > c.h_words[5];          // fewer than 10 output bytes per sequence (zk_launch_exec)
+    const uint64_t out_bytes = c.h_words[5], max_frame = c.h_words[7];
     if (nblocks > 0xFFFFFFF0ull) return -(int)ZK_E_GENERIC;
     if ((rc = zk_devbuf_reserve(e, c.blocks, (size_t)(nblocks + 1) * sizeof(ZkBlock)))) return rc;
     if ((rc = zk_devbuf_reserve(e, c.seqs, (size_t)(nseq + 1) * sizeof(ZkSeqP)))) return rc;
@@ -267,7 +286,22 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
     // checksum waves run on the context's second queue beside it, the ordinary pass behind the executor takes what they left
     // (not in the host pipeline's chunks: they overlap whole chunks on one queue per context, PCIe bounds them, and the extra queues
     //  cost the copy queues 1-2 %: 46.4 -> 45.3 GiB/s end to end)
-    const bool follow = a.verify && !a.single_queue && zk_follow_wanted(e, count, c.h_words[5], a.alone);
+    const bool follow = a.verify && !a.single_queue && zk_follow_wanted(e, count, c.h_words[5], a.alone);      // (in segments: behind the fill pass's progress words)
+    // The executor in segments (several workgroups per frame; zk_device.h): where a frame is long and the frames alone do not fill the device.
+    ZkSegScratch sgs{};
+    const bool seg = zk_seg_wanted(e, a, count, out_bytes, max_frame, nblocks, follow);
+    if (seg) {
+        zk_engine::DecCtx &x = e->dctx[c.slot];
+        sgs.seg_bytes = e->choice.seg_kib ? (uint32_t)e->choice.seg_kib << 10 : ZK_SEG_BYTES;
+        sgs.max_segs = 2u * (uint32_t)((max_frame + sgs.seg_bytes - 1) / sgs.seg_bytes) + 1u;
+        const uint64_t nsg = (uint64_t)count * sgs.max_segs;
+        if ((rc = zk_devbuf_reserve(e, x.seg_tab, (size_t)nsg * sizeof(ZkSeg)))) return rc;
+        if ((rc = zk_devbuf_reserve(e, x.seg_cnt, (size_t)(nsg + count) * sizeof(uint32_t)))) return rc;
+        if ((rc = zk_devbuf_reserve(e, x.seg_holes, (size_t)((out_bytes >> 2) + 16 * nsg + 16) * sizeof(ZkHole)))) return rc;
+        if ((rc = zk_devbuf_reserve(e, x.seg_tiles, (size_t)((out_bytes >> 10) + 2 * nblocks + 8 * nsg + 16) * sizeof(uint32_t)))) return rc;
+        sgs.segs = (ZkSeg *)x.seg_tab.p; sgs.nsegs = (uint32_t *)x.seg_cnt.p; sgs.segn = sgs.nsegs + count;
+        sgs.holes = (ZkHole *)x.seg_holes.p; sgs.tilecnt = (uint32_t *)x.seg_tiles.p;
+    }
     ZkKernelChoice kc = e->choice;
     if (follow && !kc.exec_resident) kc.exec_resident = 4;
     uint64_t *prog = nullptr;
@@ -302,7 +336,8 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
         ZK_HIP(hipEventRecord(x.ev_fork, st));               // (in front of the executor: the checksum waves start with it)
         ZK_HIP(hipStreamWaitEvent(x.aux, x.ev_fork, 0));
     }
-    { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, a.ids, a.out_off, blocks, bases, infos, seqs, lit, (uint8_t *)a.d_dst, (const uint8_t *)a.d_prefix, a.d_prefix ? a.prefix_len : 0, kc, dense, prog); }
+    if (seg) { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec_seg(st, comp, d_off, first, count, a.ids, a.out_off, blocks, bases, infos, seqs, lit, (uint8_t *)a.d_dst, sgs, kc, dense, prog); }
+    else { zk_kernel_timer t(e, ZK_K_EXEC, st); zk_launch_exec(st, comp, d_off, first, count, a.ids, a.out_off, blocks, bases, infos, seqs, lit, (uint8_t *)a.d_dst, (const uint8_t *)a.d_prefix, a.d_prefix ? a.prefix_len : 0, kc, dense, prog); }
     if (a.mark_exec) ZK_HIP(hipEventRecord(c.ev_exec, st));
     if (follow) {
         // enqueued BEHIND the executor's launch: were the two queues ever served one after the other, the checksum waves would find

@@ -15,7 +15,12 @@ struct ZkKernelChoice {
                             // 4 zk_k_xxh64_follow beside the executor (zk_engine.hip)
     int exec_resident = 0;  // zk_k_exec<256>: workgroups per CU (4 / 5) through LDS the launch asks for and does not use
     int small_path = 0;     // host-pointer decode of <= 64 frames: 1 the general pipeline instead, 2 the small path's entropy roles as two kernels
+    int exec_seg = 0;       // the executor in segments (zk_k_seg_prep / zk_k_exec_seg / zk_k_exec_fill): 1 never, 2 always (without a prefix); 0 by batch shape
+    int seg_kib = 0;        // ... output KiB per segment (1..128; 0 = 128)
+    int seg_fill = 0;       // ... the fill pass: 1 zk_k_exec_fill<1024> (rounds through memory), 2 zk_k_exec_fill<256>, 3 zk_k_exec_fill_lds (the segment's holes in LDS); 0 by batch size
 };
+// scratch of the segmented executor (zk_engine.hip sizes it; zk_device.h: zk_seg_region)
+struct ZkSegScratch { ZkSeg *segs; uint32_t *nsegs, *segn; ZkHole *holes; uint32_t *tilecnt; uint32_t max_segs, seg_bytes; };
 
 void zk_launch_walk(hipStream_t st, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off, const uint64_t *d_off, uint32_t first,
                     uint32_t count, const uint32_t *ids, const uint64_t *out_off, uint64_t dst_cap, const ZkFrameBase *bases, ZkBlock *blocks, ZkFrameInfo *infos);
@@ -27,6 +32,9 @@ void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, 
                     const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeqP *seqs,
                     const uint8_t *lit, uint8_t *dst, const uint8_t *prefix, uint64_t plen, const ZkKernelChoice &k, bool dense = false,
                     uint64_t *progress = nullptr);      // progress: one word per frame for zk_launch_xxh64_follow (zk_decode.hip: zk_publish)
+void zk_launch_exec_seg(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, uint32_t first, uint32_t count,
+                        const uint32_t *ids, const uint64_t *out_off, const ZkBlock *blocks, const ZkFrameBase *bases, ZkFrameInfo *infos, const ZkSeqP *seqs,
+                        const uint8_t *lit, uint8_t *dst, const ZkSegScratch &sg, const ZkKernelChoice &k, bool dense, uint64_t *progress = nullptr);
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
                      ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k, const uint64_t *skip = nullptr,
                      uint32_t wide_from = 1024);         // frames from which sixteen share a wave (the encoder passes 512: zk_decode.hip)

@@ -55,7 +55,7 @@ class Engine:
             self._raise(rc)
 
     CHOICES = {"reset": 0, "fse_own": 1, "fse_shared": 2, "exec_lanes": 3, "exec_ring": 4, "xxh64": 5, "small_path": 6,
-               "pipe_contexts": 7, "pipe_chunk_mib": 8, "exec_resident": 9}
+               "pipe_contexts": 7, "pipe_chunk_mib": 8, "exec_resident": 9, "exec_seg": 10, "seg_kib": 11, "seg_fill": 12}
 
     def frame_content_sizes(self, comp: bytes, c_off, first=0, count=None):
         """zk_frame_content_sizes: the decompressed sizes of frames nobody holds seek entries for (header walk + sequence walks on the device,
