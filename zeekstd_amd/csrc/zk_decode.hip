@@ -77,13 +77,20 @@ __global__ __launch_bounds__(1024) void zk_k_scan(const ZkFrameInfo *infos, uint
     if (tid < 4) carry[tid] = 0;
     if (tid == 0) s_maxd = 0;
     __syncthreads();
+    // [8]: frames that carry a Content_Checksum (none: no checksum kernel has anything to do)
+    __shared__ uint32_t s_ncks;
+    if (tid == 0) s_ncks = 0;
+    __syncthreads();
     {
         unsigned long long mx = 0;
+        uint32_t ncks = 0;
         for (uint32_t f = tid; f < count; f += 1024) {
             const unsigned long long dsz = out_off ? out_off[f + 1] - out_off[f] : d_off ? d_off[first + f + 1] - d_off[first + f] : 0;
             mx = dsz > mx ? dsz : mx;
+            ncks += infos[f].status == ZK_OK && infos[f].checksum_flag ? 1u : 0u;
         }
         if (mx) atomicMax(&s_maxd, mx);
+        if (ncks) atomicAdd(&s_ncks, ncks);
     }
     for (uint32_t base = 0; base < count; base += 1024) {
         uint32_t f = base + tid;
@@ -115,6 +122,7 @@ __global__ __launch_bounds__(1024) void zk_k_scan(const ZkFrameInfo *infos, uint
     if (tid < 3) totals[tid] = carry[tid];
     if (tid == 3) totals[4] = carry[3];
     if (tid == 4) totals[7] = s_maxd;
+    if (tid == 5) totals[8] = s_ncks;
 }
 
 // ------------------------------------------------------------------------------------------------ Huffman literals
@@ -2156,7 +2164,10 @@ void zk_launch_fse(hipStream_t st, const uint8_t *comp, ZkBlock *blocks, uint32_
     // a small batch (a seek, a handful of frames) is all chain latency: every block, predefined tables or not, takes a
     // quad of lanes (each block builds its own copy of the tables: microseconds)
     if (own_kernel == 0 && k.fse_shared == 0 && nblocks <= 16u * 256u) {
-        hipLaunchKernelGGL((zk_k_fse_quad<ZkCellsX16, 16, 1>), dim3((nblocks + 15) / 16), dim3(192), 0, st, comp, blocks, nblocks, seqs, 1u);
+        // ... and while 8-block workgroups (8-byte cells: ~63 instead of ~80 instructions per sequence of a chain, 10 KiB of tables per
+        // block, one workgroup per CU) hold every block in one round, those (what the small path's kernel runs: zk_k_small_entropy)
+        if (nblocks <= 8u * 256u) hipLaunchKernelGGL((zk_k_fse_quad<ZkCells64, 8, 1>), dim3((nblocks + 7) / 8), dim3(192), 0, st, comp, blocks, nblocks, seqs, 1u);
+        else hipLaunchKernelGGL((zk_k_fse_quad<ZkCellsX16, 16, 1>), dim3((nblocks + 15) / 16), dim3(192), 0, st, comp, blocks, nblocks, seqs, 1u);
         return;
     }
     // blocks that share their tables with their neighbours (predefined, or one set per frame): one lane each

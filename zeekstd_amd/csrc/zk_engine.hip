@@ -266,9 +266,10 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
     zk_profile_begin(e);
     { zk_kernel_timer t(e, ZK_K_WALK_COUNT, st); zk_launch_walk(st, comp, a.comp_size, c_off, d_off, first, count, a.ids, a.out_off, a.dst_cap, nullptr, nullptr, infos); }
     { zk_kernel_timer t(e, ZK_K_SCAN, st); zk_launch_scan(st, infos, count, bases, words, d_off, first, a.out_off); }
-    ZK_HIP(hipMemcpyAsync(c.h_words, words, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(c.h_words, words, 9 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     const uint64_t nblocks = c.h_words[0], nseq = c.h_words[1], nlit = c.h_words[2];
+    const bool verify = a.verify && c.h_words[8] != 0;    // (a batch without a Content_Checksum: zeekstd's library default, encode.rs:163-167 -- no checksum kernel is launched)
     const uint32_t n_own = (uint32_t)c.h_words[4];        // blocks that need per-block sequence tables
     const bool dense = nseq * 10 > c.h_words[5];          // fewer than 10 output bytes per sequence (zk_launch_exec)
     const uint64_t out_bytes = c.h_words[5], max_frame = c.h_words[7];
@@ -286,7 +287,7 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
     // checksum waves run on the context's second queue beside it, the ordinary pass behind the executor takes what they left
     // (not in the host pipeline's chunks: they overlap whole chunks on one queue per context, PCIe bounds them, and the extra queues
     //  cost the copy queues 1-2 %: 46.4 -> 45.3 GiB/s end to end)
-    const bool follow = a.verify && !a.single_queue && zk_follow_wanted(e, count, c.h_words[5], a.alone);      // (in segments: behind the fill pass's progress words)
+    const bool follow = verify && !a.single_queue && zk_follow_wanted(e, count, c.h_words[5], a.alone);      // (in segments: behind the fill pass's progress words)
     // The executor in segments (several workgroups per frame; zk_device.h): where a frame is long and the frames alone do not fill the device.
     ZkSegScratch sgs{};
     const bool seg = zk_seg_wanted(e, a, count, out_bytes, max_frame, nblocks, follow);
@@ -347,7 +348,7 @@ int zk_decode_enqueue(zk_engine *e, zk_dec_ctx &c, const zk_dec_args &a)
         ZK_HIP(hipEventRecord(x.ev_join, x.aux));
         ZK_HIP(hipStreamWaitEvent(st, x.ev_join, 0));
         zk_launch_xxh64(st, (const uint8_t *)a.d_dst, x_off, x_first, count, infos, nullptr, e->choice, prog);
-    } else if (a.verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)a.d_dst, x_off, x_first, count, infos, nullptr, e->choice); }
+    } else if (verify) { zk_kernel_timer t(e, ZK_K_XXH64, st); zk_launch_xxh64(st, (const uint8_t *)a.d_dst, x_off, x_first, count, infos, nullptr, e->choice); }
     { zk_kernel_timer t(e, ZK_K_STATUS, st); zk_launch_status(st, infos, count, (int32_t *)a.d_frame_status, words + 3, prog, words + 6); }
     ZK_HIP(hipMemcpyAsync(c.h_words + 3, words + 3, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     return 0;
