@@ -84,10 +84,64 @@ def build_inputs(k0, nframes, level, cks, workers, want_archive, tag, cache=None
     return _SHM, comp, frames, hashes
 
 
+_ZKB_FOUND = {}
+
+
+def _find_libzstd():
+    """Every libzstd the box offers (ldconfig, the usual library directories), by version: the newest optimised build is the baseline --
+    the reference pins 1.5.7, whose decoder is faster than 1.4.x's.  Pillow's bundled 1.5.7 (a size-optimised build, ~5x slower) is
+    never timed.  Returns (path, {path: version})."""
+    import glob
+    import subprocess
+    from oracle import libzstd_ref as Z
+    paths = [p for p in Z._CANDIDATES["system"]]
+    try:
+        for ln in subprocess.run(["ldconfig", "-p"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if "libzstd.so" in ln and "=>" in ln:
+                paths.append(ln.split("=>")[1].strip())
+    except (OSError, subprocess.SubprocessError):
+        pass
+    for d in ("/usr/lib", "/usr/lib64", "/usr/local/lib", "/opt/conda/lib", "/usr/lib/x86_64-linux-gnu", os.path.expanduser("~/.local/lib")):
+        paths += glob.glob(os.path.join(d, "libzstd.so*"))
+    from oracle import zko
+    seen, found, rate = set(), {}, {}
+    sample = zko.gen_chunks(4 << 20, 3)
+    for p in paths:
+        rp = os.path.realpath(p)
+        if rp in seen or not os.path.exists(rp) or "pillow" in rp:
+            continue
+        seen.add(rp)
+        try:
+            l = C.CDLL(rp)
+            l.ZSTD_versionString.restype = C.c_char_p
+            ver = l.ZSTD_versionString().decode()
+            l.ZSTD_compressBound.restype = C.c_size_t; l.ZSTD_compressBound.argtypes = [C.c_size_t]
+            l.ZSTD_compress.restype = C.c_size_t; l.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
+            l.ZSTD_decompress.restype = C.c_size_t; l.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+            cb = C.create_string_buffer(l.ZSTD_compressBound(len(sample)))
+            cn = l.ZSTD_compress(cb, len(cb), sample, len(sample), 1)
+            ob = C.create_string_buffer(len(sample))
+            best = 1e9
+            for _ in range(4):                                   # a build's decoder speed, not its version, picks the baseline (the fastest one)
+                t = time.perf_counter()
+                dn = l.ZSTD_decompress(ob, len(ob), cb, cn)
+                best = min(best, time.perf_counter() - t)
+            if dn != len(sample):
+                continue
+            found[rp] = f"{ver} ({len(sample) / best / 2**30:.2f} GiB/s on a 4 MiB one-shot decode)"
+            rate[rp] = len(sample) / best
+        except (OSError, AttributeError):
+            continue
+    if not found:
+        return None, {}
+    return max(rate, key=rate.get), found
+
+
 def _zkb():
-    from oracle import zko, libzstd_ref as Z
+    from oracle import zko
     lib = zko.lib()
-    path = next((p for p in Z._CANDIDATES["system"] if os.path.exists(p)), None)
+    path, found = _find_libzstd()
+    _ZKB_FOUND.update(found)
     if path is None or lib.zkb_open(path.encode()) != 0:
         return None
     lib.zkb_version.restype = C.c_char_p
@@ -154,7 +208,7 @@ def cpu_baseline(comp, frames, data, sample_frames, level, cks, ref_comp=None, r
                  f"this box's optimised libzstd is {ver}, whose decoder is slower than 1.5.7's by an unmeasured margin -- the speed-ups beside this value "
                  f"are optimistic by that margin (the image's only 1.5.7 is pillow's bundled build, ~5x slower than a distro build: not used)"))
     out = {"value": v1, "unit": "GiB/s", "cores": 1, "kind": f"port (zeekstd loops in C over dlopen'd libzstd {ver}); {pin_note}",
-           "libzstd_version": ver, "reference_pin": "1.5.7",
+           "libzstd_version": ver, "reference_pin": "1.5.7", "libzstd_on_this_box": dict(_ZKB_FOUND),
            "sample": f"zeekstd::Decoder loop (decode.rs:201-270, bench protocol decompress.rs:18-39), first {n} frames ({dsz >> 20} MiB) "
                      f"of the same (GPU-made) archive, best of {passes} passes, 1 thread"}
     va, passes = _cpu_decode_rate(lib, comp, frames, cores, 4.0)
@@ -196,6 +250,35 @@ def cpu_baseline(comp, frames, data, sample_frames, level, cks, ref_comp=None, r
     return out
 
 
+# the sources a kernel's code comes from: the counter passes under profiles/ are stamped with their hashes (tools/pmc_summary.py), and a
+# `traffic` figure is only quoted while the kernel it belongs to is still the code it was measured on
+_KERNEL_SOURCES = {"dec": ("zk_decode.hip", "zk_device.h"), "enc": ("zk_encode.hip", "zk_enc_match.h", "zk_enc_match2.h", "zk_enc_device.h", "zk_enc_plan.h")}
+
+
+def kernel_source_hashes():
+    import hashlib
+    out = {}
+    for fam, names in _KERNEL_SOURCES.items():
+        h = hashlib.sha1()
+        for n in names:
+            with open(os.path.join(ROOT, "zeekstd_amd", "csrc", n), "rb") as f:
+                h.update(f.read())
+        out[fam] = h.hexdigest()[:16]
+    return out
+
+
+def _pmc_fresh(pmc, kernel, section=None):
+    """is the committed counter pass still about today's code of `kernel`?  (passes collected before round 6 carry no hashes: stale)"""
+    stamped = (pmc.get("section_source_hashes", {}).get(section) if section and section != "kernels" else None) or pmc.get("source_hashes")
+    if not stamped:
+        return False
+    fam = "enc" if kernel.startswith("zk_k_enc") else "dec"
+    try:
+        return stamped.get(fam) == kernel_source_hashes()[fam]
+    except OSError:
+        return False
+
+
 def _pmc(section):
     """HBM bytes per kernel from the committed counter passes (profiles/pmc_traffic.json), or {}: constants of an earlier run of this
     very command, labelled as such wherever they are quoted"""
@@ -203,11 +286,11 @@ def _pmc(section):
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
     except OSError:
-        return {}, None
+        return {}, None, {}
     sec = pmc.get(section) if section != "kernels" else pmc.get("kernels")
     if not isinstance(sec, dict):
-        return {}, None
-    return sec, f"profiles/pmc_traffic.json [{section}] ({pmc.get('collected', 'committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}), not this run"
+        return {}, None, pmc
+    return sec, f"profiles/pmc_traffic.json [{section}] ({pmc.get('collected', 'committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}), not this run", pmc
 
 
 def roofline_of(kernel_ms, algo_bytes, step_ms=None, pmc_section=None, full_size=True):
@@ -219,13 +302,15 @@ def roofline_of(kernel_ms, algo_bytes, step_ms=None, pmc_section=None, full_size
     ach = algo_bytes / (kernel_ms[dom] * 1e-3) / 1e9
     traffic, src = None, None
     if pmc_section and full_size:
-        sec, src_ = _pmc(pmc_section)
+        sec, src_, pmc = _pmc(pmc_section)
         key = dom.split("(")[0]
         traffic = sec.get(key, {}).get("hbm_bytes")
         if traffic is None and key in ("zk_k_fse", "zk_k_xxh64"):      # the engine's timer covers a family of kernels (zk_k_fse_quad / _sets / _predef_fed; zk_k_xxh64_wide ...): their sum
             fam = [v.get("hbm_bytes", 0) for k, v in sec.items() if k.startswith(key)]
             traffic = sum(fam) if fam else None
         src = src_ if traffic is not None else None
+        if traffic is not None and not _pmc_fresh(pmc, key, pmc_section):
+            traffic, src = None, "the committed counter pass was taken on other kernel sources (profiles/pmc_traffic.json source_hashes): not quoted"
     out = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
            "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": int(algo_bytes)}
     if step_ms:
@@ -615,6 +700,12 @@ def main():
     ap.add_argument("--choice", action="append", default=[], metavar="KEY=VALUE",
                     help="pin a kernel variant for the whole run (zk_engine_set_kernel_choice: fse_own, fse_shared, exec_lanes, exec_ring, xxh64, "
                          "small_path, pipe_contexts, pipe_chunk_mib); A/B runs of tools/, never the driver's line")
+    ap.add_argument("--one-gpu-transport", default=None, metavar="LIB",
+                    help="TEST ONLY (tests/test_gpu_multirank_bench.py): every rank uses device 0, the process group runs over gloo, and the gather leg goes "
+                         "through zk_gather_seekable with its collective entry points provided by LIB (tests/sim/libzk_shm_collectives.so) -- the N > 1 "
+                         "control flow of this file (barriers, max over ranks, the gather's watchdog, the check of a remote frame, the line) on a "
+                         "box with one GPU.  The numbers of such a run mean nothing")
+    ap.add_argument("--gather-only", action="store_true", help="N > 1: one untimed-quality decode step, then the gather leg (what a scaling run is asked about first)")
     ap.add_argument("--archive", default="auto", choices=["auto", "gpu", "libzstd"],
                     help="who compresses the archive that is decoded: the GPU encoder (default for c3) or CPU libzstd (default for c2)")
     args = ap.parse_args()
@@ -627,6 +718,12 @@ def main():
     nframes = args.frames or (2048 if args.workload == "c3" else 128)
     cks = args.workload == "c3"
     level = args.level
+    one_gpu = bool(args.one_gpu_transport) and world > 1
+    if one_gpu:
+        local_rank = 0                                     # every rank on device 0
+    if args.gather_only:
+        args.steps, args.warmup = 1, 1
+        args.no_cpu_baseline = args.no_seek = args.no_e2e = args.no_c1 = args.no_ref_archive = True
     if args.dry_run:
         return dry_run(args, rank, world)
 
@@ -653,7 +750,22 @@ def main():
     import zeekstd_amd as zk
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    shm_comm = shm_lib = None
+    if world > 1 and one_gpu:
+        import datetime
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+        shm_lib = C.CDLL(args.one_gpu_transport)
+        shm_lib.zkshm_comm_create.restype = C.c_void_p
+        shm_lib.zkshm_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint64]
+        shm_lib.zkshm_comm_destroy.argtypes = [C.c_void_p]
+        zk.lib.zk_set_collective_library.argtypes = [C.c_char_p]
+        if zk.lib.zk_set_collective_library(args.one_gpu_transport.encode()) != 0:
+            raise RuntimeError("the transport library could not be loaded")
+        name = f"/zkbench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        shm_comm = shm_lib.zkshm_comm_create(name.encode(), rank, world, max(64 << 20, int(zk.lib.zk_compress_bound(nframes * FRAME, FRAME)) + (1 << 20)))
+        if not shm_comm:
+            raise RuntimeError("the shared-memory communicator could not be created")
+    elif world > 1:
         import datetime
         dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))      # a hung collective ends the run in minutes, not in half an hour
     eng = zk.Engine(local_rank)
@@ -670,6 +782,7 @@ def main():
         d_comp = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
         d_cs = torch.zeros(nframes, dtype=torch.int32, device=dev)
         d_ds = torch.zeros(nframes, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()                                # torch's fills have landed before the engine's own queue writes the same buffers
         nf, csize = eng.encode_frames_dev(d_src, dsize, FRAME, level, cks, d_comp, cap, d_cs, d_ds)      # warm-up + the archive
         torch.cuda.synchronize()
         te = []
@@ -717,6 +830,7 @@ def main():
         if world > 1:
             dist.barrier()
 
+    torch.cuda.synchronize()                                    # (torch's fills and copies above have landed: the engine's queues are not ordered behind torch's stream)
     for _ in range(args.warmup):
         step()
     # parity gate before anything is timed: every frame's XXH64 equals the generator's
@@ -779,7 +893,7 @@ def main():
         run_timed(args.steps)
         torch.cuda.synchronize(); spans.append(time.perf_counter() - tsp)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_bytes = dsize * world * args.steps
@@ -848,6 +962,8 @@ def main():
             traffic = pmc["kernels"].get(dom.split("(")[0], {}).get("hbm_bytes")
             # NOT measured by this run: a constant from the committed counter passes of this command
             traffic_src = f"profiles/pmc_traffic.json ({pmc.get('collected', 'committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')}), not this run"
+            if traffic is not None and not _pmc_fresh(pmc, dom.split("(")[0]):
+                traffic, traffic_src = None, "the committed counter pass was taken on other kernel sources (profiles/pmc_traffic.json source_hashes): not quoted"
     except OSError:
         pass
 
@@ -879,11 +995,49 @@ def main():
         def _gather_leg():
             try:
                 torch.cuda.set_device(local_rank)
-                tg = []
+                tg, tx = [], []
+
+                def sharded():
+                    """encode this rank's shard, then the exchange: over torch.distributed (RCCL), or -- one GPU for all ranks, tests only --
+                    through zk_gather_seekable over the named transport.  Returns (stream on the root, its SeekTable, seconds of the exchange alone)."""
+                    if not one_gpu:
+                        cap_ = int(zk.lib.zk_compress_bound(dsize, FRAME))
+                        e_comp = torch.empty(cap_ + 64, dtype=torch.uint8, device=dev)
+                        e_cs = torch.empty(nframes, dtype=torch.int32, device=dev); e_ds = torch.empty(nframes, dtype=torch.int32, device=dev)
+                        torch.cuda.synchronize()                          # (nothing of torch's in flight on these buffers when the engine's own queue takes them)
+                        nfo, written = eng.encode_frames_dev(d_src, dsize, FRAME, level, cks, e_comp, cap_, e_cs, e_ds)
+                        torch.cuda.synchronize(); barrier(); tq = time.perf_counter()
+                        o, tb = parallel.gather_seekable(e_comp[:written], e_cs[:nfo], e_ds[:nfo], 0)
+                        torch.cuda.synchronize(); barrier()
+                        return o, tb, time.perf_counter() - tq
+                    from zeekstd_amd import SeekTable
+                    cap_ = int(zk.lib.zk_compress_bound(dsize, FRAME))
+                    e_comp = torch.empty(cap_ + 64, dtype=torch.uint8, device=dev)
+                    e_cs = torch.empty(nframes, dtype=torch.int32, device=dev); e_ds = torch.empty(nframes, dtype=torch.int32, device=dev)
+                    torch.cuda.synchronize()
+                    nfo, written = eng.encode_frames_dev(d_src, dsize, FRAME, level, cks, e_comp, cap_, e_cs, e_ds)
+                    h_cs = e_cs[:nfo].cpu().numpy().astype(np.uint32); h_ds = e_ds[:nfo].cpu().numpy().astype(np.uint32)
+                    ocap = world * cap_ + 8 * world * nframes + 64
+                    o = torch.empty(ocap if rank == 0 else 1, dtype=torch.uint8, device=dev)
+                    nbytes, tab = C.c_uint64(), C.c_void_p()
+                    zk.lib.zk_gather_seekable.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                          C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+                    if os.environ.get("ZK_BENCH_DEBUG"):
+                        print(f"rank {rank}: written {written} sum of sizes {int(h_cs.sum())} frames {nfo}", file=sys.stderr, flush=True)
+                    torch.cuda.synchronize(); barrier(); tq = time.perf_counter()
+                    rc_ = zk.lib.zk_gather_seekable(eng._h, shm_comm, rank, world, 0, e_comp.data_ptr(), written, h_cs.ctypes.data, h_ds.ctypes.data, nfo, 1,
+                                                    o.data_ptr() if rank == 0 else None, ocap if rank == 0 else 0, C.byref(nbytes), C.byref(tab), None)
+                    torch.cuda.synchronize(); barrier()
+                    tq = time.perf_counter() - tq
+                    if rc_ != 0:
+                        raise RuntimeError(f"zk_gather_seekable: {zk.error_name(rc_)}")
+                    if rank != 0:
+                        return None, None, tq
+                    return o[:nbytes.value], SeekTable(tab.value), tq
                 for _ in range(2):
                     barrier(); torch.cuda.synchronize(); t = time.perf_counter()
-                    out, table = parallel.encode_sharded(eng, d_src, FRAME, level, cks, root=0)
-                    torch.cuda.synchronize(); barrier(); tg.append(time.perf_counter() - t)
+                    out, table, tq = sharded()
+                    torch.cuda.synchronize(); barrier(); tg.append(time.perf_counter() - t); tx.append(tq)
                 # (r5) the gathered archive is one archive: the root decodes the LAST rank's last four frames out of it -- bytes that crossed a
                 # link, located through the gathered table -- and compares them with the generator's bytes for those chunks.  No collective
                 # here (nothing that could hang a peer); a failure is a field of the line, not the end of the run.
@@ -904,10 +1058,28 @@ def main():
                         s4 = torch.zeros(4, dtype=torch.int32, device=dev)
                         eng.decode_frames_dev(piece, c1 - c0, rel_c, rel_d, 0, 4, o4, 4 * FRAME, True, s4)
                         want4 = _zko.gen_chunks(4 * FRAME, first_f)       # rank r's chunk k is generator chunk r * nframes + k
-                        remote = {"frames": [first_f, nf_all], "bit_exact": bytes(o4[:4 * FRAME].cpu().numpy()) == want4 and int(s4.abs().sum().item()) == 0}
+                        got4 = bytes(o4[:4 * FRAME].cpu().numpy())
+                        remote = {"frames": [first_f, nf_all], "bit_exact": got4 == want4 and int(s4.abs().sum().item()) == 0}
+                        if not remote["bit_exact"]:
+                            remote["status"] = [int(x) for x in s4.cpu().numpy()]
+                            remote["first_difference"] = next((i for i in range(len(want4)) if got4[i] != want4[i]), None)
+                            # where the gathered stream stops being frames: the first bytes at every rank's first frame
+                            remote["table_bytes_per_rank"] = [int(tc[(r + 1) * nframes] - tc[r * nframes]) for r in range(world)]
+                            remote["magic_at_each_ranks_first_frame"] = [bytes(out[int(tc[r * nframes]):int(tc[r * nframes]) + 4].cpu().numpy()).hex() for r in range(world)]
                     except Exception as ex:                               # noqa: BLE001
                         remote = {"error": f"{type(ex).__name__}: {ex}"}
+                # what the exchange should take on xGMI (DESIGN "multi-GPU"): every peer has its own link into the root (~153 GB/s each way), so the
+                # W - 1 receives run side by side and the slowest peer's bytes bound the step; a ring, or receives served one after the other,
+                # would show as the SUM over the peers instead
+                peer_bytes = csize
                 box["info"] = {"encode_plus_gather_GiB_per_s": round(dsize * world / min(tg) / 2**30, 2), "ms": round(min(tg) * 1e3, 2),
+                               "gather_alone_ms": round(min(tx) * 1e3, 3),
+                               "gather_expectation": {"bytes_per_peer": peer_bytes, "peers": world - 1, "link_GB_s": 153,
+                                                      "ms_if_the_receives_overlap": round(peer_bytes / 153e9 * 1e3, 2),
+                                                      "ms_if_they_are_serialised": round(peer_bytes * (world - 1) / 153e9 * 1e3, 2),
+                                                      "note": "plus two small all-gathers (~0.1 ms) and the root's table (< 1 ms); this rank's own bytes stand for every peer's"},
+                               "transport": ("TEST: shared memory between processes on ONE GPU (--one-gpu-transport): the times mean nothing" if one_gpu
+                                             else "RCCL (torch.distributed, backend nccl)"),
                                "last_ranks_frames_decoded_from_the_gathered_archive": remote,
                                "frames_on_root": table.num_frames() if table is not None else None,
                                "stream_bytes_on_root": int(out.numel()) if out is not None else None,
@@ -985,7 +1157,23 @@ def main():
             if "speedup_vs_cpu_1thread" not in line:           # no reference-made leg in this run (N > 1, --no-ref-archive)
                 line["speedup_vs_cpu_1thread"] = line["speedup_vs_cpu_1thread_gpu_made_archive"]
                 line["speedup_note"] = "GPU and CPU both on the archive this engine's encoder wrote (no reference-made leg in this run)"
+        # the numbers a reader of the line's first 500 characters should find (the driver's tail truncates long lines): short scalars in front
+        def _g(d, *path):
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        front = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+        front.update({"reference_made_GiB_s": _g(ref_info, "value"), "reference_made_level3_GiB_s": _g(ref_info, "level_3", "value"),
+                      "encode_GiB_s": _g(enc_info, "value"), "round_trip_GiB_s": _g(line.get("round_trip"), "value"),
+                      "seek_p50_us": _g(seek_info, "gpu_made_archive", "gpu_decoder_us", "p50"), "seek_p50_us_reference_made": _g(seek_info, "reference_made_archive", "gpu_decoder_us", "p50"),
+                      "seek_p50_us_cpu_reference": _g(seek_info, "reference_made_archive", "cpu_reference_us", "p50"),
+                      "configs0_decoder_GiB_s": _g(c1_info, "decoder", "value"), "roofline_frac": round(achieved / HBM_PEAK_GBS, 5),
+                      "speedup_vs_cpu_1thread": line.get("speedup_vs_cpu_1thread"), "speedup_vs_cpu_all_cores": line.get("speedup_vs_cpu_all_cores")})
+        front.update({k: v for k, v in line.items() if k not in front})
+        line = front
         print(json.dumps(line), flush=True)
+    if shm_comm and not gather_hung:
+        shm_lib.zkshm_comm_destroy(shm_comm)
     if gather_failed:                                        # the line above carries the error; the run still fails
         if gather_hung:
             os._exit(1)                                       # a collective that never completes cannot be torn down politely

@@ -20,6 +20,10 @@
  *     (lib/src/error.rs:40-45); zeekstd's own kinds map to the ZK_ERR_* values below.
  *   - "_dev" entry points take DEVICE pointers (HBM resident) and a hipStream_t passed as
  *     void*; the plain ones take HOST pointers and stage through the engine's buffers.
+ *     The engine launches on its OWN queues (non-blocking streams; the stream argument, where
+ *     there is one, replaces the main one): work the caller still has in flight on other
+ *     streams for a buffer it passes -- the kernel that produces the input, the fill of a fresh
+ *     output -- must have completed before the call, as for any two unordered HIP streams.
  *   - there is no CPU fallback: if no gfx950 device is usable, zk_engine_create fails.
  */
 #ifndef ZEEKSTD_AMD_H
@@ -151,7 +155,8 @@ int zk_decode_frame_list_dev(zk_engine *e, const void *d_comp, uint64_t comp_siz
                              int verify, void *d_frame_status, void *stream);
 
 /* The decompressed sizes of frames whose seek entries the caller does not hold: header walk + sequence walks on the device, no output
- * (a frame that carries Frame_Content_Size answers from its header).  What libzstd's streaming decoder needs no table for
+ * (a frame that carries Frame_Content_Size is walked all the same and held to it: corruption_detected when its blocks make another
+ * size).  What libzstd's streaming decoder needs no table for
  * (lib/src/decode.rs:243-245: ZSTD_decompressStream is handed bytes, not entries); the Level-C shim asks here before
  * it decodes.  sizes[count] (uint64), frame_status[count] (0 or -ZSTD_ErrorCode).  _dev: device pointers, c_off relative to d_comp. */
 int zk_frame_content_sizes(zk_engine *e, const uint8_t *comp, uint64_t comp_size, const uint64_t *c_off, uint32_t first, uint32_t count,

@@ -89,7 +89,19 @@ static int run_decode(const std::vector<uint8_t> &stream, bool expect_clean)
             const size_t before = in.pos;
             const size_t r = ZSTD_decompressStream(d, &out, &in);
             if (in.pos > n || in.pos < before || out.pos > room) { fprintf(stderr, "positions out of range\n"); exit(3); }
-            if (ZSTD_isError(r)) { failed = true; break; }
+            if (ZSTD_isError(r)) {
+                // a context that has failed stays failed, with the SAME verdict, whatever it is shown next -- until it is reset (the
+                // second call used to compute a negative count of bytes to take)
+                for (int again = 0; again < 3; again++) {
+                    std::vector<uint8_t> more(1 + rnd() % 64, (uint8_t)rnd());
+                    ZSTD_inBuffer in2{more.data(), more.size(), 0};
+                    uint8_t ob2[16];
+                    ZSTD_outBuffer out2{ob2, sizeof ob2, 0};
+                    const size_t r2 = ZSTD_decompressStream(d, &out2, &in2);
+                    if (r2 != r || in2.pos != 0 || out2.pos != 0) { fprintf(stderr, "a failed context answered %zx after %zx\n", r2, r); exit(14); }
+                }
+                failed = true; break;
+            }
             ends += r == 0;
             if (out.pos == 0 && in.pos == before) { if (++idle > 3) { fprintf(stderr, "no progress\n"); exit(4); } } else idle = 0;
             if (++guard > 4000000) { fprintf(stderr, "runaway\n"); exit(5); }
@@ -191,6 +203,34 @@ int main(int argc, char **argv)
         }
         if (!ZSTD_isError(big) || ZSTD_getErrorCode(big) != 20 || ZSTD_isError(okb) || okb == 0 || !ZSTD_isError(win) || ZSTD_getErrorCode(win) != 20 ||
             !ZSTD_isError(rsv) || ZSTD_getErrorCode(rsv) != 14 || !ZSTD_isError(typ) || ZSTD_getErrorCode(typ) != 20) { fprintf(stderr, "header verdicts\n"); return 12; }
+    }
+    // 5. a context that failed works again after a session reset; a skippable frame (the seek table of an archive) is walked over, not kept
+    {
+        ZSTD_DCtx *d = ZSTD_createDCtx();
+        uint8_t ob[64];
+        std::vector<uint8_t> bad = {0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x58, 0x07, 0x00, 0x00};
+        ZSTD_inBuffer in{bad.data(), bad.size(), 0};
+        ZSTD_outBuffer out{ob, sizeof ob, 0};
+        if (!ZSTD_isError(ZSTD_decompressStream(d, &out, &in))) { fprintf(stderr, "expected an error\n"); return 15; }
+        ZSTD_DCtx_reset(d, 1);
+        const size_t payload = 6 * 1000 * 1000 + 123;
+        std::vector<uint8_t> skip(8 + payload, 0xAB);
+        const uint8_t h[8] = {0x5E, 0x2A, 0x4D, 0x18, (uint8_t)payload, (uint8_t)(payload >> 8), (uint8_t)(payload >> 16), (uint8_t)(payload >> 24)};
+        memcpy(skip.data(), h, 8);
+        size_t pos = 0, ends = 0, most = 0;
+        while (pos < skip.size()) {
+            const size_t want = 1 + rnd() % 70000, n = want < skip.size() - pos ? want : skip.size() - pos;
+            std::vector<uint8_t> chunk(skip.begin() + (long)pos, skip.begin() + (long)(pos + n));
+            ZSTD_inBuffer i2{chunk.data(), n, 0};
+            ZSTD_outBuffer o2{ob, sizeof ob, 0};
+            const size_t r = ZSTD_decompressStream(d, &o2, &i2);
+            if (ZSTD_isError(r) || o2.pos != 0 || i2.pos == 0) { fprintf(stderr, "skippable frame: %zx\n", r); return 16; }
+            ends += r == 0;
+            most = d->acc.capacity() > most ? d->acc.capacity() : most;
+            pos += i2.pos;
+        }
+        ZSTD_freeDCtx(d);
+        if (ends != 1 || most > 4096) { fprintf(stderr, "skippable frame: %zu ends, %zu bytes kept\n", ends, most); return 17; }
     }
     printf("shim fuzz: %d damaged streams, %llu frames shown to the engine, no report\n", cases, (unsigned long long)g_seen_frames);
     return 0;

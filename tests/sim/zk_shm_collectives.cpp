@@ -86,10 +86,14 @@ int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *c
     if (!c || !bytes || bytes > c->slot_bytes) return 5;                                  // ncclInvalidArgument
     g_last = c;
     if (hipStreamSynchronize(st) != hipSuccess) return 1;
-    if (hipMemcpy(c->slot(c->rank), send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    if (hipMemcpyAsync(c->slot(c->rank), send, bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
     if (barrier(c)) return 6;
+    // ON THE CALLER'S STREAM, and waited for: a blocking hipMemcpy out of pageable memory (this mapping) returns once the bytes are staged,
+    // not once they have landed, and the engine's next command on its (non-blocking) stream would read the destination too early -- found
+    // as a gather at world 8 whose third rank's frames were misplaced now and then (round 6)
     for (int r = 0; r < c->world; r++)
-        if (hipMemcpy((uint8_t *)recv + (size_t)r * bytes, c->slot(r), bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
+        if (hipMemcpyAsync((uint8_t *)recv + (size_t)r * bytes, c->slot(r), bytes, hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+    if (hipStreamSynchronize(st) != hipSuccess) return 1;
     return barrier(c) ? 6 : 0;
 }
 int ncclGroupStart(void) { if (g_in_group) return 5; g_in_group = true; g_ops.clear(); return 0; }
@@ -111,12 +115,13 @@ int ncclGroupEnd(void)
     for (const Op &o : g_ops) {
         if (!o.send) continue;
         if (++sends > 1 || o.bytes > c->slot_bytes) return 5;                              // one send per rank and group is all the gather does
-        if (hipStreamSynchronize(o.st) != hipSuccess) return 1;
-        if (hipMemcpy(c->slot(c->rank), o.buf, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        if (hipMemcpyAsync(c->slot(c->rank), o.buf, o.bytes, hipMemcpyDeviceToHost, o.st) != hipSuccess || hipStreamSynchronize(o.st) != hipSuccess) return 1;
     }
     if (barrier(c)) return 6;
     for (const Op &o : g_ops)
-        if (!o.send && hipMemcpy(o.buf, c->slot(o.peer), o.bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
+        if (!o.send && hipMemcpyAsync(o.buf, c->slot(o.peer), o.bytes, hipMemcpyHostToDevice, o.st) != hipSuccess) return 1;
+    for (const Op &o : g_ops)
+        if (!o.send && hipStreamSynchronize(o.st) != hipSuccess) return 1;
     return barrier(c) ? 6 : 0;
 }
 

@@ -262,3 +262,16 @@ def test_level_c_shim_exports_the_symbols_the_crate_binds():
             "ZSTD_getErrorName", "ZSTD_versionNumber", "ZSTD_versionString"}
     assert want <= have, want - have
     assert not {s for s in have if s.startswith("zk_")}, "the shim re-exports nothing of Level A"
+
+
+def test_a_collective_library_that_cannot_be_loaded_is_refused_at_once():
+    """zk_set_collective_library resolves the five entry points when it is called: a path that does not load, or a library without
+    them, is an error HERE -- and leaves the provider in force untouched -- not a generic failure of some later gather."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(ROOT, "zeekstd_amd", "libzeekstd_amd.so"))
+    lib.zk_set_collective_library.argtypes = [C.c_char_p]
+    lib.zk_set_collective_library.restype = C.c_int
+    assert lib.zk_set_collective_library(b"/nonexistent/libnothing.so") != 0
+    assert lib.zk_set_collective_library(b"libm.so.6") != 0            # loads, but has no ncclAllGather
+    assert lib.zk_set_collective_library(None) == 0                    # back to RCCL (resolved, present or not: a gather says so)
+    assert lib.zk_set_collective_library(b"") == 0

@@ -508,3 +508,38 @@ def test_frame_content_sizes_without_seek_entries(engine):
     sizes, st = engine.frame_content_sizes(bytes(bad), c)
     assert st[0] == 0 and int(sizes[0]) == frames[0][1] and all(int(s) == f[1] for s, f in zip(sizes[2:], frames[2:]))
     assert st[1] != 0 or int(sizes[1]) != frames[1][1] or True   # (a flipped bit may leave the size intact: the decode's checksum is what catches it)
+
+
+def test_frame_content_sizes_hold_the_blocks_against_frame_content_size(engine):
+    """A header that carries Frame_Content_Size does not answer for the frame: the blocks are walked all the same and their regenerated sum is
+    held against the field -- a one-shot frame whose FCS says one byte more, or less, than its blocks make is corruption_detected
+    (libzstd: "corrupted block detected" at the frame's end), not a size."""
+    seen = 0
+    for g in GOLDENS:
+        if not g.name.startswith("oneshot") or len(g.frames) != 1 or g.frames[0][1] < 300:
+            continue
+        f = bytearray(g.comp)
+        fhd = f[4]
+        fcs_flag, single, did = fhd >> 6, (fhd >> 5) & 1, fhd & 3
+        fl = single if fcs_flag == 0 else 1 << fcs_flag
+        at = 5 + (0 if single else 1) + (4 if did == 3 else did)
+        if fl not in (2, 4, 8) or single:        # (Single_Segment: the field is the window too, another check answers first)
+            continue
+        for delta in (1, -1):
+            bad = bytearray(f)
+            v = int.from_bytes(bad[at:at + fl], "little") + delta
+            bad[at:at + fl] = v.to_bytes(fl, "little")
+            sizes, st = engine.frame_content_sizes(bytes(bad), [0, len(bad)])
+            assert st[0] == -20 and int(sizes[0]) == 0, (g.name, delta, st[0], int(sizes[0]))
+        sizes, st = engine.frame_content_sizes(bytes(f), [0, len(f)])
+        assert st[0] == 0 and int(sizes[0]) == g.frames[0][1]
+        seen += 1
+    if not seen:                                  # every one-shot golden is Single_Segment: make a frame with a window descriptor AND an FCS by hand
+        payload = bytes(range(256)) * 3
+        h = 1 | (0 << 1) | (len(payload) << 3)
+        frame = b"\x28\xb5\x2f\xfd" + bytes([0x40, 0x58]) + (len(payload) - 256).to_bytes(2, "little") + h.to_bytes(3, "little") + payload
+        sizes, st = engine.frame_content_sizes(frame, [0, len(frame)])
+        assert st[0] == 0 and int(sizes[0]) == len(payload)
+        bad = bytearray(frame); bad[6] ^= 1
+        sizes, st = engine.frame_content_sizes(bytes(bad), [0, len(bad)])
+        assert st[0] == -20 and int(sizes[0]) == 0

@@ -60,7 +60,9 @@ def main():
         kernels[k] = {"fetch_kib": fk, "write_kib": wk, "fetch_correction": corr,
                       "hbm_bytes": int((fk * corr + wk) * 1024)}
     import datetime
-    doc = {"workload": workload, "collected": datetime.date.today().isoformat() + " from " + os.path.basename(os.path.normpath(fdir)) + " / " + os.path.basename(os.path.normpath(wdir)),
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import kernel_source_hashes         # what the counters were taken ON: bench.py nulls `traffic` once a kernel's sources differ
+    doc = {"workload": workload, "source_hashes": kernel_source_hashes(), "collected": datetime.date.today().isoformat() + " from " + os.path.basename(os.path.normpath(fdir)) + " / " + os.path.basename(os.path.normpath(wdir)),
            "note": "per launch (last dispatch of each kernel = the serialised per-kernel-timing step of bench.py); FETCH_SIZE x2 only where the access pattern was "
                    "calibrated as wide (zk_k_xxh64, zk_k_xxh64_wide); others uncorrected lower bounds",
            "kernels": kernels}
@@ -70,6 +72,7 @@ def main():
         with open(outp) as f:
             base = json.load(f)
         base[sys.argv[5]] = kernels
+        base.setdefault("section_source_hashes", {})[sys.argv[5]] = kernel_source_hashes()
         base["collected"] = base.get("collected", "") + "; " + sys.argv[5] + ": " + doc["collected"]
         doc = base
     with open(outp, "w") as f:

@@ -22,6 +22,10 @@
 // complete (it follows the block headers: it never takes a byte of the NEXT frame), asks the engine for the frame's size when the
 // header does not say (zk_frame_content_sizes -- zeekstd's own frames carry no Frame_Content_Size), decodes it (zk_decode_frames,
 // checksum verified) and hands the bytes out.  One engine call per frame: this is the compatibility proof, Level B is the fast path.
+// What follows from "e_continue emits nothing": the unmodified crate's FrameSizePolicy::Compressed(n) counts the bytes compressStream2 hands
+// out (encode.rs:340-351, 537-541) -- none before e_end -- so under this shim that policy never closes a frame on its own: frames end
+// where Uncompressed(n) / end_frame() / SEEKABLE_MAX_FRAME_SIZE end them (and a context buffers up to that: 1 GiB).  Compressed(n) is
+// honoured at Levels A / B only (host/encoder.cpp); INTEGRATION.md, Level C.
 // Return values follow zstd.h: size_t, an error is (size_t)-ZSTD_ErrorCode; compressStream2(e_end) returns 0 when the frame is out,
 // decompressStream returns 0 when a frame is decoded AND flushed (decode.rs:246-255 resets on exactly that).
 #include <stddef.h>
@@ -66,8 +70,11 @@ struct ZSTD_CCtx_s {
     const uint8_t *prefix = nullptr; size_t plen = 0;    // ZSTD_CCtx_refPrefix: kept by reference, for the next frame only (zstd.h)
 };
 struct ZSTD_DCtx_s {
-    std::vector<uint8_t> acc, out;                       // the frame's bytes so far; its decoded bytes
+    std::vector<uint8_t> acc, out;                       // the frame's bytes so far (a skippable frame: its 8-byte header at most); its decoded bytes
     size_t out_pos = 0;
+    size_t eaten = 0;                                    // bytes of the frame taken from the caller so far (== acc.size() unless the frame is skippable)
+    size_t failed = 0;                                   // the error this frame ended with: every call returns it until ZSTD_DCtx_reset (libzstd: a context
+                                                         // that has failed is unusable until it is reset)
     size_t next_hdr = 0;                                 // where the next block header starts (0: the frame header is not parsed yet)
     size_t total = 0;                                    // the frame's length once the last block's header was seen
     bool have = false;                                   // `out` holds the frame (its last input byte is still the caller's)
@@ -171,7 +178,7 @@ size_t ZSTD_freeDCtx(ZSTD_DCtx *d) { delete d; return 0; }
 static void dctx_next_frame(ZSTD_DCtx *d)
 {
     d->acc.clear(); d->out.clear(); d->out_pos = 0; d->next_hdr = 0; d->total = 0; d->have = false; d->skippable = false; d->cks = false; d->fcs = ~0ull;
-    d->block_max = 131072;
+    d->block_max = 131072; d->eaten = 0; d->failed = 0;
 }
 size_t ZSTD_DCtx_reset(ZSTD_DCtx *d, int directive)
 {
@@ -252,6 +259,8 @@ static size_t frame_need(ZSTD_DCtx *d, const View &a, size_t *err)
 size_t ZSTD_decompressStream(ZSTD_DCtx *d, ZSTD_outBuffer *out, ZSTD_inBuffer *in)
 {
     if (!d || !out || !in || out->pos > out->size || in->pos > in->size) return zerr(ZERR_GENERIC);
+    if (d->failed) return d->failed;
+#define ZK_FAIL(code) do { d->failed = (code); return d->failed; } while (0)
     if (!d->have) {
         // Take input -- never a byte beyond the frame, and not the frame's LAST byte either until its output is out: zeekstd's loop
         // stops calling once the input it holds is consumed (decode.rs:243 `in_buffer.pos() < in_len`), as libzstd leaves a block's
@@ -261,36 +270,43 @@ size_t ZSTD_decompressStream(ZSTD_DCtx *d, ZSTD_outBuffer *out, ZSTD_inBuffer *i
         const size_t avail = in->size - in->pos;
         size_t err;
         const size_t need = frame_need(d, View{d->acc.data(), d->acc.size(), src, avail}, &err);
-        if (err) return err;
-        const bool whole = d->total && d->acc.size() + avail >= d->total;   // the frame's last byte is in sight
-        const size_t take = whole ? d->total - 1 - d->acc.size() : avail;   // (acc never holds the last byte: take >= 0)
-        if ((uint64_t)d->acc.size() + take > MAX_FRAME + (MAX_FRAME >> 7) + 1024) return zerr(ZERR_SRC_SIZE_WRONG);
-        try { d->acc.insert(d->acc.end(), src, src + take); } catch (...) { return zerr(ZERR_MEMORY); }
+        if (err) ZK_FAIL(err);
+        // A skippable frame (a Foot seek table can be a GiB) is walked over, not kept: nothing of it is needed once its size field is read
+        const bool skip = d->skippable && d->total;
+        if (d->total && d->eaten >= d->total) ZK_FAIL(zerr(ZERR_GENERIC));   // (cannot happen: the last byte is only ever taken below)
+        const bool whole = d->total && d->eaten + avail >= d->total;        // the frame's last byte is in sight
+        const size_t take = whole ? d->total - 1 - d->eaten : avail;        // (eaten < total: take >= 0)
+        if (!skip) {
+            if ((uint64_t)d->acc.size() + take > MAX_FRAME + (MAX_FRAME >> 7) + 1024) ZK_FAIL(zerr(ZERR_SRC_SIZE_WRONG));
+            try { d->acc.insert(d->acc.end(), src, src + take); } catch (...) { ZK_FAIL(zerr(ZERR_MEMORY)); }
+        }
+        d->eaten += take;
         in->pos += take;
-        if (!whole) return need - d->acc.size();                            // a hint, as libzstd gives one
+        if (!whole) return need - d->eaten;                                 // a hint, as libzstd gives one
         d->out.clear(); d->out_pos = 0;
         if (!d->skippable) {
-            try { d->acc.push_back(src[take]); d->acc.resize(d->total + 8); } catch (...) { return zerr(ZERR_MEMORY); }   // a COPY of the last byte (in->pos stays) + readable padding (ZK_COMP_PADDING)
+            try { d->acc.push_back(src[take]); d->acc.resize(d->total + 8); } catch (...) { ZK_FAIL(zerr(ZERR_MEMORY)); }   // a COPY of the last byte (in->pos stays) + readable padding (ZK_COMP_PADDING)
             uint64_t c_off[2] = {0, d->total}, d_off[2] = {0, 0};
             int32_t st = 0;
             int rc;
             std::lock_guard<std::mutex> lk(g_mu);
             zk_engine *e;
-            if ((rc = engine(&e))) return from_zk(rc);
+            if ((rc = engine(&e))) ZK_FAIL(from_zk(rc));
             uint64_t dsz = d->fcs;
             if (dsz == ~0ull) {                                              // no Frame_Content_Size (zeekstd's own frames): the engine walks the frame
-                if ((rc = zk_frame_content_sizes(e, d->acc.data(), d->total, c_off, 0, 1, &dsz, &st))) return from_zk(rc);
-                if (st) return from_zk(st);
+                if ((rc = zk_frame_content_sizes(e, d->acc.data(), d->total, c_off, 0, 1, &dsz, &st))) ZK_FAIL(from_zk(rc));
+                if (st) ZK_FAIL(from_zk(st));
             }
-            if (dsz > MAX_FRAME) return zerr(ZERR_PARAM_UNSUPPORTED);
+            if (dsz > MAX_FRAME) ZK_FAIL(zerr(ZERR_PARAM_UNSUPPORTED));
             d_off[1] = dsz;
-            try { d->out.resize((size_t)dsz + 64); } catch (...) { return zerr(ZERR_MEMORY); }
+            try { d->out.resize((size_t)dsz + 64); } catch (...) { ZK_FAIL(zerr(ZERR_MEMORY)); }
             rc = zk_decode_frames_prefix(e, d->acc.data(), d->total, c_off, d_off, 0, 1, d->prefix, d->plen, d->out.data(), d->out.size(), 1, &st);
-            if (rc) return from_zk(st ? st : rc);
+            if (rc) ZK_FAIL(from_zk(st ? st : rc));
             d->out.resize((size_t)dsz);
         }
         d->have = true;
     }
+#undef ZK_FAIL
     const size_t room = out->size - out->pos, left = d->out.size() - d->out_pos, k = room < left ? room : left;
     if (k) memcpy((uint8_t *)out->dst + out->pos, d->out.data() + d->out_pos, k);
     out->pos += k; d->out_pos += k;

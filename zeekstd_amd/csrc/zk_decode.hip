@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64) void zk_k_walk(const uint8_t *comp, uint64_t co
     uint64_t dsz = d_off ? d_off[id + 1] - d_off[id] : ZK_SIZE_UNKNOWN;
     ZkFrameInfo fi;
     if (!bases && !d_off) {
-        if (ce < cb || ce > comp_size) { fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; fi.status = ZK_E_SRC_SIZE_WRONG; fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.n_own_tables = 0; }
+        if (ce < cb || ce > comp_size) { fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; fi.status = ZK_E_SRC_SIZE_WRONG; fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.n_own_tables = 0; fi.fcs = ZK_SIZE_UNKNOWN; }
         else zk_walk_frame(comp, cb, ce, dsz, f, nullptr, nullptr, fi);
         if (fi.status != ZK_OK) { fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; }
         infos[f] = fi;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64) void zk_k_walk(const uint8_t *comp, uint64_t co
         const uint64_t o = out_off ? out_off[f] : d_off[id] - d_off[first];
         if (ce < cb || ce > comp_size || d_off[id + 1] < d_off[id]) {
             fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; fi.status = ZK_E_SRC_SIZE_WRONG;
-            fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.n_own_tables = 0;
+            fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.n_own_tables = 0; fi.fcs = ZK_SIZE_UNKNOWN;
             infos[f] = fi;
             return;
         }
@@ -1961,6 +1961,9 @@ __global__ __launch_bounds__(256) void zk_k_frame_sizes(const ZkFrameInfo *infos
             sum += b[i].out_size;
         }
         if (st == ZK_OK && sum > ZK_MAX_FRAME) st = ZK_E_FRAMEPARAM_UNSUPPORTED;
+        // a header that carries Frame_Content_Size is held to it: what the blocks regenerate IS the frame's size (libzstd: "corrupted block
+        // detected" when the two differ at the frame's end) -- the answer never comes from the header alone
+        if (st == ZK_OK && infos[f].fcs != ZK_SIZE_UNKNOWN && infos[f].fcs != sum) st = ZK_E_CORRUPTION;
     }
     sizes[f] = st == ZK_OK ? sum : 0;
     status_out[f] = -(int32_t)st;
@@ -2028,7 +2031,7 @@ __global__ __launch_bounds__(256) void zk_k_small_walk(const uint8_t *h_comp, ui
     __syncthreads();
     const uint64_t *c_off = d_offs, *d_off = d_offs + count + 1;
     ZkFrameInfo fi;
-    fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; fi.status = ZK_OK; fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.n_own_tables = 0;
+    fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; fi.status = ZK_OK; fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.n_own_tables = 0; fi.fcs = ZK_SIZE_UNKNOWN;
     uint64_t cb = 0, ce = 0, dsz = 0;
     if (tid < count) {
         cb = c_off[tid]; ce = c_off[tid + 1]; dsz = d_off[tid + 1] - d_off[tid];

@@ -84,6 +84,7 @@ struct ZkFrameInfo {            // written by the frame walker, one per frame
     uint32_t window;            // clamped to 2^31
     uint32_t n_own_tables;      // blocks that DEFINE a sequence table (FSE_Compressed / RLE mode): how much zk_k_fse_quad may have to do
                                 // (blocks that only repeat or use predefined tables share them with their neighbours: zk_k_fse_predef)
+    uint64_t fcs;               // Frame_Content_Size where the header carries one, else ZK_SIZE_UNKNOWN (zk_k_frame_sizes holds the blocks' sum against it)
 };
 
 struct ZkFrameBase {            // exclusive prefix sums over frames
@@ -671,7 +672,7 @@ ZK_HD void zk_walk_frame(const uint8_t *comp, uint64_t c_begin, uint64_t c_end, 
                          uint32_t frame_idx, const ZkFrameBase *base, ZkBlock *blocks, ZkFrameInfo &fi)
 {
     fi.n_blocks = 0; fi.n_seq = 0; fi.lit_bytes = 0; fi.status = ZK_OK;
-    fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.n_own_tables = 0;
+    fi.checksum_flag = 0; fi.checksum = 0; fi.window = 0; fi.n_own_tables = 0; fi.fcs = ZK_SIZE_UNKNOWN;
     uint64_t csz = c_end - c_begin;
     const uint8_t *f = comp + c_begin;
     if (csz < 6) { fi.status = ZK_E_SRC_SIZE_WRONG; return; }
@@ -697,6 +698,7 @@ ZK_HD void zk_walk_frame(const uint8_t *comp, uint64_t c_begin, uint64_t c_end, 
     for (uint32_t i = 0; i < fl; i++) fcs |= (uint64_t)f[p + i] << (8 * i);
     if (fl == 2) fcs += 256;
     p += fl;
+    if (fl) fi.fcs = fcs;
     if (single) window = fcs;
     // d_size == ZK_SIZE_UNKNOWN: a frame nobody holds a seek entry for (zk_frame_content_sizes: the walk + the sequence walks then tell
     // its size); the bounds below are taken against the largest frame the format of the reference allows

@@ -885,21 +885,25 @@ __global__ __launch_bounds__(256) void zk_k_enc_ldm_build_frames(const uint8_t *
         }
     }
 }
-void zk_launch_enc_ldm_build_frames(hipStream_t st, const uint8_t *src, const ZkEncLdm &ldm, uint32_t *table, uint32_t nframes)
+// (both return the HIP verdict of clearing the table: a table that was not cleared holds an earlier call's positions, and the matcher
+//  would follow them -- ADVICE r4 / r5)
+int zk_launch_enc_ldm_build_frames(hipStream_t st, const uint8_t *src, const ZkEncLdm &ldm, uint32_t *table, uint32_t nframes)
 {
-    (void)hipMemsetAsync(table, 0xFF, ((size_t)nframes * sizeof(uint32_t)) << ldm.log, st);
+    if (hipMemsetAsync(table, 0xFF, ((size_t)nframes * sizeof(uint32_t)) << ldm.log, st) != hipSuccess) return -1;
     const uint64_t wgs = ((uint64_t)ldm.frame_size + 4095) / 4096;
     // a grid's y dimension ends at 65535 (4 GiB of 64 KiB frames are 65536 of them): frames in launches of at most that many
     for (uint32_t f0 = 0; f0 < nframes; f0 += 65535u) {
         const uint32_t cnt = nframes - f0 < 65535u ? nframes - f0 : 65535u;
         hipLaunchKernelGGL(zk_k_enc_ldm_build_frames, dim3((uint32_t)(wgs < 1024 ? wgs : 1024), cnt), dim3(256), 0, st, src, ldm, table, f0);
     }
+    return 0;
 }
-void zk_launch_enc_ldm_build(hipStream_t st, const ZkEncLdm &ldm, uint32_t *table)
+int zk_launch_enc_ldm_build(hipStream_t st, const ZkEncLdm &ldm, uint32_t *table)
 {
-    (void)hipMemsetAsync(table, 0xFF, sizeof(uint32_t) << ldm.log, st);
+    if (hipMemsetAsync(table, 0xFF, sizeof(uint32_t) << ldm.log, st) != hipSuccess) return -1;
     const uint64_t n = ldm.plen - ldm.u0, wgs = (n + 1023) / 1024;
     hipLaunchKernelGGL(zk_k_enc_ldm_build, dim3((uint32_t)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, st, ldm, table);
+    return 0;
 }
 void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *segs, uint32_t nsegs, ZkEncBlock *blocks, uint64_t *seqs, uint8_t *lits, int level, const ZkEncLdm &ldm)
 {

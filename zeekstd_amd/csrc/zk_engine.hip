@@ -442,7 +442,10 @@ extern "C" int zk_decode_frame_list_dev(zk_engine *e, const void *d_comp, uint64
 // What libzstd's streaming decoder needs no table for -- how many bytes a frame decodes to -- this engine is told by the seek table
 // (lib/src/seek_table.rs:750).  A host that holds frames WITHOUT their entries (the Level-C shim under an unmodified zeekstd hands
 // over what ZSTD_decompressStream receives, lib/src/decode.rs:243-245) asks first: header walk + sequence walks, no literals, no
-// output.  Frames that carry Frame_Content_Size answer from their header.
+// output.  A frame that carries Frame_Content_Size is walked like any other and its blocks' sum is held against the header's field
+// (zk_k_frame_sizes: corruption_detected when they differ) -- the sizes reported are always what the blocks regenerate.
+// (The host-pointer variant below relies on context 0's queue being the engine's own stream: its uploads and this call's kernels are
+//  one queue, in order.)
 extern "C" int zk_frame_content_sizes_dev(zk_engine *e, const void *d_comp, uint64_t comp_size, const void *d_c_off, uint32_t first, uint32_t count,
                                           void *d_sizes, void *d_frame_status, void *stream)
 {

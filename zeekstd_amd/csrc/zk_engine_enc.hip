@@ -119,14 +119,14 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         // in-frame far history (level >= 2, no prefix, frames beyond the ring's reach): one table per frame over its own bytes
         ldm.inframe = 1; ldm.frame_size = frame_size; ldm.n_total = a.n; ldm.log = zke_ldm_log(frame_size < a.n ? frame_size : a.n);
         if ((rc = zk_devbuf_reserve(e, e->enc_ldm, (((size_t)nf * sizeof(uint32_t)) << ldm.log) + 64))) return rc;
-        zk_launch_enc_ldm_build_frames(st, src, ldm, (uint32_t *)e->enc_ldm.p, nf);
+        if (zk_launch_enc_ldm_build_frames(st, src, ldm, (uint32_t *)e->enc_ldm.p, nf)) { e->last_err = "hipMemsetAsync (in-frame long-distance table)"; return ZK_ERR_HIP; }
         ldm.table = (const uint32_t *)e->enc_ldm.p;
     }
     if (hist && a.prefix_len > ZKE_WINDOW) {
         const uint64_t usable = zke_ldm_usable(a.prefix_len);
         ldm.pfx = (const uint8_t *)a.d_prefix; ldm.plen = a.prefix_len; ldm.u0 = a.prefix_len - usable; ldm.log = zke_ldm_log(usable);
         if ((rc = zk_devbuf_reserve(e, e->enc_ldm, (sizeof(uint32_t) << ldm.log) + 64))) return rc;
-        zk_launch_enc_ldm_build(st, ldm, (uint32_t *)e->enc_ldm.p);
+        if (zk_launch_enc_ldm_build(st, ldm, (uint32_t *)e->enc_ldm.p)) { e->last_err = "hipMemsetAsync (long-distance table)"; return ZK_ERR_HIP; }
         ldm.table = (const uint32_t *)e->enc_ldm.p;
     }
     // the matcher's workgroups are launched over the segments (one per <= 256 KiB of a frame)

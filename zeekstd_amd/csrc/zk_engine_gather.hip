@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/zeekstd_amd.h"
@@ -33,18 +34,21 @@ typedef int (*allgather_fn)(const void *, void *, size_t, int, void *, hipStream
 typedef int (*sendrecv_fn)(void *, size_t, int, int, void *, hipStream_t);
 typedef int (*group_fn)(void);
 struct Rccl { allgather_fn all_gather = nullptr; sendrecv_fn send = nullptr, recv = nullptr; group_fn group_start = nullptr, group_end = nullptr; bool ok = false; };
+// Who provides the five entry points: resolved ONCE per naming, under a lock, into a table that is published whole (a gather on another
+// thread sees the old table or the new one, never half of one) -- and eagerly, so that a library that cannot be loaded is an error of
+// zk_set_collective_library, not a generic one of some later gather.
+std::mutex g_mu;
 std::string g_collective_path;            // zk_set_collective_library: which library provides the five entry points ("" = RCCL)
-bool g_tried = false;
-Rccl &rccl()
+bool g_resolved = false;
+Rccl g_table;
+Rccl resolve(const std::string &path)
 {
-    static Rccl r;
-    if (g_tried) return r;
-    g_tried = true;
+    Rccl r;
     void *h = nullptr;
-    const bool named = !g_collective_path.empty();
+    const bool named = !path.empty();
     // a named library is asked first and alone; otherwise symbols already in the process (a host that linked RCCL), then librccl.so.1
     auto sym = [&](const char *n) { void *p = named ? nullptr : dlsym(RTLD_DEFAULT, n); if (!p && h) p = dlsym(h, n); return p; };
-    if (named) h = dlopen(g_collective_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (named) h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
     else if (!dlsym(RTLD_DEFAULT, "ncclAllGather")) {
         h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -57,16 +61,27 @@ Rccl &rccl()
     r.ok = r.all_gather && r.send && r.recv && r.group_start && r.group_end;
     return r;
 }
+Rccl rccl()                                // a copy: five pointers and a flag
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_resolved) { g_table = resolve(g_collective_path); g_resolved = true; }
+    return g_table;
+}
 enum { kUint8 = 1, kUint32 = 3, kUint64 = 5 };           // ncclDataType_t (rccl.h)
 }  // namespace
 
 // Which shared library provides ncclAllGather / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd for zk_gather_seekable: NULL or ""
-// = RCCL (the default).  Process-wide, to be called before the first gather (later calls re-resolve).  Replaces round 4's environment
+// = RCCL (the default).  Process-wide; resolved at once (an unloadable library is refused here: ZK_ERR_ARGUMENT, the provider in force stays), safe against gathers on other threads.  Replaces round 4's environment
 // variable: the library reads no environment.
 extern "C" int zk_set_collective_library(const char *path)
 {
-    g_collective_path = path ? path : "";
-    g_tried = false;
+    const std::string want = path ? path : "";
+    Rccl r = resolve(want);                 // (outside the lock: dlopen may take its time)
+    if (!want.empty() && !r.ok) return ZK_ERR_ARGUMENT;      // a named library that cannot be loaded, or lacks one of the five: nothing changes
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_collective_path = want;
+    g_table = r;
+    g_resolved = true;                      // (RCCL itself may be absent on a single-GPU host: that stays an error of the gather that needs it)
     return 0;
 }
 
@@ -78,7 +93,7 @@ extern "C" int zk_gather_seekable(zk_engine *e, void *nccl_comm, int rank, int w
     if (table_out) *table_out = nullptr;
     if (!e || !nccl_comm || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || (payload_bytes && !d_payload) ||
         (n_frames && (!c_sizes || !d_sizes))) return ZK_ERR_ARGUMENT;
-    Rccl &R = rccl();
+    const Rccl R = rccl();
     if (!R.ok) { e->last_err = "RCCL (librccl.so.1) could not be loaded"; return ZK_ERR_HIP; }
     ZK_HIP(hipSetDevice(e->device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;

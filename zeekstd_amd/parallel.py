@@ -95,8 +95,13 @@ def encode_sharded(engine, d_src: torch.Tensor, frame_size: int, level: int = 1,
     nf = max(1, -(-n // frame_size))
     dev = d_src.device
     d_comp = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
-    d_cs = torch.zeros(nf, dtype=torch.int32, device=dev)
-    d_ds = torch.zeros(nf, dtype=torch.int32, device=dev)
+    d_cs = torch.empty(nf, dtype=torch.int32, device=dev)                    # (the engine writes every entry: no fill kernel of torch's to race with)
+    d_ds = torch.empty(nf, dtype=torch.int32, device=dev)
+    # The engine works on ITS queue (a non-blocking stream): whatever torch still has in flight on the caller's stream for these buffers --
+    # the kernel that produced d_src, a fill of a fresh tensor -- must have finished before the call.  (Found on one GPU shared by eight
+    # ranks: a delayed torch.zeros() landed on top of the seek entries the encoder had just written.)
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
     nfo, written = engine.encode_frames_dev(d_src, n, frame_size, level, checksum, d_comp, cap, d_cs, d_ds)
     return gather_seekable(d_comp[:written], d_cs[:nfo], d_ds[:nfo], root, group, fmt, out_cap)
 
