@@ -28,6 +28,8 @@ VARIANTS = {
     "fed_exec256_checksums_follow": dict(fse_shared=2, exec_lanes=256, exec_ring=1, xxh64=4, small_path=1),
     "exec256_five_resident_checksums_follow": dict(exec_lanes=256, exec_resident=5, xxh64=4, small_path=1),
     "exec1024_checksums_follow": dict(exec_lanes=1024, xxh64=4, small_path=1),
+    # 512-lane tiles (what batches of dense sequence streams get: libzstd's level 3 and up)
+    "exec512_wide_checksums": dict(exec_lanes=512, xxh64=2, small_path=1),
 }
 
 

@@ -10,7 +10,7 @@ import bench
 from oracle import zko
 
 CHOICES = [("default", {}), ("t256_ring2", {"exec_lanes": 256, "exec_ring": 1}), ("t256_ring4", {"exec_lanes": 256, "exec_ring": 2}),
-           ("t512", {"exec_lanes": 512}), ("t1024", {"exec_lanes": 1024}), ("t128", {"exec_lanes": 128})]
+           ("t512", {"exec_lanes": 512}), ("t1024", {"exec_lanes": 1024}), ("t128", {"exec_lanes": 128})]     # (round 6 also timed exec_far = the sources of far matches touched ahead: slower, removed -- profiles/r06_l3_far_touch_probe.txt)
 
 
 def main():

@@ -844,6 +844,16 @@ __device__ __forceinline__ void zk_publish(uint64_t *word, uint32_t bytes, uint6
     __hip_atomic_store(word, flags | ((uint64_t)(zk_xcc_id() + 1) << 32) | bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // REDO: only the frames zk_k_exec_seg gave up on (ZK_E_SEG_OVERFLOW: more hole records than their region holds) are executed, from scratch
+// (Measured and dropped, round 6: touching the sources of FAR matches ahead of time.  A record that was settled into the ring -- one to two
+//  tiles before its bytes are gathered -- with a match more than 24 KiB back had the line of its source requested by a load nobody waits
+//  for (global_load_lds_dword into a scratch row of LDS, issued behind the tile's store: the next wait for memory is a tile later).  On
+//  4 GiB of the reference's level-3 frames (window = the frame, 28 % of the offsets beyond 64 KiB): 512-lane tiles 15.87 -> 16.61 ms,
+//  256-lane tiles with a ring of 4 T 17.06 -> 17.78 ms; level 1: 9.39 -> 9.55 / 9.46 -> 9.65 ms.  Slower everywhere: the executor does
+//  not sit waiting for those lines -- five workgroups per CU cover each other's misses -- it is the NUMBER of lines that costs
+//  (profiles/r05_ref3_pmc_fetch_write.txt: 23 GiB fetched for 4 GiB of output), and a touch that is evicted before its gather fetches
+//  the line twice.  What did help there: fewer frames resident, zk_launch_exec.  profiles/r06_l3_far_touch_probe.txt.
+//  A first form of the touch -- a byte load into a "sink" register -- faulted: the compiler reuses a register it does not know a load
+//  is still going to write.)
 template <int T, bool PFX, int CAPX = 2, bool REDO = false>
 __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
                                                const uint32_t *ids, const uint64_t *out_off,
@@ -2204,7 +2214,11 @@ void zk_launch_exec(hipStream_t st, const uint8_t *comp, const uint64_t *d_off, 
     // 2-wave workgroups per CU hold all 2048 frames in one round -- but leave no room for the neighbouring batch: with two
     // batches in flight the step is 18.8 ms against 17.2.  1024 frames: 256 lanes 4.95 ms, 128 lanes 6.9; 512 -> 512, 128 -> 1024)
 #define ZK_EXEC_LAUNCH(TT, PP, CC) hipLaunchKernelGGL((zk_k_exec<TT, PP, CC>), dim3(count), dim3(TT), (TT) == 256 ? pad : 0, st, comp, d_off, first, ids, out_off, blocks, bases, infos, seqs, lit, dst, prefix, plen, progress)
-    const int lanes = k.exec_lanes ? k.exec_lanes : count >= 1024 ? 256 : count >= 256 ? 512 : 1024;
+    // ... and what a frame's matches reach: dense sequence streams (fewer than 10 output bytes per sequence: libzstd from level 3 up, whose
+    // window is the whole 2 MiB frame -- every far match a line from beyond the L2) run better with FEWER frames resident: 512-lane tiles
+    // hold 512 frames' histories live instead of 1 280 (4 GiB of the reference's level-3 frames: executor 17.0 -> 15.6 ms, the step with
+    // two batches in flight 30.6 -> 29.5 ms; level 1, whose matches stay near: 8.4 -> 9.3 ms -- hence only there; tools/gpu_calls/r6a.sh, r6n.sh)
+    const int lanes = k.exec_lanes ? k.exec_lanes : count >= 1024 ? (dense ? 512 : 256) : count >= 256 ? 512 : 1024;
     // 93 registers and 31 000 bytes of LDS: five 256-lane workgroups per CU.  Four of them leave 128 registers on every SIMD (room for
     // checksum waves, zk_k_xxh64_follow); a launch that asks for 2.5 KiB more LDS than the kernel uses gets four
     const uint32_t pad = k.exec_resident == 4 ? 2560u : 0u;

@@ -54,6 +54,13 @@ __device__ __forceinline__ void zke_runs2(const uint32_t x[5], uint32_t &r0, uin
 // keeps a value's computation where it is written (the compiler otherwise sinks it behind the condition that selects it: a branch)
 #define ZKE_KEEP(x) asm volatile("" : "+v"(x))
 #endif
+// (Measured and dropped, round 6 -- VERDICT r5 "next" 2a: the walk off the scalar unit.  The chain's pointers are per-lane values, so its
+//  powers are too: n2 = n1 o n1, n4, n8 by three rounds of ds_bpermute, beside each the 64-bit SET of slots the jump passes; the scalar
+//  loop then takes 8 instructions per EIGHT steps (three v_readlane, two s_or, compare, wait state, branch) instead of 5 per step.  Same
+//  sequences (emulator + twin), 81 GPU tests green -- and the same speed: 29.3 / 29.6 ms against 29.6 (tables per pass / for both passes
+//  at once); phase clocks: the walk 1 780 / 1 690 clocks per group and wave (2 600 before), the sweep in front of it 1 350 (600): the 14
+//  ds_bpermute + ~60 vector instructions of the tables cost what the loop saved.  Every unit is near one instruction per turn (DESIGN
+//  5.2e): moving work between them does not shorten the kernel.  tools/gpu_calls/r6o.sh ... r6q.sh, gpurun_out -> profiles/r06_enc_walk8.txt)
 #ifndef ZKE_WALK
 #define ZKE_WALK(taken, f, nx) asm volatile("1:\n\ts_bitset1_b64 %0, %1\n\ts_nop 0\n\tv_readlane_b32 %1, %2, %1\n\ts_cmp_lt_u32 %1, 64\n\ts_cbranch_scc1 1b" \
                                             : "+s"(taken), "+s"(f) : "v"(nx) : "scc")
