@@ -457,6 +457,26 @@ static int zk_decode_small(zk_engine *e, zk_hostpipe *hp, const zk_host_src &src
         ZK_HIP(hipEventRecord(x.ev_fork, st));
         ZK_HIP(hipStreamWaitEvent(x.aux, x.ev_fork, 0));
     }
+    // long frames (a read of one or two 2 MiB frames -- zeekstd's default frame size): the executor in segments, several workgroups per
+    // frame (zk_k_seg_prep / zk_k_exec_seg / zk_k_exec_fill_lds: 1.37 -> 0.6 ms for a 2 MiB frame); the host knows the frames' sizes here
+    const bool seg = !d_prefix && e->choice.exec_seg != 1 && (e->choice.exec_seg == 2 || dsz >= (uint64_t)count * (4u * ZK_SEG_BYTES));
+    if (seg) {
+        zk_engine::DecCtx &x = e->dctx[0];
+        ZkSegScratch sgs{};
+        uint64_t max_frame = 0;
+        for (uint32_t k = 0; k < count; k++) { const uint64_t d = d_off[first + k + 1] - d_off[first + k]; max_frame = d > max_frame ? d : max_frame; }
+        sgs.seg_bytes = e->choice.seg_kib ? (uint32_t)e->choice.seg_kib << 10 : ZK_SEG_BYTES;
+        sgs.max_segs = 2u * (uint32_t)((max_frame + sgs.seg_bytes - 1) / sgs.seg_bytes) + 1u;
+        const uint64_t nsg = (uint64_t)count * sgs.max_segs;
+        if ((rc = zk_devbuf_reserve(e, x.seg_tab, (size_t)nsg * sizeof(ZkSeg)))) return rc;
+        if ((rc = zk_devbuf_reserve(e, x.seg_cnt, (size_t)(nsg + count) * sizeof(uint32_t)))) return rc;
+        if ((rc = zk_devbuf_reserve(e, x.seg_holes, (size_t)((dsz >> 2) + 16 * nsg + 16) * sizeof(ZkHole)))) return rc;
+        if ((rc = zk_devbuf_reserve(e, x.seg_tiles, (size_t)((dsz >> 10) + 2 * (uint64_t)block_cap + 8 * nsg + 16) * sizeof(uint32_t)))) return rc;
+        sgs.segs = (ZkSeg *)x.seg_tab.p; sgs.nsegs = (uint32_t *)x.seg_cnt.p; sgs.segn = sgs.nsegs + count;
+        sgs.holes = (ZkHole *)x.seg_holes.p; sgs.tilecnt = (uint32_t *)x.seg_tiles.p;
+        zk_launch_exec_seg(st, comp, d_offs + count + 1, 0, count, nullptr, nullptr, blocks, (const ZkFrameBase *)c.bases.p, infos, (const ZkSeqP *)c.seqs.p,
+                           (const uint8_t *)c.lit.p, (uint8_t *)s.d_out.p, sgs, e->choice, false, prog);
+    } else
     zk_launch_exec(st, comp, d_offs + count + 1, 0, count, nullptr, nullptr, blocks, (const ZkFrameBase *)c.bases.p, infos, (const ZkSeqP *)c.seqs.p,
                    (const uint8_t *)c.lit.p, (uint8_t *)s.d_out.p, (const uint8_t *)d_prefix, d_prefix ? prefix_len : 0, e->choice, false, prog);
     if (prog) {
