@@ -1475,6 +1475,10 @@ __global__ __launch_bounds__(L) void zk_k_exec_fill(const uint64_t *d_off, uint3
 //   E  the image -> memory.
 // A record moves as two 8-byte reads and its bytes as byte writes (a run is 1 ... 16 bytes at any alignment; the image's neighbours
 // belong to other lanes).  Other shapes take the tile loop with their records from memory.  One workgroup of L = 1024 lanes per frame.
+// (Measured, round 6: a 2 MiB frame = 16 turns of ~26 us = 0.42 ms.  A turn rebuilt as TWO trips to memory -- every segment's place and
+//  tile counts read ahead, the image by LDS DMA in the same trip as the records, the stores of the turn before waited out by the loads
+//  behind them -- took the same 0.42 ms (tools/gpu_calls/r6v.sh): the turn is what its 16 waves issue for ~11 000 runs of ~5 bytes, byte
+//  writes each, not what it waits for.  The simpler form stays.)
 constexpr int ZK_FILL_NT = 12;
 constexpr uint32_t ZK_FILL_IMG = ZK_SEG_BYTES + 48;                              // up to 15 bytes of alignment in front, 16-byte reads behind
 // bytes [lo, hi) of the 16-byte value (w0, w1) -> img[at + lo .. at + hi)
