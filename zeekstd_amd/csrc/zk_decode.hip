@@ -1523,13 +1523,21 @@ __device__ __forceinline__ void zk_fill_from_image(ZkHole r, uint32_t seg_pos, u
     }
     zk_img_put(img, d - ibase, lo, mine ? n : 0u, w0, w1);
 }
+// A TURN of the kernel = as many consecutive segments as fit the image (one 128 KiB segment of a long frame; all sixteen 4 KiB blocks of a
+// 64 KiB frame: a seek): their bytes loaded once, their tiles in order -- segment after segment -- image -> image, the bytes stored once.
+// The frame's first ZK_FILL_META segment descriptors and tile counts are read ahead into LDS (a turn of several segments would
+// otherwise pay a trip to memory per segment before it can ask for that segment's records).
+constexpr uint32_t ZK_FILL_META = 64, ZK_FILL_TC = 16;
 template <int L>
 __global__ __launch_bounds__(L) void zk_k_exec_fill_lds(const uint64_t *d_off, uint32_t first, const uint32_t *ids, const uint64_t *out_off, const ZkFrameBase *bases,
                                                         const ZkFrameInfo *infos, uint8_t *dst, const ZkSeg *segs, const uint32_t *nsegs, uint32_t max_segs,
                                                         const ZkHole *holes, const uint32_t *tilecnt, const uint32_t *segn, uint64_t *progress)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t img[ZK_FILL_IMG];            // frame byte p of the segment at [p - ibase]
+    __shared__ __attribute__((aligned(16))) uint8_t img[ZK_FILL_IMG];            // frame byte p of the turn at [p - ibase]
     __shared__ uint32_t s_cnt[L];
+    __shared__ uint32_t s_meta[ZK_FILL_META][4];                                 // pos, out, first block, tiles with records
+    __shared__ uint32_t s_tc[ZK_FILL_META][ZK_FILL_TC];
+    static_assert(L >= (int)(ZK_FILL_META * ZK_FILL_TC), "one lane per tile count read ahead");
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
     if (zk_uni(infos[f].status) != ZK_OK) {
         if (progress && tid == 0) zk_publish(progress + f, 0, ZK_PROG_ABORT);
@@ -1543,70 +1551,99 @@ __global__ __launch_bounds__(L) void zk_k_exec_fill_lds(const uint64_t *d_off, u
     uint8_t *out = zk_uni(dst + frame_off);
     const uint64_t block_base = zk_uni(bases[f].block_base);
     const uint32_t ns = zk_uni(nsegs[f]);
-    for (uint32_t j = 0; j < ns; j++) {
-        const uint64_t seg_no = (uint64_t)f * max_segs + j;
-        const ZkSeg &sg = segs[seg_no];
-        const uint32_t seg_pos = zk_uni(sg.pos), seg_out = zk_uni(sg.out);
-        const uint32_t nt = zk_uni(segn[seg_no]);
-        if (!nt) { final_to = seg_pos + seg_out; continue; }                     // (no holes: pass 1 left it complete)
-        const ZkHole *rec = zk_uni(holes + zk_seg_region(frame_off, seg_pos, seg_no));
-        const uint32_t *tc = zk_uni(tilecnt + zk_seg_tile_region(frame_off, seg_pos, block_base + zk_uni(sg.b0), seg_no));
-        const uint32_t shift = (uint32_t)((uintptr_t)(out + seg_pos) & 15u), ibase = seg_pos - shift, total = shift + seg_out;
-        const uint8_t *A = out + seg_pos - shift;                                // 16-byte aligned; image byte i <-> A[i]
-        uint8_t *Aw = out + seg_pos - shift;
-        __syncthreads();                                                         // (the segment before: its image stored and the stores waited out, s_cnt read)
+    const uint64_t seg0 = (uint64_t)f * max_segs;
+    {
+        const uint32_t nm = ns < ZK_FILL_META ? ns : ZK_FILL_META;
+        if (tid < nm) {
+            const ZkSeg sg = segs[seg0 + tid];
+            s_meta[tid][0] = sg.pos; s_meta[tid][1] = sg.out; s_meta[tid][2] = sg.b0; s_meta[tid][3] = segn[seg0 + tid];
+        }
+        __syncthreads();
+        const uint32_t j = tid / ZK_FILL_TC, t = tid % ZK_FILL_TC;
+        if (j < nm && t < s_meta[j][3]) s_tc[j][t] = tilecnt[zk_seg_tile_region(frame_off, s_meta[j][0], block_base + s_meta[j][2], seg0 + j) + t];
+        __syncthreads();
+    }
+    auto seg_pos_of = [&](uint32_t j) { return j < ZK_FILL_META ? zk_uni(s_meta[j][0]) : zk_uni(segs[seg0 + j].pos); };
+    auto seg_out_of = [&](uint32_t j) { return j < ZK_FILL_META ? zk_uni(s_meta[j][1]) : zk_uni(segs[seg0 + j].out); };
+    auto seg_b0_of = [&](uint32_t j) { return j < ZK_FILL_META ? zk_uni(s_meta[j][2]) : zk_uni(segs[seg0 + j].b0); };
+    auto seg_nt_of = [&](uint32_t j) { return j < ZK_FILL_META ? zk_uni(s_meta[j][3]) : zk_uni(segn[seg0 + j]); };
+    for (uint32_t j0 = 0; j0 < ns;) {
+        // the turn: segments j0 .. j1 - 1
+        const uint32_t tpos = seg_pos_of(j0);
+        uint32_t j1 = j0, tout = 0, steps = 0;
+        while (j1 < ns && (j1 == j0 || tout + seg_out_of(j1) <= ZK_SEG_BYTES)) { tout += seg_out_of(j1); steps += seg_nt_of(j1); j1++; }
+        if (!steps) { final_to = tpos + tout; j0 = j1; continue; }               // (no holes: pass 1 left these segments complete)
+        const uint32_t shift = (uint32_t)((uintptr_t)(out + tpos) & 15u), ibase = tpos - shift, total = shift + tout;
+        const uint8_t *A = out + tpos - shift;                                   // 16-byte aligned; image byte i <-> A[i]
+        uint8_t *Aw = out + tpos - shift;
+        __syncthreads();                                                         // (the turn before: its image stored and the stores waited out, s_cnt read)
         if (progress && final_to && tid == 0) zk_publish(progress + f, final_to);
-        s_cnt[tid] = tid < nt ? tc[tid] : 0u;
-        // 0: whole 16-byte units inside the segment; the ragged ends byte by byte (bytes outside the segment are not this workgroup's)
+        // 0: whole 16-byte units inside the turn's bytes; the ragged ends byte by byte (bytes outside are not this workgroup's)
         for (uint32_t u = tid; u * 16u < total; u += L) {
             const uint32_t i0 = u * 16u;
             if (i0 >= shift && i0 + 16u <= total) *reinterpret_cast<uint4 *>(img + i0) = *reinterpret_cast<const uint4 *>(A + i0);
             else for (uint32_t k = 0; k < 16u; k++) if (i0 + k >= shift && i0 + k < total) img[i0 + k] = A[i0 + k];
         }
-        __syncthreads();
-        bool fast = nt <= (uint32_t)ZK_FILL_NT;
+        const uint32_t nt0 = seg_nt_of(j0);
+        bool fast = j1 == j0 + 1 && j0 < ZK_FILL_META && nt0 <= (uint32_t)ZK_FILL_NT;       // one long segment: its records in registers
         if (fast) {
+            const ZkHole *rec = zk_uni(holes + zk_seg_region(frame_off, tpos, seg0 + j0));
             ZkHole r0[ZK_FILL_NT], r1[ZK_FILL_NT];
             uint32_t base = 0;
 #pragma unroll
             for (int t = 0; t < ZK_FILL_NT; t++) {                               // A
-                const uint32_t cnt = zk_uni(s_cnt[t]);
+                const uint32_t cnt = (uint32_t)t < nt0 ? zk_uni(s_tc[j0][t]) : 0u;
                 fast = fast && cnt <= 2u * L;
                 r0[t] = tid < cnt ? rec[base + tid] : 0;
                 r1[t] = tid + L < cnt ? rec[base + tid + L] : 0;
                 base += cnt;
             }
+            __syncthreads();                                                     // (the image is loaded)
             if (fast) {
 #pragma unroll
                 for (int t = 0; t < ZK_FILL_NT; t++) {                           // B
-                    zk_fill_from_memory(r0[t], seg_pos, ibase, flimit, out, img);
-                    zk_fill_from_memory(r1[t], seg_pos, ibase, flimit, out, img);
+                    zk_fill_from_memory(r0[t], tpos, ibase, flimit, out, img);
+                    zk_fill_from_memory(r1[t], tpos, ibase, flimit, out, img);
                 }
                 ZK_LDS_BARRIER();
 #pragma unroll
                 for (int t = 0; t < ZK_FILL_NT; t++) {                           // C
-                    if ((uint32_t)t < nt) {
-                        zk_fill_from_image(r0[t], seg_pos, ibase, img);
-                        zk_fill_from_image(r1[t], seg_pos, ibase, img);
+                    if ((uint32_t)t < nt0) {
+                        zk_fill_from_image(r0[t], tpos, ibase, img);
+                        zk_fill_from_image(r1[t], tpos, ibase, img);
                         ZK_LDS_BARRIER();
                     }
                 }
             }
-        }
-        if (!fast) {                                                             // any other shape: the tiles in order, their records from memory
-            uint32_t base = 0;
-            for (uint32_t t0 = 0; t0 < nt; t0 += L) {                            // (the tile counts, L at a time)
-                if (t0) { __syncthreads(); s_cnt[tid] = t0 + tid < nt ? tc[t0 + tid] : 0u; __syncthreads(); }
-                const uint32_t nchunk = nt - t0 < (uint32_t)L ? nt - t0 : (uint32_t)L;
-                for (uint32_t t = 0; t < nchunk; t++) {
-                    const uint32_t cnt = zk_uni(s_cnt[t]);
-                    for (uint32_t i0 = 0; i0 < cnt; i0 += L) {                   // (all lanes: the helpers vote)
-                        const ZkHole r = i0 + tid < cnt ? rec[base + i0 + tid] : 0;
-                        zk_fill_from_memory(r, seg_pos, ibase, flimit, out, img);
-                        zk_fill_from_image(r, seg_pos, ibase, img);
+        } else __syncthreads();                                                  // (the image is loaded)
+        if (!fast) {
+            // any other shape (several short segments: a seek; more tiles or records than the registers hold): segment after segment, tile after
+            // tile, a tile's first L records requested a tile ahead (the counts are known: read ahead, or staged L at a time)
+            for (uint32_t j = j0; j < j1; j++) {
+                const uint32_t nt = seg_nt_of(j);
+                if (!nt) continue;
+                const uint32_t spos = seg_pos_of(j);
+                const ZkHole *rec = zk_uni(holes + zk_seg_region(frame_off, spos, seg0 + j));
+                const uint32_t *tc = zk_uni(tilecnt + zk_seg_tile_region(frame_off, spos, block_base + seg_b0_of(j), seg0 + j));
+                const bool ahead = j < ZK_FILL_META && nt <= ZK_FILL_TC;
+                uint32_t base = 0;
+                for (uint32_t t0 = 0; t0 < nt; t0 += L) {
+                    if (!ahead) { __syncthreads(); s_cnt[tid] = t0 + tid < nt ? tc[t0 + tid] : 0u; __syncthreads(); }
+                    const uint32_t nchunk = nt - t0 < (uint32_t)L ? nt - t0 : (uint32_t)L;
+                    uint32_t cnt = ahead ? zk_uni(s_tc[j][0]) : zk_uni(s_cnt[0]);
+                    ZkHole nxt = tid < cnt ? rec[base + tid] : 0;
+                    for (uint32_t t = 0; t < nchunk; t++) {
+                        const ZkHole cur = nxt;
+                        const uint32_t ncnt = t + 1 < nchunk ? (ahead ? zk_uni(s_tc[j][t + 1]) : zk_uni(s_cnt[t + 1])) : 0u;
+                        nxt = tid < ncnt ? rec[base + cnt + tid] : 0;
+                        for (uint32_t i0 = 0; i0 < cnt; i0 += L) {               // (all lanes: the helpers vote)
+                            const ZkHole r = i0 ? (i0 + tid < cnt ? rec[base + i0 + tid] : 0) : cur;
+                            zk_fill_from_memory(r, tpos, ibase, flimit, out, img);
+                            zk_fill_from_image(r, tpos, ibase, img);
+                        }
+                        base += cnt; cnt = ncnt;
+                        ZK_LDS_BARRIER();
                     }
-                    base += cnt;
-                    ZK_LDS_BARRIER();
                 }
             }
         }
@@ -1616,7 +1653,8 @@ __global__ __launch_bounds__(L) void zk_k_exec_fill_lds(const uint64_t *d_off, u
             if (i0 >= shift && i0 + 16u <= total) *reinterpret_cast<uint4 *>(Aw + i0) = *reinterpret_cast<const uint4 *>(img + i0);
             else for (uint32_t k = 0; k < 16u; k++) if (i0 + k >= shift && i0 + k < total) Aw[i0 + k] = img[i0 + k];
         }
-        final_to = seg_pos + seg_out;
+        final_to = tpos + tout;
+        j0 = j1;
     }
     if (progress) {
         __syncthreads();

@@ -459,14 +459,33 @@ static int zk_decode_small(zk_engine *e, zk_hostpipe *hp, const zk_host_src &src
     }
     // long frames (a read of one or two 2 MiB frames -- zeekstd's default frame size): the executor in segments, several workgroups per
     // frame (zk_k_seg_prep / zk_k_exec_seg / zk_k_exec_fill_lds: 1.37 -> 0.6 ms for a 2 MiB frame); the host knows the frames' sizes here
-    const bool seg = !d_prefix && e->choice.exec_seg != 1 && (e->choice.exec_seg == 2 || dsz >= (uint64_t)count * (4u * ZK_SEG_BYTES));
+    // ... and SHORT frames in a handful (a seek into 64 KiB frames: sixteen blocks of 4 KiB as this encoder writes them, executed one
+    // after the other at ~7 us each by a frame's workgroup): a segment per block, all at once, and one turn of the fill pass for the frame
+    uint64_t max_frame = 0;
+    for (uint32_t k = 0; k < count; k++) { const uint64_t d = d_off[first + k + 1] - d_off[first + k]; max_frame = d > max_frame ? d : max_frame; }
+    const bool long_frames = dsz >= (uint64_t)count * (4u * ZK_SEG_BYTES);
+    const uint32_t seg_bytes = e->choice.seg_kib ? (uint32_t)e->choice.seg_kib << 10 : long_frames ? ZK_SEG_BYTES : 4096u;
+    const uint64_t max_segs64 = 2 * ((max_frame + seg_bytes - 1) / seg_bytes) + 1;
+    bool short_frames = !long_frames && max_frame >= 32768 && max_frame <= ZK_SEG_BYTES && (uint64_t)count * max_segs64 <= 256;
+    if (short_frames && e->choice.exec_seg != 2) {
+        // ... if they HAVE blocks to deal out: the reference's own 64 KiB frames are one block (+ an empty last one), executed by one
+        // workgroup either way -- the extra launches would only cost them ~25 us.  The host holds the frames' bytes (pinned, just
+        // filled): the walk over a handful of block headers is the device's lane code, run here (zk_walk_frame is host + device)
+        uint32_t nb = 0;
+        for (uint32_t k = 0; k < count && short_frames; k++) {
+            ZkFrameInfo fi;
+            zk_walk_frame(h_comp, h_offs[k], h_offs[k + 1], h_offs[count + 1 + k + 1] - h_offs[count + 1 + k], k, nullptr, nullptr, fi);
+            if (fi.status != ZK_OK) short_frames = false;          // (the device gives the verdict)
+            nb += fi.n_blocks;
+        }
+        short_frames = short_frames && nb >= 6u * count;
+    }
+    const bool seg = !d_prefix && e->choice.exec_seg != 1 && max_segs64 <= 65535 && (e->choice.exec_seg == 2 || long_frames || short_frames);
     if (seg) {
         zk_engine::DecCtx &x = e->dctx[0];
         ZkSegScratch sgs{};
-        uint64_t max_frame = 0;
-        for (uint32_t k = 0; k < count; k++) { const uint64_t d = d_off[first + k + 1] - d_off[first + k]; max_frame = d > max_frame ? d : max_frame; }
-        sgs.seg_bytes = e->choice.seg_kib ? (uint32_t)e->choice.seg_kib << 10 : ZK_SEG_BYTES;
-        sgs.max_segs = 2u * (uint32_t)((max_frame + sgs.seg_bytes - 1) / sgs.seg_bytes) + 1u;
+        sgs.seg_bytes = seg_bytes;
+        sgs.max_segs = (uint32_t)max_segs64;
         const uint64_t nsg = (uint64_t)count * sgs.max_segs;
         if ((rc = zk_devbuf_reserve(e, x.seg_tab, (size_t)nsg * sizeof(ZkSeg)))) return rc;
         if ((rc = zk_devbuf_reserve(e, x.seg_cnt, (size_t)(nsg + count) * sizeof(uint32_t)))) return rc;
