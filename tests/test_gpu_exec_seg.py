@@ -124,3 +124,86 @@ def test_damaged_archives_reach_the_frame_executors_verdict(engine):
     finally:
         engine.set_kernel_choice(reset=0)
     assert differ > 0
+
+
+def test_frame_lists_and_device_pointers_in_segments(engine):
+    """zk_decode_frame_list_dev (frames by index, any order, repeats, packed output) and zk_decode_frames_dev with the executor in segments:
+    long frames of an engine-made and a libzstd-made archive, by shape (<= 32 long frames without checksums to verify) and pinned; and two
+    batches in flight (zk_decode_submit_dev) whose contexts each own their segment scratch."""
+    import torch
+    dev = torch.device("cuda:0")
+    data = zko.gen_chunks(24 << 20, 123)
+    fs = 2 << 20
+    archives = [engine.encode_frames(data, fs, 1, False), Z.encode_seekable_frames(data, fs, 3, False)]
+    try:
+        for comp, frames in archives:
+            c, d = offsets_from_frames(frames)
+            d_comp = torch.from_numpy(np.frombuffer(comp + b"\0" * 64, np.uint8).copy()).to(dev)
+            d_c = torch.from_numpy(c.view(np.int64)).to(dev)
+            d_d = torch.from_numpy(d.view(np.int64)).to(dev)
+            ids = np.array([7, 0, 11, 3, 3, 9], np.uint32)
+            off = np.zeros(len(ids) + 1, np.uint64)
+            off[1:] = np.cumsum(d[ids.astype(np.int64) + 1] - d[ids.astype(np.int64)])
+            d_ids = torch.from_numpy(ids.view(np.int32)).to(dev)
+            d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+            for choice in ({}, {"exec_seg": 2, "exec_lanes": 256}, {"exec_seg": 2, "seg_kib": 48, "seg_fill": 1}):
+                engine.set_kernel_choice(reset=0)
+                engine.set_kernel_choice(**choice)
+                d_out = torch.full((int(off[-1]) + 64,), 0x77, dtype=torch.uint8, device=dev)
+                d_st = torch.full((len(ids),), -1, dtype=torch.int32, device=dev)
+                assert engine.decode_frame_list_dev(d_comp, len(comp), d_c, d_d, d_ids, d_off, len(ids), d_out, int(off[-1]), True, d_st) == 0
+                assert int(d_st.abs().sum().item()) == 0
+                out = bytes(d_out[:int(off[-1])].cpu().numpy())
+                for i, f in enumerate(ids):
+                    assert out[int(off[i]):int(off[i + 1])] == data[int(d[f]):int(d[f + 1])], (choice, i)
+                # a frame range from the middle through the device-pointer call
+                n = int(d[9] - d[4])
+                d_o2 = torch.full((n + 64,), 0x33, dtype=torch.uint8, device=dev)
+                d_s2 = torch.full((5,), -1, dtype=torch.int32, device=dev)
+                assert engine.decode_frames_dev(d_comp, len(comp), d_c, d_d, 4, 5, d_o2, n, False, d_s2) == 0
+                assert bytes(d_o2[:n].cpu().numpy()) == data[int(d[4]):int(d[9])] and int(d_s2.abs().sum().item()) == 0
+            # two batches in flight, both by shape in segments
+            engine.set_kernel_choice(reset=0)
+            n = int(d[6] - d[0])
+            outs = [torch.zeros(n + 64, dtype=torch.uint8, device=dev) for _ in range(2)]
+            sts = [torch.zeros(6, dtype=torch.int32, device=dev) for _ in range(2)]
+            s0 = engine.decode_submit_dev(d_comp, len(comp), d_c, d_d, 0, 6, outs[0], n, False, sts[0])
+            s1 = engine.decode_submit_dev(d_comp, len(comp), d_c, d_d, 6, 6, outs[1], n, False, sts[1])
+            assert engine.decode_wait(s0) == 0 and engine.decode_wait(s1) == 0
+            assert bytes(outs[0][:n].cpu().numpy()) == data[:n] and bytes(outs[1][:n].cpu().numpy()) == data[n:2 * n]
+    finally:
+        engine.set_kernel_choice(reset=0)
+
+
+def test_seeks_into_short_frames_in_segments(engine):
+    """The small path's short-frame case (a seek into 64 KiB frames of sixteen 4 KiB blocks: a segment per block, one turn of the fill pass per
+    frame) through the Decoder handle: random offsets and lengths against the input, unverified -- and the same reads with the executor
+    per frame."""
+    from zeekstd_amd import DecodeOptions, SeekTable
+    data = zko.gen_chunks(6 << 20, 321)
+    comp, frames = engine.encode_frames(data, 65536, 1, False)
+    st = SeekTable.new()
+    for c_, d_ in frames:
+        st.log_frame(c_, d_)
+    arch = comp + st.to_bytes()
+    rng = np.random.default_rng(77)
+    try:
+        for choice in ({}, {"exec_seg": 1}, {"exec_seg": 2, "seg_kib": 8}):
+            engine.set_kernel_choice(reset=0)
+            engine.set_kernel_choice(**choice)
+            dec = DecodeOptions(arch).engine(engine).into_decoder()
+            buf = bytearray(200000)
+            for _ in range(150):
+                off = int(rng.integers(0, len(data) - 1))
+                ln = int(rng.integers(1, 150000 if rng.integers(0, 4) == 0 else 9000))
+                lim = min(len(data), off + ln)
+                dec.set_offset(off); dec.set_offset_limit(lim)
+                got = bytearray()
+                while True:
+                    k = dec.decompress(buf)
+                    if k == 0:
+                        break
+                    got += buf[:k]
+                assert bytes(got) == data[off:lim], (choice, off, lim)
+    finally:
+        engine.set_kernel_choice(reset=0)
