@@ -1995,6 +1995,100 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     zk_xxh64_follow_body<ZK_FOLLOW_W>(data, d_off, first, count, infos, progress);
 }
 
+// The same for a HANDFUL of frames (r6): a wave per frame -- zk_k_xxh64's layout, the fastest a frame's four chains run on this device
+// (1.7 ms per 2 MiB; sixteen frames to a wave: 2.25 ms) -- behind the frame's progress word.  Eight waves per group of eight frames;
+// wave g takes, of its group, the frame whose executor shares ITS XCD (the word says where it runs; two waves of a group on one XCD hash
+// the same frame twice and leave another to the pass behind the executor, which takes every frame that is not marked verified).
+__global__ __launch_bounds__(64) void zk_k_xxh64_follow1(const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
+                                                         const ZkFrameInfo *infos, uint64_t *progress)
+{
+    __shared__ uint64_t prod[128];
+    const uint32_t lane = threadIdx.x, g = blockIdx.x;
+    const uint32_t here = zk_xcc_id() + 1;
+    uint64_t t_news = wall_clock64();
+    const uint32_t g0 = g & ~7u;
+    uint32_t f = 0xFFFFFFFFu;
+    for (;;) {                                               // whose executor runs here?  Once every word of the group has spoken:
+        bool mine = false, pending = false;
+        if (lane < 8 && g0 + lane < count) {
+            const uint64_t w = __hip_atomic_load(progress + g0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (w == 0) pending = true;
+            else mine = !(w & ZK_PROG_ABORT) && ((uint32_t)(w >> 32) & 15u) == here;
+        }
+        const unsigned long long mm = __ballot(mine), pm = __ballot(pending);
+        if (!pm) {
+            if (!mm) return;                                 // none of the group's frames runs on this XCD
+            // the frames that run here, in order; this wave takes number (its place in the group) mod (how many): one each when the
+            // dispatcher deals waves and workgroups round the XCDs alike
+            unsigned long long m2 = mm;
+            for (uint32_t k = (g & 7u) % (uint32_t)__popcll(mm); k; k--) m2 &= m2 - 1;
+            f = g0 + (uint32_t)__builtin_ctzll(m2);
+            break;
+        }
+        const uint32_t waited = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wall_clock64() - t_news > ZK_FOLLOW_PATIENCE));
+        if (waited) return;
+        __builtin_amdgcn_s_sleep(20);
+    }
+    if (!(infos[f].status == ZK_OK && infos[f].checksum_flag)) return;
+    const uint8_t *p = data + (d_off[first + f] - d_off[first]);
+    const uint64_t len = d_off[first + f + 1] - d_off[first + f];
+    const uint64_t nchunks = len >> 10;
+    const uint32_t kl = lane & 3;
+    uint64_t acc = kl == 0 ? XP1 + XP2 : kl == 1 ? XP2 : kl == 2 ? 0 : 0 - XP1;
+    const bool aligned = (((uintptr_t)p) & 15) == 0;
+    uint64_t a = 0, b = 0;
+    auto ldpair = [&](uint64_t c) {
+        const uint8_t *q = p + (c << 10) + lane * 16;
+        if (aligned) { uint4 v = *reinterpret_cast<const uint4 *>(q); a = v.x | ((uint64_t)v.y << 32); b = v.z | ((uint64_t)v.w << 32); }
+        else { a = zk_ld64(q); b = zk_ld64(q + 8); }
+    };
+    uint64_t have = 0;                                       // bytes of the frame known to be final
+    // wait until `need` bytes are final; false: the frame is not (any more) this wave's -- it failed, ran elsewhere, or nothing was heard for too long
+    auto wait_for = [&](uint64_t need) -> bool {
+        while (have < need) {
+            const uint64_t w = zk_uni((uint64_t)__hip_atomic_load(progress + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));     // one verdict per pass for the whole wave
+            if ((w & ZK_PROG_ABORT) || ((uint32_t)(w >> 32) & 15u) != here) return false;
+            const uint64_t got = (uint32_t)w;
+            if (got > have) { have = got; t_news = wall_clock64(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); continue; }     // (this CU's L1 may hold the buffer's bytes of an earlier decode)
+            if (wall_clock64() - t_news > ZK_FOLLOW_PATIENCE) return false;
+            __builtin_amdgcn_s_sleep(50);
+        }
+        return true;
+    };
+    // (the word is wave-uniform, so is every verdict: the loops below are left by the whole wave)
+    if (nchunks) { if (!wait_for(1024)) return; ldpair(0); }
+    for (uint64_t c = 0; c < nchunks; c++) {
+        prod[2 * lane] = a * XP2; prod[2 * lane + 1] = b * XP2;
+        if (c + 1 < nchunks) { if (!wait_for((c + 2) << 10)) return; ldpair(c + 1); }
+        __syncthreads();
+        if (lane < 16) {
+#pragma unroll 8
+            for (int r = 0; r < 32; r++) acc = zk_rotl64(acc + prod[4 * r + kl], 31) * XP1;
+        }
+        __syncthreads();
+    }
+    if (!wait_for(len)) return;
+    const uint64_t nstripes = len >> 5;
+    if (lane < 16) for (uint64_t i = nchunks << 5; i < nstripes; i++) acc = zk_xround(acc, zk_ld64(p + (i << 5) + 8 * kl));
+    uint64_t v1 = __shfl(acc, 0, 64), v2 = __shfl(acc, 1, 64), v3 = __shfl(acc, 2, 64), v4 = __shfl(acc, 3, 64);
+    if (lane != 0) return;
+    uint64_t h;
+    if (len >= 32) {
+        h = zk_rotl64(v1, 1) + zk_rotl64(v2, 7) + zk_rotl64(v3, 12) + zk_rotl64(v4, 18);
+        h = (h ^ zk_xround(0, v1)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v2)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v3)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v4)) * XP1 + XP4;
+    } else h = XP5;
+    h += len;
+    const uint8_t *t = p + (nstripes << 5), *end = p + len;
+    while (t + 8 <= end) { h ^= zk_xround(0, zk_ld64(t)); h = zk_rotl64(h, 27) * XP1 + XP4; t += 8; }
+    if (t + 4 <= end) { h ^= (uint64_t)zk_rd32(t) * XP1; h = zk_rotl64(h, 23) * XP2 + XP3; t += 4; }
+    while (t < end) { h ^= (uint64_t)(*t) * XP5; h = zk_rotl64(h, 11) * XP1; t++; }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    atomicOr((unsigned long long *)(progress + f), (uint32_t)h == infos[f].checksum ? ZK_PROG_VERIFIED : ZK_PROG_MISMATCH);
+}
+
 // per-frame status words + first failing frame ((frame << 32) | code, min over frames); with `followed`: the number of frames whose
 // checksums zk_k_xxh64_follow verified
 // zk_frame_content_sizes: a frame's decompressed size = the regenerated sizes of its blocks, known once the sequence walks have run
@@ -2315,6 +2409,8 @@ void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off,
 }
 void zk_launch_xxh64_follow(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count, const ZkFrameInfo *infos, uint64_t *progress)
 {
+    // a handful of frames: a wave per frame (a frame's chains run 1.7 ms per 2 MiB there, 2.25 ms sixteen frames to a wave)
+    if (count <= 32) { hipLaunchKernelGGL(zk_k_xxh64_follow1, dim3(8 * ((count + 7) / 8)), dim3(64), 0, st, data, d_off, first, count, infos, progress); return; }
     // eight waves per 128 frames: each takes the frames of one XCD
     hipLaunchKernelGGL(zk_k_xxh64_follow, dim3(8 * ((count + 127) / 128)), dim3(64), 0, st, data, d_off, first, count, infos, progress);
 }

@@ -242,7 +242,9 @@ static bool zk_seg_wanted(const zk_engine *e, const zk_dec_args &a, uint32_t cou
     // unverified, ms: 1 / 5 / 16 / 32 frames 2.58 / 2.60 / 2.62 / 2.65 -> 1.79 / 1.83 / 1.85 / 2.39; 64 frames 2.80 -> 2.88: profiles/r06_seg_probe.txt).
     // Not where the checksums run beside the executor: a frame's four XXH64 chains (1.7-2.3 ms per 2 MiB, whoever runs them) then end
     // the decode, not the executor (verified, 16 frames: 3.52 ms either way).
-    return !follow && count <= 32 && out_bytes >= (uint64_t)count * (4u * ZK_SEG_BYTES);
+    // (r6, with a wave per frame behind the progress words -- zk_k_xxh64_follow1 -- verified, ms, frame executor | segments: 1 frame 2.94 | 3.01,
+    //  5: 3.05 | 3.14, 16: 3.08 | 3.31, 32: 3.69 | 3.33)
+    return (!follow || count > 16) && count <= 32 && out_bytes >= (uint64_t)count * (4u * ZK_SEG_BYTES);
 }
 
 // Enqueue the whole decode on the context's queues.  Blocks the host once, for the block / sequence / literal totals
