@@ -815,7 +815,8 @@ extern "C" void zk_debug_clocks(unsigned long long *out, int reset)
 // nothing tells the compiler they are read-only -- and stayed in vector registers for the whole kernel: ~30 of them.)
 __device__ __forceinline__ uint32_t zk_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint64_t zk_uni(uint64_t v) { return (uint64_t)zk_uni((uint32_t)v) | ((uint64_t)zk_uni((uint32_t)(v >> 32)) << 32); }
-template <typename P> __device__ __forceinline__ P *zk_uni(P *p) { return reinterpret_cast<P *>(zk_uni((uint64_t)(uintptr_t)p)); }
+// (A POINTER is made uniform through its offset -- base + zk_uni(offset), the base a kernel argument: a pointer rebuilt from an integer is a
+// generic one, and the compiler emits FLAT loads and stores for it instead of global ones.)
 
 // PROGRESS WORDS (zk_k_xxh64_follow): with `progress` set, lane 0 of a frame's workgroup publishes how many bytes of the frame are
 // complete -- whenever a block ends behind another 2^ZK_PUB_LOG bytes, and at the frame's end -- so that the checksum of a frame can
@@ -887,8 +888,8 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
     const uint64_t d_size = zk_uni(d_off[id + 1] - d_off[id]);
     uint32_t published = 0;                                  // the last published count >> ZK_PUB_LOG
     if (progress && tid == 0) zk_publish(progress + f, 0);   // (which XCD this is: a checksum wave elsewhere stops waiting for the frame)
-    uint8_t *out = zk_uni(dst + (out_off ? out_off[f] : d_off[id] - d_off[first]));     // indexed batches are packed in list order
-    const ZkBlock *fb = zk_uni(blocks + bases[f].block_base);
+    uint8_t *out = dst + zk_uni((uint64_t)(out_off ? out_off[f] : d_off[id] - d_off[first]));     // indexed batches are packed in list order
+    const ZkBlock *fb = blocks + zk_uni((uint64_t)bases[f].block_base);
     uint64_t pos = 0;
     uint32_t rep[3] = {1, 4, 8};
     uint32_t err = ZK_OK;
@@ -930,6 +931,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
             const uint32_t b_lit_type = zk_uni((uint32_t)b.lit_type);
             const uint8_t *lit = b_lit_type >= 2 ? lit_scratch + zk_uni(b.lit_base) : comp + zk_uni(b.src) + zk_uni(b.lit_off);
             const uint32_t lit_mask = b_lit_type == 1 ? 0u : 0x7fffffffu;       // RLE literals: every index reads byte 0
+            const uint64_t lit_w = (uint64_t)(uintptr_t)lit - ZK_SRC_LIT, his_w = (uint64_t)(uintptr_t)bout - ZK_SRC_BIAS;    // + a source word = the byte's address
             const uint32_t nseq = zk_uni(b.nseq), out_size = b_out_size, lit_regen = zk_uni(b.lit_regen);
             // record idx of the block (idx == nseq: the trailing-literals pseudo sequence) -> staged form, offsets resolved
             // and validated.  Without a prefix an offset is bounded by the bytes produced so far and by the frame's window;
@@ -1055,6 +1057,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                     } while (again);
                     ZK_CLK(4);
                     uint32_t ob[ZK_EXEC_B];
+#ifdef ZK_EXEC_GATHER_OLD
 #pragma unroll
                     for (int k = 0; k < ZK_EXEC_B; k++) {
                         const uint32_t s = sw[k];
@@ -1066,6 +1069,26 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                         if ((uint32_t)k >= nb) a = bout;     // harmless address for the bytes past the tile end
                         ob[k] = *a;
                     }
+#else
+                    // A byte's address = its source word + one of two bases (the words' tags folded into them): a compare, two selects
+                    // and a 64-bit add per byte, and a GLOBAL load -- the bases went through zk_uni (an integer), which left the compiler
+                    // with generic pointers: flat loads, and twelve instructions per byte.  Words past the tile's end are ZK_SRC_LIT
+                    // (zk_exec_slot_words*): literal 0, always readable.  RLE literals: every literal word becomes literal 0.
+                    if (lit_mask == 0) {
+#pragma unroll
+                        for (int k = 0; k < ZK_EXEC_B; k++) sw[k] = (sw[k] & ZK_SRC_LIT) ? ZK_SRC_LIT : sw[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < ZK_EXEC_B; k++) {
+                        const uint32_t s = sw[k];
+                        uint64_t a = ((int32_t)s < 0 ? lit_w : his_w) + s;
+                        if (PFX && (int32_t)s >= 0) {        // a position before the frame's first byte lies in the prefix
+                            const int64_t rel = (int64_t)pos + (int32_t)(s - ZK_SRC_BIAS);
+                            if (rel < 0) a = (uint64_t)(uintptr_t)prefix + plen + rel;
+                        }
+                        ob[k] = *(const __attribute__((address_space(1))) uint8_t *)a;
+                    }
+#endif
                     uint8_t *w = bout + q0;
                     if (nb == ZK_EXEC_B && (((uintptr_t)w) & 15) == 0) {
                         uint4 v;
@@ -1188,12 +1211,12 @@ __global__ __launch_bounds__(T) void zk_k_exec_seg(const uint8_t *comp, const ui
     const uint32_t seg_pos = zk_uni(sg.pos), seg_out = zk_uni(sg.out), seg_nb = zk_uni(sg.nb), seg_b0 = zk_uni(sg.b0);
     const uint32_t id = zk_uni(ids ? ids[f] : first + f);
     const uint64_t frame_off = zk_uni(out_off ? out_off[f] : d_off[id] - d_off[first]);
-    uint8_t *out = zk_uni(dst + frame_off);
+    uint8_t *out = dst + frame_off;
     const uint64_t block_base = zk_uni(bases[f].block_base);
-    const ZkBlock *fb = zk_uni(blocks + block_base + seg_b0);
-    ZkHole *rec = zk_uni(holes + zk_seg_region(frame_off, seg_pos, seg_no));
+    const ZkBlock *fb = blocks + (block_base + seg_b0);
+    ZkHole *rec = holes + zk_uni((uint64_t)zk_seg_region(frame_off, seg_pos, seg_no));
     const uint32_t rec_cap = zk_seg_region_cap(seg_out);
-    uint32_t *tc = zk_uni(tilecnt + zk_seg_tile_region(frame_off, seg_pos, block_base + seg_b0, seg_no));
+    uint32_t *tc = tilecnt + zk_uni((uint64_t)zk_seg_tile_region(frame_off, seg_pos, block_base + seg_b0, seg_no));
     const uint32_t tc_cap = zk_seg_tile_cap(seg_out, seg_nb);
     uint32_t nrec = 0, ntile = 0;                            // records / tile counts left so far (uniform)
     bool overflow = false;
@@ -1232,6 +1255,7 @@ __global__ __launch_bounds__(T) void zk_k_exec_seg(const uint8_t *comp, const ui
             const uint32_t b_lit_type = zk_uni((uint32_t)b.lit_type);
             const uint8_t *lit = b_lit_type >= 2 ? lit_scratch + zk_uni(b.lit_base) : comp + zk_uni(b.src) + zk_uni(b.lit_off);
             const uint32_t lit_mask = b_lit_type == 1 ? 0u : 0x7fffffffu;
+            const uint64_t lit_w = (uint64_t)(uintptr_t)lit - ZK_SRC_LIT, his_w = (uint64_t)(uintptr_t)bout - ZK_SRC_BIAS;
             const uint32_t nseq = zk_uni(b.nseq), out_size = b_out_size, lit_regen = zk_uni(b.lit_regen);
             const int32_t seg_lo = -(int32_t)seg_done;       // block-relative position of the segment's first byte
             auto fetch = [&](uint32_t idx, ZkSeqP &p0, ZkSeqP &p1) {
@@ -1342,12 +1366,13 @@ __global__ __launch_bounds__(T) void zk_k_exec_seg(const uint8_t *comp, const ui
                     hm = zk_seg_slot_holes(sw, nb, seg_lo, [&](uint32_t p) { return (bool)((taint[p >> 5] >> (p & 31u)) & 1u); });
                     starts = zk_seg_slot_runs(sw, hm, len);
                     uint32_t ob[ZK_EXEC_B];
+                    // (the gathers as in zk_k_exec: a word + one of two bases; a hole reads literal 0 like the words past the tile's end)
 #pragma unroll
                     for (int k = 0; k < ZK_EXEC_B; k++) {
-                        const uint32_t s = sw[k];
-                        const uint8_t *a = (s & ZK_SRC_LIT) ? lit + (s & lit_mask) : bout + (int64_t)(int32_t)(s - ZK_SRC_BIAS);
-                        if ((uint32_t)k >= nb || ((hm >> k) & 1u)) a = bout;       // harmless address: bytes past the tile end, holes
-                        ob[k] = *a;
+                        uint32_t s = sw[k];
+                        if (lit_mask == 0) s = (s & ZK_SRC_LIT) ? ZK_SRC_LIT : s;
+                        s = ((hm >> k) & 1u) ? ZK_SRC_LIT : s;
+                        ob[k] = *(const __attribute__((address_space(1))) uint8_t *)(((int32_t)s < 0 ? lit_w : his_w) + s);
                     }
                     uint8_t *w = bout + q0;
                     if (nb == ZK_EXEC_B && (((uintptr_t)w) & 15) == 0) {
@@ -1433,7 +1458,7 @@ __global__ __launch_bounds__(L) void zk_k_exec_fill(const uint64_t *d_off, uint3
     }
     const uint32_t id = zk_uni(ids ? ids[f] : first + f);
     const uint64_t frame_off = zk_uni(out_off ? out_off[f] : d_off[id] - d_off[first]);
-    uint8_t *out = zk_uni(dst + frame_off);
+    uint8_t *out = dst + frame_off;
     const uint64_t block_base = zk_uni(bases[f].block_base);
     const uint32_t ns = zk_uni(nsegs[f]);
     if (progress && tid == 0) zk_publish(progress + f, 0);   // (which XCD this is)
@@ -1442,8 +1467,8 @@ __global__ __launch_bounds__(L) void zk_k_exec_fill(const uint64_t *d_off, uint3
         const ZkSeg &sg = segs[seg_no];
         const uint32_t seg_pos = zk_uni(sg.pos);
         const uint32_t nt = zk_uni(segn[seg_no]);
-        const ZkHole *rec = zk_uni(holes + zk_seg_region(frame_off, seg_pos, seg_no));
-        const uint32_t *tc = zk_uni(tilecnt + zk_seg_tile_region(frame_off, seg_pos, block_base + zk_uni(sg.b0), seg_no));
+        const ZkHole *rec = holes + zk_uni((uint64_t)zk_seg_region(frame_off, seg_pos, seg_no));
+        const uint32_t *tc = tilecnt + zk_uni((uint64_t)zk_seg_tile_region(frame_off, seg_pos, block_base + zk_uni(sg.b0), seg_no));
         if (progress && j && tid == 0) zk_publish(progress + f, seg_pos);        // everything in front of this segment is final (every wave has waited out its stores at the tile barriers)
         for (uint32_t t = 0; t < nt; t++) {
             const uint32_t cnt = zk_uni(tc[t]);
@@ -1548,7 +1573,7 @@ __global__ __launch_bounds__(L) void zk_k_exec_fill_lds(const uint64_t *d_off, u
     const uint32_t id = zk_uni(ids ? ids[f] : first + f);
     const uint64_t frame_off = zk_uni(out_off ? out_off[f] : d_off[id] - d_off[first]);
     const uint32_t flimit = (uint32_t)zk_uni(d_off[id + 1] - d_off[id]);
-    uint8_t *out = zk_uni(dst + frame_off);
+    uint8_t *out = dst + frame_off;
     const uint64_t block_base = zk_uni(bases[f].block_base);
     const uint32_t ns = zk_uni(nsegs[f]);
     const uint64_t seg0 = (uint64_t)f * max_segs;
@@ -1587,7 +1612,7 @@ __global__ __launch_bounds__(L) void zk_k_exec_fill_lds(const uint64_t *d_off, u
         const uint32_t nt0 = seg_nt_of(j0);
         bool fast = j1 == j0 + 1 && j0 < ZK_FILL_META && nt0 <= (uint32_t)ZK_FILL_NT;       // one long segment: its records in registers
         if (fast) {
-            const ZkHole *rec = zk_uni(holes + zk_seg_region(frame_off, tpos, seg0 + j0));
+            const ZkHole *rec = holes + zk_uni((uint64_t)zk_seg_region(frame_off, tpos, seg0 + j0));
             ZkHole r0[ZK_FILL_NT], r1[ZK_FILL_NT];
             uint32_t base = 0;
 #pragma unroll
@@ -1623,8 +1648,8 @@ __global__ __launch_bounds__(L) void zk_k_exec_fill_lds(const uint64_t *d_off, u
                 const uint32_t nt = seg_nt_of(j);
                 if (!nt) continue;
                 const uint32_t spos = seg_pos_of(j);
-                const ZkHole *rec = zk_uni(holes + zk_seg_region(frame_off, spos, seg0 + j));
-                const uint32_t *tc = zk_uni(tilecnt + zk_seg_tile_region(frame_off, spos, block_base + seg_b0_of(j), seg0 + j));
+                const ZkHole *rec = holes + zk_uni((uint64_t)zk_seg_region(frame_off, spos, seg0 + j));
+                const uint32_t *tc = tilecnt + zk_uni((uint64_t)zk_seg_tile_region(frame_off, spos, block_base + seg_b0_of(j), seg0 + j));
                 const bool ahead = j < ZK_FILL_META && nt <= ZK_FILL_TC;
                 uint32_t base = 0;
                 for (uint32_t t0 = 0; t0 < nt; t0 += L) {
