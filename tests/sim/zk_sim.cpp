@@ -37,6 +37,11 @@ extern "C" void zk_sim_set_fse_quad(int on) { g_fse_quad = on; }
 static uint32_t g_seg_bytes = 0, g_fill_lanes = 64, g_seg_cap_shift = 2;
 static uint64_t g_seg_stats[4];                 // holes records, hole bytes, fill steps, frames that overflowed (executed again)
 extern "C" void zk_sim_set_exec_seg(uint32_t seg_bytes, uint32_t fill_lanes, uint32_t cap_shift) { g_seg_bytes = seg_bytes; g_fill_lanes = fill_lanes ? fill_lanes : 64; g_seg_cap_shift = cap_shift; }
+static int g_chase_stats_on = 0;
+static uint64_t g_slot_stats[2];
+extern "C" void zk_sim_slot_stats(uint64_t *out) { out[0] = g_slot_stats[0]; out[1] = g_slot_stats[1]; g_slot_stats[0] = g_slot_stats[1] = 0; }
+static uint64_t g_chase_stats[32];       // [0..15]: waves by their deepest chain, [16..31]: bytes by the depth of their chain
+extern "C" void zk_sim_chase_stats(uint64_t *out, int on) { for (int i = 0; i < 32; i++) { out[i] = g_chase_stats[i]; g_chase_stats[i] = 0; } g_chase_stats_on = on; }
 extern "C" void zk_sim_seg_stats(uint64_t *out, int reset) { for (int i = 0; i < 4; i++) { out[i] = g_seg_stats[i]; if (reset) g_seg_stats[i] = 0; } }
 // poison: the tables and scratch a block's lane builds and reads (on the device: LDS that holds whatever the workgroup before left
 // there) are filled with pseudo-random bytes before every block -- code that reads what it has not written shows up as a mismatch
@@ -260,6 +265,7 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
     std::vector<ZkSeq> st(RING);
     std::vector<uint32_t> srcmap(THREADS * B), slot_seq(THREADS * B / ZK_EXEC_SLOT + 1);
     std::vector<uint8_t> tile(THREADS * B);
+    std::vector<uint32_t> slow(THREADS * B / ZK_EXEC_SLOT / 32 + 1);        // the tile's slots for the general walk (zk_exec_mark_runs)
     // SEGMENT MODE (sg != nullptr): the bytes whose origin lies before the segment, or at a tainted byte of it, are not written
     // (poisoned here); their runs go to the hole list, their taint bits are set once the tile is done
     struct SegCtx { int32_t seg_lo; uint32_t seg_done; std::vector<uint32_t> *taint; std::vector<ZkHole> *holes; std::vector<uint32_t> *tiles; uint32_t cap; bool overflow; };
@@ -297,16 +303,18 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
             uint32_t jn = nl;
             std::fill(srcmap.begin(), srcmap.end(), 0u);                        // the map starts empty (run markers)
             std::fill(slot_seq.begin(), slot_seq.end(), 0xFFFFFFFFu);
+            std::fill(slow.begin(), slow.end(), 0u);
             for (uint32_t i = 0; i < nl; i++) {                                  // "lane per sequence"
                 const uint32_t idx = ja + i;
                 const uint32_t end = st[idx & M].out_end;
                 const uint32_t start = i ? st[(idx - 1) & M].out_end : prev_end;
+                const uint32_t prev_off = i ? st[(idx - 1) & M].off : 0xDEADBEEFu;   // (a sequence that has left the ring: its offset is never needed, and the kernel does not have it)
                 const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
                 if (lo < hi) {
                     uint32_t s0, n;
                     zk_exec_slot_span(ts, lo, hi, s0, n);
                     for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = idx;
-                    zk_exec_mark_runs(st[idx & M], start, ts, te, srcmap.data());
+                    zk_exec_mark_runs(st[idx & M], prev_off, start, ts, te, srcmap.data(), [&](uint32_t w, uint32_t bits) { slow[w] |= bits; });
                 }
                 if (end > te && start <= te) jn = i;
             }
@@ -315,11 +323,25 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
                 uint32_t sw[ZK_EXEC_SLOT];
                 uint32_t mk[ZK_EXEC_SLOT];
                 for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) mk[k] = q0 - ts + k < srcmap.size() ? srcmap[q0 - ts + k] : 0u;
-                zk_exec_slot_words_marked(st.data(), slot_seq[(q0 - ts) / ZK_EXEC_SLOT], q0, nb, mk, sw, M);
+                const uint32_t slot = (q0 - ts) / ZK_EXEC_SLOT;
+                if (g_chase_stats_on) { g_slot_stats[0]++; g_slot_stats[1] += (slow[slot >> 5] >> (slot & 31u)) & 1u; }
+                zk_exec_slot_words_marked(st.data(), slot_seq[slot], (slow[slot >> 5] >> (slot & 31u)) & 1u, q0, nb, mk, sw, M);
                 for (uint32_t k = 0; k < nb; k++) srcmap[q0 - ts + k] = sw[k];
             }
             const uint32_t mbase = ZK_SRC_BIAS + ts, span = te - ts;
             if (!sg) {
+                if (g_chase_stats_on) {                                          // statistics (tools/chase_stats.py): per "wave" of 64 slots the deepest chain, per byte its depth
+                    for (uint32_t w0 = ts; w0 < te; w0 += 64 * ZK_EXEC_SLOT) {
+                        uint32_t deepest = 0;
+                        for (uint32_t q = w0; q < te && q < w0 + 64 * ZK_EXEC_SLOT; q++) {
+                            uint32_t s = srcmap[q - ts], dep = 0;
+                            while (s - mbase < span) { s = srcmap[s - mbase]; dep++; }
+                            g_chase_stats[16 + (dep < 15 ? dep : 15)]++;
+                            deepest = dep > deepest ? dep : deepest;
+                        }
+                        g_chase_stats[deepest < 15 ? deepest : 15]++;
+                    }
+                }
                 for (uint32_t q = ts; q < te; q++) {                             // origins + gathers
                     uint32_t s = srcmap[q - ts];
                     while (s - mbase < span) s = srcmap[s - mbase];

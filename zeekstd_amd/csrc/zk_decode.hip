@@ -844,6 +844,21 @@ __device__ __forceinline__ void zk_publish(uint64_t *word, uint32_t bytes, uint6
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(word, flags | ((uint64_t)(zk_xcc_id() + 1) << 32) | bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// THE CHASE: a source word that points into the tile [ts, te) is replaced by the word of the byte it points at, until none does.
+// Counted on the bench's text (tools/chase_stats.py, the lane code on the CPU): 81.6 % of the bytes need no step, 18.1 % one, 0.3 % two --
+// but a WAVE runs as many passes over all 16 words of all its lanes as its deepest chain, plus the one that finds nothing to do: 2.76 on
+// average.  So the pass that finds nothing is not a pass: the least of the lane's sixteen (word - first in-tile word) says whether
+// any word still points into the tile (a subtraction and a third of a min3 per word, one vote per wave), and the passes themselves keep no
+// "again".  The first in-tile word in ONE scalar register (through zk_uni: the compiler otherwise subtracts ts and the bias separately).
+#define ZK_EXEC_CHASE(sw, srcmap, ts, te) do {                                                                         \
+        const uint32_t mbase_ = zk_uni(ZK_SRC_BIAS + (ts)), span_ = (te) - (ts);                                        \
+        for (;;) {                                                                                                      \
+            _Pragma("unroll") for (int k = 0; k < ZK_EXEC_B; k++) { const uint32_t d_ = sw[k] - mbase_; if (d_ < span_) sw[k] = srcmap[d_]; }  \
+            uint32_t least_ = sw[0] - mbase_;                                                                           \
+            _Pragma("unroll") for (int k = 1; k < ZK_EXEC_B; k++) { const uint32_t d_ = sw[k] - mbase_; least_ = d_ < least_ ? d_ : least_; } \
+            if (!__any(least_ < span_)) break;                                                                          \
+        }                                                                                                               \
+    } while (0)
 // REDO: only the frames zk_k_exec_seg gave up on (ZK_E_SEG_OVERFLOW: more hole records than their region holds) are executed, from scratch
 // (Measured and dropped, round 6: touching the sources of FAR matches ahead of time.  A record that was settled into the ring -- one to two
 //  tiles before its bytes are gathered -- with a match more than 24 KiB back had the line of its source requested by a load nobody waits
@@ -855,8 +870,13 @@ __device__ __forceinline__ void zk_publish(uint64_t *word, uint32_t bytes, uint6
 //  the line twice.  What did help there: fewer frames resident, zk_launch_exec.  profiles/r06_l3_far_touch_probe.txt.
 //  A first form of the touch -- a byte load into a "sink" register -- faulted: the compiler reuses a register it does not know a load
 //  is still going to write.)
+#ifdef ZK_EXEC_NO_WPE
+#define ZK_EXEC_WPE(T)
+#else
+#define ZK_EXEC_WPE(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 5 : 1)))
+#endif
 template <int T, bool PFX, int CAPX = 2, bool REDO = false>
-__global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
+__global__ __launch_bounds__(T) ZK_EXEC_WPE(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
                                                const uint32_t *ids, const uint64_t *out_off,
                                                const ZkBlock *blocks, const ZkFrameBase *bases,
                                                ZkFrameInfo *infos, const ZkSeqP *seqs,
@@ -875,6 +895,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
     __shared__ __attribute__((aligned(16))) uint32_t srcmap[T * ZK_EXEC_B];
     __shared__ uint32_t slot_seq[T];
     __shared__ uint32_t longlist[CAP + 1];
+    __shared__ uint32_t s_slow[(T + 31) / 32];   // the tile's slots that hold bytes of a match overlapping its own output (zk_exec_mark_runs)
     __shared__ uint32_t s_jn, s_nlong;
     __shared__ uint32_t s_bad[2];                // a lane found a bad record in a tile of this parity (the tile loop's barriers order LDS only)
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
@@ -973,6 +994,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                 //     run adds to a position (zk_exec_mark_runs); the slot pass below only carries them forward
 #pragma unroll
                 for (int k = 0; k < ZK_EXEC_B; k += 4) *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(0, 0, 0, 0);
+                if (tid < (T + 31) / 32) s_slow[tid] = 0;
                 ZK_LDS_BARRIER();
                 if (tid == 0) s_bad[tpar ^ 1] = 0;                               // the flag of the tile before: every wave has read it (in front of this barrier); the next tile sets it
                 // 2. lane per sequence: mark the slots it starts; the first sequence that outlives the tile sets jn
@@ -980,14 +1002,15 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                     const uint32_t idx = ja + i;
                     const ZkSeq me = S[idx & M];
                     const uint32_t end = me.out_end;
-                    const uint32_t start = i ? S[(idx - 1) & M].out_end : prev_end;
+                    uint32_t start = prev_end, prev_off = 1;                      // (the offset of a sequence that has left the ring is never needed: zk_exec_mark_runs)
+                    if (i) { const ZkSeq &pv = S[(idx - 1) & M]; start = pv.out_end; prev_off = pv.off; }
                     const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
                     if (lo < hi) {
                         uint32_t s0, n;
                         zk_exec_slot_span(ts, lo, hi, s0, n);
                         if (n > ZK_EXEC_LONG) longlist[atomicAdd(&s_nlong, 1u)] = idx;
                         else for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = idx;
-                        zk_exec_mark_runs(me, start, ts, te, srcmap);
+                        zk_exec_mark_runs(me, prev_off, start, ts, te, srcmap, [&](uint32_t w, uint32_t bits) { atomicOr(&s_slow[w], bits); });
                     }
                     if (end > te && start <= te) s_jn = i;
                 }
@@ -1027,7 +1050,11 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                             const uint4 v = *reinterpret_cast<const uint4 *>(&srcmap[tid * ZK_EXEC_B + k]);
                             mk[k] = v.x; mk[k + 1] = v.y; mk[k + 2] = v.z; mk[k + 3] = v.w;
                         }
-                        zk_exec_slot_words_marked(S, slot_seq[tid], q0, nb, mk, sw, M);
+                        // (the slot's first mark is never read; said to be, so that the reads stay four of 16 bytes: narrowed to the fifteen words
+                        //  that are, they became eight ds_read2_b32 at a lane stride of 64 bytes -- two banks for 64 lanes -- and the executor took
+                        //  9.4 instead of 7.4 ms)
+                        asm volatile("" :: "v"(mk[0]));
+                        zk_exec_slot_words_marked(S, slot_seq[tid], (s_slow[tid >> 5] >> (tid & 31u)) & 1u, q0, nb, mk, sw, M);
                     }
 #pragma unroll
                     for (int k = 0; k < ZK_EXEC_B; k += 4)
@@ -1045,16 +1072,7 @@ __global__ __launch_bounds__(T) void zk_k_exec(const uint8_t *comp, const uint64
                 }
                 // 4. origins (in-tile history words are exactly [BIAS + ts, BIAS + te)), gathers, one coalesced store
                 if (nb) {
-                    const uint32_t mbase = ZK_SRC_BIAS + ts, span = te - ts;
-                    bool again;
-                    do {
-                        again = false;
-#pragma unroll
-                        for (int k = 0; k < ZK_EXEC_B; k++) {
-                            const uint32_t d = sw[k] - mbase;
-                            if (d < span) { sw[k] = srcmap[d]; again = true; }
-                        }
-                    } while (again);
+                    ZK_EXEC_CHASE(sw, srcmap, ts, te);
                     ZK_CLK(4);
                     uint32_t ob[ZK_EXEC_B];
 #ifdef ZK_EXEC_GATHER_OLD
@@ -1199,6 +1217,7 @@ __global__ __launch_bounds__(T) void zk_k_exec_seg(const uint8_t *comp, const ui
     __shared__ __attribute__((aligned(16))) uint32_t taint[ZK_SEG_BYTES / 32 + 4];      // one bit per byte of the segment: the byte is a hole
     __shared__ uint32_t slot_seq[T];
     __shared__ uint32_t longlist[CAP + 1];
+    __shared__ uint32_t s_slow[(T + 31) / 32];   // the tile's slots that hold bytes of a match overlapping its own output (zk_exec_mark_runs)
     __shared__ uint32_t s_jn, s_nlong, s_nrec;
     __shared__ uint32_t s_bad[2];
     const uint32_t f = blockIdx.x, sgi = blockIdx.y, tid = threadIdx.x;
@@ -1287,20 +1306,22 @@ __global__ __launch_bounds__(T) void zk_k_exec_seg(const uint8_t *comp, const ui
                 const uint32_t te = ts + T * ZK_EXEC_B < cap_end ? ts + T * ZK_EXEC_B : cap_end;
 #pragma unroll
                 for (int k = 0; k < ZK_EXEC_B; k += 4) *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(0, 0, 0, 0);
+                if (tid < (T + 31) / 32) s_slow[tid] = 0;
                 ZK_LDS_BARRIER();
                 if (tid == 0) { s_bad[tpar ^ 1] = 0; s_nrec = 0; }                // (the tile before: every wave has read both in front of this barrier)
                 for (uint32_t i = tid; i < nl; i += T) {
                     const uint32_t idx = ja + i;
                     const ZkSeq me = S[idx & M];
                     const uint32_t end = me.out_end;
-                    const uint32_t start = i ? S[(idx - 1) & M].out_end : prev_end;
+                    uint32_t start = prev_end, prev_off = 1;                      // (the offset of a sequence that has left the ring is never needed: zk_exec_mark_runs)
+                    if (i) { const ZkSeq &pv = S[(idx - 1) & M]; start = pv.out_end; prev_off = pv.off; }
                     const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
                     if (lo < hi) {
                         uint32_t s0, n;
                         zk_exec_slot_span(ts, lo, hi, s0, n);
                         if (n > ZK_EXEC_LONG) longlist[atomicAdd(&s_nlong, 1u)] = idx;
                         else for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = idx;
-                        zk_exec_mark_runs(me, start, ts, te, srcmap);
+                        zk_exec_mark_runs(me, prev_off, start, ts, te, srcmap, [&](uint32_t w, uint32_t bits) { atomicOr(&s_slow[w], bits); });
                     }
                     if (end > te && start <= te) s_jn = i;
                 }
@@ -1336,7 +1357,11 @@ __global__ __launch_bounds__(T) void zk_k_exec_seg(const uint8_t *comp, const ui
                             const uint4 v = *reinterpret_cast<const uint4 *>(&srcmap[tid * ZK_EXEC_B + k]);
                             mk[k] = v.x; mk[k + 1] = v.y; mk[k + 2] = v.z; mk[k + 3] = v.w;
                         }
-                        zk_exec_slot_words_marked(S, slot_seq[tid], q0, nb, mk, sw, M);
+                        // (the slot's first mark is never read; said to be, so that the reads stay four of 16 bytes: narrowed to the fifteen words
+                        //  that are, they became eight ds_read2_b32 at a lane stride of 64 bytes -- two banks for 64 lanes -- and the executor took
+                        //  9.4 instead of 7.4 ms)
+                        asm volatile("" :: "v"(mk[0]));
+                        zk_exec_slot_words_marked(S, slot_seq[tid], (s_slow[tid >> 5] >> (tid & 31u)) & 1u, q0, nb, mk, sw, M);
                     }
 #pragma unroll
                     for (int k = 0; k < ZK_EXEC_B; k += 4)
@@ -1353,16 +1378,7 @@ __global__ __launch_bounds__(T) void zk_k_exec_seg(const uint8_t *comp, const ui
                 //    the others, one coalesced store (a hole's byte of the store is whatever: zk_k_exec_fill writes it), the holes' runs as records
                 uint32_t hm = 0, starts = 0, len[ZK_EXEC_B];
                 if (nb) {
-                    const uint32_t mbase = ZK_SRC_BIAS + ts, span = te - ts;
-                    bool again;
-                    do {
-                        again = false;
-#pragma unroll
-                        for (int k = 0; k < ZK_EXEC_B; k++) {
-                            const uint32_t d = sw[k] - mbase;
-                            if (d < span) { sw[k] = srcmap[d]; again = true; }
-                        }
-                    } while (again);
+                    ZK_EXEC_CHASE(sw, srcmap, ts, te);
                     hm = zk_seg_slot_holes(sw, nb, seg_lo, [&](uint32_t p) { return (bool)((taint[p >> 5] >> (p & 31u)) & 1u); });
                     starts = zk_seg_slot_runs(sw, hm, len);
                     uint32_t ob[ZK_EXEC_B];

@@ -1350,36 +1350,50 @@ ZK_HD void zk_exec_slot_seq(const ZkSeq &e, uint32_t q, ZkSlotCur &c)
 
 ZK_HD void zk_exec_slot_words(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t nb, uint32_t *sw, uint32_t ring_mask);
 // The common form of a slot's 16 source words.  Within a run -- the literals of a sequence, or its match unless the match
-// overlaps its own output -- a byte's word is its position plus a constant: (LIT | lit_end) - ms for literals,
-// BIAS - off for a match.  The lane that owns a SEQUENCE leaves these constants in the (emptied) map at the bytes where its
-// two runs start (zk_exec_mark_runs, part of the marking pass); the lane that owns a SLOT then only carries the last
-// constant forward over its 16 bytes (zk_exec_slot_words_marked) -- no walk over sequence ends, which used to be 16 steps
-// with a divergent branch and an LDS round trip each (a third of the executor's time).  A match that overlaps itself
-// leaves ZK_MARK_SLOW: its slots take the general walk (zk_exec_slot_words).
-constexpr uint32_t ZK_MARK_SLOW = 0xFFFFFFFFu;          // no run constant has this value (literals: 0x7FFE0000..0x80020000, matches: 1..2^30)
-ZK_HD void zk_exec_mark_runs(const ZkSeq &e, uint32_t start, uint32_t ts, uint32_t te, uint32_t *map)
+// overlaps its own output -- a byte's word is its position plus a constant: (LIT | lit_end) - ms for literals, BIAS - off for a
+// match.  The lane that owns a SEQUENCE leaves, in the (emptied) map at the bytes where its two runs start, what each run ADDS to
+// the constant of the run before it (zk_exec_mark_runs, part of the marking pass: the run before a sequence's literals is the
+// match of the sequence before it, which the lane reads anyway); the lane that owns a SLOT starts from the constant of the
+// sequence that covers its first byte and then takes ONE addition per byte, word[k] = word[k - 1] + 1 + map[k]
+// (zk_exec_slot_words_marked) -- no walk over sequence ends, which used to be 16 steps with a divergent branch and an LDS round
+// trip each (a third of the executor's time), and (r6) no compare-and-select per byte either (marks used to be the constants
+// themselves: a compare, a select and an addition per byte, and a wait state between the first two).  A match that overlaps its
+// own output (offset < length: its bytes repeat with the period of the offset) flags the slots it touches in a bitmap of the
+// tile's slots: those take the general walk (zk_exec_slot_words).  A mark that falls on a slot's FIRST byte is never read: that
+// byte's constant comes from the covering sequence.
+ZK_HD uint32_t zk_exec_lit_const(const ZkSeq &e) { return (ZK_SRC_LIT | e.lit_end) - (e.out_end - e.ml); }
+ZK_HD uint32_t zk_exec_match_const(uint32_t off) { return ZK_SRC_BIAS - off; }
+// e: the sequence, start: where its literals start (= the end of the sequence before it), prev_off: that sequence's offset (any
+// value when start <= ts: no mark depends on it then); slow_or(word, bits): or into the tile's bitmap of slots for the general walk
+template <typename OR>
+ZK_HD void zk_exec_mark_runs(const ZkSeq &e, uint32_t prev_off, uint32_t start, uint32_t ts, uint32_t te, uint32_t *map, OR &&slow_or)
 {
     const uint32_t ms = e.out_end - e.ml;
-    if (ms > start && start >= ts && start < te) map[start - ts] = (ZK_SRC_LIT | e.lit_end) - ms;
-    if (e.ml && ms >= ts && ms < te) map[ms - ts] = e.off < e.ml ? ZK_MARK_SLOW : ZK_SRC_BIAS - e.off;
+    const uint32_t cl = zk_exec_lit_const(e), cm = zk_exec_match_const(e.off), cp = zk_exec_match_const(prev_off);
+    if (ms > start && start > ts && start < te) map[start - ts] = cl - cp;
+    if (e.ml && ms > ts && ms < te) map[ms - ts] = cm - (ms > start ? cl : cp);
+    if (e.ml && e.off < e.ml) {
+        const uint32_t lo = ms > ts ? ms : ts, hi = e.out_end < te ? e.out_end : te;
+        if (lo < hi) {
+            const uint32_t s_lo = (lo - ts) / ZK_EXEC_SLOT, s_hi = (hi - 1 - ts) / ZK_EXEC_SLOT;       // slots [s_lo, s_hi] hold bytes of the match
+            for (uint32_t w = s_lo >> 5; w <= (s_hi >> 5); w++) {
+                const uint32_t b0 = s_lo > w * 32u ? s_lo - w * 32u : 0u, b1 = s_hi < w * 32u + 31u ? s_hi - w * 32u : 31u;
+                slow_or(w, (0xFFFFFFFFu >> (31u - b1)) & (0xFFFFFFFFu << b0));
+            }
+        }
+    }
 }
-// mk: the slot's 16 words of the map after the marking pass (0 = no run starts here); i0: the sequence that covers q0
-ZK_HD void zk_exec_slot_words_marked(const ZkSeq *S, uint32_t i0, uint32_t q0, uint32_t nb, const uint32_t *mk, uint32_t *sw, uint32_t ring_mask = 0xFFFFFFFFu)
+// mk: the slot's 16 words of the map after the marking pass; i0: the sequence that covers q0; slow: the slot's bit of the bitmap
+ZK_HD void zk_exec_slot_words_marked(const ZkSeq *S, uint32_t i0, bool slow, uint32_t q0, uint32_t nb, const uint32_t *mk, uint32_t *sw, uint32_t ring_mask = 0xFFFFFFFFu)
 {
+    if (slow) { zk_exec_slot_words(S, i0, q0, nb, sw, ring_mask); return; }
     const ZkSeq e0 = S[i0 & ring_mask];
-    const uint32_t ms0 = e0.out_end - e0.ml;
-    const bool inm = q0 >= ms0;
-    uint32_t c = inm ? ZK_SRC_BIAS - e0.off : (ZK_SRC_LIT | e0.lit_end) - ms0;
-    uint32_t top = 0;
+    uint32_t w = q0 + (q0 >= e0.out_end - e0.ml ? zk_exec_match_const(e0.off) : zk_exec_lit_const(e0));
+    sw[0] = w;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) top = mk[k] > top ? mk[k] : top;
-    if (top == ZK_MARK_SLOW || (inm && e0.off < e0.ml)) { zk_exec_slot_words(S, i0, q0, nb, sw, ring_mask); return; }
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) { c = mk[k] ? mk[k] : c; sw[k] = q0 + k + c; }
+    for (uint32_t k = 1; k < ZK_EXEC_SLOT; k++) { w += mk[k] + 1u; sw[k] = w; }
     if (nb < ZK_EXEC_SLOT) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
