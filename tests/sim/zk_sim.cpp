@@ -322,11 +322,11 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
                 const uint32_t nb = te - q0 < ZK_EXEC_SLOT ? te - q0 : ZK_EXEC_SLOT;
                 uint32_t sw[ZK_EXEC_SLOT];
                 uint32_t mk[ZK_EXEC_SLOT];
-                for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) mk[k] = q0 - ts + k < srcmap.size() ? srcmap[q0 - ts + k] : 0u;
+                for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) mk[k] = q0 - ts + k < srcmap.size() ? srcmap[zk_exec_map_index(q0 - ts + k)] : 0u;
                 const uint32_t slot = (q0 - ts) / ZK_EXEC_SLOT;
                 if (g_chase_stats_on) { g_slot_stats[0]++; g_slot_stats[1] += (slow[slot >> 5] >> (slot & 31u)) & 1u; }
                 zk_exec_slot_words_marked(st.data(), slot_seq[slot], (slow[slot >> 5] >> (slot & 31u)) & 1u, q0, nb, mk, sw, M);
-                for (uint32_t k = 0; k < nb; k++) srcmap[q0 - ts + k] = sw[k];
+                for (uint32_t k = 0; k < nb; k++) srcmap[zk_exec_map_index(q0 - ts + k)] = sw[k];
             }
             const uint32_t mbase = ZK_SRC_BIAS + ts, span = te - ts;
             if (!sg) {
@@ -334,8 +334,8 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
                     for (uint32_t w0 = ts; w0 < te; w0 += 64 * ZK_EXEC_SLOT) {
                         uint32_t deepest = 0;
                         for (uint32_t q = w0; q < te && q < w0 + 64 * ZK_EXEC_SLOT; q++) {
-                            uint32_t s = srcmap[q - ts], dep = 0;
-                            while (s - mbase < span) { s = srcmap[s - mbase]; dep++; }
+                            uint32_t s = srcmap[zk_exec_map_index(q - ts)], dep = 0;
+                            while (s - mbase < span) { s = srcmap[zk_exec_map_index(s - mbase)]; dep++; }
                             g_chase_stats[16 + (dep < 15 ? dep : 15)]++;
                             deepest = dep > deepest ? dep : deepest;
                         }
@@ -343,8 +343,8 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
                     }
                 }
                 for (uint32_t q = ts; q < te; q++) {                             // origins + gathers
-                    uint32_t s = srcmap[q - ts];
-                    while (s - mbase < span) s = srcmap[s - mbase];
+                    uint32_t s = srcmap[zk_exec_map_index(q - ts)];
+                    while (s - mbase < span) s = srcmap[zk_exec_map_index(s - mbase)];
                     if (s & ZK_SRC_LIT) tile[q - ts] = l[(s & lit_mask)];
                     else {
                         const int64_t rel = (int64_t)pos + (int32_t)(s - ZK_SRC_BIAS);
@@ -363,8 +363,8 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
                         const uint32_t nb = te - q0 < ZK_EXEC_SLOT ? te - q0 : ZK_EXEC_SLOT;
                         uint32_t sw[ZK_EXEC_SLOT], len[ZK_EXEC_SLOT];
                         for (uint32_t k = 0; k < ZK_EXEC_SLOT; k++) {
-                            uint32_t s = k < nb ? srcmap[q0 - ts + k] : ZK_SRC_LIT;
-                            while (s - mbase < span) s = srcmap[s - mbase];
+                            uint32_t s = k < nb ? srcmap[zk_exec_map_index(q0 - ts + k)] : ZK_SRC_LIT;
+                            while (s - mbase < span) s = srcmap[zk_exec_map_index(s - mbase)];
                             sw[k] = s;
                         }
                         const std::vector<uint32_t> &tb = *sg->taint;

@@ -853,7 +853,7 @@ __device__ __forceinline__ void zk_publish(uint64_t *word, uint32_t bytes, uint6
 #define ZK_EXEC_CHASE(sw, srcmap, ts, te) do {                                                                         \
         const uint32_t mbase_ = zk_uni(ZK_SRC_BIAS + (ts)), span_ = (te) - (ts);                                        \
         for (;;) {                                                                                                      \
-            _Pragma("unroll") for (int k = 0; k < ZK_EXEC_B; k++) { const uint32_t d_ = sw[k] - mbase_; if (d_ < span_) sw[k] = srcmap[d_]; }  \
+            _Pragma("unroll") for (int k = 0; k < ZK_EXEC_B; k++) { const uint32_t d_ = sw[k] - mbase_; if (d_ < span_) sw[k] = srcmap[zk_exec_map_index(d_)]; }  \
             uint32_t least_ = sw[0] - mbase_;                                                                           \
             _Pragma("unroll") for (int k = 1; k < ZK_EXEC_B; k++) { const uint32_t d_ = sw[k] - mbase_; least_ = d_ < least_ ? d_ : least_; } \
             if (!__any(least_ < span_)) break;                                                                          \
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(T) ZK_EXEC_WPE(T) void zk_k_exec(const uint8_t *com
                 // 1a. the map starts empty: the lane of a sequence leaves, at the bytes where its two runs start, the word that
                 //     run adds to a position (zk_exec_mark_runs); the slot pass below only carries them forward
 #pragma unroll
-                for (int k = 0; k < ZK_EXEC_B; k += 4) *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(0, 0, 0, 0);
+                for (int k = 0; k < ZK_EXEC_B; k += 4) *reinterpret_cast<uint4 *>(&srcmap[zk_exec_map_index(tid * ZK_EXEC_B + k)]) = make_uint4(0, 0, 0, 0);
                 if (tid < (T + 31) / 32) s_slow[tid] = 0;
                 ZK_LDS_BARRIER();
                 if (tid == 0) s_bad[tpar ^ 1] = 0;                               // the flag of the tile before: every wave has read it (in front of this barrier); the next tile sets it
@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(T) ZK_EXEC_WPE(T) void zk_k_exec(const uint8_t *com
                         uint32_t mk[ZK_EXEC_B];
 #pragma unroll
                         for (int k = 0; k < ZK_EXEC_B; k += 4) {
-                            const uint4 v = *reinterpret_cast<const uint4 *>(&srcmap[tid * ZK_EXEC_B + k]);
+                            const uint4 v = *reinterpret_cast<const uint4 *>(&srcmap[zk_exec_map_index(tid * ZK_EXEC_B + k)]);
                             mk[k] = v.x; mk[k + 1] = v.y; mk[k + 2] = v.z; mk[k + 3] = v.w;
                         }
                         // (the slot's first mark is never read; said to be, so that the reads stay four of 16 bytes: narrowed to the fifteen words
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(T) ZK_EXEC_WPE(T) void zk_k_exec(const uint8_t *com
                     }
 #pragma unroll
                     for (int k = 0; k < ZK_EXEC_B; k += 4)
-                        *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(sw[k], sw[k + 1], sw[k + 2], sw[k + 3]);
+                        *reinterpret_cast<uint4 *>(&srcmap[zk_exec_map_index(tid * ZK_EXEC_B + k)]) = make_uint4(sw[k], sw[k + 1], sw[k + 2], sw[k + 3]);
                 }
                 ZK_CLK(3);
                 __syncthreads();                                                 // the full one: every wave's stores of the tile before are in memory
@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(T) void zk_k_exec_seg(const uint8_t *comp, const ui
                 const uint32_t cap_end = zk_uni(S[(staged_end - 1) & M].out_end);
                 const uint32_t te = ts + T * ZK_EXEC_B < cap_end ? ts + T * ZK_EXEC_B : cap_end;
 #pragma unroll
-                for (int k = 0; k < ZK_EXEC_B; k += 4) *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(0, 0, 0, 0);
+                for (int k = 0; k < ZK_EXEC_B; k += 4) *reinterpret_cast<uint4 *>(&srcmap[zk_exec_map_index(tid * ZK_EXEC_B + k)]) = make_uint4(0, 0, 0, 0);
                 if (tid < (T + 31) / 32) s_slow[tid] = 0;
                 ZK_LDS_BARRIER();
                 if (tid == 0) { s_bad[tpar ^ 1] = 0; s_nrec = 0; }                // (the tile before: every wave has read both in front of this barrier)
@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(T) void zk_k_exec_seg(const uint8_t *comp, const ui
                         uint32_t mk[ZK_EXEC_B];
 #pragma unroll
                         for (int k = 0; k < ZK_EXEC_B; k += 4) {
-                            const uint4 v = *reinterpret_cast<const uint4 *>(&srcmap[tid * ZK_EXEC_B + k]);
+                            const uint4 v = *reinterpret_cast<const uint4 *>(&srcmap[zk_exec_map_index(tid * ZK_EXEC_B + k)]);
                             mk[k] = v.x; mk[k + 1] = v.y; mk[k + 2] = v.z; mk[k + 3] = v.w;
                         }
                         // (the slot's first mark is never read; said to be, so that the reads stay four of 16 bytes: narrowed to the fifteen words
@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(T) void zk_k_exec_seg(const uint8_t *comp, const ui
                     }
 #pragma unroll
                     for (int k = 0; k < ZK_EXEC_B; k += 4)
-                        *reinterpret_cast<uint4 *>(&srcmap[tid * ZK_EXEC_B + k]) = make_uint4(sw[k], sw[k + 1], sw[k + 2], sw[k + 3]);
+                        *reinterpret_cast<uint4 *>(&srcmap[zk_exec_map_index(tid * ZK_EXEC_B + k)]) = make_uint4(sw[k], sw[k + 1], sw[k + 2], sw[k + 3]);
                 }
                 __syncthreads();                                                 // the full one: every wave's stores of the tile before are in memory
                 if (tid == 0) { s_jn = fetch_end - (ja + jn); s_nlong = 0; }

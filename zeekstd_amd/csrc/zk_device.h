@@ -1361,6 +1361,14 @@ ZK_HD void zk_exec_slot_words(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t 
 // own output (offset < length: its bytes repeat with the period of the offset) flags the slots it touches in a bitmap of the
 // tile's slots: those take the general walk (zk_exec_slot_words).  A mark that falls on a slot's FIRST byte is never read: that
 // byte's constant comes from the covering sequence.
+// WHERE a position's word lies in the map.  A lane reads and writes the sixteen words of its slot as four 16-byte accesses; laid out
+// in position order, consecutive lanes are 64 bytes apart and eight of them (one pass of the LDS: 8 x 16 bytes = its 32 banks) use
+// two groups of four banks -- every such access runs four times (the map is emptied, read and written that way every tile: twelve
+// accesses per lane).  So the 16-byte chunk c of the map lies at chunk c ^ ((c >> 3) & 7): inside every 128 bytes the chunks are
+// permuted by the number of their 128-byte row, eight consecutive lanes' chunks fall into eight different groups of banks, a lane's own
+// chunks stay 16-byte units at one xor from each other.  What pays: the accesses BY POSITION (marks, the chase), three instructions
+// instead of one for the address.
+ZK_HD uint32_t zk_exec_map_index(uint32_t p) { return p ^ (((p >> 5) & 7u) << 2); }
 ZK_HD uint32_t zk_exec_lit_const(const ZkSeq &e) { return (ZK_SRC_LIT | e.lit_end) - (e.out_end - e.ml); }
 ZK_HD uint32_t zk_exec_match_const(uint32_t off) { return ZK_SRC_BIAS - off; }
 // e: the sequence, start: where its literals start (= the end of the sequence before it), prev_off: that sequence's offset (any
@@ -1370,8 +1378,8 @@ ZK_HD void zk_exec_mark_runs(const ZkSeq &e, uint32_t prev_off, uint32_t start, 
 {
     const uint32_t ms = e.out_end - e.ml;
     const uint32_t cl = zk_exec_lit_const(e), cm = zk_exec_match_const(e.off), cp = zk_exec_match_const(prev_off);
-    if (ms > start && start > ts && start < te) map[start - ts] = cl - cp;
-    if (e.ml && ms > ts && ms < te) map[ms - ts] = cm - (ms > start ? cl : cp);
+    if (ms > start && start > ts && start < te) map[zk_exec_map_index(start - ts)] = cl - cp;
+    if (e.ml && ms > ts && ms < te) map[zk_exec_map_index(ms - ts)] = cm - (ms > start ? cl : cp);
     if (e.ml && e.off < e.ml) {
         const uint32_t lo = ms > ts ? ms : ts, hi = e.out_end < te ? e.out_end : te;
         if (lo < hi) {
@@ -1423,7 +1431,7 @@ ZK_HD void zk_exec_slot_words(const ZkSeq *S, uint32_t i, uint32_t q0, uint32_t 
 // Follow in-tile sources: returns a word that is a literal or a history position before the tile.
 ZK_HD uint32_t zk_exec_origin(const uint32_t *srcmap, uint32_t s, uint32_t ts)
 {
-    while (!(s & ZK_SRC_LIT) && (int32_t)(s - ZK_SRC_BIAS) >= (int32_t)ts) s = srcmap[(s - ZK_SRC_BIAS) - ts];
+    while (!(s & ZK_SRC_LIT) && (int32_t)(s - ZK_SRC_BIAS) >= (int32_t)ts) s = srcmap[zk_exec_map_index((s - ZK_SRC_BIAS) - ts)];
     return s;
 }
 
