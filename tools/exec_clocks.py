@@ -31,7 +31,7 @@ torch.cuda.synchronize()
 out = (C.c_ulonglong * 8)()
 raw.zk_debug_clocks(out, 0)
 v = np.array(list(out), dtype=np.float64)
-names = ["block setup + first staging", "mark", "barrier waits", "prefetch + long + slot words + map", "settle + chase", "gathers + store", "-", "-"]
+names = ["block setup + first staging", "mark", "barrier waits", "prefetch + long + slot words + map", "chase", "pack + store", "settle", "gather addresses + loads + their wait"]
 tot = v.sum()
 print("exec ms", round(eng.kernel_times()["zk_k_exec"], 3), "waves", nf * 4)
 for nm, x in zip(names, v):

@@ -870,6 +870,9 @@ __device__ __forceinline__ void zk_publish(uint64_t *word, uint32_t bytes, uint6
 //  the line twice.  What did help there: fewer frames resident, zk_launch_exec.  profiles/r06_l3_far_touch_probe.txt.
 //  A first form of the touch -- a byte load into a "sink" register -- faulted: the compiler reuses a register it does not know a load
 //  is still going to write.)
+#ifndef ZK_EXEC_WIDE
+#define ZK_EXEC_WIDE 1
+#endif
 #ifdef ZK_EXEC_NO_WPE
 #define ZK_EXEC_WPE(T)
 #else
@@ -1070,54 +1073,77 @@ __global__ __launch_bounds__(T) ZK_EXEC_WPE(T) void zk_k_exec(const uint8_t *com
                     const uint32_t idx = staged_end + tid + (uint32_t)u * T;
                     if (idx < fetch_end) settle(idx, pf0[u], pf1[u], bad);
                 }
+                ZK_CLK(6);
                 // 4. origins (in-tile history words are exactly [BIAS + ts, BIAS + te)), gathers, one coalesced store
                 if (nb) {
                     ZK_EXEC_CHASE(sw, srcmap, ts, te);
                     ZK_CLK(4);
-                    uint32_t ob[ZK_EXEC_B];
-#ifdef ZK_EXEC_GATHER_OLD
-#pragma unroll
-                    for (int k = 0; k < ZK_EXEC_B; k++) {
-                        const uint32_t s = sw[k];
-                        const uint8_t *a = (s & ZK_SRC_LIT) ? lit + (s & lit_mask) : bout + (int64_t)(int32_t)(s - ZK_SRC_BIAS);
-                        if (PFX && !(s & ZK_SRC_LIT)) {      // a position before the frame's first byte lies in the prefix
-                            const int64_t rel = (int64_t)pos + (int32_t)(s - ZK_SRC_BIAS);
-                            if (rel < 0) a = prefix + plen + rel;
-                        }
-                        if ((uint32_t)k >= nb) a = bout;     // harmless address for the bytes past the tile end
-                        ob[k] = *a;
-                    }
-#else
                     // A byte's address = its source word + one of two bases (the words' tags folded into them): a compare, two selects
-                    // and a 64-bit add per byte, and a GLOBAL load -- the bases went through zk_uni (an integer), which left the compiler
+                    // and a 64-bit add, and a GLOBAL load -- the bases went through zk_uni (an integer), which left the compiler
                     // with generic pointers: flat loads, and twelve instructions per byte.  Words past the tile's end are ZK_SRC_LIT
                     // (zk_exec_slot_words*): literal 0, always readable.  RLE literals: every literal word becomes literal 0.
                     if (lit_mask == 0) {
 #pragma unroll
                         for (int k = 0; k < ZK_EXEC_B; k++) sw[k] = (sw[k] & ZK_SRC_LIT) ? ZK_SRC_LIT : sw[k];
                     }
+                    uint32_t ov[ZK_EXEC_B / 4];                       // the slot's sixteen bytes
+                    typedef const __attribute__((address_space(1))) uint8_t *gbyte_t;
+                    if (!PFX && ZK_EXEC_WIDE && pos + te + 3 <= d_size) {
+                        // FOUR BYTES PER LOOKUP where a run allows it.  The L1 takes one lookup per LANE of a byte load whatever the
+                        // addresses (TCP_TOTAL_CACHE_ACCESSES: 4.29 G for 4 GiB of output, one per cycle and CU for the whole kernel: the
+                        // unit that is full, profiles/r06_exec_gather_probe.txt).  Of a lane's four groups of four bytes about half lie
+                        // inside one run -- four consecutive source words: one unaligned 4-byte load at the first word's address brings
+                        // all four; the other lanes keep its low byte and load three more bytes, with the first group of lanes masked
+                        // off.  The load reads up to three bytes past a source: literals have that slack (ZK_COMP_PADDING, the scratch's
+                        // own), history has it unless the frame ends within three bytes of the tile (then: the loop below).
+                        uint32_t lone = 0;                            // bit g: group g is not one run
+                        uint32_t b1[ZK_EXEC_B / 4], b2[ZK_EXEC_B / 4], b3[ZK_EXEC_B / 4];
 #pragma unroll
-                    for (int k = 0; k < ZK_EXEC_B; k++) {
-                        const uint32_t s = sw[k];
-                        uint64_t a = ((int32_t)s < 0 ? lit_w : his_w) + s;
-                        if (PFX && (int32_t)s >= 0) {        // a position before the frame's first byte lies in the prefix
-                            const int64_t rel = (int64_t)pos + (int32_t)(s - ZK_SRC_BIAS);
-                            if (rel < 0) a = (uint64_t)(uintptr_t)prefix + plen + rel;
+                        for (int g = 0; g < ZK_EXEC_B / 4; g++) {
+                            const uint32_t s0 = sw[4 * g];
+                            const bool run = ((sw[4 * g + 1] - s0) == 1u) & ((sw[4 * g + 2] - s0) == 2u) & ((sw[4 * g + 3] - s0) == 3u);
+                            uint32_t v;
+                            __builtin_memcpy(&v, (const void *)(gbyte_t)(((int32_t)s0 < 0 ? lit_w : his_w) + s0), 4);
+                            ov[g] = v; b1[g] = 0; b2[g] = 0; b3[g] = 0;
+                            if (!run) {
+                                lone |= 1u << g;
+                                const uint32_t s1 = sw[4 * g + 1], s2 = sw[4 * g + 2], s3 = sw[4 * g + 3];
+                                b1[g] = *(gbyte_t)(((int32_t)s1 < 0 ? lit_w : his_w) + s1);
+                                b2[g] = *(gbyte_t)(((int32_t)s2 < 0 ? lit_w : his_w) + s2);
+                                b3[g] = *(gbyte_t)(((int32_t)s3 < 0 ? lit_w : his_w) + s3);
+                            }
                         }
-                        ob[k] = *(const __attribute__((address_space(1))) uint8_t *)a;
-                    }
-#endif
-                    uint8_t *w = bout + q0;
-                    if (nb == ZK_EXEC_B && (((uintptr_t)w) & 15) == 0) {
-                        uint4 v;
-                        v.x = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
-                        v.y = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
-                        v.z = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
-                        v.w = ob[12] | (ob[13] << 8) | (ob[14] << 16) | (ob[15] << 24);
-                        *reinterpret_cast<uint4 *>(w) = v;
-                    } else {
+                        // (byte permutes, not shifts: a shift of "the loaded byte, or 0 where the loads were skipped" is moved INTO the masked
+                        //  region by the compiler, with a wait for the load in front of it -- four round trips to memory in a row)
 #pragma unroll
-                        for (int k = 0; k < ZK_EXEC_B; k++) if ((uint32_t)k < nb) w[k] = (uint8_t)ob[k];
+                        for (int g = 0; g < ZK_EXEC_B / 4; g++) {
+                            const uint32_t lo = __builtin_amdgcn_perm(b1[g], ov[g], 0x0c0c0400u), hi = __builtin_amdgcn_perm(b3[g], b2[g], 0x04000c0cu);
+                            ov[g] = (lone >> g) & 1u ? lo | hi : ov[g];
+                        }
+                    } else {
+                        uint32_t ob[ZK_EXEC_B];
+#pragma unroll
+                        for (int k = 0; k < ZK_EXEC_B; k++) {
+                            const uint32_t s = sw[k];
+                            uint64_t a = ((int32_t)s < 0 ? lit_w : his_w) + s;
+                            if (PFX && (int32_t)s >= 0) {        // a position before the frame's first byte lies in the prefix
+                                const int64_t rel = (int64_t)pos + (int32_t)(s - ZK_SRC_BIAS);
+                                if (rel < 0) a = (uint64_t)(uintptr_t)prefix + plen + rel;
+                            }
+                            ob[k] = *(gbyte_t)a;
+                        }
+#pragma unroll
+                        for (int g = 0; g < ZK_EXEC_B / 4; g++) ov[g] = ob[4 * g] | (ob[4 * g + 1] << 8) | (ob[4 * g + 2] << 16) | (ob[4 * g + 3] << 24);
+                    }
+                    uint8_t *w = bout + q0;
+#ifdef ZK_EXEC_CLOCKS
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    ZK_CLK(7);
+#endif
+                    if (nb == ZK_EXEC_B && (((uintptr_t)w) & 15) == 0) *reinterpret_cast<uint4 *>(w) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < ZK_EXEC_B; k++) if ((uint32_t)k < nb) w[k] = (uint8_t)(ov[k >> 2] >> (8 * (k & 3)));
                     }
                 }
                 prev_end = next_prev_end;
