@@ -879,12 +879,12 @@ __device__ __forceinline__ void zk_publish(uint64_t *word, uint32_t bytes, uint6
 #define ZK_EXEC_WPE(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 5 : 1)))
 #endif
 template <int T, bool PFX, int CAPX = 2, bool REDO = false>
-__global__ __launch_bounds__(T) ZK_EXEC_WPE(T) void zk_k_exec(const uint8_t *comp, const uint64_t *d_off, uint32_t first,
-                                               const uint32_t *ids, const uint64_t *out_off,
-                                               const ZkBlock *blocks, const ZkFrameBase *bases,
-                                               ZkFrameInfo *infos, const ZkSeqP *seqs,
-                                               const uint8_t *lit_scratch, uint8_t *dst,
-                                               const uint8_t *prefix, uint64_t plen, uint64_t *progress)
+__global__ __launch_bounds__(T) ZK_EXEC_WPE(T) void zk_k_exec(const uint8_t *__restrict__ comp, const uint64_t *__restrict__ d_off, uint32_t first,
+                                               const uint32_t *__restrict__ ids, const uint64_t *__restrict__ out_off,
+                                               const ZkBlock *__restrict__ blocks, const ZkFrameBase *__restrict__ bases,
+                                               ZkFrameInfo *__restrict__ infos, const ZkSeqP *__restrict__ seqs,
+                                               const uint8_t *__restrict__ lit_scratch, uint8_t *__restrict__ dst,
+                                               const uint8_t *__restrict__ prefix, uint64_t plen, uint64_t *__restrict__ progress)
 {
     // The staged sequences live in an LDS RING of CAP records, slot = block sequence index & (CAP - 1).  A tile retires the
     // jn sequences it has consumed and exactly as many new ones are fetched for the tiles to come -- requested right after
