@@ -91,9 +91,11 @@ enum {
     ZK_CHOICE_EXEC_LANES = 3,     /* zk_k_exec tile: 128 / 256 / 512 / 1024 lanes */
     ZK_CHOICE_EXEC_RING = 4,      /* 256-lane tiles: 1 = a ring of 2 T records, 2 = 4 T */
     ZK_CHOICE_XXH64 = 5,          /* 1 zk_k_xxh64 (a wave per frame), 2 zk_k_xxh64_wide (sixteen frames per wave), 3 zk_k_xxh64_lean (the same in 64
-                                   * registers) -- behind the executor; 4 zk_k_xxh64_follow: BESIDE the executor, behind its progress words, on
-                                   * the decode's second queue (zk_engine_checksums_followed says how many frames it verified; what it leaves
-                                   * is checked behind the executor as with 2).  By batch shape: 4 for a synchronous decode of >= 512 frames */
+                                   * registers), 5 zk_k_xxh64_fed<4> (four frames per workgroup: sixteen chains in one wave, their products
+                                   * brought by another; large batches take it by themselves) -- behind the executor;
+                                   * 4 zk_k_xxh64_follow: BESIDE the executor, behind its progress words, on the decode's second queue
+                                   * (zk_engine_checksums_followed says how many frames it verified; what it leaves is checked behind the
+                                   * executor as with 5).  By batch shape: 4 for a synchronous decode of >= 512 frames */
     ZK_CHOICE_SMALL_PATH = 6,     /* host-pointer decode of <= 64 frames: 1 = through the general pipeline, 2 = the small path with its
                                    * entropy roles as two kernels */
     ZK_CHOICE_PIPE_CONTEXTS = 7,  /* host pipeline: decode contexts it rotates through (1..6; 0 = 2) */

@@ -30,6 +30,8 @@ VARIANTS = {
     "exec1024_checksums_follow": dict(exec_lanes=1024, xxh64=4, small_path=1),
     # 512-lane tiles (what batches of dense sequence streams get: libzstd's level 3 and up)
     "exec512_wide_checksums": dict(exec_lanes=512, xxh64=2, small_path=1),
+    # (r6) the chains' wave fed by producer waves: four frames per workgroup (what large batches take)
+    "exec256_checksums_fed4": dict(exec_lanes=256, xxh64=5, small_path=1),
 }
 
 
@@ -43,7 +45,7 @@ def pinned(request, engine):
 
 def test_unknown_choices_are_refused(engine):
     import zeekstd_amd as zk
-    for key, value in [("exec_lanes", 64), ("fse_shared", 4), ("xxh64", 5), ("exec_ring", -1), ("pipe_contexts", 7), ("exec_resident", 3)]:
+    for key, value in [("exec_lanes", 64), ("fse_shared", 4), ("xxh64", 6), ("exec_ring", -1), ("pipe_contexts", 7), ("exec_resident", 3)]:
         with pytest.raises(zk.ZkError):
             engine.set_kernel_choice(**{key: value})
     assert zk.lib.zk_engine_set_kernel_choice(engine._h, 99, 0) != 0

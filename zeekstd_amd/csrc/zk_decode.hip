@@ -1731,7 +1731,13 @@ __global__ __launch_bounds__(L) void zk_k_exec_fill_lds(const uint64_t *d_off, u
 
 // ------------------------------------------------------------------------------------------------ XXH64
 // hashes != nullptr -> store the 64-bit hash; infos != nullptr -> verify Content_Checksum.
-__device__ __forceinline__ uint64_t zk_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+// rotl by 1 ... 31 as two v_alignbit_b32 (the compiler's form: a 64-bit shift, a 32-bit one and an or -- three instructions of a chain on
+// which every instruction is ~8 clocks of a lone wave, the 64-bit shift more)
+__device__ __forceinline__ uint64_t zk_rotl64(uint64_t x, int r)
+{
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    return ((uint64_t)__builtin_amdgcn_alignbit(hi, lo, 32u - (uint32_t)r) << 32) | __builtin_amdgcn_alignbit(lo, hi, 32u - (uint32_t)r);
+}
 constexpr uint64_t XP1 = 0x9E3779B185EBCA87ull, XP2 = 0xC2B2AE3D27D4EB4Full, XP3 = 0x165667B19E3779F9ull,
                    XP4 = 0x85EBCA77C2B2AE63ull, XP5 = 0x27D4EB2F165667C5ull;
 __device__ __forceinline__ uint64_t zk_xround(uint64_t acc, uint64_t x) { return zk_rotl64(acc + x * XP2, 31) * XP1; }
@@ -1835,6 +1841,123 @@ __global__ __launch_bounds__(64) void zk_k_xxh64_wide(const uint8_t *data, const
     }
     // what is left of the longer frames, stripe by stripe
     for (uint64_t i = common; i < nstripes; i++) acc = zk_xround(acc, zk_ld64(q + (i << 5)));
+    const uint32_t base = lane & ~3u;
+    const uint64_t v1 = __shfl(acc, base, 64), v2 = __shfl(acc, base + 1, 64), v3 = __shfl(acc, base + 2, 64), v4 = __shfl(acc, base + 3, 64);
+    if (kl != 0 || !live) return;
+    uint64_t h;
+    if (len >= 32) {
+        h = zk_rotl64(v1, 1) + zk_rotl64(v2, 7) + zk_rotl64(v3, 12) + zk_rotl64(v4, 18);
+        h = (h ^ zk_xround(0, v1)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v2)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v3)) * XP1 + XP4;
+        h = (h ^ zk_xround(0, v4)) * XP1 + XP4;
+    } else h = XP5;
+    h += len;
+    const uint8_t *t = p + (nstripes << 5), *end = p + len;
+    while (t + 8 <= end) { h ^= zk_xround(0, zk_ld64(t)); h = zk_rotl64(h, 27) * XP1 + XP4; t += 8; }
+    if (t + 4 <= end) { h ^= (uint64_t)zk_rd32(t) * XP1; h = zk_rotl64(h, 23) * XP2 + XP3; t += 4; }
+    while (t < end) { h ^= (uint64_t)(*t) * XP5; h = zk_rotl64(h, 11) * XP1; t++; }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    if (hashes) hashes[f] = h;
+    if (infos && (uint32_t)h != infos[f].checksum) infos[f].status = ZK_E_CHECKSUM_WRONG;
+}
+
+// A WAVE THAT ONLY RUNS THE CHAINS, FED BY ANOTHER (r6).  zk_k_xxh64_wide's wave does everything for its 64 chains: per round the load,
+// the product x * P2 (four instructions) and the chain's own six -- of one wave, all 64 lanes at work: an instruction is four passes of the
+// SIMD, a 32-bit multiply sixteen clocks: ~100 clocks per round, 2.7 ms per 2 MiB frame, during which the device is all but idle (128
+// waves) and the decode waits (the step's stages run one after the other).  Here wave 0 runs the chains and nothing else -- a product out
+// of LDS, mad + two mul_lo + add3, two alignbit -- in SIXTEEN lanes (NF = 4 frames per workgroup): one pass of the SIMD per instruction
+// instead of four.  Wave 1 brings the products a chunk of 32 stripes ahead: 16-byte loads (lane l: words 2l and 2l + 1 of the frame's
+// next KiB), D chunks of every frame under way, two products per lane, one 16-byte LDS write -- rows of NF x 32 bytes + 32 bytes of
+// padding, so that eight lanes' writes (four rows) fall into eight groups of banks.  One barrier per chunk: behind barrier k the chains
+// take buffer k & 1 while the producer fills the other one.
+//   Measured (2048 x 2 MiB, tools/gpu_calls/r6am.sh ... r6an.sh): wide 2.72 ms (2.52 with the rotations as two alignbit), 64 chains fed by
+// two waves 2.96 (the chains' instructions still take four passes), 16 chains fed by one wave with two chunks under way 2.36 (the chains
+// wait for memory at the barrier), with six: 1.65 ms.
+constexpr int ZK_XF_CHUNK = 32;
+template <int NF>                                            // frames per workgroup: 4 (16 chains: one of the SIMD's four passes per instruction)
+__global__ __launch_bounds__(64 * (1 + (NF >= 8 ? NF / 8 : 1))) void zk_k_xxh64_fed(const uint8_t *__restrict__ data, const uint64_t *__restrict__ d_off, uint32_t first, uint32_t count,
+                                                      ZkFrameInfo *infos, uint64_t *hashes, const uint64_t *skip)
+{
+    constexpr int PF = NF >= 8 ? 8 : NF;                     // frames per producer wave
+    constexpr int ZK_XF_ROW = NF * 32 + 32;
+    __shared__ __attribute__((aligned(16))) uint8_t ring[2][ZK_XF_CHUNK * ZK_XF_ROW];
+    const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t f = blockIdx.x * NF + (lane >> 2), kl = lane & 3;
+    bool live = lane < 4 * NF && f < count;
+    if (live && infos && !(infos[f].status == ZK_OK && infos[f].checksum_flag)) live = false;
+    if (live && skip && (skip[f] & ZK_PROG_VERIFIED)) live = false;       // zk_k_xxh64_follow has verified this frame
+    const uint32_t fa = live ? f : 0;                       // (a lane without a frame reads frame 0 and keeps nothing)
+    const uint8_t *p = data + (d_off[first + fa] - d_off[first]);
+    const uint64_t len = d_off[first + fa + 1] - d_off[first + fa];
+    const uint64_t nstripes = live ? len >> 5 : 0;
+    uint64_t least = live ? nstripes : ~0ull;
+    bool ragged = (((uintptr_t)p) & 15) != 0;
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) { const uint64_t o = __shfl_xor(least, m, 64); least = o < least ? o : least; }
+    if (least == ~0ull) return;                             // no frame to hash in this workgroup (every wave finds the same)
+    const bool any_ragged = __any(ragged);
+    const uint64_t nchunks = least / ZK_XF_CHUNK;            // the chunks every live frame of the group has
+    if (wave != 0) {
+        // producers: frames PF (wave - 1) ... of the group; the frame's pointer sits in lane 4 j of the consumer's layout
+        const uint32_t j0 = PF * (wave - 1);
+        const uint8_t *pj[PF];
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            const uint64_t a = (uint64_t)(uintptr_t)p;
+            pj[j] = (const uint8_t *)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(a >> 32), 4 * (int)(j0 + j)) << 32) |
+                                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, 4 * (int)(j0 + j)));
+        }
+        // D chunks of every frame under way (a chunk of the chains is ~0.8 us, a load from memory two or three times that; D = 2 left the
+        // chains waiting at the barrier: 2.36 ms per 2 MiB frame with four frames per workgroup)
+        constexpr int D = NF == 4 ? 6 : 2;
+        uint64_t wa[D][PF], wb[D][PF];
+        auto load = [&](uint64_t c, uint64_t *xa, uint64_t *xb) {
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                const uint8_t *q = pj[j] + (c << 10) + lane * 16;
+                if (!any_ragged) { const uint4 v = *reinterpret_cast<const uint4 *>(q); xa[j] = v.x | ((uint64_t)v.y << 32); xb[j] = v.z | ((uint64_t)v.w << 32); }
+                else { xa[j] = zk_ld64(q); xb[j] = zk_ld64(q + 8); }
+            }
+        };
+        auto fill = [&](uint32_t buf, const uint64_t *xa, const uint64_t *xb) {
+            uint8_t *row = ring[buf] + (lane >> 1) * ZK_XF_ROW + j0 * 32 + (lane & 1) * 16;
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                const uint64_t pa = xa[j] * XP2, pb = xb[j] * XP2;
+                *reinterpret_cast<uint4 *>(row + j * 32) = make_uint4((uint32_t)pa, (uint32_t)(pa >> 32), (uint32_t)pb, (uint32_t)(pb >> 32));
+            }
+        };
+        // chunk c lives in registers [c % D]; before barrier k the buffer k & 1 holds chunk k, behind it chunk k + 1 is written
+#pragma unroll
+        for (int d = 0; d < D; d++) if ((uint64_t)d < nchunks) load(d, wa[d], wb[d]);
+        if (nchunks) fill(0, wa[0], wb[0]);
+        for (uint64_t k0 = 0; k0 < nchunks; k0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const uint64_t k = k0 + d;
+                if (k < nchunks) {
+                    __syncthreads();
+                    if (k + D < nchunks) load(k + D, wa[d], wb[d]);              // (chunk k's registers are free: it went into the ring before this barrier)
+                    if (k + 1 < nchunks) fill((uint32_t)(k + 1) & 1u, wa[(d + 1) % D], wb[(d + 1) % D]);
+                }
+            }
+        }
+        return;
+    }
+    // the chains
+    uint64_t acc = kl == 0 ? XP1 + XP2 : kl == 1 ? XP2 : kl == 2 ? 0 : 0 - XP1;
+    for (uint64_t k = 0; k < nchunks; k++) {
+        __syncthreads();
+        if (lane < 4 * NF) {                                 // (NF = 4: sixteen lanes at work -- an instruction of the chain takes one pass of the SIMD, not four)
+            const uint8_t *row = ring[k & 1] + lane * 8;
+#pragma unroll 8
+            for (int r = 0; r < ZK_XF_CHUNK; r++) acc = zk_rotl64(acc + *reinterpret_cast<const uint64_t *>(row + r * ZK_XF_ROW), 31) * XP1;
+        }
+    }
+    // what is left of the longer frames, stripe by stripe
+    const uint8_t *q = p + 8 * kl;
+    for (uint64_t i = nchunks * ZK_XF_CHUNK; i < nstripes; i++) acc = zk_xround(acc, zk_ld64(q + (i << 5)));
     const uint32_t base = lane & ~3u;
     const uint64_t v1 = __shfl(acc, base, 64), v2 = __shfl(acc, base + 1, 64), v3 = __shfl(acc, base + 2, 64), v4 = __shfl(acc, base + 3, 64);
     if (kl != 0 || !live) return;
@@ -2463,15 +2586,18 @@ void zk_launch_exec_seg(hipStream_t st, const uint8_t *comp, const uint64_t *d_o
                        (const uint8_t *)nullptr, (uint64_t)0, (uint64_t *)nullptr);
 }
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
-                     ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k, const uint64_t *skip, uint32_t wide_from)
+                     ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k, const uint64_t *skip, uint32_t wide_from, bool beside)
 {
     // a large batch: sixteen frames per wave (the chains' latency is the same, the instruction slots a sixteenth).  From how many frames:
     // the decoder's pass runs alone on the device or beside a neighbour's entropy stage -- 512 frames of 2 MiB: a wave per frame 5.3 / 6.5 ms
     // per step against 5.9 / 7.6 (two batches in flight / one at a time), hence 1024; the encoder's runs beside its matcher, which pays for
     // every instruction slot the checksums take -- measured from 512 frames in round 3, and left there
-    if (skip) { hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes, skip); return; }
-    if (k.xxh == 3) hipLaunchKernelGGL(zk_k_xxh64_lean, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
-    else if (k.xxh ? k.xxh == 2 || k.xxh >= 4 : count >= wide_from) hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes, (const uint64_t *)nullptr);
+    // (r6) the decoder's large batches: FOUR frames per workgroup, sixteen chains in one wave fed by another (zk_k_xxh64_fed<4>: 1.65 instead
+    // of 2.7 ms per 2 MiB frame, three times the instructions); the encoder's pass, beside its entropy stage and shorter than it either way,
+    // keeps sixteen frames per wave; 2 / 3 pin the earlier forms for the tests and the probes
+    if (!skip && k.xxh == 3) hipLaunchKernelGGL(zk_k_xxh64_lean, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
+    else if (k.xxh == 2 || (beside && k.xxh == 0 && count >= wide_from)) hipLaunchKernelGGL(zk_k_xxh64_wide, dim3((count + 15) / 16), dim3(64), 0, st, data, d_off, first, count, infos, hashes, skip);
+    else if (skip || k.xxh >= 4 || (k.xxh == 0 && count >= wide_from)) hipLaunchKernelGGL(zk_k_xxh64_fed<4>, dim3((count + 3) / 4), dim3(128), 0, st, data, d_off, first, count, infos, hashes, skip);
     else hipLaunchKernelGGL(zk_k_xxh64, dim3(count), dim3(64), 0, st, data, d_off, first, count, infos, hashes);
 }
 void zk_launch_xxh64_follow(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count, const ZkFrameInfo *infos, uint64_t *progress)

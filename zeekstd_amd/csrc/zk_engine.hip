@@ -63,7 +63,7 @@ extern "C" int zk_engine_set_kernel_choice(zk_engine *e, int what, int value)
     case ZK_CHOICE_FSE_SHARED: if (value < 0 || value > 3) return ZK_ERR_ARGUMENT; k.fse_shared = value; return 0;
     case ZK_CHOICE_EXEC_LANES: if (value != 0 && value != 128 && value != 256 && value != 512 && value != 1024) return ZK_ERR_ARGUMENT; k.exec_lanes = value; return 0;
     case ZK_CHOICE_EXEC_RING: if (value < 0 || value > 2) return ZK_ERR_ARGUMENT; k.exec_ring = value; return 0;
-    case ZK_CHOICE_XXH64: if (value < 0 || value > 4) return ZK_ERR_ARGUMENT; k.xxh = value; return 0;
+    case ZK_CHOICE_XXH64: if (value < 0 || value > 5) return ZK_ERR_ARGUMENT; k.xxh = value; return 0;
     case ZK_CHOICE_EXEC_RESIDENT: if (value != 0 && value != 4 && value != 5) return ZK_ERR_ARGUMENT; k.exec_resident = value; return 0;
     case ZK_CHOICE_SMALL_PATH: if (value < 0 || value > 2) return ZK_ERR_ARGUMENT; k.small_path = value; return 0;
     case ZK_CHOICE_EXEC_SEG: if (value < 0 || value > 2) return ZK_ERR_ARGUMENT; k.exec_seg = value; return 0;

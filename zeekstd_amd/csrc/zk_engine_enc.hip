@@ -145,10 +145,10 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         if (!e->profiling && e->enc_aux) {
             ZK_HIP(hipEventRecord(e->enc_ev_fork, st));
             ZK_HIP(hipStreamWaitEvent(e->enc_aux, e->enc_ev_fork, 0));
-            zk_launch_xxh64(e->enc_aux, src, d_doff, 0, nf, nullptr, hashes, e->choice, nullptr, 512);
+            zk_launch_xxh64(e->enc_aux, src, d_doff, 0, nf, nullptr, hashes, e->choice, nullptr, 512, true);
             ZK_HIP(hipEventRecord(e->enc_ev_join, e->enc_aux));
             cks_beside = true;
-        } else { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, d_doff, 0, nf, nullptr, hashes, e->choice, nullptr, 512); }
+        } else { zk_kernel_timer t(e, ZK_K_ENC_XXH64, st); zk_launch_xxh64(st, src, d_doff, 0, nf, nullptr, hashes, e->choice, nullptr, 512, true); }
     }
     { zk_kernel_timer t(e, ZK_K_ENC_ENTROPY, st); zk_launch_enc_entropy(st, src, dfr, dbl, nb, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), (const uint8_t *)e->enc_c.p, (uint8_t *)e->enc_d.p, ftab); }
     zk_launch_enc_sizes(st, dfr, nf, dbl, ftab, a.checksum, c64, (uint32_t *)a.d_c_sizes, (uint32_t *)a.d_d_sizes);

@@ -37,7 +37,8 @@ void zk_launch_exec_seg(hipStream_t st, const uint8_t *comp, const uint64_t *d_o
                         const uint8_t *lit, uint8_t *dst, const ZkSegScratch &sg, const ZkKernelChoice &k, bool dense, uint64_t *progress = nullptr);
 void zk_launch_xxh64(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count,
                      ZkFrameInfo *infos, uint64_t *hashes, const ZkKernelChoice &k, const uint64_t *skip = nullptr,
-                     uint32_t wide_from = 1024);         // frames from which sixteen share a wave (the encoder passes 512: zk_decode.hip)
+                     uint32_t wide_from = 1024,          // frames from which several share a workgroup (the encoder passes 512: zk_decode.hip)
+                     bool beside = false);               // the pass runs beside a kernel that pays for its instruction slots (the encoder's): sixteen frames per wave
 // the checksums beside the executor that publishes `progress` (launched on another queue); frames it verifies are marked in `progress`,
 // zk_launch_xxh64(..., skip = progress) behind the executor takes the rest
 void zk_launch_xxh64_follow(hipStream_t st, const uint8_t *data, const uint64_t *d_off, uint32_t first, uint32_t count, const ZkFrameInfo *infos, uint64_t *progress);
