@@ -6,4 +6,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_SALU
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $set --kernel-trace -d gpurun_out/pmcx/$tag -o p --output-format csv -- python tools/exec_probe.py $N > gpurun_out/pmcx_$tag.log 2>&1 || echo "pass failed: $set"
 done
-KERNELS=exec python tools/pmc_table.py gpurun_out/pmcx/*
+KERNELS=${KERNELS:-exec} python tools/pmc_table.py gpurun_out/pmcx/*

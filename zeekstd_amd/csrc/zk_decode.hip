@@ -873,6 +873,9 @@ __device__ __forceinline__ void zk_publish(uint64_t *word, uint32_t bytes, uint6
 #ifndef ZK_EXEC_WIDE
 #define ZK_EXEC_WIDE 1
 #endif
+#ifndef ZK_EXEC_TOUCH
+#define ZK_EXEC_TOUCH 1
+#endif
 #ifdef ZK_EXEC_NO_WPE
 #define ZK_EXEC_WPE(T)
 #else
@@ -955,6 +958,10 @@ __global__ __launch_bounds__(T) ZK_EXEC_WPE(T) void zk_k_exec(const uint8_t *__r
             const uint32_t b_lit_type = zk_uni((uint32_t)b.lit_type);
             const uint8_t *lit = b_lit_type >= 2 ? lit_scratch + zk_uni(b.lit_base) : comp + zk_uni(b.src) + zk_uni(b.lit_off);
             const uint32_t lit_mask = b_lit_type == 1 ? 0u : 0x7fffffffu;       // RLE literals: every index reads byte 0
+            // the records the NEXT block starts with, touched during this block's last tile (ZK_EXEC_TOUCH_NEXT below)
+            const bool nx_any = ZK_EXEC_TOUCH && bk + 1 < fi.n_blocks && zk_uni((uint32_t)fb[bk + 1].type) == 2u;
+            const ZkSeqP *nx_sq = seqs + (nx_any ? zk_uni(fb[bk + 1].seq_base) : 0);
+            const uint32_t nx_lines = nx_any ? (zk_uni(fb[bk + 1].nseq) + 7u) / 8u : 0u;     // 64-byte lines of its records
             const uint64_t lit_w = (uint64_t)(uintptr_t)lit - ZK_SRC_LIT, his_w = (uint64_t)(uintptr_t)bout - ZK_SRC_BIAS;    // + a source word = the byte's address
             const uint32_t nseq = zk_uni(b.nseq), out_size = b_out_size, lit_regen = zk_uni(b.lit_regen);
             // record idx of the block (idx == nseq: the trailing-literals pseudo sequence) -> staged form, offsets resolved
@@ -1030,7 +1037,15 @@ __global__ __launch_bounds__(T) ZK_EXEC_WPE(T) void zk_k_exec(const uint8_t *__r
                     pf0[u] = 0; pf1[u] = 0;
                     if (idx < fetch_end) fetch(idx, pf0[u], pf1[u]);
                 }
+                // A block opens with two round trips to memory in a row -- its descriptor, then the first CAP records -- before its first
+                // tile can be marked (phase clocks: 15 % of a wave's time).  In the block's LAST tile the lines of the next block's first
+                // records are asked for (one 4-byte load per line, nobody needs the value: the tile's full barrier waits for it with
+                // everything else), so that the staging finds them in the L2.
+                uint32_t touched = 0;
+                if (ZK_EXEC_TOUCH && te >= out_size && tid < nx_lines && tid < (uint32_t)(CAP / 8)) touched = *reinterpret_cast<const uint32_t *>(nx_sq + 8u * tid);
                 const uint32_t next_prev_end = jn ? zk_uni(S[(ja + jn - 1) & M].out_end) : prev_end;
+                // (the same for the LITERALS of the next tile -- a byte per 64-byte line, 2 KiB from where this tile's sequences end -- measured:
+                //  6.72 -> 6.91 ms; their lines are not what the gathers wait for, and the touch is one more load per tile.  r6at.sh)
                 for (uint32_t k = 0; k < nlong; k++) {       // sequences spanning many slots: all lanes
                     const uint32_t idx = longlist[k];
                     const uint32_t end = S[idx & M].out_end;
@@ -1065,6 +1080,7 @@ __global__ __launch_bounds__(T) ZK_EXEC_WPE(T) void zk_k_exec(const uint8_t *__r
                 }
                 ZK_CLK(3);
                 __syncthreads();                                                 // the full one: every wave's stores of the tile before are in memory
+                if (ZK_EXEC_TOUCH) asm volatile("" :: "v"(touched));             // (the touch is complete here; its value goes nowhere)
                 ZK_CLK(2);
                 if (tid == 0) { s_jn = fetch_end - (ja + jn); s_nlong = 0; }      // the next tile's marking pass starts from these (every lane has read this tile's)
                 // the slot pass is done with the retired records: the fetched ones move in

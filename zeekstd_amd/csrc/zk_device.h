@@ -1032,6 +1032,10 @@ ZK_HD ZkRevLShared *zk_rd_shared_type(const ZkRevL &) { return nullptr; }
 // 16-B records are one 64-B line of its block's record array, so instead of every lane storing its own ring
 // (4 instructions x 64 separate L2 write requests) four neighbouring lanes store one ring per instruction
 // (4 x 16 requests of 64 B).  All 64 lanes must run the walk in lock step (nloop = the wave's longest block).
+// WHERE record i of a lane's ring lies: every lane of the wave parks record i in the same step, the rings are RING x 8 bytes apart (64 bytes:
+// sixteen lanes -- one pass of the LDS -- on two pairs of banks, the write ran eight times: 21 % of zk_k_fse_predef_fed's clocks were LDS bank
+// conflicts, profiles/r06_pmc_entropy.txt), so lane l keeps record i in slot i ^ ((l >> 1) & 7): sixteen lanes, sixteen pairs of banks.
+template <int RING> ZK_HD uint32_t zk_coop_ring_swz(uint32_t lane) { return RING == 8 ? (lane >> 1) & 7u : 0u; }
 struct ZkCoopFlush {
     ZkSeqP *ring;                    // [64][RING]
     ZkSeqP *seqs;                    // the record array of the whole batch
@@ -1067,6 +1071,7 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const t
     // window guarantees leaves the block for a field-by-field slow step.
     typename CP::cell_t cl = LL[sl], co = OF[so], cm = ML[sm];
     const uint32_t nloop = coop ? coop->nloop : nseq;
+    const uint32_t swz = coop ? zk_coop_ring_swz<RING>(lane) : 0u;
     for (uint32_t g0 = 0; g0 < nloop; g0 += RING) {
         for (uint32_t i = g0; i < g0 + RING; i++) {
             if (i >= nseq) break;
@@ -1120,7 +1125,7 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const t
             rep0 = off;
             lit += ll; out += ll + ml;
             bad |= (lit > b.lit_regen) | (out > ZK_BLOCK_MAX) | (!zk_rep_is_sym(off) & (off > ZK_OFF_MAX));
-            ring[i & (RING - 1)] = zk_seq_pack(out, lit, off);
+            ring[(i & (RING - 1)) ^ swz] = zk_seq_pack(out, lit, off);
         }
         // records are parked in LDS and written out a group at a time (few, wide store bursts)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1129,7 +1134,7 @@ ZK_HD void zk_seq_walk(const uint8_t *comp, ZkBlock &b, uint32_t bs_off, const t
             static_assert(RING == 4 || RING == 8 || RING == 16, "ring");
             for (uint32_t j = 0; j < (uint32_t)RING; j++) {
                 const uint32_t m = (64 / RING) * j + lane / RING, piece = lane % RING, k = g0 + piece;
-                if (k < coop->nseq[m]) zk_glb_st<ZkSeqP>(&coop->seqs[coop->base[m] + k], zk_lds_ld<ZkSeqP>(&coop->ring[m * RING + piece]));
+                if (k < coop->nseq[m]) zk_glb_st<ZkSeqP>(&coop->seqs[coop->base[m] + k], zk_lds_ld<ZkSeqP>(&coop->ring[m * RING + (piece ^ zk_coop_ring_swz<RING>(m))]));
             }
             continue;
         }
