@@ -22,7 +22,8 @@ c = np.zeros(nf + 1, np.uint64); d = np.zeros(nf + 1, np.uint64); c[1:] = np.cum
 d_c = torch.from_numpy(c.view(np.int64)).to(dev); d_d = torch.from_numpy(d.view(np.int64)).to(dev)
 d_out = torch.empty(n + 64, dtype=torch.uint8, device=dev); d_st = torch.zeros(nf, dtype=torch.int32, device=dev)
 eng.set_profiling(True)
+if os.environ.get("ZK_LANES"): eng.set_kernel_choice(exec_lanes=int(os.environ["ZK_LANES"]))
 if os.environ.get("ZK_XXH"): eng.set_kernel_choice(xxh64=int(os.environ["ZK_XXH"]))
 for r in range(3):
     rc = eng.decode_frames_dev(d_comp, csize, d_c, d_d, 0, nf, d_out, n, verify, d_st)
-print("EXECVAR", "xxh=" + os.environ.get("ZK_XXH", "auto"), "rc", rc, "ok", bool(torch.equal(d_out[:n], d_src)) and int(d_st.abs().sum()) == 0, {k: round(v, 3) for k, v in eng.kernel_times().items()}, flush=True)
+print("EXECVAR", "lanes=" + os.environ.get("ZK_LANES", "auto"), "xxh=" + os.environ.get("ZK_XXH", "auto"), "rc", rc, "ok", bool(torch.equal(d_out[:n], d_src)) and int(d_st.abs().sum()) == 0, {k: round(v, 3) for k, v in eng.kernel_times().items()}, flush=True)

@@ -850,13 +850,27 @@ __device__ __forceinline__ void zk_publish(uint64_t *word, uint32_t bytes, uint6
 // average.  So the pass that finds nothing is not a pass: the least of the lane's sixteen (word - first in-tile word) says whether
 // any word still points into the tile (a subtraction and a third of a min3 per word, one vote per wave), and the passes themselves keep no
 // "again".  The first in-tile word in ONE scalar register (through zk_uni: the compiler otherwise subtracts ts and the bias separately).
+// Passes after the first take the lane's words in four groups of four: a group in which no lane of the wave has anything left (the rule:
+// 0.3 % of the bytes need a second step) is skipped by a scalar branch -- the least distance of each group is what the test computed anyway.
+#ifndef ZK_EXEC_CHASE_GROUPS
+#define ZK_EXEC_CHASE_GROUPS 1
+#endif
 #define ZK_EXEC_CHASE(sw, srcmap, ts, te) do {                                                                         \
         const uint32_t mbase_ = zk_uni(ZK_SRC_BIAS + (ts)), span_ = (te) - (ts);                                        \
+        _Pragma("unroll") for (int k = 0; k < ZK_EXEC_B; k++) { const uint32_t d_ = sw[k] - mbase_; if (d_ < span_) sw[k] = srcmap[zk_exec_map_index(d_)]; }  \
         for (;;) {                                                                                                      \
-            _Pragma("unroll") for (int k = 0; k < ZK_EXEC_B; k++) { const uint32_t d_ = sw[k] - mbase_; if (d_ < span_) sw[k] = srcmap[zk_exec_map_index(d_)]; }  \
-            uint32_t least_ = sw[0] - mbase_;                                                                           \
-            _Pragma("unroll") for (int k = 1; k < ZK_EXEC_B; k++) { const uint32_t d_ = sw[k] - mbase_; least_ = d_ < least_ ? d_ : least_; } \
+            uint32_t lg_[ZK_EXEC_B / 4];                                                                                \
+            _Pragma("unroll") for (int g = 0; g < ZK_EXEC_B / 4; g++) {                                                 \
+                const uint32_t d0_ = sw[4 * g] - mbase_, d1_ = sw[4 * g + 1] - mbase_, d2_ = sw[4 * g + 2] - mbase_, d3_ = sw[4 * g + 3] - mbase_;      \
+                const uint32_t m_ = d0_ < d1_ ? d0_ : d1_, n_ = d2_ < d3_ ? d2_ : d3_; lg_[g] = m_ < n_ ? m_ : n_;      \
+            }                                                                                                           \
+            uint32_t least_ = lg_[0];                                                                                   \
+            _Pragma("unroll") for (int g = 1; g < ZK_EXEC_B / 4; g++) least_ = lg_[g] < least_ ? lg_[g] : least_;      \
             if (!__any(least_ < span_)) break;                                                                          \
+            _Pragma("unroll") for (int g = 0; g < ZK_EXEC_B / 4; g++) {                                                 \
+                if (ZK_EXEC_CHASE_GROUPS && !__any(lg_[g] < span_)) continue;                                           \
+                _Pragma("unroll") for (int k = 4 * g; k < 4 * g + 4; k++) { const uint32_t d_ = sw[k] - mbase_; if (d_ < span_) sw[k] = srcmap[zk_exec_map_index(d_)]; } \
+            }                                                                                                           \
         }                                                                                                               \
     } while (0)
 // REDO: only the frames zk_k_exec_seg gave up on (ZK_E_SEG_OVERFLOW: more hole records than their region holds) are executed, from scratch
@@ -1019,7 +1033,10 @@ __global__ __launch_bounds__(T) ZK_EXEC_WPE(T) void zk_k_exec(const uint8_t *__r
                         uint32_t s0, n;
                         zk_exec_slot_span(ts, lo, hi, s0, n);
                         if (n > ZK_EXEC_LONG) longlist[atomicAdd(&s_nlong, 1u)] = idx;
-                        else for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = idx;
+                        else {                                   // (written out: as a loop it was two loops, pairs and a remainder, with the mask juggling of both)
+#pragma unroll
+                            for (uint32_t k = 0; k < ZK_EXEC_LONG; k++) if (k < n) slot_seq[s0 + k] = idx;
+                        }
                         zk_exec_mark_runs(me, prev_off, start, ts, te, srcmap, [&](uint32_t w, uint32_t bits) { atomicOr(&s_slow[w], bits); });
                     }
                     if (end > te && start <= te) s_jn = i;
@@ -1362,7 +1379,10 @@ __global__ __launch_bounds__(T) void zk_k_exec_seg(const uint8_t *comp, const ui
                         uint32_t s0, n;
                         zk_exec_slot_span(ts, lo, hi, s0, n);
                         if (n > ZK_EXEC_LONG) longlist[atomicAdd(&s_nlong, 1u)] = idx;
-                        else for (uint32_t k = 0; k < n; k++) slot_seq[s0 + k] = idx;
+                        else {                                   // (written out: as a loop it was two loops, pairs and a remainder, with the mask juggling of both)
+#pragma unroll
+                            for (uint32_t k = 0; k < ZK_EXEC_LONG; k++) if (k < n) slot_seq[s0 + k] = idx;
+                        }
                         zk_exec_mark_runs(me, prev_off, start, ts, te, srcmap, [&](uint32_t w, uint32_t bits) { atomicOr(&s_slow[w], bits); });
                     }
                     if (end > te && start <= te) s_jn = i;
