@@ -1022,12 +1022,23 @@ __global__ __launch_bounds__(T) ZK_EXEC_WPE(T) void zk_k_exec(const uint8_t *__r
                 ZK_LDS_BARRIER();
                 if (tid == 0) s_bad[tpar ^ 1] = 0;                               // the flag of the tile before: every wave has read it (in front of this barrier); the next tile sets it
                 // 2. lane per sequence: mark the slots it starts; the first sequence that outlives the tile sets jn
-                for (uint32_t i = tid; i < nl; i += T) {
+                // (nl <= CAP = NPF x T: the loop written out, every turn's LDS reads in front -- as a loop each turn waited for its own)
+                ZkSeq mes[NPF]; uint32_t starts_[NPF], poffs_[NPF];
+#pragma unroll
+                for (int u = 0; u < NPF; u++) {
+                    const uint32_t i = tid + (uint32_t)u * T, idx = ja + i;
+                    mes[u] = S[idx & M];
+                    const ZkSeq &pv = S[(idx - 1) & M];
+                    starts_[u] = i ? pv.out_end : prev_end; poffs_[u] = pv.off;   // (the offset of a sequence that has left the ring is never needed: zk_exec_mark_runs)
+                }
+#pragma unroll
+                for (int u = 0; u < NPF; u++) {
+                    const uint32_t i = tid + (uint32_t)u * T;
+                    if (i >= nl) break;
                     const uint32_t idx = ja + i;
-                    const ZkSeq me = S[idx & M];
+                    const ZkSeq me = mes[u];
                     const uint32_t end = me.out_end;
-                    uint32_t start = prev_end, prev_off = 1;                      // (the offset of a sequence that has left the ring is never needed: zk_exec_mark_runs)
-                    if (i) { const ZkSeq &pv = S[(idx - 1) & M]; start = pv.out_end; prev_off = pv.off; }
+                    const uint32_t start = starts_[u], prev_off = poffs_[u];
                     const uint32_t lo = start > ts ? start : ts, hi = end < te ? end : te;
                     if (lo < hi) {
                         uint32_t s0, n;
