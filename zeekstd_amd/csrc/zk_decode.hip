@@ -631,6 +631,10 @@ __global__ __launch_bounds__(ZK_FSEP_LANES) void zk_k_fse_predef(const uint8_t *
 
 // The same with a feeder wave: wave 0 walks (reader ZkRevL: stream words out of an LDS ring, no global load in the
 // walking wave), wave 1 feeds the ring lane for lane.  Used when the device is full of walkers (zk_launch_fse).
+// (Measured and dropped, round 6: TWO walker waves of 32 lanes each -- blocks 0..31 and 32..63 of the workgroup -- instead of one of 64, so
+//  that four half-busy walker waves interleave on a SIMD where two full ones leave its vector unit 46 % busy (profiles/r06_pmc_entropy.txt);
+//  a wave with 32 lanes at work takes two passes of the SIMD per instruction.  Six waves per SIMD need 80 registers (85 without the
+//  limit; with it 36 bytes of scratch outside the walk): bit-exact, 3.13 -> 4.8 ms.  profiles/r06_fse_half_waves_probe.txt)
 __global__ __launch_bounds__(2 * ZK_FSEP_LANES) void zk_k_fse_predef_fed(const uint8_t *comp, ZkBlock *blocks, uint32_t nblocks, ZkSeqP *seqs)
 {
     __shared__ ZkSeqTablesT<ZkCells64> T;                  // 64-bit cells: the value baseline rides along (shared tables, LDS is free)
