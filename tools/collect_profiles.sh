@@ -5,9 +5,9 @@ tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 one() {   # $1 = suffix, rest = extra bench flags
   sfx=$1; shift
-  # --sync --choice xxh64=2: one batch at a time with the checksums BEHIND the executor, so that every kernel runs alone and its average
+  # --sync --choice xxh64=5: one batch at a time with the checksums BEHIND the executor, so that every kernel runs alone and its average
   # duration in the trace is the one bench.py's HIP events measure (a lone batch would otherwise get zk_k_xxh64_follow beside the executor)
-  common="--no-cpu-baseline --no-seek --no-ref-archive --no-e2e --no-c1 --sync --choice xxh64=2 --no-fork --cache /tmp/zkcache $*"
+  common="--no-cpu-baseline --no-seek --no-ref-archive --no-e2e --no-c1 --sync --choice xxh64=5 --no-fork --cache /tmp/zkcache $*"
   rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag$sfx -- python bench.py --steps 3 --warmup 1 $common > gpurun_out/prof_$tag$sfx.json 2> gpurun_out/prof_$tag$sfx.err
   python tools/prof_summary.py gpurun_out/prof_$tag$sfx 20 > gpurun_out/${tag}${sfx}_bench_c3_kernel_trace_stats.txt
   for c in FETCH_SIZE WRITE_SIZE; do

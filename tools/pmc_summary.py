@@ -15,7 +15,7 @@ import json
 import os
 import sys
 
-WIDE = {"zk_k_xxh64": 2.0, "zk_k_xxh64_wide": 2.0}     # both read exactly the decompressed bytes, 8 / 16 bytes per lane and load
+WIDE = {"zk_k_xxh64": 2.0, "zk_k_xxh64_wide": 2.0, "zk_k_xxh64_fed": 2.0}     # all read exactly the decompressed bytes, 8 / 16 bytes per lane and load
 
 
 def short(name):
