@@ -583,6 +583,9 @@ ZK_HD bool zk_huf_decode_stream(const uint16_t *table, uint32_t maxbits, const u
         }
     }
     const uint32_t i0 = i;                               // the mailbox counts packs from here
+    // (Measured and dropped, round 6: the four symbols of a window as two PAIRS out of its upper 32 bits -- the second symbol of a pair is
+    //  (w << n) >> (32 - maxbits), one 64-bit shift per window instead of eight: bit-exact, zk_k_huf 2.80 -> 3.09 ms.  The 64-bit shifts are
+    //  not what the chain shift -> cell -> shift waits for; the pair form has more instructions on it.  tools/gpu_calls/r6bc.sh)
     while (i + 8 <= n) {
         uint64_t pack = 0;
         uint64_t cur = zk_hufrd_refill(r);
