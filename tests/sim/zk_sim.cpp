@@ -39,6 +39,8 @@ static uint64_t g_seg_stats[4];                 // holes records, hole bytes, fi
 extern "C" void zk_sim_set_exec_seg(uint32_t seg_bytes, uint32_t fill_lanes, uint32_t cap_shift) { g_seg_bytes = seg_bytes; g_fill_lanes = fill_lanes ? fill_lanes : 64; g_seg_cap_shift = cap_shift; }
 static int g_chase_stats_on = 0;
 static uint64_t g_slot_stats[2];
+static uint64_t g_huf_depth[16];
+extern "C" void zk_sim_huf_depth(uint64_t *out) { for (int i = 0; i < 16; i++) { out[i] = g_huf_depth[i]; g_huf_depth[i] = 0; } }
 extern "C" void zk_sim_slot_stats(uint64_t *out) { out[0] = g_slot_stats[0]; out[1] = g_slot_stats[1]; g_slot_stats[0] = g_slot_stats[1] = 0; }
 static uint64_t g_chase_stats[32];       // [0..15]: waves by their deepest chain, [16..31]: bytes by the depth of their chain
 extern "C" void zk_sim_chase_stats(uint64_t *out, int on) { for (int i = 0; i < 32; i++) { out[i] = g_chase_stats[i]; g_chase_stats[i] = 0; } g_chase_stats_on = on; }
@@ -194,6 +196,7 @@ extern "C" int zk_sim_decode_prefix(const uint8_t *comp, const uint64_t *c_off, 
         uint32_t mb = 0, nsym = 0;
         zk_sim_poison(tab.data(), tab.size() * 2); zk_sim_poison(&hd, sizeof hd); zk_sim_poison(&tmp, sizeof tmp);
         uint32_t r = zk_huf_read_weights(comp + def.src + def.lit_off, def.lit_comp, &hd, &tmp, &nsym, &mb);
+        if (g_chase_stats_on && r) g_huf_depth[mb < 16 ? mb : 15]++;
         bool ok = r != 0;
         if (ok) {
             zk_huf_fill_table(tab.data(), &hd, nsym, mb);

@@ -17,6 +17,8 @@ def stats(comp, frames, lanes):
     rc, out, st = sim_decode(comp, frames, CH=2 * lanes)
     assert rc == 0 and out == data
     sim_lib().zk_sim_chase_stats(buf, 0)
+    hd = (C.c_uint64 * 16)(); sim_lib().zk_sim_huf_depth(hd)
+    print("  Huffman trees by depth (a table of 2^depth cells; zk_k_huf's pool holds 8192 cells for 16 blocks): " + " ".join("%d:%d" % (i, hd[i]) for i in range(16) if hd[i]))
     sl = (C.c_uint64 * 2)(); sim_lib().zk_sim_slot_stats(sl)
     print("  slots that take the general walk (a match overlapping its own output): %d of %d = %.2f%%" % (sl[1], sl[0], 100.0 * sl[1] / max(1, sl[0])))
     v = np.array(buf[:], np.float64)
