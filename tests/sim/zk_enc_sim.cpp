@@ -37,7 +37,7 @@ extern "C" int zk_enc_sim_match(const uint8_t *src, uint64_t n, uint32_t frame_s
     }
     // long-distance table over the prefix (the engine builds it with zk_k_enc_ldm_build; here sequentially, same rule)
     ZkEncLdm ldm = {nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
-    std::vector<uint32_t> table;
+    std::vector<uint32_t> table, dense;
     std::vector<uint8_t> pcopy;
     if (!prefix && zke_ldm_in_frame(level, 0, frame_size < n ? frame_size : n)) {
         // in-frame far history: one table per frame over its own bytes (the engine: zk_k_enc_ldm_build_frames; here sequentially, same rule)
@@ -55,6 +55,42 @@ extern "C" int zk_enc_sim_match(const uint8_t *src, uint64_t n, uint32_t frame_s
             }
         }
         ldm.table = table.data();
+        if (zke_dense_in_frame(level, 0, frame_size < n ? frame_size : n)) {
+            // dense far history: every position's far candidate out of the first / last occurrence per slot and segment (the engine:
+            // zk_k_enc_dense_cand; here sequentially, same rule)
+            ldm.dlog = zke_dense_log(level);
+            dense.assign((size_t)n + ZKE_DENSE_SLACK, 0);
+            const size_t slots = (size_t)1 << ldm.dlog;
+            std::vector<uint32_t> first(slots), last(slots), prev(slots);
+            auto h5 = [&](const uint8_t *p) { uint32_t lo; memcpy(&lo, p, 4); return zke_hash(lo, p[4], ldm.dlog); };
+            for (uint32_t g = 0; g < pl.nseg; g++) {
+                const ZkEncFrame &sg = segs[g];
+                const uint8_t *frame = src + sg.src_off;
+                const uint64_t fsz = n - sg.src_off < frame_size ? n - sg.src_off : frame_size;
+                prev = last;                                                   // (a segment behind a frame's first follows it in the list)
+                std::fill(first.begin(), first.end(), ZKE_DENSE_NONE); std::fill(last.begin(), last.end(), 0u);
+                const uint64_t e1 = (uint64_t)sg.seg_at + sg.d_size;
+                for (uint64_t q = sg.seg_at; q < e1 && q + 8 <= fsz; q++) {
+                    const uint32_t h = h5(frame + q), r = (uint32_t)(q - sg.seg_at);
+                    if (r < first[h]) first[h] = r;
+                    if (r + 1 > last[h]) last[h] = r + 1;
+                }
+                for (uint64_t q = sg.seg_at; q < e1 && q + 8 <= fsz; q++) {
+                    const uint32_t h = h5(frame + q), r = (uint32_t)(q - sg.seg_at), m1 = first[h], m2 = sg.seg_at ? prev[h] : 0u;
+                    uint32_t d = 0;
+                    const uint8_t *b = frame + q;
+                    if (b[1] == b[0] && b[2] == b[0] && b[3] == b[0]) d = 0;      // a byte run
+                    else if (m1 != ZKE_DENSE_NONE && m1 < r && r - m1 > ZKE_WINDOW) d = r - m1;
+                    else if (m2 && r + ZKE_SEGMENT - (m2 - 1) > ZKE_WINDOW) d = r + ZKE_SEGMENT - (m2 - 1);
+                    if (!d) continue;
+                    uint32_t l = 0;
+                    while (l < 16 && q + l < fsz && frame[q + l] == frame[q + l - d]) l++;
+                    while (l < 16 && q + l >= fsz && frame[q + l - d] == 0) l++;     // the kernel reads zeros behind the frame's last byte (the match kernel caps the length at its tile's end)
+                    if (l >= ZKE_DENSE_MIN) dense[sg.src_off + q] = l | (d << 5);
+                }
+            }
+            ldm.dense = dense.data();
+        }
     }
     if (prefix && prefix_len > ZKE_WINDOW) {
         const uint64_t usable = zke_ldm_usable(prefix_len);
@@ -74,7 +110,11 @@ extern "C" int zk_enc_sim_match(const uint8_t *src, uint64_t n, uint32_t frame_s
     }
     for (uint32_t s = 0; s < pl.nseg; s++) {
         auto run = [&]() {
-            if (ldm.table) {
+            if (ldm.dense) {
+                if (zke_step(level) == 1024) zk_k_enc_match<15, 1, 1024, true, true>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
+                else zk_k_enc_match<15, 1, 4096, true, true>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
+            }
+            else if (ldm.table) {
                 if (zke_fast(level)) zk_k_enc_match<14, 0, 4096, true>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
                 else if (zke_step(level) == 1024) zk_k_enc_match<15, 1, 1024, true>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);
                 else zk_k_enc_match<15, 1, 4096, true>(msrc, segs.data(), blocks.data(), seqs, lits, ldm);

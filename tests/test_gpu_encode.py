@@ -88,13 +88,14 @@ def test_compression_ratio_sanity(engine):
     assert len(frames) == 4 and len(data) / len(comp) > 2.45         # text: libzstd level 1 gets 2.49; this encoder 2.47
 
 
-@pytest.mark.parametrize("level", [-5, 0, 1, 2, 3, 5, 6, 19])
+@pytest.mark.parametrize("level", [-5, 0, 1, 2, 3, 5, 6, 9, 19])
 def test_levels_are_honoured(engine, level):
     """EncodeOptions::compression_level (encode.rs:170, 281-282; CLI default 3, cli/src/args.rs:192): level <= 1: table
     matches of 6+ bytes, 2^14 table entries, greedy parse; levels 2..5 and 0 (= the default 3): 5+ bytes, 2^15 entries, lazy
-    parse; level >= 6: the same with lookup steps of 1024 positions.  Byte-identical to the CPU twin at that level, valid
-    zstd, and the step from 1 to 3 compresses the survey's text better (2.47 -> 2.59; steps of 1024 pay on source code, not
-    on this text: within 0.2 %)."""
+    parse; level >= 6: the same with lookup steps of 1024 positions; (round 6) level 0 and 3 and up: dense far history (every
+    position in two tables per matcher segment, 2^17 slots, 2^18 from level 9 on).  Byte-identical to the CPU twin at that level,
+    valid zstd, and the ladder compresses the survey's text better step by step: 2.48 (1) -> 2.65 (2) -> 2.71 (3) -> 2.72 (9);
+    steps of 1024 pay on source code, not on this text: within 0.2 %."""
     data = zko.gen_chunks(4 << 20, 11)
     comp, frames = engine.encode_frames(data, 2 << 20, level, True)
     check_payload(engine, data, comp, frames, 2 << 20, True)
@@ -103,13 +104,19 @@ def test_levels_are_honoured(engine, level):
         assert comp[pos:pos + c] == zko.frame_encode(data[dpos:dpos + d], level, True), (level, dpos)
         pos += c; dpos += d
     low, _ = engine.encode_frames(data, 2 << 20, 1, True)
+    two, _ = engine.encode_frames(data, 2 << 20, 2, True)
     mid, _ = engine.encode_frames(data, 2 << 20, 3, True)
+    assert len(mid) < 0.985 * len(two) < len(two) < len(low) and len(data) / len(mid) > 2.69         # the dense levels: 2 % on top of level 2
     if level <= 1 and level != 0:
         assert comp == low and len(data) / len(low) > 2.45
+    elif level == 2:
+        assert comp == two and len(data) / len(two) > 2.63
+    elif level >= 9:
+        assert len(comp) < len(mid) * 0.999                                                           # 2^18 slots
     elif level >= 6:
-        assert len(comp) < len(mid) * 1.002 and len(mid) < len(low)
+        assert len(comp) < len(mid) * 1.002
     else:
-        assert comp == mid and len(mid) < len(low) and len(data) / len(mid) > 2.56
+        assert comp == mid
 
 
 def _ratio_inputs():

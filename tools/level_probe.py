@@ -10,7 +10,7 @@ d_src = torch.from_numpy(np.tile(data, nf // 64)).to(dev)
 n = nf * F
 cap = int(zk.lib.zk_compress_bound(n, F))
 d_comp = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
-for lvl in (1, 3, 6):
+for lvl in (1, 2, 3, 6, 9):
     eng.set_profiling(False)
     eng.encode_frames_dev(d_src, n, F, lvl, True, d_comp, cap)
     torch.cuda.synchronize(); t = time.perf_counter()

@@ -12,7 +12,9 @@ constexpr uint32_t ZKE_BLOCK = 131072;
 //   level 2..5 and 0 = libzstd's default 3 (cli/src/args.rs:192): 5+ bytes, 2^15 entries, lazy parse (a longer match one or
 //     two positions later wins)
 //   level >= 6: the same with lookup steps of 1024 positions instead of 4096 (fresher tables: +3 % on source code)
-// 8d text: 2.470 / 2.587 / 2.585; python sources: 3.29 / 3.46 / 3.57.
+//   (round 6) level 0 and 3 and up, frames beyond the ring's reach: DENSE far history -- every position of a matcher segment in two
+//     tables of 2^17 slots (first / last occurrence), from level 9 on 2^18 (ZkEncLdm below; zk_k_enc_dense_cand)
+// 8d text (round 6): 2.484 (1) / 2.654 (2) / 2.709 (3) / 2.712 (6) / 2.721 (9); libzstd 1.5.7: 2.50 / 2.79 / 2.85 / 2.88.
 ZK_HD bool zke_fast(int level) { return level != 0 && level < 2; }
 ZK_HD uint32_t zke_minmatch(int level) { return zke_fast(level) ? 6u : 5u; }
 ZK_HD uint32_t zke_hash_log(int level) { return zke_fast(level) ? 14u : 15u; }
@@ -96,9 +98,20 @@ struct ZkEncLdm {
     uint32_t inframe;
     uint32_t frame_size, pad;
     uint64_t n_total;
+    // DENSE far history (round 6; oracle/zstd_oracle_enc.c dense_build_frame has the rule and the measurements): per input byte position
+    // (indexed like the source buffer, + ZKE_DENSE_SLACK entries) the position's far candidate as zk_k_enc_dense_cand found it -- length
+    // (<= 16) | distance << 5, 0: none -- out of two tables per matcher segment over the 5-byte hash of EVERY position (2^dlog slots: the
+    // first occurrence in the segment, the last one in the segment before), which live in LDS only.  nullptr: none (levels 1 and 2,
+    // prefixes, frames within the ring's reach).
+    const uint32_t *dense;
+    uint32_t dlog, pad2;
 };
+constexpr uint32_t ZKE_DENSE_AHEAD = 4, ZKE_DENSE_BONUS = 3;
+constexpr uint32_t ZKE_DENSE_MIN = 6, ZKE_DENSE_MARGIN = 2, ZKE_DENSE_NONE = 0xFFFFFFFFu, ZKE_DENSE_SLACK = 4096 + 16;
+ZK_HD uint32_t zke_dense_log(int level) { return level >= 9 ? 18u : 17u; }
 constexpr uint32_t ZKE_LDM_FILL = 6;    // in frame a far candidate is taken where the ring's best is shorter than this (the twin has the measurements)
 ZK_HD bool zke_ldm_in_frame(int level, uint64_t prefix_len, uint64_t frame_bytes) { return !zke_fast(level) && prefix_len == 0 && frame_bytes > ZKE_WINDOW; }
+ZK_HD bool zke_dense_in_frame(int level, uint64_t prefix_len, uint64_t frame_bytes) { return zke_ldm_in_frame(level, prefix_len, frame_bytes) && (level == 0 || level >= 3); }
 
 // A compressed block's payload is put together by zk_k_enc_assemble out of the pieces the entropy stage leaves in the block's scratch:
 //   [0, 16)      ZkEncPieces

@@ -168,11 +168,11 @@ __device__ __forceinline__ void zke_far_xor(const ZkEncLdm &ldm, int64_t a, bool
 // HLOG: log2 of the table entries (<= 14: 32-bit entries, 15: 16-bit entries); LAZY: a longer match one (or a clearly longer
 // one two) positions later wins; STEP: positions per lookup step (4096 = the whole group at once, 1024 = four steps of 256
 // lanes each)
-// LDM: long-distance candidates out of a prefix (zk_enc_device.h ZkEncLdm)
-template <int HLOG, int LAZY, int STEP, bool LDM>
+// LDM: long-distance candidates out of a prefix (zk_enc_device.h ZkEncLdm); DENSE: ... and the dense far history of the frame (round 6)
+template <int HLOG, int LAZY, int STEP, bool LDM, bool DENSE = false>
 __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src, const ZkEncFrame *segs, ZkEncBlock *blocks, uint64_t *seqs, uint8_t *lits, ZkEncLdm ldm)
 {
-    static_assert(HLOG >= 10 && HLOG <= 15 && (STEP == 1024 || STEP == (int)ZKE_GROUP_POS), "parameters");
+    static_assert(HLOG >= 10 && HLOG <= 15 && (STEP == 1024 || STEP == (int)ZKE_GROUP_POS) && (LDM || !DENSE), "parameters");
     constexpr bool T32 = HLOG <= 14;
     constexpr uint32_t TWORDS = T32 ? (1u << HLOG) : (1u << (HLOG - 1)), DUMMY = TWORDS;   // table[DUMMY]: where lanes without a position read and write
     constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -197,6 +197,9 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
         LD.pfx = base - abs0; LD.plen = fsz; LD.u0 = 0; LD.log = zke_ldm_log(fsz);
         LD.table = ldm.table + ((fr.src_off / ldm.frame_size) << ldm.log);
     }
+    // dense far history (round 6): per position of my segment its far candidate, length | distance << 5, as zk_k_enc_dense_cand left it
+    // (0: none); four positions per lane and group in one 16-byte read
+    const uint32_t *dcand = DENSE ? ldm.dense + fr.src_off + fr.seg_at : nullptr;
 
     ZKE_CLK_BEGIN();
     // ---- segment start: empty table, history + the first group (+ lookahead) into the ring, history positions into the table
@@ -362,6 +365,8 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
             const uint32_t dm1 = ring[(i0 - 1) & 16383u], d0 = ring[i0], d1 = ring[i0 + 1], d2 = ring[i0 + 2], d3 = ring[i0 + 3], d4 = ring[i0 + 4];
             uint32_t wlo[4], whi[4], hsh[4], tix[4], tw[4], e1[4];
             bool tabled[4];
+            uint32_t dcv[4] = {0, 0, 0, 0};
+            if (DENSE) memcpy(dcv, dcand + (P0 - hist), 16);                            // (lanes past the segment's end read on into the slack: unused)
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 wlo[k] = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)k);
@@ -448,6 +453,12 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                 // table's part of the prefix
                 auto far_ok = [&](uint32_t off) { const int64_t a = ap0 - (int64_t)off; return a >= (int64_t)LD.u0 && a + 20 <= (int64_t)LD.plen; };
                 const bool okR = farR && far_ok(R);
+                // dense far history: what zk_k_enc_dense_cand found for my four positions (requested at the top of the group)
+                uint32_t dpk[4] = {0, 0, 0, 0};
+                if (DENSE) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) dpk[k] = tabled[k] ? dcv[k] : 0u;
+                }
                 {
                     const uint32_t rb = P0 - R, ri = (rb >> 2) & 16383u, rs = rb & 3u;  // R <= P0 is tested below; a wrong address reads some ring bytes
                     x1[0] = d0 ^ __builtin_amdgcn_alignbyte(d0, dm1, 3u); x1[1] = d1 ^ __builtin_amdgcn_alignbyte(d1, d0, 3u); x1[2] = d2 ^ __builtin_amdgcn_alignbyte(d2, d1, 3u);
@@ -529,6 +540,10 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                         const uint32_t l2 = zke_first16(__builtin_amdgcn_alignbyte(x2[1], x2[0], (uint32_t)k), __builtin_amdgcn_alignbyte(x2[2], x2[1], (uint32_t)k),
                                                         __builtin_amdgcn_alignbyte(x2[3], x2[2], (uint32_t)k), __builtin_amdgcn_alignbyte(x2[4], x2[3], (uint32_t)k));
                         if (tfar && ok2 && tabled[k] && n == ZKE_PARCAP && l2 == ZKE_PARCAP && (!ldm.inframe || bl < ZKE_LDM_FILL)) { bl = ZKE_PARCAP; bo = tfar; }
+                        if (DENSE) {
+                            const uint32_t cd = (dpk[k] & 31u) < n ? dpk[k] & 31u : n;
+                            if ((dpk[k] >> 5) && cd >= ZKE_DENSE_MIN && cd >= bl + ZKE_DENSE_MARGIN) { bl = cd; bo = dpk[k] >> 5; }
+                        }
                         if (ok1 && c1 >= bl) { bl = c1; bo = 1; }
                         if (okr && cr + 1 >= bl) { bl = cr; bo = R; }
                         best[4 * tid + k] = bl | (bo << 5);
@@ -582,6 +597,16 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                         // (round 5) a CHEAP offset one position later -- the previous offset or offset 1 -- wins against a fresh one even one byte shorter
                         // (the twin has the measurements: runs of 10 bytes 5.5 -> 8.8)
                         if ((v >> 5) != R && (v >> 5) != 1 && p + 1 < te && l1 && ((n1 >> 5) == R || (n1 >> 5) == 1) && l1 + 1 >= len) cand = false;
+                        // (round 6) ... and a FAR candidate of the dense tables gives way to a cheap offset up to ZKE_DENSE_AHEAD positions later
+                        // unless it is ZKE_DENSE_BONUS bytes longer still (the twin has the cases: records, byte runs cut by a tile's end)
+                        if (DENSE) {
+                            const bool far = (v >> 5) > ZKE_WINDOW && (v >> 5) != R;
+#pragma unroll
+                            for (uint32_t j = 1; j <= ZKE_DENSE_AHEAD; j++) {
+                                const uint32_t nj = j == 1 ? n1 : best[wave * ZKE_TILE + pos + j < ZKE_GROUP_POS ? wave * ZKE_TILE + pos + j : 0], lj = nj & 0x1F;
+                                if (far && p + j < te && lj && ((nj >> 5) == R || (nj >> 5) == 1) && lj + j + ZKE_DENSE_BONUS >= len) cand = false;
+                            }
+                        }
                     }
                     pv[u] = v; plen[u] = len;
                     pbk[u] = ((const uint8_t *)bkb)[wave * ZKE_TILE + pos];

@@ -885,6 +885,128 @@ __global__ __launch_bounds__(256) void zk_k_enc_ldm_build_frames(const uint8_t *
         }
     }
 }
+// DENSE far history (round 6; ZkEncLdm in zk_enc_device.h, the rule: oracle/zstd_oracle_enc.c dense_build_frame / dense_lookup): a
+// workgroup per matcher segment leaves every position's far candidate (length | distance << 5) in `cand`, where the match kernel
+// reads it in whole lines.  The two tables a position is looked up in -- smallest position per slot of its own segment, largest
+// position + 1 per slot of the segment before, over the 5-byte hash of EVERY position -- exist in LDS only, 2^14 slots of both per pass
+// (128 KiB): per pass the two segments are read again (L2) and hashed (a few instructions per position), positions whose slot lies
+// in the pass's range enter with LDS atomics, then the segment's own positions of that range look their candidate up and store its
+// distance.  The first form kept the tables in HBM and let the match kernel read them: two random 4-byte reads per input byte
+// into 1 MiB per segment = a line from HBM each, matcher 67 -> 212 ms per 4 GiB (profiles/r06c_dense_probe.txt).  A last sweep
+// measures the candidates (16 bytes through memory, all lanes at work).  HBM-bound byte work; 4 bytes of `cand` per input byte,
+// written twice (a list entry, the final entry) and read once here, once by the match kernel.
+__global__ __launch_bounds__(1024) void zk_k_enc_dense_cand(const uint8_t *src, const ZkEncFrame *segs, ZkEncLdm ldm, uint32_t *cand)
+{
+    constexpr uint32_t PLOG = 14, PSLOTS = 1u << PLOG;
+    constexpr uint32_t U = 8;                                                       // steps of 4096 positions in flight per lane
+    constexpr uint32_t CLOG = 13, CHUNK = 1u << CLOG, NCHUNK = ZKE_SEGMENT / CHUNK;     // found candidates are listed per chunk of 8192 positions
+    static_assert(ZKE_SEGMENT + ZKE_SEGMENT - ZKE_WINDOW <= (1u << (32 - CLOG)), "a list entry: position inside the chunk | (distance - ZKE_WINDOW - 1) << 13");
+    __shared__ uint32_t first[PSLOTS], last[PSLOTS];
+    __shared__ uint32_t count[NCHUNK];
+    const ZkEncFrame sg = segs[blockIdx.x];
+    const uint8_t *frame = src + sg.src_off;
+    const uint64_t left = ldm.n_total - sg.src_off;
+    const uint32_t fsz = (uint32_t)(left < ldm.frame_size ? left : ldm.frame_size);
+    const uint32_t s0 = sg.seg_at, e1 = s0 + sg.d_size, tid = threadIdx.x, dlog = ldm.dlog;
+    const uint32_t p0 = s0 ? s0 - ZKE_SEGMENT : 0;                   // the segment before mine is a whole one
+    uint32_t *out = cand + sg.src_off;                              // indexed by the position inside the frame
+    if (tid < NCHUNK) count[tid] = 0;
+    // Passes over the slots.  What a pass finds is NOT stored by position -- a line of `cand` would be written an eighth at a time, pass
+    // after pass, and leave the L2 half-written in between (the first form: 134 ms per 4 GiB, profiles/r06c_dense_probe.txt) -- but
+    // appended to the list of the position's chunk, which lives where the chunk's entries of `cand` will be (a chunk has at most as many
+    // candidates as positions): whole lines, filled front to back.
+    for (uint32_t pass = 0; pass < (1u << (dlog - PLOG)); pass++) {
+        for (uint32_t i = tid; i < PSLOTS; i += 1024) { first[i] = ZKE_DENSE_NONE; last[i] = 0; }
+        __syncthreads();
+        // (eight steps' input requested before the first is hashed: four waves per SIMD do not cover a trip to L2 per step)
+        for (uint32_t qb = p0 + 4 * tid; qb < e1; qb += 4096 * U) {
+            uint32_t w0[U], w1[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t q0 = qb + 4096 * u, at = q0 < e1 && q0 + 8 <= fsz ? q0 : 0;      // (none of a step's four positions has its eight bytes: the frame's first bytes, unused)
+                memcpy(&w0[u], frame + at, 4); memcpy(&w1[u], frame + at + 4, 4);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t q0 = qb + 4096 * u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t q = q0 + k;
+                    const uint32_t h = zke_hash(__builtin_amdgcn_alignbyte(w1[u], w0[u], (uint32_t)k), (w1[u] >> (8 * k)) & 0xFFu, dlog);
+                    if (q < e1 && q + 8 <= fsz && (h >> PLOG) == pass) {
+                        if (q0 < s0) atomicMax(&last[h & (PSLOTS - 1)], q - p0 + 1);
+                        else atomicMin(&first[h & (PSLOTS - 1)], q - s0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t qb = s0 + 4 * tid; qb < e1; qb += 4096 * U) {
+            uint32_t w0[U], w1[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t q0 = qb + 4096 * u, at = q0 < e1 && q0 + 8 <= fsz ? q0 : 0;
+                memcpy(&w0[u], frame + at, 4); memcpy(&w1[u], frame + at + 4, 4);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t q0 = qb + 4096 * u, chunk = (q0 - s0) >> CLOG;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t q = q0 + k, r = q - s0;
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(w1[u], w0[u], (uint32_t)k);
+                    const uint32_t h = zke_hash(lo, (w1[u] >> (8 * k)) & 0xFFu, dlog);
+                    uint32_t d = 0;
+                    if (q < e1 && q + 8 <= fsz && (h >> PLOG) == pass) {
+                        const uint32_t m1 = first[h & (PSLOTS - 1)], m2 = last[h & (PSLOTS - 1)];
+                        if (lo == (lo & 0xFFu) * 0x01010101u) d = 0;          // four equal bytes: a byte run, offset 1 codes it better (the twin has the numbers)
+                        else if (m1 != ZKE_DENSE_NONE && m1 < r && r - m1 > ZKE_WINDOW) d = r - m1;
+                        else if (s0 && m2 && r + ZKE_SEGMENT - (m2 - 1) > ZKE_WINDOW) d = r + ZKE_SEGMENT - (m2 - 1);
+                    }
+                    // (a reservation per wave -- ballot, one atomic, readlane -- measured slower than a bump per lane: 106 -> 115 ms; the kernel
+                    //  is bound by its vector instructions: ~75 per position and pass, four cycles each on a 16-lane SIMD; a copy of the loops without
+                    //  the end-of-frame tests for whole segments: 106 -> 122 ms, 65 registers instead of 56)
+                    if (d) out[s0 + (chunk << CLOG) + atomicAdd(&count[chunk], 1u)] = (r & (CHUNK - 1)) | ((d - ZKE_WINDOW - 1) << CLOG);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // Chunk by chunk: the list into LDS by position, then every position's candidate measured -- 16 bytes at the position against 16
+    // bytes `distance` before it, every lane at work -- and the chunk's entries of `cand` written in whole lines over its list.
+    uint32_t *dist = first;
+    for (uint32_t c = 0; (c << CLOG) < sg.d_size; c++) {
+        const uint32_t cb = s0 + (c << CLOG);
+        for (uint32_t i = tid; i < CHUNK; i += 1024) dist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < count[c]; i += 1024) { const uint32_t e = out[cb + i]; dist[e & (CHUNK - 1)] = (e >> CLOG) + ZKE_WINDOW + 1; }
+        __syncthreads();
+        for (uint32_t q0 = cb + 4 * tid; q0 < cb + CHUNK && q0 < e1; q0 += 4096) {
+            uint32_t d[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) d[k] = dist[q0 - cb + k];
+            uint32_t own[5] = {0, 0, 0, 0, 0};
+            if (q0 + 20 <= fsz) memcpy(own, frame + q0, 20);
+            else for (uint32_t b = q0; b < fsz; b++) own[(b - q0) >> 2] |= (uint32_t)frame[b] << (8 * ((b - q0) & 3));     // the frame's last bytes: zeros behind them
+            uint32_t cc[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) memcpy(cc[k], frame + (d[k] ? q0 + k - d[k] : 0), 16);     // (a candidate lies more than ZKE_WINDOW bytes before its position)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t l = zke_first16(cc[k][0] ^ __builtin_amdgcn_alignbyte(own[1], own[0], (uint32_t)k), cc[k][1] ^ __builtin_amdgcn_alignbyte(own[2], own[1], (uint32_t)k),
+                                               cc[k][2] ^ __builtin_amdgcn_alignbyte(own[3], own[2], (uint32_t)k), cc[k][3] ^ __builtin_amdgcn_alignbyte(own[4], own[3], (uint32_t)k));
+                d[k] = d[k] && l >= ZKE_DENSE_MIN ? l | (d[k] << 5) : 0u;
+            }
+            if (q0 + 4 <= e1) memcpy(out + q0, d, 16);
+            else for (uint32_t k = 0; q0 + k < e1; k++) out[q0 + k] = d[k];
+        }
+        __syncthreads();
+    }
+}
+void zk_launch_enc_dense_cand(hipStream_t st, const uint8_t *src, const ZkEncFrame *segs, uint32_t nsegs, const ZkEncLdm &ldm, uint32_t *cand)
+{
+    if (nsegs) hipLaunchKernelGGL(zk_k_enc_dense_cand, dim3(nsegs), dim3(1024), 0, st, src, segs, ldm, cand);
+}
 // (both return the HIP verdict of clearing the table: a table that was not cleared holds an earlier call's positions, and the matcher
 //  would follow them -- ADVICE r4 / r5)
 int zk_launch_enc_ldm_build_frames(hipStream_t st, const uint8_t *src, const ZkEncLdm &ldm, uint32_t *table, uint32_t nframes)
@@ -910,7 +1032,11 @@ void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *s
     if (!nsegs) return;
     // one instance per setting of zk_enc_device.h (zke_hash_log / zke_lazy / zke_step), with and without long-distance matching
 #define ZKE_GO(H, L, S, D) hipLaunchKernelGGL((zk_k_enc_match<H, L, S, D>), dim3(nsegs), dim3(ZKE_THREADS), 0, st, src, segs, blocks, seqs, lits, ldm)
-    if (ldm.table) {
+    if (ldm.dense) {                                            // (level 0 / >= 3 in frame: never the fast setting)
+        if (zke_step(level) == 1024) hipLaunchKernelGGL((zk_k_enc_match<15, 1, 1024, true, true>), dim3(nsegs), dim3(ZKE_THREADS), 0, st, src, segs, blocks, seqs, lits, ldm);
+        else hipLaunchKernelGGL((zk_k_enc_match<15, 1, 4096, true, true>), dim3(nsegs), dim3(ZKE_THREADS), 0, st, src, segs, blocks, seqs, lits, ldm);
+    }
+    else if (ldm.table) {
         if (zke_fast(level)) ZKE_GO(14, 0, 4096, true);
         else if (zke_step(level) == 1024) ZKE_GO(15, 1, 1024, true);
         else ZKE_GO(15, 1, 4096, true);

@@ -7,7 +7,7 @@
 #include "zk_kernels.h"
 
 enum { ZK_K_WALK_COUNT = 0, ZK_K_SCAN, ZK_K_WALK_FILL, ZK_K_HUF, ZK_K_FSE, ZK_K_EXEC, ZK_K_XXH64, ZK_K_STATUS,
-       ZK_K_ENC_MATCH, ZK_K_ENC_ENTROPY, ZK_K_ENC_COMPACT, ZK_K_ENC_XXH64, ZK_K_ENC_FSE_BUILD, ZK_NKERNELS };
+       ZK_K_ENC_MATCH, ZK_K_ENC_ENTROPY, ZK_K_ENC_COMPACT, ZK_K_ENC_XXH64, ZK_K_ENC_FSE_BUILD, ZK_K_ENC_DENSE, ZK_NKERNELS };
 
 struct zk_devbuf { void *p = nullptr; size_t cap = 0; };
 enum { ZK_MAX_CTX = 6 };
@@ -59,6 +59,7 @@ struct zk_engine {
     void *enc_pin = nullptr; size_t enc_pin_cap = 0;   // pinned host copy of the frame / block lists of the encode in flight
     zk_devbuf enc_hist;                     // prefix mode: [prefix tail | frame] records for the matcher
     zk_devbuf enc_seg;                      // frames above ZKE_SEGMENT: the matcher's segment records
+    zk_devbuf enc_dense;                    // dense far history (level 0 / >= 3, frames beyond the ring's reach): a candidate per input byte (ZkEncLdm::dense)
     zk_devbuf enc_ldm;                      // prefix beyond the matcher's ring: the long-distance table (ZkEncLdm)
     ZkEncTables enc_tables;
     bool enc_tables_ready = false;

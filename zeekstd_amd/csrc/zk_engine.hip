@@ -80,7 +80,7 @@ extern "C" int zk_engine_kernel_count(void) { return ZK_NKERNELS; }
 extern "C" const char *zk_engine_kernel_name(int k)
 {
     static const char *names[ZK_NKERNELS] = {"zk_k_walk(count)", "zk_k_scan", "zk_k_walk(fill)", "zk_k_huf", "zk_k_fse", "zk_k_exec",
-                                             "zk_k_xxh64", "zk_k_status", "zk_k_enc_match", "zk_k_enc_entropy", "zk_k_enc_compact", "zk_k_enc_xxh64", "zk_k_enc_fse_build"};
+                                             "zk_k_xxh64", "zk_k_status", "zk_k_enc_match", "zk_k_enc_entropy", "zk_k_enc_compact", "zk_k_enc_xxh64", "zk_k_enc_fse_build", "zk_k_enc_dense_cand"};
     return k >= 0 && k < ZK_NKERNELS ? names[k] : "";
 }
 extern "C" int zk_engine_kernel_times(const zk_engine *e, float *ms_out, int n)
@@ -159,7 +159,7 @@ extern "C" void zk_engine_destroy(zk_engine *e)
     if (e->enc_pin) (void)hipHostFree(e->enc_pin);
     for (auto &c : e->dctx) if (c.st) (void)hipStreamSynchronize(c.st);
     zk_devbuf *bufs[] = {&e->st_prefix, &e->st_comp, &e->st_off, &e->st_dst, &e->st_misc,
-                         &e->enc_a, &e->enc_b, &e->enc_c, &e->enc_d, &e->enc_e, &e->enc_f, &e->enc_hist, &e->enc_seg, &e->enc_ldm};
+                         &e->enc_a, &e->enc_b, &e->enc_c, &e->enc_d, &e->enc_e, &e->enc_f, &e->enc_hist, &e->enc_seg, &e->enc_ldm, &e->enc_dense};
     for (zk_devbuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (e->h_words) (void)hipHostFree(e->h_words);
     for (int k = 0; k < ZK_NKERNELS; k++) { if (e->ev_start[k]) (void)hipEventDestroy(e->ev_start[k]); if (e->ev_stop[k]) (void)hipEventDestroy(e->ev_stop[k]); }

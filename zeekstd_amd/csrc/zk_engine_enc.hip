@@ -114,13 +114,22 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         msrc = (const uint8_t *)e->enc_hist.p;
     }
     // a prefix the ring cannot hold: its sampled positions enter a table in HBM (rebuilt per call: the bytes are the caller's)
-    ZkEncLdm ldm = {nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
+    ZkEncLdm ldm = {nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, 0, 0};
+    // the matcher's workgroups are launched over the segments (one per <= 256 KiB of a frame)
+    if ((rc = zk_devbuf_reserve(e, e->enc_seg, segs_bytes + 64))) return rc;
+    ZK_HIP(hipMemcpyAsync(e->enc_seg.p, segs, (size_t)nseg * sizeof(ZkEncFrame), hipMemcpyHostToDevice, st));
     if (!hist && zke_ldm_in_frame(a.level, 0, frame_size < a.n ? frame_size : a.n)) {
         // in-frame far history (level >= 2, no prefix, frames beyond the ring's reach): one table per frame over its own bytes
         ldm.inframe = 1; ldm.frame_size = frame_size; ldm.n_total = a.n; ldm.log = zke_ldm_log(frame_size < a.n ? frame_size : a.n);
         if ((rc = zk_devbuf_reserve(e, e->enc_ldm, (((size_t)nf * sizeof(uint32_t)) << ldm.log) + 64))) return rc;
         if (zk_launch_enc_ldm_build_frames(st, src, ldm, (uint32_t *)e->enc_ldm.p, nf)) { e->last_err = "hipMemsetAsync (in-frame long-distance table)"; return ZK_ERR_HIP; }
         ldm.table = (const uint32_t *)e->enc_ldm.p;
+        if (zke_dense_in_frame(a.level, 0, frame_size < a.n ? frame_size : a.n)) {
+            // dense far history (level 0 / >= 3): a far candidate per input byte, 4 bytes each (4 x the input: HBM is what this device has)
+            ldm.dlog = zke_dense_log(a.level);
+            if ((rc = zk_devbuf_reserve(e, e->enc_dense, ((size_t)n + ZKE_DENSE_SLACK) * sizeof(uint32_t) + 64))) return rc;
+            ldm.dense = (const uint32_t *)e->enc_dense.p;
+        }
     }
     if (hist && a.prefix_len > ZKE_WINDOW) {
         const uint64_t usable = zke_ldm_usable(a.prefix_len);
@@ -129,9 +138,7 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         if (zk_launch_enc_ldm_build(st, ldm, (uint32_t *)e->enc_ldm.p)) { e->last_err = "hipMemsetAsync (long-distance table)"; return ZK_ERR_HIP; }
         ldm.table = (const uint32_t *)e->enc_ldm.p;
     }
-    // the matcher's workgroups are launched over the segments (one per <= 256 KiB of a frame)
-    if ((rc = zk_devbuf_reserve(e, e->enc_seg, segs_bytes + 64))) return rc;
-    ZK_HIP(hipMemcpyAsync(e->enc_seg.p, segs, (size_t)nseg * sizeof(ZkEncFrame), hipMemcpyHostToDevice, st));
+    if (ldm.dense) { zk_kernel_timer t(e, ZK_K_ENC_DENSE, st); zk_launch_enc_dense_cand(st, src, (const ZkEncFrame *)e->enc_seg.p, nseg, ldm, (uint32_t *)e->enc_dense.p); }
     { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, (const ZkEncFrame *)e->enc_seg.p, nseg, dbl, (uint64_t *)e->enc_b.p, (uint8_t *)e->enc_c.p, a.level, ldm); }
     ZkEncTables *ftab = (ZkEncTables *)e->enc_f.p;
     { zk_kernel_timer t(e, ZK_K_ENC_FSE_BUILD, st); zk_launch_enc_fse_build(st, src, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), dtab, ftab); }
