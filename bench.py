@@ -801,6 +801,35 @@ def main():
                     "ms": round(min(te) * 1e3, 2), "kernel_ms": {k: round(v, 3) for k, v in ek.items()},
                     "calls_ms": _stats_ms(te),
                     "roofline": roofline_of(ek, dsize + csize, min(te) * 1e3, "kernels", nframes == 2048)}
+        # (r6) the same input at the reference CLI's default level (cli/src/args.rs:192): dense far history (zk_k_enc_dense_cand); its first
+        # eight frames decoded and compared with the input.  Not the headline: one line of the report.
+        if rank == 0 and world == 1 and level == 1 and not args.no_e2e:
+            try:
+                d_comp3 = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+                d_cs3 = torch.zeros(nframes, dtype=torch.int32, device=dev)
+                torch.cuda.synchronize()
+                _, csize3 = eng.encode_frames_dev(d_src, dsize, FRAME, 3, cks, d_comp3, cap, d_cs3, d_ds)
+                t3 = []
+                for _ in range(2):
+                    t = time.perf_counter()
+                    eng.encode_frames_dev(d_src, dsize, FRAME, 3, cks, d_comp3, cap, d_cs3, d_ds)
+                    t3.append(time.perf_counter() - t)
+                eng.set_profiling(True)
+                eng.encode_frames_dev(d_src, dsize, FRAME, 3, cks, d_comp3, cap, d_cs3, d_ds)
+                ek3 = eng.kernel_times()
+                eng.set_profiling(False)
+                nchk = min(8, nframes)
+                c3 = np.zeros(nchk + 1, np.int64); c3[1:] = np.cumsum(d_cs3[:nchk].cpu().numpy().astype(np.int64))
+                d3 = np.arange(nchk + 1, dtype=np.int64) * FRAME
+                o3 = torch.empty(nchk * FRAME + 64, dtype=torch.uint8, device=dev)
+                s3 = torch.zeros(nchk, dtype=torch.int32, device=dev)
+                eng.decode_frames_dev(d_comp3, int(c3[-1]), torch.from_numpy(c3).to(dev), torch.from_numpy(d3).to(dev), 0, nchk, o3, nchk * FRAME, True, s3)
+                ok3 = bool(torch.equal(o3[:nchk * FRAME], d_src[:nchk * FRAME])) and int(s3.abs().sum().item()) == 0
+                enc_info["level_3"] = {"value": round(dsize / min(t3) / 2**30, 2), "unit": "GiB/s", "ratio": round(dsize / csize3, 3), "ms": round(min(t3) * 1e3, 2),
+                                       "kernel_ms": {k: round(v, 3) for k, v in ek3.items() if "enc" in k}, "first_frames_round_trip": ok3}
+                del d_comp3, d_cs3, o3
+            except Exception as ex:                                   # noqa: BLE001  (a leg of the report, not the run)
+                enc_info["level_3"] = {"error": f"{type(ex).__name__}: {ex}"}
     else:
         frames, comp = z_frames, z_comp
         d_comp = torch.from_numpy(np.frombuffer(comp + b"\0" * 64, np.uint8).copy()).to(dev)
@@ -1164,7 +1193,7 @@ def main():
             return d
         front = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
         front.update({"reference_made_GiB_s": _g(ref_info, "value"), "reference_made_level3_GiB_s": _g(ref_info, "level_3", "value"),
-                      "encode_GiB_s": _g(enc_info, "value"), "round_trip_GiB_s": _g(line.get("round_trip"), "value"),
+                      "encode_GiB_s": _g(enc_info, "value"), "encode_level3_GiB_s": _g(enc_info, "level_3", "value"), "encode_level3_ratio": _g(enc_info, "level_3", "ratio"), "round_trip_GiB_s": _g(line.get("round_trip"), "value"),
                       "seek_p50_us": _g(seek_info, "gpu_made_archive", "gpu_decoder_us", "p50"), "seek_p50_us_reference_made": _g(seek_info, "reference_made_archive", "gpu_decoder_us", "p50"),
                       "seek_p50_us_cpu_reference": _g(seek_info, "reference_made_archive", "cpu_reference_us", "p50"),
                       "configs0_decoder_GiB_s": _g(c1_info, "decoder", "value"), "roofline_frac": round(achieved / HBM_PEAK_GBS, 5),
