@@ -86,7 +86,9 @@ extern "C" int zk_enc_sim_match(const uint8_t *src, uint64_t n, uint32_t frame_s
                     uint32_t l = 0;
                     while (l < 16 && q + l < fsz && frame[q + l] == frame[q + l - d]) l++;
                     while (l < 16 && q + l >= fsz && frame[q + l - d] == 0) l++;     // the kernel reads zeros behind the frame's last byte (the match kernel caps the length at its tile's end)
-                    if (l >= ZKE_DENSE_MIN) dense[sg.src_off + q] = l | (d << 5);
+                    uint32_t bk = 0;
+                    while (bk < 4 && q - bk > d && frame[q - bk - 1] == frame[q - bk - 1 - d]) bk++;      // not past the frame's first byte
+                    if (l >= ZKE_DENSE_MIN) dense[sg.src_off + q] = l | (bk << 5) | (d << 8);
                 }
             }
             ldm.dense = dense.data();

@@ -94,7 +94,7 @@ def test_levels_are_honoured(engine, level):
     matches of 6+ bytes, 2^14 table entries, greedy parse; levels 2..5 and 0 (= the default 3): 5+ bytes, 2^15 entries, lazy
     parse; level >= 6: the same with lookup steps of 1024 positions; (round 6) level 0 and 3 and up: dense far history (every
     position in two tables per matcher segment, 2^17 slots, 2^18 from level 9 on).  Byte-identical to the CPU twin at that level,
-    valid zstd, and the ladder compresses the survey's text better step by step: 2.48 (1) -> 2.65 (2) -> 2.71 (3) -> 2.72 (9);
+    valid zstd, and the ladder compresses the survey's text better step by step: 2.48 (1) -> 2.65 (2) -> 2.73 (3) -> 2.74 (9);
     steps of 1024 pay on source code, not on this text: within 0.2 %."""
     data = zko.gen_chunks(4 << 20, 11)
     comp, frames = engine.encode_frames(data, 2 << 20, level, True)
@@ -106,7 +106,7 @@ def test_levels_are_honoured(engine, level):
     low, _ = engine.encode_frames(data, 2 << 20, 1, True)
     two, _ = engine.encode_frames(data, 2 << 20, 2, True)
     mid, _ = engine.encode_frames(data, 2 << 20, 3, True)
-    assert len(mid) < 0.985 * len(two) < len(two) < len(low) and len(data) / len(mid) > 2.69         # the dense levels: 2 % on top of level 2
+    assert len(mid) < 0.985 * len(two) < len(two) < len(low) and len(data) / len(mid) > 2.71         # the dense levels: 2 % on top of level 2
     if level <= 1 and level != 0:
         assert comp == low and len(data) / len(low) > 2.45
     elif level == 2:

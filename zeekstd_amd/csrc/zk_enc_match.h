@@ -197,7 +197,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
         LD.pfx = base - abs0; LD.plen = fsz; LD.u0 = 0; LD.log = zke_ldm_log(fsz);
         LD.table = ldm.table + ((fr.src_off / ldm.frame_size) << ldm.log);
     }
-    // dense far history (round 6): per position of my segment its far candidate, length | distance << 5, as zk_k_enc_dense_cand left it
+    // dense far history (round 6): per position of my segment its far candidate, length | catch-up << 5 | distance << 8, as zk_k_enc_dense_cand left it
     // (0: none); four positions per lane and group in one 16-byte read
     const uint32_t *dcand = DENSE ? ldm.dense + fr.src_off + fr.seg_at : nullptr;
 
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                         if (tfar && ok2 && tabled[k] && n == ZKE_PARCAP && l2 == ZKE_PARCAP && (!ldm.inframe || bl < ZKE_LDM_FILL)) { bl = ZKE_PARCAP; bo = tfar; }
                         if (DENSE) {
                             const uint32_t cd = (dpk[k] & 31u) < n ? dpk[k] & 31u : n;
-                            if ((dpk[k] >> 5) && cd >= ZKE_DENSE_MIN && cd >= bl + ZKE_DENSE_MARGIN) { bl = cd; bo = dpk[k] >> 5; }
+                            if ((dpk[k] >> 8) && cd >= ZKE_DENSE_MIN && cd >= bl + ZKE_DENSE_MARGIN) { bl = cd; bo = dpk[k] >> 8; }
                         }
                         if (ok1 && c1 >= bl) { bl = c1; bo = 1; }
                         if (okr && cr + 1 >= bl) { bl = cr; bo = R; }
@@ -566,6 +566,8 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                     const uint32_t room = p - ts < p - off ? p - ts : p - off;
                     bk = bk < room ? bk : room;
                     if (!wl[k] || off + 4 > ZKE_WINDOW || p < ts) bk = 0;
+                    // (round 6) a winner at the distance of the position's dense candidate: the count its entry carries (through memory, zk_k_enc_dense_cand)
+                    if (DENSE && wl[k] && (dpk[k] >> 8) && off == (dpk[k] >> 8) && p >= ts) { bk = (dpk[k] >> 5) & 7u; bk = bk < p - ts ? bk : p - ts; }
                     bk4 |= bk << (8 * k);
                 }
                 bkb[tid] = bk4;

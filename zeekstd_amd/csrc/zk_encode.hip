@@ -887,7 +887,7 @@ __global__ __launch_bounds__(256) void zk_k_enc_ldm_build_frames(const uint8_t *
 }
 // DENSE far history (round 6; ZkEncLdm in zk_enc_device.h, the rule: oracle/zstd_oracle_enc.c dense_build_frame / dense_lookup): a
 // workgroup per matcher segment leaves every position's far candidate (length | distance << 5) in `cand`, where the match kernel
-// reads it in whole lines.  The two tables a position is looked up in -- smallest position per slot of its own segment, largest
+// reads it in whole lines (length | catch-up << 5 | distance << 8).  The two tables a position is looked up in -- smallest position per slot of its own segment, largest
 // position + 1 per slot of the segment before, over the 5-byte hash of EVERY position -- exist in LDS only, 2^14 slots of both per pass
 // (128 KiB): per pass the two segments are read again (L2) and hashed (a few instructions per position), positions whose slot lies
 // in the pass's range enter with LDS atomics, then the segment's own positions of that range look their candidate up and store its
@@ -988,14 +988,26 @@ __global__ __launch_bounds__(1024) void zk_k_enc_dense_cand(const uint8_t *src, 
             uint32_t own[5] = {0, 0, 0, 0, 0};
             if (q0 + 20 <= fsz) memcpy(own, frame + q0, 20);
             else for (uint32_t b = q0; b < fsz; b++) own[(b - q0) >> 2] |= (uint32_t)frame[b] << (8 * ((b - q0) & 3));     // the frame's last bytes: zeros behind them
-            uint32_t cc[4][4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) memcpy(cc[k], frame + (d[k] ? q0 + k - d[k] : 0), 16);     // (a candidate lies more than ZKE_WINDOW bytes before its position)
+            // ... and the four bytes in front of both (the catch-up count of the entry: how many of them agree, not past the frame's first byte)
+            uint32_t before = 0;                                              // bytes q0 - 4 .. q0 - 1 (zeros in front of the frame)
+            if (q0 >= 4) memcpy(&before, frame + q0 - 4, 4);
+            uint32_t cc[4][5];                                                // the candidate's bytes e - 4 .. e + 15
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t l = zke_first16(cc[k][0] ^ __builtin_amdgcn_alignbyte(own[1], own[0], (uint32_t)k), cc[k][1] ^ __builtin_amdgcn_alignbyte(own[2], own[1], (uint32_t)k),
-                                               cc[k][2] ^ __builtin_amdgcn_alignbyte(own[3], own[2], (uint32_t)k), cc[k][3] ^ __builtin_amdgcn_alignbyte(own[4], own[3], (uint32_t)k));
-                d[k] = d[k] && l >= ZKE_DENSE_MIN ? l | (d[k] << 5) : 0u;
+                const uint32_t e = d[k] ? q0 + k - d[k] : 4u;                     // (no candidate: the frame's first bytes, unused)
+                if (e >= 4) memcpy(cc[k], frame + e - 4, 20);
+                else { cc[k][0] = 0; for (uint32_t b = 0; b < e; b++) cc[k][0] |= (uint32_t)frame[b] << (8 * (4 - e + b)); memcpy(&cc[k][1], frame + e, 16); }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t l = zke_first16(cc[k][1] ^ __builtin_amdgcn_alignbyte(own[1], own[0], (uint32_t)k), cc[k][2] ^ __builtin_amdgcn_alignbyte(own[2], own[1], (uint32_t)k),
+                                               cc[k][3] ^ __builtin_amdgcn_alignbyte(own[3], own[2], (uint32_t)k), cc[k][4] ^ __builtin_amdgcn_alignbyte(own[4], own[3], (uint32_t)k));
+                const uint32_t mine4 = k ? __builtin_amdgcn_alignbyte(own[0], before, (uint32_t)k) : before;      // the four bytes that end at q0 + k
+                uint32_t bk = ZKE_FFBH(mine4 ^ cc[k][0]);
+                bk = (bk < 32u ? bk : 32u) >> 3;
+                const uint32_t e = q0 + k - d[k];
+                bk = bk < e ? bk : e;
+                d[k] = d[k] && l >= ZKE_DENSE_MIN ? l | (bk << 5) | (d[k] << 8) : 0u;
             }
             if (q0 + 4 <= e1) memcpy(out + q0, d, 16);
             else for (uint32_t k = 0; q0 + k < e1; k++) out[q0 + k] = d[k];
