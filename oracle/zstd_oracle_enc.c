@@ -484,6 +484,7 @@ static void dense_build_frame(enc_state *st, const u8 *frame, size_t n, int leve
         memset(first, 0xFF, sizeof(u32) << log); memset(last, 0, sizeof(u32) << log);
         const u64 s0 = (u64)g * ZKE_SEGMENT, e1 = s0 + ZKE_SEGMENT < n ? s0 + ZKE_SEGMENT : n;
         for (u64 q = s0; q < e1 && q + 8 <= n; q++) {
+            if (frame[q + 1] == frame[q] && frame[q + 2] == frame[q] && frame[q + 3] == frame[q]) continue;      /* a byte run: neither entered nor looked up (dense_lookup) */
             const u32 h = hash5(frame + q, log), r = (u32)(q - s0);
             if (r < first[h]) first[h] = r;
             if (r + 1 > last[h]) last[h] = r + 1;

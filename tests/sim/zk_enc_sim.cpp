@@ -71,6 +71,7 @@ extern "C" int zk_enc_sim_match(const uint8_t *src, uint64_t n, uint32_t frame_s
                 std::fill(first.begin(), first.end(), ZKE_DENSE_NONE); std::fill(last.begin(), last.end(), 0u);
                 const uint64_t e1 = (uint64_t)sg.seg_at + sg.d_size;
                 for (uint64_t q = sg.seg_at; q < e1 && q + 8 <= fsz; q++) {
+                    if (frame[q + 1] == frame[q] && frame[q + 2] == frame[q] && frame[q + 3] == frame[q]) continue;      // a byte run: neither entered nor looked up
                     const uint32_t h = h5(frame + q), r = (uint32_t)(q - sg.seg_at);
                     if (r < first[h]) first[h] = r;
                     if (r + 1 > last[h]) last[h] = r + 1;

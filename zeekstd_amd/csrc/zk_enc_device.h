@@ -107,6 +107,7 @@ struct ZkEncLdm {
     uint32_t dlog, pad2;
 };
 constexpr uint32_t ZKE_DENSE_AHEAD = 4, ZKE_DENSE_BONUS = 3;
+constexpr uint32_t ZKE_DENSE_PASSES_MAX = 32;          // passes of the candidate kernel at 2^18 slots (2^13 of both tables in LDS per pass)
 constexpr uint32_t ZKE_DENSE_MIN = 6, ZKE_DENSE_MARGIN = 2, ZKE_DENSE_NONE = 0xFFFFFFFFu, ZKE_DENSE_SLACK = 4096 + 16;
 ZK_HD uint32_t zke_dense_log(int level) { return level >= 9 ? 18u : 17u; }
 constexpr uint32_t ZKE_LDM_FILL = 6;    // in frame a far candidate is taken where the ring's best is shorter than this (the twin has the measurements)

@@ -885,89 +885,137 @@ __global__ __launch_bounds__(256) void zk_k_enc_ldm_build_frames(const uint8_t *
         }
     }
 }
-// DENSE far history (round 6; ZkEncLdm in zk_enc_device.h, the rule: oracle/zstd_oracle_enc.c dense_build_frame / dense_lookup): a
-// workgroup per matcher segment leaves every position's far candidate (length | distance << 5) in `cand`, where the match kernel
-// reads it in whole lines (length | catch-up << 5 | distance << 8).  The two tables a position is looked up in -- smallest position per slot of its own segment, largest
-// position + 1 per slot of the segment before, over the 5-byte hash of EVERY position -- exist in LDS only, 2^14 slots of both per pass
-// (128 KiB): per pass the two segments are read again (L2) and hashed (a few instructions per position), positions whose slot lies
-// in the pass's range enter with LDS atomics, then the segment's own positions of that range look their candidate up and store its
-// distance.  The first form kept the tables in HBM and let the match kernel read them: two random 4-byte reads per input byte
-// into 1 MiB per segment = a line from HBM each, matcher 67 -> 212 ms per 4 GiB (profiles/r06c_dense_probe.txt).  A last sweep
-// measures the candidates (16 bytes through memory, all lanes at work).  HBM-bound byte work; 4 bytes of `cand` per input byte,
-// written twice (a list entry, the final entry) and read once here, once by the match kernel.
-__global__ __launch_bounds__(1024) void zk_k_enc_dense_cand(const uint8_t *src, const ZkEncFrame *segs, ZkEncLdm ldm, uint32_t *cand)
+// DENSE far history (round 6; ZkEncLdm in zk_enc_device.h, the rule: oracle/zstd_oracle_enc.c dense_build_frame / dense_lookup): two
+// kernels, a workgroup per matcher segment each, leave every position's far candidate (length | catch-up << 5 | distance << 8) in
+// `cand`, where the match kernel reads it in whole lines.  The two tables a position is looked up in -- smallest position per slot of
+// its own segment, largest position + 1 per slot of the segment before, over the 5-byte hash of EVERY position -- exist in LDS only,
+// 2^14 slots of both per pass (128 KiB).
+//   zk_k_enc_dense_part  hashes every position ONCE and sorts it by the pass its slot belongs to: per segment and pass a list of
+//                        `position in the segment << 14 | slot in the pass` in `part` (count, prefix, place: every wave owns a piece of
+//                        every list, so the only atomics are a wave's own LDS cursors)
+//   zk_k_enc_dense_cand  per pass: the list of the segment before and the own list into the tables (every lane has an entry), the own
+//                        list again for the lookups; what a pass finds is appended to the list of the position's 8192-position chunk,
+//                        which lives where the chunk's entries of `cand` will be; a last sweep per chunk measures the candidates
+//                        (16 bytes + the 4 bytes in front, through L2, all lanes at work) and writes the entries in whole lines.
+// How it got here (profiles/r06c_dense_probe.txt, ms per 4 GiB): tables in HBM read by the match kernel 212 (two random 4-byte reads
+// per input byte = a line from HBM each); one kernel that hashed both segments in every pass and filtered by slot range 107-114 (~650
+// vector instructions per position, one lane in eight at work behind the filter); the partition: see the probe.  HBM-bound byte
+// work: 4 bytes of `part` and 4 of `cand` per input byte.
+constexpr uint32_t ZKD_PLOG = 13, ZKD_PSLOTS = 1u << ZKD_PLOG, ZKD_NBMAX = ZKE_DENSE_PASSES_MAX, ZKD_U = 8;
+template <bool PLACE>
+__device__ __forceinline__ void zkd_sweep(const uint8_t *frame, uint32_t s0, uint32_t e1, uint32_t fsz, uint32_t dlog, uint32_t tid, uint32_t *wcnt, uint32_t *lst)
 {
-    constexpr uint32_t PLOG = 14, PSLOTS = 1u << PLOG;
-    constexpr uint32_t U = 8;                                                       // steps of 4096 positions in flight per lane
-    constexpr uint32_t CLOG = 13, CHUNK = 1u << CLOG, NCHUNK = ZKE_SEGMENT / CHUNK;     // found candidates are listed per chunk of 8192 positions
-    static_assert(ZKE_SEGMENT + ZKE_SEGMENT - ZKE_WINDOW <= (1u << (32 - CLOG)), "a list entry: position inside the chunk | (distance - ZKE_WINDOW - 1) << 13");
-    __shared__ uint32_t first[PSLOTS], last[PSLOTS];
-    __shared__ uint32_t count[NCHUNK];
+    // (eight steps' input requested before the first is hashed: four waves per SIMD do not cover a trip to L2 per step)
+    for (uint32_t qb = s0 + 4 * tid; qb < e1; qb += 4096 * ZKD_U) {
+        uint32_t w0[ZKD_U], w1[ZKD_U];
+#pragma unroll
+        for (uint32_t u = 0; u < ZKD_U; u++) {
+            const uint32_t q0 = qb + 4096 * u, at = q0 < e1 && q0 + 8 <= fsz ? q0 : 0;      // (none of a step's four positions has its eight bytes: the frame's first bytes, unused)
+            memcpy(&w0[u], frame + at, 4); memcpy(&w1[u], frame + at + 4, 4);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < ZKD_U; u++) {
+            const uint32_t q0 = qb + 4096 * u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t q = q0 + k;
+                const uint32_t lo = __builtin_amdgcn_alignbyte(w1[u], w0[u], (uint32_t)k);
+                const uint32_t h = zke_hash(lo, (w1[u] >> (8 * k)) & 0xFFu, dlog);
+                // a position whose four bytes are one byte stays out: a byte run, offset 1 codes it better (the twin has the numbers)
+                if (q < e1 && q + 8 <= fsz && lo != (lo & 0xFFu) * 0x01010101u) {
+                    const uint32_t i = atomicAdd(&wcnt[h >> ZKD_PLOG], 1u);
+                    if (PLACE) lst[i] = ((q - s0) << ZKD_PLOG) | (h & (ZKD_PSLOTS - 1));
+                }
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(1024) void zk_k_enc_dense_part(const uint8_t *src, const ZkEncFrame *segs, ZkEncLdm ldm, uint32_t *part, uint32_t *poff)
+{
+    // per wave and pass: its count, then its cursor.  (A counter per LANE and pass -- no two lanes on one LDS word -- measured slower, 74.9 ->
+    // 98.7 ms: a wave's 64 stores then go to 64 different places of the lists instead of a handful of dense streams)
+    __shared__ uint32_t cnt[16][ZKD_NBMAX];
+    __shared__ uint32_t total[ZKD_NBMAX], start[ZKD_NBMAX + 1];
     const ZkEncFrame sg = segs[blockIdx.x];
     const uint8_t *frame = src + sg.src_off;
     const uint64_t left = ldm.n_total - sg.src_off;
     const uint32_t fsz = (uint32_t)(left < ldm.frame_size ? left : ldm.frame_size);
+    const uint32_t s0 = sg.seg_at, e1 = s0 + sg.d_size, tid = threadIdx.x, dlog = ldm.dlog, wave = tid >> 6, nb = 1u << (dlog - ZKD_PLOG);
+    uint32_t *lst = part + sg.src_off + s0;                         // the segment's lists, pass after pass
+    static_assert(16 * ZKD_NBMAX <= 1024, "one counter per lane");
+    if (tid < 16 * ZKD_NBMAX) (&cnt[0][0])[tid] = 0;
+    __syncthreads();
+    zkd_sweep<false>(frame, s0, e1, fsz, dlog, tid, cnt[wave], lst);
+    __syncthreads();
+    if (tid < nb) { uint32_t t = 0; for (uint32_t w = 0; w < 16; w++) t += cnt[w][tid]; total[tid] = t; }
+    __syncthreads();
+    if (tid == 0) { uint32_t run = 0; for (uint32_t b = 0; b < nb; b++) { start[b] = run; run += total[b]; } start[nb] = run; }
+    __syncthreads();
+    if (tid < nb) { uint32_t run = start[tid]; for (uint32_t w = 0; w < 16; w++) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = run; run += c; } }
+    if (tid <= nb) poff[(size_t)blockIdx.x * (ZKD_NBMAX + 1) + tid] = start[tid];
+    __syncthreads();
+    zkd_sweep<true>(frame, s0, e1, fsz, dlog, tid, cnt[wave], lst);
+}
+__global__ __launch_bounds__(1024) void zk_k_enc_dense_cand(const uint8_t *src, const ZkEncFrame *segs, ZkEncLdm ldm, const uint32_t *part, const uint32_t *poff, uint32_t *cand)
+{
+    constexpr uint32_t PLOG = ZKD_PLOG, PSLOTS = ZKD_PSLOTS;
+    constexpr uint32_t CLOG = 13, CHUNK = 1u << CLOG, NCHUNK = ZKE_SEGMENT / CHUNK;     // found candidates are listed per chunk of 8192 positions
+    static_assert(ZKE_SEGMENT + ZKE_SEGMENT - ZKE_WINDOW <= (1u << (32 - CLOG)), "a list entry: position inside the chunk | (distance - ZKE_WINDOW - 1) << 13");
+    static_assert(ZKE_SEGMENT <= (1u << (32 - PLOG)), "an entry of `part`: position inside the segment << 14 | slot");
+    __shared__ uint32_t first[PSLOTS], last[PSLOTS];
+    __shared__ uint32_t count[NCHUNK];
+    // Which segment: workgroups go to the eight XCDs in turn, each with an L2 of its own; workgroup b takes segment (b % 8) * (n / 8) + b / 8, so
+    // that an XCD works through CONSECUTIVE segments -- the candidates of a segment lie in its own and the segment before's bytes, which the
+    // same L2 has just seen -- instead of every eighth one of all frames (62.4 -> see profiles/r06c_dense_probe.txt)
+    const uint32_t nwg = gridDim.x, seg = (nwg & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (nwg >> 3) + (blockIdx.x >> 3);
+    const ZkEncFrame sg = segs[seg];
+    const uint8_t *frame = src + sg.src_off;
+    const uint64_t left = ldm.n_total - sg.src_off;
+    const uint32_t fsz = (uint32_t)(left < ldm.frame_size ? left : ldm.frame_size);
     const uint32_t s0 = sg.seg_at, e1 = s0 + sg.d_size, tid = threadIdx.x, dlog = ldm.dlog;
-    const uint32_t p0 = s0 ? s0 - ZKE_SEGMENT : 0;                   // the segment before mine is a whole one
     uint32_t *out = cand + sg.src_off;                              // indexed by the position inside the frame
+    const uint32_t *olist = part + sg.src_off + s0, *plist = olist - ZKE_SEGMENT;           // the segment before mine is a whole one, and the one before me in the list
+    const uint32_t *oo = poff + (size_t)seg * (ZKD_NBMAX + 1), *po = oo - (ZKD_NBMAX + 1);
     if (tid < NCHUNK) count[tid] = 0;
-    // Passes over the slots.  What a pass finds is NOT stored by position -- a line of `cand` would be written an eighth at a time, pass
-    // after pass, and leave the L2 half-written in between (the first form: 134 ms per 4 GiB, profiles/r06c_dense_probe.txt) -- but
-    // appended to the list of the position's chunk, which lives where the chunk's entries of `cand` will be (a chunk has at most as many
-    // candidates as positions): whole lines, filled front to back.
     for (uint32_t pass = 0; pass < (1u << (dlog - PLOG)); pass++) {
         for (uint32_t i = tid; i < PSLOTS; i += 1024) { first[i] = ZKE_DENSE_NONE; last[i] = 0; }
         __syncthreads();
-        // (eight steps' input requested before the first is hashed: four waves per SIMD do not cover a trip to L2 per step)
-        for (uint32_t qb = p0 + 4 * tid; qb < e1; qb += 4096 * U) {
-            uint32_t w0[U], w1[U];
+        // (four entries requested per lane before the first is used)
+        if (s0) {
+            const uint32_t *l = plist + po[pass], n = po[pass + 1] - po[pass];
+            for (uint32_t i0 = tid; i0 < n; i0 += 4096) {
+                uint32_t e[4];
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t q0 = qb + 4096 * u, at = q0 < e1 && q0 + 8 <= fsz ? q0 : 0;      // (none of a step's four positions has its eight bytes: the frame's first bytes, unused)
-                memcpy(&w0[u], frame + at, 4); memcpy(&w1[u], frame + at + 4, 4);
-            }
+                for (uint32_t u = 0; u < 4; u++) e[u] = l[i0 + 1024 * u < n ? i0 + 1024 * u : i0];
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t q0 = qb + 4096 * u;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t q = q0 + k;
-                    const uint32_t h = zke_hash(__builtin_amdgcn_alignbyte(w1[u], w0[u], (uint32_t)k), (w1[u] >> (8 * k)) & 0xFFu, dlog);
-                    if (q < e1 && q + 8 <= fsz && (h >> PLOG) == pass) {
-                        if (q0 < s0) atomicMax(&last[h & (PSLOTS - 1)], q - p0 + 1);
-                        else atomicMin(&first[h & (PSLOTS - 1)], q - s0);
-                    }
-                }
+                for (uint32_t u = 0; u < 4; u++) if (i0 + 1024 * u < n) atomicMax(&last[e[u] & (PSLOTS - 1)], (e[u] >> PLOG) + 1);
             }
         }
+        const uint32_t *l = olist + oo[pass], n = oo[pass + 1] - oo[pass];
+        for (uint32_t i0 = tid; i0 < n; i0 += 4096) {
+            uint32_t e[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) e[u] = l[i0 + 1024 * u < n ? i0 + 1024 * u : i0];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) if (i0 + 1024 * u < n) atomicMin(&first[e[u] & (PSLOTS - 1)], e[u] >> PLOG);
+        }
         __syncthreads();
-        for (uint32_t qb = s0 + 4 * tid; qb < e1; qb += 4096 * U) {
-            uint32_t w0[U], w1[U];
+        // What a pass finds is NOT stored by position -- a line of `cand` would be written an eighth at a time, pass after pass -- but appended
+        // to the list of the position's chunk, which lives where the chunk's entries of `cand` will be (a chunk has at most as many candidates
+        // as positions): whole lines, filled front to back.
+        for (uint32_t i0 = tid; i0 < n; i0 += 4096) {
+            uint32_t e[4];
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t q0 = qb + 4096 * u, at = q0 < e1 && q0 + 8 <= fsz ? q0 : 0;
-                memcpy(&w0[u], frame + at, 4); memcpy(&w1[u], frame + at + 4, 4);
-            }
+            for (uint32_t u = 0; u < 4; u++) e[u] = l[i0 + 1024 * u < n ? i0 + 1024 * u : i0];
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t q0 = qb + 4096 * u, chunk = (q0 - s0) >> CLOG;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t q = q0 + k, r = q - s0;
-                    const uint32_t lo = __builtin_amdgcn_alignbyte(w1[u], w0[u], (uint32_t)k);
-                    const uint32_t h = zke_hash(lo, (w1[u] >> (8 * k)) & 0xFFu, dlog);
-                    uint32_t d = 0;
-                    if (q < e1 && q + 8 <= fsz && (h >> PLOG) == pass) {
-                        const uint32_t m1 = first[h & (PSLOTS - 1)], m2 = last[h & (PSLOTS - 1)];
-                        if (lo == (lo & 0xFFu) * 0x01010101u) d = 0;          // four equal bytes: a byte run, offset 1 codes it better (the twin has the numbers)
-                        else if (m1 != ZKE_DENSE_NONE && m1 < r && r - m1 > ZKE_WINDOW) d = r - m1;
-                        else if (s0 && m2 && r + ZKE_SEGMENT - (m2 - 1) > ZKE_WINDOW) d = r + ZKE_SEGMENT - (m2 - 1);
-                    }
-                    // (a reservation per wave -- ballot, one atomic, readlane -- measured slower than a bump per lane: 106 -> 115 ms; the kernel
-                    //  is bound by its vector instructions: ~75 per position and pass, four cycles each on a 16-lane SIMD; a copy of the loops without
-                    //  the end-of-frame tests for whole segments: 106 -> 122 ms, 65 registers instead of 56)
-                    if (d) out[s0 + (chunk << CLOG) + atomicAdd(&count[chunk], 1u)] = (r & (CHUNK - 1)) | ((d - ZKE_WINDOW - 1) << CLOG);
-                }
+            for (uint32_t u = 0; u < 4; u++) {
+                if (i0 + 1024 * u >= n) continue;
+                const uint32_t r = e[u] >> PLOG, m1 = first[e[u] & (PSLOTS - 1)], m2 = last[e[u] & (PSLOTS - 1)];
+                uint32_t d = 0;
+                if (m1 < r && r - m1 > ZKE_WINDOW) d = r - m1;                             // (the slot holds a position: mine at the latest)
+                else if (m2 && r + ZKE_SEGMENT - (m2 - 1) > ZKE_WINDOW) d = r + ZKE_SEGMENT - (m2 - 1);
+                const uint32_t chunk = r >> CLOG;
+                if (d) out[s0 + (chunk << CLOG) + atomicAdd(&count[chunk], 1u)] = (r & (CHUNK - 1)) | ((d - ZKE_WINDOW - 1) << CLOG);
             }
         }
         __syncthreads();
@@ -1015,9 +1063,11 @@ __global__ __launch_bounds__(1024) void zk_k_enc_dense_cand(const uint8_t *src, 
         __syncthreads();
     }
 }
-void zk_launch_enc_dense_cand(hipStream_t st, const uint8_t *src, const ZkEncFrame *segs, uint32_t nsegs, const ZkEncLdm &ldm, uint32_t *cand)
+void zk_launch_enc_dense_cand(hipStream_t st, const uint8_t *src, const ZkEncFrame *segs, uint32_t nsegs, const ZkEncLdm &ldm, uint32_t *cand, uint32_t *part, uint32_t *poff)
 {
-    if (nsegs) hipLaunchKernelGGL(zk_k_enc_dense_cand, dim3(nsegs), dim3(1024), 0, st, src, segs, ldm, cand);
+    if (!nsegs) return;
+    hipLaunchKernelGGL(zk_k_enc_dense_part, dim3(nsegs), dim3(1024), 0, st, src, segs, ldm, part, poff);
+    hipLaunchKernelGGL(zk_k_enc_dense_cand, dim3(nsegs), dim3(1024), 0, st, src, segs, ldm, (const uint32_t *)part, (const uint32_t *)poff, cand);
 }
 // (both return the HIP verdict of clearing the table: a table that was not cleared holds an earlier call's positions, and the matcher
 //  would follow them -- ADVICE r4 / r5)

@@ -125,9 +125,10 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         if (zk_launch_enc_ldm_build_frames(st, src, ldm, (uint32_t *)e->enc_ldm.p, nf)) { e->last_err = "hipMemsetAsync (in-frame long-distance table)"; return ZK_ERR_HIP; }
         ldm.table = (const uint32_t *)e->enc_ldm.p;
         if (zke_dense_in_frame(a.level, 0, frame_size < a.n ? frame_size : a.n)) {
-            // dense far history (level 0 / >= 3): a far candidate per input byte, 4 bytes each (4 x the input: HBM is what this device has)
+            // dense far history (level 0 / >= 3): a far candidate per input byte, 4 bytes each (with the sorted positions 8 x the input: HBM is what this device has)
             ldm.dlog = zke_dense_log(a.level);
-            if ((rc = zk_devbuf_reserve(e, e->enc_dense, ((size_t)n + ZKE_DENSE_SLACK) * sizeof(uint32_t) + 64))) return rc;
+            // + as much again for the positions sorted by the pass their slot belongs to, and a word per segment and pass (+ 1)
+            if ((rc = zk_devbuf_reserve(e, e->enc_dense, (2 * ((size_t)n + ZKE_DENSE_SLACK) + (size_t)nseg * (ZKE_DENSE_PASSES_MAX + 1)) * sizeof(uint32_t) + 64))) return rc;
             ldm.dense = (const uint32_t *)e->enc_dense.p;
         }
     }
@@ -138,7 +139,8 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         if (zk_launch_enc_ldm_build(st, ldm, (uint32_t *)e->enc_ldm.p)) { e->last_err = "hipMemsetAsync (long-distance table)"; return ZK_ERR_HIP; }
         ldm.table = (const uint32_t *)e->enc_ldm.p;
     }
-    if (ldm.dense) { zk_kernel_timer t(e, ZK_K_ENC_DENSE, st); zk_launch_enc_dense_cand(st, src, (const ZkEncFrame *)e->enc_seg.p, nseg, ldm, (uint32_t *)e->enc_dense.p); }
+    if (ldm.dense) { zk_kernel_timer t(e, ZK_K_ENC_DENSE, st); uint32_t *dc = (uint32_t *)e->enc_dense.p, *dp = dc + ((size_t)n + ZKE_DENSE_SLACK);
+                     zk_launch_enc_dense_cand(st, src, (const ZkEncFrame *)e->enc_seg.p, nseg, ldm, dc, dp, dp + ((size_t)n + ZKE_DENSE_SLACK)); }
     { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, (const ZkEncFrame *)e->enc_seg.p, nseg, dbl, (uint64_t *)e->enc_b.p, (uint8_t *)e->enc_c.p, a.level, ldm); }
     ZkEncTables *ftab = (ZkEncTables *)e->enc_f.p;
     { zk_kernel_timer t(e, ZK_K_ENC_FSE_BUILD, st); zk_launch_enc_fse_build(st, src, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), dtab, ftab); }

@@ -57,7 +57,8 @@ void zk_launch_small_publish(hipStream_t st, const ZkFrameInfo *infos, const uin
 void zk_launch_enc_stage_hist(hipStream_t st, const uint8_t *src, const uint8_t *prefix_tail, const ZkEncFrame *frames, uint32_t nframes, uint8_t *stage);
 void zk_launch_enc_match(hipStream_t st, const uint8_t *src, const ZkEncFrame *segs, uint32_t nsegs, ZkEncBlock *blocks, uint64_t *seqs, uint8_t *lits, int level, const ZkEncLdm &ldm);
 int zk_launch_enc_ldm_build(hipStream_t st, const ZkEncLdm &ldm, uint32_t *table);                        // 0, or -1: the table could not be cleared
-void zk_launch_enc_dense_cand(hipStream_t st, const uint8_t *src, const ZkEncFrame *segs, uint32_t nsegs, const ZkEncLdm &ldm, uint32_t *cand);   // every position's entry is written: no clear
+// cand, part: an entry per input byte + ZKE_DENSE_SLACK; poff: (ZKE_DENSE_PASSES_MAX + 1) words per segment; every entry that is read is written first: no clear
+void zk_launch_enc_dense_cand(hipStream_t st, const uint8_t *src, const ZkEncFrame *segs, uint32_t nsegs, const ZkEncLdm &ldm, uint32_t *cand, uint32_t *part, uint32_t *poff);
 int zk_launch_enc_ldm_build_frames(hipStream_t st, const uint8_t *src, const ZkEncLdm &ldm, uint32_t *table, uint32_t nframes);
 void zk_launch_enc_fse_build(hipStream_t st, const uint8_t *src, const ZkEncFrame *frames, uint32_t nframes, const ZkEncBlock *blocks, uint64_t *seqs, uint32_t *mpos,
                              const ZkEncTables *predef, ZkEncTables *ftab);
