@@ -555,6 +555,22 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                 // the frame: none); not past the tile's start, not before the record's first byte.  The parse cuts it down to the literals
                 // the match really has in front of it (zk_enc_match2.h has the measurements: the stale table finds many a match late).
                 uint32_t bk4 = 0;
+                if (DENSE) {
+                    // which of my four far winners give way to a cheap offset (the previous one, or 1) up to four positions later: the cheap
+                    // winners' lengths of my positions and of the next lane's (the tile's positions lie four to a lane along the wave), five bits each
+                    uint32_t cp = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) cp |= ((wo[k] == R || wo[k] == 1u) ? wl[k] : 0u) << (5 * k);
+                    const uint32_t nx_ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 1) & 63u) << 2), (int)cp);
+                    const uint64_t both = (uint64_t)cp | ((uint64_t)(lane == 63 ? 0u : nx_) << 20);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t m = 0;
+#pragma unroll
+                        for (uint32_t j = 1; j <= ZKE_DENSE_AHEAD; j++) { const uint32_t c = (uint32_t)(both >> (5 * (k + j))) & 31u, v = c ? c + j : 0u; m = m > v ? m : v; }
+                        if (wl[k] && wo[k] > ZKE_WINDOW && wo[k] != R && m + ZKE_DENSE_BONUS >= wl[k]) bk4 |= 0x80u << (8 * k);
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t p = P0 + k, off = wo[k];
@@ -601,17 +617,14 @@ __global__ __launch_bounds__(ZKE_THREADS) void zk_k_enc_match(const uint8_t *src
                         if ((v >> 5) != R && (v >> 5) != 1 && p + 1 < te && l1 && ((n1 >> 5) == R || (n1 >> 5) == 1) && l1 + 1 >= len) cand = false;
                         // (round 6) ... and a FAR candidate of the dense tables gives way to a cheap offset up to ZKE_DENSE_AHEAD positions later
                         // unless it is ZKE_DENSE_BONUS bytes longer still (the twin has the cases: records, byte runs cut by a tile's end)
-                        if (DENSE) {
-                            const bool far = (v >> 5) > ZKE_WINDOW && (v >> 5) != R;
-#pragma unroll
-                            for (uint32_t j = 1; j <= ZKE_DENSE_AHEAD; j++) {
-                                const uint32_t nj = j == 1 ? n1 : best[wave * ZKE_TILE + pos + j < ZKE_GROUP_POS ? wave * ZKE_TILE + pos + j : 0], lj = nj & 0x1F;
-                                if (far && p + j < te && lj && ((nj >> 5) == R || (nj >> 5) == 1) && lj + j + ZKE_DENSE_BONUS >= len) cand = false;
-                            }
-                        }
+                        // (round 6) ... and a FAR candidate of the dense tables gives way to a cheap offset up to ZKE_DENSE_AHEAD positions later
+                        // unless it is ZKE_DENSE_BONUS bytes longer still (the twin has the cases: records, byte runs cut by a tile's end): decided
+                        // where the candidates are made (3a), bit 7 of the position's catch-up byte -- four more LDS reads and compares per
+                        // position HERE were 7 000 of a tile's 18 000 parse clocks (profiles/r06c_dense_probe.txt)
+                        if (DENSE && (((const uint8_t *)bkb)[wave * ZKE_TILE + pos] & 0x80u)) cand = false;
                     }
                     pv[u] = v; plen[u] = len;
-                    pbk[u] = ((const uint8_t *)bkb)[wave * ZKE_TILE + pos];
+                    pbk[u] = ((const uint8_t *)bkb)[wave * ZKE_TILE + pos] & 7u;
                     pcand[u] = __ballot(cand); pcap[u] = __ballot(cand && len == ZKE_PARCAP);
                     // every lane: the first candidate at or behind the end of its own match (64: none in this pass); the walk
                     // below then costs the scalar unit a handful of instructions per match
