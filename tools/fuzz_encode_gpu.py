@@ -30,8 +30,8 @@ def main():
             m = int(min(left, rng.integers(1, max(2, n))))
             parts.append(piece(rng, m)); left -= m
         data = b"".join(parts)
-        level = int(rng.choice([1, 3, 6, 0]))
-        fs = int(rng.choice([1000, 65536, 1 << 20, 2 << 20, 5 << 20]))
+        level = int(rng.choice([1, 2, 3, 6, 0, 9]))
+        fs = int(rng.choice([1000, 65536, 100003, 300001, 1 << 20, 2 << 20, 5 << 20]))      # (odd sizes: unaligned frames in the dense levels' candidate array)
         prefix = None
         if rng.integers(0, 3) == 0:
             pn = int(rng.choice([10, 5000, 57280, 57284, 200000, 1 << 20]))

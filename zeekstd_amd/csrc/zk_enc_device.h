@@ -13,7 +13,7 @@ constexpr uint32_t ZKE_BLOCK = 131072;
 //     two positions later wins)
 //   level >= 6: the same with lookup steps of 1024 positions instead of 4096 (fresher tables: +3 % on source code)
 //   (round 6) level 0 and 3 and up, frames beyond the ring's reach: DENSE far history -- every position of a matcher segment in two
-//     tables of 2^17 slots (first / last occurrence), from level 9 on 2^18 (ZkEncLdm below; zk_k_enc_dense_cand)
+//     tables of 2^17 slots (first / last occurrence), from level 9 on 2^18 (ZkEncLdm below; zk_k_enc_dense_part / _cand)
 // 8d text (round 6): 2.484 (1) / 2.654 (2) / 2.732 (3) / 2.735 (6) / 2.742 (9); libzstd 1.5.7: 2.50 / 2.79 / 2.85 / 2.88.
 ZK_HD bool zke_fast(int level) { return level != 0 && level < 2; }
 ZK_HD uint32_t zke_minmatch(int level) { return zke_fast(level) ? 6u : 5u; }
@@ -99,7 +99,7 @@ struct ZkEncLdm {
     uint32_t frame_size, pad;
     uint64_t n_total;
     // DENSE far history (round 6; oracle/zstd_oracle_enc.c dense_build_frame has the rule and the measurements): per input byte position
-    // (indexed like the source buffer, + ZKE_DENSE_SLACK entries) the position's far candidate as zk_k_enc_dense_cand found it -- length
+    // (indexed like the source buffer, + ZKE_DENSE_SLACK entries; behind it as much again for the positions sorted by slot range) the position's far candidate as zk_k_enc_dense_cand found it -- length
     // (<= 16) | catch-up (<= 4: bytes in front of the position that agree at that distance) << 5 | distance << 8, 0: none -- out of two tables per matcher segment over the 5-byte hash of EVERY position (2^dlog slots: the
     // first occurrence in the segment, the last one in the segment before), which live in LDS only.  nullptr: none (levels 1 and 2,
     // prefixes, frames within the ring's reach).

@@ -889,17 +889,17 @@ __global__ __launch_bounds__(256) void zk_k_enc_ldm_build_frames(const uint8_t *
 // kernels, a workgroup per matcher segment each, leave every position's far candidate (length | catch-up << 5 | distance << 8) in
 // `cand`, where the match kernel reads it in whole lines.  The two tables a position is looked up in -- smallest position per slot of
 // its own segment, largest position + 1 per slot of the segment before, over the 5-byte hash of EVERY position -- exist in LDS only,
-// 2^14 slots of both per pass (128 KiB).
+// 2^13 slots of both per pass (64 KiB: two workgroups per CU).
 //   zk_k_enc_dense_part  hashes every position ONCE and sorts it by the pass its slot belongs to: per segment and pass a list of
-//                        `position in the segment << 14 | slot in the pass` in `part` (count, prefix, place: every wave owns a piece of
+//                        `position in the segment << 13 | slot in the pass` in `part` (count, prefix, place: every wave owns a piece of
 //                        every list, so the only atomics are a wave's own LDS cursors)
 //   zk_k_enc_dense_cand  per pass: the list of the segment before and the own list into the tables (every lane has an entry), the own
 //                        list again for the lookups; what a pass finds is appended to the list of the position's 8192-position chunk,
 //                        which lives where the chunk's entries of `cand` will be; a last sweep per chunk measures the candidates
 //                        (16 bytes + the 4 bytes in front, through L2, all lanes at work) and writes the entries in whole lines.
 // How it got here (profiles/r06c_dense_probe.txt, ms per 4 GiB): tables in HBM read by the match kernel 212 (two random 4-byte reads
-// per input byte = a line from HBM each); one kernel that hashed both segments in every pass and filtered by slot range 107-114 (~650
-// vector instructions per position, one lane in eight at work behind the filter); the partition: see the probe.  HBM-bound byte
+// per input byte = a line from HBM each); one kernel that hashed both segments in every pass and filtered by slot range 107-134 (~650
+// vector instructions per position, one lane in eight at work behind the filter); the partition 75; two workgroups per CU 63.  HBM-bound byte
 // work: 4 bytes of `part` and 4 of `cand` per input byte.
 constexpr uint32_t ZKD_PLOG = 13, ZKD_PSLOTS = 1u << ZKD_PLOG, ZKD_NBMAX = ZKE_DENSE_PASSES_MAX, ZKD_U = 8;
 template <bool PLACE>
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(1024) void zk_k_enc_dense_cand(const uint8_t *src, 
     constexpr uint32_t PLOG = ZKD_PLOG, PSLOTS = ZKD_PSLOTS;
     constexpr uint32_t CLOG = 13, CHUNK = 1u << CLOG, NCHUNK = ZKE_SEGMENT / CHUNK;     // found candidates are listed per chunk of 8192 positions
     static_assert(ZKE_SEGMENT + ZKE_SEGMENT - ZKE_WINDOW <= (1u << (32 - CLOG)), "a list entry: position inside the chunk | (distance - ZKE_WINDOW - 1) << 13");
-    static_assert(ZKE_SEGMENT <= (1u << (32 - PLOG)), "an entry of `part`: position inside the segment << 14 | slot");
+    static_assert(ZKE_SEGMENT <= (1u << (32 - PLOG)), "an entry of `part`: position inside the segment << 13 | slot");
     __shared__ uint32_t first[PSLOTS], last[PSLOTS];
     __shared__ uint32_t count[NCHUNK];
     // Which segment: workgroups go to the eight XCDs in turn, each with an L2 of its own; workgroup b takes segment (b % 8) * (n / 8) + b / 8, so
