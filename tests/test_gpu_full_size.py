@@ -106,6 +106,52 @@ def test_configs2_encode_decode_4gib(engine, big):
     d_comp[at] = d_comp[at] ^ 1
 
 
+def test_configs2_at_the_reference_clis_default_level(engine, big):
+    """(round 6) The same 4 GiB at level 3 -- the reference CLI's default (cli/src/args.rs:192), this encoder's dense far history
+    (zk_k_enc_dense_part / zk_k_enc_dense_cand, 8 bytes of device scratch per input byte): a sample of frames is byte-identical to the
+    CPU twin and decodes with the box's libzstd, the whole archive decodes on the device to the input with every Content_Checksum
+    verified, the ratio is the twin's (2.73 on this text), and the dense kernels ran (their time is reported)."""
+    import zeekstd_amd as zk
+    torch, dev = _dev(engine)
+    data, hashes = big
+    n = data.size
+    d_src = torch.from_numpy(data).to(dev)
+    cap = int(zk.lib.zk_compress_bound(n, FRAME))
+    d_comp = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+    d_cs = torch.zeros(NFRAMES, dtype=torch.int32, device=dev)
+    d_ds = torch.zeros(NFRAMES, dtype=torch.int32, device=dev)
+    engine.set_profiling(True)
+    nf, csize = engine.encode_frames_dev(d_src, n, FRAME, 3, True, d_comp, cap, d_cs, d_ds)
+    times = engine.kernel_times()
+    engine.set_profiling(False)
+    torch.cuda.synchronize()
+    assert nf == NFRAMES and times.get("zk_k_enc_dense_cand", 0) > 0, times
+    cs = d_cs.cpu().numpy().astype(np.uint64)
+    assert int(cs.sum()) == csize and 2.70 < n / csize < 2.77, n / csize
+    c = np.zeros(NFRAMES + 1, np.uint64); c[1:] = np.cumsum(cs)
+    d = np.arange(NFRAMES + 1, dtype=np.uint64) * FRAME
+    for f in (0, 1, 777, NFRAMES - 1):
+        fr = bytes(d_comp[int(c[f]):int(c[f + 1])].cpu().numpy())
+        want = data[f * FRAME:(f + 1) * FRAME].tobytes()
+        assert fr == zko.frame_encode(want, 3, True), f
+        if Z.load("system") is not None:
+            assert Z.decode_stream(fr, FRAME, "system") == want, f
+    d_c = torch.from_numpy(c.view(np.int64)).to(dev); d_d = torch.from_numpy(d.view(np.int64)).to(dev)
+    d_out = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    d_st = torch.full((NFRAMES,), -1, dtype=torch.int32, device=dev)
+    assert engine.decode_frames_dev(d_comp, csize, d_c, d_d, 0, NFRAMES, d_out, n, True, d_st) == 0
+    assert int(d_st.abs().sum().item()) == 0 and torch.equal(d_out[:n], d_src)
+    d_hash = torch.zeros(NFRAMES, dtype=torch.int64, device=dev)
+    engine.xxh64_frames_dev(d_out, d_d, NFRAMES, d_hash)
+    assert np.array_equal(d_hash.cpu().numpy().view(np.uint64), hashes)
+    # level 2 of the same engine runs without the dense kernels
+    engine.set_profiling(True)
+    engine.encode_frames_dev(d_src[:64 * FRAME], 64 * FRAME, FRAME, 2, True, d_comp, cap, d_cs, d_ds)
+    t2 = engine.kernel_times()
+    engine.set_profiling(False)
+    assert not t2.get("zk_k_enc_dense_cand", 0), t2
+
+
 def test_configs3_seeks_over_65536_frames(engine, big):
     import zeekstd_amd as zk
     from zeekstd_amd import api
