@@ -29,7 +29,8 @@ raw.zk_debug_enc_clocks(out, 0)
 v = np.array(list(out), dtype=np.float64)
 names = ["0 segment start (table, ring, history)", "1 ring words + hashes + far lookups", "2 wait barrier 1", "3 insert", "4 wait barrier 2",
          "5 comparisons -> best[]", "6 tile summary", "7 -", "8 near lookups + stitch + stores of the group before", "9 parse A: entries, masks, next table",
-         "10 parse B: the walk", "11 parse C1: starts + sequences", "12 parse C2: literal bytes", "13 -", "14 -", "15 -"]
+         "10 parse B: the walk", "11 parse C1: starts + sequences", "12 parse C2: literal bytes",
+         "13 zk_k_enc_dense_cand: lists into the tables", "14 zk_k_enc_dense_cand: lookups", "15 zk_k_enc_dense_cand: last sweep"]
 tot = v.sum()
 groups = n / 4096
 print("match ms", round(eng.kernel_times()["zk_k_enc_match"], 3), "ratio", round(n / csize, 3), "level", level)

@@ -977,6 +977,7 @@ __global__ __launch_bounds__(1024) void zk_k_enc_dense_cand(const uint8_t *src, 
     const uint32_t *olist = part + sg.src_off + s0, *plist = olist - ZKE_SEGMENT;           // the segment before mine is a whole one, and the one before me in the list
     const uint32_t *oo = poff + (size_t)seg * (ZKD_NBMAX + 1), *po = oo - (ZKD_NBMAX + 1);
     if (tid < NCHUNK) count[tid] = 0;
+    ZKE_CLK_BEGIN();
     for (uint32_t pass = 0; pass < (1u << (dlog - PLOG)); pass++) {
         for (uint32_t i = tid; i < PSLOTS; i += 1024) { first[i] = ZKE_DENSE_NONE; last[i] = 0; }
         __syncthreads();
@@ -1000,6 +1001,7 @@ __global__ __launch_bounds__(1024) void zk_k_enc_dense_cand(const uint8_t *src, 
             for (uint32_t u = 0; u < 4; u++) if (i0 + 1024 * u < n) atomicMin(&first[e[u] & (PSLOTS - 1)], e[u] >> PLOG);
         }
         __syncthreads();
+        ZKE_CLK(13);
         // What a pass finds is NOT stored by position -- a line of `cand` would be written an eighth at a time, pass after pass -- but appended
         // to the list of the position's chunk, which lives where the chunk's entries of `cand` will be (a chunk has at most as many candidates
         // as positions): whole lines, filled front to back.
@@ -1019,6 +1021,7 @@ __global__ __launch_bounds__(1024) void zk_k_enc_dense_cand(const uint8_t *src, 
             }
         }
         __syncthreads();
+        ZKE_CLK(14);
     }
     // Chunk by chunk: the list into LDS by position, then every position's candidate measured -- 16 bytes at the position against 16
     // bytes `distance` before it, every lane at work -- and the chunk's entries of `cand` written in whole lines over its list.
@@ -1062,6 +1065,8 @@ __global__ __launch_bounds__(1024) void zk_k_enc_dense_cand(const uint8_t *src, 
         }
         __syncthreads();
     }
+    ZKE_CLK(15);
+    ZKE_CLK_END();
 }
 void zk_launch_enc_dense_cand(hipStream_t st, const uint8_t *src, const ZkEncFrame *segs, uint32_t nsegs, const ZkEncLdm &ldm, uint32_t *cand, uint32_t *part, uint32_t *poff)
 {
