@@ -374,6 +374,21 @@ def test_patch_against_a_prefix_longer_than_the_long_distance_span(engine):
     assert not st.any() and out == new
 
 
+def test_a_prefix_too_short_to_leave_history(engine):
+    """(round 6, found by reading) A raw-content prefix of one to three bytes leaves the matcher no history (it takes whole words), but it IS a
+    prefix: the frame's window is planned without far history, so the far tables must stay out as they do in the twin -- the engine had
+    asked "is there history" instead of "is there a prefix", and a frame beyond the ring's reach would have carried offsets beyond its
+    declared window.  Levels 2 and 3, byte-identical to the twin, taken back by libzstd."""
+    data = zko.gen_chunks(300000, 5)
+    for level in (2, 3):
+        for plen in (1, 3):
+            prefix = data[1000:1000 + plen]
+            comp, frames = engine.encode_frames(data, 2 << 20, level, True, prefix=prefix)
+            assert len(frames) == 1 and comp == zko.frame_encode(data, level, True, prefix=prefix), (level, plen)
+            out, used = zko.frame_decode(comp, len(data), prefix=prefix)
+            assert out == data and used == len(comp)
+
+
 @pytest.mark.parametrize("level", [1, 3])
 @pytest.mark.parametrize("with_prefix", [False, True])
 def test_frames_above_the_matcher_segment(engine, level, with_prefix):

@@ -34,7 +34,7 @@ def main():
         fs = int(rng.choice([1000, 65536, 100003, 300001, 1 << 20, 2 << 20, 5 << 20]))      # (odd sizes: unaligned frames in the dense levels' candidate array)
         prefix = None
         if rng.integers(0, 3) == 0:
-            pn = int(rng.choice([10, 5000, 57280, 57284, 200000, 1 << 20]))
+            pn = int(rng.choice([1, 3, 10, 5000, 57280, 57284, 200000, 1 << 20]))
             prefix = piece(rng, pn)
             if rng.integers(0, 2) and len(data) > 1000 and pn > 2000:      # make the frame share content with the prefix
                 data = prefix[pn // 3:pn // 3 + len(data) // 2] + data[len(data) // 2:]

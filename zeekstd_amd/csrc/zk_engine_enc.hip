@@ -118,13 +118,16 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
     // the matcher's workgroups are launched over the segments (one per <= 256 KiB of a frame)
     if ((rc = zk_devbuf_reserve(e, e->enc_seg, segs_bytes + 64))) return rc;
     ZK_HIP(hipMemcpyAsync(e->enc_seg.p, segs, (size_t)nseg * sizeof(ZkEncFrame), hipMemcpyHostToDevice, st));
-    if (!hist && zke_ldm_in_frame(a.level, 0, frame_size < a.n ? frame_size : a.n)) {
+    // (a prefix of one to three bytes leaves no history -- hist is a multiple of 4 -- but it is a prefix: the frames' windows were planned without
+    //  far history, as the twin does; found by reading, round 6: such a frame would have carried offsets beyond its window)
+    const uint64_t plen_eff = a.d_prefix ? a.prefix_len : 0;
+    if (!hist && zke_ldm_in_frame(a.level, plen_eff, frame_size < a.n ? frame_size : a.n)) {
         // in-frame far history (level >= 2, no prefix, frames beyond the ring's reach): one table per frame over its own bytes
         ldm.inframe = 1; ldm.frame_size = frame_size; ldm.n_total = a.n; ldm.log = zke_ldm_log(frame_size < a.n ? frame_size : a.n);
         if ((rc = zk_devbuf_reserve(e, e->enc_ldm, (((size_t)nf * sizeof(uint32_t)) << ldm.log) + 64))) return rc;
         if (zk_launch_enc_ldm_build_frames(st, src, ldm, (uint32_t *)e->enc_ldm.p, nf)) { e->last_err = "hipMemsetAsync (in-frame long-distance table)"; return ZK_ERR_HIP; }
         ldm.table = (const uint32_t *)e->enc_ldm.p;
-        if (zke_dense_in_frame(a.level, 0, frame_size < a.n ? frame_size : a.n)) {
+        if (zke_dense_in_frame(a.level, plen_eff, frame_size < a.n ? frame_size : a.n)) {
             // dense far history (level 0 / >= 3): a far candidate per input byte, 4 bytes each (with the sorted positions 8 x the input: HBM is what this device has)
             ldm.dlog = zke_dense_log(a.level);
             // + as much again for the positions sorted by the pass their slot belongs to, and a word per segment and pass (+ 1)
