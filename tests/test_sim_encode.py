@@ -159,7 +159,8 @@ def test_match_kernel_under_sanitizers(tmp_path):
     kernel's `__shared__` arrays are real arrays on the CPU, so an index that leaves the ring, the table, `best[]` or a tile's sequence
     area -- on the device silent corruption of whatever lies next to it in LDS -- is a report, as is an access outside the source /
     prefix / output buffers (exact-size heap allocations).  Text with a prefix beyond the ring (the long-distance table), byte runs in
-    small frames at level 6, a frame larger than a segment with far history inside it at level 3.  (54 further shapes: DESIGN.md 3.)"""
+    small frames at level 6, a frame larger than a segment with far history inside it at level 3 (the DENSE instance: its entries per
+    position, the over-read into the slack), odd-sized frames at level 9.  (54 further shapes: DESIGN.md 3.)"""
     import os
     import shutil
     import subprocess
@@ -173,7 +174,8 @@ def test_match_kernel_under_sanitizers(tmp_path):
         pytest.skip("no sanitizer runtime for g++ here")
     assert cc.returncode == 0, cc.stderr[-2000:]
     first = True
-    for cfg in (("1", "90000", "90000", "0", "200000"), ("6", "100000", "32768", "1", "20000"), ("3", "400000", "400000", "0")):
+    for cfg in (("1", "90000", "90000", "0", "200000"), ("6", "100000", "32768", "1", "20000"), ("3", "400000", "400000", "0"),
+                ("9", "420001", "300001", "0")):       # (round 6) the dense levels' candidate entries: frames of an odd size, a second frame beyond the ring's reach
         r = subprocess.run([exe, *cfg], capture_output=True, text=True, timeout=900)
         if first and r.returncode != 0 and "AddressSanitizer" in r.stderr and "ERROR: AddressSanitizer:" not in r.stderr:
             pytest.skip("the sanitizer runtime cannot start here")
