@@ -186,13 +186,15 @@ int zk_decode_wait(zk_engine *e, int slot);
  * SeekTable::log_frame receives (seek_table.rs:513-525).  checksum != 0 appends the XXH64 Content_Checksum
  * (ZSTD_c_checksumFlag, encode.rs:283-284).  level is ZSTD_c_compressionLevel (encode.rs:281-282): one strategy
  * (hash matching in a 57 280-byte window -- from level 2 on plus sampled far matches anywhere behind it in the frame, the frame
- * then declares a window over its size --, Huffman literals, FSE tables measured per frame) with three settings
- * (zk_enc_device.h: zke_fast / zke_minmatch / zke_hash_log / zke_lazy / zke_step) --
- * level <= 1 (negative levels included): table matches of 6+ bytes, 2^14 table entries, greedy parse; levels 2..5 and 0
- * (= libzstd's default 3, the reference CLI's default): 5+ bytes, 2^15 entries, lazy parse; level >= 6: the same with the
- * table refreshed every 1024 instead of 4096 positions (ratio 2.47 / 2.59 / 2.59 on the survey's text, 3.29 / 3.46 / 3.57
- * on Python sources; libzstd on the text: 2.49 at level 1, 2.77 at level 3).  Replaces the ZSTD_compressStream2 loops of
- * encode.rs:340-346, 442-464.
+ * then declares a window over its size --, Huffman literals, FSE tables measured per frame) with five settings
+ * (zk_enc_device.h: zke_fast / zke_minmatch / zke_hash_log / zke_lazy / zke_step / zke_dense_in_frame / zke_dense_log) --
+ * level <= 1 (negative levels included): table matches of 6+ bytes, 2^14 table entries, greedy parse; level 2: 5+ bytes,
+ * 2^15 entries, lazy parse; levels 3..5 and 0 (= libzstd's default 3, the reference CLI's default): the same plus DENSE far
+ * history (round 6: every position of the frame looked up in two tables per 256 KiB, 2^17 slots -- the short far matches
+ * libzstd's level 3 finds in its 2 MiB window; 8 bytes of device scratch per input byte); level 6..8: the same with the table
+ * refreshed every 1024 instead of 4096 positions; level >= 9: 2^18 slots.  Ratio on the survey's text 2.485 / 2.655 / 2.732 /
+ * 2.736 / 2.743 (libzstd 1.5.7: 2.50 at level 1, 2.79 at 3, 2.88 at 9), encode 100 / 47 / 24 / 20 / 20 GiB/s HBM to HBM.
+ * Replaces the ZSTD_compressStream2 loops of encode.rs:340-346, 442-464.
  * dst_cap >= zk_compress_bound(n, frame_size) always suffices; otherwise -70 (dstSize_tooSmall) may come back.
  */
 uint64_t zk_compress_bound(uint64_t n, uint32_t frame_size);
