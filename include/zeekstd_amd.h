@@ -191,7 +191,7 @@ int zk_decode_wait(zk_engine *e, int slot);
  * level <= 1 (negative levels included): table matches of 6+ bytes, 2^14 table entries, greedy parse; level 2: 5+ bytes,
  * 2^15 entries, lazy parse; levels 3..5 and 0 (= libzstd's default 3, the reference CLI's default): the same plus DENSE far
  * history (round 6: every position of the frame looked up in two tables per 256 KiB, 2^17 slots -- the short far matches
- * libzstd's level 3 finds in its 2 MiB window; 8 bytes of device scratch per input byte); level 6..8: the same with the table
+ * libzstd's level 3 finds in its 2 MiB window; 8 bytes of device scratch per input byte, at most 32 GiB); level 6..8: the same with the table
  * refreshed every 1024 instead of 4096 positions; level >= 9: 2^18 slots.  Ratio on the survey's text 2.485 / 2.655 / 2.732 /
  * 2.736 / 2.743 (libzstd 1.5.7: 2.50 at level 1, 2.79 at 3, 2.88 at 9), encode 100 / 47 / 24 / 20 / 20 GiB/s HBM to HBM.
  * Replaces the ZSTD_compressStream2 loops of encode.rs:340-346, 442-464.

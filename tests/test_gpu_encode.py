@@ -374,6 +374,22 @@ def test_patch_against_a_prefix_longer_than_the_long_distance_span(engine):
     assert not st.any() and out == new
 
 
+def test_dense_levels_in_slices(engine, monkeypatch):
+    """(round 6) The dense levels' scratch (8 bytes per input byte) is reserved for a slice of whole frames -- 4 GiB of input unless
+    ZK_DENSE_SLICE_BYTES says otherwise -- and the dense kernels + the match kernel run slice after slice over it (zk_engine_enc.hip), so a call of
+    any size takes at most 32 GiB of it.  Slices of two, one and all frames (odd frame size, a ragged last frame): the same bytes as the twin's."""
+    fs = 300001
+    data = zko.gen_chunks(5 * fs + 12345, 9)
+    want = b"".join(zko.frame_encode(data[o:o + fs], 3, True) for o in range(0, len(data), fs))
+    for slice_bytes in (700000, 300001, 100, 1 << 30):
+        monkeypatch.setenv("ZK_DENSE_SLICE_BYTES", str(slice_bytes))
+        comp, frames = engine.encode_frames(data, fs, 3, True)
+        assert len(frames) == 6 and comp == want, slice_bytes
+    monkeypatch.delenv("ZK_DENSE_SLICE_BYTES")
+    comp, frames = engine.encode_frames(data, fs, 9, False)
+    assert comp == b"".join(zko.frame_encode(data[o:o + fs], 9, False) for o in range(0, len(data), fs))
+
+
 def test_a_prefix_too_short_to_leave_history(engine):
     """(round 6, found by reading) A raw-content prefix of one to three bytes leaves the matcher no history (it takes whole words), but it IS a
     prefix: the frame's window is planned without far history, so the far tables must stay out as they do in the twin -- the engine had

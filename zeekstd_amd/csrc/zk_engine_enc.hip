@@ -1,5 +1,6 @@
 // zk_engine_enc.hip -- encode half of the batch engine (Level A of include/zeekstd_amd.h).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "../../include/zeekstd_amd.h"
@@ -121,6 +122,9 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
     // (a prefix of one to three bytes leaves no history -- hist is a multiple of 4 -- but it is a prefix: the frames' windows were planned without
     //  far history, as the twin does; found by reading, round 6: such a frame would have carried offsets beyond its window)
     const uint64_t plen_eff = a.d_prefix ? a.prefix_len : 0;
+    uint64_t dense_slice = 4ull << 30;
+    if (const char *v = getenv("ZK_DENSE_SLICE_BYTES")) { const unsigned long long x = strtoull(v, nullptr, 10); if (x) dense_slice = x; }
+    size_t dense_span = 0;
     if (!hist && zke_ldm_in_frame(a.level, plen_eff, frame_size < a.n ? frame_size : a.n)) {
         // in-frame far history (level >= 2, no prefix, frames beyond the ring's reach): one table per frame over its own bytes
         ldm.inframe = 1; ldm.frame_size = frame_size; ldm.n_total = a.n; ldm.log = zke_ldm_log(frame_size < a.n ? frame_size : a.n);
@@ -131,7 +135,11 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
             // dense far history (level 0 / >= 3): a far candidate per input byte, 4 bytes each (with the sorted positions 8 x the input: HBM is what this device has)
             ldm.dlog = zke_dense_log(a.level);
             // + as much again for the positions sorted by the pass their slot belongs to, and a word per segment and pass (+ 1)
-            if ((rc = zk_devbuf_reserve(e, e->enc_dense, (2 * ((size_t)n + ZKE_DENSE_SLACK) + (size_t)nseg * (ZKE_DENSE_PASSES_MAX + 1)) * sizeof(uint32_t) + 64))) return rc;
+            // -- for a SLICE of whole frames at a time (at most dense_slice bytes of input: 4 GiB unless ZK_DENSE_SLICE_BYTES says otherwise, which
+            // the tests use): the dense kernels and the match kernel run slice after slice over the same scratch, so a call of any size takes at
+            // most 8 x 4 GiB of it
+            dense_span = (size_t)(n < dense_slice ? n : (dense_slice / frame_size ? dense_slice / frame_size : 1) * (uint64_t)frame_size);
+            if ((rc = zk_devbuf_reserve(e, e->enc_dense, (2 * (dense_span + ZKE_DENSE_SLACK) + (size_t)nseg * (ZKE_DENSE_PASSES_MAX + 1)) * sizeof(uint32_t) + 64))) return rc;
             ldm.dense = (const uint32_t *)e->enc_dense.p;
         }
     }
@@ -142,9 +150,26 @@ int zk_encode_enqueue(zk_engine *e, const zk_enc_args &a, hipStream_t st, uint32
         if (zk_launch_enc_ldm_build(st, ldm, (uint32_t *)e->enc_ldm.p)) { e->last_err = "hipMemsetAsync (long-distance table)"; return ZK_ERR_HIP; }
         ldm.table = (const uint32_t *)e->enc_ldm.p;
     }
-    if (ldm.dense) { zk_kernel_timer t(e, ZK_K_ENC_DENSE, st); uint32_t *dc = (uint32_t *)e->enc_dense.p, *dp = dc + ((size_t)n + ZKE_DENSE_SLACK);
-                     zk_launch_enc_dense_cand(st, src, (const ZkEncFrame *)e->enc_seg.p, nseg, ldm, dc, dp, dp + ((size_t)n + ZKE_DENSE_SLACK)); }
-    { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, (const ZkEncFrame *)e->enc_seg.p, nseg, dbl, (uint64_t *)e->enc_b.p, (uint8_t *)e->enc_c.p, a.level, ldm); }
+    if (ldm.dense && dense_span < n) {
+        // slice after slice (whole frames): the candidate arrays are indexed like the source, so a slice's kernels get them shifted by
+        // the slice's first byte; the timer of the match kernel covers the dense kernels of such a call too
+        zk_kernel_timer t(e, ZK_K_ENC_MATCH, st);
+        uint32_t *dc = (uint32_t *)e->enc_dense.p, *dp = dc + (dense_span + ZKE_DENSE_SLACK), *po = dp + (dense_span + ZKE_DENSE_SLACK);
+        const uint32_t fpf = (uint32_t)(dense_span / frame_size), spf = (frame_size + ZKE_SEGMENT - 1) / ZKE_SEGMENT;   // frames per slice, segments per whole frame
+        for (uint32_t f0 = 0; f0 < nf; f0 += fpf) {
+            const uint32_t f1 = nf - f0 < fpf ? nf : f0 + fpf, s0 = f0 * spf, s1 = f1 == nf ? nseg : f1 * spf;
+            const uint64_t lo = (uint64_t)f0 * frame_size;
+            ZkEncLdm sl = ldm;
+            sl.dense = dc - lo;
+            const ZkEncFrame *sg = (const ZkEncFrame *)e->enc_seg.p + s0;
+            zk_launch_enc_dense_cand(st, src, sg, s1 - s0, sl, dc - lo, dp - lo, po);
+            zk_launch_enc_match(st, msrc, sg, s1 - s0, dbl, (uint64_t *)e->enc_b.p, (uint8_t *)e->enc_c.p, a.level, sl);
+        }
+    } else {
+        if (ldm.dense) { zk_kernel_timer t(e, ZK_K_ENC_DENSE, st); uint32_t *dc = (uint32_t *)e->enc_dense.p, *dp = dc + (dense_span + ZKE_DENSE_SLACK);
+                         zk_launch_enc_dense_cand(st, src, (const ZkEncFrame *)e->enc_seg.p, nseg, ldm, dc, dp, dp + (dense_span + ZKE_DENSE_SLACK)); }
+        { zk_kernel_timer t(e, ZK_K_ENC_MATCH, st); zk_launch_enc_match(st, msrc, (const ZkEncFrame *)e->enc_seg.p, nseg, dbl, (uint64_t *)e->enc_b.p, (uint8_t *)e->enc_c.p, a.level, ldm); }
+    }
     ZkEncTables *ftab = (ZkEncTables *)e->enc_f.p;
     { zk_kernel_timer t(e, ZK_K_ENC_FSE_BUILD, st); zk_launch_enc_fse_build(st, src, dfr, nf, dbl, (uint64_t *)e->enc_b.p, (uint32_t *)((uint64_t *)e->enc_b.p + seq_total + 1), dtab, ftab); }
     bool cks_beside = false;                                 // the checksums run on the second queue beside the entropy stage (which waits on its own chains; beside the matcher they
