@@ -826,7 +826,8 @@ def main():
                 eng.decode_frames_dev(d_comp3, int(c3[-1]), torch.from_numpy(c3).to(dev), torch.from_numpy(d3).to(dev), 0, nchk, o3, nchk * FRAME, True, s3)
                 ok3 = bool(torch.equal(o3[:nchk * FRAME], d_src[:nchk * FRAME])) and int(s3.abs().sum().item()) == 0
                 enc_info["level_3"] = {"value": round(dsize / min(t3) / 2**30, 2), "unit": "GiB/s", "ratio": round(dsize / csize3, 3), "ms": round(min(t3) * 1e3, 2),
-                                       "kernel_ms": {k: round(v, 3) for k, v in ek3.items() if "enc" in k}, "first_frames_round_trip": ok3}
+                                       "kernel_ms": {k: round(v, 3) for k, v in ek3.items() if "enc" in k}, "first_frames_round_trip": ok3,
+                                       "roofline": roofline_of({k: v for k, v in ek3.items() if "enc" in k}, dsize + csize3, min(t3) * 1e3, None, False)}
                 del d_comp3, d_cs3, o3
             except Exception as ex:                                   # noqa: BLE001  (a leg of the report, not the run)
                 enc_info["level_3"] = {"error": f"{type(ex).__name__}: {ex}"}
