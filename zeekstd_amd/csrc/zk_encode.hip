@@ -959,6 +959,10 @@ __global__ __launch_bounds__(1024) void zk_k_enc_dense_part(const uint8_t *src, 
 __global__ __launch_bounds__(1024) void zk_k_enc_dense_cand(const uint8_t *src, const ZkEncFrame *segs, ZkEncLdm ldm, const uint32_t *part, const uint32_t *poff, uint32_t *cand)
 {
     constexpr uint32_t PLOG = ZKD_PLOG, PSLOTS = ZKD_PSLOTS;
+#ifndef ZKD_E
+#define ZKD_E 16
+#endif
+    constexpr uint32_t E = ZKD_E;                                   // list entries requested per lane before the first is used (4 | 8 | 16: 50.1 | 47.9 | 47.1 ms per 4 GiB)
     constexpr uint32_t CLOG = 13, CHUNK = 1u << CLOG, NCHUNK = ZKE_SEGMENT / CHUNK;     // found candidates are listed per chunk of 8192 positions
     static_assert(ZKE_SEGMENT + ZKE_SEGMENT - ZKE_WINDOW <= (1u << (32 - CLOG)), "a list entry: position inside the chunk | (distance - ZKE_WINDOW - 1) << 13");
     static_assert(ZKE_SEGMENT <= (1u << (32 - PLOG)), "an entry of `part`: position inside the segment << 13 | slot");
@@ -981,36 +985,36 @@ __global__ __launch_bounds__(1024) void zk_k_enc_dense_cand(const uint8_t *src, 
     for (uint32_t pass = 0; pass < (1u << (dlog - PLOG)); pass++) {
         for (uint32_t i = tid; i < PSLOTS; i += 1024) { first[i] = ZKE_DENSE_NONE; last[i] = 0; }
         __syncthreads();
-        // (four entries requested per lane before the first is used)
+        // (E entries requested per lane before the first is used: a pass's lists are ~16 entries per lane, so usually all of them)
         if (s0) {
             const uint32_t *l = plist + po[pass], n = po[pass + 1] - po[pass];
-            for (uint32_t i0 = tid; i0 < n; i0 += 4096) {
-                uint32_t e[4];
+            for (uint32_t i0 = tid; i0 < n; i0 += 1024 * E) {
+                uint32_t e[E];
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++) e[u] = l[i0 + 1024 * u < n ? i0 + 1024 * u : i0];
+                for (uint32_t u = 0; u < E; u++) e[u] = l[i0 + 1024 * u < n ? i0 + 1024 * u : i0];
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++) if (i0 + 1024 * u < n) atomicMax(&last[e[u] & (PSLOTS - 1)], (e[u] >> PLOG) + 1);
+                for (uint32_t u = 0; u < E; u++) if (i0 + 1024 * u < n) atomicMax(&last[e[u] & (PSLOTS - 1)], (e[u] >> PLOG) + 1);
             }
         }
         const uint32_t *l = olist + oo[pass], n = oo[pass + 1] - oo[pass];
-        for (uint32_t i0 = tid; i0 < n; i0 += 4096) {
-            uint32_t e[4];
+        for (uint32_t i0 = tid; i0 < n; i0 += 1024 * E) {
+            uint32_t e[E];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) e[u] = l[i0 + 1024 * u < n ? i0 + 1024 * u : i0];
+            for (uint32_t u = 0; u < E; u++) e[u] = l[i0 + 1024 * u < n ? i0 + 1024 * u : i0];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) if (i0 + 1024 * u < n) atomicMin(&first[e[u] & (PSLOTS - 1)], e[u] >> PLOG);
+            for (uint32_t u = 0; u < E; u++) if (i0 + 1024 * u < n) atomicMin(&first[e[u] & (PSLOTS - 1)], e[u] >> PLOG);
         }
         __syncthreads();
         ZKE_CLK(13);
         // What a pass finds is NOT stored by position -- a line of `cand` would be written an eighth at a time, pass after pass -- but appended
         // to the list of the position's chunk, which lives where the chunk's entries of `cand` will be (a chunk has at most as many candidates
         // as positions): whole lines, filled front to back.
-        for (uint32_t i0 = tid; i0 < n; i0 += 4096) {
-            uint32_t e[4];
+        for (uint32_t i0 = tid; i0 < n; i0 += 1024 * E) {
+            uint32_t e[E];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) e[u] = l[i0 + 1024 * u < n ? i0 + 1024 * u : i0];
+            for (uint32_t u = 0; u < E; u++) e[u] = l[i0 + 1024 * u < n ? i0 + 1024 * u : i0];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
+            for (uint32_t u = 0; u < E; u++) {
                 if (i0 + 1024 * u >= n) continue;
                 const uint32_t r = e[u] >> PLOG, m1 = first[e[u] & (PSLOTS - 1)], m2 = last[e[u] & (PSLOTS - 1)];
                 uint32_t d = 0;
